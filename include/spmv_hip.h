@@ -1,0 +1,273 @@
+/*
+ * include/spmv_hip.h -- C ABI of libspmv_hip.so, the MI355X (gfx950) backend
+ * for the LIBSPMV hot path: fp64/fp32 CSR and symmetric-CSR SpMV, the ghost
+ * pack kernel, the CG loop's fused BLAS-1 kernels, device memory/stream
+ * plumbing and the RCCL halo / all-reduce transport.
+ *
+ * This is the drop-in boundary.  Each entry point names the reference
+ * interface (file:line relative to the LIBSPMV tree) it stands behind; a
+ * `spmv::HipExecutor` (spmv_amd/csrc/host/hip_executor.h) binds exactly these
+ * symbols, and INTEGRATION.md shows the same binding inside the reference.
+ *
+ * Conventions
+ *   - Every function returns int: 0 = success, >0 = hipError_t,
+ *     >=10000 = 10000 + ncclResult_t, <0 = SPMV_HIP_E*.  Nothing throws,
+ *     nothing calls exit().  spmv_hip_error_string() decodes a code.
+ *   - All `const T*` / `T*` data arguments are DEVICE pointers unless the
+ *     parameter name starts with `host_`.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the context's current
+ *     stream, see spmv_hip_set_stream).  Nothing synchronises the host unless
+ *     its name says so.
+ *   - One context per GPU; a context is used by one host thread at a time
+ *     (same rule as the reference's executors).
+ */
+#ifndef SPMV_HIP_H
+#define SPMV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPMV_HIP_ABI_VERSION 1
+
+enum {
+  SPMV_HIP_OK = 0,
+  SPMV_HIP_EINVAL = -1,   /* bad argument (null handle, negative size, ...) */
+  SPMV_HIP_ENOMEM = -2,   /* host allocation failed                         */
+  SPMV_HIP_ENOTSUP = -3,  /* feature not available in this build           */
+  SPMV_HIP_ERANGE = -4    /* size exceeds a 32-bit index the format fixes  */
+};
+
+typedef struct spmv_hip_ctx spmv_hip_ctx;           /* one GPU             */
+typedef struct spmv_hip_csr_plan spmv_hip_csr_plan; /* CSRSpMV::_aux_data  */
+typedef struct spmv_hip_cg_ws spmv_hip_cg_ws;       /* cg() work vectors   */
+typedef struct spmv_hip_comm spmv_hip_comm;         /* RCCL communicator   */
+
+int spmv_hip_abi_version(void);
+const char* spmv_hip_error_string(int code);
+
+/* ---- context / device queries ------------------------------------------
+ * HipExecutor ctor/dtor, get_num_devices, get_num_cus, synchronize
+ * (device_executor.h:82-85; cuda/cuda_executor.cpp:13-47). */
+int spmv_hip_device_count(int* count);
+int spmv_hip_ctx_create(int device_id, spmv_hip_ctx** ctx);
+int spmv_hip_ctx_destroy(spmv_hip_ctx* ctx);
+int spmv_hip_ctx_device(const spmv_hip_ctx* ctx, int* device_id);
+int spmv_hip_num_cus(const spmv_hip_ctx* ctx, int* num_cus);
+int spmv_hip_synchronize(spmv_hip_ctx* ctx); /* whole device */
+
+/* ---- streams / events ---------------------------------------------------
+ * CudaExecutor::set/reset/get_cuda_stream (cuda/cuda_executor.h:72-76). */
+int spmv_hip_stream_create(spmv_hip_ctx* ctx, void** stream);
+int spmv_hip_stream_destroy(spmv_hip_ctx* ctx, void* stream);
+int spmv_hip_stream_synchronize(spmv_hip_ctx* ctx, void* stream);
+int spmv_hip_set_stream(spmv_hip_ctx* ctx, void* stream); /* NULL = reset */
+int spmv_hip_get_stream(const spmv_hip_ctx* ctx, void** stream);
+int spmv_hip_event_create(spmv_hip_ctx* ctx, int timing, void** event);
+int spmv_hip_event_destroy(spmv_hip_ctx* ctx, void* event);
+int spmv_hip_event_record(spmv_hip_ctx* ctx, void* event, void* stream);
+int spmv_hip_event_synchronize(spmv_hip_ctx* ctx, void* event);
+int spmv_hip_stream_wait_event(spmv_hip_ctx* ctx, void* stream, void* event);
+int spmv_hip_event_elapsed_ms(spmv_hip_ctx* ctx, void* start, void* stop,
+                              float* ms);
+
+/* ---- memory ---------------------------------------------------------------
+ * DeviceExecutor::_alloc/_free/_memset/_copy/_copy_async/_copy_from/_copy_to
+ * (device_executor.h:129-139). */
+int spmv_hip_alloc(spmv_hip_ctx* ctx, size_t num_bytes, void** ptr);
+int spmv_hip_free(spmv_hip_ctx* ctx, void* ptr);
+int spmv_hip_host_alloc(spmv_hip_ctx* ctx, size_t num_bytes, void** host_ptr);
+int spmv_hip_host_free(spmv_hip_ctx* ctx, void* host_ptr);
+int spmv_hip_memset_async(spmv_hip_ctx* ctx, void* ptr, int value,
+                          size_t num_bytes, void* stream);
+int spmv_hip_copy_d2d_async(spmv_hip_ctx* ctx, void* dst, const void* src,
+                            size_t num_bytes, void* stream);
+int spmv_hip_copy_h2d_async(spmv_hip_ctx* ctx, void* dst,
+                            const void* host_src, size_t num_bytes,
+                            void* stream);
+int spmv_hip_copy_d2h_async(spmv_hip_ctx* ctx, void* host_dst, const void* src,
+                            size_t num_bytes, void* stream);
+/* peer copy between two contexts (cuda/cuda_executor.cpp:82-94) */
+int spmv_hip_copy_peer_async(spmv_hip_ctx* dst_ctx, void* dst,
+                             spmv_hip_ctx* src_ctx, const void* src,
+                             size_t num_bytes, void* stream);
+
+/* ---- CSR SpMV -------------------------------------------------------------
+ * CSRSpMV<T>::init / run / finalize (csr_kernels.h:26-78); reference
+ * arithmetic csr_kernels.cpp:20-52.
+ *
+ * plan_create inspects the (device-resident) row pointer once and picks the
+ * kernel and launch shape; it stores no copy of the matrix.  `symmetric`
+ * selects the strictly-lower + diagonal kernel.  rowptr/colind may be NULL
+ * when num_non_zeros == 0 (csr_matrix.cpp:34).
+ *
+ * run computes out = alpha * A * in + beta * out.
+ *   - beta == 0: out is write-only and never read.
+ *   - general kernel, SPMV_HIP_ALGO_ROWBLOCK: each row is summed left to
+ *     right in fp64 without FMA contraction, i.e. bit-identical to
+ *     csr_kernels.cpp:41-51.
+ *   - symmetric kernel: out is first scaled by beta (zero-filled when
+ *     beta == 0) inside run, then every term is accumulated with hardware
+ *     fp64 atomics; the order of additions is not deterministic.
+ *   - `dot_partials` (optional, general kernel only, may be NULL): fuses
+ *     the CG dot product sum_i in[i]*out[i] over the rows of this block;
+ *     the kernel writes spmv_hip_dot_partials_len() doubles, to be reduced
+ *     by spmv_hip_reduce_partials_f64.
+ */
+enum {
+  SPMV_HIP_ALGO_AUTO = 0,
+  SPMV_HIP_ALGO_ROWBLOCK = 1, /* row blocks streamed through LDS, exact order */
+  SPMV_HIP_ALGO_VECTOR = 2,   /* sub-wavefront per row, shuffle reduction     */
+  SPMV_HIP_ALGO_SCALAR = 3    /* one lane per row (short rows, reference)     */
+};
+
+int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
+                             int32_t num_cols, int64_t num_non_zeros,
+                             const int32_t* rowptr, const int32_t* colind,
+                             int symmetric, int algo,
+                             spmv_hip_csr_plan** plan);
+int spmv_hip_csr_plan_destroy(spmv_hip_csr_plan* plan);
+int spmv_hip_csr_plan_algo(const spmv_hip_csr_plan* plan, int* algo);
+/* tuning knobs, used by the benchmark sweep: key/value, returns EINVAL for
+ * an unknown key. */
+int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value);
+
+int spmv_hip_csr_spmv_f64(spmv_hip_ctx* ctx, const spmv_hip_csr_plan* plan,
+                          int32_t num_rows, int32_t num_cols,
+                          int64_t num_non_zeros, const int32_t* rowptr,
+                          const int32_t* colind, const double* values,
+                          const double* diagonal, double alpha,
+                          const double* in, double beta, double* out,
+                          double* dot_partials, void* stream);
+int spmv_hip_csr_spmv_f32(spmv_hip_ctx* ctx, const spmv_hip_csr_plan* plan,
+                          int32_t num_rows, int32_t num_cols,
+                          int64_t num_non_zeros, const int32_t* rowptr,
+                          const int32_t* colind, const float* values,
+                          const float* diagonal, float alpha, const float* in,
+                          float beta, float* out, void* stream);
+
+/* ---- ghost pack -------------------------------------------------------------
+ * DeviceExecutor::gather_ghosts_run (device_executor.h:123-126;
+ * reference_executor.cpp:150-164): out[i] = in[indices[i]]. */
+int spmv_hip_gather_f64(spmv_hip_ctx* ctx, int num_indices,
+                        const int32_t* indices, const double* in, double* out,
+                        void* stream);
+int spmv_hip_gather_f32(spmv_hip_ctx* ctx, int num_indices,
+                        const int32_t* indices, const float* in, float* out,
+                        void* stream);
+
+/* ---- CG building blocks -----------------------------------------------------
+ * spmv::cg (cg.cpp:21-98).  All scalars live on the device (precedent:
+ * cuda/cg.cuda.cu:73-84); the host never waits inside an iteration.
+ *
+ * Reductions are two-stage and deterministic: a kernel writes
+ * spmv_hip_dot_partials_len() per-block partial sums, then
+ * spmv_hip_reduce_partials_f64 adds them in index order into one double.
+ */
+int spmv_hip_dot_partials_len(const spmv_hip_ctx* ctx, int* len);
+int spmv_hip_dot_partial_f64(spmv_hip_ctx* ctx, int64_t n, const double* x,
+                             const double* y, double* partials, void* stream);
+int spmv_hip_reduce_partials_f64(spmv_hip_ctx* ctx, const double* partials,
+                                 double* result, void* stream);
+
+/* Device-resident CG state: scalar history + flags.
+ *   rr[k]  = ||r_k||^2 (k = 0..kmax), pAp[k] = p_k . A p_k (k = 1..kmax)
+ *   done   = 1 once sqrt(rr[k]) / sqrt(rr[0]) < rtol; kstop = that k.
+ * After `done` every cg_* kernel and every SpMV issued through
+ * spmv_hip_cg_guard_* is a no-op, so the host may enqueue iterations ahead
+ * without reading anything back (cg.cpp:80-81 semantics: x, r updated, p not).
+ */
+int spmv_hip_cg_ws_create(spmv_hip_ctx* ctx, int kmax, spmv_hip_cg_ws** ws);
+int spmv_hip_cg_ws_destroy(spmv_hip_cg_ws* ws);
+int spmv_hip_cg_ws_reset(spmv_hip_cg_ws* ws, double rtol, void* stream);
+/* device addresses of the scalar slots (for the all-reduce) */
+int spmv_hip_cg_ws_rr(spmv_hip_cg_ws* ws, int k, double** slot);
+int spmv_hip_cg_ws_pAp(spmv_hip_cg_ws* ws, int k, double** slot);
+int spmv_hip_cg_ws_partials(spmv_hip_cg_ws* ws, double** partials);
+int spmv_hip_cg_ws_done_flag(spmv_hip_cg_ws* ws, const int32_t** done);
+/* copies {done, kstop} and rr[0..kmax] to the host (async on stream) */
+int spmv_hip_cg_ws_read_async(spmv_hip_cg_ws* ws, int32_t* host_done_kstop,
+                              double* host_rr, void* stream);
+
+/* x += alpha p ; r -= alpha Ap ; partials of r.r   (cg.cpp:66-73)
+ * alpha = (s*s)/pAp[k] with s = sqrt(rr[k-1]), evaluated on the device. */
+int spmv_hip_cg_update_xr_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
+                              int64_t n, const double* p, const double* Ap,
+                              double* x, double* r, void* stream);
+/* convergence test on rr[k] then p = beta p + r  (cg.cpp:77-85) */
+int spmv_hip_cg_update_p_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
+                             int64_t n, const double* r, double* p,
+                             void* stream);
+/* partials -> rr[k] / pAp[k] (local part; all-reduce it afterwards) */
+int spmv_hip_cg_reduce_rr(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
+                          void* stream);
+int spmv_hip_cg_reduce_pAp(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
+                           void* stream);
+/* r.r partials for k = 0 (cg.cpp:47) */
+int spmv_hip_cg_dot_rr_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int64_t n,
+                           const double* r, void* stream);
+
+/* ---- 3-D Poisson generator (not in the reference)
+ * 7-point stencil on an n^3 grid, natural ordering, diag 6, off-diag -1.
+ * Generates, directly in device memory, the CSR block of global rows
+ * [row_begin,row_end) in the local column numbering create_matrix would
+ * produce (Matrix.cpp:295-318): owned columns first, then ghost columns in
+ * ascending global order.  `part` selects which entries are kept:
+ */
+enum {
+  SPMV_HIP_PART_ALL = 0,        /* every entry (blocking models, Matrix.cpp:357) */
+  SPMV_HIP_PART_LOCAL = 1,      /* owned columns only (Matrix.cpp:350-353)       */
+  SPMV_HIP_PART_REMOTE = 2,     /* ghost columns only (Matrix.cpp:354-355)       */
+  SPMV_HIP_PART_LOCAL_LOWER = 3 /* owned columns, global_row > global_col
+                                   (Matrix.cpp:337-347); diagonal separate       */
+};
+int spmv_hip_poisson3d_count(spmv_hip_ctx* ctx, int32_t n, int64_t row_begin,
+                             int64_t row_end, int part, int32_t* rowptr,
+                             int64_t* host_nnz, void* stream);
+int spmv_hip_poisson3d_fill_f64(spmv_hip_ctx* ctx, int32_t n,
+                                int64_t row_begin, int64_t row_end, int part,
+                                const int32_t* rowptr, int32_t* colind,
+                                double* values, double* diagonal,
+                                void* stream);
+/* number of ghost columns below / above the owned range for this row block */
+int spmv_hip_poisson3d_ghosts(int32_t n, int64_t row_begin, int64_t row_end,
+                              int64_t* ghosts_below, int64_t* ghosts_above);
+/* x_i = exp(-10 (5 (i/N - 1/2))^2), i = i_begin.. (demos/spmv.cpp:63-67) */
+int spmv_hip_fill_gaussian_f64(spmv_hip_ctx* ctx, int64_t N, int64_t i_begin,
+                               int64_t count, double* x, void* stream);
+int spmv_hip_fill_const_f64(spmv_hip_ctx* ctx, int64_t count, double value,
+                            double* x, void* stream);
+
+/* ---- RCCL transport (L2GMap::update p2p models, L2GMap.cpp:564-642;
+ *      MPI_Allreduce in cg.cpp:49,65,75) ---------------------------------- */
+#define SPMV_HIP_UNIQUE_ID_BYTES 128
+int spmv_hip_comm_unique_id(void* host_id_bytes);
+int spmv_hip_comm_create(spmv_hip_ctx* ctx, int nranks, int rank,
+                         const void* host_id_bytes, spmv_hip_comm** comm);
+int spmv_hip_comm_destroy(spmv_hip_comm* comm);
+/* one grouped exchange: for every neighbour i, send send_counts[i] doubles
+ * from send_buf + send_offsets[i] and receive recv_counts[i] doubles into
+ * recv_base + recv_offsets[i] (offsets in elements). */
+int spmv_hip_comm_neighbor_exchange_f64(spmv_hip_comm* comm, int num_neighbours,
+                                        const int32_t* host_neighbours,
+                                        const double* send_buf,
+                                        const int32_t* host_send_counts,
+                                        const int32_t* host_send_offsets,
+                                        double* recv_base,
+                                        const int32_t* host_recv_counts,
+                                        const int32_t* host_recv_offsets,
+                                        void* stream);
+int spmv_hip_comm_allreduce_sum_f64(spmv_hip_comm* comm, double* inout,
+                                    size_t count, void* stream);
+/* byte-wise all-gather of small host-side setup data, staged through device
+ * memory (plan construction only; L2GMap.cpp:353-354,387-388) */
+int spmv_hip_comm_allgather_host(spmv_hip_comm* comm, const void* host_send,
+                                 void* host_recv, size_t bytes_per_rank);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPMV_HIP_H */

@@ -1,0 +1,523 @@
+// Ghost pack kernel and the CG loop's fused BLAS-1 kernels (gfx950).
+//
+// gather: DeviceExecutor::gather_ghosts_run (spmv/device_executor.h:123-126,
+//         spmv/reference_executor.cpp:150-164).
+// CG:     spmv::cg (spmv/cg.cpp:21-98).  Seven BLAS calls + two host
+//         reductions per iteration become two streaming kernels
+//           K2: x += alpha p ; r -= alpha Ap ; partial r.r      (cg.cpp:66-73)
+//           K3: converged? ; p = beta p + r                     (cg.cpp:77-85)
+//         plus single-workgroup reducers.  alpha, beta and the stopping test
+//         are evaluated on the device from the scalar history rr[], pAp[];
+//         precedent for device-resident scalars: cuda/cg.cuda.cu:14-38,73-84.
+//
+// Built with -ffp-contract=off: axpy/scal round like unfused BLAS-1.
+// All of this is HBM-bound streaming; 16 B per lane, grid-stride.
+#include "common.h"
+
+#include <cmath>
+#include <new>
+
+namespace
+{
+
+__device__ __forceinline__ double block_sum(double v, double* s_red)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+    v += __shfl_down(v, off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0)
+    s_red[wave] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w)
+      r += s_red[w];
+  }
+  return r; // valid in thread 0
+}
+
+__device__ __forceinline__ void clear_partials_tail(double* partials, int len)
+{
+  for (int i = gridDim.x + blockIdx.x * blockDim.x + threadIdx.x; i < len;
+       i += gridDim.x * blockDim.x)
+    partials[i] = 0.0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void gather_kernel(
+    int n, const int32_t* __restrict__ indices, const T* __restrict__ in,
+    T* __restrict__ out)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x)
+    out[i] = in[indices[i]];
+}
+
+__global__ __launch_bounds__(kBlock) void dot_partial_kernel(
+    int64_t n, const double* __restrict__ x, const double* __restrict__ y,
+    double* __restrict__ partials, int len)
+{
+  __shared__ double s_red[kBlock / 64];
+  double acc = 0.0;
+  const int64_t n2 = n >> 1;
+  const double2* x2 = reinterpret_cast<const double2*>(x);
+  const double2* y2 = reinterpret_cast<const double2*>(y);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2;
+       i += stride) {
+    double2 a = x2[i], b = y2[i];
+    acc += a.x * b.x;
+    acc += a.y * b.y;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
+    acc += x[n - 1] * y[n - 1];
+  double s = block_sum(acc, s_red);
+  if (threadIdx.x == 0)
+    partials[blockIdx.x] = s;
+  clear_partials_tail(partials, len);
+}
+
+// Sum `len` partials in a fixed order with one workgroup.
+__global__ __launch_bounds__(kBlock) void reduce_partials_kernel(
+    const double* __restrict__ partials, int len, double* __restrict__ result,
+    const int32_t* __restrict__ done)
+{
+  __shared__ double s_red[kBlock / 64];
+  if (done && *done)
+    return;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < len; i += kBlock)
+    acc += partials[i];
+  double s = block_sum(acc, s_red);
+  if (threadIdx.x == 0)
+    *result = s;
+}
+
+// ---- CG -----------------------------------------------------------------
+struct CgScalars {
+  double rtol;
+  int32_t done;
+  int32_t kstop;
+};
+
+// x += alpha p ; r += (-alpha) Ap ; partial r.r
+__global__ __launch_bounds__(kBlock) void cg_update_xr_kernel(
+    int64_t n, const double* __restrict__ rr_prev,
+    const double* __restrict__ pAp, const CgScalars* __restrict__ sc,
+    const double* __restrict__ p, const double* __restrict__ Ap,
+    double* __restrict__ x, double* __restrict__ r,
+    double* __restrict__ partials, int len)
+{
+  __shared__ double s_red[kBlock / 64];
+  if (sc->done)
+    return;
+  const double rnorm_old = sqrt(*rr_prev);             // cg.cpp:50,76
+  const double alpha = (rnorm_old * rnorm_old) / *pAp; // cg.cpp:66
+  const double nalpha = -alpha;
+  double acc = 0.0;
+  const int64_t n2 = n >> 1;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const double2* p2 = reinterpret_cast<const double2*>(p);
+  const double2* Ap2 = reinterpret_cast<const double2*>(Ap);
+  double2* x2 = reinterpret_cast<double2*>(x);
+  double2* r2 = reinterpret_cast<double2*>(r);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2;
+       i += stride) {
+    double2 pv = p2[i], av = Ap2[i], xv = x2[i], rv = r2[i];
+    xv.x += alpha * pv.x; // cg.cpp:69
+    xv.y += alpha * pv.y;
+    rv.x += nalpha * av.x; // cg.cpp:70
+    rv.y += nalpha * av.y;
+    x2[i] = xv;
+    r2[i] = rv;
+    acc += rv.x * rv.x; // cg.cpp:73
+    acc += rv.y * rv.y;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    x[i] += alpha * p[i];
+    double rv = r[i] + nalpha * Ap[i];
+    r[i] = rv;
+    acc += rv * rv;
+  }
+  double s = block_sum(acc, s_red);
+  if (threadIdx.x == 0)
+    partials[blockIdx.x] = s;
+  clear_partials_tail(partials, len);
+}
+
+// stopping test on rr[k], then p = beta p + r
+__global__ __launch_bounds__(kBlock) void cg_update_p_kernel(
+    int64_t n, int k, const double* __restrict__ rr0,
+    const double* __restrict__ rr_prev, const double* __restrict__ rr_new,
+    CgScalars* __restrict__ sc, const double* __restrict__ r,
+    double* __restrict__ p)
+{
+  if (sc->done)
+    return;
+  const double rnorm0 = sqrt(*rr0);
+  const double rnorm_old = sqrt(*rr_prev);
+  const double rnorm_new = sqrt(*rr_new);                           // cg.cpp:76
+  const double beta = (rnorm_new * rnorm_new) / (rnorm_old * rnorm_old); // :77
+  if (rnorm_new / rnorm0 < sc->rtol)                                // :80
+    return; // p is left untouched (:81); cg_reduce_pAp_kernel raises `done`
+  const int64_t n2 = n >> 1;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const double2* r2 = reinterpret_cast<const double2*>(r);
+  double2* p2 = reinterpret_cast<double2*>(p);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2;
+       i += stride) {
+    double2 pv = p2[i], rv = r2[i];
+    pv.x = beta * pv.x; // cg.cpp:84
+    pv.y = beta * pv.y;
+    pv.x += rv.x; // cg.cpp:85
+    pv.y += rv.y;
+    p2[i] = pv;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    p[i] = beta * p[i] + r[i];
+  }
+}
+
+// Reduces the p.Ap partials of iteration k.  It is the first single-workgroup
+// kernel after the p-update of iteration k-1, so it also raises `done` when
+// rr[k-1] met the tolerance (cg.cpp:80-81): every later cg_* kernel then
+// returns at once and x, r, p keep their iteration-(k-1) values.  In-order
+// stream execution makes the flag visible to the following launches.
+__global__ __launch_bounds__(kBlock) void cg_reduce_pAp_kernel(
+    const double* __restrict__ partials, int len, int k,
+    const double* __restrict__ rr, double* __restrict__ pAp,
+    CgScalars* __restrict__ sc)
+{
+  __shared__ double s_red[kBlock / 64];
+  if (sc->done)
+    return;
+  if (k >= 2) {
+    const double rnorm0 = sqrt(rr[0]);
+    const double rnorm_prev = sqrt(rr[k - 1]);
+    if (rnorm_prev / rnorm0 < sc->rtol) { // uniform across the workgroup
+      if (threadIdx.x == 0) {
+        sc->kstop = k - 1;
+        sc->done = 1;
+      }
+      return;
+    }
+  }
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < len; i += kBlock)
+    acc += partials[i];
+  double s = block_sum(acc, s_red);
+  if (threadIdx.x == 0)
+    pAp[k] = s;
+}
+
+__global__ void cg_reset_kernel(CgScalars* sc, double rtol, double* rr,
+                                double* pAp, int kmax)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) {
+    sc->rtol = rtol;
+    sc->done = 0;
+    sc->kstop = -1;
+  }
+  if (i <= kmax) {
+    rr[i] = 0.0;
+    pAp[i] = 0.0;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void fill_gaussian_kernel(
+    int64_t N, int64_t i_begin, int64_t count, double* __restrict__ x)
+{
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < count;
+       k += (int64_t)gridDim.x * blockDim.x) {
+    const double z = (double)(k + i_begin) / (double)N; // demos/spmv.cpp:65
+    const double u = 5 * (z - 0.5);
+    x[k] = exp(-10 * (u * u)); // pow(u, 2.0) == u*u exactly
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void fill_const_kernel(
+    int64_t count, double value, double* __restrict__ x)
+{
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < count;
+       k += (int64_t)gridDim.x * blockDim.x)
+    x[k] = value;
+}
+
+bool aligned16(const void* p)
+{
+  return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
+}
+
+} // namespace
+
+struct spmv_hip_cg_ws {
+  spmv_hip_ctx* ctx = nullptr;
+  int kmax = 0;
+  double* rr = nullptr;       // kmax + 1
+  double* pAp = nullptr;      // kmax + 1
+  double* partials = nullptr; // ctx->dot_blocks
+  CgScalars* sc = nullptr;
+};
+
+extern "C" {
+
+int spmv_hip_gather_f64(spmv_hip_ctx* ctx, int num_indices,
+                        const int32_t* indices, const double* in, double* out,
+                        void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(num_indices >= 0);
+  if (num_indices == 0)
+    return SPMV_HIP_OK;
+  SPMV_REQUIRE(indices && in && out);
+  const int grid = spmv_grid_for(ctx, num_indices, kBlock);
+  hipLaunchKernelGGL((gather_kernel<double>), dim3(grid), dim3(kBlock), 0,
+                     spmv_stream(ctx, stream), num_indices, indices, in, out);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_gather_f32(spmv_hip_ctx* ctx, int num_indices,
+                        const int32_t* indices, const float* in, float* out,
+                        void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(num_indices >= 0);
+  if (num_indices == 0)
+    return SPMV_HIP_OK;
+  SPMV_REQUIRE(indices && in && out);
+  const int grid = spmv_grid_for(ctx, num_indices, kBlock);
+  hipLaunchKernelGGL((gather_kernel<float>), dim3(grid), dim3(kBlock), 0,
+                     spmv_stream(ctx, stream), num_indices, indices, in, out);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_dot_partials_len(const spmv_hip_ctx* ctx, int* len)
+{
+  SPMV_REQUIRE(ctx && len);
+  *len = ctx->dot_blocks;
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_dot_partial_f64(spmv_hip_ctx* ctx, int64_t n, const double* x,
+                             const double* y, double* partials, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(n >= 0 && partials && (n == 0 || (x && y)));
+  SPMV_REQUIRE(aligned16(x) && aligned16(y));
+  const int grid = spmv_grid_for(ctx, n / 2, kBlock);
+  hipLaunchKernelGGL(dot_partial_kernel, dim3(grid), dim3(kBlock), 0,
+                     spmv_stream(ctx, stream), n, x, y, partials,
+                     ctx->dot_blocks);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_reduce_partials_f64(spmv_hip_ctx* ctx, const double* partials,
+                                 double* result, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(partials && result);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kBlock), 0,
+                     spmv_stream(ctx, stream), partials, ctx->dot_blocks,
+                     result, (const int32_t*)nullptr);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+// ---- CG workspace -------------------------------------------------------------
+int spmv_hip_cg_ws_create(spmv_hip_ctx* ctx, int kmax, spmv_hip_cg_ws** out)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(out && kmax >= 0);
+  spmv_hip_cg_ws* ws = new (std::nothrow) spmv_hip_cg_ws;
+  if (!ws)
+    return SPMV_HIP_ENOMEM;
+  ws->ctx = ctx;
+  ws->kmax = kmax;
+  hipError_t e = hipMalloc(&ws->rr, sizeof(double) * (kmax + 1));
+  if (e == hipSuccess)
+    e = hipMalloc(&ws->pAp, sizeof(double) * (kmax + 1));
+  if (e == hipSuccess)
+    e = hipMalloc(&ws->partials, sizeof(double) * ctx->dot_blocks);
+  if (e == hipSuccess)
+    e = hipMalloc(&ws->sc, sizeof(CgScalars));
+  if (e != hipSuccess) {
+    spmv_hip_cg_ws_destroy(ws);
+    return static_cast<int>(e);
+  }
+  *out = ws;
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_cg_ws_destroy(spmv_hip_cg_ws* ws)
+{
+  if (!ws)
+    return SPMV_HIP_OK;
+  (void)hipSetDevice(ws->ctx->device);
+  (void)hipFree(ws->rr);
+  (void)hipFree(ws->pAp);
+  (void)hipFree(ws->partials);
+  (void)hipFree(ws->sc);
+  delete ws;
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_cg_ws_reset(spmv_hip_cg_ws* ws, double rtol, void* stream)
+{
+  SPMV_REQUIRE(ws);
+  SPMV_SET_DEVICE(ws->ctx);
+  const int n = ws->kmax + 1;
+  hipLaunchKernelGGL(cg_reset_kernel, dim3((n + kBlock - 1) / kBlock),
+                     dim3(kBlock), 0, spmv_stream(ws->ctx, stream), ws->sc,
+                     rtol, ws->rr, ws->pAp, ws->kmax);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_cg_ws_rr(spmv_hip_cg_ws* ws, int k, double** slot)
+{
+  SPMV_REQUIRE(ws && slot && k >= 0 && k <= ws->kmax);
+  *slot = ws->rr + k;
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_cg_ws_pAp(spmv_hip_cg_ws* ws, int k, double** slot)
+{
+  SPMV_REQUIRE(ws && slot && k >= 0 && k <= ws->kmax);
+  *slot = ws->pAp + k;
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_cg_ws_partials(spmv_hip_cg_ws* ws, double** partials)
+{
+  SPMV_REQUIRE(ws && partials);
+  *partials = ws->partials;
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_cg_ws_done_flag(spmv_hip_cg_ws* ws, const int32_t** done)
+{
+  SPMV_REQUIRE(ws && done);
+  *done = &ws->sc->done;
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_cg_ws_read_async(spmv_hip_cg_ws* ws, int32_t* host_done_kstop,
+                              double* host_rr, void* stream)
+{
+  SPMV_REQUIRE(ws);
+  SPMV_SET_DEVICE(ws->ctx);
+  hipStream_t st = spmv_stream(ws->ctx, stream);
+  if (host_done_kstop)
+    SPMV_CHECK_HIP(hipMemcpyAsync(host_done_kstop, &ws->sc->done,
+                                  2 * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                  st));
+  if (host_rr)
+    SPMV_CHECK_HIP(hipMemcpyAsync(host_rr, ws->rr,
+                                  sizeof(double) * (ws->kmax + 1),
+                                  hipMemcpyDeviceToHost, st));
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_cg_dot_rr_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int64_t n,
+                           const double* r, void* stream)
+{
+  SPMV_REQUIRE(ws && ws->ctx == ctx);
+  return spmv_hip_dot_partial_f64(ctx, n, r, r, ws->partials, stream);
+}
+
+int spmv_hip_cg_reduce_rr(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
+                          void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(ws && ws->ctx == ctx && k >= 0 && k <= ws->kmax);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kBlock), 0,
+                     spmv_stream(ctx, stream), ws->partials, ctx->dot_blocks,
+                     ws->rr + k, &ws->sc->done);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_cg_reduce_pAp(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
+                           void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(ws && ws->ctx == ctx && k >= 1 && k <= ws->kmax);
+  hipLaunchKernelGGL(cg_reduce_pAp_kernel, dim3(1), dim3(kBlock), 0,
+                     spmv_stream(ctx, stream), ws->partials, ctx->dot_blocks,
+                     k, ws->rr, ws->pAp, ws->sc);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_cg_update_xr_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
+                              int64_t n, const double* p, const double* Ap,
+                              double* x, double* r, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(ws && ws->ctx == ctx && k >= 1 && k <= ws->kmax && n >= 0);
+  SPMV_REQUIRE(n == 0 || (p && Ap && x && r));
+  SPMV_REQUIRE(aligned16(p) && aligned16(Ap) && aligned16(x) && aligned16(r));
+  const int grid = spmv_grid_for(ctx, n / 2, kBlock);
+  hipLaunchKernelGGL(cg_update_xr_kernel, dim3(grid), dim3(kBlock), 0,
+                     spmv_stream(ctx, stream), n, ws->rr + (k - 1),
+                     ws->pAp + k, ws->sc, p, Ap, x, r, ws->partials,
+                     ctx->dot_blocks);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_cg_update_p_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
+                             int64_t n, const double* r, double* p,
+                             void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(ws && ws->ctx == ctx && k >= 1 && k <= ws->kmax && n >= 0);
+  SPMV_REQUIRE(n == 0 || (r && p));
+  SPMV_REQUIRE(aligned16(r) && aligned16(p));
+  hipStream_t st = spmv_stream(ctx, stream);
+  const int grid = spmv_grid_for(ctx, n / 2, kBlock);
+  hipLaunchKernelGGL(cg_update_p_kernel, dim3(grid), dim3(kBlock), 0, st, n, k,
+                     ws->rr, ws->rr + (k - 1), ws->rr + k, ws->sc, r, p);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_fill_gaussian_f64(spmv_hip_ctx* ctx, int64_t N, int64_t i_begin,
+                               int64_t count, double* x, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(N > 0 && i_begin >= 0 && count >= 0);
+  if (count == 0)
+    return SPMV_HIP_OK;
+  SPMV_REQUIRE(x);
+  const int grid = spmv_grid_for(ctx, count, kBlock);
+  hipLaunchKernelGGL(fill_gaussian_kernel, dim3(grid), dim3(kBlock), 0,
+                     spmv_stream(ctx, stream), N, i_begin, count, x);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_fill_const_f64(spmv_hip_ctx* ctx, int64_t count, double value,
+                            double* x, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(count >= 0);
+  if (count == 0)
+    return SPMV_HIP_OK;
+  SPMV_REQUIRE(x);
+  const int grid = spmv_grid_for(ctx, count, kBlock);
+  hipLaunchKernelGGL(fill_const_kernel, dim3(grid), dim3(kBlock), 0,
+                     spmv_stream(ctx, stream), count, value, x);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,169 @@
+// RCCL transport over xGMI: one process per GPU, one communicator per process.
+//
+// Stands behind the MPI calls of the reference's hot path:
+//   - L2GMap::update p2p models (spmv/L2GMap.cpp:564-642): MPI_Irecv straight
+//     into the ghost tail + MPI_Isend from the packed buffer become ONE
+//     grouped ncclSend/ncclRecv on the caller's (side) stream; completion is
+//     an event on that stream instead of MPI_Waitall -- the host never waits.
+//   - MPI_Allreduce(1 x double) in cg (spmv/cg.cpp:49,65,75): in-stream
+//     ncclAllReduce on the device-resident scalar.
+//   - the small host-side collectives of plan construction
+//     (L2GMap.cpp:353-354,387-388,444-447) are staged through device memory.
+// xGMI is point-to-point; a slab partition talks to <= 2 neighbours, each on
+// its own link, so the exchange is latency- not bandwidth-bound.
+#include "common.h"
+
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <new>
+
+static_assert(sizeof(ncclUniqueId) <= SPMV_HIP_UNIQUE_ID_BYTES,
+              "unique id does not fit the ABI's byte buffer");
+
+struct spmv_hip_comm {
+  spmv_hip_ctx* ctx = nullptr;
+  ncclComm_t comm = nullptr;
+  int nranks = 1;
+  int rank = 0;
+};
+
+#define SPMV_CHECK_NCCL(expr)                                                  \
+  do {                                                                         \
+    ncclResult_t _r = (expr);                                                  \
+    if (_r != ncclSuccess)                                                     \
+      return 10000 + static_cast<int>(_r);                                     \
+  } while (0)
+
+extern "C" {
+
+int spmv_hip_comm_unique_id(void* host_id_bytes)
+{
+  SPMV_REQUIRE(host_id_bytes);
+  ncclUniqueId id;
+  SPMV_CHECK_NCCL(ncclGetUniqueId(&id));
+  memset(host_id_bytes, 0, SPMV_HIP_UNIQUE_ID_BYTES);
+  memcpy(host_id_bytes, &id, sizeof(id));
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_comm_create(spmv_hip_ctx* ctx, int nranks, int rank,
+                         const void* host_id_bytes, spmv_hip_comm** out)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(out && host_id_bytes && nranks >= 1 && rank >= 0
+               && rank < nranks);
+  spmv_hip_comm* c = new (std::nothrow) spmv_hip_comm;
+  if (!c)
+    return SPMV_HIP_ENOMEM;
+  c->ctx = ctx;
+  c->nranks = nranks;
+  c->rank = rank;
+  ncclUniqueId id;
+  memcpy(&id, host_id_bytes, sizeof(id));
+  ncclResult_t r = ncclCommInitRank(&c->comm, nranks, id, rank);
+  if (r != ncclSuccess) {
+    delete c;
+    return 10000 + static_cast<int>(r);
+  }
+  *out = c;
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_comm_destroy(spmv_hip_comm* comm)
+{
+  if (!comm)
+    return SPMV_HIP_OK;
+  (void)hipSetDevice(comm->ctx->device);
+  if (comm->comm)
+    (void)ncclCommDestroy(comm->comm);
+  delete comm;
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_comm_neighbor_exchange_f64(
+    spmv_hip_comm* comm, int num_neighbours, const int32_t* host_neighbours,
+    const double* send_buf, const int32_t* host_send_counts,
+    const int32_t* host_send_offsets, double* recv_base,
+    const int32_t* host_recv_counts, const int32_t* host_recv_offsets,
+    void* stream)
+{
+  SPMV_REQUIRE(comm && num_neighbours >= 0);
+  if (num_neighbours == 0)
+    return SPMV_HIP_OK;
+  SPMV_REQUIRE(host_neighbours && host_send_counts && host_send_offsets
+               && host_recv_counts && host_recv_offsets);
+  SPMV_SET_DEVICE(comm->ctx);
+  hipStream_t st = spmv_stream(comm->ctx, stream);
+  for (int i = 0; i < num_neighbours; ++i) {
+    SPMV_REQUIRE(host_neighbours[i] >= 0 && host_neighbours[i] < comm->nranks
+                 && host_neighbours[i] != comm->rank);
+    SPMV_REQUIRE(host_send_counts[i] >= 0 && host_recv_counts[i] >= 0);
+    SPMV_REQUIRE(host_send_counts[i] == 0 || send_buf);
+    SPMV_REQUIRE(host_recv_counts[i] == 0 || recv_base);
+  }
+  SPMV_CHECK_NCCL(ncclGroupStart());
+  ncclResult_t r = ncclSuccess;
+  for (int i = 0; i < num_neighbours && r == ncclSuccess; ++i) {
+    if (host_recv_counts[i] > 0) // L2GMap.cpp:624-628
+      r = ncclRecv(recv_base + host_recv_offsets[i], host_recv_counts[i],
+                   ncclDouble, host_neighbours[i], comm->comm, st);
+    if (r == ncclSuccess && host_send_counts[i] > 0) // L2GMap.cpp:630-634
+      r = ncclSend(send_buf + host_send_offsets[i], host_send_counts[i],
+                   ncclDouble, host_neighbours[i], comm->comm, st);
+  }
+  ncclResult_t r2 = ncclGroupEnd();
+  if (r != ncclSuccess)
+    return 10000 + static_cast<int>(r);
+  SPMV_CHECK_NCCL(r2);
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_comm_allreduce_sum_f64(spmv_hip_comm* comm, double* inout,
+                                    size_t count, void* stream)
+{
+  SPMV_REQUIRE(comm && (count == 0 || inout));
+  if (count == 0 || comm->nranks == 1)
+    return SPMV_HIP_OK;
+  SPMV_SET_DEVICE(comm->ctx);
+  SPMV_CHECK_NCCL(ncclAllReduce(inout, inout, count, ncclDouble, ncclSum,
+                                comm->comm, spmv_stream(comm->ctx, stream)));
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_comm_allgather_host(spmv_hip_comm* comm, const void* host_send,
+                                 void* host_recv, size_t bytes_per_rank)
+{
+  SPMV_REQUIRE(comm && (bytes_per_rank == 0 || (host_send && host_recv)));
+  if (bytes_per_rank == 0)
+    return SPMV_HIP_OK;
+  if (comm->nranks == 1) {
+    memcpy(host_recv, host_send, bytes_per_rank);
+    return SPMV_HIP_OK;
+  }
+  SPMV_SET_DEVICE(comm->ctx);
+  hipStream_t st = comm->ctx->stream;
+  char *d_send = nullptr, *d_recv = nullptr;
+  SPMV_CHECK_HIP(hipMalloc(&d_send, bytes_per_rank));
+  hipError_t e = hipMalloc(&d_recv, bytes_per_rank * comm->nranks);
+  ncclResult_t r = ncclSuccess;
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(d_send, host_send, bytes_per_rank,
+                       hipMemcpyHostToDevice, st);
+  if (e == hipSuccess)
+    r = ncclAllGather(d_send, d_recv, bytes_per_rank, ncclChar, comm->comm, st);
+  if (e == hipSuccess && r == ncclSuccess)
+    e = hipMemcpyAsync(host_recv, d_recv, bytes_per_rank * comm->nranks,
+                       hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && r == ncclSuccess)
+    e = hipStreamSynchronize(st);
+  (void)hipFree(d_send);
+  (void)hipFree(d_recv);
+  if (r != ncclSuccess)
+    return 10000 + static_cast<int>(r);
+  if (e != hipSuccess)
+    return static_cast<int>(e);
+  return SPMV_HIP_OK;
+}
+
+} // extern "C"

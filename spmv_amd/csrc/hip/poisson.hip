@@ -1,0 +1,224 @@
+// 3-D 7-point Poisson matrix generator, directly into device memory.
+//
+// Not part of the reference (demos/CreateA.cpp builds a
+// 1-D tridiagonal matrix).  The structure -- contiguous row ranges per rank,
+// ghost columns renumbered after the owned ones in ascending global order --
+// follows Matrix::create_matrix (spmv/Matrix.cpp:295-318) so the blocks this
+// kernel writes are exactly what create_matrix would build from the host
+// CSR; tests compare the two at small n.  Setup only, untimed.
+//
+// Grid n^3, natural ordering i = x + n (y + n z), diagonal 6, off-diagonal
+// -1, neighbours outside the grid dropped.  Columns of a row are emitted in
+// ascending order: i-n^2, i-n, i-1, i, i+1, i+n, i+n^2.
+#include "common.h"
+
+#include <hipcub/hipcub.hpp>
+
+namespace
+{
+
+struct Geom {
+  int32_t n;
+  int64_t n2, N;
+  int64_t r0, r1;       // owned global rows (= owned global columns)
+  int64_t gb_start, gb; // ghosts below: [gb_start, r0), gb of them
+  int64_t ga;           // ghosts above: [r1, r1 + ga)
+};
+
+__host__ __device__ inline bool keep(int part, int64_t row, int64_t col,
+                                     int64_t r0, int64_t r1)
+{
+  const bool owned = col >= r0 && col < r1;
+  switch (part) {
+  case SPMV_HIP_PART_ALL: return true;
+  case SPMV_HIP_PART_LOCAL: return owned;
+  case SPMV_HIP_PART_REMOTE: return !owned;
+  default: return owned && row > col; // LOCAL_LOWER (Matrix.cpp:343-344)
+  }
+}
+
+__device__ inline int32_t local_col(const Geom& g, int64_t col)
+{
+  if (col < g.r0)
+    return (int32_t)((g.r1 - g.r0) + (col - g.gb_start));
+  if (col >= g.r1)
+    return (int32_t)((g.r1 - g.r0) + g.gb + (col - g.r1));
+  return (int32_t)(col - g.r0);
+}
+
+// neighbours of global row i in ascending column order; returns count
+__device__ inline int stencil(const Geom& g, int64_t i, int64_t* cols)
+{
+  const int64_t x = i % g.n, y = (i / g.n) % g.n, z = i / g.n2;
+  int c = 0;
+  if (z > 0) cols[c++] = i - g.n2;
+  if (y > 0) cols[c++] = i - g.n;
+  if (x > 0) cols[c++] = i - 1;
+  cols[c++] = i;
+  if (x < g.n - 1) cols[c++] = i + 1;
+  if (y < g.n - 1) cols[c++] = i + g.n;
+  if (z < g.n - 1) cols[c++] = i + g.n2;
+  return c;
+}
+
+__global__ __launch_bounds__(kBlock) void poisson_count_kernel(Geom g, int part,
+                                                               int32_t* counts)
+{
+  const int64_t nrows = g.r1 - g.r0;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k <= nrows;
+       k += (int64_t)gridDim.x * blockDim.x) {
+    int cnt = 0;
+    if (k < nrows) {
+      int64_t cols[7];
+      const int64_t i = g.r0 + k;
+      const int c = stencil(g, i, cols);
+      for (int e = 0; e < c; ++e)
+        cnt += keep(part, i, cols[e], g.r0, g.r1) ? 1 : 0;
+    }
+    counts[k] = cnt; // counts[nrows] = 0 closes the exclusive scan
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void poisson_fill_kernel(
+    Geom g, int part, const int32_t* __restrict__ rowptr,
+    int32_t* __restrict__ colind, double* __restrict__ values,
+    double* __restrict__ diagonal)
+{
+  const int64_t nrows = g.r1 - g.r0;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nrows;
+       k += (int64_t)gridDim.x * blockDim.x) {
+    int64_t cols[7];
+    const int64_t i = g.r0 + k;
+    const int c = stencil(g, i, cols);
+    int64_t pos = rowptr[k];
+    for (int e = 0; e < c; ++e) {
+      if (!keep(part, i, cols[e], g.r0, g.r1))
+        continue;
+      colind[pos] = local_col(g, cols[e]);
+      values[pos] = (cols[e] == i) ? 6.0 : -1.0;
+      ++pos;
+    }
+    if (diagonal)
+      diagonal[k] = 6.0;
+  }
+}
+
+int make_geom(int32_t n, int64_t r0, int64_t r1, Geom* g)
+{
+  if (n < 1 || n > 1290) // n^3 rows must fit the int32 local index space
+    return SPMV_HIP_ERANGE;
+  const int64_t n2 = (int64_t)n * n, N = n2 * n;
+  if (r0 < 0 || r1 < r0 || r1 > N)
+    return SPMV_HIP_EINVAL;
+  // Closed-form ghost numbering needs the ghost sets to be whole runs:
+  // true when the block is the whole matrix or holds >= n^2 rows.
+  const bool whole = (r0 == 0 && r1 == N);
+  if (!whole && (r1 - r0) < n2)
+    return SPMV_HIP_ENOTSUP;
+  g->n = n;
+  g->n2 = n2;
+  g->N = N;
+  g->r0 = r0;
+  g->r1 = r1;
+  g->gb = r0 < n2 ? r0 : n2;
+  g->gb_start = r0 - g->gb;
+  g->ga = (N - r1) < n2 ? (N - r1) : n2;
+  if ((r1 - r0) + g->gb + g->ga > INT32_MAX)
+    return SPMV_HIP_ERANGE;
+  return SPMV_HIP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int spmv_hip_poisson3d_ghosts(int32_t n, int64_t row_begin, int64_t row_end,
+                              int64_t* ghosts_below, int64_t* ghosts_above)
+{
+  Geom g;
+  int rc = make_geom(n, row_begin, row_end, &g);
+  if (rc)
+    return rc;
+  if (ghosts_below)
+    *ghosts_below = g.gb;
+  if (ghosts_above)
+    *ghosts_above = g.ga;
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_poisson3d_count(spmv_hip_ctx* ctx, int32_t n, int64_t row_begin,
+                             int64_t row_end, int part, int32_t* rowptr,
+                             int64_t* host_nnz, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(rowptr && part >= SPMV_HIP_PART_ALL
+               && part <= SPMV_HIP_PART_LOCAL_LOWER);
+  Geom g;
+  int rc = make_geom(n, row_begin, row_end, &g);
+  if (rc)
+    return rc;
+  const int64_t nrows = g.r1 - g.r0;
+  if (7 * nrows > INT32_MAX)
+    return SPMV_HIP_ERANGE; // int32 rowptr (csr_kernels.h:28)
+  hipStream_t st = spmv_stream(ctx, stream);
+  const int grid = spmv_grid_for(ctx, nrows + 1, kBlock);
+  hipLaunchKernelGGL(poisson_count_kernel, dim3(grid), dim3(kBlock), 0, st, g,
+                     part, rowptr);
+  SPMV_CHECK_LAUNCH();
+  // in-place exclusive scan of nrows+1 counts -> row pointer
+  void* tmp = nullptr;
+  size_t tmp_bytes = 0;
+  SPMV_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(
+      nullptr, tmp_bytes, rowptr, rowptr, (int)(nrows + 1), st));
+  SPMV_CHECK_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+  hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, rowptr,
+                                                  rowptr, (int)(nrows + 1), st);
+  int32_t total = 0;
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(&total, rowptr + nrows, sizeof(int32_t),
+                       hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st);
+  (void)hipFree(tmp);
+  if (e != hipSuccess)
+    return static_cast<int>(e);
+  if (host_nnz)
+    *host_nnz = total;
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_poisson3d_fill_f64(spmv_hip_ctx* ctx, int32_t n,
+                                int64_t row_begin, int64_t row_end, int part,
+                                const int32_t* rowptr, int32_t* colind,
+                                double* values, double* diagonal, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(rowptr && part >= SPMV_HIP_PART_ALL
+               && part <= SPMV_HIP_PART_LOCAL_LOWER);
+  Geom g;
+  int rc = make_geom(n, row_begin, row_end, &g);
+  if (rc)
+    return rc;
+  const int64_t nrows = g.r1 - g.r0;
+  if (nrows == 0)
+    return SPMV_HIP_OK;
+  // colind/values may be NULL only if the caller knows the part is empty
+  // (e.g. REMOTE on one rank); the kernel would then write nothing, but a
+  // NULL with entries to write must never reach the device.
+  if (!colind || !values) {
+    int32_t total = 0;
+    SPMV_CHECK_HIP(hipMemcpy(&total, rowptr + nrows, sizeof(int32_t),
+                             hipMemcpyDeviceToHost));
+    SPMV_REQUIRE(total == 0);
+    if (!diagonal)
+      return SPMV_HIP_OK;
+  }
+  const int grid = spmv_grid_for(ctx, nrows, kBlock);
+  hipLaunchKernelGGL(poisson_fill_kernel, dim3(grid), dim3(kBlock), 0,
+                     spmv_stream(ctx, stream), g, part, rowptr, colind, values,
+                     diagonal);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,283 @@
+// Context, memory, stream and event plumbing of libspmv_hip.so.
+// Stands behind DeviceExecutor's byte-level virtuals
+// (spmv/device_executor.h:129-139) and CudaExecutor's stream accessors
+// (spmv/cuda/cuda_executor.h:72-76).
+#include "common.h"
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+extern "C" {
+
+int spmv_hip_abi_version(void) { return SPMV_HIP_ABI_VERSION; }
+
+const char* spmv_hip_error_string(int code)
+{
+  if (code == SPMV_HIP_OK)
+    return "success";
+  if (code == SPMV_HIP_EINVAL)
+    return "spmv_hip: invalid argument";
+  if (code == SPMV_HIP_ENOMEM)
+    return "spmv_hip: host allocation failed";
+  if (code == SPMV_HIP_ENOTSUP)
+    return "spmv_hip: not supported in this build";
+  if (code == SPMV_HIP_ERANGE)
+    return "spmv_hip: size exceeds 32-bit index range";
+  if (code >= 10000)
+    return "spmv_hip: RCCL error (code - 10000 = ncclResult_t)";
+  if (code > 0)
+    return hipGetErrorString(static_cast<hipError_t>(code));
+  return "spmv_hip: unknown error";
+}
+
+int spmv_hip_device_count(int* count)
+{
+  SPMV_REQUIRE(count != nullptr);
+  SPMV_CHECK_HIP(hipGetDeviceCount(count));
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_ctx_create(int device_id, spmv_hip_ctx** out)
+{
+  SPMV_REQUIRE(out != nullptr && device_id >= 0);
+  int count = 0;
+  SPMV_CHECK_HIP(hipGetDeviceCount(&count));
+  SPMV_REQUIRE(device_id < count);
+  SPMV_CHECK_HIP(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  SPMV_CHECK_HIP(hipGetDeviceProperties(&prop, device_id));
+  spmv_hip_ctx* ctx = new (std::nothrow) spmv_hip_ctx;
+  if (!ctx)
+    return SPMV_HIP_ENOMEM;
+  ctx->device = device_id;
+  ctx->num_cus = prop.multiProcessorCount;
+  ctx->dot_blocks = ctx->num_cus * kBlocksPerCU;
+  *out = ctx;
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_ctx_destroy(spmv_hip_ctx* ctx)
+{
+  delete ctx;
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_ctx_device(const spmv_hip_ctx* ctx, int* device_id)
+{
+  SPMV_REQUIRE(ctx && device_id);
+  *device_id = ctx->device;
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_num_cus(const spmv_hip_ctx* ctx, int* num_cus)
+{
+  SPMV_REQUIRE(ctx && num_cus);
+  *num_cus = ctx->num_cus;
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_synchronize(spmv_hip_ctx* ctx)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_CHECK_HIP(hipDeviceSynchronize());
+  return SPMV_HIP_OK;
+}
+
+// ---- streams / events ------------------------------------------------------
+int spmv_hip_stream_create(spmv_hip_ctx* ctx, void** stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(stream);
+  hipStream_t s;
+  SPMV_CHECK_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream = s;
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_stream_destroy(spmv_hip_ctx* ctx, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  if (stream) {
+    if (ctx->stream == stream)
+      ctx->stream = nullptr;
+    SPMV_CHECK_HIP(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+  }
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_stream_synchronize(spmv_hip_ctx* ctx, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_CHECK_HIP(hipStreamSynchronize(spmv_stream(ctx, stream)));
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_set_stream(spmv_hip_ctx* ctx, void* stream)
+{
+  SPMV_REQUIRE(ctx);
+  ctx->stream = static_cast<hipStream_t>(stream);
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_get_stream(const spmv_hip_ctx* ctx, void** stream)
+{
+  SPMV_REQUIRE(ctx && stream);
+  *stream = ctx->stream;
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_event_create(spmv_hip_ctx* ctx, int timing, void** event)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(event);
+  hipEvent_t e;
+  SPMV_CHECK_HIP(hipEventCreateWithFlags(
+      &e, timing ? hipEventDefault : hipEventDisableTiming));
+  *event = e;
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_event_destroy(spmv_hip_ctx* ctx, void* event)
+{
+  SPMV_SET_DEVICE(ctx);
+  if (event)
+    SPMV_CHECK_HIP(hipEventDestroy(static_cast<hipEvent_t>(event)));
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_event_record(spmv_hip_ctx* ctx, void* event, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(event);
+  SPMV_CHECK_HIP(hipEventRecord(static_cast<hipEvent_t>(event),
+                                spmv_stream(ctx, stream)));
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_event_synchronize(spmv_hip_ctx* ctx, void* event)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(event);
+  SPMV_CHECK_HIP(hipEventSynchronize(static_cast<hipEvent_t>(event)));
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_stream_wait_event(spmv_hip_ctx* ctx, void* stream, void* event)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(event);
+  SPMV_CHECK_HIP(hipStreamWaitEvent(spmv_stream(ctx, stream),
+                                    static_cast<hipEvent_t>(event), 0));
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_event_elapsed_ms(spmv_hip_ctx* ctx, void* start, void* stop,
+                              float* ms)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(start && stop && ms);
+  SPMV_CHECK_HIP(hipEventElapsedTime(ms, static_cast<hipEvent_t>(start),
+                                     static_cast<hipEvent_t>(stop)));
+  return SPMV_HIP_OK;
+}
+
+// ---- memory ------------------------------------------------------------------
+int spmv_hip_alloc(spmv_hip_ctx* ctx, size_t num_bytes, void** ptr)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(ptr);
+  *ptr = nullptr;
+  if (num_bytes == 0)
+    return SPMV_HIP_OK;
+  SPMV_CHECK_HIP(hipMalloc(ptr, num_bytes));
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_free(spmv_hip_ctx* ctx, void* ptr)
+{
+  SPMV_SET_DEVICE(ctx);
+  if (ptr)
+    SPMV_CHECK_HIP(hipFree(ptr));
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_host_alloc(spmv_hip_ctx* ctx, size_t num_bytes, void** host_ptr)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(host_ptr);
+  *host_ptr = nullptr;
+  if (num_bytes == 0)
+    return SPMV_HIP_OK;
+  SPMV_CHECK_HIP(hipHostMalloc(host_ptr, num_bytes, hipHostMallocDefault));
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_host_free(spmv_hip_ctx* ctx, void* host_ptr)
+{
+  SPMV_SET_DEVICE(ctx);
+  if (host_ptr)
+    SPMV_CHECK_HIP(hipHostFree(host_ptr));
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_memset_async(spmv_hip_ctx* ctx, void* ptr, int value,
+                          size_t num_bytes, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  if (num_bytes == 0)
+    return SPMV_HIP_OK;
+  SPMV_REQUIRE(ptr);
+  SPMV_CHECK_HIP(hipMemsetAsync(ptr, value, num_bytes,
+                                spmv_stream(ctx, stream)));
+  return SPMV_HIP_OK;
+}
+
+static int copy_async(spmv_hip_ctx* ctx, void* dst, const void* src,
+                      size_t num_bytes, hipMemcpyKind kind, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  if (num_bytes == 0 || dst == src)
+    return SPMV_HIP_OK;
+  SPMV_REQUIRE(dst && src);
+  SPMV_CHECK_HIP(hipMemcpyAsync(dst, src, num_bytes, kind,
+                                spmv_stream(ctx, stream)));
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_copy_d2d_async(spmv_hip_ctx* ctx, void* dst, const void* src,
+                            size_t num_bytes, void* stream)
+{
+  return copy_async(ctx, dst, src, num_bytes, hipMemcpyDeviceToDevice, stream);
+}
+
+int spmv_hip_copy_h2d_async(spmv_hip_ctx* ctx, void* dst,
+                            const void* host_src, size_t num_bytes,
+                            void* stream)
+{
+  return copy_async(ctx, dst, host_src, num_bytes, hipMemcpyHostToDevice,
+                    stream);
+}
+
+int spmv_hip_copy_d2h_async(spmv_hip_ctx* ctx, void* host_dst, const void* src,
+                            size_t num_bytes, void* stream)
+{
+  return copy_async(ctx, host_dst, src, num_bytes, hipMemcpyDeviceToHost,
+                    stream);
+}
+
+int spmv_hip_copy_peer_async(spmv_hip_ctx* dst_ctx, void* dst,
+                             spmv_hip_ctx* src_ctx, const void* src,
+                             size_t num_bytes, void* stream)
+{
+  SPMV_REQUIRE(dst_ctx && src_ctx);
+  SPMV_SET_DEVICE(dst_ctx);
+  if (num_bytes == 0)
+    return SPMV_HIP_OK;
+  SPMV_REQUIRE(dst && src);
+  SPMV_CHECK_HIP(hipMemcpyPeerAsync(dst, dst_ctx->device, src, src_ctx->device,
+                                    num_bytes, spmv_stream(dst_ctx, stream)));
+  return SPMV_HIP_OK;
+}
+
+} // extern "C"

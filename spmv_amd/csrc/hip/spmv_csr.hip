@@ -1,0 +1,803 @@
+// CSR and symmetric-CSR SpMV kernels for gfx950 (MI355X).
+//
+// Stands behind CSRSpMV<T>::init/run/finalize (spmv/csr_kernels.h:26-78);
+// arithmetic follows spmv/csr_kernels.cpp:20-52.  Built with
+// -ffp-contract=off so a*b+c is two roundings, as in the reference build.
+//
+// HBM-bound gather (0.13-0.17 flop/B): MFMA is deliberately unused.
+//
+// ROWBLOCK kernel (the hot one)
+//   A workgroup of 256 threads owns ROWS consecutive rows.  The nnz span of
+//   those rows is contiguous in CSR, so the workgroup streams it in tiles of
+//   TILE entries with 16-byte-per-lane coalesced loads (values) and the
+//   matching 8/16-byte colind loads, multiplies by the gathered x and parks
+//   the products in LDS.  Then each thread owns one row and adds its
+//   products left to right out of LDS -- the same order as the reference's
+//   scalar loop, so the result is bit-identical to csr_kernels.cpp:41-51.
+//   The row pointer is read once, coalesced, into LDS.  Launches are
+//   grid-stride (<= 8 workgroups per CU) so the optional fused dot product
+//   sum_i in[i]*out[i] leaves a fixed, small number of partials.
+//
+// VECTOR kernel: LPR lanes per row with a __shfl_down segmented reduction,
+//   for matrices with long rows.
+// SCALAR kernel: one lane per row, reference loop verbatim.
+//
+// Symmetric kernel (strictly-lower CSR + diagonal, csr_kernels.cpp:26-40)
+//   Same streaming structure; the row owner walks its entries in LDS and
+//   scatters alpha*v*x[i] with hardware fp64 atomics (global_atomic_add_f64).
+//   Consecutive lanes own consecutive rows, so for banded matrices each
+//   atomic wave-instruction touches a contiguous run of `out`.  `out` is
+//   scaled by beta (or zero-filled) by a separate pre-pass on the same
+//   stream.
+#include "common.h"
+
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include <cstring>
+#include <new>
+
+namespace
+{
+
+constexpr int kRows = kBlock; // rows per workgroup in ROWBLOCK kernels
+
+// clang ext-vector types: 16-byte loads/stores, accepted by the
+// non-temporal builtins (HIP's double2/int4 wrapper structs are not).
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+struct VecOf;
+template <>
+struct VecOf<double> {
+  static constexpr int V = 2; // 16 B of values per lane per load
+  using val_t = f64x2;
+  using col_t = i32x2;
+};
+template <>
+struct VecOf<float> {
+  static constexpr int V = 4;
+  using val_t = f32x4;
+  using col_t = i32x4;
+};
+
+template <bool NT, typename P>
+__device__ __forceinline__ P stream_load(const P* p)
+{
+  if constexpr (NT)
+    return __builtin_nontemporal_load(p);
+  else
+    return *p;
+}
+
+// Block-wide sum of one double per thread (fixed tree => deterministic).
+__device__ __forceinline__ double block_sum(double v, double* s_red)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+    v += __shfl_down(v, off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0)
+    s_red[wave] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w)
+      r += s_red[w];
+  }
+  return r; // valid in thread 0
+}
+
+// The partial array has a fixed length; producers with a smaller grid clear
+// the tail so the reducer can always add all of it.
+__device__ __forceinline__ void clear_partials_tail(double* partials, int len)
+{
+  for (int i = gridDim.x + blockIdx.x * blockDim.x + threadIdx.x; i < len;
+       i += gridDim.x * blockDim.x)
+    partials[i] = 0.0;
+}
+
+// ---------------------------------------------------------------------------
+// ROWBLOCK general kernel
+//   CH      = 16-byte value loads per lane per tile (tile = 256*CH*V entries)
+//   NT      = non-temporal loads for the read-once matrix stream
+//   ALIGNED = values 16-B / colind 8|16-B aligned => wide loads
+//   XCD     = remap row blocks so each XCD walks a contiguous chunk
+// ---------------------------------------------------------------------------
+template <typename T, int CH, bool NT, bool ALIGNED, bool DOT, bool XCD>
+__global__ __launch_bounds__(kBlock) void csr_rowblock_kernel(
+    int32_t num_rows, int64_t nnz, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ colind, const T* __restrict__ values, T alpha,
+    const T* __restrict__ in, T beta, T* __restrict__ out,
+    double* __restrict__ dot_partials, int dot_len, int num_row_blocks)
+{
+  constexpr int V = VecOf<T>::V;
+  constexpr int TILE = kBlock * CH * V;
+  using val_t = typename VecOf<T>::val_t;
+  using col_t = typename VecOf<T>::col_t;
+
+  __shared__ T s_prod[TILE];
+  __shared__ int32_t s_rowptr[kRows + 1];
+  __shared__ double s_red[kBlock / 64];
+
+  const int t = threadIdx.x;
+  double dot_acc = 0.0;
+
+  // XCD remap: blocks b and b+8 share an XCD (round-robin dispatch), so slot
+  // `it` is sent to row block (it%8)*per + it/8: each XCD walks a contiguous
+  // slice of the matrix.  Speed only, never correctness: the map is a
+  // bijection of [0, 8*per) and slots past the last row block are skipped.
+  const int per_xcd = (num_row_blocks + 7) >> 3;
+  const int num_slots = XCD ? 8 * per_xcd : num_row_blocks;
+  for (int it = blockIdx.x; it < num_slots; it += gridDim.x) {
+    int rb = it;
+    if constexpr (XCD) {
+      rb = (it & 7) * per_xcd + (it >> 3);
+      if (rb >= num_row_blocks)
+        continue; // uniform per workgroup
+    }
+    const int32_t r0 = rb * kRows;
+    const int nr = min(kRows, num_rows - r0);
+
+    __syncthreads(); // previous iteration done with s_rowptr / s_prod
+    if (t <= nr)
+      s_rowptr[t] = rowptr[r0 + t];
+    if (t == 0 && nr == kRows)
+      s_rowptr[kRows] = rowptr[r0 + kRows];
+    __syncthreads();
+
+    const int32_t a = s_rowptr[0];
+    const int32_t b = s_rowptr[nr];
+    int32_t lo = 0, hi = 0;
+    if (t < nr) {
+      lo = s_rowptr[t];
+      hi = s_rowptr[t + 1];
+    }
+    T sum = 0;
+
+    // tiles start V-aligned so the wide loads are naturally aligned
+    const int64_t base0 = a & ~(V - 1);
+    // last V-aligned slot of this row block's span: lanes past the span
+    // re-read it (one cached line) instead of streaming the next block's data
+    const int64_t jclamp = (int64_t)(b - 1) & ~(int64_t)(V - 1);
+    for (int64_t base = base0; base < b; base += TILE) {
+      if (base != base0)
+        __syncthreads(); // row owners finished reading the previous tile
+      // Fast path: every wide load of the tile is inside the arrays.  All
+      // matrix loads are issued first, then all gathers, then the products,
+      // so one lane keeps CH*(1+V) loads in flight.
+      if (ALIGNED && jclamp + V <= nnz) {
+        val_t v[CH];
+        col_t ci[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int64_t j0 = base + (int64_t)(c * kBlock + t) * V;
+          const int64_t jl = j0 < jclamp ? j0 : jclamp;
+          v[c] = stream_load<NT>(reinterpret_cast<const val_t*>(values + jl));
+          ci[c] = stream_load<NT>(reinterpret_cast<const col_t*>(colind + jl));
+        }
+        T xg[CH][V];
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+          for (int e = 0; e < V; ++e)
+            xg[c][e] = in[ci[c][e]];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int64_t j0 = base + (int64_t)(c * kBlock + t) * V;
+          val_t pv;
+#pragma unroll
+          for (int e = 0; e < V; ++e)
+            pv[e] = (j0 + e < b) ? v[c][e] * xg[c][e] : T(0);
+          *reinterpret_cast<val_t*>(&s_prod[(c * kBlock + t) * V]) = pv;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int64_t j0 = base + (int64_t)(c * kBlock + t) * V;
+          val_t pv;
+#pragma unroll
+          for (int e = 0; e < V; ++e) {
+            const int64_t j = j0 + e;
+            pv[e] = (j < b) ? values[j] * in[colind[j]] : T(0);
+          }
+          *reinterpret_cast<val_t*>(&s_prod[(c * kBlock + t) * V]) = pv;
+        }
+      }
+      // entries in [base, a) belong to earlier rows; no row of this block
+      // reads them, so their (valid) products are simply ignored.
+      __syncthreads();
+      const int32_t jlo = max((int64_t)lo, base) - base;
+      const int32_t jhi = min((int64_t)hi, base + TILE) - base;
+      int32_t j = jlo;
+      // four LDS reads in flight, adds strictly left to right
+      for (; j + 4 <= jhi; j += 4) {
+        const T p0 = s_prod[j], p1 = s_prod[j + 1], p2 = s_prod[j + 2],
+                p3 = s_prod[j + 3];
+        sum += p0;
+        sum += p1;
+        sum += p2;
+        sum += p3;
+      }
+      for (; j < jhi; ++j)
+        sum += s_prod[j];
+    }
+
+    if (t < nr) {
+      const int32_t r = r0 + t;
+      T y = alpha * sum;
+      if (beta != T(0))
+        y = y + beta * out[r];
+      out[r] = y;
+      if constexpr (DOT)
+        dot_acc += (double)in[r] * (double)y;
+    }
+  }
+
+  if constexpr (DOT) {
+    double s = block_sum(dot_acc, s_red);
+    if (t == 0)
+      dot_partials[blockIdx.x] = s;
+    clear_partials_tail(dot_partials, dot_len);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// SCALAR kernel: one lane per row, the reference loop verbatim.
+// ---------------------------------------------------------------------------
+template <typename T, bool DOT>
+__global__ __launch_bounds__(kBlock) void csr_scalar_kernel(
+    int32_t num_rows, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ colind, const T* __restrict__ values, T alpha,
+    const T* __restrict__ in, T beta, T* __restrict__ out,
+    double* __restrict__ dot_partials, int dot_len)
+{
+  __shared__ double s_red[kBlock / 64];
+  double dot_acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+       i < num_rows; i += (int64_t)gridDim.x * blockDim.x) {
+    T sum = 0;
+    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j)
+      sum += values[j] * in[colind[j]];
+    T y = alpha * sum;
+    if (beta != T(0))
+      y = y + beta * out[i];
+    out[i] = y;
+    if constexpr (DOT)
+      dot_acc += (double)in[i] * (double)y;
+  }
+  if constexpr (DOT) {
+    double s = block_sum(dot_acc, s_red);
+    if (threadIdx.x == 0)
+      dot_partials[blockIdx.x] = s;
+    clear_partials_tail(dot_partials, dot_len);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// VECTOR kernel: LPR lanes per row, strided walk + shuffle reduction.
+// ---------------------------------------------------------------------------
+template <typename T, int LPR, bool DOT>
+__global__ __launch_bounds__(kBlock) void csr_vector_kernel(
+    int32_t num_rows, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ colind, const T* __restrict__ values, T alpha,
+    const T* __restrict__ in, T beta, T* __restrict__ out,
+    double* __restrict__ dot_partials, int dot_len)
+{
+  __shared__ double s_red[kBlock / 64];
+  constexpr int RPB = kBlock / LPR; // rows per workgroup
+  const int sub = threadIdx.x % LPR;
+  const int grp = threadIdx.x / LPR;
+  double dot_acc = 0.0;
+  const int64_t nblk = ((int64_t)num_rows + RPB - 1) / RPB;
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int64_t i = blk * RPB + grp;
+    T sum = 0;
+    if (i < num_rows) {
+      const int32_t lo = rowptr[i], hi = rowptr[i + 1];
+      for (int32_t j = lo + sub; j < hi; j += LPR)
+        sum += values[j] * in[colind[j]];
+    }
+#pragma unroll
+    for (int off = LPR / 2; off > 0; off >>= 1)
+      sum += __shfl_down(sum, off, LPR);
+    if (i < num_rows && sub == 0) {
+      T y = alpha * sum;
+      if (beta != T(0))
+        y = y + beta * out[i];
+      out[i] = y;
+      if constexpr (DOT)
+        dot_acc += (double)in[i] * (double)y;
+    }
+  }
+  if constexpr (DOT) {
+    double s = block_sum(dot_acc, s_red);
+    if (threadIdx.x == 0)
+      dot_partials[blockIdx.x] = s;
+    clear_partials_tail(dot_partials, dot_len);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Symmetric kernels
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void atomic_add(double* p, double v)
+{
+  unsafeAtomicAdd(p, v); // global_atomic_add_f64, no CAS loop
+}
+__device__ __forceinline__ void atomic_add(float* p, float v)
+{
+  unsafeAtomicAdd(p, v);
+}
+
+// out *= beta (zero-fill for beta == 0 without reading out: SURVEY F7b)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void scale_kernel(int64_t n, T beta,
+                                                       T* __restrict__ out)
+{
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (beta == T(0)) ? T(0) : beta * out[i];
+}
+
+// diagonal-only block: out = alpha*d*x + beta*out
+// (openmp/csr_kernels.openmp.cpp:222-225 covers the same nnz == 0 case)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void diag_kernel(
+    int64_t n, const T* __restrict__ diagonal, T alpha,
+    const T* __restrict__ in, T beta, T* __restrict__ out)
+{
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    T y = alpha * (diagonal[i] * in[i]);
+    if (beta != T(0))
+      y = y + beta * out[i];
+    out[i] = y;
+  }
+}
+
+template <typename T, int CH, bool NT, bool ALIGNED>
+__global__ __launch_bounds__(kBlock) void csr_sym_rowblock_kernel(
+    int32_t num_rows, int64_t nnz, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ colind, const T* __restrict__ values,
+    const T* __restrict__ diagonal, T alpha, const T* __restrict__ in,
+    T* __restrict__ out, int num_row_blocks)
+{
+  constexpr int V = VecOf<T>::V;
+  constexpr int TILE = kBlock * CH * V;
+  using val_t = typename VecOf<T>::val_t;
+  using col_t = typename VecOf<T>::col_t;
+
+  __shared__ T s_prod[TILE];
+  __shared__ T s_val[TILE];
+  __shared__ int32_t s_col[TILE];
+  __shared__ int32_t s_rowptr[kRows + 1];
+
+  const int t = threadIdx.x;
+  for (int rb = blockIdx.x; rb < num_row_blocks; rb += gridDim.x) {
+    const int32_t r0 = rb * kRows;
+    const int nr = min(kRows, num_rows - r0);
+    __syncthreads();
+    if (t <= nr)
+      s_rowptr[t] = rowptr[r0 + t];
+    if (t == 0 && nr == kRows)
+      s_rowptr[kRows] = rowptr[r0 + kRows];
+    __syncthreads();
+
+    const int32_t a = s_rowptr[0];
+    const int32_t b = s_rowptr[nr];
+    int32_t lo = 0, hi = 0;
+    T xi = 0, sum = 0;
+    if (t < nr) {
+      lo = s_rowptr[t];
+      hi = s_rowptr[t + 1];
+      xi = in[r0 + t];
+      sum = diagonal[r0 + t] * xi; // csr_kernels.cpp:28
+    }
+
+    const int64_t base0 = a & ~(V - 1);
+    const int64_t jclamp = (int64_t)(b - 1) & ~(int64_t)(V - 1);
+    for (int64_t base = base0; base < b; base += TILE) {
+      if (base != base0)
+        __syncthreads();
+      if (ALIGNED && jclamp + V <= nnz) {
+        // fast path: all matrix loads, then all gathers (see general kernel)
+        val_t v[CH];
+        col_t ci[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int64_t j0 = base + (int64_t)(c * kBlock + t) * V;
+          const int64_t jl = j0 < jclamp ? j0 : jclamp;
+          v[c] = stream_load<NT>(reinterpret_cast<const val_t*>(values + jl));
+          ci[c] = stream_load<NT>(reinterpret_cast<const col_t*>(colind + jl));
+        }
+        T xg[CH][V];
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+          for (int e = 0; e < V; ++e)
+            xg[c][e] = in[ci[c][e]];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int slot = (c * kBlock + t) * V;
+          const int64_t j0 = base + slot;
+          val_t pv;
+#pragma unroll
+          for (int e = 0; e < V; ++e)
+            pv[e] = (j0 + e < b) ? v[c][e] * xg[c][e] : T(0);
+          *reinterpret_cast<val_t*>(&s_prod[slot]) = pv;
+          *reinterpret_cast<val_t*>(&s_val[slot]) = v[c];
+          *reinterpret_cast<col_t*>(&s_col[slot]) = ci[c];
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int slot = (c * kBlock + t) * V;
+#pragma unroll
+          for (int e = 0; e < V; ++e) {
+            const int64_t j = base + slot + e;
+            const bool live = j < b;
+            const T vv = live ? values[j] : T(0);
+            const int32_t cc = live ? colind[j] : 0;
+            s_prod[slot + e] = live ? vv * in[cc] : T(0);
+            s_val[slot + e] = vv;
+            s_col[slot + e] = cc;
+          }
+        }
+      }
+      __syncthreads();
+      const int32_t jlo = max((int64_t)lo, base) - base;
+      const int32_t jhi = min((int64_t)hi, base + TILE) - base;
+      for (int32_t k = jlo; k < jhi; ++k) {
+        sum += s_prod[k];                                  // csr_kernels.cpp:34
+        atomic_add(&out[s_col[k]], alpha * s_val[k] * xi); // :35
+      }
+    }
+    if (t < nr)
+      atomic_add(&out[r0 + t], alpha * sum); // :39 (beta applied by pre-pass)
+  }
+}
+
+template <typename T>
+bool aligned16(const T* p)
+{
+  return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// Plan = CSRSpMV::_aux_data
+// ---------------------------------------------------------------------------
+struct spmv_hip_csr_plan {
+  spmv_hip_ctx* ctx = nullptr;
+  int32_t num_rows = 0, num_cols = 0;
+  int64_t nnz = 0;
+  bool symmetric = false;
+  int algo = SPMV_HIP_ALGO_ROWBLOCK;
+  int lanes_per_row = 8;  // VECTOR
+  int chunks = 2;         // ROWBLOCK: 16-B loads per lane per tile (1, 2, 4)
+  int nontemporal = 1;    // ROWBLOCK: nt loads on the matrix stream
+  int xcd_remap = 0;      // ROWBLOCK: XCD-contiguous row-block order
+  int blocks_per_cu = kBlocksPerCU;
+};
+
+namespace
+{
+
+template <typename T, int CH, bool NT, bool ALIGNED, bool DOT>
+int launch_rowblock_x(const spmv_hip_csr_plan* pl, hipStream_t st, int grid,
+                      int nrb, const int32_t* rowptr, const int32_t* colind,
+                      const T* values, T alpha, const T* in, T beta, T* out,
+                      double* dot)
+{
+  const int len = pl->ctx->dot_blocks;
+  if (pl->xcd_remap)
+    hipLaunchKernelGGL((csr_rowblock_kernel<T, CH, NT, ALIGNED, DOT, true>),
+                       dim3(grid), dim3(kBlock), 0, st, pl->num_rows, pl->nnz,
+                       rowptr, colind, values, alpha, in, beta, out, dot, len,
+                       nrb);
+  else
+    hipLaunchKernelGGL((csr_rowblock_kernel<T, CH, NT, ALIGNED, DOT, false>),
+                       dim3(grid), dim3(kBlock), 0, st, pl->num_rows, pl->nnz,
+                       rowptr, colind, values, alpha, in, beta, out, dot, len,
+                       nrb);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+template <typename T, bool DOT>
+int launch_rowblock(const spmv_hip_csr_plan* pl, hipStream_t st,
+                    const int32_t* rowptr, const int32_t* colind,
+                    const T* values, T alpha, const T* in, T beta, T* out,
+                    double* dot)
+{
+  const int nrb = (pl->num_rows + kRows - 1) / kRows;
+  int grid = pl->ctx->num_cus * pl->blocks_per_cu;
+  if (grid > pl->ctx->dot_blocks)
+    grid = pl->ctx->dot_blocks;
+  if (grid > nrb)
+    grid = nrb;
+  if (grid < 1)
+    grid = 1;
+  const bool al = aligned16(values) && aligned16(colind);
+#define SPMV_RB(CH, NT, AL)                                                    \
+  return launch_rowblock_x<T, CH, NT, AL, DOT>(pl, st, grid, nrb, rowptr,      \
+                                               colind, values, alpha, in,     \
+                                               beta, out, dot)
+  if (!al)
+    SPMV_RB(2, false, false);
+  if (pl->nontemporal) {
+    if (pl->chunks == 1)
+      SPMV_RB(1, true, true);
+    if (pl->chunks == 4)
+      SPMV_RB(4, true, true);
+    SPMV_RB(2, true, true);
+  }
+  if (pl->chunks == 1)
+    SPMV_RB(1, false, true);
+  if (pl->chunks == 4)
+    SPMV_RB(4, false, true);
+  SPMV_RB(2, false, true);
+#undef SPMV_RB
+}
+
+template <typename T, bool DOT>
+int launch_vector(const spmv_hip_csr_plan* pl, hipStream_t st,
+                  const int32_t* rowptr, const int32_t* colind,
+                  const T* values, T alpha, const T* in, T beta, T* out,
+                  double* dot)
+{
+  const int len = pl->ctx->dot_blocks;
+  const int lpr = pl->lanes_per_row;
+  const int64_t nblk = ((int64_t)pl->num_rows * lpr + kBlock - 1) / kBlock;
+  int grid = pl->ctx->dot_blocks;
+  if (grid > nblk)
+    grid = (int)(nblk < 1 ? 1 : nblk);
+#define SPMV_VEC(L)                                                            \
+  hipLaunchKernelGGL((csr_vector_kernel<T, L, DOT>), dim3(grid), dim3(kBlock), \
+                     0, st, pl->num_rows, rowptr, colind, values, alpha, in,   \
+                     beta, out, dot, len)
+  switch (lpr) {
+  case 4: SPMV_VEC(4); break;
+  case 8: SPMV_VEC(8); break;
+  case 16: SPMV_VEC(16); break;
+  case 32: SPMV_VEC(32); break;
+  default: SPMV_VEC(64); break;
+  }
+#undef SPMV_VEC
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+template <typename T, bool DOT>
+int launch_scalar(const spmv_hip_csr_plan* pl, hipStream_t st,
+                  const int32_t* rowptr, const int32_t* colind,
+                  const T* values, T alpha, const T* in, T beta, T* out,
+                  double* dot)
+{
+  const int grid = spmv_grid_for(pl->ctx, pl->num_rows, kBlock);
+  hipLaunchKernelGGL((csr_scalar_kernel<T, DOT>), dim3(grid), dim3(kBlock), 0,
+                     st, pl->num_rows, rowptr, colind, values, alpha, in, beta,
+                     out, dot, pl->ctx->dot_blocks);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+template <typename T, bool DOT>
+int run_general(const spmv_hip_csr_plan* pl, hipStream_t st,
+                const int32_t* rowptr, const int32_t* colind, const T* values,
+                T alpha, const T* in, T beta, T* out, double* dot)
+{
+  switch (pl->algo) {
+  case SPMV_HIP_ALGO_VECTOR:
+    return launch_vector<T, DOT>(pl, st, rowptr, colind, values, alpha, in,
+                                 beta, out, dot);
+  case SPMV_HIP_ALGO_SCALAR:
+    return launch_scalar<T, DOT>(pl, st, rowptr, colind, values, alpha, in,
+                                 beta, out, dot);
+  default:
+    return launch_rowblock<T, DOT>(pl, st, rowptr, colind, values, alpha, in,
+                                   beta, out, dot);
+  }
+}
+
+template <typename T>
+int run_symmetric(const spmv_hip_csr_plan* pl, hipStream_t st,
+                  const int32_t* rowptr, const int32_t* colind,
+                  const T* values, const T* diagonal, T alpha, const T* in,
+                  T beta, T* out)
+{
+  if (diagonal == nullptr)
+    return SPMV_HIP_EINVAL;
+  const int n = pl->num_rows;
+  if (pl->nnz == 0) {
+    const int grid = spmv_grid_for(pl->ctx, n, kBlock);
+    hipLaunchKernelGGL((diag_kernel<T>), dim3(grid), dim3(kBlock), 0, st,
+                       (int64_t)n, diagonal, alpha, in, beta, out);
+    SPMV_CHECK_LAUNCH();
+    return SPMV_HIP_OK;
+  }
+  // pre-pass: out *= beta (zero-fill when beta == 0)
+  if (beta != T(1)) {
+    if (beta == T(0)) {
+      SPMV_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(T) * (size_t)n, st));
+    } else {
+      const int grid = spmv_grid_for(pl->ctx, n, kBlock);
+      hipLaunchKernelGGL((scale_kernel<T>), dim3(grid), dim3(kBlock), 0, st,
+                         (int64_t)n, beta, out);
+      SPMV_CHECK_LAUNCH();
+    }
+  }
+  const int nrb = (n + kRows - 1) / kRows;
+  int grid = pl->ctx->num_cus * pl->blocks_per_cu;
+  if (grid > nrb)
+    grid = nrb;
+  const bool al = aligned16(values) && aligned16(colind);
+#define SPMV_SYM(CH, NT, AL)                                                   \
+  hipLaunchKernelGGL((csr_sym_rowblock_kernel<T, CH, NT, AL>), dim3(grid),     \
+                     dim3(kBlock), 0, st, n, pl->nnz, rowptr, colind, values,  \
+                     diagonal, alpha, in, out, nrb)
+  if (!al)
+    SPMV_SYM(1, false, false);
+  else if (pl->nontemporal)
+    SPMV_SYM(1, true, true);
+  else
+    SPMV_SYM(1, false, true);
+#undef SPMV_SYM
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
+                             int32_t num_cols, int64_t num_non_zeros,
+                             const int32_t* rowptr, const int32_t* colind,
+                             int symmetric, int algo, spmv_hip_csr_plan** plan)
+{
+  SPMV_REQUIRE(ctx && plan && num_rows >= 0 && num_cols >= 0
+               && num_non_zeros >= 0);
+  SPMV_REQUIRE(num_non_zeros == 0 || (rowptr && colind));
+  // rowptr is int32 in the reference format (csr_kernels.h:28)
+  if (num_non_zeros > INT32_MAX)
+    return SPMV_HIP_ERANGE;
+  spmv_hip_csr_plan* pl = new (std::nothrow) spmv_hip_csr_plan;
+  if (!pl)
+    return SPMV_HIP_ENOMEM;
+  pl->ctx = ctx;
+  pl->num_rows = num_rows;
+  pl->num_cols = num_cols;
+  pl->nnz = num_non_zeros;
+  pl->symmetric = symmetric != 0;
+  const double avg = num_rows > 0 ? (double)num_non_zeros / num_rows : 0.0;
+  if (algo == SPMV_HIP_ALGO_AUTO)
+    algo = (avg <= 64.0) ? SPMV_HIP_ALGO_ROWBLOCK : SPMV_HIP_ALGO_VECTOR;
+  SPMV_REQUIRE(algo >= SPMV_HIP_ALGO_ROWBLOCK && algo <= SPMV_HIP_ALGO_SCALAR);
+  pl->algo = algo;
+  int lpr = 4;
+  while (lpr < 64 && lpr < avg / 2)
+    lpr *= 2;
+  pl->lanes_per_row = lpr;
+  *plan = pl;
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_csr_plan_destroy(spmv_hip_csr_plan* plan)
+{
+  delete plan;
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_csr_plan_algo(const spmv_hip_csr_plan* plan, int* algo)
+{
+  SPMV_REQUIRE(plan && algo);
+  *algo = plan->algo;
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
+{
+  SPMV_REQUIRE(plan && key);
+  if (!strcmp(key, "algo")) {
+    SPMV_REQUIRE(value >= SPMV_HIP_ALGO_ROWBLOCK
+                 && value <= SPMV_HIP_ALGO_SCALAR);
+    plan->algo = value;
+  } else if (!strcmp(key, "lanes_per_row")) {
+    SPMV_REQUIRE(value == 4 || value == 8 || value == 16 || value == 32
+                 || value == 64);
+    plan->lanes_per_row = value;
+  } else if (!strcmp(key, "chunks")) {
+    SPMV_REQUIRE(value == 1 || value == 2 || value == 4);
+    plan->chunks = value;
+  } else if (!strcmp(key, "nontemporal")) {
+    plan->nontemporal = value != 0;
+  } else if (!strcmp(key, "xcd_remap")) {
+    plan->xcd_remap = value != 0;
+  } else if (!strcmp(key, "blocks_per_cu")) {
+    SPMV_REQUIRE(value >= 1 && value <= kBlocksPerCU);
+    plan->blocks_per_cu = value;
+  } else {
+    return SPMV_HIP_EINVAL;
+  }
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_csr_spmv_f64(spmv_hip_ctx* ctx, const spmv_hip_csr_plan* plan,
+                          int32_t num_rows, int32_t num_cols,
+                          int64_t num_non_zeros, const int32_t* rowptr,
+                          const int32_t* colind, const double* values,
+                          const double* diagonal, double alpha,
+                          const double* in, double beta, double* out,
+                          double* dot_partials, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(plan && plan->ctx == ctx);
+  // the operands must be the ones the plan (and the launch shape) was built
+  // for: a mismatch would index out of bounds on the device
+  SPMV_REQUIRE(num_rows == plan->num_rows && num_cols == plan->num_cols
+               && num_non_zeros == plan->nnz);
+  if (num_rows == 0)
+    return SPMV_HIP_OK;
+  SPMV_REQUIRE(in && out);
+  SPMV_REQUIRE(num_non_zeros == 0 || (rowptr && colind && values));
+  hipStream_t st = spmv_stream(ctx, stream);
+  if (plan->symmetric) {
+    SPMV_REQUIRE(dot_partials == nullptr);
+    return run_symmetric<double>(plan, st, rowptr, colind, values, diagonal,
+                                 alpha, in, beta, out);
+  }
+  if (num_non_zeros == 0) {
+    // empty general block: out = beta*out (csr_kernels.cpp:44-49 with an
+    // empty inner loop); CSRMatrix::mult skips the call entirely
+    // (csr_matrix.cpp:85), the executor keeps the arithmetic definition.
+    SPMV_REQUIRE(dot_partials == nullptr);
+    const int grid = spmv_grid_for(ctx, num_rows, kBlock);
+    hipLaunchKernelGGL((scale_kernel<double>), dim3(grid), dim3(kBlock), 0, st,
+                       (int64_t)num_rows, beta, out);
+    SPMV_CHECK_LAUNCH();
+    return SPMV_HIP_OK;
+  }
+  if (dot_partials)
+    return run_general<double, true>(plan, st, rowptr, colind, values, alpha,
+                                     in, beta, out, dot_partials);
+  return run_general<double, false>(plan, st, rowptr, colind, values, alpha, in,
+                                    beta, out, nullptr);
+}
+
+int spmv_hip_csr_spmv_f32(spmv_hip_ctx* ctx, const spmv_hip_csr_plan* plan,
+                          int32_t num_rows, int32_t num_cols,
+                          int64_t num_non_zeros, const int32_t* rowptr,
+                          const int32_t* colind, const float* values,
+                          const float* diagonal, float alpha, const float* in,
+                          float beta, float* out, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(plan && plan->ctx == ctx);
+  SPMV_REQUIRE(num_rows == plan->num_rows && num_cols == plan->num_cols
+               && num_non_zeros == plan->nnz);
+  if (num_rows == 0)
+    return SPMV_HIP_OK;
+  SPMV_REQUIRE(in && out);
+  SPMV_REQUIRE(num_non_zeros == 0 || (rowptr && colind && values));
+  hipStream_t st = spmv_stream(ctx, stream);
+  if (plan->symmetric)
+    return run_symmetric<float>(plan, st, rowptr, colind, values, diagonal,
+                                alpha, in, beta, out);
+  if (num_non_zeros == 0) {
+    const int grid = spmv_grid_for(ctx, num_rows, kBlock);
+    hipLaunchKernelGGL((scale_kernel<float>), dim3(grid), dim3(kBlock), 0, st,
+                       (int64_t)num_rows, beta, out);
+    SPMV_CHECK_LAUNCH();
+    return SPMV_HIP_OK;
+  }
+  return run_general<float, false>(plan, st, rowptr, colind, values, alpha, in,
+                                   beta, out, nullptr);
+}
+
+} // extern "C"

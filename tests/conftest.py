@@ -1,0 +1,32 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def _have_gpu():
+    import spmv_amd
+    from spmv_amd import hip
+    try:
+        return hip.device_count() > 0
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """One spmv_hip context on GPU 0 for the whole session.  GPU tests do not
+    skip when the device or the HIP library is missing: they fail."""
+    from spmv_amd import hip
+    c = hip.Context(0)
+    yield c
+    c.synchronize()
+    c.close()

@@ -1,0 +1,468 @@
+"""GPU parity tests of the HIP kernels, called through the C ABI
+(include/spmv_hip.h) and checked against the CPU oracle.
+
+Bars (BASELINE.json north_star "within a stated fp64
+tolerance"):
+  * general CSR, ROWBLOCK and SCALAR kernels: BIT-EXACT against
+    oracle.csr_spmv (= spmv/csr_kernels.cpp:41-51): same left-to-right order,
+    no FMA contraction.
+  * VECTOR kernel and the symmetric (atomic) kernel: element-wise
+    |y - y_ref|_i <= 16 u (|alpha||A||x| + |beta||y0|)_i, u = 2^-53.
+  * the reference's own check: ||y||_2 agrees with the KAT norm to 1 ulp
+    relative (tests/test_spmv.cpp:20-23,159-160) for the exact kernels and to
+    1e-14 relative for the others.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from spmv_amd import hip, poisson
+from util import U, abs_bound, lower_split, random_csr
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+EXACT_ALGOS = [hip.ALGO_ROWBLOCK, hip.ALGO_SCALAR]
+
+
+def run_spmv(ctx, rowptr, colind, values, x, nrows, ncols, alpha=1.0,
+             beta=0.0, y0=None, algo=hip.ALGO_AUTO, diagonal=None,
+             symmetric=False, knobs=None, dtype=np.float64):
+    blk = hip.CsrBlock(ctx, nrows, ncols, rowptr, colind, values, diagonal,
+                       symmetric, algo, dtype)
+    for k, v in (knobs or {}).items():
+        blk.set(k, v)
+    dx = ctx.upload(x, dtype)
+    # NaN-poisoned output when beta == 0: the kernel must not read it
+    init = np.full(nrows, np.nan, dtype) if y0 is None else y0
+    dy = ctx.upload(init, dtype)
+    blk.mult(alpha, dx.ptr, beta, dy.ptr)
+    y = dy.numpy()
+    for b in (dx, dy):
+        b.free()
+    blk.free()
+    return y
+
+
+# ---------------------------------------------------------------------------
+# KAT (tests/test_spmv.cpp:56-80)
+# ---------------------------------------------------------------------------
+def kat():
+    with open(os.path.join(GOLDEN, "kat.json")) as f:
+        k = json.load(f)
+    return (np.array(k["rowptr"], np.int32), np.array(k["colind"], np.int32),
+            np.array(k["values"], np.float64), np.array(k["x"]),
+            np.array(k["y"]), k["norm_y"])
+
+
+@pytest.mark.parametrize("algo", EXACT_ALGOS)
+def test_kat_general_exact(ctx, algo):
+    rp, ci, va, x, y_ref, norm_ref = kat()
+    y = run_spmv(ctx, rp, ci, va, x, 5, 5, algo=algo)
+    assert np.array_equal(y, y_ref)
+    norm = float(np.sqrt(np.sum(y * y)))
+    assert abs(norm - norm_ref) <= min(abs(norm), abs(norm_ref)) * np.finfo(float).eps
+
+
+def test_kat_vector_and_symmetric(ctx):
+    rp, ci, va, x, y_ref, norm_ref = kat()
+    bound = 16 * U * abs_bound(rp, ci, va, x)
+    y = run_spmv(ctx, rp, ci, va, x, 5, 5, algo=hip.ALGO_VECTOR)
+    assert np.all(np.abs(y - y_ref) <= bound)
+    lrp, lci, lva, dg = lower_split(rp, ci, va)
+    ys = run_spmv(ctx, lrp, lci, lva, x, 5, 5, diagonal=dg, symmetric=True)
+    assert np.all(np.abs(ys - y_ref) <= bound)
+    assert abs(np.linalg.norm(ys) - norm_ref) <= 1e-14 * norm_ref
+
+
+# ---------------------------------------------------------------------------
+# Poisson + random ragged matrices, general kernels
+# ---------------------------------------------------------------------------
+KNOBS = [dict(), dict(chunks=1), dict(chunks=4), dict(nontemporal=0),
+         dict(xcd_remap=1), dict(chunks=4, xcd_remap=1, blocks_per_cu=2)]
+
+
+@pytest.mark.parametrize("n", [4, 9, 16, 33])
+@pytest.mark.parametrize("knobs", KNOBS)
+def test_poisson_general_exact(ctx, n, knobs):
+    rp, ci, va = poisson.poisson3d_csr(n)
+    ci = ci.astype(np.int32)
+    N = n ** 3
+    x = oracle.gaussian_x_fast(N)
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    y = run_spmv(ctx, rp, ci, va, x, N, N, algo=hip.ALGO_ROWBLOCK, knobs=knobs)
+    assert np.array_equal(y, y_ref)
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("algo", EXACT_ALGOS + [hip.ALGO_VECTOR])
+def test_random_ragged(ctx, seed, algo):
+    rng = np.random.default_rng(0x5EED0001 + seed)
+    nrows = int(rng.integers(1, 3000))
+    ncols = int(rng.integers(1, 4000))
+    avg = [0.5, 3, 7, 20, 70, 300][seed]
+    rp, ci, va = random_csr(rng, nrows, ncols, avg, long_rows=seed % 3,
+                            long_len=5000)
+    x = rng.uniform(-1, 1, ncols)
+    y0 = rng.uniform(-1, 1, nrows)
+    for alpha, beta in [(1.0, 0.0), (-0.75, 0.0), (1.0, 1.0), (2.5, -0.5)]:
+        y_ref = oracle.csr_spmv(rp, ci, va, x, alpha, beta, y0)
+        y = run_spmv(ctx, rp, ci, va, x, nrows, ncols, alpha, beta,
+                     None if beta == 0 else y0, algo=algo)
+        if algo in EXACT_ALGOS:
+            assert np.array_equal(y, y_ref), (alpha, beta)
+        else:
+            # a different summation order: (len_i + 16) u per row
+            bound = (16 + np.diff(rp)) * U * abs_bound(rp, ci, va, x, alpha,
+                                                       beta, y0)
+            assert np.all(np.abs(y - y_ref) <= bound + 1e-300)
+
+
+@pytest.mark.parametrize("lpr", [4, 8, 16, 32, 64])
+def test_vector_lanes_per_row(ctx, lpr):
+    rng = np.random.default_rng(lpr)
+    rp, ci, va = random_csr(rng, 777, 555, 40)
+    x = rng.uniform(-1, 1, 555)
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    y = run_spmv(ctx, rp, ci, va, x, 777, 555, algo=hip.ALGO_VECTOR,
+                 knobs=dict(lanes_per_row=lpr))
+    bound = (16 + np.diff(rp)) * U * abs_bound(rp, ci, va, x)
+    assert np.all(np.abs(y - y_ref) <= bound + 1e-300)
+
+
+def test_empty_and_degenerate(ctx):
+    # all rows empty, nnz == 0, rowptr NULL (csr_matrix.cpp:34)
+    y0 = np.arange(7, dtype=np.float64)
+    y = run_spmv(ctx, None, None, None, np.ones(3), 7, 3, 2.0, 0.5, y0)
+    assert np.array_equal(y, 0.5 * y0)
+    y = run_spmv(ctx, None, None, None, np.ones(3), 7, 3, 2.0, 0.0)
+    assert np.array_equal(y, np.zeros(7))
+    # single entry, single row
+    y = run_spmv(ctx, [0, 1], [0], [3.0], np.array([2.0]), 1, 1)
+    assert np.array_equal(y, [6.0])
+    # nnz not a multiple of the vector width, rows straddling tile edges
+    rng = np.random.default_rng(7)
+    for nnz_row in (1, 3, 5):
+        nrows = 1031
+        rp = (np.arange(nrows + 1) * nnz_row).astype(np.int32)
+        ci = rng.integers(0, 50, nrows * nnz_row).astype(np.int32)
+        va = rng.uniform(-1, 1, nrows * nnz_row)
+        x = rng.uniform(-1, 1, 50)
+        assert np.array_equal(run_spmv(ctx, rp, ci, va, x, nrows, 50,
+                                       algo=hip.ALGO_ROWBLOCK),
+                              oracle.csr_spmv(rp, ci, va, x))
+
+
+def test_plan_mismatch_is_rejected(ctx):
+    rp, ci, va = poisson.poisson3d_csr(4)
+    blk = hip.CsrBlock(ctx, 64, 64, rp, ci.astype(np.int32), va)
+    dx, dy = ctx.zeros(64, np.float64), ctx.zeros(64, np.float64)
+    rc = hip._lib.hip.spmv_hip_csr_spmv_f64(
+        ctx.h, blk.plan, 63, 64, blk.nnz, blk.rowptr.ptr, blk.colind.ptr,
+        blk.values.ptr, None, 1.0, dx.ptr, 0.0, dy.ptr, None, None)
+    assert rc == -1  # SPMV_HIP_EINVAL, nothing launched
+    for b in (dx, dy):
+        b.free()
+    blk.free()
+
+
+def test_unaligned_views(ctx):
+    """colind/values that are not 16-byte aligned take the element-wise path
+    and stay exact."""
+    rng = np.random.default_rng(11)
+    rp, ci, va = random_csr(rng, 900, 900, 6)
+    x = rng.uniform(-1, 1, 900)
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    nnz = len(va)
+    dci = ctx.upload(np.concatenate([[0], ci]).astype(np.int32))
+    dva = ctx.upload(np.concatenate([[0.0], va]))
+    drp = ctx.upload(rp)
+    dx, dy = ctx.upload(x), ctx.zeros(900, np.float64)
+    plan = C.c_void_p()
+    hip.call("spmv_hip_csr_plan_create", ctx.h, 900, 900, nnz, drp.ptr,
+             dci.at(1), 0, hip.ALGO_ROWBLOCK, C.byref(plan))
+    hip.call("spmv_hip_csr_spmv_f64", ctx.h, plan, 900, 900, nnz, drp.ptr,
+             dci.at(1), dva.at(1), None, 1.0, dx.ptr, 0.0, dy.ptr, None, None)
+    assert np.array_equal(dy.numpy(), y_ref)
+    hip.call("spmv_hip_csr_plan_destroy", plan)
+    for b in (dci, dva, drp, dx, dy):
+        b.free()
+
+
+# ---------------------------------------------------------------------------
+# symmetric kernel
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [4, 9, 16, 33])
+def test_poisson_symmetric(ctx, n):
+    rp, ci, va = poisson.poisson3d_csr(n)
+    ci = ci.astype(np.int32)
+    N = n ** 3
+    x = oracle.gaussian_x_fast(N)
+    lrp, lci, lva, dg = lower_split(rp, ci, va)
+    y_ref = oracle.csr_spmv_sym(lrp, lci, lva, dg, x)
+    bound = 16 * U * abs_bound(rp, ci, va, x)
+    for alpha, beta in [(1.0, 0.0), (0.5, 2.0), (1.0, 1.0)]:
+        y0 = np.cos(np.arange(N))
+        y_ref = oracle.csr_spmv_sym(lrp, lci, lva, dg, x, alpha, beta, y0)
+        y = run_spmv(ctx, lrp, lci, lva, x, N, N, alpha, beta,
+                     None if beta == 0 else y0, diagonal=dg, symmetric=True)
+        b = 16 * U * abs_bound(rp, ci, va, x, alpha, beta, y0)
+        assert np.all(np.abs(y - y_ref) <= b)
+    # and against the general kernel on the full matrix
+    y_gen = oracle.csr_spmv(rp, ci, va, x)
+    y = run_spmv(ctx, lrp, lci, lva, x, N, N, diagonal=dg, symmetric=True)
+    assert np.all(np.abs(y - y_gen) <= bound)
+
+
+def test_symmetric_random_and_diag_only(ctx):
+    rng = np.random.default_rng(3)
+    n = 1500
+    rp, ci, va = random_csr(rng, n, n, 9, long_rows=2, long_len=1400)
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    keep = ci < rows
+    lrp = np.zeros(n + 1, np.int64)
+    np.add.at(lrp, rows[keep] + 1, 1)
+    lrp = np.cumsum(lrp).astype(np.int32)
+    lci, lva = ci[keep], va[keep]
+    dg = rng.uniform(1, 2, n)
+    x = rng.uniform(-1, 1, n)
+    y_ref = oracle.csr_spmv_sym(lrp, lci, lva, dg, x, 1.5, 0.0)
+    y = run_spmv(ctx, lrp, lci, lva, x, n, n, 1.5, 0.0, diagonal=dg,
+                 symmetric=True)
+    full = np.zeros(n)
+    np.add.at(full, rows[keep], np.abs(lva * x[lci]))
+    np.add.at(full, lci, np.abs(lva * x[rows[keep]]))
+    full += np.abs(dg * x)
+    terms = np.diff(lrp) + np.bincount(lci, minlength=n) + 1
+    assert np.all(np.abs(y - y_ref) <= (16 + terms) * U * 1.5 * full)
+    # diagonal-only symmetric block (nnz == 0, diagonal != NULL)
+    y = run_spmv(ctx, None, None, None, x, n, n, 2.0, 0.0, diagonal=dg,
+                 symmetric=True)
+    assert np.array_equal(y, 2.0 * (dg * x))
+
+
+# ---------------------------------------------------------------------------
+# fp32 instantiations (device_executor.h:88-99)
+# ---------------------------------------------------------------------------
+def test_fp32(ctx):
+    rng = np.random.default_rng(5)
+    rp, ci, va = random_csr(rng, 2000, 1800, 8, dtype=np.float32)
+    x = rng.uniform(-1, 1, 1800).astype(np.float32)
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    for algo in EXACT_ALGOS:
+        y = run_spmv(ctx, rp, ci, va, x, 2000, 1800, algo=algo,
+                     dtype=np.float32)
+        assert np.array_equal(y, y_ref)
+    y = run_spmv(ctx, rp, ci, va, x, 2000, 1800, algo=hip.ALGO_VECTOR,
+                 dtype=np.float32)
+    assert np.allclose(y, y_ref, rtol=0, atol=64 * 2.0 ** -24 * 8)
+    n = 16
+    rp, ci, va = poisson.poisson3d_csr(n, dtype=np.float32)
+    ci = ci.astype(np.int32)
+    lrp, lci, lva, dg = lower_split(rp, ci, va)
+    x = oracle.gaussian_x_fast(n ** 3).astype(np.float32)
+    y_ref = oracle.csr_spmv_sym(lrp, lci, lva, dg, x)
+    y = run_spmv(ctx, lrp, lci, lva, x, n ** 3, n ** 3, diagonal=dg,
+                 symmetric=True, dtype=np.float32)
+    assert np.allclose(y, y_ref, rtol=0, atol=16 * 2.0 ** -24 * 12)
+
+
+# ---------------------------------------------------------------------------
+# gather, dot, fills
+# ---------------------------------------------------------------------------
+def test_gather(ctx):
+    rng = np.random.default_rng(9)
+    x = rng.uniform(-1, 1, 10000)
+    for n in (0, 1, 255, 256, 257, 5000):
+        idx = rng.integers(0, 10000, n).astype(np.int32)
+        dx, di = ctx.upload(x), ctx.upload(idx)
+        do = ctx.empty(max(n, 1), np.float64)
+        ctx.gather(di, dx, do, n)
+        if n:
+            assert np.array_equal(do.numpy(n), oracle.gather_ghosts(idx, x))
+        for b in (dx, di, do):
+            b.free()
+
+
+def test_dot_and_fill(ctx):
+    rng = np.random.default_rng(13)
+    for n in (1, 2, 1001, 1 << 20):
+        x, y = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+        dx, dy = ctx.upload(x), ctx.upload(y)
+        d = ctx.dot(n, dx.ptr, dy.ptr)
+        ref = oracle.ddot(x, y)
+        assert abs(d - ref) <= 8 * U * n ** 0.5 * np.sum(np.abs(x * y)) + 1e-300
+        # deterministic: same bits on a second run
+        assert d == ctx.dot(n, dx.ptr, dy.ptr)
+        dx.free(), dy.free()
+    N = 4096
+    g = ctx.empty(N, np.float64)
+    ctx.fill_gaussian(N, 0, N, g.ptr)
+    ref = oracle.gaussian_x_fast(N)
+    assert np.allclose(g.numpy(), ref, rtol=4 * 2.0 ** -52, atol=1e-300)
+    ctx.fill_const(N, 1.25, g.ptr)
+    assert np.array_equal(g.numpy(), np.full(N, 1.25))
+    g.free()
+
+
+# ---------------------------------------------------------------------------
+# device Poisson generator vs the host generator
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("n,P", [(4, 1), (6, 1), (8, 2), (8, 4), (9, 3), (16, 8)])
+def test_device_poisson_matches_host(ctx, n, P):
+    N = n ** 3
+    ranges = poisson.owner_ranges(P, N)
+    for r in range(P):
+        r0, r1 = int(ranges[r]), int(ranges[r + 1])
+        lrp, lci, lva, ghosts = oracle.localise_rows(
+            *poisson.poisson3d_csr(n), r0, r1)
+        nloc = r1 - r0
+        rows = np.repeat(np.arange(nloc), np.diff(lrp))
+        sel = {hip.PART_ALL: np.ones(len(lci), bool),
+               hip.PART_LOCAL: lci < nloc,
+               hip.PART_REMOTE: lci >= nloc,
+               hip.PART_LOCAL_LOWER: (lci < nloc) & (lci < rows)}
+        for part, m in sel.items():
+            blk = hip.poisson3d_block(ctx, n, r0, r1, part,
+                                      with_diagonal=(part == hip.PART_LOCAL_LOWER))
+            assert blk.ghosts_below + blk.ghosts_above == len(ghosts)
+            exp_rp = np.zeros(nloc + 1, np.int64)
+            np.add.at(exp_rp, rows[m] + 1, 1)
+            exp_rp = np.cumsum(exp_rp)
+            assert blk.nnz == int(m.sum())
+            if blk.nnz:  # an empty block owns no arrays (csr_matrix.cpp:34)
+                assert np.array_equal(blk.rowptr.numpy(), exp_rp)
+                assert np.array_equal(blk.colind.numpy(), lci[m])
+                assert np.array_equal(blk.values.numpy(), lva[m])
+            if blk.diagonal is not None:
+                assert np.array_equal(blk.diagonal.numpy(), np.full(nloc, 6.0))
+            blk.free()
+
+
+# ---------------------------------------------------------------------------
+# CG building blocks: drive the kernels exactly as spmv::cg does and compare
+# with the oracle's CG (cg.cpp:21-98)
+# ---------------------------------------------------------------------------
+def gpu_cg(ctx, blk, b, kmax, rtol, fused_dot=True):
+    n = blk.nrows
+    ws = C.c_void_p()
+    hip.call("spmv_hip_cg_ws_create", ctx.h, kmax, C.byref(ws))
+    hip.call("spmv_hip_cg_ws_reset", ws, rtol, None)
+    part = C.c_void_p()
+    hip.call("spmv_hip_cg_ws_partials", ws, C.byref(part))
+    r, p = ctx.upload(b), ctx.upload(b)
+    x, Ap = ctx.zeros(n, np.float64), ctx.zeros(n, np.float64)
+    hip.call("spmv_hip_cg_dot_rr_f64", ctx.h, ws, n, r.ptr, None)
+    hip.call("spmv_hip_cg_reduce_rr", ctx.h, ws, 0, None)
+    for k in range(1, kmax + 1):
+        if fused_dot and not blk.symmetric:
+            blk.mult(1.0, p.ptr, 0.0, Ap.ptr, dot_partials=part)
+        else:
+            blk.mult(1.0, p.ptr, 0.0, Ap.ptr)
+            hip.call("spmv_hip_dot_partial_f64", ctx.h, n, p.ptr, Ap.ptr, part,
+                     None)
+        hip.call("spmv_hip_cg_reduce_pAp", ctx.h, ws, k, None)
+        hip.call("spmv_hip_cg_update_xr_f64", ctx.h, ws, k, n, p.ptr, Ap.ptr,
+                 x.ptr, r.ptr, None)
+        hip.call("spmv_hip_cg_reduce_rr", ctx.h, ws, k, None)
+        hip.call("spmv_hip_cg_update_p_f64", ctx.h, ws, k, n, r.ptr, p.ptr,
+                 None)
+    flags = np.zeros(2, np.int32)
+    rr = np.zeros(kmax + 1)
+    hip.call("spmv_hip_cg_ws_read_async", ws, flags.ctypes.data_as(C.c_void_p),
+             rr.ctypes.data_as(C.c_void_p), None)
+    ctx.stream_sync()
+    xs = x.numpy()
+    hip.call("spmv_hip_cg_ws_destroy", ws)
+    for buf in (r, p, x, Ap):
+        buf.free()
+    return xs, flags, np.sqrt(rr)
+
+
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_cg_kernels_match_oracle(ctx, symmetric):
+    n = 12
+    N = n ** 3
+    rp, ci, va = poisson.poisson3d_csr(n)
+    ci = ci.astype(np.int32)
+    b = oracle.csr_spmv(rp, ci, va, np.ones(N))  # exact solution = ones
+    if symmetric:
+        lrp, lci, lva, dg = lower_split(rp, ci, va)
+        blk = hip.CsrBlock(ctx, N, N, lrp, lci, lva, dg, True)
+        x_ref, k_ref, hist_ref = oracle.cg(lrp, lci, lva, b, 200, 1e-10, dg)
+    else:
+        blk = hip.CsrBlock(ctx, N, N, rp, ci, va)
+        x_ref, k_ref, hist_ref = oracle.cg(rp, ci, va, b, 200, 1e-10)
+    assert k_ref < 200
+    x, flags, hist = gpu_cg(ctx, blk, b, 200, 1e-10)
+    # the host enqueued all 200 iterations; the device stopped itself
+    assert flags[0] == 1 and abs(int(flags[1]) - k_ref) <= 1
+    k = int(flags[1])
+    m = min(k, k_ref, 50)
+    assert np.allclose(hist[:m + 1], hist_ref[:m + 1], rtol=1e-6, atol=0)
+    assert hist[k] / hist[0] < 1e-10
+    assert np.linalg.norm(x - x_ref) <= 1e-8 * np.linalg.norm(x_ref)
+    assert np.linalg.norm(x - 1.0) <= 1e-8 * np.sqrt(N)
+    blk.free()
+
+
+def test_cg_kmax_reached_and_unfused_dot(ctx):
+    n = 10
+    N = n ** 3
+    rp, ci, va = poisson.poisson3d_csr(n)
+    ci = ci.astype(np.int32)
+    b = oracle.gaussian_x_fast(N)
+    blk = hip.CsrBlock(ctx, N, N, rp, ci, va)
+    x_ref, k_ref, hist_ref = oracle.cg(rp, ci, va, b, 7, 1e-30)
+    assert k_ref == 7
+    for fused in (True, False):
+        x, flags, hist = gpu_cg(ctx, blk, b, 7, 1e-30, fused_dot=fused)
+        assert flags[0] == 0  # never converged: host returns kmax
+        assert np.allclose(hist, hist_ref, rtol=1e-10, atol=0)
+        assert np.linalg.norm(x - x_ref) <= 1e-12 * np.linalg.norm(x_ref)
+    blk.free()
+
+
+# ---------------------------------------------------------------------------
+# size-independent properties at benchmark scale (no oracle run needed)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [128])
+def test_full_size_properties(ctx, n):
+    """A * ones is an exact small integer per row (6 - #neighbours), so both
+    the general and the atomic symmetric kernel must reproduce it bit for
+    bit at full size; linearity A(2x) == 2 A x is exact as well."""
+    N = n ** 3
+    blk = hip.poisson3d_block(ctx, n, 0, N, hip.PART_ALL)
+    assert blk.nnz == poisson.poisson3d_nnz(n)
+    x, y = ctx.empty(N, np.float64), ctx.empty(N, np.float64)
+    ctx.fill_const(N, 1.0, x.ptr)
+    blk.mult(1.0, x.ptr, 0.0, y.ptr)
+    i = np.arange(N)
+    xx, yy, zz = i % n, (i // n) % n, i // (n * n)
+    nb = ((xx > 0).astype(int) + (xx < n - 1) + (yy > 0) + (yy < n - 1)
+          + (zz > 0) + (zz < n - 1))
+    expect = (6 - nb).astype(np.float64)
+    assert np.array_equal(y.numpy(), expect)
+    sym = hip.poisson3d_block(ctx, n, 0, N, hip.PART_LOCAL_LOWER,
+                              with_diagonal=True)
+    assert sym.nnz == (poisson.poisson3d_nnz(n) - N) // 2
+    sym.mult(1.0, x.ptr, 0.0, y.ptr)
+    assert np.array_equal(y.numpy(), expect)
+    # linearity + general == symmetric within the stated tolerance
+    ctx.fill_gaussian(N, 0, N, x.ptr)
+    blk.mult(1.0, x.ptr, 0.0, y.ptr)
+    y1 = y.numpy()
+    blk.mult(2.0, x.ptr, 0.0, y.ptr)
+    assert np.array_equal(y.numpy(), 2.0 * y1)
+    sym.mult(1.0, x.ptr, 0.0, y.ptr)
+    xh = x.numpy()
+    assert np.all(np.abs(y.numpy() - y1) <= 16 * U * 12 * np.abs(xh).max())
+    # checksum: sum(A x) == sum over boundary-weighted x (A symmetric)
+    assert abs(y1.sum() - float(expect @ xh)) <= 1e-9 * np.abs(xh).sum()
+    for b in (x, y):
+        b.free()
+    blk.free(), sym.free()

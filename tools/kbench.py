@@ -1,0 +1,157 @@
+"""Kernel sweep on one GPU: times SpMV variants on the device-generated
+Poisson matrix, all variants interleaved in ONE process (guide rule 24).
+
+    python tools/kbench.py --n 216 512 --reps 20 --out gpurun_out/kbench.json
+
+Algorithmic bytes follow SURVEY section 8d.  Prints one JSON line per variant.
+"""
+import argparse
+import ctypes as C
+import itertools
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from spmv_amd import hip, poisson  # noqa: E402
+
+HBM_PEAK = 8000.0  # GB/s, MI355X spec
+
+
+def time_ms(ctx, fn, reps, rounds=3):
+    e0, e1 = ctx.event_create(), ctx.event_create()
+    fn()
+    ctx.synchronize()
+    best = []
+    for _ in range(rounds):
+        ctx.event_record(e0)
+        for _ in range(reps):
+            fn()
+        ctx.event_record(e1)
+        ctx.event_sync(e1)
+        best.append(ctx.elapsed_ms(e0, e1) / reps)
+    ctx.event_destroy(e0), ctx.event_destroy(e1)
+    return min(best), float(np.median(best))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, nargs="+", default=[128, 216])
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--quick", action="store_true")
+    args = ap.parse_args()
+    ctx = hip.Context(0)
+    results = []
+
+    def emit(**kw):
+        results.append(kw)
+        print(json.dumps(kw), flush=True)
+
+    for n in args.n:
+        N = n ** 3
+        blk = hip.poisson3d_block(ctx, n, 0, N, hip.PART_ALL)
+        x, y = ctx.empty(N, np.float64), ctx.empty(N, np.float64)
+        ctx.fill_gaussian(N, 0, N, x.ptr)
+        part = ctx.empty(ctx.dot_partials_len, np.float64)
+        bytes_csr = poisson.csr_bytes(N, N, blk.nnz)
+        reps = max(3, args.reps if n < 400 else args.reps // 4)
+
+        # known-good ceiling on this device: d2d copy of the same byte count
+        nb = min(bytes_csr // 2, 4 << 30) // 8 * 8
+        src, dst = ctx.empty(nb // 8, np.float64), ctx.empty(nb // 8, np.float64)
+        tmin, tmed = time_ms(ctx, lambda: ctx.copy(dst.ptr, src.ptr, nb), reps)
+        emit(n=n, variant="memcpy_d2d", ms=tmin, ms_med=tmed,
+             gbs=2 * nb / tmin / 1e6, frac=2 * nb / tmin / 1e6 / HBM_PEAK)
+        src.free(), dst.free()
+
+        variants = []
+        chunks = [2, 4] if args.quick else [1, 2, 4]
+        for ch, nt, xcd, bpc in itertools.product(chunks, [1, 0], [0, 1], [8, 4]):
+            if args.quick and (bpc == 4 or (nt == 0 and xcd == 1)):
+                continue
+            variants.append(("rowblock", dict(algo=hip.ALGO_ROWBLOCK, chunks=ch,
+                                              nontemporal=nt, xcd_remap=xcd,
+                                              blocks_per_cu=bpc)))
+        variants.append(("scalar", dict(algo=hip.ALGO_SCALAR)))
+        for lpr in (4, 8):
+            variants.append(("vector", dict(algo=hip.ALGO_VECTOR,
+                                            lanes_per_row=lpr)))
+        for name, kn in variants:
+            for k, v in kn.items():
+                blk.set(k, v)
+            tmin, tmed = time_ms(
+                ctx, lambda: blk.mult(1.0, x.ptr, 0.0, y.ptr), reps)
+            emit(n=n, variant=name, knobs=kn, ms=tmin, ms_med=tmed,
+                 gbs=bytes_csr / tmin / 1e6,
+                 frac=bytes_csr / tmin / 1e6 / HBM_PEAK)
+        # fused dot on the default variant
+        for k, v in dict(algo=hip.ALGO_ROWBLOCK, chunks=2, nontemporal=1,
+                         xcd_remap=0, blocks_per_cu=8).items():
+            blk.set(k, v)
+        tmin, tmed = time_ms(
+            ctx, lambda: blk.mult(1.0, x.ptr, 0.0, y.ptr, dot_partials=part.ptr),
+            reps)
+        emit(n=n, variant="rowblock+dot", ms=tmin, ms_med=tmed,
+             gbs=bytes_csr / tmin / 1e6, frac=bytes_csr / tmin / 1e6 / HBM_PEAK)
+        blk.free()
+
+        # symmetric
+        sym = hip.poisson3d_block(ctx, n, 0, N, hip.PART_LOCAL_LOWER,
+                                  with_diagonal=True)
+        bytes_sym = poisson.sym_csr_bytes(N, sym.nnz)
+        for nt in (1, 0):
+            sym.set("nontemporal", nt)
+            tmin, tmed = time_ms(
+                ctx, lambda: sym.mult(1.0, x.ptr, 0.0, y.ptr), reps)
+            emit(n=n, variant="symmetric", knobs=dict(nontemporal=nt), ms=tmin,
+                 ms_med=tmed, gbs=bytes_sym / tmin / 1e6,
+                 frac=bytes_sym / tmin / 1e6 / HBM_PEAK,
+                 gbs_equiv_general=bytes_csr / tmin / 1e6)
+        sym.free()
+
+        # CG vector kernels at this size
+        ws = C.c_void_p()
+        hip.call("spmv_hip_cg_ws_create", ctx.h, 4, C.byref(ws))
+        hip.call("spmv_hip_cg_ws_reset", ws, 0.0, None)
+        r, p = ctx.empty(N, np.float64), ctx.empty(N, np.float64)
+        ctx.fill_const(N, 1.0, r.ptr), ctx.fill_const(N, 1.0, p.ptr)
+        ctx.fill_const(N, 1.0, y.ptr)
+        hip.call("spmv_hip_cg_dot_rr_f64", ctx.h, ws, N, r.ptr, None)
+        hip.call("spmv_hip_cg_reduce_rr", ctx.h, ws, 0, None)
+        hip.call("spmv_hip_dot_partial_f64", ctx.h, N, p.ptr, y.ptr, part.ptr,
+                 None)
+        pslot = C.c_void_p()
+        hip.call("spmv_hip_cg_ws_pAp", ws, 1, C.byref(pslot))
+        hip.call("spmv_hip_reduce_partials_f64", ctx.h, part.ptr, pslot, None)
+        rslot = C.c_void_p()
+        hip.call("spmv_hip_cg_ws_rr", ws, 1, C.byref(rslot))
+        ctx.copy(rslot, pslot, 8)
+        tmin, tmed = time_ms(ctx, lambda: hip.call(
+            "spmv_hip_cg_update_xr_f64", ctx.h, ws, 1, N, p.ptr, y.ptr, x.ptr,
+            r.ptr, None), reps)
+        emit(n=n, variant="cg_update_xr", ms=tmin, ms_med=tmed,
+             gbs=6 * N * 8 / tmin / 1e6, frac=6 * N * 8 / tmin / 1e6 / HBM_PEAK)
+        ctx.copy(rslot, pslot, 8)
+        tmin, tmed = time_ms(ctx, lambda: hip.call(
+            "spmv_hip_cg_update_p_f64", ctx.h, ws, 1, N, r.ptr, p.ptr, None),
+            reps)
+        emit(n=n, variant="cg_update_p", ms=tmin, ms_med=tmed,
+             gbs=3 * N * 8 / tmin / 1e6, frac=3 * N * 8 / tmin / 1e6 / HBM_PEAK)
+        tmin, tmed = time_ms(ctx, lambda: hip.call(
+            "spmv_hip_cg_reduce_rr", ctx.h, ws, 2, None), reps)
+        emit(n=n, variant="cg_reduce", ms=tmin, ms_med=tmed)
+        hip.call("spmv_hip_cg_ws_destroy", ws)
+        for b in (x, y, part, r, p):
+            b.free()
+    if args.out:
+        os.makedirs(os.path.dirname(args.out), exist_ok=True)
+        with open(args.out, "w") as f:
+            json.dump(results, f, indent=1)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
