@@ -113,15 +113,19 @@ int spmv_hip_copy_peer_async(spmv_hip_ctx* dst_ctx, void* dst,
  *     beta == 0) inside run, then every term is accumulated with hardware
  *     fp64 atomics; the order of additions is not deterministic.
  *   - `dot_partials` (optional, general kernel only, may be NULL): fuses
- *     the CG dot product sum_i in[i]*out[i] over the rows of this block;
- *     the kernel writes spmv_hip_dot_partials_len() doubles, to be reduced
- *     by spmv_hip_reduce_partials_f64.
+ *     the CG dot product.  The kernel writes spmv_hip_dot_partials_len()
+ *     doubles whose sum is sum_i in[i] * (alpha * (A in)_i), this block's own
+ *     share (beta*out is not included, so the shares of a local and a remote
+ *     block add up to in . (A in)); reduce with spmv_hip_reduce_partials_f64.
  */
 enum {
   SPMV_HIP_ALGO_AUTO = 0,
   SPMV_HIP_ALGO_ROWBLOCK = 1, /* row blocks streamed through LDS, exact order */
   SPMV_HIP_ALGO_VECTOR = 2,   /* sub-wavefront per row, shuffle reduction     */
-  SPMV_HIP_ALGO_SCALAR = 3    /* one lane per row (short rows, reference)     */
+  SPMV_HIP_ALGO_SCALAR = 3,   /* one lane per row (short rows, reference)     */
+  SPMV_HIP_ALGO_ROWLIST = 4   /* mostly-empty block: walk the compacted list of
+                                 non-empty rows (built by plan_create), exact
+                                 order; general kernel only                    */
 };
 
 int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
@@ -206,6 +210,10 @@ int spmv_hip_cg_reduce_rr(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
                           void* stream);
 int spmv_hip_cg_reduce_pAp(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
                            void* stream);
+/* same, adding a second partial array (the remote block's share of p.Ap,
+ * spmv_hip_dot_partials_len() doubles) */
+int spmv_hip_cg_reduce_pAp2(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
+                            const double* partials2, void* stream);
 /* r.r partials for k = 0 (cg.cpp:47) */
 int spmv_hip_cg_dot_rr_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int64_t n,
                            const double* r, void* stream);
@@ -248,6 +256,7 @@ int spmv_hip_comm_unique_id(void* host_id_bytes);
 int spmv_hip_comm_create(spmv_hip_ctx* ctx, int nranks, int rank,
                          const void* host_id_bytes, spmv_hip_comm** comm);
 int spmv_hip_comm_destroy(spmv_hip_comm* comm);
+int spmv_hip_comm_rank(const spmv_hip_comm* comm, int* rank, int* nranks);
 /* one grouped exchange: for every neighbour i, send send_counts[i] doubles
  * from send_buf + send_offsets[i] and receive recv_counts[i] doubles into
  * recv_base + recv_offsets[i] (offsets in elements). */
@@ -257,6 +266,15 @@ int spmv_hip_comm_neighbor_exchange_f64(spmv_hip_comm* comm, int num_neighbours,
                                         const int32_t* host_send_counts,
                                         const int32_t* host_send_offsets,
                                         double* recv_base,
+                                        const int32_t* host_recv_counts,
+                                        const int32_t* host_recv_offsets,
+                                        void* stream);
+int spmv_hip_comm_neighbor_exchange_f32(spmv_hip_comm* comm, int num_neighbours,
+                                        const int32_t* host_neighbours,
+                                        const float* send_buf,
+                                        const int32_t* host_send_counts,
+                                        const int32_t* host_send_offsets,
+                                        float* recv_base,
                                         const int32_t* host_recv_counts,
                                         const int32_t* host_recv_offsets,
                                         void* stream);

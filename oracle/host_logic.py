@@ -58,8 +58,11 @@ def poisson3d_csr(n):
     import scipy.sparse as sp
     T = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(n, n), format="csr")
     I = sp.identity(n, format="csr")
-    A = (sp.kron(sp.kron(I, I), T) + sp.kron(sp.kron(I, T), I)
-         + sp.kron(sp.kron(T, I), I)).tocsr()
+    A = (sp.kron(sp.kron(I, I), T, format="csr")
+         + sp.kron(sp.kron(I, T), I, format="csr")
+         + sp.kron(sp.kron(T, I), I, format="csr")).tocsr()
+    A.sum_duplicates()
+    A.eliminate_zeros()
     A.sort_indices()
     return (A.indptr.astype(np.int32), A.indices.astype(np.int32),
             A.data.astype(np.float64))

@@ -95,6 +95,7 @@ _PROTOS = {
     "spmv_hip_cg_update_p_f64": ([vp, vp, C.c_int, i64, vp, vp, vp], C.c_int),
     "spmv_hip_cg_reduce_rr": ([vp, vp, C.c_int, vp], C.c_int),
     "spmv_hip_cg_reduce_pAp": ([vp, vp, C.c_int, vp], C.c_int),
+    "spmv_hip_cg_reduce_pAp2": ([vp, vp, C.c_int, vp, vp], C.c_int),
     "spmv_hip_cg_dot_rr_f64": ([vp, vp, i64, vp, vp], C.c_int),
     "spmv_hip_poisson3d_count": ([vp, i32, i64, i64, C.c_int, vp, P(i64), vp],
                                  C.c_int),
@@ -108,6 +109,9 @@ _PROTOS = {
     "spmv_hip_comm_destroy": ([vp], C.c_int),
     "spmv_hip_comm_neighbor_exchange_f64": ([vp, C.c_int, vp, vp, vp, vp, vp,
                                              vp, vp, vp], C.c_int),
+    "spmv_hip_comm_neighbor_exchange_f32": ([vp, C.c_int, vp, vp, vp, vp, vp,
+                                             vp, vp, vp], C.c_int),
+    "spmv_hip_comm_rank": ([vp, P(C.c_int), P(C.c_int)], C.c_int),
     "spmv_hip_comm_allreduce_sum_f64": ([vp, vp, sz, vp], C.c_int),
     "spmv_hip_comm_allgather_host": ([vp, vp, vp, sz], C.c_int),
 }

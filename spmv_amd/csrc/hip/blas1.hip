@@ -188,7 +188,8 @@ __global__ __launch_bounds__(kBlock) void cg_update_p_kernel(
 // returns at once and x, r, p keep their iteration-(k-1) values.  In-order
 // stream execution makes the flag visible to the following launches.
 __global__ __launch_bounds__(kBlock) void cg_reduce_pAp_kernel(
-    const double* __restrict__ partials, int len, int k,
+    const double* __restrict__ partials, const double* __restrict__ partials2,
+    int len, int k,
     const double* __restrict__ rr, double* __restrict__ pAp,
     CgScalars* __restrict__ sc)
 {
@@ -209,6 +210,9 @@ __global__ __launch_bounds__(kBlock) void cg_reduce_pAp_kernel(
   double acc = 0.0;
   for (int i = threadIdx.x; i < len; i += kBlock)
     acc += partials[i];
+  if (partials2) // the remote block's share of p.Ap
+    for (int i = threadIdx.x; i < len; i += kBlock)
+      acc += partials2[i];
   double s = block_sum(acc, s_red);
   if (threadIdx.x == 0)
     pAp[k] = s;
@@ -451,8 +455,21 @@ int spmv_hip_cg_reduce_pAp(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
   SPMV_SET_DEVICE(ctx);
   SPMV_REQUIRE(ws && ws->ctx == ctx && k >= 1 && k <= ws->kmax);
   hipLaunchKernelGGL(cg_reduce_pAp_kernel, dim3(1), dim3(kBlock), 0,
-                     spmv_stream(ctx, stream), ws->partials, ctx->dot_blocks,
-                     k, ws->rr, ws->pAp, ws->sc);
+                     spmv_stream(ctx, stream), ws->partials,
+                     (const double*)nullptr, ctx->dot_blocks, k, ws->rr,
+                     ws->pAp, ws->sc);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_cg_reduce_pAp2(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
+                            const double* partials2, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(ws && ws->ctx == ctx && k >= 1 && k <= ws->kmax && partials2);
+  hipLaunchKernelGGL(cg_reduce_pAp_kernel, dim3(1), dim3(kBlock), 0,
+                     spmv_stream(ctx, stream), ws->partials, partials2,
+                     ctx->dot_blocks, k, ws->rr, ws->pAp, ws->sc);
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;
 }

@@ -37,6 +37,16 @@ struct spmv_hip_comm {
 
 extern "C" {
 
+int spmv_hip_comm_rank(const spmv_hip_comm* comm, int* rank, int* nranks)
+{
+  SPMV_REQUIRE(comm);
+  if (rank)
+    *rank = comm->rank;
+  if (nranks)
+    *nranks = comm->nranks;
+  return SPMV_HIP_OK;
+}
+
 int spmv_hip_comm_unique_id(void* host_id_bytes)
 {
   SPMV_REQUIRE(host_id_bytes);
@@ -81,12 +91,12 @@ int spmv_hip_comm_destroy(spmv_hip_comm* comm)
   return SPMV_HIP_OK;
 }
 
-int spmv_hip_comm_neighbor_exchange_f64(
-    spmv_hip_comm* comm, int num_neighbours, const int32_t* host_neighbours,
-    const double* send_buf, const int32_t* host_send_counts,
-    const int32_t* host_send_offsets, double* recv_base,
-    const int32_t* host_recv_counts, const int32_t* host_recv_offsets,
-    void* stream)
+static int neighbor_exchange(spmv_hip_comm* comm, size_t elem, int num_neighbours,
+                             const int32_t* host_neighbours, const char* send_buf,
+                             const int32_t* host_send_counts,
+                             const int32_t* host_send_offsets, char* recv_base,
+                             const int32_t* host_recv_counts,
+                             const int32_t* host_recv_offsets, void* stream)
 {
   SPMV_REQUIRE(comm && num_neighbours >= 0);
   if (num_neighbours == 0)
@@ -106,17 +116,46 @@ int spmv_hip_comm_neighbor_exchange_f64(
   ncclResult_t r = ncclSuccess;
   for (int i = 0; i < num_neighbours && r == ncclSuccess; ++i) {
     if (host_recv_counts[i] > 0) // L2GMap.cpp:624-628
-      r = ncclRecv(recv_base + host_recv_offsets[i], host_recv_counts[i],
-                   ncclDouble, host_neighbours[i], comm->comm, st);
+      r = ncclRecv(recv_base + (size_t)host_recv_offsets[i] * elem,
+                   (size_t)host_recv_counts[i] * elem, ncclChar,
+                   host_neighbours[i], comm->comm, st);
     if (r == ncclSuccess && host_send_counts[i] > 0) // L2GMap.cpp:630-634
-      r = ncclSend(send_buf + host_send_offsets[i], host_send_counts[i],
-                   ncclDouble, host_neighbours[i], comm->comm, st);
+      r = ncclSend(send_buf + (size_t)host_send_offsets[i] * elem,
+                   (size_t)host_send_counts[i] * elem, ncclChar,
+                   host_neighbours[i], comm->comm, st);
   }
   ncclResult_t r2 = ncclGroupEnd();
   if (r != ncclSuccess)
     return 10000 + static_cast<int>(r);
   SPMV_CHECK_NCCL(r2);
   return SPMV_HIP_OK;
+}
+
+int spmv_hip_comm_neighbor_exchange_f64(
+    spmv_hip_comm* comm, int num_neighbours, const int32_t* host_neighbours,
+    const double* send_buf, const int32_t* host_send_counts,
+    const int32_t* host_send_offsets, double* recv_base,
+    const int32_t* host_recv_counts, const int32_t* host_recv_offsets,
+    void* stream)
+{
+  return neighbor_exchange(comm, sizeof(double), num_neighbours,
+                           host_neighbours, (const char*)send_buf,
+                           host_send_counts, host_send_offsets,
+                           (char*)recv_base, host_recv_counts,
+                           host_recv_offsets, stream);
+}
+
+int spmv_hip_comm_neighbor_exchange_f32(
+    spmv_hip_comm* comm, int num_neighbours, const int32_t* host_neighbours,
+    const float* send_buf, const int32_t* host_send_counts,
+    const int32_t* host_send_offsets, float* recv_base,
+    const int32_t* host_recv_counts, const int32_t* host_recv_offsets,
+    void* stream)
+{
+  return neighbor_exchange(comm, sizeof(float), num_neighbours, host_neighbours,
+                           (const char*)send_buf, host_send_counts,
+                           host_send_offsets, (char*)recv_base,
+                           host_recv_counts, host_recv_offsets, stream);
 }
 
 int spmv_hip_comm_allreduce_sum_f64(spmv_hip_comm* comm, double* inout,

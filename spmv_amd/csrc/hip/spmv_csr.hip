@@ -32,6 +32,7 @@
 #include "common.h"
 
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+#include <hipcub/hipcub.hpp>
 
 #include <cstring>
 #include <new>
@@ -228,12 +229,13 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_kernel(
 
     if (t < nr) {
       const int32_t r = r0 + t;
-      T y = alpha * sum;
+      const T c = alpha * sum;
+      T y = c;
       if (beta != T(0))
-        y = y + beta * out[r];
+        y = c + beta * out[r];
       out[r] = y;
-      if constexpr (DOT)
-        dot_acc += (double)in[r] * (double)y;
+      if constexpr (DOT) // this block's own share: in . (alpha A in)
+        dot_acc += (double)in[r] * (double)c;
     }
   }
 
@@ -262,12 +264,13 @@ __global__ __launch_bounds__(kBlock) void csr_scalar_kernel(
     T sum = 0;
     for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j)
       sum += values[j] * in[colind[j]];
-    T y = alpha * sum;
+    const T c = alpha * sum;
+    T y = c;
     if (beta != T(0))
-      y = y + beta * out[i];
+      y = c + beta * out[i];
     out[i] = y;
     if constexpr (DOT)
-      dot_acc += (double)in[i] * (double)y;
+      dot_acc += (double)in[i] * (double)c;
   }
   if constexpr (DOT) {
     double s = block_sum(dot_acc, s_red);
@@ -276,6 +279,49 @@ __global__ __launch_bounds__(kBlock) void csr_scalar_kernel(
     clear_partials_tail(dot_partials, dot_len);
   }
 }
+
+// ---------------------------------------------------------------------------
+// ROWLIST kernel: for blocks whose rows are mostly empty (the "remote" block
+// of a row-partitioned matrix, Matrix.cpp:354-355: only boundary rows touch
+// ghost columns).  The plan holds the compacted list of non-empty rows; one
+// lane per listed row, reference order.  `out` has already been scaled by
+// beta for ALL rows (a no-op for the beta == 1 the reference uses here,
+// Matrix.cpp:508,529,551), so out[r] = alpha*sum + out[r] rounds exactly like
+// alpha*sum + beta*out[r].  With DOT the kernel emits the partials of
+// sum_r in[r] * (alpha*sum_r): the block's own share of p.Ap.
+// ---------------------------------------------------------------------------
+template <typename T, bool DOT>
+__global__ __launch_bounds__(kBlock) void csr_rowlist_kernel(
+    int32_t num_listed, const int32_t* __restrict__ rows,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
+    const T* __restrict__ values, T alpha, const T* __restrict__ in,
+    T* __restrict__ out, double* __restrict__ dot_partials, int dot_len)
+{
+  __shared__ double s_red[kBlock / 64];
+  double dot_acc = 0.0;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+       k < num_listed; k += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t i = rows[k];
+    T sum = 0;
+    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j)
+      sum += values[j] * in[colind[j]];
+    const T c = alpha * sum;
+    out[i] = c + out[i];
+    if constexpr (DOT)
+      dot_acc += (double)in[i] * (double)c;
+  }
+  if constexpr (DOT) {
+    double s = block_sum(dot_acc, s_red);
+    if (threadIdx.x == 0)
+      dot_partials[blockIdx.x] = s;
+    clear_partials_tail(dot_partials, dot_len);
+  }
+}
+
+struct NonEmptyRow {
+  const int32_t* rowptr;
+  __device__ bool operator()(int i) const { return rowptr[i + 1] > rowptr[i]; }
+};
 
 // ---------------------------------------------------------------------------
 // VECTOR kernel: LPR lanes per row, strided walk + shuffle reduction.
@@ -305,12 +351,13 @@ __global__ __launch_bounds__(kBlock) void csr_vector_kernel(
     for (int off = LPR / 2; off > 0; off >>= 1)
       sum += __shfl_down(sum, off, LPR);
     if (i < num_rows && sub == 0) {
-      T y = alpha * sum;
+      const T c = alpha * sum;
+      T y = c;
       if (beta != T(0))
-        y = y + beta * out[i];
+        y = c + beta * out[i];
       out[i] = y;
       if constexpr (DOT)
-        dot_acc += (double)in[i] * (double)y;
+        dot_acc += (double)in[i] * (double)c;
     }
   }
   if constexpr (DOT) {
@@ -483,6 +530,8 @@ struct spmv_hip_csr_plan {
   int nontemporal = 1;    // ROWBLOCK: nt loads on the matrix stream
   int xcd_remap = 0;      // ROWBLOCK: XCD-contiguous row-block order
   int blocks_per_cu = kBlocksPerCU;
+  int32_t* row_list = nullptr; // ROWLIST: device list of non-empty rows
+  int32_t num_listed = 0;
 };
 
 namespace
@@ -588,6 +637,31 @@ int launch_scalar(const spmv_hip_csr_plan* pl, hipStream_t st,
 }
 
 template <typename T, bool DOT>
+int launch_rowlist(const spmv_hip_csr_plan* pl, hipStream_t st,
+                   const int32_t* rowptr, const int32_t* colind,
+                   const T* values, T alpha, const T* in, T beta, T* out,
+                   double* dot)
+{
+  const int n = pl->num_rows;
+  if (beta != T(1)) { // all rows: out = beta*out (0 without reading it)
+    if (beta == T(0)) {
+      SPMV_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(T) * (size_t)n, st));
+    } else {
+      const int grid = spmv_grid_for(pl->ctx, n, kBlock);
+      hipLaunchKernelGGL((scale_kernel<T>), dim3(grid), dim3(kBlock), 0, st,
+                         (int64_t)n, beta, out);
+      SPMV_CHECK_LAUNCH();
+    }
+  }
+  const int grid = spmv_grid_for(pl->ctx, pl->num_listed, kBlock);
+  hipLaunchKernelGGL((csr_rowlist_kernel<T, DOT>), dim3(grid), dim3(kBlock), 0,
+                     st, pl->num_listed, pl->row_list, rowptr, colind, values,
+                     alpha, in, out, dot, pl->ctx->dot_blocks);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+template <typename T, bool DOT>
 int run_general(const spmv_hip_csr_plan* pl, hipStream_t st,
                 const int32_t* rowptr, const int32_t* colind, const T* values,
                 T alpha, const T* in, T beta, T* out, double* dot)
@@ -599,6 +673,9 @@ int run_general(const spmv_hip_csr_plan* pl, hipStream_t st,
   case SPMV_HIP_ALGO_SCALAR:
     return launch_scalar<T, DOT>(pl, st, rowptr, colind, values, alpha, in,
                                  beta, out, dot);
+  case SPMV_HIP_ALGO_ROWLIST:
+    return launch_rowlist<T, DOT>(pl, st, rowptr, colind, values, alpha, in,
+                                  beta, out, dot);
   default:
     return launch_rowblock<T, DOT>(pl, st, rowptr, colind, values, alpha, in,
                                    beta, out, dot);
@@ -652,6 +729,45 @@ int run_symmetric(const spmv_hip_csr_plan* pl, hipStream_t st,
   return SPMV_HIP_OK;
 }
 
+// Compact the indices of the non-empty rows on the device (plan time, once).
+int build_row_list(spmv_hip_csr_plan* pl, const int32_t* rowptr)
+{
+  SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
+  hipStream_t st = pl->ctx->stream;
+  const int n = pl->num_rows;
+  const size_t cap = (size_t)(pl->nnz < n ? pl->nnz : n);
+  int32_t* d_count = nullptr;
+  void* tmp = nullptr;
+  size_t tmp_bytes = 0;
+  SPMV_CHECK_HIP(hipMalloc(&pl->row_list, sizeof(int32_t) * (cap ? cap : 1)));
+  hipError_t e = hipMalloc(&d_count, sizeof(int32_t));
+  hipcub::CountingInputIterator<int32_t> first(0);
+  NonEmptyRow pred{rowptr};
+  if (e == hipSuccess)
+    e = hipcub::DeviceSelect::If(nullptr, tmp_bytes, first, pl->row_list,
+                                 d_count, n, pred, st);
+  if (e == hipSuccess)
+    e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16);
+  if (e == hipSuccess)
+    e = hipcub::DeviceSelect::If(tmp, tmp_bytes, first, pl->row_list, d_count,
+                                 n, pred, st);
+  int32_t count = 0;
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(&count, d_count, sizeof(int32_t), hipMemcpyDeviceToHost,
+                       st);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st);
+  (void)hipFree(tmp);
+  (void)hipFree(d_count);
+  if (e != hipSuccess) {
+    (void)hipFree(pl->row_list);
+    pl->row_list = nullptr;
+    return static_cast<int>(e);
+  }
+  pl->num_listed = count;
+  return SPMV_HIP_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -676,10 +792,27 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
   pl->nnz = num_non_zeros;
   pl->symmetric = symmetric != 0;
   const double avg = num_rows > 0 ? (double)num_non_zeros / num_rows : 0.0;
-  if (algo == SPMV_HIP_ALGO_AUTO)
-    algo = (avg <= 64.0) ? SPMV_HIP_ALGO_ROWBLOCK : SPMV_HIP_ALGO_VECTOR;
-  SPMV_REQUIRE(algo >= SPMV_HIP_ALGO_ROWBLOCK && algo <= SPMV_HIP_ALGO_SCALAR);
+  if (algo == SPMV_HIP_ALGO_AUTO) {
+    // fewer entries than a quarter of the rows: most rows are empty, walk
+    // only the non-empty ones (the remote block of a partitioned matrix)
+    if (!symmetric && num_non_zeros > 0 && num_non_zeros * 4 < num_rows)
+      algo = SPMV_HIP_ALGO_ROWLIST;
+    else
+      algo = (avg <= 64.0) ? SPMV_HIP_ALGO_ROWBLOCK : SPMV_HIP_ALGO_VECTOR;
+  }
+  if (algo < SPMV_HIP_ALGO_ROWBLOCK || algo > SPMV_HIP_ALGO_ROWLIST
+      || (algo == SPMV_HIP_ALGO_ROWLIST && (symmetric || num_non_zeros == 0))) {
+    delete pl;
+    return SPMV_HIP_EINVAL;
+  }
   pl->algo = algo;
+  if (algo == SPMV_HIP_ALGO_ROWLIST) {
+    int rc = build_row_list(pl, rowptr);
+    if (rc != SPMV_HIP_OK) {
+      delete pl;
+      return rc;
+    }
+  }
   int lpr = 4;
   while (lpr < 64 && lpr < avg / 2)
     lpr *= 2;
@@ -690,6 +823,10 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
 
 int spmv_hip_csr_plan_destroy(spmv_hip_csr_plan* plan)
 {
+  if (plan && plan->row_list) {
+    (void)hipSetDevice(plan->ctx->device);
+    (void)hipFree(plan->row_list);
+  }
   delete plan;
   return SPMV_HIP_OK;
 }
@@ -705,8 +842,10 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
 {
   SPMV_REQUIRE(plan && key);
   if (!strcmp(key, "algo")) {
+    // ROWLIST needs the list built at plan creation
     SPMV_REQUIRE(value >= SPMV_HIP_ALGO_ROWBLOCK
-                 && value <= SPMV_HIP_ALGO_SCALAR);
+                 && (value <= SPMV_HIP_ALGO_SCALAR
+                     || (value == SPMV_HIP_ALGO_ROWLIST && plan->row_list)));
     plan->algo = value;
   } else if (!strcmp(key, "lanes_per_row")) {
     SPMV_REQUIRE(value == 4 || value == 8 || value == 16 || value == 32

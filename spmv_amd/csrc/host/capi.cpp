@@ -1,0 +1,565 @@
+// C facade over the host mirror: see include/spmv_host_c.h.
+#include "spmv_host_c.h"
+
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "cg.h"
+#include "comm.h"
+#include "csr.h"
+#include "executor.h"
+#include "l2gmap.h"
+#include "matrix.h"
+
+using namespace spmv;
+
+struct spmvh_exec {
+  std::shared_ptr<HostExecutor> host;
+  std::shared_ptr<HipExecutor> hip;
+};
+struct spmvh_comm {
+  std::shared_ptr<const Comm> comm;
+};
+struct spmvh_matrix {
+  std::unique_ptr<Matrix<double>> A;
+};
+struct spmvh_l2g {
+  std::unique_ptr<L2GMap> map;
+};
+struct spmvh_split {
+  Matrix<double>::Split s;
+};
+
+namespace
+{
+thread_local std::string g_last_error;
+
+template <typename F>
+int guarded(F&& f)
+{
+  try {
+    f();
+    return 0;
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+  } catch (...) {
+    g_last_error = "unknown C++ exception";
+  }
+  return -1;
+}
+
+void require(bool ok, const char* what)
+{
+  if (!ok)
+    throw std::invalid_argument(what);
+}
+
+CommunicationModel to_cm(int cm)
+{
+  require(cm >= 0 && cm <= 7, "unknown CommunicationModel");
+  return static_cast<CommunicationModel>(cm);
+}
+
+void copy_plan(const L2GMap& m, int32_t* neighbours, int32_t* send_count,
+               int32_t* recv_count, int32_t* send_offset, int32_t* recv_offset,
+               int32_t* indexbuf)
+{
+  const size_t nn = m.neighbours().size();
+  for (size_t i = 0; i < nn; ++i) {
+    neighbours[i] = m.neighbours()[i];
+    send_count[i] = m.send_count()[i];
+    recv_count[i] = m.recv_count()[i];
+  }
+  for (size_t i = 0; i <= nn; ++i) {
+    send_offset[i] = m.send_offset()[i];
+    recv_offset[i] = m.recv_offset()[i];
+  }
+  std::copy(m.indexbuf().begin(), m.indexbuf().end(), indexbuf);
+}
+} // namespace
+
+extern "C" {
+
+const char* spmvh_last_error(void) { return g_last_error.c_str(); }
+
+// ---- executor -------------------------------------------------------------------
+int spmvh_exec_create(int device_id, spmvh_exec** exec)
+{
+  return guarded([&] {
+    require(exec != nullptr, "exec == NULL");
+    auto e = std::make_unique<spmvh_exec>();
+    e->host = HostExecutor::create();
+    e->hip = HipExecutor::create(device_id, e->host);
+    *exec = e.release();
+  });
+}
+
+int spmvh_exec_destroy(spmvh_exec* exec)
+{
+  return guarded([&] { delete exec; });
+}
+
+int spmvh_exec_alloc(spmvh_exec* exec, size_t num_bytes, void** ptr)
+{
+  return guarded([&] {
+    require(exec && ptr, "NULL argument");
+    *ptr = exec->hip->alloc<char>(num_bytes);
+  });
+}
+
+int spmvh_exec_free(spmvh_exec* exec, void* ptr)
+{
+  return guarded([&] {
+    require(exec, "NULL argument");
+    exec->hip->free(ptr);
+  });
+}
+
+int spmvh_exec_memset(spmvh_exec* exec, void* ptr, int value, size_t num_bytes)
+{
+  return guarded([&] {
+    require(exec, "NULL argument");
+    exec->hip->memset<char>(static_cast<char*>(ptr), value, num_bytes);
+  });
+}
+
+int spmvh_exec_copy(spmvh_exec* exec, void* dst, const void* src,
+                    size_t num_bytes)
+{
+  return guarded([&] {
+    require(exec, "NULL argument");
+    exec->hip->copy<char>(static_cast<char*>(dst),
+                          static_cast<const char*>(src), num_bytes);
+  });
+}
+
+int spmvh_exec_copy_from_host(spmvh_exec* exec, void* dst, const void* host_src,
+                              size_t num_bytes)
+{
+  return guarded([&] {
+    require(exec, "NULL argument");
+    exec->hip->copy_from<char>(static_cast<char*>(dst), exec->hip->get_host(),
+                               static_cast<const char*>(host_src), num_bytes);
+  });
+}
+
+int spmvh_exec_copy_to_host(spmvh_exec* exec, void* host_dst, const void* src,
+                            size_t num_bytes)
+{
+  return guarded([&] {
+    require(exec, "NULL argument");
+    exec->hip->copy_to<char>(static_cast<char*>(host_dst),
+                             exec->hip->get_host(),
+                             static_cast<const char*>(src), num_bytes);
+  });
+}
+
+int spmvh_exec_synchronize(spmvh_exec* exec)
+{
+  return guarded([&] {
+    require(exec, "NULL argument");
+    exec->hip->synchronize();
+  });
+}
+
+int spmvh_exec_num_cus(spmvh_exec* exec, int* num_cus)
+{
+  return guarded([&] {
+    require(exec && num_cus, "NULL argument");
+    *num_cus = exec->hip->get_num_cus();
+  });
+}
+
+int spmvh_exec_device_type(spmvh_exec* exec, int* type)
+{
+  return guarded([&] {
+    require(exec && type, "NULL argument");
+    *type = static_cast<int>(exec->hip->get_device_type());
+  });
+}
+
+int spmvh_exec_context(spmvh_exec* exec, void** ctx)
+{
+  return guarded([&] {
+    require(exec && ctx, "NULL argument");
+    *ctx = exec->hip->context();
+  });
+}
+
+int spmvh_host_executor_rejects_compute(void)
+{
+  try {
+    std::shared_ptr<DeviceExecutor> host = HostExecutor::create();
+    const int32_t rowptr[2] = {0, 1}, colind[1] = {0};
+    const double values[1] = {1.0};
+    CSRMatrix<double> m(host, 1, 1, 1, rowptr, colind, values);
+    (void)m;
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    return 0;
+  }
+  return 1;
+}
+
+// ---- communicators ----------------------------------------------------------------
+int spmvh_comm_self(spmvh_comm** comm)
+{
+  return guarded([&] {
+    require(comm != nullptr, "comm == NULL");
+    auto c = std::make_unique<spmvh_comm>();
+    c->comm = std::make_shared<SelfComm>();
+    *comm = c.release();
+  });
+}
+
+int spmvh_rccl_unique_id(void* id_bytes)
+{
+  return guarded([&] {
+    require(id_bytes != nullptr, "id_bytes == NULL");
+    std::vector<unsigned char> id = RcclComm::unique_id();
+    std::memcpy(id_bytes, id.data(), id.size());
+  });
+}
+
+int spmvh_comm_rccl(spmvh_exec* exec, int nranks, int rank, const void* id_bytes,
+                    spmvh_comm** comm)
+{
+  return guarded([&] {
+    require(exec && comm && id_bytes, "NULL argument");
+    auto c = std::make_unique<spmvh_comm>();
+    c->comm = std::make_shared<RcclComm>(*exec->hip, nranks, rank, id_bytes);
+    *comm = c.release();
+  });
+}
+
+int spmvh_comm_callback(int rank, int nranks, spmvh_allgather_fn allgather,
+                        spmvh_exchange_fn exchange, spmvh_allreduce_fn allreduce,
+                        void* user, spmvh_comm** comm)
+{
+  return guarded([&] {
+    require(comm && allgather && nranks >= 1 && rank >= 0 && rank < nranks,
+            "bad argument");
+    CommCallbacks cb;
+    cb.user = user;
+    cb.allgather = allgather;
+    cb.neighbor_exchange = exchange;
+    cb.allreduce_sum = allreduce;
+    auto c = std::make_unique<spmvh_comm>();
+    c->comm = std::make_shared<CallbackComm>(rank, nranks, cb);
+    *comm = c.release();
+  });
+}
+
+int spmvh_comm_destroy(spmvh_comm* comm)
+{
+  return guarded([&] { delete comm; });
+}
+
+// ---- matrix -------------------------------------------------------------------------
+int spmvh_matrix_create(spmvh_comm* comm, spmvh_exec* exec,
+                        const int32_t* rowptr, const int32_t* colind,
+                        const double* values, int64_t nrows_local,
+                        int64_t ncols_local, const int64_t* col_ghosts,
+                        int64_t num_col_ghosts, int symmetric, int cm,
+                        spmvh_matrix** A)
+{
+  return guarded([&] {
+    require(comm && exec && A && rowptr, "NULL argument");
+    std::vector<int64_t> ghosts;
+    if (num_col_ghosts > 0)
+      ghosts.assign(col_ghosts, col_ghosts + num_col_ghosts);
+    auto m = std::make_unique<spmvh_matrix>();
+    m->A.reset(Matrix<double>::create_matrix(comm->comm, exec->hip, rowptr,
+                                             colind, values, nrows_local,
+                                             ncols_local, {}, ghosts,
+                                             symmetric != 0, to_cm(cm)));
+    *A = m.release();
+  });
+}
+
+int spmvh_matrix_create_poisson3d(spmvh_comm* comm, spmvh_exec* exec, int32_t n,
+                                  int symmetric, int cm, spmvh_matrix** A)
+{
+  return guarded([&] {
+    require(comm && exec && A, "NULL argument");
+    auto m = std::make_unique<spmvh_matrix>();
+    m->A.reset(Matrix<double>::create_poisson3d(comm->comm, exec->hip, n,
+                                                symmetric != 0, to_cm(cm)));
+    *A = m.release();
+  });
+}
+
+int spmvh_matrix_destroy(spmvh_matrix* A)
+{
+  return guarded([&] { delete A; });
+}
+
+int spmvh_matrix_rows(spmvh_matrix* A, int* rows)
+{
+  return guarded([&] {
+    require(A && rows, "NULL argument");
+    *rows = A->A->rows();
+  });
+}
+
+int spmvh_matrix_cols(spmvh_matrix* A, int* cols)
+{
+  return guarded([&] {
+    require(A && cols, "NULL argument");
+    *cols = A->A->cols();
+  });
+}
+
+int spmvh_matrix_non_zeros(spmvh_matrix* A, int64_t* nnz)
+{
+  return guarded([&] {
+    require(A && nnz, "NULL argument");
+    *nnz = A->A->non_zeros();
+  });
+}
+
+int spmvh_matrix_format_size(spmvh_matrix* A, size_t* bytes)
+{
+  return guarded([&] {
+    require(A && bytes, "NULL argument");
+    *bytes = A->A->format_size();
+  });
+}
+
+int spmvh_matrix_symmetric(spmvh_matrix* A, int* symmetric)
+{
+  return guarded([&] {
+    require(A && symmetric, "NULL argument");
+    *symmetric = A->A->symmetric() ? 1 : 0;
+  });
+}
+
+int spmvh_matrix_blocks(spmvh_matrix* A, int64_t out[6])
+{
+  return guarded([&] {
+    require(A && out, "NULL argument");
+    for (int i = 0; i < 6; ++i)
+      out[i] = 0;
+    if (const SubMatrix<double>* l = A->A->local_block()) {
+      out[0] = l->rows();
+      out[1] = l->cols();
+      out[2] = l->non_zeros();
+    }
+    if (const SubMatrix<double>* r = A->A->remote_block()) {
+      out[3] = r->rows();
+      out[4] = r->cols();
+      out[5] = r->non_zeros();
+    }
+  });
+}
+
+int spmvh_matrix_update(spmvh_matrix* A, double* x)
+{
+  return guarded([&] {
+    require(A != nullptr, "NULL argument");
+    A->A->col_map()->update(x);
+  });
+}
+
+int spmvh_matrix_update_finalise(spmvh_matrix* A, double* x)
+{
+  return guarded([&] {
+    require(A != nullptr, "NULL argument");
+    A->A->col_map()->update_finalise(x);
+  });
+}
+
+int spmvh_matrix_mult(spmvh_matrix* A, double* x, double* y)
+{
+  return guarded([&] {
+    require(A != nullptr, "NULL argument");
+    A->A->mult(x, y);
+  });
+}
+
+int spmvh_split_create(const int32_t* rowptr, const int32_t* colind,
+                       const double* values, int64_t nrows_local,
+                       int64_t ncols_local, int64_t global_row_offset,
+                       int64_t global_col_offset, const int64_t* col_ghosts,
+                       int64_t num_col_ghosts, int symmetric, int cm,
+                       spmvh_split** split, int64_t sizes[8])
+{
+  return guarded([&] {
+    require(rowptr && split && sizes, "NULL argument");
+    std::vector<int64_t> ghosts;
+    if (num_col_ghosts > 0)
+      ghosts.assign(col_ghosts, col_ghosts + num_col_ghosts);
+    auto sp = std::make_unique<spmvh_split>();
+    sp->s = Matrix<double>::split_rows(rowptr, colind, values, nrows_local,
+                                       ncols_local, global_row_offset,
+                                       global_col_offset, ghosts,
+                                       symmetric != 0, to_cm(cm));
+    const auto& s = sp->s;
+    sizes[0] = s.local.rows;
+    sizes[1] = s.local.cols;
+    sizes[2] = s.local.non_zeros();
+    sizes[3] = s.remote.rows;
+    sizes[4] = s.remote.cols;
+    sizes[5] = s.remote.non_zeros();
+    sizes[6] = static_cast<int64_t>(s.col_ghosts.size());
+    sizes[7] = s.nnz_full;
+    *split = sp.release();
+  });
+}
+
+int spmvh_split_get(spmvh_split* split, int which, int32_t* rowptr,
+                    int32_t* colind, double* values)
+{
+  return guarded([&] {
+    require(split && (which == 0 || which == 1), "bad argument");
+    const CsrHost<double>& m = which == 0 ? split->s.local : split->s.remote;
+    if (rowptr)
+      std::copy(m.rowptr.begin(), m.rowptr.end(), rowptr);
+    if (colind)
+      std::copy(m.colind.begin(), m.colind.end(), colind);
+    if (values)
+      std::copy(m.values.begin(), m.values.end(), values);
+  });
+}
+
+int spmvh_split_extra(spmvh_split* split, double* diagonal, int64_t* ghosts)
+{
+  return guarded([&] {
+    require(split != nullptr, "NULL argument");
+    if (diagonal)
+      std::copy(split->s.diagonal.begin(), split->s.diagonal.end(), diagonal);
+    if (ghosts)
+      std::copy(split->s.col_ghosts.begin(), split->s.col_ghosts.end(), ghosts);
+  });
+}
+
+int spmvh_split_destroy(spmvh_split* split)
+{
+  return guarded([&] { delete split; });
+}
+
+// ---- L2GMap inspection ----------------------------------------------------------------
+int spmvh_l2g_sizes(spmvh_matrix* A, int32_t* local_size, int32_t* num_ghosts,
+                    int64_t* global_size, int64_t* global_offset,
+                    int* overlapping, int* num_neighbours, int* num_indices,
+                    int* packs)
+{
+  return guarded([&] {
+    require(A != nullptr, "NULL argument");
+    std::shared_ptr<const L2GMap> m = A->A->col_map();
+    if (local_size) *local_size = m->local_size();
+    if (num_ghosts) *num_ghosts = m->num_ghosts();
+    if (global_size) *global_size = m->global_size();
+    if (global_offset) *global_offset = m->global_offset();
+    if (overlapping) *overlapping = m->overlapping() ? 1 : 0;
+    if (num_neighbours) *num_neighbours = static_cast<int>(m->neighbours().size());
+    if (num_indices) *num_indices = static_cast<int>(m->indexbuf().size());
+    if (packs) *packs = m->packs() ? 1 : 0;
+  });
+}
+
+int spmvh_l2g_ghosts(spmvh_matrix* A, int64_t* ghosts)
+{
+  return guarded([&] {
+    require(A && ghosts, "NULL argument");
+    const std::vector<int64_t>& g = A->A->col_map()->ghosts();
+    std::copy(g.begin(), g.end(), ghosts);
+  });
+}
+
+int spmvh_l2g_plan(spmvh_matrix* A, int32_t* neighbours, int32_t* send_count,
+                   int32_t* recv_count, int32_t* send_offset,
+                   int32_t* recv_offset, int32_t* indexbuf)
+{
+  return guarded([&] {
+    require(A != nullptr, "NULL argument");
+    copy_plan(*A->A->col_map(), neighbours, send_count, recv_count, send_offset,
+              recv_offset, indexbuf);
+  });
+}
+
+int spmvh_l2g_global_to_local(spmvh_matrix* A, int64_t global, int32_t* local)
+{
+  return guarded([&] {
+    require(A && local, "NULL argument");
+    *local = A->A->col_map()->global_to_local(global);
+  });
+}
+
+int spmvh_l2g_create(spmvh_comm* comm, spmvh_exec* exec, int use_host_exec,
+                     int64_t local_size, const int64_t* ghosts,
+                     int64_t num_ghosts, int cm, spmvh_l2g** map)
+{
+  return guarded([&] {
+    require(comm && map && (use_host_exec || exec), "NULL argument");
+    std::vector<int64_t> g;
+    if (num_ghosts > 0)
+      g.assign(ghosts, ghosts + num_ghosts);
+    std::shared_ptr<DeviceExecutor> e;
+    if (use_host_exec)
+      e = HostExecutor::create();
+    else
+      e = exec->hip;
+    auto m = std::make_unique<spmvh_l2g>();
+    m->map.reset(new L2GMap(comm->comm, local_size, g, e, to_cm(cm)));
+    *map = m.release();
+  });
+}
+
+int spmvh_l2g_destroy(spmvh_l2g* map)
+{
+  return guarded([&] { delete map; });
+}
+
+int spmvh_l2g_map_sizes(spmvh_l2g* map, int* num_neighbours, int* num_indices,
+                        int* packs)
+{
+  return guarded([&] {
+    require(map != nullptr, "NULL argument");
+    if (num_neighbours)
+      *num_neighbours = static_cast<int>(map->map->neighbours().size());
+    if (num_indices)
+      *num_indices = static_cast<int>(map->map->indexbuf().size());
+    if (packs)
+      *packs = map->map->packs() ? 1 : 0;
+  });
+}
+
+int spmvh_l2g_map_plan(spmvh_l2g* map, int32_t* neighbours, int32_t* send_count,
+                       int32_t* recv_count, int32_t* send_offset,
+                       int32_t* recv_offset, int32_t* indexbuf)
+{
+  return guarded([&] {
+    require(map != nullptr, "NULL argument");
+    copy_plan(*map->map, neighbours, send_count, recv_count, send_offset,
+              recv_offset, indexbuf);
+  });
+}
+
+int spmvh_l2g_map_update(spmvh_l2g* map, double* x)
+{
+  return guarded([&] {
+    require(map != nullptr, "NULL argument");
+    map->map->update(x);
+  });
+}
+
+// ---- cg ---------------------------------------------------------------------------------
+int spmvh_cg(spmvh_comm* comm, spmvh_exec* exec, spmvh_matrix* A,
+             const double* b, double* x, int kmax, double rtol, int* num_its,
+             double* rnorm_history)
+{
+  return guarded([&] {
+    require(comm && exec && A && num_its, "NULL argument");
+    std::vector<double> hist;
+    *num_its = cg(*comm->comm, *exec->hip, *A->A, b, x, kmax, rtol,
+                  rnorm_history ? &hist : nullptr);
+    if (rnorm_history)
+      std::copy(hist.begin(), hist.end(), rnorm_history);
+  });
+}
+
+} // extern "C"

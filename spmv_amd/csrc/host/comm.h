@@ -1,0 +1,174 @@
+// Communicator abstraction replacing MPI_Comm in the mirrored signatures
+// (L2GMap, Matrix::create_matrix, cg).  MPI may be absent on a GPU box and
+// the hot path runs on RCCL over xGMI, one process per GPU (SURVEY section
+// 8b "MPI in signatures").  Argument order of the mirrored functions is
+// otherwise identical to the reference.
+//
+//   host side  : allgather() is the only primitive; plan construction builds
+//                the reference's Allgather / Alltoall / Neighbor_alltoallv
+//                (L2GMap.cpp:353-354,387-388,444-447) on top of it.  Setup
+//                only, untimed.
+//   device side: neighbor_exchange() = the p2p halo (L2GMap.cpp:564-642),
+//                allreduce_sum() = MPI_Allreduce(1 x double) of cg
+//                (cg.cpp:49,65,75); both are stream-ordered, the host never
+//                waits.
+//
+// Implementations: SelfComm (1 rank, no transport), RcclComm (libspmv_hip.so's
+// RCCL wrappers), CallbackComm (function pointers supplied by the embedding
+// program -- e.g. MPI in the reference's own drivers, or torch.distributed in
+// this repo's tests).
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <vector>
+
+struct spmv_hip_comm;
+
+namespace spmv
+{
+
+class HipExecutor;
+
+// same enumerators, same order as spmv/mpi_utils.h:43-52
+enum class CommunicationModel {
+  p2p_blocking,
+  p2p_nonblocking,
+  collective_blocking,
+  collective_nonblocking,
+  onesided_put_active,
+  onesided_put_passive,
+  shmem,
+  shmem_nodup
+};
+
+class Comm
+{
+public:
+  virtual ~Comm() = default;
+  virtual int rank() const = 0;
+  virtual int size() const = 0;
+
+  // recv[r*bytes_per_rank ...] = rank r's send buffer (host memory)
+  virtual void allgather(const void* send, void* recv,
+                         size_t bytes_per_rank) const = 0;
+
+  // Grouped neighbour exchange on DEVICE memory, enqueued on `stream`:
+  // for each neighbour i send send_counts[i] elements of `elem_bytes` from
+  // send_buf + send_offsets[i], receive recv_counts[i] into
+  // recv_base + recv_offsets[i] (offsets in elements).
+  virtual void neighbor_exchange(size_t elem_bytes,
+                                 const std::vector<int>& neighbours,
+                                 const void* send_buf,
+                                 const std::vector<int32_t>& send_counts,
+                                 const std::vector<int32_t>& send_offsets,
+                                 void* recv_base,
+                                 const std::vector<int32_t>& recv_counts,
+                                 const std::vector<int32_t>& recv_offsets,
+                                 void* stream) const = 0;
+
+  // In-place sum of `count` device doubles over all ranks, on `stream`.
+  virtual void allreduce_sum(double* device_inout, size_t count,
+                             void* stream) const = 0;
+
+  // ---- helpers built on allgather (host, setup only) ----------------------
+  template <typename T>
+  std::vector<T> allgather_value(const T& v) const
+  {
+    std::vector<T> out(size());
+    allgather(&v, out.data(), sizeof(T));
+    return out;
+  }
+  // every rank contributes a vector of arbitrary length; returns all of them
+  std::vector<std::vector<int32_t>>
+  allgatherv(const std::vector<int32_t>& mine) const;
+};
+
+class SelfComm final : public Comm
+{
+public:
+  int rank() const override { return 0; }
+  int size() const override { return 1; }
+  void allgather(const void* send, void* recv, size_t bytes) const override;
+  void neighbor_exchange(size_t, const std::vector<int>&, const void*,
+                         const std::vector<int32_t>&,
+                         const std::vector<int32_t>&, void*,
+                         const std::vector<int32_t>&,
+                         const std::vector<int32_t>&, void*) const override;
+  void allreduce_sum(double*, size_t, void*) const override {}
+};
+
+class RcclComm final : public Comm
+{
+public:
+  // `unique_id` = SPMV_HIP_UNIQUE_ID_BYTES bytes produced by
+  // RcclComm::unique_id() on one rank and handed to every rank by the
+  // launcher (torch.distributed store, MPI_Bcast, a file, ...).
+  RcclComm(const HipExecutor& exec, int nranks, int rank,
+           const void* unique_id);
+  ~RcclComm() override;
+  static std::vector<unsigned char> unique_id();
+
+  int rank() const override { return _rank; }
+  int size() const override { return _size; }
+  void allgather(const void* send, void* recv, size_t bytes) const override;
+  void neighbor_exchange(size_t elem_bytes, const std::vector<int>& neighbours,
+                         const void* send_buf,
+                         const std::vector<int32_t>& send_counts,
+                         const std::vector<int32_t>& send_offsets,
+                         void* recv_base,
+                         const std::vector<int32_t>& recv_counts,
+                         const std::vector<int32_t>& recv_offsets,
+                         void* stream) const override;
+  void allreduce_sum(double* device_inout, size_t count,
+                     void* stream) const override;
+
+private:
+  spmv_hip_comm* _comm = nullptr;
+  int _rank = 0, _size = 1;
+};
+
+// Transport supplied as C callbacks (all must return 0 on success).
+struct CommCallbacks {
+  void* user = nullptr;
+  int (*allgather)(void* user, const void* send, void* recv,
+                   size_t bytes_per_rank) = nullptr;
+  // optional: device transport; when null the device calls throw
+  int (*neighbor_exchange)(void* user, size_t elem_bytes, int num_neighbours,
+                           const int* neighbours, const void* send_buf,
+                           const int32_t* send_counts,
+                           const int32_t* send_offsets, void* recv_base,
+                           const int32_t* recv_counts,
+                           const int32_t* recv_offsets, void* stream) = nullptr;
+  int (*allreduce_sum)(void* user, double* device_inout, size_t count,
+                       void* stream) = nullptr;
+};
+
+class CallbackComm final : public Comm
+{
+public:
+  CallbackComm(int rank, int size, CommCallbacks cb)
+      : _rank(rank), _size(size), _cb(cb)
+  {
+  }
+  int rank() const override { return _rank; }
+  int size() const override { return _size; }
+  void allgather(const void* send, void* recv, size_t bytes) const override;
+  void neighbor_exchange(size_t elem_bytes, const std::vector<int>& neighbours,
+                         const void* send_buf,
+                         const std::vector<int32_t>& send_counts,
+                         const std::vector<int32_t>& send_offsets,
+                         void* recv_base,
+                         const std::vector<int32_t>& recv_counts,
+                         const std::vector<int32_t>& recv_offsets,
+                         void* stream) const override;
+  void allreduce_sum(double* device_inout, size_t count,
+                     void* stream) const override;
+
+private:
+  int _rank, _size;
+  CommCallbacks _cb;
+};
+
+} // namespace spmv

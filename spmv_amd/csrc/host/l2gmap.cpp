@@ -1,0 +1,250 @@
+// L2GMap: see l2gmap.h.  Plan construction follows spmv/L2GMap.cpp:346-479.
+#include "l2gmap.h"
+
+#include <algorithm>
+#include <stdexcept>
+
+namespace spmv
+{
+
+L2GMap::L2GMap(std::shared_ptr<const Comm> comm, std::int64_t local_size,
+               const std::vector<std::int64_t>& ghosts,
+               std::shared_ptr<DeviceExecutor> exec, CommunicationModel cm)
+    : _comm(std::move(comm)), _exec(std::move(exec)), _cm(cm), _ghosts(ghosts)
+{
+  switch (cm) {
+  case CommunicationModel::p2p_blocking:
+  case CommunicationModel::p2p_nonblocking:
+  case CommunicationModel::collective_blocking:
+  case CommunicationModel::collective_nonblocking:
+    break;
+  default:
+    throw std::runtime_error(
+        "L2GMap: one-sided and shmem models have no MI355X counterpart; use "
+        "a p2p or collective model (all map to RCCL send/recv over xGMI)");
+  }
+  _hip = dynamic_cast<HipExecutor*>(_exec.get());
+  const int P = _comm->size();
+  _rank = _comm->rank();
+
+  // ownership ranges (L2GMap.cpp:351-356)
+  std::vector<std::int64_t> sizes = _comm->allgather_value<std::int64_t>(local_size);
+  _ranges.assign(P + 1, 0);
+  for (int r = 0; r < P; ++r)
+    _ranges[r + 1] = _ranges[r] + sizes[r];
+  const std::int64_t r0 = _ranges[_rank], r1 = _ranges[_rank + 1];
+
+  if (!std::is_sorted(_ghosts.begin(), _ghosts.end()))
+    throw std::runtime_error("Ghosts must be sorted"); // :362-363
+
+  // owner and owner-local index of every ghost (:366-381)
+  std::vector<std::int32_t> ghost_count(P, 0), ghost_local;
+  ghost_local.reserve(_ghosts.size());
+  for (std::size_t i = 0; i < _ghosts.size(); ++i) {
+    const std::int64_t idx = _ghosts[i];
+    if (idx >= r0 && idx < r1)
+      throw std::runtime_error("Ghost index in local range"); // :371-372
+    if (idx < 0 || idx >= _ranges[P])
+      throw std::runtime_error("Ghost index outside the global range");
+    _global_to_local.insert({idx, static_cast<std::int32_t>(local_size + i)});
+    const int p = static_cast<int>(
+        std::upper_bound(_ranges.begin(), _ranges.end(), idx) - _ranges.begin()
+        - 1);
+    ++ghost_count[p];
+    ghost_local.push_back(static_cast<std::int32_t>(idx - _ranges[p]));
+  }
+
+  // who needs what from whom: the reference's Alltoall (:386-388) as an
+  // allgather of every rank's per-owner counts
+  std::vector<std::int32_t> all_counts(static_cast<std::size_t>(P) * P);
+  _comm->allgather(ghost_count.data(), all_counts.data(),
+                   sizeof(std::int32_t) * P);
+  auto wants = [&](int from, int owner) { return all_counts[from * P + owner]; };
+
+  // symmetric neighbour list in rank order (:390-412)
+  for (int p = 0; p < P; ++p) {
+    const std::int32_t c = ghost_count[p], rc = wants(p, _rank);
+    if (c > 0 || rc > 0) {
+      _neighbours.push_back(p);
+      _send_count.push_back(c);
+      _recv_count.push_back(rc);
+    }
+  }
+  if (_neighbours.empty()) { // :421-425 keeps one zero entry
+    _send_count = {0};
+    _recv_count = {0};
+  }
+  _send_offset = {0};
+  for (std::int32_t c : _send_count)
+    _send_offset.push_back(_send_offset.back() + c);
+  _recv_offset = {0};
+  for (std::int32_t c : _recv_count)
+    _recv_offset.push_back(_recv_offset.back() + c);
+  _num_indices = _recv_offset.back();
+
+  // index buffer: the owner-local indices each neighbour asks me for, in the
+  // neighbour's ghost order (Neighbor_alltoallv, :444-447)
+  _indexbuf_host.assign(_num_indices, 0);
+  if (P > 1) {
+    std::vector<std::vector<std::int32_t>> lists = _comm->allgatherv(ghost_local);
+    for (std::size_t i = 0; i < _neighbours.size(); ++i) {
+      const int p = _neighbours[i];
+      std::int64_t off = 0; // p's ghosts are sorted, so grouped by owner
+      for (int q = 0; q < _rank; ++q)
+        off += wants(p, q);
+      std::copy_n(lists[p].begin() + off, _recv_count[i],
+                  _indexbuf_host.begin() + _recv_offset[i]);
+    }
+  }
+  for (std::int32_t idx : _indexbuf_host)
+    if (idx < 0 || idx >= local_size)
+      throw std::runtime_error("L2GMap: neighbour requested a non-local index");
+
+  // ghosts land after the owned entries (:460-461)
+  for (std::int32_t& s : _send_offset)
+    s += static_cast<std::int32_t>(local_size);
+
+  // contiguous-run detection: one run per neighbour => no pack kernel
+  _direct_send = !_neighbours.empty();
+  _direct_offset.assign(_neighbours.size(), 0);
+  for (std::size_t i = 0; i < _neighbours.size() && _direct_send; ++i) {
+    const std::int32_t* seg = _indexbuf_host.data() + _recv_offset[i];
+    for (std::int32_t k = 1; k < _recv_count[i]; ++k)
+      if (seg[k] != seg[0] + k) {
+        _direct_send = false;
+        break;
+      }
+    _direct_offset[i] = _recv_count[i] > 0 ? seg[0] : 0;
+  }
+
+  if (_num_indices > 0) { // :473-478
+    _indexbuf = _exec->alloc<std::int32_t>(_num_indices);
+    _exec->copy_from<std::int32_t>(_indexbuf, _exec->get_host(),
+                                   _indexbuf_host.data(), _num_indices);
+  }
+  if (_hip && !_neighbours.empty()) {
+    _comm_stream = _hip->create_stream();
+    _ev_ready = _hip->create_event();
+    _ev_done = _hip->create_event();
+  }
+}
+
+L2GMap::~L2GMap()
+{
+  try {
+    if (_hip) {
+      if (_comm_stream)
+        _hip->synchronize_stream(_comm_stream);
+      _hip->destroy_event(_ev_ready);
+      _hip->destroy_event(_ev_done);
+      _hip->destroy_stream(_comm_stream);
+    }
+    _exec->free(_send_buf);
+    _exec->free(_indexbuf); // the reference leaks this
+  } catch (...) {
+  }
+}
+
+std::int32_t L2GMap::local_size() const
+{
+  return static_cast<std::int32_t>(_ranges[_rank + 1] - _ranges[_rank]);
+}
+
+std::int32_t L2GMap::global_to_local(std::int64_t i) const // :961-973
+{
+  const std::int64_t r0 = _ranges[_rank], r1 = _ranges[_rank + 1];
+  if (i >= r0 && i < r1)
+    return static_cast<std::int32_t>(i - r0);
+  auto it = _global_to_local.find(i);
+  if (it == _global_to_local.end())
+    throw std::runtime_error("L2GMap::global_to_local: index is not a ghost");
+  return it->second;
+}
+
+bool L2GMap::overlapping() const // :975-981
+{
+  return _cm == CommunicationModel::p2p_nonblocking
+         || _cm == CommunicationModel::collective_nonblocking;
+}
+
+template <typename T>
+void L2GMap::start_exchange(T* vec) const
+{
+  if (!_hip)
+    throw std::runtime_error(
+        "L2GMap::update: the halo exchange needs a HipExecutor");
+  void* compute = _hip->get_stream();
+  // the exchange may only start once the kernels producing vec are done
+  _hip->record_event(_ev_ready, compute);
+  _hip->stream_wait_event(_comm_stream, _ev_ready);
+
+  const void* send_base = vec;
+  const std::vector<std::int32_t>* send_offs = &_direct_offset;
+  if (!_direct_send) {
+    const size_t need = sizeof(T) * static_cast<size_t>(_num_indices > 0 ? _num_indices : 1);
+    if (_send_buf == nullptr || _send_buf_bytes < need) { // :607-614
+      _exec->free(_send_buf);
+      _send_buf = _exec->alloc<char>(need);
+      _send_buf_bytes = need;
+    }
+    // pack on the comm stream through the executor interface (:618)
+    _hip->set_stream(_comm_stream);
+    try {
+      _exec->gather_ghosts_run(_num_indices, _indexbuf, vec,
+                               static_cast<T*>(_send_buf));
+    } catch (...) {
+      _hip->set_stream(compute);
+      throw;
+    }
+    _hip->set_stream(compute);
+    send_base = _send_buf;
+    send_offs = &_recv_offset;
+  }
+  // receive straight into the ghost tail (:624-628), send packed or direct
+  // data (:630-634); one grouped call, ordered on the comm stream
+  std::vector<std::int32_t> soffs(send_offs->begin(),
+                                  send_offs->begin() + _neighbours.size());
+  std::vector<std::int32_t> scnt(_recv_count.begin(),
+                                 _recv_count.begin() + _neighbours.size());
+  std::vector<std::int32_t> rcnt(_send_count.begin(),
+                                 _send_count.begin() + _neighbours.size());
+  std::vector<std::int32_t> roffs(_send_offset.begin(),
+                                  _send_offset.begin() + _neighbours.size());
+  _comm->neighbor_exchange(sizeof(T), _neighbours, send_base, scnt, soffs, vec,
+                           rcnt, roffs, _comm_stream);
+  _hip->record_event(_ev_done, _comm_stream);
+}
+
+template <typename T>
+void L2GMap::update(T* vec) const // :868-896
+{
+  if (_neighbours.empty())
+    return;
+  start_exchange(vec);
+  if (!overlapping()) // blocking models: later compute-stream work sees ghosts
+    _hip->stream_wait_event(_hip->get_stream(), _ev_done);
+}
+
+template <typename T>
+void L2GMap::update_finalise(T*) const // :899-905
+{
+  if (_neighbours.empty() || !overlapping())
+    return;
+  _hip->stream_wait_event(_hip->get_stream(), _ev_done); // no host wait
+}
+
+template <typename T>
+void L2GMap::reverse_update(T*) const
+{
+  throw std::runtime_error(
+      "L2GMap::reverse_update is outside the accelerated hot path");
+}
+
+template void L2GMap::update<float>(float*) const;
+template void L2GMap::update<double>(double*) const;
+template void L2GMap::update_finalise<float>(float*) const;
+template void L2GMap::update_finalise<double>(double*) const;
+template void L2GMap::reverse_update<float>(float*) const;
+template void L2GMap::reverse_update<double>(double*) const;
+
+} // namespace spmv

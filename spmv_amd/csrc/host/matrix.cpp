@@ -1,0 +1,452 @@
+// Matrix<T>: see matrix.h.
+#include "matrix.h"
+
+#include <algorithm>
+#include <numeric>
+#include <stdexcept>
+#include <type_traits>
+
+#include "spmv_hip.h"
+
+namespace spmv
+{
+
+std::vector<int64_t> owner_ranges(int size, int64_t N)
+{
+  const int64_t q = N / size, r = N % size;
+  std::vector<int64_t> ranges(size + 1);
+  for (int k = 0; k <= size; ++k)
+    ranges[k] = (k < r) ? k * (q + 1) : k * q + r;
+  return ranges;
+}
+
+// ---------------------------------------------------------------------------
+// constructors
+// ---------------------------------------------------------------------------
+template <typename T>
+Matrix<T>::Matrix(const CsrHost<T>& mat, std::shared_ptr<L2GMap> col_map,
+                  std::shared_ptr<L2GMap> row_map,
+                  std::shared_ptr<DeviceExecutor> exec)
+    : _exec(exec), _col_map(col_map), _row_map(row_map), _nnz(mat.non_zeros())
+{
+  if (col_map->overlapping()) // Matrix.cpp:28-29
+    throw std::runtime_error("Ovelapping not supported in this format!");
+  _mat_local.reset(new CSRMatrix<T>(exec, &mat));
+}
+
+template <typename T>
+Matrix<T>::Matrix(const CsrHost<T>& mat_local, const CsrHost<T>& mat_remote,
+                  std::shared_ptr<L2GMap> col_map,
+                  std::shared_ptr<L2GMap> row_map,
+                  std::shared_ptr<DeviceExecutor> exec)
+    : _exec(exec), _col_map(col_map), _row_map(row_map),
+      _nnz(mat_local.non_zeros() + mat_remote.non_zeros())
+{
+  if (!col_map->overlapping()) // Matrix.cpp:44-45
+    throw std::runtime_error("Ovelapping not enabled in column mapping!");
+  _mat_local.reset(new CSRMatrix<T>(exec, &mat_local));
+  _mat_remote.reset(new CSRMatrix<T>(exec, &mat_remote));
+}
+
+template <typename T>
+Matrix<T>::Matrix(const CsrHost<T>& mat_local, const CsrHost<T>& mat_remote,
+                  const std::vector<T>& mat_diagonal,
+                  std::shared_ptr<L2GMap> col_map,
+                  std::shared_ptr<L2GMap> row_map, int64_t nnz_full,
+                  std::shared_ptr<DeviceExecutor> exec)
+    : _exec(exec), _col_map(col_map), _row_map(row_map), _nnz(nnz_full),
+      _symmetric(true)
+{
+  if (exec->get_device_type() == DeviceType::undefined) // Matrix.cpp:68-70
+    throw std::runtime_error("Device type not set!");
+  _mat_local.reset(new CSRMatrix<T>(exec, &mat_local, &mat_diagonal, true));
+  _mat_remote.reset(new CSRMatrix<T>(exec, &mat_remote));
+}
+
+// ---------------------------------------------------------------------------
+// queries (Matrix.cpp:75-128)
+// ---------------------------------------------------------------------------
+template <typename T>
+int Matrix<T>::rows() const
+{
+  if (_mat_local)
+    return _mat_local->rows();
+  return _mat_remote ? _mat_remote->rows() : 0;
+}
+
+template <typename T>
+int Matrix<T>::cols() const
+{
+  if (_mat_local)
+    return _mat_local->cols();
+  return _mat_remote ? _mat_remote->cols() : 0;
+}
+
+template <typename T>
+int64_t Matrix<T>::non_zeros() const
+{
+  if (_symmetric)
+    return _nnz;
+  if (_col_map->overlapping())
+    return _mat_local->non_zeros() + _mat_remote->non_zeros();
+  return _mat_local->non_zeros();
+}
+
+template <typename T>
+size_t Matrix<T>::format_size() const
+{
+  size_t bytes = sizeof(int) * _mat_local->rows()
+                 + (sizeof(int) + sizeof(T)) * _mat_local->non_zeros();
+  if (_symmetric || _col_map->overlapping())
+    bytes += sizeof(int) * _mat_remote->rows()
+             + (sizeof(int) + sizeof(T)) * _mat_remote->non_zeros();
+  if (_symmetric)
+    bytes += sizeof(T) * _mat_local->rows();
+  return bytes;
+}
+
+// ---------------------------------------------------------------------------
+// SpMV (Matrix.cpp:131-141, 483-552)
+// ---------------------------------------------------------------------------
+template <typename T>
+void Matrix<T>::mult(T* x, T* y) const
+{
+  if (_symmetric && _col_map->overlapping())
+    spmv_sym_overlap(x, y);
+  else if (_symmetric)
+    spmv_sym(x, y);
+  else if (_col_map->overlapping())
+    spmv_overlap(x, y);
+  else
+    spmv(x, y);
+}
+
+template <typename T>
+void Matrix<T>::spmv(T* x, T* y) const
+{
+  _mat_local->mult(1, x, 0, y);
+}
+
+template <typename T>
+void Matrix<T>::spmv_overlap(T* x, T* y) const
+{
+  _mat_local->mult(1, x, 0, y);  // runs while the halo is in flight
+  _col_map->update_finalise(x);  // compute stream waits for the halo event
+  if (_mat_local->non_zeros() > 0)
+    _mat_remote->mult(1, x, 1, y);
+  else
+    _mat_remote->mult(1, x, 0, y);
+}
+
+template <typename T>
+void Matrix<T>::spmv_sym(T* x, T* y) const
+{
+  _mat_local->mult(1, x, 0, y);
+  _mat_remote->mult(1, x, 1, y);
+}
+
+template <typename T>
+void Matrix<T>::spmv_sym_overlap(T* x, T* y) const
+{
+  _mat_local->mult(1, x, 0, y);
+  _col_map->update_finalise(x);
+  _mat_remote->mult(1, x, 1, y);
+}
+
+template <typename T>
+bool Matrix<T>::mult_dot(T* x, T* y, double* dot_local,
+                         double* dot_remote) const
+{
+  if (_symmetric || !std::is_same<T, double>::value) {
+    mult(x, y);
+    return false;
+  }
+  if (!_col_map->overlapping()) {
+    if (!_mat_local->mult_dot(1, x, 0, y, dot_local)) {
+      mult(x, y);
+      return false;
+    }
+    return true;
+  }
+  // overlapping: local share, halo wait, remote share (same order as
+  // spmv_overlap).  An empty local block cannot fuse -> plain path.
+  if (!_mat_local->mult_dot(1, x, 0, y, dot_local)) {
+    mult(x, y);
+    return false;
+  }
+  _col_map->update_finalise(x);
+  if (_mat_remote->non_zeros() > 0)
+    _mat_remote->mult_dot(1, x, 1, y, dot_remote);
+  return true;
+}
+
+// ---------------------------------------------------------------------------
+// create_matrix (Matrix.cpp:164-480, row_ghosts empty)
+// ---------------------------------------------------------------------------
+namespace
+{
+
+template <typename T>
+struct Triplet {
+  int32_t row, col;
+  T val;
+};
+
+// Eigen::setFromTriplets: per row ascending columns, duplicates summed.
+template <typename T>
+CsrHost<T> assemble(int32_t nrows, int32_t ncols, std::vector<Triplet<T>>& tr)
+{
+  std::stable_sort(tr.begin(), tr.end(),
+                   [](const Triplet<T>& a, const Triplet<T>& b) {
+                     return a.row != b.row ? a.row < b.row : a.col < b.col;
+                   });
+  CsrHost<T> m;
+  m.rows = nrows;
+  m.cols = ncols;
+  m.rowptr.assign(nrows + 1, 0);
+  for (size_t k = 0; k < tr.size(); ++k) {
+    if (k > 0 && tr[k].row == tr[k - 1].row && tr[k].col == tr[k - 1].col) {
+      m.values.back() += tr[k].val;
+      continue;
+    }
+    m.colind.push_back(tr[k].col);
+    m.values.push_back(tr[k].val);
+    ++m.rowptr[tr[k].row + 1];
+  }
+  std::partial_sum(m.rowptr.begin(), m.rowptr.end(), m.rowptr.begin());
+  return m;
+}
+
+bool nonblocking(CommunicationModel cm)
+{
+  return cm == CommunicationModel::p2p_nonblocking
+         || cm == CommunicationModel::collective_nonblocking;
+}
+
+} // namespace
+
+template <typename T>
+typename Matrix<T>::Split Matrix<T>::split_rows(
+    const int32_t* rowptr, const int32_t* colind, const T* values,
+    int64_t nrows_local, int64_t ncols_local, int64_t global_row_offset,
+    int64_t global_col_offset, const std::vector<int64_t>& col_ghosts,
+    bool symmetric, CommunicationModel cm)
+{
+  Split out;
+  // ghost columns renumbered in ascending global order after the owned
+  // columns (Matrix.cpp:295-318)
+  out.col_ghosts = col_ghosts;
+  std::sort(out.col_ghosts.begin(), out.col_ghosts.end());
+  out.col_ghosts.erase(
+      std::unique(out.col_ghosts.begin(), out.col_ghosts.end()),
+      out.col_ghosts.end());
+  const std::vector<int64_t>& new_ghosts = out.col_ghosts;
+  const int32_t ncols_all = static_cast<int32_t>(ncols_local + new_ghosts.size());
+
+  std::vector<Triplet<T>> loc, rem;
+  std::vector<char> has_diag;
+  if (symmetric) {
+    out.diagonal.assign(nrows_local, T(0)); // Matrix.cpp:429
+    has_diag.assign(nrows_local, 0);
+  }
+  for (int64_t row = 0; row < nrows_local; ++row) {
+    for (int32_t j = rowptr[row]; j < rowptr[row + 1]; ++j) {
+      int64_t col = colind[j];
+      if (col >= ncols_local) {
+        const size_t g = static_cast<size_t>(col - ncols_local);
+        if (g >= col_ghosts.size())
+          throw std::runtime_error("create_matrix: ghost column out of range");
+        col = ncols_local
+              + (std::lower_bound(new_ghosts.begin(), new_ghosts.end(),
+                                  col_ghosts[g])
+                 - new_ghosts.begin());
+      } else if (col < 0) {
+        throw std::runtime_error("create_matrix: negative column index");
+      }
+      const Triplet<T> t{static_cast<int32_t>(row), static_cast<int32_t>(col),
+                         values[j]};
+      if (symmetric) { // Matrix.cpp:337-349
+        if (col < ncols_local) {
+          const int64_t grow = row + global_row_offset;
+          const int64_t gcol = col + global_col_offset;
+          if (grow > gcol)
+            loc.push_back(t);
+          else if (grow == gcol) {
+            out.diagonal[row] += values[j];
+            has_diag[row] = 1;
+          } // strictly-upper entries are implied by symmetry and dropped
+        } else {
+          rem.push_back(t);
+        }
+      } else if (nonblocking(cm)) { // Matrix.cpp:350-355
+        (col < ncols_local ? loc : rem).push_back(t);
+      } else { // Matrix.cpp:357
+        loc.push_back(t);
+      }
+    }
+  }
+  const int32_t nrows = static_cast<int32_t>(nrows_local);
+  if (symmetric) { // Matrix.cpp:415-446
+    out.local = assemble(nrows, ncols_all, loc);
+    out.remote = assemble(nrows, ncols_all, rem);
+    out.two_blocks = true;
+    out.nnz_full = 2 * out.local.non_zeros() + out.remote.non_zeros()
+                   + std::count(has_diag.begin(), has_diag.end(), 1);
+  } else if (nonblocking(cm)) { // Matrix.cpp:447-466
+    out.local = assemble(nrows, static_cast<int32_t>(ncols_local), loc);
+    out.remote = assemble(nrows, ncols_all, rem);
+    out.two_blocks = true;
+    out.nnz_full = out.local.non_zeros() + out.remote.non_zeros();
+  } else { // Matrix.cpp:467-479
+    out.local = assemble(nrows, ncols_all, loc);
+    out.remote.rows = nrows;
+    out.remote.cols = ncols_all;
+    out.remote.rowptr.assign(nrows + 1, 0);
+    out.nnz_full = out.local.non_zeros();
+  }
+  return out;
+}
+
+template <typename T>
+Matrix<T>* Matrix<T>::create_matrix(
+    std::shared_ptr<const Comm> comm, std::shared_ptr<DeviceExecutor> exec,
+    const int32_t* rowptr, const int32_t* colind, const T* values,
+    int64_t nrows_local, int64_t ncols_local, std::vector<int64_t> row_ghosts,
+    std::vector<int64_t> col_ghosts, bool symmetric, CommunicationModel cm)
+{
+  if (!row_ghosts.empty())
+    throw std::runtime_error(
+        "Matrix::create_matrix: row ghosts (rows assembled on a non-owner "
+        "rank, Matrix.cpp:188-292) are not supported by this backend yet");
+  const int P = comm->size(), me = comm->rank();
+
+  // global row / column offsets (Matrix.cpp:175-186)
+  std::vector<int64_t> nr = comm->allgather_value<int64_t>(nrows_local);
+  std::vector<int64_t> nc = comm->allgather_value<int64_t>(ncols_local);
+  int64_t row_off = 0, col_off = 0;
+  for (int r = 0; r < me; ++r) {
+    row_off += nr[r];
+    col_off += nc[r];
+  }
+  (void)P;
+  Split s = split_rows(rowptr, colind, values, nrows_local, ncols_local,
+                       row_off, col_off, col_ghosts, symmetric, cm);
+
+  auto col_map = std::make_shared<L2GMap>(comm, ncols_local, s.col_ghosts, exec,
+                                          cm);
+  auto row_map = std::make_shared<L2GMap>(comm, nrows_local,
+                                          std::vector<int64_t>(), exec);
+  if (symmetric)
+    return new Matrix<T>(s.local, s.remote, s.diagonal, col_map, row_map,
+                         s.nnz_full, exec);
+  if (nonblocking(cm))
+    return new Matrix<T>(s.local, s.remote, col_map, row_map, exec);
+  return new Matrix<T>(s.local, col_map, row_map, exec);
+}
+
+// ---------------------------------------------------------------------------
+// create_poisson3d: blocks generated on the device
+// ---------------------------------------------------------------------------
+namespace
+{
+
+struct DeviceBlock {
+  int32_t* rowptr = nullptr;
+  int32_t* colind = nullptr;
+  double* values = nullptr;
+  double* diagonal = nullptr;
+  int64_t nnz = 0;
+};
+
+DeviceBlock generate_block(HipExecutor& hip, int32_t n, int64_t r0, int64_t r1,
+                           int part, bool with_diagonal)
+{
+  DeviceBlock b;
+  const int64_t nrows = r1 - r0;
+  b.rowptr = hip.alloc<int32_t>(nrows + 1);
+  throw_on_error(spmv_hip_poisson3d_count(hip.context(), n, r0, r1, part,
+                                          b.rowptr, &b.nnz, nullptr),
+                 "spmv_hip_poisson3d_count");
+  b.colind = hip.alloc<int32_t>(b.nnz);
+  b.values = hip.alloc<double>(b.nnz);
+  if (with_diagonal)
+    b.diagonal = hip.alloc<double>(nrows);
+  throw_on_error(spmv_hip_poisson3d_fill_f64(hip.context(), n, r0, r1, part,
+                                             b.rowptr, b.colind, b.values,
+                                             b.diagonal, nullptr),
+                 "spmv_hip_poisson3d_fill_f64");
+  return b;
+}
+
+} // namespace
+
+template <typename T>
+Matrix<T>* Matrix<T>::create_poisson3d(std::shared_ptr<const Comm> comm,
+                                       std::shared_ptr<DeviceExecutor> exec,
+                                       int32_t n, bool symmetric,
+                                       CommunicationModel cm)
+{
+  if constexpr (!std::is_same<T, double>::value) {
+    throw std::runtime_error("create_poisson3d is available for double only");
+  } else {
+    auto* hip = dynamic_cast<HipExecutor*>(exec.get());
+    if (!hip)
+      throw std::runtime_error("create_poisson3d needs a HipExecutor");
+    const int P = comm->size(), me = comm->rank();
+    const int64_t N = static_cast<int64_t>(n) * n * n;
+    const std::vector<int64_t> ranges = owner_ranges(P, N);
+    const int64_t r0 = ranges[me], r1 = ranges[me + 1];
+    int64_t gb = 0, ga = 0;
+    throw_on_error(spmv_hip_poisson3d_ghosts(n, r0, r1, &gb, &ga),
+                   "spmv_hip_poisson3d_ghosts (each rank needs >= n^2 rows)");
+    std::vector<int64_t> ghosts;
+    ghosts.reserve(gb + ga);
+    for (int64_t g = r0 - gb; g < r0; ++g)
+      ghosts.push_back(g);
+    for (int64_t g = r1; g < r1 + ga; ++g)
+      ghosts.push_back(g);
+    const int32_t nrows = static_cast<int32_t>(r1 - r0);
+    const int32_t ncols_all = static_cast<int32_t>(nrows + gb + ga);
+
+    auto col_map = std::make_shared<L2GMap>(comm, nrows, ghosts, exec, cm);
+    auto row_map = std::make_shared<L2GMap>(comm, nrows, std::vector<int64_t>(),
+                                            exec);
+    std::unique_ptr<Matrix<T>> A(new Matrix<T>());
+    A->_exec = exec;
+    A->_col_map = col_map;
+    A->_row_map = row_map;
+    A->_symmetric = symmetric;
+    using Adopt = typename CSRMatrix<T>::AdoptDevice;
+    auto adopt = [&](const DeviceBlock& b, int32_t ncols, bool sym) {
+      return new CSRMatrix<T>(Adopt{}, exec, nrows, ncols, b.nnz, b.rowptr,
+                              b.colind, b.values, b.diagonal, sym);
+    };
+    if (symmetric) {
+      DeviceBlock L = generate_block(*hip, n, r0, r1,
+                                     SPMV_HIP_PART_LOCAL_LOWER, true);
+      DeviceBlock R = generate_block(*hip, n, r0, r1, SPMV_HIP_PART_REMOTE,
+                                     false);
+      A->_mat_local.reset(adopt(L, ncols_all, true));
+      A->_mat_remote.reset(adopt(R, ncols_all, false));
+      A->_nnz = 2 * L.nnz + R.nnz + nrows; // Matrix.cpp:443-444
+    } else if (nonblocking(cm)) {
+      DeviceBlock L = generate_block(*hip, n, r0, r1, SPMV_HIP_PART_LOCAL,
+                                     false);
+      DeviceBlock R = generate_block(*hip, n, r0, r1, SPMV_HIP_PART_REMOTE,
+                                     false);
+      A->_mat_local.reset(adopt(L, nrows, false));
+      A->_mat_remote.reset(adopt(R, ncols_all, false));
+      A->_nnz = L.nnz + R.nnz;
+    } else {
+      DeviceBlock B = generate_block(*hip, n, r0, r1, SPMV_HIP_PART_ALL, false);
+      A->_mat_local.reset(adopt(B, ncols_all, false));
+      A->_nnz = B.nnz;
+    }
+    return A.release();
+  }
+}
+
+template class Matrix<float>;
+template class Matrix<double>;
+
+} // namespace spmv

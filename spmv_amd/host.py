@@ -1,0 +1,408 @@
+"""ctypes handles over the C facade (include/spmv_host_c.h) of the C++17 host
+mirror: spmv::HipExecutor, L2GMap, Matrix<double>, cg.
+
+Harness plumbing for tests/ and bench.py.  Method names follow the C++
+classes so the parity tests read like the reference's tests/test_spmv.cpp.
+Nothing here computes.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+P2P_BLOCKING, P2P_NONBLOCKING, COLLECTIVE_BLOCKING, COLLECTIVE_NONBLOCKING = 0, 1, 2, 3
+ONESIDED_PUT_ACTIVE, ONESIDED_PUT_PASSIVE, SHMEM, SHMEM_NODUP = 4, 5, 6, 7
+
+lib = _lib._load("libspmv_host.so")
+lib.spmvh_last_error.restype = C.c_char_p
+
+vp, i32, i64, f64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_size_t
+PTR = C.POINTER
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, vp, vp, vp, sz)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, vp, sz, C.c_int, PTR(C.c_int), vp,
+                          PTR(i32), PTR(i32), vp, PTR(i32), PTR(i32), vp)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, vp, vp, sz, vp)
+
+_PROTOS = {
+    "spmvh_exec_create": [C.c_int, PTR(vp)],
+    "spmvh_exec_destroy": [vp],
+    "spmvh_exec_alloc": [vp, sz, PTR(vp)],
+    "spmvh_exec_free": [vp, vp],
+    "spmvh_exec_memset": [vp, vp, C.c_int, sz],
+    "spmvh_exec_copy": [vp, vp, vp, sz],
+    "spmvh_exec_copy_from_host": [vp, vp, vp, sz],
+    "spmvh_exec_copy_to_host": [vp, vp, vp, sz],
+    "spmvh_exec_synchronize": [vp],
+    "spmvh_exec_num_cus": [vp, PTR(C.c_int)],
+    "spmvh_exec_device_type": [vp, PTR(C.c_int)],
+    "spmvh_exec_context": [vp, PTR(vp)],
+    "spmvh_host_executor_rejects_compute": [],
+    "spmvh_comm_self": [PTR(vp)],
+    "spmvh_rccl_unique_id": [vp],
+    "spmvh_comm_rccl": [vp, C.c_int, C.c_int, vp, PTR(vp)],
+    "spmvh_comm_callback": [C.c_int, C.c_int, ALLGATHER_FN, EXCHANGE_FN,
+                            ALLREDUCE_FN, vp, PTR(vp)],
+    "spmvh_comm_destroy": [vp],
+    "spmvh_matrix_create": [vp, vp, vp, vp, vp, i64, i64, vp, i64, C.c_int,
+                            C.c_int, PTR(vp)],
+    "spmvh_matrix_create_poisson3d": [vp, vp, i32, C.c_int, C.c_int, PTR(vp)],
+    "spmvh_matrix_destroy": [vp],
+    "spmvh_matrix_rows": [vp, PTR(C.c_int)],
+    "spmvh_matrix_cols": [vp, PTR(C.c_int)],
+    "spmvh_matrix_non_zeros": [vp, PTR(i64)],
+    "spmvh_matrix_format_size": [vp, PTR(sz)],
+    "spmvh_matrix_symmetric": [vp, PTR(C.c_int)],
+    "spmvh_matrix_blocks": [vp, PTR(i64)],
+    "spmvh_matrix_update": [vp, vp],
+    "spmvh_matrix_update_finalise": [vp, vp],
+    "spmvh_matrix_mult": [vp, vp, vp],
+    "spmvh_split_create": [vp, vp, vp, i64, i64, i64, i64, vp, i64, C.c_int,
+                           C.c_int, PTR(vp), PTR(i64)],
+    "spmvh_split_get": [vp, C.c_int, vp, vp, vp],
+    "spmvh_split_extra": [vp, vp, vp],
+    "spmvh_split_destroy": [vp],
+    "spmvh_l2g_sizes": [vp, PTR(i32), PTR(i32), PTR(i64), PTR(i64),
+                        PTR(C.c_int), PTR(C.c_int), PTR(C.c_int), PTR(C.c_int)],
+    "spmvh_l2g_ghosts": [vp, vp],
+    "spmvh_l2g_plan": [vp, vp, vp, vp, vp, vp, vp],
+    "spmvh_l2g_global_to_local": [vp, i64, PTR(i32)],
+    "spmvh_l2g_create": [vp, vp, C.c_int, i64, vp, i64, C.c_int, PTR(vp)],
+    "spmvh_l2g_destroy": [vp],
+    "spmvh_l2g_map_sizes": [vp, PTR(C.c_int), PTR(C.c_int), PTR(C.c_int)],
+    "spmvh_l2g_map_plan": [vp, vp, vp, vp, vp, vp, vp],
+    "spmvh_l2g_map_update": [vp, vp],
+    "spmvh_cg": [vp, vp, vp, vp, vp, C.c_int, f64, PTR(C.c_int), vp],
+}
+for _n, _a in _PROTOS.items():
+    _f = getattr(lib, _n)
+    _f.argtypes = _a
+    _f.restype = C.c_int
+HOST_SYMBOLS = tuple(_PROTOS) + ("spmvh_last_error",)
+
+
+class SpmvHostError(RuntimeError):
+    pass
+
+
+def call(name, *args):
+    if getattr(lib, name)(*args) != 0:
+        raise SpmvHostError(f"{name}: {lib.spmvh_last_error().decode()}")
+
+
+def _np_ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class HipExecutor:
+    """spmv::HipExecutor::create(device_id, HostExecutor::create())"""
+
+    def __init__(self, device_id=0):
+        h = vp()
+        call("spmvh_exec_create", device_id, C.byref(h))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            call("spmvh_exec_destroy", self.h)
+            self.h = None
+
+    def alloc(self, count, dtype=np.float64):
+        p = vp()
+        call("spmvh_exec_alloc", self.h, int(count) * np.dtype(dtype).itemsize,
+             C.byref(p))
+        return p.value or 0
+
+    def free(self, ptr):
+        call("spmvh_exec_free", self.h, ptr)
+
+    def memset(self, ptr, value, nbytes):
+        call("spmvh_exec_memset", self.h, ptr, value, nbytes)
+
+    def copy(self, dst, src, nbytes):
+        call("spmvh_exec_copy", self.h, dst, src, nbytes)
+
+    def copy_from_host(self, dst, arr):
+        arr = np.ascontiguousarray(arr)
+        call("spmvh_exec_copy_from_host", self.h, dst, _np_ptr(arr), arr.nbytes)
+
+    def copy_to_host(self, src, count, dtype=np.float64):
+        out = np.empty(count, dtype)
+        call("spmvh_exec_copy_to_host", self.h, _np_ptr(out), src, out.nbytes)
+        return out
+
+    def synchronize(self):
+        call("spmvh_exec_synchronize", self.h)
+
+    @property
+    def num_cus(self):
+        n = C.c_int()
+        call("spmvh_exec_num_cus", self.h, C.byref(n))
+        return n.value
+
+    @property
+    def device_type(self):
+        t = C.c_int()
+        call("spmvh_exec_device_type", self.h, C.byref(t))
+        return t.value
+
+    @property
+    def context(self):
+        """spmv_hip_ctx* behind the executor (timing events in bench.py)."""
+        c = vp()
+        call("spmvh_exec_context", self.h, C.byref(c))
+        return c
+
+
+class Comm:
+    def __init__(self, h, keep=()):
+        self.h, self._keep = h, keep
+
+    @classmethod
+    def self_comm(cls):
+        h = vp()
+        call("spmvh_comm_self", C.byref(h))
+        return cls(h)
+
+    @classmethod
+    def rccl(cls, exec_, nranks, rank, unique_id):
+        h = vp()
+        buf = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
+        call("spmvh_comm_rccl", exec_.h, nranks, rank, buf, C.byref(h))
+        return cls(h)
+
+    @classmethod
+    def callback(cls, rank, nranks, allgather, exchange=None, allreduce=None):
+        """Transport supplied as Python callables (see spmv_host_c.h)."""
+        ag = ALLGATHER_FN(allgather)
+        ex = EXCHANGE_FN(exchange) if exchange else EXCHANGE_FN()
+        ar = ALLREDUCE_FN(allreduce) if allreduce else ALLREDUCE_FN()
+        h = vp()
+        call("spmvh_comm_callback", rank, nranks, ag, ex, ar, None, C.byref(h))
+        return cls(h, keep=(ag, ex, ar))
+
+    def close(self):
+        if self.h:
+            call("spmvh_comm_destroy", self.h)
+            self.h = None
+
+
+def rccl_unique_id():
+    buf = (C.c_ubyte * 128)()
+    call("spmvh_rccl_unique_id", buf)
+    return bytes(buf)
+
+
+class L2GPlanView:
+    """Plan arrays of an L2GMap (reference member names, no underscore)."""
+
+    def __init__(self, nn, ni, getter):
+        self.neighbours = np.zeros(nn, np.int32)
+        self.send_count = np.zeros(max(nn, 1), np.int32)
+        self.recv_count = np.zeros(max(nn, 1), np.int32)
+        self.send_offset = np.zeros(max(nn, 1) + 1, np.int32)
+        self.recv_offset = np.zeros(max(nn, 1) + 1, np.int32)
+        self.indexbuf = np.zeros(ni, np.int32)
+        getter(_np_ptr(self.neighbours), _np_ptr(self.send_count),
+               _np_ptr(self.recv_count), _np_ptr(self.send_offset),
+               _np_ptr(self.recv_offset), _np_ptr(self.indexbuf))
+        self.send_count = self.send_count[:nn]
+        self.recv_count = self.recv_count[:nn]
+        self.send_offset = self.send_offset[:nn + 1]
+        self.recv_offset = self.recv_offset[:nn + 1]
+
+
+class L2GMap:
+    """Stand-alone spmv::L2GMap (plan tests)."""
+
+    def __init__(self, comm, local_size, ghosts, exec_=None,
+                 cm=COLLECTIVE_BLOCKING):
+        g = np.ascontiguousarray(ghosts, dtype=np.int64)
+        h = vp()
+        call("spmvh_l2g_create", comm.h, exec_.h if exec_ else None,
+             0 if exec_ else 1, int(local_size), _np_ptr(g), len(g), cm,
+             C.byref(h))
+        self.h = h
+
+    def plan(self):
+        nn, ni, packs = C.c_int(), C.c_int(), C.c_int()
+        call("spmvh_l2g_map_sizes", self.h, C.byref(nn), C.byref(ni),
+             C.byref(packs))
+        v = L2GPlanView(nn.value, ni.value,
+                        lambda *a: call("spmvh_l2g_map_plan", self.h, *a))
+        v.packs = bool(packs.value)
+        return v
+
+    def update(self, x_ptr):
+        call("spmvh_l2g_map_update", self.h, x_ptr)
+
+    def close(self):
+        if self.h:
+            call("spmvh_l2g_destroy", self.h)
+            self.h = None
+
+
+class ColMapView:
+    """A.col_map() of a Matrix."""
+
+    def __init__(self, A):
+        self.A = A
+        ls, ng, gs, go = i32(), i32(), i64(), i64()
+        ov, nn, ni, pk = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        call("spmvh_l2g_sizes", A.h, C.byref(ls), C.byref(ng), C.byref(gs),
+             C.byref(go), C.byref(ov), C.byref(nn), C.byref(ni), C.byref(pk))
+        self._local_size, self._num_ghosts = ls.value, ng.value
+        self._global_size, self._global_offset = gs.value, go.value
+        self._overlapping, self._nn, self._ni = bool(ov.value), nn.value, ni.value
+        self.packs = bool(pk.value)
+
+    def local_size(self):
+        return self._local_size
+
+    def num_ghosts(self):
+        return self._num_ghosts
+
+    def global_size(self):
+        return self._global_size
+
+    def global_offset(self):
+        return self._global_offset
+
+    def overlapping(self):
+        return self._overlapping
+
+    def ghosts(self):
+        g = np.zeros(self._num_ghosts, np.int64)
+        call("spmvh_l2g_ghosts", self.A.h, _np_ptr(g))
+        return g
+
+    def global_to_local(self, i):
+        out = i32()
+        call("spmvh_l2g_global_to_local", self.A.h, int(i), C.byref(out))
+        return out.value
+
+    def plan(self):
+        return L2GPlanView(self._nn, self._ni,
+                           lambda *a: call("spmvh_l2g_plan", self.A.h, *a))
+
+    def update(self, x_ptr):
+        call("spmvh_matrix_update", self.A.h, x_ptr)
+
+    def update_finalise(self, x_ptr):
+        call("spmvh_matrix_update_finalise", self.A.h, x_ptr)
+
+
+class Matrix:
+    """spmv::Matrix<double>"""
+
+    def __init__(self, h):
+        self.h = h
+
+    @classmethod
+    def create_matrix(cls, comm, exec_, rowptr, colind, values, nrows_local,
+                      ncols_local, row_ghosts, col_ghosts, symmetric=False,
+                      cm=COLLECTIVE_BLOCKING):
+        assert len(row_ghosts) == 0
+        rp = np.ascontiguousarray(rowptr, np.int32)
+        ci = np.ascontiguousarray(colind, np.int32)
+        va = np.ascontiguousarray(values, np.float64)
+        cg = np.ascontiguousarray(col_ghosts, np.int64)
+        h = vp()
+        call("spmvh_matrix_create", comm.h, exec_.h, _np_ptr(rp), _np_ptr(ci),
+             _np_ptr(va), int(nrows_local), int(ncols_local), _np_ptr(cg),
+             len(cg), int(symmetric), cm, C.byref(h))
+        return cls(h)
+
+    @classmethod
+    def create_poisson3d(cls, comm, exec_, n, symmetric=False,
+                         cm=COLLECTIVE_BLOCKING):
+        h = vp()
+        call("spmvh_matrix_create_poisson3d", comm.h, exec_.h, n,
+             int(symmetric), cm, C.byref(h))
+        return cls(h)
+
+    def close(self):
+        if self.h:
+            call("spmvh_matrix_destroy", self.h)
+            self.h = None
+
+    def rows(self):
+        v = C.c_int()
+        call("spmvh_matrix_rows", self.h, C.byref(v))
+        return v.value
+
+    def cols(self):
+        v = C.c_int()
+        call("spmvh_matrix_cols", self.h, C.byref(v))
+        return v.value
+
+    def non_zeros(self):
+        v = i64()
+        call("spmvh_matrix_non_zeros", self.h, C.byref(v))
+        return v.value
+
+    def format_size(self):
+        v = sz()
+        call("spmvh_matrix_format_size", self.h, C.byref(v))
+        return v.value
+
+    def symmetric(self):
+        v = C.c_int()
+        call("spmvh_matrix_symmetric", self.h, C.byref(v))
+        return bool(v.value)
+
+    def blocks(self):
+        out = (i64 * 6)()
+        call("spmvh_matrix_blocks", self.h, out)
+        return dict(local=tuple(out[0:3]), remote=tuple(out[3:6]))
+
+    def col_map(self):
+        return ColMapView(self)
+
+    def mult(self, x_ptr, y_ptr):
+        call("spmvh_matrix_mult", self.h, x_ptr, y_ptr)
+
+
+def split_rows(rowptr, colind, values, nrows_local, ncols_local, row_offset,
+               col_offset, col_ghosts, symmetric, cm):
+    """Matrix<double>::split_rows: the host half of create_matrix (no GPU)."""
+    rp = np.ascontiguousarray(rowptr, np.int32)
+    ci = np.ascontiguousarray(colind, np.int32)
+    va = np.ascontiguousarray(values, np.float64)
+    cg = np.ascontiguousarray(col_ghosts, np.int64)
+    h, sizes = vp(), (i64 * 8)()
+    call("spmvh_split_create", _np_ptr(rp), _np_ptr(ci), _np_ptr(va),
+         int(nrows_local), int(ncols_local), int(row_offset), int(col_offset),
+         _np_ptr(cg), len(cg), int(symmetric), cm, C.byref(h), sizes)
+    out = dict(nnz=sizes[7])
+    for which, name in ((0, "local"), (1, "remote")):
+        rows, cols, nnz = sizes[3 * which:3 * which + 3]
+        brp = np.zeros(rows + 1, np.int32)
+        bci = np.zeros(nnz, np.int32)
+        bva = np.zeros(nnz, np.float64)
+        call("spmvh_split_get", h, which, _np_ptr(brp), _np_ptr(bci),
+             _np_ptr(bva))
+        out[name] = (brp, bci, bva)
+        out[name + "_cols"] = cols
+    diag = np.zeros(nrows_local if symmetric else 0, np.float64)
+    ghosts = np.zeros(sizes[6], np.int64)
+    call("spmvh_split_extra", h, _np_ptr(diag) if symmetric else None,
+         _np_ptr(ghosts))
+    out["diagonal"] = diag if symmetric else None
+    out["ghosts"] = ghosts
+    call("spmvh_split_destroy", h)
+    return out
+
+
+def cg(comm, exec_, A, b_ptr, x_ptr, kmax, rtol, history=True):
+    """spmv::cg(comm, exec, A, b, x, kmax, rtol) -> (k, rnorm_history)"""
+    k = C.c_int()
+    hist = np.zeros(kmax + 1) if history else None
+    call("spmvh_cg", comm.h, exec_.h, A.h, b_ptr, x_ptr, kmax, float(rtol),
+         C.byref(k), _np_ptr(hist))
+    return k.value, (hist[:k.value + 1] if history else None)
+
+
+def host_executor_rejects_compute():
+    return lib.spmvh_host_executor_rejects_compute() == 0
