@@ -8,8 +8,8 @@
 // CSR; tests compare the two at small n.  Setup only, untimed.
 //
 // Grid n^3, natural ordering i = x + n (y + n z), diagonal 6, off-diagonal
-// -1, neighbours outside the grid dropped.  Columns of a row are emitted in
-// ascending order: i-n^2, i-n, i-1, i, i+1, i+n, i+n^2.
+// -1, neighbours outside the grid dropped.  Within a row, entries are stored
+// in ascending local column order (owned columns, then ghosts).
 #include "common.h"
 
 #include <hipcub/hipcub.hpp>
@@ -90,14 +90,19 @@ __global__ __launch_bounds__(kBlock) void poisson_fill_kernel(
     int64_t cols[7];
     const int64_t i = g.r0 + k;
     const int c = stencil(g, i, cols);
+    // Entries are stored in ascending LOCAL column order, as create_matrix
+    // leaves them (Eigen setFromTriplets sorts each row): owned columns
+    // first, then ghost columns (which are numbered after the owned ones).
     int64_t pos = rowptr[k];
-    for (int e = 0; e < c; ++e) {
-      if (!keep(part, i, cols[e], g.r0, g.r1))
-        continue;
-      colind[pos] = local_col(g, cols[e]);
-      values[pos] = (cols[e] == i) ? 6.0 : -1.0;
-      ++pos;
-    }
+    for (int pass = 0; pass < 2; ++pass)
+      for (int e = 0; e < c; ++e) {
+        const bool owned = cols[e] >= g.r0 && cols[e] < g.r1;
+        if (owned != (pass == 0) || !keep(part, i, cols[e], g.r0, g.r1))
+          continue;
+        colind[pos] = local_col(g, cols[e]);
+        values[pos] = (cols[e] == i) ? 6.0 : -1.0;
+        ++pos;
+      }
     if (diagonal)
       diagonal[k] = 6.0;
   }

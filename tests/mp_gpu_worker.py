@@ -1,0 +1,132 @@
+"""Worker for tests/test_gpu_matrix.py::test_multirank_on_one_gpu.
+
+Every rank drives the C++ Matrix / L2GMap / cg on GPU 0 exactly as
+tests/test_spmv_cuda.cpp does on rank r of an MPI job; the transport is a
+CallbackComm over torch.distributed gloo (tests/dist_util.py).  Results are
+compared with the oracle's P-rank simulation.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import dist_util  # noqa: E402
+import oracle  # noqa: E402
+from spmv_amd import host, poisson  # noqa: E402
+from util import U, abs_bound  # noqa: E402
+
+EPS = np.finfo(float).eps
+
+
+def main():
+    rank, world = dist_util.init_gloo()
+    exec_ = host.HipExecutor(0)
+    ex, ar = dist_util.make_device_transport(exec_.context)
+    comm = host.Comm.callback(rank, world, dist_util.make_allgather(world), ex, ar)
+
+    kat = (np.array([0, 3, 6, 9, 13, 15], np.int32),
+           np.array([0, 1, 3, 0, 1, 3, 2, 3, 4, 0, 1, 2, 3, 2, 4], np.int64),
+           np.array([1, -2, -3, -2, 5, 4, 6, 4, -4, -3, 4, 4, 8, -4, 8], float))
+    rng = np.random.default_rng(7)
+    N = 53
+    dense = (rng.random((N, N)) < 0.12) | np.eye(N, dtype=bool)
+    dense = dense | dense.T
+    rp = np.concatenate([[0], np.cumsum(dense.sum(1))]).astype(np.int32)
+    ci = np.nonzero(dense)[1].astype(np.int64)
+    vals = rng.uniform(-1, 1, (N, N))
+    vals = (vals + vals.T) / 2
+    unstructured = (rp, ci, vals[dense])
+    cases = [("kat", kat), ("poisson6", poisson.poisson3d_csr(6)),
+             ("unstructured", unstructured)]
+
+    for name, (rp, ci, va) in cases:
+        N = len(rp) - 1
+        x = oracle.gaussian_x_fast(N) if name != "kat" else oracle.gaussian_x(N)
+        y_seq = oracle.csr_spmv(rp, ci.astype(np.int32), va, x)
+        norm_ref = float(np.sqrt(np.sum(y_seq * y_seq)))
+        ranges = oracle.owner_ranges(world, N)
+        r0, r1 = int(ranges[rank]), int(ranges[rank + 1])
+        lrp, lci, lva, ghosts = oracle.localise_rows(rp, ci, va, r0, r1)
+        for symmetric in (False, True):
+            for cm in (host.P2P_BLOCKING, host.P2P_NONBLOCKING):
+                # --- tests/test_spmv_cuda.cpp:127-160 ---
+                A = host.Matrix.create_matrix(comm, exec_, lrp, lci, lva,
+                                              r1 - r0, r1 - r0, [], ghosts,
+                                              symmetric, cm)
+                l2g = A.col_map()
+                assert l2g.local_size() == r1 - r0
+                assert l2g.num_ghosts() == len(ghosts)
+                assert l2g.global_size() == N and l2g.global_offset() == r0
+                d_y = exec_.alloc(r1 - r0)
+                exec_.memset(d_y, 0, 8 * (r1 - r0))
+                d_x = exec_.alloc(l2g.local_size() + l2g.num_ghosts())
+                exec_.copy_from_host(d_x, x[r0:r1])
+                l2g.update(d_x)
+                A.mult(d_x, d_y)
+                exec_.synchronize()
+                # the halo put the owners' values into the ghost tail
+                xs = exec_.copy_to_host(d_x, l2g.local_size() + l2g.num_ghosts())
+                assert np.array_equal(xs[r1 - r0:], x[ghosts])
+                y = dist_util.gather_concat(exec_.copy_to_host(d_y, r1 - r0))
+                y_ref = oracle.dist_spmv(world, rp, ci, va, x, symmetric, cm)
+                norm = float(np.sqrt(np.sum(y * y)))
+                if symmetric:
+                    assert np.all(np.abs(y - y_seq) <= 16 * U * abs_bound(rp, ci, va, x)), name
+                    assert abs(norm - norm_ref) <= 1e-14 * norm_ref
+                else:  # bit-exact against the oracle's P-rank simulation
+                    assert np.array_equal(y, y_ref), (name, cm)
+                    assert abs(norm - norm_ref) <= 4 * EPS * norm_ref
+                A.close()
+                exec_.free(d_x), exec_.free(d_y)
+
+    # device-generated Poisson blocks, slab partition (>= n^2 rows per rank)
+    n = 8
+    N = n ** 3
+    rp, ci, va = poisson.poisson3d_csr(n)
+    x = oracle.gaussian_x_fast(N)
+    y_seq = oracle.csr_spmv(rp, ci.astype(np.int32), va, x)
+    ranges = oracle.owner_ranges(world, N)
+    r0, r1 = int(ranges[rank]), int(ranges[rank + 1])
+    for symmetric in (False, True):
+        for cm in (host.P2P_BLOCKING, host.P2P_NONBLOCKING):
+            A = host.Matrix.create_poisson3d(comm, exec_, n, symmetric, cm)
+            l2g = A.col_map()
+            pl = l2g.plan()
+            assert not l2g.packs, "slab halo must take the direct-send path"
+            assert len(pl.neighbours) == (1 if rank in (0, world - 1) else 2)
+            d_x = exec_.alloc(l2g.local_size() + l2g.num_ghosts())
+            d_y = exec_.alloc(r1 - r0)
+            exec_.copy_from_host(d_x, x[r0:r1])
+            l2g.update(d_x)
+            A.mult(d_x, d_y)
+            y = dist_util.gather_concat(exec_.copy_to_host(d_y, r1 - r0))
+            if symmetric:
+                assert np.all(np.abs(y - y_seq) <= 16 * U * abs_bound(rp, ci, va, x))
+            else:
+                assert np.array_equal(
+                    y, oracle.dist_spmv(world, rp, ci, va, x, False, cm))
+            # CG on the distributed matrix vs the oracle's P-rank CG
+            b = oracle.csr_spmv(rp, ci.astype(np.int32), va, np.ones(N))
+            x_ref, k_ref, hist_ref = oracle.dist_cg(world, rp, ci, va, b, 100,
+                                                    1e-10, symmetric, cm)
+            d_b, d_s = exec_.alloc(r1 - r0), exec_.alloc(r1 - r0)
+            exec_.copy_from_host(d_b, b[r0:r1])
+            k, hist = host.cg(comm, exec_, A, d_b, d_s, 100, 1e-10)
+            xs = dist_util.gather_concat(exec_.copy_to_host(d_s, r1 - r0))
+            assert abs(k - k_ref) <= 1 and k < 100, (k, k_ref)
+            m = min(k, k_ref, 50)
+            assert np.allclose(hist[:m + 1], hist_ref[:m + 1], rtol=1e-6)
+            assert np.linalg.norm(xs - x_ref) <= 1e-8 * np.linalg.norm(x_ref)
+            A.close()
+            for p in (d_x, d_y, d_b, d_s):
+                exec_.free(p)
+    comm.close()
+    exec_.close()
+    print(f"rank {rank}/{world}: multirank OK", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -314,33 +314,37 @@ def test_dot_and_fill(ctx):
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("n,P", [(4, 1), (6, 1), (8, 2), (8, 4), (9, 3), (16, 8)])
 def test_device_poisson_matches_host(ctx, n, P):
+    """The device generator writes exactly the blocks create_matrix builds
+    from the host CSR (oracle.create_matrix = spmv/Matrix.cpp:295-480)."""
     N = n ** 3
     ranges = poisson.owner_ranges(P, N)
+    grp, gci, gva = poisson.poisson3d_csr(n)
     for r in range(P):
         r0, r1 = int(ranges[r]), int(ranges[r + 1])
-        lrp, lci, lva, ghosts = oracle.localise_rows(
-            *poisson.poisson3d_csr(n), r0, r1)
+        lrp, lci, lva, ghosts = oracle.localise_rows(grp, gci, gva, r0, r1)
         nloc = r1 - r0
-        rows = np.repeat(np.arange(nloc), np.diff(lrp))
-        sel = {hip.PART_ALL: np.ones(len(lci), bool),
-               hip.PART_LOCAL: lci < nloc,
-               hip.PART_REMOTE: lci >= nloc,
-               hip.PART_LOCAL_LOWER: (lci < nloc) & (lci < rows)}
-        for part, m in sel.items():
+        single = oracle.create_matrix(r, ranges, ranges, lrp, lci, lva, ghosts,
+                                      False, oracle.P2P_BLOCKING)
+        split = oracle.create_matrix(r, ranges, ranges, lrp, lci, lva, ghosts,
+                                     False, oracle.P2P_NONBLOCKING)
+        sym = oracle.create_matrix(r, ranges, ranges, lrp, lci, lva, ghosts,
+                                   True, oracle.P2P_BLOCKING)
+        expect = {hip.PART_ALL: single["local"], hip.PART_LOCAL: split["local"],
+                  hip.PART_REMOTE: split["remote"],
+                  hip.PART_LOCAL_LOWER: sym["local"]}
+        for part, (erp, eci, eva) in expect.items():
             blk = hip.poisson3d_block(ctx, n, r0, r1, part,
                                       with_diagonal=(part == hip.PART_LOCAL_LOWER))
             assert blk.ghosts_below + blk.ghosts_above == len(ghosts)
-            exp_rp = np.zeros(nloc + 1, np.int64)
-            np.add.at(exp_rp, rows[m] + 1, 1)
-            exp_rp = np.cumsum(exp_rp)
-            assert blk.nnz == int(m.sum())
+            assert blk.nnz == len(eva)
             if blk.nnz:  # an empty block owns no arrays (csr_matrix.cpp:34)
-                assert np.array_equal(blk.rowptr.numpy(), exp_rp)
-                assert np.array_equal(blk.colind.numpy(), lci[m])
-                assert np.array_equal(blk.values.numpy(), lva[m])
+                assert np.array_equal(blk.rowptr.numpy(), erp)
+                assert np.array_equal(blk.colind.numpy(), eci)
+                assert np.array_equal(blk.values.numpy(), eva)
             if blk.diagonal is not None:
-                assert np.array_equal(blk.diagonal.numpy(), np.full(nloc, 6.0))
+                assert np.array_equal(blk.diagonal.numpy(), sym["diagonal"])
             blk.free()
+        assert np.array_equal(sym["remote"][1], split["remote"][1])
 
 
 # ---------------------------------------------------------------------------

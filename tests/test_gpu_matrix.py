@@ -1,0 +1,191 @@
+"""GPU parity tests of the C++ host mirror (HipExecutor / Matrix / L2GMap /
+cg) through its C facade.  The single-rank tests follow the reference's
+tests/test_spmv_cuda.cpp step by step; the multi-rank ones launch one process
+per rank (gloo transport, several ranks on the one GPU of the test box)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+from spmv_amd import hip, host, poisson
+from util import U, abs_bound
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EPS = np.finfo(float).eps
+CMS = [host.P2P_BLOCKING, host.P2P_NONBLOCKING, host.COLLECTIVE_BLOCKING,
+       host.COLLECTIVE_NONBLOCKING]
+
+
+@pytest.fixture(scope="module")
+def exec_():
+    e = host.HipExecutor(0)
+    yield e
+    e.synchronize()
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def comm():
+    c = host.Comm.self_comm()
+    yield c
+    c.close()
+
+
+def essentially_equal(a, b, eps):  # tests/test_spmv.cpp:20-23
+    return abs(a - b) <= min(abs(a), abs(b)) * eps
+
+
+def spmv_like_reference_test(exec_, comm, rowptr, colind, values, x, symmetric,
+                             cm):
+    """tests/test_spmv_cuda.cpp:118-160 on one rank."""
+    N = len(rowptr) - 1
+    A = host.Matrix.create_matrix(comm, exec_, rowptr, colind, values, N, N,
+                                  [], [], symmetric, cm)
+    l2g = A.col_map()
+    d_y = exec_.alloc(N)
+    exec_.memset(d_y, 0, 8 * N)
+    d_x = exec_.alloc(l2g.local_size() + l2g.num_ghosts())
+    exec_.copy_from_host(d_x, x)
+    l2g.update(d_x)
+    exec_.synchronize()
+    A.mult(d_x, d_y)
+    exec_.synchronize()
+    y = exec_.copy_to_host(d_y, N)
+    meta = dict(rows=A.rows(), cols=A.cols(), nnz=A.non_zeros(),
+                symmetric=A.symmetric(), fmt=A.format_size(), blocks=A.blocks())
+    A.close()
+    exec_.free(d_y), exec_.free(d_x)
+    return y, meta
+
+
+@pytest.mark.parametrize("symmetric", [False, True])
+@pytest.mark.parametrize("cm", CMS)
+def test_kat_like_reference(exec_, comm, symmetric, cm):
+    k = json.load(open(os.path.join(ROOT, "tests", "golden", "kat.json")))
+    y, meta = spmv_like_reference_test(exec_, comm, k["rowptr"], k["colind"],
+                                       k["values"], np.array(k["x"]),
+                                       symmetric, cm)
+    norm = float(np.sqrt(np.sum(y * y)))
+    if symmetric:  # atomics: any order; reference tolerance relaxed to 1e-14
+        assert abs(norm - k["norm_y"]) <= 1e-14 * k["norm_y"]
+        assert np.all(np.abs(y - np.array(k["y"])) <= 16 * U * abs_bound(
+            np.array(k["rowptr"]), np.array(k["colind"]),
+            np.array(k["values"]), np.array(k["x"])))
+    else:          # the reference's own criterion, and bit-exact y
+        assert essentially_equal(norm, k["norm_y"], EPS)
+        assert list(y) == k["y"]
+    assert meta["rows"] == 5 and meta["nnz"] == 15
+    assert meta["symmetric"] == symmetric
+    assert exec_.device_type == 2  # DeviceType::gpu
+
+
+def test_unsupported_models_throw(exec_, comm):
+    for cm in (host.ONESIDED_PUT_ACTIVE, host.ONESIDED_PUT_PASSIVE, host.SHMEM,
+               host.SHMEM_NODUP):
+        with pytest.raises(host.SpmvHostError, match="no MI355X counterpart"):
+            host.Matrix.create_matrix(comm, exec_, [0, 1], [0], [1.0], 1, 1, [],
+                                      [], False, cm)
+
+
+@pytest.mark.parametrize("n", [5, 12])
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_poisson_host_vs_device_generator(exec_, comm, n, symmetric):
+    N = n ** 3
+    rp, ci, va = poisson.poisson3d_csr(n)
+    x = oracle.gaussian_x_fast(N)
+    y_ref = oracle.csr_spmv(rp, ci.astype(np.int32), va, x)
+    bound = 16 * U * abs_bound(rp, ci, va, x)
+    for cm in (host.P2P_BLOCKING, host.P2P_NONBLOCKING):
+        y, meta = spmv_like_reference_test(exec_, comm, rp, ci, va, x,
+                                           symmetric, cm)
+        if symmetric:
+            assert np.all(np.abs(y - y_ref) <= bound)
+        else:
+            assert np.array_equal(y, y_ref)
+        A = host.Matrix.create_poisson3d(comm, exec_, n, symmetric, cm)
+        assert (A.rows(), A.non_zeros(), A.format_size()) == (
+            meta["rows"], meta["nnz"], meta["fmt"])
+        assert A.blocks() == meta["blocks"]
+        d_x, d_y = exec_.alloc(N), exec_.alloc(N)
+        exec_.copy_from_host(d_x, x)
+        A.col_map().update(d_x)
+        A.mult(d_x, d_y)
+        y2 = exec_.copy_to_host(d_y, N)
+        if symmetric:
+            assert np.all(np.abs(y2 - y_ref) <= bound)
+        else:
+            assert np.array_equal(y2, y_ref)
+        A.close()
+        exec_.free(d_x), exec_.free(d_y)
+
+
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_cg_matches_oracle(exec_, comm, symmetric):
+    """spmv::cg vs oracle.cg (spmv/cg.cpp:21-98): same k (+-1), residual
+    history to 1e-6 over the first 50 iterations, x to 1e-8."""
+    n = 14
+    N = n ** 3
+    rp, ci, va = poisson.poisson3d_csr(n)
+    ci32 = ci.astype(np.int32)
+    for rhs in ("A*ones", "gaussian"):
+        b = (oracle.csr_spmv(rp, ci32, va, np.ones(N)) if rhs == "A*ones"
+             else oracle.gaussian_x_fast(N))
+        x_ref, k_ref, hist_ref = oracle.cg(rp, ci32, va, b, 100, 1e-10)
+        A = host.Matrix.create_matrix(comm, exec_, rp, ci, va, N, N, [], [],
+                                      symmetric, host.P2P_NONBLOCKING)
+        d_b, d_x = exec_.alloc(N), exec_.alloc(N)
+        exec_.copy_from_host(d_b, b)
+        k, hist = host.cg(comm, exec_, A, d_b, d_x, 100, 1e-10)
+        x = exec_.copy_to_host(d_x, N)
+        assert k_ref < 100 and abs(k - k_ref) <= 1
+        assert len(hist) == k + 1 and hist[-1] / hist[0] < 1e-10
+        m = min(k, k_ref, 50)
+        assert np.allclose(hist[:m + 1], hist_ref[:m + 1], rtol=1e-6, atol=0)
+        assert np.linalg.norm(x - x_ref) <= 1e-8 * np.linalg.norm(x_ref)
+        # kmax smaller than needed: returns kmax (cg.cpp:55), x = iterate kmax
+        k2, hist2 = host.cg(comm, exec_, A, d_b, d_x, 5, 1e-10)
+        x5_ref, k5, h5 = oracle.cg(rp, ci32, va, b, 5, 1e-10)
+        assert k2 == 5 == k5
+        assert np.allclose(hist2, h5, rtol=1e-9)
+        assert np.linalg.norm(exec_.copy_to_host(d_x, N) - x5_ref) <= 1e-11 * np.linalg.norm(x5_ref)
+        A.close()
+        exec_.free(d_b), exec_.free(d_x)
+
+
+def test_cg_early_convergence_with_long_queue(exec_, comm):
+    """kmax far beyond convergence: the device stops itself, the host stops
+    enqueuing at the next poll; k and x are those of the converged iterate."""
+    n = 6
+    N = n ** 3
+    rp, ci, va = poisson.poisson3d_csr(n)
+    b = oracle.csr_spmv(rp, ci.astype(np.int32), va, np.ones(N))
+    x_ref, k_ref, _ = oracle.cg(rp, ci.astype(np.int32), va, b, 2000, 1e-12)
+    A = host.Matrix.create_matrix(comm, exec_, rp, ci, va, N, N, [], [], False,
+                                  host.P2P_BLOCKING)
+    d_b, d_x = exec_.alloc(N), exec_.alloc(N)
+    exec_.copy_from_host(d_b, b)
+    k, hist = host.cg(comm, exec_, A, d_b, d_x, 2000, 1e-12)
+    assert abs(k - k_ref) <= 1 and k < 100
+    assert np.linalg.norm(exec_.copy_to_host(d_x, N) - 1.0) < 1e-9 * np.sqrt(N)
+    A.close()
+    exec_.free(d_b), exec_.free(d_x)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_multirank_on_one_gpu(world):
+    """N>1 path: one process per rank, all on GPU 0, halo + reductions over a
+    gloo-backed CallbackComm (tests/mp_gpu_worker.py)."""
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29800 + world),
+           os.path.join(ROOT, "tests", "mp_gpu_worker.py")]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert res.returncode == 0, res.stdout[-4000:] + res.stderr[-4000:]
+    assert res.stdout.count("multirank OK") == world
