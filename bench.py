@@ -1,0 +1,216 @@
+"""Benchmark of the hot path: fp64 CG on the 3-D Poisson CSR matrix.
+
+    python bench.py --gpus 1 --steps 100 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one CG iteration of spmv::cg (spmv/cg.cpp:55-86): halo update of
+p, SpMV (local + remote block) with the fused p.Ap, x/r update with the fused
+r.r, p update -- through the C++ host mirror and the HIP kernels.  The matrix
+is the 512^3 7-point Poisson matrix (BASELINE.json configs[2]/[4]) split into
+contiguous row slabs over the N ranks (strong scaling: total work is fixed),
+generated on the device, inputs resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0.  `value` = CG iterations per second of the
+whole job; `roofline` describes the dominant kernel (the local-block CSR
+SpMV), timed live with HIP events on its own stream inside the timed region;
+`cpu_baseline` is the oracle's OpenMP CG (= the reference's CPU path,
+restated) on a bounded sample, rank 0 at N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--n", type=int, default=512, help="grid points per side")
+    ap.add_argument("--symmetric", action="store_true",
+                    help="symmetric-CSR storage (BASELINE configs[3])")
+    ap.add_argument("--cm", default="p2p_nonblocking",
+                    choices=["p2p_blocking", "p2p_nonblocking"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-n", type=int, default=256,
+                    help="grid of the bounded CPU sample")
+    ap.add_argument("--cpu-iters", type=int, default=10)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, n_gpu, rows_gpu):
+    """Oracle OpenMP CG on a bounded sample, scaled by row count to the GPU
+    workload (a CG iteration is O(rows) for this matrix)."""
+    import numpy as np
+
+    import oracle
+    n = min(args.cpu_n, n_gpu)
+    rp, ci, va = oracle.poisson3d(n)
+    b = np.ones(n ** 3)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 64))
+    oracle.time_cg(rp, ci, va, b, 1, threads)  # first touch / warm-up
+    best = None
+    for t in sorted({threads, 1}, reverse=True):
+        secs, its = oracle.time_cg(rp, ci, va, b, args.cpu_iters, t)
+        rate = its / secs * (n ** 3) / rows_gpu
+        if best is None or rate > best[0]:
+            best = (rate, t, secs)
+    rate, t, secs = best
+    return {"value": rate, "unit": "iters/s", "cores": t, "kind": "port",
+            "sample": (f"oracle OpenMP CG (restated spmv/openmp path), "
+                       f"{n}^3 Poisson, {args.cpu_iters} iterations in "
+                       f"{secs:.2f} s on {t} threads, scaled by rows "
+                       f"{n ** 3}/{rows_gpu} to the {n_gpu}^3 workload")}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch "
+                         "N>1 through torch.distributed.run")
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from spmv_amd import _lib, host, poisson
+
+    torch.cuda.set_device(local_rank)
+    exec_ = host.HipExecutor(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+        ident = [host.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)
+        comm = host.Comm.rccl(exec_, world, rank, ident[0])
+    else:
+        comm = host.Comm.self_comm()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    n = args.n
+    N = n ** 3
+    cm = getattr(host, args.cm.upper())
+    A = host.Matrix.create_poisson3d(comm, exec_, n, args.symmetric, cm)
+    l2g = A.col_map()
+    M = l2g.local_size()
+    blocks = A.blocks()
+    nnz_local = blocks["local"][2]
+
+    # RHS b = Gaussian bump (demos/spmv.cpp:63-67) -- resident before timing
+    ctx = exec_.context
+    d_b, d_x = exec_.alloc(M), exec_.alloc(M)
+    _lib.call("spmv_hip_fill_gaussian_f64", ctx, N, l2g.global_offset(), M, d_b,
+              None)
+    ws = host.CgWorkspace(exec_)
+    exec_.synchronize()
+
+    # warm-up: W untimed iterations (also sizes the workspace, RCCL rings)
+    if args.warmup > 0:
+        host.cg_ex(comm, exec_, A, d_b, d_x, args.warmup, 0.0, ws)
+    torch.cuda.synchronize()
+    barrier()
+
+    # ---- timed region: exactly K iterations (rtol = 0 never converges) ----
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    k, _, spmv_ms, spmv_launches = host.cg_ex(comm, exec_, A, d_b, d_x,
+                                              args.steps, 0.0, ws,
+                                              time_spmv=True)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assert k == args.steps, (k, args.steps)
+
+    # max over ranks
+    if world > 1:
+        t = torch.tensor([elapsed, spmv_ms / max(spmv_launches, 1)],
+                         dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, spmv_ms_avg = float(t[0]), float(t[1])
+    else:
+        spmv_ms_avg = spmv_ms / max(spmv_launches, 1)
+
+    if rank == 0:
+        # algorithmic bytes of the dominant kernel on THIS rank (DESIGN.md,
+        # SURVEY 8d): entries*12 + (rows+1)*4 + x (cols*8) + y (rows*8)
+        rows_b, cols_b, nnz_b = blocks["local"]
+        if args.symmetric:
+            kernel_bytes = poisson.sym_csr_bytes(rows_b, nnz_b)
+            kernel = "csr_sym_rowblock_kernel<double>"
+        else:
+            kernel_bytes = poisson.csr_bytes(rows_b, cols_b, nnz_b)
+            kernel = "csr_rowblock_kernel<double> (local block, fused p.Ap)"
+        achieved = kernel_bytes / (spmv_ms_avg * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if os.path.exists(pmc) and world == 1 and n == 512 and not args.symmetric:
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "fp64 CG iters/sec (SpMV effective GB/s vs HBM roofline)",
+            "value": args.steps / elapsed,
+            "unit": "iters/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"poisson3d_{n}^3_csr_fp64_cg",
+                       "rows": N, "nnz": poisson.poisson3d_nnz(n),
+                       "storage": "symmetric-csr" if args.symmetric else "csr",
+                       "partition": f"row-slab x{world}",
+                       "halo": args.cm + " (RCCL send/recv on a side stream)"
+                       if world > 1 else "none (1 rank)"},
+            "roofline": {"bound": "hbm", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": kernel,
+                         "algorithmic_bytes_per_launch": kernel_bytes,
+                         "avg_launch_ms": spmv_ms_avg,
+                         "launches_timed": spmv_launches},
+            # whole-iteration effective bandwidth: SpMV + fused BLAS-1 minimum
+            # (9 vectors of 8 B per row)
+            "cg_gbs_per_gpu": (kernel_bytes + 9 * M * 8)
+            / (elapsed / args.steps) / 1e9,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, n, N)
+        print(json.dumps(out), flush=True)
+
+    ws.close()
+    A.close()
+    exec_.free(d_b), exec_.free(d_x)
+    comm.close()
+    exec_.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

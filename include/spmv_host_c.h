@@ -162,6 +162,17 @@ int spmvh_cg(spmvh_comm* comm, spmvh_exec* exec, spmvh_matrix* A,
              const double* b, double* x, int kmax, double rtol, int* num_its,
              double* rnorm_history);
 
+/* Same solve with the optional arguments of the C++ overload: a reusable
+ * spmv::CgWorkspace (may be NULL) and per-iteration HIP-event timing of the
+ * local-block SpMV kernel (time_spmv != 0 -> *spmv_ms_total, *spmv_launches). */
+typedef struct spmvh_cg_workspace spmvh_cg_workspace;
+int spmvh_cg_workspace_create(spmvh_exec* exec, spmvh_cg_workspace** ws);
+int spmvh_cg_workspace_destroy(spmvh_cg_workspace* ws);
+int spmvh_cg_ex(spmvh_comm* comm, spmvh_exec* exec, spmvh_matrix* A,
+                const double* b, double* x, int kmax, double rtol, int* num_its,
+                double* rnorm_history, spmvh_cg_workspace* ws, int time_spmv,
+                double* spmv_ms_total, int* spmv_launches);
+
 #ifdef __cplusplus
 }
 #endif

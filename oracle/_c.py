@@ -73,6 +73,12 @@ def lib():
     L.oracle_time_spmv.argtypes = [C.c_int32, C.c_int64, _i32p, _i32p, _f64p,
                                    C.c_void_p, _f64p, _f64p, C.c_int, C.c_int]
     L.oracle_time_spmv.restype = C.c_double
+    L.oracle_poisson3d.argtypes = [C.c_int32, _i32p, _i32p, _f64p]
+    L.oracle_poisson3d.restype = None
+    L.oracle_time_cg.argtypes = [C.c_int32, C.c_int64, _i32p, _i32p, _f64p,
+                                 _f64p, _f64p, C.c_int, C.c_int,
+                                 C.POINTER(C.c_int)]
+    L.oracle_time_cg.restype = C.c_double
     L.oracle_max_threads.argtypes = []
     L.oracle_max_threads.restype = C.c_int
     _lib = L
@@ -181,6 +187,27 @@ def time_spmv(rowptr, colind, values, x, diagonal=None, reps=10,
     out = np.zeros(n)
     return lib().oracle_time_spmv(n, len(va), rp, ci, va, _ptr(dg),
                                   _c(x, np.float64), out, reps, num_threads)
+
+
+def poisson3d(n):
+    """C generator of the benchmark matrix (fast path for the cpu_baseline)."""
+    N, nnz = n ** 3, 7 * n ** 3 - 6 * n ** 2
+    rp = np.zeros(N + 1, np.int32)
+    ci = np.zeros(nnz, np.int32)
+    va = np.zeros(nnz, np.float64)
+    lib().oracle_poisson3d(n, rp, ci, va)
+    return rp, ci, va
+
+
+def time_cg(rowptr, colind, values, b, kmax, num_threads):
+    """(seconds, iterations) of one fixed-length oracle CG solve."""
+    n = len(b)
+    x = np.zeros(n)
+    k = C.c_int()
+    t = lib().oracle_time_cg(n, len(values), rowptr, colind, values,
+                             _c(b, np.float64), x, kmax, num_threads,
+                             C.byref(k))
+    return t, k.value
 
 
 def max_threads():

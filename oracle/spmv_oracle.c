@@ -455,6 +455,43 @@ double oracle_time_spmv(int32_t num_rows, int64_t nnz, const int32_t* rowptr,
   return (t1 - t0) / (reps > 0 ? reps : 1);
 }
 
+/* Synthetic input of the cpu_baseline leg: the same 3-D 7-point Poisson
+ * matrix the product generates (not a reference
+ * function).  Caller provides rowptr[n^3+1], colind/values[7n^3-6n^2]. */
+void oracle_poisson3d(int32_t n, int32_t* rowptr, int32_t* colind,
+                      double* values)
+{
+  const int64_t n2 = (int64_t)n * n, N = n2 * n;
+  int64_t pos = 0;
+  rowptr[0] = 0;
+  for (int64_t i = 0; i < N; ++i) {
+    const int64_t x = i % n, y = (i / n) % n, z = i / n2;
+    if (z > 0) { colind[pos] = (int32_t)(i - n2); values[pos++] = -1.0; }
+    if (y > 0) { colind[pos] = (int32_t)(i - n); values[pos++] = -1.0; }
+    if (x > 0) { colind[pos] = (int32_t)(i - 1); values[pos++] = -1.0; }
+    colind[pos] = (int32_t)i; values[pos++] = 6.0;
+    if (x < n - 1) { colind[pos] = (int32_t)(i + 1); values[pos++] = -1.0; }
+    if (y < n - 1) { colind[pos] = (int32_t)(i + n); values[pos++] = -1.0; }
+    if (z < n - 1) { colind[pos] = (int32_t)(i + n2); values[pos++] = -1.0; }
+    rowptr[i + 1] = (int32_t)pos;
+  }
+}
+
+/* Wall-clock seconds of one oracle_cg call (cpu_baseline leg). */
+double oracle_time_cg(int32_t n, int64_t nnz, const int32_t* rowptr,
+                      const int32_t* colind, const double* values,
+                      const double* b, double* x, int kmax, int num_threads,
+                      int* iterations)
+{
+  double t0 = now_s();
+  int k = oracle_cg(n, nnz, rowptr, colind, values, NULL, b, x, kmax, 0.0, NULL,
+                    num_threads);
+  double t1 = now_s();
+  if (iterations)
+    *iterations = k;
+  return t1 - t0;
+}
+
 int oracle_max_threads(void)
 {
 #ifdef _OPENMP

@@ -103,6 +103,12 @@ double oracle_time_spmv(int32_t num_rows, int64_t nnz, const int32_t* rowptr,
                         const double* diagonal, const double* in, double* out,
                         int reps, int num_threads);
 
+void oracle_poisson3d(int32_t n, int32_t* rowptr, int32_t* colind,
+                      double* values);
+double oracle_time_cg(int32_t n, int64_t nnz, const int32_t* rowptr,
+                      const int32_t* colind, const double* values,
+                      const double* b, double* x, int kmax, int num_threads,
+                      int* iterations);
 int oracle_max_threads(void);
 
 #ifdef __cplusplus

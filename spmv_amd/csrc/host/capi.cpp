@@ -32,6 +32,10 @@ struct spmvh_l2g {
 struct spmvh_split {
   Matrix<double>::Split s;
 };
+struct spmvh_cg_workspace {
+  std::shared_ptr<HipExecutor> exec; // keeps the executor alive
+  std::unique_ptr<CgWorkspace> ws;
+};
 
 namespace
 {
@@ -559,6 +563,45 @@ int spmvh_cg(spmvh_comm* comm, spmvh_exec* exec, spmvh_matrix* A,
                   rnorm_history ? &hist : nullptr);
     if (rnorm_history)
       std::copy(hist.begin(), hist.end(), rnorm_history);
+  });
+}
+
+int spmvh_cg_workspace_create(spmvh_exec* exec, spmvh_cg_workspace** ws)
+{
+  return guarded([&] {
+    require(exec && ws, "NULL argument");
+    auto w = std::make_unique<spmvh_cg_workspace>();
+    w->exec = exec->hip;
+    w->ws.reset(new CgWorkspace(*exec->hip));
+    *ws = w.release();
+  });
+}
+
+int spmvh_cg_workspace_destroy(spmvh_cg_workspace* ws)
+{
+  return guarded([&] { delete ws; });
+}
+
+int spmvh_cg_ex(spmvh_comm* comm, spmvh_exec* exec, spmvh_matrix* A,
+                const double* b, double* x, int kmax, double rtol, int* num_its,
+                double* rnorm_history, spmvh_cg_workspace* ws, int time_spmv,
+                double* spmv_ms_total, int* spmv_launches)
+{
+  return guarded([&] {
+    require(comm && exec && A && num_its, "NULL argument");
+    std::vector<double> hist;
+    CgOptions opt;
+    opt.time_spmv = time_spmv != 0;
+    CgStats st;
+    *num_its = cg(*comm->comm, *exec->hip, *A->A, b, x, kmax, rtol,
+                  rnorm_history ? &hist : nullptr, &opt, &st,
+                  ws ? ws->ws.get() : nullptr);
+    if (rnorm_history)
+      std::copy(hist.begin(), hist.end(), rnorm_history);
+    if (spmv_ms_total)
+      *spmv_ms_total = st.spmv_ms_total;
+    if (spmv_launches)
+      *spmv_launches = st.spmv_launches;
   });
 }
 

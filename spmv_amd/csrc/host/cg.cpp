@@ -23,43 +23,102 @@
 namespace spmv
 {
 
+// ---------------------------------------------------------------------------
+CgWorkspace::~CgWorkspace() { release(); }
+
+void CgWorkspace::release()
+{
+  try {
+    if (stream)
+      _exec.synchronize_stream(stream);
+    _exec.destroy_event(poll_event);
+    if (stream)
+      _exec.destroy_stream(stream);
+    spmv_hip_cg_ws_destroy(ws);
+    _exec.free(r);
+    _exec.free(Ap);
+    _exec.free(x);
+    _exec.free(p);
+    _exec.free(dot2);
+    spmv_hip_host_free(_exec.context(), flags);
+  } catch (...) {
+  }
+  ws = nullptr;
+  r = Ap = x = p = dot2 = nullptr;
+  flags = nullptr;
+  stream = poll_event = nullptr;
+  kmax_cap = -1;
+  m_cap = n_cap = -1;
+}
+
+void CgWorkspace::ensure(int64_t M, int64_t N_padded, int kmax, int len)
+{
+  spmv_hip_ctx* ctx = _exec.context();
+  if (!stream) {
+    stream = _exec.create_stream();
+    poll_event = _exec.create_event();
+    void* mem = nullptr;
+    throw_on_error(spmv_hip_host_alloc(ctx, 2 * sizeof(int32_t), &mem),
+                   "spmv_hip_host_alloc");
+    flags = static_cast<int32_t*>(mem);
+    dot2 = _exec.alloc<double>(len);
+  }
+  if (kmax > kmax_cap) {
+    spmv_hip_cg_ws_destroy(ws);
+    ws = nullptr;
+    throw_on_error(spmv_hip_cg_ws_create(ctx, kmax, &ws),
+                   "spmv_hip_cg_ws_create");
+    kmax_cap = kmax;
+  }
+  if (M > m_cap) {
+    _exec.free(r);
+    _exec.free(Ap);
+    r = _exec.alloc<double>(M); // cg.cpp:39-40
+    Ap = _exec.alloc<double>(M);
+    m_cap = M;
+  }
+  if (N_padded > n_cap) {
+    _exec.free(x);
+    _exec.free(p);
+    x = _exec.alloc<double>(N_padded); // cg.cpp:41-42
+    p = _exec.alloc<double>(N_padded);
+    n_cap = N_padded;
+  }
+}
+
 namespace
 {
-struct Workspace {
+// restores the executor's stream when cg() leaves, also on exceptions
+struct StreamGuard {
   HipExecutor& exec;
-  spmv_hip_cg_ws* ws = nullptr;
-  double *r = nullptr, *Ap = nullptr, *x = nullptr, *p = nullptr;
-  double* dot2 = nullptr;   // partials of the remote block's p.Ap share
-  int32_t* flags = nullptr; // pinned {done, kstop}
-  void* stream = nullptr;
-  void* prev_stream = nullptr;
-  void* poll_event = nullptr;
-  explicit Workspace(HipExecutor& e) : exec(e) {}
-  ~Workspace()
+  void* prev;
+  ~StreamGuard()
   {
     try {
-      exec.set_stream(prev_stream);
-      if (stream)
-        exec.synchronize_stream(stream);
-      exec.destroy_event(poll_event);
-      if (stream)
-        exec.destroy_stream(stream);
-      spmv_hip_cg_ws_destroy(ws);
-      exec.free(r);
-      exec.free(Ap);
-      exec.free(x);
-      exec.free(p);
-      exec.free(dot2);
-      spmv_hip_host_free(exec.context(), flags);
+      exec.set_stream(prev);
     } catch (...) {
     }
+  }
+};
+
+struct EventList {
+  HipExecutor& exec;
+  std::vector<void*> ev;
+  ~EventList()
+  {
+    for (void* e : ev)
+      try {
+        exec.destroy_event(e);
+      } catch (...) {
+      }
   }
 };
 } // namespace
 
 int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
        const double* b, double* x, int kmax, double rtol,
-       std::vector<double>* rnorm_history, int poll_every)
+       std::vector<double>* rnorm_history, const CgOptions* options,
+       CgStats* stats, CgWorkspace* workspace)
 {
   std::shared_ptr<const L2GMap> col_l2g = A.col_map();
   std::shared_ptr<const L2GMap> row_l2g = A.row_map();
@@ -67,54 +126,44 @@ int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
     throw std::runtime_error("spmv::cg - Error: A.row_map() has ghost entries");
   if (kmax < 0)
     throw std::runtime_error("spmv::cg - Error: kmax < 0");
-  if (poll_every < 1)
-    poll_every = 1;
+  const CgOptions opt = options ? *options : CgOptions();
+  const int poll_every = opt.poll_every < 1 ? 1 : opt.poll_every;
 
   const int64_t M = row_l2g->local_size();
   const int64_t N_padded = col_l2g->local_size() + col_l2g->num_ghosts();
   spmv_hip_ctx* ctx = exec.context();
+  int len = 0;
+  throw_on_error(spmv_hip_dot_partials_len(ctx, &len),
+                 "spmv_hip_dot_partials_len");
 
-  Workspace w(exec);
-  w.prev_stream = exec.get_stream();
-  w.stream = exec.create_stream();
+  CgWorkspace own(exec);
+  CgWorkspace& w = workspace ? *workspace : own;
+  w.ensure(M, N_padded, kmax, len);
+
+  StreamGuard guard{exec, exec.get_stream()};
   { // order after whatever the caller enqueued (b may still be in flight)
     void* ev = exec.create_event();
-    exec.record_event(ev, w.prev_stream);
+    exec.record_event(ev, guard.prev);
     exec.stream_wait_event(w.stream, ev);
     exec.destroy_event(ev);
   }
   exec.set_stream(w.stream); // every launch below goes to this stream
 
-  throw_on_error(spmv_hip_cg_ws_create(ctx, kmax, &w.ws),
-                 "spmv_hip_cg_ws_create");
   throw_on_error(spmv_hip_cg_ws_reset(w.ws, rtol, nullptr),
                  "spmv_hip_cg_ws_reset");
-  int len = 0;
-  throw_on_error(spmv_hip_dot_partials_len(ctx, &len),
-                 "spmv_hip_dot_partials_len");
   double* partials = nullptr;
   throw_on_error(spmv_hip_cg_ws_partials(w.ws, &partials),
                  "spmv_hip_cg_ws_partials");
 
-  // work vectors (cg.cpp:39-45); x0 = 0 and the ghost tail of p are defined
-  // here instead of relying on fresh pages
-  w.r = exec.alloc<double>(M);
-  w.Ap = exec.alloc<double>(M);
-  w.x = exec.alloc<double>(N_padded);
-  w.p = exec.alloc<double>(N_padded);
-  w.dot2 = exec.alloc<double>(len);
+  // x0 = 0 and the ghost tail of p are defined here instead of relying on
+  // fresh pages; r = p = b (cg.cpp:44-45)
   exec.memset<double>(w.x, 0, N_padded);
   exec.memset<double>(w.p, 0, N_padded);
   exec.memset<double>(w.dot2, 0, len);
   exec.copy<double>(w.r, b, M);
   exec.copy<double>(w.p, b, M);
-  void* flags_mem = nullptr;
-  throw_on_error(spmv_hip_host_alloc(ctx, 2 * sizeof(int32_t), &flags_mem),
-                 "spmv_hip_host_alloc");
-  w.flags = static_cast<int32_t*>(flags_mem);
   w.flags[0] = 0;
   w.flags[1] = -1;
-  w.poll_event = exec.create_event();
 
   auto slot = [&](bool rr, int k) {
     double* s = nullptr;
@@ -131,14 +180,23 @@ int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
                  "spmv_hip_cg_reduce_rr");
   comm.allreduce_sum(slot(true, 0), 1, w.stream);
 
+  EventList timing{exec, {}};
   int k = 0;
   bool stopped = false;
   bool poll_pending = false;
   while (k < kmax && !stopped) { // cg.cpp:55
     ++k;
     col_l2g->update(w.p); // cg.cpp:59 (starts on the side stream)
+    void* ev1 = nullptr;
+    if (opt.time_spmv) {
+      void* ev0 = exec.create_event(true);
+      ev1 = exec.create_event(true);
+      timing.ev.push_back(ev0);
+      timing.ev.push_back(ev1);
+      exec.record_event(ev0, w.stream);
+    }
     // cg.cpp:60,63: Ap = A p with the p.Ap partials fused into the kernels
-    const bool fused = A.mult_dot(w.p, w.Ap, partials, w.dot2);
+    const bool fused = A.mult_dot(w.p, w.Ap, partials, w.dot2, ev1);
     if (fused) {
       // local + remote shares -> pAp[k]
       throw_on_error(spmv_hip_cg_reduce_pAp2(ctx, w.ws, k, w.dot2, nullptr),
@@ -185,13 +243,26 @@ int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
   exec.copy<double>(x, w.x, M); // cg.cpp:89
   exec.synchronize_stream(w.stream);
 
+  if (stats) {
+    stats->spmv_launches = 0;
+    stats->spmv_ms_total = 0.0;
+    for (size_t i = 0; i + 1 < timing.ev.size(); i += 2) {
+      float ms = 0.f;
+      throw_on_error(spmv_hip_event_elapsed_ms(ctx, timing.ev[i],
+                                               timing.ev[i + 1], &ms),
+                     "spmv_hip_event_elapsed_ms");
+      stats->spmv_ms_total += ms;
+      ++stats->spmv_launches;
+    }
+  }
+
   int k_final = k;
   if (w.flags[0] != 0) {
     k_final = w.flags[1];
   } else {
     // `done` is raised by the p.Ap reducer of the NEXT iteration; when the
-    // loop ends first, apply the same test (cg.cpp:80) to the last entry on
-    // the host.  Either way the value returned is the reference's k.
+    // loop ends first, apply the same test (cg.cpp:80) to the history on the
+    // host.  Either way the value returned is the reference's k.
     const double rnorm0 = std::sqrt(rr[0]);
     for (int j = 1; j <= k; ++j)
       if (std::sqrt(rr[j]) / rnorm0 < rtol) {

@@ -2,14 +2,53 @@
 // per-executor overload set of spmv::cg (spmv/cg.h, spmv/cuda/cg_cuda.h:30-32).
 #pragma once
 
+#include <cstdint>
 #include <vector>
 
 #include "comm.h"
 #include "executor.h"
 #include "matrix.h"
 
+struct spmv_hip_cg_ws;
+
 namespace spmv
 {
+
+// Work vectors + device scalars of one solve (cg.cpp:39-42 allocates and
+// frees them on every call).  Passing the same CgWorkspace to repeated cg()
+// calls keeps the allocations; it regrows itself when a call needs more.
+class CgWorkspace
+{
+public:
+  explicit CgWorkspace(HipExecutor& exec) : _exec(exec) {}
+  ~CgWorkspace();
+  CgWorkspace(const CgWorkspace&) = delete;
+  CgWorkspace& operator=(const CgWorkspace&) = delete;
+
+  // ---- internal to cg() ----
+  void ensure(int64_t M, int64_t N_padded, int kmax, int partials_len);
+  void release();
+
+  HipExecutor& _exec;
+  spmv_hip_cg_ws* ws = nullptr;
+  int kmax_cap = -1;
+  int64_t m_cap = -1, n_cap = -1;
+  double *r = nullptr, *Ap = nullptr, *x = nullptr, *p = nullptr;
+  double* dot2 = nullptr;   // partials of the remote block's p.Ap share
+  int32_t* flags = nullptr; // pinned {done, kstop}
+  void* stream = nullptr;   // compute stream of the solve
+  void* poll_event = nullptr;
+};
+
+struct CgOptions {
+  int poll_every = 16;    // host looks at the device's `done` flag this often
+  bool time_spmv = false; // bracket every local-block SpMV with HIP events
+};
+
+struct CgStats {
+  int spmv_launches = 0;    // local-block SpMV kernels timed
+  double spmv_ms_total = 0; // sum of their durations (HIP events, same stream)
+};
 
 // Unpreconditioned CG from x0 = 0 (spmv/cg.cpp:21-98).  `b` and `x` are
 // DEVICE pointers of A.row_map()->local_size() doubles (cuda/cg.cuda.cu:70).
@@ -24,6 +63,8 @@ namespace spmv
 // If rnorm_history != nullptr it receives ||r_0||, ..., ||r_k||.
 int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
        const double* b, double* x, int kmax, double rtol,
-       std::vector<double>* rnorm_history = nullptr, int poll_every = 16);
+       std::vector<double>* rnorm_history = nullptr,
+       const CgOptions* options = nullptr, CgStats* stats = nullptr,
+       CgWorkspace* workspace = nullptr);
 
 } // namespace spmv

@@ -154,26 +154,45 @@ void Matrix<T>::spmv_sym_overlap(T* x, T* y) const
 }
 
 template <typename T>
-bool Matrix<T>::mult_dot(T* x, T* y, double* dot_local,
-                         double* dot_remote) const
+bool Matrix<T>::mult_dot(T* x, T* y, double* dot_local, double* dot_remote,
+                         void* ev_local_done) const
 {
-  if (_symmetric || !std::is_same<T, double>::value) {
+  auto* hip = dynamic_cast<HipExecutor*>(_exec.get());
+  auto mark = [&] {
+    if (ev_local_done && hip)
+      hip->record_event(ev_local_done, hip->get_stream());
+  };
+  if (!std::is_same<T, double>::value) {
     mult(x, y);
+    mark();
+    return false;
+  }
+  if (_symmetric) {
+    // symmetric blocks cannot fuse the dot product (atomic scatter);
+    // same sequence as spmv_sym / spmv_sym_overlap
+    _mat_local->mult(1, x, 0, y);
+    mark();
+    if (_col_map->overlapping())
+      _col_map->update_finalise(x);
+    if (_mat_remote)
+      _mat_remote->mult(1, x, 1, y);
     return false;
   }
   if (!_col_map->overlapping()) {
-    if (!_mat_local->mult_dot(1, x, 0, y, dot_local)) {
+    const bool ok = _mat_local->mult_dot(1, x, 0, y, dot_local);
+    if (!ok)
       mult(x, y);
-      return false;
-    }
-    return true;
+    mark();
+    return ok;
   }
   // overlapping: local share, halo wait, remote share (same order as
   // spmv_overlap).  An empty local block cannot fuse -> plain path.
   if (!_mat_local->mult_dot(1, x, 0, y, dot_local)) {
     mult(x, y);
+    mark();
     return false;
   }
+  mark();
   _col_map->update_finalise(x);
   if (_mat_remote->non_zeros() > 0)
     _mat_remote->mult_dot(1, x, 1, y, dot_remote);

@@ -54,7 +54,10 @@ public:
   // spmv_hip_dot_partials_len() device doubles; their total is x[0:rows].y).
   // Returns false if it fell back to plain mult() (symmetric matrices): the
   // caller then computes the dot product itself.
-  bool mult_dot(T* x, T* y, double* dot_local, double* dot_remote) const;
+  // `ev_local_done` (optional, a HipExecutor event) is recorded right after
+  // the local block's kernel was enqueued -- benchmarks time that kernel.
+  bool mult_dot(T* x, T* y, double* dot_local, double* dot_remote,
+                void* ev_local_done = nullptr) const;
 
   std::shared_ptr<L2GMap> row_map() const { return _row_map; }
   std::shared_ptr<const L2GMap> col_map() const { return _col_map; }

@@ -74,6 +74,10 @@ _PROTOS = {
     "spmvh_l2g_map_plan": [vp, vp, vp, vp, vp, vp, vp],
     "spmvh_l2g_map_update": [vp, vp],
     "spmvh_cg": [vp, vp, vp, vp, vp, C.c_int, f64, PTR(C.c_int), vp],
+    "spmvh_cg_workspace_create": [vp, PTR(vp)],
+    "spmvh_cg_workspace_destroy": [vp],
+    "spmvh_cg_ex": [vp, vp, vp, vp, vp, C.c_int, f64, PTR(C.c_int), vp, vp,
+                    C.c_int, PTR(f64), PTR(C.c_int)],
 }
 for _n, _a in _PROTOS.items():
     _f = getattr(lib, _n)
@@ -402,6 +406,34 @@ def cg(comm, exec_, A, b_ptr, x_ptr, kmax, rtol, history=True):
     call("spmvh_cg", comm.h, exec_.h, A.h, b_ptr, x_ptr, kmax, float(rtol),
          C.byref(k), _np_ptr(hist))
     return k.value, (hist[:k.value + 1] if history else None)
+
+
+class CgWorkspace:
+    """spmv::CgWorkspace: work vectors kept across cg() calls."""
+
+    def __init__(self, exec_):
+        h = vp()
+        call("spmvh_cg_workspace_create", exec_.h, C.byref(h))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            call("spmvh_cg_workspace_destroy", self.h)
+            self.h = None
+
+
+def cg_ex(comm, exec_, A, b_ptr, x_ptr, kmax, rtol, workspace=None,
+          time_spmv=False, history=False):
+    """cg with the optional arguments: returns (k, history, spmv_ms_total,
+    spmv_launches)."""
+    k, n = C.c_int(), C.c_int()
+    ms = f64()
+    hist = np.zeros(kmax + 1) if history else None
+    call("spmvh_cg_ex", comm.h, exec_.h, A.h, b_ptr, x_ptr, kmax, float(rtol),
+         C.byref(k), _np_ptr(hist), workspace.h if workspace else None,
+         int(time_spmv), C.byref(ms), C.byref(n))
+    return (k.value, hist[:k.value + 1] if history else None, ms.value,
+            n.value)
 
 
 def host_executor_rejects_compute():
