@@ -106,14 +106,15 @@ __device__ __forceinline__ void clear_partials_tail(double* partials, int len)
 //   CH      = 16-byte value loads per lane per tile (tile = 256*CH*V entries)
 //   NT      = non-temporal loads for the read-once matrix stream
 //   ALIGNED = values 16-B / colind 8|16-B aligned => wide loads
-//   XCD     = remap row blocks so each XCD walks a contiguous chunk
+//   XCD     = group consecutive row blocks per XCD (see xcd_group below)
 // ---------------------------------------------------------------------------
 template <typename T, int CH, bool NT, bool ALIGNED, bool DOT, bool XCD>
 __global__ __launch_bounds__(kBlock) void csr_rowblock_kernel(
     int32_t num_rows, int64_t nnz, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ colind, const T* __restrict__ values, T alpha,
     const T* __restrict__ in, T beta, T* __restrict__ out,
-    double* __restrict__ dot_partials, int dot_len, int num_row_blocks)
+    double* __restrict__ dot_partials, int dot_len, int num_row_blocks,
+    int xcd_group)
 {
   constexpr int V = VecOf<T>::V;
   constexpr int TILE = kBlock * CH * V;
@@ -127,16 +128,24 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_kernel(
   const int t = threadIdx.x;
   double dot_acc = 0.0;
 
-  // XCD remap: blocks b and b+8 share an XCD (round-robin dispatch), so slot
-  // `it` is sent to row block (it%8)*per + it/8: each XCD walks a contiguous
-  // slice of the matrix.  Speed only, never correctness: the map is a
-  // bijection of [0, 8*per) and slots past the last row block are skipped.
-  const int per_xcd = (num_row_blocks + 7) >> 3;
-  const int num_slots = XCD ? 8 * per_xcd : num_row_blocks;
+  // XCD grouping.  Workgroups are dealt round-robin over the 8 XCDs (blocks
+  // b and b+8 share an XCD and its private L2), so in plain order every XCD
+  // touches every x window and pulls it through its own L2.  With a group
+  // size G the slot `it` is sent to row block
+  //     (it / 8G) * 8G + (it % 8) * G + (it / 8) % G,
+  // i.e. inside each run of 8G row blocks XCD k owns G consecutive ones: the
+  // +-1 / +-n neighbours of a row are then served by the same L2, while all
+  // XCDs still advance through the matrix together (the far +-n^2 planes stay
+  // resident in the Infinity Cache).  A bijection of [0, slots); placement
+  // only changes speed, never the result.
+  const int super = 8 * xcd_group;
+  const int num_slots
+      = XCD ? ((num_row_blocks + super - 1) / super) * super : num_row_blocks;
   for (int it = blockIdx.x; it < num_slots; it += gridDim.x) {
     int rb = it;
     if constexpr (XCD) {
-      rb = (it & 7) * per_xcd + (it >> 3);
+      const int q = it % super;
+      rb = (it - q) + (q & 7) * xcd_group + (q >> 3);
       if (rb >= num_row_blocks)
         continue; // uniform per workgroup
     }
@@ -526,9 +535,9 @@ struct spmv_hip_csr_plan {
   bool symmetric = false;
   int algo = SPMV_HIP_ALGO_ROWBLOCK;
   int lanes_per_row = 8;  // VECTOR
-  int chunks = 2;         // ROWBLOCK: 16-B loads per lane per tile (1, 2, 4)
-  int nontemporal = 1;    // ROWBLOCK: nt loads on the matrix stream
-  int xcd_remap = 0;      // ROWBLOCK: XCD-contiguous row-block order
+  int chunks = 1;         // ROWBLOCK: 16-B loads per lane per tile (1, 2, 4)
+  int nontemporal = 0;    // ROWBLOCK: nt loads on the matrix stream
+  int xcd_group = 0;      // ROWBLOCK: consecutive row blocks per XCD (0 = off)
   int blocks_per_cu = kBlocksPerCU;
   int32_t* row_list = nullptr; // ROWLIST: device list of non-empty rows
   int32_t num_listed = 0;
@@ -544,16 +553,16 @@ int launch_rowblock_x(const spmv_hip_csr_plan* pl, hipStream_t st, int grid,
                       double* dot)
 {
   const int len = pl->ctx->dot_blocks;
-  if (pl->xcd_remap)
+  if (pl->xcd_group > 0)
     hipLaunchKernelGGL((csr_rowblock_kernel<T, CH, NT, ALIGNED, DOT, true>),
                        dim3(grid), dim3(kBlock), 0, st, pl->num_rows, pl->nnz,
                        rowptr, colind, values, alpha, in, beta, out, dot, len,
-                       nrb);
+                       nrb, pl->xcd_group);
   else
     hipLaunchKernelGGL((csr_rowblock_kernel<T, CH, NT, ALIGNED, DOT, false>),
                        dim3(grid), dim3(kBlock), 0, st, pl->num_rows, pl->nnz,
                        rowptr, colind, values, alpha, in, beta, out, dot, len,
-                       nrb);
+                       nrb, 1);
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;
 }
@@ -856,8 +865,9 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
     plan->chunks = value;
   } else if (!strcmp(key, "nontemporal")) {
     plan->nontemporal = value != 0;
-  } else if (!strcmp(key, "xcd_remap")) {
-    plan->xcd_remap = value != 0;
+  } else if (!strcmp(key, "xcd_group")) {
+    SPMV_REQUIRE(value >= 0 && value <= 4096);
+    plan->xcd_group = value;
   } else if (!strcmp(key, "blocks_per_cu")) {
     SPMV_REQUIRE(value >= 1 && value <= kBlocksPerCU);
     plan->blocks_per_cu = value;

@@ -83,7 +83,7 @@ def test_kat_vector_and_symmetric(ctx):
 # Poisson + random ragged matrices, general kernels
 # ---------------------------------------------------------------------------
 KNOBS = [dict(), dict(chunks=1), dict(chunks=4), dict(nontemporal=0),
-         dict(xcd_remap=1), dict(chunks=4, xcd_remap=1, blocks_per_cu=2)]
+         dict(xcd_group=1), dict(xcd_group=16), dict(chunks=4, xcd_group=3, blocks_per_cu=2)]
 
 
 @pytest.mark.parametrize("n", [4, 9, 16, 33])

@@ -189,3 +189,27 @@ def test_multirank_on_one_gpu(world):
                          timeout=600)
     assert res.returncode == 0, res.stdout[-4000:] + res.stderr[-4000:]
     assert res.stdout.count("multirank OK") == world
+
+
+def test_rccl_comm_single_rank(exec_):
+    """RcclComm over a 1-rank communicator: exercises ncclGetUniqueId /
+    ncclCommInitRank / in-stream all-reduce / staged all-gather through the
+    library the process actually loaded (torch's bundled RCCL)."""
+    ident = host.rccl_unique_id()
+    assert len(ident) == 128 and any(ident)
+    comm = host.Comm.rccl(exec_, 1, 0, ident)
+    n = 9
+    N = n ** 3
+    rp, ci, va = poisson.poisson3d_csr(n)
+    A = host.Matrix.create_matrix(comm, exec_, rp, ci, va, N, N, [], [], False,
+                                  host.P2P_NONBLOCKING)
+    b = oracle.csr_spmv(rp, ci.astype(np.int32), va, np.ones(N))
+    d_b, d_x = exec_.alloc(N), exec_.alloc(N)
+    exec_.copy_from_host(d_b, b)
+    k, hist = host.cg(comm, exec_, A, d_b, d_x, 100, 1e-10)
+    x_ref, k_ref, _ = oracle.cg(rp, ci.astype(np.int32), va, b, 100, 1e-10)
+    assert abs(k - k_ref) <= 1
+    assert np.linalg.norm(exec_.copy_to_host(d_x, N) - x_ref) <= 1e-8 * np.linalg.norm(x_ref)
+    A.close()
+    exec_.free(d_b), exec_.free(d_x)
+    comm.close()

@@ -68,13 +68,14 @@ def main():
         src.free(), dst.free()
 
         variants = []
-        chunks = [2, 4] if args.quick else [1, 2, 4]
-        for ch, nt, xcd, bpc in itertools.product(chunks, [1, 0], [0, 1], [8, 4]):
-            if args.quick and (bpc == 4 or (nt == 0 and xcd == 1)):
+        chunks = [1, 2] if args.quick else [1, 2, 4]
+        for ch, nt, grp in itertools.product(chunks, [0, 1],
+                                             [0, 4, 16, 64, 256]):
+            if args.quick and nt == 1:
                 continue
             variants.append(("rowblock", dict(algo=hip.ALGO_ROWBLOCK, chunks=ch,
-                                              nontemporal=nt, xcd_remap=xcd,
-                                              blocks_per_cu=bpc)))
+                                              nontemporal=nt, xcd_group=grp,
+                                              blocks_per_cu=8)))
         variants.append(("scalar", dict(algo=hip.ALGO_SCALAR)))
         for lpr in (4, 8):
             variants.append(("vector", dict(algo=hip.ALGO_VECTOR,
@@ -88,8 +89,8 @@ def main():
                  gbs=bytes_csr / tmin / 1e6,
                  frac=bytes_csr / tmin / 1e6 / HBM_PEAK)
         # fused dot on the default variant
-        for k, v in dict(algo=hip.ALGO_ROWBLOCK, chunks=2, nontemporal=1,
-                         xcd_remap=0, blocks_per_cu=8).items():
+        for k, v in dict(algo=hip.ALGO_ROWBLOCK, chunks=1, nontemporal=0,
+                         xcd_group=16, blocks_per_cu=8).items():
             blk.set(k, v)
         tmin, tmed = time_ms(
             ctx, lambda: blk.mult(1.0, x.ptr, 0.0, y.ptr, dot_partials=part.ptr),
