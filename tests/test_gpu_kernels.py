@@ -208,10 +208,14 @@ def test_poisson_symmetric(ctx, n):
     for alpha, beta in [(1.0, 0.0), (0.5, 2.0), (1.0, 1.0)]:
         y0 = np.cos(np.arange(N))
         y_ref = oracle.csr_spmv_sym(lrp, lci, lva, dg, x, alpha, beta, y0)
-        y = run_spmv(ctx, lrp, lci, lva, x, N, N, alpha, beta,
-                     None if beta == 0 else y0, diagonal=dg, symmetric=True)
         b = 16 * U * abs_bound(rp, ci, va, x, alpha, beta, y0)
-        assert np.all(np.abs(y - y_ref) <= b)
+        # plain per-entry atomics (0) and LDS-window variants
+        for window, srows in ((0, 1024), (256, 512), (1024, 1024),
+                              (4096, 2048)):
+            y = run_spmv(ctx, lrp, lci, lva, x, N, N, alpha, beta,
+                         None if beta == 0 else y0, diagonal=dg, symmetric=True,
+                         knobs=dict(sym_window=window, sym_rows=srows))
+            assert np.all(np.abs(y - y_ref) <= b), (window, srows)
     # and against the general kernel on the full matrix
     y_gen = oracle.csr_spmv(rp, ci, va, x)
     y = run_spmv(ctx, lrp, lci, lva, x, N, N, diagonal=dg, symmetric=True)
@@ -231,14 +235,15 @@ def test_symmetric_random_and_diag_only(ctx):
     dg = rng.uniform(1, 2, n)
     x = rng.uniform(-1, 1, n)
     y_ref = oracle.csr_spmv_sym(lrp, lci, lva, dg, x, 1.5, 0.0)
-    y = run_spmv(ctx, lrp, lci, lva, x, n, n, 1.5, 0.0, diagonal=dg,
-                 symmetric=True)
     full = np.zeros(n)
     np.add.at(full, rows[keep], np.abs(lva * x[lci]))
     np.add.at(full, lci, np.abs(lva * x[rows[keep]]))
     full += np.abs(dg * x)
     terms = np.diff(lrp) + np.bincount(lci, minlength=n) + 1
-    assert np.all(np.abs(y - y_ref) <= (16 + terms) * U * 1.5 * full)
+    for window in (0, 256, 1024):  # targets both inside and below the window
+        y = run_spmv(ctx, lrp, lci, lva, x, n, n, 1.5, 0.0, diagonal=dg,
+                     symmetric=True, knobs=dict(sym_window=window))
+        assert np.all(np.abs(y - y_ref) <= (16 + terms) * U * 1.5 * full), window
     # diagonal-only symmetric block (nnz == 0, diagonal != NULL)
     y = run_spmv(ctx, None, None, None, x, n, n, 2.0, 0.0, diagonal=dg,
                  symmetric=True)

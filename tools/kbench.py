@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--out", default=None)
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--only", default=None, help="comma list of variants")
     args = ap.parse_args()
     ctx = hip.Context(0)
     results = []
@@ -103,11 +104,18 @@ def main():
         sym = hip.poisson3d_block(ctx, n, 0, N, hip.PART_LOCAL_LOWER,
                                   with_diagonal=True)
         bytes_sym = poisson.sym_csr_bytes(N, sym.nnz)
-        for nt in (1, 0):
+        for window, srows, nt in ((0, 1024, 0), (256, 512, 0), (512, 512, 0),
+                                  (256, 1024, 0), (512, 1024, 0),
+                                  (512, 1024, 1), (512, 2048, 0),
+                                  (768, 1024, 0)):
             sym.set("nontemporal", nt)
+            sym.set("sym_window", window)
+            sym.set("sym_rows", srows)
             tmin, tmed = time_ms(
                 ctx, lambda: sym.mult(1.0, x.ptr, 0.0, y.ptr), reps)
-            emit(n=n, variant="symmetric", knobs=dict(nontemporal=nt), ms=tmin,
+            emit(n=n, variant="symmetric",
+                 knobs=dict(sym_window=window, sym_rows=srows,
+                            nontemporal=nt), ms=tmin,
                  ms_med=tmed, gbs=bytes_sym / tmin / 1e6,
                  frac=bytes_sym / tmin / 1e6 / HBM_PEAK,
                  gbs_equiv_general=bytes_csr / tmin / 1e6)
