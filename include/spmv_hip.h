@@ -201,6 +201,17 @@ int spmv_hip_cg_ws_read_async(spmv_hip_cg_ws* ws, int32_t* host_done_kstop,
 int spmv_hip_cg_update_xr_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
                               int64_t n, const double* p, const double* Ap,
                               double* x, double* r, void* stream);
+/* The same updates regrouped so that p is read once per iteration (8 vector
+ * passes instead of 9); per-element arithmetic identical:
+ *   update_r : r -= alpha Ap ; partials of r.r            (cg.cpp:66,70,73)
+ *   update_xp: x += alpha p ; stop test ; p = beta p + r   (cg.cpp:69,77-85)
+ * x still takes the update of the converging iteration, p does not. */
+int spmv_hip_cg_update_r_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
+                             int64_t n, const double* Ap, double* r,
+                             void* stream);
+int spmv_hip_cg_update_xp_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
+                              int64_t n, const double* r, double* x, double* p,
+                              void* stream);
 /* convergence test on rr[k] then p = beta p + r  (cg.cpp:77-85) */
 int spmv_hip_cg_update_p_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
                              int64_t n, const double* r, double* p,

@@ -93,6 +93,9 @@ _PROTOS = {
     "spmv_hip_cg_update_xr_f64": ([vp, vp, C.c_int, i64, vp, vp, vp, vp, vp],
                                   C.c_int),
     "spmv_hip_cg_update_p_f64": ([vp, vp, C.c_int, i64, vp, vp, vp], C.c_int),
+    "spmv_hip_cg_update_r_f64": ([vp, vp, C.c_int, i64, vp, vp, vp], C.c_int),
+    "spmv_hip_cg_update_xp_f64": ([vp, vp, C.c_int, i64, vp, vp, vp, vp],
+                                  C.c_int),
     "spmv_hip_cg_reduce_rr": ([vp, vp, C.c_int, vp], C.c_int),
     "spmv_hip_cg_reduce_pAp": ([vp, vp, C.c_int, vp], C.c_int),
     "spmv_hip_cg_reduce_pAp2": ([vp, vp, C.c_int, vp, vp], C.c_int),

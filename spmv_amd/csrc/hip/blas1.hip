@@ -182,6 +182,101 @@ __global__ __launch_bounds__(kBlock) void cg_update_p_kernel(
   }
 }
 
+// ---- the same two updates, regrouped so that p is read once ---------------
+// K2': r += (-alpha) Ap ; partial r.r                  (cg.cpp:66,70,73)
+// K3': x += alpha p ; stop test ; p = beta p + r        (cg.cpp:69,77-85)
+// Element-wise arithmetic and its order per element are unchanged; only the
+// kernel an update lives in differs (8 instead of 9 vector passes).  x is
+// still updated in the iteration that converges and p is not (cg.cpp:80-81).
+__global__ __launch_bounds__(kBlock) void cg_update_r_kernel(
+    int64_t n, const double* __restrict__ rr_prev,
+    const double* __restrict__ pAp, const CgScalars* __restrict__ sc,
+    const double* __restrict__ Ap, double* __restrict__ r,
+    double* __restrict__ partials, int len)
+{
+  __shared__ double s_red[kBlock / 64];
+  if (sc->done)
+    return;
+  const double rnorm_old = sqrt(*rr_prev);
+  const double alpha = (rnorm_old * rnorm_old) / *pAp; // cg.cpp:66
+  const double nalpha = -alpha;
+  double acc = 0.0;
+  const int64_t n2 = n >> 1;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const double2* Ap2 = reinterpret_cast<const double2*>(Ap);
+  double2* r2 = reinterpret_cast<double2*>(r);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2;
+       i += stride) {
+    double2 av = Ap2[i], rv = r2[i];
+    rv.x += nalpha * av.x; // cg.cpp:70
+    rv.y += nalpha * av.y;
+    r2[i] = rv;
+    acc += rv.x * rv.x; // cg.cpp:73
+    acc += rv.y * rv.y;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    double rv = r[i] + nalpha * Ap[i];
+    r[i] = rv;
+    acc += rv * rv;
+  }
+  double s = block_sum(acc, s_red);
+  if (threadIdx.x == 0)
+    partials[blockIdx.x] = s;
+  clear_partials_tail(partials, len);
+}
+
+__global__ __launch_bounds__(kBlock) void cg_update_xp_kernel(
+    int64_t n, int k, const double* __restrict__ rr0,
+    const double* __restrict__ rr_prev, const double* __restrict__ rr_new,
+    const double* __restrict__ pAp, CgScalars* __restrict__ sc,
+    const double* __restrict__ r, double* __restrict__ x,
+    double* __restrict__ p)
+{
+  if (sc->done)
+    return;
+  const double rnorm0 = sqrt(*rr0);
+  const double rnorm_old = sqrt(*rr_prev);
+  const double rnorm_new = sqrt(*rr_new);                                // :76
+  const double alpha = (rnorm_old * rnorm_old) / *pAp;                   // :66
+  const double beta = (rnorm_new * rnorm_new) / (rnorm_old * rnorm_old); // :77
+  const bool converged = rnorm_new / rnorm0 < sc->rtol;                  // :80
+  const int64_t n2 = n >> 1;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const double2* r2 = reinterpret_cast<const double2*>(r);
+  double2* x2 = reinterpret_cast<double2*>(x);
+  double2* p2 = reinterpret_cast<double2*>(p);
+  if (converged) { // x takes this iteration's update, p stays (:80-81)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2;
+         i += stride) {
+      double2 pv = p2[i], xv = x2[i];
+      xv.x += alpha * pv.x; // cg.cpp:69
+      xv.y += alpha * pv.y;
+      x2[i] = xv;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
+      x[n - 1] += alpha * p[n - 1];
+    return;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2;
+       i += stride) {
+    double2 pv = p2[i], xv = x2[i], rv = r2[i];
+    xv.x += alpha * pv.x; // cg.cpp:69
+    xv.y += alpha * pv.y;
+    x2[i] = xv;
+    pv.x = beta * pv.x; // cg.cpp:84
+    pv.y = beta * pv.y;
+    pv.x += rv.x; // cg.cpp:85
+    pv.y += rv.y;
+    p2[i] = pv;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    x[i] += alpha * p[i];
+    p[i] = beta * p[i] + r[i];
+  }
+}
+
 // Reduces the p.Ap partials of iteration k.  It is the first single-workgroup
 // kernel after the p-update of iteration k-1, so it also raises `done` when
 // rr[k-1] met the tolerance (cg.cpp:80-81): every later cg_* kernel then
@@ -503,6 +598,38 @@ int spmv_hip_cg_update_p_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
   const int grid = spmv_grid_for(ctx, n / 2, kBlock);
   hipLaunchKernelGGL(cg_update_p_kernel, dim3(grid), dim3(kBlock), 0, st, n, k,
                      ws->rr, ws->rr + (k - 1), ws->rr + k, ws->sc, r, p);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_cg_update_r_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
+                             int64_t n, const double* Ap, double* r,
+                             void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(ws && ws->ctx == ctx && k >= 1 && k <= ws->kmax && n >= 0);
+  SPMV_REQUIRE(n == 0 || (Ap && r));
+  SPMV_REQUIRE(aligned16(Ap) && aligned16(r));
+  const int grid = spmv_grid_for(ctx, n / 2, kBlock);
+  hipLaunchKernelGGL(cg_update_r_kernel, dim3(grid), dim3(kBlock), 0,
+                     spmv_stream(ctx, stream), n, ws->rr + (k - 1), ws->pAp + k,
+                     ws->sc, Ap, r, ws->partials, ctx->dot_blocks);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_cg_update_xp_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
+                              int64_t n, const double* r, double* x, double* p,
+                              void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(ws && ws->ctx == ctx && k >= 1 && k <= ws->kmax && n >= 0);
+  SPMV_REQUIRE(n == 0 || (r && x && p));
+  SPMV_REQUIRE(aligned16(r) && aligned16(x) && aligned16(p));
+  const int grid = spmv_grid_for(ctx, n / 2, kBlock);
+  hipLaunchKernelGGL(cg_update_xp_kernel, dim3(grid), dim3(kBlock), 0,
+                     spmv_stream(ctx, stream), n, k, ws->rr, ws->rr + (k - 1),
+                     ws->rr + k, ws->pAp + k, ws->sc, r, x, p);
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;
 }

@@ -6,9 +6,9 @@
 //     SpMV local block  (+ fused p.Ap share)   cg.cpp:60,63
 //     [wait halo event] SpMV remote block      Matrix.cpp:498-511
 //     reduce partials -> pAp[k]; all-reduce    cg.cpp:64-65
-//     x += a p; r -= a Ap; partials of r.r     cg.cpp:66-73
+//     r -= a Ap; partials of r.r               cg.cpp:66,70,73
 //     reduce partials -> rr[k];  all-reduce    cg.cpp:74-76
-//     stop test; p = beta p + r                cg.cpp:77-85
+//     x += a p; stop test; p = beta p + r      cg.cpp:69,77-85
 //
 // 5 kernel launches + (multi-rank) 2 RCCL all-reduces of one double; the
 // reference's CUDA path needs 7 cuBLAS calls, 5 scalar kernels and 3 host
@@ -209,14 +209,17 @@ int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
                      "spmv_hip_cg_reduce_pAp");
     }
     comm.allreduce_sum(slot(false, k), 1, w.stream); // cg.cpp:65
-    throw_on_error(spmv_hip_cg_update_xr_f64(ctx, w.ws, k, M, w.p, w.Ap, w.x,
-                                             w.r, nullptr),
-                   "spmv_hip_cg_update_xr_f64"); // cg.cpp:66-73
+    // r -= alpha Ap with the r.r partials (cg.cpp:66,70,73); the x update of
+    // :69 rides with the p update below so p is read once per iteration
+    throw_on_error(spmv_hip_cg_update_r_f64(ctx, w.ws, k, M, w.Ap, w.r, nullptr),
+                   "spmv_hip_cg_update_r_f64");
     throw_on_error(spmv_hip_cg_reduce_rr(ctx, w.ws, k, nullptr),
                    "spmv_hip_cg_reduce_rr");
     comm.allreduce_sum(slot(true, k), 1, w.stream); // cg.cpp:75
-    throw_on_error(spmv_hip_cg_update_p_f64(ctx, w.ws, k, M, w.r, w.p, nullptr),
-                   "spmv_hip_cg_update_p_f64"); // cg.cpp:77-85
+    // x += alpha p ; stop test ; p = beta p + r   (cg.cpp:69,77-85)
+    throw_on_error(spmv_hip_cg_update_xp_f64(ctx, w.ws, k, M, w.r, w.x, w.p,
+                                             nullptr),
+                   "spmv_hip_cg_update_xp_f64");
 
     if (k % poll_every == 0 && k < kmax) {
       // Lagging look at the flag: wait for the copy issued `poll_every`

@@ -356,7 +356,7 @@ def test_device_poisson_matches_host(ctx, n, P):
 # CG building blocks: drive the kernels exactly as spmv::cg does and compare
 # with the oracle's CG (cg.cpp:21-98)
 # ---------------------------------------------------------------------------
-def gpu_cg(ctx, blk, b, kmax, rtol, fused_dot=True):
+def gpu_cg(ctx, blk, b, kmax, rtol, fused_dot=True, regrouped=False):
     n = blk.nrows
     ws = C.c_void_p()
     hip.call("spmv_hip_cg_ws_create", ctx.h, kmax, C.byref(ws))
@@ -375,11 +375,18 @@ def gpu_cg(ctx, blk, b, kmax, rtol, fused_dot=True):
             hip.call("spmv_hip_dot_partial_f64", ctx.h, n, p.ptr, Ap.ptr, part,
                      None)
         hip.call("spmv_hip_cg_reduce_pAp", ctx.h, ws, k, None)
-        hip.call("spmv_hip_cg_update_xr_f64", ctx.h, ws, k, n, p.ptr, Ap.ptr,
-                 x.ptr, r.ptr, None)
-        hip.call("spmv_hip_cg_reduce_rr", ctx.h, ws, k, None)
-        hip.call("spmv_hip_cg_update_p_f64", ctx.h, ws, k, n, r.ptr, p.ptr,
-                 None)
+        if regrouped:  # what spmv::cg issues: p is read once per iteration
+            hip.call("spmv_hip_cg_update_r_f64", ctx.h, ws, k, n, Ap.ptr, r.ptr,
+                     None)
+            hip.call("spmv_hip_cg_reduce_rr", ctx.h, ws, k, None)
+            hip.call("spmv_hip_cg_update_xp_f64", ctx.h, ws, k, n, r.ptr, x.ptr,
+                     p.ptr, None)
+        else:
+            hip.call("spmv_hip_cg_update_xr_f64", ctx.h, ws, k, n, p.ptr,
+                     Ap.ptr, x.ptr, r.ptr, None)
+            hip.call("spmv_hip_cg_reduce_rr", ctx.h, ws, k, None)
+            hip.call("spmv_hip_cg_update_p_f64", ctx.h, ws, k, n, r.ptr, p.ptr,
+                     None)
     flags = np.zeros(2, np.int32)
     rr = np.zeros(kmax + 1)
     hip.call("spmv_hip_cg_ws_read_async", ws, flags.ctypes.data_as(C.c_void_p),
@@ -408,6 +415,13 @@ def test_cg_kernels_match_oracle(ctx, symmetric):
         x_ref, k_ref, hist_ref = oracle.cg(rp, ci, va, b, 200, 1e-10)
     assert k_ref < 200
     x, flags, hist = gpu_cg(ctx, blk, b, 200, 1e-10)
+    # both groupings of the vector updates are the same arithmetic
+    x2, flags2, hist2 = gpu_cg(ctx, blk, b, 200, 1e-10, regrouped=True)
+    assert np.array_equal(flags, flags2)
+    if not symmetric:  # deterministic kernels: bit-identical
+        assert np.array_equal(x, x2) and np.array_equal(hist, hist2)
+    else:
+        assert np.linalg.norm(x - x2) <= 1e-9 * np.linalg.norm(x)
     # the host enqueued all 200 iterations; the device stopped itself
     assert flags[0] == 1 and abs(int(flags[1]) - k_ref) <= 1
     k = int(flags[1])

@@ -152,6 +152,31 @@ def main():
         tmin, tmed = time_ms(ctx, lambda: hip.call(
             "spmv_hip_cg_reduce_rr", ctx.h, ws, 2, None), reps)
         emit(n=n, variant="cg_reduce", ms=tmin, ms_med=tmed)
+        # the same three kernels in CG order, each bracketed by its own events
+        gen = hip.poisson3d_block(ctx, n, 0, N, hip.PART_ALL)
+        evs = [ctx.event_create() for _ in range(4)]
+        acc = [0.0, 0.0, 0.0]
+        rounds = max(5, reps)
+        for it in range(rounds + 2):
+            ctx.copy(rslot, pslot, 8)
+            ctx.event_record(evs[0])
+            gen.mult(1.0, p.ptr, 0.0, y.ptr, dot_partials=part.ptr)
+            ctx.event_record(evs[1])
+            hip.call("spmv_hip_cg_update_xr_f64", ctx.h, ws, 1, N, p.ptr, y.ptr,
+                     x.ptr, r.ptr, None)
+            ctx.event_record(evs[2])
+            ctx.copy(rslot, pslot, 8)
+            hip.call("spmv_hip_cg_update_p_f64", ctx.h, ws, 1, N, r.ptr, p.ptr,
+                     None)
+            ctx.event_record(evs[3])
+            ctx.event_sync(evs[3])
+            if it >= 2:
+                for i in range(3):
+                    acc[i] += ctx.elapsed_ms(evs[i], evs[i + 1])
+        emit(n=n, variant="sequence[spmv+dot,xr,p]",
+             ms_spmv=acc[0] / rounds, ms_xr=acc[1] / rounds,
+             ms_p=acc[2] / rounds, ms=sum(acc) / rounds, ms_med=0.0)
+        gen.free()
         hip.call("spmv_hip_cg_ws_destroy", ws)
         for b in (x, y, part, r, p):
             b.free()
