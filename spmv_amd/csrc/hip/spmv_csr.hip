@@ -664,7 +664,7 @@ struct spmv_hip_csr_plan {
   int lanes_per_row = 8;  // VECTOR
   int chunks = 1;         // ROWBLOCK: 16-B loads per lane per tile (1, 2, 4)
   int nontemporal = 0;    // ROWBLOCK: nt loads on the matrix stream
-  int xcd_group = 0;      // ROWBLOCK: consecutive row blocks per XCD (0 = off)
+  int xcd_group = 16;     // ROWBLOCK: consecutive row blocks per XCD (0 = off)
   int blocks_per_cu = kBlocksPerCU;
   int sym_window = 256;   // symmetric: LDS window below the block (0 = plain
                           // per-entry global atomics)
@@ -993,6 +993,10 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
   while (lpr < 64 && lpr < avg / 2)
     lpr *= 2;
   pl->lanes_per_row = lpr;
+  // Non-temporal matrix loads keep the read-once stream out of the caches so
+  // that x stays resident; measured +5 % when x fits the 256 MiB Infinity
+  // Cache with room to spare (216^3) and -3 % when it does not (512^3).
+  pl->nontemporal = ((int64_t)num_cols * 8 <= (int64_t)128 << 20) ? 1 : 0;
   *plan = pl;
   return SPMV_HIP_OK;
 }
