@@ -162,6 +162,25 @@ int spmvh_cg(spmvh_comm* comm, spmvh_exec* exec, spmvh_matrix* A,
              const double* b, double* x, int kmax, double rtol, int* num_its,
              double* rnorm_history);
 
+/* ---- PETSc binary ingest (spmv/read_petsc.{h,cpp}) ------------------------------
+ * read_petsc_binary_matrix / read_petsc_binary_vector of the mirror.  The
+ * vector comes back as a device pointer the caller frees with
+ * spmvh_exec_free. */
+int spmvh_read_petsc_matrix(spmvh_comm* comm, spmvh_exec* exec,
+                            const char* filename, int symmetric, int cm,
+                            spmvh_matrix** A);
+int spmvh_read_petsc_vector(spmvh_comm* comm, spmvh_exec* exec,
+                            const char* filename, double** device_vec,
+                            int64_t* nrows_local);
+/* host-only parse of rank `rank` of `size` (no device): sizes[0..6] = global
+ * rows, cols, nnz, row_begin, row_end, local nnz, number of ghost columns */
+typedef struct spmvh_petsc_rows spmvh_petsc_rows;
+int spmvh_petsc_rows_read(const char* filename, int rank, int size,
+                          spmvh_petsc_rows** rows, int64_t sizes[7]);
+int spmvh_petsc_rows_get(spmvh_petsc_rows* rows, int32_t* rowptr,
+                         int32_t* colind, double* values, int64_t* col_ghosts);
+int spmvh_petsc_rows_destroy(spmvh_petsc_rows* rows);
+
 /* Same solve with the optional arguments of the C++ overload: a reusable
  * spmv::CgWorkspace (may be NULL) and per-iteration HIP-event timing of the
  * local-block SpMV kernel (time_spmv != 0 -> *spmv_ms_total, *spmv_launches). */

@@ -7,4 +7,4 @@ from ._c import (build, cg, csr_spmv, csr_spmv_sym, ddot, gather_ghosts,  # noqa
                  max_threads, omp_row_split, omp_spmv, poisson3d, time_cg,
                  time_spmv)
 from .host_logic import *  # noqa: F401,F403
-from . import host_logic  # noqa: F401
+from . import host_logic, petsc_io  # noqa: F401

@@ -257,6 +257,147 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// ROWBLOCK, wave-private variant: the same algorithm with each of the four
+// waves of a workgroup owning 64 of its 256 rows and a private LDS slice, so
+// no workgroup barrier sits between a wave's loads and its row sums (LDS
+// operations of one wave execute in issue order; wave_barrier() only stops
+// the compiler from reordering them).  Same results, bit for bit.
+// ---------------------------------------------------------------------------
+template <typename T, int CH, bool NT, bool DOT>
+__global__ __launch_bounds__(kBlock) void csr_rowwave_kernel(
+    int32_t num_rows, int64_t nnz, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ colind, const T* __restrict__ values, T alpha,
+    const T* __restrict__ in, T beta, T* __restrict__ out,
+    double* __restrict__ dot_partials, int dot_len, int num_row_blocks,
+    int xcd_group)
+{
+  constexpr int V = VecOf<T>::V;
+  constexpr int W = 64;               // lanes = rows per wave
+  constexpr int NW = kBlock / W;      // waves per workgroup
+  constexpr int TILE = W * CH * V;    // entries per wave tile
+  using val_t = typename VecOf<T>::val_t;
+  using col_t = typename VecOf<T>::col_t;
+
+  __shared__ T s_prod_all[NW][TILE];
+  __shared__ int32_t s_rowptr_all[NW][W + 1];
+  __shared__ double s_red[NW];
+
+  const int wave = threadIdx.x / W;
+  const int t = threadIdx.x % W;
+  T* s_prod = s_prod_all[wave];
+  int32_t* s_rowptr = s_rowptr_all[wave];
+  double dot_acc = 0.0;
+
+  const int super = 8 * (xcd_group > 0 ? xcd_group : 1);
+  const int num_slots = xcd_group > 0
+                            ? ((num_row_blocks + super - 1) / super) * super
+                            : num_row_blocks;
+  for (int it = blockIdx.x; it < num_slots; it += gridDim.x) {
+    int rb = it;
+    if (xcd_group > 0) {
+      const int q = it % super;
+      rb = (it - q) + (q & 7) * xcd_group + (q >> 3);
+    }
+    const int64_t r0 = (int64_t)rb * kRows + wave * W;
+    if (rb >= num_row_blocks || r0 >= num_rows)
+      continue; // per wave; no workgroup barrier inside this loop
+    const int nr = (int)min((int64_t)W, (int64_t)num_rows - r0);
+
+    __builtin_amdgcn_wave_barrier();
+    if (t <= nr)
+      s_rowptr[t] = rowptr[r0 + t];
+    if (t == 0 && nr == W)
+      s_rowptr[W] = rowptr[r0 + W];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const int32_t a = s_rowptr[0];
+    const int32_t b = s_rowptr[nr];
+    int32_t lo = 0, hi = 0;
+    if (t < nr) {
+      lo = s_rowptr[t];
+      hi = s_rowptr[t + 1];
+    }
+    T sum = 0;
+    const int64_t base0 = a & ~(V - 1);
+    const int64_t jclamp = (int64_t)(b - 1) & ~(int64_t)(V - 1);
+    for (int64_t base = base0; base < b; base += TILE) {
+      __builtin_amdgcn_wave_barrier();
+      if (jclamp + V <= nnz) {
+        val_t v[CH];
+        col_t ci[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int64_t j0 = base + (int64_t)(c * W + t) * V;
+          const int64_t jl = j0 < jclamp ? j0 : jclamp;
+          v[c] = stream_load<NT>(reinterpret_cast<const val_t*>(values + jl));
+          ci[c] = stream_load<NT>(reinterpret_cast<const col_t*>(colind + jl));
+        }
+        T xg[CH][V];
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+          for (int e = 0; e < V; ++e)
+            xg[c][e] = in[ci[c][e]];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int64_t j0 = base + (int64_t)(c * W + t) * V;
+          val_t pv;
+#pragma unroll
+          for (int e = 0; e < V; ++e)
+            pv[e] = (j0 + e < b) ? v[c][e] * xg[c][e] : T(0);
+          *reinterpret_cast<val_t*>(&s_prod[(c * W + t) * V]) = pv;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int64_t j0 = base + (int64_t)(c * W + t) * V;
+          val_t pv;
+#pragma unroll
+          for (int e = 0; e < V; ++e) {
+            const int64_t j = j0 + e;
+            pv[e] = (j < b) ? values[j] * in[colind[j]] : T(0);
+          }
+          *reinterpret_cast<val_t*>(&s_prod[(c * W + t) * V]) = pv;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int32_t jlo = max((int64_t)lo, base) - base;
+      const int32_t jhi = min((int64_t)hi, base + TILE) - base;
+      int32_t j = jlo;
+      for (; j + 4 <= jhi; j += 4) {
+        const T p0 = s_prod[j], p1 = s_prod[j + 1], p2 = s_prod[j + 2],
+                p3 = s_prod[j + 3];
+        sum += p0;
+        sum += p1;
+        sum += p2;
+        sum += p3;
+      }
+      for (; j < jhi; ++j)
+        sum += s_prod[j];
+    }
+    if (t < nr) {
+      const int64_t r = r0 + t;
+      const T c = alpha * sum;
+      T y = c;
+      if (beta != T(0))
+        y = c + beta * out[r];
+      out[r] = y;
+      if constexpr (DOT)
+        dot_acc += (double)in[r] * (double)c;
+    }
+  }
+
+  if constexpr (DOT) {
+    double s = block_sum(dot_acc, s_red);
+    if (threadIdx.x == 0)
+      dot_partials[blockIdx.x] = s;
+    clear_partials_tail(dot_partials, dot_len);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // SCALAR kernel: one lane per row, the reference loop verbatim.
 // ---------------------------------------------------------------------------
 template <typename T, bool DOT>
@@ -666,6 +807,7 @@ struct spmv_hip_csr_plan {
   int nontemporal = 0;    // ROWBLOCK: nt loads on the matrix stream
   int xcd_group = 16;     // ROWBLOCK: consecutive row blocks per XCD (0 = off)
   int blocks_per_cu = kBlocksPerCU;
+  int wave_private = 0;   // ROWBLOCK: wave-private LDS slices, no barriers
   int sym_window = 256;   // symmetric: LDS window below the block (0 = plain
                           // per-entry global atomics)
   int sym_rows = 1024;    // symmetric: rows per workgroup (512, 1024, 2048)
@@ -712,6 +854,32 @@ int launch_rowblock(const spmv_hip_csr_plan* pl, hipStream_t st,
   if (grid < 1)
     grid = 1;
   const bool al = aligned16(values) && aligned16(colind);
+  if (pl->wave_private && al) {
+    const int len = pl->ctx->dot_blocks;
+#define SPMV_RW(CH, NT)                                                        \
+  hipLaunchKernelGGL((csr_rowwave_kernel<T, CH, NT, DOT>), dim3(grid),         \
+                     dim3(kBlock), 0, st, pl->num_rows, pl->nnz, rowptr,       \
+                     colind, values, alpha, in, beta, out, dot, len, nrb,      \
+                     pl->xcd_group)
+    if (pl->nontemporal) {
+      if (pl->chunks == 1)
+        SPMV_RW(1, true);
+      else if (pl->chunks == 2)
+        SPMV_RW(2, true);
+      else
+        SPMV_RW(4, true);
+    } else {
+      if (pl->chunks == 1)
+        SPMV_RW(1, false);
+      else if (pl->chunks == 2)
+        SPMV_RW(2, false);
+      else
+        SPMV_RW(4, false);
+    }
+#undef SPMV_RW
+    SPMV_CHECK_LAUNCH();
+    return SPMV_HIP_OK;
+  }
 #define SPMV_RB(CH, NT, AL)                                                    \
   return launch_rowblock_x<T, CH, NT, AL, DOT>(pl, st, grid, nrb, rowptr,      \
                                                colind, values, alpha, in,     \
@@ -1039,6 +1207,8 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
   } else if (!strcmp(key, "xcd_group")) {
     SPMV_REQUIRE(value >= 0 && value <= 4096);
     plan->xcd_group = value;
+  } else if (!strcmp(key, "wave_private")) {
+    plan->wave_private = value != 0;
   } else if (!strcmp(key, "sym_window")) {
     SPMV_REQUIRE(value >= 0 && value <= 4096 && value % 256 == 0);
     plan->sym_window = value;

@@ -13,6 +13,7 @@
 #include "executor.h"
 #include "l2gmap.h"
 #include "matrix.h"
+#include "read_petsc.h"
 
 using namespace spmv;
 
@@ -31,6 +32,9 @@ struct spmvh_l2g {
 };
 struct spmvh_split {
   Matrix<double>::Split s;
+};
+struct spmvh_petsc_rows {
+  PetscRows rows;
 };
 struct spmvh_cg_workspace {
   std::shared_ptr<HipExecutor> exec; // keeps the executor alive
@@ -564,6 +568,71 @@ int spmvh_cg(spmvh_comm* comm, spmvh_exec* exec, spmvh_matrix* A,
     if (rnorm_history)
       std::copy(hist.begin(), hist.end(), rnorm_history);
   });
+}
+
+int spmvh_read_petsc_matrix(spmvh_comm* comm, spmvh_exec* exec,
+                            const char* filename, int symmetric, int cm,
+                            spmvh_matrix** A)
+{
+  return guarded([&] {
+    require(comm && exec && filename && A, "NULL argument");
+    auto m = std::make_unique<spmvh_matrix>();
+    m->A = read_petsc_binary_matrix(filename, comm->comm, exec->hip,
+                                    symmetric != 0, to_cm(cm));
+    *A = m.release();
+  });
+}
+
+int spmvh_read_petsc_vector(spmvh_comm* comm, spmvh_exec* exec,
+                            const char* filename, double** device_vec,
+                            int64_t* nrows_local)
+{
+  return guarded([&] {
+    require(comm && exec && filename && device_vec, "NULL argument");
+    *device_vec = read_petsc_binary_vector(*comm->comm, exec->hip.get(),
+                                           filename, nrows_local);
+  });
+}
+
+int spmvh_petsc_rows_read(const char* filename, int rank, int size,
+                          spmvh_petsc_rows** rows, int64_t sizes[7])
+{
+  return guarded([&] {
+    require(filename && rows && sizes && size >= 1 && rank >= 0 && rank < size,
+            "bad argument");
+    auto r = std::make_unique<spmvh_petsc_rows>();
+    r->rows = read_petsc_binary_rows(filename, rank, size);
+    sizes[0] = r->rows.nrows_global;
+    sizes[1] = r->rows.ncols_global;
+    sizes[2] = r->rows.nnz_global;
+    sizes[3] = r->rows.row_begin;
+    sizes[4] = r->rows.row_end;
+    sizes[5] = static_cast<int64_t>(r->rows.values.size());
+    sizes[6] = static_cast<int64_t>(r->rows.col_ghosts.size());
+    *rows = r.release();
+  });
+}
+
+int spmvh_petsc_rows_get(spmvh_petsc_rows* rows, int32_t* rowptr,
+                         int32_t* colind, double* values, int64_t* col_ghosts)
+{
+  return guarded([&] {
+    require(rows != nullptr, "NULL argument");
+    const PetscRows& r = rows->rows;
+    if (rowptr)
+      std::copy(r.rowptr.begin(), r.rowptr.end(), rowptr);
+    if (colind)
+      std::copy(r.colind.begin(), r.colind.end(), colind);
+    if (values)
+      std::copy(r.values.begin(), r.values.end(), values);
+    if (col_ghosts)
+      std::copy(r.col_ghosts.begin(), r.col_ghosts.end(), col_ghosts);
+  });
+}
+
+int spmvh_petsc_rows_destroy(spmvh_petsc_rows* rows)
+{
+  return guarded([&] { delete rows; });
 }
 
 int spmvh_cg_workspace_create(spmvh_exec* exec, spmvh_cg_workspace** ws)

@@ -74,6 +74,11 @@ _PROTOS = {
     "spmvh_l2g_map_plan": [vp, vp, vp, vp, vp, vp, vp],
     "spmvh_l2g_map_update": [vp, vp],
     "spmvh_cg": [vp, vp, vp, vp, vp, C.c_int, f64, PTR(C.c_int), vp],
+    "spmvh_read_petsc_matrix": [vp, vp, C.c_char_p, C.c_int, C.c_int, PTR(vp)],
+    "spmvh_read_petsc_vector": [vp, vp, C.c_char_p, PTR(vp), PTR(i64)],
+    "spmvh_petsc_rows_read": [C.c_char_p, C.c_int, C.c_int, PTR(vp), PTR(i64)],
+    "spmvh_petsc_rows_get": [vp, vp, vp, vp, vp],
+    "spmvh_petsc_rows_destroy": [vp],
     "spmvh_cg_workspace_create": [vp, PTR(vp)],
     "spmvh_cg_workspace_destroy": [vp],
     "spmvh_cg_ex": [vp, vp, vp, vp, vp, C.c_int, f64, PTR(C.c_int), vp, vp,
@@ -406,6 +411,41 @@ def cg(comm, exec_, A, b_ptr, x_ptr, kmax, rtol, history=True):
     call("spmvh_cg", comm.h, exec_.h, A.h, b_ptr, x_ptr, kmax, float(rtol),
          C.byref(k), _np_ptr(hist))
     return k.value, (hist[:k.value + 1] if history else None)
+
+
+def read_petsc_binary_matrix(filename, comm, exec_, symmetric=False,
+                             cm=COLLECTIVE_BLOCKING):
+    """spmv::read_petsc_binary_matrix (spmv/read_petsc.cpp:40-228)"""
+    h = vp()
+    call("spmvh_read_petsc_matrix", comm.h, exec_.h, str(filename).encode(),
+         int(symmetric), cm, C.byref(h))
+    return Matrix(h)
+
+
+def read_petsc_binary_vector(comm, exec_, filename):
+    """-> (device pointer, local length); free with exec_.free()"""
+    p, n = vp(), i64()
+    call("spmvh_read_petsc_vector", comm.h, exec_.h, str(filename).encode(),
+         C.byref(p), C.byref(n))
+    return p.value or 0, n.value
+
+
+def read_petsc_binary_rows(filename, rank, size):
+    """Host-only parse of one rank's slice (no device)."""
+    h, sizes = vp(), (i64 * 7)()
+    call("spmvh_petsc_rows_read", str(filename).encode(), rank, size,
+         C.byref(h), sizes)
+    nloc = sizes[4] - sizes[3]
+    rp = np.zeros(nloc + 1, np.int32)
+    ci = np.zeros(sizes[5], np.int32)
+    va = np.zeros(sizes[5], np.float64)
+    gh = np.zeros(sizes[6], np.int64)
+    call("spmvh_petsc_rows_get", h, _np_ptr(rp), _np_ptr(ci), _np_ptr(va),
+         _np_ptr(gh))
+    call("spmvh_petsc_rows_destroy", h)
+    return dict(nrows=sizes[0], ncols=sizes[1], nnz=sizes[2],
+                row_begin=sizes[3], row_end=sizes[4], rowptr=rp, colind=ci,
+                values=va, col_ghosts=gh)
 
 
 class CgWorkspace:

@@ -123,6 +123,41 @@ def main():
             A.close()
             for p in (d_x, d_y, d_b, d_s):
                 exec_.free(p)
+    # PETSc binary ingest on every rank (demos/cg.cpp flow), unstructured
+    import tempfile
+    import torch.distributed as dist
+    rp, ci, va = unstructured
+    N = len(rp) - 1
+    tmp = [tempfile.mkdtemp() if rank == 0 else None]
+    dist.broadcast_object_list(tmp, src=0)
+    fa, fb = os.path.join(tmp[0], "A.dat"), os.path.join(tmp[0], "x.dat")
+    x = oracle.gaussian_x_fast(N)
+    if rank == 0:
+        oracle.petsc_io.write_matrix(fa, rp, ci, va)
+        oracle.petsc_io.write_vector(fb, x)
+    dist.barrier()
+    ranges = oracle.owner_ranges(world, N)
+    r0, r1 = int(ranges[rank]), int(ranges[rank + 1])
+    for symmetric in (False, True):
+        for cm in (host.P2P_BLOCKING, host.P2P_NONBLOCKING):
+            A = host.read_petsc_binary_matrix(fa, comm, exec_, symmetric, cm)
+            l2g = A.col_map()
+            d_v, nloc = host.read_petsc_binary_vector(comm, exec_, fb)
+            assert nloc == r1 - r0
+            d_x = exec_.alloc(l2g.local_size() + l2g.num_ghosts())
+            exec_.copy(d_x, d_v, 8 * nloc)
+            d_y = exec_.alloc(nloc)
+            l2g.update(d_x)
+            A.mult(d_x, d_y)
+            y = dist_util.gather_concat(exec_.copy_to_host(d_y, nloc))
+            y_ref = oracle.dist_spmv(world, rp, ci, va, x, symmetric, cm)
+            if symmetric:
+                assert np.all(np.abs(y - y_ref) <= 16 * U * abs_bound(rp, ci, va, x) + 1e-300)
+            else:
+                assert np.array_equal(y, y_ref)
+            A.close()
+            for ptr in (d_v, d_x, d_y):
+                exec_.free(ptr)
     comm.close()
     exec_.close()
     print(f"rank {rank}/{world}: multirank OK", flush=True)

@@ -83,7 +83,9 @@ def test_kat_vector_and_symmetric(ctx):
 # Poisson + random ragged matrices, general kernels
 # ---------------------------------------------------------------------------
 KNOBS = [dict(), dict(chunks=1), dict(chunks=4), dict(nontemporal=0),
-         dict(xcd_group=1), dict(xcd_group=16), dict(chunks=4, xcd_group=3, blocks_per_cu=2)]
+         dict(xcd_group=1), dict(xcd_group=16), dict(chunks=4, xcd_group=3, blocks_per_cu=2),
+         dict(wave_private=1, chunks=4), dict(wave_private=1, chunks=1, xcd_group=0),
+         dict(wave_private=1, chunks=2, nontemporal=1)]
 
 
 @pytest.mark.parametrize("n", [4, 9, 16, 33])

@@ -15,6 +15,13 @@ from spmv_amd import hip, host, poisson
 from util import U, abs_bound
 
 pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EPS = np.finfo(float).eps
 CMS = [host.P2P_BLOCKING, host.P2P_NONBLOCKING, host.COLLECTIVE_BLOCKING,
@@ -183,7 +190,7 @@ def test_multirank_on_one_gpu(world):
     env = dict(os.environ, OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
            f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29800 + world),
+           "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "mp_gpu_worker.py")]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True,
                          timeout=600)
@@ -213,3 +220,27 @@ def test_rccl_comm_single_rank(exec_):
     A.close()
     exec_.free(d_b), exec_.free(d_x)
     comm.close()
+
+
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_read_petsc_binary(exec_, comm, tmp_path, symmetric):
+    """demos/cg.cpp flow: read A and b from PETSc binary files, solve."""
+    n = 7
+    N = n ** 3
+    rp, ci, va = poisson.poisson3d_csr(n)
+    b = oracle.csr_spmv(rp, ci.astype(np.int32), va, np.ones(N))
+    fa, fb = tmp_path / "A.dat", tmp_path / "b.dat"
+    oracle.petsc_io.write_matrix(fa, rp, ci, va)
+    oracle.petsc_io.write_vector(fb, b)
+    A = host.read_petsc_binary_matrix(fa, comm, exec_, symmetric,
+                                      host.P2P_NONBLOCKING)
+    assert A.rows() == N and A.non_zeros() == len(va)
+    d_b, nloc = host.read_petsc_binary_vector(comm, exec_, fb)
+    assert nloc == N and np.array_equal(exec_.copy_to_host(d_b, N), b)
+    d_x = exec_.alloc(N)
+    k, hist = host.cg(comm, exec_, A, d_b, d_x, 100, 1e-10)
+    x_ref, k_ref, _ = oracle.cg(rp, ci.astype(np.int32), va, b, 100, 1e-10)
+    assert abs(k - k_ref) <= 1
+    assert np.linalg.norm(exec_.copy_to_host(d_x, N) - x_ref) <= 1e-8 * np.linalg.norm(x_ref)
+    A.close()
+    exec_.free(d_b), exec_.free(d_x)

@@ -14,6 +14,13 @@ from spmv_amd import _lib, host, poisson
 from util import U, abs_bound, lower_split, random_csr
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
@@ -252,13 +259,49 @@ def test_l2gmap_single_rank_and_errors():
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("world", [2, 3])
 def test_l2g_plan_gloo(world):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1",
-               MASTER_PORT=str(29600 + world), OMP_NUM_THREADS="1")
+    env = dict(os.environ, OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
            f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29700 + world),
+           "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "mp_plan_worker.py")]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True,
                          timeout=300)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     assert res.stdout.count("plan + split OK") == world
+
+
+# ---------------------------------------------------------------------------
+# PETSc binary ingest (spmv/read_petsc.cpp), host-only parse
+# ---------------------------------------------------------------------------
+def test_petsc_reader_matches_restatement(tmp_path):
+    rng = np.random.default_rng(17)
+    cases = []
+    rp, ci, va = poisson.poisson3d_csr(4)
+    cases.append((rp, ci, va, 64))
+    rp, ci, va = random_csr(rng, 37, 53, 4)      # rectangular, empty rows
+    cases.append((rp, ci, va, 53))
+    for idx, (rp, ci, va, ncols) in enumerate(cases):
+        f = tmp_path / f"m{idx}.dat"
+        oracle.petsc_io.write_matrix(f, rp, ci, va, ncols)
+        for size in (1, 2, 3, 5):
+            for rank in range(size):
+                got = host.read_petsc_binary_rows(f, rank, size)
+                exp = oracle.petsc_io.read_matrix_rows(f, rank, size)
+                for key in ("nrows", "ncols", "nnz", "row_begin", "row_end"):
+                    assert got[key] == exp[key]
+                for key in ("rowptr", "colind", "values", "col_ghosts"):
+                    assert np.array_equal(got[key], exp[key]), key
+            # the slices reassemble the matrix that was written
+            rows = [host.read_petsc_binary_rows(f, r, size) for r in range(size)]
+            assert sum(len(r["values"]) for r in rows) == len(va)
+            assert np.array_equal(np.concatenate([r["values"] for r in rows]), va)
+    bad = tmp_path / "bad.dat"
+    bad.write_bytes(b"\x00" * 64)
+    with pytest.raises(host.SpmvHostError, match="Bad signature"):
+        host.read_petsc_binary_rows(bad, 0, 1)
+    with pytest.raises(host.SpmvHostError, match="Could not open"):
+        host.read_petsc_binary_rows(tmp_path / "missing.dat", 0, 1)
+    trunc = tmp_path / "trunc.dat"
+    trunc.write_bytes((tmp_path / "m0.dat").read_bytes()[:200])
+    with pytest.raises(host.SpmvHostError, match="truncated"):
+        host.read_petsc_binary_rows(trunc, 0, 1)

@@ -69,13 +69,12 @@ def main():
         src.free(), dst.free()
 
         variants = []
-        chunks = [1, 2] if args.quick else [1, 2, 4]
-        for ch, nt, grp in itertools.product(chunks, [0, 1],
-                                             [0, 4, 16, 64, 256]):
-            if args.quick and nt == 1:
+        for ch, nt, wp in itertools.product([1, 2, 4], [0, 1], [0, 1]):
+            if args.quick and nt == 1 and n >= 400:
                 continue
             variants.append(("rowblock", dict(algo=hip.ALGO_ROWBLOCK, chunks=ch,
-                                              nontemporal=nt, xcd_group=grp,
+                                              nontemporal=nt, xcd_group=16,
+                                              wave_private=wp,
                                               blocks_per_cu=8)))
         variants.append(("scalar", dict(algo=hip.ALGO_SCALAR)))
         for lpr in (4, 8):
