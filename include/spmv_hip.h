@@ -62,6 +62,11 @@ int spmv_hip_synchronize(spmv_hip_ctx* ctx); /* whole device */
 /* ---- streams / events ---------------------------------------------------
  * CudaExecutor::set/reset/get_cuda_stream (cuda/cuda_executor.h:72-76). */
 int spmv_hip_stream_create(spmv_hip_ctx* ctx, void** stream);
+/* high_priority != 0: the stream's kernels are dispatched ahead of other
+ * ready work -- used for the halo stream so the small RCCL send/recv kernel is
+ * placed before the CU-filling local SpMV that becomes ready at the same time */
+int spmv_hip_stream_create_priority(spmv_hip_ctx* ctx, int high_priority,
+                                    void** stream);
 int spmv_hip_stream_destroy(spmv_hip_ctx* ctx, void* stream);
 int spmv_hip_stream_synchronize(spmv_hip_ctx* ctx, void* stream);
 int spmv_hip_set_stream(spmv_hip_ctx* ctx, void* stream); /* NULL = reset */

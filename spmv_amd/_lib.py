@@ -49,6 +49,7 @@ _PROTOS = {
     "spmv_hip_num_cus": ([vp, P(C.c_int)], C.c_int),
     "spmv_hip_synchronize": ([vp], C.c_int),
     "spmv_hip_stream_create": ([vp, P(vp)], C.c_int),
+    "spmv_hip_stream_create_priority": ([vp, C.c_int, P(vp)], C.c_int),
     "spmv_hip_stream_destroy": ([vp, vp], C.c_int),
     "spmv_hip_stream_synchronize": ([vp, vp], C.c_int),
     "spmv_hip_set_stream": ([vp, vp], C.c_int),

@@ -95,6 +95,20 @@ int spmv_hip_stream_create(spmv_hip_ctx* ctx, void** stream)
   return SPMV_HIP_OK;
 }
 
+int spmv_hip_stream_create_priority(spmv_hip_ctx* ctx, int high_priority,
+                                    void** stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(stream);
+  int least = 0, greatest = 0; // numerically lower = higher priority
+  SPMV_CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  hipStream_t s;
+  SPMV_CHECK_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking,
+                                             high_priority ? greatest : least));
+  *stream = s;
+  return SPMV_HIP_OK;
+}
+
 int spmv_hip_stream_destroy(spmv_hip_ctx* ctx, void* stream)
 {
   SPMV_SET_DEVICE(ctx);

@@ -145,10 +145,14 @@ void* HipExecutor::get_stream() const
   throw_on_error(spmv_hip_get_stream(_ctx, &s), "spmv_hip_get_stream");
   return s;
 }
-void* HipExecutor::create_stream() const
+void* HipExecutor::create_stream(bool high_priority) const
 {
   void* s = nullptr;
-  throw_on_error(spmv_hip_stream_create(_ctx, &s), "spmv_hip_stream_create");
+  if (high_priority)
+    throw_on_error(spmv_hip_stream_create_priority(_ctx, 1, &s),
+                   "spmv_hip_stream_create_priority");
+  else
+    throw_on_error(spmv_hip_stream_create(_ctx, &s), "spmv_hip_stream_create");
   return s;
 }
 void HipExecutor::destroy_stream(void* s) const

@@ -206,7 +206,7 @@ public:
 
   // Extended API of this backend (stream/event plumbing for overlap).
   spmv_hip_ctx* context() const { return _ctx; }
-  void* create_stream() const;
+  void* create_stream(bool high_priority = false) const;
   void destroy_stream(void* stream) const;
   void* create_event(bool timing = false) const;
   void destroy_event(void* event) const;

@@ -123,7 +123,9 @@ L2GMap::L2GMap(std::shared_ptr<const Comm> comm, std::int64_t local_size,
                                    _indexbuf_host.data(), _num_indices);
   }
   if (_hip && !_neighbours.empty()) {
-    _comm_stream = _hip->create_stream();
+    // high priority: the (small) RCCL kernel must be placed before the local
+    // SpMV, whose persistent workgroups would otherwise fill every CU first
+    _comm_stream = _hip->create_stream(/*high_priority=*/true);
     _ev_ready = _hip->create_event();
     _ev_done = _hip->create_event();
   }

@@ -76,6 +76,11 @@ def main():
                                               nontemporal=nt, xcd_group=16,
                                               wave_private=wp,
                                               blocks_per_cu=8)))
+        for bpc in (7, 6):
+            variants.append(("rowblock", dict(algo=hip.ALGO_ROWBLOCK, chunks=1,
+                                              nontemporal=0, xcd_group=16,
+                                              wave_private=0,
+                                              blocks_per_cu=bpc)))
         variants.append(("scalar", dict(algo=hip.ALGO_SCALAR)))
         for lpr in (4, 8):
             variants.append(("vector", dict(algo=hip.ALGO_VECTOR,
