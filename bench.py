@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--cm", default="p2p_nonblocking",
                     choices=["p2p_blocking", "p2p_nonblocking"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fused-reductions", action="store_true",
+                    help="finish dot products in the producing kernels")
     ap.add_argument("--cpu-n", type=int, default=256,
                     help="grid of the bounded CPU sample")
     ap.add_argument("--cpu-iters", type=int, default=10)
@@ -125,7 +127,8 @@ def main():
 
     # warm-up: W untimed iterations (also sizes the workspace, RCCL rings)
     if args.warmup > 0:
-        host.cg_ex(comm, exec_, A, d_b, d_x, args.warmup, 0.0, ws)
+        host.cg_ex(comm, exec_, A, d_b, d_x, args.warmup, 0.0, ws,
+                   fused_reductions=args.fused_reductions)
     torch.cuda.synchronize()
     barrier()
 
@@ -135,7 +138,8 @@ def main():
     t0 = time.perf_counter()
     k, _, spmv_ms, spmv_launches = host.cg_ex(comm, exec_, A, d_b, d_x,
                                               args.steps, 0.0, ws,
-                                              time_spmv=True)
+                                              time_spmv=True,
+                                              fused_reductions=args.fused_reductions)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0

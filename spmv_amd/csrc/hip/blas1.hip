@@ -57,9 +57,10 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(
 
 __global__ __launch_bounds__(kBlock) void dot_partial_kernel(
     int64_t n, const double* __restrict__ x, const double* __restrict__ y,
-    double* __restrict__ partials, int len)
+    DotOut dot)
 {
   __shared__ double s_red[kBlock / 64];
+  __shared__ int s_flag;
   double acc = 0.0;
   const int64_t n2 = n >> 1;
   const double2* x2 = reinterpret_cast<const double2*>(x);
@@ -73,10 +74,7 @@ __global__ __launch_bounds__(kBlock) void dot_partial_kernel(
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
     acc += x[n - 1] * y[n - 1];
-  double s = block_sum(acc, s_red);
-  if (threadIdx.x == 0)
-    partials[blockIdx.x] = s;
-  clear_partials_tail(partials, len);
+  spmv_dot_epilogue(dot, acc, s_red, &s_flag);
 }
 
 // Sum `len` partials in a fixed order with one workgroup.
@@ -277,6 +275,56 @@ __global__ __launch_bounds__(kBlock) void cg_update_xp_kernel(
   }
 }
 
+// K2' with both reductions folded in: the workgroup that finishes last adds
+// the r.r partials into rr[k] (no reducer launch), and the prologue raises
+// `done` when rr[k-1] met the tolerance (what cg_reduce_pAp_kernel does in the
+// two-stage form).  Every workgroup evaluates the same scalars, so the early
+// return is uniform across the grid.
+__global__ __launch_bounds__(kBlock) void cg_update_r_fused_kernel(
+    int64_t n, int k, const double* __restrict__ rr, const double* __restrict__ pAp,
+    CgScalars* __restrict__ sc, const double* __restrict__ Ap,
+    double* __restrict__ r, DotOut dot)
+{
+  __shared__ double s_red[kBlock / 64];
+  __shared__ int s_flag;
+  if (sc->done)
+    return;
+  const double rnorm_old = sqrt(rr[k - 1]);
+  if (k >= 2) {
+    const double rnorm0 = sqrt(rr[0]);
+    if (rnorm_old / rnorm0 < sc->rtol) { // cg.cpp:80-81 of iteration k-1
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc->kstop = k - 1;
+        sc->done = 1;
+      }
+      return;
+    }
+  }
+  const double alpha = (rnorm_old * rnorm_old) / pAp[k]; // cg.cpp:66
+  const double nalpha = -alpha;
+  double acc = 0.0;
+  const int64_t n2 = n >> 1;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const double2* Ap2 = reinterpret_cast<const double2*>(Ap);
+  double2* r2 = reinterpret_cast<double2*>(r);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2;
+       i += stride) {
+    double2 av = Ap2[i], rv = r2[i];
+    rv.x += nalpha * av.x; // cg.cpp:70
+    rv.y += nalpha * av.y;
+    r2[i] = rv;
+    acc += rv.x * rv.x; // cg.cpp:73
+    acc += rv.y * rv.y;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    double rv = r[i] + nalpha * Ap[i];
+    r[i] = rv;
+    acc += rv * rv;
+  }
+  spmv_dot_epilogue(dot, acc, s_red, &s_flag);
+}
+
 // Reduces the p.Ap partials of iteration k.  It is the first single-workgroup
 // kernel after the p-update of iteration k-1, so it also raises `done` when
 // rr[k-1] met the tolerance (cg.cpp:80-81): every later cg_* kernel then
@@ -314,7 +362,7 @@ __global__ __launch_bounds__(kBlock) void cg_reduce_pAp_kernel(
 }
 
 __global__ void cg_reset_kernel(CgScalars* sc, double rtol, double* rr,
-                                double* pAp, int kmax)
+                                double* pAp, int kmax, unsigned int* counters)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) {
@@ -322,6 +370,8 @@ __global__ void cg_reset_kernel(CgScalars* sc, double rtol, double* rr,
     sc->done = 0;
     sc->kstop = -1;
   }
+  if (i < 2 * (kDotShards + 1))
+    counters[i] = 0u;
   if (i <= kmax) {
     rr[i] = 0.0;
     pAp[i] = 0.0;
@@ -361,6 +411,7 @@ struct spmv_hip_cg_ws {
   double* pAp = nullptr;      // kmax + 1
   double* partials = nullptr; // ctx->dot_blocks
   CgScalars* sc = nullptr;
+  unsigned int* counters = nullptr; // arrival tickets of the fused reductions
 };
 
 extern "C" {
@@ -411,9 +462,11 @@ int spmv_hip_dot_partial_f64(spmv_hip_ctx* ctx, int64_t n, const double* x,
   SPMV_REQUIRE(n >= 0 && partials && (n == 0 || (x && y)));
   SPMV_REQUIRE(aligned16(x) && aligned16(y));
   const int grid = spmv_grid_for(ctx, n / 2, kBlock);
+  DotOut dot;
+  dot.partials = partials;
+  dot.len = ctx->dot_blocks;
   hipLaunchKernelGGL(dot_partial_kernel, dim3(grid), dim3(kBlock), 0,
-                     spmv_stream(ctx, stream), n, x, y, partials,
-                     ctx->dot_blocks);
+                     spmv_stream(ctx, stream), n, x, y, dot);
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;
 }
@@ -447,6 +500,11 @@ int spmv_hip_cg_ws_create(spmv_hip_ctx* ctx, int kmax, spmv_hip_cg_ws** out)
     e = hipMalloc(&ws->partials, sizeof(double) * ctx->dot_blocks);
   if (e == hipSuccess)
     e = hipMalloc(&ws->sc, sizeof(CgScalars));
+  if (e == hipSuccess)
+    e = hipMalloc(&ws->counters, 2 * (kDotShards + 1) * sizeof(unsigned int));
+  if (e == hipSuccess)
+    e = hipMemset(ws->counters, 0,
+                  2 * (kDotShards + 1) * sizeof(unsigned int));
   if (e != hipSuccess) {
     spmv_hip_cg_ws_destroy(ws);
     return static_cast<int>(e);
@@ -464,6 +522,7 @@ int spmv_hip_cg_ws_destroy(spmv_hip_cg_ws* ws)
   (void)hipFree(ws->pAp);
   (void)hipFree(ws->partials);
   (void)hipFree(ws->sc);
+  (void)hipFree(ws->counters);
   delete ws;
   return SPMV_HIP_OK;
 }
@@ -475,7 +534,7 @@ int spmv_hip_cg_ws_reset(spmv_hip_cg_ws* ws, double rtol, void* stream)
   const int n = ws->kmax + 1;
   hipLaunchKernelGGL(cg_reset_kernel, dim3((n + kBlock - 1) / kBlock),
                      dim3(kBlock), 0, spmv_stream(ws->ctx, stream), ws->sc,
-                     rtol, ws->rr, ws->pAp, ws->kmax);
+                     rtol, ws->rr, ws->pAp, ws->kmax, ws->counters);
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;
 }
@@ -630,6 +689,70 @@ int spmv_hip_cg_update_xp_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
   hipLaunchKernelGGL(cg_update_xp_kernel, dim3(grid), dim3(kBlock), 0,
                      spmv_stream(ctx, stream), n, k, ws->rr, ws->rr + (k - 1),
                      ws->rr + k, ws->pAp + k, ws->sc, r, x, p);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_dot_f64(spmv_hip_ctx* ctx, int64_t n, const double* x,
+                     const double* y, double* partials, double* result,
+                     uint32_t* counter, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(n >= 0 && partials && result && counter && (n == 0 || (x && y)));
+  SPMV_REQUIRE(aligned16(x) && aligned16(y));
+  const int grid = spmv_grid_for(ctx, n / 2, kBlock);
+  DotOut dot;
+  dot.partials = partials;
+  dot.len = ctx->dot_blocks;
+  dot.result = result;
+  dot.counter = counter;
+  hipLaunchKernelGGL(dot_partial_kernel, dim3(grid), dim3(kBlock), 0,
+                     spmv_stream(ctx, stream), n, x, y, dot);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_cg_ws_counter(spmv_hip_cg_ws* ws, uint32_t** counter)
+{
+  SPMV_REQUIRE(ws && counter);
+  *counter = ws->counters;
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_cg_dot_rr0_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int64_t n,
+                            const double* r, void* stream)
+{
+  SPMV_REQUIRE(ws && ws->ctx == ctx);
+  return spmv_hip_dot_f64(ctx, n, r, r, ws->partials, ws->rr,
+                          ws->counters + (kDotShards + 1), stream);
+}
+
+int spmv_hip_cg_dot_pAp_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
+                            int64_t n, const double* p, const double* Ap,
+                            void* stream)
+{
+  SPMV_REQUIRE(ws && ws->ctx == ctx && k >= 1 && k <= ws->kmax);
+  return spmv_hip_dot_f64(ctx, n, p, Ap, ws->partials, ws->pAp + k,
+                          ws->counters, stream);
+}
+
+int spmv_hip_cg_update_r_fused_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
+                                   int64_t n, const double* Ap, double* r,
+                                   void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(ws && ws->ctx == ctx && k >= 1 && k <= ws->kmax && n >= 0);
+  SPMV_REQUIRE(n == 0 || (Ap && r));
+  SPMV_REQUIRE(aligned16(Ap) && aligned16(r));
+  const int grid = spmv_grid_for(ctx, n / 2, kBlock);
+  DotOut dot;
+  dot.partials = ws->partials;
+  dot.len = ctx->dot_blocks;
+  dot.result = ws->rr + k;
+  dot.counter = ws->counters + (kDotShards + 1);
+  hipLaunchKernelGGL(cg_update_r_fused_kernel, dim3(grid), dim3(kBlock), 0,
+                     spmv_stream(ctx, stream), n, k, ws->rr, ws->pAp, ws->sc, Ap,
+                     r, dot);
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;
 }

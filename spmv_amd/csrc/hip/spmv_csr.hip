@@ -73,34 +73,6 @@ __device__ __forceinline__ P stream_load(const P* p)
     return *p;
 }
 
-// Block-wide sum of one double per thread (fixed tree => deterministic).
-__device__ __forceinline__ double block_sum(double v, double* s_red)
-{
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1)
-    v += __shfl_down(v, off, 64);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0)
-    s_red[wave] = v;
-  __syncthreads();
-  double r = 0.0;
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int w = 0; w < kBlock / 64; ++w)
-      r += s_red[w];
-  }
-  return r; // valid in thread 0
-}
-
-// The partial array has a fixed length; producers with a smaller grid clear
-// the tail so the reducer can always add all of it.
-__device__ __forceinline__ void clear_partials_tail(double* partials, int len)
-{
-  for (int i = gridDim.x + blockIdx.x * blockDim.x + threadIdx.x; i < len;
-       i += gridDim.x * blockDim.x)
-    partials[i] = 0.0;
-}
-
 // ---------------------------------------------------------------------------
 // ROWBLOCK general kernel
 //   CH      = 16-byte value loads per lane per tile (tile = 256*CH*V entries)
@@ -113,8 +85,7 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_kernel(
     int32_t num_rows, int64_t nnz, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ colind, const T* __restrict__ values, T alpha,
     const T* __restrict__ in, T beta, T* __restrict__ out,
-    double* __restrict__ dot_partials, int dot_len, int num_row_blocks,
-    int xcd_group)
+    DotOut dot, int num_row_blocks, int xcd_group)
 {
   constexpr int V = VecOf<T>::V;
   constexpr int TILE = kBlock * CH * V;
@@ -124,6 +95,7 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_kernel(
   __shared__ T s_prod[TILE];
   __shared__ int32_t s_rowptr[kRows + 1];
   __shared__ double s_red[kBlock / 64];
+  __shared__ int s_flag;
 
   const int t = threadIdx.x;
   double dot_acc = 0.0;
@@ -248,12 +220,8 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_kernel(
     }
   }
 
-  if constexpr (DOT) {
-    double s = block_sum(dot_acc, s_red);
-    if (t == 0)
-      dot_partials[blockIdx.x] = s;
-    clear_partials_tail(dot_partials, dot_len);
-  }
+  if constexpr (DOT)
+    spmv_dot_epilogue(dot, dot_acc, s_red, &s_flag);
 }
 
 // ---------------------------------------------------------------------------
@@ -268,8 +236,7 @@ __global__ __launch_bounds__(kBlock) void csr_rowwave_kernel(
     int32_t num_rows, int64_t nnz, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ colind, const T* __restrict__ values, T alpha,
     const T* __restrict__ in, T beta, T* __restrict__ out,
-    double* __restrict__ dot_partials, int dot_len, int num_row_blocks,
-    int xcd_group)
+    DotOut dot, int num_row_blocks, int xcd_group)
 {
   constexpr int V = VecOf<T>::V;
   constexpr int W = 64;               // lanes = rows per wave
@@ -281,6 +248,7 @@ __global__ __launch_bounds__(kBlock) void csr_rowwave_kernel(
   __shared__ T s_prod_all[NW][TILE];
   __shared__ int32_t s_rowptr_all[NW][W + 1];
   __shared__ double s_red[NW];
+  __shared__ int s_flag;
 
   const int wave = threadIdx.x / W;
   const int t = threadIdx.x % W;
@@ -389,12 +357,8 @@ __global__ __launch_bounds__(kBlock) void csr_rowwave_kernel(
     }
   }
 
-  if constexpr (DOT) {
-    double s = block_sum(dot_acc, s_red);
-    if (threadIdx.x == 0)
-      dot_partials[blockIdx.x] = s;
-    clear_partials_tail(dot_partials, dot_len);
-  }
+  if constexpr (DOT)
+    spmv_dot_epilogue(dot, dot_acc, s_red, &s_flag);
 }
 
 // ---------------------------------------------------------------------------
@@ -405,9 +369,10 @@ __global__ __launch_bounds__(kBlock) void csr_scalar_kernel(
     int32_t num_rows, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ colind, const T* __restrict__ values, T alpha,
     const T* __restrict__ in, T beta, T* __restrict__ out,
-    double* __restrict__ dot_partials, int dot_len)
+    DotOut dot)
 {
   __shared__ double s_red[kBlock / 64];
+  __shared__ int s_flag;
   double dot_acc = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
        i < num_rows; i += (int64_t)gridDim.x * blockDim.x) {
@@ -422,12 +387,8 @@ __global__ __launch_bounds__(kBlock) void csr_scalar_kernel(
     if constexpr (DOT)
       dot_acc += (double)in[i] * (double)c;
   }
-  if constexpr (DOT) {
-    double s = block_sum(dot_acc, s_red);
-    if (threadIdx.x == 0)
-      dot_partials[blockIdx.x] = s;
-    clear_partials_tail(dot_partials, dot_len);
-  }
+  if constexpr (DOT)
+    spmv_dot_epilogue(dot, dot_acc, s_red, &s_flag);
 }
 
 // ---------------------------------------------------------------------------
@@ -445,9 +406,10 @@ __global__ __launch_bounds__(kBlock) void csr_rowlist_kernel(
     int32_t num_listed, const int32_t* __restrict__ rows,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
     const T* __restrict__ values, T alpha, const T* __restrict__ in,
-    T* __restrict__ out, double* __restrict__ dot_partials, int dot_len)
+    T* __restrict__ out, DotOut dot)
 {
   __shared__ double s_red[kBlock / 64];
+  __shared__ int s_flag;
   double dot_acc = 0.0;
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
        k < num_listed; k += (int64_t)gridDim.x * blockDim.x) {
@@ -460,12 +422,8 @@ __global__ __launch_bounds__(kBlock) void csr_rowlist_kernel(
     if constexpr (DOT)
       dot_acc += (double)in[i] * (double)c;
   }
-  if constexpr (DOT) {
-    double s = block_sum(dot_acc, s_red);
-    if (threadIdx.x == 0)
-      dot_partials[blockIdx.x] = s;
-    clear_partials_tail(dot_partials, dot_len);
-  }
+  if constexpr (DOT)
+    spmv_dot_epilogue(dot, dot_acc, s_red, &s_flag);
 }
 
 struct NonEmptyRow {
@@ -481,9 +439,10 @@ __global__ __launch_bounds__(kBlock) void csr_vector_kernel(
     int32_t num_rows, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ colind, const T* __restrict__ values, T alpha,
     const T* __restrict__ in, T beta, T* __restrict__ out,
-    double* __restrict__ dot_partials, int dot_len)
+    DotOut dot)
 {
   __shared__ double s_red[kBlock / 64];
+  __shared__ int s_flag;
   constexpr int RPB = kBlock / LPR; // rows per workgroup
   const int sub = threadIdx.x % LPR;
   const int grp = threadIdx.x / LPR;
@@ -510,12 +469,8 @@ __global__ __launch_bounds__(kBlock) void csr_vector_kernel(
         dot_acc += (double)in[i] * (double)c;
     }
   }
-  if constexpr (DOT) {
-    double s = block_sum(dot_acc, s_red);
-    if (threadIdx.x == 0)
-      dot_partials[blockIdx.x] = s;
-    clear_partials_tail(dot_partials, dot_len);
-  }
+  if constexpr (DOT)
+    spmv_dot_epilogue(dot, dot_acc, s_red, &s_flag);
 }
 
 // ---------------------------------------------------------------------------
@@ -825,19 +780,18 @@ template <typename T, int CH, bool NT, bool ALIGNED, bool DOT>
 int launch_rowblock_x(const spmv_hip_csr_plan* pl, hipStream_t st, int grid,
                       int nrb, const int32_t* rowptr, const int32_t* colind,
                       const T* values, T alpha, const T* in, T beta, T* out,
-                      double* dot)
+                      DotOut dot)
 {
-  const int len = pl->ctx->dot_blocks;
   if (pl->xcd_group > 0)
     hipLaunchKernelGGL((csr_rowblock_kernel<T, CH, NT, ALIGNED, DOT, true>),
                        dim3(grid), dim3(kBlock), 0, st, pl->num_rows, pl->nnz,
-                       rowptr, colind, values, alpha, in, beta, out, dot, len,
-                       nrb, pl->xcd_group);
+                       rowptr, colind, values, alpha, in, beta, out, dot, nrb,
+                       pl->xcd_group);
   else
     hipLaunchKernelGGL((csr_rowblock_kernel<T, CH, NT, ALIGNED, DOT, false>),
                        dim3(grid), dim3(kBlock), 0, st, pl->num_rows, pl->nnz,
-                       rowptr, colind, values, alpha, in, beta, out, dot, len,
-                       nrb, 1);
+                       rowptr, colind, values, alpha, in, beta, out, dot, nrb,
+                       1);
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;
 }
@@ -846,7 +800,7 @@ template <typename T, bool DOT>
 int launch_rowblock(const spmv_hip_csr_plan* pl, hipStream_t st,
                     const int32_t* rowptr, const int32_t* colind,
                     const T* values, T alpha, const T* in, T beta, T* out,
-                    double* dot)
+                    DotOut dot)
 {
   const int nrb = (pl->num_rows + kRows - 1) / kRows;
   int grid = pl->ctx->num_cus * pl->blocks_per_cu;
@@ -858,11 +812,10 @@ int launch_rowblock(const spmv_hip_csr_plan* pl, hipStream_t st,
     grid = 1;
   const bool al = aligned16(values) && aligned16(colind);
   if (pl->wave_private && al) {
-    const int len = pl->ctx->dot_blocks;
 #define SPMV_RW(CH, NT)                                                        \
   hipLaunchKernelGGL((csr_rowwave_kernel<T, CH, NT, DOT>), dim3(grid),         \
                      dim3(kBlock), 0, st, pl->num_rows, pl->nnz, rowptr,       \
-                     colind, values, alpha, in, beta, out, dot, len, nrb,      \
+                     colind, values, alpha, in, beta, out, dot, nrb,           \
                      pl->xcd_group)
     if (pl->nontemporal) {
       if (pl->chunks == 1)
@@ -908,9 +861,8 @@ template <typename T, bool DOT>
 int launch_vector(const spmv_hip_csr_plan* pl, hipStream_t st,
                   const int32_t* rowptr, const int32_t* colind,
                   const T* values, T alpha, const T* in, T beta, T* out,
-                  double* dot)
+                  DotOut dot)
 {
-  const int len = pl->ctx->dot_blocks;
   const int lpr = pl->lanes_per_row;
   const int64_t nblk = ((int64_t)pl->num_rows * lpr + kBlock - 1) / kBlock;
   int grid = pl->ctx->dot_blocks;
@@ -919,7 +871,7 @@ int launch_vector(const spmv_hip_csr_plan* pl, hipStream_t st,
 #define SPMV_VEC(L)                                                            \
   hipLaunchKernelGGL((csr_vector_kernel<T, L, DOT>), dim3(grid), dim3(kBlock), \
                      0, st, pl->num_rows, rowptr, colind, values, alpha, in,   \
-                     beta, out, dot, len)
+                     beta, out, dot)
   switch (lpr) {
   case 4: SPMV_VEC(4); break;
   case 8: SPMV_VEC(8); break;
@@ -936,12 +888,12 @@ template <typename T, bool DOT>
 int launch_scalar(const spmv_hip_csr_plan* pl, hipStream_t st,
                   const int32_t* rowptr, const int32_t* colind,
                   const T* values, T alpha, const T* in, T beta, T* out,
-                  double* dot)
+                  DotOut dot)
 {
   const int grid = spmv_grid_for(pl->ctx, pl->num_rows, kBlock);
   hipLaunchKernelGGL((csr_scalar_kernel<T, DOT>), dim3(grid), dim3(kBlock), 0,
                      st, pl->num_rows, rowptr, colind, values, alpha, in, beta,
-                     out, dot, pl->ctx->dot_blocks);
+                     out, dot);
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;
 }
@@ -950,7 +902,7 @@ template <typename T, bool DOT>
 int launch_rowlist(const spmv_hip_csr_plan* pl, hipStream_t st,
                    const int32_t* rowptr, const int32_t* colind,
                    const T* values, T alpha, const T* in, T beta, T* out,
-                   double* dot)
+                   DotOut dot)
 {
   const int n = pl->num_rows;
   if (beta != T(1)) { // all rows: out = beta*out (0 without reading it)
@@ -966,7 +918,7 @@ int launch_rowlist(const spmv_hip_csr_plan* pl, hipStream_t st,
   const int grid = spmv_grid_for(pl->ctx, pl->num_listed, kBlock);
   hipLaunchKernelGGL((csr_rowlist_kernel<T, DOT>), dim3(grid), dim3(kBlock), 0,
                      st, pl->num_listed, pl->row_list, rowptr, colind, values,
-                     alpha, in, out, dot, pl->ctx->dot_blocks);
+                     alpha, in, out, dot);
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;
 }
@@ -974,7 +926,7 @@ int launch_rowlist(const spmv_hip_csr_plan* pl, hipStream_t st,
 template <typename T, bool DOT>
 int run_general(const spmv_hip_csr_plan* pl, hipStream_t st,
                 const int32_t* rowptr, const int32_t* colind, const T* values,
-                T alpha, const T* in, T beta, T* out, double* dot)
+                T alpha, const T* in, T beta, T* out, DotOut dot)
 {
   switch (pl->algo) {
   case SPMV_HIP_ALGO_VECTOR:
@@ -1262,11 +1214,41 @@ int spmv_hip_csr_spmv_f64(spmv_hip_ctx* ctx, const spmv_hip_csr_plan* plan,
     SPMV_CHECK_LAUNCH();
     return SPMV_HIP_OK;
   }
-  if (dot_partials)
+  if (dot_partials) {
+    DotOut dot;
+    dot.partials = dot_partials;
+    dot.len = ctx->dot_blocks;
     return run_general<double, true>(plan, st, rowptr, colind, values, alpha,
-                                     in, beta, out, dot_partials);
+                                     in, beta, out, dot);
+  }
   return run_general<double, false>(plan, st, rowptr, colind, values, alpha, in,
-                                    beta, out, nullptr);
+                                    beta, out, DotOut());
+}
+
+int spmv_hip_csr_spmv_dot_f64(spmv_hip_ctx* ctx, const spmv_hip_csr_plan* plan,
+                              int32_t num_rows, int32_t num_cols,
+                              int64_t num_non_zeros, const int32_t* rowptr,
+                              const int32_t* colind, const double* values,
+                              double alpha, const double* in, double beta,
+                              double* out, double* dot_partials,
+                              double* dot_result, uint32_t* dot_counter,
+                              int accumulate, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(plan && plan->ctx == ctx && !plan->symmetric);
+  SPMV_REQUIRE(num_rows == plan->num_rows && num_cols == plan->num_cols
+               && num_non_zeros == plan->nnz);
+  SPMV_REQUIRE(num_rows > 0 && num_non_zeros > 0);
+  SPMV_REQUIRE(in && out && rowptr && colind && values);
+  SPMV_REQUIRE(dot_partials && dot_result && dot_counter);
+  DotOut dot;
+  dot.partials = dot_partials;
+  dot.len = ctx->dot_blocks;
+  dot.result = dot_result;
+  dot.counter = dot_counter;
+  dot.accumulate = accumulate ? 1 : 0;
+  return run_general<double, true>(plan, spmv_stream(ctx, stream), rowptr,
+                                   colind, values, alpha, in, beta, out, dot);
 }
 
 int spmv_hip_csr_spmv_f32(spmv_hip_ctx* ctx, const spmv_hip_csr_plan* plan,
@@ -1296,7 +1278,7 @@ int spmv_hip_csr_spmv_f32(spmv_hip_ctx* ctx, const spmv_hip_csr_plan* plan,
     return SPMV_HIP_OK;
   }
   return run_general<float, false>(plan, st, rowptr, colind, values, alpha, in,
-                                   beta, out, nullptr);
+                                   beta, out, DotOut());
 }
 
 } // extern "C"

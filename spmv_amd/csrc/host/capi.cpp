@@ -660,7 +660,8 @@ int spmvh_cg_ex(spmvh_comm* comm, spmvh_exec* exec, spmvh_matrix* A,
     require(comm && exec && A && num_its, "NULL argument");
     std::vector<double> hist;
     CgOptions opt;
-    opt.time_spmv = time_spmv != 0;
+    opt.time_spmv = (time_spmv & 1) != 0;
+    opt.fused_reductions = (time_spmv & 2) != 0;
     CgStats st;
     *num_its = cg(*comm->comm, *exec->hip, *A->A, b, x, kmax, rtol,
                   rnorm_history ? &hist : nullptr, &opt, &st,

@@ -10,7 +10,11 @@
 //     reduce partials -> rr[k];  all-reduce    cg.cpp:74-76
 //     x += a p; stop test; p = beta p + r      cg.cpp:69,77-85
 //
-// 5 kernel launches + (multi-rank) 2 RCCL all-reduces of one double; the
+// The partial sums of a dot product are added in a fixed order either by a
+// single-workgroup reducer kernel (default) or by the last workgroup of the
+// producing kernel (CgOptions::fused_reductions: arrival ticket, nobody
+// waits).  5 (or 3) kernel launches per iteration (+ the small remote-block
+// kernel and two one-double RCCL all-reduces with more than one rank); the
 // reference's CUDA path needs 7 cuBLAS calls, 5 scalar kernels and 3 host
 // synchronisations for the same step (cuda/cg.cuda.cu:101-151).
 #include "cg.h"
@@ -173,11 +177,20 @@ int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
     return s;
   };
 
+  uint32_t* counters = nullptr; // [0] p.Ap, [1] r.r arrival tickets
+  throw_on_error(spmv_hip_cg_ws_counter(w.ws, &counters),
+                 "spmv_hip_cg_ws_counter");
+
   // rnorm0 (cg.cpp:47-50)
-  throw_on_error(spmv_hip_cg_dot_rr_f64(ctx, w.ws, M, w.r, nullptr),
-                 "spmv_hip_cg_dot_rr_f64");
-  throw_on_error(spmv_hip_cg_reduce_rr(ctx, w.ws, 0, nullptr),
-                 "spmv_hip_cg_reduce_rr");
+  if (opt.fused_reductions) {
+    throw_on_error(spmv_hip_cg_dot_rr0_f64(ctx, w.ws, M, w.r, nullptr),
+                   "spmv_hip_cg_dot_rr0_f64");
+  } else {
+    throw_on_error(spmv_hip_cg_dot_rr_f64(ctx, w.ws, M, w.r, nullptr),
+                   "spmv_hip_cg_dot_rr_f64");
+    throw_on_error(spmv_hip_cg_reduce_rr(ctx, w.ws, 0, nullptr),
+                   "spmv_hip_cg_reduce_rr");
+  }
   comm.allreduce_sum(slot(true, 0), 1, w.stream);
 
   EventList timing{exec, {}};
@@ -195,26 +208,41 @@ int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
       timing.ev.push_back(ev1);
       exec.record_event(ev0, w.stream);
     }
-    // cg.cpp:60,63: Ap = A p with the p.Ap partials fused into the kernels
-    const bool fused = A.mult_dot(w.p, w.Ap, partials, w.dot2, ev1);
-    if (fused) {
-      // local + remote shares -> pAp[k]
-      throw_on_error(spmv_hip_cg_reduce_pAp2(ctx, w.ws, k, w.dot2, nullptr),
-                     "spmv_hip_cg_reduce_pAp2");
+    // cg.cpp:60,63: Ap = A p with the p.Ap partials produced by the SpMV
+    // kernels themselves (local block's share + remote block's share)
+    if (opt.fused_reductions) {
+      // ... and added up by their last workgroup: no reducer launch
+      const bool fused = A.mult_dot(w.p, w.Ap, partials, w.dot2, ev1,
+                                    slot(false, k), counters);
+      if (!fused) // symmetric storage: the atomic scatter cannot carry the dot
+        throw_on_error(spmv_hip_cg_dot_pAp_f64(ctx, w.ws, k, M, w.p, w.Ap,
+                                               nullptr),
+                       "spmv_hip_cg_dot_pAp_f64");
+      comm.allreduce_sum(slot(false, k), 1, w.stream); // cg.cpp:65
+      throw_on_error(spmv_hip_cg_update_r_fused_f64(ctx, w.ws, k, M, w.Ap, w.r,
+                                                    nullptr),
+                     "spmv_hip_cg_update_r_fused_f64");
     } else {
-      throw_on_error(spmv_hip_dot_partial_f64(ctx, M, w.p, w.Ap, partials,
+      const bool fused = A.mult_dot(w.p, w.Ap, partials, w.dot2, ev1);
+      if (fused) {
+        throw_on_error(spmv_hip_cg_reduce_pAp2(ctx, w.ws, k, w.dot2, nullptr),
+                       "spmv_hip_cg_reduce_pAp2");
+      } else {
+        throw_on_error(spmv_hip_dot_partial_f64(ctx, M, w.p, w.Ap, partials,
+                                                nullptr),
+                       "spmv_hip_dot_partial_f64");
+        throw_on_error(spmv_hip_cg_reduce_pAp(ctx, w.ws, k, nullptr),
+                       "spmv_hip_cg_reduce_pAp");
+      }
+      comm.allreduce_sum(slot(false, k), 1, w.stream); // cg.cpp:65
+      // r -= alpha Ap with the r.r partials (cg.cpp:66,70,73); the x update
+      // of :69 rides with the p update below so p is read once per iteration
+      throw_on_error(spmv_hip_cg_update_r_f64(ctx, w.ws, k, M, w.Ap, w.r,
                                               nullptr),
-                     "spmv_hip_dot_partial_f64");
-      throw_on_error(spmv_hip_cg_reduce_pAp(ctx, w.ws, k, nullptr),
-                     "spmv_hip_cg_reduce_pAp");
+                     "spmv_hip_cg_update_r_f64");
+      throw_on_error(spmv_hip_cg_reduce_rr(ctx, w.ws, k, nullptr),
+                     "spmv_hip_cg_reduce_rr");
     }
-    comm.allreduce_sum(slot(false, k), 1, w.stream); // cg.cpp:65
-    // r -= alpha Ap with the r.r partials (cg.cpp:66,70,73); the x update of
-    // :69 rides with the p update below so p is read once per iteration
-    throw_on_error(spmv_hip_cg_update_r_f64(ctx, w.ws, k, M, w.Ap, w.r, nullptr),
-                   "spmv_hip_cg_update_r_f64");
-    throw_on_error(spmv_hip_cg_reduce_rr(ctx, w.ws, k, nullptr),
-                   "spmv_hip_cg_reduce_rr");
     comm.allreduce_sum(slot(true, k), 1, w.stream); // cg.cpp:75
     // x += alpha p ; stop test ; p = beta p + r   (cg.cpp:69,77-85)
     throw_on_error(spmv_hip_cg_update_xp_f64(ctx, w.ws, k, M, w.r, w.x, w.p,

@@ -43,6 +43,13 @@ public:
 struct CgOptions {
   int poll_every = 16;    // host looks at the device's `done` flag this often
   bool time_spmv = false; // bracket every local-block SpMV with HIP events
+  // false: every dot product is finished by a single-workgroup reducer kernel
+  //        (5 launches per iteration);
+  // true : by the last workgroup of the producing kernel (3 launches).
+  // Measured on MI355X: equal at 216^3 and 512^3, the reducer kernels are 9 %
+  // faster at 128^3 (the arrival tickets sit on the tail of a persistent
+  // grid), hence the default.
+  bool fused_reductions = false;
 };
 
 struct CgStats {

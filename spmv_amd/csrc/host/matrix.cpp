@@ -155,8 +155,11 @@ void Matrix<T>::spmv_sym_overlap(T* x, T* y) const
 
 template <typename T>
 bool Matrix<T>::mult_dot(T* x, T* y, double* dot_local, double* dot_remote,
-                         void* ev_local_done) const
+                         void* ev_local_done, double* result,
+                         uint32_t* counter) const
 {
+  const DotTarget tl{dot_local, result, counter, false};
+  const DotTarget tr{dot_remote, result, counter, true};
   auto* hip = dynamic_cast<HipExecutor*>(_exec.get());
   auto mark = [&] {
     if (ev_local_done && hip)
@@ -179,7 +182,7 @@ bool Matrix<T>::mult_dot(T* x, T* y, double* dot_local, double* dot_remote,
     return false;
   }
   if (!_col_map->overlapping()) {
-    const bool ok = _mat_local->mult_dot(1, x, 0, y, dot_local);
+    const bool ok = _mat_local->mult_dot(1, x, 0, y, tl);
     if (!ok)
       mult(x, y);
     mark();
@@ -187,7 +190,7 @@ bool Matrix<T>::mult_dot(T* x, T* y, double* dot_local, double* dot_remote,
   }
   // overlapping: local share, halo wait, remote share (same order as
   // spmv_overlap).  An empty local block cannot fuse -> plain path.
-  if (!_mat_local->mult_dot(1, x, 0, y, dot_local)) {
+  if (!_mat_local->mult_dot(1, x, 0, y, tl)) {
     mult(x, y);
     mark();
     return false;
@@ -195,7 +198,7 @@ bool Matrix<T>::mult_dot(T* x, T* y, double* dot_local, double* dot_remote,
   mark();
   _col_map->update_finalise(x);
   if (_mat_remote->non_zeros() > 0)
-    _mat_remote->mult_dot(1, x, 1, y, dot_remote);
+    _mat_remote->mult_dot(1, x, 1, y, tr);
   return true;
 }
 

@@ -463,7 +463,7 @@ class CgWorkspace:
 
 
 def cg_ex(comm, exec_, A, b_ptr, x_ptr, kmax, rtol, workspace=None,
-          time_spmv=False, history=False):
+          time_spmv=False, history=False, fused_reductions=False):
     """cg with the optional arguments: returns (k, history, spmv_ms_total,
     spmv_launches)."""
     k, n = C.c_int(), C.c_int()
@@ -471,7 +471,8 @@ def cg_ex(comm, exec_, A, b_ptr, x_ptr, kmax, rtol, workspace=None,
     hist = np.zeros(kmax + 1) if history else None
     call("spmvh_cg_ex", comm.h, exec_.h, A.h, b_ptr, x_ptr, kmax, float(rtol),
          C.byref(k), _np_ptr(hist), workspace.h if workspace else None,
-         int(time_spmv), C.byref(ms), C.byref(n))
+         int(time_spmv) | (2 if fused_reductions else 0), C.byref(ms),
+         C.byref(n))
     return (k.value, hist[:k.value + 1] if history else None, ms.value,
             n.value)
 

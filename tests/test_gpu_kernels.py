@@ -358,7 +358,8 @@ def test_device_poisson_matches_host(ctx, n, P):
 # CG building blocks: drive the kernels exactly as spmv::cg does and compare
 # with the oracle's CG (cg.cpp:21-98)
 # ---------------------------------------------------------------------------
-def gpu_cg(ctx, blk, b, kmax, rtol, fused_dot=True, regrouped=False):
+def gpu_cg(ctx, blk, b, kmax, rtol, fused_dot=True, regrouped=False,
+           single_launch=False):
     n = blk.nrows
     ws = C.c_void_p()
     hip.call("spmv_hip_cg_ws_create", ctx.h, kmax, C.byref(ws))
@@ -367,9 +368,32 @@ def gpu_cg(ctx, blk, b, kmax, rtol, fused_dot=True, regrouped=False):
     hip.call("spmv_hip_cg_ws_partials", ws, C.byref(part))
     r, p = ctx.upload(b), ctx.upload(b)
     x, Ap = ctx.zeros(n, np.float64), ctx.zeros(n, np.float64)
-    hip.call("spmv_hip_cg_dot_rr_f64", ctx.h, ws, n, r.ptr, None)
-    hip.call("spmv_hip_cg_reduce_rr", ctx.h, ws, 0, None)
-    for k in range(1, kmax + 1):
+    if single_launch:  # exactly the sequence of spmv::cg (host/cg.cpp)
+        cnt = C.c_void_p()
+        hip.call("spmv_hip_cg_ws_counter", ws, C.byref(cnt))
+        hip.call("spmv_hip_cg_dot_rr0_f64", ctx.h, ws, n, r.ptr, None)
+        for k in range(1, kmax + 1):
+            slot = C.c_void_p()
+            hip.call("spmv_hip_cg_ws_pAp", ws, k, C.byref(slot))
+            if blk.symmetric:
+                blk.mult(1.0, p.ptr, 0.0, Ap.ptr)
+                hip.call("spmv_hip_cg_dot_pAp_f64", ctx.h, ws, k, n, p.ptr,
+                         Ap.ptr, None)
+            else:
+                hip.call("spmv_hip_csr_spmv_dot_f64", ctx.h, blk.plan, n,
+                         blk.ncols, blk.nnz, blk.rowptr.ptr, blk.colind.ptr,
+                         blk.values.ptr, 1.0, p.ptr, 0.0, Ap.ptr, part, slot,
+                         cnt, 0, None)
+            hip.call("spmv_hip_cg_update_r_fused_f64", ctx.h, ws, k, n, Ap.ptr,
+                     r.ptr, None)
+            hip.call("spmv_hip_cg_update_xp_f64", ctx.h, ws, k, n, r.ptr, x.ptr,
+                     p.ptr, None)
+        kmax_loop = 0
+    else:
+        hip.call("spmv_hip_cg_dot_rr_f64", ctx.h, ws, n, r.ptr, None)
+        hip.call("spmv_hip_cg_reduce_rr", ctx.h, ws, 0, None)
+        kmax_loop = kmax
+    for k in range(1, kmax_loop + 1):
         if fused_dot and not blk.symmetric:
             blk.mult(1.0, p.ptr, 0.0, Ap.ptr, dot_partials=part)
         else:
@@ -420,6 +444,13 @@ def test_cg_kernels_match_oracle(ctx, symmetric):
     # both groupings of the vector updates are the same arithmetic
     x2, flags2, hist2 = gpu_cg(ctx, blk, b, 200, 1e-10, regrouped=True)
     assert np.array_equal(flags, flags2)
+    x3, flags3, hist3 = gpu_cg(ctx, blk, b, 200, 1e-10, single_launch=True)
+    assert flags3[0] == 1 and abs(int(flags3[1]) - int(flags[1])) <= 1
+    if not symmetric:  # same partials, same summation order => same bits
+        assert np.array_equal(flags, flags3)
+        assert np.array_equal(x, x3) and np.array_equal(hist, hist3)
+    else:
+        assert np.linalg.norm(x - x3) <= 1e-9 * np.linalg.norm(x)
     if not symmetric:  # deterministic kernels: bit-identical
         assert np.array_equal(x, x2) and np.array_equal(hist, hist2)
     else:
@@ -491,3 +522,58 @@ def test_full_size_properties(ctx, n):
     for b in (x, y):
         b.free()
     blk.free(), sym.free()
+
+
+# ---------------------------------------------------------------------------
+# single-launch (last-workgroup) reductions == the two-stage ones, bit for bit
+# ---------------------------------------------------------------------------
+def test_fused_reductions_match_two_stage(ctx):
+    rng = np.random.default_rng(21)
+    counter = ctx.zeros(33, np.uint32)
+    res = ctx.empty(2, np.float64)
+    part = ctx.empty(ctx.dot_partials_len, np.float64)
+    for n in (1, 2, 513, 1 << 16, (1 << 22) + 3):
+        x, y = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+        dx, dy = ctx.upload(x), ctx.upload(y)
+        two_stage = ctx.dot(n, dx.ptr, dy.ptr)
+        for rep in range(3):  # the ticket resets itself between launches
+            hip.call("spmv_hip_dot_f64", ctx.h, n, dx.ptr, dy.ptr, part.ptr,
+                     res.ptr, counter.ptr, None)
+            assert res.numpy(1)[0] == two_stage
+            assert not counter.numpy().any()
+        dx.free(), dy.free()
+    # SpMV with the fused p.Ap: assign, then accumulate a second block's share
+    n = 20
+    N = n ** 3
+    rp, ci, va = poisson.poisson3d_csr(n)
+    ci = ci.astype(np.int32)
+    blk = hip.CsrBlock(ctx, N, N, rp, ci, va)
+    x = oracle.gaussian_x_fast(N)
+    dx, dy = ctx.upload(x), ctx.empty(N, np.float64)
+    blk.mult(1.0, dx.ptr, 0.0, dy.ptr, dot_partials=part.ptr)
+    ref = ctx.empty(1, np.float64)
+    hip.call("spmv_hip_reduce_partials_f64", ctx.h, part.ptr, ref.ptr, None)
+    expect = ref.numpy()[0]
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    assert abs(expect - float(x @ y_ref)) <= 1e-12 * abs(expect)
+    for knobs in (dict(), dict(algo=hip.ALGO_SCALAR), dict(algo=hip.ALGO_VECTOR),
+                  dict(wave_private=1)):
+        for k, v in knobs.items():
+            blk.set(k, v)
+        for accumulate in (0, 1):
+            ctx.fill_const(1, 100.0, res.ptr)
+            hip.call("spmv_hip_csr_spmv_dot_f64", ctx.h, blk.plan, N, N, blk.nnz,
+                     blk.rowptr.ptr, blk.colind.ptr, blk.values.ptr, 1.0, dx.ptr,
+                     0.0, dy.ptr, part.ptr, res.ptr, counter.ptr, accumulate,
+                     None)
+            got = res.numpy(1)[0] - (100.0 if accumulate else 0.0)
+            if knobs or accumulate:  # other kernels group the rows differently
+                assert abs(got - expect) <= 1e-12 * abs(expect)
+            else:                    # same kernel, same order: same bits
+                assert got == expect
+            assert np.array_equal(dy.numpy(), y_ref) or knobs.get("algo") == hip.ALGO_VECTOR
+        blk.set("algo", hip.ALGO_ROWBLOCK)
+        blk.set("wave_private", 0)
+    for b in (dx, dy, counter, res, part, ref):
+        b.free()
+    blk.free()
