@@ -89,10 +89,14 @@ int spmvh_comm_callback(int rank, int nranks, spmvh_allgather_fn allgather,
 int spmvh_comm_destroy(spmvh_comm* comm);
 
 /* ---- matrix: Matrix<double>::create_matrix / create_poisson3d --------------- */
+/* rowptr has nrows_local + num_row_ghosts + 1 entries: the extra rows hold
+ * contributions to the global rows `row_ghosts` owned by other ranks and are
+ * shipped to them (Matrix.cpp:188-292). */
 int spmvh_matrix_create(spmvh_comm* comm, spmvh_exec* exec,
                         const int32_t* rowptr, const int32_t* colind,
                         const double* values, int64_t nrows_local,
-                        int64_t ncols_local, const int64_t* col_ghosts,
+                        int64_t ncols_local, const int64_t* row_ghosts,
+                        int64_t num_row_ghosts, const int64_t* col_ghosts,
                         int64_t num_col_ghosts, int symmetric, int cm,
                         spmvh_matrix** A);
 int spmvh_matrix_create_poisson3d(spmvh_comm* comm, spmvh_exec* exec, int32_t n,
@@ -123,6 +127,14 @@ int spmvh_split_create(const int32_t* rowptr, const int32_t* colind,
                        spmvh_split** split, int64_t sizes[8]);
 /* which: 0 local, 1 remote.  Arrays sized from `sizes`; diagonal/ghosts may
  * be NULL. */
+/* collective variant with ghost-row elimination (split_rows_distributed) */
+int spmvh_split_create_dist(spmvh_comm* comm, const int32_t* rowptr,
+                            const int32_t* colind, const double* values,
+                            int64_t nrows_local, int64_t ncols_local,
+                            const int64_t* row_ghosts, int64_t num_row_ghosts,
+                            const int64_t* col_ghosts, int64_t num_col_ghosts,
+                            int symmetric, int cm, spmvh_split** split,
+                            int64_t sizes[8]);
 int spmvh_split_get(spmvh_split* split, int which, int32_t* rowptr,
                     int32_t* colind, double* values);
 int spmvh_split_extra(spmvh_split* split, double* diagonal, int64_t* ghosts);

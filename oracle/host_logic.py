@@ -231,6 +231,65 @@ def create_matrix(rank, row_ranges, col_ranges, rowptr, colind, values,
     return out
 
 
+def create_matrices_with_row_ghosts(ranges, inputs, symmetric=False,
+                                    cm=COLLECTIVE_BLOCKING):
+    """Matrix::create_matrix INCLUDING row-ghost elimination
+    (spmv/Matrix.cpp:188-292, 295-318, 363-408) for all ranks at once.
+
+    inputs[r] = (rowptr, colind, values, row_ghosts, col_ghosts): rowptr has
+    nrows_local + len(row_ghosts) rows; the extra rows hold contributions to
+    the global rows `row_ghosts` (owned elsewhere); colind is local (ghost
+    columns >= ncols_local index into col_ghosts).  Returns one block dict per
+    rank (as create_matrix)."""
+    P = len(inputs)
+    sent = [[] for _ in range(P)]  # sent[owner] = list of (src, grow, gcols, vals)
+    for r, (rp, ci, va, rg, cg) in enumerate(inputs):
+        nloc = int(ranges[r + 1] - ranges[r])
+        rp, ci, va = np.asarray(rp), np.asarray(ci, dtype=np.int64), np.asarray(va)
+        cg = np.asarray(cg, dtype=np.int64)
+        for i, grow in enumerate(rg):                               # :229-251
+            owner = int(np.searchsorted(ranges, grow, side="right") - 1)
+            assert owner != r
+            a, b = int(rp[nloc + i]), int(rp[nloc + i + 1])
+            lc = ci[a:b]
+            gc = np.where(lc < nloc, lc + ranges[r], cg[np.maximum(lc - nloc, 0)])
+            sent[owner].append((r, int(grow), gc, va[a:b]))
+    out = []
+    for r, (rp, ci, va, rg, cg) in enumerate(inputs):
+        nloc = int(ranges[r + 1] - ranges[r])
+        rp = np.asarray(rp)
+        ci = np.asarray(ci, dtype=np.int64)[:rp[nloc]]
+        va = np.asarray(va)[:rp[nloc]]
+        cg = np.asarray(cg, dtype=np.int64)
+        recv = sorted(sent[r], key=lambda t: t[0])  # by source rank (alltoallv)
+        extra_cols = [gc[(gc < ranges[r]) | (gc >= ranges[r + 1])]
+                      for _, _, gc, _ in recv]
+        new_ghosts = np.unique(np.concatenate([cg] + extra_cols)).astype(np.int64)
+        # local entries (global columns), then received ones, in that order
+        row = np.repeat(np.arange(nloc, dtype=np.int64), np.diff(rp[:nloc + 1]))
+        gcol = np.where(ci < nloc, ci + ranges[r], cg[np.maximum(ci - nloc, 0)])
+        rows = [row] + [np.full(len(gc), grow - ranges[r], np.int64)
+                        for _, grow, gc, _ in recv]
+        gcols = [gcol] + [gc for _, _, gc, _ in recv]
+        vals = [va] + [v for _, _, _, v in recv]
+        row, gcol, val = (np.concatenate(rows), np.concatenate(gcols),
+                          np.concatenate(vals))
+        owned = (gcol >= ranges[r]) & (gcol < ranges[r + 1])
+        lcol = np.where(owned, gcol - ranges[r],
+                        nloc + np.searchsorted(new_ghosts, gcol))
+        # hand the merged triplets to the no-row-ghost splitter: one "row
+        # block" whose columns are already final
+        order = np.argsort(row, kind="stable")
+        rp2 = np.zeros(nloc + 1, np.int64)
+        np.add.at(rp2, row + 1, 1)
+        rp2 = np.cumsum(rp2)
+        # ghost list is already sorted/unique, so create_matrix keeps numbering
+        A = create_matrix(r, ranges, ranges, rp2, lcol[order], val[order],
+                          new_ghosts, symmetric, cm)
+        out.append(A)
+    return out
+
+
 def _block_mult(block, alpha, x, beta, y, diagonal=None, symmetric=False):
     """CSRMatrix::mult, spmv/csr_matrix.cpp:81-87 (+ guard :85)."""
     rp, ci, va = block

@@ -270,19 +270,22 @@ int spmvh_comm_destroy(spmvh_comm* comm)
 int spmvh_matrix_create(spmvh_comm* comm, spmvh_exec* exec,
                         const int32_t* rowptr, const int32_t* colind,
                         const double* values, int64_t nrows_local,
-                        int64_t ncols_local, const int64_t* col_ghosts,
+                        int64_t ncols_local, const int64_t* row_ghosts,
+                        int64_t num_row_ghosts, const int64_t* col_ghosts,
                         int64_t num_col_ghosts, int symmetric, int cm,
                         spmvh_matrix** A)
 {
   return guarded([&] {
     require(comm && exec && A && rowptr, "NULL argument");
-    std::vector<int64_t> ghosts;
+    std::vector<int64_t> rg, cg;
+    if (num_row_ghosts > 0)
+      rg.assign(row_ghosts, row_ghosts + num_row_ghosts);
     if (num_col_ghosts > 0)
-      ghosts.assign(col_ghosts, col_ghosts + num_col_ghosts);
+      cg.assign(col_ghosts, col_ghosts + num_col_ghosts);
     auto m = std::make_unique<spmvh_matrix>();
     m->A.reset(Matrix<double>::create_matrix(comm->comm, exec->hip, rowptr,
                                              colind, values, nrows_local,
-                                             ncols_local, {}, ghosts,
+                                             ncols_local, rg, cg,
                                              symmetric != 0, to_cm(cm)));
     *A = m.release();
   });
@@ -414,6 +417,45 @@ int spmvh_split_create(const int32_t* rowptr, const int32_t* colind,
     sizes[5] = s.remote.non_zeros();
     sizes[6] = static_cast<int64_t>(s.col_ghosts.size());
     sizes[7] = s.nnz_full;
+    *split = sp.release();
+  });
+}
+
+namespace
+{
+void fill_split_sizes(const Matrix<double>::Split& s, int64_t sizes[8])
+{
+  sizes[0] = s.local.rows;
+  sizes[1] = s.local.cols;
+  sizes[2] = s.local.non_zeros();
+  sizes[3] = s.remote.rows;
+  sizes[4] = s.remote.cols;
+  sizes[5] = s.remote.non_zeros();
+  sizes[6] = static_cast<int64_t>(s.col_ghosts.size());
+  sizes[7] = s.nnz_full;
+}
+} // namespace
+
+int spmvh_split_create_dist(spmvh_comm* comm, const int32_t* rowptr,
+                            const int32_t* colind, const double* values,
+                            int64_t nrows_local, int64_t ncols_local,
+                            const int64_t* row_ghosts, int64_t num_row_ghosts,
+                            const int64_t* col_ghosts, int64_t num_col_ghosts,
+                            int symmetric, int cm, spmvh_split** split,
+                            int64_t sizes[8])
+{
+  return guarded([&] {
+    require(comm && rowptr && split && sizes, "NULL argument");
+    std::vector<int64_t> rg, cg;
+    if (num_row_ghosts > 0)
+      rg.assign(row_ghosts, row_ghosts + num_row_ghosts);
+    if (num_col_ghosts > 0)
+      cg.assign(col_ghosts, col_ghosts + num_col_ghosts);
+    auto sp = std::make_unique<spmvh_split>();
+    sp->s = Matrix<double>::split_rows_distributed(
+        *comm->comm, rowptr, colind, values, nrows_local, ncols_local, rg, cg,
+        symmetric != 0, to_cm(cm));
+    fill_split_sizes(sp->s, sizes);
     *split = sp.release();
   });
 }

@@ -31,6 +31,26 @@ Comm::allgatherv(const std::vector<int32_t>& mine) const
   return out;
 }
 
+std::vector<std::vector<unsigned char>>
+Comm::allgatherv_bytes(const void* mine, size_t num_bytes) const
+{
+  const int P = size();
+  std::vector<int64_t> lens
+      = allgather_value<int64_t>(static_cast<int64_t>(num_bytes));
+  const int64_t max_len = *std::max_element(lens.begin(), lens.end());
+  std::vector<std::vector<unsigned char>> out(P);
+  if (max_len == 0)
+    return out;
+  std::vector<unsigned char> send(max_len, 0), recv(max_len * P);
+  if (num_bytes)
+    std::memcpy(send.data(), mine, num_bytes);
+  allgather(send.data(), recv.data(), static_cast<size_t>(max_len));
+  for (int r = 0; r < P; ++r)
+    out[r].assign(recv.begin() + r * max_len,
+                  recv.begin() + r * max_len + lens[r]);
+  return out;
+}
+
 // ---- SelfComm ----------------------------------------------------------------
 void SelfComm::allgather(const void* send, void* recv, size_t bytes) const
 {

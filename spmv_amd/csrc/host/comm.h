@@ -83,6 +83,9 @@ public:
   // every rank contributes a vector of arbitrary length; returns all of them
   std::vector<std::vector<int32_t>>
   allgatherv(const std::vector<int32_t>& mine) const;
+  // byte-level variant: out[r] = rank r's buffer
+  std::vector<std::vector<unsigned char>>
+  allgatherv_bytes(const void* mine, size_t num_bytes) const;
 };
 
 class SelfComm final : public Comm

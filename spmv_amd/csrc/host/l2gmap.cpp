@@ -12,17 +12,12 @@ L2GMap::L2GMap(std::shared_ptr<const Comm> comm, std::int64_t local_size,
                std::shared_ptr<DeviceExecutor> exec, CommunicationModel cm)
     : _comm(std::move(comm)), _exec(std::move(exec)), _cm(cm), _ghosts(ghosts)
 {
-  switch (cm) {
-  case CommunicationModel::p2p_blocking:
-  case CommunicationModel::p2p_nonblocking:
-  case CommunicationModel::collective_blocking:
-  case CommunicationModel::collective_nonblocking:
-    break;
-  default:
-    throw std::runtime_error(
-        "L2GMap: one-sided and shmem models have no MI355X counterpart; use "
-        "a p2p or collective model (all map to RCCL send/recv over xGMI)");
-  }
+  // All eight models of the reference are accepted.  They differ only in the
+  // MPI mechanism that moves the ghosts (L2GMap.cpp:868-896); here every one
+  // of them is the same grouped RCCL send/recv.  Only the two *_nonblocking
+  // models defer completion to update_finalise() (overlapping(), :975-981);
+  // the one-sided and shmem models complete inside update() like the
+  // reference's.
   _hip = dynamic_cast<HipExecutor*>(_exec.get());
   const int P = _comm->size();
   _rank = _comm->rank();

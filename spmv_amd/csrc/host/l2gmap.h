@@ -10,8 +10,9 @@
 //     stream wait inside update(); "non-blocking" models (p2p_nonblocking,
 //     collective_nonblocking) defer that wait to update_finalise(), so the
 //     local-block SpMV overlaps the exchange (Matrix.cpp:498-511).
-//   * one-sided and shmem models are CPU-MPI research variants with no
-//     counterpart here: the constructor rejects them.
+//   * the one-sided and shmem models (CPU-MPI research variants) are accepted
+//     and behave like the blocking p2p model: same data movement, same
+//     completion point.
 //   * when the indices a neighbour wants are one contiguous run (slab
 //     partitions of stencil matrices), the data is sent straight out of the
 //     vector and the pack kernel is skipped.

@@ -252,12 +252,17 @@ typename Matrix<T>::Split Matrix<T>::split_rows(
     const int32_t* rowptr, const int32_t* colind, const T* values,
     int64_t nrows_local, int64_t ncols_local, int64_t global_row_offset,
     int64_t global_col_offset, const std::vector<int64_t>& col_ghosts,
-    bool symmetric, CommunicationModel cm)
+    bool symmetric, CommunicationModel cm, const std::vector<ExtraEntry>* extra)
 {
   Split out;
   // ghost columns renumbered in ascending global order after the owned
-  // columns (Matrix.cpp:295-318)
+  // columns (Matrix.cpp:295-318); received rows may bring new ones (:299-313)
   out.col_ghosts = col_ghosts;
+  if (extra)
+    for (const ExtraEntry& e : *extra)
+      if (e.global_col < global_col_offset
+          || e.global_col >= global_col_offset + ncols_local)
+        out.col_ghosts.push_back(e.global_col);
   std::sort(out.col_ghosts.begin(), out.col_ghosts.end());
   out.col_ghosts.erase(
       std::unique(out.col_ghosts.begin(), out.col_ghosts.end()),
@@ -271,6 +276,28 @@ typename Matrix<T>::Split Matrix<T>::split_rows(
     out.diagonal.assign(nrows_local, T(0)); // Matrix.cpp:429
     has_diag.assign(nrows_local, 0);
   }
+  // one rule for local and received entries (Matrix.cpp:337-358, 388-407)
+  auto place = [&](int32_t row, int64_t col, T val) {
+    const Triplet<T> t{row, static_cast<int32_t>(col), val};
+    if (symmetric) { // Matrix.cpp:337-349
+      if (col < ncols_local) {
+        const int64_t grow = row + global_row_offset;
+        const int64_t gcol = col + global_col_offset;
+        if (grow > gcol)
+          loc.push_back(t);
+        else if (grow == gcol) {
+          out.diagonal[row] += val;
+          has_diag[row] = 1;
+        } // strictly-upper entries are implied by symmetry and dropped
+      } else {
+        rem.push_back(t);
+      }
+    } else if (nonblocking(cm)) { // Matrix.cpp:350-355
+      (col < ncols_local ? loc : rem).push_back(t);
+    } else { // Matrix.cpp:357
+      loc.push_back(t);
+    }
+  };
   for (int64_t row = 0; row < nrows_local; ++row) {
     for (int32_t j = rowptr[row]; j < rowptr[row + 1]; ++j) {
       int64_t col = colind[j];
@@ -285,28 +312,24 @@ typename Matrix<T>::Split Matrix<T>::split_rows(
       } else if (col < 0) {
         throw std::runtime_error("create_matrix: negative column index");
       }
-      const Triplet<T> t{static_cast<int32_t>(row), static_cast<int32_t>(col),
-                         values[j]};
-      if (symmetric) { // Matrix.cpp:337-349
-        if (col < ncols_local) {
-          const int64_t grow = row + global_row_offset;
-          const int64_t gcol = col + global_col_offset;
-          if (grow > gcol)
-            loc.push_back(t);
-          else if (grow == gcol) {
-            out.diagonal[row] += values[j];
-            has_diag[row] = 1;
-          } // strictly-upper entries are implied by symmetry and dropped
-        } else {
-          rem.push_back(t);
-        }
-      } else if (nonblocking(cm)) { // Matrix.cpp:350-355
-        (col < ncols_local ? loc : rem).push_back(t);
-      } else { // Matrix.cpp:357
-        loc.push_back(t);
-      }
+      place(static_cast<int32_t>(row), col, values[j]);
     }
   }
+  if (extra) // received ghost rows, after the local entries (Matrix.cpp:363-408)
+    for (const ExtraEntry& e : *extra) {
+      int64_t col;
+      if (e.global_col >= global_col_offset
+          && e.global_col < global_col_offset + ncols_local)
+        col = e.global_col - global_col_offset;
+      else
+        col = ncols_local
+              + (std::lower_bound(new_ghosts.begin(), new_ghosts.end(),
+                                  e.global_col)
+                 - new_ghosts.begin());
+      if (e.row < 0 || e.row >= nrows_local)
+        throw std::runtime_error("create_matrix: received row out of range");
+      place(e.row, col, e.val);
+    }
   const int32_t nrows = static_cast<int32_t>(nrows_local);
   if (symmetric) { // Matrix.cpp:415-446
     out.local = assemble(nrows, ncols_all, loc);
@@ -330,29 +353,97 @@ typename Matrix<T>::Split Matrix<T>::split_rows(
 }
 
 template <typename T>
+typename Matrix<T>::Split Matrix<T>::split_rows_distributed(
+    const Comm& comm, const int32_t* rowptr, const int32_t* colind,
+    const T* values, int64_t nrows_local, int64_t ncols_local,
+    const std::vector<int64_t>& row_ghosts,
+    const std::vector<int64_t>& col_ghosts, bool symmetric,
+    CommunicationModel cm)
+{
+  const int P = comm.size(), me = comm.rank();
+  // global row / column ranges (Matrix.cpp:175-186)
+  std::vector<int64_t> nr = comm.allgather_value<int64_t>(nrows_local);
+  std::vector<int64_t> nc = comm.allgather_value<int64_t>(ncols_local);
+  std::vector<int64_t> row_ranges(P + 1, 0), col_ranges(P + 1, 0);
+  for (int r = 0; r < P; ++r) {
+    row_ranges[r + 1] = row_ranges[r] + nr[r];
+    col_ranges[r + 1] = col_ranges[r] + nc[r];
+  }
+
+  // does anybody hold ghost rows?  (collective decision)
+  std::vector<int64_t> ng
+      = comm.allgather_value<int64_t>(static_cast<int64_t>(row_ghosts.size()));
+  bool any = false;
+  for (int64_t c : ng)
+    any = any || c > 0;
+  std::vector<ExtraEntry> extra;
+  if (any) {
+    // Ship every ghost row to its owner with GLOBAL column ids
+    // (Matrix.cpp:229-292).  Packet: {global row, nnz, cols...} in an int64
+    // stream and the values at the same positions of a T stream; all ranks
+    // see all packets (host all-gather) and keep the rows they own.
+    std::vector<int64_t> idx;
+    std::vector<T> val;
+    for (size_t i = 0; i < row_ghosts.size(); ++i) {
+      const int64_t grow = row_ghosts[i];
+      if (grow < 0 || grow >= row_ranges[P]
+          || (grow >= row_ranges[me] && grow < row_ranges[me + 1]))
+        throw std::runtime_error("create_matrix: bad ghost row index");
+      const int32_t a = rowptr[nrows_local + i], b = rowptr[nrows_local + i + 1];
+      idx.push_back(grow);
+      val.push_back(T(0));
+      idx.push_back(b - a);
+      val.push_back(T(0));
+      for (int32_t j = a; j < b; ++j) {
+        int64_t gcol;
+        if (colind[j] < ncols_local) {
+          gcol = colind[j] + col_ranges[me];
+        } else {
+          const size_t g = static_cast<size_t>(colind[j] - ncols_local);
+          if (g >= col_ghosts.size())
+            throw std::runtime_error("create_matrix: ghost column out of range");
+          gcol = col_ghosts[g];
+        }
+        idx.push_back(gcol);
+        val.push_back(values[j]);
+      }
+    }
+    auto all_idx = comm.allgatherv_bytes(idx.data(), idx.size() * sizeof(int64_t));
+    auto all_val = comm.allgatherv_bytes(val.data(), val.size() * sizeof(T));
+    for (int src = 0; src < P; ++src) { // source-rank order, like alltoallv
+      if (src == me)
+        continue;
+      const int64_t* pi = reinterpret_cast<const int64_t*>(all_idx[src].data());
+      const T* pv = reinterpret_cast<const T*>(all_val[src].data());
+      const size_t n = all_idx[src].size() / sizeof(int64_t);
+      size_t pos = 0;
+      while (pos < n) {
+        const int64_t grow = pi[pos];
+        const int64_t cnt = pi[pos + 1];
+        pos += 2;
+        const bool mine = grow >= row_ranges[me] && grow < row_ranges[me + 1];
+        for (int64_t k = 0; k < cnt; ++k, ++pos)
+          if (mine)
+            extra.push_back({static_cast<int32_t>(grow - row_ranges[me]),
+                             pi[pos], pv[pos]});
+      }
+    }
+  }
+  return split_rows(rowptr, colind, values, nrows_local, ncols_local,
+                    row_ranges[me], col_ranges[me], col_ghosts, symmetric, cm,
+                    any ? &extra : nullptr);
+}
+
+template <typename T>
 Matrix<T>* Matrix<T>::create_matrix(
     std::shared_ptr<const Comm> comm, std::shared_ptr<DeviceExecutor> exec,
     const int32_t* rowptr, const int32_t* colind, const T* values,
     int64_t nrows_local, int64_t ncols_local, std::vector<int64_t> row_ghosts,
     std::vector<int64_t> col_ghosts, bool symmetric, CommunicationModel cm)
 {
-  if (!row_ghosts.empty())
-    throw std::runtime_error(
-        "Matrix::create_matrix: row ghosts (rows assembled on a non-owner "
-        "rank, Matrix.cpp:188-292) are not supported by this backend yet");
-  const int P = comm->size(), me = comm->rank();
-
-  // global row / column offsets (Matrix.cpp:175-186)
-  std::vector<int64_t> nr = comm->allgather_value<int64_t>(nrows_local);
-  std::vector<int64_t> nc = comm->allgather_value<int64_t>(ncols_local);
-  int64_t row_off = 0, col_off = 0;
-  for (int r = 0; r < me; ++r) {
-    row_off += nr[r];
-    col_off += nc[r];
-  }
-  (void)P;
-  Split s = split_rows(rowptr, colind, values, nrows_local, ncols_local,
-                       row_off, col_off, col_ghosts, symmetric, cm);
+  Split s = split_rows_distributed(*comm, rowptr, colind, values, nrows_local,
+                                   ncols_local, row_ghosts, col_ghosts,
+                                   symmetric, cm);
 
   auto col_map = std::make_shared<L2GMap>(comm, ncols_local, s.col_ghosts, exec,
                                           cm);

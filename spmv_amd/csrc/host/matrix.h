@@ -5,8 +5,8 @@
 // Differences, all forced by the environment or the scope:
 //   * Eigen::SparseMatrix arguments become CsrHost<T> (no Eigen here).
 //   * MPI_Comm becomes std::shared_ptr<const Comm>.
-//   * create_matrix accepts an empty `row_ghosts` only: shipping ghost rows
-//     to their owners (Matrix.cpp:188-292) is "next" in SURVEY section 8f.
+//   * ghost rows are shipped to their owners over the communicator's host
+//     all-gather instead of MPI neighbourhood collectives (Matrix.cpp:188-292).
 //   * create_poisson3d builds the blocks directly on the device (the
 //     reference has no Poisson generator).
 #pragma once
@@ -86,12 +86,28 @@ public:
     int64_t nnz_full = 0;            // what Matrix::non_zeros() reports
     bool two_blocks = false;
   };
+  // Contributions to this rank's rows received from other ranks (ghost-row
+  // elimination): local row, GLOBAL column, value.
+  struct ExtraEntry {
+    int32_t row;
+    int64_t global_col;
+    T val;
+  };
   static Split split_rows(const int32_t* rowptr, const int32_t* colind,
                           const T* values, int64_t nrows_local,
                           int64_t ncols_local, int64_t global_row_offset,
                           int64_t global_col_offset,
                           const std::vector<int64_t>& col_ghosts,
-                          bool symmetric, CommunicationModel cm);
+                          bool symmetric, CommunicationModel cm,
+                          const std::vector<ExtraEntry>* extra = nullptr);
+  // Host half of create_matrix including the ghost-row exchange
+  // (Matrix.cpp:175-292): collective over `comm`, touches no device.
+  static Split split_rows_distributed(
+      const Comm& comm, const int32_t* rowptr, const int32_t* colind,
+      const T* values, int64_t nrows_local, int64_t ncols_local,
+      const std::vector<int64_t>& row_ghosts,
+      const std::vector<int64_t>& col_ghosts, bool symmetric,
+      CommunicationModel cm);
 
   // 3-D 7-point Poisson matrix on an n^3 grid, rows split over the ranks of
   // `comm` by the reference's even rule (read_petsc.cpp:20-37), generated on

@@ -45,8 +45,10 @@ _PROTOS = {
     "spmvh_comm_callback": [C.c_int, C.c_int, ALLGATHER_FN, EXCHANGE_FN,
                             ALLREDUCE_FN, vp, PTR(vp)],
     "spmvh_comm_destroy": [vp],
-    "spmvh_matrix_create": [vp, vp, vp, vp, vp, i64, i64, vp, i64, C.c_int,
-                            C.c_int, PTR(vp)],
+    "spmvh_matrix_create": [vp, vp, vp, vp, vp, i64, i64, vp, i64, vp, i64,
+                            C.c_int, C.c_int, PTR(vp)],
+    "spmvh_split_create_dist": [vp, vp, vp, vp, i64, i64, vp, i64, vp, i64,
+                                C.c_int, C.c_int, PTR(vp), PTR(i64)],
     "spmvh_matrix_create_poisson3d": [vp, vp, i32, C.c_int, C.c_int, PTR(vp)],
     "spmvh_matrix_destroy": [vp],
     "spmvh_matrix_rows": [vp, PTR(C.c_int)],
@@ -312,15 +314,15 @@ class Matrix:
     def create_matrix(cls, comm, exec_, rowptr, colind, values, nrows_local,
                       ncols_local, row_ghosts, col_ghosts, symmetric=False,
                       cm=COLLECTIVE_BLOCKING):
-        assert len(row_ghosts) == 0
         rp = np.ascontiguousarray(rowptr, np.int32)
         ci = np.ascontiguousarray(colind, np.int32)
         va = np.ascontiguousarray(values, np.float64)
+        rg = np.ascontiguousarray(row_ghosts, np.int64)
         cg = np.ascontiguousarray(col_ghosts, np.int64)
         h = vp()
         call("spmvh_matrix_create", comm.h, exec_.h, _np_ptr(rp), _np_ptr(ci),
-             _np_ptr(va), int(nrows_local), int(ncols_local), _np_ptr(cg),
-             len(cg), int(symmetric), cm, C.byref(h))
+             _np_ptr(va), int(nrows_local), int(ncols_local), _np_ptr(rg),
+             len(rg), _np_ptr(cg), len(cg), int(symmetric), cm, C.byref(h))
         return cls(h)
 
     @classmethod
@@ -373,17 +375,7 @@ class Matrix:
         call("spmvh_matrix_mult", self.h, x_ptr, y_ptr)
 
 
-def split_rows(rowptr, colind, values, nrows_local, ncols_local, row_offset,
-               col_offset, col_ghosts, symmetric, cm):
-    """Matrix<double>::split_rows: the host half of create_matrix (no GPU)."""
-    rp = np.ascontiguousarray(rowptr, np.int32)
-    ci = np.ascontiguousarray(colind, np.int32)
-    va = np.ascontiguousarray(values, np.float64)
-    cg = np.ascontiguousarray(col_ghosts, np.int64)
-    h, sizes = vp(), (i64 * 8)()
-    call("spmvh_split_create", _np_ptr(rp), _np_ptr(ci), _np_ptr(va),
-         int(nrows_local), int(ncols_local), int(row_offset), int(col_offset),
-         _np_ptr(cg), len(cg), int(symmetric), cm, C.byref(h), sizes)
+def _split_result(h, sizes, nrows_local, symmetric):
     out = dict(nnz=sizes[7])
     for which, name in ((0, "local"), (1, "remote")):
         rows, cols, nnz = sizes[3 * which:3 * which + 3]
@@ -402,6 +394,36 @@ def split_rows(rowptr, colind, values, nrows_local, ncols_local, row_offset,
     out["ghosts"] = ghosts
     call("spmvh_split_destroy", h)
     return out
+
+
+def split_rows(rowptr, colind, values, nrows_local, ncols_local, row_offset,
+               col_offset, col_ghosts, symmetric, cm):
+    """Matrix<double>::split_rows: the host half of create_matrix (no GPU)."""
+    rp = np.ascontiguousarray(rowptr, np.int32)
+    ci = np.ascontiguousarray(colind, np.int32)
+    va = np.ascontiguousarray(values, np.float64)
+    cg = np.ascontiguousarray(col_ghosts, np.int64)
+    h, sizes = vp(), (i64 * 8)()
+    call("spmvh_split_create", _np_ptr(rp), _np_ptr(ci), _np_ptr(va),
+         int(nrows_local), int(ncols_local), int(row_offset), int(col_offset),
+         _np_ptr(cg), len(cg), int(symmetric), cm, C.byref(h), sizes)
+    return _split_result(h, sizes, nrows_local, symmetric)
+
+
+def split_rows_distributed(comm, rowptr, colind, values, nrows_local,
+                           ncols_local, row_ghosts, col_ghosts, symmetric, cm):
+    """Matrix<double>::split_rows_distributed: collective over `comm`, ships
+    ghost rows to their owners (Matrix.cpp:188-292); no GPU."""
+    rp = np.ascontiguousarray(rowptr, np.int32)
+    ci = np.ascontiguousarray(colind, np.int32)
+    va = np.ascontiguousarray(values, np.float64)
+    rg = np.ascontiguousarray(row_ghosts, np.int64)
+    cg = np.ascontiguousarray(col_ghosts, np.int64)
+    h, sizes = vp(), (i64 * 8)()
+    call("spmvh_split_create_dist", comm.h, _np_ptr(rp), _np_ptr(ci),
+         _np_ptr(va), int(nrows_local), int(ncols_local), _np_ptr(rg), len(rg),
+         _np_ptr(cg), len(cg), int(symmetric), cm, C.byref(h), sizes)
+    return _split_result(h, sizes, nrows_local, symmetric)
 
 
 def cg(comm, exec_, A, b_ptr, x_ptr, kmax, rtol, history=True):

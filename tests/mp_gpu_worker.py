@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import dist_util  # noqa: E402
 import oracle  # noqa: E402
 from spmv_amd import host, poisson  # noqa: E402
-from util import U, abs_bound  # noqa: E402
+from util import U, abs_bound, assembled_inputs  # noqa: E402
 
 EPS = np.finfo(float).eps
 
@@ -51,7 +51,9 @@ def main():
         r0, r1 = int(ranges[rank]), int(ranges[rank + 1])
         lrp, lci, lva, ghosts = oracle.localise_rows(rp, ci, va, r0, r1)
         for symmetric in (False, True):
-            for cm in (host.P2P_BLOCKING, host.P2P_NONBLOCKING):
+            for cm in (host.P2P_BLOCKING, host.P2P_NONBLOCKING,
+                       host.COLLECTIVE_NONBLOCKING, host.ONESIDED_PUT_ACTIVE,
+                       host.SHMEM):
                 # --- tests/test_spmv_cuda.cpp:127-160 ---
                 A = host.Matrix.create_matrix(comm, exec_, lrp, lci, lva,
                                               r1 - r0, r1 - r0, [], ghosts,
@@ -71,7 +73,8 @@ def main():
                 xs = exec_.copy_to_host(d_x, l2g.local_size() + l2g.num_ghosts())
                 assert np.array_equal(xs[r1 - r0:], x[ghosts])
                 y = dist_util.gather_concat(exec_.copy_to_host(d_y, r1 - r0))
-                y_ref = oracle.dist_spmv(world, rp, ci, va, x, symmetric, cm)
+                y_ref = oracle.dist_spmv(world, rp, ci, va, x, symmetric,
+                                         cm if cm < 4 else host.P2P_BLOCKING)
                 norm = float(np.sqrt(np.sum(y * y)))
                 if symmetric:
                     assert np.all(np.abs(y - y_seq) <= 16 * U * abs_bound(rp, ci, va, x)), name
@@ -123,6 +126,29 @@ def main():
             A.close()
             for p in (d_x, d_y, d_b, d_s):
                 exec_.free(p)
+    # create_matrix WITH row ghosts (FEM-style assembly, Matrix.cpp:188-292):
+    # dyadic values => the assembled product is exact, y must equal A x
+    for seed, sym in ((3, False), (4, True)):
+        rng = np.random.default_rng(seed)
+        Ad, ranges, inputs = assembled_inputs(rng, world, 61, symmetric=sym)
+        N = Ad.shape[0]
+        x = np.round(rng.uniform(-2, 2, N) * 16) / 16
+        r0, r1 = int(ranges[rank]), int(ranges[rank + 1])
+        rp, ci, va, rg, cg = inputs[rank]
+        for cm in (host.P2P_BLOCKING, host.P2P_NONBLOCKING):
+            A = host.Matrix.create_matrix(comm, exec_, rp, ci, va, r1 - r0,
+                                          r1 - r0, rg, cg, sym, cm)
+            l2g = A.col_map()
+            d_x = exec_.alloc(l2g.local_size() + l2g.num_ghosts())
+            d_y = exec_.alloc(r1 - r0)
+            exec_.copy_from_host(d_x, x[r0:r1])
+            l2g.update(d_x)
+            A.mult(d_x, d_y)
+            y = dist_util.gather_concat(exec_.copy_to_host(d_y, r1 - r0))
+            assert np.array_equal(y, Ad @ x), (sym, cm)
+            A.close()
+            exec_.free(d_x), exec_.free(d_y)
+
     # PETSc binary ingest on every rank (demos/cg.cpp flow), unstructured
     import tempfile
     import torch.distributed as dist

@@ -16,6 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import dist_util  # noqa: E402
 import oracle  # noqa: E402
 from spmv_amd import host, poisson  # noqa: E402
+from util import assembled_inputs  # noqa: E402
 
 
 def main():
@@ -75,6 +76,28 @@ def main():
                         assert np.array_equal(a, b), name
                 if sym:
                     assert np.array_equal(s["diagonal"], A["diagonal"])
+    # ghost-row elimination (Matrix.cpp:188-292): every rank holds pieces of
+    # rows it does not own; the C++ exchange + split must equal the oracle's
+    for seed, sym in ((1, False), (2, True)):
+        rng = np.random.default_rng(seed)  # same stream on every rank
+        A, ranges, inputs = assembled_inputs(rng, world, 29, symmetric=sym)
+        rp, ci, va, rg, cg = inputs[rank]
+        nloc = int(ranges[rank + 1] - ranges[rank])
+        for cm in (host.P2P_BLOCKING, host.P2P_NONBLOCKING):
+            exp = oracle.create_matrices_with_row_ghosts(ranges, inputs, sym,
+                                                         cm)[rank]
+            got = host.split_rows_distributed(comm, rp, ci, va, nloc, nloc, rg,
+                                              cg, sym, cm)
+            assert np.array_equal(got["ghosts"], exp["ghosts"])
+            assert got["nnz"] == exp["nnz"]
+            for name in ("local", "remote"):
+                if exp[name] is None:
+                    assert len(got[name][2]) == 0
+                    continue
+                for a, b in zip(got[name], exp[name]):
+                    assert np.array_equal(a, b), (name, sym, cm)
+            if sym:
+                assert np.array_equal(got["diagonal"], exp["diagonal"])
     comm.close()
     print(f"rank {rank}/{world}: plan + split OK", flush=True)
 

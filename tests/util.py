@@ -45,3 +45,58 @@ def lower_split(rowptr, colind, values):
     np.add.at(rp, rows[lo] + 1, 1)
     return (np.cumsum(rp).astype(np.int32), colind[lo].astype(np.int32),
             values[lo].copy(), diag)
+
+
+def assembled_inputs(rng, P, N, density=0.2, symmetric=False):
+    """A global matrix A and, per rank, the pieces a finite-element style
+    assembly would hold: contributions to its own rows AND to rows owned by
+    other ranks ("row ghosts", spmv/Matrix.cpp:188-292), some entries split
+    over two ranks.  Values are dyadic so every partial sum is exact.
+    Returns (A dense, ranges, inputs) with inputs[r] = (rowptr, colind local,
+    values, row_ghosts, col_ghosts)."""
+    dense = (rng.random((N, N)) < density) | np.eye(N, dtype=bool)
+    vals = np.round(rng.uniform(-4, 4, (N, N)) * 8) / 8
+    if symmetric:
+        dense = dense | dense.T
+        vals = np.round((vals + vals.T) * 4) / 8
+    A = np.where(dense, vals, 0.0)
+    q, rem = divmod(N, P)
+    ranges = np.array([k * (q + 1) if k < rem else k * q + rem
+                       for k in range(P + 1)], dtype=np.int64)
+    owner = lambda i: int(np.searchsorted(ranges, i, side="right") - 1)  # noqa: E731
+    contrib = [[] for _ in range(P)]
+    for i, j in zip(*np.nonzero(dense)):
+        v, o = A[i, j], owner(i)
+        u = rng.random()
+        if u < 0.25 and P > 1:      # split over the owner and another rank
+            other = int(rng.integers(P))
+            contrib[o].append((i, j, v / 2))
+            contrib[other].append((i, j, v / 2))
+        elif u < 0.5 and P > 1:     # assembled entirely elsewhere
+            contrib[int(rng.integers(P))].append((i, j, v))
+        else:
+            contrib[o].append((i, j, v))
+    inputs = []
+    for r in range(P):
+        r0, r1 = int(ranges[r]), int(ranges[r + 1])
+        nloc = r1 - r0
+        ent = contrib[r]
+        rg = sorted({i for i, _, _ in ent if not r0 <= i < r1})
+        cg = sorted({j for _, j, _ in ent if not r0 <= j < r1})
+        rowmap = {**{i: i - r0 for i in range(r0, r1)},
+                  **{g: nloc + k for k, g in enumerate(rg)}}
+        colmap = {**{j: j - r0 for j in range(r0, r1)},
+                  **{g: nloc + k for k, g in enumerate(cg)}}
+        rows = [[] for _ in range(nloc + len(rg))]
+        for i, j, v in ent:
+            rows[rowmap[i]].append((colmap[j], v))
+        rp, ci, va = [0], [], []
+        for rr in rows:
+            for c, v in rr:
+                ci.append(c)
+                va.append(v)
+            rp.append(len(ci))
+        inputs.append((np.array(rp, np.int32), np.array(ci, np.int64),
+                       np.array(va, np.float64), np.array(rg, np.int64),
+                       np.array(cg, np.int64)))
+    return A, ranges, inputs
