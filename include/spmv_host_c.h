@@ -115,6 +115,22 @@ int spmvh_matrix_update(spmvh_matrix* A, double* x);
 int spmvh_matrix_update_finalise(spmvh_matrix* A, double* x);
 int spmvh_matrix_mult(spmvh_matrix* A, double* x, double* y);
 
+/* ---- fp32 instantiation: Matrix<float> (device_executor.h:88-99 carries float
+ * visitors).  Same calls, float data. */
+typedef struct spmvh_matrix_f32 spmvh_matrix_f32;
+int spmvh_matrix_f32_create(spmvh_comm* comm, spmvh_exec* exec,
+                            const int32_t* rowptr, const int32_t* colind,
+                            const float* values, int64_t nrows_local,
+                            int64_t ncols_local, const int64_t* row_ghosts,
+                            int64_t num_row_ghosts, const int64_t* col_ghosts,
+                            int64_t num_col_ghosts, int symmetric, int cm,
+                            spmvh_matrix_f32** A);
+int spmvh_matrix_f32_destroy(spmvh_matrix_f32* A);
+int spmvh_matrix_f32_info(spmvh_matrix_f32* A, int* rows, int64_t* nnz,
+                          int32_t* local_size, int32_t* num_ghosts);
+int spmvh_matrix_f32_update(spmvh_matrix_f32* A, float* x);
+int spmvh_matrix_f32_mult(spmvh_matrix_f32* A, float* x, float* y);
+
 /* Host half of create_matrix only (Matrix<double>::split_rows): no device.
  * sizes[0..7] = local rows, cols, nnz, remote rows, cols, nnz, number of
  * (renumbered) ghost columns, nnz_full. */

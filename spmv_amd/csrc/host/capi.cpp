@@ -27,6 +27,9 @@ struct spmvh_comm {
 struct spmvh_matrix {
   std::unique_ptr<Matrix<double>> A;
 };
+struct spmvh_matrix_f32 {
+  std::unique_ptr<Matrix<float>> A;
+};
 struct spmvh_l2g {
   std::unique_ptr<L2GMap> map;
 };
@@ -418,6 +421,63 @@ int spmvh_split_create(const int32_t* rowptr, const int32_t* colind,
     sizes[6] = static_cast<int64_t>(s.col_ghosts.size());
     sizes[7] = s.nnz_full;
     *split = sp.release();
+  });
+}
+
+int spmvh_matrix_f32_create(spmvh_comm* comm, spmvh_exec* exec,
+                            const int32_t* rowptr, const int32_t* colind,
+                            const float* values, int64_t nrows_local,
+                            int64_t ncols_local, const int64_t* row_ghosts,
+                            int64_t num_row_ghosts, const int64_t* col_ghosts,
+                            int64_t num_col_ghosts, int symmetric, int cm,
+                            spmvh_matrix_f32** A)
+{
+  return guarded([&] {
+    require(comm && exec && A && rowptr, "NULL argument");
+    std::vector<int64_t> rg, cg;
+    if (num_row_ghosts > 0)
+      rg.assign(row_ghosts, row_ghosts + num_row_ghosts);
+    if (num_col_ghosts > 0)
+      cg.assign(col_ghosts, col_ghosts + num_col_ghosts);
+    auto m = std::make_unique<spmvh_matrix_f32>();
+    m->A.reset(Matrix<float>::create_matrix(comm->comm, exec->hip, rowptr,
+                                            colind, values, nrows_local,
+                                            ncols_local, rg, cg, symmetric != 0,
+                                            to_cm(cm)));
+    *A = m.release();
+  });
+}
+
+int spmvh_matrix_f32_destroy(spmvh_matrix_f32* A)
+{
+  return guarded([&] { delete A; });
+}
+
+int spmvh_matrix_f32_info(spmvh_matrix_f32* A, int* rows, int64_t* nnz,
+                          int32_t* local_size, int32_t* num_ghosts)
+{
+  return guarded([&] {
+    require(A != nullptr, "NULL argument");
+    if (rows) *rows = A->A->rows();
+    if (nnz) *nnz = A->A->non_zeros();
+    if (local_size) *local_size = A->A->col_map()->local_size();
+    if (num_ghosts) *num_ghosts = A->A->col_map()->num_ghosts();
+  });
+}
+
+int spmvh_matrix_f32_update(spmvh_matrix_f32* A, float* x)
+{
+  return guarded([&] {
+    require(A != nullptr, "NULL argument");
+    A->A->col_map()->update(x);
+  });
+}
+
+int spmvh_matrix_f32_mult(spmvh_matrix_f32* A, float* x, float* y)
+{
+  return guarded([&] {
+    require(A != nullptr, "NULL argument");
+    A->A->mult(x, y);
   });
 }
 

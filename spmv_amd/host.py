@@ -47,6 +47,12 @@ _PROTOS = {
     "spmvh_comm_destroy": [vp],
     "spmvh_matrix_create": [vp, vp, vp, vp, vp, i64, i64, vp, i64, vp, i64,
                             C.c_int, C.c_int, PTR(vp)],
+    "spmvh_matrix_f32_create": [vp, vp, vp, vp, vp, i64, i64, vp, i64, vp, i64,
+                                C.c_int, C.c_int, PTR(vp)],
+    "spmvh_matrix_f32_destroy": [vp],
+    "spmvh_matrix_f32_info": [vp, PTR(C.c_int), PTR(i64), PTR(i32), PTR(i32)],
+    "spmvh_matrix_f32_update": [vp, vp],
+    "spmvh_matrix_f32_mult": [vp, vp, vp],
     "spmvh_split_create_dist": [vp, vp, vp, vp, i64, i64, vp, i64, vp, i64,
                                 C.c_int, C.c_int, PTR(vp), PTR(i64)],
     "spmvh_matrix_create_poisson3d": [vp, vp, i32, C.c_int, C.c_int, PTR(vp)],
@@ -373,6 +379,43 @@ class Matrix:
 
     def mult(self, x_ptr, y_ptr):
         call("spmvh_matrix_mult", self.h, x_ptr, y_ptr)
+
+
+class MatrixF32:
+    """spmv::Matrix<float> (fp32 instantiation)"""
+
+    def __init__(self, comm, exec_, rowptr, colind, values, nrows_local,
+                 ncols_local, row_ghosts, col_ghosts, symmetric=False,
+                 cm=COLLECTIVE_BLOCKING):
+        rp = np.ascontiguousarray(rowptr, np.int32)
+        ci = np.ascontiguousarray(colind, np.int32)
+        va = np.ascontiguousarray(values, np.float32)
+        rg = np.ascontiguousarray(row_ghosts, np.int64)
+        cg = np.ascontiguousarray(col_ghosts, np.int64)
+        h = vp()
+        call("spmvh_matrix_f32_create", comm.h, exec_.h, _np_ptr(rp),
+             _np_ptr(ci), _np_ptr(va), int(nrows_local), int(ncols_local),
+             _np_ptr(rg), len(rg), _np_ptr(cg), len(cg), int(symmetric), cm,
+             C.byref(h))
+        self.h = h
+
+    def info(self):
+        rows, nnz, ls, ng = C.c_int(), i64(), i32(), i32()
+        call("spmvh_matrix_f32_info", self.h, C.byref(rows), C.byref(nnz),
+             C.byref(ls), C.byref(ng))
+        return dict(rows=rows.value, nnz=nnz.value, local_size=ls.value,
+                    num_ghosts=ng.value)
+
+    def update(self, x_ptr):
+        call("spmvh_matrix_f32_update", self.h, x_ptr)
+
+    def mult(self, x_ptr, y_ptr):
+        call("spmvh_matrix_f32_mult", self.h, x_ptr, y_ptr)
+
+    def close(self):
+        if self.h:
+            call("spmvh_matrix_f32_destroy", self.h)
+            self.h = None
 
 
 def _split_result(h, sizes, nrows_local, symmetric):

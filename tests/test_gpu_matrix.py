@@ -271,3 +271,28 @@ def test_cg_fused_reductions_equal_default(exec_, comm):
     assert np.array_equal(out[0][2], out[1][2])
     A.close()
     exec_.free(d_b), exec_.free(d_x)
+
+
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_matrix_fp32(exec_, comm, symmetric):
+    """Matrix<float>: the fp32 visitors of the executor interface
+    (device_executor.h:88-99)."""
+    n = 9
+    N = n ** 3
+    rp, ci, va = poisson.poisson3d_csr(n, dtype=np.float32)
+    x = oracle.gaussian_x_fast(N).astype(np.float32)
+    y_ref = oracle.csr_spmv(rp, ci.astype(np.int32), va, x)
+    for cm in (host.P2P_BLOCKING, host.P2P_NONBLOCKING):
+        A = host.MatrixF32(comm, exec_, rp, ci, va, N, N, [], [], symmetric, cm)
+        assert A.info() == dict(rows=N, nnz=len(va), local_size=N, num_ghosts=0)
+        d_x, d_y = exec_.alloc(N, np.float32), exec_.alloc(N, np.float32)
+        exec_.copy_from_host(d_x, x)
+        A.update(d_x)
+        A.mult(d_x, d_y)
+        y = exec_.copy_to_host(d_y, N, np.float32)
+        if symmetric:
+            assert np.allclose(y, y_ref, rtol=0, atol=16 * 2.0 ** -24 * 12)
+        else:
+            assert np.array_equal(y, y_ref)
+        A.close()
+        exec_.free(d_x), exec_.free(d_y)

@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--out", default=None)
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--fp32", action="store_true",
+                    help="also time the fp32 instantiation (host-built matrix)")
     ap.add_argument("--only", default=None, help="comma list of variants")
     args = ap.parse_args()
     ctx = hip.Context(0)
@@ -103,6 +105,24 @@ def main():
         emit(n=n, variant="rowblock+dot", ms=tmin, ms_med=tmed,
              gbs=bytes_csr / tmin / 1e6, frac=bytes_csr / tmin / 1e6 / HBM_PEAK)
         blk.free()
+
+        if args.fp32 and n <= 256:
+            rp32, ci32, va32 = poisson.poisson3d_csr(n, dtype=np.float32)
+            b32 = hip.CsrBlock(ctx, N, N, rp32, ci32.astype(np.int32), va32,
+                               dtype=np.float32)
+            del rp32, ci32, va32
+            x32, y32 = ctx.zeros(N, np.float32), ctx.empty(N, np.float32)
+            bytes32 = poisson.csr_bytes(N, N, b32.nnz, value_bytes=4)
+            for ch, nt in ((1, 0), (1, 1), (2, 1), (4, 1)):
+                b32.set("chunks", ch)
+                b32.set("nontemporal", nt)
+                tmin, tmed = time_ms(
+                    ctx, lambda: b32.mult(1.0, x32.ptr, 0.0, y32.ptr), reps)
+                emit(n=n, variant="rowblock_fp32",
+                     knobs=dict(chunks=ch, nontemporal=nt), ms=tmin,
+                     ms_med=tmed, gbs=bytes32 / tmin / 1e6,
+                     frac=bytes32 / tmin / 1e6 / HBM_PEAK)
+            b32.free(), x32.free(), y32.free()
 
         # symmetric
         sym = hip.poisson3d_block(ctx, n, 0, N, hip.PART_LOCAL_LOWER,
