@@ -45,7 +45,7 @@ def parse():
                     help="finish dot products in the producing kernels")
     ap.add_argument("--cpu-n", type=int, default=256,
                     help="grid of the bounded CPU sample")
-    ap.add_argument("--cpu-iters", type=int, default=10)
+    ap.add_argument("--cpu-iters", type=int, default=30)
     return ap.parse_args()
 
 
