@@ -225,6 +225,181 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// ROWBLOCK, software-pipelined variant (aligned arrays, one 16-B value load
+// per lane per tile).  Same arithmetic and order as csr_rowblock_kernel; what
+// changes is when loads are issued:
+//   * the row pointer of the NEXT row block is fetched into registers while
+//     the current one is processed;
+//   * inside a row block the matrix loads of tile k+1 are issued right after
+//     the x gathers of tile k (vmcnt counts in issue order, so the gathers can
+//     be waited for while the younger prefetch stays in flight);
+//   * the product tile is double-buffered in LDS: one barrier per tile.
+// Per row block the dependent chain shrinks from K*(matrix + gather latency)
+// to matrix + K*gather, which matters because only 7-8 workgroups per CU are
+// available to hide it.
+// ---------------------------------------------------------------------------
+template <typename T, bool NT, bool DOT>
+__global__ __launch_bounds__(kBlock) void csr_rowblock_pipe_kernel(
+    int32_t num_rows, int64_t nnz, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ colind, const T* __restrict__ values, T alpha,
+    const T* __restrict__ in, T beta, T* __restrict__ out, DotOut dot,
+    int num_row_blocks, int xcd_group)
+{
+  constexpr int V = VecOf<T>::V;
+  constexpr int TILE = kBlock * V;
+  using val_t = typename VecOf<T>::val_t;
+  using col_t = typename VecOf<T>::col_t;
+
+  __shared__ T s_prod[2][TILE];
+  __shared__ int32_t s_rowptr[2][kRows + 1];
+  __shared__ double s_red[kBlock / 64];
+  __shared__ int s_flag;
+
+  const int t = threadIdx.x;
+  double dot_acc = 0.0;
+  const int grp = xcd_group > 0 ? xcd_group : 1;
+  const int super = 8 * grp;
+  const int num_slots = xcd_group > 0
+                            ? ((num_row_blocks + super - 1) / super) * super
+                            : num_row_blocks;
+  auto slot_to_rb = [&](int it) {
+    if (xcd_group <= 0)
+      return it;
+    const int q = it % super;
+    return (it - q) + (q & 7) * grp + (q >> 3);
+  };
+  // first valid slot of this workgroup and its row pointer
+  int it = blockIdx.x;
+  while (it < num_slots && slot_to_rb(it) >= num_row_blocks)
+    it += gridDim.x;
+  int32_t rp_reg = 0, rp_last = 0;
+  if (it < num_slots) {
+    const int32_t r0 = slot_to_rb(it) * kRows;
+    const int nr = min(kRows, num_rows - r0);
+    if (t <= nr)
+      rp_reg = rowptr[r0 + t];
+    if (t == 0 && nr == kRows)
+      rp_last = rowptr[r0 + kRows];
+  }
+  int buf = 0;  // s_rowptr buffer
+  int pbuf = 0; // s_prod buffer
+  while (it < num_slots) {
+    const int rb = slot_to_rb(it);
+    const int32_t r0 = rb * kRows;
+    const int nr = min(kRows, num_rows - r0);
+    if (t <= nr)
+      s_rowptr[buf][t] = rp_reg;
+    if (t == 0 && nr == kRows)
+      s_rowptr[buf][kRows] = rp_last;
+    // next valid slot: fetch its row pointer now, use it one iteration later
+    int itn = it + gridDim.x;
+    while (itn < num_slots && slot_to_rb(itn) >= num_row_blocks)
+      itn += gridDim.x;
+    if (itn < num_slots) {
+      const int32_t r0n = slot_to_rb(itn) * kRows;
+      const int nrn = min(kRows, num_rows - r0n);
+      if (t <= nrn)
+        rp_reg = rowptr[r0n + t];
+      if (t == 0 && nrn == kRows)
+        rp_last = rowptr[r0n + kRows];
+    }
+    __syncthreads();
+
+    const int32_t a = s_rowptr[buf][0];
+    const int32_t b = s_rowptr[buf][nr];
+    int32_t lo = 0, hi = 0;
+    T xr = 0;
+    if (t < nr) {
+      lo = s_rowptr[buf][t];
+      hi = s_rowptr[buf][t + 1];
+      if constexpr (DOT)
+        xr = in[r0 + t]; // early: its latency hides under the tile loop
+    }
+    T sum = 0;
+    const int64_t base0 = a & ~(V - 1);
+    if (b > a) {
+      const int64_t jclamp = (int64_t)(b - 1) & ~(int64_t)(V - 1);
+      if (jclamp + V <= nnz) {
+        // ---- pipelined fast path ----
+        int64_t j0 = base0 + (int64_t)t * V;
+        int64_t jl = j0 < jclamp ? j0 : jclamp;
+        val_t v = stream_load<NT>(reinterpret_cast<const val_t*>(values + jl));
+        col_t ci = stream_load<NT>(reinterpret_cast<const col_t*>(colind + jl));
+        for (int64_t base = base0; base < b; base += TILE) {
+          T xg[V];
+#pragma unroll
+          for (int e = 0; e < V; ++e)
+            xg[e] = in[ci[e]];
+          val_t vn = v;
+          col_t cin = ci;
+          const int64_t j0n = j0 + TILE;
+          if (base + TILE < b) { // prefetch the next tile behind the gathers
+            const int64_t jln = j0n < jclamp ? j0n : jclamp;
+            vn = stream_load<NT>(reinterpret_cast<const val_t*>(values + jln));
+            cin = stream_load<NT>(reinterpret_cast<const col_t*>(colind + jln));
+          }
+          val_t pv;
+#pragma unroll
+          for (int e = 0; e < V; ++e)
+            pv[e] = (j0 + e < b) ? v[e] * xg[e] : T(0);
+          *reinterpret_cast<val_t*>(&s_prod[pbuf][t * V]) = pv;
+          __syncthreads();
+          const int32_t jlo = max((int64_t)lo, base) - base;
+          const int32_t jhi = min((int64_t)hi, base + TILE) - base;
+          int32_t j = jlo;
+          for (; j + 4 <= jhi; j += 4) {
+            const T p0 = s_prod[pbuf][j], p1 = s_prod[pbuf][j + 1],
+                    p2 = s_prod[pbuf][j + 2], p3 = s_prod[pbuf][j + 3];
+            sum += p0;
+            sum += p1;
+            sum += p2;
+            sum += p3;
+          }
+          for (; j < jhi; ++j)
+            sum += s_prod[pbuf][j];
+          pbuf ^= 1;
+          v = vn;
+          ci = cin;
+          j0 = j0n;
+        }
+      } else {
+        // ---- guarded path (the tile that touches the end of the arrays) ----
+        for (int64_t base = base0; base < b; base += TILE) {
+          val_t pv;
+#pragma unroll
+          for (int e = 0; e < V; ++e) {
+            const int64_t j = base + (int64_t)t * V + e;
+            pv[e] = (j < b) ? values[j] * in[colind[j]] : T(0);
+          }
+          *reinterpret_cast<val_t*>(&s_prod[pbuf][t * V]) = pv;
+          __syncthreads();
+          const int32_t jlo = max((int64_t)lo, base) - base;
+          const int32_t jhi = min((int64_t)hi, base + TILE) - base;
+          for (int32_t j = jlo; j < jhi; ++j)
+            sum += s_prod[pbuf][j];
+          pbuf ^= 1;
+        }
+      }
+    }
+    if (t < nr) {
+      const int32_t r = r0 + t;
+      const T c = alpha * sum;
+      T y = c;
+      if (beta != T(0))
+        y = c + beta * out[r];
+      out[r] = y;
+      if constexpr (DOT)
+        dot_acc += (double)xr * (double)c;
+    }
+    buf ^= 1;
+    it = itn;
+  }
+
+  if constexpr (DOT)
+    spmv_dot_epilogue(dot, dot_acc, s_red, &s_flag);
+}
+
+// ---------------------------------------------------------------------------
 // ROWBLOCK, wave-private variant: the same algorithm with each of the four
 // waves of a workgroup owning 64 of its 256 rows and a private LDS slice, so
 // no workgroup barrier sits between a wave's loads and its row sums (LDS
@@ -766,6 +941,7 @@ struct spmv_hip_csr_plan {
   // send/recv kernel of the halo can run beside the persistent SpMV grid
   int blocks_per_cu = kBlocksPerCU - 1;
   int wave_private = 0;   // ROWBLOCK: wave-private LDS slices, no barriers
+  int pipeline = 0;       // ROWBLOCK: software-pipelined variant
   int sym_window = 256;   // symmetric: LDS window below the block (0 = plain
                           // per-entry global atomics)
   int sym_rows = 1024;    // symmetric: rows per workgroup (512, 1024, 2048)
@@ -811,6 +987,20 @@ int launch_rowblock(const spmv_hip_csr_plan* pl, hipStream_t st,
   if (grid < 1)
     grid = 1;
   const bool al = aligned16(values) && aligned16(colind);
+  if (pl->pipeline && al) {
+    if (pl->nontemporal)
+      hipLaunchKernelGGL((csr_rowblock_pipe_kernel<T, true, DOT>), dim3(grid),
+                         dim3(kBlock), 0, st, pl->num_rows, pl->nnz, rowptr,
+                         colind, values, alpha, in, beta, out, dot, nrb,
+                         pl->xcd_group);
+    else
+      hipLaunchKernelGGL((csr_rowblock_pipe_kernel<T, false, DOT>), dim3(grid),
+                         dim3(kBlock), 0, st, pl->num_rows, pl->nnz, rowptr,
+                         colind, values, alpha, in, beta, out, dot, nrb,
+                         pl->xcd_group);
+    SPMV_CHECK_LAUNCH();
+    return SPMV_HIP_OK;
+  }
   if (pl->wave_private && al) {
 #define SPMV_RW(CH, NT)                                                        \
   hipLaunchKernelGGL((csr_rowwave_kernel<T, CH, NT, DOT>), dim3(grid),         \
@@ -1162,6 +1352,8 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
   } else if (!strcmp(key, "xcd_group")) {
     SPMV_REQUIRE(value >= 0 && value <= 4096);
     plan->xcd_group = value;
+  } else if (!strcmp(key, "pipeline")) {
+    plan->pipeline = value != 0;
   } else if (!strcmp(key, "wave_private")) {
     plan->wave_private = value != 0;
   } else if (!strcmp(key, "sym_window")) {

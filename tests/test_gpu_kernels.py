@@ -85,7 +85,9 @@ def test_kat_vector_and_symmetric(ctx):
 KNOBS = [dict(), dict(chunks=1), dict(chunks=4), dict(nontemporal=0),
          dict(xcd_group=1), dict(xcd_group=16), dict(chunks=4, xcd_group=3, blocks_per_cu=2),
          dict(wave_private=1, chunks=4), dict(wave_private=1, chunks=1, xcd_group=0),
-         dict(wave_private=1, chunks=2, nontemporal=1)]
+         dict(wave_private=1, chunks=2, nontemporal=1),
+         dict(pipeline=1), dict(pipeline=1, xcd_group=0, nontemporal=1),
+         dict(pipeline=1, xcd_group=5, blocks_per_cu=3)]
 
 
 @pytest.mark.parametrize("n", [4, 9, 16, 33])
@@ -115,6 +117,11 @@ def test_random_ragged(ctx, seed, algo):
         y_ref = oracle.csr_spmv(rp, ci, va, x, alpha, beta, y0)
         y = run_spmv(ctx, rp, ci, va, x, nrows, ncols, alpha, beta,
                      None if beta == 0 else y0, algo=algo)
+        if algo == hip.ALGO_ROWBLOCK:  # and its software-pipelined variant
+            yp = run_spmv(ctx, rp, ci, va, x, nrows, ncols, alpha, beta,
+                          None if beta == 0 else y0, algo=algo,
+                          knobs=dict(pipeline=1))
+            assert np.array_equal(yp, y_ref), (alpha, beta, "pipeline")
         if algo in EXACT_ALGOS:
             assert np.array_equal(y, y_ref), (alpha, beta)
         else:

@@ -71,17 +71,10 @@ def main():
         src.free(), dst.free()
 
         variants = []
-        for ch, nt, wp in itertools.product([1, 2, 4], [0, 1], [0, 1]):
-            if args.quick and nt == 1 and n >= 400:
-                continue
-            variants.append(("rowblock", dict(algo=hip.ALGO_ROWBLOCK, chunks=ch,
-                                              nontemporal=nt, xcd_group=16,
-                                              wave_private=wp,
-                                              blocks_per_cu=8)))
-        for bpc in (7, 6):
+        for pipe, nt, bpc in itertools.product([0, 1], [0, 1], [8, 7, 5]):
             variants.append(("rowblock", dict(algo=hip.ALGO_ROWBLOCK, chunks=1,
-                                              nontemporal=0, xcd_group=16,
-                                              wave_private=0,
+                                              nontemporal=nt, xcd_group=16,
+                                              pipeline=pipe,
                                               blocks_per_cu=bpc)))
         variants.append(("scalar", dict(algo=hip.ALGO_SCALAR)))
         for lpr in (4, 8):
@@ -96,14 +89,17 @@ def main():
                  gbs=bytes_csr / tmin / 1e6,
                  frac=bytes_csr / tmin / 1e6 / HBM_PEAK)
         # fused dot on the default variant
-        for k, v in dict(algo=hip.ALGO_ROWBLOCK, chunks=1, nontemporal=0,
-                         xcd_group=16, blocks_per_cu=8).items():
-            blk.set(k, v)
-        tmin, tmed = time_ms(
-            ctx, lambda: blk.mult(1.0, x.ptr, 0.0, y.ptr, dot_partials=part.ptr),
-            reps)
-        emit(n=n, variant="rowblock+dot", ms=tmin, ms_med=tmed,
-             gbs=bytes_csr / tmin / 1e6, frac=bytes_csr / tmin / 1e6 / HBM_PEAK)
+        for pipe in (0, 1):
+            for k, v in dict(algo=hip.ALGO_ROWBLOCK, chunks=1, nontemporal=0,
+                             xcd_group=16, blocks_per_cu=7,
+                             pipeline=pipe).items():
+                blk.set(k, v)
+            tmin, tmed = time_ms(
+                ctx, lambda: blk.mult(1.0, x.ptr, 0.0, y.ptr,
+                                      dot_partials=part.ptr), reps)
+            emit(n=n, variant="rowblock+dot", knobs=dict(pipeline=pipe),
+                 ms=tmin, ms_med=tmed, gbs=bytes_csr / tmin / 1e6,
+                 frac=bytes_csr / tmin / 1e6 / HBM_PEAK)
         blk.free()
 
         if args.fp32 and n <= 256:
