@@ -78,6 +78,43 @@ def cpu_baseline(args, n_gpu, rows_gpu):
                        f"{n ** 3}/{rows_gpu} to the {n_gpu}^3 workload")}
 
 
+def north_star_spmv(exec_, comm, host, _lib, poisson, n=216, reps=200):
+    """BASELINE.json's target line: plain fp64 CSR SpMV (y = A x, the
+    demos/spmv.cpp protocol: 1 warm-up + timed applies) on the ~10 M-row
+    Poisson matrix, one GPU, HIP events around the applies."""
+    import ctypes as C
+    N = n ** 3
+    A = host.Matrix.create_poisson3d(comm, exec_, n, False, host.P2P_BLOCKING)
+    d_x, d_y = exec_.alloc(N), exec_.alloc(N)
+    ctx = exec_.context
+    _lib.call("spmv_hip_fill_gaussian_f64", ctx, N, 0, N, d_x, None)
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    _lib.call("spmv_hip_event_create", ctx, 1, C.byref(e0))
+    _lib.call("spmv_hip_event_create", ctx, 1, C.byref(e1))
+    A.col_map().update(d_x)
+    A.mult(d_x, d_y)  # warm-up
+    best = None
+    for _ in range(3):
+        _lib.call("spmv_hip_event_record", ctx, e0, None)
+        for _ in range(reps):
+            A.mult(d_x, d_y)
+        _lib.call("spmv_hip_event_record", ctx, e1, None)
+        _lib.call("spmv_hip_event_synchronize", ctx, e1)
+        ms = C.c_float()
+        _lib.call("spmv_hip_event_elapsed_ms", ctx, e0, e1, C.byref(ms))
+        best = ms.value / reps if best is None else min(best, ms.value / reps)
+    nnz = A.non_zeros()
+    nbytes = poisson.csr_bytes(N, N, nnz)
+    _lib.call("spmv_hip_event_destroy", ctx, e0)
+    _lib.call("spmv_hip_event_destroy", ctx, e1)
+    A.close()
+    exec_.free(d_x), exec_.free(d_y)
+    gbs = nbytes / (best * 1e-3) / 1e9
+    return {"workload": f"poisson3d_{n}^3_csr_fp64_spmv", "rows": N, "nnz": nnz,
+            "ms_per_apply": best, "algorithmic_bytes": nbytes, "GB/s": gbs,
+            "frac_of_8TBs": gbs / HBM_PEAK_GBS, "applies_timed": reps}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -203,6 +240,9 @@ def main():
             "cg_gbs_per_gpu": (kernel_bytes + 9 * M * 8)
             / (elapsed / args.steps) / 1e9,
         }
+        if world == 1 and not args.symmetric:
+            out["north_star_spmv"] = north_star_spmv(exec_, comm, host, _lib,
+                                                     poisson)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, n, N)
         print(json.dumps(out), flush=True)
