@@ -117,11 +117,14 @@ int spmv_hip_copy_peer_async(spmv_hip_ctx* dst_ctx, void* dst,
  *   - symmetric kernel: out is first scaled by beta (zero-filled when
  *     beta == 0) inside run, then every term is accumulated with hardware
  *     fp64 atomics; the order of additions is not deterministic.
- *   - `dot_partials` (optional, general kernel only, may be NULL): fuses
+ *   - `dot_partials` (optional, may be NULL; not for a diagonal-only
+ *     symmetric block): fuses
  *     the CG dot product.  The kernel writes spmv_hip_dot_partials_len()
  *     doubles whose sum is sum_i in[i] * (alpha * (A in)_i), this block's own
  *     share (beta*out is not included, so the shares of a local and a remote
  *     block add up to in . (A in)); reduce with spmv_hip_reduce_partials_f64.
+ *     The symmetric kernel uses the mirror identity: row i contributes
+ *     in_i * alpha * (2 (d_i in_i + (L in)_i) - d_i in_i).
  */
 enum {
   SPMV_HIP_ALGO_AUTO = 0,

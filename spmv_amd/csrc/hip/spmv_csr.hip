@@ -691,10 +691,13 @@ __global__ __launch_bounds__(kBlock) void csr_sym_rowblock_kernel(
     int32_t num_rows, int64_t nnz, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ colind, const T* __restrict__ values,
     const T* __restrict__ diagonal, T alpha, const T* __restrict__ in,
-    T* __restrict__ out, int num_row_blocks)
+    T* __restrict__ out, int num_row_blocks, DotOut dot)
 {
   constexpr int V = VecOf<T>::V;
   constexpr int TILE = kBlock * CH * V;
+  __shared__ double s_red[kBlock / 64];
+  __shared__ int s_flag;
+  double dot_acc = 0.0;
   using val_t = typename VecOf<T>::val_t;
   using col_t = typename VecOf<T>::col_t;
 
@@ -783,9 +786,17 @@ __global__ __launch_bounds__(kBlock) void csr_sym_rowblock_kernel(
         atomic_add(&out[s_col[k]], alpha * s_val[k] * xi); // :35
       }
     }
-    if (t < nr)
+    if (t < nr) {
       atomic_add(&out[r0 + t], alpha * sum); // :39 (beta applied by pre-pass)
+      // in . (alpha A in) with A = L + D + L^T: row i contributes
+      // x_i (2 (d_i x_i + (L x)_i) - d_i x_i); the L^T terms are the mirror
+      // images of the L terms, so no finished `out` is needed.
+      dot_acc += (double)xi
+                 * (double)(alpha * (sum + (sum - diagonal[r0 + t] * xi)));
+    }
   }
+  if (dot.partials) // uniform
+    spmv_dot_epilogue(dot, dot_acc, s_red, &s_flag);
 }
 
 // ---------------------------------------------------------------------------
@@ -809,8 +820,11 @@ __global__ __launch_bounds__(kBlock) void csr_sym_window_kernel(
     int32_t num_rows, int64_t nnz, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ colind, const T* __restrict__ values,
     const T* __restrict__ diagonal, T alpha, const T* __restrict__ in,
-    T* __restrict__ out, int num_blocks, int low)
+    T* __restrict__ out, int num_blocks, int low, DotOut dot)
 {
+  __shared__ double s_red[kBlock / 64];
+  __shared__ int s_flag;
+  double dot_acc = 0.0;
   constexpr int V = VecOf<T>::V;
   constexpr int TILE = kBlock * V;
   using val_t = typename VecOf<T>::val_t;
@@ -901,8 +915,12 @@ __global__ __launch_bounds__(kBlock) void csr_sym_window_kernel(
             atomic_add(&out[c], term);
         }
       }
-      if (t < nr) // :39, beta already applied by the pre-pass
+      if (t < nr) { // :39, beta already applied by the pre-pass
         atomic_add(&s_acc[r0 + t - win_lo], alpha * sum);
+        // this row's share of in . (alpha A in), see csr_sym_rowblock_kernel
+        dot_acc += (double)xi
+                   * (double)(alpha * (sum + (sum - diagonal[r0 + t] * xi)));
+      }
     }
     __syncthreads();
     // flush: one coalesced pass of global atomics over the window
@@ -913,6 +931,8 @@ __global__ __launch_bounds__(kBlock) void csr_sym_window_kernel(
         atomic_add(&out[g], v);
     }
   }
+  if (dot.partials) // uniform
+    spmv_dot_epilogue(dot, dot_acc, s_red, &s_flag);
 }
 
 template <typename T>
@@ -1138,10 +1158,12 @@ template <typename T>
 int run_symmetric(const spmv_hip_csr_plan* pl, hipStream_t st,
                   const int32_t* rowptr, const int32_t* colind,
                   const T* values, const T* diagonal, T alpha, const T* in,
-                  T beta, T* out)
+                  T beta, T* out, DotOut dot = DotOut())
 {
   if (diagonal == nullptr)
     return SPMV_HIP_EINVAL;
+  if (dot.partials && pl->nnz == 0)
+    return SPMV_HIP_ENOTSUP; // diagonal-only block: caller uses a plain dot
   const int n = pl->num_rows;
   if (pl->nnz == 0) {
     const int grid = spmv_grid_for(pl->ctx, n, kBlock);
@@ -1178,7 +1200,8 @@ int run_symmetric(const spmv_hip_csr_plan* pl, hipStream_t st,
 #define SPMV_SYMW(R, NT, AL)                                                   \
   hipLaunchKernelGGL((csr_sym_window_kernel<T, R, NT, AL>), dim3(grid),        \
                      dim3(kBlock), lds, st, n, pl->nnz, rowptr, colind,        \
-                     values, diagonal, alpha, in, out, nblk, pl->sym_window)
+                     values, diagonal, alpha, in, out, nblk, pl->sym_window,   \
+                     dot)
 #define SPMV_SYMW_R(NT, AL)                                                    \
   do {                                                                         \
     if (srows == 512)                                                          \
@@ -1206,7 +1229,7 @@ int run_symmetric(const spmv_hip_csr_plan* pl, hipStream_t st,
 #define SPMV_SYM(CH, NT, AL)                                                   \
   hipLaunchKernelGGL((csr_sym_rowblock_kernel<T, CH, NT, AL>), dim3(grid),     \
                      dim3(kBlock), 0, st, n, pl->nnz, rowptr, colind, values,  \
-                     diagonal, alpha, in, out, nrb)
+                     diagonal, alpha, in, out, nrb, dot)
   if (!al)
     SPMV_SYM(1, false, false);
   else if (pl->nontemporal)
@@ -1391,9 +1414,11 @@ int spmv_hip_csr_spmv_f64(spmv_hip_ctx* ctx, const spmv_hip_csr_plan* plan,
   SPMV_REQUIRE(num_non_zeros == 0 || (rowptr && colind && values));
   hipStream_t st = spmv_stream(ctx, stream);
   if (plan->symmetric) {
-    SPMV_REQUIRE(dot_partials == nullptr);
+    DotOut dot;
+    dot.partials = dot_partials; // may be NULL
+    dot.len = ctx->dot_blocks;
     return run_symmetric<double>(plan, st, rowptr, colind, values, diagonal,
-                                 alpha, in, beta, out);
+                                 alpha, in, beta, out, dot);
   }
   if (num_non_zeros == 0) {
     // empty general block: out = beta*out (csr_kernels.cpp:44-49 with an

@@ -75,6 +75,24 @@ void CSRSpMV<T>::run_dot(int32_t num_rows, int32_t num_cols,
 }
 
 template <typename T>
+void CSRSpMV<T>::run_dot_sym(int32_t num_rows, int32_t num_cols,
+                             int64_t num_non_zeros, const int32_t* rowptr,
+                             const int32_t* colind, const T* values,
+                             const T* diagonal, T alpha, T* in, T beta, T* out,
+                             double* dot_partials,
+                             const HipExecutor& exec) const
+{
+  if constexpr (std::is_same<T, double>::value)
+    throw_on_error(spmv_hip_csr_spmv_f64(exec.context(), plan(), num_rows,
+                                         num_cols, num_non_zeros, rowptr,
+                                         colind, values, diagonal, alpha, in,
+                                         beta, out, dot_partials, nullptr),
+                   "spmv_hip_csr_spmv_f64");
+  else
+    throw std::runtime_error("CSRSpMV<float>::run_dot_sym is not available");
+}
+
+template <typename T>
 void CSRSpMV<T>::finalize(const HipExecutor&) const
 {
   spmv_hip_csr_plan_destroy(plan());
@@ -177,11 +195,21 @@ template <typename T>
 bool CSRMatrix<T>::mult_dot(T alpha, T* in, T beta, T* out,
                             const DotTarget& dot) const
 {
-  if (this->_symmetric || this->_num_non_zeros == 0)
+  if (this->_num_non_zeros == 0)
     return false;
   auto* hip = dynamic_cast<const HipExecutor*>(this->_exec.get());
   if (!hip)
     return false;
+  if (this->_symmetric) {
+    // the symmetric kernel produces its share from the mirror identity; only
+    // the partial form exists (no last-workgroup reduction)
+    if (dot.result != nullptr || !std::is_same<T, double>::value)
+      return false;
+    _op.run_dot_sym(this->_num_rows, this->_num_cols, this->_num_non_zeros,
+                    _rowptr, _colind, _values, this->_diagonal, alpha, in, beta,
+                    out, dot.partials, *hip);
+    return true;
+  }
   _op.run_dot(this->_num_rows, this->_num_cols, this->_num_non_zeros, _rowptr,
               _colind, _values, alpha, in, beta, out, dot, *hip);
   return true;

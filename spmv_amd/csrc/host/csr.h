@@ -62,6 +62,13 @@ public:
                T alpha, T* in, T beta, T* out, const DotTarget& dot,
                const HipExecutor& exec) const;
 
+  // symmetric block: run() + the block's share of in . (alpha A in) as
+  // per-workgroup partials (mirror identity, see include/spmv_hip.h)
+  void run_dot_sym(int32_t num_rows, int32_t num_cols, int64_t num_non_zeros,
+                   const int32_t* rowptr, const int32_t* colind, const T* values,
+                   const T* diagonal, T alpha, T* in, T beta, T* out,
+                   double* dot_partials, const HipExecutor& exec) const;
+
   bool symmetric() const { return _symmetric; }
   spmv_hip_csr_plan* plan() const
   {

@@ -171,15 +171,22 @@ bool Matrix<T>::mult_dot(T* x, T* y, double* dot_local, double* dot_remote,
     return false;
   }
   if (_symmetric) {
-    // symmetric blocks cannot fuse the dot product (atomic scatter);
-    // same sequence as spmv_sym / spmv_sym_overlap
-    _mat_local->mult(1, x, 0, y);
+    // same sequence as spmv_sym / spmv_sym_overlap.  The symmetric kernel
+    // carries its share of x.(A x) through the mirror identity (partials
+    // only), the remote block adds its own share.
+    const bool want = (result == nullptr);
+    const bool ok = want && _mat_local->mult_dot(1, x, 0, y, tl);
+    if (!ok)
+      _mat_local->mult(1, x, 0, y);
     mark();
     if (_col_map->overlapping())
       _col_map->update_finalise(x);
-    if (_mat_remote)
-      _mat_remote->mult(1, x, 1, y);
-    return false;
+    if (_mat_remote) {
+      if (!(ok && _mat_remote->mult_dot(1, x, 1, y, tr)))
+        _mat_remote->mult(1, x, 1, y);
+      // a remote block that could not fuse has no entries => zero share
+    }
+    return ok;
   }
   if (!_col_map->overlapping()) {
     const bool ok = _mat_local->mult_dot(1, x, 0, y, tl);

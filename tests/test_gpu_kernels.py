@@ -584,3 +584,33 @@ def test_fused_reductions_match_two_stage(ctx):
     for b in (dx, dy, counter, res, part, ref):
         b.free()
     blk.free()
+
+
+@pytest.mark.parametrize("window", [0, 256])
+def test_symmetric_fused_dot(ctx, window):
+    """x.(A x) produced by the symmetric kernel itself through the mirror
+    identity sum_i x_i (2 (d_i x_i + (L x)_i) - d_i x_i)."""
+    n = 18
+    N = n ** 3
+    rp, ci, va = poisson.poisson3d_csr(n)
+    ci = ci.astype(np.int32)
+    lrp, lci, lva, dg = lower_split(rp, ci, va)
+    rng = np.random.default_rng(2)
+    x = rng.uniform(-1, 1, N)
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    blk = hip.CsrBlock(ctx, N, N, lrp, lci, lva, dg, True)
+    blk.set("sym_window", window)
+    dx, dy = ctx.upload(x), ctx.empty(N, np.float64)
+    part = ctx.empty(ctx.dot_partials_len, np.float64)
+    res = ctx.empty(1, np.float64)
+    for alpha in (1.0, -0.5):
+        blk.mult(alpha, dx.ptr, 0.0, dy.ptr, dot_partials=part.ptr)
+        hip.call("spmv_hip_reduce_partials_f64", ctx.h, part.ptr, res.ptr, None)
+        got = res.numpy()[0]
+        expect = alpha * float(x @ y_ref)
+        scale = abs(alpha) * float(np.abs(x) @ (np.abs(va[np.arange(len(va))]) @ np.ones(1) if False else np.abs(y_ref) + 12 * np.abs(x)))
+        assert abs(got - expect) <= 1e-13 * scale
+        assert np.all(np.abs(dy.numpy() - alpha * y_ref) <= 16 * U * 12 * abs(alpha))
+    for b in (dx, dy, part, res):
+        b.free()
+    blk.free()
