@@ -35,7 +35,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--n", type=int, default=512, help="grid points per side")
+    ap.add_argument("--grid", dest="n", type=int, default=512,
+                    help="grid points per side (not --n: torchrun's own parser "
+                         "treats that as an abbreviation of its options)")
     ap.add_argument("--symmetric", action="store_true",
                     help="symmetric-CSR storage (BASELINE configs[3])")
     ap.add_argument("--cm", default="p2p_nonblocking",
@@ -43,6 +45,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fused-reductions", action="store_true",
                     help="finish dot products in the producing kernels")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "gloo"],
+                    help="gloo: REHEARSAL ONLY -- halo and reductions staged "
+                         "through the host so that several ranks can share one "
+                         "GPU (implies --share-gpu); never a benchmark result")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="all ranks use GPU 0 (rehearsal on a 1-GPU box)")
     ap.add_argument("--cpu-n", type=int, default=256,
                     help="grid of the bounded CPU sample")
     ap.add_argument("--cpu-iters", type=int, default=30)
@@ -130,11 +138,20 @@ def main():
 
     from spmv_amd import _lib, host, poisson
 
-    torch.cuda.set_device(local_rank)
-    exec_ = host.HipExecutor(local_rank)
-    if world > 1:
+    rehearsal = args.transport == "gloo"
+    dev = 0 if (args.share_gpu or rehearsal) else local_rank
+    torch.cuda.set_device(dev)
+    exec_ = host.HipExecutor(dev)
+    if world > 1 and rehearsal:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import dist_util  # gloo-backed CallbackComm transport (tests/)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        ex, ar = dist_util.make_device_transport(exec_.context)
+        comm = host.Comm.callback(rank, world, dist_util.make_allgather(world),
+                                  ex, ar)
+    elif world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+                                device_id=torch.device("cuda", dev))
         ident = [host.rccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ident, src=0)
         comm = host.Comm.rccl(exec_, world, rank, ident[0])
@@ -185,7 +202,8 @@ def main():
     # max over ranks
     if world > 1:
         t = torch.tensor([elapsed, spmv_ms / max(spmv_launches, 1)],
-                         dtype=torch.float64, device="cuda")
+                         dtype=torch.float64,
+                         device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, spmv_ms_avg = float(t[0]), float(t[1])
     else:
@@ -221,7 +239,8 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic" + (" (REHEARSAL: gloo transport, shared GPU)"
+                                   if rehearsal else ""),
             "config": {"workload": f"poisson3d_{n}^3_csr_fp64_cg",
                        "rows": N, "nnz": poisson.poisson3d_nnz(n),
                        "storage": "symmetric-csr" if args.symmetric else "csr",

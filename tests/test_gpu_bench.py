@@ -1,0 +1,65 @@
+"""bench.py contract checks on a small grid: the single-GPU line and a
+2-rank rehearsal (gloo transport, both ranks on GPU 0)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup",
+            "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline"]
+
+
+def _line(out):
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def _check(d, n_gpus, steps, warmup):
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == n_gpus and d["steps"] == steps and d["warmup"] == warmup
+    assert d["unit"] == "iters/s" and d["higher_is_better"] is True
+    assert d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - steps / (d["ms_per_step"] * steps / 1e3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["launches_timed"] == steps and r["avg_launch_ms"] > 0
+
+
+def test_bench_single_gpu_line():
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"),
+                          "--grid", "64", "--steps", "20", "--warmup", "3",
+                          "--cpu-n", "32", "--cpu-iters", "3"],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = _line(res.stdout)
+    _check(d, 1, 20, 3)
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
+    assert "sample" in c and d["north_star_spmv"]["rows"] == 216 ** 3
+
+
+def test_bench_two_rank_rehearsal():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    res = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+         "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus",
+         "2", "--steps", "10", "--warmup", "2", "--grid", "64", "--transport",
+         "gloo"], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    d = _line(res.stdout)
+    _check(d, 2, 10, 2)
+    assert "REHEARSAL" in d["data"] and "cpu_baseline" not in d
