@@ -171,6 +171,19 @@ int spmv_hip_gather_f32(spmv_hip_ctx* ctx, int num_indices,
                         const int32_t* indices, const float* in, float* out,
                         void* stream);
 
+/* ---- reverse halo accumulate -------------------------------------------------
+ * The owner-side loop of L2GMap::reverse_update (L2GMap.cpp:921-922,947-948):
+ * out[indices[i]] += in[i].  The indices of ONE call must be distinct (one
+ * neighbour's segment of the index buffer); the caller issues one call per
+ * neighbour, in neighbour order, which reproduces the reference's ascending-i
+ * accumulation order bit for bit. */
+int spmv_hip_scatter_add_f64(spmv_hip_ctx* ctx, int num_indices,
+                             const int32_t* indices, const double* in,
+                             double* out, void* stream);
+int spmv_hip_scatter_add_f32(spmv_hip_ctx* ctx, int num_indices,
+                             const int32_t* indices, const float* in,
+                             float* out, void* stream);
+
 /* ---- CG building blocks -----------------------------------------------------
  * spmv::cg (cg.cpp:21-98).  All scalars live on the device (precedent:
  * cuda/cg.cuda.cu:73-84); the host never waits inside an iteration.

@@ -183,6 +183,9 @@ int spmvh_l2g_map_plan(spmvh_l2g* map, int32_t* neighbours, int32_t* send_count,
                        int32_t* recv_count, int32_t* send_offset,
                        int32_t* recv_offset, int32_t* indexbuf);
 int spmvh_l2g_map_update(spmvh_l2g* map, double* x);
+/* L2GMap::reverse_update(vec) (L2GMap.h:103): ghost tail -> owners, added */
+int spmvh_l2g_map_reverse_update(spmvh_l2g* map, double* x);
+int spmvh_l2g_map_reverse_update_f32(spmvh_l2g* map, float* x);
 
 /* ---- cg: spmv::cg(comm, exec, A, b, x, kmax, rtol) ---------------------------- */
 /* rnorm_history (host, kmax+1 doubles) may be NULL; *num_its = returned k */

@@ -68,6 +68,41 @@ def poisson3d_csr(n):
             A.data.astype(np.float64))
 
 
+def tridiag_csr(N, gamma=0.1):
+    """Global CSR of the 1-D operator of demos/CreateA.cpp:31-64: rows 0 and
+    N-1 hold (1-gamma, gamma) / (gamma, 1-gamma), interior rows
+    (gamma, 1-2 gamma, gamma).  Rank slices come from localise_rows()."""
+    N = int(N)
+    cnt = np.full(N, 3, np.int64)
+    cnt[0] = cnt[-1] = 2
+    rowptr = np.zeros(N + 1, np.int64)
+    np.cumsum(cnt, out=rowptr[1:])
+    colind = np.empty(int(rowptr[-1]), np.int32)
+    values = np.empty(int(rowptr[-1]), np.float64)
+    i = np.arange(1, N - 1, dtype=np.int64)
+    base = rowptr[1:N - 1]
+    for k, v in ((0, gamma), (1, 1.0 - 2.0 * gamma), (2, gamma)):
+        colind[base + k] = i - 1 + k
+        values[base + k] = v
+    colind[0:2] = (0, 1)
+    values[0:2] = (1.0 - gamma, gamma)
+    colind[-2:] = (N - 2, N - 1)
+    values[-2:] = (gamma, 1.0 - gamma)
+    return rowptr.astype(np.int32), colind, values
+
+
+def splitmix64_unit(count, seed=0x5EED0001):
+    """`count` doubles in [-1, 1) from the splitmix64 stream of `seed`
+    (SURVEY section 8d "robustness" inputs): top 53 bits -> [0,1) -> 2u-1."""
+    with np.errstate(over="ignore"):
+        z = (np.uint64(seed)
+             + np.uint64(0x9E3779B97F4A7C15) * np.arange(1, count + 1, dtype=np.uint64))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (2.0 ** -52) - 1.0
+
+
 def localise_rows(rowptr, colind, values, r0, r1):
     """tests/test_spmv.cpp:83-124: slice rows [r0,r1) of a global CSR, shift
     owned columns by -r0, append ghost columns in ascending global order.
@@ -159,6 +194,26 @@ def l2g_update(plans, vecs):
                            q["recv_offset"][j] + q["recv_count"][j]]
             off = pl["send_offset"][i]                             # :586,625
             v[off:off + pl["send_count"][i]] = src
+    return vecs
+
+
+def l2g_reverse_update(plans, vecs):
+    """Reverse halo, spmv/L2GMap.cpp:907-950: every rank sends the slices of
+    its ghost tail to their owners (:937-941); the owner receives them in
+    index-buffer order and accumulates `vec[indexbuf[i]] += databuf[i]` for
+    ascending i (:921-922,:947-948).  Ghost tails are left as they are.
+    In place."""
+    tails = [np.array(v, copy=True) for v in vecs]  # all sends read pre-update data
+    for pl, v in zip(plans, vecs):
+        databuf = np.zeros(pl["num_indices"], v.dtype)
+        for i, nb in enumerate(pl["neighbours"]):
+            q = plans[nb]
+            j = list(q["neighbours"]).index(pl["rank"])
+            src = tails[nb][q["send_offset"][j]:
+                            q["send_offset"][j] + q["send_count"][j]]
+            databuf[pl["recv_offset"][i]:pl["recv_offset"][i] + len(src)] = src
+        for i in range(pl["num_indices"]):  # sequential: duplicates keep order
+            v[pl["indexbuf"][i]] += databuf[i]
     return vecs
 
 

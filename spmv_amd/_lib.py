@@ -80,6 +80,8 @@ _PROTOS = {
                                f32, vp, vp], C.c_int),
     "spmv_hip_gather_f64": ([vp, C.c_int, vp, vp, vp, vp], C.c_int),
     "spmv_hip_gather_f32": ([vp, C.c_int, vp, vp, vp, vp], C.c_int),
+    "spmv_hip_scatter_add_f64": ([vp, C.c_int, vp, vp, vp, vp], C.c_int),
+    "spmv_hip_scatter_add_f32": ([vp, C.c_int, vp, vp, vp, vp], C.c_int),
     "spmv_hip_dot_partials_len": ([vp, P(C.c_int)], C.c_int),
     "spmv_hip_dot_partial_f64": ([vp, i64, vp, vp, vp, vp], C.c_int),
     "spmv_hip_reduce_partials_f64": ([vp, vp, vp, vp], C.c_int),

@@ -55,6 +55,18 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(
     out[i] = in[indices[i]];
 }
 
+// reverse halo accumulate (spmv/L2GMap.cpp:921-922,947-948) for ONE neighbour's
+// segment: indices are distinct inside a segment, so no atomics are needed
+template <typename T>
+__global__ __launch_bounds__(kBlock) void scatter_add_kernel(
+    int n, const int32_t* __restrict__ indices, const T* __restrict__ in,
+    T* __restrict__ out)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x)
+    out[indices[i]] += in[i];
+}
+
 __global__ __launch_bounds__(kBlock) void dot_partial_kernel(
     int64_t n, const double* __restrict__ x, const double* __restrict__ y,
     DotOut dot)
@@ -427,6 +439,38 @@ int spmv_hip_gather_f64(spmv_hip_ctx* ctx, int num_indices,
   SPMV_REQUIRE(indices && in && out);
   const int grid = spmv_grid_for(ctx, num_indices, kBlock);
   hipLaunchKernelGGL((gather_kernel<double>), dim3(grid), dim3(kBlock), 0,
+                     spmv_stream(ctx, stream), num_indices, indices, in, out);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_scatter_add_f64(spmv_hip_ctx* ctx, int num_indices,
+                             const int32_t* indices, const double* in,
+                             double* out, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(num_indices >= 0);
+  if (num_indices == 0)
+    return SPMV_HIP_OK;
+  SPMV_REQUIRE(indices && in && out);
+  const int grid = spmv_grid_for(ctx, num_indices, kBlock);
+  hipLaunchKernelGGL((scatter_add_kernel<double>), dim3(grid), dim3(kBlock), 0,
+                     spmv_stream(ctx, stream), num_indices, indices, in, out);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_scatter_add_f32(spmv_hip_ctx* ctx, int num_indices,
+                             const int32_t* indices, const float* in,
+                             float* out, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(num_indices >= 0);
+  if (num_indices == 0)
+    return SPMV_HIP_OK;
+  SPMV_REQUIRE(indices && in && out);
+  const int grid = spmv_grid_for(ctx, num_indices, kBlock);
+  hipLaunchKernelGGL((scatter_add_kernel<float>), dim3(grid), dim3(kBlock), 0,
                      spmv_stream(ctx, stream), num_indices, indices, in, out);
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;

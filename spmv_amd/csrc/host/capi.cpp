@@ -657,6 +657,22 @@ int spmvh_l2g_map_update(spmvh_l2g* map, double* x)
   });
 }
 
+int spmvh_l2g_map_reverse_update(spmvh_l2g* map, double* x)
+{
+  return guarded([&] {
+    require(map != nullptr, "NULL argument");
+    map->map->reverse_update(x);
+  });
+}
+
+int spmvh_l2g_map_reverse_update_f32(spmvh_l2g* map, float* x)
+{
+  return guarded([&] {
+    require(map != nullptr, "NULL argument");
+    map->map->reverse_update(x);
+  });
+}
+
 // ---- cg ---------------------------------------------------------------------------------
 int spmvh_cg(spmvh_comm* comm, spmvh_exec* exec, spmvh_matrix* A,
              const double* b, double* x, int kmax, double rtol, int* num_its,

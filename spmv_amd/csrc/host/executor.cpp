@@ -296,4 +296,19 @@ void HipExecutor::gather_ghosts_run(int num_indices, const int32_t* indices,
                  "spmv_hip_gather_f64");
 }
 
+void HipExecutor::scatter_add_run(int num_indices, const int32_t* indices,
+                                  const float* in, float* out) const
+{
+  throw_on_error(spmv_hip_scatter_add_f32(_ctx, num_indices, indices, in, out,
+                                          nullptr),
+                 "spmv_hip_scatter_add_f32");
+}
+void HipExecutor::scatter_add_run(int num_indices, const int32_t* indices,
+                                  const double* in, double* out) const
+{
+  throw_on_error(spmv_hip_scatter_add_f64(_ctx, num_indices, indices, in, out,
+                                          nullptr),
+                 "spmv_hip_scatter_add_f64");
+}
+
 } // namespace spmv

@@ -214,6 +214,11 @@ public:
   void stream_wait_event(void* stream, void* event) const;
   void synchronize_stream(void* stream) const;
   void synchronize_event(void* event) const;
+  // owner-side accumulate of L2GMap::reverse_update (distinct indices)
+  void scatter_add_run(int num_indices, const int32_t* indices, const float* in,
+                       float* out) const;
+  void scatter_add_run(int num_indices, const int32_t* indices,
+                       const double* in, double* out) const;
 
 protected:
   void* _alloc(size_t num_bytes) const override;

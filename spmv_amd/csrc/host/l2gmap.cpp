@@ -230,11 +230,48 @@ void L2GMap::update_finalise(T*) const // :899-905
   _hip->stream_wait_event(_hip->get_stream(), _ev_done); // no host wait
 }
 
+// Ghost tail -> owners, accumulating (L2GMap.cpp:907-959).  The transfer is the
+// forward exchange with the roles swapped: each neighbour's slice of the ghost
+// tail is sent as it lies (contiguous, no pack), the owner receives into the
+// staging buffer in index-buffer order and adds segment by segment, neighbour
+// by neighbour -- the ascending-i order of the reference's loop (:921,:947),
+// so a value wanted by two neighbours is accumulated in the same order.
+// The reference only acts for the two blocking models (:953-959) and silently
+// does nothing for the rest; here every model performs the (blocking) update.
 template <typename T>
-void L2GMap::reverse_update(T*) const
+void L2GMap::reverse_update(T* vec) const
 {
-  throw std::runtime_error(
-      "L2GMap::reverse_update is outside the accelerated hot path");
+  if (_neighbours.empty())
+    return;
+  if (!_hip)
+    throw std::runtime_error(
+        "L2GMap::reverse_update: the halo exchange needs a HipExecutor");
+  void* compute = _hip->get_stream();
+  const size_t need
+      = sizeof(T) * static_cast<size_t>(_num_indices > 0 ? _num_indices : 1);
+  if (_send_buf == nullptr || _send_buf_bytes < need) {
+    _hip->synchronize_stream(_comm_stream); // nobody still reads the old one
+    _exec->free(_send_buf);
+    _send_buf = _exec->alloc<char>(need);
+    _send_buf_bytes = need;
+  }
+  _hip->record_event(_ev_ready, compute);
+  _hip->stream_wait_event(_comm_stream, _ev_ready);
+  const size_t nn = _neighbours.size();
+  std::vector<std::int32_t> scnt(_send_count.begin(), _send_count.begin() + nn);
+  std::vector<std::int32_t> soffs(_send_offset.begin(),
+                                  _send_offset.begin() + nn);
+  std::vector<std::int32_t> rcnt(_recv_count.begin(), _recv_count.begin() + nn);
+  std::vector<std::int32_t> roffs(_recv_offset.begin(),
+                                  _recv_offset.begin() + nn);
+  _comm->neighbor_exchange(sizeof(T), _neighbours, vec, scnt, soffs, _send_buf,
+                           rcnt, roffs, _comm_stream);
+  _hip->record_event(_ev_done, _comm_stream);
+  _hip->stream_wait_event(compute, _ev_done);
+  const T* staged = static_cast<const T*>(_send_buf);
+  for (size_t i = 0; i < nn; ++i)
+    _hip->scatter_add_run(_recv_count[i], _indexbuf + _recv_offset[i],
+                          staged + _recv_offset[i], vec);
 }
 
 template void L2GMap::update<float>(float*) const;

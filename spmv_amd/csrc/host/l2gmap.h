@@ -58,7 +58,9 @@ public:
   void update(T* vec_data) const;
   template <typename T>
   void update_finalise(T* vec_data) const;
-  // Not on the hot path (nothing calls it); throws.
+  // Reverse halo (L2GMap.cpp:907-959): every ghost-tail value is sent to its
+  // owner and ADDED to the owner's entry; the ghost tail itself is unchanged.
+  // Stream-ordered on the executor's stream; the host does not wait.
   template <typename T>
   void reverse_update(T* vec_data) const;
 

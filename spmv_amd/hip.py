@@ -145,6 +145,11 @@ class Context:
         call("spmv_hip_gather_f64", self.h, n, indices.ptr, x.ptr, out.ptr,
              stream)
 
+    def scatter_add(self, indices, x, out, n, stream=None, dtype=np.float64):
+        fn = ("spmv_hip_scatter_add_f64" if dtype == np.float64
+              else "spmv_hip_scatter_add_f32")
+        call(fn, self.h, n, indices.ptr, x.ptr, out.ptr, stream)
+
     def fill_gaussian(self, N, i_begin, count, x_ptr, stream=None):
         call("spmv_hip_fill_gaussian_f64", self.h, N, i_begin, count, x_ptr,
              stream)

@@ -81,6 +81,8 @@ _PROTOS = {
     "spmvh_l2g_map_sizes": [vp, PTR(C.c_int), PTR(C.c_int), PTR(C.c_int)],
     "spmvh_l2g_map_plan": [vp, vp, vp, vp, vp, vp, vp],
     "spmvh_l2g_map_update": [vp, vp],
+    "spmvh_l2g_map_reverse_update": [vp, vp],
+    "spmvh_l2g_map_reverse_update_f32": [vp, vp],
     "spmvh_cg": [vp, vp, vp, vp, vp, C.c_int, f64, PTR(C.c_int), vp],
     "spmvh_read_petsc_matrix": [vp, vp, C.c_char_p, C.c_int, C.c_int, PTR(vp)],
     "spmvh_read_petsc_vector": [vp, vp, C.c_char_p, PTR(vp), PTR(i64)],
@@ -253,6 +255,10 @@ class L2GMap:
 
     def update(self, x_ptr):
         call("spmvh_l2g_map_update", self.h, x_ptr)
+
+    def reverse_update(self, x_ptr, f32=False):
+        call("spmvh_l2g_map_reverse_update_f32" if f32
+             else "spmvh_l2g_map_reverse_update", self.h, x_ptr)
 
     def close(self):
         if self.h:

@@ -39,8 +39,10 @@ def main():
     vals = rng.uniform(-1, 1, (N, N))
     vals = (vals + vals.T) / 2
     unstructured = (rp, ci, vals[dense])
+    trp, tci, tva = oracle.tridiag_csr(1001)  # demos/CreateA.cpp:31-64
     cases = [("kat", kat), ("poisson6", poisson.poisson3d_csr(6)),
-             ("unstructured", unstructured)]
+             ("unstructured", unstructured),
+             ("tridiag", (trp, tci.astype(np.int64), tva))]
 
     for name, (rp, ci, va) in cases:
         N = len(rp) - 1
@@ -126,6 +128,36 @@ def main():
             A.close()
             for p in (d_x, d_y, d_b, d_s):
                 exec_.free(p)
+    # L2GMap::reverse_update (L2GMap.cpp:907-959) on stand-alone maps with
+    # overlapping requests: ghost tails are added into the owners' entries in
+    # the reference's order, so the result is bit-exact
+    sizes = [17 + 5 * r for r in range(world)]
+    rngs = np.concatenate([[0], np.cumsum(sizes)])
+    rng = np.random.default_rng(11)
+    ghosts_all, vec_all = [], []
+    for r in range(world):
+        others = np.setdiff1d(np.arange(rngs[-1]), np.arange(rngs[r], rngs[r + 1]))
+        ghosts_all.append(np.sort(rng.choice(others, size=min(len(others), 12),
+                                             replace=False)).astype(np.int64))
+        vec_all.append(rng.uniform(-1, 1, sizes[r] + len(ghosts_all[r])))
+    plans = oracle.l2g_plans(sizes, ghosts_all)
+    for dtype, f32 in ((np.float64, False), (np.float32, True)):
+        vecs = [v.astype(dtype) for v in vec_all]
+        ref = oracle.l2g_reverse_update(plans, [v.copy() for v in vecs])
+        for cm in (host.P2P_BLOCKING, host.COLLECTIVE_BLOCKING,
+                   host.P2P_NONBLOCKING):
+            m = host.L2GMap(comm, sizes[rank], ghosts_all[rank], exec_, cm)
+            d_v = exec_.alloc(len(vecs[rank]), dtype)
+            exec_.copy_from_host(d_v, vecs[rank])
+            m.reverse_update(d_v, f32)
+            m.reverse_update(d_v, f32)  # twice: staging buffer reuse
+            exec_.synchronize()
+            got = exec_.copy_to_host(d_v, len(vecs[rank]), dtype)
+            twice = oracle.l2g_reverse_update(plans, [v.copy() for v in ref])
+            assert np.array_equal(got, twice[rank]), (dtype, cm)
+            exec_.free(d_v)
+            m.close()
+
     # create_matrix WITH row ghosts (FEM-style assembly, Matrix.cpp:188-292):
     # dyadic values => the assembled product is exact, y must equal A x
     for seed, sym in ((3, False), (4, True)):

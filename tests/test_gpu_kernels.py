@@ -614,3 +614,60 @@ def test_symmetric_fused_dot(ctx, window):
     for b in (dx, dy, part, res):
         b.free()
     blk.free()
+
+
+# ---------------------------------------------------------------------------
+# SURVEY 8d "robustness" inputs
+# ---------------------------------------------------------------------------
+def test_tridiagonal_ten_million_rows(ctx):
+    """1-D operator of demos/CreateA.cpp (gamma = 0.1) at N = 1e7."""
+    N = 10_000_000
+    rp, ci, va = oracle.tridiag_csr(N)
+    x = oracle.gaussian_x_fast(N)
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    for algo in EXACT_ALGOS + [hip.ALGO_AUTO]:
+        y = run_spmv(ctx, rp, ci, va, x, N, N, algo=algo)
+        assert np.array_equal(y, y_ref), algo
+    bound = 16 * U * abs_bound(rp, ci, va, x)
+    y = run_spmv(ctx, rp, ci, va, x, N, N, algo=hip.ALGO_VECTOR)
+    assert np.all(np.abs(y - y_ref) <= bound)
+    lrp, lci, lva, dg = lower_split(rp, ci, va)
+    for knobs in (dict(), dict(sym_window=0)):
+        ys = run_spmv(ctx, lrp, lci, lva, x, N, N, diagonal=dg, symmetric=True,
+                      knobs=knobs)
+        assert np.all(np.abs(ys - y_ref) <= bound), knobs
+
+
+@pytest.mark.parametrize("n", [64, 216])
+def test_poisson_sparsity_splitmix_values(ctx, n):
+    """Poisson sparsity with values and x drawn from splitmix64(0x5EED0001);
+    n = 216 is the north-star size (10,077,696 rows)."""
+    rp, ci, _ = oracle.poisson3d(n)
+    N = n ** 3
+    u = oracle.splitmix64_unit(len(ci) + N)
+    va, x = u[:len(ci)].copy(), u[len(ci):].copy()
+    y_ref = oracle.csr_spmv(rp, ci, va, x, -0.75, 0.0)
+    y = run_spmv(ctx, rp, ci, va, x, N, N, alpha=-0.75)
+    assert np.array_equal(y, y_ref)
+    y0 = oracle.splitmix64_unit(N, seed=0x5EED0002)
+    y_ref = oracle.csr_spmv(rp, ci, va, x, 1.0, 1.0, y0)
+    y = run_spmv(ctx, rp, ci, va, x, N, N, beta=1.0, y0=y0)
+    assert np.array_equal(y, y_ref)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_scatter_add_distinct_indices(ctx, dtype):
+    """Owner-side accumulate of L2GMap::reverse_update (L2GMap.cpp:921-922)."""
+    rng = np.random.default_rng(3)
+    n, m = 100_000, 37_111
+    idx = rng.permutation(n)[:m].astype(np.int32)
+    src = rng.uniform(-1, 1, m).astype(dtype)
+    dst = rng.uniform(-1, 1, n).astype(dtype)
+    want = dst.copy()
+    want[idx] += src
+    d_i, d_s, d_d = ctx.upload(idx, np.int32), ctx.upload(src, dtype), ctx.upload(dst, dtype)
+    ctx.scatter_add(d_i, d_s, d_d, m, dtype=dtype)
+    ctx.scatter_add(d_i, d_s, d_d, 0, dtype=dtype)  # empty call is a no-op
+    assert np.array_equal(d_d.numpy(), want)
+    for b in (d_i, d_s, d_d):
+        b.free()

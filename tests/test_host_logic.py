@@ -305,3 +305,53 @@ def test_petsc_reader_matches_restatement(tmp_path):
     trunc.write_bytes((tmp_path / "m0.dat").read_bytes()[:200])
     with pytest.raises(host.SpmvHostError, match="truncated"):
         host.read_petsc_binary_rows(trunc, 0, 1)
+
+
+def test_tridiag_and_splitmix_generators():
+    rp, ci, va = oracle.tridiag_csr(7)
+    assert rp.tolist() == [0, 2, 5, 8, 11, 14, 17, 19]
+    assert ci.tolist() == [0, 1, 0, 1, 2, 1, 2, 3, 2, 3, 4, 3, 4, 5, 4, 5, 6, 5, 6]
+    assert va[0] == 1.0 - 0.1 and va[1] == 0.1 and va[3] == 1.0 - 2.0 * 0.1
+    assert va[-1] == 1.0 - 0.1 and va[-2] == 0.1
+    # every row sums to one (demos/CreateA.cpp:41-58), so A.1 = 1 to rounding
+    y = oracle.csr_spmv(rp, ci, va, np.ones(7))
+    assert np.allclose(y, 1.0, rtol=0, atol=2e-16)
+    # splitmix64 known answer: seed 0 -> first output 0xE220A8397B1DCDAF
+    u = oracle.splitmix64_unit(3, seed=0)
+    assert u[0] == (0xE220A8397B1DCDAF >> 11) * 2.0 ** -52 - 1.0
+    u = oracle.splitmix64_unit(100000)
+    assert u.min() >= -1.0 and u.max() < 1.0 and abs(u.mean()) < 0.01
+
+
+def test_oracle_reverse_update_counts_and_conserves():
+    """L2GMap.cpp:907-950: with zeros in the owned part and ones in every
+    ghost tail, an owner ends up with the number of ranks ghosting each entry;
+    in general the grand total of owned entries grows by the sum of all tails."""
+    sizes = [6, 4, 7]
+    ghosts = [np.array([6, 7, 12]), np.array([0, 5, 12, 16]), np.array([5, 7])]
+    plans = oracle.l2g_plans(sizes, ghosts)
+    vecs = [np.concatenate([np.zeros(n), np.ones(len(g))])
+            for n, g in zip(sizes, ghosts)]
+    out = oracle.l2g_reverse_update(plans, vecs)
+    owned = np.concatenate([v[:n] for v, n in zip(out, sizes)])
+    want = np.zeros(17)
+    for g in ghosts:
+        want[g] += 1
+    assert np.array_equal(owned, want)
+    assert all(np.all(v[n:] == 1.0) for v, n in zip(out, sizes))
+    rng = np.random.default_rng(5)
+    vecs = [rng.integers(-8, 8, n + len(g)).astype(float)
+            for n, g in zip(sizes, ghosts)]
+    before = sum(v[:n].sum() for v, n in zip(vecs, sizes))
+    tails = sum(v[n:].sum() for v, n in zip(vecs, sizes))
+    out = oracle.l2g_reverse_update(plans, [v.copy() for v in vecs])
+    assert sum(v[:n].sum() for v, n in zip(out, sizes)) == before + tails
+    # adjoint of the forward halo: <update(x), y> == <x, reverse(y)> on integers
+    xs = [v.copy() for v in vecs]
+    ys = [rng.integers(-8, 8, len(v)).astype(float) for v in vecs]
+    fwd = oracle.l2g_update(plans, [v.copy() for v in xs])
+    rev = oracle.l2g_reverse_update(plans, [v.copy() for v in ys])
+    lhs = sum(np.dot(f, y) for f, y in zip(fwd, ys))
+    # forward overwrites ghost tails, so compare against x with zeroed tails
+    rhs = sum(np.dot(x[:n], r[:n]) for x, r, n in zip(xs, rev, sizes))
+    assert lhs == rhs
