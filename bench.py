@@ -27,6 +27,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# dmabuf IPC is the only mode the host driver supports; RCCL's intra-node
+# transport fails with "hipIpcGetMemHandle: invalid argument" without it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
