@@ -203,26 +203,33 @@ def main():
     elapsed = time.perf_counter() - t0
     assert k == args.steps, (k, args.steps)
 
-    # max over ranks
+    # algorithmic bytes of the dominant kernel on THIS rank (DESIGN.md,
+    # SURVEY 8d): entries*12 + (rows+1)*4 + x (cols*8) + y (rows*8)
+    rows_b, cols_b, nnz_b = blocks["local"]
+    if args.symmetric:
+        kernel_bytes = poisson.sym_csr_bytes(rows_b, nnz_b)
+        kernel = "csr_sym_window_kernel<double> (local lower block + diagonal)"
+    else:
+        kernel_bytes = poisson.csr_bytes(rows_b, cols_b, nnz_b)
+        kernel = "csr_rowblock_kernel<double> (local block, fused p.Ap)"
+    iter_bytes = kernel_bytes + 9 * M * 8  # + fused BLAS-1 minimum, SURVEY 8d
+
+    # max over ranks of the times, sum over ranks of the bytes
     if world > 1:
+        dev_t = "cpu" if rehearsal else "cuda"
         t = torch.tensor([elapsed, spmv_ms / max(spmv_launches, 1)],
-                         dtype=torch.float64,
-                         device="cpu" if rehearsal else "cuda")
+                         dtype=torch.float64, device=dev_t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, spmv_ms_avg = float(t[0]), float(t[1])
+        bsum = torch.tensor([kernel_bytes, iter_bytes], dtype=torch.float64,
+                            device=dev_t)
+        dist.all_reduce(bsum, op=dist.ReduceOp.SUM)
+        kernel_bytes_all, iter_bytes_all = float(bsum[0]), float(bsum[1])
     else:
         spmv_ms_avg = spmv_ms / max(spmv_launches, 1)
+        kernel_bytes_all, iter_bytes_all = kernel_bytes, iter_bytes
 
     if rank == 0:
-        # algorithmic bytes of the dominant kernel on THIS rank (DESIGN.md,
-        # SURVEY 8d): entries*12 + (rows+1)*4 + x (cols*8) + y (rows*8)
-        rows_b, cols_b, nnz_b = blocks["local"]
-        if args.symmetric:
-            kernel_bytes = poisson.sym_csr_bytes(rows_b, nnz_b)
-            kernel = "csr_sym_rowblock_kernel<double>"
-        else:
-            kernel_bytes = poisson.csr_bytes(rows_b, cols_b, nnz_b)
-            kernel = "csr_rowblock_kernel<double> (local block, fused p.Ap)"
         achieved = kernel_bytes / (spmv_ms_avg * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
@@ -260,8 +267,10 @@ def main():
                          "launches_timed": spmv_launches},
             # whole-iteration effective bandwidth: SpMV + fused BLAS-1 minimum
             # (9 vectors of 8 B per row)
-            "cg_gbs_per_gpu": (kernel_bytes + 9 * M * 8)
-            / (elapsed / args.steps) / 1e9,
+            "cg_gbs_per_gpu": iter_bytes / (elapsed / args.steps) / 1e9,
+            # all ranks together: sum of bytes / time of the slowest rank
+            "spmv_gbs_aggregate": kernel_bytes_all / (spmv_ms_avg * 1e-3) / 1e9,
+            "cg_gbs_aggregate": iter_bytes_all / (elapsed / args.steps) / 1e9,
         }
         if world == 1 and not args.symmetric:
             out["north_star_spmv"] = north_star_spmv(exec_, comm, host, _lib,

@@ -15,7 +15,7 @@ import os
 import torch  # noqa: F401  (must precede loading libspmv_hip.so, see above)
 
 # SPMV_AMD_LIBDIR: developer override (the AddressSanitizer build of the host
-# mirror lives in lib/asan, see `make -C spmv_amd/csrc asan`)
+# mirror lives in gpurun_out/asan (scratch, not shipped), see `make -C spmv_amd/csrc asan`)
 _LIBDIR = os.environ.get("SPMV_AMD_LIBDIR") or os.path.join(
     os.path.dirname(os.path.abspath(__file__)), "lib")
 
