@@ -331,3 +331,119 @@ def test_benchmark_scale_512_cubed(exec_, comm):
             exec_.free(d_x)
         A.close()
     exec_.free(d_one), exec_.free(d_b)
+
+
+# ---------------------------------------------------------------------------
+# Many ranks as threads of this process, all on GPU 0 (tests/thread_world.py):
+# the 8-way slab layout of BASELINE configs[4] and unstructured halos with up
+# to 7 neighbours per rank, end to end through Matrix / L2GMap / cg
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("world,n", [(8, 16), (5, 12), (8, 8)])
+def test_slab_ranks_threaded_spmv_and_cg(world, n):
+    from thread_world import ThreadWorld
+    N = n ** 3
+    rp, ci, va = poisson.poisson3d_csr(n)
+    x = oracle.gaussian_x_fast(N)
+    b = oracle.csr_spmv(rp, ci.astype(np.int32), va, np.ones(N))
+    y_seq = oracle.csr_spmv(rp, ci.astype(np.int32), va, x)
+    ranges = oracle.owner_ranges(world, N)
+    refs = {}
+    for sym in (False, True):
+        for cm in (host.P2P_BLOCKING, host.P2P_NONBLOCKING):
+            refs[(sym, cm)] = (
+                oracle.dist_spmv(world, rp, ci, va, x, sym, cm),
+                oracle.dist_cg(world, rp, ci, va, b, 200, 1e-10, sym, cm))
+    tw = ThreadWorld(world, timeout=45.0)
+
+    def rank_body(rank, comm, exec_):
+        r0, r1 = int(ranges[rank]), int(ranges[rank + 1])
+        for (sym, cm), (y_ref, (x_ref, k_ref, hist_ref)) in refs.items():
+            A = host.Matrix.create_poisson3d(comm, exec_, n, sym, cm)
+            l2g = A.col_map()
+            assert l2g.local_size() == r1 - r0
+            assert len(l2g.plan().neighbours) == (1 if rank in (0, world - 1) else 2)
+            d_x = exec_.alloc(l2g.local_size() + l2g.num_ghosts())
+            d_y = exec_.alloc(r1 - r0)
+            exec_.copy_from_host(d_x, x[r0:r1])
+            l2g.update(d_x)
+            A.mult(d_x, d_y)
+            y = tw.gather(rank, exec_.copy_to_host(d_y, r1 - r0))
+            if sym:
+                assert np.all(np.abs(y - y_seq) <= 16 * U * abs_bound(rp, ci, va, x))
+            else:
+                assert np.array_equal(y, y_ref), cm
+            d_b, d_s = exec_.alloc(r1 - r0), exec_.alloc(r1 - r0)
+            exec_.copy_from_host(d_b, b[r0:r1])
+            k, hist = host.cg(comm, exec_, A, d_b, d_s, 200, 1e-10)
+            xs = tw.gather(rank, exec_.copy_to_host(d_s, r1 - r0))
+            assert abs(k - k_ref) <= 1 and k < 200, (k, k_ref)
+            m = min(k, k_ref, 50)
+            assert np.allclose(hist[:m + 1], hist_ref[:m + 1], rtol=1e-6)
+            assert np.linalg.norm(xs - x_ref) <= 1e-8 * np.linalg.norm(x_ref)
+            A.close()
+            for p in (d_x, d_y, d_b, d_s):
+                exec_.free(p)
+
+    tw.run(rank_body, gpu=True)
+
+
+@pytest.mark.parametrize("world,N,seed", [(8, 120, 21), (6, 75, 22)])
+def test_unstructured_ranks_threaded(world, N, seed):
+    """Every rank talks to (almost) every other rank: packed sends, up to 7
+    neighbours, forward halo + mult + reverse_update."""
+    from thread_world import ThreadWorld
+    rng = np.random.default_rng(seed)
+    dense = rng.random((N, N)) < 0.12
+    dense = dense | dense.T | np.eye(N, dtype=bool)
+    rp = np.concatenate([[0], np.cumsum(dense.sum(1))]).astype(np.int32)
+    ci = np.nonzero(dense)[1].astype(np.int64)
+    vals = rng.uniform(-1, 1, (N, N))
+    va = ((vals + vals.T) / 2)[dense]
+    x = rng.uniform(-1, 1, N)
+    y_seq = oracle.csr_spmv(rp, ci.astype(np.int32), va, x)
+    ranges = oracle.owner_ranges(world, N)
+    sizes = np.diff(ranges)
+    locs = [oracle.localise_rows(rp, ci, va, int(ranges[r]), int(ranges[r + 1]))
+            for r in range(world)]
+    plans = oracle.l2g_plans(sizes, [l[3] for l in locs])
+    assert max(len(p["neighbours"]) for p in plans) == world - 1
+    # some ranks must pack (scattered requests), the dense ones send directly
+    tails = [rng.uniform(-1, 1, int(sizes[r]) + len(locs[r][3])) for r in range(world)]
+    rev_ref = oracle.l2g_reverse_update(plans, [t.copy() for t in tails])
+    tw = ThreadWorld(world, timeout=45.0)
+
+    def rank_body(rank, comm, exec_):
+        r0, r1 = int(ranges[rank]), int(ranges[rank + 1])
+        lrp, lci, lva, ghosts = locs[rank]
+        for sym in (False, True):
+            for cm in (host.P2P_BLOCKING, host.P2P_NONBLOCKING):
+                A = host.Matrix.create_matrix(comm, exec_, lrp, lci, lva, r1 - r0,
+                                              r1 - r0, [], ghosts, sym, cm)
+                l2g = A.col_map()
+                d_x = exec_.alloc(l2g.local_size() + l2g.num_ghosts())
+                d_y = exec_.alloc(r1 - r0)
+                exec_.copy_from_host(d_x, x[r0:r1])
+                l2g.update(d_x)
+                A.mult(d_x, d_y)
+                exec_.synchronize()
+                xs = exec_.copy_to_host(d_x, l2g.local_size() + l2g.num_ghosts())
+                assert np.array_equal(xs[r1 - r0:], x[ghosts])
+                y = tw.gather(rank, exec_.copy_to_host(d_y, r1 - r0))
+                if sym:
+                    bound = (16 + np.diff(rp)) * U * abs_bound(rp, ci, va, x)
+                    assert np.all(np.abs(y - y_seq) <= bound)
+                else:
+                    assert np.array_equal(
+                        y, oracle.dist_spmv(world, rp, ci, va, x, False, cm))
+                A.close()
+                exec_.free(d_x), exec_.free(d_y)
+        m = host.L2GMap(comm, int(sizes[rank]), ghosts, exec_, host.P2P_BLOCKING)
+        d_v = exec_.alloc(len(tails[rank]))
+        exec_.copy_from_host(d_v, tails[rank])
+        m.reverse_update(d_v)
+        exec_.synchronize()
+        assert np.array_equal(exec_.copy_to_host(d_v, len(tails[rank])), rev_ref[rank])
+        exec_.free(d_v)
+        m.close()
+
+    tw.run(rank_body, gpu=True)

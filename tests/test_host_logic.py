@@ -355,3 +355,102 @@ def test_oracle_reverse_update_counts_and_conserves():
     # forward overwrites ghost tails, so compare against x with zeroed tails
     rhs = sum(np.dot(x[:n], r[:n]) for x, r, n in zip(xs, rev, sizes))
     assert lhs == rhs
+
+
+# ---------------------------------------------------------------------------
+# many ranks in one process (threads): random unstructured halos with up to
+# P-1 neighbours per rank, uneven and EMPTY row ranges
+# ---------------------------------------------------------------------------
+def _random_global_csr(rng, N, density, symmetric_pattern):
+    dense = rng.random((N, N)) < density
+    if symmetric_pattern:
+        dense = dense | dense.T
+    dense |= np.eye(N, dtype=bool)
+    rp = np.concatenate([[0], np.cumsum(dense.sum(1))]).astype(np.int32)
+    ci = np.nonzero(dense)[1].astype(np.int64)
+    vals = rng.uniform(-1, 1, (N, N))
+    vals = (vals + vals.T) / 2
+    return rp, ci, vals[dense]
+
+
+@pytest.mark.parametrize("world,N,density,seed", [
+    (4, 41, 0.15, 0), (5, 64, 0.05, 1), (8, 97, 0.08, 2), (8, 40, 0.3, 3),
+    (6, 9, 0.4, 4),   # fewer than two rows on most ranks
+    (7, 5, 0.5, 5),   # some ranks own NO rows
+])
+def test_plan_and_split_many_ranks_threaded(world, N, density, seed):
+    from thread_world import ThreadWorld
+    rng = np.random.default_rng(seed)
+    rp, ci, va = _random_global_csr(rng, N, density, symmetric_pattern=True)
+    ranges = oracle.owner_ranges(world, N)
+    sizes = np.diff(ranges)
+    locs = [oracle.localise_rows(rp, ci, va, int(ranges[r]), int(ranges[r + 1]))
+            for r in range(world)]
+    plans = oracle.l2g_plans(sizes, [l[3] for l in locs])
+    assert max(len(p["neighbours"]) for p in plans) >= min(3, world - 1) or N < 10
+
+    def rank_body(rank, comm):
+        lrp, lci, lva, ghosts = locs[rank]
+        nloc = int(sizes[rank])
+        for cm in (host.P2P_BLOCKING, host.P2P_NONBLOCKING,
+                   host.COLLECTIVE_BLOCKING):
+            m = host.L2GMap(comm, nloc, ghosts, None, cm)
+            got, exp = m.plan(), plans[rank]
+            nn = len(exp["neighbours"])
+            assert np.array_equal(got.neighbours, exp["neighbours"])
+            assert np.array_equal(got.send_count, exp["send_count"][:nn])
+            assert np.array_equal(got.recv_count, exp["recv_count"][:nn])
+            assert np.array_equal(got.send_offset, exp["send_offset"][:nn + 1])
+            assert np.array_equal(got.recv_offset, exp["recv_offset"][:nn + 1])
+            assert np.array_equal(got.indexbuf, exp["indexbuf"])
+            m.close()
+        for sym in (False, True):
+            for cm in (host.P2P_BLOCKING, host.P2P_NONBLOCKING):
+                A = oracle.create_matrix(rank, ranges, ranges, lrp, lci, lva,
+                                         ghosts, sym, cm)
+                s = host.split_rows(lrp, lci, lva, nloc, nloc, ranges[rank],
+                                    ranges[rank], ghosts, sym, cm)
+                assert s["nnz"] == A["nnz"]
+                assert np.array_equal(s["ghosts"], A["ghosts"])
+                for name in ("local", "remote"):
+                    if A[name] is None:
+                        assert len(s[name][2]) == 0
+                        continue
+                    for a, b in zip(s[name], A[name]):
+                        assert np.array_equal(a, b), (name, sym, cm)
+                if sym:
+                    assert np.array_equal(s["diagonal"], A["diagonal"])
+
+    ThreadWorld(world).run(rank_body)
+
+
+@pytest.mark.parametrize("world,N,seed,sym", [(4, 37, 10, False), (5, 53, 11, True),
+                                              (8, 71, 12, False), (8, 90, 13, True)])
+def test_row_ghost_assembly_many_ranks_threaded(world, N, seed, sym):
+    """Matrix.cpp:188-292 with up to 7 ranks contributing pieces of a row."""
+    from thread_world import ThreadWorld
+    from util import assembled_inputs
+    rng = np.random.default_rng(seed)
+    _, ranges, inputs = assembled_inputs(rng, world, N, symmetric=sym)
+    expected = {cm: oracle.create_matrices_with_row_ghosts(ranges, inputs, sym, cm)
+                for cm in (host.P2P_BLOCKING, host.P2P_NONBLOCKING)}
+
+    def rank_body(rank, comm):
+        rp, ci, va, rg, cg = inputs[rank]
+        nloc = int(ranges[rank + 1] - ranges[rank])
+        for cm, exp_all in expected.items():
+            exp = exp_all[rank]
+            got = host.split_rows_distributed(comm, rp, ci, va, nloc, nloc, rg,
+                                              cg, sym, cm)
+            assert np.array_equal(got["ghosts"], exp["ghosts"])
+            assert got["nnz"] == exp["nnz"]
+            for name in ("local", "remote"):
+                if exp[name] is None:
+                    assert len(got[name][2]) == 0
+                    continue
+                for a, b in zip(got[name], exp[name]):
+                    assert np.array_equal(a, b), (name, sym, cm)
+            if sym:
+                assert np.array_equal(got["diagonal"], exp["diagonal"])
+
+    ThreadWorld(world).run(rank_body)
