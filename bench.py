@@ -83,11 +83,37 @@ def cpu_baseline(args, n_gpu, rows_gpu):
         if best is None or rate > best[0]:
             best = (rate, t, secs)
     rate, t, secs = best
-    return {"value": rate, "unit": "iters/s", "cores": t, "kind": "port",
-            "sample": (f"oracle OpenMP CG (restated spmv/openmp path), "
-                       f"{n}^3 Poisson, {args.cpu_iters} iterations in "
-                       f"{secs:.2f} s on {t} threads, scaled by rows "
-                       f"{n ** 3}/{rows_gpu} to the {n_gpu}^3 workload")}
+    out = {"value": rate, "unit": "iters/s", "cores": t, "kind": "port",
+           "sample": (f"oracle OpenMP CG (restated spmv/openmp path), "
+                      f"{n}^3 Poisson, {args.cpu_iters} iterations in "
+                      f"{secs:.2f} s on {t} threads, scaled by rows "
+                      f"{n ** 3}/{rows_gpu} to the {n_gpu}^3 workload")}
+    # SURVEY 8d extras on the same sample: plain SpMV on the OpenMP path and
+    # the 1-thread ReferenceExecutor-equivalent loop (BASELINE configs[0] at
+    # 128^3), both in algorithmic GB/s (same formula as the GPU figure)
+    try:
+        from spmv_amd import poisson
+        x = np.ones(n ** 3)
+        nbytes = poisson.csr_bytes(n ** 3, n ** 3, len(va))
+        s_omp = oracle.time_spmv(rp, ci, va, x, reps=10, num_threads=t)
+        out["spmv_omp"] = {"grid": n, "threads": t, "ms_per_apply": s_omp * 1e3,
+                           "GB/s": nbytes / s_omp / 1e9}
+        if n > 128:
+            rp, ci, va = oracle.poisson3d(128)
+            x = np.ones(128 ** 3)
+            nbytes = poisson.csr_bytes(128 ** 3, 128 ** 3, len(va))
+        s_ref = oracle.time_spmv(rp, ci, va, x, reps=5, num_threads=1)
+        out["spmv_reference_1thread"] = {"grid": min(n, 128),
+                                         "ms_per_apply": s_ref * 1e3,
+                                         "GB/s": nbytes / s_ref / 1e9}
+        with open("/proc/cpuinfo") as f:
+            models = [ln.split(":", 1)[1].strip() for ln in f
+                      if ln.startswith("model name")]
+        out["host"] = {"model": models[0] if models else "unknown",
+                       "logical_cpus": os.cpu_count(), "usable": cores}
+    except Exception as e:  # extras only; the baseline itself is above
+        out["extras_error"] = repr(e)
+    return out
 
 
 def north_star_spmv(exec_, comm, host, _lib, poisson, n=216, reps=200):

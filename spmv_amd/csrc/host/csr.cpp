@@ -93,6 +93,14 @@ void CSRSpMV<T>::run_dot_sym(int32_t num_rows, int32_t num_cols,
 }
 
 template <typename T>
+void CSRSpMV<T>::tune(const char* key, int value) const
+{
+  if (plan())
+    throw_on_error(spmv_hip_csr_plan_set(plan(), key, value),
+                   "spmv_hip_csr_plan_set");
+}
+
+template <typename T>
 void CSRSpMV<T>::finalize(const HipExecutor&) const
 {
   spmv_hip_csr_plan_destroy(plan());

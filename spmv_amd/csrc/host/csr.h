@@ -69,6 +69,10 @@ public:
                    const T* diagonal, T alpha, T* in, T beta, T* out,
                    double* dot_partials, const HipExecutor& exec) const;
 
+  // launch-shape knob of the plan (spmv_hip_csr_plan_set); throws on an
+  // unknown key
+  void tune(const char* key, int value) const;
+
   bool symmetric() const { return _symmetric; }
   spmv_hip_csr_plan* plan() const
   {
@@ -137,6 +141,7 @@ public:
   const int32_t* colind() const { return _colind; }
   const T* values() const { return _values; }
   const CSRSpMV<T>& op() const { return _op; }
+  void tune(const char* key, int value) const { _op.tune(key, value); }
 
 private:
   int32_t* _rowptr = nullptr;

@@ -11,7 +11,7 @@ import numpy as np
 from . import _lib
 from ._lib import call
 
-ALGO_AUTO, ALGO_ROWBLOCK, ALGO_VECTOR, ALGO_SCALAR = 0, 1, 2, 3
+ALGO_AUTO, ALGO_ROWBLOCK, ALGO_VECTOR, ALGO_SCALAR, ALGO_ROWLIST = 0, 1, 2, 3, 4
 PART_ALL, PART_LOCAL, PART_REMOTE, PART_LOCAL_LOWER = 0, 1, 2, 3
 
 

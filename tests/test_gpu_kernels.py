@@ -671,3 +671,57 @@ def test_scatter_add_distinct_indices(ctx, dtype):
     assert np.array_equal(d_d.numpy(), want)
     for b in (d_i, d_s, d_d):
         b.free()
+
+
+def test_fuzz_shapes_all_kernels(ctx):
+    """Sixty random shapes in one test: tiny and empty matrices, one column,
+    nnz just below / at / above tile boundaries, block-boundary row counts,
+    all-empty rows; exact kernels bit-exact, the others inside their bound;
+    symmetric storage derived from a random symmetric pattern."""
+    rng = np.random.default_rng(0xF022)
+    specials = [(1, 1, 0.0), (1, 1, 3.0), (255, 7, 2.0), (256, 256, 1.0),
+                (257, 300, 2.0), (511, 1, 4.0), (512, 2000, 0.0), (513, 50, 9.0),
+                (1024, 1024, 0.5), (2049, 4096, 2.0)]
+    for case in range(60):
+        if case < len(specials):
+            nrows, ncols, avg = specials[case]
+        else:
+            nrows = int(rng.integers(1, 6000))
+            ncols = int(rng.integers(1, 6000))
+            avg = float(rng.choice([0.2, 1, 2, 5, 11, 40]))
+        rp, ci, va = random_csr(rng, nrows, ncols, avg,
+                                empty_frac=float(rng.choice([0.0, 0.1, 0.6])),
+                                long_rows=int(rng.integers(0, 3)),
+                                long_len=int(rng.integers(300, 3000)))
+        x = rng.uniform(-1, 1, ncols)
+        alpha, beta = float(rng.choice([1.0, -2.0, 0.5])), float(rng.choice([0.0, 1.0, -0.25]))
+        y0 = rng.uniform(-1, 1, nrows)
+        y_ref = oracle.csr_spmv(rp, ci, va, x, alpha, beta, y0)
+        bound = (16 + np.diff(rp)) * U * abs_bound(rp, ci, va, x, alpha, beta, y0)
+        for algo in (hip.ALGO_AUTO, hip.ALGO_ROWBLOCK, hip.ALGO_SCALAR,
+                     hip.ALGO_VECTOR, hip.ALGO_ROWLIST):
+            y = run_spmv(ctx, rp, ci, va, x, nrows, ncols, alpha, beta,
+                         None if beta == 0 else y0, algo=algo)
+            if algo in (hip.ALGO_ROWBLOCK, hip.ALGO_SCALAR, hip.ALGO_ROWLIST):
+                assert np.array_equal(y, y_ref), (case, algo)
+            else:
+                assert np.all(np.abs(y - y_ref) <= bound + 1e-300), (case, algo)
+        if case % 3 == 0:  # symmetric storage of a random symmetric matrix
+            n = min(nrows, 1500)
+            dense = rng.random((n, n)) < min(0.5, (avg + 1) / n)
+            dense = dense | dense.T
+            vals = rng.uniform(-1, 1, (n, n))
+            vals = (vals + vals.T) / 2
+            srp = np.concatenate([[0], np.cumsum(dense.sum(1))]).astype(np.int32)
+            sci = np.nonzero(dense)[1].astype(np.int32)
+            sva = vals[dense]
+            xs = rng.uniform(-1, 1, n)
+            ys0 = rng.uniform(-1, 1, n)
+            ref = oracle.csr_spmv(srp, sci, sva, xs, alpha, beta, ys0)
+            lrp, lci, lva, dg = lower_split(srp, sci, sva)
+            sb = (16 + 2 * np.diff(srp)) * U * abs_bound(srp, sci, sva, xs, alpha, beta, ys0)
+            for knobs in (dict(), dict(sym_window=0), dict(sym_window=512, sym_rows=512)):
+                ys = run_spmv(ctx, lrp, lci, lva, xs, n, n, alpha, beta,
+                              None if beta == 0 else ys0, diagonal=dg,
+                              symmetric=True, knobs=knobs)
+                assert np.all(np.abs(ys - ref) <= sb + 1e-300), (case, knobs)
