@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--cpu-n", type=int, default=256,
                     help="grid of the bounded CPU sample")
     ap.add_argument("--cpu-iters", type=int, default=30)
+    ap.add_argument("--blas1-nt-min", type=int, default=None,
+                    help="override the context option blas1_nt_min_elems "
+                         "(experiments)")
     return ap.parse_args()
 
 
@@ -203,6 +206,9 @@ def main():
 
     # RHS b = Gaussian bump (demos/spmv.cpp:63-67) -- resident before timing
     ctx = exec_.context
+    if args.blas1_nt_min is not None:
+        _lib.call("spmv_hip_ctx_set_option", ctx, b"blas1_nt_min_elems",
+                  args.blas1_nt_min)
     d_b, d_x = exec_.alloc(M), exec_.alloc(M)
     _lib.call("spmv_hip_fill_gaussian_f64", ctx, N, l2g.global_offset(), M, d_b,
               None)

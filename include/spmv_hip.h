@@ -58,6 +58,11 @@ int spmv_hip_ctx_destroy(spmv_hip_ctx* ctx);
 int spmv_hip_ctx_device(const spmv_hip_ctx* ctx, int* device_id);
 int spmv_hip_num_cus(const spmv_hip_ctx* ctx, int* num_cus);
 int spmv_hip_synchronize(spmv_hip_ctx* ctx); /* whole device */
+/* tuning options of a context; EINVAL for an unknown key.
+ *   "blas1_nt_min_elems": the CG vector kernels stream vectors of at least
+ *   this many elements past the caches (non-temporal loads and stores);
+ *   shorter vectors stay cached between kernels.  Default 2^24. */
+int spmv_hip_ctx_set_option(spmv_hip_ctx* ctx, const char* key, int64_t value);
 
 /* ---- streams / events ---------------------------------------------------
  * CudaExecutor::set/reset/get_cuda_stream (cuda/cuda_executor.h:72-76). */
@@ -146,6 +151,12 @@ int spmv_hip_csr_plan_algo(const spmv_hip_csr_plan* plan, int* algo);
 /* tuning knobs, used by the benchmark sweep: key/value, returns EINVAL for
  * an unknown key. */
 int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value);
+/* what the plan decided: "algo", "lattice_d1", "lattice_d2" (row offsets of the
+ * next grid line / plane when the matrix looks like a 3-D stencil, else 0),
+ * "band_lines" / "order_slots" (band-sweep row-block order, 0 = none),
+ * "band_order", "blocks_per_cu", "nontemporal" */
+int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
+                          int* value);
 
 int spmv_hip_csr_spmv_f64(spmv_hip_ctx* ctx, const spmv_hip_csr_plan* plan,
                           int32_t num_rows, int32_t num_cols,

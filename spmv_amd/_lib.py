@@ -51,6 +51,7 @@ _PROTOS = {
     "spmv_hip_ctx_device": ([vp, P(C.c_int)], C.c_int),
     "spmv_hip_num_cus": ([vp, P(C.c_int)], C.c_int),
     "spmv_hip_synchronize": ([vp], C.c_int),
+    "spmv_hip_ctx_set_option": ([vp, C.c_char_p, i64], C.c_int),
     "spmv_hip_stream_create": ([vp, P(vp)], C.c_int),
     "spmv_hip_stream_create_priority": ([vp, C.c_int, P(vp)], C.c_int),
     "spmv_hip_stream_destroy": ([vp, vp], C.c_int),
@@ -77,6 +78,7 @@ _PROTOS = {
     "spmv_hip_csr_plan_destroy": ([vp], C.c_int),
     "spmv_hip_csr_plan_algo": ([vp, P(C.c_int)], C.c_int),
     "spmv_hip_csr_plan_set": ([vp, C.c_char_p, C.c_int], C.c_int),
+    "spmv_hip_csr_plan_get": ([vp, C.c_char_p, P(C.c_int)], C.c_int),
     "spmv_hip_csr_spmv_f64": ([vp, vp, i32, i32, i64, vp, vp, vp, vp, f64, vp,
                                f64, vp, vp, vp], C.c_int),
     "spmv_hip_csr_spmv_f32": ([vp, vp, i32, i32, i64, vp, vp, vp, vp, f32, vp,

@@ -11,7 +11,14 @@
 //         precedent for device-resident scalars: cuda/cg.cuda.cu:14-38,73-84.
 //
 // Built with -ffp-contract=off: axpy/scal round like unfused BLAS-1.
-// All of this is HBM-bound streaming; 16 B per lane, grid-stride.
+//
+// Streaming shape (measured with tools/membench on MI355X, 1-4 GiB vectors):
+// a persistent grid walks UNITS of kU x 4 KiB, every lane keeps kU 16-byte
+// loads per stream in flight, and vectors that cannot stay in the 256 MiB
+// Infinity Cache anyway are read and written non-temporally.  Against plain
+// 16-byte grid-stride loops this gave 4.6-4.9 -> 5.8-5.9 TB/s for the
+// two-read-one-write shape (r -= alpha Ap), 4.7-5.0 -> 5.6-5.7 TB/s for the
+// three-read-two-write shape (x, p update) and 6.3 -> 7.1 TB/s for dots.
 #include "common.h"
 
 #include <cmath>
@@ -36,6 +43,191 @@ __device__ __forceinline__ double block_sum(double v, double* s_red)
       r += s_red[w];
   }
   return r; // valid in thread 0
+}
+
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+constexpr int kU = 4;                           // 16-B loads in flight per stream
+constexpr int64_t kUnit = (int64_t)kU * kBlock; // double2 elements per step
+
+template <bool NT>
+__device__ __forceinline__ f64x2 vload(const double* p, int64_t i2)
+{
+  const f64x2* q = reinterpret_cast<const f64x2*>(p) + i2;
+  return NT ? __builtin_nontemporal_load(q) : *q;
+}
+template <bool NT>
+__device__ __forceinline__ void vstore(double* p, int64_t i2, f64x2 v)
+{
+  f64x2* q = reinterpret_cast<f64x2*>(p) + i2;
+  if (NT)
+    __builtin_nontemporal_store(v, q);
+  else
+    *q = v;
+}
+
+// for (unit of this workgroup) { load phase ; compute + store phase }
+#define SPMV_FOR_UNITS(n2)                                                     \
+  for (int64_t base = (int64_t)blockIdx.x * kUnit; base < (n2);               \
+       base += (int64_t)gridDim.x * kUnit)
+#define SPMV_FOR_LANE_ELEMS(i, n2)                                             \
+  _Pragma("unroll") for (int u = 0; u < kU; ++u)                               \
+    if (const int64_t i = base + u * kBlock + threadIdx.x; i < (n2))
+
+// sum over the double2 elements [0, n2) of x . y : this thread's share
+template <bool NT>
+__device__ __forceinline__ double stream_dot(int64_t n2, const double* x,
+                                             const double* y)
+{
+  double acc = 0.0;
+  SPMV_FOR_UNITS(n2)
+  {
+    f64x2 a[kU], b[kU];
+    SPMV_FOR_LANE_ELEMS(i, n2)
+    {
+      a[u] = vload<NT>(x, i);
+      b[u] = vload<NT>(y, i);
+    }
+    SPMV_FOR_LANE_ELEMS(i, n2)
+    {
+      acc += a[u].x * b[u].x;
+      acc += a[u].y * b[u].y;
+    }
+  }
+  return acc;
+}
+
+// r += nalpha * Ap (cg.cpp:70), returns this thread's share of r.r (:73)
+template <bool NT>
+__device__ __forceinline__ double stream_update_r(int64_t n2, double nalpha,
+                                                  const double* Ap, double* r)
+{
+  double acc = 0.0;
+  SPMV_FOR_UNITS(n2)
+  {
+    f64x2 av[kU], rv[kU];
+    SPMV_FOR_LANE_ELEMS(i, n2)
+    {
+      av[u] = vload<NT>(Ap, i);
+      rv[u] = vload<NT>(r, i);
+    }
+    SPMV_FOR_LANE_ELEMS(i, n2)
+    {
+      rv[u].x += nalpha * av[u].x;
+      rv[u].y += nalpha * av[u].y;
+      vstore<NT>(r, i, rv[u]);
+      acc += rv[u].x * rv[u].x;
+      acc += rv[u].y * rv[u].y;
+    }
+  }
+  return acc;
+}
+
+// x += alpha p (cg.cpp:69) ; r += nalpha Ap (:70) ; share of r.r (:73)
+template <bool NT>
+__device__ __forceinline__ double stream_update_xr(int64_t n2, double alpha,
+                                                   double nalpha, const double* p,
+                                                   const double* Ap, double* x,
+                                                   double* r)
+{
+  double acc = 0.0;
+  SPMV_FOR_UNITS(n2)
+  {
+    f64x2 pv[kU], av[kU], xv[kU], rv[kU];
+    SPMV_FOR_LANE_ELEMS(i, n2)
+    {
+      pv[u] = vload<NT>(p, i);
+      av[u] = vload<NT>(Ap, i);
+      xv[u] = vload<NT>(x, i);
+      rv[u] = vload<NT>(r, i);
+    }
+    SPMV_FOR_LANE_ELEMS(i, n2)
+    {
+      xv[u].x += alpha * pv[u].x;
+      xv[u].y += alpha * pv[u].y;
+      rv[u].x += nalpha * av[u].x;
+      rv[u].y += nalpha * av[u].y;
+      vstore<NT>(x, i, xv[u]);
+      vstore<NT>(r, i, rv[u]);
+      acc += rv[u].x * rv[u].x;
+      acc += rv[u].y * rv[u].y;
+    }
+  }
+  return acc;
+}
+
+// p = beta p + r (cg.cpp:84-85)
+template <bool NT>
+__device__ __forceinline__ void stream_update_p(int64_t n2, double beta,
+                                                const double* r, double* p)
+{
+  SPMV_FOR_UNITS(n2)
+  {
+    f64x2 pv[kU], rv[kU];
+    SPMV_FOR_LANE_ELEMS(i, n2)
+    {
+      pv[u] = vload<NT>(p, i);
+      rv[u] = vload<NT>(r, i);
+    }
+    SPMV_FOR_LANE_ELEMS(i, n2)
+    {
+      pv[u].x = beta * pv[u].x;
+      pv[u].y = beta * pv[u].y;
+      pv[u].x += rv[u].x;
+      pv[u].y += rv[u].y;
+      vstore<NT>(p, i, pv[u]);
+    }
+  }
+}
+
+// x += alpha p (cg.cpp:69)
+template <bool NT>
+__device__ __forceinline__ void stream_axpy(int64_t n2, double alpha,
+                                            const double* p, double* x)
+{
+  SPMV_FOR_UNITS(n2)
+  {
+    f64x2 pv[kU], xv[kU];
+    SPMV_FOR_LANE_ELEMS(i, n2)
+    {
+      pv[u] = vload<NT>(p, i);
+      xv[u] = vload<NT>(x, i);
+    }
+    SPMV_FOR_LANE_ELEMS(i, n2)
+    {
+      xv[u].x += alpha * pv[u].x;
+      xv[u].y += alpha * pv[u].y;
+      vstore<NT>(x, i, xv[u]);
+    }
+  }
+}
+
+// x += alpha p (cg.cpp:69) ; p = beta p + r (:84-85)
+template <bool NT>
+__device__ __forceinline__ void stream_update_xp(int64_t n2, double alpha,
+                                                 double beta, const double* r,
+                                                 double* x, double* p)
+{
+  SPMV_FOR_UNITS(n2)
+  {
+    f64x2 pv[kU], xv[kU], rv[kU];
+    SPMV_FOR_LANE_ELEMS(i, n2)
+    {
+      pv[u] = vload<NT>(p, i);
+      xv[u] = vload<NT>(x, i);
+      rv[u] = vload<NT>(r, i);
+    }
+    SPMV_FOR_LANE_ELEMS(i, n2)
+    {
+      xv[u].x += alpha * pv[u].x;
+      xv[u].y += alpha * pv[u].y;
+      vstore<NT>(x, i, xv[u]);
+      pv[u].x = beta * pv[u].x;
+      pv[u].y = beta * pv[u].y;
+      pv[u].x += rv[u].x;
+      pv[u].y += rv[u].y;
+      vstore<NT>(p, i, pv[u]);
+    }
+  }
 }
 
 __device__ __forceinline__ void clear_partials_tail(double* partials, int len)
@@ -67,23 +259,14 @@ __global__ __launch_bounds__(kBlock) void scatter_add_kernel(
     out[indices[i]] += in[i];
 }
 
+template <bool NT>
 __global__ __launch_bounds__(kBlock) void dot_partial_kernel(
     int64_t n, const double* __restrict__ x, const double* __restrict__ y,
     DotOut dot)
 {
   __shared__ double s_red[kBlock / 64];
   __shared__ int s_flag;
-  double acc = 0.0;
-  const int64_t n2 = n >> 1;
-  const double2* x2 = reinterpret_cast<const double2*>(x);
-  const double2* y2 = reinterpret_cast<const double2*>(y);
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2;
-       i += stride) {
-    double2 a = x2[i], b = y2[i];
-    acc += a.x * b.x;
-    acc += a.y * b.y;
-  }
+  double acc = stream_dot<NT>(n >> 1, x, y);
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
     acc += x[n - 1] * y[n - 1];
   spmv_dot_epilogue(dot, acc, s_red, &s_flag);
@@ -113,6 +296,7 @@ struct CgScalars {
 };
 
 // x += alpha p ; r += (-alpha) Ap ; partial r.r
+template <bool NT>
 __global__ __launch_bounds__(kBlock) void cg_update_xr_kernel(
     int64_t n, const double* __restrict__ rr_prev,
     const double* __restrict__ pAp, const CgScalars* __restrict__ sc,
@@ -126,25 +310,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_xr_kernel(
   const double rnorm_old = sqrt(*rr_prev);             // cg.cpp:50,76
   const double alpha = (rnorm_old * rnorm_old) / *pAp; // cg.cpp:66
   const double nalpha = -alpha;
-  double acc = 0.0;
-  const int64_t n2 = n >> 1;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const double2* p2 = reinterpret_cast<const double2*>(p);
-  const double2* Ap2 = reinterpret_cast<const double2*>(Ap);
-  double2* x2 = reinterpret_cast<double2*>(x);
-  double2* r2 = reinterpret_cast<double2*>(r);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2;
-       i += stride) {
-    double2 pv = p2[i], av = Ap2[i], xv = x2[i], rv = r2[i];
-    xv.x += alpha * pv.x; // cg.cpp:69
-    xv.y += alpha * pv.y;
-    rv.x += nalpha * av.x; // cg.cpp:70
-    rv.y += nalpha * av.y;
-    x2[i] = xv;
-    r2[i] = rv;
-    acc += rv.x * rv.x; // cg.cpp:73
-    acc += rv.y * rv.y;
-  }
+  double acc = stream_update_xr<NT>(n >> 1, alpha, nalpha, p, Ap, x, r);
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const int64_t i = n - 1;
     x[i] += alpha * p[i];
@@ -159,6 +325,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_xr_kernel(
 }
 
 // stopping test on rr[k], then p = beta p + r
+template <bool NT>
 __global__ __launch_bounds__(kBlock) void cg_update_p_kernel(
     int64_t n, int k, const double* __restrict__ rr0,
     const double* __restrict__ rr_prev, const double* __restrict__ rr_new,
@@ -173,19 +340,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_p_kernel(
   const double beta = (rnorm_new * rnorm_new) / (rnorm_old * rnorm_old); // :77
   if (rnorm_new / rnorm0 < sc->rtol)                                // :80
     return; // p is left untouched (:81); cg_reduce_pAp_kernel raises `done`
-  const int64_t n2 = n >> 1;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const double2* r2 = reinterpret_cast<const double2*>(r);
-  double2* p2 = reinterpret_cast<double2*>(p);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2;
-       i += stride) {
-    double2 pv = p2[i], rv = r2[i];
-    pv.x = beta * pv.x; // cg.cpp:84
-    pv.y = beta * pv.y;
-    pv.x += rv.x; // cg.cpp:85
-    pv.y += rv.y;
-    p2[i] = pv;
-  }
+  stream_update_p<NT>(n >> 1, beta, r, p);
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const int64_t i = n - 1;
     p[i] = beta * p[i] + r[i];
@@ -198,6 +353,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_p_kernel(
 // Element-wise arithmetic and its order per element are unchanged; only the
 // kernel an update lives in differs (8 instead of 9 vector passes).  x is
 // still updated in the iteration that converges and p is not (cg.cpp:80-81).
+template <bool NT>
 __global__ __launch_bounds__(kBlock) void cg_update_r_kernel(
     int64_t n, const double* __restrict__ rr_prev,
     const double* __restrict__ pAp, const CgScalars* __restrict__ sc,
@@ -210,20 +366,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_r_kernel(
   const double rnorm_old = sqrt(*rr_prev);
   const double alpha = (rnorm_old * rnorm_old) / *pAp; // cg.cpp:66
   const double nalpha = -alpha;
-  double acc = 0.0;
-  const int64_t n2 = n >> 1;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const double2* Ap2 = reinterpret_cast<const double2*>(Ap);
-  double2* r2 = reinterpret_cast<double2*>(r);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2;
-       i += stride) {
-    double2 av = Ap2[i], rv = r2[i];
-    rv.x += nalpha * av.x; // cg.cpp:70
-    rv.y += nalpha * av.y;
-    r2[i] = rv;
-    acc += rv.x * rv.x; // cg.cpp:73
-    acc += rv.y * rv.y;
-  }
+  double acc = stream_update_r<NT>(n >> 1, nalpha, Ap, r);
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const int64_t i = n - 1;
     double rv = r[i] + nalpha * Ap[i];
@@ -236,6 +379,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_r_kernel(
   clear_partials_tail(partials, len);
 }
 
+template <bool NT>
 __global__ __launch_bounds__(kBlock) void cg_update_xp_kernel(
     int64_t n, int k, const double* __restrict__ rr0,
     const double* __restrict__ rr_prev, const double* __restrict__ rr_new,
@@ -251,35 +395,13 @@ __global__ __launch_bounds__(kBlock) void cg_update_xp_kernel(
   const double alpha = (rnorm_old * rnorm_old) / *pAp;                   // :66
   const double beta = (rnorm_new * rnorm_new) / (rnorm_old * rnorm_old); // :77
   const bool converged = rnorm_new / rnorm0 < sc->rtol;                  // :80
-  const int64_t n2 = n >> 1;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const double2* r2 = reinterpret_cast<const double2*>(r);
-  double2* x2 = reinterpret_cast<double2*>(x);
-  double2* p2 = reinterpret_cast<double2*>(p);
   if (converged) { // x takes this iteration's update, p stays (:80-81)
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2;
-         i += stride) {
-      double2 pv = p2[i], xv = x2[i];
-      xv.x += alpha * pv.x; // cg.cpp:69
-      xv.y += alpha * pv.y;
-      x2[i] = xv;
-    }
+    stream_axpy<NT>(n >> 1, alpha, p, x);
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
       x[n - 1] += alpha * p[n - 1];
     return;
   }
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2;
-       i += stride) {
-    double2 pv = p2[i], xv = x2[i], rv = r2[i];
-    xv.x += alpha * pv.x; // cg.cpp:69
-    xv.y += alpha * pv.y;
-    x2[i] = xv;
-    pv.x = beta * pv.x; // cg.cpp:84
-    pv.y = beta * pv.y;
-    pv.x += rv.x; // cg.cpp:85
-    pv.y += rv.y;
-    p2[i] = pv;
-  }
+  stream_update_xp<NT>(n >> 1, alpha, beta, r, x, p);
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const int64_t i = n - 1;
     x[i] += alpha * p[i];
@@ -292,6 +414,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_xp_kernel(
 // `done` when rr[k-1] met the tolerance (what cg_reduce_pAp_kernel does in the
 // two-stage form).  Every workgroup evaluates the same scalars, so the early
 // return is uniform across the grid.
+template <bool NT>
 __global__ __launch_bounds__(kBlock) void cg_update_r_fused_kernel(
     int64_t n, int k, const double* __restrict__ rr, const double* __restrict__ pAp,
     CgScalars* __restrict__ sc, const double* __restrict__ Ap,
@@ -314,20 +437,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_r_fused_kernel(
   }
   const double alpha = (rnorm_old * rnorm_old) / pAp[k]; // cg.cpp:66
   const double nalpha = -alpha;
-  double acc = 0.0;
-  const int64_t n2 = n >> 1;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const double2* Ap2 = reinterpret_cast<const double2*>(Ap);
-  double2* r2 = reinterpret_cast<double2*>(r);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2;
-       i += stride) {
-    double2 av = Ap2[i], rv = r2[i];
-    rv.x += nalpha * av.x; // cg.cpp:70
-    rv.y += nalpha * av.y;
-    r2[i] = rv;
-    acc += rv.x * rv.x; // cg.cpp:73
-    acc += rv.y * rv.y;
-  }
+  double acc = stream_update_r<NT>(n >> 1, nalpha, Ap, r);
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const int64_t i = n - 1;
     double rv = r[i] + nalpha * Ap[i];
@@ -426,6 +536,18 @@ struct spmv_hip_cg_ws {
   unsigned int* counters = nullptr; // arrival tickets of the fused reductions
 };
 
+// Vectors of at least ctx->blas1_nt_min_elems doubles stream past the caches
+// (non-temporal loads and stores); shorter ones stay cached between kernels.
+#define SPMV_LAUNCH_NT(ctx, n, kernel, grid, st, ...)                          \
+  do {                                                                         \
+    if ((int64_t)(n) >= (ctx)->blas1_nt_min_elems)                             \
+      hipLaunchKernelGGL(kernel<true>, dim3(grid), dim3(kBlock), 0, st,        \
+                         __VA_ARGS__);                                         \
+    else                                                                       \
+      hipLaunchKernelGGL(kernel<false>, dim3(grid), dim3(kBlock), 0, st,       \
+                         __VA_ARGS__);                                         \
+  } while (0)
+
 extern "C" {
 
 int spmv_hip_gather_f64(spmv_hip_ctx* ctx, int num_indices,
@@ -505,12 +627,11 @@ int spmv_hip_dot_partial_f64(spmv_hip_ctx* ctx, int64_t n, const double* x,
   SPMV_SET_DEVICE(ctx);
   SPMV_REQUIRE(n >= 0 && partials && (n == 0 || (x && y)));
   SPMV_REQUIRE(aligned16(x) && aligned16(y));
-  const int grid = spmv_grid_for(ctx, n / 2, kBlock);
+  const int grid = spmv_grid_for(ctx, n / 2, (int)kUnit);
   DotOut dot;
   dot.partials = partials;
   dot.len = ctx->dot_blocks;
-  hipLaunchKernelGGL(dot_partial_kernel, dim3(grid), dim3(kBlock), 0,
-                     spmv_stream(ctx, stream), n, x, y, dot);
+  SPMV_LAUNCH_NT(ctx, n, dot_partial_kernel, grid, spmv_stream(ctx, stream), n, x, y, dot);
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;
 }
@@ -680,9 +801,8 @@ int spmv_hip_cg_update_xr_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
   SPMV_REQUIRE(ws && ws->ctx == ctx && k >= 1 && k <= ws->kmax && n >= 0);
   SPMV_REQUIRE(n == 0 || (p && Ap && x && r));
   SPMV_REQUIRE(aligned16(p) && aligned16(Ap) && aligned16(x) && aligned16(r));
-  const int grid = spmv_grid_for(ctx, n / 2, kBlock);
-  hipLaunchKernelGGL(cg_update_xr_kernel, dim3(grid), dim3(kBlock), 0,
-                     spmv_stream(ctx, stream), n, ws->rr + (k - 1),
+  const int grid = spmv_grid_for(ctx, n / 2, (int)kUnit);
+  SPMV_LAUNCH_NT(ctx, n, cg_update_xr_kernel, grid, spmv_stream(ctx, stream), n, ws->rr + (k - 1),
                      ws->pAp + k, ws->sc, p, Ap, x, r, ws->partials,
                      ctx->dot_blocks);
   SPMV_CHECK_LAUNCH();
@@ -698,8 +818,8 @@ int spmv_hip_cg_update_p_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
   SPMV_REQUIRE(n == 0 || (r && p));
   SPMV_REQUIRE(aligned16(r) && aligned16(p));
   hipStream_t st = spmv_stream(ctx, stream);
-  const int grid = spmv_grid_for(ctx, n / 2, kBlock);
-  hipLaunchKernelGGL(cg_update_p_kernel, dim3(grid), dim3(kBlock), 0, st, n, k,
+  const int grid = spmv_grid_for(ctx, n / 2, (int)kUnit);
+  SPMV_LAUNCH_NT(ctx, n, cg_update_p_kernel, grid, st, n, k,
                      ws->rr, ws->rr + (k - 1), ws->rr + k, ws->sc, r, p);
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;
@@ -713,9 +833,8 @@ int spmv_hip_cg_update_r_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
   SPMV_REQUIRE(ws && ws->ctx == ctx && k >= 1 && k <= ws->kmax && n >= 0);
   SPMV_REQUIRE(n == 0 || (Ap && r));
   SPMV_REQUIRE(aligned16(Ap) && aligned16(r));
-  const int grid = spmv_grid_for(ctx, n / 2, kBlock);
-  hipLaunchKernelGGL(cg_update_r_kernel, dim3(grid), dim3(kBlock), 0,
-                     spmv_stream(ctx, stream), n, ws->rr + (k - 1), ws->pAp + k,
+  const int grid = spmv_grid_for(ctx, n / 2, (int)kUnit);
+  SPMV_LAUNCH_NT(ctx, n, cg_update_r_kernel, grid, spmv_stream(ctx, stream), n, ws->rr + (k - 1), ws->pAp + k,
                      ws->sc, Ap, r, ws->partials, ctx->dot_blocks);
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;
@@ -729,9 +848,8 @@ int spmv_hip_cg_update_xp_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
   SPMV_REQUIRE(ws && ws->ctx == ctx && k >= 1 && k <= ws->kmax && n >= 0);
   SPMV_REQUIRE(n == 0 || (r && x && p));
   SPMV_REQUIRE(aligned16(r) && aligned16(x) && aligned16(p));
-  const int grid = spmv_grid_for(ctx, n / 2, kBlock);
-  hipLaunchKernelGGL(cg_update_xp_kernel, dim3(grid), dim3(kBlock), 0,
-                     spmv_stream(ctx, stream), n, k, ws->rr, ws->rr + (k - 1),
+  const int grid = spmv_grid_for(ctx, n / 2, (int)kUnit);
+  SPMV_LAUNCH_NT(ctx, n, cg_update_xp_kernel, grid, spmv_stream(ctx, stream), n, k, ws->rr, ws->rr + (k - 1),
                      ws->rr + k, ws->pAp + k, ws->sc, r, x, p);
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;
@@ -744,14 +862,13 @@ int spmv_hip_dot_f64(spmv_hip_ctx* ctx, int64_t n, const double* x,
   SPMV_SET_DEVICE(ctx);
   SPMV_REQUIRE(n >= 0 && partials && result && counter && (n == 0 || (x && y)));
   SPMV_REQUIRE(aligned16(x) && aligned16(y));
-  const int grid = spmv_grid_for(ctx, n / 2, kBlock);
+  const int grid = spmv_grid_for(ctx, n / 2, (int)kUnit);
   DotOut dot;
   dot.partials = partials;
   dot.len = ctx->dot_blocks;
   dot.result = result;
   dot.counter = counter;
-  hipLaunchKernelGGL(dot_partial_kernel, dim3(grid), dim3(kBlock), 0,
-                     spmv_stream(ctx, stream), n, x, y, dot);
+  SPMV_LAUNCH_NT(ctx, n, dot_partial_kernel, grid, spmv_stream(ctx, stream), n, x, y, dot);
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;
 }
@@ -788,14 +905,13 @@ int spmv_hip_cg_update_r_fused_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
   SPMV_REQUIRE(ws && ws->ctx == ctx && k >= 1 && k <= ws->kmax && n >= 0);
   SPMV_REQUIRE(n == 0 || (Ap && r));
   SPMV_REQUIRE(aligned16(Ap) && aligned16(r));
-  const int grid = spmv_grid_for(ctx, n / 2, kBlock);
+  const int grid = spmv_grid_for(ctx, n / 2, (int)kUnit);
   DotOut dot;
   dot.partials = ws->partials;
   dot.len = ctx->dot_blocks;
   dot.result = ws->rr + k;
   dot.counter = ws->counters + (kDotShards + 1);
-  hipLaunchKernelGGL(cg_update_r_fused_kernel, dim3(grid), dim3(kBlock), 0,
-                     spmv_stream(ctx, stream), n, k, ws->rr, ws->pAp, ws->sc, Ap,
+  SPMV_LAUNCH_NT(ctx, n, cg_update_r_fused_kernel, grid, spmv_stream(ctx, stream), n, k, ws->rr, ws->pAp, ws->sc, Ap,
                      r, dot);
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;

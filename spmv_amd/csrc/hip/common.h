@@ -13,6 +13,9 @@ struct spmv_hip_ctx {
   int num_cus = 0;
   hipStream_t stream = nullptr;  // current stream (set_stream), null = default
   int dot_blocks = 0;            // length of every dot-partials array
+  // BLAS-1 kernels read/write vectors of at least this many doubles
+  // non-temporally (spmv_hip_ctx_set_option "blas1_nt_min_elems")
+  int64_t blas1_nt_min_elems = (int64_t)1 << 24;
 };
 
 #define SPMV_CHECK_HIP(expr)                                                   \

@@ -77,6 +77,17 @@ int spmv_hip_num_cus(const spmv_hip_ctx* ctx, int* num_cus)
   return SPMV_HIP_OK;
 }
 
+int spmv_hip_ctx_set_option(spmv_hip_ctx* ctx, const char* key, int64_t value)
+{
+  SPMV_REQUIRE(ctx && key);
+  if (!strcmp(key, "blas1_nt_min_elems")) {
+    SPMV_REQUIRE(value >= 0);
+    ctx->blas1_nt_min_elems = value;
+    return SPMV_HIP_OK;
+  }
+  return SPMV_HIP_EINVAL;
+}
+
 int spmv_hip_synchronize(spmv_hip_ctx* ctx)
 {
   SPMV_SET_DEVICE(ctx);

@@ -34,8 +34,11 @@
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include <cstring>
+#include <map>
 #include <new>
+#include <vector>
 
 namespace
 {
@@ -74,6 +77,50 @@ __device__ __forceinline__ P stream_load(const P* p)
 }
 
 // ---------------------------------------------------------------------------
+// Row-block traversal order.  A persistent grid walks "slots" it = blockIdx.x,
+// blockIdx.x + gridDim.x, ...; this maps a slot to the row block it computes.
+// Placement only changes speed, never the result.
+//   table      plan-time order table (band sweep, see build_band_order);
+//              -1 marks an empty slot.  Slots it with equal it % 8 run on the
+//              same XCD, because workgroups are dealt round-robin over the XCDs.
+//   xcd_group  no table: inside each run of 8G row blocks XCD k owns G
+//              consecutive ones:  (it / 8G) * 8G + (it % 8) * G + (it / 8) % G
+//   otherwise  identity
+// ---------------------------------------------------------------------------
+struct RowBlockOrder {
+  const int32_t* table;
+  int num_slots; // table length
+  int xcd_group;
+  int num_row_blocks;
+  int nt_store; // write y non-temporally (plain row-block kernel)
+};
+
+__device__ __forceinline__ int order_slots(const RowBlockOrder& o)
+{
+  if (o.table)
+    return o.num_slots;
+  if (o.xcd_group > 0) {
+    const int super = 8 * o.xcd_group;
+    return ((o.num_row_blocks + super - 1) / super) * super;
+  }
+  return o.num_row_blocks;
+}
+
+// row block of slot `it`, or -1 for an empty slot (uniform per workgroup)
+__device__ __forceinline__ int order_row_block(const RowBlockOrder& o, int it)
+{
+  int rb = it;
+  if (o.table) {
+    rb = o.table[it];
+  } else if (o.xcd_group > 0) {
+    const int super = 8 * o.xcd_group;
+    const int q = it % super;
+    rb = (it - q) + (q & 7) * o.xcd_group + (q >> 3);
+  }
+  return rb < o.num_row_blocks ? rb : -1;
+}
+
+// ---------------------------------------------------------------------------
 // ROWBLOCK general kernel
 //   CH      = 16-byte value loads per lane per tile (tile = 256*CH*V entries)
 //   NT      = non-temporal loads for the read-once matrix stream
@@ -85,7 +132,7 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_kernel(
     int32_t num_rows, int64_t nnz, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ colind, const T* __restrict__ values, T alpha,
     const T* __restrict__ in, T beta, T* __restrict__ out,
-    DotOut dot, int num_row_blocks, int xcd_group)
+    DotOut dot, RowBlockOrder ord)
 {
   constexpr int V = VecOf<T>::V;
   constexpr int TILE = kBlock * CH * V;
@@ -100,27 +147,12 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_kernel(
   const int t = threadIdx.x;
   double dot_acc = 0.0;
 
-  // XCD grouping.  Workgroups are dealt round-robin over the 8 XCDs (blocks
-  // b and b+8 share an XCD and its private L2), so in plain order every XCD
-  // touches every x window and pulls it through its own L2.  With a group
-  // size G the slot `it` is sent to row block
-  //     (it / 8G) * 8G + (it % 8) * G + (it / 8) % G,
-  // i.e. inside each run of 8G row blocks XCD k owns G consecutive ones: the
-  // +-1 / +-n neighbours of a row are then served by the same L2, while all
-  // XCDs still advance through the matrix together (the far +-n^2 planes stay
-  // resident in the Infinity Cache).  A bijection of [0, slots); placement
-  // only changes speed, never the result.
-  const int super = 8 * xcd_group;
-  const int num_slots
-      = XCD ? ((num_row_blocks + super - 1) / super) * super : num_row_blocks;
+  // XCD = false: plain order (small problems, tests)
+  const int num_slots = XCD ? order_slots(ord) : ord.num_row_blocks;
   for (int it = blockIdx.x; it < num_slots; it += gridDim.x) {
-    int rb = it;
-    if constexpr (XCD) {
-      const int q = it % super;
-      rb = (it - q) + (q & 7) * xcd_group + (q >> 3);
-      if (rb >= num_row_blocks)
-        continue; // uniform per workgroup
-    }
+    const int rb = XCD ? order_row_block(ord, it) : it;
+    if (rb < 0)
+      continue; // uniform per workgroup
     const int32_t r0 = rb * kRows;
     const int nr = min(kRows, num_rows - r0);
 
@@ -214,7 +246,10 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_kernel(
       T y = c;
       if (beta != T(0))
         y = c + beta * out[r];
-      out[r] = y;
+      if (ord.nt_store) // y is not read again before it leaves the caches
+        __builtin_nontemporal_store(y, &out[r]);
+      else
+        out[r] = y;
       if constexpr (DOT) // this block's own share: in . (alpha A in)
         dot_acc += (double)in[r] * (double)c;
     }
@@ -243,7 +278,7 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_pipe_kernel(
     int32_t num_rows, int64_t nnz, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ colind, const T* __restrict__ values, T alpha,
     const T* __restrict__ in, T beta, T* __restrict__ out, DotOut dot,
-    int num_row_blocks, int xcd_group)
+    RowBlockOrder ord)
 {
   constexpr int V = VecOf<T>::V;
   constexpr int TILE = kBlock * V;
@@ -257,16 +292,12 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_pipe_kernel(
 
   const int t = threadIdx.x;
   double dot_acc = 0.0;
-  const int grp = xcd_group > 0 ? xcd_group : 1;
-  const int super = 8 * grp;
-  const int num_slots = xcd_group > 0
-                            ? ((num_row_blocks + super - 1) / super) * super
-                            : num_row_blocks;
+  const int num_row_blocks = ord.num_row_blocks;
+  const int num_slots = order_slots(ord);
+  // empty slots map past the end so the skip loops below step over them
   auto slot_to_rb = [&](int it) {
-    if (xcd_group <= 0)
-      return it;
-    const int q = it % super;
-    return (it - q) + (q & 7) * grp + (q >> 3);
+    const int rb = order_row_block(ord, it);
+    return rb < 0 ? num_row_blocks : rb;
   };
   // first valid slot of this workgroup and its row pointer
   int it = blockIdx.x;
@@ -411,7 +442,7 @@ __global__ __launch_bounds__(kBlock) void csr_rowwave_kernel(
     int32_t num_rows, int64_t nnz, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ colind, const T* __restrict__ values, T alpha,
     const T* __restrict__ in, T beta, T* __restrict__ out,
-    DotOut dot, int num_row_blocks, int xcd_group)
+    DotOut dot, RowBlockOrder ord)
 {
   constexpr int V = VecOf<T>::V;
   constexpr int W = 64;               // lanes = rows per wave
@@ -431,16 +462,12 @@ __global__ __launch_bounds__(kBlock) void csr_rowwave_kernel(
   int32_t* s_rowptr = s_rowptr_all[wave];
   double dot_acc = 0.0;
 
-  const int super = 8 * (xcd_group > 0 ? xcd_group : 1);
-  const int num_slots = xcd_group > 0
-                            ? ((num_row_blocks + super - 1) / super) * super
-                            : num_row_blocks;
+  const int num_row_blocks = ord.num_row_blocks;
+  const int num_slots = order_slots(ord);
   for (int it = blockIdx.x; it < num_slots; it += gridDim.x) {
-    int rb = it;
-    if (xcd_group > 0) {
-      const int q = it % super;
-      rb = (it - q) + (q & 7) * xcd_group + (q >> 3);
-    }
+    int rb = order_row_block(ord, it);
+    if (rb < 0)
+      rb = num_row_blocks;
     const int64_t r0 = (int64_t)rb * kRows + wave * W;
     if (rb >= num_row_blocks || r0 >= num_rows)
       continue; // per wave; no workgroup barrier inside this loop
@@ -967,6 +994,24 @@ struct spmv_hip_csr_plan {
   int sym_rows = 1024;    // symmetric: rows per workgroup (512, 1024, 2048)
   int32_t* row_list = nullptr; // ROWLIST: device list of non-empty rows
   int32_t num_listed = 0;
+  // ROWBLOCK: band-sweep order table for lattice-structured matrices whose far
+  // planes do not fit the L2s (build_band_order); band_order = 0 ignores it
+  int32_t* order = nullptr;
+  int order_slots = 0;
+  int band_order = 0;
+  int nt_store = 0; // non-temporal y stores
+  int lattice_d1 = 0, lattice_d2 = 0, band_lines = 0; // what was detected
+
+  RowBlockOrder row_block_order(int nrb) const
+  {
+    RowBlockOrder o;
+    o.table = band_order ? order : nullptr;
+    o.num_slots = order_slots;
+    o.xcd_group = xcd_group;
+    o.num_row_blocks = nrb;
+    o.nt_store = nt_store;
+    return o;
+  }
 };
 
 namespace
@@ -978,16 +1023,15 @@ int launch_rowblock_x(const spmv_hip_csr_plan* pl, hipStream_t st, int grid,
                       const T* values, T alpha, const T* in, T beta, T* out,
                       DotOut dot)
 {
-  if (pl->xcd_group > 0)
+  const RowBlockOrder ord = pl->row_block_order(nrb);
+  if (ord.table || ord.xcd_group > 0)
     hipLaunchKernelGGL((csr_rowblock_kernel<T, CH, NT, ALIGNED, DOT, true>),
                        dim3(grid), dim3(kBlock), 0, st, pl->num_rows, pl->nnz,
-                       rowptr, colind, values, alpha, in, beta, out, dot, nrb,
-                       pl->xcd_group);
+                       rowptr, colind, values, alpha, in, beta, out, dot, ord);
   else
     hipLaunchKernelGGL((csr_rowblock_kernel<T, CH, NT, ALIGNED, DOT, false>),
                        dim3(grid), dim3(kBlock), 0, st, pl->num_rows, pl->nnz,
-                       rowptr, colind, values, alpha, in, beta, out, dot, nrb,
-                       1);
+                       rowptr, colind, values, alpha, in, beta, out, dot, ord);
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;
 }
@@ -1006,18 +1050,21 @@ int launch_rowblock(const spmv_hip_csr_plan* pl, hipStream_t st,
     grid = nrb;
   if (grid < 1)
     grid = 1;
+  // slots it with equal it % 8 must stay on one XCD (order table, XCD groups)
+  if (grid >= 8)
+    grid -= grid % 8;
   const bool al = aligned16(values) && aligned16(colind);
   if (pl->pipeline && al) {
     if (pl->nontemporal)
       hipLaunchKernelGGL((csr_rowblock_pipe_kernel<T, true, DOT>), dim3(grid),
                          dim3(kBlock), 0, st, pl->num_rows, pl->nnz, rowptr,
-                         colind, values, alpha, in, beta, out, dot, nrb,
-                         pl->xcd_group);
+                         colind, values, alpha, in, beta, out, dot,
+                         pl->row_block_order(nrb));
     else
       hipLaunchKernelGGL((csr_rowblock_pipe_kernel<T, false, DOT>), dim3(grid),
                          dim3(kBlock), 0, st, pl->num_rows, pl->nnz, rowptr,
-                         colind, values, alpha, in, beta, out, dot, nrb,
-                         pl->xcd_group);
+                         colind, values, alpha, in, beta, out, dot,
+                         pl->row_block_order(nrb));
     SPMV_CHECK_LAUNCH();
     return SPMV_HIP_OK;
   }
@@ -1025,8 +1072,8 @@ int launch_rowblock(const spmv_hip_csr_plan* pl, hipStream_t st,
 #define SPMV_RW(CH, NT)                                                        \
   hipLaunchKernelGGL((csr_rowwave_kernel<T, CH, NT, DOT>), dim3(grid),         \
                      dim3(kBlock), 0, st, pl->num_rows, pl->nnz, rowptr,       \
-                     colind, values, alpha, in, beta, out, dot, nrb,           \
-                     pl->xcd_group)
+                     colind, values, alpha, in, beta, out, dot,                \
+                     pl->row_block_order(nrb))
     if (pl->nontemporal) {
       if (pl->chunks == 1)
         SPMV_RW(1, true);
@@ -1280,6 +1327,138 @@ int build_row_list(spmv_hip_csr_plan* pl, const int32_t* rowptr)
   return SPMV_HIP_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Band-sweep order for lattice-structured matrices (plan time, host side).
+//
+// Rows of a 3-D stencil in natural ordering couple to rows +-1, +-D1 (next
+// grid line) and +-D2 (next grid plane).  In row order the three uses of an x
+// plane by the planes z-1, z, z+1 lie D2 rows apart; once D2 rows of matrix
+// stream exceed what the L2s hold, every XCD pulls every x plane through its
+// L2 three to four times, and that refetch traffic -- not HBM -- caps the
+// kernel (measured with tools/membench/spmv_probe: 4.8 -> 5.6 TB/s on the
+// gather stage at 512^3).  The order built here cuts the grid's y axis into
+// bands of `yc` lines, gives each XCD its own bands and lets it sweep a band
+// through all planes: the lines z-1, z, z+1 of a band stay in that XCD's L2
+// and every x value is fetched about once.
+//
+// Nothing here depends on the matrix being exactly a stencil: D1 and D2 only
+// choose a permutation of the row blocks, so a wrong guess costs speed, never
+// correctness.
+// ---------------------------------------------------------------------------
+
+// Column offsets that at least half of `rows` sampled rows share.
+int detect_lattice(spmv_hip_csr_plan* pl, const int32_t* rowptr,
+                   const int32_t* colind)
+{
+  pl->lattice_d1 = pl->lattice_d2 = 0;
+  constexpr int kSample = 64;
+  if (pl->num_rows < 8 * kSample || pl->nnz == 0)
+    return SPMV_HIP_OK;
+  SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
+  SPMV_CHECK_HIP(hipDeviceSynchronize()); // the arrays may still be in flight
+  const int32_t r_first = pl->num_rows / 2;
+  int32_t rp[kSample + 1];
+  SPMV_CHECK_HIP(hipMemcpy(rp, rowptr + r_first, sizeof(rp),
+                           hipMemcpyDeviceToHost));
+  const int64_t count = (int64_t)rp[kSample] - rp[0];
+  if (count <= 0 || count > 64 * 1024) // long rows: not a stencil
+    return SPMV_HIP_OK;
+  std::vector<int32_t> cols((size_t)count);
+  SPMV_CHECK_HIP(hipMemcpy(cols.data(), colind + rp[0],
+                           sizeof(int32_t) * (size_t)count,
+                           hipMemcpyDeviceToHost));
+  std::map<int64_t, int> rows_with; // |offset| -> sampled rows containing it
+  for (int i = 0; i < kSample; ++i) {
+    std::vector<int64_t> seen;
+    for (int32_t j = rp[i]; j < rp[i + 1]; ++j) {
+      int64_t d = (int64_t)cols[(size_t)(j - rp[0])] - (r_first + i);
+      d = d < 0 ? -d : d;
+      if (d > 0 && std::find(seen.begin(), seen.end(), d) == seen.end())
+        seen.push_back(d);
+    }
+    for (int64_t d : seen)
+      ++rows_with[d];
+  }
+  int64_t d1 = 0, d2 = 0;
+  for (const auto& kv : rows_with) { // ascending |offset|
+    if (kv.second * 2 < kSample)
+      continue;
+    if (d1 == 0) {
+      if (kv.first >= 8)
+        d1 = kv.first;
+    } else if (kv.first >= 8 * d1 && kv.first % d1 == 0) {
+      d2 = kv.first;
+      break;
+    }
+  }
+  if (d1 > 0 && d2 > 0 && d2 < INT32_MAX) {
+    pl->lattice_d1 = (int)d1;
+    pl->lattice_d2 = (int)d2;
+  }
+  return SPMV_HIP_OK;
+}
+
+// (Re)build the order table for bands of `yc` lines (0 = choose).  Needs a
+// detected lattice.
+int build_band_order(spmv_hip_csr_plan* pl, int yc)
+{
+  SPMV_REQUIRE(pl->lattice_d1 > 0 && pl->lattice_d2 > 0);
+  SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
+  const int64_t d1 = pl->lattice_d1, d2 = pl->lattice_d2;
+  const int64_t ny = d2 / d1;
+  const int64_t nz = (pl->num_rows + d2 - 1) / d2;
+  const int nrb = (pl->num_rows + kRows - 1) / kRows;
+  if (yc <= 0) {
+    // lines z-1 .. z+2 of a band (the resident workgroups span about two
+    // sweep steps) should take well under half of one 4 MiB L2
+    int64_t ymax = ((int64_t)3 << 19) / (32 * d1) - 2;
+    ymax = ymax < 8 ? 8 : ymax;
+    int64_t nb = (ny + ymax - 1) / ymax;
+    nb = (nb + 7) / 8 * 8; // every XCD gets the same number of bands
+    yc = (int)((ny + nb - 1) / nb);
+  }
+  yc = yc < 1 ? 1 : yc;
+  // key = (band, plane, line); row blocks keep their order inside a line
+  std::vector<std::pair<int64_t, int32_t>> keyed((size_t)nrb);
+  for (int k = 0; k < nrb; ++k) {
+    const int64_t line = ((int64_t)k * kRows) / d1;
+    const int64_t y = line % ny, z = line / ny;
+    const int64_t band = y / yc;
+    keyed[(size_t)k] = {((band * nz + z) * ny + y), k};
+  }
+  std::stable_sort(keyed.begin(), keyed.end());
+  std::vector<std::vector<int32_t>> lists(8);
+  for (const auto& kv : keyed) {
+    const int64_t band = kv.first / (nz * ny);
+    lists[(size_t)(band % 8)].push_back(kv.second);
+  }
+  size_t longest = 0;
+  for (const auto& l : lists)
+    longest = std::max(longest, l.size());
+  std::vector<int32_t> table(8 * longest, -1);
+  for (size_t x = 0; x < 8; ++x)
+    for (size_t i = 0; i < lists[x].size(); ++i)
+      table[8 * i + x] = lists[x][i];
+  if (pl->order) {
+    SPMV_CHECK_HIP(hipDeviceSynchronize()); // no launch still reads the old one
+    (void)hipFree(pl->order);
+    pl->order = nullptr;
+    pl->order_slots = 0;
+  }
+  SPMV_CHECK_HIP(hipMalloc(&pl->order, sizeof(int32_t) * table.size()));
+  hipError_t e = hipMemcpy(pl->order, table.data(),
+                           sizeof(int32_t) * table.size(),
+                           hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(pl->order);
+    pl->order = nullptr;
+    return static_cast<int>(e);
+  }
+  pl->order_slots = (int)table.size();
+  pl->band_lines = yc;
+  return SPMV_HIP_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -1333,15 +1512,27 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
   // that x stays resident; measured +5 % when x fits the 256 MiB Infinity
   // Cache with room to spare (216^3) and -3 % when it does not (512^3).
   pl->nontemporal = ((int64_t)num_cols * 8 <= (int64_t)128 << 20) ? 1 : 0;
+  if (!symmetric && algo == SPMV_HIP_ALGO_ROWBLOCK) {
+    // Only the detection runs here.  The band-sweep order itself is opt-in
+    // (plan_set "band_lines"): on MI355X it lifted the gather stage of the
+    // probe kernel by 5-17 % at 512^3 but left the full kernel, whose row sums
+    // sit behind workgroup barriers, unchanged to 8 % slower.
+    int rc = detect_lattice(pl, rowptr, colind);
+    if (rc != SPMV_HIP_OK) {
+      spmv_hip_csr_plan_destroy(pl);
+      return rc;
+    }
+  }
   *plan = pl;
   return SPMV_HIP_OK;
 }
 
 int spmv_hip_csr_plan_destroy(spmv_hip_csr_plan* plan)
 {
-  if (plan && plan->row_list) {
+  if (plan && (plan->row_list || plan->order)) {
     (void)hipSetDevice(plan->ctx->device);
     (void)hipFree(plan->row_list);
+    (void)hipFree(plan->order);
   }
   delete plan;
   return SPMV_HIP_OK;
@@ -1388,9 +1579,46 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
   } else if (!strcmp(key, "blocks_per_cu")) {
     SPMV_REQUIRE(value >= 1 && value <= kBlocksPerCU);
     plan->blocks_per_cu = value;
+  } else if (!strcmp(key, "nt_store")) {
+    plan->nt_store = value != 0;
+  } else if (!strcmp(key, "band_order")) {
+    plan->band_order = value != 0; // 0: ignore the order table
+  } else if (!strcmp(key, "band_lines")) {
+    // (re)build the band-sweep table with bands of `value` grid lines
+    // (0 = automatic); EINVAL when no lattice was detected at plan creation
+    SPMV_REQUIRE(value >= 0);
+    const int rc = build_band_order(plan, value);
+    if (rc == SPMV_HIP_OK)
+      plan->band_order = 1;
+    return rc;
   } else {
     return SPMV_HIP_EINVAL;
   }
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
+                          int* value)
+{
+  SPMV_REQUIRE(plan && key && value);
+  if (!strcmp(key, "algo"))
+    *value = plan->algo;
+  else if (!strcmp(key, "lattice_d1"))
+    *value = plan->lattice_d1;
+  else if (!strcmp(key, "lattice_d2"))
+    *value = plan->lattice_d2;
+  else if (!strcmp(key, "band_lines"))
+    *value = plan->order ? plan->band_lines : 0;
+  else if (!strcmp(key, "order_slots"))
+    *value = plan->order ? plan->order_slots : 0;
+  else if (!strcmp(key, "band_order"))
+    *value = plan->band_order && plan->order ? 1 : 0;
+  else if (!strcmp(key, "blocks_per_cu"))
+    *value = plan->blocks_per_cu;
+  else if (!strcmp(key, "nontemporal"))
+    *value = plan->nontemporal;
+  else
+    return SPMV_HIP_EINVAL;
   return SPMV_HIP_OK;
 }
 

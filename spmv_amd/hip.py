@@ -104,6 +104,9 @@ class Context:
         call("spmv_hip_memset_async", self.h, ptr, value, nbytes, stream)
 
     # -- streams / events -------------------------------------------------
+    def set_option(self, key, value):
+        call("spmv_hip_ctx_set_option", self.h, key.encode(), int(value))
+
     def synchronize(self):
         call("spmv_hip_synchronize", self.h)
 
@@ -202,6 +205,11 @@ class CsrBlock:
 
     def set(self, key, value):
         call("spmv_hip_csr_plan_set", self.plan, key.encode(), int(value))
+
+    def get(self, key):
+        v = C.c_int()
+        call("spmv_hip_csr_plan_get", self.plan, key.encode(), C.byref(v))
+        return v.value
 
     @property
     def algo(self):

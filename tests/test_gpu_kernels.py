@@ -725,3 +725,58 @@ def test_fuzz_shapes_all_kernels(ctx):
                               None if beta == 0 else ys0, diagonal=dg,
                               symmetric=True, knobs=knobs)
                 assert np.all(np.abs(ys - ref) <= sb + 1e-300), (case, knobs)
+
+
+# ---------------------------------------------------------------------------
+# band-sweep row-block order (plan-time table for lattice-structured matrices)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [16, 20, 33])
+def test_band_order_is_a_permutation_of_the_work(ctx, n):
+    """Any band height gives the same bits as the plain order: the table only
+    permutes row blocks.  Small grids never build a table on their own, so it
+    is forced through the knob."""
+    rp, ci, va = poisson.poisson3d_csr(n)
+    ci = ci.astype(np.int32)
+    N = n ** 3
+    x = oracle.gaussian_x_fast(N)
+    y_ref = oracle.csr_spmv(rp, ci, va, x, 0.5, 0.0)
+    blk = hip.CsrBlock(ctx, N, N, rp, ci, va, None, False, hip.ALGO_ROWBLOCK)
+    assert blk.get("lattice_d1") == n and blk.get("lattice_d2") == n * n
+    assert blk.get("order_slots") == 0  # too small to need it
+    dx = ctx.upload(x)
+    for yc in (0, 1, 3, 8, n, 5 * n):
+        blk.set("band_lines", yc)
+        nrb = (N + 255) // 256
+        assert blk.get("order_slots") >= nrb and blk.get("order_slots") % 8 == 0
+        if yc:
+            assert blk.get("band_lines") == yc
+        for knobs in (dict(), dict(pipeline=1), dict(wave_private=1),
+                      dict(blocks_per_cu=1), dict(nontemporal=0, chunks=4)):
+            for k, v in {**dict(pipeline=0, wave_private=0, blocks_per_cu=7,
+                                nontemporal=1, chunks=1), **knobs}.items():
+                blk.set(k, v)
+            dy = ctx.upload(np.full(N, np.nan))
+            blk.mult(0.5, dx.ptr, 0.0, dy.ptr)
+            assert np.array_equal(dy.numpy(), y_ref), (yc, knobs)
+            dy.free()
+        blk.set("band_order", 0)
+        assert blk.get("band_order") == 0
+        blk.set("band_order", 1)
+    dx.free()
+    blk.free()
+
+
+def test_no_lattice_no_band_order(ctx):
+    rng = np.random.default_rng(8)
+    rp, ci, va = random_csr(rng, 5000, 5000, 6)
+    blk = hip.CsrBlock(ctx, 5000, 5000, rp, ci, va, None, False, hip.ALGO_ROWBLOCK)
+    assert blk.get("lattice_d1") == 0 and blk.get("order_slots") == 0
+    with pytest.raises(Exception):
+        blk.set("band_lines", 4)
+    blk.free()
+    # the 1-D operator has one off-diagonal distance only: no planes, no table
+    rp, ci, va = oracle.tridiag_csr(100000)
+    blk = hip.CsrBlock(ctx, 100000, 100000, rp, ci, va, None, False,
+                       hip.ALGO_ROWBLOCK)
+    assert blk.get("lattice_d2") == 0 and blk.get("order_slots") == 0
+    blk.free()

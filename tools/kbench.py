@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--fp32", action="store_true",
                     help="also time the fp32 instantiation (host-built matrix)")
     ap.add_argument("--only", default=None, help="comma list of variants")
+    ap.add_argument("--band-lines", type=int, nargs="*", default=[],
+                    help="extra band heights of the band-sweep order to time")
     args = ap.parse_args()
     ctx = hip.Context(0)
     results = []
@@ -71,11 +73,28 @@ def main():
         src.free(), dst.free()
 
         variants = []
-        for pipe, nt, bpc in itertools.product([0, 1], [0, 1], [8, 7, 5]):
+        if blk.get("lattice_d2") > 0 and args.band_lines:
+            blk.set("band_lines", 0)  # build the (opt-in) band-sweep table
+        has_band = blk.get("order_slots") > 0
+        print(json.dumps(dict(n=n, lattice=(blk.get("lattice_d1"),
+                                            blk.get("lattice_d2")),
+                              band_lines=blk.get("band_lines"))), flush=True)
+        for band, pipe, wavep, nt, bpc in itertools.product(
+                [1, 0] if has_band else [0], [0, 1], [0, 1], [0, 1], [8, 7]):
+            if pipe and wavep:
+                continue
             variants.append(("rowblock", dict(algo=hip.ALGO_ROWBLOCK, chunks=1,
                                               nontemporal=nt, xcd_group=16,
-                                              pipeline=pipe,
+                                              band_order=band, pipeline=pipe,
+                                              wave_private=wavep,
                                               blocks_per_cu=bpc)))
+        if has_band and args.band_lines:
+            for yc in args.band_lines:
+                variants.append(("rowblock", dict(band_lines=yc, band_order=1,
+                                                  pipeline=0, wave_private=0,
+                                                  nontemporal=1,
+                                                  blocks_per_cu=8)))
+            variants.append(("rowblock", dict(band_lines=0)))
         variants.append(("scalar", dict(algo=hip.ALGO_SCALAR)))
         for lpr in (4, 8):
             variants.append(("vector", dict(algo=hip.ALGO_VECTOR,
@@ -91,7 +110,7 @@ def main():
         # fused dot on the default variant
         for pipe in (0, 1):
             for k, v in dict(algo=hip.ALGO_ROWBLOCK, chunks=1, nontemporal=0,
-                             xcd_group=16, blocks_per_cu=7,
+                             xcd_group=16, blocks_per_cu=7, wave_private=0,
                              pipeline=pipe).items():
                 blk.set(k, v)
             tmin, tmed = time_ms(

@@ -1,0 +1,61 @@
+"""Ad-hoc knob sweep of the general row-block SpMV on the device-generated
+Poisson matrix: every combination of the given knob values, interleaved.
+
+    python tools/ksweep.py --n 512 --reps 8 --knob band_order=0,1 --knob chunks=1,2,4
+"""
+import argparse
+import itertools
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from spmv_amd import hip, poisson  # noqa: E402
+from kbench import time_ms  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=512)
+    ap.add_argument("--reps", type=int, default=8)
+    ap.add_argument("--knob", action="append", default=[],
+                    help="name=v1,v2,... (applied in the order given)")
+    ap.add_argument("--dot", action="store_true", help="fused p.Ap partials")
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    ctx = hip.Context(0)
+    n, N = args.n, args.n ** 3
+    blk = hip.poisson3d_block(ctx, n, 0, N, hip.PART_ALL)
+    x, y = ctx.empty(N, np.float64), ctx.empty(N, np.float64)
+    ctx.fill_gaussian(N, 0, N, x.ptr)
+    part = ctx.empty(ctx.dot_partials_len, np.float64)
+    nbytes = poisson.csr_bytes(N, N, blk.nnz)
+    names = [k.split("=")[0] for k in args.knob]
+    values = [[int(v) for v in k.split("=")[1].split(",")] for k in args.knob]
+    rows = []
+    for combo in itertools.product(*values):
+        try:
+            for k, v in zip(names, combo):
+                blk.set(k, v)
+        except Exception as e:  # an invalid combination: report and go on
+            print(json.dumps(dict(knobs=dict(zip(names, combo)), error=str(e))))
+            continue
+        fn = (lambda: blk.mult(1.0, x.ptr, 0.0, y.ptr, dot_partials=part.ptr)) \
+            if args.dot else (lambda: blk.mult(1.0, x.ptr, 0.0, y.ptr))
+        best, med = time_ms(ctx, fn, args.reps)
+        row = dict(n=n, knobs=dict(zip(names, combo)), ms=round(best, 4),
+                   ms_med=round(med, 4), gbs=round(nbytes / best / 1e6, 1))
+        rows.append(row)
+        print(json.dumps(row), flush=True)
+    rows.sort(key=lambda r: r["ms"])
+    print("best:", json.dumps(rows[:5]))
+    if args.out:
+        with open(args.out, "w") as f:
+            json.dump(rows, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
