@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--cpu-n", type=int, default=256,
                     help="grid of the bounded CPU sample")
     ap.add_argument("--cpu-iters", type=int, default=30)
+    ap.add_argument("--no-lx", action="store_true",
+                    help="do not build the LX form of the matrix (experiments)")
     ap.add_argument("--blas1-nt-min", type=int, default=None,
                     help="override the context option blas1_nt_min_elems "
                          "(experiments)")
@@ -197,6 +199,9 @@ def main():
 
     n = args.n
     N = n ** 3
+    if args.no_lx:
+        _lib.call("spmv_hip_ctx_set_option", exec_.context, b"lx_min_nnz",
+                  1 << 62)
     cm = getattr(host, args.cm.upper())
     A = host.Matrix.create_poisson3d(comm, exec_, n, args.symmetric, cm)
     l2g = A.col_map()

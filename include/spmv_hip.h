@@ -63,6 +63,10 @@ int spmv_hip_synchronize(spmv_hip_ctx* ctx); /* whole device */
  *   this many elements past the caches (non-temporal loads and stores);
  *   shorter vectors stay cached between kernels.  Default 2^24. */
 int spmv_hip_ctx_set_option(spmv_hip_ctx* ctx, const char* key, int64_t value);
+/*   "lx_min_nnz": csr_plan_create builds the LX form of a general matrix
+ *   (LDS-staged x windows + 16-bit column offsets, 2 B per entry of extra
+ *   device memory) from this many entries on.  Default 2^20; a huge value
+ *   switches the form off. */
 
 /* ---- streams / events ---------------------------------------------------
  * CudaExecutor::set/reset/get_cuda_stream (cuda/cuda_executor.h:72-76). */

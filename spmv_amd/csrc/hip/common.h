@@ -16,6 +16,9 @@ struct spmv_hip_ctx {
   // BLAS-1 kernels read/write vectors of at least this many doubles
   // non-temporally (spmv_hip_ctx_set_option "blas1_nt_min_elems")
   int64_t blas1_nt_min_elems = (int64_t)1 << 24;
+  // plans build the LX form (LDS-staged x windows, 16-bit column offsets)
+  // for general matrices with at least this many entries ("lx_min_nnz")
+  int64_t lx_min_nnz = (int64_t)1 << 20;
 };
 
 #define SPMV_CHECK_HIP(expr)                                                   \

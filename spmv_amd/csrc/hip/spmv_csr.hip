@@ -260,6 +260,299 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// ROWBLOCK with LDS-staged x windows and 16-bit local column indices ("LX").
+//
+// The gather `in[colind[j]]` is what separates the row-block kernel from a
+// pure stream: per-lane 8-byte requests through the texture path, and the same
+// x lines pulled through the L2s several times (tools/membench/spmv_probe:
+// 6.3 TB/s without the gather, 5.4 with it).  For matrices whose row blocks
+// reference few contiguous column ranges -- stencils, banded and well-ordered
+// FEM matrices -- plan creation rewrites the column indices of every row block
+// as 16-bit offsets into a small set of column WINDOWS (lx_build_kernel).
+// The kernel then
+//   1. copies the windows of x into LDS with coalesced 16-byte loads,
+//   2. streams values (16 B) and local indices (2 B per entry instead of 4),
+//   3. takes x from LDS; products, row sums and y exactly as csr_rowblock_kernel
+//      (same products, same left-to-right order => bit-identical results).
+// Row blocks whose columns do not fit the LDS budget keep the global gather
+// (nwin < 0); the decision is per row block.
+//   lx.nwin[rb]            number of windows, or -1 = direct
+//   lx.wstart[rb*kLxMaxWin + k]   first column of window k (even)
+//   lx.woff  [rb*(kLxMaxWin+1) + k] offset of window k in the staged buffer
+//                                   (even; entry nwin = staged length)
+//   lx.lidx[j]             offset of column colind[j] in the staged buffer
+// ---------------------------------------------------------------------------
+constexpr int kLxMaxWin = 16;
+constexpr int kLxCap = 1792; // staged x elements per row block (14 KiB fp64)
+constexpr int kLxGap = 16;   // columns closer than this share a window
+
+struct LxView {
+  const uint16_t* lidx;
+  const int32_t* nwin;
+  const int32_t* wstart;
+  const int32_t* woff;
+};
+
+template <typename T, bool NT, bool DOT>
+__global__ __launch_bounds__(kBlock) void csr_rowblock_lx_kernel(
+    int32_t num_rows, int32_t num_cols, int64_t nnz,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
+    const T* __restrict__ values, LxView lx, T alpha, const T* __restrict__ in,
+    T beta, T* __restrict__ out, DotOut dot, RowBlockOrder ord)
+{
+  constexpr int V = VecOf<T>::V;
+  constexpr int TILE = kBlock * V;
+  using val_t = typename VecOf<T>::val_t;
+  using col_t = typename VecOf<T>::col_t;
+  typedef T pair_t __attribute__((ext_vector_type(2)));
+  typedef unsigned short lidx_t __attribute__((ext_vector_type(V)));
+
+  __shared__ __attribute__((aligned(16))) T s_x[kLxCap];
+  __shared__ __attribute__((aligned(16))) T s_prod[TILE];
+  __shared__ int32_t s_rowptr[kRows + 1];
+  __shared__ int32_t s_wstart[kLxMaxWin];
+  __shared__ int32_t s_woff[kLxMaxWin + 1];
+  __shared__ double s_red[kBlock / 64];
+  __shared__ int s_flag;
+
+  const int t = threadIdx.x;
+  double dot_acc = 0.0;
+  const int num_slots = order_slots(ord);
+  for (int it = blockIdx.x; it < num_slots; it += gridDim.x) {
+    const int rb = order_row_block(ord, it);
+    if (rb < 0)
+      continue; // uniform per workgroup
+    const int32_t r0 = rb * kRows;
+    const int nr = min(kRows, num_rows - r0);
+    const int K = lx.nwin[rb]; // uniform
+
+    __syncthreads(); // previous iteration done with every LDS array
+    if (t <= nr)
+      s_rowptr[t] = rowptr[r0 + t];
+    if (t == 0 && nr == kRows)
+      s_rowptr[kRows] = rowptr[r0 + kRows];
+    if (K > 0) {
+      if (t < K)
+        s_wstart[t] = lx.wstart[(int64_t)rb * kLxMaxWin + t];
+      if (t <= K)
+        s_woff[t] = lx.woff[(int64_t)rb * (kLxMaxWin + 1) + t];
+    }
+    __syncthreads();
+
+    const int32_t a = s_rowptr[0];
+    const int32_t b = s_rowptr[nr];
+    int32_t lo = 0, hi = 0;
+    if (t < nr) {
+      lo = s_rowptr[t];
+      hi = s_rowptr[t + 1];
+    }
+    // stage the x windows: pairs of elements, coalesced (in is 2-element
+    // aligned, checked at launch; window starts and offsets are even)
+    for (int k = 0; k < K; ++k) {
+      const int32_t ws = s_wstart[k], wo = s_woff[k];
+      const int32_t len = s_woff[k + 1] - wo;
+      for (int e = 2 * t; e < len; e += 2 * kBlock) {
+        const int32_t c = ws + e;
+        pair_t xv;
+        if (c + 1 < num_cols) {
+          xv = *reinterpret_cast<const pair_t*>(in + c);
+        } else { // the window was rounded up past the last column
+          xv[0] = c < num_cols ? in[c] : T(0);
+          xv[1] = T(0);
+        }
+        *reinterpret_cast<pair_t*>(&s_x[wo + e]) = xv;
+      }
+    }
+    T sum = 0;
+    const int64_t base0 = a & ~(V - 1);
+    const int64_t jclamp = (int64_t)(b - 1) & ~(int64_t)(V - 1);
+    bool staged_visible = K <= 0;
+    for (int64_t base = base0; base < b; base += TILE) {
+      if (base != base0)
+        __syncthreads(); // row owners finished reading the previous tile
+      const int64_t j0 = base + (int64_t)t * V;
+      val_t pv;
+      if (jclamp + V <= nnz) {
+        const int64_t jl = j0 < jclamp ? j0 : jclamp;
+        const val_t v
+            = stream_load<NT>(reinterpret_cast<const val_t*>(values + jl));
+        if (K >= 0) {
+          const lidx_t li
+              = stream_load<NT>(reinterpret_cast<const lidx_t*>(lx.lidx + jl));
+          if (!staged_visible) {
+            __syncthreads(); // s_x complete (matrix loads already in flight)
+            staged_visible = true;
+          }
+#pragma unroll
+          for (int e = 0; e < V; ++e)
+            pv[e] = (j0 + e < b) ? v[e] * s_x[li[e]] : T(0);
+        } else {
+          const col_t ci
+              = stream_load<NT>(reinterpret_cast<const col_t*>(colind + jl));
+          T xg[V];
+#pragma unroll
+          for (int e = 0; e < V; ++e)
+            xg[e] = in[ci[e]];
+#pragma unroll
+          for (int e = 0; e < V; ++e)
+            pv[e] = (j0 + e < b) ? v[e] * xg[e] : T(0);
+        }
+      } else { // the last row block of the matrix: element-wise, in bounds
+        if (!staged_visible) {
+          __syncthreads();
+          staged_visible = true;
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const int64_t j = j0 + e;
+          T p = T(0);
+          if (j < b)
+            p = values[j] * (K >= 0 ? s_x[lx.lidx[j]] : in[colind[j]]);
+          pv[e] = p;
+        }
+      }
+      *reinterpret_cast<val_t*>(&s_prod[t * V]) = pv;
+      __syncthreads();
+      const int32_t jlo = max((int64_t)lo, base) - base;
+      const int32_t jhi = min((int64_t)hi, base + TILE) - base;
+      int32_t j = jlo;
+      for (; j + 4 <= jhi; j += 4) {
+        const T p0 = s_prod[j], p1 = s_prod[j + 1], p2 = s_prod[j + 2],
+                p3 = s_prod[j + 3];
+        sum += p0;
+        sum += p1;
+        sum += p2;
+        sum += p3;
+      }
+      for (; j < jhi; ++j)
+        sum += s_prod[j];
+    }
+
+    if (t < nr) {
+      const int32_t r = r0 + t;
+      const T c = alpha * sum;
+      T y = c;
+      if (beta != T(0))
+        y = c + beta * out[r];
+      out[r] = y;
+      if constexpr (DOT)
+        dot_acc += (double)in[r] * (double)c;
+    }
+  }
+
+  if constexpr (DOT)
+    spmv_dot_epilogue(dot, dot_acc, s_red, &s_flag);
+}
+
+// Plan-time analysis for the LX kernel: one workgroup per row block sorts the
+// block's column indices, cuts them into windows (gap > kLxGap), and writes the
+// windows and every entry's offset into the staged buffer.  Blocks with more
+// than 256*ITEMS entries, more than kLxMaxWin windows or more than kLxCap
+// staged elements are marked direct (nwin = -1).
+template <int ITEMS>
+__global__ __launch_bounds__(kBlock) void lx_build_kernel(
+    int32_t num_rows, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ colind, uint16_t* __restrict__ lidx,
+    int32_t* __restrict__ nwin, int32_t* __restrict__ wstart,
+    int32_t* __restrict__ woff, int num_row_blocks, int end_bit)
+{
+  using Sort = hipcub::BlockRadixSort<int32_t, kBlock, ITEMS, int32_t>;
+  using Scan = hipcub::BlockScan<int32_t, kBlock>;
+  constexpr int CAP = kBlock * ITEMS;
+  __shared__ union {
+    typename Sort::TempStorage sort;
+    typename Scan::TempStorage scan;
+  } tmp;
+  __shared__ int32_t s_key[CAP];
+  __shared__ int32_t s_ws[kLxMaxWin], s_we[kLxMaxWin], s_wo[kLxMaxWin + 1];
+  __shared__ int s_direct;
+  const int t = threadIdx.x;
+  for (int rb = blockIdx.x; rb < num_row_blocks; rb += gridDim.x) {
+    const int32_t r0 = rb * kRows;
+    const int nr = min(kRows, num_rows - r0);
+    const int32_t a = rowptr[r0], b = rowptr[r0 + nr];
+    const int cnt = b - a;
+    __syncthreads(); // previous block done with the shared arrays
+    if (cnt > CAP) {
+      if (t == 0)
+        nwin[rb] = -1;
+      continue; // uniform
+    }
+    int32_t key[ITEMS], pos[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const int idx = t * ITEMS + i;
+      key[i] = idx < cnt ? colind[a + idx] : INT32_MAX;
+      pos[i] = idx;
+    }
+    Sort(tmp.sort).Sort(key, pos, 0, end_bit);
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i)
+      s_key[t * ITEMS + i] = key[i];
+    if (t == 0)
+      s_direct = 0;
+    __syncthreads();
+    // window starts: first valid key, or a gap larger than kLxGap
+    int32_t flag[ITEMS], wid[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const int idx = t * ITEMS + i;
+      const bool valid = idx < cnt; // INT32_MAX padding sorts to the end
+      flag[i] = valid && (idx == 0 || key[i] - s_key[idx - 1] > kLxGap) ? 1 : 0;
+    }
+    int32_t total_windows = 0;
+    Scan(tmp.scan).InclusiveSum(flag, wid, total_windows);
+    if (total_windows > kLxMaxWin) {
+      if (t == 0)
+        nwin[rb] = -1;
+      continue; // uniform (block-wide aggregate)
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const int idx = t * ITEMS + i;
+      if (idx < cnt) {
+        if (flag[i])
+          s_ws[wid[i] - 1] = key[i] & ~1;
+        // last entry of its window: end of data or the next key starts one
+        const bool last = idx == cnt - 1 || s_key[idx + 1] - key[i] > kLxGap;
+        if (last)
+          s_we[wid[i] - 1] = (key[i] + 2) & ~1;
+      }
+    }
+    __syncthreads();
+    if (t == 0) {
+      int off = 0;
+      for (int k = 0; k < total_windows; ++k) {
+        s_wo[k] = off;
+        off += s_we[k] - s_ws[k];
+      }
+      s_wo[total_windows] = off;
+      if (off > kLxCap)
+        s_direct = 1;
+    }
+    __syncthreads();
+    if (s_direct) {
+      if (t == 0)
+        nwin[rb] = -1;
+      continue;
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const int idx = t * ITEMS + i;
+      if (idx < cnt)
+        lidx[a + pos[i]]
+            = (uint16_t)(s_wo[wid[i] - 1] + (key[i] - s_ws[wid[i] - 1]));
+    }
+    if (t < total_windows)
+      wstart[(int64_t)rb * kLxMaxWin + t] = s_ws[t];
+    if (t <= total_windows)
+      woff[(int64_t)rb * (kLxMaxWin + 1) + t] = s_wo[t];
+    if (t == 0)
+      nwin[rb] = total_windows;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // ROWBLOCK, software-pipelined variant (aligned arrays, one 16-B value load
 // per lane per tile).  Same arithmetic and order as csr_rowblock_kernel; what
 // changes is when loads are issued:
@@ -1000,6 +1293,15 @@ struct spmv_hip_csr_plan {
   int order_slots = 0;
   int band_order = 0;
   int nt_store = 0; // non-temporal y stores
+  // ROWBLOCK "LX" form: LDS-staged x windows + 16-bit local column indices
+  // (csr_rowblock_lx_kernel); built by plan_create when most row blocks qualify
+  uint16_t* lx_lidx = nullptr;
+  int32_t* lx_nwin = nullptr;
+  int32_t* lx_wstart = nullptr;
+  int32_t* lx_woff = nullptr;
+  int lx = 0;            // use it (plan_set "lx")
+  int lx_staged = 0;     // row blocks that take the staged path
+  int lx_blocks = 0;     // row blocks analysed
   int lattice_d1 = 0, lattice_d2 = 0, band_lines = 0; // what was detected
 
   RowBlockOrder row_block_order(int nrb) const
@@ -1054,6 +1356,21 @@ int launch_rowblock(const spmv_hip_csr_plan* pl, hipStream_t st,
   if (grid >= 8)
     grid -= grid % 8;
   const bool al = aligned16(values) && aligned16(colind);
+  if (pl->lx && al && aligned16(in) && !pl->pipeline && !pl->wave_private) {
+    LxView lx{pl->lx_lidx, pl->lx_nwin, pl->lx_wstart, pl->lx_woff};
+#define SPMV_LX(NT)                                                            \
+  hipLaunchKernelGGL((csr_rowblock_lx_kernel<T, NT, DOT>), dim3(grid),         \
+                     dim3(kBlock), 0, st, pl->num_rows, pl->num_cols, pl->nnz, \
+                     rowptr, colind, values, lx, alpha, in, beta, out, dot,    \
+                     pl->row_block_order(nrb))
+    if (pl->nontemporal)
+      SPMV_LX(true);
+    else
+      SPMV_LX(false);
+#undef SPMV_LX
+    SPMV_CHECK_LAUNCH();
+    return SPMV_HIP_OK;
+  }
   if (pl->pipeline && al) {
     if (pl->nontemporal)
       hipLaunchKernelGGL((csr_rowblock_pipe_kernel<T, true, DOT>), dim3(grid),
@@ -1398,6 +1715,101 @@ int detect_lattice(spmv_hip_csr_plan* pl, const int32_t* rowptr,
   return SPMV_HIP_OK;
 }
 
+void free_lx(spmv_hip_csr_plan* pl)
+{
+  (void)hipFree(pl->lx_lidx);
+  (void)hipFree(pl->lx_nwin);
+  (void)hipFree(pl->lx_wstart);
+  (void)hipFree(pl->lx_woff);
+  pl->lx_lidx = nullptr;
+  pl->lx_nwin = pl->lx_wstart = pl->lx_woff = nullptr;
+  pl->lx = pl->lx_staged = pl->lx_blocks = 0;
+}
+
+struct IsStagedInt {
+  __host__ __device__ int32_t operator()(int32_t nwin) const
+  {
+    return nwin >= 0 ? 1 : 0;
+  }
+};
+
+// Build the LX form (see csr_rowblock_lx_kernel).  Costs 2 B per entry plus
+// 132 B per row block of device memory; kept only if most blocks are staged.
+int build_lx(spmv_hip_csr_plan* pl, const int32_t* rowptr,
+             const int32_t* colind)
+{
+  SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
+  free_lx(pl);
+  const int nrb = (pl->num_rows + kRows - 1) / kRows;
+  if (nrb == 0 || pl->nnz == 0)
+    return SPMV_HIP_OK;
+  hipStream_t st = pl->ctx->stream;
+  hipError_t e = hipMalloc(&pl->lx_lidx, sizeof(uint16_t) * (pl->nnz + 8));
+  if (e == hipSuccess)
+    e = hipMalloc(&pl->lx_nwin, sizeof(int32_t) * nrb);
+  if (e == hipSuccess)
+    e = hipMalloc(&pl->lx_wstart, sizeof(int32_t) * (size_t)nrb * kLxMaxWin);
+  if (e == hipSuccess)
+    e = hipMalloc(&pl->lx_woff,
+                  sizeof(int32_t) * (size_t)nrb * (kLxMaxWin + 1));
+  if (e == hipSuccess)
+    e = hipMemsetAsync(pl->lx_lidx, 0, sizeof(uint16_t) * (pl->nnz + 8), st);
+  if (e != hipSuccess) {
+    free_lx(pl);
+    return e == hipErrorOutOfMemory ? SPMV_HIP_OK : static_cast<int>(e);
+  }
+  int end_bit = 1;
+  while (end_bit < 31 && ((int64_t)1 << end_bit) < pl->num_cols)
+    ++end_bit;
+  int grid = pl->ctx->num_cus * 4;
+  grid = grid > nrb ? nrb : grid;
+  const double avg = (double)pl->nnz / pl->num_rows;
+  if (avg <= 6.0)
+    hipLaunchKernelGGL(lx_build_kernel<8>, dim3(grid), dim3(kBlock), 0, st,
+                       pl->num_rows, rowptr, colind, pl->lx_lidx, pl->lx_nwin,
+                       pl->lx_wstart, pl->lx_woff, nrb, end_bit);
+  else
+    hipLaunchKernelGGL(lx_build_kernel<16>, dim3(grid), dim3(kBlock), 0, st,
+                       pl->num_rows, rowptr, colind, pl->lx_lidx, pl->lx_nwin,
+                       pl->lx_wstart, pl->lx_woff, nrb, end_bit);
+  e = hipGetLastError();
+  // how many row blocks are staged?
+  int32_t* d_count = nullptr;
+  void* tmp = nullptr;
+  size_t tmp_bytes = 0;
+  int32_t staged = 0;
+  if (e == hipSuccess)
+    e = hipMalloc(&d_count, sizeof(int32_t));
+  hipcub::TransformInputIterator<int32_t, IsStagedInt, const int32_t*> flags(
+      pl->lx_nwin, IsStagedInt());
+  if (e == hipSuccess)
+    e = hipcub::DeviceReduce::Sum(nullptr, tmp_bytes, flags, d_count, nrb, st);
+  if (e == hipSuccess)
+    e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16);
+  if (e == hipSuccess)
+    e = hipcub::DeviceReduce::Sum(tmp, tmp_bytes, flags, d_count, nrb, st);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(&staged, d_count, sizeof(int32_t), hipMemcpyDeviceToHost,
+                       st);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st);
+  (void)hipFree(tmp);
+  (void)hipFree(d_count);
+  if (e != hipSuccess) {
+    free_lx(pl);
+    return static_cast<int>(e);
+  }
+  pl->lx_blocks = nrb;
+  pl->lx_staged = staged;
+  if ((int64_t)staged * 2 < nrb) { // mostly direct blocks: not worth the memory
+    free_lx(pl);
+    pl->lx_blocks = nrb;
+    return SPMV_HIP_OK;
+  }
+  pl->lx = 1;
+  return SPMV_HIP_OK;
+}
+
 // (Re)build the order table for bands of `yc` lines (0 = choose).  Needs a
 // detected lattice.
 int build_band_order(spmv_hip_csr_plan* pl, int yc)
@@ -1518,6 +1930,15 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
     // probe kernel by 5-17 % at 512^3 but left the full kernel, whose row sums
     // sit behind workgroup barriers, unchanged to 8 % slower.
     int rc = detect_lattice(pl, rowptr, colind);
+    // LX form: from ctx->lx_min_nnz entries on (set-up time, memory), rows
+    // short enough for the plan kernel's sort, and only while x fits the
+    // Infinity Cache: measured +2...8 % at 128^3 and 216^3, equal at 256^3,
+    // 1-6 % slower from 320^3 on (there the row-block kernels are bound by
+    // their dependent chain of loads, not by bytes, and the extra table loads
+    // lengthen it)
+    if (rc == SPMV_HIP_OK && num_non_zeros >= ctx->lx_min_nnz && avg <= 16.0
+        && pl->nontemporal)
+      rc = build_lx(pl, rowptr, colind);
     if (rc != SPMV_HIP_OK) {
       spmv_hip_csr_plan_destroy(pl);
       return rc;
@@ -1529,10 +1950,11 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
 
 int spmv_hip_csr_plan_destroy(spmv_hip_csr_plan* plan)
 {
-  if (plan && (plan->row_list || plan->order)) {
+  if (plan && (plan->row_list || plan->order || plan->lx_lidx)) {
     (void)hipSetDevice(plan->ctx->device);
     (void)hipFree(plan->row_list);
     (void)hipFree(plan->order);
+    free_lx(plan);
   }
   delete plan;
   return SPMV_HIP_OK;
@@ -1579,6 +2001,10 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
   } else if (!strcmp(key, "blocks_per_cu")) {
     SPMV_REQUIRE(value >= 1 && value <= kBlocksPerCU);
     plan->blocks_per_cu = value;
+  } else if (!strcmp(key, "lx")) {
+    // 1 needs the LX form built at plan creation (or by "lx_build")
+    SPMV_REQUIRE(value == 0 || plan->lx_lidx);
+    plan->lx = value != 0;
   } else if (!strcmp(key, "nt_store")) {
     plan->nt_store = value != 0;
   } else if (!strcmp(key, "band_order")) {
@@ -1613,6 +2039,12 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
     *value = plan->order ? plan->order_slots : 0;
   else if (!strcmp(key, "band_order"))
     *value = plan->band_order && plan->order ? 1 : 0;
+  else if (!strcmp(key, "lx"))
+    *value = plan->lx;
+  else if (!strcmp(key, "lx_staged"))
+    *value = plan->lx_staged;
+  else if (!strcmp(key, "lx_blocks"))
+    *value = plan->lx_blocks;
   else if (!strcmp(key, "blocks_per_cu"))
     *value = plan->blocks_per_cu;
   else if (!strcmp(key, "nontemporal"))

@@ -780,3 +780,106 @@ def test_no_lattice_no_band_order(ctx):
                        hip.ALGO_ROWBLOCK)
     assert blk.get("lattice_d2") == 0 and blk.get("order_slots") == 0
     blk.free()
+
+
+# ---------------------------------------------------------------------------
+# LX form: LDS-staged x windows + 16-bit local column offsets
+# ---------------------------------------------------------------------------
+@pytest.fixture()
+def lx_ctx():
+    c = hip.Context(0)
+    c.set_option("lx_min_nnz", 0)  # build the form for small test matrices too
+    yield c
+    c.close()
+
+
+def _banded_mixed(rng, n):
+    """Rows near the diagonal plus a few far blocks, and a stretch of rows with
+    scattered columns (those row blocks cannot be staged)."""
+    rows, cols = [], []
+    for i in range(n):
+        near = i + rng.integers(-40, 41, 5)
+        far = (i + 2000 + rng.integers(0, 30, 2)) % n
+        c = np.concatenate([near, far])
+        if 1024 <= i < 1536:  # two row blocks of scattered columns
+            c = rng.integers(0, n, 9)
+        c = np.clip(c, 0, n - 1)
+        rows += [i] * len(c)
+        cols += list(c)
+    order = np.lexsort((np.arange(len(rows)), rows))
+    rows, cols = np.array(rows)[order], np.array(cols, np.int32)[order]
+    rp = np.zeros(n + 1, np.int64)
+    np.add.at(rp, rows + 1, 1)
+    return np.cumsum(rp).astype(np.int32), cols, rng.uniform(-1, 1, len(cols))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_lx_form_bit_exact(lx_ctx, dtype):
+    ctx = lx_ctx
+    rng = np.random.default_rng(77)
+    cases = []
+    for n in (16, 20, 33):
+        rp, ci, va = poisson.poisson3d_csr(n)
+        cases.append((f"poisson{n}", rp, ci.astype(np.int32), va, n ** 3, n ** 3))
+    rp, ci, va = _banded_mixed(rng, 5000)
+    cases.append(("banded_mixed", rp, ci, va, 5000, 5000))
+    rp, ci, va = oracle.tridiag_csr(70001)  # odd column count: rounded windows
+    cases.append(("tridiag", rp, ci, va, 70001, 70001))
+    for name, rp, ci, va, nrows, ncols in cases:
+        va = va.astype(dtype)
+        x = rng.uniform(-1, 1, ncols).astype(dtype)
+        y0 = rng.uniform(-1, 1, nrows).astype(dtype)
+        blk = hip.CsrBlock(ctx, nrows, ncols, rp, ci, va, None, False,
+                           hip.ALGO_ROWBLOCK, dtype)
+        assert blk.get("lx") == 1, name
+        nrb = (nrows + 255) // 256
+        assert blk.get("lx_blocks") == nrb
+        if name == "banded_mixed":
+            assert 0 < blk.get("lx_staged") < nrb  # some blocks stay direct
+        else:
+            assert blk.get("lx_staged") == nrb
+        dx = ctx.upload(x, dtype)
+        for alpha, beta in ((1.0, 0.0), (-0.5, 0.0), (2.0, 1.0), (1.0, -0.25)):
+            y_ref = oracle.csr_spmv(rp, ci, va, x, alpha, beta, y0)  # f32-aware
+            for nt in (0, 1):
+                blk.set("nontemporal", nt)
+                for lx in (1, 0):  # with and without the form: same bits
+                    blk.set("lx", lx)
+                    dy = ctx.upload(np.full(nrows, np.nan, dtype) if beta == 0
+                                    else y0, dtype)
+                    blk.mult(alpha, dx.ptr, beta, dy.ptr)
+                    y = dy.numpy()
+                    dy.free()
+                    if lx == 1:
+                        y_lx = y
+                    else:
+                        assert np.array_equal(y, y_lx), (name, alpha, beta, nt)
+                    assert np.array_equal(y, y_ref), (name, alpha, beta, nt, lx)
+        dx.free()
+        blk.free()
+
+
+def test_lx_fused_dot_and_row_block_orders(lx_ctx):
+    ctx = lx_ctx
+    n = 24
+    rp, ci, va = poisson.poisson3d_csr(n)
+    ci = ci.astype(np.int32)
+    N = n ** 3
+    x = oracle.gaussian_x_fast(N)
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    blk = hip.CsrBlock(ctx, N, N, rp, ci, va, None, False, hip.ALGO_ROWBLOCK)
+    assert blk.get("lx") == 1
+    dx, dy = ctx.upload(x), ctx.upload(np.zeros(N))
+    part = ctx.empty(ctx.dot_partials_len, np.float64)
+    want = float(np.dot(x, y_ref))
+    for knobs in (dict(), dict(xcd_group=0), dict(xcd_group=3), dict(band_lines=4),
+                  dict(blocks_per_cu=1), dict(blocks_per_cu=8)):
+        for k, v in knobs.items():
+            blk.set(k, v)
+        blk.mult(1.0, dx.ptr, 0.0, dy.ptr, dot_partials=part.ptr)
+        assert np.array_equal(dy.numpy(), y_ref), knobs
+        got = float(np.sum(part.numpy()))
+        assert abs(got - want) <= 1e-12 * abs(want), knobs
+    for b in (dx, dy, part):
+        b.free()
+    blk.free()

@@ -25,8 +25,13 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 constexpr int kRows = 256, kTile = 512;
 
+// staged-x layout of MODE 8: five windows per 256-row block
+//   [r0-n^2,+256) [r0-n,+256) [r0-2,+260) [r0+n,+256) [r0+n^2,+256)
+__device__ __host__ inline int win_off(int w) { return w < 3 ? 256 * w : 256 * w + 4; }
+constexpr int kStaged = 4 * 256 + 260;
+
 __global__ void gen(int n, long N, int* rowptr, int* colind, double* values,
-                    double* x)
+                    double* x, unsigned short* lidx)
 {
   const long stride = (long)gridDim.x * blockDim.x;
   const long n2 = (long)n * n;
@@ -38,6 +43,14 @@ __global__ void gen(int n, long N, int* rowptr, int* colind, double* values,
       c = c < 0 ? c + N : (c >= N ? c - N : c);
       colind[7 * i + k] = (int)c;
       values[7 * i + k] = k == 3 ? 6.0 : -1.0;
+    }
+    {
+      const int t = (int)(i % kRows);
+      const int l[7] = {win_off(0) + t, win_off(1) + t, win_off(2) + t + 1,
+                        win_off(2) + t + 2, win_off(2) + t + 3, win_off(3) + t,
+                        win_off(4) + t};
+      for (int k = 0; k < 7; ++k)
+        lidx[7 * i + k] = (unsigned short)l[k];
     }
     x[i] = 1.0 + 1e-3 * (double)(i % 1000);
     if (i == N - 1)
@@ -88,8 +101,11 @@ __global__ __launch_bounds__(256) void probe(int nrows, const int* __restrict__ 
                                              const int* __restrict__ colind,
                                              const double* __restrict__ values,
                                              const double* __restrict__ x,
-                                             double* __restrict__ y)
+                                             double* __restrict__ y,
+                                             const unsigned short* __restrict__ lidx,
+                                             int n)
 {
+  __shared__ double s_x[MODE >= 8 ? kStaged : 2];
   __shared__ double s_prod[2][kTile];
   __shared__ int s_rp[kRows + 1];
   const int t = threadIdx.x;
@@ -129,6 +145,44 @@ __global__ __launch_bounds__(256) void probe(int nrows, const int* __restrict__ 
         a = rowptr[r0];
         b = rowptr[r0 + kRows];
       }
+    }
+    if (MODE >= 8) {
+      // stage the five x windows of this row block (coalesced 16-B loads)
+      const long N = nrows, n2l = (long)n * n;
+      const long starts[5] = {r0 - n2l, r0 - n, r0 - 2, r0 + n, r0 + n2l};
+      __syncthreads(); // previous block done with s_x
+      for (int f = t; f < kStaged / 2; f += 256) {
+        int w = f < 128 ? 0 : f < 256 ? 1 : f < 386 ? 2 : f < 514 ? 3 : 4;
+        const int e = f - win_off(w) / 2;
+        const int len = w == 2 ? 260 : 256;
+        long st = starts[w];
+        st = st < 0 ? 0 : (st + len > N ? N - len : st); // probe: clamp
+        const f64x2 v = *reinterpret_cast<const f64x2*>(x + st + 2 * e);
+        *reinterpret_cast<f64x2*>(&s_x[win_off(w) + 2 * e]) = v;
+      }
+      __syncthreads();
+      double acc8 = 0.0;
+      for (long base = a & ~1L; base < b; base += kTile) {
+        const long j = base + 2 * t;
+        const long jl = j < b - 2 ? j : b - 2;
+        const f64x2 v = sld<NT>(reinterpret_cast<const f64x2*>(values + jl));
+        const unsigned int li
+            = sld<NT>(reinterpret_cast<const unsigned int*>(lidx + jl));
+        const double x0 = s_x[li & 0xffffu], x1 = s_x[li >> 16];
+        const double p0 = j < b ? v.x * x0 : 0.0, p1 = j + 1 < b ? v.y * x1 : 0.0;
+        if (base != (a & ~1L))
+          __syncthreads();
+        s_prod[0][2 * t] = p0;
+        s_prod[0][2 * t + 1] = p1;
+        __syncthreads();
+        const long rlo = a + 7L * t, rhi = rlo + 7;
+        const long klo = (rlo > base ? rlo : base) - base;
+        const long khi = (rhi < base + kTile ? rhi : base + kTile) - base;
+        for (long k = klo; k < khi; ++k)
+          acc8 += s_prod[0][k];
+      }
+      y[r0 + t] = acc8;
+      continue;
     }
     double acc = 0.0;
     int buf = 0;
@@ -206,7 +260,9 @@ int main(int argc, char** argv)
   CK(hipMalloc(&values, nnz * 8));
   CK(hipMalloc(&x, N * 8));
   CK(hipMalloc(&y, N * 8));
-  gen<<<cus * 8, 256>>>(n, N, rowptr, colind, values, x);
+  unsigned short* lidx;
+  CK(hipMalloc(&lidx, nnz * 2));
+  gen<<<cus * 8, 256>>>(n, N, rowptr, colind, values, x, lidx);
   CK(hipDeviceSynchronize());
   // SCHED 3: every XCD sweeps its own band of `yc` grid lines through all z
   // (row blocks of one XCD = virtual indices q with q % 8 == xcd)
@@ -260,7 +316,8 @@ int main(int argc, char** argv)
   };
 #define P(MODE, NT, SCHED)                                                     \
   run("mode" #MODE "_nt" #NT "_sched" #SCHED, wpc, [&](int grid) {             \
-    probe<MODE, NT, SCHED><<<grid, 256>>>((int)N, rowptr, colind, values, x, y); \
+    probe<MODE, NT, SCHED><<<grid, 256>>>((int)N, rowptr, colind, values, x, y, \
+                                          lidx, n);                              \
   })
   for (int wpc : {8}) {
     P(0, false, 0); P(0, true, 0); P(0, false, 1); P(0, true, 1); P(0, false, 2); P(0, true, 2);
@@ -268,6 +325,7 @@ int main(int argc, char** argv)
     P(2, false, 0); P(2, false, 1); P(2, true, 1); P(2, false, 2); P(2, true, 2);
     P(3, false, 0); P(3, false, 1); P(3, true, 1); P(3, false, 2); P(3, true, 2);
     P(4, false, 1); P(4, true, 1); P(4, true, 2);
+    P(8, false, 0); P(8, false, 1); P(8, true, 1); P(8, false, 3); P(8, true, 3);
     P(5, true, 3); P(6, true, 3); P(7, true, 3); P(5, false, 1); P(6, false, 1); P(7, false, 1);
     P(2, true, 4); P(3, false, 4); P(3, true, 4); P(4, true, 4); P(7, true, 4);
     P(0, false, 3); P(2, false, 3); P(2, true, 3); P(3, false, 3); P(3, true, 3);
