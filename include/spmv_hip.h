@@ -66,7 +66,10 @@ int spmv_hip_ctx_set_option(spmv_hip_ctx* ctx, const char* key, int64_t value);
 /*   "lx_min_nnz": csr_plan_create builds the LX form of a general matrix
  *   (LDS-staged x windows + 16-bit column offsets, 2 B per entry of extra
  *   device memory) from this many entries on.  Default 2^20; a huge value
- *   switches the form off. */
+ *   switches the form off.
+ *   "lx_max_x_bytes": ... and only for matrices whose input vector
+ *   (num_cols * 8 bytes) is at most this large.  Default 128 MiB (the form
+ *   pays while x stays in the Infinity Cache). */
 
 /* ---- streams / events ---------------------------------------------------
  * CudaExecutor::set/reset/get_cuda_stream (cuda/cuda_executor.h:72-76). */

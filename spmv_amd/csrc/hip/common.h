@@ -19,6 +19,9 @@ struct spmv_hip_ctx {
   // plans build the LX form (LDS-staged x windows, 16-bit column offsets)
   // for general matrices with at least this many entries ("lx_min_nnz")
   int64_t lx_min_nnz = (int64_t)1 << 20;
+  // ... and only while x (num_cols * 8 bytes) is at most this large
+  // ("lx_max_x_bytes"): beyond the Infinity Cache the form stops paying
+  int64_t lx_max_x_bytes = (int64_t)128 << 20;
 };
 
 #define SPMV_CHECK_HIP(expr)                                                   \

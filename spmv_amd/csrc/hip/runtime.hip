@@ -85,6 +85,11 @@ int spmv_hip_ctx_set_option(spmv_hip_ctx* ctx, const char* key, int64_t value)
     ctx->blas1_nt_min_elems = value;
     return SPMV_HIP_OK;
   }
+  if (!strcmp(key, "lx_max_x_bytes")) {
+    SPMV_REQUIRE(value >= 0);
+    ctx->lx_max_x_bytes = value;
+    return SPMV_HIP_OK;
+  }
   if (!strcmp(key, "lx_min_nnz")) {
     SPMV_REQUIRE(value >= 0);
     ctx->lx_min_nnz = value;

@@ -1937,7 +1937,7 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
     // their dependent chain of loads, not by bytes, and the extra table loads
     // lengthen it)
     if (rc == SPMV_HIP_OK && num_non_zeros >= ctx->lx_min_nnz && avg <= 16.0
-        && pl->nontemporal)
+        && (int64_t)num_cols * 8 <= ctx->lx_max_x_bytes)
       rc = build_lx(pl, rowptr, colind);
     if (rc != SPMV_HIP_OK) {
       spmv_hip_csr_plan_destroy(pl);

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     ctx = hip.Context(0)
+    ctx.set_option("lx_max_x_bytes", 1 << 62)  # build the LX form at any size
     n, N = args.n, args.n ** 3
     blk = hip.poisson3d_block(ctx, n, 0, N, hip.PART_ALL)
     x, y = ctx.empty(N, np.float64), ctx.empty(N, np.float64)

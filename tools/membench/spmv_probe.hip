@@ -97,7 +97,7 @@ __device__ __forceinline__ bool next_block(int it, int nrb, int& rb)
 // MODE 0 stream, 1 +rowptr, 2 +gather, 3 +LDS row sums (full), 4 = 3 without
 // the trailing barrier per tile (double-buffered LDS)
 template <int MODE, bool NT, int SCHED>
-__global__ __launch_bounds__(256) void probe(int nrows, const int* __restrict__ rowptr,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void probe(int nrows, const int* __restrict__ rowptr,
                                              const int* __restrict__ colind,
                                              const double* __restrict__ values,
                                              const double* __restrict__ x,
@@ -145,6 +145,44 @@ __global__ __launch_bounds__(256) void probe(int nrows, const int* __restrict__ 
         a = rowptr[r0];
         b = rowptr[r0 + kRows];
       }
+    }
+    if (MODE == 9) {
+      // whole row block in ONE round: 4 x (16-B value + 8-B column) loads per
+      // lane issued up front, then 8 gathers, one LDS exchange
+      __shared__ double s_big[4 * kTile];
+      const double* vb = values + (a & ~1L); // uniform bases, 32-bit offsets
+      const int* cb = colind + (a & ~1L);
+      const int span = (int)(b - (a & ~1L));
+      f64x2 v[4];
+      i32x2 c[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int off = u * kTile + 2 * t;
+        off = off < span - 2 ? off : span - 2;
+        v[u] = sld<NT>(reinterpret_cast<const f64x2*>(vb + off));
+        c[u] = sld<NT>(reinterpret_cast<const i32x2*>(cb + off));
+      }
+      double xg[8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        xg[2 * u] = x[c[u].x];
+        xg[2 * u + 1] = x[c[u].y];
+      }
+      __syncthreads(); // previous block done with s_big
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int off = u * kTile + 2 * t;
+        s_big[off] = off < span ? v[u].x * xg[2 * u] : 0.0;
+        s_big[off + 1] = off + 1 < span ? v[u].y * xg[2 * u + 1] : 0.0;
+      }
+      __syncthreads();
+      double acc9 = 0.0;
+      const int rl = (int)(a - (a & ~1L)) + 7 * t;
+#pragma unroll
+      for (int k = 0; k < 7; ++k)
+        acc9 += s_big[rl + k];
+      y[r0 + t] = acc9;
+      continue;
     }
     if (MODE >= 8) {
       // stage the five x windows of this row block (coalesced 16-B loads)
@@ -325,6 +363,7 @@ int main(int argc, char** argv)
     P(2, false, 0); P(2, false, 1); P(2, true, 1); P(2, false, 2); P(2, true, 2);
     P(3, false, 0); P(3, false, 1); P(3, true, 1); P(3, false, 2); P(3, true, 2);
     P(4, false, 1); P(4, true, 1); P(4, true, 2);
+    P(9, false, 0); P(9, false, 1); P(9, true, 1);
     P(8, false, 0); P(8, false, 1); P(8, true, 1); P(8, false, 3); P(8, true, 3);
     P(5, true, 3); P(6, true, 3); P(7, true, 3); P(5, false, 1); P(6, false, 1); P(7, false, 1);
     P(2, true, 4); P(3, false, 4); P(3, true, 4); P(4, true, 4); P(7, true, 4);

@@ -22,8 +22,12 @@ def main():
     ap.add_argument("--symmetric", action="store_true")
     ap.add_argument("--dot", action="store_true")
     ap.add_argument("--set", nargs="*", default=[], help="knob=value ...")
+    ap.add_argument("--lx", action="store_true",
+                    help="build the LX form whatever the size of x")
     args = ap.parse_args()
     ctx = hip.Context(0)
+    if args.lx:
+        ctx.set_option("lx_max_x_bytes", 1 << 62)
     n, N = args.n, args.n ** 3
     part = hip.PART_LOCAL_LOWER if args.symmetric else hip.PART_ALL
     blk = hip.poisson3d_block(ctx, n, 0, N, part, with_diagonal=args.symmetric)
