@@ -883,3 +883,19 @@ def test_lx_fused_dot_and_row_block_orders(lx_ctx):
     for b in (dx, dy, part):
         b.free()
     blk.free()
+
+
+def test_options_and_plan_queries_reject_unknown_keys(ctx):
+    with pytest.raises(Exception):
+        ctx.set_option("no_such_option", 1)
+    with pytest.raises(Exception):
+        ctx.set_option("blas1_nt_min_elems", -1)
+    rp, ci, va = poisson.poisson3d_csr(6)
+    blk = hip.CsrBlock(ctx, 216, 216, rp, ci.astype(np.int32), va, None, False,
+                       hip.ALGO_ROWBLOCK)
+    with pytest.raises(Exception):
+        blk.get("no_such_key")
+    with pytest.raises(Exception):
+        blk.set("lx", 1)  # the form was not built for this small matrix
+    assert blk.get("lx") == 0 and blk.get("algo") == hip.ALGO_ROWBLOCK
+    blk.free()
