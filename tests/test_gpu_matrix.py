@@ -356,6 +356,9 @@ def test_slab_ranks_threaded_spmv_and_cg(world, n):
     tw = ThreadWorld(world, timeout=45.0)
 
     def rank_body(rank, comm, exec_):
+        from spmv_amd import _lib
+        # small as they are, the local blocks take the LX form (staged x windows)
+        _lib.call("spmv_hip_ctx_set_option", exec_.context, b"lx_min_nnz", 0)
         r0, r1 = int(ranges[rank]), int(ranges[rank + 1])
         for (sym, cm), (y_ref, (x_ref, k_ref, hist_ref)) in refs.items():
             A = host.Matrix.create_poisson3d(comm, exec_, n, sym, cm)
