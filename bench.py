@@ -248,7 +248,10 @@ def main():
         kernel = "csr_sym_window_kernel<double> (local lower block + diagonal)"
     else:
         kernel_bytes = poisson.csr_bytes(rows_b, cols_b, nnz_b)
-        kernel = "csr_rowblock_kernel<double> (local block, fused p.Ap)"
+        kernel = ("csr_rowblock_kernel<double> (local block, fused p.Ap)"
+                  if args.no_lx else
+                  "csr_rowblock_lx_kernel<double> (local block, LX form: x "
+                  "windows staged in LDS, 16-bit column offsets; fused p.Ap)")
     iter_bytes = kernel_bytes + 9 * M * 8  # + fused BLAS-1 minimum, SURVEY 8d
 
     # max over ranks of the times, sum over ranks of the bytes
@@ -272,7 +275,10 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
         if os.path.exists(pmc) and world == 1 and n == 512 and not args.symmetric:
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                summary = json.load(open(pmc))
+                if args.no_lx:
+                    summary = summary.get("gather_kernel", {})
+                traffic = summary.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {

@@ -20,8 +20,8 @@ struct spmv_hip_ctx {
   // for general matrices with at least this many entries ("lx_min_nnz")
   int64_t lx_min_nnz = (int64_t)1 << 20;
   // ... and only while x (num_cols * 8 bytes) is at most this large
-  // ("lx_max_x_bytes"): beyond the Infinity Cache the form stops paying
-  int64_t lx_max_x_bytes = (int64_t)128 << 20;
+  // ("lx_max_x_bytes"; no limit by default)
+  int64_t lx_max_x_bytes = INT64_MAX;
 };
 
 #define SPMV_CHECK_HIP(expr)                                                   \

@@ -276,21 +276,22 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_kernel(
 //      (same products, same left-to-right order => bit-identical results).
 // Row blocks whose columns do not fit the LDS budget keep the global gather
 // (nwin < 0); the decision is per row block.
-//   lx.nwin[rb]            number of windows, or -1 = direct
-//   lx.wstart[rb*kLxMaxWin + k]   first column of window k (even)
-//   lx.woff  [rb*(kLxMaxWin+1) + k] offset of window k in the staged buffer
-//                                   (even; entry nwin = staged length)
+//   lx.tab[rb*kLxRec + 0]          number of windows, or -1 = direct
+//   lx.tab[rb*kLxRec + 1 + k]      first column of window k (even)
+//   lx.tab[rb*kLxRec + 17 + k]     offset of window k in the staged buffer
+//                                  (even; entry nwin = staged length)
 //   lx.lidx[j]             offset of column colind[j] in the staged buffer
+// One record per row block, fetched unconditionally next to the row pointer:
+// nothing in the block's prologue depends on an earlier load.
 // ---------------------------------------------------------------------------
 constexpr int kLxMaxWin = 16;
+constexpr int kLxRec = 36;   // ints per row-block record (1 + 16 + 17, padded)
 constexpr int kLxCap = 1792; // staged x elements per row block (14 KiB fp64)
 constexpr int kLxGap = 16;   // columns closer than this share a window
 
 struct LxView {
   const uint16_t* lidx;
-  const int32_t* nwin;
-  const int32_t* wstart;
-  const int32_t* woff;
+  const int32_t* tab;
 };
 
 template <typename T, bool NT, bool DOT>
@@ -310,10 +311,11 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_lx_kernel(
   __shared__ __attribute__((aligned(16))) T s_x[kLxCap];
   __shared__ __attribute__((aligned(16))) T s_prod[TILE];
   __shared__ int32_t s_rowptr[kRows + 1];
-  __shared__ int32_t s_wstart[kLxMaxWin];
-  __shared__ int32_t s_woff[kLxMaxWin + 1];
+  __shared__ int32_t s_tab[kLxRec];
   __shared__ double s_red[kBlock / 64];
   __shared__ int s_flag;
+  const int32_t* s_wstart = s_tab + 1;
+  const int32_t* s_woff = s_tab + 1 + kLxMaxWin;
 
   const int t = threadIdx.x;
   double dot_acc = 0.0;
@@ -324,20 +326,17 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_lx_kernel(
       continue; // uniform per workgroup
     const int32_t r0 = rb * kRows;
     const int nr = min(kRows, num_rows - r0);
-    const int K = lx.nwin[rb]; // uniform
 
     __syncthreads(); // previous iteration done with every LDS array
     if (t <= nr)
       s_rowptr[t] = rowptr[r0 + t];
     if (t == 0 && nr == kRows)
       s_rowptr[kRows] = rowptr[r0 + kRows];
-    if (K > 0) {
-      if (t < K)
-        s_wstart[t] = lx.wstart[(int64_t)rb * kLxMaxWin + t];
-      if (t <= K)
-        s_woff[t] = lx.woff[(int64_t)rb * (kLxMaxWin + 1) + t];
-    }
+    if (t >= kBlock - kLxRec) // the last wave fetches the block's record
+      s_tab[t - (kBlock - kLxRec)]
+          = lx.tab[(int64_t)rb * kLxRec + (t - (kBlock - kLxRec))];
     __syncthreads();
+    const int K = s_tab[0]; // uniform
 
     const int32_t a = s_rowptr[0];
     const int32_t b = s_rowptr[nr];
@@ -453,8 +452,7 @@ template <int ITEMS>
 __global__ __launch_bounds__(kBlock) void lx_build_kernel(
     int32_t num_rows, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ colind, uint16_t* __restrict__ lidx,
-    int32_t* __restrict__ nwin, int32_t* __restrict__ wstart,
-    int32_t* __restrict__ woff, int num_row_blocks, int end_bit)
+    int32_t* __restrict__ tab, int num_row_blocks, int end_bit)
 {
   using Sort = hipcub::BlockRadixSort<int32_t, kBlock, ITEMS, int32_t>;
   using Scan = hipcub::BlockScan<int32_t, kBlock>;
@@ -475,7 +473,7 @@ __global__ __launch_bounds__(kBlock) void lx_build_kernel(
     __syncthreads(); // previous block done with the shared arrays
     if (cnt > CAP) {
       if (t == 0)
-        nwin[rb] = -1;
+        tab[(int64_t)rb * kLxRec] = -1;
       continue; // uniform
     }
     int32_t key[ITEMS], pos[ITEMS];
@@ -504,7 +502,7 @@ __global__ __launch_bounds__(kBlock) void lx_build_kernel(
     Scan(tmp.scan).InclusiveSum(flag, wid, total_windows);
     if (total_windows > kLxMaxWin) {
       if (t == 0)
-        nwin[rb] = -1;
+        tab[(int64_t)rb * kLxRec] = -1;
       continue; // uniform (block-wide aggregate)
     }
 #pragma unroll
@@ -533,7 +531,7 @@ __global__ __launch_bounds__(kBlock) void lx_build_kernel(
     __syncthreads();
     if (s_direct) {
       if (t == 0)
-        nwin[rb] = -1;
+        tab[(int64_t)rb * kLxRec] = -1;
       continue;
     }
 #pragma unroll
@@ -543,12 +541,13 @@ __global__ __launch_bounds__(kBlock) void lx_build_kernel(
         lidx[a + pos[i]]
             = (uint16_t)(s_wo[wid[i] - 1] + (key[i] - s_ws[wid[i] - 1]));
     }
+    int32_t* rec = tab + (int64_t)rb * kLxRec;
     if (t < total_windows)
-      wstart[(int64_t)rb * kLxMaxWin + t] = s_ws[t];
+      rec[1 + t] = s_ws[t];
     if (t <= total_windows)
-      woff[(int64_t)rb * (kLxMaxWin + 1) + t] = s_wo[t];
+      rec[1 + kLxMaxWin + t] = s_wo[t];
     if (t == 0)
-      nwin[rb] = total_windows;
+      rec[0] = total_windows;
   }
 }
 
@@ -1296,9 +1295,7 @@ struct spmv_hip_csr_plan {
   // ROWBLOCK "LX" form: LDS-staged x windows + 16-bit local column indices
   // (csr_rowblock_lx_kernel); built by plan_create when most row blocks qualify
   uint16_t* lx_lidx = nullptr;
-  int32_t* lx_nwin = nullptr;
-  int32_t* lx_wstart = nullptr;
-  int32_t* lx_woff = nullptr;
+  int32_t* lx_tab = nullptr; // kLxRec ints per row block
   int lx = 0;            // use it (plan_set "lx")
   int lx_staged = 0;     // row blocks that take the staged path
   int lx_blocks = 0;     // row blocks analysed
@@ -1357,7 +1354,7 @@ int launch_rowblock(const spmv_hip_csr_plan* pl, hipStream_t st,
     grid -= grid % 8;
   const bool al = aligned16(values) && aligned16(colind);
   if (pl->lx && al && aligned16(in) && !pl->pipeline && !pl->wave_private) {
-    LxView lx{pl->lx_lidx, pl->lx_nwin, pl->lx_wstart, pl->lx_woff};
+    LxView lx{pl->lx_lidx, pl->lx_tab};
 #define SPMV_LX(NT)                                                            \
   hipLaunchKernelGGL((csr_rowblock_lx_kernel<T, NT, DOT>), dim3(grid),         \
                      dim3(kBlock), 0, st, pl->num_rows, pl->num_cols, pl->nnz, \
@@ -1718,23 +1715,22 @@ int detect_lattice(spmv_hip_csr_plan* pl, const int32_t* rowptr,
 void free_lx(spmv_hip_csr_plan* pl)
 {
   (void)hipFree(pl->lx_lidx);
-  (void)hipFree(pl->lx_nwin);
-  (void)hipFree(pl->lx_wstart);
-  (void)hipFree(pl->lx_woff);
+  (void)hipFree(pl->lx_tab);
   pl->lx_lidx = nullptr;
-  pl->lx_nwin = pl->lx_wstart = pl->lx_woff = nullptr;
+  pl->lx_tab = nullptr;
   pl->lx = pl->lx_staged = pl->lx_blocks = 0;
 }
 
-struct IsStagedInt {
-  __host__ __device__ int32_t operator()(int32_t nwin) const
+struct IsStagedRecord {
+  const int32_t* tab;
+  __host__ __device__ int32_t operator()(int32_t rb) const
   {
-    return nwin >= 0 ? 1 : 0;
+    return tab[(int64_t)rb * kLxRec] >= 0 ? 1 : 0;
   }
 };
 
 // Build the LX form (see csr_rowblock_lx_kernel).  Costs 2 B per entry plus
-// 132 B per row block of device memory; kept only if most blocks are staged.
+// 144 B per row block of device memory; kept only if most blocks are staged.
 int build_lx(spmv_hip_csr_plan* pl, const int32_t* rowptr,
              const int32_t* colind)
 {
@@ -1746,14 +1742,11 @@ int build_lx(spmv_hip_csr_plan* pl, const int32_t* rowptr,
   hipStream_t st = pl->ctx->stream;
   hipError_t e = hipMalloc(&pl->lx_lidx, sizeof(uint16_t) * (pl->nnz + 8));
   if (e == hipSuccess)
-    e = hipMalloc(&pl->lx_nwin, sizeof(int32_t) * nrb);
-  if (e == hipSuccess)
-    e = hipMalloc(&pl->lx_wstart, sizeof(int32_t) * (size_t)nrb * kLxMaxWin);
-  if (e == hipSuccess)
-    e = hipMalloc(&pl->lx_woff,
-                  sizeof(int32_t) * (size_t)nrb * (kLxMaxWin + 1));
+    e = hipMalloc(&pl->lx_tab, sizeof(int32_t) * (size_t)nrb * kLxRec);
   if (e == hipSuccess)
     e = hipMemsetAsync(pl->lx_lidx, 0, sizeof(uint16_t) * (pl->nnz + 8), st);
+  if (e == hipSuccess)
+    e = hipMemsetAsync(pl->lx_tab, 0, sizeof(int32_t) * (size_t)nrb * kLxRec, st);
   if (e != hipSuccess) {
     free_lx(pl);
     return e == hipErrorOutOfMemory ? SPMV_HIP_OK : static_cast<int>(e);
@@ -1766,12 +1759,12 @@ int build_lx(spmv_hip_csr_plan* pl, const int32_t* rowptr,
   const double avg = (double)pl->nnz / pl->num_rows;
   if (avg <= 6.0)
     hipLaunchKernelGGL(lx_build_kernel<8>, dim3(grid), dim3(kBlock), 0, st,
-                       pl->num_rows, rowptr, colind, pl->lx_lidx, pl->lx_nwin,
-                       pl->lx_wstart, pl->lx_woff, nrb, end_bit);
+                       pl->num_rows, rowptr, colind, pl->lx_lidx, pl->lx_tab, nrb,
+                       end_bit);
   else
     hipLaunchKernelGGL(lx_build_kernel<16>, dim3(grid), dim3(kBlock), 0, st,
-                       pl->num_rows, rowptr, colind, pl->lx_lidx, pl->lx_nwin,
-                       pl->lx_wstart, pl->lx_woff, nrb, end_bit);
+                       pl->num_rows, rowptr, colind, pl->lx_lidx, pl->lx_tab, nrb,
+                       end_bit);
   e = hipGetLastError();
   // how many row blocks are staged?
   int32_t* d_count = nullptr;
@@ -1780,8 +1773,11 @@ int build_lx(spmv_hip_csr_plan* pl, const int32_t* rowptr,
   int32_t staged = 0;
   if (e == hipSuccess)
     e = hipMalloc(&d_count, sizeof(int32_t));
-  hipcub::TransformInputIterator<int32_t, IsStagedInt, const int32_t*> flags(
-      pl->lx_nwin, IsStagedInt());
+  // the window count is the first int of every record
+  hipcub::CountingInputIterator<int32_t> block_ids(0);
+  hipcub::TransformInputIterator<int32_t, IsStagedRecord,
+                                 hipcub::CountingInputIterator<int32_t>>
+      flags(block_ids, IsStagedRecord{pl->lx_tab});
   if (e == hipSuccess)
     e = hipcub::DeviceReduce::Sum(nullptr, tmp_bytes, flags, d_count, nrb, st);
   if (e == hipSuccess)

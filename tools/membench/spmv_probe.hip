@@ -65,6 +65,7 @@ __device__ __forceinline__ P sld(const P* p)
 }
 
 // SCHED: 0 grid-stride, 1 XCD groups of 16 row blocks, 2 contiguous range per WG
+__device__ const long* g_wtab = nullptr; // MODE 11: 8 longs per row block
 __device__ const int* g_order = nullptr; // SCHED 3: table, -1 = skip
 __device__ int g_order_len = 0;
 
@@ -105,9 +106,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void p
                                              const unsigned short* __restrict__ lidx,
                                              int n)
 {
-  __shared__ double s_x[MODE >= 8 ? kStaged : 2];
+  __shared__ double s_x[MODE >= 8 && MODE != 9 ? kStaged : 2];
   __shared__ double s_prod[2][kTile];
   __shared__ int s_rp[kRows + 1];
+  __shared__ long s_win[8];
   const int t = threadIdx.x;
   const int nrb = nrows / kRows;
   int rb;
@@ -187,8 +189,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void p
     if (MODE >= 8) {
       // stage the five x windows of this row block (coalesced 16-B loads)
       const long N = nrows, n2l = (long)n * n;
-      const long starts[5] = {r0 - n2l, r0 - n, r0 - 2, r0 + n, r0 + n2l};
+      long starts[5] = {r0 - n2l, r0 - n, r0 - 2, r0 + n, r0 + n2l};
       __syncthreads(); // previous block done with s_x
+      if (MODE >= 10) { // row pointer through memory and LDS, as the library does
+        s_rp[t] = rowptr[r0 + t];
+        if (t == 0)
+          s_rp[kRows] = rowptr[r0 + kRows];
+        if (MODE >= 11 && t < 5) // window table of this block from memory
+          s_win[t] = g_wtab[(long)rb * 8 + t];
+        __syncthreads();
+        a = s_rp[0];
+        b = s_rp[kRows];
+        if (MODE >= 11)
+          for (int w = 0; w < 5; ++w)
+            starts[w] = s_win[w];
+      }
       for (int f = t; f < kStaged / 2; f += 256) {
         int w = f < 128 ? 0 : f < 256 ? 1 : f < 386 ? 2 : f < 514 ? 3 : 4;
         const int e = f - win_off(w) / 2;
@@ -213,7 +228,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void p
         s_prod[0][2 * t] = p0;
         s_prod[0][2 * t + 1] = p1;
         __syncthreads();
-        const long rlo = a + 7L * t, rhi = rlo + 7;
+        const long rlo = MODE >= 10 ? (long)s_rp[t] : a + 7L * t;
+        const long rhi = MODE >= 10 ? (long)s_rp[t + 1] : rlo + 7;
         const long klo = (rlo > base ? rlo : base) - base;
         const long khi = (rhi < base + kTile ? rhi : base + kTile) - base;
         for (long k = klo; k < khi; ++k)
@@ -328,6 +344,20 @@ int main(int argc, char** argv)
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_order), &d_order, sizeof(d_order)));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_order_len), &len, sizeof(len)));
   }
+  {
+    const long nrbl = N / kRows, n2l = (long)n * n;
+    std::vector<long> wt((size_t)nrbl * 8, 0);
+    for (long k = 0; k < nrbl; ++k) {
+      const long r0 = k * kRows;
+      const long st[5] = {r0 - n2l, r0 - n, r0 - 2, r0 + n, r0 + n2l};
+      for (int w = 0; w < 5; ++w)
+        wt[(size_t)k * 8 + w] = st[w];
+    }
+    long* d_wt;
+    CK(hipMalloc(&d_wt, wt.size() * 8));
+    CK(hipMemcpy(d_wt, wt.data(), wt.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_wtab), &d_wt, sizeof(d_wt)));
+  }
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
@@ -363,6 +393,7 @@ int main(int argc, char** argv)
     P(2, false, 0); P(2, false, 1); P(2, true, 1); P(2, false, 2); P(2, true, 2);
     P(3, false, 0); P(3, false, 1); P(3, true, 1); P(3, false, 2); P(3, true, 2);
     P(4, false, 1); P(4, true, 1); P(4, true, 2);
+    P(10, false, 1); P(10, true, 1); P(11, false, 1); P(11, true, 1);
     P(9, false, 0); P(9, false, 1); P(9, true, 1);
     P(8, false, 0); P(8, false, 1); P(8, true, 1); P(8, false, 3); P(8, true, 3);
     P(5, true, 3); P(6, true, 3); P(7, true, 3); P(5, false, 1); P(6, false, 1); P(7, false, 1);
