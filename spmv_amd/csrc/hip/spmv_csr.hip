@@ -1275,10 +1275,12 @@ struct spmv_hip_csr_plan {
   int chunks = 1;         // ROWBLOCK: 16-B loads per lane per tile (1, 2, 4)
   int nontemporal = 0;    // ROWBLOCK: nt loads on the matrix stream
   int xcd_group = 16;     // ROWBLOCK: consecutive row blocks per XCD (0 = off)
-  // 7 of the 8 possible workgroups per CU: measured equal to 8 (2.973 vs
-  // 2.968 ms at 512^3) and leaves four wave slots per CU free, so the RCCL
-  // send/recv kernel of the halo can run beside the persistent SpMV grid
-  int blocks_per_cu = kBlocksPerCU - 1;
+  // All 8 workgroups per CU (= 32 waves, the occupancy limit).  Leaving one
+  // slot per CU free for the RCCL halo kernel cost the LX kernel 6 % and, at
+  // 19.6 KB of LDS per workgroup, would not leave a communication kernel the
+  // LDS it needs anyway; the halo is enqueued first, on a high-priority
+  // stream, and takes its slots before the persistent grid fills the chip.
+  int blocks_per_cu = kBlocksPerCU;
   int wave_private = 0;   // ROWBLOCK: wave-private LDS slices, no barriers
   int pipeline = 0;       // ROWBLOCK: software-pipelined variant
   int sym_window = 256;   // symmetric: LDS window below the block (0 = plain

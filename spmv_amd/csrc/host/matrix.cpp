@@ -32,7 +32,6 @@ Matrix<T>::Matrix(const CsrHost<T>& mat, std::shared_ptr<L2GMap> col_map,
   if (col_map->overlapping()) // Matrix.cpp:28-29
     throw std::runtime_error("Ovelapping not supported in this format!");
   _mat_local.reset(new CSRMatrix<T>(exec, &mat));
-  tune_for_topology();
 }
 
 template <typename T>
@@ -47,7 +46,6 @@ Matrix<T>::Matrix(const CsrHost<T>& mat_local, const CsrHost<T>& mat_remote,
     throw std::runtime_error("Ovelapping not enabled in column mapping!");
   _mat_local.reset(new CSRMatrix<T>(exec, &mat_local));
   _mat_remote.reset(new CSRMatrix<T>(exec, &mat_remote));
-  tune_for_topology();
 }
 
 template <typename T>
@@ -63,15 +61,6 @@ Matrix<T>::Matrix(const CsrHost<T>& mat_local, const CsrHost<T>& mat_remote,
     throw std::runtime_error("Device type not set!");
   _mat_local.reset(new CSRMatrix<T>(exec, &mat_local, &mat_diagonal, true));
   _mat_remote.reset(new CSRMatrix<T>(exec, &mat_remote));
-  tune_for_topology();
-}
-
-template <typename T>
-void Matrix<T>::tune_for_topology()
-{
-  if (_mat_local && _col_map && _col_map->neighbours().empty()
-      && _exec->get_device_type() == DeviceType::gpu)
-    _mat_local->tune("blocks_per_cu", 8);
 }
 
 // ---------------------------------------------------------------------------
@@ -573,7 +562,6 @@ Matrix<T>* Matrix<T>::create_poisson3d(std::shared_ptr<const Comm> comm,
       A->_mat_local.reset(adopt(B, ncols_all, false));
       A->_nnz = B.nnz;
     }
-    A->tune_for_topology();
     return A.release();
   }
 }

@@ -130,9 +130,6 @@ private:
   int64_t _nnz = 0; // the reference keeps an int (Matrix.h:122); 512^3 fits
   bool _symmetric = false;
 
-  // With no halo there is no RCCL kernel to leave wave slots for: the local
-  // block's persistent grid takes all 8 workgroups per CU.
-  void tune_for_topology();
   void spmv(T* x, T* y) const;
   void spmv_overlap(T* x, T* y) const;
   void spmv_sym(T* x, T* y) const;
