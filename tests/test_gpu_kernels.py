@@ -899,3 +899,46 @@ def test_options_and_plan_queries_reject_unknown_keys(ctx):
         blk.set("lx", 1)  # the form was not built for this small matrix
     assert blk.get("lx") == 0 and blk.get("algo") == hip.ALGO_ROWBLOCK
     blk.free()
+
+
+def test_lx_fuzz_banded(lx_ctx):
+    """Random banded matrices in LX form: empty rows, empty row blocks, ragged
+    last block, duplicates, a row too long for the plan kernel (direct block),
+    bands too wide to stage."""
+    ctx = lx_ctx
+    rng = np.random.default_rng(0x1F)
+    for case in range(24):
+        nrows = int(rng.choice([1, 255, 256, 257, 700, 3001]))
+        ncols = nrows + int(rng.integers(0, 50))
+        half = int(rng.choice([3, 40, 200, 900, 4000]))
+        lens = rng.poisson(float(rng.choice([1.0, 4.0, 9.0])), nrows)
+        lens[rng.random(nrows) < float(rng.choice([0.0, 0.3]))] = 0
+        if case % 5 == 0 and nrows > 600:
+            lens[256:512] = 0          # a whole row block without entries
+        if case % 7 == 0 and nrows > 300:
+            lens[rng.integers(0, nrows)] = 5000  # > 4096 entries in one block
+        rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        rows = np.repeat(np.arange(nrows), lens)
+        ci = np.clip(rows + rng.integers(-half, half + 1, len(rows)), 0,
+                     ncols - 1).astype(np.int32)
+        va = rng.uniform(-1, 1, len(ci))
+        x = rng.uniform(-1, 1, ncols)
+        y0 = rng.uniform(-1, 1, nrows)
+        if len(ci) == 0:
+            continue
+        try:
+            blk = hip.CsrBlock(ctx, nrows, ncols, rp, ci, va, None, False,
+                               hip.ALGO_ROWBLOCK)
+        except Exception as e:  # pragma: no cover
+            raise AssertionError((case, nrows, half)) from e
+        dx = ctx.upload(x)
+        for alpha, beta in ((1.0, 0.0), (0.5, -1.0)):
+            y_ref = oracle.csr_spmv(rp, ci, va, x, alpha, beta, y0)
+            dy = ctx.upload(np.full(nrows, np.nan) if beta == 0 else y0)
+            blk.mult(alpha, dx.ptr, beta, dy.ptr)
+            assert np.array_equal(dy.numpy(), y_ref), (case, nrows, half,
+                                                       blk.get("lx"),
+                                                       blk.get("lx_staged"))
+            dy.free()
+        dx.free()
+        blk.free()
