@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--cpu-n", type=int, default=256,
                     help="grid of the bounded CPU sample")
     ap.add_argument("--cpu-iters", type=int, default=30)
+    ap.add_argument("--reducer-kernels", action="store_true",
+                    help="finish dot products with the single-workgroup reducer "
+                         "launches even on one rank (experiments)")
     ap.add_argument("--no-lx", action="store_true",
                     help="do not build the LX form of the matrix (experiments)")
     ap.add_argument("--blas1-nt-min", type=int, default=None,
@@ -223,7 +226,8 @@ def main():
     # warm-up: W untimed iterations (also sizes the workspace, RCCL rings)
     if args.warmup > 0:
         host.cg_ex(comm, exec_, A, d_b, d_x, args.warmup, 0.0, ws,
-                   fused_reductions=args.fused_reductions)
+                   fused_reductions=args.fused_reductions,
+                   consumer_reductions=not args.reducer_kernels)
     torch.cuda.synchronize()
     barrier()
 
@@ -234,7 +238,8 @@ def main():
     k, _, spmv_ms, spmv_launches = host.cg_ex(comm, exec_, A, d_b, d_x,
                                               args.steps, 0.0, ws,
                                               time_spmv=True,
-                                              fused_reductions=args.fused_reductions)
+                                              fused_reductions=args.fused_reductions,
+                   consumer_reductions=not args.reducer_kernels)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0

@@ -251,6 +251,23 @@ int spmv_hip_cg_update_r_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
 int spmv_hip_cg_update_xp_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
                               int64_t n, const double* r, double* x, double* p,
                               void* stream);
+/* ---- consumer-side reductions (one rank) -----------------------------------------
+ * The same two updates with the reducer launches folded into their prologues:
+ * every workgroup adds the partials of the preceding producer itself, in the
+ * reducers' order (bit-identical scalars), workgroup 0 stores pAp[k] / rr[k].
+ *   update_r_cs : [p.Ap partials of the SpMV (+ pap_partials2, may be NULL)]
+ *                 -> pAp[k]; stop test of iteration k-1; r -= alpha Ap;
+ *                 partials of r.r into the workspace's second partial array
+ *   update_xp_cs: [those r.r partials] -> rr[k]; x += alpha p; stop test;
+ *                 p = beta p + r
+ * For a single rank only: no all-reduce can be placed between producer and
+ * consumer. */
+int spmv_hip_cg_update_r_cs_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
+                                int64_t n, const double* Ap, double* r,
+                                const double* pap_partials2, void* stream);
+int spmv_hip_cg_update_xp_cs_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
+                                 int64_t n, const double* r, double* x,
+                                 double* p, void* stream);
 /* ---- single-launch reductions -------------------------------------------------
  * The same dot products with the final sum folded into the producing kernel:
  * the workgroup that finishes last adds all partials in index order into

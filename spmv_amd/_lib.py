@@ -90,6 +90,8 @@ _PROTOS = {
     "spmv_hip_dot_partials_len": ([vp, P(C.c_int)], C.c_int),
     "spmv_hip_dot_partial_f64": ([vp, i64, vp, vp, vp, vp], C.c_int),
     "spmv_hip_reduce_partials_f64": ([vp, vp, vp, vp], C.c_int),
+    "spmv_hip_cg_update_r_cs_f64": ([vp, vp, C.c_int, i64, vp, vp, vp, vp], C.c_int),
+    "spmv_hip_cg_update_xp_cs_f64": ([vp, vp, C.c_int, i64, vp, vp, vp, vp], C.c_int),
     "spmv_hip_cg_ws_create": ([vp, C.c_int, P(vp)], C.c_int),
     "spmv_hip_cg_ws_destroy": ([vp], C.c_int),
     "spmv_hip_cg_ws_reset": ([vp, f64, vp], C.c_int),

@@ -483,6 +483,111 @@ __global__ __launch_bounds__(kBlock) void cg_reduce_pAp_kernel(
     pAp[k] = s;
 }
 
+// ---- consumer-side reductions (one rank) -----------------------------------
+// Instead of a single-workgroup reducer launch between producer and consumer,
+// EVERY workgroup of the consuming kernel adds the <= 2048 partials itself, in
+// the reducers' order (same loop, same tree => the same bits), and workgroup 0
+// records the value in the history.  16 KB of L2-resident reads per workgroup
+// against two kernel launches per iteration: what a small problem spends most
+// of its iteration on.  Needs the scalar on this rank only, so it is used when
+// the communicator has one rank.
+__device__ __forceinline__ double consume_partials(
+    const double* __restrict__ partials, const double* __restrict__ partials2,
+    int len, double* s_red, double* s_bcast)
+{
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < len; i += kBlock)
+    acc += partials[i];
+  if (partials2)
+    for (int i = threadIdx.x; i < len; i += kBlock)
+      acc += partials2[i];
+  const double s = block_sum(acc, s_red);
+  if (threadIdx.x == 0)
+    *s_bcast = s;
+  __syncthreads();
+  return *s_bcast;
+}
+
+// cg_reduce_pAp_kernel + cg_update_r_kernel in one launch
+template <bool NT>
+__global__ __launch_bounds__(kBlock) void cg_update_r_cs_kernel(
+    int64_t n, int k, const double* __restrict__ rr, double* __restrict__ pAp,
+    CgScalars* __restrict__ sc, const double* __restrict__ pap_partials,
+    const double* __restrict__ pap_partials2, int len,
+    const double* __restrict__ Ap, double* __restrict__ r,
+    double* __restrict__ rr_partials)
+{
+  __shared__ double s_red[kBlock / 64];
+  __shared__ double s_bcast;
+  if (sc->done)
+    return;
+  if (k >= 2) { // cg.cpp:80-81 of iteration k-1, as cg_reduce_pAp_kernel
+    const double rnorm0 = sqrt(rr[0]);
+    const double rnorm_prev = sqrt(rr[k - 1]);
+    if (rnorm_prev / rnorm0 < sc->rtol) { // uniform across the grid
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc->kstop = k - 1;
+        sc->done = 1;
+      }
+      return;
+    }
+  }
+  const double pap
+      = consume_partials(pap_partials, pap_partials2, len, s_red, &s_bcast);
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    pAp[k] = pap;
+  const double rnorm_old = sqrt(rr[k - 1]);
+  const double alpha = (rnorm_old * rnorm_old) / pap; // cg.cpp:66
+  const double nalpha = -alpha;
+  double acc = stream_update_r<NT>(n >> 1, nalpha, Ap, r);
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    double rv = r[i] + nalpha * Ap[i];
+    r[i] = rv;
+    acc += rv * rv;
+  }
+  __syncthreads(); // s_red is reused
+  double s = block_sum(acc, s_red);
+  if (threadIdx.x == 0)
+    rr_partials[blockIdx.x] = s;
+  clear_partials_tail(rr_partials, len);
+}
+
+// reduce_partials_kernel (r.r) + cg_update_xp_kernel in one launch
+template <bool NT>
+__global__ __launch_bounds__(kBlock) void cg_update_xp_cs_kernel(
+    int64_t n, int k, double* __restrict__ rr, const double* __restrict__ pAp,
+    CgScalars* __restrict__ sc, const double* __restrict__ rr_partials, int len,
+    const double* __restrict__ r, double* __restrict__ x, double* __restrict__ p)
+{
+  __shared__ double s_red[kBlock / 64];
+  __shared__ double s_bcast;
+  if (sc->done)
+    return;
+  const double rr_new
+      = consume_partials(rr_partials, nullptr, len, s_red, &s_bcast);
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    rr[k] = rr_new;
+  const double rnorm0 = sqrt(rr[0]);
+  const double rnorm_old = sqrt(rr[k - 1]);
+  const double rnorm_new = sqrt(rr_new);                                 // :76
+  const double alpha = (rnorm_old * rnorm_old) / pAp[k];                 // :66
+  const double beta = (rnorm_new * rnorm_new) / (rnorm_old * rnorm_old); // :77
+  const bool converged = rnorm_new / rnorm0 < sc->rtol;                  // :80
+  if (converged) { // x takes this iteration's update, p stays (:80-81)
+    stream_axpy<NT>(n >> 1, alpha, p, x);
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
+      x[n - 1] += alpha * p[n - 1];
+    return;
+  }
+  stream_update_xp<NT>(n >> 1, alpha, beta, r, x, p);
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    x[i] += alpha * p[i];
+    p[i] = beta * p[i] + r[i];
+  }
+}
+
 __global__ void cg_reset_kernel(CgScalars* sc, double rtol, double* rr,
                                 double* pAp, int kmax, unsigned int* counters)
 {
@@ -532,6 +637,7 @@ struct spmv_hip_cg_ws {
   double* rr = nullptr;       // kmax + 1
   double* pAp = nullptr;      // kmax + 1
   double* partials = nullptr; // ctx->dot_blocks
+  double* partials_rr = nullptr; // ctx->dot_blocks (consumer-side reductions)
   CgScalars* sc = nullptr;
   unsigned int* counters = nullptr; // arrival tickets of the fused reductions
 };
@@ -664,6 +770,8 @@ int spmv_hip_cg_ws_create(spmv_hip_ctx* ctx, int kmax, spmv_hip_cg_ws** out)
   if (e == hipSuccess)
     e = hipMalloc(&ws->partials, sizeof(double) * ctx->dot_blocks);
   if (e == hipSuccess)
+    e = hipMalloc(&ws->partials_rr, sizeof(double) * ctx->dot_blocks);
+  if (e == hipSuccess)
     e = hipMalloc(&ws->sc, sizeof(CgScalars));
   if (e == hipSuccess)
     e = hipMalloc(&ws->counters, 2 * (kDotShards + 1) * sizeof(unsigned int));
@@ -686,6 +794,7 @@ int spmv_hip_cg_ws_destroy(spmv_hip_cg_ws* ws)
   (void)hipFree(ws->rr);
   (void)hipFree(ws->pAp);
   (void)hipFree(ws->partials);
+  (void)hipFree(ws->partials_rr);
   (void)hipFree(ws->sc);
   (void)hipFree(ws->counters);
   delete ws;
@@ -851,6 +960,38 @@ int spmv_hip_cg_update_xp_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
   const int grid = spmv_grid_for(ctx, n / 2, (int)kUnit);
   SPMV_LAUNCH_NT(ctx, n, cg_update_xp_kernel, grid, spmv_stream(ctx, stream), n, k, ws->rr, ws->rr + (k - 1),
                      ws->rr + k, ws->pAp + k, ws->sc, r, x, p);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_cg_update_r_cs_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
+                                int64_t n, const double* Ap, double* r,
+                                const double* pap_partials2, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(ws && ws->ctx == ctx && k >= 1 && k <= ws->kmax && n >= 0);
+  SPMV_REQUIRE(n == 0 || (Ap && r));
+  SPMV_REQUIRE(aligned16(Ap) && aligned16(r));
+  const int grid = spmv_grid_for(ctx, n / 2, (int)kUnit);
+  SPMV_LAUNCH_NT(ctx, n, cg_update_r_cs_kernel, grid, spmv_stream(ctx, stream),
+                 n, k, ws->rr, ws->pAp, ws->sc, ws->partials, pap_partials2,
+                 ctx->dot_blocks, Ap, r, ws->partials_rr);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_cg_update_xp_cs_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
+                                 int64_t n, const double* r, double* x,
+                                 double* p, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(ws && ws->ctx == ctx && k >= 1 && k <= ws->kmax && n >= 0);
+  SPMV_REQUIRE(n == 0 || (r && x && p));
+  SPMV_REQUIRE(aligned16(r) && aligned16(x) && aligned16(p));
+  const int grid = spmv_grid_for(ctx, n / 2, (int)kUnit);
+  SPMV_LAUNCH_NT(ctx, n, cg_update_xp_cs_kernel, grid, spmv_stream(ctx, stream),
+                 n, k, ws->rr, ws->pAp, ws->sc, ws->partials_rr,
+                 ctx->dot_blocks, r, x, p);
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;
 }

@@ -193,6 +193,8 @@ int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
   }
   comm.allreduce_sum(slot(true, 0), 1, w.stream);
 
+  const bool consume
+      = opt.consumer_reductions && !opt.fused_reductions && comm.size() == 1;
   EventList timing{exec, {}};
   int k = 0;
   bool stopped = false;
@@ -210,7 +212,21 @@ int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
     }
     // cg.cpp:60,63: Ap = A p with the p.Ap partials produced by the SpMV
     // kernels themselves (local block's share + remote block's share)
-    if (opt.fused_reductions) {
+    if (consume) {
+      // one rank: the update kernels add the partials themselves
+      const bool fused = A.mult_dot(w.p, w.Ap, partials, w.dot2, ev1);
+      if (!fused)
+        throw_on_error(spmv_hip_dot_partial_f64(ctx, M, w.p, w.Ap, partials,
+                                                nullptr),
+                       "spmv_hip_dot_partial_f64");
+      throw_on_error(spmv_hip_cg_update_r_cs_f64(ctx, w.ws, k, M, w.Ap, w.r,
+                                                 fused ? w.dot2 : nullptr,
+                                                 nullptr),
+                     "spmv_hip_cg_update_r_cs_f64");
+      throw_on_error(spmv_hip_cg_update_xp_cs_f64(ctx, w.ws, k, M, w.r, w.x,
+                                                  w.p, nullptr),
+                     "spmv_hip_cg_update_xp_cs_f64");
+    } else if (opt.fused_reductions) {
       // ... and added up by their last workgroup: no reducer launch
       const bool fused = A.mult_dot(w.p, w.Ap, partials, w.dot2, ev1,
                                     slot(false, k), counters);
@@ -243,11 +259,13 @@ int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
       throw_on_error(spmv_hip_cg_reduce_rr(ctx, w.ws, k, nullptr),
                      "spmv_hip_cg_reduce_rr");
     }
-    comm.allreduce_sum(slot(true, k), 1, w.stream); // cg.cpp:75
-    // x += alpha p ; stop test ; p = beta p + r   (cg.cpp:69,77-85)
-    throw_on_error(spmv_hip_cg_update_xp_f64(ctx, w.ws, k, M, w.r, w.x, w.p,
-                                             nullptr),
-                   "spmv_hip_cg_update_xp_f64");
+    if (!consume) {
+      comm.allreduce_sum(slot(true, k), 1, w.stream); // cg.cpp:75
+      // x += alpha p ; stop test ; p = beta p + r   (cg.cpp:69,77-85)
+      throw_on_error(spmv_hip_cg_update_xp_f64(ctx, w.ws, k, M, w.r, w.x, w.p,
+                                               nullptr),
+                     "spmv_hip_cg_update_xp_f64");
+    }
 
     if (k % poll_every == 0 && k < kmax) {
       // Lagging look at the flag: wait for the copy issued `poll_every`

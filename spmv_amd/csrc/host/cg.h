@@ -50,6 +50,11 @@ struct CgOptions {
   // faster at 128^3 (the arrival tickets sit on the tail of a persistent
   // grid), hence the default.
   bool fused_reductions = false;
+  // One rank only (no all-reduce between producer and consumer): the update
+  // kernels add the dot-product partials themselves, in the reducers' order,
+  // so an iteration is 3 launches and the scalars keep their bits.  Ignored
+  // for more than one rank and when fused_reductions is set.
+  bool consumer_reductions = true;
 };
 
 struct CgStats {

@@ -534,7 +534,8 @@ class CgWorkspace:
 
 
 def cg_ex(comm, exec_, A, b_ptr, x_ptr, kmax, rtol, workspace=None,
-          time_spmv=False, history=False, fused_reductions=False):
+          time_spmv=False, history=False, fused_reductions=False,
+          consumer_reductions=True):
     """cg with the optional arguments: returns (k, history, spmv_ms_total,
     spmv_launches)."""
     k, n = C.c_int(), C.c_int()
@@ -542,7 +543,8 @@ def cg_ex(comm, exec_, A, b_ptr, x_ptr, kmax, rtol, workspace=None,
     hist = np.zeros(kmax + 1) if history else None
     call("spmvh_cg_ex", comm.h, exec_.h, A.h, b_ptr, x_ptr, kmax, float(rtol),
          C.byref(k), _np_ptr(hist), workspace.h if workspace else None,
-         int(time_spmv) | (2 if fused_reductions else 0), C.byref(ms),
+         int(time_spmv) | (2 if fused_reductions else 0)
+         | (0 if consumer_reductions else 4), C.byref(ms),
          C.byref(n))
     return (k.value, hist[:k.value + 1] if history else None, ms.value,
             n.value)

@@ -450,3 +450,36 @@ def test_unstructured_ranks_threaded(world, N, seed):
         m.close()
 
     tw.run(rank_body, gpu=True)
+
+
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_cg_consumer_reductions_equal_reducer_kernels(exec_, comm, symmetric):
+    """CgOptions::consumer_reductions (the one-rank default: the update kernels
+    add the partials themselves) leaves every scalar, the iteration count and
+    the solution bit-identical to the reducer-kernel form; also with early
+    convergence far inside a long queue and with an odd vector length."""
+    for n, kmax, rtol in ((11, 60, 1e-9), (9, 400, 1e-6), (16, 25, 1e-30)):
+        N = n ** 3
+        rp, ci, va = poisson.poisson3d_csr(n)
+        b = oracle.gaussian_x_fast(N)
+        A = host.Matrix.create_matrix(comm, exec_, rp, ci, va, N, N, [], [],
+                                      symmetric, host.P2P_NONBLOCKING)
+        d_b, d_x = exec_.alloc(N), exec_.alloc(N)
+        exec_.copy_from_host(d_b, b)
+        out = []
+        for consume in (True, False, True):
+            k, hist, _, _ = host.cg_ex(comm, exec_, A, d_b, d_x, kmax, rtol,
+                                       history=True,
+                                       consumer_reductions=consume)
+            out.append((k, hist.copy(), exec_.copy_to_host(d_x, N)))
+        for other in out[1:]:
+            if symmetric:  # atomic accumulation: runs differ in the last bits
+                assert abs(out[0][0] - other[0]) <= 1
+                m = min(out[0][0], other[0], 40)
+                assert np.allclose(out[0][1][:m + 1], other[1][:m + 1], rtol=1e-7)
+            else:
+                assert out[0][0] == other[0]
+                assert np.array_equal(out[0][1], other[1])
+                assert np.array_equal(out[0][2], other[2])
+        A.close()
+        exec_.free(d_b), exec_.free(d_x)
