@@ -278,10 +278,12 @@ def main():
         achieved = kernel_bytes / (spmv_ms_avg * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if os.path.exists(pmc) and world == 1 and n == 512 and not args.symmetric:
+        if os.path.exists(pmc) and world == 1 and n == 512:
             try:
                 summary = json.load(open(pmc))
-                if args.no_lx:
+                if args.symmetric:
+                    summary = summary.get("symmetric_kernel", {})
+                elif args.no_lx:
                     summary = summary.get("gather_kernel", {})
                 traffic = summary.get("hbm_bytes_per_launch")
             except Exception:
