@@ -223,6 +223,33 @@ def main():
     ws = host.CgWorkspace(exec_)
     exec_.synchronize()
 
+    # Several ranks: before anything is timed, prove the transport on this run's
+    # own partition -- after one halo update of the vector x_i = g(i) every
+    # ghost entry must hold g(its global index), and the locally owned part must
+    # be untouched.  A wrong offset or a lost message fails here, loudly,
+    # instead of producing a fast wrong number.
+    if world > 1:
+        ng = l2g.num_ghosts()
+        d_v = exec_.alloc(M + ng)
+        exec_.memset(d_v, 0xFF, 8 * (M + ng))  # NaN pattern in the ghost tail
+        _lib.call("spmv_hip_fill_gaussian_f64", ctx, N, l2g.global_offset(), M,
+                  d_v, None)
+        l2g.update(d_v)
+        l2g.update_finalise(d_v)  # non-blocking models complete here
+        exec_.synchronize()
+        got = exec_.copy_to_host(d_v, M + ng)
+        gidx = np.asarray(l2g.ghosts(), dtype=np.float64)
+        want = np.exp(-10 * (5 * (gidx / float(N) - 0.5)) ** 2)
+        own = np.arange(l2g.global_offset(), l2g.global_offset() + M,
+                        dtype=np.float64)
+        own = np.exp(-10 * (5 * (own / float(N) - 0.5)) ** 2)
+        bad = (not np.allclose(got[M:], want, rtol=1e-12, atol=1e-300)
+               or not np.allclose(got[:M], own, rtol=1e-12, atol=1e-300))
+        exec_.free(d_v)
+        if bad:
+            raise SystemExit(f"rank {rank}: halo self-check FAILED "
+                             f"({ng} ghosts) -- refusing to benchmark")
+
     # warm-up: W untimed iterations (also sizes the workspace, RCCL rings)
     if args.warmup > 0:
         host.cg_ex(comm, exec_, A, d_b, d_x, args.warmup, 0.0, ws,
@@ -235,9 +262,9 @@ def main():
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
-    k, _, spmv_ms, spmv_launches = host.cg_ex(comm, exec_, A, d_b, d_x,
-                                              args.steps, 0.0, ws,
-                                              time_spmv=True,
+    k, hist, spmv_ms, spmv_launches = host.cg_ex(comm, exec_, A, d_b, d_x,
+                                                 args.steps, 0.0, ws,
+                                                 time_spmv=True, history=True,
                                               fused_reductions=args.fused_reductions,
                    consumer_reductions=not args.reducer_kernels)
     torch.cuda.synchronize()
@@ -317,6 +344,12 @@ def main():
                          "launches_timed": spmv_launches},
             # whole-iteration effective bandwidth: SpMV + fused BLAS-1 minimum
             # (9 vectors of 8 B per row)
+            # ||r_k|| / ||r_0|| from the device-side history: after 10
+            # iterations the same number to ~1e-12 whatever the rank count
+            # or storage (a cross-check of the distributed path); after all K,
+            # where CG has amplified the different summation orders
+            "cg_rel_residual": {"k10": float(hist[min(10, len(hist) - 1)] / hist[0]),
+                                "kK": float(hist[-1] / hist[0])},
             "cg_gbs_per_gpu": iter_bytes / (elapsed / args.steps) / 1e9,
             # all ranks together: sum of bytes / time of the slowest rank
             "spmv_gbs_aggregate": kernel_bytes_all / (spmv_ms_avg * 1e-3) / 1e9,

@@ -34,6 +34,7 @@ def _check(d, n_gpus, steps, warmup):
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert r["launches_timed"] == steps and r["avg_launch_ms"] > 0
+    assert d["cg_rel_residual"]["k10"] > 0 and d["cg_rel_residual"]["kK"] > 0
 
 
 def test_bench_single_gpu_line():
@@ -63,3 +64,11 @@ def test_bench_two_rank_rehearsal():
     d = _line(res.stdout)
     _check(d, 2, 10, 2)
     assert "REHEARSAL" in d["data"] and "cpu_baseline" not in d
+    # the distributed run reproduces the one-rank residual after 10 iterations
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"),
+                          "--grid", "64", "--steps", "10", "--warmup", "2",
+                          "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-3000:]
+    k10 = _line(one.stdout)["cg_rel_residual"]["k10"]
+    assert abs(d["cg_rel_residual"]["k10"] - k10) <= 1e-10 * k10
