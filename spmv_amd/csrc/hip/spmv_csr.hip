@@ -286,7 +286,7 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_kernel(
 // ---------------------------------------------------------------------------
 constexpr int kLxMaxWin = 16;
 constexpr int kLxRec = 36;   // ints per row-block record (1 + 16 + 17, padded)
-constexpr int kLxCap = 1792; // staged x elements per row block (14 KiB fp64)
+constexpr int kLxCap = 1344; // staged x elements per row block (10.5 KiB fp64)
 constexpr int kLxGap = 16;   // columns closer than this share a window
 
 struct LxView {
@@ -294,7 +294,7 @@ struct LxView {
   const int32_t* tab;
 };
 
-template <typename T, bool NT, bool DOT>
+template <typename T, bool NT, bool DOT, int CH>
 __global__ __launch_bounds__(kBlock) void csr_rowblock_lx_kernel(
     int32_t num_rows, int32_t num_cols, int64_t nnz,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_lx_kernel(
     T beta, T* __restrict__ out, DotOut dot, RowBlockOrder ord)
 {
   constexpr int V = VecOf<T>::V;
-  constexpr int TILE = kBlock * V;
+  constexpr int TILE = kBlock * CH * V; // entries per barrier pair
   using val_t = typename VecOf<T>::val_t;
   using col_t = typename VecOf<T>::col_t;
   typedef T pair_t __attribute__((ext_vector_type(2)));
@@ -369,32 +369,48 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_lx_kernel(
     for (int64_t base = base0; base < b; base += TILE) {
       if (base != base0)
         __syncthreads(); // row owners finished reading the previous tile
-      const int64_t j0 = base + (int64_t)t * V;
-      val_t pv;
-      if (jclamp + V <= nnz) {
-        const int64_t jl = j0 < jclamp ? j0 : jclamp;
-        const val_t v
-            = stream_load<NT>(reinterpret_cast<const val_t*>(values + jl));
-        if (K >= 0) {
-          const lidx_t li
-              = stream_load<NT>(reinterpret_cast<const lidx_t*>(lx.lidx + jl));
-          if (!staged_visible) {
-            __syncthreads(); // s_x complete (matrix loads already in flight)
-            staged_visible = true;
-          }
+      if (jclamp + V <= nnz && K >= 0) {
+        // staged block: all matrix loads of the tile first, then the products
+        val_t v[CH];
+        lidx_t li[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int64_t j0 = base + (int64_t)(c * kBlock + t) * V;
+          const int64_t jl = j0 < jclamp ? j0 : jclamp;
+          v[c] = stream_load<NT>(reinterpret_cast<const val_t*>(values + jl));
+          li[c] = stream_load<NT>(reinterpret_cast<const lidx_t*>(lx.lidx + jl));
+        }
+        if (!staged_visible) {
+          __syncthreads(); // s_x complete (matrix loads already in flight)
+          staged_visible = true;
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int64_t j0 = base + (int64_t)(c * kBlock + t) * V;
+          val_t pv;
 #pragma unroll
           for (int e = 0; e < V; ++e)
-            pv[e] = (j0 + e < b) ? v[e] * s_x[li[e]] : T(0);
-        } else {
+            pv[e] = (j0 + e < b) ? v[c][e] * s_x[li[c][e]] : T(0);
+          *reinterpret_cast<val_t*>(&s_prod[(c * kBlock + t) * V]) = pv;
+        }
+      } else if (jclamp + V <= nnz) { // direct block: global gather
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int64_t j0 = base + (int64_t)(c * kBlock + t) * V;
+          const int64_t jl = j0 < jclamp ? j0 : jclamp;
+          const val_t v
+              = stream_load<NT>(reinterpret_cast<const val_t*>(values + jl));
           const col_t ci
               = stream_load<NT>(reinterpret_cast<const col_t*>(colind + jl));
           T xg[V];
 #pragma unroll
           for (int e = 0; e < V; ++e)
             xg[e] = in[ci[e]];
+          val_t pv;
 #pragma unroll
           for (int e = 0; e < V; ++e)
             pv[e] = (j0 + e < b) ? v[e] * xg[e] : T(0);
+          *reinterpret_cast<val_t*>(&s_prod[(c * kBlock + t) * V]) = pv;
         }
       } else { // the last row block of the matrix: element-wise, in bounds
         if (!staged_visible) {
@@ -402,15 +418,20 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_lx_kernel(
           staged_visible = true;
         }
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-          const int64_t j = j0 + e;
-          T p = T(0);
-          if (j < b)
-            p = values[j] * (K >= 0 ? s_x[lx.lidx[j]] : in[colind[j]]);
-          pv[e] = p;
+        for (int c = 0; c < CH; ++c) {
+          const int64_t j0 = base + (int64_t)(c * kBlock + t) * V;
+          val_t pv;
+#pragma unroll
+          for (int e = 0; e < V; ++e) {
+            const int64_t j = j0 + e;
+            T p = T(0);
+            if (j < b)
+              p = values[j] * (K >= 0 ? s_x[lx.lidx[j]] : in[colind[j]]);
+            pv[e] = p;
+          }
+          *reinterpret_cast<val_t*>(&s_prod[(c * kBlock + t) * V]) = pv;
         }
       }
-      *reinterpret_cast<val_t*>(&s_prod[t * V]) = pv;
       __syncthreads();
       const int32_t jlo = max((int64_t)lo, base) - base;
       const int32_t jhi = min((int64_t)hi, base + TILE) - base;
@@ -1299,6 +1320,8 @@ struct spmv_hip_csr_plan {
   uint16_t* lx_lidx = nullptr;
   int32_t* lx_tab = nullptr; // kLxRec ints per row block
   int lx = 0;            // use it (plan_set "lx")
+  int lx_chunks = 2;     // 16-byte value loads per lane per tile (1 or 2):
+                         // 2 = half the barriers, measured +7-8 % at every size
   int lx_staged = 0;     // row blocks that take the staged path
   int lx_blocks = 0;     // row blocks analysed
   int lattice_d1 = 0, lattice_d2 = 0, band_lines = 0; // what was detected
@@ -1357,15 +1380,22 @@ int launch_rowblock(const spmv_hip_csr_plan* pl, hipStream_t st,
   const bool al = aligned16(values) && aligned16(colind);
   if (pl->lx && al && aligned16(in) && !pl->pipeline && !pl->wave_private) {
     LxView lx{pl->lx_lidx, pl->lx_tab};
-#define SPMV_LX(NT)                                                            \
-  hipLaunchKernelGGL((csr_rowblock_lx_kernel<T, NT, DOT>), dim3(grid),         \
+#define SPMV_LX(NT, CH)                                                        \
+  hipLaunchKernelGGL((csr_rowblock_lx_kernel<T, NT, DOT, CH>), dim3(grid),     \
                      dim3(kBlock), 0, st, pl->num_rows, pl->num_cols, pl->nnz, \
                      rowptr, colind, values, lx, alpha, in, beta, out, dot,    \
                      pl->row_block_order(nrb))
-    if (pl->nontemporal)
-      SPMV_LX(true);
-    else
-      SPMV_LX(false);
+    if (pl->nontemporal) {
+      if (pl->lx_chunks == 2)
+        SPMV_LX(true, 2);
+      else
+        SPMV_LX(true, 1);
+    } else {
+      if (pl->lx_chunks == 2)
+        SPMV_LX(false, 2);
+      else
+        SPMV_LX(false, 1);
+    }
 #undef SPMV_LX
     SPMV_CHECK_LAUNCH();
     return SPMV_HIP_OK;
@@ -2006,6 +2036,9 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
     // 1 needs the LX form built at plan creation (or by "lx_build")
     SPMV_REQUIRE(value == 0 || plan->lx_lidx);
     plan->lx = value != 0;
+  } else if (!strcmp(key, "lx_chunks")) {
+    SPMV_REQUIRE(value == 1 || value == 2);
+    plan->lx_chunks = value;
   } else if (!strcmp(key, "nt_store")) {
     plan->nt_store = value != 0;
   } else if (!strcmp(key, "band_order")) {
