@@ -171,6 +171,11 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_kernel(
       hi = s_rowptr[t + 1];
     }
     T sum = 0;
+    // the row's own x for the fused dot, fetched ahead of its use
+    T x_own = T(0);
+    if constexpr (DOT)
+      if (t < nr)
+        x_own = in[r0 + t];
 
     // tiles start V-aligned so the wide loads are naturally aligned
     const int64_t base0 = a & ~(V - 1);
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_kernel(
       else
         out[r] = y;
       if constexpr (DOT) // this block's own share: in . (alpha A in)
-        dot_acc += (double)in[r] * (double)c;
+        dot_acc += (double)x_own * (double)c;
     }
   }
 
@@ -345,6 +350,12 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_lx_kernel(
       lo = s_rowptr[t];
       hi = s_rowptr[t + 1];
     }
+    // the row's own x for the fused dot: fetched now, used after the row sums
+    // (at the end of the block its latency would be exposed)
+    T x_own = T(0);
+    if constexpr (DOT)
+      if (t < nr)
+        x_own = in[r0 + t];
     // stage the x windows: pairs of elements, coalesced (in is 2-element
     // aligned, checked at launch; window starts and offsets are even)
     for (int k = 0; k < K; ++k) {
@@ -456,7 +467,7 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_lx_kernel(
         y = c + beta * out[r];
       out[r] = y;
       if constexpr (DOT)
-        dot_acc += (double)in[r] * (double)c;
+        dot_acc += (double)x_own * (double)c;
     }
   }
 
