@@ -356,21 +356,36 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_lx_kernel(
     if constexpr (DOT)
       if (t < nr)
         x_own = in[r0 + t];
-    // stage the x windows: pairs of elements, coalesced (in is 2-element
-    // aligned, checked at launch; window starts and offsets are even)
-    for (int k = 0; k < K; ++k) {
-      const int32_t ws = s_wstart[k], wo = s_woff[k];
-      const int32_t len = s_woff[k + 1] - wo;
-      for (int e = 2 * t; e < len; e += 2 * kBlock) {
-        const int32_t c = ws + e;
-        pair_t xv;
-        if (c + 1 < num_cols) {
-          xv = *reinterpret_cast<const pair_t*>(in + c);
-        } else { // the window was rounded up past the last column
-          xv[0] = c < num_cols ? in[c] : T(0);
-          xv[1] = T(0);
+    // Stage the x windows: pairs of elements, coalesced (in is 2-element
+    // aligned, checked at launch; window starts and offsets are even, so a
+    // pair never straddles two windows).  The staged buffer is walked as ONE
+    // flat range and all of a lane's loads are issued before the first LDS
+    // write: a loop over the windows made every window wait for its own load
+    // (five dependent L2 round trips per row block for a 7-point stencil).
+    {
+      static_assert(kLxCap <= 3 * 2 * kBlock, "three pairs per lane cover it");
+      const int staged = K > 0 ? s_woff[K] : 0;
+      pair_t xv[3];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const int f = 2 * t + 2 * kBlock * m;
+        xv[m][0] = xv[m][1] = T(0);
+        if (f < staged) {
+          int k = 0;
+          while (f >= s_woff[k + 1]) // K <= 16 windows
+            ++k;
+          const int32_t c = s_wstart[k] + (f - s_woff[k]);
+          if (c + 1 < num_cols)
+            xv[m] = *reinterpret_cast<const pair_t*>(in + c);
+          else if (c < num_cols) // the window was rounded up past the end
+            xv[m][0] = in[c];
         }
-        *reinterpret_cast<pair_t*>(&s_x[wo + e]) = xv;
+      }
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const int f = 2 * t + 2 * kBlock * m;
+        if (f < staged)
+          *reinterpret_cast<pair_t*>(&s_x[f]) = xv[m];
       }
     }
     T sum = 0;
