@@ -30,8 +30,13 @@ constexpr int kRows = 256, kTile = 512;
 __device__ __host__ inline int win_off(int w) { return w < 3 ? 256 * w : 256 * w + 4; }
 constexpr int kStaged = 4 * 256 + 260;
 
+// MODE 12 layout: five windows per 64-row wave block
+//   [r0-n^2,+64) [r0-n,+64) [r0-2,+68) [r0+n,+64) [r0+n^2,+64)
+__device__ __host__ inline int wwin_off(int w) { return w < 3 ? 64 * w : 64 * w + 4; }
+constexpr int kWStaged = 4 * 64 + 68;
+
 __global__ void gen(int n, long N, int* rowptr, int* colind, double* values,
-                    double* x, unsigned short* lidx)
+                    double* x, unsigned short* lidx, unsigned short* lidx64)
 {
   const long stride = (long)gridDim.x * blockDim.x;
   const long n2 = (long)n * n;
@@ -51,6 +56,12 @@ __global__ void gen(int n, long N, int* rowptr, int* colind, double* values,
                         win_off(4) + t};
       for (int k = 0; k < 7; ++k)
         lidx[7 * i + k] = (unsigned short)l[k];
+      const int tw = (int)(i % 64);
+      const int lw[7] = {wwin_off(0) + tw, wwin_off(1) + tw, wwin_off(2) + tw + 1,
+                         wwin_off(2) + tw + 2, wwin_off(2) + tw + 3,
+                         wwin_off(3) + tw, wwin_off(4) + tw};
+      for (int k = 0; k < 7; ++k)
+        lidx64[7 * i + k] = (unsigned short)lw[k];
     }
     x[i] = 1.0 + 1e-3 * (double)(i % 1000);
     if (i == N - 1)
@@ -104,9 +115,83 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void p
                                              const double* __restrict__ x,
                                              double* __restrict__ y,
                                              const unsigned short* __restrict__ lidx,
-                                             int n)
+                                             int n,
+                                             const unsigned short* __restrict__ lidx64)
 {
-  __shared__ double s_x[MODE >= 8 && MODE != 9 ? kStaged : 2];
+  if (MODE == 12) {
+    // wave-granular staged-x SpMV: every wave owns 64-row blocks, its own
+    // windows and product tile in LDS; no workgroup barrier anywhere
+    __shared__ double w_x[4][kWStaged];
+    __shared__ double w_prod[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* sx = w_x[wave];
+    double* sp = w_prod[wave];
+    const long N = nrows, n2l = (long)n * n;
+    const long nwb = N / 64;                                  // 64-row blocks
+    const long wstride = (long)gridDim.x * 4;
+    for (long wb = (long)blockIdx.x * 4 + wave; wb < nwb; wb += wstride) {
+      const long r0 = wb * 64;
+      const long a = 7 * r0, b = a + 448;
+      const long starts[5] = {r0 - n2l, r0 - n, r0 - 2, r0 + n, r0 + n2l};
+      // stage: 162 pairs, all loads first
+      f64x2 xv[3];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const int f = lane + 64 * m; // pair index
+        xv[m] = f64x2{0.0, 0.0};
+        if (f < kWStaged / 2) {
+          const int w = f < 32 ? 0 : f < 64 ? 1 : f < 98 ? 2 : f < 130 ? 3 : 4;
+          const int e = f - wwin_off(w) / 2;
+          const int len = w == 2 ? 68 : 64;
+          long st = starts[w];
+          st = st < 0 ? 0 : (st + len > N ? N - len : st);
+          xv[m] = *reinterpret_cast<const f64x2*>(x + st + 2 * e);
+        }
+      }
+      // both tiles' matrix loads (2 x (16 B + 4 B) per lane)
+      f64x2 v[2][2];
+      unsigned int li[2][2];
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          long j = a + tl * 256 + c * 128 + 2 * lane;
+          j = j < b - 2 ? j : b - 2;
+          v[tl][c] = sld<NT>(reinterpret_cast<const f64x2*>(values + j));
+          li[tl][c] = sld<NT>(reinterpret_cast<const unsigned int*>(lidx64 + j));
+        }
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const int f = lane + 64 * m;
+        if (f < kWStaged / 2)
+          *reinterpret_cast<f64x2*>(&sx[2 * f]) = xv[m];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      double acc = 0.0;
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const long j = a + tl * 256 + c * 128 + 2 * lane;
+          const double p0 = j < b ? v[tl][c].x * sx[li[tl][c] & 0xffffu] : 0.0;
+          const double p1 = j + 1 < b ? v[tl][c].y * sx[li[tl][c] >> 16] : 0.0;
+          *reinterpret_cast<f64x2*>(&sp[c * 128 + 2 * lane]) = f64x2{p0, p1};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int rlo = 7 * lane - tl * 256, rhi = rlo + 7;
+        const int klo = rlo > 0 ? rlo : 0, khi = rhi < 256 ? rhi : 256;
+        for (int k = klo; k < khi; ++k)
+          acc += sp[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      y[r0 + lane] = acc;
+    }
+    return;
+  }
+  __shared__ double s_x[MODE >= 8 && MODE != 9 && MODE != 12 ? kStaged : 2];
   __shared__ double s_prod[2][kTile];
   __shared__ int s_rp[kRows + 1];
   __shared__ long s_win[8];
@@ -314,9 +399,10 @@ int main(int argc, char** argv)
   CK(hipMalloc(&values, nnz * 8));
   CK(hipMalloc(&x, N * 8));
   CK(hipMalloc(&y, N * 8));
-  unsigned short* lidx;
+  unsigned short *lidx, *lidx64;
   CK(hipMalloc(&lidx, nnz * 2));
-  gen<<<cus * 8, 256>>>(n, N, rowptr, colind, values, x, lidx);
+  CK(hipMalloc(&lidx64, nnz * 2));
+  gen<<<cus * 8, 256>>>(n, N, rowptr, colind, values, x, lidx, lidx64);
   CK(hipDeviceSynchronize());
   // SCHED 3: every XCD sweeps its own band of `yc` grid lines through all z
   // (row blocks of one XCD = virtual indices q with q % 8 == xcd)
@@ -385,7 +471,7 @@ int main(int argc, char** argv)
 #define P(MODE, NT, SCHED)                                                     \
   run("mode" #MODE "_nt" #NT "_sched" #SCHED, wpc, [&](int grid) {             \
     probe<MODE, NT, SCHED><<<grid, 256>>>((int)N, rowptr, colind, values, x, y, \
-                                          lidx, n);                              \
+                                          lidx, n, lidx64);                      \
   })
   for (int wpc : {8}) {
     P(0, false, 0); P(0, true, 0); P(0, false, 1); P(0, true, 1); P(0, false, 2); P(0, true, 2);
@@ -393,6 +479,7 @@ int main(int argc, char** argv)
     P(2, false, 0); P(2, false, 1); P(2, true, 1); P(2, false, 2); P(2, true, 2);
     P(3, false, 0); P(3, false, 1); P(3, true, 1); P(3, false, 2); P(3, true, 2);
     P(4, false, 1); P(4, true, 1); P(4, true, 2);
+    P(12, false, 0); P(12, true, 0);
     P(10, false, 1); P(10, true, 1); P(11, false, 1); P(11, true, 1);
     P(9, false, 0); P(9, false, 1); P(9, true, 1);
     P(8, false, 0); P(8, false, 1); P(8, true, 1); P(8, false, 3); P(8, true, 3);
