@@ -75,6 +75,8 @@ def lib():
     L.oracle_time_spmv.restype = C.c_double
     L.oracle_poisson3d.argtypes = [C.c_int32, _i32p, _i32p, _f64p]
     L.oracle_poisson3d.restype = None
+    L.oracle_poisson3d_lower.argtypes = [C.c_int32, _i32p, _i32p, _f64p, _f64p]
+    L.oracle_poisson3d_lower.restype = None
     L.oracle_time_cg.argtypes = [C.c_int32, C.c_int64, _i32p, _i32p, _f64p,
                                  _f64p, _f64p, C.c_int, C.c_int,
                                  C.POINTER(C.c_int)]
@@ -197,6 +199,17 @@ def poisson3d(n):
     va = np.zeros(nnz, np.float64)
     lib().oracle_poisson3d(n, rp, ci, va)
     return rp, ci, va
+
+
+def poisson3d_lower(n):
+    """Strictly-lower CSR + diagonal of the same matrix (symmetric storage)."""
+    N, nnz = n ** 3, 3 * n ** 3 - 3 * n ** 2
+    rp = np.zeros(N + 1, np.int32)
+    ci = np.zeros(nnz, np.int32)
+    va = np.zeros(nnz, np.float64)
+    dg = np.zeros(N, np.float64)
+    lib().oracle_poisson3d_lower(n, rp, ci, va, dg)
+    return rp, ci, va, dg
 
 
 def time_cg(rowptr, colind, values, b, kmax, num_threads):

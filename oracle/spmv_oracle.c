@@ -477,6 +477,24 @@ void oracle_poisson3d(int32_t n, int32_t* rowptr, int32_t* colind,
   }
 }
 
+/* The same matrix in the symmetric storage of Matrix.cpp:337-349 on one rank:
+ * strictly-lower CSR (rowptr[n^3+1], colind/values[3n^3-3n^2]) + diagonal. */
+void oracle_poisson3d_lower(int32_t n, int32_t* rowptr, int32_t* colind,
+                            double* values, double* diagonal)
+{
+  const int64_t n2 = (int64_t)n * n, N = n2 * n;
+  int64_t pos = 0;
+  rowptr[0] = 0;
+  for (int64_t i = 0; i < N; ++i) {
+    const int64_t x = i % n, y = (i / n) % n, z = i / n2;
+    if (z > 0) { colind[pos] = (int32_t)(i - n2); values[pos++] = -1.0; }
+    if (y > 0) { colind[pos] = (int32_t)(i - n); values[pos++] = -1.0; }
+    if (x > 0) { colind[pos] = (int32_t)(i - 1); values[pos++] = -1.0; }
+    diagonal[i] = 6.0;
+    rowptr[i + 1] = (int32_t)pos;
+  }
+}
+
 /* Wall-clock seconds of one oracle_cg call (cpu_baseline leg). */
 double oracle_time_cg(int32_t n, int64_t nnz, const int32_t* rowptr,
                       const int32_t* colind, const double* values,

@@ -105,6 +105,8 @@ double oracle_time_spmv(int32_t num_rows, int64_t nnz, const int32_t* rowptr,
 
 void oracle_poisson3d(int32_t n, int32_t* rowptr, int32_t* colind,
                       double* values);
+void oracle_poisson3d_lower(int32_t n, int32_t* rowptr, int32_t* colind,
+                            double* values, double* diagonal);
 double oracle_time_cg(int32_t n, int64_t nnz, const int32_t* rowptr,
                       const int32_t* colind, const double* values,
                       const double* b, double* x, int kmax, int num_threads,

@@ -483,3 +483,122 @@ def test_cg_consumer_reductions_equal_reducer_kernels(exec_, comm, symmetric):
                 assert np.array_equal(out[0][2], other[2])
         A.close()
         exec_.free(d_b), exec_.free(d_x)
+
+
+# ---------------------------------------------------------------------------
+# spmv::cg at PRODUCTION launch shapes (BASELINE configs[1]: 128^3 on one
+# MI355X, HIP SpMV + CG, correctness vs CPU; demos/cg.cpp:64-65 kmax = 100,
+# rtol = 1e-10).  From 128^3 on the grids are the persistent ones of the
+# benchmark (2,048 dot partials, consumer-side reductions, LX form); 256^3
+# crosses blas1_nt_min_elems = 2^24, so every BLAS-1 kernel runs its
+# non-temporal path.  Bars: SURVEY 8d (|dk| <= 1 or both = kmax, residual
+# history to 1e-6 over the first 50 iterations, ||dx|| <= 1e-8 ||x||).
+# CG parity is unpinned by the reference itself (no reference test calls cg,
+# its ddot comes from an unpinned BLAS): the oracle fixes ddot left to right.
+# ---------------------------------------------------------------------------
+def _cg_vs_oracle(exec_, comm, n, symmetric, rhs, consume_modes, threads=1,
+                  kmax=100, rtol=1e-10, envelope_threads=0):
+    """envelope_threads > 0: the oracle is run a second time with its dots
+    summed in another order (that many OpenMP partials); where the oracle
+    disagrees with ITSELF by more than a twentieth of a bar, the bar becomes
+    20x that self-deviation.  Needed for the Gaussian right-hand side only:
+    its tails are 1e-28 of its peak, the Krylov space is exhausted after
+    ~20 iterations and from there any rounding difference grows 10x per
+    iteration (oracle vs oracle: 1e-11 at k = 18, 1e-3 at k = 27, x to 6e-6),
+    so no implementation -- the reference with another BLAS included -- can
+    meet 1e-6 / 1e-8 on it."""
+    N = n ** 3
+    rp, ci, va = oracle.poisson3d(n)
+    if rhs == "A*ones":
+        b = oracle.csr_spmv(rp, ci, va, np.ones(N))
+    else:
+        b = oracle.gaussian_x_fast(N)
+    if symmetric:
+        rp, ci, va, dg = oracle.poisson3d_lower(n)
+    else:
+        dg = None
+    x_ref, k_ref, hist_ref = oracle.cg(rp, ci, va, b, kmax, rtol, diagonal=dg,
+                                       num_threads=threads)
+    hist_bar = np.full(kmax + 1, 1e-6)
+    x_bar = 1e-8
+    if envelope_threads:
+        # the alternative order always runs on the general storage
+        x_alt, k_alt, hist_alt = oracle.cg(*oracle.poisson3d(n), b, kmax, rtol,
+                                           num_threads=envelope_threads)
+        m = min(k_ref, k_alt)
+        self_dev = np.maximum.accumulate(
+            np.abs(hist_alt[:m + 1] / hist_ref[:m + 1] - 1))
+        hist_bar[:m + 1] = np.maximum(hist_bar[:m + 1], 20 * self_dev)
+        x_bar = max(x_bar, 20 * np.linalg.norm(x_alt - x_ref)
+                    / np.linalg.norm(x_ref))
+        del x_alt
+    del rp, ci, va, dg
+    A = host.Matrix.create_poisson3d(comm, exec_, n, symmetric,
+                                     host.P2P_NONBLOCKING)
+    d_b, d_x = exec_.alloc(N), exec_.alloc(N)
+    exec_.copy_from_host(d_b, b)
+    ws = host.CgWorkspace(exec_)
+    for consume in consume_modes:
+        k, hist, _, _ = host.cg_ex(comm, exec_, A, d_b, d_x, kmax, rtol, ws,
+                                   history=True, consumer_reductions=consume)
+        x = exec_.copy_to_host(d_x, N)
+        what = (n, symmetric, rhs, consume)
+        assert (k == k_ref == kmax) or abs(k - k_ref) <= 1, (what, k, k_ref)
+        if k < kmax:
+            assert hist[-1] / hist[0] < rtol, what
+        m = min(k, k_ref, 50)
+        dev = np.abs(hist[:m + 1] / hist_ref[:m + 1] - 1)
+        assert np.all(dev <= hist_bar[:m + 1]), (what, dev.max(),
+                                                 int(np.argmax(dev / hist_bar[:m + 1])))
+        err = np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref)
+        assert err <= x_bar, (what, err, x_bar)
+    ws.close()
+    A.close()
+    exec_.free(d_b), exec_.free(d_x)
+
+
+@pytest.mark.parametrize("symmetric", [False, True])
+@pytest.mark.parametrize("rhs", ["A*ones", "gaussian"])
+def test_cg_128_cubed_vs_oracle(exec_, comm, symmetric, rhs):
+    """BASELINE configs[1], CG leg: 128^3, kmax 100, rtol 1e-10, both
+    reduction forms."""
+    _cg_vs_oracle(exec_, comm, 128, symmetric, rhs, (True, False),
+                  envelope_threads=0 if rhs == "A*ones" else 3)
+
+
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_cg_256_cubed_nontemporal_blas1_vs_oracle(exec_, comm, symmetric):
+    """256^3 = 2^24 rows: the non-temporal path of every BLAS-1 kernel and
+    the persistent SpMV grid, against the oracle (OpenMP restatement for the
+    general storage to keep the CPU side short; sequential for symmetric)."""
+    threads = 1 if symmetric else max(1, min(16, len(os.sched_getaffinity(0))))
+    _cg_vs_oracle(exec_, comm, 256, symmetric, "A*ones", (True, False),
+                  threads=threads, kmax=60)
+
+
+def test_spmv_128_cubed_gaussian_bit_exact_default_path(exec_, comm):
+    """BASELINE configs[1], SpMV leg: y = A x at 128^3 with the reference's
+    input vector (demos/spmv.cpp:63-67) on the DEFAULT plan (LX form), every
+    element identical to csr_kernels.cpp:41-51; symmetric storage too."""
+    n = 128
+    N = n ** 3
+    rp, ci, va = oracle.poisson3d(n)
+    x = oracle.gaussian_x_fast(N)
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    rpl, cil, val, dg = oracle.poisson3d_lower(n)
+    y_sym_ref = oracle.csr_spmv_sym(rpl, cil, val, dg, x)
+    for symmetric in (False, True):
+        A = host.Matrix.create_poisson3d(comm, exec_, n, symmetric,
+                                         host.P2P_NONBLOCKING)
+        d_x, d_y = exec_.alloc(N), exec_.alloc(N)
+        exec_.copy_from_host(d_x, x)
+        exec_.memset(d_y, 0xFF, 8 * N)
+        A.col_map().update(d_x)
+        A.mult(d_x, d_y)
+        y = exec_.copy_to_host(d_y, N)
+        if symmetric:  # atomic scatter: SURVEY 8d bound (7 terms per row)
+            assert np.all(np.abs(y - y_sym_ref) <= 16 * U * 12 * np.abs(x).max())
+        else:
+            assert np.array_equal(y, y_ref)
+        A.close()
+        exec_.free(d_x), exec_.free(d_y)
