@@ -47,8 +47,6 @@ def parse():
     ap.add_argument("--cm", default="p2p_nonblocking",
                     choices=["p2p_blocking", "p2p_nonblocking"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fused-reductions", action="store_true",
-                    help="finish dot products in the producing kernels")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "gloo"],
                     help="gloo: REHEARSAL ONLY -- halo and reductions staged "
                          "through the host so that several ranks can share one "
@@ -253,8 +251,8 @@ def main():
     # warm-up: W untimed iterations (also sizes the workspace, RCCL rings)
     if args.warmup > 0:
         host.cg_ex(comm, exec_, A, d_b, d_x, args.warmup, 0.0, ws,
-                   fused_reductions=args.fused_reductions,
                    consumer_reductions=not args.reducer_kernels)
+    ws.reserve_timing(args.steps)  # HIP events created outside the timed region
     torch.cuda.synchronize()
     barrier()
 
@@ -265,8 +263,7 @@ def main():
     k, hist, spmv_ms, spmv_launches = host.cg_ex(comm, exec_, A, d_b, d_x,
                                                  args.steps, 0.0, ws,
                                                  time_spmv=True, history=True,
-                                              fused_reductions=args.fused_reductions,
-                   consumer_reductions=not args.reducer_kernels)
+                                                 consumer_reductions=not args.reducer_kernels)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0

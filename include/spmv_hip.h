@@ -268,41 +268,6 @@ int spmv_hip_cg_update_r_cs_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
 int spmv_hip_cg_update_xp_cs_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
                                  int64_t n, const double* r, double* x,
                                  double* p, void* stream);
-/* ---- single-launch reductions -------------------------------------------------
- * The same dot products with the final sum folded into the producing kernel:
- * the workgroup that finishes last adds all partials in index order into
- * *result (deterministic, nobody waits).  `counter` points to
- * SPMV_HIP_DOT_COUNTER_WORDS device uint32 (a sharded arrival ticket) that are
- * zero before the launch and are reset by the kernel.
- *   spmv_hip_dot_f64            result = x . y
- *   spmv_hip_csr_spmv_dot_f64   SpMV + (result = | +=) in . (alpha A in)
- *   spmv_hip_cg_dot_rr0_f64     rr[0] = r . r                    (cg.cpp:47)
- *   spmv_hip_cg_dot_pAp_f64     pAp[k] = p . Ap   (symmetric blocks, :63)
- *   spmv_hip_cg_update_r_fused_f64  update_r + rr[k]; also raises `done` when
- *                               rr[k-1] met the tolerance (cg.cpp:80-81)
- * spmv_hip_cg_ws_counter returns the p.Ap ticket of a CG workspace (the r.r
- * one is internal). */
-#define SPMV_HIP_DOT_COUNTER_WORDS 33
-int spmv_hip_dot_f64(spmv_hip_ctx* ctx, int64_t n, const double* x,
-                     const double* y, double* partials, double* result,
-                     uint32_t* counter, void* stream);
-int spmv_hip_csr_spmv_dot_f64(spmv_hip_ctx* ctx, const spmv_hip_csr_plan* plan,
-                              int32_t num_rows, int32_t num_cols,
-                              int64_t num_non_zeros, const int32_t* rowptr,
-                              const int32_t* colind, const double* values,
-                              double alpha, const double* in, double beta,
-                              double* out, double* dot_partials,
-                              double* dot_result, uint32_t* dot_counter,
-                              int accumulate, void* stream);
-int spmv_hip_cg_ws_counter(spmv_hip_cg_ws* ws, uint32_t** counter);
-int spmv_hip_cg_dot_rr0_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int64_t n,
-                            const double* r, void* stream);
-int spmv_hip_cg_dot_pAp_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
-                            int64_t n, const double* p, const double* Ap,
-                            void* stream);
-int spmv_hip_cg_update_r_fused_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
-                                   int64_t n, const double* Ap, double* r,
-                                   void* stream);
 /* convergence test on rr[k] then p = beta p + r  (cg.cpp:77-85) */
 int spmv_hip_cg_update_p_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
                              int64_t n, const double* r, double* p,

@@ -215,11 +215,13 @@ int spmvh_petsc_rows_destroy(spmvh_petsc_rows* rows);
 /* Same solve with the optional arguments of the C++ overload: a reusable
  * spmv::CgWorkspace (may be NULL) and per-iteration HIP-event timing of the
  * local-block SpMV kernel (time_spmv bit 0 -> *spmv_ms_total, *spmv_launches;
- * bit 1 selects CgOptions::fused_reductions, bit 2 switches
- * CgOptions::consumer_reductions off). */
+ * bit 2 switches CgOptions::consumer_reductions off). */
 typedef struct spmvh_cg_workspace spmvh_cg_workspace;
 int spmvh_cg_workspace_create(spmvh_exec* exec, spmvh_cg_workspace** ws);
 int spmvh_cg_workspace_destroy(spmvh_cg_workspace* ws);
+/* create the timing events of a time_spmv solve of up to `iterations` steps
+ * ahead of it (keeps them out of a benchmark's timed region) */
+int spmvh_cg_workspace_reserve_timing(spmvh_cg_workspace* ws, int iterations);
 int spmvh_cg_ex(spmvh_comm* comm, spmvh_exec* exec, spmvh_matrix* A,
                 const double* b, double* x, int kmax, double rtol, int* num_its,
                 double* rnorm_history, spmvh_cg_workspace* ws, int time_spmv,

@@ -106,14 +106,6 @@ _PROTOS = {
     "spmv_hip_cg_update_r_f64": ([vp, vp, C.c_int, i64, vp, vp, vp], C.c_int),
     "spmv_hip_cg_update_xp_f64": ([vp, vp, C.c_int, i64, vp, vp, vp, vp],
                                   C.c_int),
-    "spmv_hip_dot_f64": ([vp, i64, vp, vp, vp, vp, vp, vp], C.c_int),
-    "spmv_hip_csr_spmv_dot_f64": ([vp, vp, i32, i32, i64, vp, vp, vp, f64, vp,
-                                   f64, vp, vp, vp, vp, C.c_int, vp], C.c_int),
-    "spmv_hip_cg_ws_counter": ([vp, P(vp)], C.c_int),
-    "spmv_hip_cg_dot_rr0_f64": ([vp, vp, i64, vp, vp], C.c_int),
-    "spmv_hip_cg_dot_pAp_f64": ([vp, vp, C.c_int, i64, vp, vp, vp], C.c_int),
-    "spmv_hip_cg_update_r_fused_f64": ([vp, vp, C.c_int, i64, vp, vp, vp],
-                                       C.c_int),
     "spmv_hip_cg_reduce_rr": ([vp, vp, C.c_int, vp], C.c_int),
     "spmv_hip_cg_reduce_pAp": ([vp, vp, C.c_int, vp], C.c_int),
     "spmv_hip_cg_reduce_pAp2": ([vp, vp, C.c_int, vp, vp], C.c_int),

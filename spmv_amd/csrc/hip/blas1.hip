@@ -265,11 +265,10 @@ __global__ __launch_bounds__(kBlock) void dot_partial_kernel(
     DotOut dot)
 {
   __shared__ double s_red[kBlock / 64];
-  __shared__ int s_flag;
   double acc = stream_dot<NT>(n >> 1, x, y);
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
     acc += x[n - 1] * y[n - 1];
-  spmv_dot_epilogue(dot, acc, s_red, &s_flag);
+  spmv_dot_epilogue(dot, acc, s_red);
 }
 
 // Sum `len` partials in a fixed order with one workgroup.
@@ -407,44 +406,6 @@ __global__ __launch_bounds__(kBlock) void cg_update_xp_kernel(
     x[i] += alpha * p[i];
     p[i] = beta * p[i] + r[i];
   }
-}
-
-// K2' with both reductions folded in: the workgroup that finishes last adds
-// the r.r partials into rr[k] (no reducer launch), and the prologue raises
-// `done` when rr[k-1] met the tolerance (what cg_reduce_pAp_kernel does in the
-// two-stage form).  Every workgroup evaluates the same scalars, so the early
-// return is uniform across the grid.
-template <bool NT>
-__global__ __launch_bounds__(kBlock) void cg_update_r_fused_kernel(
-    int64_t n, int k, const double* __restrict__ rr, const double* __restrict__ pAp,
-    CgScalars* __restrict__ sc, const double* __restrict__ Ap,
-    double* __restrict__ r, DotOut dot)
-{
-  __shared__ double s_red[kBlock / 64];
-  __shared__ int s_flag;
-  if (sc->done)
-    return;
-  const double rnorm_old = sqrt(rr[k - 1]);
-  if (k >= 2) {
-    const double rnorm0 = sqrt(rr[0]);
-    if (rnorm_old / rnorm0 < sc->rtol) { // cg.cpp:80-81 of iteration k-1
-      if (blockIdx.x == 0 && threadIdx.x == 0) {
-        sc->kstop = k - 1;
-        sc->done = 1;
-      }
-      return;
-    }
-  }
-  const double alpha = (rnorm_old * rnorm_old) / pAp[k]; // cg.cpp:66
-  const double nalpha = -alpha;
-  double acc = stream_update_r<NT>(n >> 1, nalpha, Ap, r);
-  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-    const int64_t i = n - 1;
-    double rv = r[i] + nalpha * Ap[i];
-    r[i] = rv;
-    acc += rv * rv;
-  }
-  spmv_dot_epilogue(dot, acc, s_red, &s_flag);
 }
 
 // Reduces the p.Ap partials of iteration k.  It is the first single-workgroup
@@ -589,7 +550,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_xp_cs_kernel(
 }
 
 __global__ void cg_reset_kernel(CgScalars* sc, double rtol, double* rr,
-                                double* pAp, int kmax, unsigned int* counters)
+                                double* pAp, int kmax)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) {
@@ -597,8 +558,6 @@ __global__ void cg_reset_kernel(CgScalars* sc, double rtol, double* rr,
     sc->done = 0;
     sc->kstop = -1;
   }
-  if (i < 2 * (kDotShards + 1))
-    counters[i] = 0u;
   if (i <= kmax) {
     rr[i] = 0.0;
     pAp[i] = 0.0;
@@ -639,7 +598,6 @@ struct spmv_hip_cg_ws {
   double* partials = nullptr; // ctx->dot_blocks
   double* partials_rr = nullptr; // ctx->dot_blocks (consumer-side reductions)
   CgScalars* sc = nullptr;
-  unsigned int* counters = nullptr; // arrival tickets of the fused reductions
 };
 
 // Vectors of at least ctx->blas1_nt_min_elems doubles stream past the caches
@@ -773,11 +731,6 @@ int spmv_hip_cg_ws_create(spmv_hip_ctx* ctx, int kmax, spmv_hip_cg_ws** out)
     e = hipMalloc(&ws->partials_rr, sizeof(double) * ctx->dot_blocks);
   if (e == hipSuccess)
     e = hipMalloc(&ws->sc, sizeof(CgScalars));
-  if (e == hipSuccess)
-    e = hipMalloc(&ws->counters, 2 * (kDotShards + 1) * sizeof(unsigned int));
-  if (e == hipSuccess)
-    e = hipMemset(ws->counters, 0,
-                  2 * (kDotShards + 1) * sizeof(unsigned int));
   if (e != hipSuccess) {
     spmv_hip_cg_ws_destroy(ws);
     return static_cast<int>(e);
@@ -796,7 +749,6 @@ int spmv_hip_cg_ws_destroy(spmv_hip_cg_ws* ws)
   (void)hipFree(ws->partials);
   (void)hipFree(ws->partials_rr);
   (void)hipFree(ws->sc);
-  (void)hipFree(ws->counters);
   delete ws;
   return SPMV_HIP_OK;
 }
@@ -808,7 +760,7 @@ int spmv_hip_cg_ws_reset(spmv_hip_cg_ws* ws, double rtol, void* stream)
   const int n = ws->kmax + 1;
   hipLaunchKernelGGL(cg_reset_kernel, dim3((n + kBlock - 1) / kBlock),
                      dim3(kBlock), 0, spmv_stream(ws->ctx, stream), ws->sc,
-                     rtol, ws->rr, ws->pAp, ws->kmax, ws->counters);
+                     rtol, ws->rr, ws->pAp, ws->kmax);
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;
 }
@@ -992,68 +944,6 @@ int spmv_hip_cg_update_xp_cs_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
   SPMV_LAUNCH_NT(ctx, n, cg_update_xp_cs_kernel, grid, spmv_stream(ctx, stream),
                  n, k, ws->rr, ws->pAp, ws->sc, ws->partials_rr,
                  ctx->dot_blocks, r, x, p);
-  SPMV_CHECK_LAUNCH();
-  return SPMV_HIP_OK;
-}
-
-int spmv_hip_dot_f64(spmv_hip_ctx* ctx, int64_t n, const double* x,
-                     const double* y, double* partials, double* result,
-                     uint32_t* counter, void* stream)
-{
-  SPMV_SET_DEVICE(ctx);
-  SPMV_REQUIRE(n >= 0 && partials && result && counter && (n == 0 || (x && y)));
-  SPMV_REQUIRE(aligned16(x) && aligned16(y));
-  const int grid = spmv_grid_for(ctx, n / 2, (int)kUnit);
-  DotOut dot;
-  dot.partials = partials;
-  dot.len = ctx->dot_blocks;
-  dot.result = result;
-  dot.counter = counter;
-  SPMV_LAUNCH_NT(ctx, n, dot_partial_kernel, grid, spmv_stream(ctx, stream), n, x, y, dot);
-  SPMV_CHECK_LAUNCH();
-  return SPMV_HIP_OK;
-}
-
-int spmv_hip_cg_ws_counter(spmv_hip_cg_ws* ws, uint32_t** counter)
-{
-  SPMV_REQUIRE(ws && counter);
-  *counter = ws->counters;
-  return SPMV_HIP_OK;
-}
-
-int spmv_hip_cg_dot_rr0_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int64_t n,
-                            const double* r, void* stream)
-{
-  SPMV_REQUIRE(ws && ws->ctx == ctx);
-  return spmv_hip_dot_f64(ctx, n, r, r, ws->partials, ws->rr,
-                          ws->counters + (kDotShards + 1), stream);
-}
-
-int spmv_hip_cg_dot_pAp_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
-                            int64_t n, const double* p, const double* Ap,
-                            void* stream)
-{
-  SPMV_REQUIRE(ws && ws->ctx == ctx && k >= 1 && k <= ws->kmax);
-  return spmv_hip_dot_f64(ctx, n, p, Ap, ws->partials, ws->pAp + k,
-                          ws->counters, stream);
-}
-
-int spmv_hip_cg_update_r_fused_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
-                                   int64_t n, const double* Ap, double* r,
-                                   void* stream)
-{
-  SPMV_SET_DEVICE(ctx);
-  SPMV_REQUIRE(ws && ws->ctx == ctx && k >= 1 && k <= ws->kmax && n >= 0);
-  SPMV_REQUIRE(n == 0 || (Ap && r));
-  SPMV_REQUIRE(aligned16(Ap) && aligned16(r));
-  const int grid = spmv_grid_for(ctx, n / 2, (int)kUnit);
-  DotOut dot;
-  dot.partials = ws->partials;
-  dot.len = ctx->dot_blocks;
-  dot.result = ws->rr + k;
-  dot.counter = ws->counters + (kDotShards + 1);
-  SPMV_LAUNCH_NT(ctx, n, cg_update_r_fused_kernel, grid, spmv_stream(ctx, stream), n, k, ws->rr, ws->pAp, ws->sc, Ap,
-                     r, dot);
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;
 }

@@ -22,6 +22,10 @@ struct spmv_hip_ctx {
   // ... and only while x (num_cols * 8 bytes) is at most this large
   // ("lx_max_x_bytes"; no limit by default)
   int64_t lx_max_x_bytes = INT64_MAX;
+  // plans try the lattice form (constant column offsets per row block, no
+  // index stream) for general matrices with at least this many entries
+  // ("lat_min_nnz")
+  int64_t lat_min_nnz = (int64_t)1 << 20;
 };
 
 #define SPMV_CHECK_HIP(expr)                                                   \
@@ -70,25 +74,13 @@ static inline int spmv_grid_for(const spmv_hip_ctx* ctx, int64_t work_items,
 // ---------------------------------------------------------------------------
 // Dot-product plumbing shared by the SpMV and BLAS-1 kernels.
 //
-// Every producing workgroup leaves one partial sum; either a separate
-// single-workgroup kernel adds them (spmv_hip_reduce_partials_f64), or -- when
-// `result` is set -- the workgroup that finishes LAST adds them itself, in
-// index order, so the sum is deterministic and no extra launch is needed
-// ("single device-side reduction").  No workgroup ever waits for another one:
-// the last finisher is identified by an arrival ticket.  Visibility follows
-// cdna_hip_programming.md Guideline 16 (8-byte agent-scope atomics on both
-// sides, ticket taken after the partial's atomic has returned).
+// Every producing workgroup leaves one partial sum; a single workgroup adds
+// them in index order afterwards -- a reducer kernel, or the consuming CG
+// update kernel itself (blas1.hip) -- so every dot product is deterministic.
 // ---------------------------------------------------------------------------
-constexpr int kDotShards = 32; // ticket words = kDotShards + 1 (C ABI:
-                               // SPMV_HIP_DOT_COUNTER_WORDS)
-
 struct DotOut {
-  double* partials = nullptr;  // one slot per workgroup (>= gridDim.x, len total)
-  int len = 0;                 // length of the partial array
-  double* result = nullptr;    // optional fused final sum
-  unsigned int* counter = nullptr; // kDotShards+1 ticket words, zero before
-                                   // the launch, reset by the kernel
-  int accumulate = 0;          // result += sum instead of result = sum
+  double* partials = nullptr; // one slot per workgroup (>= gridDim.x, len total)
+  int len = 0;                // length of the partial array
 };
 
 #ifdef __HIPCC__
@@ -112,78 +104,16 @@ __device__ __forceinline__ double spmv_block_sum(double v, double* s_red)
 }
 
 // Epilogue of every dot-producing kernel.  `acc` = this thread's share.
-// s_red: kBlock/64 doubles of LDS; s_flag: one int of LDS.
+// s_red: kBlock/64 doubles of LDS.  Leaves the workgroup's partial and clears
+// the unused tail of the array.
 __device__ __forceinline__ void spmv_dot_epilogue(const DotOut& d, double acc,
-                                                  double* s_red, int* s_flag)
+                                                  double* s_red)
 {
   const double s = spmv_block_sum(acc, s_red);
-  if (d.result == nullptr) {
-    // two-stage form: leave the partial, clear the unused tail of the array
-    if (threadIdx.x == 0)
-      d.partials[blockIdx.x] = s;
-    for (int i = gridDim.x + blockIdx.x * blockDim.x + threadIdx.x; i < d.len;
-         i += gridDim.x * blockDim.x)
-      d.partials[i] = 0.0;
-    return;
-  }
-  // Hand-off with 8-byte agent-scope atomics on BOTH sides (Guideline 16,
-  // "valid forms"): atomics execute at the memory side, so neither a release
-  // fence on the producers (it would write back the whole XCD L2 once per
-  // workgroup) nor an acquire on the consumer is needed.  The partial's
-  // exchange returns before the ticket is taken (drained vmcnt), and only the
-  // workgroup whose ticket is the last one reads the partials.
-  // The arrival ticket is two-level (kDotShards shard words + one top word):
-  // a persistent grid finishes almost at once, and ~1800 arrivals on ONE word
-  // cost ~20 us (one word takes ~88 atomics/us); sharded, each word sees <= 56.
-  if (threadIdx.x == 0) {
-    (void)__hip_atomic_exchange(&d.partials[blockIdx.x], s, __ATOMIC_RELAXED,
-                                __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned int shard = blockIdx.x % kDotShards;
-    const unsigned int in_shard
-        = (gridDim.x - shard + kDotShards - 1) / kDotShards;
-    const unsigned int nshards
-        = gridDim.x < (unsigned)kDotShards ? gridDim.x : (unsigned)kDotShards;
-    int last = 0;
-    const unsigned int t1 = __hip_atomic_fetch_add(
-        &d.counter[shard], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t1 == in_shard - 1) { // last of this shard: reset it, arrive at the top
-      __hip_atomic_store(&d.counter[shard], 0u, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned int t2 = __hip_atomic_fetch_add(
-          &d.counter[kDotShards], 1u, __ATOMIC_RELAXED,
-          __HIP_MEMORY_SCOPE_AGENT);
-      if (t2 == nshards - 1) {
-        __hip_atomic_store(&d.counter[kDotShards], 0u, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        last = 1;
-      }
-    }
-    *s_flag = last;
-  }
-  __syncthreads();
-  if (*s_flag == 0)
-    return;
-  // last workgroup: add all partials in index order (atomic reads)
-  // eight independent reads in flight per lane, then a fixed-order sum
-  double a = 0.0;
-  for (int base = 0; base < (int)gridDim.x; base += 8 * kBlock) {
-    double v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int i = base + j * kBlock + threadIdx.x;
-      v[j] = (i < (int)gridDim.x)
-                 ? __hip_atomic_fetch_add(&d.partials[i], 0.0, __ATOMIC_RELAXED,
-                                          __HIP_MEMORY_SCOPE_AGENT)
-                 : 0.0;
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      a += v[j];
-  }
-  __syncthreads(); // s_red is reused
-  const double total = spmv_block_sum(a, s_red);
-  if (threadIdx.x == 0) // the ticket words were reset by their last arrivers
-    *d.result = d.accumulate ? (*d.result + total) : total;
+  if (threadIdx.x == 0)
+    d.partials[blockIdx.x] = s;
+  for (int i = gridDim.x + blockIdx.x * blockDim.x + threadIdx.x; i < d.len;
+       i += gridDim.x * blockDim.x)
+    d.partials[i] = 0.0;
 }
 #endif

@@ -1,0 +1,171 @@
+// Shared internals of the CSR SpMV translation units (gfx950 only):
+//   spmv_csr.hip   general kernels (ROWBLOCK, LX form, VECTOR, SCALAR, ROWLIST),
+//                  plan creation, the C entry points
+//   spmv_sym.hip   symmetric-storage kernels (csr_kernels.cpp:26-40)
+//   spmv_lat.hip   lattice form: constant column offsets per row block
+#pragma once
+
+#include "common.h"
+
+constexpr int kRows = kBlock; // rows per workgroup in ROWBLOCK kernels
+
+// clang ext-vector types: 16-byte loads/stores, accepted by the
+// non-temporal builtins (HIP's double2/int4 wrapper structs are not).
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+struct VecOf;
+template <>
+struct VecOf<double> {
+  static constexpr int V = 2; // 16 B of values per lane per load
+  using val_t = f64x2;
+  using col_t = i32x2;
+};
+template <>
+struct VecOf<float> {
+  static constexpr int V = 4;
+  using val_t = f32x4;
+  using col_t = i32x4;
+};
+
+template <bool NT, typename P>
+__device__ __forceinline__ P stream_load(const P* p)
+{
+  if constexpr (NT)
+    return __builtin_nontemporal_load(p);
+  else
+    return *p;
+}
+
+// ---------------------------------------------------------------------------
+// Row-block traversal order.  A persistent grid walks "slots" it = blockIdx.x,
+// blockIdx.x + gridDim.x, ...; this maps a slot to the row block it computes.
+// Placement only changes speed, never the result.  Slots it with equal it % 8
+// run on the same XCD, because workgroups are dealt round-robin over the XCDs.
+//   xcd_group  inside each run of 8G row blocks XCD k owns G consecutive
+//              ones:  (it / 8G) * 8G + (it % 8) * G + (it / 8) % G
+//   otherwise  identity
+// ---------------------------------------------------------------------------
+struct RowBlockOrder {
+  int xcd_group;
+  int num_row_blocks;
+  int nt_store; // write y non-temporally (plain row-block kernel)
+};
+
+__device__ __forceinline__ int order_slots(const RowBlockOrder& o)
+{
+  if (o.xcd_group > 0) {
+    const int super = 8 * o.xcd_group;
+    return ((o.num_row_blocks + super - 1) / super) * super;
+  }
+  return o.num_row_blocks;
+}
+
+// row block of slot `it`, or -1 for an empty slot (uniform per workgroup)
+__device__ __forceinline__ int order_row_block(const RowBlockOrder& o, int it)
+{
+  int rb = it;
+  if (o.xcd_group > 0) {
+    const int super = 8 * o.xcd_group;
+    const int q = it % super;
+    rb = (it - q) + (q & 7) * o.xcd_group + (q >> 3);
+  }
+  return rb < o.num_row_blocks ? rb : -1;
+}
+
+
+template <typename T>
+static inline bool aligned16(const T* p)
+{
+  return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
+}
+
+// out *= beta (zero-fill for beta == 0 without reading out: SURVEY F7b)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void scale_kernel(int64_t n, T beta,
+                                                       T* __restrict__ out)
+{
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (beta == T(0)) ? T(0) : beta * out[i];
+}
+
+// ---------------------------------------------------------------------------
+// Plan = CSRSpMV::_aux_data
+// ---------------------------------------------------------------------------
+struct spmv_hip_csr_plan {
+  spmv_hip_ctx* ctx = nullptr;
+  int32_t num_rows = 0, num_cols = 0;
+  int64_t nnz = 0;
+  bool symmetric = false;
+  int algo = SPMV_HIP_ALGO_ROWBLOCK;
+  int lanes_per_row = 8;  // VECTOR
+  int chunks = 1;         // ROWBLOCK: 16-B loads per lane per tile (1, 2, 4)
+  int nontemporal = 0;    // ROWBLOCK: nt loads on the matrix stream
+  int xcd_group = 16;     // ROWBLOCK: consecutive row blocks per XCD (0 = off)
+  // All 8 workgroups per CU (= 32 waves, the occupancy limit).  Leaving one
+  // slot per CU free for the RCCL halo kernel cost the LX kernel 6 % and, at
+  // 19.6 KB of LDS per workgroup, would not leave a communication kernel the
+  // LDS it needs anyway; the halo is enqueued first, on a high-priority
+  // stream, and takes its slots before the persistent grid fills the chip.
+  int blocks_per_cu = kBlocksPerCU;
+  int sym_window = 256;   // symmetric: LDS window below the block (0 = plain
+                          // per-entry global atomics)
+  int sym_rows = 1024;    // symmetric: rows per workgroup (512, 1024, 2048)
+  int32_t* row_list = nullptr; // ROWLIST: device list of non-empty rows
+  int32_t num_listed = 0;
+  int nt_store = 0; // non-temporal y stores
+  // ROWBLOCK "LX" form: LDS-staged x windows + 16-bit local column indices
+  // (csr_rowblock_lx_kernel); built by plan_create when most row blocks qualify
+  uint16_t* lx_lidx = nullptr;
+  int32_t* lx_tab = nullptr; // kLxRec ints per row block
+  int lx = 0;            // use it (plan_set "lx")
+  int lx_chunks = 2;     // 16-byte value loads per lane per tile (1 or 2):
+                         // 2 = half the barriers, measured +7-8 % at every size
+  int lx_staged = 0;     // row blocks that take the staged path
+  int lx_blocks = 0;     // row blocks analysed
+  // Lattice form (spmv_lat.hip): every row block's columns are row + one of
+  // <= 8 constant offsets => no index stream, values arrive by LDS-DMA
+  int32_t* lat_tab = nullptr;  // kLatRec ints per row block: count, offsets
+  uint8_t* lat_mask = nullptr; // per row: bit k = offset k of its block present
+  int lat = 0;                 // use it (plan_set "lat")
+  int lat_blocks = 0;          // row blocks in lattice form (all, or lat == 0)
+  int lat_blocks_per_cu = 4;   // 2 x 17 KiB of LDS per workgroup
+  int lat_xcd_group = 0;       // consecutive row blocks per XCD (0 = off)
+
+  RowBlockOrder row_block_order(int nrb) const
+  {
+    RowBlockOrder o;
+    o.xcd_group = xcd_group;
+    o.num_row_blocks = nrb;
+    o.nt_store = nt_store;
+    return o;
+  }
+};
+
+
+// --- cross-file entry points (one definition each) -------------------------
+// spmv_sym.hip
+int spmv_run_symmetric_f64(const spmv_hip_csr_plan* pl, hipStream_t st,
+                           const int32_t* rowptr, const int32_t* colind,
+                           const double* values, const double* diagonal,
+                           double alpha, const double* in, double beta,
+                           double* out, DotOut dot);
+int spmv_run_symmetric_f32(const spmv_hip_csr_plan* pl, hipStream_t st,
+                           const int32_t* rowptr, const int32_t* colind,
+                           const float* values, const float* diagonal,
+                           float alpha, const float* in, float beta,
+                           float* out);
+// spmv_lat.hip
+int spmv_lat_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
+                   const int32_t* colind);
+void spmv_lat_free(spmv_hip_csr_plan* pl);
+int spmv_lat_run_f64(const spmv_hip_csr_plan* pl, hipStream_t st,
+                     const int32_t* rowptr, const double* values, double alpha,
+                     const double* in, double beta, double* out, DotOut dot);
+int spmv_lat_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st,
+                     const int32_t* rowptr, const float* values, float alpha,
+                     const float* in, float beta, float* out);

@@ -95,6 +95,11 @@ int spmv_hip_ctx_set_option(spmv_hip_ctx* ctx, const char* key, int64_t value)
     ctx->lx_min_nnz = value;
     return SPMV_HIP_OK;
   }
+  if (!strcmp(key, "lat_min_nnz")) {
+    SPMV_REQUIRE(value >= 0);
+    ctx->lat_min_nnz = value;
+    return SPMV_HIP_OK;
+  }
   return SPMV_HIP_EINVAL;
 }
 

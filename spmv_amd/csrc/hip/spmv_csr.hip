@@ -22,103 +22,17 @@
 //   for matrices with long rows.
 // SCALAR kernel: one lane per row, reference loop verbatim.
 //
-// Symmetric kernel (strictly-lower CSR + diagonal, csr_kernels.cpp:26-40)
-//   Same streaming structure; the row owner walks its entries in LDS and
-//   scatters alpha*v*x[i] with hardware fp64 atomics (global_atomic_add_f64).
-//   Consecutive lanes own consecutive rows, so for banded matrices each
-//   atomic wave-instruction touches a contiguous run of `out`.  `out` is
-//   scaled by beta (or zero-filled) by a separate pre-pass on the same
-//   stream.
-#include "common.h"
+// The symmetric-storage kernels live in spmv_sym.hip, the lattice form in
+// spmv_lat.hip; csr_plan.h holds what the three files share.
+#include "csr_plan.h"
 
-#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 #include <hipcub/hipcub.hpp>
 
-#include <algorithm>
 #include <cstring>
-#include <map>
 #include <new>
-#include <vector>
 
 namespace
 {
-
-constexpr int kRows = kBlock; // rows per workgroup in ROWBLOCK kernels
-
-// clang ext-vector types: 16-byte loads/stores, accepted by the
-// non-temporal builtins (HIP's double2/int4 wrapper structs are not).
-typedef double f64x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x2 __attribute__((ext_vector_type(2)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-
-template <typename T>
-struct VecOf;
-template <>
-struct VecOf<double> {
-  static constexpr int V = 2; // 16 B of values per lane per load
-  using val_t = f64x2;
-  using col_t = i32x2;
-};
-template <>
-struct VecOf<float> {
-  static constexpr int V = 4;
-  using val_t = f32x4;
-  using col_t = i32x4;
-};
-
-template <bool NT, typename P>
-__device__ __forceinline__ P stream_load(const P* p)
-{
-  if constexpr (NT)
-    return __builtin_nontemporal_load(p);
-  else
-    return *p;
-}
-
-// ---------------------------------------------------------------------------
-// Row-block traversal order.  A persistent grid walks "slots" it = blockIdx.x,
-// blockIdx.x + gridDim.x, ...; this maps a slot to the row block it computes.
-// Placement only changes speed, never the result.
-//   table      plan-time order table (band sweep, see build_band_order);
-//              -1 marks an empty slot.  Slots it with equal it % 8 run on the
-//              same XCD, because workgroups are dealt round-robin over the XCDs.
-//   xcd_group  no table: inside each run of 8G row blocks XCD k owns G
-//              consecutive ones:  (it / 8G) * 8G + (it % 8) * G + (it / 8) % G
-//   otherwise  identity
-// ---------------------------------------------------------------------------
-struct RowBlockOrder {
-  const int32_t* table;
-  int num_slots; // table length
-  int xcd_group;
-  int num_row_blocks;
-  int nt_store; // write y non-temporally (plain row-block kernel)
-};
-
-__device__ __forceinline__ int order_slots(const RowBlockOrder& o)
-{
-  if (o.table)
-    return o.num_slots;
-  if (o.xcd_group > 0) {
-    const int super = 8 * o.xcd_group;
-    return ((o.num_row_blocks + super - 1) / super) * super;
-  }
-  return o.num_row_blocks;
-}
-
-// row block of slot `it`, or -1 for an empty slot (uniform per workgroup)
-__device__ __forceinline__ int order_row_block(const RowBlockOrder& o, int it)
-{
-  int rb = it;
-  if (o.table) {
-    rb = o.table[it];
-  } else if (o.xcd_group > 0) {
-    const int super = 8 * o.xcd_group;
-    const int q = it % super;
-    rb = (it - q) + (q & 7) * o.xcd_group + (q >> 3);
-  }
-  return rb < o.num_row_blocks ? rb : -1;
-}
 
 // ---------------------------------------------------------------------------
 // ROWBLOCK general kernel
@@ -142,7 +56,6 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_kernel(
   __shared__ T s_prod[TILE];
   __shared__ int32_t s_rowptr[kRows + 1];
   __shared__ double s_red[kBlock / 64];
-  __shared__ int s_flag;
 
   const int t = threadIdx.x;
   double dot_acc = 0.0;
@@ -261,7 +174,7 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_kernel(
   }
 
   if constexpr (DOT)
-    spmv_dot_epilogue(dot, dot_acc, s_red, &s_flag);
+    spmv_dot_epilogue(dot, dot_acc, s_red);
 }
 
 // ---------------------------------------------------------------------------
@@ -318,7 +231,6 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_lx_kernel(
   __shared__ int32_t s_rowptr[kRows + 1];
   __shared__ int32_t s_tab[kLxRec];
   __shared__ double s_red[kBlock / 64];
-  __shared__ int s_flag;
   const int32_t* s_wstart = s_tab + 1;
   const int32_t* s_woff = s_tab + 1 + kLxMaxWin;
 
@@ -487,7 +399,7 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_lx_kernel(
   }
 
   if constexpr (DOT)
-    spmv_dot_epilogue(dot, dot_acc, s_red, &s_flag);
+    spmv_dot_epilogue(dot, dot_acc, s_red);
 }
 
 // Plan-time analysis for the LX kernel: one workgroup per row block sorts the
@@ -599,310 +511,6 @@ __global__ __launch_bounds__(kBlock) void lx_build_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// ROWBLOCK, software-pipelined variant (aligned arrays, one 16-B value load
-// per lane per tile).  Same arithmetic and order as csr_rowblock_kernel; what
-// changes is when loads are issued:
-//   * the row pointer of the NEXT row block is fetched into registers while
-//     the current one is processed;
-//   * inside a row block the matrix loads of tile k+1 are issued right after
-//     the x gathers of tile k (vmcnt counts in issue order, so the gathers can
-//     be waited for while the younger prefetch stays in flight);
-//   * the product tile is double-buffered in LDS: one barrier per tile.
-// Per row block the dependent chain shrinks from K*(matrix + gather latency)
-// to matrix + K*gather, which matters because only 7-8 workgroups per CU are
-// available to hide it.
-// ---------------------------------------------------------------------------
-template <typename T, bool NT, bool DOT>
-__global__ __launch_bounds__(kBlock) void csr_rowblock_pipe_kernel(
-    int32_t num_rows, int64_t nnz, const int32_t* __restrict__ rowptr,
-    const int32_t* __restrict__ colind, const T* __restrict__ values, T alpha,
-    const T* __restrict__ in, T beta, T* __restrict__ out, DotOut dot,
-    RowBlockOrder ord)
-{
-  constexpr int V = VecOf<T>::V;
-  constexpr int TILE = kBlock * V;
-  using val_t = typename VecOf<T>::val_t;
-  using col_t = typename VecOf<T>::col_t;
-
-  __shared__ T s_prod[2][TILE];
-  __shared__ int32_t s_rowptr[2][kRows + 1];
-  __shared__ double s_red[kBlock / 64];
-  __shared__ int s_flag;
-
-  const int t = threadIdx.x;
-  double dot_acc = 0.0;
-  const int num_row_blocks = ord.num_row_blocks;
-  const int num_slots = order_slots(ord);
-  // empty slots map past the end so the skip loops below step over them
-  auto slot_to_rb = [&](int it) {
-    const int rb = order_row_block(ord, it);
-    return rb < 0 ? num_row_blocks : rb;
-  };
-  // first valid slot of this workgroup and its row pointer
-  int it = blockIdx.x;
-  while (it < num_slots && slot_to_rb(it) >= num_row_blocks)
-    it += gridDim.x;
-  int32_t rp_reg = 0, rp_last = 0;
-  if (it < num_slots) {
-    const int32_t r0 = slot_to_rb(it) * kRows;
-    const int nr = min(kRows, num_rows - r0);
-    if (t <= nr)
-      rp_reg = rowptr[r0 + t];
-    if (t == 0 && nr == kRows)
-      rp_last = rowptr[r0 + kRows];
-  }
-  int buf = 0;  // s_rowptr buffer
-  int pbuf = 0; // s_prod buffer
-  while (it < num_slots) {
-    const int rb = slot_to_rb(it);
-    const int32_t r0 = rb * kRows;
-    const int nr = min(kRows, num_rows - r0);
-    if (t <= nr)
-      s_rowptr[buf][t] = rp_reg;
-    if (t == 0 && nr == kRows)
-      s_rowptr[buf][kRows] = rp_last;
-    // next valid slot: fetch its row pointer now, use it one iteration later
-    int itn = it + gridDim.x;
-    while (itn < num_slots && slot_to_rb(itn) >= num_row_blocks)
-      itn += gridDim.x;
-    if (itn < num_slots) {
-      const int32_t r0n = slot_to_rb(itn) * kRows;
-      const int nrn = min(kRows, num_rows - r0n);
-      if (t <= nrn)
-        rp_reg = rowptr[r0n + t];
-      if (t == 0 && nrn == kRows)
-        rp_last = rowptr[r0n + kRows];
-    }
-    __syncthreads();
-
-    const int32_t a = s_rowptr[buf][0];
-    const int32_t b = s_rowptr[buf][nr];
-    int32_t lo = 0, hi = 0;
-    T xr = 0;
-    if (t < nr) {
-      lo = s_rowptr[buf][t];
-      hi = s_rowptr[buf][t + 1];
-      if constexpr (DOT)
-        xr = in[r0 + t]; // early: its latency hides under the tile loop
-    }
-    T sum = 0;
-    const int64_t base0 = a & ~(V - 1);
-    if (b > a) {
-      const int64_t jclamp = (int64_t)(b - 1) & ~(int64_t)(V - 1);
-      if (jclamp + V <= nnz) {
-        // ---- pipelined fast path ----
-        int64_t j0 = base0 + (int64_t)t * V;
-        int64_t jl = j0 < jclamp ? j0 : jclamp;
-        val_t v = stream_load<NT>(reinterpret_cast<const val_t*>(values + jl));
-        col_t ci = stream_load<NT>(reinterpret_cast<const col_t*>(colind + jl));
-        for (int64_t base = base0; base < b; base += TILE) {
-          T xg[V];
-#pragma unroll
-          for (int e = 0; e < V; ++e)
-            xg[e] = in[ci[e]];
-          val_t vn = v;
-          col_t cin = ci;
-          const int64_t j0n = j0 + TILE;
-          if (base + TILE < b) { // prefetch the next tile behind the gathers
-            const int64_t jln = j0n < jclamp ? j0n : jclamp;
-            vn = stream_load<NT>(reinterpret_cast<const val_t*>(values + jln));
-            cin = stream_load<NT>(reinterpret_cast<const col_t*>(colind + jln));
-          }
-          val_t pv;
-#pragma unroll
-          for (int e = 0; e < V; ++e)
-            pv[e] = (j0 + e < b) ? v[e] * xg[e] : T(0);
-          *reinterpret_cast<val_t*>(&s_prod[pbuf][t * V]) = pv;
-          __syncthreads();
-          const int32_t jlo = max((int64_t)lo, base) - base;
-          const int32_t jhi = min((int64_t)hi, base + TILE) - base;
-          int32_t j = jlo;
-          for (; j + 4 <= jhi; j += 4) {
-            const T p0 = s_prod[pbuf][j], p1 = s_prod[pbuf][j + 1],
-                    p2 = s_prod[pbuf][j + 2], p3 = s_prod[pbuf][j + 3];
-            sum += p0;
-            sum += p1;
-            sum += p2;
-            sum += p3;
-          }
-          for (; j < jhi; ++j)
-            sum += s_prod[pbuf][j];
-          pbuf ^= 1;
-          v = vn;
-          ci = cin;
-          j0 = j0n;
-        }
-      } else {
-        // ---- guarded path (the tile that touches the end of the arrays) ----
-        for (int64_t base = base0; base < b; base += TILE) {
-          val_t pv;
-#pragma unroll
-          for (int e = 0; e < V; ++e) {
-            const int64_t j = base + (int64_t)t * V + e;
-            pv[e] = (j < b) ? values[j] * in[colind[j]] : T(0);
-          }
-          *reinterpret_cast<val_t*>(&s_prod[pbuf][t * V]) = pv;
-          __syncthreads();
-          const int32_t jlo = max((int64_t)lo, base) - base;
-          const int32_t jhi = min((int64_t)hi, base + TILE) - base;
-          for (int32_t j = jlo; j < jhi; ++j)
-            sum += s_prod[pbuf][j];
-          pbuf ^= 1;
-        }
-      }
-    }
-    if (t < nr) {
-      const int32_t r = r0 + t;
-      const T c = alpha * sum;
-      T y = c;
-      if (beta != T(0))
-        y = c + beta * out[r];
-      out[r] = y;
-      if constexpr (DOT)
-        dot_acc += (double)xr * (double)c;
-    }
-    buf ^= 1;
-    it = itn;
-  }
-
-  if constexpr (DOT)
-    spmv_dot_epilogue(dot, dot_acc, s_red, &s_flag);
-}
-
-// ---------------------------------------------------------------------------
-// ROWBLOCK, wave-private variant: the same algorithm with each of the four
-// waves of a workgroup owning 64 of its 256 rows and a private LDS slice, so
-// no workgroup barrier sits between a wave's loads and its row sums (LDS
-// operations of one wave execute in issue order; wave_barrier() only stops
-// the compiler from reordering them).  Same results, bit for bit.
-// ---------------------------------------------------------------------------
-template <typename T, int CH, bool NT, bool DOT>
-__global__ __launch_bounds__(kBlock) void csr_rowwave_kernel(
-    int32_t num_rows, int64_t nnz, const int32_t* __restrict__ rowptr,
-    const int32_t* __restrict__ colind, const T* __restrict__ values, T alpha,
-    const T* __restrict__ in, T beta, T* __restrict__ out,
-    DotOut dot, RowBlockOrder ord)
-{
-  constexpr int V = VecOf<T>::V;
-  constexpr int W = 64;               // lanes = rows per wave
-  constexpr int NW = kBlock / W;      // waves per workgroup
-  constexpr int TILE = W * CH * V;    // entries per wave tile
-  using val_t = typename VecOf<T>::val_t;
-  using col_t = typename VecOf<T>::col_t;
-
-  __shared__ T s_prod_all[NW][TILE];
-  __shared__ int32_t s_rowptr_all[NW][W + 1];
-  __shared__ double s_red[NW];
-  __shared__ int s_flag;
-
-  const int wave = threadIdx.x / W;
-  const int t = threadIdx.x % W;
-  T* s_prod = s_prod_all[wave];
-  int32_t* s_rowptr = s_rowptr_all[wave];
-  double dot_acc = 0.0;
-
-  const int num_row_blocks = ord.num_row_blocks;
-  const int num_slots = order_slots(ord);
-  for (int it = blockIdx.x; it < num_slots; it += gridDim.x) {
-    int rb = order_row_block(ord, it);
-    if (rb < 0)
-      rb = num_row_blocks;
-    const int64_t r0 = (int64_t)rb * kRows + wave * W;
-    if (rb >= num_row_blocks || r0 >= num_rows)
-      continue; // per wave; no workgroup barrier inside this loop
-    const int nr = (int)min((int64_t)W, (int64_t)num_rows - r0);
-
-    __builtin_amdgcn_wave_barrier();
-    if (t <= nr)
-      s_rowptr[t] = rowptr[r0 + t];
-    if (t == 0 && nr == W)
-      s_rowptr[W] = rowptr[r0 + W];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    const int32_t a = s_rowptr[0];
-    const int32_t b = s_rowptr[nr];
-    int32_t lo = 0, hi = 0;
-    if (t < nr) {
-      lo = s_rowptr[t];
-      hi = s_rowptr[t + 1];
-    }
-    T sum = 0;
-    const int64_t base0 = a & ~(V - 1);
-    const int64_t jclamp = (int64_t)(b - 1) & ~(int64_t)(V - 1);
-    for (int64_t base = base0; base < b; base += TILE) {
-      __builtin_amdgcn_wave_barrier();
-      if (jclamp + V <= nnz) {
-        val_t v[CH];
-        col_t ci[CH];
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-          const int64_t j0 = base + (int64_t)(c * W + t) * V;
-          const int64_t jl = j0 < jclamp ? j0 : jclamp;
-          v[c] = stream_load<NT>(reinterpret_cast<const val_t*>(values + jl));
-          ci[c] = stream_load<NT>(reinterpret_cast<const col_t*>(colind + jl));
-        }
-        T xg[CH][V];
-#pragma unroll
-        for (int c = 0; c < CH; ++c)
-#pragma unroll
-          for (int e = 0; e < V; ++e)
-            xg[c][e] = in[ci[c][e]];
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-          const int64_t j0 = base + (int64_t)(c * W + t) * V;
-          val_t pv;
-#pragma unroll
-          for (int e = 0; e < V; ++e)
-            pv[e] = (j0 + e < b) ? v[c][e] * xg[c][e] : T(0);
-          *reinterpret_cast<val_t*>(&s_prod[(c * W + t) * V]) = pv;
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-          const int64_t j0 = base + (int64_t)(c * W + t) * V;
-          val_t pv;
-#pragma unroll
-          for (int e = 0; e < V; ++e) {
-            const int64_t j = j0 + e;
-            pv[e] = (j < b) ? values[j] * in[colind[j]] : T(0);
-          }
-          *reinterpret_cast<val_t*>(&s_prod[(c * W + t) * V]) = pv;
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      const int32_t jlo = max((int64_t)lo, base) - base;
-      const int32_t jhi = min((int64_t)hi, base + TILE) - base;
-      int32_t j = jlo;
-      for (; j + 4 <= jhi; j += 4) {
-        const T p0 = s_prod[j], p1 = s_prod[j + 1], p2 = s_prod[j + 2],
-                p3 = s_prod[j + 3];
-        sum += p0;
-        sum += p1;
-        sum += p2;
-        sum += p3;
-      }
-      for (; j < jhi; ++j)
-        sum += s_prod[j];
-    }
-    if (t < nr) {
-      const int64_t r = r0 + t;
-      const T c = alpha * sum;
-      T y = c;
-      if (beta != T(0))
-        y = c + beta * out[r];
-      out[r] = y;
-      if constexpr (DOT)
-        dot_acc += (double)in[r] * (double)c;
-    }
-  }
-
-  if constexpr (DOT)
-    spmv_dot_epilogue(dot, dot_acc, s_red, &s_flag);
-}
-
-// ---------------------------------------------------------------------------
 // SCALAR kernel: one lane per row, the reference loop verbatim.
 // ---------------------------------------------------------------------------
 template <typename T, bool DOT>
@@ -913,7 +521,6 @@ __global__ __launch_bounds__(kBlock) void csr_scalar_kernel(
     DotOut dot)
 {
   __shared__ double s_red[kBlock / 64];
-  __shared__ int s_flag;
   double dot_acc = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
        i < num_rows; i += (int64_t)gridDim.x * blockDim.x) {
@@ -929,7 +536,7 @@ __global__ __launch_bounds__(kBlock) void csr_scalar_kernel(
       dot_acc += (double)in[i] * (double)c;
   }
   if constexpr (DOT)
-    spmv_dot_epilogue(dot, dot_acc, s_red, &s_flag);
+    spmv_dot_epilogue(dot, dot_acc, s_red);
 }
 
 // ---------------------------------------------------------------------------
@@ -950,7 +557,6 @@ __global__ __launch_bounds__(kBlock) void csr_rowlist_kernel(
     T* __restrict__ out, DotOut dot)
 {
   __shared__ double s_red[kBlock / 64];
-  __shared__ int s_flag;
   double dot_acc = 0.0;
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
        k < num_listed; k += (int64_t)gridDim.x * blockDim.x) {
@@ -964,7 +570,7 @@ __global__ __launch_bounds__(kBlock) void csr_rowlist_kernel(
       dot_acc += (double)in[i] * (double)c;
   }
   if constexpr (DOT)
-    spmv_dot_epilogue(dot, dot_acc, s_red, &s_flag);
+    spmv_dot_epilogue(dot, dot_acc, s_red);
 }
 
 struct NonEmptyRow {
@@ -983,7 +589,6 @@ __global__ __launch_bounds__(kBlock) void csr_vector_kernel(
     DotOut dot)
 {
   __shared__ double s_red[kBlock / 64];
-  __shared__ int s_flag;
   constexpr int RPB = kBlock / LPR; // rows per workgroup
   const int sub = threadIdx.x % LPR;
   const int grp = threadIdx.x / LPR;
@@ -1011,361 +616,8 @@ __global__ __launch_bounds__(kBlock) void csr_vector_kernel(
     }
   }
   if constexpr (DOT)
-    spmv_dot_epilogue(dot, dot_acc, s_red, &s_flag);
+    spmv_dot_epilogue(dot, dot_acc, s_red);
 }
-
-// ---------------------------------------------------------------------------
-// Symmetric kernels
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void atomic_add(double* p, double v)
-{
-  unsafeAtomicAdd(p, v); // global_atomic_add_f64, no CAS loop
-}
-__device__ __forceinline__ void atomic_add(float* p, float v)
-{
-  unsafeAtomicAdd(p, v);
-}
-
-// out *= beta (zero-fill for beta == 0 without reading out: SURVEY F7b)
-template <typename T>
-__global__ __launch_bounds__(kBlock) void scale_kernel(int64_t n, T beta,
-                                                       T* __restrict__ out)
-{
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x)
-    out[i] = (beta == T(0)) ? T(0) : beta * out[i];
-}
-
-// diagonal-only block: out = alpha*d*x + beta*out
-// (openmp/csr_kernels.openmp.cpp:222-225 covers the same nnz == 0 case)
-template <typename T>
-__global__ __launch_bounds__(kBlock) void diag_kernel(
-    int64_t n, const T* __restrict__ diagonal, T alpha,
-    const T* __restrict__ in, T beta, T* __restrict__ out)
-{
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    T y = alpha * (diagonal[i] * in[i]);
-    if (beta != T(0))
-      y = y + beta * out[i];
-    out[i] = y;
-  }
-}
-
-template <typename T, int CH, bool NT, bool ALIGNED>
-__global__ __launch_bounds__(kBlock) void csr_sym_rowblock_kernel(
-    int32_t num_rows, int64_t nnz, const int32_t* __restrict__ rowptr,
-    const int32_t* __restrict__ colind, const T* __restrict__ values,
-    const T* __restrict__ diagonal, T alpha, const T* __restrict__ in,
-    T* __restrict__ out, int num_row_blocks, DotOut dot)
-{
-  constexpr int V = VecOf<T>::V;
-  constexpr int TILE = kBlock * CH * V;
-  __shared__ double s_red[kBlock / 64];
-  __shared__ int s_flag;
-  double dot_acc = 0.0;
-  using val_t = typename VecOf<T>::val_t;
-  using col_t = typename VecOf<T>::col_t;
-
-  __shared__ T s_prod[TILE];
-  __shared__ T s_val[TILE];
-  __shared__ int32_t s_col[TILE];
-  __shared__ int32_t s_rowptr[kRows + 1];
-
-  const int t = threadIdx.x;
-  for (int rb = blockIdx.x; rb < num_row_blocks; rb += gridDim.x) {
-    const int32_t r0 = rb * kRows;
-    const int nr = min(kRows, num_rows - r0);
-    __syncthreads();
-    if (t <= nr)
-      s_rowptr[t] = rowptr[r0 + t];
-    if (t == 0 && nr == kRows)
-      s_rowptr[kRows] = rowptr[r0 + kRows];
-    __syncthreads();
-
-    const int32_t a = s_rowptr[0];
-    const int32_t b = s_rowptr[nr];
-    int32_t lo = 0, hi = 0;
-    T xi = 0, sum = 0;
-    if (t < nr) {
-      lo = s_rowptr[t];
-      hi = s_rowptr[t + 1];
-      xi = in[r0 + t];
-      sum = diagonal[r0 + t] * xi; // csr_kernels.cpp:28
-    }
-
-    const int64_t base0 = a & ~(V - 1);
-    const int64_t jclamp = (int64_t)(b - 1) & ~(int64_t)(V - 1);
-    for (int64_t base = base0; base < b; base += TILE) {
-      if (base != base0)
-        __syncthreads();
-      if (ALIGNED && jclamp + V <= nnz) {
-        // fast path: all matrix loads, then all gathers (see general kernel)
-        val_t v[CH];
-        col_t ci[CH];
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-          const int64_t j0 = base + (int64_t)(c * kBlock + t) * V;
-          const int64_t jl = j0 < jclamp ? j0 : jclamp;
-          v[c] = stream_load<NT>(reinterpret_cast<const val_t*>(values + jl));
-          ci[c] = stream_load<NT>(reinterpret_cast<const col_t*>(colind + jl));
-        }
-        T xg[CH][V];
-#pragma unroll
-        for (int c = 0; c < CH; ++c)
-#pragma unroll
-          for (int e = 0; e < V; ++e)
-            xg[c][e] = in[ci[c][e]];
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-          const int slot = (c * kBlock + t) * V;
-          const int64_t j0 = base + slot;
-          val_t pv;
-#pragma unroll
-          for (int e = 0; e < V; ++e)
-            pv[e] = (j0 + e < b) ? v[c][e] * xg[c][e] : T(0);
-          *reinterpret_cast<val_t*>(&s_prod[slot]) = pv;
-          *reinterpret_cast<val_t*>(&s_val[slot]) = v[c];
-          *reinterpret_cast<col_t*>(&s_col[slot]) = ci[c];
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-          const int slot = (c * kBlock + t) * V;
-#pragma unroll
-          for (int e = 0; e < V; ++e) {
-            const int64_t j = base + slot + e;
-            const bool live = j < b;
-            const T vv = live ? values[j] : T(0);
-            const int32_t cc = live ? colind[j] : 0;
-            s_prod[slot + e] = live ? vv * in[cc] : T(0);
-            s_val[slot + e] = vv;
-            s_col[slot + e] = cc;
-          }
-        }
-      }
-      __syncthreads();
-      const int32_t jlo = max((int64_t)lo, base) - base;
-      const int32_t jhi = min((int64_t)hi, base + TILE) - base;
-      for (int32_t k = jlo; k < jhi; ++k) {
-        sum += s_prod[k];                                  // csr_kernels.cpp:34
-        atomic_add(&out[s_col[k]], alpha * s_val[k] * xi); // :35
-      }
-    }
-    if (t < nr) {
-      atomic_add(&out[r0 + t], alpha * sum); // :39 (beta applied by pre-pass)
-      // in . (alpha A in) with A = L + D + L^T: row i contributes
-      // x_i (2 (d_i x_i + (L x)_i) - d_i x_i); the L^T terms are the mirror
-      // images of the L terms, so no finished `out` is needed.
-      dot_acc += (double)xi
-                 * (double)(alpha * (sum + (sum - diagonal[r0 + t] * xi)));
-    }
-  }
-  if (dot.partials) // uniform
-    spmv_dot_epilogue(dot, dot_acc, s_red, &s_flag);
-}
-
-// ---------------------------------------------------------------------------
-// Symmetric kernel with an LDS accumulation window.
-//
-// The plain symmetric kernel issues (entries per row + 1) global fp64 atomics
-// per row and runs at the chip-wide atomic rate, not at the HBM rate.  Here a
-// workgroup owns kSymRows consecutive rows and keeps a window of `out`
-// covering rows [r0 - low, r0 + kSymRows) in LDS: the row owner's alpha*sum
-// and every scattered term whose target falls inside the window are added
-// with LDS atomics (ds_add_f64); only targets below the window go to global
-// atomics.  At the end the window is added to `out` with ONE coalesced pass
-// of global atomics (256 contiguous doubles per wave-instruction, the shape
-// the atomic units run fastest at).  For a 7-point stencil with n <= low the
-// global atomics drop from 4 to ~2.25 per row.  Works for any matrix: the
-// window only decides where an add is staged.
-// ---------------------------------------------------------------------------
-// kSymRows = rows per workgroup (a multiple of 256, walked in sub-blocks)
-template <typename T, int kSymRows, bool NT, bool ALIGNED>
-__global__ __launch_bounds__(kBlock) void csr_sym_window_kernel(
-    int32_t num_rows, int64_t nnz, const int32_t* __restrict__ rowptr,
-    const int32_t* __restrict__ colind, const T* __restrict__ values,
-    const T* __restrict__ diagonal, T alpha, const T* __restrict__ in,
-    T* __restrict__ out, int num_blocks, int low, DotOut dot)
-{
-  __shared__ double s_red[kBlock / 64];
-  __shared__ int s_flag;
-  double dot_acc = 0.0;
-  constexpr int V = VecOf<T>::V;
-  constexpr int TILE = kBlock * V;
-  using val_t = typename VecOf<T>::val_t;
-  using col_t = typename VecOf<T>::col_t;
-
-  extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-  T* s_acc = reinterpret_cast<T*>(s_dyn); // low + kSymRows entries
-  __shared__ T s_prod[TILE];
-  __shared__ T s_val[TILE];
-  __shared__ int32_t s_col[TILE];
-  __shared__ int32_t s_rowptr[kRows + 1];
-
-  const int t = threadIdx.x;
-  const int win = low + kSymRows;
-  for (int blk = blockIdx.x; blk < num_blocks; blk += gridDim.x) {
-    const int64_t r_first = (int64_t)blk * kSymRows;
-    const int64_t win_lo = r_first - low; // may be negative near row 0
-    __syncthreads();                      // previous flush finished
-    for (int j = t; j < win; j += kBlock)
-      s_acc[j] = T(0);
-
-    for (int sb = 0; sb < kSymRows / kRows; ++sb) {
-      const int64_t r0 = r_first + (int64_t)sb * kRows;
-      if (r0 >= num_rows)
-        break; // uniform
-      const int nr = (int)min((int64_t)kRows, (int64_t)num_rows - r0);
-      __syncthreads(); // s_acc zeroed / previous sub-block done with LDS tiles
-      if (t <= nr)
-        s_rowptr[t] = rowptr[r0 + t];
-      if (t == 0 && nr == kRows)
-        s_rowptr[kRows] = rowptr[r0 + kRows];
-      __syncthreads();
-
-      const int32_t a = s_rowptr[0];
-      const int32_t b = s_rowptr[nr];
-      int32_t lo = 0, hi = 0;
-      T xi = 0, sum = 0;
-      if (t < nr) {
-        lo = s_rowptr[t];
-        hi = s_rowptr[t + 1];
-        xi = in[r0 + t];
-        sum = diagonal[r0 + t] * xi; // csr_kernels.cpp:28
-      }
-      const int64_t base0 = a & ~(V - 1);
-      const int64_t jclamp = (int64_t)(b - 1) & ~(int64_t)(V - 1);
-      for (int64_t base = base0; base < b; base += TILE) {
-        if (base != base0)
-          __syncthreads();
-        const int slot = t * V;
-        const int64_t j0 = base + slot;
-        if (ALIGNED && jclamp + V <= nnz) {
-          const int64_t jl = j0 < jclamp ? j0 : jclamp;
-          val_t v = stream_load<NT>(reinterpret_cast<const val_t*>(values + jl));
-          col_t ci = stream_load<NT>(reinterpret_cast<const col_t*>(colind + jl));
-          T xg[V];
-#pragma unroll
-          for (int e = 0; e < V; ++e)
-            xg[e] = in[ci[e]];
-          val_t pv;
-#pragma unroll
-          for (int e = 0; e < V; ++e)
-            pv[e] = (j0 + e < b) ? v[e] * xg[e] : T(0);
-          *reinterpret_cast<val_t*>(&s_prod[slot]) = pv;
-          *reinterpret_cast<val_t*>(&s_val[slot]) = v;
-          *reinterpret_cast<col_t*>(&s_col[slot]) = ci;
-        } else {
-#pragma unroll
-          for (int e = 0; e < V; ++e) {
-            const int64_t j = j0 + e;
-            const bool live = j < b;
-            const T vv = live ? values[j] : T(0);
-            const int32_t cc = live ? colind[j] : 0;
-            s_prod[slot + e] = live ? vv * in[cc] : T(0);
-            s_val[slot + e] = vv;
-            s_col[slot + e] = cc;
-          }
-        }
-        __syncthreads();
-        const int32_t jlo = max((int64_t)lo, base) - base;
-        const int32_t jhi = min((int64_t)hi, base + TILE) - base;
-        for (int32_t k = jlo; k < jhi; ++k) {
-          sum += s_prod[k];                     // csr_kernels.cpp:34
-          const T term = alpha * s_val[k] * xi; // :35
-          const int64_t c = s_col[k];
-          if (c >= win_lo && c < win_lo + win)
-            atomic_add(&s_acc[c - win_lo], term); // ds_add
-          else
-            atomic_add(&out[c], term);
-        }
-      }
-      if (t < nr) { // :39, beta already applied by the pre-pass
-        atomic_add(&s_acc[r0 + t - win_lo], alpha * sum);
-        // this row's share of in . (alpha A in), see csr_sym_rowblock_kernel
-        dot_acc += (double)xi
-                   * (double)(alpha * (sum + (sum - diagonal[r0 + t] * xi)));
-      }
-    }
-    __syncthreads();
-    // flush: one coalesced pass of global atomics over the window
-    for (int j = t; j < win; j += kBlock) {
-      const int64_t g = win_lo + j;
-      const T v = s_acc[j];
-      if (g >= 0 && g < num_rows && v != T(0))
-        atomic_add(&out[g], v);
-    }
-  }
-  if (dot.partials) // uniform
-    spmv_dot_epilogue(dot, dot_acc, s_red, &s_flag);
-}
-
-template <typename T>
-bool aligned16(const T* p)
-{
-  return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
-}
-
-} // namespace
-
-// ---------------------------------------------------------------------------
-// Plan = CSRSpMV::_aux_data
-// ---------------------------------------------------------------------------
-struct spmv_hip_csr_plan {
-  spmv_hip_ctx* ctx = nullptr;
-  int32_t num_rows = 0, num_cols = 0;
-  int64_t nnz = 0;
-  bool symmetric = false;
-  int algo = SPMV_HIP_ALGO_ROWBLOCK;
-  int lanes_per_row = 8;  // VECTOR
-  int chunks = 1;         // ROWBLOCK: 16-B loads per lane per tile (1, 2, 4)
-  int nontemporal = 0;    // ROWBLOCK: nt loads on the matrix stream
-  int xcd_group = 16;     // ROWBLOCK: consecutive row blocks per XCD (0 = off)
-  // All 8 workgroups per CU (= 32 waves, the occupancy limit).  Leaving one
-  // slot per CU free for the RCCL halo kernel cost the LX kernel 6 % and, at
-  // 19.6 KB of LDS per workgroup, would not leave a communication kernel the
-  // LDS it needs anyway; the halo is enqueued first, on a high-priority
-  // stream, and takes its slots before the persistent grid fills the chip.
-  int blocks_per_cu = kBlocksPerCU;
-  int wave_private = 0;   // ROWBLOCK: wave-private LDS slices, no barriers
-  int pipeline = 0;       // ROWBLOCK: software-pipelined variant
-  int sym_window = 256;   // symmetric: LDS window below the block (0 = plain
-                          // per-entry global atomics)
-  int sym_rows = 1024;    // symmetric: rows per workgroup (512, 1024, 2048)
-  int32_t* row_list = nullptr; // ROWLIST: device list of non-empty rows
-  int32_t num_listed = 0;
-  // ROWBLOCK: band-sweep order table for lattice-structured matrices whose far
-  // planes do not fit the L2s (build_band_order); band_order = 0 ignores it
-  int32_t* order = nullptr;
-  int order_slots = 0;
-  int band_order = 0;
-  int nt_store = 0; // non-temporal y stores
-  // ROWBLOCK "LX" form: LDS-staged x windows + 16-bit local column indices
-  // (csr_rowblock_lx_kernel); built by plan_create when most row blocks qualify
-  uint16_t* lx_lidx = nullptr;
-  int32_t* lx_tab = nullptr; // kLxRec ints per row block
-  int lx = 0;            // use it (plan_set "lx")
-  int lx_chunks = 2;     // 16-byte value loads per lane per tile (1 or 2):
-                         // 2 = half the barriers, measured +7-8 % at every size
-  int lx_staged = 0;     // row blocks that take the staged path
-  int lx_blocks = 0;     // row blocks analysed
-  int lattice_d1 = 0, lattice_d2 = 0, band_lines = 0; // what was detected
-
-  RowBlockOrder row_block_order(int nrb) const
-  {
-    RowBlockOrder o;
-    o.table = band_order ? order : nullptr;
-    o.num_slots = order_slots;
-    o.xcd_group = xcd_group;
-    o.num_row_blocks = nrb;
-    o.nt_store = nt_store;
-    return o;
-  }
-};
-
-namespace
-{
 
 template <typename T, int CH, bool NT, bool ALIGNED, bool DOT>
 int launch_rowblock_x(const spmv_hip_csr_plan* pl, hipStream_t st, int grid,
@@ -1374,7 +626,7 @@ int launch_rowblock_x(const spmv_hip_csr_plan* pl, hipStream_t st, int grid,
                       DotOut dot)
 {
   const RowBlockOrder ord = pl->row_block_order(nrb);
-  if (ord.table || ord.xcd_group > 0)
+  if (ord.xcd_group > 0)
     hipLaunchKernelGGL((csr_rowblock_kernel<T, CH, NT, ALIGNED, DOT, true>),
                        dim3(grid), dim3(kBlock), 0, st, pl->num_rows, pl->nnz,
                        rowptr, colind, values, alpha, in, beta, out, dot, ord);
@@ -1400,11 +652,18 @@ int launch_rowblock(const spmv_hip_csr_plan* pl, hipStream_t st,
     grid = nrb;
   if (grid < 1)
     grid = 1;
-  // slots it with equal it % 8 must stay on one XCD (order table, XCD groups)
+  // slots it with equal it % 8 must stay on one XCD (XCD groups)
   if (grid >= 8)
     grid -= grid % 8;
   const bool al = aligned16(values) && aligned16(colind);
-  if (pl->lx && al && aligned16(in) && !pl->pipeline && !pl->wave_private) {
+  if (pl->lat && aligned16(values)) {
+    if constexpr (sizeof(T) == 8)
+      return spmv_lat_run_f64(pl, st, rowptr, values, alpha, in, beta, out,
+                              DOT ? dot : DotOut());
+    else
+      return spmv_lat_run_f32(pl, st, rowptr, values, alpha, in, beta, out);
+  }
+  if (pl->lx && al && aligned16(in)) {
     LxView lx{pl->lx_lidx, pl->lx_tab};
 #define SPMV_LX(NT, CH)                                                        \
   hipLaunchKernelGGL((csr_rowblock_lx_kernel<T, NT, DOT, CH>), dim3(grid),     \
@@ -1423,45 +682,6 @@ int launch_rowblock(const spmv_hip_csr_plan* pl, hipStream_t st,
         SPMV_LX(false, 1);
     }
 #undef SPMV_LX
-    SPMV_CHECK_LAUNCH();
-    return SPMV_HIP_OK;
-  }
-  if (pl->pipeline && al) {
-    if (pl->nontemporal)
-      hipLaunchKernelGGL((csr_rowblock_pipe_kernel<T, true, DOT>), dim3(grid),
-                         dim3(kBlock), 0, st, pl->num_rows, pl->nnz, rowptr,
-                         colind, values, alpha, in, beta, out, dot,
-                         pl->row_block_order(nrb));
-    else
-      hipLaunchKernelGGL((csr_rowblock_pipe_kernel<T, false, DOT>), dim3(grid),
-                         dim3(kBlock), 0, st, pl->num_rows, pl->nnz, rowptr,
-                         colind, values, alpha, in, beta, out, dot,
-                         pl->row_block_order(nrb));
-    SPMV_CHECK_LAUNCH();
-    return SPMV_HIP_OK;
-  }
-  if (pl->wave_private && al) {
-#define SPMV_RW(CH, NT)                                                        \
-  hipLaunchKernelGGL((csr_rowwave_kernel<T, CH, NT, DOT>), dim3(grid),         \
-                     dim3(kBlock), 0, st, pl->num_rows, pl->nnz, rowptr,       \
-                     colind, values, alpha, in, beta, out, dot,                \
-                     pl->row_block_order(nrb))
-    if (pl->nontemporal) {
-      if (pl->chunks == 1)
-        SPMV_RW(1, true);
-      else if (pl->chunks == 2)
-        SPMV_RW(2, true);
-      else
-        SPMV_RW(4, true);
-    } else {
-      if (pl->chunks == 1)
-        SPMV_RW(1, false);
-      else if (pl->chunks == 2)
-        SPMV_RW(2, false);
-      else
-        SPMV_RW(4, false);
-    }
-#undef SPMV_RW
     SPMV_CHECK_LAUNCH();
     return SPMV_HIP_OK;
   }
@@ -1573,92 +793,6 @@ int run_general(const spmv_hip_csr_plan* pl, hipStream_t st,
   }
 }
 
-template <typename T>
-int run_symmetric(const spmv_hip_csr_plan* pl, hipStream_t st,
-                  const int32_t* rowptr, const int32_t* colind,
-                  const T* values, const T* diagonal, T alpha, const T* in,
-                  T beta, T* out, DotOut dot = DotOut())
-{
-  if (diagonal == nullptr)
-    return SPMV_HIP_EINVAL;
-  if (dot.partials && pl->nnz == 0)
-    return SPMV_HIP_ENOTSUP; // diagonal-only block: caller uses a plain dot
-  const int n = pl->num_rows;
-  if (pl->nnz == 0) {
-    const int grid = spmv_grid_for(pl->ctx, n, kBlock);
-    hipLaunchKernelGGL((diag_kernel<T>), dim3(grid), dim3(kBlock), 0, st,
-                       (int64_t)n, diagonal, alpha, in, beta, out);
-    SPMV_CHECK_LAUNCH();
-    return SPMV_HIP_OK;
-  }
-  // pre-pass: out *= beta (zero-fill when beta == 0)
-  if (beta != T(1)) {
-    if (beta == T(0)) {
-      SPMV_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(T) * (size_t)n, st));
-    } else {
-      const int grid = spmv_grid_for(pl->ctx, n, kBlock);
-      hipLaunchKernelGGL((scale_kernel<T>), dim3(grid), dim3(kBlock), 0, st,
-                         (int64_t)n, beta, out);
-      SPMV_CHECK_LAUNCH();
-    }
-  }
-  const bool al = aligned16(values) && aligned16(colind);
-  if (pl->sym_window > 0) {
-    const int srows = pl->sym_rows;
-    const int nblk = (n + srows - 1) / srows;
-    const size_t lds = sizeof(T) * (size_t)(pl->sym_window + srows);
-    // LDS per workgroup: window + ~11.5 KB of tiles; as many workgroups per
-    // CU as the 160 KB allow (<= 8)
-    int per_cu = (int)((160 * 1024) / (lds + 11776));
-    per_cu = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
-    if (per_cu > pl->blocks_per_cu)
-      per_cu = pl->blocks_per_cu;
-    int grid = pl->ctx->num_cus * per_cu;
-    if (grid > nblk)
-      grid = nblk;
-#define SPMV_SYMW(R, NT, AL)                                                   \
-  hipLaunchKernelGGL((csr_sym_window_kernel<T, R, NT, AL>), dim3(grid),        \
-                     dim3(kBlock), lds, st, n, pl->nnz, rowptr, colind,        \
-                     values, diagonal, alpha, in, out, nblk, pl->sym_window,   \
-                     dot)
-#define SPMV_SYMW_R(NT, AL)                                                    \
-  do {                                                                         \
-    if (srows == 512)                                                          \
-      SPMV_SYMW(512, NT, AL);                                                  \
-    else if (srows == 2048)                                                    \
-      SPMV_SYMW(2048, NT, AL);                                                 \
-    else                                                                       \
-      SPMV_SYMW(1024, NT, AL);                                                 \
-  } while (0)
-    if (!al)
-      SPMV_SYMW_R(false, false);
-    else if (pl->nontemporal)
-      SPMV_SYMW_R(true, true);
-    else
-      SPMV_SYMW_R(false, true);
-#undef SPMV_SYMW_R
-#undef SPMV_SYMW
-    SPMV_CHECK_LAUNCH();
-    return SPMV_HIP_OK;
-  }
-  const int nrb = (n + kRows - 1) / kRows;
-  int grid = pl->ctx->num_cus * pl->blocks_per_cu;
-  if (grid > nrb)
-    grid = nrb;
-#define SPMV_SYM(CH, NT, AL)                                                   \
-  hipLaunchKernelGGL((csr_sym_rowblock_kernel<T, CH, NT, AL>), dim3(grid),     \
-                     dim3(kBlock), 0, st, n, pl->nnz, rowptr, colind, values,  \
-                     diagonal, alpha, in, out, nrb, dot)
-  if (!al)
-    SPMV_SYM(1, false, false);
-  else if (pl->nontemporal)
-    SPMV_SYM(1, true, true);
-  else
-    SPMV_SYM(1, false, true);
-#undef SPMV_SYM
-  SPMV_CHECK_LAUNCH();
-  return SPMV_HIP_OK;
-}
 
 // Compact the indices of the non-empty rows on the device (plan time, once).
 int build_row_list(spmv_hip_csr_plan* pl, const int32_t* rowptr)
@@ -1696,77 +830,6 @@ int build_row_list(spmv_hip_csr_plan* pl, const int32_t* rowptr)
     return static_cast<int>(e);
   }
   pl->num_listed = count;
-  return SPMV_HIP_OK;
-}
-
-// ---------------------------------------------------------------------------
-// Band-sweep order for lattice-structured matrices (plan time, host side).
-//
-// Rows of a 3-D stencil in natural ordering couple to rows +-1, +-D1 (next
-// grid line) and +-D2 (next grid plane).  In row order the three uses of an x
-// plane by the planes z-1, z, z+1 lie D2 rows apart; once D2 rows of matrix
-// stream exceed what the L2s hold, every XCD pulls every x plane through its
-// L2 three to four times, and that refetch traffic -- not HBM -- caps the
-// kernel (measured with tools/membench/spmv_probe: 4.8 -> 5.6 TB/s on the
-// gather stage at 512^3).  The order built here cuts the grid's y axis into
-// bands of `yc` lines, gives each XCD its own bands and lets it sweep a band
-// through all planes: the lines z-1, z, z+1 of a band stay in that XCD's L2
-// and every x value is fetched about once.
-//
-// Nothing here depends on the matrix being exactly a stencil: D1 and D2 only
-// choose a permutation of the row blocks, so a wrong guess costs speed, never
-// correctness.
-// ---------------------------------------------------------------------------
-
-// Column offsets that at least half of `rows` sampled rows share.
-int detect_lattice(spmv_hip_csr_plan* pl, const int32_t* rowptr,
-                   const int32_t* colind)
-{
-  pl->lattice_d1 = pl->lattice_d2 = 0;
-  constexpr int kSample = 64;
-  if (pl->num_rows < 8 * kSample || pl->nnz == 0)
-    return SPMV_HIP_OK;
-  SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
-  SPMV_CHECK_HIP(hipDeviceSynchronize()); // the arrays may still be in flight
-  const int32_t r_first = pl->num_rows / 2;
-  int32_t rp[kSample + 1];
-  SPMV_CHECK_HIP(hipMemcpy(rp, rowptr + r_first, sizeof(rp),
-                           hipMemcpyDeviceToHost));
-  const int64_t count = (int64_t)rp[kSample] - rp[0];
-  if (count <= 0 || count > 64 * 1024) // long rows: not a stencil
-    return SPMV_HIP_OK;
-  std::vector<int32_t> cols((size_t)count);
-  SPMV_CHECK_HIP(hipMemcpy(cols.data(), colind + rp[0],
-                           sizeof(int32_t) * (size_t)count,
-                           hipMemcpyDeviceToHost));
-  std::map<int64_t, int> rows_with; // |offset| -> sampled rows containing it
-  for (int i = 0; i < kSample; ++i) {
-    std::vector<int64_t> seen;
-    for (int32_t j = rp[i]; j < rp[i + 1]; ++j) {
-      int64_t d = (int64_t)cols[(size_t)(j - rp[0])] - (r_first + i);
-      d = d < 0 ? -d : d;
-      if (d > 0 && std::find(seen.begin(), seen.end(), d) == seen.end())
-        seen.push_back(d);
-    }
-    for (int64_t d : seen)
-      ++rows_with[d];
-  }
-  int64_t d1 = 0, d2 = 0;
-  for (const auto& kv : rows_with) { // ascending |offset|
-    if (kv.second * 2 < kSample)
-      continue;
-    if (d1 == 0) {
-      if (kv.first >= 8)
-        d1 = kv.first;
-    } else if (kv.first >= 8 * d1 && kv.first % d1 == 0) {
-      d2 = kv.first;
-      break;
-    }
-  }
-  if (d1 > 0 && d2 > 0 && d2 < INT32_MAX) {
-    pl->lattice_d1 = (int)d1;
-    pl->lattice_d2 = (int)d2;
-  }
   return SPMV_HIP_OK;
 }
 
@@ -1868,67 +931,6 @@ int build_lx(spmv_hip_csr_plan* pl, const int32_t* rowptr,
   return SPMV_HIP_OK;
 }
 
-// (Re)build the order table for bands of `yc` lines (0 = choose).  Needs a
-// detected lattice.
-int build_band_order(spmv_hip_csr_plan* pl, int yc)
-{
-  SPMV_REQUIRE(pl->lattice_d1 > 0 && pl->lattice_d2 > 0);
-  SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
-  const int64_t d1 = pl->lattice_d1, d2 = pl->lattice_d2;
-  const int64_t ny = d2 / d1;
-  const int64_t nz = (pl->num_rows + d2 - 1) / d2;
-  const int nrb = (pl->num_rows + kRows - 1) / kRows;
-  if (yc <= 0) {
-    // lines z-1 .. z+2 of a band (the resident workgroups span about two
-    // sweep steps) should take well under half of one 4 MiB L2
-    int64_t ymax = ((int64_t)3 << 19) / (32 * d1) - 2;
-    ymax = ymax < 8 ? 8 : ymax;
-    int64_t nb = (ny + ymax - 1) / ymax;
-    nb = (nb + 7) / 8 * 8; // every XCD gets the same number of bands
-    yc = (int)((ny + nb - 1) / nb);
-  }
-  yc = yc < 1 ? 1 : yc;
-  // key = (band, plane, line); row blocks keep their order inside a line
-  std::vector<std::pair<int64_t, int32_t>> keyed((size_t)nrb);
-  for (int k = 0; k < nrb; ++k) {
-    const int64_t line = ((int64_t)k * kRows) / d1;
-    const int64_t y = line % ny, z = line / ny;
-    const int64_t band = y / yc;
-    keyed[(size_t)k] = {((band * nz + z) * ny + y), k};
-  }
-  std::stable_sort(keyed.begin(), keyed.end());
-  std::vector<std::vector<int32_t>> lists(8);
-  for (const auto& kv : keyed) {
-    const int64_t band = kv.first / (nz * ny);
-    lists[(size_t)(band % 8)].push_back(kv.second);
-  }
-  size_t longest = 0;
-  for (const auto& l : lists)
-    longest = std::max(longest, l.size());
-  std::vector<int32_t> table(8 * longest, -1);
-  for (size_t x = 0; x < 8; ++x)
-    for (size_t i = 0; i < lists[x].size(); ++i)
-      table[8 * i + x] = lists[x][i];
-  if (pl->order) {
-    SPMV_CHECK_HIP(hipDeviceSynchronize()); // no launch still reads the old one
-    (void)hipFree(pl->order);
-    pl->order = nullptr;
-    pl->order_slots = 0;
-  }
-  SPMV_CHECK_HIP(hipMalloc(&pl->order, sizeof(int32_t) * table.size()));
-  hipError_t e = hipMemcpy(pl->order, table.data(),
-                           sizeof(int32_t) * table.size(),
-                           hipMemcpyHostToDevice);
-  if (e != hipSuccess) {
-    (void)hipFree(pl->order);
-    pl->order = nullptr;
-    return static_cast<int>(e);
-  }
-  pl->order_slots = (int)table.size();
-  pl->band_lines = yc;
-  return SPMV_HIP_OK;
-}
-
 } // namespace
 
 extern "C" {
@@ -1983,19 +985,17 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
   // Cache with room to spare (216^3) and -3 % when it does not (512^3).
   pl->nontemporal = ((int64_t)num_cols * 8 <= (int64_t)128 << 20) ? 1 : 0;
   if (!symmetric && algo == SPMV_HIP_ALGO_ROWBLOCK) {
-    // Only the detection runs here.  The band-sweep order itself is opt-in
-    // (plan_set "band_lines"): on MI355X it lifted the gather stage of the
-    // probe kernel by 5-17 % at 512^3 but left the full kernel, whose row sums
-    // sit behind workgroup barriers, unchanged to 8 % slower.
-    int rc = detect_lattice(pl, rowptr, colind);
-    // LX form: from ctx->lx_min_nnz entries on (set-up time, memory), rows
-    // short enough for the plan kernel's sort, and only while x fits the
-    // Infinity Cache: measured +2...8 % at 128^3 and 216^3, equal at 256^3,
-    // 1-6 % slower from 320^3 on (there the row-block kernels are bound by
-    // their dependent chain of loads, not by bytes, and the extra table loads
-    // lengthen it)
-    if (rc == SPMV_HIP_OK && num_non_zeros >= ctx->lx_min_nnz && avg <= 16.0
-        && (int64_t)num_cols * 8 <= ctx->lx_max_x_bytes)
+    // Lattice form first (spmv_lat.hip): when every row block's columns are
+    // row + one of <= 8 constant offsets the kernel needs no index stream at
+    // all.  Otherwise the LX form: from ctx->lx_min_nnz entries on (set-up
+    // time, +2 B per entry of memory) and rows short enough for the plan
+    // kernel's sort; measured faster than the gather kernel at every size
+    // from 128^3 to 512^3.
+    int rc = SPMV_HIP_OK;
+    if (num_non_zeros >= ctx->lat_min_nnz && avg <= 8.0)
+      rc = spmv_lat_build(pl, rowptr, colind);
+    if (rc == SPMV_HIP_OK && !pl->lat && num_non_zeros >= ctx->lx_min_nnz
+        && avg <= 16.0 && (int64_t)num_cols * 8 <= ctx->lx_max_x_bytes)
       rc = build_lx(pl, rowptr, colind);
     if (rc != SPMV_HIP_OK) {
       spmv_hip_csr_plan_destroy(pl);
@@ -2008,11 +1008,11 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
 
 int spmv_hip_csr_plan_destroy(spmv_hip_csr_plan* plan)
 {
-  if (plan && (plan->row_list || plan->order || plan->lx_lidx)) {
+  if (plan && (plan->row_list || plan->lx_lidx || plan->lat_tab)) {
     (void)hipSetDevice(plan->ctx->device);
     (void)hipFree(plan->row_list);
-    (void)hipFree(plan->order);
     free_lx(plan);
+    spmv_lat_free(plan);
   }
   delete plan;
   return SPMV_HIP_OK;
@@ -2046,10 +1046,6 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
   } else if (!strcmp(key, "xcd_group")) {
     SPMV_REQUIRE(value >= 0 && value <= 4096);
     plan->xcd_group = value;
-  } else if (!strcmp(key, "pipeline")) {
-    plan->pipeline = value != 0;
-  } else if (!strcmp(key, "wave_private")) {
-    plan->wave_private = value != 0;
   } else if (!strcmp(key, "sym_window")) {
     SPMV_REQUIRE(value >= 0 && value <= 4096 && value % 256 == 0);
     plan->sym_window = value;
@@ -2068,16 +1064,16 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
     plan->lx_chunks = value;
   } else if (!strcmp(key, "nt_store")) {
     plan->nt_store = value != 0;
-  } else if (!strcmp(key, "band_order")) {
-    plan->band_order = value != 0; // 0: ignore the order table
-  } else if (!strcmp(key, "band_lines")) {
-    // (re)build the band-sweep table with bands of `value` grid lines
-    // (0 = automatic); EINVAL when no lattice was detected at plan creation
-    SPMV_REQUIRE(value >= 0);
-    const int rc = build_band_order(plan, value);
-    if (rc == SPMV_HIP_OK)
-      plan->band_order = 1;
-    return rc;
+  } else if (!strcmp(key, "lat")) {
+    // 1 needs the lattice form built at plan creation
+    SPMV_REQUIRE(value == 0 || plan->lat_tab);
+    plan->lat = value != 0;
+  } else if (!strcmp(key, "lat_xcd_group")) {
+    SPMV_REQUIRE(value >= 0 && value <= 4096);
+    plan->lat_xcd_group = value;
+  } else if (!strcmp(key, "lat_blocks_per_cu")) {
+    SPMV_REQUIRE(value >= 1 && value <= kBlocksPerCU);
+    plan->lat_blocks_per_cu = value;
   } else {
     return SPMV_HIP_EINVAL;
   }
@@ -2090,16 +1086,10 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
   SPMV_REQUIRE(plan && key && value);
   if (!strcmp(key, "algo"))
     *value = plan->algo;
-  else if (!strcmp(key, "lattice_d1"))
-    *value = plan->lattice_d1;
-  else if (!strcmp(key, "lattice_d2"))
-    *value = plan->lattice_d2;
-  else if (!strcmp(key, "band_lines"))
-    *value = plan->order ? plan->band_lines : 0;
-  else if (!strcmp(key, "order_slots"))
-    *value = plan->order ? plan->order_slots : 0;
-  else if (!strcmp(key, "band_order"))
-    *value = plan->band_order && plan->order ? 1 : 0;
+  else if (!strcmp(key, "lat"))
+    *value = plan->lat;
+  else if (!strcmp(key, "lat_blocks"))
+    *value = plan->lat_blocks;
   else if (!strcmp(key, "lx"))
     *value = plan->lx;
   else if (!strcmp(key, "lx_staged"))
@@ -2138,7 +1128,7 @@ int spmv_hip_csr_spmv_f64(spmv_hip_ctx* ctx, const spmv_hip_csr_plan* plan,
     DotOut dot;
     dot.partials = dot_partials; // may be NULL
     dot.len = ctx->dot_blocks;
-    return run_symmetric<double>(plan, st, rowptr, colind, values, diagonal,
+    return spmv_run_symmetric_f64(plan, st, rowptr, colind, values, diagonal,
                                  alpha, in, beta, out, dot);
   }
   if (num_non_zeros == 0) {
@@ -2163,32 +1153,6 @@ int spmv_hip_csr_spmv_f64(spmv_hip_ctx* ctx, const spmv_hip_csr_plan* plan,
                                     beta, out, DotOut());
 }
 
-int spmv_hip_csr_spmv_dot_f64(spmv_hip_ctx* ctx, const spmv_hip_csr_plan* plan,
-                              int32_t num_rows, int32_t num_cols,
-                              int64_t num_non_zeros, const int32_t* rowptr,
-                              const int32_t* colind, const double* values,
-                              double alpha, const double* in, double beta,
-                              double* out, double* dot_partials,
-                              double* dot_result, uint32_t* dot_counter,
-                              int accumulate, void* stream)
-{
-  SPMV_SET_DEVICE(ctx);
-  SPMV_REQUIRE(plan && plan->ctx == ctx && !plan->symmetric);
-  SPMV_REQUIRE(num_rows == plan->num_rows && num_cols == plan->num_cols
-               && num_non_zeros == plan->nnz);
-  SPMV_REQUIRE(num_rows > 0 && num_non_zeros > 0);
-  SPMV_REQUIRE(in && out && rowptr && colind && values);
-  SPMV_REQUIRE(dot_partials && dot_result && dot_counter);
-  DotOut dot;
-  dot.partials = dot_partials;
-  dot.len = ctx->dot_blocks;
-  dot.result = dot_result;
-  dot.counter = dot_counter;
-  dot.accumulate = accumulate ? 1 : 0;
-  return run_general<double, true>(plan, spmv_stream(ctx, stream), rowptr,
-                                   colind, values, alpha, in, beta, out, dot);
-}
-
 int spmv_hip_csr_spmv_f32(spmv_hip_ctx* ctx, const spmv_hip_csr_plan* plan,
                           int32_t num_rows, int32_t num_cols,
                           int64_t num_non_zeros, const int32_t* rowptr,
@@ -2206,7 +1170,7 @@ int spmv_hip_csr_spmv_f32(spmv_hip_ctx* ctx, const spmv_hip_csr_plan* plan,
   SPMV_REQUIRE(num_non_zeros == 0 || (rowptr && colind && values));
   hipStream_t st = spmv_stream(ctx, stream);
   if (plan->symmetric)
-    return run_symmetric<float>(plan, st, rowptr, colind, values, diagonal,
+    return spmv_run_symmetric_f32(plan, st, rowptr, colind, values, diagonal,
                                 alpha, in, beta, out);
   if (num_non_zeros == 0) {
     const int grid = spmv_grid_for(ctx, num_rows, kBlock);

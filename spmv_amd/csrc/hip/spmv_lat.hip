@@ -1,0 +1,534 @@
+// Lattice form of the general CSR SpMV for gfx950 (MI355X).
+//
+// Stands behind the same CSRSpMV<T>::init/run hook as the other general
+// kernels (spmv/csr_kernels.h:26-78); arithmetic and summation order are those
+// of spmv/csr_kernels.cpp:41-51, so results are bit-identical to the oracle.
+//
+// Matrices assembled on a structured grid (the 7-point Poisson matrix of the
+// benchmark, any stencil with <= 8 points) have a property the CSR format does
+// not exploit: inside a block of consecutive rows every column index is
+// `row + d` for one of a handful of constant offsets d.  Plan creation checks
+// that, per block of 256 rows (lat_build_kernel):
+//   * the block's distinct offsets, ascending: D[0..nd), nd <= 8
+//   * per row one byte: bit k set <=> the row has an entry in column row + D[k]
+//   * every row's entries must appear in ascending column order without
+//     repeats, so that "walk the set bits from k = 0 up" IS the row's
+//     left-to-right order of csr_kernels.cpp:46-47.
+// If every row block qualifies the plan takes this form, and the kernel
+//   1. never reads colind: 8 B per entry (values) + 5 B per row (row pointer,
+//      mask) instead of 12 B per entry -- at 512^3 10.3 GB per SpMV instead
+//      of 13.9 GB (LX form: 12.1 GB);
+//   2. moves `values` straight into LDS with LDS-DMA
+//      (global_load_lds_dwordx4: no VGPRs, no LDS store instructions), always
+//      one row block AHEAD of the one being summed (two LDS slots), so the
+//      matrix stream never stops while a workgroup computes: the LX kernel
+//      alternates load and compute phases and reached only ~75 % of the
+//      streaming rate of the same bytes;
+//   3. loads x for column row + D[k] directly, coalesced (lane = row), into
+//      registers: no staging pass, no index arithmetic.
+// One workgroup barrier per row block (the LX kernel needs six).
+//
+// Measured on MI355X, 512^3 (profiles/r02_*): 2.03-2.07 ms against 2.57-2.62 ms
+// for the LX kernel on the same boxes.  Variants measured and dropped: waves
+// with private slots and no barrier at all (equal at 16 waves per CU, 9 %
+// slower at 32), two rows per lane with 16-byte x / y accesses (17 % slower),
+// non-temporal y stores (-1.8 %).  What the time is made of (ablations, same
+// box): without the y store 1.70 ms, without the x loads of seven of the
+// eight offsets 2.0 ms (no change), without the values 1.15 ms.
+//
+//   lat_tab[rb*kLatRec + 0]      nd, number of offsets of row block rb (-1: not
+//                                in lattice form)
+//   lat_tab[rb*kLatRec + 1]      k0: D[k0] == 0 (padding included), or -1
+//   lat_tab[rb*kLatRec + 4 + k]  D[k], ascending, padded with 0
+//   lat_mask[row]                presence bits
+#include "csr_plan.h"
+
+#include <new>
+
+namespace
+{
+
+constexpr int kLatMaxOff = 8; // offsets per row block = mask bits
+constexpr int kLatRec = 12;   // ints per row-block record: count, 3 pad, offsets
+                              // (the offsets 16-byte aligned: one scalar load)
+// LDS slot for one row block's values: 256 rows x 8 entries plus the slack of
+// the 16-byte alignment of the first DMA piece, in whole 1-KiB DMA pieces
+constexpr int kLatSlotBytes = (kRows * kLatMaxOff * 8 + 1024);
+constexpr int kLatSlots = 2;
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to
+// lds_dst + lane*16 (lds_dst wave-uniform, passed in M0).  Written as inline
+// assembly on purpose: with the builtin the compiler puts `s_waitcnt vmcnt(0)`
+// in front of every later LDS read (it cannot tell the slot being filled from
+// the slot being read) and the prefetch would be drained at once.  An
+// instruction the compiler does not count can only make its own vmcnt waits
+// stricter, never too weak (the counter retires in issue order); this file
+// waits for the pieces itself, with vmcnt(0) before the barrier that
+// publishes a slot.  M0 is saved and restored inside the statement.
+template <bool NT>
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst)
+{
+  unsigned keep;
+  if constexpr (NT)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+// Entries [base, b) of `values` -> LDS slot, base 16-byte aligned.  One DMA
+// piece = one wave-instruction = 1 KiB.  Lanes past the span re-read its last
+// 16-byte chunk (one cached line) instead of streaming the next block's data.
+template <typename T, bool NT>
+__device__ __forceinline__ void lat_issue_dma(const T* __restrict__ values,
+                                              int64_t nnz, int64_t base,
+                                              int64_t b, T* s_slot, int t)
+{
+  constexpr int V = 16 / (int)sizeof(T); // entries per 16-byte chunk
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int lane = t & 63;
+  const int64_t jclamp = (b - 1) & ~(int64_t)(V - 1);
+  const int pieces = (int)(((b - base) * (int64_t)sizeof(T) + 1023) >> 10);
+  if (jclamp + V <= nnz) {
+    // LDS byte address of the slot (uniform)
+    const unsigned lds0 = (unsigned)(uintptr_t)(
+        (__attribute__((address_space(3))) void*)s_slot);
+    for (int q = wave; q < pieces; q += kBlock / 64) {
+      int64_t j = base + (int64_t)(q * 64 + lane) * V;
+      j = j < jclamp ? j : jclamp;
+      glds16<NT>(values + j, lds0 + (unsigned)q * 1024u);
+    }
+  } else {
+    // the last row block of the array: a 16-byte chunk would end past
+    // values[nnz) -- element-wise, in bounds
+    for (int64_t j = base + t; j < b; j += kBlock)
+      s_slot[j - base] = values[j];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// The kernel.  lane = row.  A persistent workgroup walks its row blocks with
+// everything one block ahead:
+//   top     wait + ONE barrier: block k's values (DMA issued an iteration ago)
+//           and its register loads have landed, for every wave; every wave has
+//           left block k-1, whose LDS slot is free again
+//   issue   DMA of block k+1's values into that slot; block k+1's loads into
+//           registers: row pointer, mask byte, x[row + D[j]] for all 8 j (D is
+//           padded with 0 = the row's own x, a cache hit), y for beta != 0 --
+//           all independent of each other
+//   sum     block k: own row out of LDS, left to right over the set mask bits
+// so a workgroup always has a whole row block (~20 KB) in flight while it
+// computes, and nothing in an iteration waits for a load issued in it.
+// ---------------------------------------------------------------------------
+template <typename T>
+struct LatRegs {
+  int32_t lo;
+  unsigned m;
+  int k0; // uniform: xk[k0] is the row's own x (DOT), -1 = x_own was loaded
+  T xk[kLatMaxOff];
+  T y0, x_own;
+};
+
+struct LatBlock {
+  int rb;       // row block, -1 = none
+  int64_t a, b; // its span in `values`
+};
+
+template <typename T, bool DOT>
+__device__ __forceinline__ LatRegs<T> lat_loads(
+    const LatBlock& blk, int t, int32_t num_rows, int32_t num_cols,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ tab,
+    const uint8_t* __restrict__ mask, const T* __restrict__ in, T beta,
+    const T* __restrict__ out)
+{
+  LatRegs<T> g;
+  g.lo = 0;
+  g.m = 0;
+  g.k0 = 0;
+  g.y0 = g.x_own = T(0);
+#pragma unroll
+  for (int k = 0; k < kLatMaxOff; ++k)
+    g.xk[k] = T(0);
+  if (blk.rb < 0)
+    return g;
+  const int32_t r0 = blk.rb * kRows;
+  const int32_t r = r0 + t;
+  if (r < num_rows) {
+    // the block's record: one 16-byte and one 32-byte scalar load
+    const int32_t* rec = tab + (int64_t)blk.rb * kLatRec;
+    const i32x8 D = *reinterpret_cast<const i32x8*>(rec + 4);
+    g.k0 = rec[1]; // position of a zero offset in D, or -1
+    g.lo = rowptr[r];
+    g.m = mask[r];
+#pragma unroll
+    for (int k = 0; k < kLatMaxOff; ++k) {
+      // unconditional (no dependence on the mask load); a column the row does
+      // not have is clamped into range and its value ignored
+      int64_t c = (int64_t)r + D[k];
+      c = c < 0 ? 0 : (c >= num_cols ? num_cols - 1 : c);
+      g.xk[k] = in[c];
+    }
+    if (beta != T(0))
+      g.y0 = out[r];
+    if constexpr (DOT)
+      if (g.k0 < 0) // uniform: eight offsets, none of them 0
+        g.x_own = in[r];
+  }
+  return g;
+}
+
+__device__ __forceinline__ LatBlock lat_block(const RowBlockOrder& ord, int it,
+                                              int num_slots, int32_t num_rows,
+                                              const int32_t* __restrict__ rowptr,
+                                              int stride, int* it_out)
+{
+  // first non-empty slot at or after `it` (XCD groups leave holes at the end)
+  LatBlock blk{-1, 0, 0};
+  while (it < num_slots) {
+    const int rb = order_row_block(ord, it);
+    if (rb >= 0) {
+      const int32_t r0 = rb * kRows;
+      const int nr = min(kRows, num_rows - r0);
+      blk.rb = rb;
+      blk.a = rowptr[r0];
+      blk.b = rowptr[r0 + nr];
+      break;
+    }
+    it += stride;
+  }
+  *it_out = it;
+  return blk;
+}
+
+template <typename T, bool DOT, bool NT>
+__global__ __launch_bounds__(kBlock) void csr_lattice_kernel(
+    int32_t num_rows, int32_t num_cols, int64_t nnz,
+    const int32_t* __restrict__ rowptr, const T* __restrict__ values,
+    const int32_t* __restrict__ tab, const uint8_t* __restrict__ mask, T alpha,
+    const T* __restrict__ in, T beta, T* __restrict__ out, DotOut dot,
+    RowBlockOrder ord)
+{
+  constexpr int V = 16 / (int)sizeof(T);
+  constexpr int SLOT = kLatSlotBytes / (int)sizeof(T); // entries per slot
+  __shared__ __attribute__((aligned(16))) T s_val[kLatSlots * SLOT];
+  __shared__ double s_red[kBlock / 64];
+
+  const int t = threadIdx.x;
+  const int stride = gridDim.x;
+  const int num_slots = order_slots(ord);
+  double dot_acc = 0.0;
+
+  int it = blockIdx.x, itn = 0, itnn = 0;
+  LatBlock cur = lat_block(ord, it, num_slots, num_rows, rowptr, stride, &it);
+  LatBlock nxt = lat_block(ord, it + stride, num_slots, num_rows, rowptr,
+                           stride, &itn);
+  if (cur.rb >= 0 && cur.b > cur.a)
+    lat_issue_dma<T, NT>(values, nnz, cur.a & ~(int64_t)(V - 1), cur.b, s_val,
+                         t);
+  LatRegs<T> gA = lat_loads<T, DOT>(cur, t, num_rows, num_cols, rowptr, tab,
+                                    mask, in, beta, out);
+  LatRegs<T> gB;
+  int slot = 0;
+  // one step: sums block `cur` out of registers g, loads block `nxt` into gn
+  auto step = [&](const LatRegs<T>& g, LatRegs<T>& gn) {
+    // the block after the next one: its span is needed an iteration from now
+    const LatBlock nn = lat_block(ord, itn + stride, num_slots, num_rows,
+                                  rowptr, stride, &itnn);
+    // Everything this wave has in flight (block k's DMA pieces and loads, the
+    // previous y stores) has landed; after the barrier that holds for all
+    // waves, and all of them have left block k-1.  (The builtin, not inline
+    // assembly: the compiler's own wait-count bookkeeping must see it, or it
+    // would wait for "its" loads again after the barrier -- and with them for
+    // the DMA pieces issued there.)
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+    __syncthreads();
+    if (nxt.rb >= 0 && nxt.b > nxt.a)
+      lat_issue_dma<T, NT>(values, nnz, nxt.a & ~(int64_t)(V - 1), nxt.b,
+                           s_val + (slot ^ 1) * SLOT, t);
+    gn = lat_loads<T, DOT>(nxt, t, num_rows, num_cols, rowptr, tab, mask, in,
+                           beta, out);
+    const int32_t r = cur.rb * kRows + t;
+    if (r < num_rows) {
+      const int rel
+          = slot * SLOT + (g.lo - (int32_t)(cur.a & ~(int64_t)(V - 1)));
+      // all LDS reads first (independent), then the adds in entry order
+      T v[kLatMaxOff];
+#pragma unroll
+      for (int k = 0; k < kLatMaxOff; ++k) {
+        const int pk = __popc(g.m & ((1u << k) - 1u));
+        v[k] = s_val[min(rel + pk, kLatSlots * SLOT - 1)];
+      }
+      T sum = 0;
+#pragma unroll
+      for (int k = 0; k < kLatMaxOff; ++k)
+        if ((g.m >> k) & 1u) // csr_kernels.cpp:46-47, left to right
+          sum += v[k] * g.xk[k];
+      const T c = alpha * sum;
+      T y = c;
+      if (beta != T(0))
+        y = c + beta * g.y0;
+      out[r] = y;
+      if constexpr (DOT) {
+        T xo = g.x_own;
+#pragma unroll
+        for (int k = 0; k < kLatMaxOff; ++k)
+          if (k == g.k0) // uniform
+            xo = g.xk[k];
+        dot_acc += (double)xo * (double)c;
+      }
+    }
+    slot ^= 1;
+    cur = nxt;
+    nxt = nn;
+    itn = itnn;
+  };
+  // two steps per trip: the two register sets swap roles without being copied
+  // (a copy would have to wait for the loads it moves)
+  while (cur.rb >= 0) {
+    step(gA, gB);
+    if (cur.rb < 0)
+      break;
+    step(gB, gA);
+  }
+  if constexpr (DOT)
+    spmv_dot_epilogue(dot, dot_acc, s_red);
+}
+
+// ---------------------------------------------------------------------------
+// Plan-time analysis: one workgroup per row block, lane = row.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int32_t block_min(int32_t v, int32_t* s_tmp)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+    v = min(v, __shfl_down(v, off, 64));
+  __syncthreads(); // s_tmp free again
+  if ((threadIdx.x & 63) == 0)
+    s_tmp[threadIdx.x >> 6] = v;
+  __syncthreads();
+  int32_t r = s_tmp[0];
+#pragma unroll
+  for (int w = 1; w < kBlock / 64; ++w)
+    r = min(r, s_tmp[w]);
+  return r; // every thread
+}
+
+__global__ __launch_bounds__(kBlock) void lat_build_kernel(
+    int32_t num_rows, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ colind, int32_t* __restrict__ tab,
+    uint8_t* __restrict__ mask, int num_row_blocks, int32_t* __restrict__ ok_count)
+{
+  __shared__ int32_t s_tmp[kBlock / 64];
+  __shared__ int32_t s_D[kLatMaxOff];
+  __shared__ int s_fail;
+  const int t = threadIdx.x;
+  constexpr int64_t kAlign = 4; // widest 16-byte chunk (fp32): entries
+  constexpr int64_t kSlotEntries = kLatSlotBytes / 8;
+  for (int rb = blockIdx.x; rb < num_row_blocks; rb += gridDim.x) {
+    const int32_t r0 = rb * kRows;
+    const int nr = min(kRows, num_rows - r0);
+    const int32_t r = r0 + t;
+    int32_t lo = 0, hi = 0;
+    if (t < nr) {
+      lo = rowptr[r];
+      hi = rowptr[r + 1];
+    }
+    const int cnt = hi - lo;
+    int32_t d[kLatMaxOff];
+#pragma unroll
+    for (int j = 0; j < kLatMaxOff; ++j)
+      d[j] = (j < cnt && cnt <= kLatMaxOff) ? colind[lo + j] - r : INT32_MAX;
+    __syncthreads();
+    if (t == 0) {
+      // the block's values plus the alignment slack must fit one LDS slot
+      const int64_t a = rowptr[r0], b = rowptr[r0 + nr];
+      s_fail = (b - (a & ~(kAlign - 1)) > kSlotEntries) ? 1 : 0;
+    }
+    __syncthreads();
+    if (cnt > kLatMaxOff)
+      s_fail = 1;
+    // the distinct offsets, ascending: repeatedly the smallest one above the
+    // last found
+    int nd = 0;
+    int64_t last = (int64_t)INT32_MIN - 1;
+    for (int round = 0; round <= kLatMaxOff; ++round) {
+      int32_t cand = INT32_MAX;
+#pragma unroll
+      for (int j = 0; j < kLatMaxOff; ++j)
+        if ((int64_t)d[j] > last && d[j] < cand)
+          cand = d[j];
+      const int32_t next = block_min(cand, s_tmp);
+      if (next == INT32_MAX)
+        break; // uniform
+      if (round == kLatMaxOff) { // a ninth offset
+        if (t == 0)
+          s_fail = 1;
+        break;
+      }
+      if (t == 0)
+        s_D[nd] = next;
+      ++nd;
+      last = next;
+    }
+    __syncthreads();
+    // per row: entries must hit D in strictly ascending position
+    unsigned m = 0;
+    int prev = -1;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < kLatMaxOff; ++j) {
+      if (j < cnt && cnt <= kLatMaxOff) {
+        int k = 0;
+        while (k < nd && s_D[k] != d[j])
+          ++k;
+        if (k <= prev || k >= nd)
+          bad = true;
+        prev = k;
+        m |= 1u << k;
+      }
+    }
+    if (bad)
+      s_fail = 1;
+    __syncthreads();
+    const int fail = s_fail;
+    if (t < nr)
+      mask[r] = (uint8_t)m;
+    int32_t* rec = tab + (int64_t)rb * kLatRec;
+    if (t == 0) {
+      rec[0] = fail ? -1 : nd;
+      // where the kernel finds the row's own x among its eight x loads: a zero
+      // offset, or the zero padding behind the last offset
+      int k0 = nd < kLatMaxOff ? nd : -1;
+      for (int k = 0; k < nd; ++k)
+        if (s_D[k] == 0)
+          k0 = k;
+      rec[1] = k0;
+      if (!fail)
+        atomicAdd(ok_count, 1);
+    }
+    if (t < kLatMaxOff)
+      rec[4 + t] = t < nd ? s_D[t] : 0;
+  }
+}
+
+template <typename T, bool DOT>
+int lat_launch(const spmv_hip_csr_plan* pl, hipStream_t st,
+               const int32_t* rowptr, const T* values, T alpha, const T* in,
+               T beta, T* out, DotOut dot)
+{
+  const int nrb = (pl->num_rows + kRows - 1) / kRows;
+  int grid = pl->ctx->num_cus * pl->lat_blocks_per_cu;
+  if (grid > pl->ctx->dot_blocks)
+    grid = pl->ctx->dot_blocks;
+  if (grid > nrb)
+    grid = nrb;
+  if (grid < 1)
+    grid = 1;
+  // slots it with equal it % 8 must stay on one XCD (XCD groups)
+  if (grid >= 8)
+    grid -= grid % 8;
+  RowBlockOrder ord = pl->row_block_order(nrb);
+  ord.xcd_group = pl->lat_xcd_group;
+  if (pl->nontemporal)
+    hipLaunchKernelGGL((csr_lattice_kernel<T, DOT, true>), dim3(grid),
+                       dim3(kBlock), 0, st, pl->num_rows, pl->num_cols, pl->nnz,
+                       rowptr, values, pl->lat_tab, pl->lat_mask, alpha, in,
+                       beta, out, dot, ord);
+  else
+    hipLaunchKernelGGL((csr_lattice_kernel<T, DOT, false>), dim3(grid),
+                       dim3(kBlock), 0, st, pl->num_rows, pl->num_cols, pl->nnz,
+                       rowptr, values, pl->lat_tab, pl->lat_mask, alpha, in,
+                       beta, out, dot, ord);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+} // namespace
+
+void spmv_lat_free(spmv_hip_csr_plan* pl)
+{
+  (void)hipFree(pl->lat_tab);
+  (void)hipFree(pl->lat_mask);
+  pl->lat_tab = nullptr;
+  pl->lat_mask = nullptr;
+  pl->lat = 0;
+}
+
+// Build the lattice form; kept only when EVERY row block qualifies (the
+// kernel has no per-block fallback).  Costs 1 B per row + 36 B per row block.
+int spmv_lat_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
+                   const int32_t* colind)
+{
+  SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
+  spmv_lat_free(pl);
+  pl->lat_blocks = 0;
+  const int nrb = (pl->num_rows + kRows - 1) / kRows;
+  if (nrb == 0 || pl->nnz == 0)
+    return SPMV_HIP_OK;
+  hipStream_t st = pl->ctx->stream;
+  int32_t* d_ok = nullptr;
+  hipError_t e = hipMalloc(&pl->lat_tab, sizeof(int32_t) * (size_t)nrb * kLatRec);
+  if (e == hipSuccess)
+    e = hipMalloc(&pl->lat_mask, (size_t)pl->num_rows);
+  if (e == hipSuccess)
+    e = hipMalloc(&d_ok, sizeof(int32_t));
+  if (e == hipSuccess)
+    e = hipMemsetAsync(d_ok, 0, sizeof(int32_t), st);
+  int32_t ok = 0;
+  if (e == hipSuccess) {
+    int grid = pl->ctx->num_cus * 8;
+    grid = grid > nrb ? nrb : grid;
+    hipLaunchKernelGGL(lat_build_kernel, dim3(grid), dim3(kBlock), 0, st,
+                       pl->num_rows, rowptr, colind, pl->lat_tab, pl->lat_mask,
+                       nrb, d_ok);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(&ok, d_ok, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st);
+  (void)hipFree(d_ok);
+  if (e != hipSuccess) {
+    spmv_lat_free(pl);
+    return e == hipErrorOutOfMemory ? SPMV_HIP_OK : static_cast<int>(e);
+  }
+  pl->lat_blocks = ok;
+  if (ok != nrb) {
+    spmv_lat_free(pl);
+    pl->lat_blocks = ok;
+    return SPMV_HIP_OK;
+  }
+  pl->lat = 1;
+  // XCD groups of 16 row blocks while x fits the Infinity Cache (216^3: 0.153
+  // -> 0.138 ms); no effect beyond (512^3)
+  pl->lat_xcd_group = pl->nontemporal ? 16 : 0;
+  return SPMV_HIP_OK;
+}
+
+int spmv_lat_run_f64(const spmv_hip_csr_plan* pl, hipStream_t st,
+                     const int32_t* rowptr, const double* values, double alpha,
+                     const double* in, double beta, double* out, DotOut dot)
+{
+  if (dot.partials)
+    return lat_launch<double, true>(pl, st, rowptr, values, alpha, in, beta,
+                                    out, dot);
+  return lat_launch<double, false>(pl, st, rowptr, values, alpha, in, beta, out,
+                                   dot);
+}
+
+int spmv_lat_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st,
+                     const int32_t* rowptr, const float* values, float alpha,
+                     const float* in, float beta, float* out)
+{
+  return lat_launch<float, false>(pl, st, rowptr, values, alpha, in, beta, out,
+                                  DotOut());
+}

@@ -769,6 +769,14 @@ int spmvh_cg_workspace_destroy(spmvh_cg_workspace* ws)
   return guarded([&] { delete ws; });
 }
 
+int spmvh_cg_workspace_reserve_timing(spmvh_cg_workspace* ws, int iterations)
+{
+  return guarded([&] {
+    require(ws, "NULL argument");
+    ws->ws->reserve_timing(iterations);
+  });
+}
+
 int spmvh_cg_ex(spmvh_comm* comm, spmvh_exec* exec, spmvh_matrix* A,
                 const double* b, double* x, int kmax, double rtol, int* num_its,
                 double* rnorm_history, spmvh_cg_workspace* ws, int time_spmv,
@@ -779,7 +787,6 @@ int spmvh_cg_ex(spmvh_comm* comm, spmvh_exec* exec, spmvh_matrix* A,
     std::vector<double> hist;
     CgOptions opt;
     opt.time_spmv = (time_spmv & 1) != 0;
-    opt.fused_reductions = (time_spmv & 2) != 0;
     opt.consumer_reductions = (time_spmv & 4) == 0; // bit 2 switches it off
     CgStats st;
     *num_its = cg(*comm->comm, *exec->hip, *A->A, b, x, kmax, rtol,

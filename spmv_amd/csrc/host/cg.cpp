@@ -10,10 +10,9 @@
 //     reduce partials -> rr[k];  all-reduce    cg.cpp:74-76
 //     x += a p; stop test; p = beta p + r      cg.cpp:69,77-85
 //
-// The partial sums of a dot product are added in a fixed order either by a
-// single-workgroup reducer kernel (default) or by the last workgroup of the
-// producing kernel (CgOptions::fused_reductions: arrival ticket, nobody
-// waits).  5 (or 3) kernel launches per iteration (+ the small remote-block
+// The partial sums of a dot product are added in a fixed order either by the
+// consuming update kernel itself (one rank) or by a single-workgroup reducer
+// kernel.  3 (or 5) kernel launches per iteration (+ the small remote-block
 // kernel and two one-double RCCL all-reduces with more than one rank); the
 // reference's CUDA path needs 7 cuBLAS calls, 5 scalar kernels and 3 host
 // synchronisations for the same step (cuda/cg.cuda.cu:101-151).
@@ -36,6 +35,8 @@ void CgWorkspace::release()
     if (stream)
       _exec.synchronize_stream(stream);
     _exec.destroy_event(poll_event);
+    for (void* e : timing_ev)
+      _exec.destroy_event(e);
     if (stream)
       _exec.destroy_stream(stream);
     spmv_hip_cg_ws_destroy(ws);
@@ -47,6 +48,7 @@ void CgWorkspace::release()
     spmv_hip_host_free(_exec.context(), flags);
   } catch (...) {
   }
+  timing_ev.clear();
   ws = nullptr;
   r = Ap = x = p = dot2 = nullptr;
   flags = nullptr;
@@ -90,6 +92,12 @@ void CgWorkspace::ensure(int64_t M, int64_t N_padded, int kmax, int len)
   }
 }
 
+void CgWorkspace::reserve_timing(int iterations)
+{
+  while (timing_ev.size() < 2 * (size_t)(iterations < 0 ? 0 : iterations))
+    timing_ev.push_back(_exec.create_event(true));
+}
+
 namespace
 {
 // restores the executor's stream when cg() leaves, also on exceptions
@@ -105,18 +113,6 @@ struct StreamGuard {
   }
 };
 
-struct EventList {
-  HipExecutor& exec;
-  std::vector<void*> ev;
-  ~EventList()
-  {
-    for (void* e : ev)
-      try {
-        exec.destroy_event(e);
-      } catch (...) {
-      }
-  }
-};
 } // namespace
 
 int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
@@ -177,25 +173,19 @@ int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
     return s;
   };
 
-  uint32_t* counters = nullptr; // [0] p.Ap, [1] r.r arrival tickets
-  throw_on_error(spmv_hip_cg_ws_counter(w.ws, &counters),
-                 "spmv_hip_cg_ws_counter");
-
   // rnorm0 (cg.cpp:47-50)
-  if (opt.fused_reductions) {
-    throw_on_error(spmv_hip_cg_dot_rr0_f64(ctx, w.ws, M, w.r, nullptr),
-                   "spmv_hip_cg_dot_rr0_f64");
-  } else {
-    throw_on_error(spmv_hip_cg_dot_rr_f64(ctx, w.ws, M, w.r, nullptr),
-                   "spmv_hip_cg_dot_rr_f64");
-    throw_on_error(spmv_hip_cg_reduce_rr(ctx, w.ws, 0, nullptr),
-                   "spmv_hip_cg_reduce_rr");
-  }
+  throw_on_error(spmv_hip_cg_dot_rr_f64(ctx, w.ws, M, w.r, nullptr),
+                 "spmv_hip_cg_dot_rr_f64");
+  throw_on_error(spmv_hip_cg_reduce_rr(ctx, w.ws, 0, nullptr),
+                 "spmv_hip_cg_reduce_rr");
   comm.allreduce_sum(slot(true, 0), 1, w.stream);
 
-  const bool consume
-      = opt.consumer_reductions && !opt.fused_reductions && comm.size() == 1;
-  EventList timing{exec, {}};
+  const bool consume = opt.consumer_reductions && comm.size() == 1;
+  // Timing events live in the workspace: a solve that reuses one (the
+  // benchmark, after its warm-up) creates nothing inside its timed region.
+  std::vector<void*>& timing_ev = w.timing_ev;
+  if (opt.time_spmv)
+    w.reserve_timing(kmax);
   int k = 0;
   bool stopped = false;
   bool poll_pending = false;
@@ -204,11 +194,8 @@ int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
     col_l2g->update(w.p); // cg.cpp:59 (starts on the side stream)
     void* ev1 = nullptr;
     if (opt.time_spmv) {
-      void* ev0 = exec.create_event(true);
-      ev1 = exec.create_event(true);
-      timing.ev.push_back(ev0);
-      timing.ev.push_back(ev1);
-      exec.record_event(ev0, w.stream);
+      ev1 = timing_ev[2 * (size_t)(k - 1) + 1];
+      exec.record_event(timing_ev[2 * (size_t)(k - 1)], w.stream);
     }
     // cg.cpp:60,63: Ap = A p with the p.Ap partials produced by the SpMV
     // kernels themselves (local block's share + remote block's share)
@@ -226,18 +213,6 @@ int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
       throw_on_error(spmv_hip_cg_update_xp_cs_f64(ctx, w.ws, k, M, w.r, w.x,
                                                   w.p, nullptr),
                      "spmv_hip_cg_update_xp_cs_f64");
-    } else if (opt.fused_reductions) {
-      // ... and added up by their last workgroup: no reducer launch
-      const bool fused = A.mult_dot(w.p, w.Ap, partials, w.dot2, ev1,
-                                    slot(false, k), counters);
-      if (!fused) // symmetric storage: the atomic scatter cannot carry the dot
-        throw_on_error(spmv_hip_cg_dot_pAp_f64(ctx, w.ws, k, M, w.p, w.Ap,
-                                               nullptr),
-                       "spmv_hip_cg_dot_pAp_f64");
-      comm.allreduce_sum(slot(false, k), 1, w.stream); // cg.cpp:65
-      throw_on_error(spmv_hip_cg_update_r_fused_f64(ctx, w.ws, k, M, w.Ap, w.r,
-                                                    nullptr),
-                     "spmv_hip_cg_update_r_fused_f64");
     } else {
       const bool fused = A.mult_dot(w.p, w.Ap, partials, w.dot2, ev1);
       if (fused) {
@@ -295,10 +270,10 @@ int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
   if (stats) {
     stats->spmv_launches = 0;
     stats->spmv_ms_total = 0.0;
-    for (size_t i = 0; i + 1 < timing.ev.size(); i += 2) {
+    for (size_t i = 0; opt.time_spmv && i + 1 < 2 * (size_t)k; i += 2) {
       float ms = 0.f;
-      throw_on_error(spmv_hip_event_elapsed_ms(ctx, timing.ev[i],
-                                               timing.ev[i + 1], &ms),
+      throw_on_error(spmv_hip_event_elapsed_ms(ctx, timing_ev[i],
+                                               timing_ev[i + 1], &ms),
                      "spmv_hip_event_elapsed_ms");
       stats->spmv_ms_total += ms;
       ++stats->spmv_launches;

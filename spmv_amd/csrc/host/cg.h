@@ -27,6 +27,9 @@ public:
 
   // ---- internal to cg() ----
   void ensure(int64_t M, int64_t N_padded, int kmax, int partials_len);
+  // events for CgOptions::time_spmv of a solve of up to `iterations` steps,
+  // created ahead of it (a benchmark keeps them out of its timed region)
+  void reserve_timing(int iterations);
   void release();
 
   HipExecutor& _exec;
@@ -38,22 +41,17 @@ public:
   int32_t* flags = nullptr; // pinned {done, kstop}
   void* stream = nullptr;   // compute stream of the solve
   void* poll_event = nullptr;
+  std::vector<void*> timing_ev; // CgOptions::time_spmv: 2 events per iteration
 };
 
 struct CgOptions {
   int poll_every = 16;    // host looks at the device's `done` flag this often
   bool time_spmv = false; // bracket every local-block SpMV with HIP events
-  // false: every dot product is finished by a single-workgroup reducer kernel
-  //        (5 launches per iteration);
-  // true : by the last workgroup of the producing kernel (3 launches).
-  // Measured on MI355X: equal at 216^3 and 512^3, the reducer kernels are 9 %
-  // faster at 128^3 (the arrival tickets sit on the tail of a persistent
-  // grid), hence the default.
-  bool fused_reductions = false;
   // One rank only (no all-reduce between producer and consumer): the update
   // kernels add the dot-product partials themselves, in the reducers' order,
-  // so an iteration is 3 launches and the scalars keep their bits.  Ignored
-  // for more than one rank and when fused_reductions is set.
+  // so an iteration is 3 launches and the scalars keep their bits.  With more
+  // than one rank (or when switched off) every dot product is finished by a
+  // single-workgroup reducer kernel (5 launches per iteration).
   bool consumer_reductions = true;
 };
 

@@ -52,23 +52,15 @@ template <typename T>
 void CSRSpMV<T>::run_dot(int32_t num_rows, int32_t num_cols,
                          int64_t num_non_zeros, const int32_t* rowptr,
                          const int32_t* colind, const T* values, T alpha, T* in,
-                         T beta, T* out, const DotTarget& dot,
+                         T beta, T* out, double* dot_partials,
                          const HipExecutor& exec) const
 {
   if constexpr (std::is_same<T, double>::value) {
-    if (dot.result)
-      throw_on_error(spmv_hip_csr_spmv_dot_f64(
-                         exec.context(), plan(), num_rows, num_cols,
-                         num_non_zeros, rowptr, colind, values, alpha, in, beta,
-                         out, dot.partials, dot.result, dot.counter,
-                         dot.accumulate ? 1 : 0, nullptr),
-                     "spmv_hip_csr_spmv_dot_f64");
-    else
-      throw_on_error(spmv_hip_csr_spmv_f64(exec.context(), plan(), num_rows,
-                                           num_cols, num_non_zeros, rowptr,
-                                           colind, values, nullptr, alpha, in,
-                                           beta, out, dot.partials, nullptr),
-                     "spmv_hip_csr_spmv_f64");
+    throw_on_error(spmv_hip_csr_spmv_f64(exec.context(), plan(), num_rows,
+                                         num_cols, num_non_zeros, rowptr,
+                                         colind, values, nullptr, alpha, in,
+                                         beta, out, dot_partials, nullptr),
+                   "spmv_hip_csr_spmv_f64");
   } else {
     throw std::runtime_error("CSRSpMV<float>::run_dot is not available");
   }
@@ -201,7 +193,7 @@ void CSRMatrix<T>::mult(T alpha, T* in, T beta, T* out) const
 
 template <typename T>
 bool CSRMatrix<T>::mult_dot(T alpha, T* in, T beta, T* out,
-                            const DotTarget& dot) const
+                            double* dot_partials) const
 {
   if (this->_num_non_zeros == 0)
     return false;
@@ -209,17 +201,16 @@ bool CSRMatrix<T>::mult_dot(T alpha, T* in, T beta, T* out,
   if (!hip)
     return false;
   if (this->_symmetric) {
-    // the symmetric kernel produces its share from the mirror identity; only
-    // the partial form exists (no last-workgroup reduction)
-    if (dot.result != nullptr || !std::is_same<T, double>::value)
+    // the symmetric kernel produces its share from the mirror identity
+    if (!std::is_same<T, double>::value)
       return false;
     _op.run_dot_sym(this->_num_rows, this->_num_cols, this->_num_non_zeros,
                     _rowptr, _colind, _values, this->_diagonal, alpha, in, beta,
-                    out, dot.partials, *hip);
+                    out, dot_partials, *hip);
     return true;
   }
   _op.run_dot(this->_num_rows, this->_num_cols, this->_num_non_zeros, _rowptr,
-              _colind, _values, alpha, in, beta, out, dot, *hip);
+              _colind, _values, alpha, in, beta, out, dot_partials, *hip);
   return true;
 }
 

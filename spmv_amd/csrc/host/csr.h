@@ -29,16 +29,6 @@ struct CsrHost {
   int64_t non_zeros() const { return static_cast<int64_t>(values.size()); }
 };
 
-// Where a fused dot product goes (see include/spmv_hip.h, "single-launch
-// reductions").  With `result` == nullptr only the per-workgroup partials are
-// written; otherwise the last workgroup adds them into *result.
-struct DotTarget {
-  double* partials = nullptr; // spmv_hip_dot_partials_len() device doubles
-  double* result = nullptr;   // device scalar, optional
-  uint32_t* counter = nullptr; // device ticket (zero before the launch)
-  bool accumulate = false;    // *result += sum instead of = sum
-};
-
 template <typename T>
 class CSRSpMV
 {
@@ -59,7 +49,7 @@ public:
   // General blocks only.
   void run_dot(int32_t num_rows, int32_t num_cols, int64_t num_non_zeros,
                const int32_t* rowptr, const int32_t* colind, const T* values,
-               T alpha, T* in, T beta, T* out, const DotTarget& dot,
+               T alpha, T* in, T beta, T* out, double* dot_partials,
                const HipExecutor& exec) const;
 
   // symmetric block: run() + the block's share of in . (alpha A in) as
@@ -135,7 +125,7 @@ public:
   void mult(T alpha, T* in, T beta, T* out) const override;
   // mult + fused dot partials (see CSRSpMV::run_dot); false if this block
   // cannot fuse (symmetric or empty) and nothing was launched.
-  bool mult_dot(T alpha, T* in, T beta, T* out, const DotTarget& dot) const;
+  bool mult_dot(T alpha, T* in, T beta, T* out, double* dot_partials) const;
 
   const int32_t* rowptr() const { return _rowptr; }
   const int32_t* colind() const { return _colind; }

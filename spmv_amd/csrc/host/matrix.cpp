@@ -155,11 +155,10 @@ void Matrix<T>::spmv_sym_overlap(T* x, T* y) const
 
 template <typename T>
 bool Matrix<T>::mult_dot(T* x, T* y, double* dot_local, double* dot_remote,
-                         void* ev_local_done, double* result,
-                         uint32_t* counter) const
+                         void* ev_local_done) const
 {
-  const DotTarget tl{dot_local, result, counter, false};
-  const DotTarget tr{dot_remote, result, counter, true};
+  double* const tl = dot_local;
+  double* const tr = dot_remote;
   auto* hip = dynamic_cast<HipExecutor*>(_exec.get());
   auto mark = [&] {
     if (ev_local_done && hip)
@@ -174,8 +173,7 @@ bool Matrix<T>::mult_dot(T* x, T* y, double* dot_local, double* dot_remote,
     // same sequence as spmv_sym / spmv_sym_overlap.  The symmetric kernel
     // carries its share of x.(A x) through the mirror identity (partials
     // only), the remote block adds its own share.
-    const bool want = (result == nullptr);
-    const bool ok = want && _mat_local->mult_dot(1, x, 0, y, tl);
+    const bool ok = _mat_local->mult_dot(1, x, 0, y, tl);
     if (!ok)
       _mat_local->mult(1, x, 0, y);
     mark();
@@ -204,8 +202,10 @@ bool Matrix<T>::mult_dot(T* x, T* y, double* dot_local, double* dot_remote,
   }
   mark();
   _col_map->update_finalise(x);
-  if (_mat_remote->non_zeros() > 0)
-    _mat_remote->mult_dot(1, x, 1, y, tr);
+  // a remote block without entries has a zero share and nothing to add to y
+  if (_mat_remote->non_zeros() > 0 && !_mat_remote->mult_dot(1, x, 1, y, tr))
+    throw std::runtime_error("Matrix::mult_dot: the remote block could not "
+                             "run on this executor");
   return true;
 }
 

@@ -56,11 +56,8 @@ public:
   // caller then computes the dot product itself.
   // `ev_local_done` (optional, a HipExecutor event) is recorded right after
   // the local block's kernel was enqueued -- benchmarks time that kernel.
-  // With `result` (+ its zeroed device ticket `counter`) the kernels also add
-  // their partials up, so *result = x[0:rows].y needs no reducer launch.
   bool mult_dot(T* x, T* y, double* dot_local, double* dot_remote,
-                void* ev_local_done = nullptr, double* result = nullptr,
-                uint32_t* counter = nullptr) const;
+                void* ev_local_done = nullptr) const;
 
   std::shared_ptr<L2GMap> row_map() const { return _row_map; }
   std::shared_ptr<const L2GMap> col_map() const { return _col_map; }

@@ -91,6 +91,7 @@ _PROTOS = {
     "spmvh_petsc_rows_destroy": [vp],
     "spmvh_cg_workspace_create": [vp, PTR(vp)],
     "spmvh_cg_workspace_destroy": [vp],
+    "spmvh_cg_workspace_reserve_timing": [vp, C.c_int],
     "spmvh_cg_ex": [vp, vp, vp, vp, vp, C.c_int, f64, PTR(C.c_int), vp, vp,
                     C.c_int, PTR(f64), PTR(C.c_int)],
 }
@@ -527,6 +528,9 @@ class CgWorkspace:
         call("spmvh_cg_workspace_create", exec_.h, C.byref(h))
         self.h = h
 
+    def reserve_timing(self, iterations):
+        call("spmvh_cg_workspace_reserve_timing", self.h, int(iterations))
+
     def close(self):
         if self.h:
             call("spmvh_cg_workspace_destroy", self.h)
@@ -534,8 +538,7 @@ class CgWorkspace:
 
 
 def cg_ex(comm, exec_, A, b_ptr, x_ptr, kmax, rtol, workspace=None,
-          time_spmv=False, history=False, fused_reductions=False,
-          consumer_reductions=True):
+          time_spmv=False, history=False, consumer_reductions=True):
     """cg with the optional arguments: returns (k, history, spmv_ms_total,
     spmv_launches)."""
     k, n = C.c_int(), C.c_int()
@@ -543,8 +546,7 @@ def cg_ex(comm, exec_, A, b_ptr, x_ptr, kmax, rtol, workspace=None,
     hist = np.zeros(kmax + 1) if history else None
     call("spmvh_cg_ex", comm.h, exec_.h, A.h, b_ptr, x_ptr, kmax, float(rtol),
          C.byref(k), _np_ptr(hist), workspace.h if workspace else None,
-         int(time_spmv) | (2 if fused_reductions else 0)
-         | (0 if consumer_reductions else 4), C.byref(ms),
+         int(time_spmv) | (0 if consumer_reductions else 4), C.byref(ms),
          C.byref(n))
     return (k.value, hist[:k.value + 1] if history else None, ms.value,
             n.value)

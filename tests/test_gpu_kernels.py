@@ -83,11 +83,8 @@ def test_kat_vector_and_symmetric(ctx):
 # Poisson + random ragged matrices, general kernels
 # ---------------------------------------------------------------------------
 KNOBS = [dict(), dict(chunks=1), dict(chunks=4), dict(nontemporal=0),
-         dict(xcd_group=1), dict(xcd_group=16), dict(chunks=4, xcd_group=3, blocks_per_cu=2),
-         dict(wave_private=1, chunks=4), dict(wave_private=1, chunks=1, xcd_group=0),
-         dict(wave_private=1, chunks=2, nontemporal=1),
-         dict(pipeline=1), dict(pipeline=1, xcd_group=0, nontemporal=1),
-         dict(pipeline=1, xcd_group=5, blocks_per_cu=3)]
+         dict(xcd_group=1), dict(xcd_group=16),
+         dict(chunks=4, xcd_group=3, blocks_per_cu=2)]
 
 
 @pytest.mark.parametrize("n", [4, 9, 16, 33])
@@ -117,11 +114,6 @@ def test_random_ragged(ctx, seed, algo):
         y_ref = oracle.csr_spmv(rp, ci, va, x, alpha, beta, y0)
         y = run_spmv(ctx, rp, ci, va, x, nrows, ncols, alpha, beta,
                      None if beta == 0 else y0, algo=algo)
-        if algo == hip.ALGO_ROWBLOCK:  # and its software-pipelined variant
-            yp = run_spmv(ctx, rp, ci, va, x, nrows, ncols, alpha, beta,
-                          None if beta == 0 else y0, algo=algo,
-                          knobs=dict(pipeline=1))
-            assert np.array_equal(yp, y_ref), (alpha, beta, "pipeline")
         if algo in EXACT_ALGOS:
             assert np.array_equal(y, y_ref), (alpha, beta)
         else:
@@ -365,8 +357,7 @@ def test_device_poisson_matches_host(ctx, n, P):
 # CG building blocks: drive the kernels exactly as spmv::cg does and compare
 # with the oracle's CG (cg.cpp:21-98)
 # ---------------------------------------------------------------------------
-def gpu_cg(ctx, blk, b, kmax, rtol, fused_dot=True, regrouped=False,
-           single_launch=False):
+def gpu_cg(ctx, blk, b, kmax, rtol, fused_dot=True, regrouped=False):
     n = blk.nrows
     ws = C.c_void_p()
     hip.call("spmv_hip_cg_ws_create", ctx.h, kmax, C.byref(ws))
@@ -375,32 +366,9 @@ def gpu_cg(ctx, blk, b, kmax, rtol, fused_dot=True, regrouped=False,
     hip.call("spmv_hip_cg_ws_partials", ws, C.byref(part))
     r, p = ctx.upload(b), ctx.upload(b)
     x, Ap = ctx.zeros(n, np.float64), ctx.zeros(n, np.float64)
-    if single_launch:  # exactly the sequence of spmv::cg (host/cg.cpp)
-        cnt = C.c_void_p()
-        hip.call("spmv_hip_cg_ws_counter", ws, C.byref(cnt))
-        hip.call("spmv_hip_cg_dot_rr0_f64", ctx.h, ws, n, r.ptr, None)
-        for k in range(1, kmax + 1):
-            slot = C.c_void_p()
-            hip.call("spmv_hip_cg_ws_pAp", ws, k, C.byref(slot))
-            if blk.symmetric:
-                blk.mult(1.0, p.ptr, 0.0, Ap.ptr)
-                hip.call("spmv_hip_cg_dot_pAp_f64", ctx.h, ws, k, n, p.ptr,
-                         Ap.ptr, None)
-            else:
-                hip.call("spmv_hip_csr_spmv_dot_f64", ctx.h, blk.plan, n,
-                         blk.ncols, blk.nnz, blk.rowptr.ptr, blk.colind.ptr,
-                         blk.values.ptr, 1.0, p.ptr, 0.0, Ap.ptr, part, slot,
-                         cnt, 0, None)
-            hip.call("spmv_hip_cg_update_r_fused_f64", ctx.h, ws, k, n, Ap.ptr,
-                     r.ptr, None)
-            hip.call("spmv_hip_cg_update_xp_f64", ctx.h, ws, k, n, r.ptr, x.ptr,
-                     p.ptr, None)
-        kmax_loop = 0
-    else:
-        hip.call("spmv_hip_cg_dot_rr_f64", ctx.h, ws, n, r.ptr, None)
-        hip.call("spmv_hip_cg_reduce_rr", ctx.h, ws, 0, None)
-        kmax_loop = kmax
-    for k in range(1, kmax_loop + 1):
+    hip.call("spmv_hip_cg_dot_rr_f64", ctx.h, ws, n, r.ptr, None)
+    hip.call("spmv_hip_cg_reduce_rr", ctx.h, ws, 0, None)
+    for k in range(1, kmax + 1):
         if fused_dot and not blk.symmetric:
             blk.mult(1.0, p.ptr, 0.0, Ap.ptr, dot_partials=part)
         else:
@@ -451,13 +419,6 @@ def test_cg_kernels_match_oracle(ctx, symmetric):
     # both groupings of the vector updates are the same arithmetic
     x2, flags2, hist2 = gpu_cg(ctx, blk, b, 200, 1e-10, regrouped=True)
     assert np.array_equal(flags, flags2)
-    x3, flags3, hist3 = gpu_cg(ctx, blk, b, 200, 1e-10, single_launch=True)
-    assert flags3[0] == 1 and abs(int(flags3[1]) - int(flags[1])) <= 1
-    if not symmetric:  # same partials, same summation order => same bits
-        assert np.array_equal(flags, flags3)
-        assert np.array_equal(x, x3) and np.array_equal(hist, hist3)
-    else:
-        assert np.linalg.norm(x - x3) <= 1e-9 * np.linalg.norm(x)
     if not symmetric:  # deterministic kernels: bit-identical
         assert np.array_equal(x, x2) and np.array_equal(hist, hist2)
     else:
@@ -531,57 +492,28 @@ def test_full_size_properties(ctx, n):
     blk.free(), sym.free()
 
 
-# ---------------------------------------------------------------------------
-# single-launch (last-workgroup) reductions == the two-stage ones, bit for bit
-# ---------------------------------------------------------------------------
-def test_fused_reductions_match_two_stage(ctx):
-    rng = np.random.default_rng(21)
-    counter = ctx.zeros(33, np.uint32)
-    res = ctx.empty(2, np.float64)
-    part = ctx.empty(ctx.dot_partials_len, np.float64)
-    for n in (1, 2, 513, 1 << 16, (1 << 22) + 3):
-        x, y = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
-        dx, dy = ctx.upload(x), ctx.upload(y)
-        two_stage = ctx.dot(n, dx.ptr, dy.ptr)
-        for rep in range(3):  # the ticket resets itself between launches
-            hip.call("spmv_hip_dot_f64", ctx.h, n, dx.ptr, dy.ptr, part.ptr,
-                     res.ptr, counter.ptr, None)
-            assert res.numpy(1)[0] == two_stage
-            assert not counter.numpy().any()
-        dx.free(), dy.free()
-    # SpMV with the fused p.Ap: assign, then accumulate a second block's share
+def test_spmv_dot_partials_all_general_kernels(ctx):
+    """The p.Ap share every general kernel leaves next to y: the partials add
+    up to x.(A x) whatever kernel (and row grouping) produced them."""
     n = 20
     N = n ** 3
     rp, ci, va = poisson.poisson3d_csr(n)
     ci = ci.astype(np.int32)
     blk = hip.CsrBlock(ctx, N, N, rp, ci, va)
     x = oracle.gaussian_x_fast(N)
+    part = ctx.empty(ctx.dot_partials_len, np.float64)
     dx, dy = ctx.upload(x), ctx.empty(N, np.float64)
-    blk.mult(1.0, dx.ptr, 0.0, dy.ptr, dot_partials=part.ptr)
-    ref = ctx.empty(1, np.float64)
-    hip.call("spmv_hip_reduce_partials_f64", ctx.h, part.ptr, ref.ptr, None)
-    expect = ref.numpy()[0]
     y_ref = oracle.csr_spmv(rp, ci, va, x)
-    assert abs(expect - float(x @ y_ref)) <= 1e-12 * abs(expect)
-    for knobs in (dict(), dict(algo=hip.ALGO_SCALAR), dict(algo=hip.ALGO_VECTOR),
-                  dict(wave_private=1)):
+    expect = float(x @ y_ref)
+    for knobs in (dict(), dict(algo=hip.ALGO_SCALAR), dict(algo=hip.ALGO_VECTOR)):
         for k, v in knobs.items():
             blk.set(k, v)
-        for accumulate in (0, 1):
-            ctx.fill_const(1, 100.0, res.ptr)
-            hip.call("spmv_hip_csr_spmv_dot_f64", ctx.h, blk.plan, N, N, blk.nnz,
-                     blk.rowptr.ptr, blk.colind.ptr, blk.values.ptr, 1.0, dx.ptr,
-                     0.0, dy.ptr, part.ptr, res.ptr, counter.ptr, accumulate,
-                     None)
-            got = res.numpy(1)[0] - (100.0 if accumulate else 0.0)
-            if knobs or accumulate:  # other kernels group the rows differently
-                assert abs(got - expect) <= 1e-12 * abs(expect)
-            else:                    # same kernel, same order: same bits
-                assert got == expect
-            assert np.array_equal(dy.numpy(), y_ref) or knobs.get("algo") == hip.ALGO_VECTOR
+        blk.mult(1.0, dx.ptr, 0.0, dy.ptr, dot_partials=part.ptr)
+        got = float(np.sum(part.numpy()))
+        assert abs(got - expect) <= 1e-12 * abs(expect), knobs
+        assert np.array_equal(dy.numpy(), y_ref) or knobs.get("algo") == hip.ALGO_VECTOR
         blk.set("algo", hip.ALGO_ROWBLOCK)
-        blk.set("wave_private", 0)
-    for b in (dx, dy, counter, res, part, ref):
+    for b in (dx, dy, part):
         b.free()
     blk.free()
 
@@ -728,61 +660,6 @@ def test_fuzz_shapes_all_kernels(ctx):
 
 
 # ---------------------------------------------------------------------------
-# band-sweep row-block order (plan-time table for lattice-structured matrices)
-# ---------------------------------------------------------------------------
-@pytest.mark.parametrize("n", [16, 20, 33])
-def test_band_order_is_a_permutation_of_the_work(ctx, n):
-    """Any band height gives the same bits as the plain order: the table only
-    permutes row blocks.  Small grids never build a table on their own, so it
-    is forced through the knob."""
-    rp, ci, va = poisson.poisson3d_csr(n)
-    ci = ci.astype(np.int32)
-    N = n ** 3
-    x = oracle.gaussian_x_fast(N)
-    y_ref = oracle.csr_spmv(rp, ci, va, x, 0.5, 0.0)
-    blk = hip.CsrBlock(ctx, N, N, rp, ci, va, None, False, hip.ALGO_ROWBLOCK)
-    assert blk.get("lattice_d1") == n and blk.get("lattice_d2") == n * n
-    assert blk.get("order_slots") == 0  # too small to need it
-    dx = ctx.upload(x)
-    for yc in (0, 1, 3, 8, n, 5 * n):
-        blk.set("band_lines", yc)
-        nrb = (N + 255) // 256
-        assert blk.get("order_slots") >= nrb and blk.get("order_slots") % 8 == 0
-        if yc:
-            assert blk.get("band_lines") == yc
-        for knobs in (dict(), dict(pipeline=1), dict(wave_private=1),
-                      dict(blocks_per_cu=1), dict(nontemporal=0, chunks=4)):
-            for k, v in {**dict(pipeline=0, wave_private=0, blocks_per_cu=7,
-                                nontemporal=1, chunks=1), **knobs}.items():
-                blk.set(k, v)
-            dy = ctx.upload(np.full(N, np.nan))
-            blk.mult(0.5, dx.ptr, 0.0, dy.ptr)
-            assert np.array_equal(dy.numpy(), y_ref), (yc, knobs)
-            dy.free()
-        blk.set("band_order", 0)
-        assert blk.get("band_order") == 0
-        blk.set("band_order", 1)
-    dx.free()
-    blk.free()
-
-
-def test_no_lattice_no_band_order(ctx):
-    rng = np.random.default_rng(8)
-    rp, ci, va = random_csr(rng, 5000, 5000, 6)
-    blk = hip.CsrBlock(ctx, 5000, 5000, rp, ci, va, None, False, hip.ALGO_ROWBLOCK)
-    assert blk.get("lattice_d1") == 0 and blk.get("order_slots") == 0
-    with pytest.raises(Exception):
-        blk.set("band_lines", 4)
-    blk.free()
-    # the 1-D operator has one off-diagonal distance only: no planes, no table
-    rp, ci, va = oracle.tridiag_csr(100000)
-    blk = hip.CsrBlock(ctx, 100000, 100000, rp, ci, va, None, False,
-                       hip.ALGO_ROWBLOCK)
-    assert blk.get("lattice_d2") == 0 and blk.get("order_slots") == 0
-    blk.free()
-
-
-# ---------------------------------------------------------------------------
 # LX form: LDS-staged x windows + 16-bit local column offsets
 # ---------------------------------------------------------------------------
 @pytest.fixture()
@@ -872,7 +749,7 @@ def test_lx_fused_dot_and_row_block_orders(lx_ctx):
     dx, dy = ctx.upload(x), ctx.upload(np.zeros(N))
     part = ctx.empty(ctx.dot_partials_len, np.float64)
     want = float(np.dot(x, y_ref))
-    for knobs in (dict(), dict(xcd_group=0), dict(xcd_group=3), dict(band_lines=4),
+    for knobs in (dict(), dict(xcd_group=0), dict(xcd_group=3),
                   dict(blocks_per_cu=1), dict(blocks_per_cu=8)):
         for k, v in knobs.items():
             blk.set(k, v)
@@ -942,3 +819,151 @@ def test_lx_fuzz_banded(lx_ctx):
             dy.free()
         dx.free()
         blk.free()
+
+
+# ---------------------------------------------------------------------------
+# Lattice form (spmv_lat.hip): constant column offsets per row block, values by
+# LDS-DMA one row block ahead, no index stream.  Same bits as the oracle.
+# ---------------------------------------------------------------------------
+@pytest.fixture()
+def lat_ctx():
+    c = hip.Context(0)
+    c.set_option("lat_min_nnz", 0)  # try the form on small test matrices too
+    c.set_option("lx_min_nnz", 0)
+    yield c
+    c.close()
+
+
+def _stencil_csr(rng, N, offsets, drop=0.0, dtype=np.float64):
+    """Rows i with entries in columns i + d for d in `offsets` (ascending),
+    kept when in range and, with probability `drop`, removed at random."""
+    rows, cols = [], []
+    for d in sorted(offsets):
+        i = np.arange(max(0, -d), min(N, N - d))
+        keep = rng.random(len(i)) >= drop
+        rows.append(i[keep])
+        cols.append(i[keep] + d)
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    order = np.lexsort((cols, rows))
+    rows, cols = rows[order], cols[order]
+    rp = np.zeros(N + 1, np.int64)
+    np.add.at(rp, rows + 1, 1)
+    return (np.cumsum(rp).astype(np.int32), cols.astype(np.int32),
+            rng.uniform(-1, 1, len(cols)).astype(dtype))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_lattice_form_bit_exact(lat_ctx, dtype):
+    ctx = lat_ctx
+    rng = np.random.default_rng(91)
+    cases = []
+    for n in (4, 9, 16, 33):  # 64 rows (one partial block) ... 35,937 rows
+        rp, ci, va = poisson.poisson3d_csr(n)
+        cases.append((f"poisson{n}", rp, ci.astype(np.int32), va, n ** 3))
+    rp, ci, va = oracle.tridiag_csr(70001)
+    cases.append(("tridiag", rp, ci, va, 70001))
+    # eight offsets, a third of the entries missing at random, empty rows
+    cases.append(("eight", *_stencil_csr(rng, 9001, [-700, -33, -2, -1, 0, 1, 40, 900],
+                                         drop=0.33), 9001))
+    # odd entry count at the end of the array: the last 16-byte chunk of
+    # `values` would end past it (element-wise path of the last row block)
+    rp, ci, va = _stencil_csr(rng, 1025, [-1, 0, 5])
+    assert len(va) % 2 == 1
+    cases.append(("odd_tail", rp, ci, va, 1025))
+    for name, rp, ci, va, N in cases:
+        va = va.astype(dtype)
+        x = rng.uniform(-1, 1, N).astype(dtype)
+        y0 = rng.uniform(-1, 1, N).astype(dtype)
+        blk = hip.CsrBlock(ctx, N, N, rp, ci, va, None, False,
+                           hip.ALGO_ROWBLOCK, dtype)
+        assert blk.get("lat") == 1, name
+        assert blk.get("lat_blocks") == (N + 255) // 256
+        assert blk.get("lx") == 0  # not built when the lattice form was taken
+        dx = ctx.upload(x, dtype)
+        part = ctx.empty(ctx.dot_partials_len, np.float64)
+        for alpha, beta in ((1.0, 0.0), (-0.5, 0.0), (2.0, 1.0), (1.0, -0.25)):
+            y_ref = oracle.csr_spmv(rp, ci, va, x, alpha, beta, y0)
+            for knobs in (dict(lat=1, nontemporal=1), dict(lat=1, nontemporal=0),
+                          dict(lat_blocks_per_cu=1, lat_xcd_group=3),
+                          dict(lat_blocks_per_cu=2, lat_xcd_group=16),
+                          dict(lat=0)):
+                for k, v in knobs.items():
+                    blk.set(k, v)
+                dy = ctx.upload(np.full(N, np.nan, dtype) if beta == 0 else y0,
+                                dtype)
+                dot = dtype == np.float64 and alpha == 1.0 and beta == 0.0
+                blk.mult(alpha, dx.ptr, beta, dy.ptr,
+                         dot_partials=part.ptr if dot else None)
+                y = dy.numpy()
+                dy.free()
+                assert np.array_equal(y, y_ref), (name, alpha, beta, knobs)
+                if dot:
+                    want = float(np.dot(x.astype(np.float64), y_ref))
+                    got = float(np.sum(part.numpy()))
+                    assert abs(got - want) <= 1e-12 * max(abs(want), 1.0), (name, knobs)
+            for k, v in dict(lat_blocks_per_cu=4, lat_xcd_group=0).items():
+                blk.set(k, v)
+        dx.free(), part.free()
+        blk.free()
+
+
+def test_lattice_form_is_refused_when_it_does_not_apply(lat_ctx):
+    """Nine offsets, unsorted or repeated columns, scattered columns: the plan
+    falls back (LX form or gather) and the results stay exact."""
+    ctx = lat_ctx
+    rng = np.random.default_rng(92)
+    N = 6000
+    cases = []
+    cases.append(("nine", *_stencil_csr(rng, N, [-900, -40, -3, -2, -1, 0, 1, 2, 77])))
+    rp, ci, va = _stencil_csr(rng, N, [-5, -1, 0, 1, 9])
+    ci2 = ci.copy()  # swap the first two columns of one row: no longer ascending
+    r = 3000
+    ci2[rp[r]], ci2[rp[r] + 1] = ci[rp[r] + 1], ci[rp[r]]
+    cases.append(("unsorted_row", rp, ci2, va))
+    ci3 = ci.copy()  # a repeated column
+    ci3[rp[r] + 1] = ci3[rp[r]]
+    cases.append(("repeat", rp, ci3, va))
+    cases.append(("random", *random_csr(rng, N, N, 6)))
+    for name, rp, ci, va in cases:
+        blk = hip.CsrBlock(ctx, N, N, rp, ci, va, None, False, hip.ALGO_ROWBLOCK)
+        assert blk.get("lat") == 0, name
+        assert blk.get("lat_blocks") < (N + 255) // 256
+        with pytest.raises(Exception):
+            blk.set("lat", 1)
+        x = rng.uniform(-1, 1, N)
+        dx, dy = ctx.upload(x), ctx.upload(np.full(N, np.nan))
+        blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+        assert np.array_equal(dy.numpy(), oracle.csr_spmv(rp, ci, va, x)), name
+        dx.free(), dy.free()
+        blk.free()
+
+
+def test_lattice_form_rectangular_and_empty_rows(lat_ctx):
+    """Columns beyond the row count (a block with a ghost tail), rows without
+    entries, a matrix of a single row."""
+    ctx = lat_ctx
+    rng = np.random.default_rng(93)
+    N, ncols = 3000, 3500
+    rows = np.arange(N)
+    keep = rng.random(N) > 0.2
+    rp = np.zeros(N + 1, np.int64)
+    rp[1:] = np.cumsum(np.where(keep, 2, 0))
+    ci = np.stack([rows[keep], rows[keep] + 500], 1).reshape(-1).astype(np.int32)
+    va = rng.uniform(-1, 1, len(ci))
+    x = rng.uniform(-1, 1, ncols)
+    blk = hip.CsrBlock(ctx, N, ncols, rp.astype(np.int32), ci, va, None, False,
+                       hip.ALGO_ROWBLOCK)
+    assert blk.get("lat") == 1
+    dx, dy = ctx.upload(x), ctx.upload(np.full(N, np.nan))
+    blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+    assert np.array_equal(dy.numpy(), oracle.csr_spmv(rp.astype(np.int32), ci, va, x))
+    dx.free(), dy.free()
+    blk.free()
+    one = hip.CsrBlock(ctx, 1, 1, np.array([0, 1], np.int32), np.array([0], np.int32),
+                       np.array([3.0]), None, False, hip.ALGO_ROWBLOCK)
+    assert one.get("lat") == 1
+    dx, dy = ctx.upload(np.array([2.0])), ctx.upload(np.array([np.nan]))
+    one.mult(1.0, dx.ptr, 0.0, dy.ptr)
+    assert dy.numpy()[0] == 6.0
+    dx.free(), dy.free()
+    one.free()

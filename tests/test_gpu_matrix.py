@@ -250,29 +250,6 @@ def test_read_petsc_binary(exec_, comm, tmp_path, symmetric):
     exec_.free(d_b), exec_.free(d_x)
 
 
-def test_cg_fused_reductions_equal_default(exec_, comm):
-    """CgOptions::fused_reductions only changes who adds the partials: same
-    order, same bits."""
-    n = 11
-    N = n ** 3
-    rp, ci, va = poisson.poisson3d_csr(n)
-    b = oracle.gaussian_x_fast(N)
-    A = host.Matrix.create_matrix(comm, exec_, rp, ci, va, N, N, [], [], False,
-                                  host.P2P_NONBLOCKING)
-    d_b, d_x = exec_.alloc(N), exec_.alloc(N)
-    exec_.copy_from_host(d_b, b)
-    out = []
-    for fused in (False, True):
-        k, hist, _, _ = host.cg_ex(comm, exec_, A, d_b, d_x, 60, 1e-9,
-                                   history=True, fused_reductions=fused)
-        out.append((k, hist.copy(), exec_.copy_to_host(d_x, N)))
-    assert out[0][0] == out[1][0] and out[0][0] < 60
-    assert np.array_equal(out[0][1], out[1][1])
-    assert np.array_equal(out[0][2], out[1][2])
-    A.close()
-    exec_.free(d_b), exec_.free(d_x)
-
-
 @pytest.mark.parametrize("symmetric", [False, True])
 def test_matrix_fp32(exec_, comm, symmetric):
     """Matrix<float>: the fp32 visitors of the executor interface

@@ -7,7 +7,6 @@ Algorithmic bytes follow SURVEY section 8d.  Prints one JSON line per variant.
 """
 import argparse
 import ctypes as C
-import itertools
 import json
 import os
 import sys
@@ -45,8 +44,6 @@ def main():
     ap.add_argument("--fp32", action="store_true",
                     help="also time the fp32 instantiation (host-built matrix)")
     ap.add_argument("--only", default=None, help="comma list of variants")
-    ap.add_argument("--band-lines", type=int, nargs="*", default=[],
-                    help="extra band heights of the band-sweep order to time")
     args = ap.parse_args()
     ctx = hip.Context(0)
     results = []
@@ -72,53 +69,37 @@ def main():
              gbs=2 * nb / tmin / 1e6, frac=2 * nb / tmin / 1e6 / HBM_PEAK)
         src.free(), dst.free()
 
-        variants = []
-        if blk.get("lattice_d2") > 0 and args.band_lines:
-            blk.set("band_lines", 0)  # build the (opt-in) band-sweep table
-        has_band = blk.get("order_slots") > 0
-        print(json.dumps(dict(n=n, lattice=(blk.get("lattice_d1"),
-                                            blk.get("lattice_d2")),
-                              band_lines=blk.get("band_lines"))), flush=True)
-        for band, pipe, wavep, nt, bpc in itertools.product(
-                [1, 0] if has_band else [0], [0, 1], [0, 1], [0, 1], [8, 7]):
-            if pipe and wavep:
-                continue
-            variants.append(("rowblock", dict(algo=hip.ALGO_ROWBLOCK, chunks=1,
-                                              nontemporal=nt, xcd_group=16,
-                                              band_order=band, pipeline=pipe,
-                                              wave_private=wavep,
-                                              blocks_per_cu=bpc)))
-        if has_band and args.band_lines:
-            for yc in args.band_lines:
-                variants.append(("rowblock", dict(band_lines=yc, band_order=1,
-                                                  pipeline=0, wave_private=0,
-                                                  nontemporal=1,
-                                                  blocks_per_cu=8)))
-            variants.append(("rowblock", dict(band_lines=0)))
-        variants.append(("scalar", dict(algo=hip.ALGO_SCALAR)))
-        for lpr in (4, 8):
-            variants.append(("vector", dict(algo=hip.ALGO_VECTOR,
-                                            lanes_per_row=lpr)))
-        for name, kn in variants:
+        # the three forms of the general kernel, each on its own plan: lattice
+        # (default for this matrix), LX (lattice switched off), plain gather
+        forms = [("lattice", blk, dict())]
+        ctx.set_option("lat_min_nnz", 1 << 62)
+        lx = hip.poisson3d_block(ctx, n, 0, N, hip.PART_ALL)
+        forms.append(("lx", lx, dict()))
+        forms.append(("gather", lx, dict(lx=0)))
+        ctx.set_option("lat_min_nnz", 1 << 20)
+        for name, b, kn in forms:
             for k, v in kn.items():
-                blk.set(k, v)
+                b.set(k, v)
+            for dot in (False, True):
+                tmin, tmed = time_ms(
+                    ctx, lambda: b.mult(1.0, x.ptr, 0.0, y.ptr,
+                                        dot_partials=part.ptr if dot else None),
+                    reps)
+                emit(n=n, variant=name + ("+dot" if dot else ""),
+                     form=dict(lat=b.get("lat"), lx=b.get("lx")), ms=tmin,
+                     ms_med=tmed, gbs=bytes_csr / tmin / 1e6,
+                     frac=bytes_csr / tmin / 1e6 / HBM_PEAK)
+        lx.set("lx", 1)
+        for name, kn in (("scalar", dict(algo=hip.ALGO_SCALAR)),
+                         ("vector", dict(algo=hip.ALGO_VECTOR, lanes_per_row=8))):
+            for k, v in kn.items():
+                lx.set(k, v)
             tmin, tmed = time_ms(
-                ctx, lambda: blk.mult(1.0, x.ptr, 0.0, y.ptr), reps)
+                ctx, lambda: lx.mult(1.0, x.ptr, 0.0, y.ptr), reps)
             emit(n=n, variant=name, knobs=kn, ms=tmin, ms_med=tmed,
                  gbs=bytes_csr / tmin / 1e6,
                  frac=bytes_csr / tmin / 1e6 / HBM_PEAK)
-        # fused dot on the default variant
-        for pipe in (0, 1):
-            for k, v in dict(algo=hip.ALGO_ROWBLOCK, chunks=1, nontemporal=0,
-                             xcd_group=16, blocks_per_cu=7, wave_private=0,
-                             pipeline=pipe).items():
-                blk.set(k, v)
-            tmin, tmed = time_ms(
-                ctx, lambda: blk.mult(1.0, x.ptr, 0.0, y.ptr,
-                                      dot_partials=part.ptr), reps)
-            emit(n=n, variant="rowblock+dot", knobs=dict(pipeline=pipe),
-                 ms=tmin, ms_med=tmed, gbs=bytes_csr / tmin / 1e6,
-                 frac=bytes_csr / tmin / 1e6 / HBM_PEAK)
+        lx.free()
         blk.free()
 
         if args.fp32 and n <= 256:

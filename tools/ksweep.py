@@ -25,6 +25,8 @@ def main():
                     help="name=v1,v2,... (applied in the order given)")
     ap.add_argument("--dot", action="store_true", help="fused p.Ap partials")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--calib", action="store_true",
+                    help="also time plain streaming kernels on this box")
     args = ap.parse_args()
     ctx = hip.Context(0)
     ctx.set_option("lx_max_x_bytes", 1 << 62)  # build the LX form at any size
@@ -34,6 +36,19 @@ def main():
     ctx.fill_gaussian(N, 0, N, x.ptr)
     part = ctx.empty(ctx.dot_partials_len, np.float64)
     nbytes = poisson.csr_bytes(N, N, blk.nnz)
+    if args.calib:
+        # what this box streams: a dot product over two N-vectors (reads) and a
+        # fill (writes), both through the library's BLAS-1 kernels
+        y2 = ctx.empty(N, np.float64)
+        ctx.fill_const(N, 1.0, y2.ptr)
+        b_r, _ = time_ms(ctx, lambda: hip.call("spmv_hip_dot_partial_f64", ctx.h,
+                                               N, x.ptr, y2.ptr, part.ptr, None),
+                         args.reps)
+        b_w, _ = time_ms(ctx, lambda: ctx.fill_const(N, 1.0, y2.ptr), args.reps)
+        print(json.dumps(dict(calib=dict(read_gbs=round(16 * N / b_r / 1e6, 1),
+                                         write_gbs=round(8 * N / b_w / 1e6, 1)))),
+              flush=True)
+        y2.free()
     names = [k.split("=")[0] for k in args.knob]
     values = [[int(v) for v in k.split("=")[1].split(",")] for k in args.knob]
     rows = []
