@@ -115,6 +115,12 @@ struct spmv_hip_csr_plan {
   int sym_window = 256;   // symmetric: LDS window below the block (0 = plain
                           // per-entry global atomics)
   int sym_rows = 1024;    // symmetric: rows per workgroup (512, 1024, 2048)
+  // symmetric, deterministic: the transposed map (spmv_sym.hip); sym_det = 0
+  // runs the atomic kernels (plan_set "sym_det")
+  int32_t* t_ptr = nullptr; // rows + 1
+  int32_t* t_pos = nullptr; // per stored entry: position in `values` ...
+  int32_t* t_row = nullptr; // ... and its row, sorted by column
+  int sym_det = 0;
   int32_t* row_list = nullptr; // ROWLIST: device list of non-empty rows
   int32_t num_listed = 0;
   int nt_store = 0; // non-temporal y stores
@@ -159,6 +165,9 @@ int spmv_run_symmetric_f32(const spmv_hip_csr_plan* pl, hipStream_t st,
                            const float* values, const float* diagonal,
                            float alpha, const float* in, float beta,
                            float* out);
+int spmv_symt_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
+                    const int32_t* colind);
+void spmv_symt_free(spmv_hip_csr_plan* pl);
 // spmv_lat.hip
 int spmv_lat_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
                    const int32_t* colind);

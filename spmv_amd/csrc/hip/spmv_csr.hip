@@ -1002,17 +1002,28 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
       return rc;
     }
   }
+  if (symmetric && num_non_zeros > 0) {
+    // atomic-free, bit-exact form (the default when the block is strictly
+    // lower triangular)
+    const int rc = spmv_symt_build(pl, rowptr, colind);
+    if (rc != SPMV_HIP_OK) {
+      spmv_hip_csr_plan_destroy(pl);
+      return rc;
+    }
+  }
   *plan = pl;
   return SPMV_HIP_OK;
 }
 
 int spmv_hip_csr_plan_destroy(spmv_hip_csr_plan* plan)
 {
-  if (plan && (plan->row_list || plan->lx_lidx || plan->lat_tab)) {
+  if (plan
+      && (plan->row_list || plan->lx_lidx || plan->lat_tab || plan->t_ptr)) {
     (void)hipSetDevice(plan->ctx->device);
     (void)hipFree(plan->row_list);
     free_lx(plan);
     spmv_lat_free(plan);
+    spmv_symt_free(plan);
   }
   delete plan;
   return SPMV_HIP_OK;
@@ -1064,6 +1075,10 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
     plan->lx_chunks = value;
   } else if (!strcmp(key, "nt_store")) {
     plan->nt_store = value != 0;
+  } else if (!strcmp(key, "sym_det")) {
+    // 1 needs the transposed map built at plan creation
+    SPMV_REQUIRE(value == 0 || plan->t_ptr);
+    plan->sym_det = value != 0;
   } else if (!strcmp(key, "lat")) {
     // 1 needs the lattice form built at plan creation
     SPMV_REQUIRE(value == 0 || plan->lat_tab);
@@ -1086,6 +1101,8 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
   SPMV_REQUIRE(plan && key && value);
   if (!strcmp(key, "algo"))
     *value = plan->algo;
+  else if (!strcmp(key, "sym_det"))
+    *value = plan->sym_det;
   else if (!strcmp(key, "lat"))
     *value = plan->lat;
   else if (!strcmp(key, "lat_blocks"))

@@ -3,6 +3,7 @@
 #include "csr_plan.h"
 
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+#include <hipcub/hipcub.hpp>
 
 namespace
 {
@@ -287,6 +288,142 @@ __global__ __launch_bounds__(kBlock) void csr_sym_window_kernel(
 namespace
 {
 
+// ---------------------------------------------------------------------------
+// Deterministic symmetric kernel ("transposed map").
+//
+// The reference walks the rows in ascending order and, for a stored entry
+// (r, c, v) with c < r, adds alpha*v*x[r] to out[c] AFTER out[c] was finalised
+// by its own row (csr_kernels.cpp:30-39).  Seen from row i, its result is
+//   y_i = fl(alpha * sum_i + beta * y0_i)            sum_i = d_i x_i, then the
+//                                                    row's entries left to right
+//   y_i += fl(fl(alpha * v) * x_r)                   for every stored entry
+//                                                    (r, i), ascending (r, j)
+// which needs no atomics if row i can find the entries of its COLUMN.  Plan
+// creation builds that map once (a stable sort of the entries by column):
+//   t_ptr[i] .. t_ptr[i+1]   row i's column entries, in the reference's order
+//   t_pos[e]                 position of the entry in `values`
+//   t_row[e]                 its row r
+// The kernel is the row-block kernel run twice over the same 256 rows: the
+// products of the row's own entries, then the products of its column's
+// entries, both parked in LDS and added left to right by the row's lane.
+// No zero-fill pass, every y written once, results bit-identical to the
+// oracle.  Costs 8 B per stored entry of plan memory.
+// ---------------------------------------------------------------------------
+template <typename T, bool DOT>
+__global__ __launch_bounds__(kBlock) void csr_symt_kernel(
+    int32_t num_rows, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ colind, const T* __restrict__ values,
+    const T* __restrict__ diagonal, const int32_t* __restrict__ t_ptr,
+    const int32_t* __restrict__ t_pos, const int32_t* __restrict__ t_row,
+    T alpha, const T* __restrict__ in, T beta, T* __restrict__ out, DotOut dot,
+    int num_row_blocks)
+{
+  constexpr int TILE = 4 * kBlock;
+  __shared__ T s_prod[TILE];
+  __shared__ int32_t s_ptr[kRows + 1];
+  __shared__ double s_red[kBlock / 64];
+  const int t = threadIdx.x;
+  double dot_acc = 0.0;
+  for (int rb = blockIdx.x; rb < num_row_blocks; rb += gridDim.x) {
+    const int32_t r0 = rb * kRows;
+    const int nr = min(kRows, num_rows - r0);
+    const int32_t r = r0 + t;
+    T xi = T(0), acc = T(0), cacc = T(0);
+    // phase 0: the row's own entries (v * x[c]);  phase 1: its column's
+    // entries ((alpha v) * x[r'])
+    for (int phase = 0; phase < 2; ++phase) {
+      const int32_t* ptr = phase == 0 ? rowptr : t_ptr;
+      __syncthreads(); // previous pass done with s_ptr / s_prod
+      if (t <= nr)
+        s_ptr[t] = ptr[r0 + t];
+      if (t == 0 && nr == kRows)
+        s_ptr[kRows] = ptr[r0 + kRows];
+      __syncthreads();
+      const int32_t a = s_ptr[0], b = s_ptr[nr];
+      int32_t lo = 0, hi = 0;
+      if (t < nr) {
+        lo = s_ptr[t];
+        hi = s_ptr[t + 1];
+      }
+      if (phase == 0 && t < nr) {
+        xi = in[r];
+        acc = diagonal[r] * xi; // csr_kernels.cpp:28
+      }
+      for (int64_t base = a; base < b; base += TILE) {
+        if (base != a)
+          __syncthreads(); // row owners finished reading the previous tile
+#pragma unroll
+        for (int c = 0; c < TILE / kBlock; ++c) {
+          const int64_t j = base + c * kBlock + t;
+          T p = T(0);
+          if (j < b) {
+            if (phase == 0) {
+              p = values[j] * in[colind[j]]; // :34
+            } else {
+              const T av = alpha * values[t_pos[j]]; // :35, left to right
+              p = av * in[t_row[j]];
+            }
+          }
+          s_prod[c * kBlock + t] = p;
+        }
+        __syncthreads();
+        const int32_t jlo = (int32_t)(max((int64_t)lo, base) - base);
+        const int32_t jhi = (int32_t)(min((int64_t)hi, base + TILE) - base);
+        for (int32_t j = jlo; j < jhi; ++j) {
+          acc += s_prod[j];
+          if (phase == 1)
+            cacc += s_prod[j];
+        }
+      }
+      if (phase == 0 && t < nr) {
+        const T c = alpha * acc; // :39
+        cacc = c;
+        acc = c;
+        if (beta != T(0))
+          acc = c + beta * out[r];
+      }
+    }
+    if (t < nr) {
+      out[r] = acc;
+      if constexpr (DOT) // in . (alpha A in): the row's share without beta y0
+        dot_acc += (double)xi * (double)cacc;
+    }
+  }
+  if constexpr (DOT)
+    spmv_dot_epilogue(dot, dot_acc, s_red);
+}
+
+__global__ __launch_bounds__(kBlock) void symt_rowidx_kernel(
+    int32_t num_rows, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ colind, int32_t* __restrict__ rowidx,
+    int32_t* __restrict__ pos, int32_t* __restrict__ count,
+    int32_t* __restrict__ not_lower)
+{
+  // one lane per row: the row index and position of every entry, the column
+  // histogram, and the check that the block is strictly lower triangular
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < num_rows;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+      rowidx[j] = (int32_t)i;
+      pos[j] = j;
+      const int32_t c = colind[j];
+      if (c >= i || c < 0)
+        atomicOr(not_lower, 1);
+      else
+        atomicAdd(count + c, 1);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void symt_gather_rows_kernel(
+    int64_t n, const int32_t* __restrict__ rowidx,
+    const int32_t* __restrict__ t_pos, int32_t* __restrict__ t_row)
+{
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (int64_t)gridDim.x * blockDim.x)
+    t_row[e] = rowidx[t_pos[e]];
+}
+
 template <typename T>
 int run_symmetric(const spmv_hip_csr_plan* pl, hipStream_t st,
                   const int32_t* rowptr, const int32_t* colind,
@@ -305,7 +442,25 @@ int run_symmetric(const spmv_hip_csr_plan* pl, hipStream_t st,
     SPMV_CHECK_LAUNCH();
     return SPMV_HIP_OK;
   }
-  // pre-pass: out *= beta (zero-fill when beta == 0)
+  if (pl->sym_det && pl->t_ptr) {
+    const int nrb = (n + kRows - 1) / kRows;
+    int grid = pl->ctx->num_cus * pl->blocks_per_cu;
+    if (grid > pl->ctx->dot_blocks)
+      grid = pl->ctx->dot_blocks;
+    if (grid > nrb)
+      grid = nrb;
+    if (dot.partials)
+      hipLaunchKernelGGL((csr_symt_kernel<T, true>), dim3(grid), dim3(kBlock), 0,
+                         st, n, rowptr, colind, values, diagonal, pl->t_ptr,
+                         pl->t_pos, pl->t_row, alpha, in, beta, out, dot, nrb);
+    else
+      hipLaunchKernelGGL((csr_symt_kernel<T, false>), dim3(grid), dim3(kBlock),
+                         0, st, n, rowptr, colind, values, diagonal, pl->t_ptr,
+                         pl->t_pos, pl->t_row, alpha, in, beta, out, dot, nrb);
+    SPMV_CHECK_LAUNCH();
+    return SPMV_HIP_OK;
+  }
+  // atomic kernels.  pre-pass: out *= beta (zero-fill when beta == 0)
   if (beta != T(1)) {
     if (beta == T(0)) {
       SPMV_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(T) * (size_t)n, st));
@@ -394,4 +549,101 @@ int spmv_run_symmetric_f32(const spmv_hip_csr_plan* pl, hipStream_t st,
 {
   return run_symmetric<float>(pl, st, rowptr, colind, values, diagonal, alpha,
                               in, beta, out, DotOut());
+}
+
+void spmv_symt_free(spmv_hip_csr_plan* pl)
+{
+  (void)hipFree(pl->t_ptr);
+  (void)hipFree(pl->t_pos);
+  (void)hipFree(pl->t_row);
+  pl->t_ptr = pl->t_pos = pl->t_row = nullptr;
+  pl->sym_det = 0;
+}
+
+// Build the transposed map of a symmetric plan (see csr_symt_kernel).  Left
+// unbuilt -- the atomic kernels then run -- when the block is not strictly
+// lower triangular (the reference's finalise-then-scatter order is then not a
+// per-row gather) or when memory is short.
+int spmv_symt_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
+                    const int32_t* colind)
+{
+  SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
+  spmv_symt_free(pl);
+  const int32_t n = pl->num_rows;
+  const int64_t nnz = pl->nnz;
+  if (n == 0 || nnz == 0)
+    return SPMV_HIP_OK;
+  hipStream_t st = pl->ctx->stream;
+  int32_t *rowidx = nullptr, *pos = nullptr, *keys = nullptr, *flag = nullptr;
+  void* tmp = nullptr;
+  size_t tmp_bytes = 0, scan_bytes = 0;
+  int end_bit = 1;
+  while (end_bit < 31 && ((int64_t)1 << end_bit) < n)
+    ++end_bit;
+  hipError_t e = hipMalloc(&pl->t_ptr, sizeof(int32_t) * ((size_t)n + 1));
+  if (e == hipSuccess)
+    e = hipMalloc(&pl->t_pos, sizeof(int32_t) * (size_t)nnz);
+  if (e == hipSuccess)
+    e = hipMalloc(&pl->t_row, sizeof(int32_t) * (size_t)nnz);
+  if (e == hipSuccess)
+    e = hipMalloc(&rowidx, sizeof(int32_t) * (size_t)nnz);
+  if (e == hipSuccess)
+    e = hipMalloc(&pos, sizeof(int32_t) * (size_t)nnz);
+  if (e == hipSuccess)
+    e = hipMalloc(&keys, sizeof(int32_t) * (size_t)nnz);
+  if (e == hipSuccess)
+    e = hipMalloc(&flag, sizeof(int32_t));
+  if (e == hipSuccess)
+    e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, colind, keys, pos,
+                                           pl->t_pos, nnz, 0, end_bit, st);
+  if (e == hipSuccess)
+    e = hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, pl->t_ptr,
+                                         pl->t_ptr, n + 1, st);
+  if (e == hipSuccess)
+    e = hipMalloc(&tmp, (tmp_bytes > scan_bytes ? tmp_bytes : scan_bytes) + 16);
+  if (e == hipSuccess)
+    e = hipMemsetAsync(pl->t_ptr, 0, sizeof(int32_t) * ((size_t)n + 1), st);
+  if (e == hipSuccess)
+    e = hipMemsetAsync(flag, 0, sizeof(int32_t), st);
+  int32_t not_lower = 0;
+  if (e == hipSuccess) {
+    const int grid = spmv_grid_for(pl->ctx, n, kBlock);
+    hipLaunchKernelGGL(symt_rowidx_kernel, dim3(grid), dim3(kBlock), 0, st, n,
+                       rowptr, colind, rowidx, pos, pl->t_ptr, flag);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(&not_lower, flag, sizeof(int32_t), hipMemcpyDeviceToHost,
+                       st);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st);
+  if (e == hipSuccess && !not_lower) {
+    // entries by column, ties in their original (row, position) order: radix
+    // sort is stable
+    e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, colind, keys, pos,
+                                           pl->t_pos, nnz, 0, end_bit, st);
+    if (e == hipSuccess)
+      e = hipcub::DeviceScan::ExclusiveSum(tmp, scan_bytes, pl->t_ptr,
+                                           pl->t_ptr, n + 1, st);
+    if (e == hipSuccess) {
+      const int grid = spmv_grid_for(pl->ctx, nnz, kBlock);
+      hipLaunchKernelGGL(symt_gather_rows_kernel, dim3(grid), dim3(kBlock), 0,
+                         st, nnz, rowidx, pl->t_pos, pl->t_row);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+      e = hipStreamSynchronize(st);
+  }
+  (void)hipFree(tmp);
+  (void)hipFree(rowidx);
+  (void)hipFree(pos);
+  (void)hipFree(keys);
+  (void)hipFree(flag);
+  if (e != hipSuccess || not_lower) {
+    spmv_symt_free(pl);
+    return (e == hipSuccess || e == hipErrorOutOfMemory) ? SPMV_HIP_OK
+                                                         : static_cast<int>(e);
+  }
+  pl->sym_det = 1;
+  return SPMV_HIP_OK;
 }

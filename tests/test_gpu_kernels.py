@@ -6,8 +6,11 @@ tolerance"):
   * general CSR, ROWBLOCK and SCALAR kernels: BIT-EXACT against
     oracle.csr_spmv (= spmv/csr_kernels.cpp:41-51): same left-to-right order,
     no FMA contraction.
-  * VECTOR kernel and the symmetric (atomic) kernel: element-wise
-    |y - y_ref|_i <= 16 u (|alpha||A||x| + |beta||y0|)_i, u = 2^-53.
+  * symmetric storage, default (transposed map / symmetric lattice form):
+    BIT-EXACT against oracle.csr_spmv_sym (= spmv/csr_kernels.cpp:26-40).
+  * VECTOR kernel and the atomic symmetric kernels (plan_set sym_det = 0):
+    element-wise |y - y_ref|_i <= 16 u (|alpha||A||x| + |beta||y0|)_i,
+    u = 2^-53.
   * the reference's own check: ||y||_2 agrees with the KAT norm to 1 ulp
     relative (tests/test_spmv.cpp:20-23,159-160) for the exact kernels and to
     1e-14 relative for the others.
@@ -75,6 +78,9 @@ def test_kat_vector_and_symmetric(ctx):
     assert np.all(np.abs(y - y_ref) <= bound)
     lrp, lci, lva, dg = lower_split(rp, ci, va)
     ys = run_spmv(ctx, lrp, lci, lva, x, 5, 5, diagonal=dg, symmetric=True)
+    assert np.array_equal(ys, y_ref)  # reference: general == symmetric, bit for bit
+    ys = run_spmv(ctx, lrp, lci, lva, x, 5, 5, diagonal=dg, symmetric=True,
+                  knobs=dict(sym_det=0))
     assert np.all(np.abs(ys - y_ref) <= bound)
     assert abs(np.linalg.norm(ys) - norm_ref) <= 1e-14 * norm_ref
 
@@ -210,12 +216,16 @@ def test_poisson_symmetric(ctx, n):
         y0 = np.cos(np.arange(N))
         y_ref = oracle.csr_spmv_sym(lrp, lci, lva, dg, x, alpha, beta, y0)
         b = 16 * U * abs_bound(rp, ci, va, x, alpha, beta, y0)
-        # plain per-entry atomics (0) and LDS-window variants
+        # the default: atomic-free, the reference's order, the reference's bits
+        y = run_spmv(ctx, lrp, lci, lva, x, N, N, alpha, beta,
+                     None if beta == 0 else y0, diagonal=dg, symmetric=True)
+        assert np.array_equal(y, y_ref), (alpha, beta)
+        # atomic kernels: plain per-entry atomics (0) and LDS-window variants
         for window, srows in ((0, 1024), (256, 512), (1024, 1024),
                               (4096, 2048)):
             y = run_spmv(ctx, lrp, lci, lva, x, N, N, alpha, beta,
                          None if beta == 0 else y0, diagonal=dg, symmetric=True,
-                         knobs=dict(sym_window=window, sym_rows=srows))
+                         knobs=dict(sym_det=0, sym_window=window, sym_rows=srows))
             assert np.all(np.abs(y - y_ref) <= b), (window, srows)
     # and against the general kernel on the full matrix
     y_gen = oracle.csr_spmv(rp, ci, va, x)
@@ -241,9 +251,16 @@ def test_symmetric_random_and_diag_only(ctx):
     np.add.at(full, lci, np.abs(lva * x[rows[keep]]))
     full += np.abs(dg * x)
     terms = np.diff(lrp) + np.bincount(lci, minlength=n) + 1
+    y = run_spmv(ctx, lrp, lci, lva, x, n, n, 1.5, 0.0, diagonal=dg,
+                 symmetric=True)
+    assert np.array_equal(y, y_ref)  # ragged rows, repeated columns, long rows
+    y0 = rng.uniform(-1, 1, n)
+    y = run_spmv(ctx, lrp, lci, lva, x, n, n, -0.75, 0.5, y0, diagonal=dg,
+                 symmetric=True)
+    assert np.array_equal(y, oracle.csr_spmv_sym(lrp, lci, lva, dg, x, -0.75, 0.5, y0))
     for window in (0, 256, 1024):  # targets both inside and below the window
         y = run_spmv(ctx, lrp, lci, lva, x, n, n, 1.5, 0.0, diagonal=dg,
-                     symmetric=True, knobs=dict(sym_window=window))
+                     symmetric=True, knobs=dict(sym_det=0, sym_window=window))
         assert np.all(np.abs(y - y_ref) <= (16 + terms) * U * 1.5 * full), window
     # diagonal-only symmetric block (nnz == 0, diagonal != NULL)
     y = run_spmv(ctx, None, None, None, x, n, n, 2.0, 0.0, diagonal=dg,
@@ -274,6 +291,9 @@ def test_fp32(ctx):
     y_ref = oracle.csr_spmv_sym(lrp, lci, lva, dg, x)
     y = run_spmv(ctx, lrp, lci, lva, x, n ** 3, n ** 3, diagonal=dg,
                  symmetric=True, dtype=np.float32)
+    assert np.array_equal(y, y_ref)
+    y = run_spmv(ctx, lrp, lci, lva, x, n ** 3, n ** 3, diagonal=dg,
+                 symmetric=True, dtype=np.float32, knobs=dict(sym_det=0))
     assert np.allclose(y, y_ref, rtol=0, atol=16 * 2.0 ** -24 * 12)
 
 
@@ -518,9 +538,10 @@ def test_spmv_dot_partials_all_general_kernels(ctx):
     blk.free()
 
 
-@pytest.mark.parametrize("window", [0, 256])
+@pytest.mark.parametrize("window", [-1, 0, 256])
 def test_symmetric_fused_dot(ctx, window):
-    """x.(A x) produced by the symmetric kernel itself through the mirror
+    """x.(A x) produced by the symmetric kernels themselves: the deterministic
+    one (window -1) has the finished row, the atomic ones use the mirror
     identity sum_i x_i (2 (d_i x_i + (L x)_i) - d_i x_i)."""
     n = 18
     N = n ** 3
@@ -531,7 +552,10 @@ def test_symmetric_fused_dot(ctx, window):
     x = rng.uniform(-1, 1, N)
     y_ref = oracle.csr_spmv(rp, ci, va, x)
     blk = hip.CsrBlock(ctx, N, N, lrp, lci, lva, dg, True)
-    blk.set("sym_window", window)
+    assert blk.get("sym_det") == 1
+    if window >= 0:
+        blk.set("sym_det", 0)
+        blk.set("sym_window", window)
     dx, dy = ctx.upload(x), ctx.empty(N, np.float64)
     part = ctx.empty(ctx.dot_partials_len, np.float64)
     res = ctx.empty(1, np.float64)
@@ -564,9 +588,12 @@ def test_tridiagonal_ten_million_rows(ctx):
     y = run_spmv(ctx, rp, ci, va, x, N, N, algo=hip.ALGO_VECTOR)
     assert np.all(np.abs(y - y_ref) <= bound)
     lrp, lci, lva, dg = lower_split(rp, ci, va)
-    for knobs in (dict(), dict(sym_window=0)):
+    ys_ref = oracle.csr_spmv_sym(lrp, lci, lva, dg, x)
+    for knobs in (dict(), dict(sym_det=0), dict(sym_det=0, sym_window=0)):
         ys = run_spmv(ctx, lrp, lci, lva, x, N, N, diagonal=dg, symmetric=True,
                       knobs=knobs)
+        if not knobs:
+            assert np.array_equal(ys, ys_ref)
         assert np.all(np.abs(ys - y_ref) <= bound), knobs
 
 
@@ -652,10 +679,14 @@ def test_fuzz_shapes_all_kernels(ctx):
             ref = oracle.csr_spmv(srp, sci, sva, xs, alpha, beta, ys0)
             lrp, lci, lva, dg = lower_split(srp, sci, sva)
             sb = (16 + 2 * np.diff(srp)) * U * abs_bound(srp, sci, sva, xs, alpha, beta, ys0)
-            for knobs in (dict(), dict(sym_window=0), dict(sym_window=512, sym_rows=512)):
+            sref = oracle.csr_spmv_sym(lrp, lci, lva, dg, xs, alpha, beta, ys0)
+            for knobs in (dict(), dict(sym_det=0), dict(sym_det=0, sym_window=0),
+                          dict(sym_det=0, sym_window=512, sym_rows=512)):
                 ys = run_spmv(ctx, lrp, lci, lva, xs, n, n, alpha, beta,
                               None if beta == 0 else ys0, diagonal=dg,
                               symmetric=True, knobs=knobs)
+                if not knobs:
+                    assert np.array_equal(ys, sref), case
                 assert np.all(np.abs(ys - ref) <= sb + 1e-300), (case, knobs)
 
 
