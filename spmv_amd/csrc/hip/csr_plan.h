@@ -3,6 +3,7 @@
 //                  plan creation, the C entry points
 //   spmv_sym.hip   symmetric-storage kernels (csr_kernels.cpp:26-40)
 //   spmv_lat.hip   lattice form: constant column offsets per row block
+//   spmv_symlat.hip  the same idea for the symmetric storage
 #pragma once
 
 #include "common.h"
@@ -45,11 +46,15 @@ __device__ __forceinline__ P stream_load(const P* p)
 // blockIdx.x + gridDim.x, ...; this maps a slot to the row block it computes.
 // Placement only changes speed, never the result.  Slots it with equal it % 8
 // run on the same XCD, because workgroups are dealt round-robin over the XCDs.
-//   xcd_group  inside each run of 8G row blocks XCD k owns G consecutive
-//              ones:  (it / 8G) * 8G + (it % 8) * G + (it / 8) % G
+//   table      plan-time order table (band sweep, spmv_band_order_build);
+//              -1 marks an empty slot
+//   xcd_group  no table: inside each run of 8G row blocks XCD k owns G
+//              consecutive ones:  (it / 8G) * 8G + (it % 8) * G + (it / 8) % G
 //   otherwise  identity
 // ---------------------------------------------------------------------------
 struct RowBlockOrder {
+  const int32_t* table;
+  int num_slots; // table length
   int xcd_group;
   int num_row_blocks;
   int nt_store; // write y non-temporally (plain row-block kernel)
@@ -57,6 +62,8 @@ struct RowBlockOrder {
 
 __device__ __forceinline__ int order_slots(const RowBlockOrder& o)
 {
+  if (o.table)
+    return o.num_slots;
   if (o.xcd_group > 0) {
     const int super = 8 * o.xcd_group;
     return ((o.num_row_blocks + super - 1) / super) * super;
@@ -68,14 +75,15 @@ __device__ __forceinline__ int order_slots(const RowBlockOrder& o)
 __device__ __forceinline__ int order_row_block(const RowBlockOrder& o, int it)
 {
   int rb = it;
-  if (o.xcd_group > 0) {
+  if (o.table) {
+    rb = o.table[it];
+  } else if (o.xcd_group > 0) {
     const int super = 8 * o.xcd_group;
     const int q = it % super;
     rb = (it - q) + (q & 7) * o.xcd_group + (q >> 3);
   }
   return rb < o.num_row_blocks ? rb : -1;
 }
-
 
 template <typename T>
 static inline bool aligned16(const T* p)
@@ -121,6 +129,13 @@ struct spmv_hip_csr_plan {
   int32_t* t_pos = nullptr; // per stored entry: position in `values` ...
   int32_t* t_row = nullptr; // ... and its row, sorted by column
   int sym_det = 0;
+  // symmetric lattice form (spmv_symlat.hip): <= 3 constant lower offsets
+  uint8_t* slat_mask = nullptr; // per row: bit k = lower offset k present
+  int slat = 0;                 // use it (plan_set "slat")
+  int slat_nd = 0, slat_ext = 0, slat_nw = 0, slat_sub_bytes = 0;
+  int slat_D[3] = {0, 0, 0}, slat_win_of_k[3] = {0, 0, 0};
+  int slat_u_of_w[4] = {0, 0, 0, 0};
+  int slat_blocks_per_cu = kBlocksPerCU;
   int32_t* row_list = nullptr; // ROWLIST: device list of non-empty rows
   int32_t num_listed = 0;
   int nt_store = 0; // non-temporal y stores
@@ -142,9 +157,21 @@ struct spmv_hip_csr_plan {
   int lat_blocks_per_cu = 4;   // 2 x 17 KiB of LDS per workgroup
   int lat_xcd_group = 0;       // consecutive row blocks per XCD (0 = off)
 
+  // Band-sweep order for lattice-structured matrices (spmv_band_order_build):
+  // every XCD sweeps its own band of grid lines through all planes, so that
+  // the x (and, symmetric storage, value) windows of the planes z-1, z, z+1
+  // stay in that XCD's L2 instead of crossing the fabric three times.
+  int32_t* order = nullptr;
+  int order_slots = 0;
+  int band_lines = 0;                    // lines per band of the table
+  int lattice_d1 = 0, lattice_d2 = 0;    // line and plane distance (rows)
+  int band_order = 0;                    // use the table (plan_set)
+
   RowBlockOrder row_block_order(int nrb) const
   {
     RowBlockOrder o;
+    o.table = nullptr;
+    o.num_slots = 0;
     o.xcd_group = xcd_group;
     o.num_row_blocks = nrb;
     o.nt_store = nt_store;
@@ -168,6 +195,21 @@ int spmv_run_symmetric_f32(const spmv_hip_csr_plan* pl, hipStream_t st,
 int spmv_symt_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
                     const int32_t* colind);
 void spmv_symt_free(spmv_hip_csr_plan* pl);
+// spmv_csr.hip: (re)build the band-sweep table for bands of `yc` lines
+// (0 = choose); needs lattice_d1 / lattice_d2
+int spmv_band_order_build(spmv_hip_csr_plan* pl, int yc);
+// spmv_symlat.hip
+int spmv_slat_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
+                    const int32_t* colind);
+void spmv_slat_free(spmv_hip_csr_plan* pl);
+int spmv_slat_run_f64(const spmv_hip_csr_plan* pl, hipStream_t st,
+                      const int32_t* rowptr, const double* values,
+                      const double* diagonal, double alpha, const double* in,
+                      double beta, double* out, DotOut dot);
+int spmv_slat_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st,
+                      const int32_t* rowptr, const float* values,
+                      const float* diagonal, float alpha, const float* in,
+                      float beta, float* out);
 // spmv_lat.hip
 int spmv_lat_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
                    const int32_t* colind);

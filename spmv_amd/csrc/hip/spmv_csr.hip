@@ -28,8 +28,11 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include <cstring>
 #include <new>
+#include <utility>
+#include <vector>
 
 namespace
 {
@@ -933,6 +936,78 @@ int build_lx(spmv_hip_csr_plan* pl, const int32_t* rowptr,
 
 } // namespace
 
+// ---------------------------------------------------------------------------
+// Band-sweep order (plan time, host side).  Rows of a 3-D stencil in natural
+// ordering couple to rows +-1, +-d1 (next grid line) and +-d2 (next plane).
+// In row order the uses of an x plane by the planes z-1, z, z+1 lie d2 rows
+// apart: tens of MB of matrix stream, far more than the 4 MiB L2 of an XCD, so
+// every XCD pulls every plane across the fabric three times -- and the lattice
+// kernels run AT the fabric's rate.  The table cuts the
+// y axis into bands of `yc` lines, gives each XCD its own bands and lets it
+// sweep a band through all planes: the band's lines of the planes z-1, z, z+1
+// fit that XCD's L2.  d1 and d2 only choose a permutation of the row blocks: a
+// wrong guess costs speed, never correctness.
+// ---------------------------------------------------------------------------
+int spmv_band_order_build(spmv_hip_csr_plan* pl, int yc)
+{
+  SPMV_REQUIRE(pl->lattice_d1 > 0 && pl->lattice_d2 > 0);
+  SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
+  const int64_t d1 = pl->lattice_d1, d2 = pl->lattice_d2;
+  const int64_t ny = d2 / d1;
+  const int64_t nz = (pl->num_rows + d2 - 1) / d2;
+  const int nrb = (pl->num_rows + kRows - 1) / kRows;
+  if (yc <= 0) {
+    // the band's lines of about four planes (x, and for the symmetric storage
+    // the values, of z-1 .. z+2: the resident workgroups span two sweep steps)
+    // should take well under half of one 4 MiB L2
+    int64_t ymax = ((int64_t)3 << 19) / (32 * d1) - 2;
+    ymax = ymax < 8 ? 8 : ymax;
+    int64_t nb = (ny + ymax - 1) / ymax;
+    nb = (nb + 7) / 8 * 8; // every XCD gets the same number of bands
+    yc = (int)((ny + nb - 1) / nb);
+  }
+  yc = yc < 1 ? 1 : yc;
+  // key = (band, plane, line); row blocks keep their order inside a line
+  std::vector<std::pair<int64_t, int32_t>> keyed((size_t)nrb);
+  for (int k = 0; k < nrb; ++k) {
+    const int64_t line = ((int64_t)k * kRows) / d1;
+    const int64_t y = line % ny, z = line / ny;
+    const int64_t band = y / yc;
+    keyed[(size_t)k] = {((band * nz + z) * ny + y), k};
+  }
+  std::stable_sort(keyed.begin(), keyed.end());
+  std::vector<std::vector<int32_t>> lists(8);
+  for (const auto& kv : keyed) {
+    const int64_t band = kv.first / (nz * ny);
+    lists[(size_t)(band % 8)].push_back(kv.second);
+  }
+  size_t longest = 0;
+  for (const auto& l : lists)
+    longest = std::max(longest, l.size());
+  std::vector<int32_t> table(8 * longest, -1);
+  for (size_t x = 0; x < 8; ++x)
+    for (size_t i = 0; i < lists[x].size(); ++i)
+      table[8 * i + x] = lists[x][i];
+  if (pl->order) {
+    SPMV_CHECK_HIP(hipDeviceSynchronize()); // no launch still reads the old one
+    (void)hipFree(pl->order);
+    pl->order = nullptr;
+    pl->order_slots = 0;
+  }
+  SPMV_CHECK_HIP(hipMalloc(&pl->order, sizeof(int32_t) * table.size()));
+  hipError_t e = hipMemcpy(pl->order, table.data(),
+                           sizeof(int32_t) * table.size(),
+                           hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(pl->order);
+    pl->order = nullptr;
+    return static_cast<int>(e);
+  }
+  pl->order_slots = (int)table.size();
+  pl->band_lines = yc;
+  return SPMV_HIP_OK;
+}
+
 extern "C" {
 
 int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
@@ -1003,9 +1078,14 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
     }
   }
   if (symmetric && num_non_zeros > 0) {
-    // atomic-free, bit-exact form (the default when the block is strictly
-    // lower triangular)
-    const int rc = spmv_symt_build(pl, rowptr, colind);
+    // atomic-free, bit-exact forms (the default when the block is strictly
+    // lower triangular): the symmetric lattice form when the matrix has it,
+    // else the transposed map
+    int rc = SPMV_HIP_OK;
+    if (num_non_zeros >= ctx->lat_min_nnz)
+      rc = spmv_slat_build(pl, rowptr, colind);
+    if (rc == SPMV_HIP_OK && !pl->slat)
+      rc = spmv_symt_build(pl, rowptr, colind);
     if (rc != SPMV_HIP_OK) {
       spmv_hip_csr_plan_destroy(pl);
       return rc;
@@ -1018,12 +1098,15 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
 int spmv_hip_csr_plan_destroy(spmv_hip_csr_plan* plan)
 {
   if (plan
-      && (plan->row_list || plan->lx_lidx || plan->lat_tab || plan->t_ptr)) {
+      && (plan->row_list || plan->lx_lidx || plan->lat_tab || plan->t_ptr
+          || plan->slat_mask || plan->order)) {
     (void)hipSetDevice(plan->ctx->device);
     (void)hipFree(plan->row_list);
     free_lx(plan);
     spmv_lat_free(plan);
     spmv_symt_free(plan);
+    spmv_slat_free(plan);
+    (void)hipFree(plan->order);
   }
   delete plan;
   return SPMV_HIP_OK;
@@ -1075,6 +1158,23 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
     plan->lx_chunks = value;
   } else if (!strcmp(key, "nt_store")) {
     plan->nt_store = value != 0;
+  } else if (!strcmp(key, "band_order")) {
+    plan->band_order = (value != 0 && plan->order) ? 1 : 0;
+  } else if (!strcmp(key, "band_lines")) {
+    // (re)build the band-sweep table with bands of `value` grid lines
+    // (0 = automatic); EINVAL when the plan found no lattice
+    SPMV_REQUIRE(value >= 0);
+    const int rc = spmv_band_order_build(plan, value);
+    if (rc == SPMV_HIP_OK)
+      plan->band_order = 1;
+    return rc;
+  } else if (!strcmp(key, "slat")) {
+    // 1 needs the symmetric lattice form built at plan creation
+    SPMV_REQUIRE(value == 0 || plan->slat_mask);
+    plan->slat = value != 0;
+  } else if (!strcmp(key, "slat_blocks_per_cu")) {
+    SPMV_REQUIRE(value >= 1 && value <= kBlocksPerCU);
+    plan->slat_blocks_per_cu = value;
   } else if (!strcmp(key, "sym_det")) {
     // 1 needs the transposed map built at plan creation
     SPMV_REQUIRE(value == 0 || plan->t_ptr);
@@ -1103,6 +1203,16 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
     *value = plan->algo;
   else if (!strcmp(key, "sym_det"))
     *value = plan->sym_det;
+  else if (!strcmp(key, "slat"))
+    *value = plan->slat;
+  else if (!strcmp(key, "band_order"))
+    *value = plan->band_order && plan->order ? 1 : 0;
+  else if (!strcmp(key, "band_lines"))
+    *value = plan->order ? plan->band_lines : 0;
+  else if (!strcmp(key, "lattice_d1"))
+    *value = plan->lattice_d1;
+  else if (!strcmp(key, "lattice_d2"))
+    *value = plan->lattice_d2;
   else if (!strcmp(key, "lat"))
     *value = plan->lat;
   else if (!strcmp(key, "lat_blocks"))

@@ -42,6 +42,7 @@
 //   lat_tab[rb*kLatRec + 4 + k]  D[k], ascending, padded with 0
 //   lat_mask[row]                presence bits
 #include "csr_plan.h"
+#include "lat_dma.h"
 
 #include <new>
 
@@ -57,63 +58,6 @@ constexpr int kLatSlotBytes = (kRows * kLatMaxOff * 8 + 1024);
 constexpr int kLatSlots = 2;
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
-
-// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to
-// lds_dst + lane*16 (lds_dst wave-uniform, passed in M0).  Written as inline
-// assembly on purpose: with the builtin the compiler puts `s_waitcnt vmcnt(0)`
-// in front of every later LDS read (it cannot tell the slot being filled from
-// the slot being read) and the prefetch would be drained at once.  An
-// instruction the compiler does not count can only make its own vmcnt waits
-// stricter, never too weak (the counter retires in issue order); this file
-// waits for the pieces itself, with vmcnt(0) before the barrier that
-// publishes a slot.  M0 is saved and restored inside the statement.
-template <bool NT>
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst)
-{
-  unsigned keep;
-  if constexpr (NT)
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
-  else
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
-}
-
-// Entries [base, b) of `values` -> LDS slot, base 16-byte aligned.  One DMA
-// piece = one wave-instruction = 1 KiB.  Lanes past the span re-read its last
-// 16-byte chunk (one cached line) instead of streaming the next block's data.
-template <typename T, bool NT>
-__device__ __forceinline__ void lat_issue_dma(const T* __restrict__ values,
-                                              int64_t nnz, int64_t base,
-                                              int64_t b, T* s_slot, int t)
-{
-  constexpr int V = 16 / (int)sizeof(T); // entries per 16-byte chunk
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int lane = t & 63;
-  const int64_t jclamp = (b - 1) & ~(int64_t)(V - 1);
-  const int pieces = (int)(((b - base) * (int64_t)sizeof(T) + 1023) >> 10);
-  if (jclamp + V <= nnz) {
-    // LDS byte address of the slot (uniform)
-    const unsigned lds0 = (unsigned)(uintptr_t)(
-        (__attribute__((address_space(3))) void*)s_slot);
-    for (int q = wave; q < pieces; q += kBlock / 64) {
-      int64_t j = base + (int64_t)(q * 64 + lane) * V;
-      j = j < jclamp ? j : jclamp;
-      glds16<NT>(values + j, lds0 + (unsigned)q * 1024u);
-    }
-  } else {
-    // the last row block of the array: a 16-byte chunk would end past
-    // values[nnz) -- element-wise, in bounds
-    for (int64_t j = base + t; j < b; j += kBlock)
-      s_slot[j - base] = values[j];
-  }
-}
 
 // ---------------------------------------------------------------------------
 // The kernel.  lane = row.  A persistent workgroup walks its row blocks with
@@ -240,9 +184,6 @@ __global__ __launch_bounds__(kBlock) void csr_lattice_kernel(
   int slot = 0;
   // one step: sums block `cur` out of registers g, loads block `nxt` into gn
   auto step = [&](const LatRegs<T>& g, LatRegs<T>& gn) {
-    // the block after the next one: its span is needed an iteration from now
-    const LatBlock nn = lat_block(ord, itn + stride, num_slots, num_rows,
-                                  rowptr, stride, &itnn);
     // Everything this wave has in flight (block k's DMA pieces and loads, the
     // previous y stores) has landed; after the barrier that holds for all
     // waves, and all of them have left block k-1.  (The builtin, not inline
@@ -256,6 +197,10 @@ __global__ __launch_bounds__(kBlock) void csr_lattice_kernel(
                            s_val + (slot ^ 1) * SLOT, t);
     gn = lat_loads<T, DOT>(nxt, t, num_rows, num_cols, rowptr, tab, mask, in,
                            beta, out);
+    // the block after the next one (order table, row pointer: dependent scalar
+    // loads): issued behind the vector loads, needed an iteration from now
+    const LatBlock nn = lat_block(ord, itn + stride, num_slots, num_rows,
+                                  rowptr, stride, &itnn);
     const int32_t r = cur.rb * kRows + t;
     if (r < num_rows) {
       const int rel
@@ -438,6 +383,10 @@ int lat_launch(const spmv_hip_csr_plan* pl, hipStream_t st,
     grid -= grid % 8;
   RowBlockOrder ord = pl->row_block_order(nrb);
   ord.xcd_group = pl->lat_xcd_group;
+  if (pl->band_order && pl->order) {
+    ord.table = pl->order;
+    ord.num_slots = pl->order_slots;
+  }
   if (pl->nontemporal)
     hipLaunchKernelGGL((csr_lattice_kernel<T, DOT, true>), dim3(grid),
                        dim3(kBlock), 0, st, pl->num_rows, pl->num_cols, pl->nnz,
@@ -511,6 +460,29 @@ int spmv_lat_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
   // XCD groups of 16 row blocks while x fits the Infinity Cache (216^3: 0.153
   // -> 0.138 ms); no effect beyond (512^3)
   pl->lat_xcd_group = pl->nontemporal ? 16 : 0;
+  // 3-D lattice?  The offsets of a row block in the middle of the matrix: line
+  // distance d1 = second smallest positive one, plane distance d2 = largest.
+  int32_t rec[kLatRec];
+  if (hipMemcpy(rec, pl->lat_tab + (size_t)(nrb / 2) * kLatRec, sizeof(rec),
+                hipMemcpyDeviceToHost)
+          == hipSuccess
+      && rec[0] >= 3) {
+    int pos[kLatMaxOff], np = 0;
+    for (int k = 0; k < rec[0]; ++k)
+      if (rec[4 + k] > 0)
+        pos[np++] = rec[4 + k]; // ascending already
+    if (np >= 3 && pos[1] >= 8 && pos[np - 1] % pos[1] == 0
+        && pos[np - 1] / pos[1] >= 16) {
+      pl->lattice_d1 = pos[1];
+      pl->lattice_d2 = pos[np - 1];
+      // The band-sweep order is opt-in here (plan_set "band_lines"): at 512^3
+      // it cuts the fabric reads from 12.3 to 9.7 GB per launch (compulsory:
+      // 9.2) but the kernel gets 6-12 % SLOWER -- the same ~28,000 requests are
+      // in flight either way and without the Infinity-Cache hits of the plain
+      // order their average latency rises from 1,240 to 1,530 cycles
+      // (profiles/r02_pmc_lattice_512.json).
+    }
+  }
   return SPMV_HIP_OK;
 }
 

@@ -442,6 +442,14 @@ int run_symmetric(const spmv_hip_csr_plan* pl, hipStream_t st,
     SPMV_CHECK_LAUNCH();
     return SPMV_HIP_OK;
   }
+  if (pl->slat && aligned16(values)) {
+    if constexpr (sizeof(T) == 8)
+      return spmv_slat_run_f64(pl, st, rowptr, values, diagonal, alpha, in, beta,
+                               out, dot);
+    else
+      return spmv_slat_run_f32(pl, st, rowptr, values, diagonal, alpha, in, beta,
+                               out);
+  }
   if (pl->sym_det && pl->t_ptr) {
     const int nrb = (n + kRows - 1) / kRows;
     int grid = pl->ctx->num_cus * pl->blocks_per_cu;

@@ -998,3 +998,138 @@ def test_lattice_form_rectangular_and_empty_rows(lat_ctx):
     assert dy.numpy()[0] == 6.0
     dx.free(), dy.free()
     one.free()
+
+
+# ---------------------------------------------------------------------------
+# Symmetric lattice form (spmv_symlat.hip): symmetric storage with <= 3 constant
+# lower offsets -- atomic-free, the reference's order, the reference's bits
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_symmetric_lattice_form_bit_exact(lat_ctx, dtype):
+    ctx = lat_ctx
+    rng = np.random.default_rng(95)
+    cases = []
+    for n in (4, 9, 16, 33):  # offsets merged into the own window / separate
+        rp, ci, va = poisson.poisson3d_csr(n)
+        cases.append((f"poisson{n}", *lower_split(rp, ci.astype(np.int32), va), n ** 3))
+    rp, ci, va = oracle.tridiag_csr(70001)
+    cases.append(("tridiag", *lower_split(rp, ci, va), 70001))
+    # three far offsets with a third of the entries missing, ragged tail
+    N = 9001
+    rp, ci, va = _stencil_csr(rng, N, [-2000, -300, -1], drop=0.33)
+    cases.append(("far3", rp, ci, va, rng.uniform(1, 2, N), N))
+    for name, lrp, lci, lva, dg, N in cases:
+        lva, dg = lva.astype(dtype), np.asarray(dg).astype(dtype)
+        x = rng.uniform(-1, 1, N).astype(dtype)
+        y0 = rng.uniform(-1, 1, N).astype(dtype)
+        blk = hip.CsrBlock(ctx, N, N, lrp, lci, lva, dg, True, hip.ALGO_AUTO, dtype)
+        assert blk.get("slat") == 1, name
+        assert blk.get("sym_det") == 0  # the transposed map was not needed
+        dx = ctx.upload(x, dtype)
+        part = ctx.empty(ctx.dot_partials_len, np.float64)
+        for alpha, beta in ((1.0, 0.0), (-0.5, 0.0), (2.0, 1.0), (1.0, -0.25)):
+            y_ref = oracle.csr_spmv_sym(lrp, lci, lva, dg, x, alpha, beta, y0)
+            for knobs in (dict(), dict(nontemporal=0), dict(slat_blocks_per_cu=1),
+                          dict(lat_xcd_group=3)):
+                for k, v in knobs.items():
+                    blk.set(k, v)
+                dy = ctx.upload(np.full(N, np.nan, dtype) if beta == 0 else y0, dtype)
+                dot = dtype == np.float64 and beta == 0.0
+                blk.mult(alpha, dx.ptr, beta, dy.ptr,
+                         dot_partials=part.ptr if dot else None)
+                y = dy.numpy()
+                dy.free()
+                assert np.array_equal(y, y_ref), (name, alpha, beta, knobs)
+                if dot:
+                    want = float(np.dot(x.astype(np.float64), y_ref))
+                    got = float(np.sum(part.numpy()))
+                    scale = float(np.abs(x) @ np.abs(y_ref)) + 1e-300
+                    assert abs(got - want) <= 1e-12 * scale, (name, knobs)
+            for k, v in dict(slat_blocks_per_cu=8, lat_xcd_group=0, nontemporal=1).items():
+                blk.set(k, v)
+        # the atomic kernels on the same plan (tolerance) -- the form can be
+        # switched off
+        blk.set("slat", 0)
+        dy = ctx.upload(np.zeros(N, dtype), dtype)
+        blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+        y_ref = oracle.csr_spmv_sym(lrp, lci, lva, dg, x)
+        tol = (2.0 ** -24 if dtype == np.float32 else U) * 64 * (np.abs(y_ref).max() + 12)
+        assert np.all(np.abs(dy.numpy() - y_ref) <= tol), name
+        dy.free(), dx.free(), part.free()
+        blk.free()
+
+
+def test_symmetric_lattice_form_is_refused_when_it_does_not_apply(lat_ctx):
+    """Four lower offsets, unsorted rows, an entry on or above the diagonal:
+    the plan falls back to the transposed map (or, not strictly lower, to the
+    atomic kernels) and stays correct."""
+    ctx = lat_ctx
+    rng = np.random.default_rng(96)
+    N = 5000
+    cases = [("four", *_stencil_csr(rng, N, [-700, -30, -2, -1]), 1)]
+    rp, ci, va = _stencil_csr(rng, N, [-40, -3, -1])
+    ci2 = ci.copy()
+    r = 2500
+    ci2[rp[r]], ci2[rp[r] + 1] = ci[rp[r] + 1], ci[rp[r]]
+    cases.append(("unsorted_row", rp, ci2, va, 1))
+    for name, lrp, lci, lva, det in cases:
+        dg = rng.uniform(1, 2, N)
+        blk = hip.CsrBlock(ctx, N, N, lrp, lci, lva, dg, True)
+        assert blk.get("slat") == 0 and blk.get("sym_det") == det, name
+        with pytest.raises(Exception):
+            blk.set("slat", 1)
+        x = rng.uniform(-1, 1, N)
+        dx, dy = ctx.upload(x), ctx.upload(np.full(N, np.nan))
+        blk.mult(1.5, dx.ptr, 0.0, dy.ptr)
+        assert np.array_equal(dy.numpy(),
+                              oracle.csr_spmv_sym(lrp, lci, lva, dg, x, 1.5)), name
+        dx.free(), dy.free()
+        blk.free()
+
+
+@pytest.mark.parametrize("n", [16, 33])
+def test_band_order_is_a_permutation_of_the_work(lat_ctx, n):
+    """The band-sweep table only permutes row blocks: any band height gives the
+    bits of the plain order, for the general and the symmetric lattice form.
+    Small grids never build a table on their own, so it is forced."""
+    ctx = lat_ctx
+    rp, ci, va = poisson.poisson3d_csr(n)
+    ci = ci.astype(np.int32)
+    N = n ** 3
+    x = oracle.gaussian_x_fast(N)
+    lrp, lci, lva, dg = lower_split(rp, ci, va)
+    for sym in (False, True):
+        if sym:
+            blk = hip.CsrBlock(ctx, N, N, lrp, lci, lva, dg, True)
+            y_ref = oracle.csr_spmv_sym(lrp, lci, lva, dg, x, 0.5, 0.0)
+            assert blk.get("slat") == 1
+        else:
+            blk = hip.CsrBlock(ctx, N, N, rp, ci, va, None, False, hip.ALGO_ROWBLOCK)
+            y_ref = oracle.csr_spmv(rp, ci, va, x, 0.5, 0.0)
+            assert blk.get("lat") == 1
+        assert blk.get("lattice_d1") == n and blk.get("lattice_d2") == n * n
+        assert blk.get("band_order") == 0  # too small to need it
+        dx = ctx.upload(x)
+        for yc in (0, 1, 3, 8, n, 5 * n):
+            blk.set("band_lines", yc)
+            assert blk.get("band_order") == 1
+            if yc:
+                assert blk.get("band_lines") == yc
+            for bpc in (1, 4):
+                blk.set("slat_blocks_per_cu" if sym else "lat_blocks_per_cu", bpc)
+                dy = ctx.upload(np.full(N, np.nan))
+                blk.mult(0.5, dx.ptr, 0.0, dy.ptr)
+                assert np.array_equal(dy.numpy(), y_ref), (sym, yc, bpc)
+                dy.free()
+        blk.set("band_order", 0)
+        assert blk.get("band_order") == 0
+        dx.free()
+        blk.free()
+    # no lattice, no table
+    rp, ci, va = oracle.tridiag_csr(100000)
+    blk = hip.CsrBlock(ctx, 100000, 100000, rp, ci, va, None, False,
+                       hip.ALGO_ROWBLOCK)
+    assert blk.get("lattice_d2") == 0
+    with pytest.raises(Exception):
+        blk.set("band_lines", 4)
+    blk.free()

@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--knob", action="append", default=[],
                     help="name=v1,v2,... (applied in the order given)")
     ap.add_argument("--dot", action="store_true", help="fused p.Ap partials")
+    ap.add_argument("--symmetric", action="store_true",
+                    help="symmetric storage (lower block + diagonal)")
     ap.add_argument("--out", default=None)
     ap.add_argument("--calib", action="store_true",
                     help="also time plain streaming kernels on this box")
@@ -31,11 +33,16 @@ def main():
     ctx = hip.Context(0)
     ctx.set_option("lx_max_x_bytes", 1 << 62)  # build the LX form at any size
     n, N = args.n, args.n ** 3
-    blk = hip.poisson3d_block(ctx, n, 0, N, hip.PART_ALL)
+    if args.symmetric:
+        blk = hip.poisson3d_block(ctx, n, 0, N, hip.PART_LOCAL_LOWER,
+                                  with_diagonal=True)
+    else:
+        blk = hip.poisson3d_block(ctx, n, 0, N, hip.PART_ALL)
     x, y = ctx.empty(N, np.float64), ctx.empty(N, np.float64)
     ctx.fill_gaussian(N, 0, N, x.ptr)
     part = ctx.empty(ctx.dot_partials_len, np.float64)
-    nbytes = poisson.csr_bytes(N, N, blk.nnz)
+    nbytes = (poisson.sym_csr_bytes(N, blk.nnz) if args.symmetric
+              else poisson.csr_bytes(N, N, blk.nnz))
     if args.calib:
         # what this box streams: a dot product over two N-vectors (reads) and a
         # fill (writes), both through the library's BLAS-1 kernels

@@ -22,12 +22,16 @@ def main():
     ap.add_argument("--symmetric", action="store_true")
     ap.add_argument("--dot", action="store_true")
     ap.add_argument("--set", nargs="*", default=[], help="knob=value ...")
-    ap.add_argument("--lx", action="store_true",
-                    help="build the LX form whatever the size of x")
+    ap.add_argument("--no-lat", action="store_true",
+                    help="no lattice form: the plan takes the LX form")
+    ap.add_argument("--no-lx", action="store_true",
+                    help="neither: the plain gather kernel")
     args = ap.parse_args()
     ctx = hip.Context(0)
-    if args.lx:
-        ctx.set_option("lx_max_x_bytes", 1 << 62)
+    if args.no_lat or args.no_lx:
+        ctx.set_option("lat_min_nnz", 1 << 62)
+    if args.no_lx:
+        ctx.set_option("lx_min_nnz", 1 << 62)
     n, N = args.n, args.n ** 3
     part = hip.PART_LOCAL_LOWER if args.symmetric else hip.PART_ALL
     blk = hip.poisson3d_block(ctx, n, 0, N, part, with_diagonal=args.symmetric)
