@@ -14,8 +14,8 @@ generated on the device, inputs resident in HBM before the timed region.
 Prints ONE JSON line on rank 0.  `value` = CG iterations per second of the
 whole job; `roofline` describes the dominant kernel (the local-block CSR
 SpMV), timed live with HIP events on its own stream inside the timed region;
-`cpu_baseline` is the oracle's OpenMP CG (= the reference's CPU path,
-restated) on a bounded sample, rank 0 at N = 1 only.
+`cpu_baseline` is the oracle's OpenMP SpMV + CG (= the reference's CPU path,
+restated) on the host cores this job may use, rank 0 at N = 1 only.
 """
 import argparse
 import json
@@ -30,8 +30,15 @@ if ROOT not in sys.path:
 # dmabuf IPC is the only mode the host driver supports; RCCL's intra-node
 # transport fails with "hipIpcGetMemHandle: invalid argument" without it
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# the CPU baseline's threads: one per core, spread over the sockets (read by
+# the OpenMP runtime when the oracle library is loaded)
+os.environ.setdefault("OMP_PLACES", "cores")
+os.environ.setdefault("OMP_PROC_BIND", "spread")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+# ||r_10|| / ||r_0|| of the 512^3 Gaussian right-hand side on ONE rank: what
+# every N-rank line must reproduce (to the rounding of its dot products)
+K10_512 = 6.635343844806121
 
 
 def parse():
@@ -43,94 +50,192 @@ def parse():
                     help="grid points per side (not --n: torchrun's own parser "
                          "treats that as an abbreviation of its options)")
     ap.add_argument("--symmetric", action="store_true",
-                    help="symmetric-CSR storage (BASELINE configs[3])")
+                    help="symmetric-CSR storage (BASELINE configs[3]) as the "
+                         "main line (the default line carries it as a "
+                         "sub-record)")
     ap.add_argument("--cm", default="p2p_nonblocking",
                     choices=["p2p_blocking", "p2p_nonblocking"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="main line only: no symmetric / LX / 216^3 sub-records")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "gloo"],
                     help="gloo: REHEARSAL ONLY -- halo and reductions staged "
                          "through the host so that several ranks can share one "
                          "GPU (implies --share-gpu); never a benchmark result")
     ap.add_argument("--share-gpu", action="store_true",
                     help="all ranks use GPU 0 (rehearsal on a 1-GPU box)")
-    ap.add_argument("--cpu-n", type=int, default=256,
-                    help="grid of the bounded CPU sample")
-    ap.add_argument("--cpu-iters", type=int, default=30)
+    ap.add_argument("--cpu-n", type=int, default=0,
+                    help="grid of the CPU baseline (0 = the benchmark's own, "
+                         "or 256 when host memory is short)")
+    ap.add_argument("--cpu-iters", type=int, default=10)
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="0 = physical cores this job may use")
     ap.add_argument("--reducer-kernels", action="store_true",
                     help="finish dot products with the single-workgroup reducer "
                          "launches even on one rank (experiments)")
+    ap.add_argument("--no-lattice", action="store_true",
+                    help="no lattice form: the LX form as any matrix without "
+                         "lattice structure gets it (experiments)")
     ap.add_argument("--no-lx", action="store_true",
-                    help="do not build the LX form of the matrix (experiments)")
+                    help="with --no-lattice: the plain gather kernel")
     ap.add_argument("--blas1-nt-min", type=int, default=None,
                     help="override the context option blas1_nt_min_elems "
                          "(experiments)")
     return ap.parse_args()
 
 
-def cpu_baseline(args, n_gpu, rows_gpu):
-    """Oracle OpenMP CG on a bounded sample, scaled by row count to the GPU
-    workload (a CG iteration is O(rows) for this matrix)."""
-    import numpy as np
-
-    import oracle
-    n = min(args.cpu_n, n_gpu)
-    rp, ci, va = oracle.poisson3d(n)
-    b = np.ones(n ** 3)
+# ---------------------------------------------------------------------------
+# CPU baseline
+# ---------------------------------------------------------------------------
+def usable_cores():
+    """Physical cores this process may keep busy: affinity mask, distinct
+    (socket, core) pairs, and the cgroup CPU quota."""
     try:
-        cores = len(os.sched_getaffinity(0))
+        cpus = sorted(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    threads = max(1, min(cores, 64))
-    oracle.time_cg(rp, ci, va, b, 1, threads)  # first touch / warm-up
-    best = None
-    for t in sorted({threads, 1}, reverse=True):
-        secs, its = oracle.time_cg(rp, ci, va, b, args.cpu_iters, t)
-        rate = its / secs * (n ** 3) / rows_gpu
-        if best is None or rate > best[0]:
-            best = (rate, t, secs)
-    rate, t, secs = best
-    out = {"value": rate, "unit": "iters/s", "cores": t, "kind": "port",
-           "sample": (f"oracle OpenMP CG (restated spmv/openmp path), "
-                      f"{n}^3 Poisson, {args.cpu_iters} iterations in "
-                      f"{secs:.2f} s on {t} threads, scaled by rows "
-                      f"{n ** 3}/{rows_gpu} to the {n_gpu}^3 workload")}
-    # SURVEY 8d extras on the same sample: plain SpMV on the OpenMP path and
-    # the 1-thread ReferenceExecutor-equivalent loop (BASELINE configs[0] at
-    # 128^3), both in algorithmic GB/s (same formula as the GPU figure)
+        cpus = list(range(os.cpu_count() or 1))
+    phys, model = set(), "unknown"
     try:
-        from spmv_amd import poisson
-        x = np.ones(n ** 3)
-        nbytes = poisson.csr_bytes(n ** 3, n ** 3, len(va))
-        s_omp = oracle.time_spmv(rp, ci, va, x, reps=10, num_threads=t)
-        out["spmv_omp"] = {"grid": n, "threads": t, "ms_per_apply": s_omp * 1e3,
-                           "GB/s": nbytes / s_omp / 1e9}
-        if n > 128:
-            rp, ci, va = oracle.poisson3d(128)
-            x = np.ones(128 ** 3)
-            nbytes = poisson.csr_bytes(128 ** 3, 128 ** 3, len(va))
-        s_ref = oracle.time_spmv(rp, ci, va, x, reps=5, num_threads=1)
-        out["spmv_reference_1thread"] = {"grid": min(n, 128),
-                                         "ms_per_apply": s_ref * 1e3,
-                                         "GB/s": nbytes / s_ref / 1e9}
+        cur = {}
         with open("/proc/cpuinfo") as f:
-            models = [ln.split(":", 1)[1].strip() for ln in f
-                      if ln.startswith("model name")]
-        out["host"] = {"model": models[0] if models else "unknown",
-                       "logical_cpus": os.cpu_count(), "usable": cores}
-    except Exception as e:  # extras only; the baseline itself is above
+            for ln in f:
+                if ":" in ln:
+                    k, v = (s.strip() for s in ln.split(":", 1))
+                    cur[k] = v
+                elif not ln.strip():
+                    if int(cur.get("processor", -1)) in cpus:
+                        phys.add((cur.get("physical id", "0"),
+                                  cur.get("core id", cur.get("processor"))))
+                        model = cur.get("model name", model)
+                    cur = {}
+    except OSError:
+        pass
+    cores = len(phys) or len(cpus)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()
+            if q != "max":
+                quota = int(q) / int(period)
+    except (OSError, ValueError):
+        pass
+    n = cores if quota is None else max(1, min(cores, int(quota)))
+    return dict(threads=n, physical_cores=cores, logical_cpus=len(cpus),
+                cgroup_cpu_quota=quota, model=model)
+
+
+def cpu_baseline(args, n_gpu, rows_gpu, host):
+    """The oracle's OpenMP path (restated spmv/openmp/*) on the benchmark's own
+    matrix: first touch by the owning thread, threads = usable physical cores
+    spread over the sockets, only the apply / iteration loops timed.  `host` =
+    usable_cores(), taken before any OpenMP runtime bound this thread."""
+    import oracle
+    from spmv_amd import poisson
+    threads = args.cpu_threads or host["threads"]
+    n = args.cpu_n or n_gpu
+    try:
+        with open("/proc/meminfo") as f:
+            avail_kib = next(int(ln.split()[1]) for ln in f
+                             if ln.startswith("MemAvailable"))
+    except (OSError, StopIteration):
+        avail_kib = 0
+    need = 12 * 7 * n ** 3 + 44 * n ** 3  # CSR + rowptr + five vectors
+    if not args.cpu_n and avail_kib * 1024 < 2 * need:
+        n = min(n, 256)
+    r = oracle.cpu_baseline(n, threads, 5, args.cpu_iters)
+    N, nnz = n ** 3, 7 * n ** 3 - 6 * n ** 2
+    nbytes = poisson.csr_bytes(N, N, nnz)
+    its = r["cg_iters"] / r["cg_loop_s"]
+    scaled = its * N / rows_gpu
+    out = {"value": scaled, "unit": "iters/s", "cores": threads, "kind": "port",
+           "sample": (f"oracle OpenMP CG (restated spmv/openmp path) on the "
+                      f"{n}^3 Poisson matrix itself, {r['cg_iters']} iterations "
+                      f"in {r['cg_loop_s']:.2f} s (loop only; set-up "
+                      f"{r['setup_s']:.1f} s with owner first touch), "
+                      f"{threads} threads = the physical cores this job may "
+                      f"use, OMP_PLACES=cores OMP_PROC_BIND=spread"
+                      + ("" if n == n_gpu else
+                         f"; scaled by rows {N}/{rows_gpu} to {n_gpu}^3")),
+           "spmv_omp": {"grid": n, "threads": threads,
+                        "ms_per_apply": r["spmv_s_per_apply"] * 1e3,
+                        "GB/s": nbytes / r["spmv_s_per_apply"] / 1e9,
+                        "bytes": "algorithmic CSR bytes, as for the GPU"},
+           "cg_rel_residual_after": r["rel_residual"],
+           "host": host}
+    try:  # BASELINE configs[0]: the 1-thread ReferenceExecutor loop at 128^3
+        import numpy as np
+        rp, ci, va = oracle.poisson3d(128)
+        s_ref = oracle.time_spmv(rp, ci, va, np.ones(128 ** 3), reps=5,
+                                 num_threads=1)
+        nb = poisson.csr_bytes(128 ** 3, 128 ** 3, len(va))
+        out["spmv_reference_1thread"] = {"grid": 128, "ms_per_apply": s_ref * 1e3,
+                                         "GB/s": nb / s_ref / 1e9}
+    except Exception as e:  # extras only
         out["extras_error"] = repr(e)
     return out
 
 
-def north_star_spmv(exec_, comm, host, _lib, poisson, n=216, reps=200):
-    """BASELINE.json's target line: plain fp64 CSR SpMV (y = A x, the
-    demos/spmv.cpp protocol: 1 warm-up + timed applies) on the ~10 M-row
-    Poisson matrix, one GPU, HIP events around the applies."""
+# ---------------------------------------------------------------------------
+# what the local block's plan turned into, and the bytes that form moves
+# ---------------------------------------------------------------------------
+def kernel_of(A, symmetric):
+    rows, cols, nnz = A.blocks()["local"]
+    nrb = (rows + 255) // 256
+    y_x = rows * 8 + cols * 8
+    if symmetric:
+        algo = rows * 8 * 3 + (rows + 1) * 4 + nnz * 12  # SURVEY 8d B_sym
+        if A.plan_get("slat"):
+            return ("csr_sym_lattice_kernel<double> (symmetric lattice form: own "
+                    "and column value windows by LDS-DMA, no index stream, "
+                    "atomic-free, bit-exact)",
+                    algo, nnz * 8 + rows * (4 + 1 + 8) + y_x)
+        if A.plan_get("sym_det"):
+            return ("csr_symt_kernel<double> (transposed map, atomic-free, "
+                    "bit-exact)", algo, algo + (rows + 1) * 4 + nnz * 8)
+        return ("csr_sym_window_kernel<double> (LDS window + global atomics)",
+                algo, algo)
+    algo = nnz * 12 + (rows + 1) * 4 + y_x  # SURVEY 8d B_csr
+    if A.plan_get("lat"):
+        return ("csr_lattice_kernel<double> (lattice form: constant column "
+                "offsets per row block, values by LDS-DMA one block ahead, no "
+                "index stream; fused p.Ap)",
+                algo, nnz * 8 + rows * (4 + 1) + nrb * 48 + y_x)
+    if A.plan_get("lx"):
+        return ("csr_rowblock_lx_kernel<double> (LX form: x windows staged in "
+                "LDS, 16-bit column offsets; fused p.Ap)",
+                algo, nnz * 10 + (rows + 1) * 4 + nrb * 144 + y_x)
+    return ("csr_rowblock_kernel<double> (gather; fused p.Ap)", algo, algo)
+
+
+def plan_record(A):
+    return {"plan_ms": A.plan_get("plan_us") / 1e3,
+            "plan_extra_bytes": A.plan_get("plan_kib") * 1024,
+            "form": {k: A.plan_get(k) for k in
+                     ("lat", "lx", "slat", "sym_det", "band_order")}}
+
+
+def pmc_traffic(kernel_name, n, world):
+    """HBM-side bytes per launch of this kernel from the committed PMC passes
+    (profiles/): a constant of an EARLIER run on another box, returned with its
+    source, or (None, None) when no pass covers this kernel and grid."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+    if world != 1 or not os.path.exists(path):
+        return None, None
+    try:
+        for rec in json.load(open(path))["kernels"]:
+            if rec["grid"] == n and kernel_name.startswith(rec["kernel_prefix"]):
+                return rec["fabric_bytes_per_launch"], rec["source"]
+    except Exception:
+        pass
+    return None, None
+
+
+def timed_spmv(exec_, A, N, _lib, reps):
+    """plain y = A x applies (demos/spmv.cpp:73-96 protocol), best of 3 rounds
+    of `reps`, HIP events on the executor's stream"""
     import ctypes as C
-    N = n ** 3
-    A = host.Matrix.create_poisson3d(comm, exec_, n, False, host.P2P_BLOCKING)
-    d_x, d_y = exec_.alloc(N), exec_.alloc(N)
     ctx = exec_.context
+    d_x, d_y = exec_.alloc(N), exec_.alloc(N)
     _lib.call("spmv_hip_fill_gaussian_f64", ctx, N, 0, N, d_x, None)
     e0, e1 = C.c_void_p(), C.c_void_p()
     _lib.call("spmv_hip_event_create", ctx, 1, C.byref(e0))
@@ -147,16 +252,33 @@ def north_star_spmv(exec_, comm, host, _lib, poisson, n=216, reps=200):
         ms = C.c_float()
         _lib.call("spmv_hip_event_elapsed_ms", ctx, e0, e1, C.byref(ms))
         best = ms.value / reps if best is None else min(best, ms.value / reps)
-    nnz = A.non_zeros()
-    nbytes = poisson.csr_bytes(N, N, nnz)
     _lib.call("spmv_hip_event_destroy", ctx, e0)
     _lib.call("spmv_hip_event_destroy", ctx, e1)
-    A.close()
     exec_.free(d_x), exec_.free(d_y)
-    gbs = nbytes / (best * 1e-3) / 1e9
-    return {"workload": f"poisson3d_{n}^3_csr_fp64_spmv", "rows": N, "nnz": nnz,
-            "ms_per_apply": best, "algorithmic_bytes": nbytes, "GB/s": gbs,
-            "frac_of_8TBs": gbs / HBM_PEAK_GBS, "applies_timed": reps}
+    return best
+
+
+def spmv_record(exec_, comm, host, _lib, n, symmetric, reps, lattice=True):
+    """one plain-SpMV sub-record on the n^3 matrix in the given storage/form"""
+    ctx = exec_.context
+    if not lattice:
+        _lib.call("spmv_hip_ctx_set_option", ctx, b"lat_min_nnz", 1 << 62)
+    A = host.Matrix.create_poisson3d(comm, exec_, n, symmetric, host.P2P_BLOCKING)
+    if not lattice:
+        _lib.call("spmv_hip_ctx_set_option", ctx, b"lat_min_nnz", 1 << 20)
+    N = n ** 3
+    ms = timed_spmv(exec_, A, N, _lib, reps)
+    kernel, algo, req = kernel_of(A, symmetric)
+    rec = {"workload": f"poisson3d_{n}^3_{'symmetric-csr' if symmetric else 'csr'}"
+                       "_fp64_spmv",
+           "rows": N, "nnz_stored": A.blocks()["local"][2], "kernel": kernel,
+           "ms_per_apply": ms, "applies_timed": reps,
+           "algorithmic_bytes": algo, "GB/s": algo / ms / 1e6,
+           "frac": algo / ms / 1e6 / HBM_PEAK_GBS,
+           "requested_bytes": req, "frac_requested": req / ms / 1e6 / HBM_PEAK_GBS}
+    rec.update(plan_record(A))
+    A.close()
+    return rec
 
 
 def main():
@@ -167,6 +289,9 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch "
                          "N>1 through torch.distributed.run")
+    # before torch is imported: with OMP_PROC_BIND set, the first OpenMP runtime
+    # that starts pins this thread to one core and the mask would read "1 core"
+    host_cores = usable_cores()
 
     import numpy as np
     import torch
@@ -178,6 +303,7 @@ def main():
     dev = 0 if (args.share_gpu or rehearsal) else local_rank
     torch.cuda.set_device(dev)
     exec_ = host.HipExecutor(dev)
+    rccl = None
     if world > 1 and rehearsal:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import dist_util  # gloo-backed CallbackComm transport (tests/)
@@ -191,6 +317,10 @@ def main():
         ident = [host.rccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ident, src=0)
         comm = host.Comm.rccl(exec_, world, rank, ident[0])
+        rccl = comm.rccl_info()
+        if rccl["nranks"] != world or rccl["rank"] != rank:
+            raise SystemExit(f"rank {rank}: RCCL reports rank {rccl['rank']} of "
+                             f"{rccl['nranks']}, expected {rank} of {world}")
     else:
         comm = host.Comm.self_comm()
 
@@ -200,18 +330,18 @@ def main():
 
     n = args.n
     N = n ** 3
+    ctx = exec_.context
+    if args.no_lattice or args.no_lx:
+        _lib.call("spmv_hip_ctx_set_option", ctx, b"lat_min_nnz", 1 << 62)
     if args.no_lx:
-        _lib.call("spmv_hip_ctx_set_option", exec_.context, b"lx_min_nnz",
-                  1 << 62)
+        _lib.call("spmv_hip_ctx_set_option", ctx, b"lx_min_nnz", 1 << 62)
     cm = getattr(host, args.cm.upper())
     A = host.Matrix.create_poisson3d(comm, exec_, n, args.symmetric, cm)
     l2g = A.col_map()
     M = l2g.local_size()
     blocks = A.blocks()
-    nnz_local = blocks["local"][2]
 
     # RHS b = Gaussian bump (demos/spmv.cpp:63-67) -- resident before timing
-    ctx = exec_.context
     if args.blas1_nt_min is not None:
         _lib.call("spmv_hip_ctx_set_option", ctx, b"blas1_nt_min_elems",
                   args.blas1_nt_min)
@@ -226,8 +356,9 @@ def main():
     # ghost entry must hold g(its global index), and the locally owned part must
     # be untouched.  A wrong offset or a lost message fails here, loudly,
     # instead of producing a fast wrong number.
+    halo_selfcheck = None
+    ng = l2g.num_ghosts()
     if world > 1:
-        ng = l2g.num_ghosts()
         d_v = exec_.alloc(M + ng)
         exec_.memset(d_v, 0xFF, 8 * (M + ng))  # NaN pattern in the ghost tail
         _lib.call("spmv_hip_fill_gaussian_f64", ctx, N, l2g.global_offset(), M,
@@ -247,6 +378,7 @@ def main():
         if bad:
             raise SystemExit(f"rank {rank}: halo self-check FAILED "
                              f"({ng} ghosts) -- refusing to benchmark")
+        halo_selfcheck = "ok"
 
     # warm-up: W untimed iterations (also sizes the workspace, RCCL rings)
     if args.warmup > 0:
@@ -260,30 +392,22 @@ def main():
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
-    k, hist, spmv_ms, spmv_launches = host.cg_ex(comm, exec_, A, d_b, d_x,
-                                                 args.steps, 0.0, ws,
-                                                 time_spmv=True, history=True,
-                                                 consumer_reductions=not args.reducer_kernels)
+    k, hist, spmv_ms, spmv_launches = host.cg_ex(
+        comm, exec_, A, d_b, d_x, args.steps, 0.0, ws, time_spmv=True,
+        history=True, consumer_reductions=not args.reducer_kernels)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     assert k == args.steps, (k, args.steps)
 
     # algorithmic bytes of the dominant kernel on THIS rank (DESIGN.md,
-    # SURVEY 8d): entries*12 + (rows+1)*4 + x (cols*8) + y (rows*8)
-    rows_b, cols_b, nnz_b = blocks["local"]
-    if args.symmetric:
-        kernel_bytes = poisson.sym_csr_bytes(rows_b, nnz_b)
-        kernel = "csr_sym_window_kernel<double> (local lower block + diagonal)"
-    else:
-        kernel_bytes = poisson.csr_bytes(rows_b, cols_b, nnz_b)
-        kernel = ("csr_rowblock_kernel<double> (local block, fused p.Ap)"
-                  if args.no_lx else
-                  "csr_rowblock_lx_kernel<double> (local block, LX form: x "
-                  "windows staged in LDS, 16-bit column offsets; fused p.Ap)")
+    # SURVEY 8d), and the bytes its form really loads and stores
+    kernel, kernel_bytes, requested_bytes = kernel_of(A, args.symmetric)
     iter_bytes = kernel_bytes + 9 * M * 8  # + fused BLAS-1 minimum, SURVEY 8d
 
-    # max over ranks of the times, sum over ranks of the bytes
+    # max over ranks of the times, sum over ranks of the bytes; per-rank halo
+    # shape for the record
+    mine = [float(l2g._nn), float(ng), float(M)]
     if world > 1:
         dev_t = "cpu" if rehearsal else "cuda"
         t = torch.tensor([elapsed, spmv_ms / max(spmv_launches, 1)],
@@ -294,24 +418,26 @@ def main():
                             device=dev_t)
         dist.all_reduce(bsum, op=dist.ReduceOp.SUM)
         kernel_bytes_all, iter_bytes_all = float(bsum[0]), float(bsum[1])
+        shape = torch.zeros(world, 3, dtype=torch.float64, device=dev_t)
+        shape[rank] = torch.tensor(mine, dtype=torch.float64)
+        dist.all_reduce(shape, op=dist.ReduceOp.SUM)
+        per_rank = shape.cpu().tolist()
     else:
         spmv_ms_avg = spmv_ms / max(spmv_launches, 1)
         kernel_bytes_all, iter_bytes_all = kernel_bytes, iter_bytes
+        per_rank = [mine]
 
     if rank == 0:
         achieved = kernel_bytes / (spmv_ms_avg * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if os.path.exists(pmc) and world == 1 and n == 512:
-            try:
-                summary = json.load(open(pmc))
-                if args.symmetric:
-                    summary = summary.get("symmetric_kernel", {})
-                elif args.no_lx:
-                    summary = summary.get("gather_kernel", {})
-                traffic = summary.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_source = pmc_traffic(kernel, n, world)
+        k10 = float(hist[min(10, len(hist) - 1)] / hist[0])
+        resid = {"k10": k10, "kK": float(hist[-1] / hist[0])}
+        if n == 512 and len(hist) > 10:
+            # the 1-rank value: an N-rank run must land on it (its dot products
+            # are summed in another order, nothing else differs)
+            resid["k10_expected"] = K10_512
+            resid["k10_rel_deviation"] = abs(k10 / K10_512 - 1.0)
+            resid["k10_ok"] = bool(abs(k10 / K10_512 - 1.0) < 1e-9)
         out = {
             "metric": "fp64 CG iters/sec (SpMV effective GB/s vs HBM roofline)",
             "value": args.steps / elapsed,
@@ -334,34 +460,97 @@ def main():
                        if world > 1 else "none (1 rank)"},
             "roofline": {"bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         # the same launches priced with the bytes this form of
+                         # the kernel really loads and stores (no index stream)
+                         "requested_bytes_per_launch": requested_bytes,
+                         "frac_requested": requested_bytes
+                         / (spmv_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel,
                          "algorithmic_bytes_per_launch": kernel_bytes,
                          "avg_launch_ms": spmv_ms_avg,
                          "launches_timed": spmv_launches},
-            # whole-iteration effective bandwidth: SpMV + fused BLAS-1 minimum
-            # (9 vectors of 8 B per row, SURVEY 8d)
             # ||r_k|| / ||r_0|| from the device-side history: after 10
             # iterations the same number to ~1e-12 whatever the rank count
             # or storage (a cross-check of the distributed path); after all K,
-            # where CG has amplified the different summation orders
-            "cg_rel_residual": {"k10": float(hist[min(10, len(hist) - 1)] / hist[0]),
-                                "kK": float(hist[-1] / hist[0])},
+            # where CG has amplified the different summation orders.  CG parity
+            # is unpinned by the reference itself.
+            "cg_rel_residual": resid,
+            # whole-iteration effective bandwidth: SpMV + fused BLAS-1 minimum
+            # (9 vectors of 8 B per row, SURVEY 8d)
             "cg_gbs_per_gpu": iter_bytes / (elapsed / args.steps) / 1e9,
             # all ranks together: sum of bytes / time of the slowest rank
             "spmv_gbs_aggregate": kernel_bytes_all / (spmv_ms_avg * 1e-3) / 1e9,
             "cg_gbs_aggregate": iter_bytes_all / (elapsed / args.steps) / 1e9,
+            "plan": plan_record(A),
         }
-        if world == 1 and not args.symmetric:
-            out["north_star_spmv"] = north_star_spmv(exec_, comm, host, _lib,
-                                                     poisson)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, n, N)
-        print(json.dumps(out), flush=True)
-
+        if world > 1:
+            out["halo_selfcheck"] = halo_selfcheck
+            out["ranks"] = [{"rank": r, "neighbours": int(v[0]),
+                             "ghosts": int(v[1]), "rows": int(v[2])}
+                            for r, v in enumerate(per_rank)]
+            if rccl:
+                out["rccl"] = {k_: rccl[k_] for k_ in
+                               ("nranks", "version", "lib_path",
+                                "separate_reduction_comm")}
+    # the main matrix is no longer needed: make room for the sub-records
     ws.close()
     A.close()
     exec_.free(d_b), exec_.free(d_x)
+
+    if rank == 0:
+        if world == 1 and not args.no_extras:
+            self_comm = comm
+            # BASELINE configs[3]: symmetric storage at the same size, the CG
+            # loop on it and its kernel
+            if not args.symmetric:
+                As = host.Matrix.create_poisson3d(self_comm, exec_, n, True, cm)
+                d_b, d_x = exec_.alloc(N), exec_.alloc(N)
+                _lib.call("spmv_hip_fill_gaussian_f64", ctx, N, 0, N, d_b, None)
+                ws2 = host.CgWorkspace(exec_)
+                steps = min(args.steps, 20)
+                host.cg_ex(self_comm, exec_, As, d_b, d_x, 3, 0.0, ws2)
+                ws2.reserve_timing(steps)
+                exec_.synchronize()
+                t0 = time.perf_counter()
+                _, h2, ms2, l2 = host.cg_ex(self_comm, exec_, As, d_b, d_x, steps,
+                                            0.0, ws2, time_spmv=True, history=True)
+                exec_.synchronize()
+                el2 = time.perf_counter() - t0
+                kern2, algo2, req2 = kernel_of(As, True)
+                ms2 /= max(l2, 1)
+                out["symmetric"] = {
+                    "workload": f"poisson3d_{n}^3_symmetric-csr_fp64_cg",
+                    "iters/s": steps / el2, "steps": steps, "kernel": kern2,
+                    "avg_launch_ms": ms2, "algorithmic_bytes_per_launch": algo2,
+                    "GB/s": algo2 / ms2 / 1e6,
+                    "frac": algo2 / ms2 / 1e6 / HBM_PEAK_GBS,
+                    "requested_bytes_per_launch": req2,
+                    "frac_requested": req2 / ms2 / 1e6 / HBM_PEAK_GBS,
+                    "parity": "bit-exact vs the oracle (atomic-free)"
+                    if "atomic-free" in kern2 else "tolerance (atomics)",
+                    "cg_rel_residual_k10": float(h2[min(10, len(h2) - 1)] / h2[0]),
+                    "traffic": None, "traffic_source": None}
+                out["symmetric"].update(plan_record(As))
+                ws2.close()
+                As.close()
+                exec_.free(d_b), exec_.free(d_x)
+                # the LX form: what a CSR matrix WITHOUT lattice structure gets
+                # (same matrix, lattice analysis switched off)
+                if not (args.no_lattice or args.no_lx):
+                    out["csr_lx_spmv"] = spmv_record(exec_, self_comm, host, _lib,
+                                                     n, False, 20, lattice=False)
+            # BASELINE north_star: plain SpMV on the ~10 M-row matrix
+            if not args.symmetric:
+                out["north_star_spmv"] = spmv_record(exec_, self_comm, host, _lib,
+                                                     216, False, 200)
+                out["north_star_spmv"]["frac_of_8TBs"] = \
+                    out["north_star_spmv"]["frac"]
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, n, N, host_cores)
+        print(json.dumps(out), flush=True)
+
     comm.close()
     exec_.close()
     if world > 1:

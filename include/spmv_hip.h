@@ -324,6 +324,13 @@ int spmv_hip_comm_create(spmv_hip_ctx* ctx, int nranks, int rank,
                          const void* host_id_bytes, spmv_hip_comm** comm);
 int spmv_hip_comm_destroy(spmv_hip_comm* comm);
 int spmv_hip_comm_rank(const spmv_hip_comm* comm, int* rank, int* nranks);
+/* What the transport really is: rank count and rank as RCCL reports them,
+ * RCCL's version code, whether the reductions run on a communicator of their
+ * own (split off the halo one), and the path of the RCCL library that was
+ * loaded.  Any output pointer may be NULL. */
+int spmv_hip_comm_info(const spmv_hip_comm* comm, int* nranks, int* rank,
+                       int* rccl_version, int* separate_reduction_comm,
+                       char* lib_path, int lib_path_len);
 /* one grouped exchange: for every neighbour i, send send_counts[i] doubles
  * from send_buf + send_offsets[i] and receive recv_counts[i] doubles into
  * recv_base + recv_offsets[i] (offsets in elements). */

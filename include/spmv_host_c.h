@@ -86,6 +86,10 @@ typedef int (*spmvh_allreduce_fn)(void* user, double* device_inout,
 int spmvh_comm_callback(int rank, int nranks, spmvh_allgather_fn allgather,
                         spmvh_exchange_fn exchange, spmvh_allreduce_fn allreduce,
                         void* user, spmvh_comm** comm);
+/* RcclComm::info(): out = {nranks, rank (both as RCCL reports them), RCCL
+ * version code, 1 if the reductions have a communicator of their own} */
+int spmvh_comm_rccl_info(spmvh_comm* comm, int out[4], char* lib_path,
+                         int lib_path_len);
 int spmvh_comm_destroy(spmvh_comm* comm);
 
 /* ---- matrix: Matrix<double>::create_matrix / create_poisson3d --------------- */
@@ -110,6 +114,12 @@ int spmvh_matrix_symmetric(spmvh_matrix* A, int* symmetric);
 /* local / remote block sizes: out[0..5] = rows, cols, nnz of local then remote
  * (remote all zero when the matrix has a single block) */
 int spmvh_matrix_blocks(spmvh_matrix* A, int64_t out[6]);
+/* spmv_hip_csr_plan_get / _set on the local (remote = 0) or remote block's
+ * plan: which form it took, what it cost, launch-shape knobs */
+int spmvh_matrix_plan_get(spmvh_matrix* A, int remote, const char* key,
+                          int* value);
+int spmvh_matrix_plan_set(spmvh_matrix* A, int remote, const char* key,
+                          int value);
 /* A.col_map()->update(x) ; A.mult(x, y) ; A.col_map()->update_finalise(x) */
 int spmvh_matrix_update(spmvh_matrix* A, double* x);
 int spmvh_matrix_update_finalise(spmvh_matrix* A, double* x);

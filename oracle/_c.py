@@ -24,6 +24,12 @@ def build(force=False):
 
 _lib = None
 
+
+class BaselineResult(C.Structure):
+    _fields_ = [("spmv_s_per_apply", C.c_double), ("cg_loop_s", C.c_double),
+                ("setup_s", C.c_double), ("rel_residual", C.c_double),
+                ("cg_iters", C.c_int), ("threads", C.c_int)]
+
 _i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
 _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
@@ -81,6 +87,9 @@ def lib():
                                  _f64p, _f64p, C.c_int, C.c_int,
                                  C.POINTER(C.c_int)]
     L.oracle_time_cg.restype = C.c_double
+    L.oracle_cpu_baseline.argtypes = [C.c_int32, C.c_int, C.c_int, C.c_int,
+                                      C.POINTER(BaselineResult)]
+    L.oracle_cpu_baseline.restype = C.c_int
     L.oracle_max_threads.argtypes = []
     L.oracle_max_threads.restype = C.c_int
     _lib = L
@@ -221,6 +230,16 @@ def time_cg(rowptr, colind, values, b, kmax, num_threads):
                              _c(b, np.float64), x, kmax, num_threads,
                              C.byref(k))
     return t, k.value
+
+
+def cpu_baseline(n, threads, spmv_reps, cg_iters):
+    """OpenMP SpMV + CG on the n^3 Poisson matrix, owner first touch, loops
+    timed alone.  Returns a dict."""
+    res = BaselineResult()
+    rc = lib().oracle_cpu_baseline(n, threads, spmv_reps, cg_iters, C.byref(res))
+    if rc != 0:
+        raise RuntimeError(f"oracle_cpu_baseline failed ({rc})")
+    return {f: getattr(res, f) for f, _ in BaselineResult._fields_}
 
 
 def max_threads():

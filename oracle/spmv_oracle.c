@@ -510,6 +510,108 @@ double oracle_time_cg(int32_t n, int64_t nnz, const int32_t* rowptr,
   return t1 - t0;
 }
 
+/* ------------------------------------------------------------------------- */
+/* cpu_baseline leg of bench.py: the OpenMP path above on the benchmark's own
+ * matrix, set up the way SURVEY section 8d asks: every array is first touched
+ * by the thread that later streams it (same static nnz-balanced row split as
+ * the kernel, openmp/csr_kernels.openmp.cpp:56-87), threads spread over the
+ * cores (OMP_PLACES=cores OMP_PROC_BIND=spread in the environment, proc_bind
+ * here), and only the apply / iteration loops are timed -- no set-up, no
+ * allocation, no copies. */
+int oracle_cpu_baseline(int32_t n, int threads, int spmv_reps, int cg_iters,
+                        oracle_baseline_result* res)
+{
+  const int nt = threads < 1 ? 1 : threads;
+  const int64_t n2 = (int64_t)n * n, N = n2 * n;
+  const int64_t nnz = 7 * N - 6 * n2;
+  if (N > INT32_MAX || nnz > INT32_MAX)
+    return 1;
+  double t0 = now_s();
+  int32_t* rowptr = (int32_t*)malloc(sizeof(int32_t) * (size_t)(N + 1));
+  int32_t* colind = (int32_t*)malloc(sizeof(int32_t) * (size_t)nnz);
+  double* values = (double*)malloc(sizeof(double) * (size_t)nnz);
+  double *b = (double*)malloc(sizeof(double) * (size_t)N),
+         *x = (double*)malloc(sizeof(double) * (size_t)N),
+         *r = (double*)malloc(sizeof(double) * (size_t)N),
+         *p = (double*)malloc(sizeof(double) * (size_t)N),
+         *Ap = (double*)malloc(sizeof(double) * (size_t)N);
+  if (!rowptr || !colind || !values || !b || !x || !r || !p || !Ap)
+    return 2;
+  /* row lengths (even split: this array is read by all threads anyway) */
+  rowptr[0] = 0;
+#pragma omp parallel for num_threads(nt) proc_bind(spread) schedule(static)
+  for (int64_t i = 0; i < N; ++i) {
+    const int64_t xx = i % n, yy = (i / n) % n, zz = i / n2;
+    rowptr[i + 1] = 1 + (xx > 0) + (xx < n - 1) + (yy > 0) + (yy < n - 1)
+                    + (zz > 0) + (zz < n - 1);
+  }
+  for (int64_t i = 0; i < N; ++i)
+    rowptr[i + 1] += rowptr[i];
+  oracle_omp_plan* plan = oracle_omp_init((int32_t)N, nnz, rowptr, NULL, 0, nt);
+  const int32_t* row_split = plan->row_split;
+  /* matrix entries and vectors: first touch by the owner of the rows */
+#pragma omp parallel num_threads(nt) proc_bind(spread)
+  {
+#ifdef _OPENMP
+    const int tid = omp_get_thread_num();
+#else
+    const int tid = 0;
+#endif
+    for (int64_t i = row_split[tid]; i < row_split[tid + 1]; ++i) {
+      const int64_t xx = i % n, yy = (i / n) % n, zz = i / n2;
+      int64_t pos = rowptr[i];
+      if (zz > 0) { colind[pos] = (int32_t)(i - n2); values[pos++] = -1.0; }
+      if (yy > 0) { colind[pos] = (int32_t)(i - n); values[pos++] = -1.0; }
+      if (xx > 0) { colind[pos] = (int32_t)(i - 1); values[pos++] = -1.0; }
+      colind[pos] = (int32_t)i; values[pos++] = 6.0;
+      if (xx < n - 1) { colind[pos] = (int32_t)(i + 1); values[pos++] = -1.0; }
+      if (yy < n - 1) { colind[pos] = (int32_t)(i + n); values[pos++] = -1.0; }
+      if (zz < n - 1) { colind[pos] = (int32_t)(i + n2); values[pos++] = -1.0; }
+      b[i] = 1.0;
+      x[i] = 0.0;
+      r[i] = 1.0; /* cg.cpp:44-45: r = p = b */
+      p[i] = 1.0;
+      Ap[i] = 0.0;
+    }
+  }
+  res->setup_s = now_s() - t0;
+  res->threads = nt;
+  /* SpMV: 1 warm-up + reps timed (demos/spmv.cpp:73-96) */
+  oracle_omp_spmv(plan, (int32_t)N, nnz, rowptr, colind, values, NULL, 1.0, p,
+                  0.0, Ap);
+  t0 = now_s();
+  for (int k = 0; k < spmv_reps; ++k)
+    oracle_omp_spmv(plan, (int32_t)N, nnz, rowptr, colind, values, NULL, 1.0, p,
+                    0.0, Ap);
+  res->spmv_s_per_apply = (now_s() - t0) / (spmv_reps > 0 ? spmv_reps : 1);
+  /* CG iterations (openmp/cg.openmp.cpp:55-88), the loop alone */
+  double rnorm0 = sqrt(omp_ddot(N, r, r, nt));
+  double rnorm_old = rnorm0;
+  int k = 0;
+  t0 = now_s();
+  while (k < cg_iters) {
+    ++k;
+    oracle_omp_spmv(plan, (int32_t)N, nnz, rowptr, colind, values, NULL, 1.0, p,
+                    0.0, Ap);
+    double pdotAp = omp_ddot(N, p, Ap, nt);
+    double alpha = (rnorm_old * rnorm_old) / pdotAp;
+    omp_daxpy(N, alpha, p, x, nt);
+    omp_daxpy(N, -alpha, Ap, r, nt);
+    double rnorm_new = sqrt(omp_ddot(N, r, r, nt));
+    double beta = (rnorm_new * rnorm_new) / (rnorm_old * rnorm_old);
+    rnorm_old = rnorm_new;
+    omp_dscal(N, beta, p, nt);
+    omp_daxpy(N, 1.0, r, p, nt);
+  }
+  res->cg_loop_s = now_s() - t0;
+  res->cg_iters = k;
+  res->rel_residual = rnorm_old / rnorm0;
+  oracle_omp_free(plan);
+  free(rowptr); free(colind); free(values);
+  free(b); free(x); free(r); free(p); free(Ap);
+  return 0;
+}
+
 int oracle_max_threads(void)
 {
 #ifdef _OPENMP

@@ -111,6 +111,18 @@ double oracle_time_cg(int32_t n, int64_t nnz, const int32_t* rowptr,
                       const int32_t* colind, const double* values,
                       const double* b, double* x, int kmax, int num_threads,
                       int* iterations);
+/* cpu_baseline leg: OpenMP SpMV + CG on the n^3 Poisson matrix with owner
+ * first touch, spread threads, loops timed alone (see the .c file) */
+typedef struct {
+  double spmv_s_per_apply;
+  double cg_loop_s;
+  double setup_s;
+  double rel_residual;
+  int cg_iters;
+  int threads;
+} oracle_baseline_result;
+int oracle_cpu_baseline(int32_t n, int threads, int spmv_reps, int cg_iters,
+                        oracle_baseline_result* res);
 int oracle_max_threads(void);
 
 #ifdef __cplusplus

@@ -125,6 +125,8 @@ _PROTOS = {
     "spmv_hip_comm_neighbor_exchange_f32": ([vp, C.c_int, vp, vp, vp, vp, vp,
                                              vp, vp, vp], C.c_int),
     "spmv_hip_comm_rank": ([vp, P(C.c_int), P(C.c_int)], C.c_int),
+    "spmv_hip_comm_info": ([vp, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int),
+                            C.c_char_p, C.c_int], C.c_int),
     "spmv_hip_comm_allreduce_sum_f64": ([vp, vp, sz, vp], C.c_int),
     "spmv_hip_comm_allgather_host": ([vp, vp, vp, sz], C.c_int),
 }

@@ -15,15 +15,26 @@
 
 #include <rccl/rccl.h>
 
+#include <dlfcn.h>
+
 #include <cstring>
 #include <new>
 
 static_assert(sizeof(ncclUniqueId) <= SPMV_HIP_UNIQUE_ID_BYTES,
               "unique id does not fit the ABI's byte buffer");
 
+// Two communicators per process.  The grouped halo send/recv runs on the
+// map's side stream while the CG loop issues its one-double all-reduces on the
+// compute stream; RCCL serialises the operations of ONE communicator and ties
+// their streams together, which would take the overlap of the halo with the
+// local SpMV away and make correctness depend on an identical issue order on
+// every rank.  So the reductions (and the plan-time all-gathers) get their own
+// communicator, split off the first one.
 struct spmv_hip_comm {
   spmv_hip_ctx* ctx = nullptr;
-  ncclComm_t comm = nullptr;
+  ncclComm_t comm = nullptr; // halo exchange (neighbour send/recv)
+  ncclComm_t red = nullptr;  // all-reduce / all-gather; == comm if the split
+                             // is not available
   int nranks = 1;
   int rank = 0;
 };
@@ -76,7 +87,48 @@ int spmv_hip_comm_create(spmv_hip_ctx* ctx, int nranks, int rank,
     delete c;
     return 10000 + static_cast<int>(r);
   }
+  c->red = c->comm;
+  if (nranks > 1) {
+    // collective over the parent: every rank is in this call right now
+    ncclComm_t red = nullptr;
+    if (ncclCommSplit(c->comm, 0, rank, &red, nullptr) == ncclSuccess && red)
+      c->red = red;
+  }
   *out = c;
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_comm_info(const spmv_hip_comm* comm, int* nranks, int* rank,
+                       int* rccl_version, int* separate_reduction_comm,
+                       char* lib_path, int lib_path_len)
+{
+  SPMV_REQUIRE(comm);
+  if (nranks || rank) {
+    // what RCCL itself says, not what the caller passed in
+    int n = 0, r = 0;
+    SPMV_CHECK_NCCL(ncclCommCount(comm->comm, &n));
+    SPMV_CHECK_NCCL(ncclCommUserRank(comm->comm, &r));
+    if (nranks)
+      *nranks = n;
+    if (rank)
+      *rank = r;
+  }
+  if (rccl_version) {
+    int v = 0;
+    SPMV_CHECK_NCCL(ncclGetVersion(&v));
+    *rccl_version = v;
+  }
+  if (separate_reduction_comm)
+    *separate_reduction_comm = comm->red != comm->comm ? 1 : 0;
+  if (lib_path && lib_path_len > 0) {
+    lib_path[0] = 0;
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void*>(&ncclGetVersion), &info)
+        && info.dli_fname) {
+      strncpy(lib_path, info.dli_fname, (size_t)lib_path_len - 1);
+      lib_path[lib_path_len - 1] = 0;
+    }
+  }
   return SPMV_HIP_OK;
 }
 
@@ -85,6 +137,8 @@ int spmv_hip_comm_destroy(spmv_hip_comm* comm)
   if (!comm)
     return SPMV_HIP_OK;
   (void)hipSetDevice(comm->ctx->device);
+  if (comm->red && comm->red != comm->comm)
+    (void)ncclCommDestroy(comm->red);
   if (comm->comm)
     (void)ncclCommDestroy(comm->comm);
   delete comm;
@@ -166,7 +220,7 @@ int spmv_hip_comm_allreduce_sum_f64(spmv_hip_comm* comm, double* inout,
     return SPMV_HIP_OK;
   SPMV_SET_DEVICE(comm->ctx);
   SPMV_CHECK_NCCL(ncclAllReduce(inout, inout, count, ncclDouble, ncclSum,
-                                comm->comm, spmv_stream(comm->ctx, stream)));
+                                comm->red, spmv_stream(comm->ctx, stream)));
   return SPMV_HIP_OK;
 }
 
@@ -190,7 +244,7 @@ int spmv_hip_comm_allgather_host(spmv_hip_comm* comm, const void* host_send,
     e = hipMemcpyAsync(d_send, host_send, bytes_per_rank,
                        hipMemcpyHostToDevice, st);
   if (e == hipSuccess)
-    r = ncclAllGather(d_send, d_recv, bytes_per_rank, ncclChar, comm->comm, st);
+    r = ncclAllGather(d_send, d_recv, bytes_per_rank, ncclChar, comm->red, st);
   if (e == hipSuccess && r == ncclSuccess)
     e = hipMemcpyAsync(host_recv, d_recv, bytes_per_rank * comm->nranks,
                        hipMemcpyDeviceToHost, st);

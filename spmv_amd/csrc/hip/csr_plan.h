@@ -139,6 +139,7 @@ struct spmv_hip_csr_plan {
   int32_t* row_list = nullptr; // ROWLIST: device list of non-empty rows
   int32_t num_listed = 0;
   int nt_store = 0; // non-temporal y stores
+  int plan_us = 0;  // wall time of plan creation (analysis kernels included)
   // ROWBLOCK "LX" form: LDS-staged x windows + 16-bit local column indices
   // (csr_rowblock_lx_kernel); built by plan_create when most row blocks qualify
   uint16_t* lx_lidx = nullptr;

@@ -29,6 +29,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <utility>
@@ -1018,6 +1019,7 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
   SPMV_REQUIRE(ctx && plan && num_rows >= 0 && num_cols >= 0
                && num_non_zeros >= 0);
   SPMV_REQUIRE(num_non_zeros == 0 || (rowptr && colind));
+  const auto t_begin = std::chrono::steady_clock::now();
   // rowptr is int32 in the reference format (csr_kernels.h:28)
   if (num_non_zeros > INT32_MAX)
     return SPMV_HIP_ERANGE;
@@ -1091,6 +1093,10 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
       return rc;
     }
   }
+  // what the analysis cost (every builder has synchronised its stream)
+  pl->plan_us = (int)std::chrono::duration_cast<std::chrono::microseconds>(
+                    std::chrono::steady_clock::now() - t_begin)
+                    .count();
   *plan = pl;
   return SPMV_HIP_OK;
 }
@@ -1205,6 +1211,27 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
     *value = plan->sym_det;
   else if (!strcmp(key, "slat"))
     *value = plan->slat;
+  else if (!strcmp(key, "plan_us"))
+    *value = plan->plan_us;
+  else if (!strcmp(key, "plan_kib")) {
+    // device memory the plan owns beyond the caller's CSR arrays
+    const int64_t n = plan->num_rows, nnz = plan->nnz;
+    const int64_t nrb = (n + kRows - 1) / kRows;
+    int64_t b = 0;
+    if (plan->row_list)
+      b += 4 * (int64_t)plan->num_listed;
+    if (plan->lx_lidx)
+      b += 2 * (nnz + 8) + 4 * nrb * kLxRec;
+    if (plan->lat_tab)
+      b += 48 * nrb + n;
+    if (plan->slat_mask)
+      b += n;
+    if (plan->t_ptr)
+      b += 4 * (n + 1) + 8 * nnz;
+    if (plan->order)
+      b += 4 * (int64_t)plan->order_slots;
+    *value = (int)((b + 1023) / 1024);
+  }
   else if (!strcmp(key, "band_order"))
     *value = plan->band_order && plan->order ? 1 : 0;
   else if (!strcmp(key, "band_lines"))

@@ -246,6 +246,25 @@ int spmvh_comm_rccl(spmvh_exec* exec, int nranks, int rank, const void* id_bytes
   });
 }
 
+int spmvh_comm_rccl_info(spmvh_comm* comm, int out[4], char* lib_path,
+                         int lib_path_len)
+{
+  return guarded([&] {
+    require(comm && out, "NULL argument");
+    const auto* rc = dynamic_cast<const RcclComm*>(comm->comm.get());
+    require(rc != nullptr, "not an RCCL communicator");
+    const RcclComm::Info i = rc->info();
+    out[0] = i.nranks;
+    out[1] = i.rank;
+    out[2] = i.rccl_version;
+    out[3] = i.separate_reduction_comm;
+    if (lib_path && lib_path_len > 0) {
+      strncpy(lib_path, i.lib_path.c_str(), (size_t)lib_path_len - 1);
+      lib_path[lib_path_len - 1] = 0;
+    }
+  });
+}
+
 int spmvh_comm_callback(int rank, int nranks, spmvh_allgather_fn allgather,
                         spmvh_exchange_fn exchange, spmvh_allreduce_fn allreduce,
                         void* user, spmvh_comm** comm)
@@ -367,6 +386,31 @@ int spmvh_matrix_blocks(spmvh_matrix* A, int64_t out[6])
       out[4] = r->cols();
       out[5] = r->non_zeros();
     }
+  });
+}
+
+int spmvh_matrix_plan_get(spmvh_matrix* A, int remote, const char* key,
+                          int* value)
+{
+  return guarded([&] {
+    require(A && key && value, "NULL argument");
+    const SubMatrix<double>* b
+        = remote ? A->A->remote_block() : A->A->local_block();
+    const auto* csr = dynamic_cast<const CSRMatrix<double>*>(b);
+    *value = csr ? csr->query(key) : 0;
+  });
+}
+
+int spmvh_matrix_plan_set(spmvh_matrix* A, int remote, const char* key,
+                          int value)
+{
+  return guarded([&] {
+    require(A && key, "NULL argument");
+    const SubMatrix<double>* b
+        = remote ? A->A->remote_block() : A->A->local_block();
+    const auto* csr = dynamic_cast<const CSRMatrix<double>*>(b);
+    require(csr != nullptr, "no such block");
+    csr->tune(key, value);
   });
 }
 

@@ -122,6 +122,19 @@ void RcclComm::neighbor_exchange(size_t elem_bytes,
   throw_on_error(rc, "spmv_hip_comm_neighbor_exchange");
 }
 
+RcclComm::Info RcclComm::info() const
+{
+  Info out;
+  char path[512];
+  throw_on_error(spmv_hip_comm_info(_comm, &out.nranks, &out.rank,
+                                    &out.rccl_version,
+                                    &out.separate_reduction_comm, path,
+                                    (int)sizeof(path)),
+                 "spmv_hip_comm_info");
+  out.lib_path = path;
+  return out;
+}
+
 void RcclComm::allreduce_sum(double* device_inout, size_t count,
                              void* stream) const
 {

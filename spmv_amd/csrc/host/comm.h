@@ -22,6 +22,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <memory>
+#include <string>
 #include <vector>
 
 struct spmv_hip_comm;
@@ -126,6 +127,13 @@ public:
                          void* stream) const override;
   void allreduce_sum(double* device_inout, size_t count,
                      void* stream) const override;
+
+  // what the transport really is (spmv_hip_comm_info): for benchmark records
+  struct Info {
+    int nranks = 0, rank = 0, rccl_version = 0, separate_reduction_comm = 0;
+    std::string lib_path;
+  };
+  Info info() const;
 
 private:
   spmv_hip_comm* _comm = nullptr;

@@ -93,6 +93,16 @@ void CSRSpMV<T>::tune(const char* key, int value) const
 }
 
 template <typename T>
+int CSRSpMV<T>::query(const char* key) const
+{
+  int v = 0;
+  if (plan())
+    throw_on_error(spmv_hip_csr_plan_get(plan(), key, &v),
+                   "spmv_hip_csr_plan_get");
+  return v;
+}
+
+template <typename T>
 void CSRSpMV<T>::finalize(const HipExecutor&) const
 {
   spmv_hip_csr_plan_destroy(plan());

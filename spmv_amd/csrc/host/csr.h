@@ -62,6 +62,9 @@ public:
   // launch-shape knob of the plan (spmv_hip_csr_plan_set); throws on an
   // unknown key
   void tune(const char* key, int value) const;
+  // read-only counterpart (spmv_hip_csr_plan_get): which form the plan took,
+  // what it cost ("lat", "lx", "slat", "sym_det", "plan_us", "plan_kib", ...)
+  int query(const char* key) const;
 
   bool symmetric() const { return _symmetric; }
   spmv_hip_csr_plan* plan() const
@@ -132,6 +135,7 @@ public:
   const T* values() const { return _values; }
   const CSRSpMV<T>& op() const { return _op; }
   void tune(const char* key, int value) const { _op.tune(key, value); }
+  int query(const char* key) const { return _op.query(key); }
 
 private:
   int32_t* _rowptr = nullptr;

@@ -42,6 +42,7 @@ _PROTOS = {
     "spmvh_comm_self": [PTR(vp)],
     "spmvh_rccl_unique_id": [vp],
     "spmvh_comm_rccl": [vp, C.c_int, C.c_int, vp, PTR(vp)],
+    "spmvh_comm_rccl_info": [vp, PTR(C.c_int), C.c_char_p, C.c_int],
     "spmvh_comm_callback": [C.c_int, C.c_int, ALLGATHER_FN, EXCHANGE_FN,
                             ALLREDUCE_FN, vp, PTR(vp)],
     "spmvh_comm_destroy": [vp],
@@ -63,6 +64,8 @@ _PROTOS = {
     "spmvh_matrix_format_size": [vp, PTR(sz)],
     "spmvh_matrix_symmetric": [vp, PTR(C.c_int)],
     "spmvh_matrix_blocks": [vp, PTR(i64)],
+    "spmvh_matrix_plan_get": [vp, C.c_int, C.c_char_p, PTR(C.c_int)],
+    "spmvh_matrix_plan_set": [vp, C.c_int, C.c_char_p, C.c_int],
     "spmvh_matrix_update": [vp, vp],
     "spmvh_matrix_update_finalise": [vp, vp],
     "spmvh_matrix_mult": [vp, vp, vp],
@@ -191,6 +194,18 @@ class Comm:
         buf = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
         call("spmvh_comm_rccl", exec_.h, nranks, rank, buf, C.byref(h))
         return cls(h)
+
+    def rccl_info(self):
+        """{nranks, rank, version, separate_reduction_comm, lib_path} as RCCL
+        itself reports them"""
+        out = (C.c_int * 4)()
+        path = C.create_string_buffer(512)
+        call("spmvh_comm_rccl_info", self.h, out, path, 512)
+        v = out[2]
+        return dict(nranks=out[0], rank=out[1], version_code=v,
+                    version=f"{v // 10000}.{v // 100 % 100}.{v % 100}",
+                    separate_reduction_comm=bool(out[3]),
+                    lib_path=path.value.decode())
 
     @classmethod
     def callback(cls, rank, nranks, allgather, exchange=None, allreduce=None):
@@ -383,6 +398,16 @@ class Matrix:
 
     def col_map(self):
         return ColMapView(self)
+
+    def plan_get(self, key, remote=False):
+        v = C.c_int()
+        call("spmvh_matrix_plan_get", self.h, int(remote), key.encode(),
+             C.byref(v))
+        return v.value
+
+    def plan_set(self, key, value, remote=False):
+        call("spmvh_matrix_plan_set", self.h, int(remote), key.encode(),
+             int(value))
 
     def mult(self, x_ptr, y_ptr):
         call("spmvh_matrix_mult", self.h, x_ptr, y_ptr)

@@ -34,7 +34,10 @@ def _check(d, n_gpus, steps, warmup):
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert r["launches_timed"] == steps and r["avg_launch_ms"] > 0
+    assert 0 < r["frac_requested"] <= r["frac"] * 1.0000001
+    assert (r["traffic"] is None) == (r["traffic_source"] is None)
     assert d["cg_rel_residual"]["k10"] > 0 and d["cg_rel_residual"]["kK"] > 0
+    assert d["plan"]["plan_ms"] >= 0 and d["plan"]["plan_extra_bytes"] >= 0
 
 
 def test_bench_single_gpu_line():
@@ -47,7 +50,14 @@ def test_bench_single_gpu_line():
     _check(d, 1, 20, 3)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
+    assert c["cores"] <= c["host"]["physical_cores"] and "32^3" in c["sample"]
+    assert c["spmv_omp"]["GB/s"] > 0
     assert "sample" in c and d["north_star_spmv"]["rows"] == 216 ** 3
+    # BASELINE configs[3] in the default line: symmetric storage, atomic-free
+    sym = d["symmetric"]
+    assert sym["frac"] > 0 and sym["iters/s"] > 0 and "atomic-free" in sym["kernel"]
+    assert d["csr_lx_spmv"]["form"]["lx"] == 1 and d["csr_lx_spmv"]["form"]["lat"] == 0
+    assert d["north_star_spmv"]["form"]["lat"] == 1
 
 
 def test_bench_two_rank_rehearsal():
@@ -64,6 +74,10 @@ def test_bench_two_rank_rehearsal():
     d = _line(res.stdout)
     _check(d, 2, 10, 2)
     assert "REHEARSAL" in d["data"] and "cpu_baseline" not in d
+    assert d["halo_selfcheck"] == "ok" and len(d["ranks"]) == 2
+    assert [r["neighbours"] for r in d["ranks"]] == [1, 1]
+    assert [r["ghosts"] for r in d["ranks"]] == [64 * 64, 64 * 64]
+    assert sum(r["rows"] for r in d["ranks"]) == 64 ** 3
     # the distributed run reproduces the one-rank residual after 10 iterations
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"),
                           "--grid", "64", "--steps", "10", "--warmup", "2",
