@@ -343,10 +343,9 @@ def test_slab_ranks_threaded_spmv_and_cg(world, n):
             l2g.update(d_x)
             A.mult(d_x, d_y)
             y = tw.gather(rank, exec_.copy_to_host(d_y, r1 - r0))
-            if sym:
-                assert np.all(np.abs(y - y_seq) <= 16 * U * abs_bound(rp, ci, va, x))
-            else:
-                assert np.array_equal(y, y_ref), cm
+            # both storages: the oracle's P-rank simulation, bit for bit
+            assert np.array_equal(y, y_ref), (sym, cm)
+            assert np.all(np.abs(y - y_seq) <= 16 * U * abs_bound(rp, ci, va, x))
             d_b, d_s = exec_.alloc(r1 - r0), exec_.alloc(r1 - r0)
             exec_.copy_from_host(d_b, b[r0:r1])
             k, hist = host.cg(comm, exec_, A, d_b, d_s, 200, 1e-10)
@@ -571,3 +570,85 @@ def test_spmv_128_cubed_gaussian_bit_exact_default_path(exec_, comm):
         assert np.array_equal(y, y_sym_ref if symmetric else y_ref)
         A.close()
         exec_.free(d_x), exec_.free(d_y)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_async_transport_observes_stream_ordering(world):
+    """The halo over an ASYNCHRONOUS transport (tests/thread_world.py: copies
+    only enqueued, delayed by filler kernels, ranks ordered by events alone),
+    as RCCL delivers it.  The blocking transports of the other multi-rank
+    tests drain the stream inside the exchange, so a missing
+    stream_wait_event in L2GMap / Matrix / cg would pass them; here it leaves
+    NaN-poisoned ghosts in the remote block's input or lets the x/p update
+    overwrite a send buffer the neighbour has not read yet."""
+    from thread_world import ThreadWorld
+    n = 20
+    N = n ** 3
+    rp, ci, va = poisson.poisson3d_csr(n)
+    x = oracle.gaussian_x_fast(N)
+    b = oracle.csr_spmv(rp, ci.astype(np.int32), va, np.ones(N))
+    ranges = oracle.owner_ranges(world, N)
+    refs = {}
+    for sym in (False, True):
+        for cm in (host.P2P_BLOCKING, host.P2P_NONBLOCKING):
+            refs[(sym, cm)] = (
+                oracle.dist_spmv(world, rp, ci, va, x, sym, cm),
+                oracle.dist_cg(world, rp, ci, va, b, 25, 1e-30, sym, cm))
+    tw = ThreadWorld(world, timeout=60.0)
+
+    def rank_body(rank, comm, exec_):
+        from spmv_amd import _lib
+        r0, r1 = int(ranges[rank]), int(ranges[rank + 1])
+        for (sym, cm), (y_ref, (x_ref, k_ref, hist_ref)) in refs.items():
+            A = host.Matrix.create_poisson3d(comm, exec_, n, sym, cm)
+            l2g = A.col_map()
+            ng = l2g.num_ghosts()
+            d_x = exec_.alloc(r1 - r0 + ng)
+            d_y = exec_.alloc(r1 - r0)
+            for rep in range(3):  # back to back: the queues stay full
+                exec_.memset(d_x, 0xFF, 8 * (r1 - r0 + ng))  # NaN ghosts
+                exec_.copy_from_host(d_x, x[r0:r1])
+                l2g.update(d_x)
+                A.mult(d_x, d_y)
+            y = tw.gather(rank, exec_.copy_to_host(d_y, r1 - r0))
+            assert np.array_equal(y, y_ref), (sym, cm)
+            # the other direction: the PRODUCER is late (filler kernels, then a
+            # device-side copy brings x in) and the transport is prompt -- if
+            # the exchange did not wait for the compute stream it would ship
+            # the NaN pattern
+            tw.bar.wait()
+            if rank == 0:
+                tw.delay_launches = 0
+            tw.bar.wait()
+            d_stage = exec_.alloc(r1 - r0)
+            exec_.copy_from_host(d_stage, x[r0:r1])
+            filler = exec_.alloc(1 << 22)
+            exec_.memset(d_x, 0xFF, 8 * (r1 - r0 + ng))
+            exec_.memset(d_y, 0xFF, 8 * (r1 - r0))
+            exec_.synchronize()
+            for _ in range(40):
+                _lib.call("spmv_hip_fill_const_f64", exec_.context, 1 << 22, 1.0,
+                          filler, None)
+            _lib.call("spmv_hip_copy_d2d_async", exec_.context, d_x, d_stage,
+                      8 * (r1 - r0), None)
+            l2g.update(d_x)
+            A.mult(d_x, d_y)
+            y = tw.gather(rank, exec_.copy_to_host(d_y, r1 - r0))
+            assert np.array_equal(y, y_ref), ("late producer", sym, cm)
+            exec_.free(d_stage), exec_.free(filler)
+            tw.bar.wait()
+            if rank == 0:
+                tw.delay_launches = 40
+            tw.bar.wait()
+            d_b, d_s = exec_.alloc(r1 - r0), exec_.alloc(r1 - r0)
+            exec_.copy_from_host(d_b, b[r0:r1])
+            k, hist = host.cg(comm, exec_, A, d_b, d_s, 25, 1e-30)
+            xs = tw.gather(rank, exec_.copy_to_host(d_s, r1 - r0))
+            assert k == 25 == k_ref
+            assert np.allclose(hist, hist_ref, rtol=1e-7), (sym, cm)
+            assert np.linalg.norm(xs - x_ref) <= 1e-9 * np.linalg.norm(x_ref)
+            A.close()
+            for p in (d_x, d_y, d_b, d_s):
+                exec_.free(p)
+
+    tw.run(rank_body, gpu=True, asynchronous=True)
