@@ -121,21 +121,43 @@ int spmv_hip_copy_peer_async(spmv_hip_ctx* dst_ctx, void* dst,
  * selects the strictly-lower + diagonal kernel.  rowptr/colind may be NULL
  * when num_non_zeros == 0 (csr_matrix.cpp:34).
  *
+ * Plan creation also analyses the index arrays and, where the matrix allows,
+ * bakes a compressed form of their CONTENT into the plan (all of them produce
+ * the same bits as the plain kernels):
+ *   lattice form   every block of 256 rows has its columns at row + one of
+ *                  <= 8 constant offsets: no index stream at all, values by
+ *                  LDS-DMA one row block ahead
+ *   LX form        few contiguous column windows per row block: x staged in
+ *                  LDS, 16-bit column offsets
+ *   row list       mostly-empty blocks (SPMV_HIP_ALGO_ROWLIST)
+ *   symmetric      the symmetric lattice form (<= 3 constant lower offsets) or
+ *                  the transposed map (entries sorted by column): atomic-free
+ * CONTRACT: a plan with such a form must be launched with the very rowptr /
+ * colind pointers it was created with -- the kernels no longer read colind,
+ * so other arrays of the same shape would silently compute with the old
+ * structure; spmv returns SPMV_HIP_EINVAL instead.  `values`, `in`, `out` are
+ * free to change from call to call.
+ *
  * run computes out = alpha * A * in + beta * out.
  *   - beta == 0: out is write-only and never read.
  *   - general kernel, SPMV_HIP_ALGO_ROWBLOCK: each row is summed left to
  *     right in fp64 without FMA contraction, i.e. bit-identical to
  *     csr_kernels.cpp:41-51.
- *   - symmetric kernel: out is first scaled by beta (zero-filled when
- *     beta == 0) inside run, then every term is accumulated with hardware
- *     fp64 atomics; the order of additions is not deterministic.
+ *   - symmetric kernel (strictly lower block): the reference's sequential
+ *     order (csr_kernels.cpp:26-40) seen from the row -- finalise
+ *     fl(alpha*sum + beta*out), then add fl(fl(alpha*v)*in[r]) for the
+ *     entries (r, i) of the row's column in ascending r -- with no atomics:
+ *     bit-identical to the reference.  plan_set "sym_det" / "slat" = 0 (or a
+ *     block that is not strictly lower) selects the older atomic kernels: out
+ *     is scaled by beta, every term accumulated with hardware fp64 atomics,
+ *     order of additions not deterministic.
  *   - `dot_partials` (optional, may be NULL; not for a diagonal-only
  *     symmetric block): fuses
  *     the CG dot product.  The kernel writes spmv_hip_dot_partials_len()
  *     doubles whose sum is sum_i in[i] * (alpha * (A in)_i), this block's own
  *     share (beta*out is not included, so the shares of a local and a remote
  *     block add up to in . (A in)); reduce with spmv_hip_reduce_partials_f64.
- *     The symmetric kernel uses the mirror identity: row i contributes
+ *     The atomic symmetric kernels use the mirror identity: row i contributes
  *     in_i * alpha * (2 (d_i in_i + (L in)_i) - d_i in_i).
  */
 enum {
@@ -155,13 +177,23 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
                              spmv_hip_csr_plan** plan);
 int spmv_hip_csr_plan_destroy(spmv_hip_csr_plan* plan);
 int spmv_hip_csr_plan_algo(const spmv_hip_csr_plan* plan, int* algo);
-/* tuning knobs, used by the benchmark sweep: key/value, returns EINVAL for
- * an unknown key. */
+/* Knobs (key/value; EINVAL for an unknown key or a value out of range):
+ *   "algo" "lanes_per_row" "chunks" "nontemporal" "xcd_group" "blocks_per_cu"
+ *   "nt_store"                           the plain general kernels
+ *   "lx" "lx_chunks"                     LX form on/off (built plans only)
+ *   "lat" "lat_blocks_per_cu" "lat_xcd_group"      lattice form
+ *   "slat" "slat_blocks_per_cu"          symmetric lattice form
+ *   "sym_det"                            transposed-map kernel (0: atomics)
+ *   "sym_window" "sym_rows"              the atomic symmetric kernels
+ *   "band_lines" = lines per band (0 = choose): (re)build the band-sweep
+ *                  row-block order of the lattice kernels; "band_order" 0/1 */
 int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value);
-/* what the plan decided: "algo", "lattice_d1", "lattice_d2" (row offsets of the
- * next grid line / plane when the matrix looks like a 3-D stencil, else 0),
- * "band_lines" / "order_slots" (band-sweep row-block order, 0 = none),
- * "band_order", "blocks_per_cu", "nontemporal" */
+/* What the plan decided and what it cost: "algo"; "lat", "lx", "slat",
+ * "sym_det" (1 = that form is in use), "lat_blocks", "lx_blocks", "lx_staged";
+ * "lattice_d1", "lattice_d2" (row distance of the next grid line / plane when
+ * the matrix is a 3-D lattice, else 0), "band_order", "band_lines";
+ * "blocks_per_cu", "nontemporal"; "plan_us" (wall time of plan creation, its
+ * analysis kernels included) and "plan_kib" (device memory the plan owns). */
 int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
                           int* value);
 

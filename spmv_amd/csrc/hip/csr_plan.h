@@ -140,6 +140,16 @@ struct spmv_hip_csr_plan {
   int32_t num_listed = 0;
   int nt_store = 0; // non-temporal y stores
   int plan_us = 0;  // wall time of plan creation (analysis kernels included)
+  // The arrays the plan analysed.  Every form beyond the plain gather kernels
+  // bakes their CONTENT in (offsets, masks, row lists, transposed map), so a
+  // launch with other arrays of the same shape would silently use the wrong
+  // structure: it is refused (SPMV_HIP_EINVAL).
+  const int32_t* rowptr0 = nullptr;
+  const int32_t* colind0 = nullptr;
+  bool structure_baked() const
+  {
+    return row_list || lx_lidx || lat_tab || slat_mask || t_ptr;
+  }
   // ROWBLOCK "LX" form: LDS-staged x windows + 16-bit local column indices
   // (csr_rowblock_lx_kernel); built by plan_create when most row blocks qualify
   uint16_t* lx_lidx = nullptr;

@@ -1031,6 +1031,8 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
   pl->num_cols = num_cols;
   pl->nnz = num_non_zeros;
   pl->symmetric = symmetric != 0;
+  pl->rowptr0 = rowptr;
+  pl->colind0 = colind;
   const double avg = num_rows > 0 ? (double)num_non_zeros / num_rows : 0.0;
   if (algo == SPMV_HIP_ALGO_AUTO) {
     // fewer entries than a quarter of the rows: most rows are empty, walk
@@ -1273,6 +1275,9 @@ int spmv_hip_csr_spmv_f64(spmv_hip_ctx* ctx, const spmv_hip_csr_plan* plan,
   // for: a mismatch would index out of bounds on the device
   SPMV_REQUIRE(num_rows == plan->num_rows && num_cols == plan->num_cols
                && num_non_zeros == plan->nnz);
+  // ... and the arrays it analysed, whenever their content is baked in
+  SPMV_REQUIRE(!plan->structure_baked()
+               || (rowptr == plan->rowptr0 && colind == plan->colind0));
   if (num_rows == 0)
     return SPMV_HIP_OK;
   SPMV_REQUIRE(in && out);
@@ -1318,6 +1323,9 @@ int spmv_hip_csr_spmv_f32(spmv_hip_ctx* ctx, const spmv_hip_csr_plan* plan,
   SPMV_REQUIRE(plan && plan->ctx == ctx);
   SPMV_REQUIRE(num_rows == plan->num_rows && num_cols == plan->num_cols
                && num_non_zeros == plan->nnz);
+  // ... and the arrays it analysed, whenever their content is baked in
+  SPMV_REQUIRE(!plan->structure_baked()
+               || (rowptr == plan->rowptr0 && colind == plan->colind0));
   if (num_rows == 0)
     return SPMV_HIP_OK;
   SPMV_REQUIRE(in && out);

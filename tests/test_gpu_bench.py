@@ -86,3 +86,39 @@ def test_bench_two_rank_rehearsal():
     assert one.returncode == 0, one.stderr[-3000:]
     k10 = _line(one.stdout)["cg_rel_residual"]["k10"]
     assert abs(d["cg_rel_residual"]["k10"] - k10) <= 1e-10 * k10
+
+
+def _gpu_count():
+    import torch
+    return torch.cuda.device_count()  # does not initialise the GPU
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs (RCCL refuses two "
+                    "ranks on one device); the 1-GPU boxes run the gloo rehearsal")
+def test_bench_two_gpus_over_rccl():
+    """The real transport: two ranks, one GPU each, RCCL send/recv for the halo
+    on the side stream and RCCL all-reduce (its own communicator) for the
+    scalars.  The line must prove itself: RCCL reports 2 ranks, the halo
+    self-check passed, and the run lands on the one-rank residual."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    res = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+         "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus",
+         "2", "--steps", "12", "--warmup", "2", "--grid", "128"],
+        capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    d = _line(res.stdout)
+    _check(d, 2, 12, 2)
+    assert d["rccl"]["nranks"] == 2 and d["rccl"]["separate_reduction_comm"]
+    assert d["halo_selfcheck"] == "ok"
+    assert [r["ghosts"] for r in d["ranks"]] == [128 * 128] * 2
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"),
+                          "--grid", "128", "--steps", "12", "--warmup", "2",
+                          "--no-cpu-baseline", "--no-extras"],
+                         capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-3000:]
+    k10 = _line(one.stdout)["cg_rel_residual"]["k10"]
+    assert abs(d["cg_rel_residual"]["k10"] - k10) <= 1e-10 * k10

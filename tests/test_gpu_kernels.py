@@ -172,9 +172,34 @@ def test_plan_mismatch_is_rejected(ctx):
         ctx.h, blk.plan, 63, 64, blk.nnz, blk.rowptr.ptr, blk.colind.ptr,
         blk.values.ptr, None, 1.0, dx.ptr, 0.0, dy.ptr, None, None)
     assert rc == -1  # SPMV_HIP_EINVAL, nothing launched
-    for b in (dx, dy):
+    # a plain (gather) plan reads colind at run time: other index arrays of the
+    # same shape are fine
+    other = ctx.upload(ci.astype(np.int32), np.int32)
+    rc = hip._lib.hip.spmv_hip_csr_spmv_f64(
+        ctx.h, blk.plan, 64, 64, blk.nnz, blk.rowptr.ptr, other.ptr,
+        blk.values.ptr, None, 1.0, dx.ptr, 0.0, dy.ptr, None, None)
+    assert rc == 0
+    blk.free()
+    # a plan that baked the structure in (here: the lattice form) must get the
+    # very arrays it analysed -- it would silently use the old structure
+    c2 = hip.Context(0)
+    c2.set_option("lat_min_nnz", 0)
+    blk = hip.CsrBlock(c2, 64, 64, rp, ci.astype(np.int32), va)
+    assert blk.get("lat") == 1
+    other2 = c2.upload(ci.astype(np.int32), np.int32)
+    dx2, dy2 = c2.zeros(64, np.float64), c2.zeros(64, np.float64)
+    rc = hip._lib.hip.spmv_hip_csr_spmv_f64(
+        c2.h, blk.plan, 64, 64, blk.nnz, blk.rowptr.ptr, other2.ptr,
+        blk.values.ptr, None, 1.0, dx2.ptr, 0.0, dy2.ptr, None, None)
+    assert rc == -1
+    rc = hip._lib.hip.spmv_hip_csr_spmv_f64(
+        c2.h, blk.plan, 64, 64, blk.nnz, blk.rowptr.ptr, blk.colind.ptr,
+        blk.values.ptr, None, 1.0, dx2.ptr, 0.0, dy2.ptr, None, None)
+    assert rc == 0
+    for b in (dx, dy, other, dx2, dy2, other2):
         b.free()
     blk.free()
+    c2.close()
 
 
 def test_unaligned_views(ctx):

@@ -454,3 +454,52 @@ def test_row_ghost_assembly_many_ranks_threaded(world, N, seed, sym):
                 assert np.array_equal(got["diagonal"], exp["diagonal"])
 
     ThreadWorld(world).run(rank_body)
+
+
+def test_plan_of_the_real_eight_way_512_cubed_slabs():
+    """BASELINE configs[4]: the 512^3 matrix row-partitioned over 8 ranks.  The
+    halo plan the host mirror builds for THAT partition (plan only, no matrix):
+    16,777,216 local rows per rank, ghost planes of 262,144 entries (one on the
+    edge ranks, two inside), indices up to 2^27 held exactly, every send list
+    one contiguous run (the direct-send case: no pack kernel) -- array by
+    array against oracle.l2g_plans (L2GMap.cpp:346-479)."""
+    from thread_world import ThreadWorld
+    n, world = 512, 8
+    N, plane = n ** 3, n * n
+    ranges = oracle.owner_ranges(world, N)
+    sizes = np.diff(ranges)
+    assert list(sizes) == [N // world] * world
+    ghosts = []
+    for r in range(world):
+        lo, hi = int(ranges[r]), int(ranges[r + 1])
+        g = []
+        if r > 0:
+            g.append(np.arange(lo - plane, lo, dtype=np.int64))
+        if r < world - 1:
+            g.append(np.arange(hi, hi + plane, dtype=np.int64))
+        ghosts.append(np.concatenate(g))
+    plans = oracle.l2g_plans(sizes, ghosts)
+
+    def rank_body(rank, comm):
+        for cm in (host.P2P_NONBLOCKING, host.P2P_BLOCKING):
+            m = host.L2GMap(comm, int(sizes[rank]), ghosts[rank], None, cm)
+            got, exp = m.plan(), plans[rank]
+            nn = 1 if rank in (0, world - 1) else 2
+            assert len(exp["neighbours"]) == nn
+            assert np.array_equal(got.neighbours, exp["neighbours"])
+            assert np.array_equal(got.send_count, exp["send_count"][:nn])
+            assert np.array_equal(got.recv_count, exp["recv_count"][:nn])
+            assert list(got.send_count) == [plane] * nn == list(got.recv_count)
+            assert np.array_equal(got.send_offset, exp["send_offset"][:nn + 1])
+            assert np.array_equal(got.recv_offset, exp["recv_offset"][:nn + 1])
+            assert np.array_equal(got.indexbuf, exp["indexbuf"])
+            assert got.indexbuf.dtype == np.int32 and len(got.indexbuf) == nn * plane
+            # what goes to the lower neighbour is my first plane, to the upper
+            # one my last plane: contiguous runs => sent straight from the vector
+            runs = np.split(got.indexbuf, nn)
+            for run in runs:
+                assert np.array_equal(run, np.arange(run[0], run[0] + plane))
+            assert got.packs is False
+            m.close()
+
+    ThreadWorld(world, timeout=120.0).run(rank_body)
