@@ -78,6 +78,9 @@ def parse():
                          "lattice structure gets it (experiments)")
     ap.add_argument("--no-lx", action="store_true",
                     help="with --no-lattice: the plain gather kernel")
+    ap.add_argument("--mixed-grid", type=int, default=216,
+                    help="grid of the mixed-precision CG sub-record (512 takes "
+                         "~15 s more)")
     ap.add_argument("--blas1-nt-min", type=int, default=None,
                     help="override the context option blas1_nt_min_elems "
                          "(experiments)")
@@ -278,6 +281,52 @@ def spmv_record(exec_, comm, host, _lib, n, symmetric, reps, lattice=True):
            "requested_bytes": req, "frac_requested": req / ms / 1e6 / HBM_PEAK_GBS}
     rec.update(plan_record(A))
     A.close()
+    return rec
+
+
+def mixed_precision_record(exec_, comm, host, _lib, n, rtol=1e-10, kmax=6000):
+    """the same solve (Gaussian right-hand side, to rtol) with
+    the fp64 values and with CgOptions::mixed -- iterations, wall time, the
+    TRUE final residual and the distance between the two solutions."""
+    import numpy as np
+    N = n ** 3
+    ctx = exec_.context
+    A = host.Matrix.create_poisson3d(comm, exec_, n, False, host.P2P_NONBLOCKING)
+    d_b, d_x = exec_.alloc(N), exec_.alloc(N)
+    _lib.call("spmv_hip_fill_gaussian_f64", ctx, N, 0, N, d_b, None)
+    ws = host.CgWorkspace(exec_)
+    rec = {"workload": f"poisson3d_{n}^3_csr_cg_to_{rtol:g}", "rows": N}
+    sols = {}
+    for name in ("fp64", "mixed"):
+        for rep in range(2):  # first pass: warm-up (fp32 copy, workspace)
+            exec_.synchronize()
+            t0 = time.perf_counter()
+            if name == "fp64":
+                k, hist, _, _ = host.cg_ex(comm, exec_, A, d_b, d_x, kmax, rtol,
+                                           ws, history=True)
+                st = {}
+            else:
+                k, hist, st = host.cg_mixed(comm, exec_, A, d_b, d_x, kmax, rtol,
+                                            replace_every=50, workspace=ws)
+            exec_.synchronize()
+            secs = time.perf_counter() - t0
+        sols[name] = exec_.copy_to_host(d_x, N)
+        rec[name] = {"iterations": k, "seconds": secs, "iters/s": k / secs,
+                     "recurrence_rel_residual": float(hist[-1] / hist[0])}
+        rec[name].update({k_: st[k_] for k_ in
+                          ("replacements", "true_rel_residual",
+                           "continuation_iterations",
+                           "final_true_rel_residual") if k_ in st})
+    rec["speedup"] = rec["fp64"]["seconds"] / rec["mixed"]["seconds"]
+    rec["x_rel_diff"] = float(np.linalg.norm(sols["mixed"] - sols["fp64"])
+                              / np.linalg.norm(sols["fp64"]))
+    rec["note"] = ("fp32 copy of the matrix values in the SpMV, fp64 vectors and "
+                   "arithmetic, residual replacement every 50 iterations; the "
+                   "Poisson values are exact in fp32, so the iteration differs "
+                   "from the fp64 one only at the replaced residuals")
+    ws.close()
+    A.close()
+    exec_.free(d_b), exec_.free(d_x)
     return rec
 
 
@@ -547,6 +596,9 @@ def main():
                                                      216, False, 200)
                 out["north_star_spmv"]["frac_of_8TBs"] = \
                     out["north_star_spmv"]["frac"]
+                # mixed-precision CG against pure fp64, to 1e-10
+                out["mixed_precision_cg"] = mixed_precision_record(
+                    exec_, self_comm, host, _lib, args.mixed_grid)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, n, N, host_cores)
         print(json.dumps(out), flush=True)

@@ -204,6 +204,17 @@ int spmv_hip_csr_spmv_f64(spmv_hip_ctx* ctx, const spmv_hip_csr_plan* plan,
                           const double* diagonal, double alpha,
                           const double* in, double beta, double* out,
                           double* dot_partials, void* stream);
+/* Mixed precision (device_executor.h:88-99 carries the float
+ * visitors): `values` in fp32 -- half the matrix bytes -- x, y and every
+ * product and sum in fp64.  General (non-symmetric) blocks; the same plan
+ * serves both value types.  With fp32-representable values (the Poisson
+ * matrix) the result equals spmv_hip_csr_spmv_f64 bit for bit. */
+int spmv_hip_csr_spmv_f32f64(spmv_hip_ctx* ctx, const spmv_hip_csr_plan* plan,
+                             int32_t num_rows, int32_t num_cols,
+                             int64_t num_non_zeros, const int32_t* rowptr,
+                             const int32_t* colind, const float* values,
+                             double alpha, const double* in, double beta,
+                             double* out, double* dot_partials, void* stream);
 int spmv_hip_csr_spmv_f32(spmv_hip_ctx* ctx, const spmv_hip_csr_plan* plan,
                           int32_t num_rows, int32_t num_cols,
                           int64_t num_non_zeros, const int32_t* rowptr,
@@ -300,6 +311,23 @@ int spmv_hip_cg_update_r_cs_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
 int spmv_hip_cg_update_xp_cs_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
                                  int64_t n, const double* r, double* x,
                                  double* p, void* stream);
+/* CG start (cg.cpp:39-50) in one pass: r = p = b, x = 0, partials of r.r in
+ * the workspace (then spmv_hip_cg_reduce_rr(0) installs rr[0]) */
+int spmv_hip_cg_init_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int64_t n,
+                         const double* b, double* r, double* p, double* x,
+                         void* stream);
+/* Mixed-precision CG support: fp32 copy of a value array;
+ * y += a x; residual replacement r = b - Ax (Ax given) with the partials of
+ * r.r left in the workspace (then spmv_hip_cg_reduce_rr(k) installs rr[k]).
+ * respect_done = 1 inside the loop (no-op once converged), 0 for the closing
+ * check of the true residual. */
+int spmv_hip_convert_f64_f32(spmv_hip_ctx* ctx, int64_t n, const double* in,
+                             float* out, void* stream);
+int spmv_hip_axpy_f64(spmv_hip_ctx* ctx, int64_t n, double a, const double* x,
+                      double* y, void* stream);
+int spmv_hip_cg_residual_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws,
+                             int respect_done, int64_t n, const double* b,
+                             const double* Ax, double* r, void* stream);
 /* convergence test on rr[k] then p = beta p + r  (cg.cpp:77-85) */
 int spmv_hip_cg_update_p_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int k,
                              int64_t n, const double* r, double* p,

@@ -227,6 +227,17 @@ int spmvh_petsc_rows_destroy(spmvh_petsc_rows* rows);
  * local-block SpMV kernel (time_spmv bit 0 -> *spmv_ms_total, *spmv_launches;
  * bit 2 switches CgOptions::consumer_reductions off). */
 typedef struct spmvh_cg_workspace spmvh_cg_workspace;
+/* cg with CgOptions::mixed (fp32 copy of the matrix values in the SpMV,
+ * residual replacement every `replace_every` iterations, fp64 correction
+ * solve if the true residual misses rtol).  out_stats = {spmv_ms_total,
+ * spmv_launches, replacements, true ||b-Ax||/||r0|| after the mixed loop,
+ * fp64 iterations of the correction solve, true relative residual at the
+ * end}.  rnorm_history holds up to history_capacity entries. */
+int spmvh_cg_mixed(spmvh_comm* comm, spmvh_exec* exec, spmvh_matrix* A,
+                   const double* b, double* x, int kmax, double rtol,
+                   int replace_every, int* num_its, double* rnorm_history,
+                   int history_capacity, spmvh_cg_workspace* ws, int time_spmv,
+                   double out_stats[6]);
 int spmvh_cg_workspace_create(spmvh_exec* exec, spmvh_cg_workspace** ws);
 int spmvh_cg_workspace_destroy(spmvh_cg_workspace* ws);
 /* create the timing events of a time_spmv solve of up to `iterations` steps

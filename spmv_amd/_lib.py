@@ -81,6 +81,13 @@ _PROTOS = {
     "spmv_hip_csr_plan_get": ([vp, C.c_char_p, P(C.c_int)], C.c_int),
     "spmv_hip_csr_spmv_f64": ([vp, vp, i32, i32, i64, vp, vp, vp, vp, f64, vp,
                                f64, vp, vp, vp], C.c_int),
+    "spmv_hip_csr_spmv_f32f64": ([vp, vp, i32, i32, i64, vp, vp, vp, f64, vp,
+                                  f64, vp, vp, vp], C.c_int),
+    "spmv_hip_convert_f64_f32": ([vp, i64, vp, vp, vp], C.c_int),
+    "spmv_hip_cg_init_f64": ([vp, vp, i64, vp, vp, vp, vp, vp], C.c_int),
+    "spmv_hip_axpy_f64": ([vp, i64, f64, vp, vp, vp], C.c_int),
+    "spmv_hip_cg_residual_f64": ([vp, vp, C.c_int, i64, vp, vp, vp, vp],
+                                 C.c_int),
     "spmv_hip_csr_spmv_f32": ([vp, vp, i32, i32, i64, vp, vp, vp, vp, f32, vp,
                                f32, vp, vp], C.c_int),
     "spmv_hip_gather_f64": ([vp, C.c_int, vp, vp, vp, vp], C.c_int),

@@ -549,6 +549,79 @@ __global__ __launch_bounds__(kBlock) void cg_update_xp_cs_kernel(
   }
 }
 
+// CG start (cg.cpp:39-50) in one pass over b: r = p = b, x0 = 0 (defined here
+// instead of relying on fresh pages) and the partials of r.r.
+template <bool NT>
+__global__ __launch_bounds__(kBlock) void cg_init_kernel(
+    int64_t n, const double* __restrict__ b, double* __restrict__ r,
+    double* __restrict__ p, double* __restrict__ x,
+    double* __restrict__ partials, int len)
+{
+  __shared__ double s_red[kBlock / 64];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const double v = b[i];
+    if constexpr (NT) {
+      __builtin_nontemporal_store(v, &r[i]);
+      __builtin_nontemporal_store(v, &p[i]);
+      __builtin_nontemporal_store(0.0, &x[i]);
+    } else {
+      r[i] = v;
+      p[i] = v;
+      x[i] = 0.0;
+    }
+    acc += v * v;
+  }
+  double s = block_sum(acc, s_red);
+  if (threadIdx.x == 0)
+    partials[blockIdx.x] = s;
+  clear_partials_tail(partials, len);
+}
+
+// ---- mixed-precision CG support -----------------------------
+// out = (float) in
+__global__ __launch_bounds__(kBlock) void convert_f64_f32_kernel(
+    int64_t n, const double* __restrict__ in, float* __restrict__ out)
+{
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (float)in[i];
+}
+
+// y += a x
+__global__ __launch_bounds__(kBlock) void axpy_kernel(
+    int64_t n, double a, const double* __restrict__ x, double* __restrict__ y)
+{
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    y[i] += a * x[i];
+}
+
+// residual replacement: r = b - Ax (Ax given), partials of r.r.  Inside the
+// CG loop it is a no-op once `done` is raised, like every other cg_* kernel;
+// the closing check after the loop passes sc = nullptr.
+__global__ __launch_bounds__(kBlock) void cg_residual_kernel(
+    int64_t n, const CgScalars* __restrict__ sc, const double* __restrict__ b,
+    const double* __restrict__ Ax, double* __restrict__ r,
+    double* __restrict__ partials, int len)
+{
+  __shared__ double s_red[kBlock / 64];
+  if (sc && sc->done)
+    return;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const double rv = b[i] - Ax[i];
+    r[i] = rv;
+    acc += rv * rv;
+  }
+  double s = block_sum(acc, s_red);
+  if (threadIdx.x == 0)
+    partials[blockIdx.x] = s;
+  clear_partials_tail(partials, len);
+}
+
 __global__ void cg_reset_kernel(CgScalars* sc, double rtol, double* rr,
                                 double* pAp, int kmax)
 {
@@ -696,6 +769,66 @@ int spmv_hip_dot_partial_f64(spmv_hip_ctx* ctx, int64_t n, const double* x,
   dot.partials = partials;
   dot.len = ctx->dot_blocks;
   SPMV_LAUNCH_NT(ctx, n, dot_partial_kernel, grid, spmv_stream(ctx, stream), n, x, y, dot);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_cg_init_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws, int64_t n,
+                         const double* b, double* r, double* p, double* x,
+                         void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(ws && ws->ctx == ctx && n >= 0 && (n == 0 || (b && r && p && x)));
+  int grid = spmv_grid_for(ctx, n, kBlock);
+  if (grid > ctx->dot_blocks)
+    grid = ctx->dot_blocks;
+  SPMV_LAUNCH_NT(ctx, n, cg_init_kernel, grid, spmv_stream(ctx, stream), n, b, r,
+                 p, x, ws->partials, ctx->dot_blocks);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_convert_f64_f32(spmv_hip_ctx* ctx, int64_t n, const double* in,
+                             float* out, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(n >= 0 && (n == 0 || (in && out)));
+  if (n == 0)
+    return SPMV_HIP_OK;
+  const int grid = spmv_grid_for(ctx, n, kBlock);
+  hipLaunchKernelGGL(convert_f64_f32_kernel, dim3(grid), dim3(kBlock), 0,
+                     spmv_stream(ctx, stream), n, in, out);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_axpy_f64(spmv_hip_ctx* ctx, int64_t n, double a, const double* x,
+                      double* y, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(n >= 0 && (n == 0 || (x && y)));
+  if (n == 0)
+    return SPMV_HIP_OK;
+  const int grid = spmv_grid_for(ctx, n, kBlock);
+  hipLaunchKernelGGL(axpy_kernel, dim3(grid), dim3(kBlock), 0,
+                     spmv_stream(ctx, stream), n, a, x, y);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_cg_residual_f64(spmv_hip_ctx* ctx, spmv_hip_cg_ws* ws,
+                             int respect_done, int64_t n, const double* b,
+                             const double* Ax, double* r, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(ws && ws->ctx == ctx && n >= 0 && (n == 0 || (b && Ax && r)));
+  int grid = spmv_grid_for(ctx, n, kBlock);
+  if (grid > ctx->dot_blocks)
+    grid = ctx->dot_blocks;
+  hipLaunchKernelGGL(cg_residual_kernel, dim3(grid), dim3(kBlock), 0,
+                     spmv_stream(ctx, stream), n,
+                     respect_done ? ws->sc : (const CgScalars*)nullptr, b, Ax, r,
+                     ws->partials, ctx->dot_blocks);
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;
 }

@@ -231,3 +231,7 @@ int spmv_lat_run_f64(const spmv_hip_csr_plan* pl, hipStream_t st,
 int spmv_lat_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st,
                      const int32_t* rowptr, const float* values, float alpha,
                      const float* in, float beta, float* out);
+int spmv_lat_run_f32f64(const spmv_hip_csr_plan* pl, hipStream_t st,
+                        const int32_t* rowptr, const float* values,
+                        double alpha, const double* in, double beta,
+                        double* out, DotOut dot);

@@ -45,19 +45,23 @@ namespace
 //   ALIGNED = values 16-B / colind 8|16-B aligned => wide loads
 //   XCD     = group consecutive row blocks per XCD (see xcd_group below)
 // ---------------------------------------------------------------------------
-template <typename T, int CH, bool NT, bool ALIGNED, bool DOT, bool XCD>
+//   TV      = type of `values`; T = type of x, y and of the arithmetic
+//             (TV = float, T = double: the mixed-precision SpMV)
+template <typename TV, typename T, int CH, bool NT, bool ALIGNED, bool DOT,
+          bool XCD>
 __global__ __launch_bounds__(kBlock) void csr_rowblock_kernel(
     int32_t num_rows, int64_t nnz, const int32_t* __restrict__ rowptr,
-    const int32_t* __restrict__ colind, const T* __restrict__ values, T alpha,
+    const int32_t* __restrict__ colind, const TV* __restrict__ values, T alpha,
     const T* __restrict__ in, T beta, T* __restrict__ out,
     DotOut dot, RowBlockOrder ord)
 {
-  constexpr int V = VecOf<T>::V;
+  constexpr int V = VecOf<TV>::V;
   constexpr int TILE = kBlock * CH * V;
-  using val_t = typename VecOf<T>::val_t;
-  using col_t = typename VecOf<T>::col_t;
+  using val_t = typename VecOf<TV>::val_t;
+  using col_t = typename VecOf<TV>::col_t;
+  typedef T prod_t __attribute__((ext_vector_type(V)));
 
-  __shared__ T s_prod[TILE];
+  __shared__ __attribute__((aligned(32))) T s_prod[TILE];
   __shared__ int32_t s_rowptr[kRows + 1];
   __shared__ double s_red[kBlock / 64];
 
@@ -124,23 +128,23 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_kernel(
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
           const int64_t j0 = base + (int64_t)(c * kBlock + t) * V;
-          val_t pv;
+          prod_t pv;
 #pragma unroll
           for (int e = 0; e < V; ++e)
-            pv[e] = (j0 + e < b) ? v[c][e] * xg[c][e] : T(0);
-          *reinterpret_cast<val_t*>(&s_prod[(c * kBlock + t) * V]) = pv;
+            pv[e] = (j0 + e < b) ? (T)v[c][e] * xg[c][e] : T(0);
+          *reinterpret_cast<prod_t*>(&s_prod[(c * kBlock + t) * V]) = pv;
         }
       } else {
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
           const int64_t j0 = base + (int64_t)(c * kBlock + t) * V;
-          val_t pv;
+          prod_t pv;
 #pragma unroll
           for (int e = 0; e < V; ++e) {
             const int64_t j = j0 + e;
-            pv[e] = (j < b) ? values[j] * in[colind[j]] : T(0);
+            pv[e] = (j < b) ? (T)values[j] * in[colind[j]] : T(0);
           }
-          *reinterpret_cast<val_t*>(&s_prod[(c * kBlock + t) * V]) = pv;
+          *reinterpret_cast<prod_t*>(&s_prod[(c * kBlock + t) * V]) = pv;
         }
       }
       // entries in [base, a) belong to earlier rows; no row of this block
@@ -553,11 +557,11 @@ __global__ __launch_bounds__(kBlock) void csr_scalar_kernel(
 // alpha*sum + beta*out[r].  With DOT the kernel emits the partials of
 // sum_r in[r] * (alpha*sum_r): the block's own share of p.Ap.
 // ---------------------------------------------------------------------------
-template <typename T, bool DOT>
+template <typename TV, typename T, bool DOT>
 __global__ __launch_bounds__(kBlock) void csr_rowlist_kernel(
     int32_t num_listed, const int32_t* __restrict__ rows,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
-    const T* __restrict__ values, T alpha, const T* __restrict__ in,
+    const TV* __restrict__ values, T alpha, const T* __restrict__ in,
     T* __restrict__ out, DotOut dot)
 {
   __shared__ double s_red[kBlock / 64];
@@ -567,7 +571,7 @@ __global__ __launch_bounds__(kBlock) void csr_rowlist_kernel(
     const int32_t i = rows[k];
     T sum = 0;
     for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j)
-      sum += values[j] * in[colind[j]];
+      sum += (T)values[j] * in[colind[j]];
     const T c = alpha * sum;
     out[i] = c + out[i];
     if constexpr (DOT)
@@ -623,19 +627,19 @@ __global__ __launch_bounds__(kBlock) void csr_vector_kernel(
     spmv_dot_epilogue(dot, dot_acc, s_red);
 }
 
-template <typename T, int CH, bool NT, bool ALIGNED, bool DOT>
+template <typename TV, typename T, int CH, bool NT, bool ALIGNED, bool DOT>
 int launch_rowblock_x(const spmv_hip_csr_plan* pl, hipStream_t st, int grid,
                       int nrb, const int32_t* rowptr, const int32_t* colind,
-                      const T* values, T alpha, const T* in, T beta, T* out,
+                      const TV* values, T alpha, const T* in, T beta, T* out,
                       DotOut dot)
 {
   const RowBlockOrder ord = pl->row_block_order(nrb);
   if (ord.xcd_group > 0)
-    hipLaunchKernelGGL((csr_rowblock_kernel<T, CH, NT, ALIGNED, DOT, true>),
+    hipLaunchKernelGGL((csr_rowblock_kernel<TV, T, CH, NT, ALIGNED, DOT, true>),
                        dim3(grid), dim3(kBlock), 0, st, pl->num_rows, pl->nnz,
                        rowptr, colind, values, alpha, in, beta, out, dot, ord);
   else
-    hipLaunchKernelGGL((csr_rowblock_kernel<T, CH, NT, ALIGNED, DOT, false>),
+    hipLaunchKernelGGL((csr_rowblock_kernel<TV, T, CH, NT, ALIGNED, DOT, false>),
                        dim3(grid), dim3(kBlock), 0, st, pl->num_rows, pl->nnz,
                        rowptr, colind, values, alpha, in, beta, out, dot, ord);
   SPMV_CHECK_LAUNCH();
@@ -690,7 +694,7 @@ int launch_rowblock(const spmv_hip_csr_plan* pl, hipStream_t st,
     return SPMV_HIP_OK;
   }
 #define SPMV_RB(CH, NT, AL)                                                    \
-  return launch_rowblock_x<T, CH, NT, AL, DOT>(pl, st, grid, nrb, rowptr,      \
+  return launch_rowblock_x<T, T, CH, NT, AL, DOT>(pl, st, grid, nrb, rowptr,   \
                                                colind, values, alpha, in,     \
                                                beta, out, dot)
   if (!al)
@@ -751,10 +755,10 @@ int launch_scalar(const spmv_hip_csr_plan* pl, hipStream_t st,
   return SPMV_HIP_OK;
 }
 
-template <typename T, bool DOT>
+template <typename TV, typename T, bool DOT>
 int launch_rowlist(const spmv_hip_csr_plan* pl, hipStream_t st,
                    const int32_t* rowptr, const int32_t* colind,
-                   const T* values, T alpha, const T* in, T beta, T* out,
+                   const TV* values, T alpha, const T* in, T beta, T* out,
                    DotOut dot)
 {
   const int n = pl->num_rows;
@@ -769,7 +773,7 @@ int launch_rowlist(const spmv_hip_csr_plan* pl, hipStream_t st,
     }
   }
   const int grid = spmv_grid_for(pl->ctx, pl->num_listed, kBlock);
-  hipLaunchKernelGGL((csr_rowlist_kernel<T, DOT>), dim3(grid), dim3(kBlock), 0,
+  hipLaunchKernelGGL((csr_rowlist_kernel<TV, T, DOT>), dim3(grid), dim3(kBlock), 0,
                      st, pl->num_listed, pl->row_list, rowptr, colind, values,
                      alpha, in, out, dot);
   SPMV_CHECK_LAUNCH();
@@ -789,7 +793,7 @@ int run_general(const spmv_hip_csr_plan* pl, hipStream_t st,
     return launch_scalar<T, DOT>(pl, st, rowptr, colind, values, alpha, in,
                                  beta, out, dot);
   case SPMV_HIP_ALGO_ROWLIST:
-    return launch_rowlist<T, DOT>(pl, st, rowptr, colind, values, alpha, in,
+    return launch_rowlist<T, T, DOT>(pl, st, rowptr, colind, values, alpha, in,
                                   beta, out, dot);
   default:
     return launch_rowblock<T, DOT>(pl, st, rowptr, colind, values, alpha, in,
@@ -933,6 +937,39 @@ int build_lx(spmv_hip_csr_plan* pl, const int32_t* rowptr,
   // order once it does not (512^3)
   pl->xcd_group = pl->nontemporal ? 16 : 0;
   return SPMV_HIP_OK;
+}
+
+// Mixed precision: fp32 `values`, fp64 vectors and arithmetic.
+// General blocks only; lattice form, plain row blocks, row list.
+template <bool DOT>
+int run_mixed(const spmv_hip_csr_plan* pl, hipStream_t st,
+                     const int32_t* rowptr, const int32_t* colind,
+                     const float* values, double alpha, const double* in,
+                     double beta, double* out, DotOut dot)
+{
+  if (pl->algo == SPMV_HIP_ALGO_ROWLIST)
+    return launch_rowlist<float, double, DOT>(pl, st, rowptr, colind, values,
+                                              alpha, in, beta, out, dot);
+  if (pl->algo != SPMV_HIP_ALGO_ROWBLOCK)
+    return SPMV_HIP_ENOTSUP;
+  if (pl->lat && aligned16(values))
+    return spmv_lat_run_f32f64(pl, st, rowptr, values, alpha, in, beta, out,
+                               DOT ? dot : DotOut());
+  const int nrb = (pl->num_rows + kRows - 1) / kRows;
+  int grid = pl->ctx->num_cus * pl->blocks_per_cu;
+  if (grid > pl->ctx->dot_blocks)
+    grid = pl->ctx->dot_blocks;
+  if (grid > nrb)
+    grid = nrb;
+  if (grid < 1)
+    grid = 1;
+  if (grid >= 8)
+    grid -= grid % 8;
+  if (aligned16(values) && aligned16(colind))
+    return launch_rowblock_x<float, double, 1, false, true, DOT>(
+        pl, st, grid, nrb, rowptr, colind, values, alpha, in, beta, out, dot);
+  return launch_rowblock_x<float, double, 1, false, false, DOT>(
+      pl, st, grid, nrb, rowptr, colind, values, alpha, in, beta, out, dot);
 }
 
 } // namespace
@@ -1310,6 +1347,43 @@ int spmv_hip_csr_spmv_f64(spmv_hip_ctx* ctx, const spmv_hip_csr_plan* plan,
   }
   return run_general<double, false>(plan, st, rowptr, colind, values, alpha, in,
                                     beta, out, DotOut());
+}
+
+int spmv_hip_csr_spmv_f32f64(spmv_hip_ctx* ctx, const spmv_hip_csr_plan* plan,
+                             int32_t num_rows, int32_t num_cols,
+                             int64_t num_non_zeros, const int32_t* rowptr,
+                             const int32_t* colind, const float* values,
+                             double alpha, const double* in, double beta,
+                             double* out, double* dot_partials, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(plan && plan->ctx == ctx && !plan->symmetric);
+  SPMV_REQUIRE(num_rows == plan->num_rows && num_cols == plan->num_cols
+               && num_non_zeros == plan->nnz);
+  SPMV_REQUIRE(!plan->structure_baked()
+               || (rowptr == plan->rowptr0 && colind == plan->colind0));
+  if (num_rows == 0)
+    return SPMV_HIP_OK;
+  SPMV_REQUIRE(in && out);
+  hipStream_t st = spmv_stream(ctx, stream);
+  if (num_non_zeros == 0) {
+    SPMV_REQUIRE(dot_partials == nullptr);
+    const int grid = spmv_grid_for(ctx, num_rows, kBlock);
+    hipLaunchKernelGGL((scale_kernel<double>), dim3(grid), dim3(kBlock), 0, st,
+                       (int64_t)num_rows, beta, out);
+    SPMV_CHECK_LAUNCH();
+    return SPMV_HIP_OK;
+  }
+  SPMV_REQUIRE(rowptr && colind && values);
+  if (dot_partials) {
+    DotOut dot;
+    dot.partials = dot_partials;
+    dot.len = ctx->dot_blocks;
+    return run_mixed<true>(plan, st, rowptr, colind, values, alpha, in, beta,
+                           out, dot);
+  }
+  return run_mixed<false>(plan, st, rowptr, colind, values, alpha, in, beta,
+                          out, DotOut());
 }
 
 int spmv_hip_csr_spmv_f32(spmv_hip_ctx* ctx, const spmv_hip_csr_plan* plan,

@@ -153,17 +153,20 @@ __device__ __forceinline__ LatBlock lat_block(const RowBlockOrder& ord, int it,
   return blk;
 }
 
-template <typename T, bool DOT, bool NT>
+// TV = type of `values` (what is streamed), T = type of x, y and of all the
+// arithmetic.  TV = float with T = double is the mixed-precision SpMV (SURVEY
+// 8f n3): half the matrix bytes, every product and sum still in fp64.
+template <typename TV, typename T, bool DOT, bool NT>
 __global__ __launch_bounds__(kBlock) void csr_lattice_kernel(
     int32_t num_rows, int32_t num_cols, int64_t nnz,
-    const int32_t* __restrict__ rowptr, const T* __restrict__ values,
+    const int32_t* __restrict__ rowptr, const TV* __restrict__ values,
     const int32_t* __restrict__ tab, const uint8_t* __restrict__ mask, T alpha,
     const T* __restrict__ in, T beta, T* __restrict__ out, DotOut dot,
     RowBlockOrder ord)
 {
-  constexpr int V = 16 / (int)sizeof(T);
-  constexpr int SLOT = kLatSlotBytes / (int)sizeof(T); // entries per slot
-  __shared__ __attribute__((aligned(16))) T s_val[kLatSlots * SLOT];
+  constexpr int V = 16 / (int)sizeof(TV);
+  constexpr int SLOT = kLatSlotBytes / (int)sizeof(TV); // entries per slot
+  __shared__ __attribute__((aligned(16))) TV s_val[kLatSlots * SLOT];
   __shared__ double s_red[kBlock / 64];
 
   const int t = threadIdx.x;
@@ -176,8 +179,8 @@ __global__ __launch_bounds__(kBlock) void csr_lattice_kernel(
   LatBlock nxt = lat_block(ord, it + stride, num_slots, num_rows, rowptr,
                            stride, &itn);
   if (cur.rb >= 0 && cur.b > cur.a)
-    lat_issue_dma<T, NT>(values, nnz, cur.a & ~(int64_t)(V - 1), cur.b, s_val,
-                         t);
+    lat_issue_dma<TV, NT>(values, nnz, cur.a & ~(int64_t)(V - 1), cur.b, s_val,
+                          t);
   LatRegs<T> gA = lat_loads<T, DOT>(cur, t, num_rows, num_cols, rowptr, tab,
                                     mask, in, beta, out);
   LatRegs<T> gB;
@@ -193,8 +196,8 @@ __global__ __launch_bounds__(kBlock) void csr_lattice_kernel(
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
     __syncthreads();
     if (nxt.rb >= 0 && nxt.b > nxt.a)
-      lat_issue_dma<T, NT>(values, nnz, nxt.a & ~(int64_t)(V - 1), nxt.b,
-                           s_val + (slot ^ 1) * SLOT, t);
+      lat_issue_dma<TV, NT>(values, nnz, nxt.a & ~(int64_t)(V - 1), nxt.b,
+                            s_val + (slot ^ 1) * SLOT, t);
     gn = lat_loads<T, DOT>(nxt, t, num_rows, num_cols, rowptr, tab, mask, in,
                            beta, out);
     // the block after the next one (order table, row pointer: dependent scalar
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(kBlock) void csr_lattice_kernel(
 #pragma unroll
       for (int k = 0; k < kLatMaxOff; ++k) {
         const int pk = __popc(g.m & ((1u << k) - 1u));
-        v[k] = s_val[min(rel + pk, kLatSlots * SLOT - 1)];
+        v[k] = (T)s_val[min(rel + pk, kLatSlots * SLOT - 1)];
       }
       T sum = 0;
 #pragma unroll
@@ -365,9 +368,9 @@ __global__ __launch_bounds__(kBlock) void lat_build_kernel(
   }
 }
 
-template <typename T, bool DOT>
+template <typename TV, typename T, bool DOT>
 int lat_launch(const spmv_hip_csr_plan* pl, hipStream_t st,
-               const int32_t* rowptr, const T* values, T alpha, const T* in,
+               const int32_t* rowptr, const TV* values, T alpha, const T* in,
                T beta, T* out, DotOut dot)
 {
   const int nrb = (pl->num_rows + kRows - 1) / kRows;
@@ -388,12 +391,12 @@ int lat_launch(const spmv_hip_csr_plan* pl, hipStream_t st,
     ord.num_slots = pl->order_slots;
   }
   if (pl->nontemporal)
-    hipLaunchKernelGGL((csr_lattice_kernel<T, DOT, true>), dim3(grid),
+    hipLaunchKernelGGL((csr_lattice_kernel<TV, T, DOT, true>), dim3(grid),
                        dim3(kBlock), 0, st, pl->num_rows, pl->num_cols, pl->nnz,
                        rowptr, values, pl->lat_tab, pl->lat_mask, alpha, in,
                        beta, out, dot, ord);
   else
-    hipLaunchKernelGGL((csr_lattice_kernel<T, DOT, false>), dim3(grid),
+    hipLaunchKernelGGL((csr_lattice_kernel<TV, T, DOT, false>), dim3(grid),
                        dim3(kBlock), 0, st, pl->num_rows, pl->num_cols, pl->nnz,
                        rowptr, values, pl->lat_tab, pl->lat_mask, alpha, in,
                        beta, out, dot, ord);
@@ -491,16 +494,28 @@ int spmv_lat_run_f64(const spmv_hip_csr_plan* pl, hipStream_t st,
                      const double* in, double beta, double* out, DotOut dot)
 {
   if (dot.partials)
-    return lat_launch<double, true>(pl, st, rowptr, values, alpha, in, beta,
-                                    out, dot);
-  return lat_launch<double, false>(pl, st, rowptr, values, alpha, in, beta, out,
-                                   dot);
+    return lat_launch<double, double, true>(pl, st, rowptr, values, alpha, in,
+                                            beta, out, dot);
+  return lat_launch<double, double, false>(pl, st, rowptr, values, alpha, in,
+                                           beta, out, dot);
+}
+
+int spmv_lat_run_f32f64(const spmv_hip_csr_plan* pl, hipStream_t st,
+                        const int32_t* rowptr, const float* values,
+                        double alpha, const double* in, double beta,
+                        double* out, DotOut dot)
+{
+  if (dot.partials)
+    return lat_launch<float, double, true>(pl, st, rowptr, values, alpha, in,
+                                           beta, out, dot);
+  return lat_launch<float, double, false>(pl, st, rowptr, values, alpha, in,
+                                          beta, out, dot);
 }
 
 int spmv_lat_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st,
                      const int32_t* rowptr, const float* values, float alpha,
                      const float* in, float beta, float* out)
 {
-  return lat_launch<float, false>(pl, st, rowptr, values, alpha, in, beta, out,
-                                  DotOut());
+  return lat_launch<float, float, false>(pl, st, rowptr, values, alpha, in, beta,
+                                         out, DotOut());
 }

@@ -1,6 +1,7 @@
 // C facade over the host mirror: see include/spmv_host_c.h.
 #include "spmv_host_c.h"
 
+#include <algorithm>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -818,6 +819,40 @@ int spmvh_cg_workspace_reserve_timing(spmvh_cg_workspace* ws, int iterations)
   return guarded([&] {
     require(ws, "NULL argument");
     ws->ws->reserve_timing(iterations);
+  });
+}
+
+int spmvh_cg_mixed(spmvh_comm* comm, spmvh_exec* exec, spmvh_matrix* A,
+                   const double* b, double* x, int kmax, double rtol,
+                   int replace_every, int* num_its, double* rnorm_history,
+                   int history_capacity, spmvh_cg_workspace* ws, int time_spmv,
+                   double out_stats[6])
+{
+  return guarded([&] {
+    require(comm && exec && A && num_its, "NULL argument");
+    std::vector<double> hist;
+    CgOptions opt;
+    opt.time_spmv = (time_spmv & 1) != 0;
+    opt.consumer_reductions = (time_spmv & 4) == 0;
+    opt.mixed = true;
+    opt.replace_every = replace_every;
+    CgStats st;
+    *num_its = cg(*comm->comm, *exec->hip, *A->A, b, x, kmax, rtol,
+                  rnorm_history ? &hist : nullptr, &opt, &st,
+                  ws ? ws->ws.get() : nullptr);
+    if (rnorm_history)
+      std::copy(hist.begin(),
+                hist.begin()
+                    + std::min<size_t>(hist.size(), (size_t)history_capacity),
+                rnorm_history);
+    if (out_stats) {
+      out_stats[0] = st.spmv_ms_total;
+      out_stats[1] = st.spmv_launches;
+      out_stats[2] = st.replacements;
+      out_stats[3] = st.true_rel_residual;
+      out_stats[4] = st.continuation_iterations;
+      out_stats[5] = st.final_true_rel_residual;
+    }
   });
 }
 

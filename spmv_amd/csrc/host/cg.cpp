@@ -155,13 +155,21 @@ int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
   throw_on_error(spmv_hip_cg_ws_partials(w.ws, &partials),
                  "spmv_hip_cg_ws_partials");
 
-  // x0 = 0 and the ghost tail of p are defined here instead of relying on
-  // fresh pages; r = p = b (cg.cpp:44-45)
-  exec.memset<double>(w.x, 0, N_padded);
-  exec.memset<double>(w.p, 0, N_padded);
+  // The iterate lives in the caller's x (no copy at the end, cg.cpp:89) unless
+  // the mixed mode needs its halo (then in the padded work vector).
+  const bool mixed = opt.mixed && A.enable_mixed();
+  const bool x_aligned = (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
+  double* const xi = (mixed || !x_aligned) ? w.x : x;
+  // r = p = b, x0 = 0, partials of r.r: one pass (cg.cpp:41-47; x0 and the
+  // ghost tails are defined here instead of relying on fresh pages)
+  if (N_padded > M) {
+    exec.memset<double>(w.p + M, 0, N_padded - M);
+    if (mixed)
+      exec.memset<double>(w.x + M, 0, N_padded - M);
+  }
   exec.memset<double>(w.dot2, 0, len);
-  exec.copy<double>(w.r, b, M);
-  exec.copy<double>(w.p, b, M);
+  throw_on_error(spmv_hip_cg_init_f64(ctx, w.ws, M, b, w.r, w.p, xi, nullptr),
+                 "spmv_hip_cg_init_f64");
   w.flags[0] = 0;
   w.flags[1] = -1;
 
@@ -174,13 +182,17 @@ int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
   };
 
   // rnorm0 (cg.cpp:47-50)
-  throw_on_error(spmv_hip_cg_dot_rr_f64(ctx, w.ws, M, w.r, nullptr),
-                 "spmv_hip_cg_dot_rr_f64");
   throw_on_error(spmv_hip_cg_reduce_rr(ctx, w.ws, 0, nullptr),
                  "spmv_hip_cg_reduce_rr");
   comm.allreduce_sum(slot(true, 0), 1, w.stream);
 
   const bool consume = opt.consumer_reductions && comm.size() == 1;
+  // whatever happens below, leave the matrix in fp64 mode
+  struct MixedGuard {
+    const Matrix<double>& A;
+    ~MixedGuard() { A.use_mixed(false); }
+  } mixed_guard{A};
+  int replacements = 0;
   // Timing events live in the workspace: a solve that reuses one (the
   // benchmark, after its warm-up) creates nothing inside its timed region.
   std::vector<void*>& timing_ev = w.timing_ev;
@@ -199,7 +211,42 @@ int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
     }
     // cg.cpp:60,63: Ap = A p with the p.Ap partials produced by the SpMV
     // kernels themselves (local block's share + remote block's share)
-    if (consume) {
+    const bool replace
+        = mixed && opt.replace_every > 0 && k % opt.replace_every == 0;
+    A.use_mixed(mixed);
+    if (replace) {
+      // residual replacement: the usual iteration in the reference's grouping
+      // (x first), then r := b - A x with the fp64 values instead of the
+      // recurrence, rr[k] from it, p from both
+      const bool fused = A.mult_dot(w.p, w.Ap, partials, w.dot2, ev1);
+      if (fused) {
+        throw_on_error(spmv_hip_cg_reduce_pAp2(ctx, w.ws, k, w.dot2, nullptr),
+                       "spmv_hip_cg_reduce_pAp2");
+      } else {
+        throw_on_error(spmv_hip_dot_partial_f64(ctx, M, w.p, w.Ap, partials,
+                                                nullptr),
+                       "spmv_hip_dot_partial_f64");
+        throw_on_error(spmv_hip_cg_reduce_pAp(ctx, w.ws, k, nullptr),
+                       "spmv_hip_cg_reduce_pAp");
+      }
+      comm.allreduce_sum(slot(false, k), 1, w.stream);
+      throw_on_error(spmv_hip_cg_update_xr_f64(ctx, w.ws, k, M, w.p, w.Ap, xi,
+                                               w.r, nullptr),
+                     "spmv_hip_cg_update_xr_f64");
+      A.use_mixed(false);
+      col_l2g->update(xi);
+      A.mult(xi, w.Ap);
+      throw_on_error(spmv_hip_cg_residual_f64(ctx, w.ws, 1, M, b, w.Ap, w.r,
+                                              nullptr),
+                     "spmv_hip_cg_residual_f64");
+      throw_on_error(spmv_hip_cg_reduce_rr(ctx, w.ws, k, nullptr),
+                     "spmv_hip_cg_reduce_rr");
+      comm.allreduce_sum(slot(true, k), 1, w.stream);
+      throw_on_error(spmv_hip_cg_update_p_f64(ctx, w.ws, k, M, w.r, w.p,
+                                              nullptr),
+                     "spmv_hip_cg_update_p_f64");
+      ++replacements;
+    } else if (consume) {
       // one rank: the update kernels add the partials themselves
       const bool fused = A.mult_dot(w.p, w.Ap, partials, w.dot2, ev1);
       if (!fused)
@@ -210,7 +257,7 @@ int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
                                                  fused ? w.dot2 : nullptr,
                                                  nullptr),
                      "spmv_hip_cg_update_r_cs_f64");
-      throw_on_error(spmv_hip_cg_update_xp_cs_f64(ctx, w.ws, k, M, w.r, w.x,
+      throw_on_error(spmv_hip_cg_update_xp_cs_f64(ctx, w.ws, k, M, w.r, xi,
                                                   w.p, nullptr),
                      "spmv_hip_cg_update_xp_cs_f64");
     } else {
@@ -234,10 +281,10 @@ int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
       throw_on_error(spmv_hip_cg_reduce_rr(ctx, w.ws, k, nullptr),
                      "spmv_hip_cg_reduce_rr");
     }
-    if (!consume) {
+    if (!consume && !replace) {
       comm.allreduce_sum(slot(true, k), 1, w.stream); // cg.cpp:75
       // x += alpha p ; stop test ; p = beta p + r   (cg.cpp:69,77-85)
-      throw_on_error(spmv_hip_cg_update_xp_f64(ctx, w.ws, k, M, w.r, w.x, w.p,
+      throw_on_error(spmv_hip_cg_update_xp_f64(ctx, w.ws, k, M, w.r, xi, w.p,
                                                nullptr),
                      "spmv_hip_cg_update_xp_f64");
     }
@@ -264,7 +311,24 @@ int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
   std::vector<double> rr(kmax + 1, 0.0);
   throw_on_error(spmv_hip_cg_ws_read_async(w.ws, w.flags, rr.data(), nullptr),
                  "spmv_hip_cg_ws_read_async");
-  exec.copy<double>(x, w.x, M); // cg.cpp:89
+  double true_rr = -1.0;
+  if (mixed) {
+    // the true residual of what the mixed loop produced, with the fp64 values
+    A.use_mixed(false);
+    col_l2g->update(xi);
+    A.mult(xi, w.Ap);
+    throw_on_error(spmv_hip_cg_residual_f64(ctx, w.ws, 0, M, b, w.Ap, w.r,
+                                            nullptr),
+                   "spmv_hip_cg_residual_f64");
+    throw_on_error(spmv_hip_reduce_partials_f64(ctx, partials, w.dot2, nullptr),
+                   "spmv_hip_reduce_partials_f64");
+    comm.allreduce_sum(w.dot2, 1, w.stream);
+    throw_on_error(spmv_hip_copy_d2h_async(ctx, &true_rr, w.dot2,
+                                           sizeof(double), nullptr),
+                   "spmv_hip_copy_d2h_async");
+  }
+  if (xi != x)
+    exec.copy<double>(x, xi, M); // cg.cpp:89
   exec.synchronize_stream(w.stream);
 
   if (stats) {
@@ -298,6 +362,56 @@ int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
     rnorm_history->resize(k_final + 1);
     for (int j = 0; j <= k_final; ++j)
       (*rnorm_history)[j] = std::sqrt(rr[j]);
+  }
+  if (mixed) {
+    const double rnorm0 = std::sqrt(rr[0]);
+    const double true_rel = rnorm0 > 0 ? std::sqrt(true_rr) / rnorm0 : 0.0;
+    int extra = 0;
+    double final_rel = true_rel;
+    if (true_rel >= rtol && rtol > 0 && k_final < kmax) {
+      // The fp32 values took the iteration as far as they could: solve the
+      // correction equation A d = b - A x with the fp64 values (w.r still
+      // holds that residual) and add it.  A fresh workspace: this one's
+      // vectors are the operands.
+      A.use_mixed(false);
+      double* d = exec.alloc<double>(M);
+      double* rhs = exec.alloc<double>(M);
+      exec.copy<double>(rhs, w.r, M);
+      exec.synchronize_stream(w.stream);
+      exec.set_stream(guard.prev);
+      std::vector<double> h2;
+      CgOptions o2 = opt;
+      o2.mixed = false;
+      o2.time_spmv = false;
+      try {
+        extra = cg(comm, exec, A, rhs, d, kmax - k_final, rtol / true_rel, &h2,
+                   &o2, nullptr, nullptr);
+        throw_on_error(spmv_hip_axpy_f64(ctx, M, 1.0, d, x, nullptr),
+                       "spmv_hip_axpy_f64");
+        exec.synchronize();
+      } catch (...) {
+        exec.free(d);
+        exec.free(rhs);
+        throw;
+      }
+      exec.free(d);
+      exec.free(rhs);
+      if (!h2.empty() && rnorm0 > 0)
+        final_rel = h2.back() / rnorm0;
+      if (rnorm_history)
+        for (size_t j = 1; j < h2.size(); ++j)
+          rnorm_history->push_back(h2[j]);
+    }
+    if (stats) {
+      // iterations enqueued past the converged one were no-ops on the device
+      stats->replacements
+          = opt.replace_every > 0 ? k_final / opt.replace_every : 0;
+      (void)replacements;
+      stats->true_rel_residual = true_rel;
+      stats->continuation_iterations = extra;
+      stats->final_true_rel_residual = final_rel;
+    }
+    return k_final + extra;
   }
   return k_final;
 }

@@ -53,11 +53,27 @@ struct CgOptions {
   // than one rank (or when switched off) every dot product is finished by a
   // single-workgroup reducer kernel (5 launches per iteration).
   bool consumer_reductions = true;
+  // Mixed precision: the SpMV of every iteration streams an
+  // fp32 copy of the matrix values (half the matrix bytes; x, p, r and all
+  // arithmetic stay fp64).  Every `replace_every` iterations the recurrence
+  // residual is replaced by the true one, r = b - A x, computed with the fp64
+  // values (residual replacement keeps the single Krylov sequence); when the
+  // loop ends the true residual is checked once more and, if it misses rtol,
+  // the correction equation A d = r is solved with the fp64 values and added
+  // (CgStats reports both).  General storage only; ignored for symmetric.
+  bool mixed = false;
+  int replace_every = 50;
 };
 
 struct CgStats {
   int spmv_launches = 0;    // local-block SpMV kernels timed
   double spmv_ms_total = 0; // sum of their durations (HIP events, same stream)
+  // CgOptions::mixed
+  int replacements = 0;             // residual replacements inside the loop
+  double true_rel_residual = -1.0;  // ||b - A x|| / ||r_0|| with fp64 values,
+                                    // at the end of the mixed loop
+  int continuation_iterations = 0;  // fp64 iterations of the correction solve
+  double final_true_rel_residual = -1.0; // ... after it (= the above if none)
 };
 
 // Unpreconditioned CG from x0 = 0 (spmv/cg.cpp:21-98).  `b` and `x` are

@@ -93,6 +93,23 @@ void CSRSpMV<T>::tune(const char* key, int value) const
 }
 
 template <typename T>
+void CSRSpMV<T>::run_mixed(int32_t num_rows, int32_t num_cols,
+                           int64_t num_non_zeros, const int32_t* rowptr,
+                           const int32_t* colind, const float* values32, T alpha,
+                           T* in, T beta, T* out, double* dot_partials,
+                           const HipExecutor& exec) const
+{
+  if constexpr (std::is_same<T, double>::value)
+    throw_on_error(spmv_hip_csr_spmv_f32f64(exec.context(), plan(), num_rows,
+                                            num_cols, num_non_zeros, rowptr,
+                                            colind, values32, alpha, in, beta,
+                                            out, dot_partials, nullptr),
+                   "spmv_hip_csr_spmv_f32f64");
+  else
+    throw std::runtime_error("CSRSpMV<float>::run_mixed is not available");
+}
+
+template <typename T>
 int CSRSpMV<T>::query(const char* key) const
 {
   int v = 0;
@@ -182,9 +199,27 @@ CSRMatrix<T>::~CSRMatrix()
     this->_exec->free(_rowptr);
     this->_exec->free(_colind);
     this->_exec->free(_values);
+    this->_exec->free(_values32);
     this->_exec->free(this->_diagonal);
   } catch (...) {
   }
+}
+
+template <typename T>
+void CSRMatrix<T>::enable_mixed() const
+{
+  if (_values32 || this->_symmetric || this->_num_non_zeros == 0
+      || !std::is_same<T, double>::value)
+    return;
+  auto* hip = dynamic_cast<const HipExecutor*>(this->_exec.get());
+  if (!hip)
+    return;
+  _values32 = this->_exec->template alloc<float>(this->_num_non_zeros);
+  if constexpr (std::is_same<T, double>::value)
+    throw_on_error(spmv_hip_convert_f64_f32(hip->context(),
+                                            this->_num_non_zeros, _values,
+                                            _values32, nullptr),
+                   "spmv_hip_convert_f64_f32");
 }
 
 template <typename T>
@@ -197,6 +232,13 @@ size_t CSRMatrix<T>::format_size() const // csr_matrix.cpp:72-78
 template <typename T>
 void CSRMatrix<T>::mult(T alpha, T* in, T beta, T* out) const
 {
+  if (_mixed_on && this->_num_non_zeros > 0) {
+    auto* hip = dynamic_cast<const HipExecutor*>(this->_exec.get());
+    _op.run_mixed(this->_num_rows, this->_num_cols, this->_num_non_zeros,
+                  _rowptr, _colind, _values32, alpha, in, beta, out, nullptr,
+                  *hip);
+    return;
+  }
   if (this->_num_non_zeros > 0 || this->_diagonal != nullptr) // :85
     this->_exec->spmv_run(_op, *this, alpha, in, beta, out);
 }
@@ -219,8 +261,13 @@ bool CSRMatrix<T>::mult_dot(T alpha, T* in, T beta, T* out,
                     out, dot_partials, *hip);
     return true;
   }
-  _op.run_dot(this->_num_rows, this->_num_cols, this->_num_non_zeros, _rowptr,
-              _colind, _values, alpha, in, beta, out, dot_partials, *hip);
+  if (_mixed_on)
+    _op.run_mixed(this->_num_rows, this->_num_cols, this->_num_non_zeros,
+                  _rowptr, _colind, _values32, alpha, in, beta, out,
+                  dot_partials, *hip);
+  else
+    _op.run_dot(this->_num_rows, this->_num_cols, this->_num_non_zeros, _rowptr,
+                _colind, _values, alpha, in, beta, out, dot_partials, *hip);
   return true;
 }
 

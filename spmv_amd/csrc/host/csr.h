@@ -62,6 +62,14 @@ public:
   // launch-shape knob of the plan (spmv_hip_csr_plan_set); throws on an
   // unknown key
   void tune(const char* key, int value) const;
+  // Mixed precision (the float visitors of
+  // device_executor.h:88-99): `values32` is an fp32 copy of the block's values,
+  // x / y / arithmetic stay fp64.  General blocks; dot_partials may be NULL.
+  void run_mixed(int32_t num_rows, int32_t num_cols, int64_t num_non_zeros,
+                 const int32_t* rowptr, const int32_t* colind,
+                 const float* values32, T alpha, T* in, T beta, T* out,
+                 double* dot_partials, const HipExecutor& exec) const;
+
   // read-only counterpart (spmv_hip_csr_plan_get): which form the plan took,
   // what it cost ("lat", "lx", "slat", "sym_det", "plan_us", "plan_kib", ...)
   int query(const char* key) const;
@@ -130,6 +138,13 @@ public:
   // cannot fuse (symmetric or empty) and nothing was launched.
   bool mult_dot(T alpha, T* in, T beta, T* out, double* dot_partials) const;
 
+  // Mixed precision: build (once) the fp32 copy of the values; afterwards
+  // use_mixed(true) makes mult / mult_dot stream that copy instead (x, y and
+  // all arithmetic stay fp64).  General fp64 blocks only; a no-op elsewhere.
+  void enable_mixed() const;
+  void use_mixed(bool on) const { _mixed_on = on && _values32 != nullptr; }
+  bool mixed_in_use() const { return _mixed_on; }
+
   const int32_t* rowptr() const { return _rowptr; }
   const int32_t* colind() const { return _colind; }
   const T* values() const { return _values; }
@@ -141,6 +156,8 @@ private:
   int32_t* _rowptr = nullptr;
   int32_t* _colind = nullptr;
   T* _values = nullptr;
+  mutable float* _values32 = nullptr; // enable_mixed()
+  mutable bool _mixed_on = false;
   CSRSpMV<T> _op;
 };
 

@@ -154,6 +154,27 @@ void Matrix<T>::spmv_sym_overlap(T* x, T* y) const
 }
 
 template <typename T>
+bool Matrix<T>::enable_mixed() const
+{
+  if (_symmetric || !std::is_same<T, double>::value)
+    return false;
+  if (_mat_local)
+    _mat_local->enable_mixed();
+  if (_mat_remote)
+    _mat_remote->enable_mixed();
+  return true;
+}
+
+template <typename T>
+void Matrix<T>::use_mixed(bool on) const
+{
+  if (_mat_local)
+    _mat_local->use_mixed(on);
+  if (_mat_remote)
+    _mat_remote->use_mixed(on);
+}
+
+template <typename T>
 bool Matrix<T>::mult_dot(T* x, T* y, double* dot_local, double* dot_remote,
                          void* ev_local_done) const
 {

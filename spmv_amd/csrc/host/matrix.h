@@ -59,6 +59,13 @@ public:
   bool mult_dot(T* x, T* y, double* dot_local, double* dot_remote,
                 void* ev_local_done = nullptr) const;
 
+  // Mixed precision: enable_mixed() builds fp32 copies of the
+  // blocks' values (general storage only, returns false otherwise);
+  // use_mixed(true) then makes mult / mult_dot stream those, x, y and the
+  // arithmetic staying fp64.  cg() switches it per SpMV.
+  bool enable_mixed() const;
+  void use_mixed(bool on) const;
+
   std::shared_ptr<L2GMap> row_map() const { return _row_map; }
   std::shared_ptr<const L2GMap> col_map() const { return _col_map; }
 

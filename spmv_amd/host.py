@@ -94,6 +94,9 @@ _PROTOS = {
     "spmvh_petsc_rows_destroy": [vp],
     "spmvh_cg_workspace_create": [vp, PTR(vp)],
     "spmvh_cg_workspace_destroy": [vp],
+    "spmvh_cg_mixed": [vp, vp, vp, vp, vp, C.c_int, C.c_double, C.c_int,
+                       PTR(C.c_int), vp, C.c_int, vp, C.c_int,
+                       PTR(C.c_double)],
     "spmvh_cg_workspace_reserve_timing": [vp, C.c_int],
     "spmvh_cg_ex": [vp, vp, vp, vp, vp, C.c_int, f64, PTR(C.c_int), vp, vp,
                     C.c_int, PTR(f64), PTR(C.c_int)],
@@ -508,6 +511,23 @@ def cg(comm, exec_, A, b_ptr, x_ptr, kmax, rtol, history=True):
     call("spmvh_cg", comm.h, exec_.h, A.h, b_ptr, x_ptr, kmax, float(rtol),
          C.byref(k), _np_ptr(hist))
     return k.value, (hist[:k.value + 1] if history else None)
+
+
+def cg_mixed(comm, exec_, A, b_ptr, x_ptr, kmax, rtol, replace_every=50,
+             workspace=None, time_spmv=False, consumer_reductions=True):
+    """spmv::cg with CgOptions::mixed -> (k, rnorm_history, stats)"""
+    k = C.c_int()
+    hist = np.zeros(kmax + 2)
+    st = (C.c_double * 6)()
+    call("spmvh_cg_mixed", comm.h, exec_.h, A.h, b_ptr, x_ptr, kmax,
+         float(rtol), int(replace_every), C.byref(k), _np_ptr(hist), len(hist),
+         workspace.h if workspace else None,
+         int(time_spmv) | (0 if consumer_reductions else 4), st)
+    stats = dict(spmv_ms_total=st[0], spmv_launches=int(st[1]),
+                 replacements=int(st[2]), true_rel_residual=st[3],
+                 continuation_iterations=int(st[4]),
+                 final_true_rel_residual=st[5])
+    return k.value, hist[:k.value + 1], stats
 
 
 def read_petsc_binary_matrix(filename, comm, exec_, symmetric=False,

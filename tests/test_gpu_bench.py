@@ -43,7 +43,8 @@ def _check(d, n_gpus, steps, warmup):
 def test_bench_single_gpu_line():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"),
                           "--grid", "64", "--steps", "20", "--warmup", "3",
-                          "--cpu-n", "32", "--cpu-iters", "3"],
+                          "--cpu-n", "32", "--cpu-iters", "3", "--mixed-grid",
+                          "48"],
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
     d = _line(res.stdout)
@@ -58,6 +59,10 @@ def test_bench_single_gpu_line():
     assert sym["frac"] > 0 and sym["iters/s"] > 0 and "atomic-free" in sym["kernel"]
     assert d["csr_lx_spmv"]["form"]["lx"] == 1 and d["csr_lx_spmv"]["form"]["lat"] == 0
     assert d["north_star_spmv"]["form"]["lat"] == 1
+    mp = d["mixed_precision_cg"]
+    assert mp["mixed"]["final_true_rel_residual"] < 1.001e-10
+    assert abs(mp["mixed"]["iterations"] - mp["fp64"]["iterations"]) <= 5
+    assert mp["x_rel_diff"] < 1e-7
 
 
 def test_bench_two_rank_rehearsal():

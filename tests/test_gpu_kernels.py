@@ -1158,3 +1158,61 @@ def test_band_order_is_a_permutation_of_the_work(lat_ctx, n):
     with pytest.raises(Exception):
         blk.set("band_lines", 4)
     blk.free()
+
+
+# ---------------------------------------------------------------------------
+# Mixed precision: fp32 values, fp64 vectors and arithmetic
+# ---------------------------------------------------------------------------
+def test_mixed_precision_spmv_bit_exact(lat_ctx):
+    """spmv_hip_csr_spmv_f32f64 = the reference loop on the fp32-rounded
+    values, in fp64: lattice form, plain row blocks (aligned and not), row
+    list; with the fused dot."""
+    ctx = lat_ctx
+    rng = np.random.default_rng(97)
+    cases = []
+    for n in (9, 20):
+        rp, ci, _ = poisson.poisson3d_csr(n)
+        cases.append((f"poisson{n}", rp, ci.astype(np.int32), n ** 3, n ** 3))
+    rp, ci, _ = random_csr(rng, 3000, 3500, 7, long_rows=2, long_len=900)
+    cases.append(("ragged", rp, ci, 3000, 3500))
+    rp, ci, _ = random_csr(rng, 5000, 5000, 0.05)  # mostly empty: row list
+    cases.append(("rowlist", rp, ci, 5000, 5000))
+    for name, rp, ci, nrows, ncols in cases:
+        va = rng.uniform(-1, 1, len(ci))
+        va32 = va.astype(np.float32)
+        x = rng.uniform(-1, 1, ncols)
+        y0 = rng.uniform(-1, 1, nrows)
+        blk = hip.CsrBlock(ctx, nrows, ncols, rp, ci, va)
+        if name.startswith("poisson"):
+            assert blk.get("lat") == 1
+        d32 = ctx.upload(va32, np.float32)
+        dx = ctx.upload(x)
+        part = ctx.empty(ctx.dot_partials_len, np.float64)
+        for alpha, beta in ((1.0, 0.0), (-0.5, 0.75)):
+            y_ref = oracle.csr_spmv(rp, ci, va32.astype(np.float64), x, alpha,
+                                    beta, y0)
+            for off in (0, 1):  # 1: a view 4 bytes into the array (unaligned)
+                if off and name != "ragged":
+                    continue
+                vals = d32
+                if off:
+                    vals = ctx.upload(np.concatenate([[0], va32]).astype(np.float32),
+                                      np.float32)
+                dy = ctx.upload(np.full(nrows, np.nan) if beta == 0 else y0)
+                dot = beta == 0 and nrows == ncols
+                hip.call("spmv_hip_csr_spmv_f32f64", ctx.h, blk.plan, nrows,
+                         ncols, blk.nnz, blk.rowptr.ptr, blk.colind.ptr,
+                         vals.ptr + 4 * off, float(alpha), dx.ptr, float(beta),
+                         dy.ptr, part.ptr if dot else None, None)
+                y = dy.numpy()
+                assert np.array_equal(y, y_ref), (name, alpha, beta, off)
+                if dot:
+                    want = float(np.dot(x[:nrows], y_ref))
+                    got = float(np.sum(part.numpy()))
+                    assert abs(got - want) <= 1e-12 * (np.abs(x[:nrows]) @ np.abs(y_ref))
+                dy.free()
+                if off:
+                    vals.free()
+        for b in (d32, dx, part):
+            b.free()
+        blk.free()

@@ -652,3 +652,57 @@ def test_async_transport_observes_stream_ordering(world):
                 exec_.free(p)
 
     tw.run(rank_body, gpu=True, asynchronous=True)
+
+
+def test_cg_mixed_precision(exec_, comm):
+    """CgOptions::mixed (SURVEY 8f n3): fp32 matrix values in the SpMV, fp64
+    everywhere else.  (a) The Poisson matrix is exactly representable in fp32:
+    without replacements the iteration is the fp64 one bit for bit; with them it
+    still converges to the same tolerance.  (b) A diagonally scaled Poisson
+    matrix (irrational values, same sparsity, SPD): the run must end with the
+    TRUE residual under rtol -- residual replacement, and the fp64 correction
+    solve when the fp32 values cannot get there -- and land on the fp64
+    solution."""
+    from spmv_amd import _lib
+    n = 24
+    N = n ** 3
+    rp, ci, va = poisson.poisson3d_csr(n)
+    ci32 = ci.astype(np.int32)
+    rng = np.random.default_rng(41)
+    d = rng.uniform(0.5, 2.0, N)
+    rows = np.repeat(np.arange(N), np.diff(rp))
+    va_scaled = d[rows] * va * d[ci]
+    for name, vals in (("poisson", va), ("scaled", va_scaled)):
+        b = oracle.csr_spmv(rp, ci32, vals, np.ones(N))
+        A = host.Matrix.create_matrix(comm, exec_, rp, ci, vals, N, N, [], [],
+                                      False, host.P2P_NONBLOCKING)
+        d_b, d_x = exec_.alloc(N), exec_.alloc(N)
+        exec_.copy_from_host(d_b, b)
+        k64, h64 = host.cg(comm, exec_, A, d_b, d_x, 2000, 1e-10)
+        x64 = exec_.copy_to_host(d_x, N)
+        assert k64 < 2000
+        for every in (0, 7, 50):
+            k, h, st = host.cg_mixed(comm, exec_, A, d_b, d_x, 2000, 1e-10,
+                                     replace_every=every)
+            x = exec_.copy_to_host(d_x, N)
+            true_rel = (np.linalg.norm(b - oracle.csr_spmv(rp, ci32, vals, x))
+                        / np.linalg.norm(b))
+            what = (name, every, k, st)
+            if name == "poisson" and every == 0:
+                assert k == k64 and np.array_equal(h, h64), what
+                assert np.array_equal(x, x64), what
+                assert st["continuation_iterations"] == 0
+            assert true_rel < 1.001e-10, (what, true_rel)
+            assert abs(st["final_true_rel_residual"] - true_rel) <= 0.05 * 1e-10 + 0.5 * true_rel, what
+            assert np.linalg.norm(x - x64) <= 1e-7 * np.linalg.norm(x64), what
+            assert st["replacements"] == (0 if every == 0 else k_loop(k, st) // every), what
+            # the mixed switch was left off: a plain solve is the fp64 one again
+        k2, h2 = host.cg(comm, exec_, A, d_b, d_x, 2000, 1e-10)
+        assert k2 == k64 and np.array_equal(h2, h64)
+        A.close()
+        exec_.free(d_b), exec_.free(d_x)
+
+
+def k_loop(k, st):
+    """iterations of the mixed loop itself (the correction solve excluded)"""
+    return k - st["continuation_iterations"]
