@@ -202,7 +202,7 @@ def kernel_of(A, symmetric):
         return ("csr_lattice_kernel<double> (lattice form: constant column "
                 "offsets per row block, values by LDS-DMA one block ahead, no "
                 "index stream; fused p.Ap)",
-                algo, nnz * 8 + rows * (4 + 1) + nrb * 48 + y_x)
+                algo, nnz * 8 + rows * 1 + nrb * 48 + y_x)
     if A.plan_get("lx"):
         return ("csr_rowblock_lx_kernel<double> (LX form: x windows staged in "
                 "LDS, 16-bit column offsets; fused p.Ap)",

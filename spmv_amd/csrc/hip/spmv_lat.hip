@@ -15,9 +15,12 @@
 //     repeats, so that "walk the set bits from k = 0 up" IS the row's
 //     left-to-right order of csr_kernels.cpp:46-47.
 // If every row block qualifies the plan takes this form, and the kernel
-//   1. never reads colind: 8 B per entry (values) + 5 B per row (row pointer,
-//      mask) instead of 12 B per entry -- at 512^3 10.3 GB per SpMV instead
-//      of 13.9 GB (LX form: 12.1 GB);
+//   1. reads neither colind nor (per row) the row pointer: 8 B per entry
+//      (values) + 1 B per row (mask) instead of 12 B per entry + 4 B per row --
+//      at 512^3 9.8 GB per SpMV instead of 13.9 GB (LX form: 12.1 GB).  A
+//      row's position in `values` is the block's start + the entries of the
+//      earlier waves (three 16-bit counts in the block's record) + the mask
+//      popcounts of the lower lanes of its wave (four ballots);
 //   2. moves `values` straight into LDS with LDS-DMA
 //      (global_load_lds_dwordx4: no VGPRs, no LDS store instructions), always
 //      one row block AHEAD of the one being summed (two LDS slots), so the
@@ -39,6 +42,9 @@
 //   lat_tab[rb*kLatRec + 0]      nd, number of offsets of row block rb (-1: not
 //                                in lattice form)
 //   lat_tab[rb*kLatRec + 1]      k0: D[k0] == 0 (padding included), or -1
+//   lat_tab[rb*kLatRec + 2, 3]   entries in front of the waves 1, 2, 3 of the
+//                                block (16 bits each): row positions come
+//                                from these and the mask popcounts
 //   lat_tab[rb*kLatRec + 4 + k]  D[k], ascending, padded with 0
 //   lat_mask[row]                presence bits
 #include "csr_plan.h"
@@ -66,7 +72,7 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 //           and its register loads have landed, for every wave; every wave has
 //           left block k-1, whose LDS slot is free again
 //   issue   DMA of block k+1's values into that slot; block k+1's loads into
-//           registers: row pointer, mask byte, x[row + D[j]] for all 8 j (D is
+//           registers: mask byte, x[row + D[j]] for all 8 j (D is
 //           padded with 0 = the row's own x, a cache hit), y for beta != 0 --
 //           all independent of each other
 //   sum     block k: own row out of LDS, left to right over the set mask bits
@@ -75,7 +81,8 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 // ---------------------------------------------------------------------------
 template <typename T>
 struct LatRegs {
-  int32_t lo;
+  int32_t wbase; // entries of the block in front of this lane's wave (uniform
+                 // per wave)
   unsigned m;
   int k0; // uniform: xk[k0] is the row's own x (DOT), -1 = x_own was loaded
   T xk[kLatMaxOff];
@@ -95,7 +102,7 @@ __device__ __forceinline__ LatRegs<T> lat_loads(
     const T* __restrict__ out)
 {
   LatRegs<T> g;
-  g.lo = 0;
+  g.wbase = 0;
   g.m = 0;
   g.k0 = 0;
   g.y0 = g.x_own = T(0);
@@ -111,7 +118,9 @@ __device__ __forceinline__ LatRegs<T> lat_loads(
     const int32_t* rec = tab + (int64_t)blk.rb * kLatRec;
     const i32x8 D = *reinterpret_cast<const i32x8*>(rec + 4);
     g.k0 = rec[1]; // position of a zero offset in D, or -1
-    g.lo = rowptr[r];
+    const int32_t c12 = rec[2], c3 = rec[3];
+    const int w = t >> 6;
+    g.wbase = w == 0 ? 0 : (w == 1 ? (c12 & 0xffff) : (w == 2 ? (c12 >> 16) : c3));
     g.m = mask[r];
 #pragma unroll
     for (int k = 0; k < kLatMaxOff; ++k) {
@@ -206,8 +215,21 @@ __global__ __launch_bounds__(kBlock) void csr_lattice_kernel(
                                   rowptr, stride, &itnn);
     const int32_t r = cur.rb * kRows + t;
     if (r < num_rows) {
-      const int rel
-          = slot * SLOT + (g.lo - (int32_t)(cur.a & ~(int64_t)(V - 1)));
+      // the row's first entry: block start + entries of the earlier waves +
+      // entries of the lower lanes of this wave (sum of their mask
+      // popcounts, <= 8 each: four ballots, one per bit of the count)
+      const unsigned cnt = __popc(g.m);
+      int before = 0;
+#pragma unroll
+      for (int bit = 0; bit < 4; ++bit) {
+        const uint64_t has = __ballot((cnt >> bit) & 1u);
+        before += (int)__builtin_amdgcn_mbcnt_hi(
+                      (unsigned)(has >> 32),
+                      __builtin_amdgcn_mbcnt_lo((unsigned)has, 0u))
+                  << bit;
+      }
+      const int rel = slot * SLOT + (int)(cur.a & (int64_t)(V - 1)) + g.wbase
+                      + before;
       // all LDS reads first (independent), then the adds in entry order
       T v[kLatMaxOff];
 #pragma unroll
@@ -360,6 +382,16 @@ __global__ __launch_bounds__(kBlock) void lat_build_kernel(
         if (s_D[k] == 0)
           k0 = k;
       rec[1] = k0;
+      // entries in front of the block's second, third and fourth wave of 64
+      // rows: with the mask bytes the kernel rebuilds every row's position
+      // (row pointer = block start + this + the popcounts of the lower lanes)
+      // and never loads the row pointer per row
+      const int32_t a = rowptr[r0];
+      const int32_t c1 = rowptr[r0 + min(64, nr)] - a;
+      const int32_t c2 = rowptr[r0 + min(128, nr)] - a;
+      const int32_t c3 = rowptr[r0 + min(192, nr)] - a;
+      rec[2] = c1 | (c2 << 16); // <= 2176 each (slot check above)
+      rec[3] = c3;
       if (!fail)
         atomicAdd(ok_count, 1);
     }
