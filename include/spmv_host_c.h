@@ -105,6 +105,21 @@ int spmvh_matrix_create(spmvh_comm* comm, spmvh_exec* exec,
                         spmvh_matrix** A);
 int spmvh_matrix_create_poisson3d(spmvh_comm* comm, spmvh_exec* exec, int32_t n,
                                   int symmetric, int cm, spmvh_matrix** A);
+/* The Poisson matrix on a 3-D block partition (the reference
+ * partitions by row slabs only, read_petsc.cpp:20-37): px * py * pz boxes,
+ * rank = ix + px (iy + py iz), rank-major global numbering (a box's points are
+ * consecutive, x fastest), so each rank still owns one contiguous row range.
+ * px * py * pz must equal the communicator's size. */
+int spmvh_matrix_create_poisson3d_boxes(spmvh_comm* comm, spmvh_exec* exec,
+                                        int32_t n, int px, int py, int pz,
+                                        int symmetric, int cm, spmvh_matrix** A);
+/* Its host half (no device, no communicator): rank `rank`'s rows in
+ * spmvh_matrix_create's input form.  sizes = {rows, non-zeros, ghosts, global
+ * row offset, box extents x y z}; the arrays are filled when non-NULL (call
+ * once with NULLs for the sizes). */
+int spmvh_poisson3d_box_rows(int32_t n, int px, int py, int pz, int rank,
+                             int64_t sizes[7], int32_t* rowptr, int32_t* colind,
+                             double* values, int64_t* col_ghosts);
 int spmvh_matrix_destroy(spmvh_matrix* A);
 int spmvh_matrix_rows(spmvh_matrix* A, int* rows);
 int spmvh_matrix_cols(spmvh_matrix* A, int* cols);

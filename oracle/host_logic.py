@@ -370,12 +370,14 @@ def matrix_mult(A, x, y=None):
 
 
 def partition(P, rowptr, colind, values, symmetric=False,
-              cm=COLLECTIVE_BLOCKING):
+              cm=COLLECTIVE_BLOCKING, ranges=None):
     """Row-block partition of a global square CSR over P ranks, exactly as
     tests/test_spmv.cpp:83-129 does on each rank.  Returns (ranges, mats,
-    plans)."""
+    plans).  `ranges` replaces the even split by given contiguous row ranges
+    (the 3-D block partition's box sizes)."""
     N = len(rowptr) - 1
-    ranges = owner_ranges(P, N)
+    ranges = owner_ranges(P, N) if ranges is None else np.asarray(ranges, np.int64)
+    assert len(ranges) == P + 1 and ranges[0] == 0 and ranges[-1] == N
     mats, ghosts = [], []
     for r in range(P):
         rp, ci, va, cg = localise_rows(rowptr, colind, values,
@@ -388,10 +390,11 @@ def partition(P, rowptr, colind, values, symmetric=False,
 
 
 def dist_spmv(P, rowptr, colind, values, x, symmetric=False,
-              cm=COLLECTIVE_BLOCKING):
+              cm=COLLECTIVE_BLOCKING, ranges=None):
     """`l2g->update(x); A->mult(x, y)` on P simulated ranks
     (tests/test_spmv.cpp:131-144).  Returns the global y."""
-    ranges, mats, plans = partition(P, rowptr, colind, values, symmetric, cm)
+    ranges, mats, plans = partition(P, rowptr, colind, values, symmetric, cm,
+                                    ranges)
     xs = []
     for r in range(P):
         v = np.zeros(mats[r]["ncols"], np.asarray(x).dtype)
@@ -402,11 +405,12 @@ def dist_spmv(P, rowptr, colind, values, x, symmetric=False,
 
 
 def dist_cg(P, rowptr, colind, values, b, kmax, rtol, symmetric=False,
-            cm=COLLECTIVE_BLOCKING):
+            cm=COLLECTIVE_BLOCKING, ranges=None):
     """spmv/cg.cpp:21-98 on P simulated ranks.  ddot = left-to-right per
     rank, MPI_Allreduce(SUM) = sum over ranks in rank order (both pinned by
     the oracle, unpinned in the reference).  Returns (x, k, rnorm_history)."""
-    ranges, mats, plans = partition(P, rowptr, colind, values, symmetric, cm)
+    ranges, mats, plans = partition(P, rowptr, colind, values, symmetric, cm,
+                                    ranges)
     M = [int(ranges[r + 1] - ranges[r]) for r in range(P)]
 
     def allreduce(parts):

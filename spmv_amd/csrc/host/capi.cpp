@@ -326,6 +326,44 @@ int spmvh_matrix_create_poisson3d(spmvh_comm* comm, spmvh_exec* exec, int32_t n,
   });
 }
 
+int spmvh_matrix_create_poisson3d_boxes(spmvh_comm* comm, spmvh_exec* exec,
+                                        int32_t n, int px, int py, int pz,
+                                        int symmetric, int cm, spmvh_matrix** A)
+{
+  return guarded([&] {
+    require(comm && exec && A, "NULL argument");
+    auto m = std::make_unique<spmvh_matrix>();
+    m->A.reset(Matrix<double>::create_poisson3d_boxes(
+        comm->comm, exec->hip, n, px, py, pz, symmetric != 0, to_cm(cm)));
+    *A = m.release();
+  });
+}
+
+int spmvh_poisson3d_box_rows(int32_t n, int px, int py, int pz, int rank,
+                             int64_t sizes[7], int32_t* rowptr, int32_t* colind,
+                             double* values, int64_t* col_ghosts)
+{
+  return guarded([&] {
+    require(sizes, "NULL argument");
+    auto b = Matrix<double>::poisson3d_box_rows(n, px, py, pz, rank);
+    sizes[0] = b.rows.rows;
+    sizes[1] = b.rows.non_zeros();
+    sizes[2] = static_cast<int64_t>(b.col_ghosts.size());
+    sizes[3] = b.global_row_offset;
+    sizes[4] = b.box[0];
+    sizes[5] = b.box[1];
+    sizes[6] = b.box[2];
+    if (rowptr)
+      std::copy(b.rows.rowptr.begin(), b.rows.rowptr.end(), rowptr);
+    if (colind)
+      std::copy(b.rows.colind.begin(), b.rows.colind.end(), colind);
+    if (values)
+      std::copy(b.rows.values.begin(), b.rows.values.end(), values);
+    if (col_ghosts)
+      std::copy(b.col_ghosts.begin(), b.col_ghosts.end(), col_ghosts);
+  });
+}
+
 int spmvh_matrix_destroy(spmvh_matrix* A)
 {
   return guarded([&] { delete A; });

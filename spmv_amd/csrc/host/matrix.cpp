@@ -587,6 +587,151 @@ Matrix<T>* Matrix<T>::create_poisson3d(std::shared_ptr<const Comm> comm,
   }
 }
 
+// ---------------------------------------------------------------------------
+// 3-D block partition of the Poisson matrix
+// ---------------------------------------------------------------------------
+namespace
+{
+// first index and extent of part i of an axis of n points cut into p parts
+// (read_petsc.cpp:20-37 per axis: the first n mod p parts get one more)
+inline void axis_part(int64_t n, int p, int i, int64_t* first, int64_t* len)
+{
+  const int64_t q = n / p, rem = n % p;
+  *len = q + (i < rem ? 1 : 0);
+  *first = i * q + (i < rem ? i : rem);
+}
+inline int axis_owner(int64_t n, int p, int64_t c)
+{
+  const int64_t q = n / p, rem = n % p;
+  const int64_t big = rem * (q + 1); // points in the parts of size q + 1
+  return c < big ? (int)(c / (q + 1)) : (int)(rem + (c - big) / q);
+}
+} // namespace
+
+template <typename T>
+typename Matrix<T>::BoxRows Matrix<T>::poisson3d_box_rows(int32_t n, int px,
+                                                          int py, int pz,
+                                                          int rank)
+{
+  if (n < 1 || px < 1 || py < 1 || pz < 1 || px > n || py > n || pz > n
+      || rank < 0 || rank >= px * py * pz)
+    throw std::runtime_error("poisson3d_box_rows: bad partition");
+  const int P[3] = {px, py, pz};
+  // box of every rank: first point and extents; global offset = points of the
+  // lower ranks
+  auto box_of = [&](int r, int64_t first[3], int64_t len[3]) {
+    const int i[3] = {r % px, (r / px) % py, r / (px * py)};
+    for (int a = 0; a < 3; ++a)
+      axis_part(n, P[a], i[a], &first[a], &len[a]);
+  };
+  const int nranks = px * py * pz;
+  std::vector<int64_t> offset(nranks + 1, 0);
+  for (int r = 0; r < nranks; ++r) {
+    int64_t f[3], l[3];
+    box_of(r, f, l);
+    offset[r + 1] = offset[r] + l[0] * l[1] * l[2];
+  }
+  // global id of grid point (x, y, z)
+  auto global_id = [&](int64_t x, int64_t y, int64_t z) {
+    const int r = axis_owner(n, px, x)
+                  + px * (axis_owner(n, py, y) + py * axis_owner(n, pz, z));
+    int64_t f[3], l[3];
+    box_of(r, f, l);
+    return offset[r] + (x - f[0]) + l[0] * ((y - f[1]) + l[1] * (z - f[2]));
+  };
+  int64_t f[3], l[3];
+  box_of(rank, f, l);
+  BoxRows out;
+  out.global_row_offset = offset[rank];
+  out.box[0] = l[0];
+  out.box[1] = l[1];
+  out.box[2] = l[2];
+  const int64_t nloc = l[0] * l[1] * l[2];
+  const int64_t g0 = offset[rank], g1 = offset[rank + 1];
+  // pass 1: the ghost columns (points one step outside the six faces)
+  std::vector<int64_t>& ghosts = out.col_ghosts;
+  for (int64_t z = 0; z < l[2]; ++z)
+    for (int64_t y = 0; y < l[1]; ++y)
+      for (int64_t x = 0; x < l[0]; ++x) {
+        const bool face = x == 0 || y == 0 || z == 0 || x == l[0] - 1
+                          || y == l[1] - 1 || z == l[2] - 1;
+        if (!face)
+          continue;
+        const int64_t X = f[0] + x, Y = f[1] + y, Z = f[2] + z;
+        const int64_t nb[6][3] = {{X - 1, Y, Z}, {X + 1, Y, Z}, {X, Y - 1, Z},
+                                  {X, Y + 1, Z}, {X, Y, Z - 1}, {X, Y, Z + 1}};
+        for (const auto& q : nb) {
+          if (q[0] < 0 || q[1] < 0 || q[2] < 0 || q[0] >= n || q[1] >= n
+              || q[2] >= n)
+            continue;
+          const int64_t g = global_id(q[0], q[1], q[2]);
+          if (g < g0 || g >= g1)
+            ghosts.push_back(g);
+        }
+      }
+  std::sort(ghosts.begin(), ghosts.end());
+  ghosts.erase(std::unique(ghosts.begin(), ghosts.end()), ghosts.end());
+  // pass 2: the rows, entries ascending by global column
+  CsrHost<T>& A = out.rows;
+  A.rows = static_cast<int32_t>(nloc);
+  A.cols = static_cast<int32_t>(nloc + (int64_t)ghosts.size());
+  A.rowptr.assign(1, 0);
+  A.rowptr.reserve(nloc + 1);
+  A.colind.reserve(7 * nloc);
+  A.values.reserve(7 * nloc);
+  for (int64_t z = 0; z < l[2]; ++z)
+    for (int64_t y = 0; y < l[1]; ++y)
+      for (int64_t x = 0; x < l[0]; ++x) {
+        const int64_t X = f[0] + x, Y = f[1] + y, Z = f[2] + z;
+        const int64_t nb[7][3] = {{X, Y, Z - 1}, {X, Y - 1, Z}, {X - 1, Y, Z},
+                                  {X, Y, Z},     {X + 1, Y, Z}, {X, Y + 1, Z},
+                                  {X, Y, Z + 1}};
+        std::pair<int64_t, T> ent[7];
+        int ne = 0;
+        for (int k = 0; k < 7; ++k) {
+          const auto& q = nb[k];
+          if (q[0] < 0 || q[1] < 0 || q[2] < 0 || q[0] >= n || q[1] >= n
+              || q[2] >= n)
+            continue;
+          ent[ne++] = {global_id(q[0], q[1], q[2]), k == 3 ? T(6) : T(-1)};
+        }
+        std::sort(ent, ent + ne,
+                  [](const std::pair<int64_t, T>& a,
+                     const std::pair<int64_t, T>& b) { return a.first < b.first; });
+        for (int k = 0; k < ne; ++k) {
+          const int64_t g = ent[k].first;
+          int32_t c;
+          if (g >= g0 && g < g1)
+            c = static_cast<int32_t>(g - g0);
+          else
+            c = static_cast<int32_t>(
+                nloc
+                + (std::lower_bound(ghosts.begin(), ghosts.end(), g)
+                   - ghosts.begin()));
+          A.colind.push_back(c);
+          A.values.push_back(ent[k].second);
+        }
+        A.rowptr.push_back(static_cast<int32_t>(A.colind.size()));
+      }
+  return out;
+}
+
+template <typename T>
+Matrix<T>* Matrix<T>::create_poisson3d_boxes(std::shared_ptr<const Comm> comm,
+                                             std::shared_ptr<DeviceExecutor> exec,
+                                             int32_t n, int px, int py, int pz,
+                                             bool symmetric,
+                                             CommunicationModel cm)
+{
+  if (px * py * pz != comm->size())
+    throw std::runtime_error(
+        "create_poisson3d_boxes: px * py * pz must equal the number of ranks");
+  BoxRows b = poisson3d_box_rows(n, px, py, pz, comm->rank());
+  return create_matrix(comm, exec, b.rows.rowptr.data(), b.rows.colind.data(),
+                       b.rows.values.data(), b.rows.rows, b.rows.rows, {},
+                       b.col_ghosts, symmetric, cm);
+}
+
 template class Matrix<float>;
 template class Matrix<double>;
 

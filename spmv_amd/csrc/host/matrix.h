@@ -121,6 +121,30 @@ public:
       int32_t n, bool symmetric = false,
       CommunicationModel cm = CommunicationModel::collective_blocking);
 
+  // The same matrix on a 3-D BLOCK partition (the reference has
+  // row slabs only): the n^3 grid is cut into px * py * pz boxes (sizes by the
+  // even rule per axis), rank = ix + px (iy + py iz) owns one box, and the
+  // global numbering is rank-major -- a box's points are consecutive, in
+  // x-fastest order -- so that every rank still owns one contiguous row range,
+  // as L2GMap requires.  The halo is the six faces of the box (surface, not
+  // two full planes); it goes through the general pack / exchange path.  The
+  // rows are generated on the host and handed to create_matrix.
+  static Matrix<T>* create_poisson3d_boxes(
+      std::shared_ptr<const Comm> comm, std::shared_ptr<DeviceExecutor> exec,
+      int32_t n, int px, int py, int pz, bool symmetric = false,
+      CommunicationModel cm = CommunicationModel::collective_blocking);
+  // its host half: this rank's rows in create_matrix's input form (columns
+  // local: owned first, ghosts as col_ghosts.size()-relative indices behind
+  // them, col_ghosts ascending global ids; entries of a row ascending by
+  // global column)
+  struct BoxRows {
+    CsrHost<T> rows;
+    std::vector<int64_t> col_ghosts;
+    int64_t global_row_offset = 0;
+    int64_t box[3] = {0, 0, 0}; // box extents
+  };
+  static BoxRows poisson3d_box_rows(int32_t n, int px, int py, int pz, int rank);
+
   const SubMatrix<T>* local_block() const { return _mat_local.get(); }
   const SubMatrix<T>* remote_block() const { return _mat_remote.get(); }
 

@@ -57,6 +57,10 @@ _PROTOS = {
     "spmvh_split_create_dist": [vp, vp, vp, vp, i64, i64, vp, i64, vp, i64,
                                 C.c_int, C.c_int, PTR(vp), PTR(i64)],
     "spmvh_matrix_create_poisson3d": [vp, vp, i32, C.c_int, C.c_int, PTR(vp)],
+    "spmvh_matrix_create_poisson3d_boxes": [vp, vp, i32, C.c_int, C.c_int,
+                                            C.c_int, C.c_int, C.c_int, PTR(vp)],
+    "spmvh_poisson3d_box_rows": [i32, C.c_int, C.c_int, C.c_int, C.c_int, vp,
+                                 vp, vp, vp, vp],
     "spmvh_matrix_destroy": [vp],
     "spmvh_matrix_rows": [vp, PTR(C.c_int)],
     "spmvh_matrix_cols": [vp, PTR(C.c_int)],
@@ -364,6 +368,16 @@ class Matrix:
              int(symmetric), cm, C.byref(h))
         return cls(h)
 
+    @classmethod
+    def create_poisson3d_boxes(cls, comm, exec_, n, parts, symmetric=False,
+                               cm=COLLECTIVE_BLOCKING):
+        """The Poisson matrix on a 3-D block partition, parts = (px, py, pz)."""
+        h = vp()
+        call("spmvh_matrix_create_poisson3d_boxes", comm.h, exec_.h, n,
+             int(parts[0]), int(parts[1]), int(parts[2]), int(symmetric), cm,
+             C.byref(h))
+        return cls(h)
+
     def close(self):
         if self.h:
             call("spmvh_matrix_destroy", self.h)
@@ -502,6 +516,22 @@ def split_rows_distributed(comm, rowptr, colind, values, nrows_local,
          _np_ptr(va), int(nrows_local), int(ncols_local), _np_ptr(rg), len(rg),
          _np_ptr(cg), len(cg), int(symmetric), cm, C.byref(h), sizes)
     return _split_result(h, sizes, nrows_local, symmetric)
+
+
+def poisson3d_box_rows(n, parts, rank):
+    """Host half of Matrix.create_poisson3d_boxes: (rowptr, colind, values,
+    col_ghosts, global_row_offset, box extents) of one rank; no device."""
+    sizes = (i64 * 7)()
+    px, py, pz = (int(p) for p in parts)
+    call("spmvh_poisson3d_box_rows", n, px, py, pz, rank, sizes, None, None,
+         None, None)
+    rowptr = np.empty(sizes[0] + 1, np.int32)
+    colind = np.empty(sizes[1], np.int32)
+    values = np.empty(sizes[1], np.float64)
+    ghosts = np.empty(sizes[2], np.int64)
+    call("spmvh_poisson3d_box_rows", n, px, py, pz, rank, sizes,
+         _np_ptr(rowptr), _np_ptr(colind), _np_ptr(values), _np_ptr(ghosts))
+    return rowptr, colind, values, ghosts, int(sizes[3]), tuple(sizes[4:7])
 
 
 def cg(comm, exec_, A, b_ptr, x_ptr, kmax, rtol, history=True):

@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import dist_util  # noqa: E402
 import oracle  # noqa: E402
 from spmv_amd import host, poisson  # noqa: E402
-from util import assembled_inputs  # noqa: E402
+from util import assembled_inputs, box_partition, permute_csr  # noqa: E402
 
 
 def main():
@@ -76,6 +76,37 @@ def main():
                         assert np.array_equal(a, b), name
                 if sym:
                     assert np.array_equal(s["diagonal"], A["diagonal"])
+    # 3-D block partition: this rank's generated box rows give
+    # the plan and the split the oracle derives from the permuted matrix
+    n, parts = 6, {2: (2, 1, 1), 3: (1, 3, 1)}.get(world, (1, 1, world))
+    perm, ranges = box_partition(n, parts)
+    brp, bci, bva = permute_csr(*poisson.poisson3d_csr(n), perm)
+    locs = [oracle.localise_rows(brp, bci, bva, int(ranges[r]), int(ranges[r + 1]))
+            for r in range(world)]
+    plans = oracle.l2g_plans(np.diff(ranges), [l[3] for l in locs])
+    lrp, lci, lva, ghosts, off, _ = host.poisson3d_box_rows(n, parts, rank)
+    nloc = int(ranges[rank + 1] - ranges[rank])
+    assert off == ranges[rank] and np.array_equal(ghosts, locs[rank][3])
+    for cm in (host.P2P_BLOCKING, host.P2P_NONBLOCKING):
+        m = host.L2GMap(comm, nloc, ghosts, None, cm)
+        got, exp = m.plan(), plans[rank]
+        nn = len(exp["neighbours"])
+        assert np.array_equal(got.neighbours, exp["neighbours"])
+        assert np.array_equal(got.send_count, exp["send_count"][:nn])
+        assert np.array_equal(got.recv_count, exp["recv_count"][:nn])
+        assert np.array_equal(got.indexbuf, exp["indexbuf"])
+        m.close()
+        for sym in (False, True):
+            A = oracle.create_matrix(rank, ranges, ranges, *locs[rank], sym, cm)
+            s = host.split_rows_distributed(comm, lrp, lci, lva, nloc, nloc, [],
+                                            ghosts, sym, cm)
+            assert s["nnz"] == A["nnz"]
+            for name in ("local", "remote"):
+                if A[name] is None:
+                    assert len(s[name][2]) == 0
+                    continue
+                for a, b in zip(s[name], A[name]):
+                    assert np.array_equal(a, b), (name, sym, cm)
     # ghost-row elimination (Matrix.cpp:188-292): every rank holds pieces of
     # rows it does not own; the C++ exchange + split must equal the oracle's
     for seed, sym in ((1, False), (2, True)):

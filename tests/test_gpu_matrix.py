@@ -12,7 +12,7 @@ import pytest
 
 import oracle
 from spmv_amd import hip, host, poisson
-from util import U, abs_bound
+from util import U, abs_bound, box_partition, permute_csr
 
 pytestmark = pytest.mark.gpu
 
@@ -354,6 +354,59 @@ def test_slab_ranks_threaded_spmv_and_cg(world, n):
             m = min(k, k_ref, 50)
             assert np.allclose(hist[:m + 1], hist_ref[:m + 1], rtol=1e-6)
             assert np.linalg.norm(xs - x_ref) <= 1e-8 * np.linalg.norm(x_ref)
+            A.close()
+            for p in (d_x, d_y, d_b, d_s):
+                exec_.free(p)
+
+    tw.run(rank_body, gpu=True)
+
+
+@pytest.mark.parametrize("n,parts", [(12, (2, 2, 2)), (10, (3, 2, 1)),
+                                     (9, (1, 2, 4))])
+def test_box_partition_ranks_threaded_spmv_and_cg(n, parts):
+    """the Poisson matrix on a 3-D block partition
+    (Matrix::create_poisson3d_boxes), up to 6 face neighbours and packed
+    sends per rank; y equals the oracle's simulation of the same partition of
+    the permuted global matrix bit for bit, CG follows its history."""
+    from thread_world import ThreadWorld
+    world = parts[0] * parts[1] * parts[2]
+    N = n ** 3
+    perm, ranges = box_partition(n, parts)
+    rp, ci, va = permute_csr(*poisson.poisson3d_csr(n), perm)
+    x = oracle.gaussian_x_fast(N)
+    b = oracle.csr_spmv(rp, ci.astype(np.int32), va, np.ones(N))
+    y_seq = oracle.csr_spmv(rp, ci.astype(np.int32), va, x)
+    refs = {}
+    for sym in (False, True):
+        for cm in (host.P2P_BLOCKING, host.P2P_NONBLOCKING):
+            refs[(sym, cm)] = (
+                oracle.dist_spmv(world, rp, ci, va, x, sym, cm, ranges),
+                oracle.dist_cg(world, rp, ci, va, b, 200, 1e-10, sym, cm, ranges))
+    tw = ThreadWorld(world, timeout=45.0)
+
+    def rank_body(rank, comm, exec_):
+        r0, r1 = int(ranges[rank]), int(ranges[rank + 1])
+        for (sym, cm), (y_ref, (x_ref, k_ref, hist_ref)) in refs.items():
+            A = host.Matrix.create_poisson3d_boxes(comm, exec_, n, parts, sym, cm)
+            l2g = A.col_map()
+            assert l2g.local_size() == r1 - r0 == A.rows()
+            d_x = exec_.alloc(l2g.local_size() + l2g.num_ghosts())
+            d_y = exec_.alloc(r1 - r0)
+            exec_.copy_from_host(d_x, x[r0:r1])
+            l2g.update(d_x)
+            A.mult(d_x, d_y)
+            y = tw.gather(rank, exec_.copy_to_host(d_y, r1 - r0))
+            assert np.array_equal(y, y_ref), (sym, cm)
+            assert np.all(np.abs(y - y_seq) <= 16 * U * abs_bound(rp, ci, va, x))
+            d_b, d_s = exec_.alloc(r1 - r0), exec_.alloc(r1 - r0)
+            exec_.copy_from_host(d_b, b[r0:r1])
+            k, hist = host.cg(comm, exec_, A, d_b, d_s, 200, 1e-10)
+            xs = tw.gather(rank, exec_.copy_to_host(d_s, r1 - r0))
+            assert abs(k - k_ref) <= 1 and k < 200, (k, k_ref)
+            m = min(k, k_ref, 50)
+            assert np.allclose(hist[:m + 1], hist_ref[:m + 1], rtol=1e-6)
+            assert np.linalg.norm(xs - x_ref) <= 1e-8 * np.linalg.norm(x_ref)
+            assert np.abs(xs - 1.0).max() < 1e-6
             A.close()
             for p in (d_x, d_y, d_b, d_s):
                 exec_.free(p)

@@ -11,7 +11,8 @@ import pytest
 
 import oracle
 from spmv_amd import _lib, host, poisson
-from util import U, abs_bound, lower_split, random_csr
+from util import (U, abs_bound, box_partition, lower_split, permute_csr,
+                  random_csr)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -424,6 +425,38 @@ def test_plan_and_split_many_ranks_threaded(world, N, density, seed):
     ThreadWorld(world).run(rank_body)
 
 
+@pytest.mark.parametrize("n,parts", [(8, (2, 2, 2)), (7, (3, 2, 2)), (6, (1, 2, 3))])
+def test_box_partition_plan_many_ranks_threaded(n, parts):
+    """The halo plan of the 3-D block partition: up to 6 face neighbours per
+    rank, scattered (packed) sends."""
+    from thread_world import ThreadWorld
+    world = parts[0] * parts[1] * parts[2]
+    perm, ranges = box_partition(n, parts)
+    brp, bci, bva = permute_csr(*poisson.poisson3d_csr(n), perm)
+    locs = [oracle.localise_rows(brp, bci, bva, int(ranges[r]), int(ranges[r + 1]))
+            for r in range(world)]
+    plans = oracle.l2g_plans(np.diff(ranges), [l[3] for l in locs])
+    if parts == (2, 2, 2):
+        assert all(len(p["neighbours"]) == 3 for p in plans)
+
+    def rank_body(rank, comm):
+        lrp, lci, lva, ghosts, off, box = host.poisson3d_box_rows(n, parts, rank)
+        nloc = int(ranges[rank + 1] - ranges[rank])
+        for cm in (host.P2P_BLOCKING, host.P2P_NONBLOCKING):
+            m = host.L2GMap(comm, nloc, ghosts, None, cm)
+            got, exp = m.plan(), plans[rank]
+            nn = len(exp["neighbours"])
+            assert np.array_equal(got.neighbours, exp["neighbours"])
+            assert np.array_equal(got.send_count, exp["send_count"][:nn])
+            assert np.array_equal(got.recv_count, exp["recv_count"][:nn])
+            assert np.array_equal(got.send_offset, exp["send_offset"][:nn + 1])
+            assert np.array_equal(got.recv_offset, exp["recv_offset"][:nn + 1])
+            assert np.array_equal(got.indexbuf, exp["indexbuf"])
+            m.close()
+
+    ThreadWorld(world).run(rank_body)
+
+
 @pytest.mark.parametrize("world,N,seed,sym", [(4, 37, 10, False), (5, 53, 11, True),
                                               (8, 71, 12, False), (8, 90, 13, True)])
 def test_row_ghost_assembly_many_ranks_threaded(world, N, seed, sym):
@@ -503,3 +536,35 @@ def test_plan_of_the_real_eight_way_512_cubed_slabs():
             m.close()
 
     ThreadWorld(world, timeout=120.0).run(rank_body)
+
+
+@pytest.mark.parametrize("n,parts", [(6, (2, 2, 2)), (7, (3, 2, 1)),
+                                     (5, (1, 1, 4)), (4, (4, 1, 1)),
+                                     (9, (2, 3, 2)), (3, (1, 1, 1))])
+def test_box_partition_rows_match_the_permuted_matrix(n, parts):
+    """Matrix::poisson3d_box_rows (SURVEY 8f n4, 3-D block partition): every
+    rank's rows, ghosts and numbering equal the slice the reference's test
+    harness (tests/test_spmv.cpp:83-124, oracle.localise_rows) takes of the
+    permuted global matrix, array for array."""
+    rp, ci, va = poisson.poisson3d_csr(n)
+    perm, ranges = box_partition(n, parts)
+    assert np.array_equal(np.sort(perm), np.arange(n ** 3))
+    brp, bci, bva = permute_csr(rp, ci, va, perm)
+    P = parts[0] * parts[1] * parts[2]
+    nnz = 0
+    for rank in range(P):
+        lrp, lci, lva, ghosts, off, box = host.poisson3d_box_rows(n, parts, rank)
+        r0, r1 = int(ranges[rank]), int(ranges[rank + 1])
+        assert off == r0 and box[0] * box[1] * box[2] == r1 - r0
+        erp, eci, eva, eghosts = oracle.localise_rows(brp, bci, bva, r0, r1)
+        assert np.array_equal(lrp, erp) and np.array_equal(lci, eci)
+        assert np.array_equal(lva, eva) and np.array_equal(ghosts, eghosts)
+        # the halo is the box's surface: at most one layer of points per face
+        bx, by, bz = box
+        assert len(ghosts) <= 2 * (bx * by + by * bz + bx * bz)
+        nnz += len(lva)
+    assert nnz == len(va)
+    with pytest.raises(host.SpmvHostError):
+        host.poisson3d_box_rows(n, (n + 1, 1, 1), 0)
+    with pytest.raises(host.SpmvHostError):
+        host.poisson3d_box_rows(n, parts, P)

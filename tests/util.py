@@ -100,3 +100,43 @@ def assembled_inputs(rng, P, N, density=0.2, symmetric=False):
                        np.array(va, np.float64), np.array(rg, np.int64),
                        np.array(cg, np.int64)))
     return A, ranges, inputs
+
+
+def box_partition(n, parts):
+    """3-D block partition of the n^3 grid (Matrix::create_poisson3d_boxes):
+    parts = (px, py, pz) boxes with the even rule per axis, rank = ix + px (iy
+    + py iz), rank-major numbering with x fastest inside a box.  An
+    independent numpy statement of it.  Returns (perm, ranges): perm[natural
+    id x + n (y + n z)] = box-partition global id, ranges = row range of each
+    rank."""
+    def cuts(p):
+        q, rem = divmod(n, p)
+        return np.array([k * (q + 1) if k < rem else k * q + rem
+                         for k in range(p + 1)], dtype=np.int64)
+
+    cx, cy, cz = (cuts(p) for p in parts)
+    px, py, pz = parts
+    z, y, x = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+    ix = np.searchsorted(cx, x, side="right") - 1
+    iy = np.searchsorted(cy, y, side="right") - 1
+    iz = np.searchsorted(cz, z, side="right") - 1
+    rank = ix + px * (iy + py * iz)
+    lx, ly, lz = np.diff(cx)[ix], np.diff(cy)[iy], np.diff(cz)[iz]
+    sizes = np.zeros(px * py * pz, np.int64)
+    np.add.at(sizes, rank.ravel(), 1)
+    ranges = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    local = (x - cx[ix]) + lx * ((y - cy[iy]) + ly * (z - cz[iz]))
+    del lz
+    return (ranges[rank] + local).ravel(), ranges
+
+
+def permute_csr(rowptr, colind, values, perm):
+    """P A P^T for new id = perm[old id]; rows' entries ascending by column."""
+    n = len(rowptr) - 1
+    rows = perm[np.repeat(np.arange(n), np.diff(rowptr))]
+    cols = perm[np.asarray(colind, dtype=np.int64)]
+    order = np.lexsort((cols, rows))
+    rp = np.zeros(n + 1, np.int64)
+    np.add.at(rp, rows + 1, 1)
+    return (np.cumsum(rp).astype(np.int32), cols[order].astype(np.int64),
+            np.asarray(values)[order].copy())
