@@ -187,6 +187,12 @@ def kernel_of(A, symmetric):
     y_x = rows * 8 + cols * 8
     if symmetric:
         algo = rows * 8 * 3 + (rows + 1) * 4 + nnz * 12  # SURVEY 8d B_sym
+        if A.plan_get("sdia"):
+            nd = 3
+            return ("csr_sym_dia_kernel<double> (symmetric diagonal form: the "
+                    "plan's copy of the values by offset, own and column windows "
+                    "by LDS-DMA, no index stream, atomic-free, bit-exact)",
+                    algo, rows * (8 * nd + 8 + 1) + y_x)
         if A.plan_get("slat"):
             return ("csr_sym_lattice_kernel<double> (symmetric lattice form: own "
                     "and column value windows by LDS-DMA, no index stream, "
@@ -214,7 +220,7 @@ def plan_record(A):
     return {"plan_ms": A.plan_get("plan_us") / 1e3,
             "plan_extra_bytes": A.plan_get("plan_kib") * 1024,
             "form": {k: A.plan_get(k) for k in
-                     ("lat", "lx", "slat", "sym_det", "band_order")}}
+                     ("lat", "lx", "slat", "sdia", "sym_det", "band_order")}}
 
 
 def pmc_traffic(kernel_name, n, world):

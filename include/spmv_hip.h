@@ -117,7 +117,8 @@ int spmv_hip_copy_peer_async(spmv_hip_ctx* dst_ctx, void* dst,
  * arithmetic csr_kernels.cpp:20-52.
  *
  * plan_create inspects the (device-resident) row pointer once and picks the
- * kernel and launch shape; it stores no copy of the matrix.  `symmetric`
+ * kernel and launch shape; it stores no copy of the matrix (plan_bake_values_*
+ * below is the one, explicit exception).  `symmetric`
  * selects the strictly-lower + diagonal kernel.  rowptr/colind may be NULL
  * when num_non_zeros == 0 (csr_matrix.cpp:34).
  *
@@ -176,6 +177,23 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
                              int symmetric, int algo,
                              spmv_hip_csr_plan** plan);
 int spmv_hip_csr_plan_destroy(spmv_hip_csr_plan* plan);
+/* Optional, symmetric plans in the symmetric lattice form only (else
+ * SPMV_HIP_ENOTSUP): let the plan keep its OWN copy of the matrix values in
+ * the layout its kernel streams best -- one array per lower offset plus the
+ * diagonal ("symmetric diagonal form", a DIA fast path).  This
+ * is what CSRSpMV::init does with the matrix it is given (csr_kernels.h:26-78;
+ * the cuSPARSE descriptor of cuda/csr_kernels.cu binds the values there too).
+ * Costs (offsets + 1) * 8 B per row of device memory.  A launch that passes
+ * these very `values` and `diagonal` pointers takes the diagonal-form kernel
+ * (same bits as every other symmetric kernel); a launch with other pointers
+ * takes the CSR-order kernels as before.  CONTRACT: whoever rewrites the baked
+ * arrays in place bakes again (or drops the copy: values = diagonal = NULL). */
+int spmv_hip_csr_plan_bake_values_f64(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan,
+                                      const double* values,
+                                      const double* diagonal, void* stream);
+int spmv_hip_csr_plan_bake_values_f32(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan,
+                                      const float* values, const float* diagonal,
+                                      void* stream);
 int spmv_hip_csr_plan_algo(const spmv_hip_csr_plan* plan, int* algo);
 /* Knobs (key/value; EINVAL for an unknown key or a value out of range):
  *   "algo" "lanes_per_row" "chunks" "nontemporal" "xcd_group" "blocks_per_cu"
@@ -183,12 +201,13 @@ int spmv_hip_csr_plan_algo(const spmv_hip_csr_plan* plan, int* algo);
  *   "lx" "lx_chunks"                     LX form on/off (built plans only)
  *   "lat" "lat_blocks_per_cu" "lat_xcd_group"      lattice form
  *   "slat" "slat_blocks_per_cu"          symmetric lattice form
+ *   "sdia"                               symmetric diagonal form (baked plans)
  *   "sym_det"                            transposed-map kernel (0: atomics)
  *   "sym_window" "sym_rows"              the atomic symmetric kernels
  *   "band_lines" = lines per band (0 = choose): (re)build the band-sweep
  *                  row-block order of the lattice kernels; "band_order" 0/1 */
 int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value);
-/* What the plan decided and what it cost: "algo"; "lat", "lx", "slat",
+/* What the plan decided and what it cost: "algo"; "lat", "lx", "slat", "sdia",
  * "sym_det" (1 = that form is in use), "lat_blocks", "lx_blocks", "lx_staged";
  * "lattice_d1", "lattice_d2" (row distance of the next grid line / plane when
  * the matrix is a 3-D lattice, else 0), "band_order", "band_lines";

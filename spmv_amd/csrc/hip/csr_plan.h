@@ -4,6 +4,7 @@
 //   spmv_sym.hip   symmetric-storage kernels (csr_kernels.cpp:26-40)
 //   spmv_lat.hip   lattice form: constant column offsets per row block
 //   spmv_symlat.hip  the same idea for the symmetric storage
+//   spmv_symdia.hip  ... with the values re-laid out by offset (baked copy)
 #pragma once
 
 #include "common.h"
@@ -136,6 +137,17 @@ struct spmv_hip_csr_plan {
   int slat_D[3] = {0, 0, 0}, slat_win_of_k[3] = {0, 0, 0};
   int slat_u_of_w[4] = {0, 0, 0, 0};
   int slat_blocks_per_cu = kBlocksPerCU;
+  // symmetric diagonal form (spmv_symdia.hip): the plan's own copy of the
+  // values, one array per lower offset + the diagonal, made by
+  // spmv_hip_csr_plan_bake_values_*; used when a launch passes the baked
+  // pointers
+  void* sdia_val = nullptr;       // (slat_nd + 1) arrays of sdia_len entries
+  uint8_t* sdia_cmask = nullptr;  // per row: own bits 0..2, column bits 4..6
+  int64_t sdia_len = 0;
+  int sdia_elem = 0;              // sizeof the baked value type
+  const void* sdia_values0 = nullptr;
+  const void* sdia_diag0 = nullptr;
+  int sdia = 0;                   // use it (plan_set "sdia")
   int32_t* row_list = nullptr; // ROWLIST: device list of non-empty rows
   int32_t num_listed = 0;
   int nt_store = 0; // non-temporal y stores
@@ -221,6 +233,16 @@ int spmv_slat_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st,
                       const int32_t* rowptr, const float* values,
                       const float* diagonal, float alpha, const float* in,
                       float beta, float* out);
+// spmv_symdia.hip
+void spmv_sdia_free(spmv_hip_csr_plan* pl);
+int spmv_sdia_bake_f64(spmv_hip_csr_plan* pl, const double* values,
+                       const double* diagonal, hipStream_t st);
+int spmv_sdia_bake_f32(spmv_hip_csr_plan* pl, const float* values,
+                       const float* diagonal, hipStream_t st);
+int spmv_sdia_run_f64(const spmv_hip_csr_plan* pl, hipStream_t st, double alpha,
+                      const double* in, double beta, double* out, DotOut dot);
+int spmv_sdia_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st, float alpha,
+                      const float* in, float beta, float* out);
 // spmv_lat.hip
 int spmv_lat_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
                    const int32_t* colind);

@@ -1150,11 +1150,30 @@ int spmv_hip_csr_plan_destroy(spmv_hip_csr_plan* plan)
     free_lx(plan);
     spmv_lat_free(plan);
     spmv_symt_free(plan);
+    spmv_sdia_free(plan);
     spmv_slat_free(plan);
     (void)hipFree(plan->order);
   }
   delete plan;
   return SPMV_HIP_OK;
+}
+
+int spmv_hip_csr_plan_bake_values_f64(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan,
+                                      const double* values,
+                                      const double* diagonal, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(plan && plan->ctx == ctx);
+  return spmv_sdia_bake_f64(plan, values, diagonal, spmv_stream(ctx, stream));
+}
+
+int spmv_hip_csr_plan_bake_values_f32(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan,
+                                      const float* values, const float* diagonal,
+                                      void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(plan && plan->ctx == ctx);
+  return spmv_sdia_bake_f32(plan, values, diagonal, spmv_stream(ctx, stream));
 }
 
 int spmv_hip_csr_plan_algo(const spmv_hip_csr_plan* plan, int* algo)
@@ -1217,6 +1236,10 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
     // 1 needs the symmetric lattice form built at plan creation
     SPMV_REQUIRE(value == 0 || plan->slat_mask);
     plan->slat = value != 0;
+  } else if (!strcmp(key, "sdia")) {
+    SPMV_REQUIRE(value == 0 || value == 1);
+    SPMV_REQUIRE(value == 0 || plan->sdia_val);
+    plan->sdia = value;
   } else if (!strcmp(key, "slat_blocks_per_cu")) {
     SPMV_REQUIRE(value >= 1 && value <= kBlocksPerCU);
     plan->slat_blocks_per_cu = value;
@@ -1250,6 +1273,8 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
     *value = plan->sym_det;
   else if (!strcmp(key, "slat"))
     *value = plan->slat;
+  else if (!strcmp(key, "sdia"))
+    *value = plan->sdia && plan->sdia_val ? 1 : 0;
   else if (!strcmp(key, "plan_us"))
     *value = plan->plan_us;
   else if (!strcmp(key, "plan_kib")) {
@@ -1265,6 +1290,8 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
       b += 48 * nrb + n;
     if (plan->slat_mask)
       b += n;
+    if (plan->sdia_val)
+      b += (int64_t)(plan->slat_nd + 1) * plan->sdia_len * plan->sdia_elem + n;
     if (plan->t_ptr)
       b += 4 * (n + 1) + 8 * nnz;
     if (plan->order)

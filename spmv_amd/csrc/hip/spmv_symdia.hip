@@ -1,0 +1,422 @@
+// Symmetric DIAGONAL form for gfx950 (MI355X): the symmetric lattice form
+// (spmv_symlat.hip) with the matrix VALUES re-laid out by the plan -- one
+// array per lower offset plus the diagonal -- so that the entries a row needs
+// from its column are a plain shifted window of the same arrays.  SURVEY 8f n4
+// ("DIA fast path for stencils") for the symmetric storage of
+// spmv/csr_kernels.cpp:26-40; same arithmetic, same order, same bits.
+//
+// Why: in CSR order a row of the 7-point matrix holds its three lower entries
+// side by side, and row i needs, besides its own, ONE of the three of each of
+// the rows i+1, i+n, i+n^2.  The symmetric lattice kernel therefore pulls
+// three more full value windows per row block (72 B of values per row for 24
+// used) and spends a row pointer, two masks and popcounts per entry to find
+// them (2.55 ms at 512^3, 12.5 GB through the fabric for 8.6 GB algorithmic).
+// By offset, v_k[i] = L(i, i + D[k]):
+//   own entries      v_k[i]            window [r0, r0 + 256) of array k
+//   column entries   v_k[i - D[k]]     window [r0 - D[k], ...) of the SAME array
+// -- the window another row block reads as its own one line / one plane later,
+// which the band-sweep order keeps in the XCD's L2.  No row pointer, no
+// positions: LDS index = window base + lane.  Per row: 24 B of values + 8
+// (diagonal) + 1 (mask) + 8 (x) + 8 (y) = 49 B from HBM.
+//
+// The copy is made by spmv_hip_csr_plan_bake_values_* (the plan's only use of
+// the VALUES; everything else in a plan is structure).  A launch with the
+// baked pointers takes this kernel; any other `values` / `diagonal` pointer
+// takes the CSR-order kernels, so a stale copy can only be used by a caller
+// who rewrites the baked arrays in place without baking again (documented in
+// spmv_hip.h).
+//
+// Kernel skeleton = csr_lattice_kernel (spmv_lat.hip): persistent grid, two
+// LDS slots, all value windows of the NEXT row block by LDS-DMA, x / mask / y0
+// of the next block into registers, one barrier per block.
+#include <chrono>
+
+#include "csr_plan.h"
+#include "lat_dma.h"
+
+namespace
+{
+
+constexpr int kSdiaMaxOff = 3;
+constexpr int kSdiaMaxWin = 2 * kSdiaMaxOff + 1; // own + far per offset, diagonal
+
+struct SdiaGeom {
+  int nd;                 // lower offsets
+  int U[kSdiaMaxOff];     // row distance -D[k] > 0 (D ascending: U descending)
+  int nwin;               // DMA windows per row block
+  int arr[kSdiaMaxWin];   // array of window j (nd = diagonal)
+  int first[kSdiaMaxWin]; // its first row relative to r0
+  int pieces[kSdiaMaxWin];  // 1-KiB DMA pieces (<= 4: one per wave)
+  int lds[kSdiaMaxWin];   // entry offset of the window inside a slot
+  int own_idx[kSdiaMaxOff]; // slot entry of v_k[r0]      (+ lane = own entry)
+  int col_idx[kSdiaMaxOff]; // slot entry of v_k[r0 + U_k] (+ lane = column entry)
+  int d_idx;              // slot entry of d[r0]
+  int slot_entries;
+};
+
+template <typename T>
+struct SdiaRegs {
+  unsigned cm;          // bits 0..2: own entry k, bits 4..6: column entry k
+  T xi, y0;
+  T xl[kSdiaMaxOff];    // x[i - U_k]
+  T xu[kSdiaMaxOff];    // x[i + U_k]
+};
+
+template <typename T>
+__device__ __forceinline__ SdiaRegs<T> sdia_loads(
+    int rb, const SdiaGeom& g, int t, int32_t num_rows,
+    const uint8_t* __restrict__ cmask, const T* __restrict__ in, T beta,
+    const T* __restrict__ out)
+{
+  SdiaRegs<T> q;
+  q.cm = 0;
+  q.xi = q.y0 = T(0);
+#pragma unroll
+  for (int k = 0; k < kSdiaMaxOff; ++k)
+    q.xl[k] = q.xu[k] = T(0);
+  if (rb < 0)
+    return q;
+  const int32_t i = rb * kRows + t;
+  if (i < num_rows) {
+    q.cm = cmask[i];
+    q.xi = in[i];
+    if (beta != T(0))
+      q.y0 = out[i];
+#pragma unroll
+    for (int k = 0; k < kSdiaMaxOff; ++k) {
+      if (k < g.nd) { // uniform
+        // unconditional and clamped: no dependence on the mask load; what the
+        // row does not have is never used
+        const int64_t c = (int64_t)i - g.U[k];
+        q.xl[k] = in[c < 0 ? 0 : c];
+        const int64_t r = (int64_t)i + g.U[k];
+        q.xu[k] = in[r < num_rows ? r : (int64_t)num_rows - 1];
+      }
+    }
+  }
+  return q;
+}
+
+__device__ __forceinline__ int sdia_next_block(const RowBlockOrder& ord, int it,
+                                               int num_slots, int stride,
+                                               int* it_out)
+{
+  int rb = -1;
+  while (it < num_slots) {
+    rb = order_row_block(ord, it);
+    if (rb >= 0)
+      break;
+    it += stride;
+  }
+  *it_out = it;
+  return rb;
+}
+
+template <typename T, bool DOT>
+__global__ __launch_bounds__(kBlock) void csr_sym_dia_kernel(
+    int32_t num_rows, int64_t arr_len, const T* __restrict__ sval,
+    const uint8_t* __restrict__ cmask, T alpha, const T* __restrict__ in, T beta,
+    T* __restrict__ out, DotOut dot, RowBlockOrder ord, SdiaGeom g)
+{
+  constexpr int V = 16 / (int)sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+  __shared__ double s_red[kBlock / 64];
+  T* const s_val = reinterpret_cast<T*>(s_dyn);
+  const unsigned lds0 = (unsigned)(uintptr_t)(
+      (__attribute__((address_space(3))) void*)s_val);
+
+  const int t = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int lane = t & 63;
+  const int stride = gridDim.x;
+  const int num_slots = order_slots(ord);
+  double dot_acc = 0.0;
+
+  // all windows of row block rb -> LDS slot: one piece per wave and window
+  auto issue = [&](int rb, int slot) {
+    const int64_t r0 = (int64_t)rb * kRows;
+#pragma unroll
+    for (int j = 0; j < kSdiaMaxWin; ++j) {
+      if (j < g.nwin && wave < g.pieces[j]) { // uniform
+        const int64_t base = (r0 + g.first[j]) & ~(int64_t)(V - 1);
+        int64_t e = base + (int64_t)(wave * 64 + lane) * V;
+        e = e < arr_len - V ? e : arr_len - V; // arrays are padded with zeros
+        glds16<false>(sval + (int64_t)g.arr[j] * arr_len + e,
+                      lds0
+                          + (unsigned)((slot * g.slot_entries + g.lds[j])
+                                       * (int)sizeof(T))
+                          + (unsigned)wave * 1024u);
+      }
+    }
+  };
+
+  int it = 0, itn = 0;
+  int cur = sdia_next_block(ord, blockIdx.x, num_slots, stride, &it);
+  int nxt = sdia_next_block(ord, it + stride, num_slots, stride, &itn);
+  if (cur >= 0)
+    issue(cur, 0);
+  SdiaRegs<T> qA = sdia_loads<T>(cur, g, t, num_rows, cmask, in, beta, out);
+  SdiaRegs<T> qB;
+  int slot = 0;
+  auto step = [&](const SdiaRegs<T>& q, SdiaRegs<T>& qn) {
+    // everything of this block has landed, all waves have left the previous
+    // one (the builtin, not asm: see csr_lattice_kernel)
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+    __syncthreads();
+    if (nxt >= 0)
+      issue(nxt, slot ^ 1);
+    qn = sdia_loads<T>(nxt, g, t, num_rows, cmask, in, beta, out);
+    int itnn = 0;
+    const int nn = sdia_next_block(ord, itn + stride, num_slots, stride, &itnn);
+    const int32_t i = cur * kRows + t;
+    if (i < num_rows) {
+      const T* sv = s_val + slot * g.slot_entries + t;
+      T vl[kSdiaMaxOff], vu[kSdiaMaxOff];
+#pragma unroll
+      for (int k = 0; k < kSdiaMaxOff; ++k) {
+        vl[k] = vu[k] = T(0);
+        if (k < g.nd) { // uniform
+          vl[k] = sv[g.own_idx[k]];
+          vu[k] = sv[g.col_idx[k]];
+        }
+      }
+      const T d = sv[g.d_idx];
+      T sum = d * q.xi; // csr_kernels.cpp:28
+#pragma unroll
+      for (int k = 0; k < kSdiaMaxOff; ++k)
+        if (k < g.nd && ((q.cm >> k) & 1u)) // :34, left to right
+          sum += vl[k] * q.xl[k];
+      const T c = alpha * sum; // :39
+      T y = c, cy = c;
+      if (beta != T(0))
+        y = c + beta * q.y0;
+      // the column's entries in ascending row order: nearest row first
+#pragma unroll
+      for (int k = kSdiaMaxOff - 1; k >= 0; --k)
+        if (k < g.nd && ((q.cm >> (4 + k)) & 1u)) { // :35
+          const T term = (alpha * vu[k]) * q.xu[k];
+          y += term;
+          cy += term;
+        }
+      out[i] = y;
+      if constexpr (DOT) // in . (alpha A in): the finished row without beta y0
+        dot_acc += (double)q.xi * (double)cy;
+    }
+    slot ^= 1;
+    cur = nxt;
+    nxt = nn;
+    itn = itnn;
+  };
+  while (cur >= 0) {
+    step(qA, qB);
+    if (cur < 0)
+      break;
+    step(qB, qA);
+  }
+  if constexpr (DOT)
+    spmv_dot_epilogue(dot, dot_acc, s_red);
+}
+
+// values in CSR order -> one array per offset (+ the diagonal), zero where a
+// row has no entry; combined mask byte
+template <typename T>
+__global__ __launch_bounds__(kBlock) void sdia_bake_kernel(
+    int32_t num_rows, int nd, int u0, int u1, int u2,
+    const int32_t* __restrict__ rowptr, const uint8_t* __restrict__ mask,
+    const T* __restrict__ values, const T* __restrict__ diagonal,
+    int64_t arr_len, T* __restrict__ sval, uint8_t* __restrict__ cmask)
+{
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < num_rows;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned m = mask[i];
+    int32_t j = rowptr[i];
+    unsigned cm = m;
+    for (int k = 0; k < nd; ++k) {
+      T v = T(0);
+      if ((m >> k) & 1u)
+        v = values[j++];
+      sval[(int64_t)k * arr_len + i] = v;
+      const int64_t r = i + (k == 0 ? u0 : (k == 1 ? u1 : u2));
+      if (r < num_rows && ((mask[r] >> k) & 1u))
+        cm |= 1u << (4 + k);
+    }
+    sval[(int64_t)nd * arr_len + i] = diagonal[i];
+    cmask[i] = (uint8_t)cm;
+  }
+}
+
+// LDS geometry of one slot for element size sizeof(T)
+template <typename T>
+SdiaGeom sdia_geom(const spmv_hip_csr_plan* pl)
+{
+  constexpr int V = 16 / (int)sizeof(T);
+  constexpr int per_piece = 1024 / (int)sizeof(T);
+  SdiaGeom g{};
+  g.nd = pl->slat_nd;
+  int w = 0, entries = 0;
+  auto add = [&](int arr, int first, int rows) {
+    const int lead = first & (V - 1); // alignment slack in front
+    const int pieces = (lead + rows + per_piece - 1) / per_piece;
+    g.arr[w] = arr;
+    g.first[w] = first;
+    g.pieces[w] = pieces;
+    g.lds[w] = entries;
+    entries += pieces * per_piece;
+    ++w;
+    return g.lds[w - 1] + lead; // slot entry of row r0 + first
+  };
+  for (int k = 0; k < g.nd; ++k) {
+    g.U[k] = -pl->slat_D[k];
+    if (g.U[k] < kRows) { // the column window overlaps the own one: extend it
+      g.own_idx[k] = add(k, 0, kRows + g.U[k]);
+      g.col_idx[k] = g.own_idx[k] + g.U[k];
+    } else {
+      g.own_idx[k] = add(k, 0, kRows);
+      g.col_idx[k] = add(k, g.U[k], kRows);
+    }
+  }
+  g.d_idx = add(g.nd, 0, kRows);
+  g.nwin = w;
+  g.slot_entries = entries;
+  return g;
+}
+
+template <typename T>
+int sdia_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha,
+                const T* in, T beta, T* out, DotOut dot)
+{
+  const SdiaGeom g = sdia_geom<T>(pl);
+  const int nrb = (pl->num_rows + kRows - 1) / kRows;
+  const size_t lds = (size_t)2 * g.slot_entries * sizeof(T);
+  int per_cu = (int)((160 * 1024) / (lds + 64));
+  per_cu = per_cu > pl->slat_blocks_per_cu ? pl->slat_blocks_per_cu : per_cu;
+  per_cu = per_cu < 1 ? 1 : per_cu;
+  int grid = pl->ctx->num_cus * per_cu;
+  if (grid > pl->ctx->dot_blocks)
+    grid = pl->ctx->dot_blocks;
+  if (grid > nrb)
+    grid = nrb;
+  if (grid >= 8)
+    grid -= grid % 8;
+  if (grid < 1)
+    grid = 1;
+  RowBlockOrder ord = pl->row_block_order(nrb);
+  ord.xcd_group = pl->lat_xcd_group;
+  if (pl->band_order && pl->order) {
+    ord.table = pl->order;
+    ord.num_slots = pl->order_slots;
+  }
+  const T* sval = static_cast<const T*>(pl->sdia_val);
+  if (dot.partials)
+    hipLaunchKernelGGL((csr_sym_dia_kernel<T, true>), dim3(grid), dim3(kBlock),
+                       lds, st, pl->num_rows, pl->sdia_len, sval, pl->sdia_cmask,
+                       alpha, in, beta, out, dot, ord, g);
+  else
+    hipLaunchKernelGGL((csr_sym_dia_kernel<T, false>), dim3(grid), dim3(kBlock),
+                       lds, st, pl->num_rows, pl->sdia_len, sval, pl->sdia_cmask,
+                       alpha, in, beta, out, dot, ord, g);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+template <typename T>
+int sdia_bake(spmv_hip_csr_plan* pl, const T* values, const T* diagonal,
+              hipStream_t st)
+{
+  SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
+  const auto t_begin = std::chrono::steady_clock::now();
+  spmv_sdia_free(pl);
+  if (values == nullptr && diagonal == nullptr)
+    return SPMV_HIP_OK; // dropped
+  SPMV_REQUIRE(values && diagonal);
+  // the diagonal form rests on the symmetric lattice analysis
+  if (!pl->symmetric || !pl->slat_mask || pl->nnz == 0)
+    return SPMV_HIP_ENOTSUP;
+  const SdiaGeom g = sdia_geom<T>(pl);
+  for (int j = 0; j < g.nwin; ++j)
+    if (g.pieces[j] > kBlock / 64)
+      return SPMV_HIP_ENOTSUP;
+  if ((size_t)2 * g.slot_entries * sizeof(T) > 150 * 1024)
+    return SPMV_HIP_ENOTSUP;
+  const int32_t n = pl->num_rows;
+  // every window of every row block stays inside its array
+  const int64_t len = (((int64_t)n + kRows - 1) / kRows) * kRows + 2 * kRows;
+  const size_t bytes = (size_t)(g.nd + 1) * len * sizeof(T);
+  void* sval = nullptr;
+  uint8_t* cm = nullptr;
+  hipError_t e = hipMalloc(&sval, bytes);
+  if (e == hipSuccess)
+    e = hipMalloc(&cm, (size_t)n);
+  if (e == hipSuccess)
+    e = hipMemsetAsync(sval, 0, bytes, st);
+  if (e == hipSuccess) {
+    const int grid = spmv_grid_for(pl->ctx, n, kBlock);
+    hipLaunchKernelGGL((sdia_bake_kernel<T>), dim3(grid), dim3(kBlock), 0, st, n,
+                       g.nd, g.U[0], g.U[1], g.U[2], pl->rowptr0, pl->slat_mask,
+                       values, diagonal, len, static_cast<T*>(sval), cm);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st);
+  if (e != hipSuccess) {
+    (void)hipFree(sval);
+    (void)hipFree(cm);
+    return static_cast<int>(e);
+  }
+  pl->sdia_val = sval;
+  pl->sdia_cmask = cm;
+  pl->sdia_len = len;
+  pl->sdia_elem = (int)sizeof(T);
+  pl->sdia_values0 = values;
+  pl->sdia_diag0 = diagonal;
+  pl->sdia = 1;
+  pl->plan_us += (int)std::chrono::duration_cast<std::chrono::microseconds>(
+                     std::chrono::steady_clock::now() - t_begin)
+                     .count(); // part of what the plan cost
+  // measured at 512^3 (4 workgroups per CU: 1024 = the row blocks of one
+  // plane, so every workgroup walks straight down z and finds its far column
+  // window in the block it reads next): plain order 1.47 ms, 8 consecutive
+  // row blocks per XCD 1.43, band sweep 1.60
+  pl->band_order = 0;
+  pl->lat_xcd_group = 8;
+  pl->slat_blocks_per_cu = 4;
+  return SPMV_HIP_OK;
+}
+
+} // namespace
+
+void spmv_sdia_free(spmv_hip_csr_plan* pl)
+{
+  (void)hipFree(pl->sdia_val);
+  (void)hipFree(pl->sdia_cmask);
+  pl->sdia_val = nullptr;
+  pl->sdia_cmask = nullptr;
+  pl->sdia_values0 = pl->sdia_diag0 = nullptr;
+  pl->sdia_len = 0;
+  pl->sdia_elem = 0;
+  pl->sdia = 0;
+}
+
+int spmv_sdia_bake_f64(spmv_hip_csr_plan* pl, const double* values,
+                       const double* diagonal, hipStream_t st)
+{
+  return sdia_bake<double>(pl, values, diagonal, st);
+}
+
+int spmv_sdia_bake_f32(spmv_hip_csr_plan* pl, const float* values,
+                       const float* diagonal, hipStream_t st)
+{
+  return sdia_bake<float>(pl, values, diagonal, st);
+}
+
+int spmv_sdia_run_f64(const spmv_hip_csr_plan* pl, hipStream_t st, double alpha,
+                      const double* in, double beta, double* out, DotOut dot)
+{
+  return sdia_launch<double>(pl, st, alpha, in, beta, out, dot);
+}
+
+int spmv_sdia_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st, float alpha,
+                      const float* in, float beta, float* out)
+{
+  return sdia_launch<float>(pl, st, alpha, in, beta, out, DotOut());
+}

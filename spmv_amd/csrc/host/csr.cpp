@@ -29,6 +29,25 @@ void CSRSpMV<T>::init(int32_t num_rows, int32_t num_cols,
 }
 
 template <typename T>
+bool CSRSpMV<T>::bake_values(const T* values, const T* diagonal,
+                             const HipExecutor& exec) const
+{
+  if (!plan() || !values || !diagonal)
+    return false;
+  int rc;
+  if constexpr (std::is_same<T, double>::value)
+    rc = spmv_hip_csr_plan_bake_values_f64(exec.context(), plan(), values,
+                                           diagonal, nullptr);
+  else
+    rc = spmv_hip_csr_plan_bake_values_f32(exec.context(), plan(), values,
+                                           diagonal, nullptr);
+  if (rc == SPMV_HIP_ENOTSUP)
+    return false;
+  throw_on_error(rc, "spmv_hip_csr_plan_bake_values");
+  return true;
+}
+
+template <typename T>
 void CSRSpMV<T>::run(int32_t num_rows, int32_t num_cols, int64_t num_non_zeros,
                      const int32_t* rowptr, const int32_t* colind,
                      const T* values, const T* diagonal, T alpha, T* in, T beta,

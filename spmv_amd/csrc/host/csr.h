@@ -42,6 +42,13 @@ public:
            const T* diagonal, T alpha, T* in, T beta, T* out,
            const HipExecutor& exec) const;
   void finalize(const HipExecutor& exec) const;
+  // Second half of init for a symmetric block (the reference's init sees the
+  // values, csr_kernels.h:28; the diagonal lives in SubMatrix): lets the plan
+  // keep the values by offset (spmv_hip_csr_plan_bake_values_*).  Returns
+  // false, and changes nothing, when the block is not in the symmetric
+  // lattice form.
+  bool bake_values(const T* values, const T* diagonal,
+                   const HipExecutor& exec) const;
 
   // Extension used by cg(): same as run() and additionally emits the
   // per-workgroup partial sums of sum_i in[i]*(alpha*(A in)_i) into

@@ -97,6 +97,13 @@ class Context:
             self.stream_sync()  # arr may be a temporary
         return b
 
+    def copy_h2d(self, dst_ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        if arr.nbytes:
+            call("spmv_hip_copy_h2d_async", self.h, dst_ptr,
+                 arr.ctypes.data_as(C.c_void_p), arr.nbytes, None)
+            self.stream_sync()
+
     def copy(self, dst, src, nbytes, stream=None):
         call("spmv_hip_copy_d2d_async", self.h, dst, src, nbytes, stream)
 
@@ -202,6 +209,14 @@ class CsrBlock:
              self.nnz, _p(self.rowptr), _p(self.colind), int(self.symmetric),
              algo, C.byref(plan))
         self.plan = plan
+
+    def bake(self, drop=False):
+        """spmv_hip_csr_plan_bake_values_*: the plan's own copy of the values
+        by offset (symmetric diagonal form)."""
+        name = ("spmv_hip_csr_plan_bake_values_f64" if self.dtype == np.float64
+                else "spmv_hip_csr_plan_bake_values_f32")
+        call(name, self.ctx.h, self.plan, None if drop else _p(self.values),
+             None if drop else _p(self.diagonal), None)
 
     def set(self, key, value):
         call("spmv_hip_csr_plan_set", self.plan, key.encode(), int(value))

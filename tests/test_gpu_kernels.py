@@ -1084,6 +1084,98 @@ def test_symmetric_lattice_form_bit_exact(lat_ctx, dtype):
         blk.free()
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_symmetric_diagonal_form_bit_exact(lat_ctx, dtype):
+    """spmv_hip_csr_plan_bake_values_*: values re-laid out by offset.  Same bits
+    as the reference for every offset geometry (merged / separate / misaligned
+    windows), missing entries, ragged tails; a launch with other pointers, or
+    with the form switched off, takes the CSR-order kernel; baking again picks
+    up rewritten values."""
+    ctx = lat_ctx
+    rng = np.random.default_rng(97)
+    cases = []
+    for n in (4, 9, 16, 33):
+        rp, ci, va = poisson.poisson3d_csr(n)
+        cases.append((f"poisson{n}", *lower_split(rp, ci.astype(np.int32), va), n ** 3))
+    rp, ci, va = oracle.tridiag_csr(70001)
+    cases.append(("tridiag", *lower_split(rp, ci, va), 70001))
+    N = 9001
+    rp, ci, va = _stencil_csr(rng, N, [-2000, -300, -1], drop=0.33)
+    cases.append(("far3", rp, ci, va, rng.uniform(1, 2, N), N))
+    N = 7013  # odd far offsets (misaligned windows), one merged offset of 255
+    rp, ci, va = _stencil_csr(rng, N, [-1001, -257, -255], drop=0.2)
+    cases.append(("odd", rp, ci, va, rng.uniform(1, 2, N), N))
+    N = 700  # two offsets, fewer rows than the far offset reaches
+    rp, ci, va = _stencil_csr(rng, N, [-650, -3], drop=0.1)
+    cases.append(("short", rp, ci, va, rng.uniform(1, 2, N), N))
+    for name, lrp, lci, lva, dg, N in cases:
+        lva, dg = lva.astype(dtype), np.asarray(dg).astype(dtype)
+        x = rng.uniform(-1, 1, N).astype(dtype)
+        y0 = rng.uniform(-1, 1, N).astype(dtype)
+        blk = hip.CsrBlock(ctx, N, N, lrp, lci, lva, dg, True, hip.ALGO_AUTO, dtype)
+        assert blk.get("slat") == 1 and blk.get("sdia") == 0, name
+        with pytest.raises(Exception):
+            blk.set("sdia", 1)  # nothing baked yet
+        kib0 = blk.get("plan_kib")
+        blk.bake()
+        assert blk.get("sdia") == 1, name
+        assert blk.get("plan_kib") > kib0
+        dx = ctx.upload(x, dtype)
+        part = ctx.empty(ctx.dot_partials_len, np.float64)
+        for alpha, beta in ((1.0, 0.0), (-0.5, 0.0), (2.0, 1.0), (1.0, -0.25)):
+            y_ref = oracle.csr_spmv_sym(lrp, lci, lva, dg, x, alpha, beta, y0)
+            for knobs in (dict(), dict(slat_blocks_per_cu=1), dict(lat_xcd_group=3),
+                          dict(sdia=0), dict(sdia=1, slat_blocks_per_cu=8,
+                                             lat_xcd_group=0)):
+                for k, v in knobs.items():
+                    blk.set(k, v)
+                dy = ctx.upload(np.full(N, np.nan, dtype) if beta == 0 else y0, dtype)
+                dot = dtype == np.float64 and beta == 0.0
+                blk.mult(alpha, dx.ptr, beta, dy.ptr,
+                         dot_partials=part.ptr if dot else None)
+                y = dy.numpy()
+                dy.free()
+                assert np.array_equal(y, y_ref), (name, alpha, beta, knobs)
+                if dot:
+                    want = float(np.dot(x.astype(np.float64), y_ref))
+                    got = float(np.sum(part.numpy()))
+                    scale = float(np.abs(x) @ np.abs(y_ref)) + 1e-300
+                    assert abs(got - want) <= 1e-12 * scale, (name, knobs)
+        # the baked copy is the plan's own: new values in place are seen only
+        # after baking again; other pointers never use it
+        lva2 = (lva * dtype(1.5)).astype(dtype)
+        dg2 = (dg + dtype(1)).astype(dtype)
+        y_old = oracle.csr_spmv_sym(lrp, lci, lva, dg, x)
+        y_new = oracle.csr_spmv_sym(lrp, lci, lva2, dg2, x)
+        ctx.copy_h2d(blk.values.ptr, lva2)
+        ctx.copy_h2d(blk.diagonal.ptr, dg2)
+        dy = ctx.upload(np.full(N, np.nan, dtype), dtype)
+        blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+        assert np.array_equal(dy.numpy(), y_old), name   # stale by contract
+        blk.bake()
+        blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+        assert np.array_equal(dy.numpy(), y_new), name
+        other = ctx.upload(lva, dtype)                   # another values array
+        keep = blk.values
+        blk.values = other
+        blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+        assert np.array_equal(dy.numpy(),
+                              oracle.csr_spmv_sym(lrp, lci, lva, dg2, x)), name
+        blk.values = keep
+        blk.bake(drop=True)
+        assert blk.get("sdia") == 0
+        blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+        assert np.array_equal(dy.numpy(), y_new), name
+        other.free(), dy.free(), dx.free(), part.free()
+        blk.free()
+    # not in the symmetric lattice form: nothing to bake
+    rp, ci, va = _stencil_csr(rng, 5000, [-700, -30, -2, -1])
+    blk = hip.CsrBlock(ctx, 5000, 5000, rp, ci, va, rng.uniform(1, 2, 5000), True)
+    with pytest.raises(Exception):
+        blk.bake()
+    blk.free()
+
+
 def test_symmetric_lattice_form_is_refused_when_it_does_not_apply(lat_ctx):
     """Four lower offsets, unsorted rows, an entry on or above the diagonal:
     the plan falls back to the transposed map (or, not strictly lower, to the
