@@ -190,6 +190,18 @@ struct spmv_hip_csr_plan {
   int lattice_d1 = 0, lattice_d2 = 0;    // line and plane distance (rows)
   int band_order = 0;                    // use the table (plan_set)
 
+  // Plane-walk order (spmv_zwalk_order_build): every workgroup of a grid of
+  // zw_grid walks one 256-row column of the lattice from plane to plane, so the
+  // windows one plane ahead (x, and the symmetric forms' column values) are
+  // the ones it -- or a neighbour on the same XCD -- loads as its own one step
+  // later.  The table is tied to the grid size.
+  int32_t* zw_table = nullptr;
+  int zw_slots = 0;
+  int zw_grid = 0;
+  int zw_segments = 0; // runs the plane axis is cut into
+  int64_t zw_d2 = 0;   // plane distance the last build was asked for
+  int zwalk = 0;       // use the table (plan_set "zwalk")
+
   RowBlockOrder row_block_order(int nrb) const
   {
     RowBlockOrder o;
@@ -221,6 +233,13 @@ void spmv_symt_free(spmv_hip_csr_plan* pl);
 // spmv_csr.hip: (re)build the band-sweep table for bands of `yc` lines
 // (0 = choose); needs lattice_d1 / lattice_d2
 int spmv_band_order_build(spmv_hip_csr_plan* pl, int yc);
+// spmv_csr.hip: (re)build the plane-walk table for planes `d2` rows apart, a
+// grid of `grid` workgroups and `segments` runs along the plane axis (0 =
+// choose); leaves zw_table null when the lattice is too small for it to pay
+// (unless `force`)
+int spmv_zwalk_order_build(spmv_hip_csr_plan* pl, int64_t d2, int grid,
+                           int segments, bool force);
+void spmv_zwalk_free(spmv_hip_csr_plan* pl);
 // spmv_symlat.hip
 int spmv_slat_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
                     const int32_t* colind);
@@ -239,6 +258,7 @@ int spmv_sdia_bake_f64(spmv_hip_csr_plan* pl, const double* values,
                        const double* diagonal, hipStream_t st);
 int spmv_sdia_bake_f32(spmv_hip_csr_plan* pl, const float* values,
                        const float* diagonal, hipStream_t st);
+int spmv_sdia_grid(const spmv_hip_csr_plan* pl); // launch grid without a table
 int spmv_sdia_run_f64(const spmv_hip_csr_plan* pl, hipStream_t st, double alpha,
                       const double* in, double beta, double* out, DotOut dot);
 int spmv_sdia_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st, float alpha,

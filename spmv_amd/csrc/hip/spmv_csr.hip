@@ -1046,6 +1046,108 @@ int spmv_band_order_build(spmv_hip_csr_plan* pl, int yc)
   return SPMV_HIP_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Plane-walk order.  Planes are d2 rows apart; plane z owns the row blocks
+// [B_z, B_{z+1}), B_z = ceil(z d2 / 256), and its c-th block is "column" c.  A
+// walker (segment q, column c) visits column c of the planes of segment q in
+// ascending z; walkers are dealt to the `grid` workgroups in rounds, 8
+// consecutive columns to one XCD.  Slot layout: ((round * L + step) * grid +
+// workgroup), L = planes per segment.  One segment (512^3 on 1024 workgroups:
+// the identity order) keeps every far window in the workgroup's own next
+// block; more segments trade a little of that for balance when the columns do
+// not fill the grid evenly.  Like every order table: a permutation of the row
+// blocks plus empty slots -- it changes speed, never results.
+// ---------------------------------------------------------------------------
+void spmv_zwalk_free(spmv_hip_csr_plan* pl)
+{
+  (void)hipFree(pl->zw_table);
+  pl->zw_table = nullptr;
+  pl->zw_slots = pl->zw_grid = pl->zw_segments = 0;
+  pl->zwalk = 0; // zw_d2 stays: a knob can rebuild
+}
+
+int spmv_zwalk_order_build(spmv_hip_csr_plan* pl, int64_t d2, int grid,
+                           int segments, bool force)
+{
+  SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
+  if (pl->zw_table) {
+    SPMV_CHECK_HIP(hipDeviceSynchronize()); // no launch still reads the old one
+    spmv_zwalk_free(pl);
+  }
+  const int64_t nrb = ((int64_t)pl->num_rows + kRows - 1) / kRows;
+  SPMV_REQUIRE(d2 > 0 && grid > 0 && segments >= 0);
+  pl->zw_d2 = d2;
+  const int64_t nz = ((int64_t)pl->num_rows + d2 - 1) / d2;
+  const int64_t P = (d2 + kRows - 1) / kRows; // columns
+  // worth it only for a real 3-D (or wide 2-D) lattice that outgrows the grid
+  if (!force && (P < 8 || nz < 8 || nrb < 4 * (int64_t)grid))
+    return SPMV_HIP_OK;
+  auto first_block = [&](int64_t z) {
+    const int64_t b = (z * d2 + kRows - 1) / kRows;
+    return b < nrb ? b : nrb;
+  };
+  int64_t Q = segments;
+  if (Q == 0) {
+    // steps per workgroup = rounds * L, a step without the plane-ahead reuse
+    // (the first of every run) counted as 1.3 steps
+    double best = 0.0;
+    for (int64_t q = 1; q <= nz; q *= 2) {
+      const int64_t L = (nz + q - 1) / q;
+      if (L < 4 && q > 1)
+        break;
+      const int64_t rounds = (q * P + grid - 1) / grid;
+      const double cost = (double)rounds * ((double)L + 0.3);
+      if (Q == 0 || cost < best) {
+        best = cost;
+        Q = q;
+      }
+    }
+  }
+  const int64_t L = (nz + Q - 1) / Q;
+  Q = (nz + L - 1) / L; // no empty segments
+  const int64_t W = Q * P;
+  const int64_t rounds = (W + grid - 1) / grid;
+  const int64_t slots = rounds * L * grid;
+  if (slots > INT32_MAX)
+    return SPMV_HIP_OK;
+  const int g = 8; // consecutive columns per XCD
+  const bool by_xcd = grid % (8 * g) == 0;
+  std::vector<int32_t> table((size_t)slots, -1);
+  for (int64_t r = 0; r < rounds; ++r)
+    for (int w = 0; w < grid; ++w) {
+      int64_t idx = w;
+      if (by_xcd) {
+        const int x = w % 8, m = w / 8;
+        idx = (int64_t)(m / g) * (8 * g) + x * g + (m % g);
+      }
+      const int64_t v = r * grid + idx;
+      if (v >= W)
+        continue;
+      const int64_t q = v / P, c = v % P;
+      for (int64_t s = 0; s < L; ++s) {
+        const int64_t z = q * L + s;
+        if (z >= nz)
+          break;
+        const int64_t b = first_block(z) + c;
+        if (b < first_block(z + 1))
+          table[(size_t)((r * L + s) * grid + w)] = (int32_t)b;
+      }
+    }
+  SPMV_CHECK_HIP(hipMalloc(&pl->zw_table, sizeof(int32_t) * table.size()));
+  hipError_t e = hipMemcpy(pl->zw_table, table.data(),
+                           sizeof(int32_t) * table.size(),
+                           hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    spmv_zwalk_free(pl);
+    return static_cast<int>(e);
+  }
+  pl->zw_slots = (int)slots;
+  pl->zw_grid = grid;
+  pl->zw_segments = (int)Q;
+  pl->zwalk = 1;
+  return SPMV_HIP_OK;
+}
+
 extern "C" {
 
 int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
@@ -1144,7 +1246,7 @@ int spmv_hip_csr_plan_destroy(spmv_hip_csr_plan* plan)
 {
   if (plan
       && (plan->row_list || plan->lx_lidx || plan->lat_tab || plan->t_ptr
-          || plan->slat_mask || plan->order)) {
+          || plan->slat_mask || plan->order || plan->zw_table)) {
     (void)hipSetDevice(plan->ctx->device);
     (void)hipFree(plan->row_list);
     free_lx(plan);
@@ -1152,6 +1254,7 @@ int spmv_hip_csr_plan_destroy(spmv_hip_csr_plan* plan)
     spmv_symt_free(plan);
     spmv_sdia_free(plan);
     spmv_slat_free(plan);
+    spmv_zwalk_free(plan);
     (void)hipFree(plan->order);
   }
   delete plan;
@@ -1243,6 +1346,18 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
   } else if (!strcmp(key, "slat_blocks_per_cu")) {
     SPMV_REQUIRE(value >= 1 && value <= kBlocksPerCU);
     plan->slat_blocks_per_cu = value;
+    if (plan->zw_table && plan->sdia_val) // the table is tied to the grid
+      return spmv_zwalk_order_build(plan, plan->zw_d2, spmv_sdia_grid(plan),
+                                    0, true);
+  } else if (!strcmp(key, "zwalk")) {
+    SPMV_REQUIRE(value == 0 || plan->zw_table);
+    plan->zwalk = value != 0;
+  } else if (!strcmp(key, "zwalk_segments")) {
+    // (re)build the plane-walk table of the symmetric diagonal form with
+    // `value` runs along the plane axis (0 = choose), whatever the size
+    SPMV_REQUIRE(value >= 0 && plan->sdia_val && plan->zw_d2 > 0);
+    return spmv_zwalk_order_build(plan, plan->zw_d2, spmv_sdia_grid(plan),
+                                  value, true);
   } else if (!strcmp(key, "sym_det")) {
     // 1 needs the transposed map built at plan creation
     SPMV_REQUIRE(value == 0 || plan->t_ptr);
@@ -1296,12 +1411,20 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
       b += 4 * (n + 1) + 8 * nnz;
     if (plan->order)
       b += 4 * (int64_t)plan->order_slots;
+    if (plan->zw_table)
+      b += 4 * (int64_t)plan->zw_slots;
     *value = (int)((b + 1023) / 1024);
   }
   else if (!strcmp(key, "band_order"))
     *value = plan->band_order && plan->order ? 1 : 0;
   else if (!strcmp(key, "band_lines"))
     *value = plan->order ? plan->band_lines : 0;
+  else if (!strcmp(key, "zwalk"))
+    *value = plan->zwalk && plan->zw_table ? 1 : 0;
+  else if (!strcmp(key, "zwalk_segments"))
+    *value = plan->zw_table ? plan->zw_segments : 0;
+  else if (!strcmp(key, "zwalk_grid"))
+    *value = plan->zw_table ? plan->zw_grid : 0;
   else if (!strcmp(key, "lattice_d1"))
     *value = plan->lattice_d1;
   else if (!strcmp(key, "lattice_d2"))

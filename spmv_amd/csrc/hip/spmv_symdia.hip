@@ -97,19 +97,26 @@ __device__ __forceinline__ SdiaRegs<T> sdia_loads(
   return q;
 }
 
-__device__ __forceinline__ int sdia_next_block(const RowBlockOrder& ord, int it,
-                                               int num_slots, int stride,
-                                               int* it_out)
+// Row block of slot `it`, -1 for an empty slot or past the end.  No search for
+// the next non-empty slot: an empty slot is a step without work.  With an
+// order table the entry is a global load; sdia_slot_raw issues it two steps
+// ahead into a (uniform) vector register and sdia_slot_decode reads it after
+// the step's own vmcnt(0), so that it is never waited for by itself.
+__device__ __forceinline__ int sdia_slot_raw(const RowBlockOrder& ord, int it,
+                                             int num_slots)
 {
-  int rb = -1;
-  while (it < num_slots) {
-    rb = order_row_block(ord, it);
-    if (rb >= 0)
-      break;
-    it += stride;
-  }
-  *it_out = it;
-  return rb;
+  if (it >= num_slots)
+    return -1;
+  if (ord.table)
+    return ord.table[it];
+  RowBlockOrder o = ord;
+  o.num_row_blocks = INT32_MAX; // bounds are checked by decode
+  return order_row_block(o, it);
+}
+__device__ __forceinline__ int sdia_slot_decode(const RowBlockOrder& ord, int raw)
+{
+  const int rb = __builtin_amdgcn_readfirstlane(raw);
+  return rb < ord.num_row_blocks ? rb : -1;
 }
 
 template <typename T, bool DOT>
@@ -150,9 +157,9 @@ __global__ __launch_bounds__(kBlock) void csr_sym_dia_kernel(
     }
   };
 
-  int it = 0, itn = 0;
-  int cur = sdia_next_block(ord, blockIdx.x, num_slots, stride, &it);
-  int nxt = sdia_next_block(ord, it + stride, num_slots, stride, &itn);
+  int it = blockIdx.x;
+  int cur = sdia_slot_decode(ord, sdia_slot_raw(ord, it, num_slots));
+  int nxt_raw = sdia_slot_raw(ord, it + stride, num_slots);
   if (cur >= 0)
     issue(cur, 0);
   SdiaRegs<T> qA = sdia_loads<T>(cur, g, t, num_rows, cmask, in, beta, out);
@@ -163,13 +170,13 @@ __global__ __launch_bounds__(kBlock) void csr_sym_dia_kernel(
     // one (the builtin, not asm: see csr_lattice_kernel)
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
     __syncthreads();
+    const int nxt = sdia_slot_decode(ord, nxt_raw);
+    const int nn_raw = sdia_slot_raw(ord, it + 2 * stride, num_slots);
     if (nxt >= 0)
       issue(nxt, slot ^ 1);
     qn = sdia_loads<T>(nxt, g, t, num_rows, cmask, in, beta, out);
-    int itnn = 0;
-    const int nn = sdia_next_block(ord, itn + stride, num_slots, stride, &itnn);
     const int32_t i = cur * kRows + t;
-    if (i < num_rows) {
+    if (cur >= 0 && i < num_rows) {
       const T* sv = s_val + slot * g.slot_entries + t;
       T vl[kSdiaMaxOff], vu[kSdiaMaxOff];
 #pragma unroll
@@ -204,12 +211,12 @@ __global__ __launch_bounds__(kBlock) void csr_sym_dia_kernel(
     }
     slot ^= 1;
     cur = nxt;
-    nxt = nn;
-    itn = itnn;
+    nxt_raw = nn_raw;
+    it += stride;
   };
-  while (cur >= 0) {
+  while (it < num_slots) {
     step(qA, qB);
-    if (cur < 0)
+    if (it >= num_slots)
       break;
     step(qB, qA);
   }
@@ -281,9 +288,9 @@ SdiaGeom sdia_geom(const spmv_hip_csr_plan* pl)
   return g;
 }
 
+// launch grid of the baked element type
 template <typename T>
-int sdia_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha,
-                const T* in, T beta, T* out, DotOut dot)
+int sdia_grid(const spmv_hip_csr_plan* pl)
 {
   const SdiaGeom g = sdia_geom<T>(pl);
   const int nrb = (pl->num_rows + kRows - 1) / kRows;
@@ -298,13 +305,22 @@ int sdia_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha,
     grid = nrb;
   if (grid >= 8)
     grid -= grid % 8;
-  if (grid < 1)
-    grid = 1;
+  return grid < 1 ? 1 : grid;
+}
+
+template <typename T>
+int sdia_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha,
+                const T* in, T beta, T* out, DotOut dot)
+{
+  const SdiaGeom g = sdia_geom<T>(pl);
+  const int nrb = (pl->num_rows + kRows - 1) / kRows;
+  const size_t lds = (size_t)2 * g.slot_entries * sizeof(T);
+  const int grid = sdia_grid<T>(pl);
   RowBlockOrder ord = pl->row_block_order(nrb);
   ord.xcd_group = pl->lat_xcd_group;
-  if (pl->band_order && pl->order) {
-    ord.table = pl->order;
-    ord.num_slots = pl->order_slots;
+  if (pl->zwalk && pl->zw_table && pl->zw_grid == grid) {
+    ord.table = pl->zw_table;
+    ord.num_slots = pl->zw_slots;
   }
   const T* sval = static_cast<const T*>(pl->sdia_val);
   if (dot.partials)
@@ -380,7 +396,9 @@ int sdia_bake(spmv_hip_csr_plan* pl, const T* values, const T* diagonal,
   pl->band_order = 0;
   pl->lat_xcd_group = 8;
   pl->slat_blocks_per_cu = 4;
-  return SPMV_HIP_OK;
+  // the plane-walk order makes that true for every size (planes = the
+  // farthest offset apart)
+  return spmv_zwalk_order_build(pl, g.U[0], sdia_grid<T>(pl), 0, false);
 }
 
 } // namespace
@@ -395,6 +413,13 @@ void spmv_sdia_free(spmv_hip_csr_plan* pl)
   pl->sdia_len = 0;
   pl->sdia_elem = 0;
   pl->sdia = 0;
+  spmv_zwalk_free(pl);
+  pl->zw_d2 = 0;
+}
+
+int spmv_sdia_grid(const spmv_hip_csr_plan* pl)
+{
+  return pl->sdia_elem == 4 ? sdia_grid<float>(pl) : sdia_grid<double>(pl);
 }
 
 int spmv_sdia_bake_f64(spmv_hip_csr_plan* pl, const double* values,

@@ -1124,9 +1124,14 @@ def test_symmetric_diagonal_form_bit_exact(lat_ctx, dtype):
         part = ctx.empty(ctx.dot_partials_len, np.float64)
         for alpha, beta in ((1.0, 0.0), (-0.5, 0.0), (2.0, 1.0), (1.0, -0.25)):
             y_ref = oracle.csr_spmv_sym(lrp, lci, lva, dg, x, alpha, beta, y0)
+            # zwalk_segments forces the plane-walk table (built on its own
+            # only for large lattices): a permutation of the row blocks
             for knobs in (dict(), dict(slat_blocks_per_cu=1), dict(lat_xcd_group=3),
                           dict(sdia=0), dict(sdia=1, slat_blocks_per_cu=8,
-                                             lat_xcd_group=0)):
+                                             lat_xcd_group=0),
+                          dict(zwalk_segments=0), dict(zwalk_segments=1),
+                          dict(slat_blocks_per_cu=2, zwalk_segments=3),
+                          dict(zwalk=0)):
                 for k, v in knobs.items():
                     blk.set(k, v)
                 dy = ctx.upload(np.full(N, np.nan, dtype) if beta == 0 else y0, dtype)
@@ -1136,6 +1141,10 @@ def test_symmetric_diagonal_form_bit_exact(lat_ctx, dtype):
                 y = dy.numpy()
                 dy.free()
                 assert np.array_equal(y, y_ref), (name, alpha, beta, knobs)
+                if "zwalk_segments" in knobs:
+                    assert blk.get("zwalk") == 1 and blk.get("zwalk_grid") > 0
+                    if knobs["zwalk_segments"]:
+                        assert blk.get("zwalk_segments") <= knobs["zwalk_segments"]
                 if dot:
                     want = float(np.dot(x.astype(np.float64), y_ref))
                     got = float(np.sum(part.numpy()))
