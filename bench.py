@@ -585,8 +585,9 @@ def main():
                     "frac_requested": req2 / ms2 / 1e6 / HBM_PEAK_GBS,
                     "parity": "bit-exact vs the oracle (atomic-free)"
                     if "atomic-free" in kern2 else "tolerance (atomics)",
-                    "cg_rel_residual_k10": float(h2[min(10, len(h2) - 1)] / h2[0]),
-                    "traffic": None, "traffic_source": None}
+                    "cg_rel_residual_k10": float(h2[min(10, len(h2) - 1)] / h2[0])}
+                (out["symmetric"]["traffic"],
+                 out["symmetric"]["traffic_source"]) = pmc_traffic(kern2, n, world)
                 out["symmetric"].update(plan_record(As))
                 ws2.close()
                 As.close()

@@ -201,7 +201,11 @@ int spmv_hip_csr_plan_algo(const spmv_hip_csr_plan* plan, int* algo);
  *   "lx" "lx_chunks"                     LX form on/off (built plans only)
  *   "lat" "lat_blocks_per_cu" "lat_xcd_group"      lattice form
  *   "slat" "slat_blocks_per_cu"          symmetric lattice form
- *   "sdia"                               symmetric diagonal form (baked plans)
+ *   "sdia" "sdia_chain" "sdia_nt"        symmetric diagonal form (baked plans):
+ *                  on/off, plane chain on/off, non-temporal streams (bit mask)
+ *   "zwalk" "zwalk_segments"             its plane-walk row-block order: use the
+ *                  table; (re)build it with that many runs along the plane axis
+ *                  (0 = choose), whatever the size of the matrix
  *   "sym_det"                            transposed-map kernel (0: atomics)
  *   "sym_window" "sym_rows"              the atomic symmetric kernels
  *   "band_lines" = lines per band (0 = choose): (re)build the band-sweep
@@ -210,7 +214,7 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value);
 /* What the plan decided and what it cost: "algo"; "lat", "lx", "slat", "sdia",
  * "sym_det" (1 = that form is in use), "lat_blocks", "lx_blocks", "lx_staged";
  * "lattice_d1", "lattice_d2" (row distance of the next grid line / plane when
- * the matrix is a 3-D lattice, else 0), "band_order", "band_lines";
+ * the matrix is a 3-D lattice, else 0), "band_order", "band_lines", "zwalk", "zwalk_segments", "zwalk_grid";
  * "blocks_per_cu", "nontemporal"; "plan_us" (wall time of plan creation, its
  * analysis kernels included) and "plan_kib" (device memory the plan owns). */
 int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,

@@ -148,6 +148,10 @@ struct spmv_hip_csr_plan {
   const void* sdia_values0 = nullptr;
   const void* sdia_diag0 = nullptr;
   int sdia = 0;                   // use it (plan_set "sdia")
+  int sdia_chain = 1;             // plane chain where the geometry allows
+  // non-temporal streams (bit mask, see sdia_geom).  512^3: ring planes and
+  // diagonal -0.5 %, y stores +-0, the far windows two workgroups share +10 %
+  int sdia_nt = 3;
   int32_t* row_list = nullptr; // ROWLIST: device list of non-empty rows
   int32_t num_listed = 0;
   int nt_store = 0; // non-temporal y stores

@@ -1349,6 +1349,15 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
     if (plan->zw_table && plan->sdia_val) // the table is tied to the grid
       return spmv_zwalk_order_build(plan, plan->zw_d2, spmv_sdia_grid(plan),
                                     0, true);
+  } else if (!strcmp(key, "sdia_nt")) {
+    SPMV_REQUIRE(value >= 0 && value < 32);
+    plan->sdia_nt = value;
+  } else if (!strcmp(key, "sdia_chain")) {
+    SPMV_REQUIRE(value == 0 || value == 1);
+    plan->sdia_chain = value; // LDS footprint, hence the grid, may change
+    if (plan->zw_table && plan->sdia_val)
+      return spmv_zwalk_order_build(plan, plan->zw_d2, spmv_sdia_grid(plan),
+                                    0, true);
   } else if (!strcmp(key, "zwalk")) {
     SPMV_REQUIRE(value == 0 || plan->zw_table);
     plan->zwalk = value != 0;
@@ -1419,6 +1428,10 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
     *value = plan->band_order && plan->order ? 1 : 0;
   else if (!strcmp(key, "band_lines"))
     *value = plan->order ? plan->band_lines : 0;
+  else if (!strcmp(key, "sdia_chain"))
+    *value = plan->sdia_chain;
+  else if (!strcmp(key, "sdia_nt"))
+    *value = plan->sdia_nt;
   else if (!strcmp(key, "zwalk"))
     *value = plan->zwalk && plan->zw_table ? 1 : 0;
   else if (!strcmp(key, "zwalk_segments"))

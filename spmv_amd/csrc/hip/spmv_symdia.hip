@@ -14,10 +14,24 @@
 // By offset, v_k[i] = L(i, i + D[k]):
 //   own entries      v_k[i]            window [r0, r0 + 256) of array k
 //   column entries   v_k[i - D[k]]     window [r0 - D[k], ...) of the SAME array
-// -- the window another row block reads as its own one line / one plane later,
-// which the band-sweep order keeps in the XCD's L2.  No row pointer, no
-// positions: LDS index = window base + lane.  Per row: 24 B of values + 8
-// (diagonal) + 1 (mask) + 8 (x) + 8 (y) = 49 B from HBM.
+// -- the window another row block reads as its own one line / one plane later.
+// No row pointer, no positions: LDS index = window base + lane.  Per row: 24 B
+// of values + 8 (diagonal) + 1 (mask) + 8 (x) + 8 (y) = 49 B from HBM.
+//
+// Order and reuse: the plane-walk table (spmv_zwalk_order_build) lets every
+// workgroup walk one 256-row column of the lattice from plane to plane; where
+// the planes are a whole number of row blocks apart the kernel then CHAINS the
+// planes (RING kernels below): the far window of the farthest offset and the x
+// of the plane ahead are handed to the next step in LDS / registers instead of
+// being loaded again.
+//
+// Measured at 512^3 (MI355X, profiles/r02_pmc_symdia_512.json): 1.33-1.36 ms
+// = 0.79-0.80 of the symmetric-CSR roofline; 7.45 GB read + 1.07 GB written
+// through the fabric for 5.50 + 1.07 unique, i.e. 6.3 TB/s of real traffic --
+// the rate the general lattice kernel and a plain copy reach on this part.
+// What is left over the unique bytes is mostly x: a plane's x lines are
+// fetched as "plane ahead" and, one step (~2 MiB of L2 traffic per XCD) later,
+// asked for again by the +-1 / +-n neighbours; about half of those miss.
 //
 // The copy is made by spmv_hip_csr_plan_bake_values_* (the plan's only use of
 // the VALUES; everything else in a plan is structure).  A launch with the
@@ -38,6 +52,7 @@ namespace
 {
 
 constexpr int kSdiaMaxOff = 3;
+
 constexpr int kSdiaMaxWin = 2 * kSdiaMaxOff + 1; // own + far per offset, diagonal
 
 struct SdiaGeom {
@@ -47,11 +62,19 @@ struct SdiaGeom {
   int arr[kSdiaMaxWin];   // array of window j (nd = diagonal)
   int first[kSdiaMaxWin]; // its first row relative to r0
   int pieces[kSdiaMaxWin];  // 1-KiB DMA pieces (<= 4: one per wave)
+  int last[kSdiaMaxWin];  // last 16-byte chunk the window needs
   int lds[kSdiaMaxWin];   // entry offset of the window inside a slot
   int own_idx[kSdiaMaxOff]; // slot entry of v_k[r0]      (+ lane = own entry)
   int col_idx[kSdiaMaxOff]; // slot entry of v_k[r0 + U_k] (+ lane = column entry)
   int d_idx;              // slot entry of d[r0]
   int slot_entries;
+  // Plane chain (RING kernels): when the farthest offset is a whole number of
+  // row blocks, offset 0 has no windows in the slots; its planes live in a
+  // ring of four 256-row buffers behind the slots (see the kernel)
+  int chain_blocks;       // U[0] / 256, 0 = no ring
+  int ring_off;           // entry offset of the ring
+  int nt[kSdiaMaxWin];    // window j is streamed non-temporally
+  int nt_ring, nt_store;  // ... the ring planes, the y stores
 };
 
 template <typename T>
@@ -62,11 +85,13 @@ struct SdiaRegs {
   T xu[kSdiaMaxOff];    // x[i + U_k]
 };
 
+// `chain`: row block rb lies exactly one plane (U[0] rows) behind the block
+// `prev` was loaded for: its x_i is prev's x[i + U_0], its x[i - U_0] prev's x_i
 template <typename T>
 __device__ __forceinline__ SdiaRegs<T> sdia_loads(
     int rb, const SdiaGeom& g, int t, int32_t num_rows,
     const uint8_t* __restrict__ cmask, const T* __restrict__ in, T beta,
-    const T* __restrict__ out)
+    const T* __restrict__ out, bool chain, const SdiaRegs<T>& prev)
 {
   SdiaRegs<T> q;
   q.cm = 0;
@@ -79,7 +104,10 @@ __device__ __forceinline__ SdiaRegs<T> sdia_loads(
   const int32_t i = rb * kRows + t;
   if (i < num_rows) {
     q.cm = cmask[i];
-    q.xi = in[i];
+    if (chain) // uniform
+      q.xi = prev.xu[0];
+    else
+      q.xi = in[i];
     if (beta != T(0))
       q.y0 = out[i];
 #pragma unroll
@@ -87,8 +115,13 @@ __device__ __forceinline__ SdiaRegs<T> sdia_loads(
       if (k < g.nd) { // uniform
         // unconditional and clamped: no dependence on the mask load; what the
         // row does not have is never used
+        // (taking x[i -+ 1] from the neighbour lanes' x_i by shuffle instead
+        // of loading it was measured: 1 % slower, these loads hit the caches)
         const int64_t c = (int64_t)i - g.U[k];
-        q.xl[k] = in[c < 0 ? 0 : c];
+        if (k == 0 && chain)
+          q.xl[k] = prev.xi;
+        else
+          q.xl[k] = in[c < 0 ? 0 : c];
         const int64_t r = (int64_t)i + g.U[k];
         q.xu[k] = in[r < num_rows ? r : (int64_t)num_rows - 1];
       }
@@ -119,7 +152,17 @@ __device__ __forceinline__ int sdia_slot_decode(const RowBlockOrder& ord, int ra
   return rb < ord.num_row_blocks ? rb : -1;
 }
 
-template <typename T, bool DOT>
+// RING: the plane chain.  In the plane-walk order a workgroup's next row block
+// is, most of the time, exactly one plane (U[0] rows) below the current one.
+// Then the far column window of offset 0 it has in LDS IS the next block's own
+// window, and the x it holds for the rows one plane ahead IS the next block's
+// x_i: nothing of that is loaded again (2.5-D streaming; measured before: those
+// re-reads, one step and ~3 MiB of other L2 traffic later, missed the 4 MiB L2
+// more often than not -- 7.7 GB through the fabric for 5.5 GB of unique reads).
+// The offset-0 planes sit in a ring of four buffers: two in use (own, far), up
+// to two being filled for the next block (far only when chained; own and far
+// after a jump).
+template <typename T, bool DOT, bool RING>
 __global__ __launch_bounds__(kBlock) void csr_sym_dia_kernel(
     int32_t num_rows, int64_t arr_len, const T* __restrict__ sval,
     const uint8_t* __restrict__ cmask, T alpha, const T* __restrict__ in, T beta,
@@ -146,24 +189,57 @@ __global__ __launch_bounds__(kBlock) void csr_sym_dia_kernel(
     for (int j = 0; j < kSdiaMaxWin; ++j) {
       if (j < g.nwin && wave < g.pieces[j]) { // uniform
         const int64_t base = (r0 + g.first[j]) & ~(int64_t)(V - 1);
-        int64_t e = base + (int64_t)(wave * 64 + lane) * V;
+        // lanes past the window re-read its last chunk (one cached line)
+        // instead of streaming the next row block's data
+        int chunk = wave * 64 + lane;
+        chunk = chunk < g.last[j] ? chunk : g.last[j];
+        int64_t e = base + (int64_t)chunk * V;
         e = e < arr_len - V ? e : arr_len - V; // arrays are padded with zeros
-        glds16<false>(sval + (int64_t)g.arr[j] * arr_len + e,
-                      lds0
-                          + (unsigned)((slot * g.slot_entries + g.lds[j])
-                                       * (int)sizeof(T))
-                          + (unsigned)wave * 1024u);
+        const T* src = sval + (int64_t)g.arr[j] * arr_len + e;
+        const unsigned dst
+            = lds0
+              + (unsigned)((slot * g.slot_entries + g.lds[j]) * (int)sizeof(T))
+              + (unsigned)wave * 1024u;
+        if (g.nt[j]) // uniform
+          glds16<true>(src, dst);
+        else
+          glds16<false>(src, dst);
       }
     }
   };
 
+  // 256 rows of array 0 from `first_row` -> ring buffer r
+  auto ring_dma = [&](int64_t first_row, int r) {
+    constexpr int pieces = kRows * (int)sizeof(T) / 1024;
+    if (wave < pieces) { // uniform
+      int64_t e = first_row + (int64_t)(wave * 64 + lane) * V;
+      e = e < arr_len - V ? e : arr_len - V;
+      const unsigned dst = lds0
+                           + (unsigned)((g.ring_off + r * kRows) * (int)sizeof(T))
+                           + (unsigned)wave * 1024u;
+      if (g.nt_ring) // uniform
+        glds16<true>(sval + e, dst);
+      else
+        glds16<false>(sval + e, dst);
+    }
+  };
+  int R0 = 0, R1 = 1, R2 = 2, R3 = 3; // ring: own, far, free, free
+
   int it = blockIdx.x;
   int cur = sdia_slot_decode(ord, sdia_slot_raw(ord, it, num_slots));
   int nxt_raw = sdia_slot_raw(ord, it + stride, num_slots);
-  if (cur >= 0)
+  if (cur >= 0) {
     issue(cur, 0);
-  SdiaRegs<T> qA = sdia_loads<T>(cur, g, t, num_rows, cmask, in, beta, out);
+    if constexpr (RING) {
+      ring_dma((int64_t)cur * kRows, R0);
+      ring_dma((int64_t)cur * kRows + g.U[0], R1);
+    }
+  }
   SdiaRegs<T> qB;
+  qB.xi = T(0);
+  qB.xu[0] = T(0);
+  SdiaRegs<T> qA = sdia_loads<T>(cur, g, t, num_rows, cmask, in, beta, out,
+                                 false, qB);
   int slot = 0;
   auto step = [&](const SdiaRegs<T>& q, SdiaRegs<T>& qn) {
     // everything of this block has landed, all waves have left the previous
@@ -172,9 +248,20 @@ __global__ __launch_bounds__(kBlock) void csr_sym_dia_kernel(
     __syncthreads();
     const int nxt = sdia_slot_decode(ord, nxt_raw);
     const int nn_raw = sdia_slot_raw(ord, it + 2 * stride, num_slots);
-    if (nxt >= 0)
+    const bool chain
+        = RING && cur >= 0 && nxt >= 0 && nxt - cur == g.chain_blocks;
+    if (nxt >= 0) {
       issue(nxt, slot ^ 1);
-    qn = sdia_loads<T>(nxt, g, t, num_rows, cmask, in, beta, out);
+      if constexpr (RING) {
+        if (chain) {
+          ring_dma((int64_t)nxt * kRows + g.U[0], R2);
+        } else {
+          ring_dma((int64_t)nxt * kRows, R2);
+          ring_dma((int64_t)nxt * kRows + g.U[0], R3);
+        }
+      }
+    }
+    qn = sdia_loads<T>(nxt, g, t, num_rows, cmask, in, beta, out, chain, q);
     const int32_t i = cur * kRows + t;
     if (cur >= 0 && i < num_rows) {
       const T* sv = s_val + slot * g.slot_entries + t;
@@ -183,8 +270,13 @@ __global__ __launch_bounds__(kBlock) void csr_sym_dia_kernel(
       for (int k = 0; k < kSdiaMaxOff; ++k) {
         vl[k] = vu[k] = T(0);
         if (k < g.nd) { // uniform
-          vl[k] = sv[g.own_idx[k]];
-          vu[k] = sv[g.col_idx[k]];
+          if (RING && k == 0) {
+            vl[k] = s_val[g.ring_off + R0 * kRows + t];
+            vu[k] = s_val[g.ring_off + R1 * kRows + t];
+          } else {
+            vl[k] = sv[g.own_idx[k]];
+            vu[k] = sv[g.col_idx[k]];
+          }
         }
       }
       const T d = sv[g.d_idx];
@@ -205,9 +297,21 @@ __global__ __launch_bounds__(kBlock) void csr_sym_dia_kernel(
           y += term;
           cy += term;
         }
-      out[i] = y;
+      if (g.nt_store) // uniform
+        __builtin_nontemporal_store(y, out + i);
+      else
+        out[i] = y;
       if constexpr (DOT) // in . (alpha A in): the finished row without beta y0
         dot_acc += (double)q.xi * (double)cy;
+    }
+    if constexpr (RING) {
+      // what was filled for the next block becomes (own, far)
+      const int a = R0, b = R1;
+      if (chain) {
+        R0 = b, R1 = R2, R2 = R3, R3 = a;
+      } else {
+        R0 = R2, R1 = R3, R2 = a, R3 = b;
+      }
     }
     slot ^= 1;
     cur = nxt;
@@ -267,6 +371,7 @@ SdiaGeom sdia_geom(const spmv_hip_csr_plan* pl)
     g.arr[w] = arr;
     g.first[w] = first;
     g.pieces[w] = pieces;
+    g.last[w] = (lead + rows - 1) / V;
     g.lds[w] = entries;
     entries += pieces * per_piece;
     ++w;
@@ -274,6 +379,10 @@ SdiaGeom sdia_geom(const spmv_hip_csr_plan* pl)
   };
   for (int k = 0; k < g.nd; ++k) {
     g.U[k] = -pl->slat_D[k];
+    if (k == 0 && pl->sdia_chain && g.U[0] >= kRows && g.U[0] % kRows == 0) {
+      g.chain_blocks = g.U[0] / kRows; // offset 0 lives in the ring
+      continue;
+    }
     if (g.U[k] < kRows) { // the column window overlaps the own one: extend it
       g.own_idx[k] = add(k, 0, kRows + g.U[k]);
       g.col_idx[k] = g.own_idx[k] + g.U[k];
@@ -285,7 +394,29 @@ SdiaGeom sdia_geom(const spmv_hip_csr_plan* pl)
   g.d_idx = add(g.nd, 0, kRows);
   g.nwin = w;
   g.slot_entries = entries;
+  g.ring_off = 2 * entries;
+  // streams nobody reads a second time leave the L2 to x and the shared
+  // windows (plan_set "sdia_nt": bit 0 ring planes, 1 diagonal, 2 windows of
+  // near offsets, 3 windows of far offsets, 4 y stores)
+  const int m = pl->sdia_nt;
+  g.nt_ring = m & 1;
+  g.nt_store = (m >> 4) & 1;
+  for (int j = 0; j < w; ++j) {
+    if (g.arr[j] == g.nd)
+      g.nt[j] = (m >> 1) & 1;
+    else if (g.U[g.arr[j]] < kRows)
+      g.nt[j] = (m >> 2) & 1;
+    else
+      g.nt[j] = (m >> 3) & 1;
+  }
   return g;
+}
+
+template <typename T>
+size_t sdia_lds_bytes(const SdiaGeom& g)
+{
+  return ((size_t)2 * g.slot_entries + (g.chain_blocks ? 4 * kRows : 0))
+         * sizeof(T);
 }
 
 // launch grid of the baked element type
@@ -294,7 +425,7 @@ int sdia_grid(const spmv_hip_csr_plan* pl)
 {
   const SdiaGeom g = sdia_geom<T>(pl);
   const int nrb = (pl->num_rows + kRows - 1) / kRows;
-  const size_t lds = (size_t)2 * g.slot_entries * sizeof(T);
+  const size_t lds = sdia_lds_bytes<T>(g);
   int per_cu = (int)((160 * 1024) / (lds + 64));
   per_cu = per_cu > pl->slat_blocks_per_cu ? pl->slat_blocks_per_cu : per_cu;
   per_cu = per_cu < 1 ? 1 : per_cu;
@@ -314,7 +445,7 @@ int sdia_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha,
 {
   const SdiaGeom g = sdia_geom<T>(pl);
   const int nrb = (pl->num_rows + kRows - 1) / kRows;
-  const size_t lds = (size_t)2 * g.slot_entries * sizeof(T);
+  const size_t lds = sdia_lds_bytes<T>(g);
   const int grid = sdia_grid<T>(pl);
   RowBlockOrder ord = pl->row_block_order(nrb);
   ord.xcd_group = pl->lat_xcd_group;
@@ -323,14 +454,22 @@ int sdia_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha,
     ord.num_slots = pl->zw_slots;
   }
   const T* sval = static_cast<const T*>(pl->sdia_val);
-  if (dot.partials)
-    hipLaunchKernelGGL((csr_sym_dia_kernel<T, true>), dim3(grid), dim3(kBlock),
-                       lds, st, pl->num_rows, pl->sdia_len, sval, pl->sdia_cmask,
-                       alpha, in, beta, out, dot, ord, g);
-  else
-    hipLaunchKernelGGL((csr_sym_dia_kernel<T, false>), dim3(grid), dim3(kBlock),
-                       lds, st, pl->num_rows, pl->sdia_len, sval, pl->sdia_cmask,
-                       alpha, in, beta, out, dot, ord, g);
+#define SPMV_SDIA(DOTV, RINGV)                                                 \
+  hipLaunchKernelGGL((csr_sym_dia_kernel<T, DOTV, RINGV>), dim3(grid),         \
+                     dim3(kBlock), lds, st, pl->num_rows, pl->sdia_len, sval,  \
+                     pl->sdia_cmask, alpha, in, beta, out, dot, ord, g)
+  if (dot.partials) {
+    if (g.chain_blocks)
+      SPMV_SDIA(true, true);
+    else
+      SPMV_SDIA(true, false);
+  } else {
+    if (g.chain_blocks)
+      SPMV_SDIA(false, true);
+    else
+      SPMV_SDIA(false, false);
+  }
+#undef SPMV_SDIA
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;
 }
@@ -352,7 +491,7 @@ int sdia_bake(spmv_hip_csr_plan* pl, const T* values, const T* diagonal,
   for (int j = 0; j < g.nwin; ++j)
     if (g.pieces[j] > kBlock / 64)
       return SPMV_HIP_ENOTSUP;
-  if ((size_t)2 * g.slot_entries * sizeof(T) > 150 * 1024)
+  if (sdia_lds_bytes<T>(g) > 150 * 1024)
     return SPMV_HIP_ENOTSUP;
   const int32_t n = pl->num_rows;
   // every window of every row block stays inside its array

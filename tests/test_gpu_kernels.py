@@ -1094,7 +1094,10 @@ def test_symmetric_diagonal_form_bit_exact(lat_ctx, dtype):
     ctx = lat_ctx
     rng = np.random.default_rng(97)
     cases = []
-    for n in (4, 9, 16, 33):
+    # n = 16, 32: planes a whole number of row blocks apart -> the plane chain
+    # (offset-0 windows and x handed from block to block) under the forced
+    # plane-walk orders below; the others take the plain slots
+    for n in (4, 9, 16, 32, 33):
         rp, ci, va = poisson.poisson3d_csr(n)
         cases.append((f"poisson{n}", *lower_split(rp, ci.astype(np.int32), va), n ** 3))
     rp, ci, va = oracle.tridiag_csr(70001)
@@ -1131,6 +1134,8 @@ def test_symmetric_diagonal_form_bit_exact(lat_ctx, dtype):
                                              lat_xcd_group=0),
                           dict(zwalk_segments=0), dict(zwalk_segments=1),
                           dict(slat_blocks_per_cu=2, zwalk_segments=3),
+                          dict(sdia_chain=0, sdia_nt=31),
+                          dict(sdia_chain=1, zwalk_segments=2, sdia_nt=0),
                           dict(zwalk=0)):
                 for k, v in knobs.items():
                     blk.set(k, v)

@@ -9,7 +9,7 @@
 set -euo pipefail
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 # optional 2nd argument: extra hipcc flags (e.g. -DSOME_PROBE=1); forces a rebuild
-if [ -n "${2:-}" ]; then rm -f "$ROOT"/spmv_amd/lib/obj/spmv_csr.o "$ROOT"/spmv_amd/lib/obj/spmv_lat.o "$ROOT"/spmv_amd/lib/obj/spmv_sym.o; fi
+if [ -n "${2:-}" ]; then rm -f "$ROOT"/spmv_amd/lib/obj/spmv_*.o; fi
 make -C "$ROOT/spmv_amd/csrc" -j8 HIPEXTRA="${2:-}" >/dev/null
 mkdir -p "$ROOT/spmv_amd/lib_$1"
 cp "$ROOT"/spmv_amd/lib/*.so "$ROOT/spmv_amd/lib_$1/"
