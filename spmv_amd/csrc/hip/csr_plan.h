@@ -86,6 +86,32 @@ __device__ __forceinline__ int order_row_block(const RowBlockOrder& o, int it)
   return rb < o.num_row_blocks ? rb : -1;
 }
 
+#ifdef __HIPCC__
+// Slot -> row block for the kernels that walk EVERY slot (an empty slot, -1, is
+// a step without work) instead of searching for the next non-empty one.  With
+// an order table the entry is a global load: order_slot_raw issues it ahead
+// into a (uniform) vector register and order_slot_decode reads it after the
+// step's own vmcnt(0), so that it is never waited for by itself -- a wait
+// there would drain the LDS-DMA prefetch with it.
+__device__ __forceinline__ int order_slot_raw(const RowBlockOrder& ord, int it,
+                                              int num_slots)
+{
+  if (it >= num_slots)
+    return -1;
+  if (ord.table)
+    return ord.table[it];
+  RowBlockOrder o = ord;
+  o.num_row_blocks = INT32_MAX; // bounds are checked by decode
+  return order_row_block(o, it);
+}
+__device__ __forceinline__ int order_slot_decode(const RowBlockOrder& ord,
+                                                 int raw)
+{
+  const int rb = __builtin_amdgcn_readfirstlane(raw);
+  return rb < ord.num_row_blocks ? rb : -1;
+}
+#endif
+
 template <typename T>
 static inline bool aligned16(const T* p)
 {
@@ -183,6 +209,7 @@ struct spmv_hip_csr_plan {
   int lat_blocks = 0;          // row blocks in lattice form (all, or lat == 0)
   int lat_blocks_per_cu = 4;   // 2 x 17 KiB of LDS per workgroup
   int lat_xcd_group = 0;       // consecutive row blocks per XCD (0 = off)
+  int lat_chain = 1;           // hand x from plane to plane (lattice_d2)
 
   // Band-sweep order for lattice-structured matrices (spmv_band_order_build):
   // every XCD sweeps its own band of grid lines through all planes, so that
@@ -271,6 +298,7 @@ int spmv_sdia_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st, float alpha,
 int spmv_lat_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
                    const int32_t* colind);
 void spmv_lat_free(spmv_hip_csr_plan* pl);
+int spmv_lat_grid(const spmv_hip_csr_plan* pl); // launch grid
 int spmv_lat_run_f64(const spmv_hip_csr_plan* pl, hipStream_t st,
                      const int32_t* rowptr, const double* values, double alpha,
                      const double* in, double beta, double* out, DotOut dot);

@@ -1364,9 +1364,11 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
   } else if (!strcmp(key, "zwalk_segments")) {
     // (re)build the plane-walk table of the symmetric diagonal form with
     // `value` runs along the plane axis (0 = choose), whatever the size
-    SPMV_REQUIRE(value >= 0 && plan->sdia_val && plan->zw_d2 > 0);
-    return spmv_zwalk_order_build(plan, plan->zw_d2, spmv_sdia_grid(plan),
-                                  value, true);
+    SPMV_REQUIRE(value >= 0 && (plan->sdia_val || plan->lat_tab)
+                 && plan->zw_d2 > 0);
+    return spmv_zwalk_order_build(
+        plan, plan->zw_d2,
+        plan->sdia_val ? spmv_sdia_grid(plan) : spmv_lat_grid(plan), value, true);
   } else if (!strcmp(key, "sym_det")) {
     // 1 needs the transposed map built at plan creation
     SPMV_REQUIRE(value == 0 || plan->t_ptr);
@@ -1375,12 +1377,18 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
     // 1 needs the lattice form built at plan creation
     SPMV_REQUIRE(value == 0 || plan->lat_tab);
     plan->lat = value != 0;
+  } else if (!strcmp(key, "lat_chain")) {
+    SPMV_REQUIRE(value == 0 || value == 1);
+    plan->lat_chain = value;
   } else if (!strcmp(key, "lat_xcd_group")) {
     SPMV_REQUIRE(value >= 0 && value <= 4096);
     plan->lat_xcd_group = value;
   } else if (!strcmp(key, "lat_blocks_per_cu")) {
     SPMV_REQUIRE(value >= 1 && value <= kBlocksPerCU);
     plan->lat_blocks_per_cu = value;
+    if (plan->zw_table && plan->lat_tab) // the table is tied to the grid
+      return spmv_zwalk_order_build(plan, plan->zw_d2, spmv_lat_grid(plan), 0,
+                                    true);
   } else {
     return SPMV_HIP_EINVAL;
   }
@@ -1444,6 +1452,8 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
     *value = plan->lattice_d2;
   else if (!strcmp(key, "lat"))
     *value = plan->lat;
+  else if (!strcmp(key, "lat_chain"))
+    *value = plan->lat_chain;
   else if (!strcmp(key, "lat_blocks"))
     *value = plan->lat_blocks;
   else if (!strcmp(key, "lx"))

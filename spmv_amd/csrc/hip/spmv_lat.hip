@@ -94,12 +94,16 @@ struct LatBlock {
   int64_t a, b; // its span in `values`
 };
 
+// Plane chain (`chain` > 0, uniform): the block lies exactly `chain` rows -- one
+// lattice plane -- behind `prev_rb`, whose loads are `prev`.  Then its x[r]
+// is prev's x[r + chain] and its x[r - chain] prev's x[r]: handed over in
+// registers instead of loaded again (2 of the 7 x loads of a 7-point row).
 template <typename T, bool DOT>
 __device__ __forceinline__ LatRegs<T> lat_loads(
     const LatBlock& blk, int t, int32_t num_rows, int32_t num_cols,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ tab,
     const uint8_t* __restrict__ mask, const T* __restrict__ in, T beta,
-    const T* __restrict__ out)
+    const T* __restrict__ out, int chain, int prev_rb, const LatRegs<T>& prev)
 {
   LatRegs<T> g;
   g.wbase = 0;
@@ -122,43 +126,59 @@ __device__ __forceinline__ LatRegs<T> lat_loads(
     const int w = t >> 6;
     g.wbase = w == 0 ? 0 : (w == 1 ? (c12 & 0xffff) : (w == 2 ? (c12 >> 16) : c3));
     g.m = mask[r];
+    T x_ahead = T(0), x_here = prev.x_own;
+    if (chain > 0) { // what the previous block holds for this one
+      const i32x8 Dp = *reinterpret_cast<const i32x8*>(
+          tab + (int64_t)prev_rb * kLatRec + 4);
+      bool have_ahead = false, have_here = prev.k0 < 0 && DOT;
+#pragma unroll
+      for (int k = 0; k < kLatMaxOff; ++k) {
+        if (Dp[k] == chain) { // uniform
+          x_ahead = prev.xk[k];
+          have_ahead = true;
+        }
+        if (Dp[k] == 0) {
+          x_here = prev.xk[k];
+          have_here = true;
+        }
+      }
+      if (!have_ahead || !have_here)
+        chain = 0;
+    }
 #pragma unroll
     for (int k = 0; k < kLatMaxOff; ++k) {
       // unconditional (no dependence on the mask load); a column the row does
       // not have is clamped into range and its value ignored
       int64_t c = (int64_t)r + D[k];
       c = c < 0 ? 0 : (c >= num_cols ? num_cols - 1 : c);
-      g.xk[k] = in[c];
+      if (chain > 0 && D[k] == 0) // uniform
+        g.xk[k] = x_ahead;
+      else if (chain > 0 && D[k] == -chain)
+        g.xk[k] = x_here;
+      else
+        g.xk[k] = in[c];
     }
     if (beta != T(0))
       g.y0 = out[r];
     if constexpr (DOT)
       if (g.k0 < 0) // uniform: eight offsets, none of them 0
-        g.x_own = in[r];
+        g.x_own = chain > 0 ? x_ahead : in[r];
   }
   return g;
 }
 
-__device__ __forceinline__ LatBlock lat_block(const RowBlockOrder& ord, int it,
-                                              int num_slots, int32_t num_rows,
-                                              const int32_t* __restrict__ rowptr,
-                                              int stride, int* it_out)
+// row block rb (-1: an empty slot) and its span in `values`: two scalar loads
+__device__ __forceinline__ LatBlock lat_block(int rb, int32_t num_rows,
+                                              const int32_t* __restrict__ rowptr)
 {
-  // first non-empty slot at or after `it` (XCD groups leave holes at the end)
   LatBlock blk{-1, 0, 0};
-  while (it < num_slots) {
-    const int rb = order_row_block(ord, it);
-    if (rb >= 0) {
-      const int32_t r0 = rb * kRows;
-      const int nr = min(kRows, num_rows - r0);
-      blk.rb = rb;
-      blk.a = rowptr[r0];
-      blk.b = rowptr[r0 + nr];
-      break;
-    }
-    it += stride;
+  if (rb >= 0) {
+    const int32_t r0 = rb * kRows;
+    const int nr = min(kRows, num_rows - r0);
+    blk.rb = rb;
+    blk.a = rowptr[r0];
+    blk.b = rowptr[r0 + nr];
   }
-  *it_out = it;
   return blk;
 }
 
@@ -171,7 +191,7 @@ __global__ __launch_bounds__(kBlock) void csr_lattice_kernel(
     const int32_t* __restrict__ rowptr, const TV* __restrict__ values,
     const int32_t* __restrict__ tab, const uint8_t* __restrict__ mask, T alpha,
     const T* __restrict__ in, T beta, T* __restrict__ out, DotOut dot,
-    RowBlockOrder ord)
+    RowBlockOrder ord, int chain_rows)
 {
   constexpr int V = 16 / (int)sizeof(TV);
   constexpr int SLOT = kLatSlotBytes / (int)sizeof(TV); // entries per slot
@@ -183,16 +203,27 @@ __global__ __launch_bounds__(kBlock) void csr_lattice_kernel(
   const int num_slots = order_slots(ord);
   double dot_acc = 0.0;
 
-  int it = blockIdx.x, itn = 0, itnn = 0;
-  LatBlock cur = lat_block(ord, it, num_slots, num_rows, rowptr, stride, &it);
-  LatBlock nxt = lat_block(ord, it + stride, num_slots, num_rows, rowptr,
-                           stride, &itn);
+  // Slots it, it + stride, ...: every one is a step, an empty slot a step
+  // without work.  Three blocks are in preparation: nxt (span known, DMA and
+  // loads issued in the current step), the one after (its order-table entry
+  // has landed; its span is fetched in the current step), and the one after
+  // that (table entry requested in the current step).
+  int it = blockIdx.x;
+  LatBlock cur = lat_block(
+      order_slot_decode(ord, order_slot_raw(ord, it, num_slots)), num_rows,
+      rowptr);
+  LatBlock nxt = lat_block(
+      order_slot_decode(ord, order_slot_raw(ord, it + stride, num_slots)),
+      num_rows, rowptr);
+  int nn_raw = order_slot_raw(ord, it + 2 * stride, num_slots);
   if (cur.rb >= 0 && cur.b > cur.a)
     lat_issue_dma<TV, NT>(values, nnz, cur.a & ~(int64_t)(V - 1), cur.b, s_val,
                           t);
-  LatRegs<T> gA = lat_loads<T, DOT>(cur, t, num_rows, num_cols, rowptr, tab,
-                                    mask, in, beta, out);
   LatRegs<T> gB;
+  gB.k0 = 0;
+  gB.x_own = T(0);
+  LatRegs<T> gA = lat_loads<T, DOT>(cur, t, num_rows, num_cols, rowptr, tab,
+                                    mask, in, beta, out, 0, 0, gB);
   int slot = 0;
   // one step: sums block `cur` out of registers g, loads block `nxt` into gn
   auto step = [&](const LatRegs<T>& g, LatRegs<T>& gn) {
@@ -207,14 +238,20 @@ __global__ __launch_bounds__(kBlock) void csr_lattice_kernel(
     if (nxt.rb >= 0 && nxt.b > nxt.a)
       lat_issue_dma<TV, NT>(values, nnz, nxt.a & ~(int64_t)(V - 1), nxt.b,
                             s_val + (slot ^ 1) * SLOT, t);
+    // one lattice plane below the current block: x handed on in registers
+    const int chain = (chain_rows > 0 && nxt.rb >= 0 && cur.rb >= 0
+                       && (nxt.rb - cur.rb) * kRows == chain_rows)
+                          ? chain_rows
+                          : 0;
     gn = lat_loads<T, DOT>(nxt, t, num_rows, num_cols, rowptr, tab, mask, in,
-                           beta, out);
-    // the block after the next one (order table, row pointer: dependent scalar
-    // loads): issued behind the vector loads, needed an iteration from now
-    const LatBlock nn = lat_block(ord, itn + stride, num_slots, num_rows,
-                                  rowptr, stride, &itnn);
+                           beta, out, chain, cur.rb, g);
+    // the block after the next one: its table entry has landed with the wait
+    // above; the row-pointer loads (scalar) are needed an iteration from now
+    const LatBlock nn = lat_block(order_slot_decode(ord, nn_raw), num_rows,
+                                  rowptr);
+    const int nnn_raw = order_slot_raw(ord, it + 3 * stride, num_slots);
     const int32_t r = cur.rb * kRows + t;
-    if (r < num_rows) {
+    if (cur.rb >= 0 && r < num_rows) {
       // the row's first entry: block start + entries of the earlier waves +
       // entries of the lower lanes of this wave (sum of their mask
       // popcounts, <= 8 each: four ballots, one per bit of the count)
@@ -259,13 +296,14 @@ __global__ __launch_bounds__(kBlock) void csr_lattice_kernel(
     slot ^= 1;
     cur = nxt;
     nxt = nn;
-    itn = itnn;
+    nn_raw = nnn_raw;
+    it += stride;
   };
   // two steps per trip: the two register sets swap roles without being copied
   // (a copy would have to wait for the loads it moves)
-  while (cur.rb >= 0) {
+  while (it < num_slots) {
     step(gA, gB);
-    if (cur.rb < 0)
+    if (it >= num_slots)
       break;
     step(gB, gA);
   }
@@ -406,6 +444,40 @@ int lat_launch(const spmv_hip_csr_plan* pl, hipStream_t st,
                T beta, T* out, DotOut dot)
 {
   const int nrb = (pl->num_rows + kRows - 1) / kRows;
+  const int grid = spmv_lat_grid(pl);
+  RowBlockOrder ord = pl->row_block_order(nrb);
+  ord.xcd_group = pl->lat_xcd_group;
+  if (pl->zwalk && pl->zw_table && pl->zw_grid == grid) {
+    ord.table = pl->zw_table;
+    ord.num_slots = pl->zw_slots;
+  } else if (pl->band_order && pl->order) {
+    ord.table = pl->order;
+    ord.num_slots = pl->order_slots;
+  }
+  // plane chain: planes a whole number of row blocks apart
+  const int chain_rows = (pl->lat_chain && pl->lattice_d2 > 0
+                          && pl->lattice_d2 % kRows == 0)
+                             ? pl->lattice_d2
+                             : 0;
+  if (pl->nontemporal)
+    hipLaunchKernelGGL((csr_lattice_kernel<TV, T, DOT, true>), dim3(grid),
+                       dim3(kBlock), 0, st, pl->num_rows, pl->num_cols, pl->nnz,
+                       rowptr, values, pl->lat_tab, pl->lat_mask, alpha, in,
+                       beta, out, dot, ord, chain_rows);
+  else
+    hipLaunchKernelGGL((csr_lattice_kernel<TV, T, DOT, false>), dim3(grid),
+                       dim3(kBlock), 0, st, pl->num_rows, pl->num_cols, pl->nnz,
+                       rowptr, values, pl->lat_tab, pl->lat_mask, alpha, in,
+                       beta, out, dot, ord, chain_rows);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+} // namespace
+
+int spmv_lat_grid(const spmv_hip_csr_plan* pl)
+{
+  const int nrb = (pl->num_rows + kRows - 1) / kRows;
   int grid = pl->ctx->num_cus * pl->lat_blocks_per_cu;
   if (grid > pl->ctx->dot_blocks)
     grid = pl->ctx->dot_blocks;
@@ -416,27 +488,8 @@ int lat_launch(const spmv_hip_csr_plan* pl, hipStream_t st,
   // slots it with equal it % 8 must stay on one XCD (XCD groups)
   if (grid >= 8)
     grid -= grid % 8;
-  RowBlockOrder ord = pl->row_block_order(nrb);
-  ord.xcd_group = pl->lat_xcd_group;
-  if (pl->band_order && pl->order) {
-    ord.table = pl->order;
-    ord.num_slots = pl->order_slots;
-  }
-  if (pl->nontemporal)
-    hipLaunchKernelGGL((csr_lattice_kernel<TV, T, DOT, true>), dim3(grid),
-                       dim3(kBlock), 0, st, pl->num_rows, pl->num_cols, pl->nnz,
-                       rowptr, values, pl->lat_tab, pl->lat_mask, alpha, in,
-                       beta, out, dot, ord);
-  else
-    hipLaunchKernelGGL((csr_lattice_kernel<TV, T, DOT, false>), dim3(grid),
-                       dim3(kBlock), 0, st, pl->num_rows, pl->num_cols, pl->nnz,
-                       rowptr, values, pl->lat_tab, pl->lat_mask, alpha, in,
-                       beta, out, dot, ord);
-  SPMV_CHECK_LAUNCH();
-  return SPMV_HIP_OK;
+  return grid;
 }
-
-} // namespace
 
 void spmv_lat_free(spmv_hip_csr_plan* pl)
 {
@@ -510,6 +563,13 @@ int spmv_lat_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
         && pos[np - 1] / pos[1] >= 16) {
       pl->lattice_d1 = pos[1];
       pl->lattice_d2 = pos[np - 1];
+      // plane-walk order (every workgroup walks a column of the lattice from
+      // plane to plane: the x of the plane ahead is the next step's own, see
+      // lat_loads); built for lattices that outgrow the grid
+      const int rc = spmv_zwalk_order_build(pl, pl->lattice_d2,
+                                            spmv_lat_grid(pl), 0, false);
+      if (rc != SPMV_HIP_OK)
+        return rc;
       // The band-sweep order is opt-in here (plan_set "band_lines"): at 512^3
       // it cuts the fabric reads from 12.3 to 9.7 GB per launch (compulsory:
       // 9.2) but the kernel gets 6-12 % SLOWER -- the same ~28,000 requests are

@@ -130,28 +130,6 @@ __device__ __forceinline__ SdiaRegs<T> sdia_loads(
   return q;
 }
 
-// Row block of slot `it`, -1 for an empty slot or past the end.  No search for
-// the next non-empty slot: an empty slot is a step without work.  With an
-// order table the entry is a global load; sdia_slot_raw issues it two steps
-// ahead into a (uniform) vector register and sdia_slot_decode reads it after
-// the step's own vmcnt(0), so that it is never waited for by itself.
-__device__ __forceinline__ int sdia_slot_raw(const RowBlockOrder& ord, int it,
-                                             int num_slots)
-{
-  if (it >= num_slots)
-    return -1;
-  if (ord.table)
-    return ord.table[it];
-  RowBlockOrder o = ord;
-  o.num_row_blocks = INT32_MAX; // bounds are checked by decode
-  return order_row_block(o, it);
-}
-__device__ __forceinline__ int sdia_slot_decode(const RowBlockOrder& ord, int raw)
-{
-  const int rb = __builtin_amdgcn_readfirstlane(raw);
-  return rb < ord.num_row_blocks ? rb : -1;
-}
-
 // RING: the plane chain.  In the plane-walk order a workgroup's next row block
 // is, most of the time, exactly one plane (U[0] rows) below the current one.
 // Then the far column window of offset 0 it has in LDS IS the next block's own
@@ -226,8 +204,8 @@ __global__ __launch_bounds__(kBlock) void csr_sym_dia_kernel(
   int R0 = 0, R1 = 1, R2 = 2, R3 = 3; // ring: own, far, free, free
 
   int it = blockIdx.x;
-  int cur = sdia_slot_decode(ord, sdia_slot_raw(ord, it, num_slots));
-  int nxt_raw = sdia_slot_raw(ord, it + stride, num_slots);
+  int cur = order_slot_decode(ord, order_slot_raw(ord, it, num_slots));
+  int nxt_raw = order_slot_raw(ord, it + stride, num_slots);
   if (cur >= 0) {
     issue(cur, 0);
     if constexpr (RING) {
@@ -246,8 +224,8 @@ __global__ __launch_bounds__(kBlock) void csr_sym_dia_kernel(
     // one (the builtin, not asm: see csr_lattice_kernel)
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
     __syncthreads();
-    const int nxt = sdia_slot_decode(ord, nxt_raw);
-    const int nn_raw = sdia_slot_raw(ord, it + 2 * stride, num_slots);
+    const int nxt = order_slot_decode(ord, nxt_raw);
+    const int nn_raw = order_slot_raw(ord, it + 2 * stride, num_slots);
     const bool chain
         = RING && cur >= 0 && nxt >= 0 && nxt - cur == g.chain_blocks;
     if (nxt >= 0) {

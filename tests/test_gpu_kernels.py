@@ -963,6 +963,47 @@ def test_lattice_form_bit_exact(lat_ctx, dtype):
         blk.free()
 
 
+@pytest.mark.parametrize("n", [16, 32, 33])
+def test_lattice_plane_walk_and_chain_bit_exact(lat_ctx, n):
+    """The plane-walk order table (forced: small lattices never build one) and
+    the plane chain of the general lattice kernel -- x of the plane ahead
+    handed to the next step in registers (n = 16, 32: planes a whole number of
+    row blocks apart) -- give the bits of the plain order; runs along the plane
+    axis break the chain at their ends."""
+    ctx = lat_ctx
+    rp, ci, va = poisson.poisson3d_csr(n)
+    ci = ci.astype(np.int32)
+    N = n ** 3
+    rng = np.random.default_rng(98)
+    va = rng.uniform(-1, 1, len(va))  # not just -1 / 6
+    x = rng.uniform(-1, 1, N)
+    y0 = rng.uniform(-1, 1, N)
+    blk = hip.CsrBlock(ctx, N, N, rp, ci, va, None, False, hip.ALGO_ROWBLOCK)
+    assert blk.get("lat") == 1 and blk.get("lattice_d2") == n * n
+    assert blk.get("zwalk") == 0 and blk.get("lat_chain") == 1
+    dx = ctx.upload(x)
+    part = ctx.empty(ctx.dot_partials_len, np.float64)
+    for alpha, beta in ((1.0, 0.0), (2.0, -0.5)):
+        y_ref = oracle.csr_spmv(rp, ci, va, x, alpha, beta, y0)
+        for knobs in (dict(zwalk_segments=0), dict(zwalk_segments=1),
+                      dict(lat_blocks_per_cu=1, zwalk_segments=3),
+                      dict(lat_chain=0), dict(lat_chain=1, lat_blocks_per_cu=2),
+                      dict(zwalk=0), dict(zwalk=1, lat_xcd_group=5)):
+            for k, v in knobs.items():
+                blk.set(k, v)
+            dy = ctx.upload(np.full(N, np.nan) if beta == 0 else y0)
+            blk.mult(alpha, dx.ptr, beta, dy.ptr,
+                     dot_partials=part.ptr if beta == 0 else None)
+            assert np.array_equal(dy.numpy(), y_ref), (alpha, beta, knobs)
+            if beta == 0:
+                want = float(np.dot(x, y_ref))
+                assert abs(float(np.sum(part.numpy())) - want) <= 1e-12 * max(abs(want), 1)
+            dy.free()
+        assert blk.get("zwalk_grid") > 0
+    dx.free(), part.free()
+    blk.free()
+
+
 def test_lattice_form_is_refused_when_it_does_not_apply(lat_ctx):
     """Nine offsets, unsorted or repeated columns, scattered columns: the plan
     falls back (LX form or gather) and the results stay exact."""
