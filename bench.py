@@ -220,7 +220,7 @@ def plan_record(A):
     return {"plan_ms": A.plan_get("plan_us") / 1e3,
             "plan_extra_bytes": A.plan_get("plan_kib") * 1024,
             "form": {k: A.plan_get(k) for k in
-                     ("lat", "lx", "slat", "sdia", "sym_det", "band_order")}}
+                     ("lat", "lx", "slat", "sdia", "sym_det", "zwalk")}}
 
 
 def pmc_traffic(kernel_name, n, world):

@@ -199,22 +199,24 @@ int spmv_hip_csr_plan_algo(const spmv_hip_csr_plan* plan, int* algo);
  *   "algo" "lanes_per_row" "chunks" "nontemporal" "xcd_group" "blocks_per_cu"
  *   "nt_store"                           the plain general kernels
  *   "lx" "lx_chunks"                     LX form on/off (built plans only)
- *   "lat" "lat_blocks_per_cu" "lat_xcd_group"      lattice form
+ *   "lat" "lat_blocks_per_cu" "lat_xcd_group" "lat_chain"   lattice form
+ *                  (lat_chain: x handed from plane to plane in registers)
  *   "slat" "slat_blocks_per_cu"          symmetric lattice form
  *   "sdia" "sdia_chain" "sdia_nt"        symmetric diagonal form (baked plans):
  *                  on/off, plane chain on/off, non-temporal streams (bit mask)
- *   "zwalk" "zwalk_segments"             its plane-walk row-block order: use the
- *                  table; (re)build it with that many runs along the plane axis
- *                  (0 = choose), whatever the size of the matrix
+ *   "zwalk" "zwalk_segments"             plane-walk row-block order of the
+ *                  three lattice kernels (every workgroup walks a 256-row
+ *                  column of the lattice from plane to plane): use the table;
+ *                  (re)build it with that many runs along the plane axis (0 =
+ *                  choose), whatever the size of the matrix
  *   "sym_det"                            transposed-map kernel (0: atomics)
- *   "sym_window" "sym_rows"              the atomic symmetric kernels
- *   "band_lines" = lines per band (0 = choose): (re)build the band-sweep
- *                  row-block order of the lattice kernels; "band_order" 0/1 */
+ *   "sym_window" "sym_rows"              the atomic symmetric kernels */
 int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value);
 /* What the plan decided and what it cost: "algo"; "lat", "lx", "slat", "sdia",
  * "sym_det" (1 = that form is in use), "lat_blocks", "lx_blocks", "lx_staged";
  * "lattice_d1", "lattice_d2" (row distance of the next grid line / plane when
- * the matrix is a 3-D lattice, else 0), "band_order", "band_lines", "zwalk", "zwalk_segments", "zwalk_grid";
+ * the matrix is a 3-D lattice, else 0), "zwalk", "zwalk_segments",
+ * "zwalk_grid", "lat_chain", "sdia_chain", "sdia_nt";
  * "blocks_per_cu", "nontemporal"; "plan_us" (wall time of plan creation, its
  * analysis kernels included) and "plan_kib" (device memory the plan owns). */
 int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,

@@ -47,7 +47,7 @@ __device__ __forceinline__ P stream_load(const P* p)
 // blockIdx.x + gridDim.x, ...; this maps a slot to the row block it computes.
 // Placement only changes speed, never the result.  Slots it with equal it % 8
 // run on the same XCD, because workgroups are dealt round-robin over the XCDs.
-//   table      plan-time order table (band sweep, spmv_band_order_build);
+//   table      plan-time order table (plane walk, spmv_zwalk_order_build);
 //              -1 marks an empty slot
 //   xcd_group  no table: inside each run of 8G row blocks XCD k owns G
 //              consecutive ones:  (it / 8G) * 8G + (it % 8) * G + (it / 8) % G
@@ -211,15 +211,8 @@ struct spmv_hip_csr_plan {
   int lat_xcd_group = 0;       // consecutive row blocks per XCD (0 = off)
   int lat_chain = 1;           // hand x from plane to plane (lattice_d2)
 
-  // Band-sweep order for lattice-structured matrices (spmv_band_order_build):
-  // every XCD sweeps its own band of grid lines through all planes, so that
-  // the x (and, symmetric storage, value) windows of the planes z-1, z, z+1
-  // stay in that XCD's L2 instead of crossing the fabric three times.
-  int32_t* order = nullptr;
-  int order_slots = 0;
-  int band_lines = 0;                    // lines per band of the table
-  int lattice_d1 = 0, lattice_d2 = 0;    // line and plane distance (rows)
-  int band_order = 0;                    // use the table (plan_set)
+  int lattice_d1 = 0, lattice_d2 = 0; // line and plane distance (rows) of a
+                                      // 3-D lattice, 0 = none found
 
   // Plane-walk order (spmv_zwalk_order_build): every workgroup of a grid of
   // zw_grid walks one 256-row column of the lattice from plane to plane, so the
@@ -261,9 +254,6 @@ int spmv_run_symmetric_f32(const spmv_hip_csr_plan* pl, hipStream_t st,
 int spmv_symt_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
                     const int32_t* colind);
 void spmv_symt_free(spmv_hip_csr_plan* pl);
-// spmv_csr.hip: (re)build the band-sweep table for bands of `yc` lines
-// (0 = choose); needs lattice_d1 / lattice_d2
-int spmv_band_order_build(spmv_hip_csr_plan* pl, int yc);
 // spmv_csr.hip: (re)build the plane-walk table for planes `d2` rows apart, a
 // grid of `grid` workgroups and `segments` runs along the plane axis (0 =
 // choose); leaves zw_table null when the lattice is too small for it to pay
@@ -271,10 +261,12 @@ int spmv_band_order_build(spmv_hip_csr_plan* pl, int yc);
 int spmv_zwalk_order_build(spmv_hip_csr_plan* pl, int64_t d2, int grid,
                            int segments, bool force);
 void spmv_zwalk_free(spmv_hip_csr_plan* pl);
+int spmv_walk_grid(const spmv_hip_csr_plan* pl); // grid of the plan's lattice kernel
 // spmv_symlat.hip
 int spmv_slat_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
                     const int32_t* colind);
 void spmv_slat_free(spmv_hip_csr_plan* pl);
+int spmv_slat_grid(const spmv_hip_csr_plan* pl); // launch grid
 int spmv_slat_run_f64(const spmv_hip_csr_plan* pl, hipStream_t st,
                       const int32_t* rowptr, const double* values,
                       const double* diagonal, double alpha, const double* in,

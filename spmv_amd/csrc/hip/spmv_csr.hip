@@ -975,78 +975,6 @@ int run_mixed(const spmv_hip_csr_plan* pl, hipStream_t st,
 } // namespace
 
 // ---------------------------------------------------------------------------
-// Band-sweep order (plan time, host side).  Rows of a 3-D stencil in natural
-// ordering couple to rows +-1, +-d1 (next grid line) and +-d2 (next plane).
-// In row order the uses of an x plane by the planes z-1, z, z+1 lie d2 rows
-// apart: tens of MB of matrix stream, far more than the 4 MiB L2 of an XCD, so
-// every XCD pulls every plane across the fabric three times -- and the lattice
-// kernels run AT the fabric's rate.  The table cuts the
-// y axis into bands of `yc` lines, gives each XCD its own bands and lets it
-// sweep a band through all planes: the band's lines of the planes z-1, z, z+1
-// fit that XCD's L2.  d1 and d2 only choose a permutation of the row blocks: a
-// wrong guess costs speed, never correctness.
-// ---------------------------------------------------------------------------
-int spmv_band_order_build(spmv_hip_csr_plan* pl, int yc)
-{
-  SPMV_REQUIRE(pl->lattice_d1 > 0 && pl->lattice_d2 > 0);
-  SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
-  const int64_t d1 = pl->lattice_d1, d2 = pl->lattice_d2;
-  const int64_t ny = d2 / d1;
-  const int64_t nz = (pl->num_rows + d2 - 1) / d2;
-  const int nrb = (pl->num_rows + kRows - 1) / kRows;
-  if (yc <= 0) {
-    // the band's lines of about four planes (x, and for the symmetric storage
-    // the values, of z-1 .. z+2: the resident workgroups span two sweep steps)
-    // should take well under half of one 4 MiB L2
-    int64_t ymax = ((int64_t)3 << 19) / (32 * d1) - 2;
-    ymax = ymax < 8 ? 8 : ymax;
-    int64_t nb = (ny + ymax - 1) / ymax;
-    nb = (nb + 7) / 8 * 8; // every XCD gets the same number of bands
-    yc = (int)((ny + nb - 1) / nb);
-  }
-  yc = yc < 1 ? 1 : yc;
-  // key = (band, plane, line); row blocks keep their order inside a line
-  std::vector<std::pair<int64_t, int32_t>> keyed((size_t)nrb);
-  for (int k = 0; k < nrb; ++k) {
-    const int64_t line = ((int64_t)k * kRows) / d1;
-    const int64_t y = line % ny, z = line / ny;
-    const int64_t band = y / yc;
-    keyed[(size_t)k] = {((band * nz + z) * ny + y), k};
-  }
-  std::stable_sort(keyed.begin(), keyed.end());
-  std::vector<std::vector<int32_t>> lists(8);
-  for (const auto& kv : keyed) {
-    const int64_t band = kv.first / (nz * ny);
-    lists[(size_t)(band % 8)].push_back(kv.second);
-  }
-  size_t longest = 0;
-  for (const auto& l : lists)
-    longest = std::max(longest, l.size());
-  std::vector<int32_t> table(8 * longest, -1);
-  for (size_t x = 0; x < 8; ++x)
-    for (size_t i = 0; i < lists[x].size(); ++i)
-      table[8 * i + x] = lists[x][i];
-  if (pl->order) {
-    SPMV_CHECK_HIP(hipDeviceSynchronize()); // no launch still reads the old one
-    (void)hipFree(pl->order);
-    pl->order = nullptr;
-    pl->order_slots = 0;
-  }
-  SPMV_CHECK_HIP(hipMalloc(&pl->order, sizeof(int32_t) * table.size()));
-  hipError_t e = hipMemcpy(pl->order, table.data(),
-                           sizeof(int32_t) * table.size(),
-                           hipMemcpyHostToDevice);
-  if (e != hipSuccess) {
-    (void)hipFree(pl->order);
-    pl->order = nullptr;
-    return static_cast<int>(e);
-  }
-  pl->order_slots = (int)table.size();
-  pl->band_lines = yc;
-  return SPMV_HIP_OK;
-}
-
-// ---------------------------------------------------------------------------
 // Plane-walk order.  Planes are d2 rows apart; plane z owns the row blocks
 // [B_z, B_{z+1}), B_z = ceil(z d2 / 256), and its c-th block is "column" c.  A
 // walker (segment q, column c) visits column c of the planes of segment q in
@@ -1058,6 +986,14 @@ int spmv_band_order_build(spmv_hip_csr_plan* pl, int yc)
 // not fill the grid evenly.  Like every order table: a permutation of the row
 // blocks plus empty slots -- it changes speed, never results.
 // ---------------------------------------------------------------------------
+// launch grid of the lattice kernel the plan runs
+int spmv_walk_grid(const spmv_hip_csr_plan* pl)
+{
+  if (!pl->symmetric)
+    return spmv_lat_grid(pl);
+  return (pl->sdia && pl->sdia_val) ? spmv_sdia_grid(pl) : spmv_slat_grid(pl);
+}
+
 void spmv_zwalk_free(spmv_hip_csr_plan* pl)
 {
   (void)hipFree(pl->zw_table);
@@ -1246,7 +1182,7 @@ int spmv_hip_csr_plan_destroy(spmv_hip_csr_plan* plan)
 {
   if (plan
       && (plan->row_list || plan->lx_lidx || plan->lat_tab || plan->t_ptr
-          || plan->slat_mask || plan->order || plan->zw_table)) {
+          || plan->slat_mask || plan->zw_table)) {
     (void)hipSetDevice(plan->ctx->device);
     (void)hipFree(plan->row_list);
     free_lx(plan);
@@ -1255,7 +1191,6 @@ int spmv_hip_csr_plan_destroy(spmv_hip_csr_plan* plan)
     spmv_sdia_free(plan);
     spmv_slat_free(plan);
     spmv_zwalk_free(plan);
-    (void)hipFree(plan->order);
   }
   delete plan;
   return SPMV_HIP_OK;
@@ -1325,16 +1260,6 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
     plan->lx_chunks = value;
   } else if (!strcmp(key, "nt_store")) {
     plan->nt_store = value != 0;
-  } else if (!strcmp(key, "band_order")) {
-    plan->band_order = (value != 0 && plan->order) ? 1 : 0;
-  } else if (!strcmp(key, "band_lines")) {
-    // (re)build the band-sweep table with bands of `value` grid lines
-    // (0 = automatic); EINVAL when the plan found no lattice
-    SPMV_REQUIRE(value >= 0);
-    const int rc = spmv_band_order_build(plan, value);
-    if (rc == SPMV_HIP_OK)
-      plan->band_order = 1;
-    return rc;
   } else if (!strcmp(key, "slat")) {
     // 1 needs the symmetric lattice form built at plan creation
     SPMV_REQUIRE(value == 0 || plan->slat_mask);
@@ -1342,13 +1267,16 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
   } else if (!strcmp(key, "sdia")) {
     SPMV_REQUIRE(value == 0 || value == 1);
     SPMV_REQUIRE(value == 0 || plan->sdia_val);
-    plan->sdia = value;
+    plan->sdia = value; // the CSR-order kernel has a grid of its own
+    if (plan->zw_table && plan->sdia_val)
+      return spmv_zwalk_order_build(plan, plan->zw_d2, spmv_walk_grid(plan), 0,
+                                    true);
   } else if (!strcmp(key, "slat_blocks_per_cu")) {
     SPMV_REQUIRE(value >= 1 && value <= kBlocksPerCU);
     plan->slat_blocks_per_cu = value;
-    if (plan->zw_table && plan->sdia_val) // the table is tied to the grid
-      return spmv_zwalk_order_build(plan, plan->zw_d2, spmv_sdia_grid(plan),
-                                    0, true);
+    if (plan->zw_table && plan->slat_mask) // the table is tied to the grid
+      return spmv_zwalk_order_build(plan, plan->zw_d2, spmv_walk_grid(plan), 0,
+                                    true);
   } else if (!strcmp(key, "sdia_nt")) {
     SPMV_REQUIRE(value >= 0 && value < 32);
     plan->sdia_nt = value;
@@ -1356,19 +1284,18 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
     SPMV_REQUIRE(value == 0 || value == 1);
     plan->sdia_chain = value; // LDS footprint, hence the grid, may change
     if (plan->zw_table && plan->sdia_val)
-      return spmv_zwalk_order_build(plan, plan->zw_d2, spmv_sdia_grid(plan),
-                                    0, true);
+      return spmv_zwalk_order_build(plan, plan->zw_d2, spmv_walk_grid(plan), 0,
+                                    true);
   } else if (!strcmp(key, "zwalk")) {
     SPMV_REQUIRE(value == 0 || plan->zw_table);
     plan->zwalk = value != 0;
   } else if (!strcmp(key, "zwalk_segments")) {
-    // (re)build the plane-walk table of the symmetric diagonal form with
-    // `value` runs along the plane axis (0 = choose), whatever the size
-    SPMV_REQUIRE(value >= 0 && (plan->sdia_val || plan->lat_tab)
+    // (re)build the plane-walk table of the plan's lattice kernel with `value`
+    // runs along the plane axis (0 = choose), whatever the size
+    SPMV_REQUIRE(value >= 0 && (plan->slat_mask || plan->lat_tab)
                  && plan->zw_d2 > 0);
-    return spmv_zwalk_order_build(
-        plan, plan->zw_d2,
-        plan->sdia_val ? spmv_sdia_grid(plan) : spmv_lat_grid(plan), value, true);
+    return spmv_zwalk_order_build(plan, plan->zw_d2, spmv_walk_grid(plan), value,
+                                  true);
   } else if (!strcmp(key, "sym_det")) {
     // 1 needs the transposed map built at plan creation
     SPMV_REQUIRE(value == 0 || plan->t_ptr);
@@ -1426,16 +1353,10 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
       b += (int64_t)(plan->slat_nd + 1) * plan->sdia_len * plan->sdia_elem + n;
     if (plan->t_ptr)
       b += 4 * (n + 1) + 8 * nnz;
-    if (plan->order)
-      b += 4 * (int64_t)plan->order_slots;
     if (plan->zw_table)
       b += 4 * (int64_t)plan->zw_slots;
     *value = (int)((b + 1023) / 1024);
   }
-  else if (!strcmp(key, "band_order"))
-    *value = plan->band_order && plan->order ? 1 : 0;
-  else if (!strcmp(key, "band_lines"))
-    *value = plan->order ? plan->band_lines : 0;
   else if (!strcmp(key, "sdia_chain"))
     *value = plan->sdia_chain;
   else if (!strcmp(key, "sdia_nt"))

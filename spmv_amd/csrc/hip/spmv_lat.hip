@@ -450,9 +450,6 @@ int lat_launch(const spmv_hip_csr_plan* pl, hipStream_t st,
   if (pl->zwalk && pl->zw_table && pl->zw_grid == grid) {
     ord.table = pl->zw_table;
     ord.num_slots = pl->zw_slots;
-  } else if (pl->band_order && pl->order) {
-    ord.table = pl->order;
-    ord.num_slots = pl->order_slots;
   }
   // plane chain: planes a whole number of row blocks apart
   const int chain_rows = (pl->lat_chain && pl->lattice_d2 > 0
@@ -570,12 +567,10 @@ int spmv_lat_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
                                             spmv_lat_grid(pl), 0, false);
       if (rc != SPMV_HIP_OK)
         return rc;
-      // The band-sweep order is opt-in here (plan_set "band_lines"): at 512^3
-      // it cuts the fabric reads from 12.3 to 9.7 GB per launch (compulsory:
-      // 9.2) but the kernel gets 6-12 % SLOWER -- the same ~28,000 requests are
-      // in flight either way and without the Infinity-Cache hits of the plain
-      // order their average latency rises from 1,240 to 1,530 cycles
-      // (profiles/r02_pmc_lattice_512.json).
+      // (A band-sweep order -- every XCD sweeping a band of grid lines through
+      // all planes -- was measured in this place earlier: 12.3 -> 9.7 GB of
+      // fabric reads at 512^3 and still 6-12 % slower, its table look-up
+      // draining the DMA prefetch every step; profiles/r02_pmc_lattice_512.json.)
     }
   }
   return SPMV_HIP_OK;

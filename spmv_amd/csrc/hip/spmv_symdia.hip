@@ -459,8 +459,11 @@ int sdia_bake(spmv_hip_csr_plan* pl, const T* values, const T* diagonal,
   SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
   const auto t_begin = std::chrono::steady_clock::now();
   spmv_sdia_free(pl);
-  if (values == nullptr && diagonal == nullptr)
-    return SPMV_HIP_OK; // dropped
+  if (values == nullptr && diagonal == nullptr) // dropped: the CSR-order
+    return pl->slat_mask                        // kernel's table again
+               ? spmv_zwalk_order_build(pl, -(int64_t)pl->slat_D[0],
+                                        spmv_slat_grid(pl), 0, false)
+               : SPMV_HIP_OK;
   SPMV_REQUIRE(values && diagonal);
   // the diagonal form rests on the symmetric lattice analysis
   if (!pl->symmetric || !pl->slat_mask || pl->nnz == 0)
@@ -509,8 +512,7 @@ int sdia_bake(spmv_hip_csr_plan* pl, const T* values, const T* diagonal,
   // measured at 512^3 (4 workgroups per CU: 1024 = the row blocks of one
   // plane, so every workgroup walks straight down z and finds its far column
   // window in the block it reads next): plain order 1.47 ms, 8 consecutive
-  // row blocks per XCD 1.43, band sweep 1.60
-  pl->band_order = 0;
+  // row blocks per XCD 1.43
   pl->lat_xcd_group = 8;
   pl->slat_blocks_per_cu = 4;
   // the plane-walk order makes that true for every size (planes = the

@@ -361,6 +361,23 @@ __global__ __launch_bounds__(kBlock) void slat_mask_kernel(
   }
 }
 
+int slat_grid(const spmv_hip_csr_plan* pl)
+{
+  const int nrb = (pl->num_rows + kRows - 1) / kRows;
+  const size_t lds = (size_t)2 * pl->slat_nw * pl->slat_sub_bytes;
+  int per_cu = (int)((160 * 1024) / (lds + 64));
+  per_cu = per_cu > pl->slat_blocks_per_cu ? pl->slat_blocks_per_cu : per_cu;
+  per_cu = per_cu < 1 ? 1 : per_cu;
+  int grid = pl->ctx->num_cus * per_cu;
+  if (grid > pl->ctx->dot_blocks)
+    grid = pl->ctx->dot_blocks;
+  if (grid > nrb)
+    grid = nrb;
+  if (grid >= 8)
+    grid -= grid % 8;
+  return grid < 1 ? 1 : grid;
+}
+
 template <typename T>
 int slat_launch(const spmv_hip_csr_plan* pl, hipStream_t st,
                 const int32_t* rowptr, const T* values, const T* diagonal,
@@ -379,23 +396,12 @@ int slat_launch(const spmv_hip_csr_plan* pl, hipStream_t st,
     g.u_of_w[w] = pl->slat_u_of_w[w];
   const int nrb = (pl->num_rows + kRows - 1) / kRows;
   const size_t lds = (size_t)2 * g.nw * g.sub_bytes;
-  int per_cu = (int)((160 * 1024) / (lds + 64));
-  per_cu = per_cu > pl->slat_blocks_per_cu ? pl->slat_blocks_per_cu : per_cu;
-  per_cu = per_cu < 1 ? 1 : per_cu;
-  int grid = pl->ctx->num_cus * per_cu;
-  if (grid > pl->ctx->dot_blocks)
-    grid = pl->ctx->dot_blocks;
-  if (grid > nrb)
-    grid = nrb;
-  if (grid >= 8)
-    grid -= grid % 8;
-  if (grid < 1)
-    grid = 1;
+  const int grid = slat_grid(pl);
   RowBlockOrder ord = pl->row_block_order(nrb);
   ord.xcd_group = pl->lat_xcd_group;
-  if (pl->band_order && pl->order) {
-    ord.table = pl->order;
-    ord.num_slots = pl->order_slots;
+  if (pl->zwalk && pl->zw_table && pl->zw_grid == grid) {
+    ord.table = pl->zw_table;
+    ord.num_slots = pl->zw_slots;
   }
 #define SPMV_SLAT(DOTV, NTV)                                                   \
   hipLaunchKernelGGL((csr_sym_lattice_kernel<T, DOTV, NTV>), dim3(grid),       \
@@ -419,6 +425,11 @@ int slat_launch(const spmv_hip_csr_plan* pl, hipStream_t st,
 }
 
 } // namespace
+
+int spmv_slat_grid(const spmv_hip_csr_plan* pl)
+{
+  return slat_grid(pl);
+}
 
 void spmv_slat_free(spmv_hip_csr_plan* pl)
 {
@@ -531,14 +542,9 @@ int spmv_slat_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
   if (nd == 3 && -(int64_t)D[1] >= 8 && D[0] % D[1] == 0 && D[0] / D[1] >= 16) {
     pl->lattice_d1 = -D[1];
     pl->lattice_d2 = -D[0];
-    const int nrb = (n + kRows - 1) / kRows;
-    // from a few million rows on the value windows of the next line and plane
-    // are re-read from beyond the L2s; the band-sweep order keeps them in the
-    // XCD's L2 (512^3: 2.71 -> 2.54 ms)
-    if (nrb >= 8192 && spmv_band_order_build(pl, 0) == SPMV_HIP_OK)
-      pl->band_order = 1;
   }
-  return SPMV_HIP_OK;
+  // plane-walk order: planes = the farthest offset apart (large lattices only)
+  return spmv_zwalk_order_build(pl, -(int64_t)D[0], slat_grid(pl), 0, false);
 }
 
 int spmv_slat_run_f64(const spmv_hip_csr_plan* pl, hipStream_t st,

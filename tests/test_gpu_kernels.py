@@ -1260,10 +1260,12 @@ def test_symmetric_lattice_form_is_refused_when_it_does_not_apply(lat_ctx):
 
 
 @pytest.mark.parametrize("n", [16, 33])
-def test_band_order_is_a_permutation_of_the_work(lat_ctx, n):
-    """The band-sweep table only permutes row blocks: any band height gives the
-    bits of the plain order, for the general and the symmetric lattice form.
-    Small grids never build a table on their own, so it is forced."""
+def test_plane_walk_order_is_a_permutation_of_the_work(lat_ctx, n):
+    """The plane-walk table only permutes row blocks (and adds empty slots):
+    any number of runs along the plane axis, on any grid, gives the bits of the
+    plain order -- general lattice form and the CSR-order symmetric lattice
+    form (the diagonal form has its own test).  Small grids never build a
+    table on their own, so it is forced."""
     ctx = lat_ctx
     rp, ci, va = poisson.poisson3d_csr(n)
     ci = ci.astype(np.int32)
@@ -1274,36 +1276,36 @@ def test_band_order_is_a_permutation_of_the_work(lat_ctx, n):
         if sym:
             blk = hip.CsrBlock(ctx, N, N, lrp, lci, lva, dg, True)
             y_ref = oracle.csr_spmv_sym(lrp, lci, lva, dg, x, 0.5, 0.0)
-            assert blk.get("slat") == 1
+            assert blk.get("slat") == 1 and blk.get("sdia") == 0
         else:
             blk = hip.CsrBlock(ctx, N, N, rp, ci, va, None, False, hip.ALGO_ROWBLOCK)
             y_ref = oracle.csr_spmv(rp, ci, va, x, 0.5, 0.0)
             assert blk.get("lat") == 1
         assert blk.get("lattice_d1") == n and blk.get("lattice_d2") == n * n
-        assert blk.get("band_order") == 0  # too small to need it
+        assert blk.get("zwalk") == 0  # too small to need it
         dx = ctx.upload(x)
-        for yc in (0, 1, 3, 8, n, 5 * n):
-            blk.set("band_lines", yc)
-            assert blk.get("band_order") == 1
-            if yc:
-                assert blk.get("band_lines") == yc
+        for segs in (0, 1, 2, 5, n, 3 * n):
+            blk.set("zwalk_segments", segs)
+            assert blk.get("zwalk") == 1
+            assert 1 <= blk.get("zwalk_segments") <= max(segs, n)
             for bpc in (1, 4):
                 blk.set("slat_blocks_per_cu" if sym else "lat_blocks_per_cu", bpc)
+                assert blk.get("zwalk") == 1  # rebuilt for the new grid
                 dy = ctx.upload(np.full(N, np.nan))
                 blk.mult(0.5, dx.ptr, 0.0, dy.ptr)
-                assert np.array_equal(dy.numpy(), y_ref), (sym, yc, bpc)
+                assert np.array_equal(dy.numpy(), y_ref), (sym, segs, bpc)
                 dy.free()
-        blk.set("band_order", 0)
-        assert blk.get("band_order") == 0
+        blk.set("zwalk", 0)
+        assert blk.get("zwalk") == 0
         dx.free()
         blk.free()
-    # no lattice, no table
+    # no 3-D lattice in a general matrix: no planes to walk
     rp, ci, va = oracle.tridiag_csr(100000)
     blk = hip.CsrBlock(ctx, 100000, 100000, rp, ci, va, None, False,
                        hip.ALGO_ROWBLOCK)
     assert blk.get("lattice_d2") == 0
     with pytest.raises(Exception):
-        blk.set("band_lines", 4)
+        blk.set("zwalk_segments", 4)
     blk.free()
 
 

@@ -1,7 +1,7 @@
 """Ad-hoc knob sweep of the general row-block SpMV on the device-generated
 Poisson matrix: every combination of the given knob values, interleaved.
 
-    python tools/ksweep.py --n 512 --reps 8 --knob band_order=0,1 --knob chunks=1,2,4
+    python tools/ksweep.py --n 512 --reps 8 --knob zwalk=0,1 --knob lat_blocks_per_cu=2,4
 """
 import argparse
 import itertools
