@@ -76,6 +76,9 @@ def parse():
     ap.add_argument("--no-lattice", action="store_true",
                     help="no lattice form: the LX form as any matrix without "
                          "lattice structure gets it (experiments)")
+    ap.add_argument("--no-bake", action="store_true",
+                    help="no plan-time symmetry check of the general matrix: the "
+                         "lattice kernel on the caller's CSR values (experiments)")
     ap.add_argument("--no-lx", action="store_true",
                     help="with --no-lattice: the plain gather kernel")
     ap.add_argument("--mixed-grid", type=int, default=216,
@@ -188,7 +191,7 @@ def kernel_of(A, symmetric):
     if symmetric:
         algo = rows * 8 * 3 + (rows + 1) * 4 + nnz * 12  # SURVEY 8d B_sym
         if A.plan_get("sdia"):
-            nd = 3
+            nd = A.plan_get("sdia_offsets")
             return ("csr_sym_dia_kernel<double> (symmetric diagonal form: the "
                     "plan's copy of the values by offset, own and column windows "
                     "by LDS-DMA, no index stream, atomic-free, bit-exact)",
@@ -204,6 +207,14 @@ def kernel_of(A, symmetric):
         return ("csr_sym_window_kernel<double> (LDS window + global atomics)",
                 algo, algo)
     algo = nnz * 12 + (rows + 1) * 4 + y_x  # SURVEY 8d B_csr
+    if A.plan_get("sdia"):
+        nd = A.plan_get("sdia_offsets")
+        return ("csr_sym_dia_kernel<double, general order> (the general matrix "
+                "was found symmetric bit for bit at plan time: the plan keeps "
+                "its lower half + diagonal by offset, windows by LDS-DMA, no "
+                "index stream, rows summed in the CSR kernel's order: "
+                "bit-exact; fused p.Ap)",
+                algo, rows * (8 * nd + 8 + 1) + y_x)
     if A.plan_get("lat"):
         return ("csr_lattice_kernel<double> (lattice form: constant column "
                 "offsets per row block, values by LDS-DMA one block ahead, no "
@@ -267,14 +278,19 @@ def timed_spmv(exec_, A, N, _lib, reps):
     return best
 
 
-def spmv_record(exec_, comm, host, _lib, n, symmetric, reps, lattice=True):
+def spmv_record(exec_, comm, host, _lib, n, symmetric, reps, lattice=True,
+                bake=True):
     """one plain-SpMV sub-record on the n^3 matrix in the given storage/form"""
     ctx = exec_.context
     if not lattice:
         _lib.call("spmv_hip_ctx_set_option", ctx, b"lat_min_nnz", 1 << 62)
+    if not bake:
+        _lib.call("spmv_hip_ctx_set_option", ctx, b"bake_general", 0)
     A = host.Matrix.create_poisson3d(comm, exec_, n, symmetric, host.P2P_BLOCKING)
     if not lattice:
         _lib.call("spmv_hip_ctx_set_option", ctx, b"lat_min_nnz", 1 << 20)
+    if not bake:
+        _lib.call("spmv_hip_ctx_set_option", ctx, b"bake_general", 1)
     N = n ** 3
     ms = timed_spmv(exec_, A, N, _lib, reps)
     kernel, algo, req = kernel_of(A, symmetric)
@@ -297,11 +313,19 @@ def mixed_precision_record(exec_, comm, host, _lib, n, rtol=1e-10, kmax=6000):
     import numpy as np
     N = n ** 3
     ctx = exec_.context
+    # both legs on the CSR-order lattice kernel (the plan-time symmetry check
+    # is off): what a lattice matrix that is NOT symmetric gains from fp32
+    # values.  For this symmetric matrix the diagonal form of the main line is
+    # faster than either (33 B of fp64 matrix data per row against 29 B here,
+    # through a kernel with half the requests).
+    _lib.call("spmv_hip_ctx_set_option", ctx, b"bake_general", 0)
     A = host.Matrix.create_poisson3d(comm, exec_, n, False, host.P2P_NONBLOCKING)
+    _lib.call("spmv_hip_ctx_set_option", ctx, b"bake_general", 1)
     d_b, d_x = exec_.alloc(N), exec_.alloc(N)
     _lib.call("spmv_hip_fill_gaussian_f64", ctx, N, 0, N, d_b, None)
     ws = host.CgWorkspace(exec_)
-    rec = {"workload": f"poisson3d_{n}^3_csr_cg_to_{rtol:g}", "rows": N}
+    rec = {"workload": f"poisson3d_{n}^3_csr_cg_to_{rtol:g}", "rows": N,
+           "kernel": "csr_lattice_kernel (symmetry check off for both legs)"}
     sols = {}
     for name in ("fp64", "mixed"):
         for rep in range(2):  # first pass: warm-up (fp32 copy, workspace)
@@ -388,6 +412,8 @@ def main():
     ctx = exec_.context
     if args.no_lattice or args.no_lx:
         _lib.call("spmv_hip_ctx_set_option", ctx, b"lat_min_nnz", 1 << 62)
+    if args.no_bake:
+        _lib.call("spmv_hip_ctx_set_option", ctx, b"bake_general", 0)
     if args.no_lx:
         _lib.call("spmv_hip_ctx_set_option", ctx, b"lx_min_nnz", 1 << 62)
     cm = getattr(host, args.cm.upper())
@@ -522,6 +548,16 @@ def main():
                          "frac_requested": requested_bytes
                          / (spmv_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source,
+                         # ... and with the bytes the PMC passes saw cross the
+                         # fabric: what the HBM side is really asked to do
+                         "frac_traffic": (traffic / (spmv_ms_avg * 1e-3) / 1e9
+                                          / HBM_PEAK_GBS) if traffic else None,
+                         "note": ("frac prices the ALGORITHMIC CSR bytes of "
+                                  "SURVEY 8d (12 B per entry, row pointer, x, y) "
+                                  "as the contract asks; the kernel named below "
+                                  "moves fewer (requested_bytes_per_launch, "
+                                  "traffic), so frac may exceed 1 -- the HBM-side "
+                                  "utilisation is frac_traffic"),
                          "kernel": kernel,
                          "algorithmic_bytes_per_launch": kernel_bytes,
                          "avg_launch_ms": spmv_ms_avg,
@@ -592,6 +628,11 @@ def main():
                 ws2.close()
                 As.close()
                 exec_.free(d_b), exec_.free(d_x)
+                # the lattice form: what a lattice matrix that is NOT symmetric
+                # gets (same matrix, symmetry check switched off)
+                if not (args.no_lattice or args.no_lx or args.no_bake):
+                    out["csr_lattice_spmv"] = spmv_record(
+                        exec_, self_comm, host, _lib, n, False, 20, bake=False)
                 # the LX form: what a CSR matrix WITHOUT lattice structure gets
                 # (same matrix, lattice analysis switched off)
                 if not (args.no_lattice or args.no_lx):

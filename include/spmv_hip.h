@@ -177,17 +177,25 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
                              int symmetric, int algo,
                              spmv_hip_csr_plan** plan);
 int spmv_hip_csr_plan_destroy(spmv_hip_csr_plan* plan);
-/* Optional, symmetric plans in the symmetric lattice form only (else
- * SPMV_HIP_ENOTSUP): let the plan keep its OWN copy of the matrix values in
- * the layout its kernel streams best -- one array per lower offset plus the
- * diagonal ("symmetric diagonal form", a DIA fast path).  This
- * is what CSRSpMV::init does with the matrix it is given (csr_kernels.h:26-78;
- * the cuSPARSE descriptor of cuda/csr_kernels.cu binds the values there too).
- * Costs (offsets + 1) * 8 B per row of device memory.  A launch that passes
- * these very `values` and `diagonal` pointers takes the diagonal-form kernel
- * (same bits as every other symmetric kernel); a launch with other pointers
- * takes the CSR-order kernels as before.  CONTRACT: whoever rewrites the baked
- * arrays in place bakes again (or drops the copy: values = diagonal = NULL). */
+/* Optional: let the plan keep its OWN copy of the matrix values in the layout
+ * its kernel streams best -- one array per lower offset plus the diagonal
+ * ("symmetric diagonal form", a DIA fast path).  This is what
+ * CSRSpMV::init does with the matrix it is given (csr_kernels.h:26-78; the
+ * cuSPARSE descriptor of cuda/csr_kernels.cu binds the values there too).
+ *   symmetric plan   in the symmetric lattice form (<= 3 constant lower
+ *                    offsets); pass values and diagonal
+ *   general plan     (diagonal = NULL) in the lattice form, square, and
+ *                    SYMMETRIC entry for entry and bit for bit with <= 3
+ *                    distinct |col - row| > 0 -- checked on the device here.
+ *                    The kernel then reads only the lower half and the
+ *                    diagonal (49 instead of 73 B per row of a 7-point matrix)
+ *                    and sums each row in the general kernel's own order:
+ *                    same bits as csr_kernels.cpp:41-51.
+ * Anything else: SPMV_HIP_ENOTSUP, nothing changes.  Costs (offsets + 1) * 8 B
+ * per row of device memory.  A launch that passes these very `values` (and
+ * `diagonal`) pointers takes the diagonal-form kernel; a launch with other
+ * pointers takes the CSR-order kernels as before.  CONTRACT: whoever rewrites
+ * the baked arrays in place bakes again (or drops the copy: values = NULL). */
 int spmv_hip_csr_plan_bake_values_f64(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan,
                                       const double* values,
                                       const double* diagonal, void* stream);
@@ -216,7 +224,8 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value);
  * "sym_det" (1 = that form is in use), "lat_blocks", "lx_blocks", "lx_staged";
  * "lattice_d1", "lattice_d2" (row distance of the next grid line / plane when
  * the matrix is a 3-D lattice, else 0), "zwalk", "zwalk_segments",
- * "zwalk_grid", "lat_chain", "sdia_chain", "sdia_nt";
+ * "zwalk_grid", "lat_chain", "sdia_chain", "sdia_nt", "sdia_offsets" (lower
+ * offsets of the baked copy), "sdia_general" (baked from a general matrix);
  * "blocks_per_cu", "nontemporal"; "plan_us" (wall time of plan creation, its
  * analysis kernels included) and "plan_kib" (device memory the plan owns). */
 int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,

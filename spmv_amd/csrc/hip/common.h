@@ -26,6 +26,9 @@ struct spmv_hip_ctx {
   // index stream) for general matrices with at least this many entries
   // ("lat_min_nnz")
   int64_t lat_min_nnz = (int64_t)1 << 20;
+  // plan_bake_values on a GENERAL plan looks for a symmetric matrix and keeps
+  // its lower half by offset ("bake_general"; 0: always SPMV_HIP_ENOTSUP)
+  int bake_general = 1;
 };
 
 #define SPMV_CHECK_HIP(expr)                                                   \

@@ -174,6 +174,10 @@ struct spmv_hip_csr_plan {
   const void* sdia_values0 = nullptr;
   const void* sdia_diag0 = nullptr;
   int sdia = 0;                   // use it (plan_set "sdia")
+  int sdia_nd = 0;                // lower offsets ...
+  int sdia_U[3] = {0, 0, 0};      // ... their row distances, descending
+  int sdia_general = 0;           // baked from a GENERAL matrix found symmetric:
+                                  // the kernel sums in the general order
   int sdia_chain = 1;             // plane chain where the geometry allows
   // non-temporal streams (bit mask, see sdia_geom).  512^3: ring planes and
   // diagonal -0.5 %, y stores +-0, the far windows two workgroups share +10 %

@@ -664,6 +664,15 @@ int launch_rowblock(const spmv_hip_csr_plan* pl, hipStream_t st,
   if (grid >= 8)
     grid -= grid % 8;
   const bool al = aligned16(values) && aligned16(colind);
+  // the plan's own copy of a symmetric matrix's lower half (spmv_symdia.hip)
+  if (pl->sdia && pl->sdia_val && pl->sdia_general
+      && pl->sdia_elem == (int)sizeof(T) && values == pl->sdia_values0) {
+    if constexpr (sizeof(T) == 8)
+      return spmv_sdia_run_f64(pl, st, alpha, in, beta, out,
+                               DOT ? dot : DotOut());
+    else
+      return spmv_sdia_run_f32(pl, st, alpha, in, beta, out);
+  }
   if (pl->lat && aligned16(values)) {
     if constexpr (sizeof(T) == 8)
       return spmv_lat_run_f64(pl, st, rowptr, values, alpha, in, beta, out,
@@ -989,9 +998,9 @@ int run_mixed(const spmv_hip_csr_plan* pl, hipStream_t st,
 // launch grid of the lattice kernel the plan runs
 int spmv_walk_grid(const spmv_hip_csr_plan* pl)
 {
-  if (!pl->symmetric)
-    return spmv_lat_grid(pl);
-  return (pl->sdia && pl->sdia_val) ? spmv_sdia_grid(pl) : spmv_slat_grid(pl);
+  if (pl->sdia && pl->sdia_val)
+    return spmv_sdia_grid(pl);
+  return pl->symmetric ? spmv_slat_grid(pl) : spmv_lat_grid(pl);
 }
 
 void spmv_zwalk_free(spmv_hip_csr_plan* pl)
@@ -1274,7 +1283,7 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
   } else if (!strcmp(key, "slat_blocks_per_cu")) {
     SPMV_REQUIRE(value >= 1 && value <= kBlocksPerCU);
     plan->slat_blocks_per_cu = value;
-    if (plan->zw_table && plan->slat_mask) // the table is tied to the grid
+    if (plan->zw_table && (plan->slat_mask || plan->sdia_val)) // tied to the grid
       return spmv_zwalk_order_build(plan, plan->zw_d2, spmv_walk_grid(plan), 0,
                                     true);
   } else if (!strcmp(key, "sdia_nt")) {
@@ -1314,7 +1323,7 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
     SPMV_REQUIRE(value >= 1 && value <= kBlocksPerCU);
     plan->lat_blocks_per_cu = value;
     if (plan->zw_table && plan->lat_tab) // the table is tied to the grid
-      return spmv_zwalk_order_build(plan, plan->zw_d2, spmv_lat_grid(plan), 0,
+      return spmv_zwalk_order_build(plan, plan->zw_d2, spmv_walk_grid(plan), 0,
                                     true);
   } else {
     return SPMV_HIP_EINVAL;
@@ -1350,13 +1359,17 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
     if (plan->slat_mask)
       b += n;
     if (plan->sdia_val)
-      b += (int64_t)(plan->slat_nd + 1) * plan->sdia_len * plan->sdia_elem + n;
+      b += (int64_t)(plan->sdia_nd + 1) * plan->sdia_len * plan->sdia_elem + n;
     if (plan->t_ptr)
       b += 4 * (n + 1) + 8 * nnz;
     if (plan->zw_table)
       b += 4 * (int64_t)plan->zw_slots;
     *value = (int)((b + 1023) / 1024);
   }
+  else if (!strcmp(key, "sdia_offsets"))
+    *value = plan->sdia_val ? plan->sdia_nd : 0;
+  else if (!strcmp(key, "sdia_general"))
+    *value = plan->sdia_val ? plan->sdia_general : 0;
   else if (!strcmp(key, "sdia_chain"))
     *value = plan->sdia_chain;
   else if (!strcmp(key, "sdia_nt"))

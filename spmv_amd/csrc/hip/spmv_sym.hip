@@ -442,8 +442,9 @@ int run_symmetric(const spmv_hip_csr_plan* pl, hipStream_t st,
     SPMV_CHECK_LAUNCH();
     return SPMV_HIP_OK;
   }
-  if (pl->sdia && pl->sdia_val && pl->sdia_elem == (int)sizeof(T)
-      && values == pl->sdia_values0 && diagonal == pl->sdia_diag0) {
+  if (pl->sdia && pl->sdia_val && !pl->sdia_general
+      && pl->sdia_elem == (int)sizeof(T) && values == pl->sdia_values0
+      && diagonal == pl->sdia_diag0) {
     if constexpr (sizeof(T) == 8)
       return spmv_sdia_run_f64(pl, st, alpha, in, beta, out, dot);
     else

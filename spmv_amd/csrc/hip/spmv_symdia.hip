@@ -140,7 +140,16 @@ __device__ __forceinline__ SdiaRegs<T> sdia_loads(
 // The offset-0 planes sit in a ring of four buffers: two in use (own, far), up
 // to two being filled for the next block (far only when chained; own and far
 // after a jump).
-template <typename T, bool DOT, bool RING>
+//
+// GEN: the same storage behind the GENERAL SpMV (spmv/csr_kernels.cpp:41-51)
+// of a matrix the plan found to be symmetric, entry for entry and bit for bit
+// (sdia_bake_general): the upper entry (i, i + u) IS the stored lower entry
+// (i + u, i).  The row is summed in the general kernel's order -- ascending
+// column: lower offsets, diagonal (mask bit 3: a row may lack it), upper
+// offsets -- so the result has the bits of the CSR kernels while only half the
+// off-diagonal values cross the fabric (49 B per row of the 7-point matrix
+// instead of 73).
+template <typename T, bool DOT, bool RING, bool GEN>
 __global__ __launch_bounds__(kBlock) void csr_sym_dia_kernel(
     int32_t num_rows, int64_t arr_len, const T* __restrict__ sval,
     const uint8_t* __restrict__ cmask, T alpha, const T* __restrict__ in, T beta,
@@ -258,23 +267,42 @@ __global__ __launch_bounds__(kBlock) void csr_sym_dia_kernel(
         }
       }
       const T d = sv[g.d_idx];
-      T sum = d * q.xi; // csr_kernels.cpp:28
+      T y, cy;
+      if constexpr (GEN) {
+        T sum = 0; // csr_kernels.cpp:45
 #pragma unroll
-      for (int k = 0; k < kSdiaMaxOff; ++k)
-        if (k < g.nd && ((q.cm >> k) & 1u)) // :34, left to right
-          sum += vl[k] * q.xl[k];
-      const T c = alpha * sum; // :39
-      T y = c, cy = c;
-      if (beta != T(0))
-        y = c + beta * q.y0;
-      // the column's entries in ascending row order: nearest row first
+        for (int k = 0; k < kSdiaMaxOff; ++k)
+          if (k < g.nd && ((q.cm >> k) & 1u)) // :46-47, ascending column
+            sum += vl[k] * q.xl[k];
+        if ((q.cm >> 3) & 1u)
+          sum += d * q.xi;
 #pragma unroll
-      for (int k = kSdiaMaxOff - 1; k >= 0; --k)
-        if (k < g.nd && ((q.cm >> (4 + k)) & 1u)) { // :35
-          const T term = (alpha * vu[k]) * q.xu[k];
-          y += term;
-          cy += term;
-        }
+        for (int k = kSdiaMaxOff - 1; k >= 0; --k)
+          if (k < g.nd && ((q.cm >> (4 + k)) & 1u))
+            sum += vu[k] * q.xu[k];
+        cy = alpha * sum; // :49
+        y = cy;
+        if (beta != T(0))
+          y = cy + beta * q.y0;
+      } else {
+        T sum = d * q.xi; // csr_kernels.cpp:28
+#pragma unroll
+        for (int k = 0; k < kSdiaMaxOff; ++k)
+          if (k < g.nd && ((q.cm >> k) & 1u)) // :34, left to right
+            sum += vl[k] * q.xl[k];
+        const T c = alpha * sum; // :39
+        y = c, cy = c;
+        if (beta != T(0))
+          y = c + beta * q.y0;
+        // the column's entries in ascending row order: nearest row first
+#pragma unroll
+        for (int k = kSdiaMaxOff - 1; k >= 0; --k)
+          if (k < g.nd && ((q.cm >> (4 + k)) & 1u)) { // :35
+            const T term = (alpha * vu[k]) * q.xu[k];
+            y += term;
+            cy += term;
+          }
+      }
       if (g.nt_store) // uniform
         __builtin_nontemporal_store(y, out + i);
       else
@@ -330,6 +358,91 @@ __global__ __launch_bounds__(kBlock) void sdia_bake_kernel(
         cm |= 1u << (4 + k);
     }
     sval[(int64_t)nd * arr_len + i] = diagonal[i];
+    cmask[i] = (uint8_t)(cm | 8u);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// General matrices: is A symmetric, entry for entry and bit for bit, with at
+// most three distinct |col - row| > 0?  Then its lower half + diagonal go into
+// the same arrays.
+// ---------------------------------------------------------------------------
+// pass 1: the set of distinct |col - row| > 0 (capacity 8, INT32_MAX = free)
+__global__ __launch_bounds__(kBlock) void sdia_offsets_kernel(
+    int32_t num_rows, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ colind, int32_t* __restrict__ set,
+    int32_t* __restrict__ fail)
+{
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < num_rows;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+      const int64_t d64 = (int64_t)colind[j] - i;
+      if (d64 == 0)
+        continue;
+      const int32_t d = (int32_t)(d64 < 0 ? -d64 : d64);
+      bool placed = false;
+      for (int s = 0; s < 8 && !placed; ++s) {
+        int32_t cur = set[s];
+        if (cur == INT32_MAX)
+          cur = atomicCAS(set + s, INT32_MAX, d);
+        placed = (cur == d || cur == INT32_MAX);
+      }
+      if (!placed)
+        atomicOr(fail, 1);
+    }
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ bool same_bits(T a, T b)
+{
+  if constexpr (sizeof(T) == 8)
+    return __double_as_longlong(a) == __double_as_longlong(b);
+  else
+    return __float_as_int(a) == __float_as_int(b);
+}
+
+// pass 2: fill the arrays and the mask; every off-diagonal entry (i, c) must
+// have its mirror (c, i) with the same bits.  (Ascending columns without
+// repeats are what the lattice form, a precondition, already guarantees.)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void sdia_bake_general_kernel(
+    int32_t num_rows, int nd, int u0, int u1, int u2,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
+    const T* __restrict__ values, int64_t arr_len, T* __restrict__ sval,
+    uint8_t* __restrict__ cmask, int32_t* __restrict__ fail)
+{
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < num_rows;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    unsigned cm = 0;
+    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+      const int64_t c = colind[j];
+      const T v = values[j];
+      if (c == i) {
+        sval[(int64_t)nd * arr_len + i] = v;
+        cm |= 8u;
+        continue;
+      }
+      const int64_t u = c < i ? i - c : c - i;
+      const int k = u == u0 ? 0 : (u == u1 ? 1 : (u == u2 ? 2 : -1));
+      bool ok = k >= 0 && k < nd && c < num_rows;
+      if (ok) {
+        ok = false;
+        for (int32_t jj = rowptr[c]; jj < rowptr[c + 1]; ++jj)
+          if (colind[jj] == i)
+            ok = same_bits(values[jj], v);
+      }
+      if (!ok) {
+        atomicOr(fail, 1);
+        continue;
+      }
+      if (c < i) {
+        sval[(int64_t)k * arr_len + i] = v;
+        cm |= 1u << k;
+      } else {
+        cm |= 1u << (4 + k);
+      }
+    }
     cmask[i] = (uint8_t)cm;
   }
 }
@@ -341,7 +454,7 @@ SdiaGeom sdia_geom(const spmv_hip_csr_plan* pl)
   constexpr int V = 16 / (int)sizeof(T);
   constexpr int per_piece = 1024 / (int)sizeof(T);
   SdiaGeom g{};
-  g.nd = pl->slat_nd;
+  g.nd = pl->sdia_nd;
   int w = 0, entries = 0;
   auto add = [&](int arr, int first, int rows) {
     const int lead = first & (V - 1); // alignment slack in front
@@ -356,7 +469,7 @@ SdiaGeom sdia_geom(const spmv_hip_csr_plan* pl)
     return g.lds[w - 1] + lead; // slot entry of row r0 + first
   };
   for (int k = 0; k < g.nd; ++k) {
-    g.U[k] = -pl->slat_D[k];
+    g.U[k] = pl->sdia_U[k];
     if (k == 0 && pl->sdia_chain && g.U[0] >= kRows && g.U[0] % kRows == 0) {
       g.chain_blocks = g.U[0] / kRows; // offset 0 lives in the ring
       continue;
@@ -433,9 +546,18 @@ int sdia_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha,
   }
   const T* sval = static_cast<const T*>(pl->sdia_val);
 #define SPMV_SDIA(DOTV, RINGV)                                                 \
-  hipLaunchKernelGGL((csr_sym_dia_kernel<T, DOTV, RINGV>), dim3(grid),         \
-                     dim3(kBlock), lds, st, pl->num_rows, pl->sdia_len, sval,  \
-                     pl->sdia_cmask, alpha, in, beta, out, dot, ord, g)
+  do {                                                                         \
+    if (pl->sdia_general)                                                      \
+      hipLaunchKernelGGL((csr_sym_dia_kernel<T, DOTV, RINGV, true>),           \
+                         dim3(grid), dim3(kBlock), lds, st, pl->num_rows,      \
+                         pl->sdia_len, sval, pl->sdia_cmask, alpha, in, beta,  \
+                         out, dot, ord, g);                                    \
+    else                                                                       \
+      hipLaunchKernelGGL((csr_sym_dia_kernel<T, DOTV, RINGV, false>),          \
+                         dim3(grid), dim3(kBlock), lds, st, pl->num_rows,      \
+                         pl->sdia_len, sval, pl->sdia_cmask, alpha, in, beta,  \
+                         out, dot, ord, g);                                    \
+  } while (0)
   if (dot.partials) {
     if (g.chain_blocks)
       SPMV_SDIA(true, true);
@@ -452,22 +574,101 @@ int sdia_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha,
   return SPMV_HIP_OK;
 }
 
+// the plan's table for the kernel it runs WITHOUT a baked copy
+int sdia_restore_walk(spmv_hip_csr_plan* pl)
+{
+  if (pl->symmetric)
+    return pl->slat_mask ? spmv_zwalk_order_build(pl, -(int64_t)pl->slat_D[0],
+                                                  spmv_slat_grid(pl), 0, false)
+                         : SPMV_HIP_OK;
+  return (pl->lat_tab && pl->lattice_d2 > 0)
+             ? spmv_zwalk_order_build(pl, pl->lattice_d2, spmv_lat_grid(pl), 0,
+                                      false)
+             : SPMV_HIP_OK;
+}
+
+// general plan: the distinct |col - row| > 0, descending, or 0 offsets when
+// there are more than three (or none)
+int sdia_general_offsets(spmv_hip_csr_plan* pl, hipStream_t st, int* nd, int* U)
+{
+  int32_t* d_w = nullptr; // [0..7] set, [8] fail
+  int32_t h_w[9];
+  for (int s = 0; s < 8; ++s)
+    h_w[s] = INT32_MAX;
+  h_w[8] = 0;
+  hipError_t e = hipMalloc(&d_w, sizeof(h_w));
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(d_w, h_w, sizeof(h_w), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) {
+    const int grid = spmv_grid_for(pl->ctx, pl->num_rows, kBlock);
+    hipLaunchKernelGGL(sdia_offsets_kernel, dim3(grid), dim3(kBlock), 0, st,
+                       pl->num_rows, pl->rowptr0, pl->colind0, d_w, d_w + 8);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(h_w, d_w, sizeof(h_w), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st);
+  (void)hipFree(d_w);
+  if (e != hipSuccess)
+    return static_cast<int>(e);
+  *nd = 0;
+  if (h_w[8])
+    return SPMV_HIP_OK;
+  int D[8], n = 0;
+  for (int s = 0; s < 8; ++s)
+    if (h_w[s] != INT32_MAX)
+      D[n++] = h_w[s];
+  if (n == 0 || n > kSdiaMaxOff)
+    return SPMV_HIP_OK;
+  for (int a = 1; a < n; ++a) // insertion sort, descending
+    for (int b = a; b > 0 && D[b] > D[b - 1]; --b) {
+      const int tmp = D[b];
+      D[b] = D[b - 1];
+      D[b - 1] = tmp;
+    }
+  for (int k = 0; k < n; ++k)
+    U[k] = D[k];
+  *nd = n;
+  return SPMV_HIP_OK;
+}
+
 template <typename T>
 int sdia_bake(spmv_hip_csr_plan* pl, const T* values, const T* diagonal,
               hipStream_t st)
 {
   SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
   const auto t_begin = std::chrono::steady_clock::now();
+  const bool had = pl->sdia_val != nullptr;
   spmv_sdia_free(pl);
-  if (values == nullptr && diagonal == nullptr) // dropped: the CSR-order
-    return pl->slat_mask                        // kernel's table again
-               ? spmv_zwalk_order_build(pl, -(int64_t)pl->slat_D[0],
-                                        spmv_slat_grid(pl), 0, false)
-               : SPMV_HIP_OK;
-  SPMV_REQUIRE(values && diagonal);
-  // the diagonal form rests on the symmetric lattice analysis
-  if (!pl->symmetric || !pl->slat_mask || pl->nnz == 0)
+  if (values == nullptr && diagonal == nullptr) // dropped
+    return had ? sdia_restore_walk(pl) : SPMV_HIP_OK;
+  const bool general = !pl->symmetric;
+  SPMV_REQUIRE(values && (general ? diagonal == nullptr : diagonal != nullptr));
+  if (pl->nnz == 0)
     return SPMV_HIP_ENOTSUP;
+  if (general) {
+    // rests on the lattice form (ascending columns without repeats, a row
+    // block's worth of structure) of a square matrix
+    if (!pl->ctx->bake_general || !pl->lat_tab || pl->num_rows != pl->num_cols)
+      return SPMV_HIP_ENOTSUP;
+    int nd = 0, U[kSdiaMaxOff] = {0, 0, 0};
+    const int rc = sdia_general_offsets(pl, st, &nd, U);
+    if (rc != SPMV_HIP_OK)
+      return rc;
+    if (nd == 0)
+      return SPMV_HIP_ENOTSUP;
+    pl->sdia_nd = nd;
+    for (int k = 0; k < kSdiaMaxOff; ++k)
+      pl->sdia_U[k] = U[k];
+  } else {
+    // rests on the symmetric lattice analysis
+    if (!pl->slat_mask)
+      return SPMV_HIP_ENOTSUP;
+    pl->sdia_nd = pl->slat_nd;
+    for (int k = 0; k < kSdiaMaxOff; ++k)
+      pl->sdia_U[k] = -pl->slat_D[k];
+  }
   const SdiaGeom g = sdia_geom<T>(pl);
   for (int j = 0; j < g.nwin; ++j)
     if (g.pieces[j] > kBlock / 64)
@@ -480,24 +681,41 @@ int sdia_bake(spmv_hip_csr_plan* pl, const T* values, const T* diagonal,
   const size_t bytes = (size_t)(g.nd + 1) * len * sizeof(T);
   void* sval = nullptr;
   uint8_t* cm = nullptr;
+  int32_t* d_fail = nullptr;
+  int32_t h_fail = 0;
   hipError_t e = hipMalloc(&sval, bytes);
   if (e == hipSuccess)
     e = hipMalloc(&cm, (size_t)n);
   if (e == hipSuccess)
+    e = hipMalloc(&d_fail, sizeof(int32_t));
+  if (e == hipSuccess)
     e = hipMemsetAsync(sval, 0, bytes, st);
+  if (e == hipSuccess)
+    e = hipMemsetAsync(d_fail, 0, sizeof(int32_t), st);
   if (e == hipSuccess) {
     const int grid = spmv_grid_for(pl->ctx, n, kBlock);
-    hipLaunchKernelGGL((sdia_bake_kernel<T>), dim3(grid), dim3(kBlock), 0, st, n,
-                       g.nd, g.U[0], g.U[1], g.U[2], pl->rowptr0, pl->slat_mask,
-                       values, diagonal, len, static_cast<T*>(sval), cm);
+    if (general)
+      hipLaunchKernelGGL((sdia_bake_general_kernel<T>), dim3(grid), dim3(kBlock),
+                         0, st, n, g.nd, g.U[0], g.U[1], g.U[2], pl->rowptr0,
+                         pl->colind0, values, len, static_cast<T*>(sval), cm,
+                         d_fail);
+    else
+      hipLaunchKernelGGL((sdia_bake_kernel<T>), dim3(grid), dim3(kBlock), 0, st,
+                         n, g.nd, g.U[0], g.U[1], g.U[2], pl->rowptr0,
+                         pl->slat_mask, values, diagonal, len,
+                         static_cast<T*>(sval), cm);
     e = hipGetLastError();
   }
   if (e == hipSuccess)
+    e = hipMemcpyAsync(&h_fail, d_fail, sizeof(int32_t), hipMemcpyDeviceToHost,
+                       st);
+  if (e == hipSuccess)
     e = hipStreamSynchronize(st);
-  if (e != hipSuccess) {
+  (void)hipFree(d_fail);
+  if (e != hipSuccess || h_fail) { // not symmetric: nothing changes
     (void)hipFree(sval);
     (void)hipFree(cm);
-    return static_cast<int>(e);
+    return e != hipSuccess ? static_cast<int>(e) : SPMV_HIP_ENOTSUP;
   }
   pl->sdia_val = sval;
   pl->sdia_cmask = cm;
@@ -505,6 +723,7 @@ int sdia_bake(spmv_hip_csr_plan* pl, const T* values, const T* diagonal,
   pl->sdia_elem = (int)sizeof(T);
   pl->sdia_values0 = values;
   pl->sdia_diag0 = diagonal;
+  pl->sdia_general = general ? 1 : 0;
   pl->sdia = 1;
   pl->plan_us += (int)std::chrono::duration_cast<std::chrono::microseconds>(
                      std::chrono::steady_clock::now() - t_begin)
@@ -513,7 +732,8 @@ int sdia_bake(spmv_hip_csr_plan* pl, const T* values, const T* diagonal,
   // plane, so every workgroup walks straight down z and finds its far column
   // window in the block it reads next): plain order 1.47 ms, 8 consecutive
   // row blocks per XCD 1.43
-  pl->lat_xcd_group = 8;
+  if (!general)
+    pl->lat_xcd_group = 8;
   pl->slat_blocks_per_cu = 4;
   // the plane-walk order makes that true for every size (planes = the
   // farthest offset apart)
@@ -532,6 +752,8 @@ void spmv_sdia_free(spmv_hip_csr_plan* pl)
   pl->sdia_len = 0;
   pl->sdia_elem = 0;
   pl->sdia = 0;
+  pl->sdia_general = 0;
+  pl->sdia_nd = 0;
   spmv_zwalk_free(pl);
   pl->zw_d2 = 0;
 }

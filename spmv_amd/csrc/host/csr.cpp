@@ -32,7 +32,7 @@ template <typename T>
 bool CSRSpMV<T>::bake_values(const T* values, const T* diagonal,
                              const HipExecutor& exec) const
 {
-  if (!plan() || !values || !diagonal)
+  if (!plan() || !values || (_symmetric && !diagonal))
     return false;
   int rc;
   if constexpr (std::is_same<T, double>::value)

@@ -42,11 +42,12 @@ public:
            const T* diagonal, T alpha, T* in, T beta, T* out,
            const HipExecutor& exec) const;
   void finalize(const HipExecutor& exec) const;
-  // Second half of init for a symmetric block (the reference's init sees the
-  // values, csr_kernels.h:28; the diagonal lives in SubMatrix): lets the plan
-  // keep the values by offset (spmv_hip_csr_plan_bake_values_*).  Returns
-  // false, and changes nothing, when the block is not in the symmetric
-  // lattice form.
+  // Second half of init (the reference's init sees the values,
+  // csr_kernels.h:28; a symmetric block's diagonal lives in SubMatrix): lets the
+  // plan keep the values by offset (spmv_hip_csr_plan_bake_values_*) -- a
+  // symmetric block in the symmetric lattice form, or a GENERAL block
+  // (diagonal = nullptr) that turns out to be symmetric entry for entry.
+  // Returns false, and changes nothing, when the block does not qualify.
   bool bake_values(const T* values, const T* diagonal,
                    const HipExecutor& exec) const;
 

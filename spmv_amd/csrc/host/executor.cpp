@@ -258,16 +258,16 @@ void HipExecutor::spmv_init(CSRSpMV<float>& op, const CSRMatrix<float>& mat) con
 {
   op.init(mat.rows(), mat.cols(), mat.non_zeros(), mat.rowptr(), mat.colind(),
           mat.values(), mat.symmetric(), *this);
-  if (mat.symmetric())
-    op.bake_values(mat.values(), mat.diagonal(), *this);
+  op.bake_values(mat.values(), mat.symmetric() ? mat.diagonal() : nullptr,
+                 *this);
 }
 void HipExecutor::spmv_init(CSRSpMV<double>& op,
                             const CSRMatrix<double>& mat) const
 {
   op.init(mat.rows(), mat.cols(), mat.non_zeros(), mat.rowptr(), mat.colind(),
           mat.values(), mat.symmetric(), *this);
-  if (mat.symmetric())
-    op.bake_values(mat.values(), mat.diagonal(), *this);
+  op.bake_values(mat.values(), mat.symmetric() ? mat.diagonal() : nullptr,
+                 *this);
 }
 void HipExecutor::spmv_run(const CSRSpMV<float>& op, const CSRMatrix<float>& mat,
                            float alpha, float* in, float beta, float* out) const

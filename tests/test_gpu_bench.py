@@ -36,6 +36,7 @@ def _check(d, n_gpus, steps, warmup):
     assert r["launches_timed"] == steps and r["avg_launch_ms"] > 0
     assert 0 < r["frac_requested"] <= r["frac"] * 1.0000001
     assert (r["traffic"] is None) == (r["traffic_source"] is None)
+    assert (r["traffic"] is None) == (r["frac_traffic"] is None) and "note" in r
     assert d["cg_rel_residual"]["k10"] > 0 and d["cg_rel_residual"]["kK"] > 0
     assert d["plan"]["plan_ms"] >= 0 and d["plan"]["plan_extra_bytes"] >= 0
 
@@ -58,6 +59,10 @@ def test_bench_single_gpu_line():
     sym = d["symmetric"]
     assert sym["frac"] > 0 and sym["iters/s"] > 0 and "atomic-free" in sym["kernel"]
     assert d["csr_lx_spmv"]["form"]["lx"] == 1 and d["csr_lx_spmv"]["form"]["lat"] == 0
+    # the general Poisson matrix is symmetric: the plan keeps its lower half
+    assert d["plan"]["form"]["sdia"] == 1 and "general order" in d["roofline"]["kernel"]
+    lat = d["csr_lattice_spmv"]["form"]
+    assert lat["lat"] == 1 and lat["sdia"] == 0
     assert d["north_star_spmv"]["form"]["lat"] == 1
     mp = d["mixed_precision_cg"]
     assert mp["mixed"]["final_true_rel_residual"] < 1.001e-10

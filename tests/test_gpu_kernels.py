@@ -1231,6 +1231,144 @@ def test_symmetric_diagonal_form_bit_exact(lat_ctx, dtype):
     blk.free()
 
 
+def _symmetric_general_csr(rng, N, lower_offsets, drop=0.0, diag_drop=0.0,
+                           dtype=np.float64):
+    """A general CSR matrix that is symmetric entry for entry: random lower
+    entries at the given offsets (some dropped), their mirrors, a diagonal
+    (some rows without)."""
+    import scipy.sparse as sp
+    lrp, lci, lva = _stencil_csr(rng, N, lower_offsets, drop=drop, dtype=dtype)
+    L = sp.csr_matrix((lva, lci, lrp), shape=(N, N))
+    keep = rng.random(N) >= diag_drop
+    D = sp.csr_matrix((rng.uniform(1, 2, int(keep.sum())).astype(dtype),
+                       (np.nonzero(keep)[0], np.nonzero(keep)[0])), shape=(N, N))
+    A = (L + L.T + D).tocsr()
+    A.sort_indices()
+    assert A.nnz == 2 * L.nnz + D.nnz
+    return (A.indptr.astype(np.int32), A.indices.astype(np.int32),
+            A.data.astype(dtype))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_general_matrix_found_symmetric_takes_the_diagonal_form(lat_ctx, dtype):
+    """plan_bake_values on a GENERAL plan: the device check finds the matrix
+    symmetric bit for bit, the plan keeps the lower half by offset, and the
+    general SpMV comes out with the bits of csr_kernels.cpp:41-51 (rows summed
+    in ascending column order) -- every geometry, rows without a diagonal,
+    missing entries, both orders, the plane chain."""
+    ctx = lat_ctx
+    rng = np.random.default_rng(99)
+    cases = []
+    for n in (9, 16, 32, 33):
+        rp, ci, va = poisson.poisson3d_csr(n)
+        lrp, lci, lva, _ = lower_split(rp, ci.astype(np.int32), va)
+        N = n ** 3
+        cases.append((f"poisson{n}",
+                      *_symmetric_general_csr(rng, N, [-n * n, -n, -1], dtype=dtype), N))
+    cases.append(("poisson_exact", *[a for a in poisson.poisson3d_csr(20)], 8000))
+    cases.append(("tridiag", *_symmetric_general_csr(rng, 70001, [-1], dtype=dtype), 70001))
+    cases.append(("far3", *_symmetric_general_csr(rng, 9001, [-2000, -300, -1],
+                                                  drop=0.33, diag_drop=0.2,
+                                                  dtype=dtype), 9001))
+    cases.append(("odd", *_symmetric_general_csr(rng, 7013, [-1001, -257, -255],
+                                                 drop=0.2, dtype=dtype), 7013))
+    for name, rp, ci, va, N in cases:
+        ci, va = ci.astype(np.int32), va.astype(dtype)
+        x = rng.uniform(-1, 1, N).astype(dtype)
+        y0 = rng.uniform(-1, 1, N).astype(dtype)
+        blk = hip.CsrBlock(ctx, N, N, rp, ci, va, None, False, hip.ALGO_ROWBLOCK,
+                           dtype)
+        assert blk.get("lat") == 1 and blk.get("sdia") == 0, name
+        blk.bake()
+        assert blk.get("sdia") == 1, name
+        dx = ctx.upload(x, dtype)
+        part = ctx.empty(ctx.dot_partials_len, np.float64)
+        for alpha, beta in ((1.0, 0.0), (-0.5, 0.0), (2.0, 1.0), (1.0, -0.25)):
+            y_ref = oracle.csr_spmv(rp, ci, va, x, alpha, beta, y0)
+            for knobs in (dict(), dict(slat_blocks_per_cu=1), dict(sdia=0),
+                          dict(sdia=1, zwalk_segments=0),
+                          dict(slat_blocks_per_cu=2, zwalk_segments=3),
+                          dict(sdia_chain=0), dict(sdia_chain=1, zwalk=0)):
+                for k, v in knobs.items():
+                    blk.set(k, v)
+                dy = ctx.upload(np.full(N, np.nan, dtype) if beta == 0 else y0, dtype)
+                dot = dtype == np.float64 and alpha == 1.0 and beta == 0.0
+                blk.mult(alpha, dx.ptr, beta, dy.ptr,
+                         dot_partials=part.ptr if dot else None)
+                y = dy.numpy()
+                dy.free()
+                assert np.array_equal(y, y_ref), (name, alpha, beta, knobs)
+                if dot:
+                    want = float(np.dot(x.astype(np.float64), y_ref))
+                    got = float(np.sum(part.numpy()))
+                    scale = float(np.abs(x) @ np.abs(y_ref)) + 1e-300
+                    assert abs(got - want) <= 1e-12 * scale, (name, knobs)
+        # other values through the same plan: the CSR-order kernel, not the copy
+        va2 = (va * dtype(0.5)).astype(dtype)
+        other = ctx.upload(va2, dtype)
+        keep = blk.values
+        blk.values = other
+        dy = ctx.upload(np.full(N, np.nan, dtype), dtype)
+        blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+        assert np.array_equal(dy.numpy(), oracle.csr_spmv(rp, ci, va2, x)), name
+        blk.values = keep
+        blk.bake(drop=True)
+        assert blk.get("sdia") == 0
+        blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+        assert np.array_equal(dy.numpy(), oracle.csr_spmv(rp, ci, va, x)), name
+        other.free(), dy.free(), dx.free(), part.free()
+        blk.free()
+
+
+def test_general_matrix_that_is_not_symmetric_is_not_baked(lat_ctx):
+    """One value off by an ulp, a sign of zero, a missing mirror entry, a fourth
+    offset, a rectangular block: the device check refuses, the plan keeps
+    running the lattice kernel on the caller's arrays."""
+    ctx = lat_ctx
+    rng = np.random.default_rng(100)
+    N = 6000
+    rp, ci, va = _symmetric_general_csr(rng, N, [-700, -30, -1])
+    x = rng.uniform(-1, 1, N)
+    cases = []
+    v2 = va.copy()
+    j = int(rp[3000])  # first entry of a middle row: a lower one
+    v2[j] = np.nextafter(v2[j], 2.0)
+    cases.append(("ulp", rp, ci, v2, N))
+    v3 = va.copy()
+    r = 2000
+    jl = int(rp[r])          # entry (r, r - 700) and its mirror
+    c = int(ci[jl])
+    jm = int(rp[c]) + int(np.nonzero(ci[rp[c]:rp[c + 1]] == r)[0][0])
+    v3[jl], v3[jm] = 0.0, -0.0
+    cases.append(("signed_zero", rp, ci, v3, N))
+    # drop one upper entry: pattern no longer symmetric
+    keep = np.ones(len(ci), bool)
+    keep[jm] = False
+    rp4 = np.concatenate([[0], np.cumsum(np.bincount(
+        np.repeat(np.arange(N), np.diff(rp))[keep], minlength=N))]).astype(np.int32)
+    cases.append(("missing_mirror", rp4, ci[keep], va[keep], N))
+    cases.append(("four", *_symmetric_general_csr(rng, N, [-700, -30, -2, -1]), N))
+    for name, rp_, ci_, va_, n_ in cases:
+        blk = hip.CsrBlock(ctx, n_, n_, rp_, ci_.astype(np.int32), va_, None, False,
+                           hip.ALGO_ROWBLOCK)
+        with pytest.raises(Exception):
+            blk.bake()
+        assert blk.get("sdia") == 0, name
+        dx, dy = ctx.upload(x), ctx.upload(np.full(n_, np.nan))
+        blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+        assert np.array_equal(dy.numpy(),
+                              oracle.csr_spmv(rp_, ci_.astype(np.int32), va_, x)), name
+        dx.free(), dy.free()
+        blk.free()
+    # rectangular (a block with a ghost tail)
+    rpr, cir, var = _stencil_csr(rng, 3000, [-5, 0, 5])
+    blk = hip.CsrBlock(ctx, 3000, 3005, rpr, np.minimum(cir, 3004).astype(np.int32),
+                       var, None, False, hip.ALGO_ROWBLOCK)
+    with pytest.raises(Exception):
+        blk.bake()
+    blk.free()
+
+
 def test_symmetric_lattice_form_is_refused_when_it_does_not_apply(lat_ctx):
     """Four lower offsets, unsorted rows, an entry on or above the diagonal:
     the plan falls back to the transposed map (or, not strictly lower, to the
