@@ -29,9 +29,14 @@
 // = 0.79-0.80 of the symmetric-CSR roofline; 7.45 GB read + 1.07 GB written
 // through the fabric for 5.50 + 1.07 unique, i.e. 6.3 TB/s of real traffic --
 // the rate the general lattice kernel and a plain copy reach on this part.
-// What is left over the unique bytes is mostly x: a plane's x lines are
-// fetched as "plane ahead" and, one step (~2 MiB of L2 traffic per XCD) later,
-// asked for again by the +-1 / +-n neighbours; about half of those miss.
+// What is left over the unique 82 lines per row block (102 are read): the x
+// loads at +-n (9 lines: the neighbour columns' lines, fetched one step
+// earlier) and the far window of the middle offset (9 lines: another
+// workgroup's own window, sometimes on another XCD); the loads at +-1 all hit
+// (profiles/r02_pmc_symdia_probes_512.json).  Removing either group entirely
+// buys 1 % and 4 % of the time: the kernel runs at the rate the fabric takes
+// this mix of reads and writes.  Tried and dropped: x[i +- 1] by shuffle
+// (-1 %), the neighbours' x loaded one plane ahead and handed on (-4.5 %).
 //
 // The copy is made by spmv_hip_csr_plan_bake_values_* (the plan's only use of
 // the VALUES; everything else in a plan is structure).  A launch with the
