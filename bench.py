@@ -313,19 +313,13 @@ def mixed_precision_record(exec_, comm, host, _lib, n, rtol=1e-10, kmax=6000):
     import numpy as np
     N = n ** 3
     ctx = exec_.context
-    # both legs on the CSR-order lattice kernel (the plan-time symmetry check
-    # is off): what a lattice matrix that is NOT symmetric gains from fp32
-    # values.  For this symmetric matrix the diagonal form of the main line is
-    # faster than either (33 B of fp64 matrix data per row against 29 B here,
-    # through a kernel with half the requests).
-    _lib.call("spmv_hip_ctx_set_option", ctx, b"bake_general", 0)
+    # both legs on the plan's default kernel, the diagonal form: fp64 copy of
+    # the values against the fp32 copy (33 against 17 B of matrix data per row)
     A = host.Matrix.create_poisson3d(comm, exec_, n, False, host.P2P_NONBLOCKING)
-    _lib.call("spmv_hip_ctx_set_option", ctx, b"bake_general", 1)
     d_b, d_x = exec_.alloc(N), exec_.alloc(N)
     _lib.call("spmv_hip_fill_gaussian_f64", ctx, N, 0, N, d_b, None)
     ws = host.CgWorkspace(exec_)
-    rec = {"workload": f"poisson3d_{n}^3_csr_cg_to_{rtol:g}", "rows": N,
-           "kernel": "csr_lattice_kernel (symmetry check off for both legs)"}
+    rec = {"workload": f"poisson3d_{n}^3_csr_cg_to_{rtol:g}", "rows": N}
     sols = {}
     for name in ("fp64", "mixed"):
         for rep in range(2):  # first pass: warm-up (fp32 copy, workspace)
@@ -348,6 +342,10 @@ def mixed_precision_record(exec_, comm, host, _lib, n, rtol=1e-10, kmax=6000):
                            "continuation_iterations",
                            "final_true_rel_residual") if k_ in st})
     rec["speedup"] = rec["fp64"]["seconds"] / rec["mixed"]["seconds"]
+    rec["kernel"] = ("csr_sym_dia_kernel, fp64 / fp32 copy of the values"
+                     if A.plan_get("sdia_mixed") else
+                     "fp64: " + kernel_of(A, False)[0].split(" ")[0]
+                     + "; mixed: CSR-order fp32 values")
     rec["x_rel_diff"] = float(np.linalg.norm(sols["mixed"] - sols["fp64"])
                               / np.linalg.norm(sols["fp64"]))
     rec["note"] = ("fp32 copy of the matrix values in the SpMV, fp64 vectors and "

@@ -202,6 +202,14 @@ int spmv_hip_csr_plan_bake_values_f64(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan
 int spmv_hip_csr_plan_bake_values_f32(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan,
                                       const float* values, const float* diagonal,
                                       void* stream);
+/* ... and the fp32 copy for spmv_hip_csr_spmv_f32f64 (mixed precision) on a
+ * general fp64 plan whose values are baked: `values32` is the caller's fp32
+ * copy of the CSR values (the same device check runs on its bits).  Launches
+ * of spmv_f32f64 with this pointer then stream 17 instead of 33 B of matrix
+ * data per row of a 7-point matrix.  values32 = NULL drops the copy. */
+int spmv_hip_csr_plan_bake_values_f32f64(spmv_hip_ctx* ctx,
+                                         spmv_hip_csr_plan* plan,
+                                         const float* values32, void* stream);
 int spmv_hip_csr_plan_algo(const spmv_hip_csr_plan* plan, int* algo);
 /* Knobs (key/value; EINVAL for an unknown key or a value out of range):
  *   "algo" "lanes_per_row" "chunks" "nontemporal" "xcd_group" "blocks_per_cu"
@@ -225,7 +233,7 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value);
  * "lattice_d1", "lattice_d2" (row distance of the next grid line / plane when
  * the matrix is a 3-D lattice, else 0), "zwalk", "zwalk_segments",
  * "zwalk_grid", "lat_chain", "sdia_chain", "sdia_nt", "sdia_offsets" (lower
- * offsets of the baked copy), "sdia_general" (baked from a general matrix);
+ * offsets of the baked copy), "sdia_general" (baked from a general matrix), "sdia_mixed" (fp32 copy);
  * "blocks_per_cu", "nontemporal"; "plan_us" (wall time of plan creation, its
  * analysis kernels included) and "plan_kib" (device memory the plan owns). */
 int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,

@@ -78,6 +78,7 @@ _PROTOS = {
     "spmv_hip_csr_plan_destroy": ([vp], C.c_int),
     "spmv_hip_csr_plan_bake_values_f64": ([vp, vp, vp, vp, vp], C.c_int),
     "spmv_hip_csr_plan_bake_values_f32": ([vp, vp, vp, vp, vp], C.c_int),
+    "spmv_hip_csr_plan_bake_values_f32f64": ([vp, vp, vp, vp], C.c_int),
     "spmv_hip_csr_plan_algo": ([vp, P(C.c_int)], C.c_int),
     "spmv_hip_csr_plan_set": ([vp, C.c_char_p, C.c_int], C.c_int),
     "spmv_hip_csr_plan_get": ([vp, C.c_char_p, P(C.c_int)], C.c_int),

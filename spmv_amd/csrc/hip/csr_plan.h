@@ -178,6 +178,10 @@ struct spmv_hip_csr_plan {
   int sdia_U[3] = {0, 0, 0};      // ... their row distances, descending
   int sdia_general = 0;           // baked from a GENERAL matrix found symmetric:
                                   // the kernel sums in the general order
+  // ... and the fp32 copy for the mixed-precision SpMV (general, fp64 plans)
+  void* sdia32_val = nullptr;
+  uint8_t* sdia32_cmask = nullptr;
+  const void* sdia32_values0 = nullptr;
   int sdia_chain = 1;             // plane chain where the geometry allows
   // non-temporal streams (bit mask, see sdia_geom).  512^3: ring planes and
   // diagonal -0.5 %, y stores +-0, the far windows two workgroups share +10 %
@@ -286,6 +290,11 @@ int spmv_sdia_bake_f64(spmv_hip_csr_plan* pl, const double* values,
 int spmv_sdia_bake_f32(spmv_hip_csr_plan* pl, const float* values,
                        const float* diagonal, hipStream_t st);
 int spmv_sdia_grid(const spmv_hip_csr_plan* pl); // launch grid without a table
+int spmv_sdia_bake_f32f64(spmv_hip_csr_plan* pl, const float* values32,
+                          hipStream_t st);
+int spmv_sdia_run_f32f64(const spmv_hip_csr_plan* pl, hipStream_t st,
+                         double alpha, const double* in, double beta,
+                         double* out, DotOut dot);
 int spmv_sdia_run_f64(const spmv_hip_csr_plan* pl, hipStream_t st, double alpha,
                       const double* in, double beta, double* out, DotOut dot);
 int spmv_sdia_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st, float alpha,

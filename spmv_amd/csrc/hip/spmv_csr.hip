@@ -961,6 +961,10 @@ int run_mixed(const spmv_hip_csr_plan* pl, hipStream_t st,
                                               alpha, in, beta, out, dot);
   if (pl->algo != SPMV_HIP_ALGO_ROWBLOCK)
     return SPMV_HIP_ENOTSUP;
+  // the plan's fp32 copy of a symmetric matrix's lower half (spmv_symdia.hip)
+  if (pl->sdia && pl->sdia32_val && values == pl->sdia32_values0)
+    return spmv_sdia_run_f32f64(pl, st, alpha, in, beta, out,
+                                DOT ? dot : DotOut());
   if (pl->lat && aligned16(values))
     return spmv_lat_run_f32f64(pl, st, rowptr, values, alpha, in, beta, out,
                                DOT ? dot : DotOut());
@@ -1223,6 +1227,15 @@ int spmv_hip_csr_plan_bake_values_f32(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan
   return spmv_sdia_bake_f32(plan, values, diagonal, spmv_stream(ctx, stream));
 }
 
+int spmv_hip_csr_plan_bake_values_f32f64(spmv_hip_ctx* ctx,
+                                         spmv_hip_csr_plan* plan,
+                                         const float* values32, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(plan && plan->ctx == ctx);
+  return spmv_sdia_bake_f32f64(plan, values32, spmv_stream(ctx, stream));
+}
+
 int spmv_hip_csr_plan_algo(const spmv_hip_csr_plan* plan, int* algo)
 {
   SPMV_REQUIRE(plan && algo);
@@ -1360,6 +1373,8 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
       b += n;
     if (plan->sdia_val)
       b += (int64_t)(plan->sdia_nd + 1) * plan->sdia_len * plan->sdia_elem + n;
+    if (plan->sdia32_val)
+      b += (int64_t)(plan->sdia_nd + 1) * plan->sdia_len * 4 + n;
     if (plan->t_ptr)
       b += 4 * (n + 1) + 8 * nnz;
     if (plan->zw_table)
@@ -1370,6 +1385,8 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
     *value = plan->sdia_val ? plan->sdia_nd : 0;
   else if (!strcmp(key, "sdia_general"))
     *value = plan->sdia_val ? plan->sdia_general : 0;
+  else if (!strcmp(key, "sdia_mixed"))
+    *value = plan->sdia32_val ? 1 : 0;
   else if (!strcmp(key, "sdia_chain"))
     *value = plan->sdia_chain;
   else if (!strcmp(key, "sdia_nt"))

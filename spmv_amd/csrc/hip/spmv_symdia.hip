@@ -154,16 +154,20 @@ __device__ __forceinline__ SdiaRegs<T> sdia_loads(
 // offsets -- so the result has the bits of the CSR kernels while only half the
 // off-diagonal values cross the fabric (49 B per row of the 7-point matrix
 // instead of 73).
-template <typename T, bool DOT, bool RING, bool GEN>
+//
+// TV = type of the baked values (what is streamed), T = type of x, y and of all
+// the arithmetic.  TV = float with T = double is the mixed-precision SpMV
+//  on the diagonal form: 17 instead of 33 B of matrix data per row.
+template <typename TV, typename T, bool DOT, bool RING, bool GEN>
 __global__ __launch_bounds__(kBlock) void csr_sym_dia_kernel(
-    int32_t num_rows, int64_t arr_len, const T* __restrict__ sval,
+    int32_t num_rows, int64_t arr_len, const TV* __restrict__ sval,
     const uint8_t* __restrict__ cmask, T alpha, const T* __restrict__ in, T beta,
     T* __restrict__ out, DotOut dot, RowBlockOrder ord, SdiaGeom g)
 {
-  constexpr int V = 16 / (int)sizeof(T);
+  constexpr int V = 16 / (int)sizeof(TV);
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   __shared__ double s_red[kBlock / 64];
-  T* const s_val = reinterpret_cast<T*>(s_dyn);
+  TV* const s_val = reinterpret_cast<TV*>(s_dyn);
   const unsigned lds0 = (unsigned)(uintptr_t)(
       (__attribute__((address_space(3))) void*)s_val);
 
@@ -187,10 +191,10 @@ __global__ __launch_bounds__(kBlock) void csr_sym_dia_kernel(
         chunk = chunk < g.last[j] ? chunk : g.last[j];
         int64_t e = base + (int64_t)chunk * V;
         e = e < arr_len - V ? e : arr_len - V; // arrays are padded with zeros
-        const T* src = sval + (int64_t)g.arr[j] * arr_len + e;
+        const TV* src = sval + (int64_t)g.arr[j] * arr_len + e;
         const unsigned dst
             = lds0
-              + (unsigned)((slot * g.slot_entries + g.lds[j]) * (int)sizeof(T))
+              + (unsigned)((slot * g.slot_entries + g.lds[j]) * (int)sizeof(TV))
               + (unsigned)wave * 1024u;
         if (g.nt[j]) // uniform
           glds16<true>(src, dst);
@@ -202,12 +206,12 @@ __global__ __launch_bounds__(kBlock) void csr_sym_dia_kernel(
 
   // 256 rows of array 0 from `first_row` -> ring buffer r
   auto ring_dma = [&](int64_t first_row, int r) {
-    constexpr int pieces = kRows * (int)sizeof(T) / 1024;
+    constexpr int pieces = kRows * (int)sizeof(TV) / 1024;
     if (wave < pieces) { // uniform
       int64_t e = first_row + (int64_t)(wave * 64 + lane) * V;
       e = e < arr_len - V ? e : arr_len - V;
       const unsigned dst = lds0
-                           + (unsigned)((g.ring_off + r * kRows) * (int)sizeof(T))
+                           + (unsigned)((g.ring_off + r * kRows) * (int)sizeof(TV))
                            + (unsigned)wave * 1024u;
       if (g.nt_ring) // uniform
         glds16<true>(sval + e, dst);
@@ -256,22 +260,22 @@ __global__ __launch_bounds__(kBlock) void csr_sym_dia_kernel(
     qn = sdia_loads<T>(nxt, g, t, num_rows, cmask, in, beta, out, chain, q);
     const int32_t i = cur * kRows + t;
     if (cur >= 0 && i < num_rows) {
-      const T* sv = s_val + slot * g.slot_entries + t;
+      const TV* sv = s_val + slot * g.slot_entries + t;
       T vl[kSdiaMaxOff], vu[kSdiaMaxOff];
 #pragma unroll
       for (int k = 0; k < kSdiaMaxOff; ++k) {
         vl[k] = vu[k] = T(0);
         if (k < g.nd) { // uniform
           if (RING && k == 0) {
-            vl[k] = s_val[g.ring_off + R0 * kRows + t];
-            vu[k] = s_val[g.ring_off + R1 * kRows + t];
+            vl[k] = (T)s_val[g.ring_off + R0 * kRows + t];
+            vu[k] = (T)s_val[g.ring_off + R1 * kRows + t];
           } else {
-            vl[k] = sv[g.own_idx[k]];
-            vu[k] = sv[g.col_idx[k]];
+            vl[k] = (T)sv[g.own_idx[k]];
+            vu[k] = (T)sv[g.col_idx[k]];
           }
         }
       }
-      const T d = sv[g.d_idx];
+      const T d = (T)sv[g.d_idx];
       T y, cy;
       if constexpr (GEN) {
         T sum = 0; // csr_kernels.cpp:45
@@ -535,33 +539,37 @@ int sdia_grid(const spmv_hip_csr_plan* pl)
   return grid < 1 ? 1 : grid;
 }
 
-template <typename T>
-int sdia_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha,
-                const T* in, T beta, T* out, DotOut dot)
+// `sval` / `cmask`: the baked copy to stream (the plan's native one, or the
+// fp32 copy of the mixed-precision SpMV)
+template <typename TV, typename T>
+int sdia_launch(const spmv_hip_csr_plan* pl, hipStream_t st, const TV* sval,
+                const uint8_t* cmask, T alpha, const T* in, T beta, T* out,
+                DotOut dot)
 {
-  const SdiaGeom g = sdia_geom<T>(pl);
+  const SdiaGeom g = sdia_geom<TV>(pl);
   const int nrb = (pl->num_rows + kRows - 1) / kRows;
-  const size_t lds = sdia_lds_bytes<T>(g);
-  const int grid = sdia_grid<T>(pl);
+  const size_t lds = sdia_lds_bytes<TV>(g);
+  const int grid = sdia_grid<TV>(pl);
   RowBlockOrder ord = pl->row_block_order(nrb);
   ord.xcd_group = pl->lat_xcd_group;
   if (pl->zwalk && pl->zw_table && pl->zw_grid == grid) {
     ord.table = pl->zw_table;
     ord.num_slots = pl->zw_slots;
   }
-  const T* sval = static_cast<const T*>(pl->sdia_val);
 #define SPMV_SDIA(DOTV, RINGV)                                                 \
   do {                                                                         \
     if (pl->sdia_general)                                                      \
-      hipLaunchKernelGGL((csr_sym_dia_kernel<T, DOTV, RINGV, true>),           \
+      hipLaunchKernelGGL((csr_sym_dia_kernel<TV, T, DOTV, RINGV, true>),       \
                          dim3(grid), dim3(kBlock), lds, st, pl->num_rows,      \
-                         pl->sdia_len, sval, pl->sdia_cmask, alpha, in, beta,  \
-                         out, dot, ord, g);                                    \
+                         pl->sdia_len, sval, cmask, alpha, in, beta, out, dot, \
+                         ord, g);                                              \
+    else if constexpr (sizeof(TV) == sizeof(T))                                \
+      hipLaunchKernelGGL((csr_sym_dia_kernel<TV, T, DOTV, RINGV, false>),      \
+                         dim3(grid), dim3(kBlock), lds, st, pl->num_rows,      \
+                         pl->sdia_len, sval, cmask, alpha, in, beta, out, dot, \
+                         ord, g);                                              \
     else                                                                       \
-      hipLaunchKernelGGL((csr_sym_dia_kernel<T, DOTV, RINGV, false>),          \
-                         dim3(grid), dim3(kBlock), lds, st, pl->num_rows,      \
-                         pl->sdia_len, sval, pl->sdia_cmask, alpha, in, beta,  \
-                         out, dot, ord, g);                                    \
+      return SPMV_HIP_ENOTSUP; /* mixed precision: general storage only */     \
   } while (0)
   if (dot.partials) {
     if (g.chain_blocks)
@@ -638,42 +646,14 @@ int sdia_general_offsets(spmv_hip_csr_plan* pl, hipStream_t st, int* nd, int* U)
   return SPMV_HIP_OK;
 }
 
+// Allocate and fill one baked copy for the offsets in pl->sdia_nd / sdia_U:
+// SPMV_HIP_ENOTSUP when the geometry does not fit or (general) the matrix is
+// not symmetric.
 template <typename T>
-int sdia_bake(spmv_hip_csr_plan* pl, const T* values, const T* diagonal,
-              hipStream_t st)
+int sdia_fill(spmv_hip_csr_plan* pl, bool general, const T* values,
+              const T* diagonal, hipStream_t st, void** out_val,
+              uint8_t** out_cmask, int64_t* out_len)
 {
-  SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
-  const auto t_begin = std::chrono::steady_clock::now();
-  const bool had = pl->sdia_val != nullptr;
-  spmv_sdia_free(pl);
-  if (values == nullptr && diagonal == nullptr) // dropped
-    return had ? sdia_restore_walk(pl) : SPMV_HIP_OK;
-  const bool general = !pl->symmetric;
-  SPMV_REQUIRE(values && (general ? diagonal == nullptr : diagonal != nullptr));
-  if (pl->nnz == 0)
-    return SPMV_HIP_ENOTSUP;
-  if (general) {
-    // rests on the lattice form (ascending columns without repeats, a row
-    // block's worth of structure) of a square matrix
-    if (!pl->ctx->bake_general || !pl->lat_tab || pl->num_rows != pl->num_cols)
-      return SPMV_HIP_ENOTSUP;
-    int nd = 0, U[kSdiaMaxOff] = {0, 0, 0};
-    const int rc = sdia_general_offsets(pl, st, &nd, U);
-    if (rc != SPMV_HIP_OK)
-      return rc;
-    if (nd == 0)
-      return SPMV_HIP_ENOTSUP;
-    pl->sdia_nd = nd;
-    for (int k = 0; k < kSdiaMaxOff; ++k)
-      pl->sdia_U[k] = U[k];
-  } else {
-    // rests on the symmetric lattice analysis
-    if (!pl->slat_mask)
-      return SPMV_HIP_ENOTSUP;
-    pl->sdia_nd = pl->slat_nd;
-    for (int k = 0; k < kSdiaMaxOff; ++k)
-      pl->sdia_U[k] = -pl->slat_D[k];
-  }
   const SdiaGeom g = sdia_geom<T>(pl);
   for (int j = 0; j < g.nwin; ++j)
     if (g.pieces[j] > kBlock / 64)
@@ -722,6 +702,58 @@ int sdia_bake(spmv_hip_csr_plan* pl, const T* values, const T* diagonal,
     (void)hipFree(cm);
     return e != hipSuccess ? static_cast<int>(e) : SPMV_HIP_ENOTSUP;
   }
+  *out_val = sval;
+  *out_cmask = cm;
+  *out_len = len;
+  return SPMV_HIP_OK;
+}
+
+template <typename T>
+int sdia_bake(spmv_hip_csr_plan* pl, const T* values, const T* diagonal,
+              hipStream_t st)
+{
+  SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
+  const auto t_begin = std::chrono::steady_clock::now();
+  const bool had = pl->sdia_val != nullptr;
+  spmv_sdia_free(pl);
+  if (values == nullptr && diagonal == nullptr) // dropped
+    return had ? sdia_restore_walk(pl) : SPMV_HIP_OK;
+  const bool general = !pl->symmetric;
+  SPMV_REQUIRE(values && (general ? diagonal == nullptr : diagonal != nullptr));
+  if (pl->nnz == 0)
+    return SPMV_HIP_ENOTSUP;
+  if (general) {
+    // rests on the lattice form (ascending columns without repeats, a row
+    // block's worth of structure) of a square matrix
+    if (!pl->ctx->bake_general || !pl->lat_tab || pl->num_rows != pl->num_cols)
+      return SPMV_HIP_ENOTSUP;
+    int nd = 0, U[kSdiaMaxOff] = {0, 0, 0};
+    const int rc = sdia_general_offsets(pl, st, &nd, U);
+    if (rc != SPMV_HIP_OK)
+      return rc;
+    if (nd == 0)
+      return SPMV_HIP_ENOTSUP;
+    pl->sdia_nd = nd;
+    for (int k = 0; k < kSdiaMaxOff; ++k)
+      pl->sdia_U[k] = U[k];
+  } else {
+    // rests on the symmetric lattice analysis
+    if (!pl->slat_mask)
+      return SPMV_HIP_ENOTSUP;
+    pl->sdia_nd = pl->slat_nd;
+    for (int k = 0; k < kSdiaMaxOff; ++k)
+      pl->sdia_U[k] = -pl->slat_D[k];
+  }
+  void* sval = nullptr;
+  uint8_t* cm = nullptr;
+  int64_t len = 0;
+  {
+    const int rc = sdia_fill<T>(pl, general, values, diagonal, st, &sval, &cm,
+                                &len);
+    if (rc != SPMV_HIP_OK)
+      return rc;
+  }
+  const SdiaGeom g = sdia_geom<T>(pl);
   pl->sdia_val = sval;
   pl->sdia_cmask = cm;
   pl->sdia_len = len;
@@ -745,12 +777,49 @@ int sdia_bake(spmv_hip_csr_plan* pl, const T* values, const T* diagonal,
   return spmv_zwalk_order_build(pl, g.U[0], sdia_grid<T>(pl), 0, false);
 }
 
+// The fp32 copy of the mixed-precision SpMV (general plans whose fp64 values
+// are baked): the same arrays filled from the caller's fp32 values -- the same
+// device check, on the fp32 bits.
+int sdia_bake_mixed(spmv_hip_csr_plan* pl, const float* values32, hipStream_t st)
+{
+  SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
+  (void)hipFree(pl->sdia32_val);
+  (void)hipFree(pl->sdia32_cmask);
+  pl->sdia32_val = nullptr;
+  pl->sdia32_cmask = nullptr;
+  pl->sdia32_values0 = nullptr;
+  if (values32 == nullptr)
+    return SPMV_HIP_OK; // dropped
+  if (!pl->sdia_val || !pl->sdia_general || pl->sdia_elem != 8)
+    return SPMV_HIP_ENOTSUP;
+  const auto t_begin = std::chrono::steady_clock::now();
+  void* sval = nullptr;
+  uint8_t* cm = nullptr;
+  int64_t len = 0;
+  const int rc = sdia_fill<float>(pl, true, values32, nullptr, st, &sval, &cm,
+                                  &len);
+  if (rc != SPMV_HIP_OK)
+    return rc;
+  pl->sdia32_val = sval;
+  pl->sdia32_cmask = cm;
+  pl->sdia32_values0 = values32;
+  pl->plan_us += (int)std::chrono::duration_cast<std::chrono::microseconds>(
+                     std::chrono::steady_clock::now() - t_begin)
+                     .count();
+  return SPMV_HIP_OK;
+}
+
 } // namespace
 
 void spmv_sdia_free(spmv_hip_csr_plan* pl)
 {
   (void)hipFree(pl->sdia_val);
   (void)hipFree(pl->sdia_cmask);
+  (void)hipFree(pl->sdia32_val);
+  (void)hipFree(pl->sdia32_cmask);
+  pl->sdia32_val = nullptr;
+  pl->sdia32_cmask = nullptr;
+  pl->sdia32_values0 = nullptr;
   pl->sdia_val = nullptr;
   pl->sdia_cmask = nullptr;
   pl->sdia_values0 = pl->sdia_diag0 = nullptr;
@@ -780,14 +849,34 @@ int spmv_sdia_bake_f32(spmv_hip_csr_plan* pl, const float* values,
   return sdia_bake<float>(pl, values, diagonal, st);
 }
 
+int spmv_sdia_bake_f32f64(spmv_hip_csr_plan* pl, const float* values32,
+                          hipStream_t st)
+{
+  return sdia_bake_mixed(pl, values32, st);
+}
+
 int spmv_sdia_run_f64(const spmv_hip_csr_plan* pl, hipStream_t st, double alpha,
                       const double* in, double beta, double* out, DotOut dot)
 {
-  return sdia_launch<double>(pl, st, alpha, in, beta, out, dot);
+  return sdia_launch<double, double>(pl, st,
+                                     static_cast<const double*>(pl->sdia_val),
+                                     pl->sdia_cmask, alpha, in, beta, out, dot);
 }
 
 int spmv_sdia_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st, float alpha,
                       const float* in, float beta, float* out)
 {
-  return sdia_launch<float>(pl, st, alpha, in, beta, out, DotOut());
+  return sdia_launch<float, float>(pl, st,
+                                   static_cast<const float*>(pl->sdia_val),
+                                   pl->sdia_cmask, alpha, in, beta, out,
+                                   DotOut());
+}
+
+int spmv_sdia_run_f32f64(const spmv_hip_csr_plan* pl, hipStream_t st,
+                         double alpha, const double* in, double beta,
+                         double* out, DotOut dot)
+{
+  return sdia_launch<float, double>(pl, st,
+                                    static_cast<const float*>(pl->sdia32_val),
+                                    pl->sdia32_cmask, alpha, in, beta, out, dot);
 }

@@ -1503,3 +1503,60 @@ def test_mixed_precision_spmv_bit_exact(lat_ctx):
         for b in (d32, dx, part):
             b.free()
         blk.free()
+
+
+def test_mixed_precision_on_the_diagonal_form_bit_exact(lat_ctx):
+    """plan_bake_values_f32f64: the fp32 copy by offset of a general matrix
+    found symmetric (fp64 copy baked first).  spmv_f32f64 with the baked fp32
+    pointer = the general reference loop on the fp32 values in fp64, bit for
+    bit; other pointers take the lattice kernel."""
+    ctx = lat_ctx
+    rng = np.random.default_rng(101)
+    for name, N, offs, kw in (("poisson16", 16 ** 3, [-256, -16, -1], {}),
+                              ("poisson33", 33 ** 3, [-1089, -33, -1], {}),
+                              ("far3", 9001, [-2000, -300, -1],
+                               dict(drop=0.3, diag_drop=0.2))):
+        rp, ci, va = _symmetric_general_csr(rng, N, offs, **kw)
+        va32 = va.astype(np.float32)
+        x = rng.uniform(-1, 1, N)
+        y0 = rng.uniform(-1, 1, N)
+        blk = hip.CsrBlock(ctx, N, N, rp, ci, va, None, False, hip.ALGO_ROWBLOCK)
+        d32 = ctx.upload(va32, np.float32)
+        with pytest.raises(Exception):  # the fp64 copy comes first
+            hip.call("spmv_hip_csr_plan_bake_values_f32f64", ctx.h, blk.plan,
+                     d32.ptr, None)
+        blk.bake()
+        hip.call("spmv_hip_csr_plan_bake_values_f32f64", ctx.h, blk.plan, d32.ptr,
+                 None)
+        assert blk.get("sdia_mixed") == 1, name
+        dx = ctx.upload(x)
+        part = ctx.empty(ctx.dot_partials_len, np.float64)
+        other = ctx.upload(va32, np.float32)
+        for alpha, beta in ((1.0, 0.0), (-0.5, 0.75)):
+            y_ref = oracle.csr_spmv(rp, ci, va32.astype(np.float64), x, alpha,
+                                    beta, y0)
+            for vals, knobs in ((d32, dict()), (d32, dict(zwalk_segments=2)),
+                                (d32, dict(sdia_chain=0)), (other, dict(sdia_chain=1))):
+                for k, v in knobs.items():
+                    blk.set(k, v)
+                dy = ctx.upload(np.full(N, np.nan) if beta == 0 else y0)
+                dot = beta == 0
+                hip.call("spmv_hip_csr_spmv_f32f64", ctx.h, blk.plan, N, N,
+                         blk.nnz, blk.rowptr.ptr, blk.colind.ptr, vals.ptr,
+                         float(alpha), dx.ptr, float(beta), dy.ptr,
+                         part.ptr if dot else None, None)
+                assert np.array_equal(dy.numpy(), y_ref), (name, alpha, beta, knobs)
+                if dot:
+                    want = float(np.dot(x, y_ref))
+                    got = float(np.sum(part.numpy()))
+                    assert abs(got - want) <= 1e-12 * (np.abs(x) @ np.abs(y_ref))
+                dy.free()
+        # the fp64 SpMV of the same plan is untouched
+        dy = ctx.upload(np.full(N, np.nan))
+        blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+        assert np.array_equal(dy.numpy(), oracle.csr_spmv(rp, ci, va, x)), name
+        hip.call("spmv_hip_csr_plan_bake_values_f32f64", ctx.h, blk.plan, None, None)
+        assert blk.get("sdia_mixed") == 0
+        for b in (d32, dx, part, other, dy):
+            b.free()
+        blk.free()

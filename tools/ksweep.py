@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--dot", action="store_true", help="fused p.Ap partials")
     ap.add_argument("--symmetric", action="store_true",
                     help="symmetric storage (lower block + diagonal)")
+    ap.add_argument("--bake", action="store_true",
+                    help="general storage: let the plan find the matrix symmetric")
     ap.add_argument("--out", default=None)
     ap.add_argument("--calib", action="store_true",
                     help="also time plain streaming kernels on this box")
@@ -38,7 +40,7 @@ def main():
                                   with_diagonal=True)
     else:
         blk = hip.poisson3d_block(ctx, n, 0, N, hip.PART_ALL)
-    if args.symmetric:
+    if args.symmetric or args.bake:
         blk.bake()  # the diagonal form; knob sdia=0 runs the CSR-order kernel
     x, y = ctx.empty(N, np.float64), ctx.empty(N, np.float64)
     ctx.fill_gaussian(N, 0, N, x.ptr)

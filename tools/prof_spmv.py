@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--no-lat", action="store_true",
                     help="no lattice form: the plan takes the LX form")
     ap.add_argument("--no-bake", action="store_true",
-                    help="symmetric: the CSR-order lattice kernel")
+                    help="no baked copy: the CSR-order lattice kernels")
     ap.add_argument("--no-lx", action="store_true",
                     help="neither: the plain gather kernel")
     args = ap.parse_args()
@@ -37,8 +37,8 @@ def main():
     n, N = args.n, args.n ** 3
     part = hip.PART_LOCAL_LOWER if args.symmetric else hip.PART_ALL
     blk = hip.poisson3d_block(ctx, n, 0, N, part, with_diagonal=args.symmetric)
-    if args.symmetric and not args.no_bake:
-        blk.bake()  # symmetric diagonal form
+    if not args.no_bake and not (args.no_lat or args.no_lx):
+        blk.bake()  # diagonal form (general: the matrix is found symmetric)
     for kv in args.set:
         k, v = kv.split("=")
         blk.set(k, int(v))
