@@ -31,8 +31,15 @@
 //      registers: no staging pass, no index arithmetic.
 // One workgroup barrier per row block (the LX kernel needs six).
 //
-// Measured on MI355X, 512^3 (profiles/r02_*): 2.03-2.07 ms against 2.57-2.62 ms
-// for the LX kernel on the same boxes.  Variants measured and dropped: waves
+// Plane walk and x chain: when the plan finds a 3-D lattice the row blocks are
+// walked column by column from plane to plane (spmv_zwalk_order_build) and
+// the x a row holds for the plane ahead is handed to the next step in
+// registers (lat_loads): 448^3 1.51 -> 1.39 ms, fabric reads at 512^3 12.2 ->
+// 9.6 GB per launch.
+//
+// Measured on MI355X, 512^3 (profiles/r02_*): 1.98-2.07 ms against 2.41-2.62 ms
+// for the LX kernel on the same boxes.  (Matrices that are also SYMMETRIC leave
+// this kernel for the diagonal form, spmv_symdia.hip: 1.35 ms.)  Variants measured and dropped: waves
 // with private slots and no barrier at all (equal at 16 waves per CU, 9 %
 // slower at 32), two rows per lane with 16-byte x / y accesses (17 % slower),
 // non-temporal y stores (-1.8 %).  What the time is made of (ablations, same
@@ -567,10 +574,10 @@ int spmv_lat_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
                                             spmv_lat_grid(pl), 0, false);
       if (rc != SPMV_HIP_OK)
         return rc;
-      // (A band-sweep order -- every XCD sweeping a band of grid lines through
-      // all planes -- was measured in this place earlier: 12.3 -> 9.7 GB of
-      // fabric reads at 512^3 and still 6-12 % slower, its table look-up
-      // draining the DMA prefetch every step; profiles/r02_pmc_lattice_512.json.)
+      // (An earlier order table -- every XCD sweeping a strip of grid lines
+      // through all planes -- cut the fabric reads at 512^3 from 12.3 to 9.7 GB
+      // and ran 6-12 % slower: higher fabric latency, and a table look-up that
+      // was waited for every step; profiles/r02_pmc_lattice_512.json.)
     }
   }
   return SPMV_HIP_OK;

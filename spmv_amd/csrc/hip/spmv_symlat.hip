@@ -23,7 +23,12 @@
 // HBM bytes per row of the 7-point matrix: 24 (values) + 8 (diagonal) + 4 + 1
 // (row pointer, mask) + 8 (x) + 8 (y) = 53 against 77 for the general lattice
 // form and 104 for plain CSR; the column spans are re-reads that the L2s and
-// the Infinity Cache serve.
+// the Infinity Cache serve -- in CSR order each of them drags a row's three
+// values along for the one that is used, which is why the DIAGONAL form
+// (spmv_symdia.hip: the plan's copy of the values by offset, 1.35 ms at 512^3
+// against 2.36 ms here) replaces this kernel whenever the values are baked.
+// This one runs on the caller's own arrays: the C ABI without
+// plan_bake_values, or a launch with other value pointers.
 //
 // Plan (slat_build): the global offset set (one for the whole matrix, so that
 // a mask bit means the same thing in every row), one mask byte per row, and
