@@ -211,6 +211,14 @@ int spmv_hip_csr_plan_bake_values_f32f64(spmv_hip_ctx* ctx,
                                          spmv_hip_csr_plan* plan,
                                          const float* values32, void* stream);
 int spmv_hip_csr_plan_algo(const spmv_hip_csr_plan* plan, int* algo);
+/* The plane-walk order table the lattice kernels take (host arithmetic only, no
+ * device: for inspection and tests).  Slot (round * L + step) * grid + w holds
+ * the row block workgroup w computes at that step, -1 = none; planes are
+ * `plane_rows` rows apart; segments = runs along the plane axis (0 = choose).
+ * Call with table = NULL for the size. */
+int spmv_hip_zwalk_table(int32_t num_rows, int64_t plane_rows, int grid,
+                         int segments, int32_t* table, int64_t capacity,
+                         int64_t* num_slots, int* segments_out);
 /* Knobs (key/value; EINVAL for an unknown key or a value out of range):
  *   "algo" "lanes_per_row" "chunks" "nontemporal" "xcd_group" "blocks_per_cu"
  *   "nt_store"                           the plain general kernels

@@ -76,6 +76,8 @@ _PROTOS = {
     "spmv_hip_csr_plan_create": ([vp, i32, i32, i64, vp, vp, C.c_int, C.c_int,
                                   P(vp)], C.c_int),
     "spmv_hip_csr_plan_destroy": ([vp], C.c_int),
+    "spmv_hip_zwalk_table": ([i32, i64, C.c_int, C.c_int, vp, i64, P(i64),
+                              P(C.c_int)], C.c_int),
     "spmv_hip_csr_plan_bake_values_f64": ([vp, vp, vp, vp, vp], C.c_int),
     "spmv_hip_csr_plan_bake_values_f32": ([vp, vp, vp, vp, vp], C.c_int),
     "spmv_hip_csr_plan_bake_values_f32f64": ([vp, vp, vp, vp], C.c_int),

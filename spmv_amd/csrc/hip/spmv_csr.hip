@@ -1015,22 +1015,18 @@ void spmv_zwalk_free(spmv_hip_csr_plan* pl)
   pl->zwalk = 0; // zw_d2 stays: a knob can rebuild
 }
 
-int spmv_zwalk_order_build(spmv_hip_csr_plan* pl, int64_t d2, int grid,
-                           int segments, bool force)
+// The table itself: host arithmetic only (spmv_hip_zwalk_table exposes it to
+// the CPU tests).  Returns false when the lattice is too small for a table to
+// pay (and !force) or the slot count would not fit an int.
+static bool zwalk_table(int32_t num_rows, int64_t d2, int grid, int segments,
+                        bool force, std::vector<int32_t>* table, int* segs_out)
 {
-  SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
-  if (pl->zw_table) {
-    SPMV_CHECK_HIP(hipDeviceSynchronize()); // no launch still reads the old one
-    spmv_zwalk_free(pl);
-  }
-  const int64_t nrb = ((int64_t)pl->num_rows + kRows - 1) / kRows;
-  SPMV_REQUIRE(d2 > 0 && grid > 0 && segments >= 0);
-  pl->zw_d2 = d2;
-  const int64_t nz = ((int64_t)pl->num_rows + d2 - 1) / d2;
+  const int64_t nrb = ((int64_t)num_rows + kRows - 1) / kRows;
+  const int64_t nz = ((int64_t)num_rows + d2 - 1) / d2;
   const int64_t P = (d2 + kRows - 1) / kRows; // columns
   // worth it only for a real 3-D (or wide 2-D) lattice that outgrows the grid
   if (!force && (P < 8 || nz < 8 || nrb < 4 * (int64_t)grid))
-    return SPMV_HIP_OK;
+    return false;
   auto first_block = [&](int64_t z) {
     const int64_t b = (z * d2 + kRows - 1) / kRows;
     return b < nrb ? b : nrb;
@@ -1052,16 +1048,18 @@ int spmv_zwalk_order_build(spmv_hip_csr_plan* pl, int64_t d2, int grid,
       }
     }
   }
+  if (Q > nz)
+    Q = nz;
   const int64_t L = (nz + Q - 1) / Q;
   Q = (nz + L - 1) / L; // no empty segments
   const int64_t W = Q * P;
   const int64_t rounds = (W + grid - 1) / grid;
   const int64_t slots = rounds * L * grid;
   if (slots > INT32_MAX)
-    return SPMV_HIP_OK;
+    return false;
   const int g = 8; // consecutive columns per XCD
   const bool by_xcd = grid % (8 * g) == 0;
-  std::vector<int32_t> table((size_t)slots, -1);
+  table->assign((size_t)slots, -1);
   for (int64_t r = 0; r < rounds; ++r)
     for (int w = 0; w < grid; ++w) {
       int64_t idx = w;
@@ -1079,9 +1077,27 @@ int spmv_zwalk_order_build(spmv_hip_csr_plan* pl, int64_t d2, int grid,
           break;
         const int64_t b = first_block(z) + c;
         if (b < first_block(z + 1))
-          table[(size_t)((r * L + s) * grid + w)] = (int32_t)b;
+          (*table)[(size_t)((r * L + s) * grid + w)] = (int32_t)b;
       }
     }
+  *segs_out = (int)Q;
+  return true;
+}
+
+int spmv_zwalk_order_build(spmv_hip_csr_plan* pl, int64_t d2, int grid,
+                           int segments, bool force)
+{
+  SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
+  if (pl->zw_table) {
+    SPMV_CHECK_HIP(hipDeviceSynchronize()); // no launch still reads the old one
+    spmv_zwalk_free(pl);
+  }
+  SPMV_REQUIRE(d2 > 0 && grid > 0 && segments >= 0);
+  pl->zw_d2 = d2;
+  std::vector<int32_t> table;
+  int segs = 0;
+  if (!zwalk_table(pl->num_rows, d2, grid, segments, force, &table, &segs))
+    return SPMV_HIP_OK;
   SPMV_CHECK_HIP(hipMalloc(&pl->zw_table, sizeof(int32_t) * table.size()));
   hipError_t e = hipMemcpy(pl->zw_table, table.data(),
                            sizeof(int32_t) * table.size(),
@@ -1090,9 +1106,9 @@ int spmv_zwalk_order_build(spmv_hip_csr_plan* pl, int64_t d2, int grid,
     spmv_zwalk_free(pl);
     return static_cast<int>(e);
   }
-  pl->zw_slots = (int)slots;
+  pl->zw_slots = (int)table.size();
   pl->zw_grid = grid;
-  pl->zw_segments = (int)Q;
+  pl->zw_segments = segs;
   pl->zwalk = 1;
   return SPMV_HIP_OK;
 }
@@ -1234,6 +1250,25 @@ int spmv_hip_csr_plan_bake_values_f32f64(spmv_hip_ctx* ctx,
   SPMV_SET_DEVICE(ctx);
   SPMV_REQUIRE(plan && plan->ctx == ctx);
   return spmv_sdia_bake_f32f64(plan, values32, spmv_stream(ctx, stream));
+}
+
+int spmv_hip_zwalk_table(int32_t num_rows, int64_t plane_rows, int grid,
+                         int segments, int32_t* table, int64_t capacity,
+                         int64_t* num_slots, int* segments_out)
+{
+  SPMV_REQUIRE(num_rows > 0 && plane_rows > 0 && grid > 0 && segments >= 0
+               && num_slots && segments_out);
+  std::vector<int32_t> t;
+  int segs = 0;
+  if (!zwalk_table(num_rows, plane_rows, grid, segments, true, &t, &segs))
+    return SPMV_HIP_ERANGE;
+  *num_slots = (int64_t)t.size();
+  *segments_out = segs;
+  if (table) {
+    SPMV_REQUIRE(capacity >= (int64_t)t.size());
+    std::copy(t.begin(), t.end(), table);
+  }
+  return SPMV_HIP_OK;
 }
 
 int spmv_hip_csr_plan_algo(const spmv_hip_csr_plan* plan, int* algo)

@@ -568,3 +568,69 @@ def test_box_partition_rows_match_the_permuted_matrix(n, parts):
         host.poisson3d_box_rows(n, (n + 1, 1, 1), 0)
     with pytest.raises(host.SpmvHostError):
         host.poisson3d_box_rows(n, parts, P)
+
+
+def _zwalk_table(rows, plane_rows, grid, segments=0):
+    import ctypes as C
+    slots, segs = C.c_int64(), C.c_int()
+    _lib.call("spmv_hip_zwalk_table", rows, plane_rows, grid, segments, None, 0,
+              C.byref(slots), C.byref(segs))
+    t = np.empty(slots.value, np.int32)
+    _lib.call("spmv_hip_zwalk_table", rows, plane_rows, grid, segments,
+              t.ctypes.data_as(C.c_void_p), len(t), C.byref(slots), C.byref(segs))
+    return t, segs.value
+
+
+@pytest.mark.parametrize("n,grid,segments", [
+    (512, 1024, 0),   # the benchmark: one plane = 1024 row blocks = the grid
+    (448, 1024, 0),   # 784 columns: runs along the plane axis balance the grid
+    (384, 1024, 0), (216, 1024, 0),  # planes not a whole number of row blocks
+    (128, 512, 3), (64, 64, 1), (33, 24, 2), (16, 1024, 5)])
+def test_plane_walk_table(n, grid, segments):
+    """spmv_hip_zwalk_table (what the lattice kernels walk): a permutation of
+    the row blocks plus empty slots; inside a run a workgroup's consecutive
+    blocks are one plane apart (exactly, when planes are whole row blocks: the
+    plane chain of the kernels rests on it); 8 consecutive columns share an
+    XCD; the work is balanced."""
+    rows, d2 = n ** 3, n * n
+    nrb = (rows + 255) // 256
+    t, segs = _zwalk_table(rows, d2, grid, segments)
+    assert len(t) % grid == 0
+    used = t[t >= 0]
+    assert np.array_equal(np.sort(used), np.arange(nrb))      # each block once
+    if segments:
+        assert 1 <= segs <= segments
+    per_wg = t.reshape(-1, grid)                              # [step, workgroup]
+    nz = (rows + d2 - 1) // d2
+    L = -(-nz // segs)
+    chained = total = 0
+    for w in range(0, grid, max(1, grid // 64)):
+        col = per_wg[:, w]
+        for r in range(len(col) // L):
+            run = col[r * L:(r + 1) * L].astype(np.int64)
+            # consecutive STEPS that both have work (the last column of a
+            # plane exists only in the planes with one row block more)
+            both = (run[1:] >= 0) & (run[:-1] >= 0)
+            d = (run[1:] - run[:-1])[both] * 256
+            total += len(d)
+            assert np.all(np.abs(d - d2) < 256 + 1), (w, r)   # one plane apart
+            chained += int(np.sum(d == d2))
+    if d2 % 256 == 0 and total:
+        assert chained == total                               # exactly
+    # balance: the busiest workgroup does at most 35 % more than the mean
+    # (much less for the large cases)
+    work = (per_wg >= 0).sum(0)
+    if nrb >= 4 * grid and segments == 0:  # the builder's own choice of runs
+        assert work.max() <= 1.35 * nrb / grid + 1
+    if n == 512:
+        assert segs == 1 and len(t) == nrb and work.min() == work.max() == 512
+    if grid % 64 == 0 and nrb >= grid:
+        # XCD = workgroup % 8 owns runs of 8 consecutive columns
+        first = per_wg[0]
+        cols = {w: int(first[w]) for w in range(64) if first[w] >= 0}
+        for x in range(8):
+            mine = sorted(c for w, c in cols.items() if w % 8 == x)
+            if len(mine) == 8:
+                assert mine == list(range(mine[0], mine[0] + 8))
+    with pytest.raises(Exception):
+        _zwalk_table(rows, 0, grid)
