@@ -1,9 +1,11 @@
-// Symmetric DIAGONAL form for gfx950 (MI355X): the symmetric lattice form
+// DIAGONAL form for gfx950 (MI355X): the symmetric lattice form
 // (spmv_symlat.hip) with the matrix VALUES re-laid out by the plan -- one
 // array per lower offset plus the diagonal -- so that the entries a row needs
 // from its column are a plain shifted window of the same arrays.  SURVEY 8f n4
-// ("DIA fast path for stencils") for the symmetric storage of
-// spmv/csr_kernels.cpp:26-40; same arithmetic, same order, same bits.
+// ("DIA fast path for stencils"), for the symmetric storage of
+// spmv/csr_kernels.cpp:26-40 and (GEN kernels, below) for a GENERAL matrix that
+// a device check finds symmetric; same arithmetic, same order, same bits as
+// the reference kernel of the storage the caller chose.
 //
 // Why: in CSR order a row of the 7-point matrix holds its three lower entries
 // side by side, and row i needs, besides its own, ONE of the three of each of
@@ -25,10 +27,11 @@
 // of the plane ahead are handed to the next step in LDS / registers instead of
 // being loaded again.
 //
-// Measured at 512^3 (MI355X, profiles/r02_pmc_symdia_512.json): 1.33-1.36 ms
-// = 0.79-0.80 of the symmetric-CSR roofline; 7.45 GB read + 1.07 GB written
-// through the fabric for 5.50 + 1.07 unique, i.e. 6.3 TB/s of real traffic --
-// the rate the general lattice kernel and a plain copy reach on this part.
+// Measured at 512^3 (MI355X, profiles/r02_pmc_summary.json): 1.35 ms = 0.79
+// of the symmetric-CSR roofline (general storage: 10.3 TB/s of CSR bytes);
+// 6.95 GB read + 1.07 GB written through the fabric for 5.50 + 1.07 unique,
+// i.e. 5.9 TB/s of real traffic -- about what this part gives a kernel that
+// mixes reads and writes (a plain copy: 4.8-5.1).
 // What is left over the unique 82 lines per row block (102 are read): the x
 // loads at +-n (9 lines: the neighbour columns' lines, fetched one step
 // earlier) and the far window of the middle offset (9 lines: another
@@ -139,9 +142,9 @@ __device__ __forceinline__ SdiaRegs<T> sdia_loads(
 // is, most of the time, exactly one plane (U[0] rows) below the current one.
 // Then the far column window of offset 0 it has in LDS IS the next block's own
 // window, and the x it holds for the rows one plane ahead IS the next block's
-// x_i: nothing of that is loaded again (2.5-D streaming; measured before: those
-// re-reads, one step and ~3 MiB of other L2 traffic later, missed the 4 MiB L2
-// more often than not -- 7.7 GB through the fabric for 5.5 GB of unique reads).
+// x_i: nothing of that is loaded again (2.5-D streaming).  It takes 32 of 220
+// L2 requests per row block away -- most of them were hits, the fabric reads
+// barely change -- and 8 % of the time.
 // The offset-0 planes sit in a ring of four buffers: two in use (own, far), up
 // to two being filled for the next block (far only when chained; own and far
 // after a jump).
