@@ -133,6 +133,11 @@ int spmvh_matrix_blocks(spmvh_matrix* A, int64_t out[6]);
  * plan: which form it took, what it cost, launch-shape knobs */
 int spmvh_matrix_plan_get(spmvh_matrix* A, int remote, const char* key,
                           int* value);
+/* Matrix::enable_mixed / use_mixed: fp32 copies of the blocks'
+ * values (ok = 0: symmetric storage, nothing done); mult / mult_dot then stream
+ * those while `on`. */
+int spmvh_matrix_enable_mixed(spmvh_matrix* A, int* ok);
+int spmvh_matrix_use_mixed(spmvh_matrix* A, int on);
 int spmvh_matrix_plan_set(spmvh_matrix* A, int remote, const char* key,
                           int value);
 /* A.col_map()->update(x) ; A.mult(x, y) ; A.col_map()->update_finalise(x) */

@@ -453,6 +453,22 @@ int spmvh_matrix_plan_set(spmvh_matrix* A, int remote, const char* key,
   });
 }
 
+int spmvh_matrix_enable_mixed(spmvh_matrix* A, int* ok)
+{
+  return guarded([&] {
+    require(A && ok, "NULL argument");
+    *ok = A->A->enable_mixed() ? 1 : 0;
+  });
+}
+
+int spmvh_matrix_use_mixed(spmvh_matrix* A, int on)
+{
+  return guarded([&] {
+    require(A, "NULL argument");
+    A->A->use_mixed(on != 0);
+  });
+}
+
 int spmvh_matrix_update(spmvh_matrix* A, double* x)
 {
   return guarded([&] {

@@ -70,6 +70,8 @@ _PROTOS = {
     "spmvh_matrix_blocks": [vp, PTR(i64)],
     "spmvh_matrix_plan_get": [vp, C.c_int, C.c_char_p, PTR(C.c_int)],
     "spmvh_matrix_plan_set": [vp, C.c_int, C.c_char_p, C.c_int],
+    "spmvh_matrix_enable_mixed": [vp, PTR(C.c_int)],
+    "spmvh_matrix_use_mixed": [vp, C.c_int],
     "spmvh_matrix_update": [vp, vp],
     "spmvh_matrix_update_finalise": [vp, vp],
     "spmvh_matrix_mult": [vp, vp, vp],
@@ -421,6 +423,14 @@ class Matrix:
         call("spmvh_matrix_plan_get", self.h, int(remote), key.encode(),
              C.byref(v))
         return v.value
+
+    def enable_mixed(self):
+        ok = C.c_int()
+        call("spmvh_matrix_enable_mixed", self.h, C.byref(ok))
+        return bool(ok.value)
+
+    def use_mixed(self, on):
+        call("spmvh_matrix_use_mixed", self.h, int(bool(on)))
 
     def plan_set(self, key, value, remote=False):
         call("spmvh_matrix_plan_set", self.h, int(remote), key.encode(),

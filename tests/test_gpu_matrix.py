@@ -305,6 +305,48 @@ def test_benchmark_scale_512_cubed(exec_, comm):
     exec_.free(d_one), exec_.free(d_b)
 
 
+@pytest.mark.parametrize("n", [448, 512])
+def test_full_size_kernels_agree_bit_for_bit(exec_, comm, n):
+    """Size-independent cross-check at the benchmark's scale (and at 448^3,
+    where the plane-walk table has 32 runs and empty slots): every kernel is
+    bit-exact against the oracle at the sizes the oracle can do, so at full
+    size the DIAGONAL form (the default) must agree bit for bit with the
+    CSR-order lattice kernels on the same plan, for the reference's Gaussian x
+    and both storages; the mixed-precision copy likewise (Poisson values are
+    exact in fp32)."""
+    N = n ** 3
+    ctx = exec_.context
+    from spmv_amd import _lib
+    d_x, d_y = exec_.alloc(N), exec_.alloc(N)
+    _lib.call("spmv_hip_fill_gaussian_f64", ctx, N, 0, N, d_x, None)
+    for symmetric in (False, True):
+        A = host.Matrix.create_poisson3d(comm, exec_, n, symmetric,
+                                         host.P2P_NONBLOCKING)
+        assert A.plan_get("sdia") == 1 and A.plan_get("zwalk") == 1
+        A.mult(d_x, d_y)
+        y_dia = exec_.copy_to_host(d_y, N)
+        assert np.isfinite(y_dia).all() and np.abs(y_dia).max() > 0
+        A.plan_set("sdia", 0)                     # lattice / symmetric lattice
+        assert A.plan_get("lat" if not symmetric else "slat") == 1
+        _lib.call("spmv_hip_fill_const_f64", ctx, N, float("nan"), d_y, None)
+        A.mult(d_x, d_y)
+        assert np.array_equal(exec_.copy_to_host(d_y, N), y_dia), symmetric
+        A.plan_set("zwalk", 0)                    # ... in the plain order
+        _lib.call("spmv_hip_fill_const_f64", ctx, N, float("nan"), d_y, None)
+        A.mult(d_x, d_y)
+        assert np.array_equal(exec_.copy_to_host(d_y, N), y_dia), symmetric
+        A.plan_set("sdia", 1)
+        if not symmetric:
+            assert A.enable_mixed() and A.plan_get("sdia_mixed") == 1
+            A.use_mixed(True)
+            _lib.call("spmv_hip_fill_const_f64", ctx, N, float("nan"), d_y, None)
+            A.mult(d_x, d_y)
+            A.use_mixed(False)
+            assert np.array_equal(exec_.copy_to_host(d_y, N), y_dia)
+        A.close()
+    exec_.free(d_x), exec_.free(d_y)
+
+
 # ---------------------------------------------------------------------------
 # Many ranks as threads of this process, all on GPU 0 (tests/thread_world.py):
 # the 8-way slab layout of BASELINE configs[4] and unstructured halos with up
