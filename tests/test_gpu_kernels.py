@@ -1560,3 +1560,67 @@ def test_mixed_precision_on_the_diagonal_form_bit_exact(lat_ctx):
         for b in (d32, dx, part, other, dy):
             b.free()
         blk.free()
+
+
+def test_diagonal_form_fuzz(lat_ctx):
+    """Random symmetric lattice matrices -- sizes around the row-block
+    boundaries, 1-3 offsets anywhere between 1 and the matrix size (merged,
+    separate, chained and misaligned windows), random drops, rows without a
+    diagonal -- through BOTH storages of the diagonal form, forced plane-walk
+    tables included: bit-exact against the oracle's general / symmetric loops."""
+    ctx = lat_ctx
+    rng = np.random.default_rng(2026)
+    sizes = [1, 2, 255, 256, 257, 511, 512, 513, 1000, 4096, 5000, 20000, 65536, 70001]
+    done = 0
+    for trial in range(60):
+        N = int(sizes[trial % len(sizes)] if trial < 28 else rng.integers(300, 60000))
+        nd = int(rng.integers(1, 4))
+        pool = [1, 2, 3, 63, 64, 65, 255, 256, 257, 512, 768, 1024, 2048, 4096]
+        pool += [int(v) for v in rng.integers(1, max(2, N), 6)]
+        offs = sorted({int(o) for o in rng.choice(pool, nd) if o < N}, reverse=True)
+        if not offs:
+            continue
+        drop = float(rng.choice([0.0, 0.0, 0.3]))
+        ddrop = float(rng.choice([0.0, 0.25]))
+        rp, ci, va = _symmetric_general_csr(rng, N, [-o for o in offs], drop=drop,
+                                            diag_drop=ddrop)
+        if len(va) == 0:
+            continue
+        x = rng.uniform(-1, 1, N)
+        y0 = rng.uniform(-1, 1, N)
+        alpha, beta = (1.0, 0.0) if trial % 2 else (-1.5, 0.5)
+        # general storage: lattice form + device symmetry check
+        blk = hip.CsrBlock(ctx, N, N, rp, ci, va, None, False, hip.ALGO_ROWBLOCK)
+        assert blk.get("lat") == 1, (trial, N, offs)
+        blk.bake()
+        assert blk.get("sdia") == 1 and blk.get("sdia_offsets") == len(offs)
+        dx = ctx.upload(x)
+        y_ref = oracle.csr_spmv(rp, ci, va, x, alpha, beta, y0)
+        for knobs in (dict(), dict(zwalk_segments=int(rng.integers(0, 4))),
+                      dict(slat_blocks_per_cu=int(rng.integers(1, 5)))):
+            for k, v in knobs.items():
+                blk.set(k, v)
+            dy = ctx.upload(np.full(N, np.nan) if beta == 0 else y0)
+            blk.mult(alpha, dx.ptr, beta, dy.ptr)
+            assert np.array_equal(dy.numpy(), y_ref), (trial, N, offs, drop, knobs)
+            dy.free()
+        blk.free()
+        # symmetric storage of the same matrix (needs a full diagonal)
+        if ddrop == 0.0:
+            lrp, lci, lva, dg = lower_split(rp, ci, va)
+            if len(lva):
+                sb = hip.CsrBlock(ctx, N, N, lrp, lci, lva, dg, True)
+                if sb.get("slat") == 1:
+                    sb.bake()
+                    ys = oracle.csr_spmv_sym(lrp, lci, lva, dg, x, alpha, beta, y0)
+                    for knobs in (dict(), dict(zwalk_segments=int(rng.integers(0, 4)))):
+                        for k, v in knobs.items():
+                            sb.set(k, v)
+                        dy = ctx.upload(np.full(N, np.nan) if beta == 0 else y0)
+                        sb.mult(alpha, dx.ptr, beta, dy.ptr)
+                        assert np.array_equal(dy.numpy(), ys), (trial, N, offs, knobs)
+                        dy.free()
+                sb.free()
+        dx.free()
+        done += 1
+    assert done >= 45
