@@ -371,11 +371,17 @@ def test_slab_ranks_threaded_spmv_and_cg(world, n):
 
     def rank_body(rank, comm, exec_):
         from spmv_amd import _lib
-        # small as they are, the local blocks take the LX form (staged x windows)
+        # small as they are, the local blocks take the forms of the benchmark:
+        # lattice analysis, and on it the diagonal form wherever the block is
+        # square (every block but the single ghost-column block of the
+        # blocking general model)
         _lib.call("spmv_hip_ctx_set_option", exec_.context, b"lx_min_nnz", 0)
+        _lib.call("spmv_hip_ctx_set_option", exec_.context, b"lat_min_nnz", 0)
         r0, r1 = int(ranges[rank]), int(ranges[rank + 1])
         for (sym, cm), (y_ref, (x_ref, k_ref, hist_ref)) in refs.items():
             A = host.Matrix.create_poisson3d(comm, exec_, n, sym, cm)
+            if r1 - r0 >= 2 * n * n:  # at least two planes: all three offsets
+                assert A.plan_get("sdia") == int(sym or cm == host.P2P_NONBLOCKING)
             l2g = A.col_map()
             assert l2g.local_size() == r1 - r0
             assert len(l2g.plan().neighbours) == (1 if rank in (0, world - 1) else 2)
@@ -427,9 +433,13 @@ def test_box_partition_ranks_threaded_spmv_and_cg(n, parts):
     tw = ThreadWorld(world, timeout=45.0)
 
     def rank_body(rank, comm, exec_):
+        from spmv_amd import _lib
+        # lattice analysis (and the diagonal form on it) for these small boxes
+        _lib.call("spmv_hip_ctx_set_option", exec_.context, b"lat_min_nnz", 0)
         r0, r1 = int(ranges[rank]), int(ranges[rank + 1])
         for (sym, cm), (y_ref, (x_ref, k_ref, hist_ref)) in refs.items():
             A = host.Matrix.create_poisson3d_boxes(comm, exec_, n, parts, sym, cm)
+            assert A.plan_get("sdia") == int(sym or cm == host.P2P_NONBLOCKING)
             l2g = A.col_map()
             assert l2g.local_size() == r1 - r0 == A.rows()
             d_x = exec_.alloc(l2g.local_size() + l2g.num_ghosts())
