@@ -67,11 +67,14 @@ struct SdiaGeom {
   int nd;                 // lower offsets
   int U[kSdiaMaxOff];     // row distance -D[k] > 0 (D ascending: U descending)
   int nwin;               // DMA windows per row block
-  int arr[kSdiaMaxWin];   // array of window j (nd = diagonal)
+  // Per window, packed: the kernel keeps all of this in scalar registers, and
+  // one word per field overflowed them (90 spills per wave)
   int first[kSdiaMaxWin]; // its first row relative to r0
-  int pieces[kSdiaMaxWin];  // 1-KiB DMA pieces (<= 4: one per wave)
-  int last[kSdiaMaxWin];  // last 16-byte chunk the window needs
-  int lds[kSdiaMaxWin];   // entry offset of the window inside a slot
+  int last[kSdiaMaxWin];  // last 16-byte chunk the window needs (its 1-KiB
+                          // DMA pieces, <= 4: one per wave, = last / 64 + 1)
+  int lds[kSdiaMaxWin];   // entry offset of the window inside a slot (a
+                          // multiple of 128) | array of the window (bits 0-1,
+                          // nd = diagonal) | non-temporal (bit 2)
   int own_idx[kSdiaMaxOff]; // slot entry of v_k[r0]      (+ lane = own entry)
   int col_idx[kSdiaMaxOff]; // slot entry of v_k[r0 + U_k] (+ lane = column entry)
   int d_idx;              // slot entry of d[r0]
@@ -81,9 +84,11 @@ struct SdiaGeom {
   // ring of four 256-row buffers behind the slots (see the kernel)
   int chain_blocks;       // U[0] / 256, 0 = no ring
   int ring_off;           // entry offset of the ring
-  int nt[kSdiaMaxWin];    // window j is streamed non-temporally
-  int nt_ring, nt_store;  // ... the ring planes, the y stores
+  int nt_ring, nt_store;  // non-temporal: the ring planes, the y stores
 };
+__host__ __device__ inline int sdia_win_arr(int lds) { return lds & 3; }
+__host__ __device__ inline int sdia_win_nt(int lds) { return (lds >> 2) & 1; }
+__host__ __device__ inline int sdia_win_lds(int lds) { return lds & ~127; }
 
 template <typename T>
 struct SdiaRegs {
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(kBlock) void csr_sym_dia_kernel(
     const int64_t r0 = (int64_t)rb * kRows;
 #pragma unroll
     for (int j = 0; j < kSdiaMaxWin; ++j) {
-      if (j < g.nwin && wave < g.pieces[j]) { // uniform
+      if (j < g.nwin && wave <= (g.last[j] >> 6)) { // uniform
         const int64_t base = (r0 + g.first[j]) & ~(int64_t)(V - 1);
         // lanes past the window re-read its last chunk (one cached line)
         // instead of streaming the next row block's data
@@ -194,12 +199,13 @@ __global__ __launch_bounds__(kBlock) void csr_sym_dia_kernel(
         chunk = chunk < g.last[j] ? chunk : g.last[j];
         int64_t e = base + (int64_t)chunk * V;
         e = e < arr_len - V ? e : arr_len - V; // arrays are padded with zeros
-        const TV* src = sval + (int64_t)g.arr[j] * arr_len + e;
+        const TV* src = sval + (int64_t)sdia_win_arr(g.lds[j]) * arr_len + e;
         const unsigned dst
             = lds0
-              + (unsigned)((slot * g.slot_entries + g.lds[j]) * (int)sizeof(TV))
+              + (unsigned)((slot * g.slot_entries + sdia_win_lds(g.lds[j]))
+                           * (int)sizeof(TV))
               + (unsigned)wave * 1024u;
-        if (g.nt[j]) // uniform
+        if (sdia_win_nt(g.lds[j])) // uniform
           glds16<true>(src, dst);
         else
           glds16<false>(src, dst);
@@ -471,14 +477,12 @@ SdiaGeom sdia_geom(const spmv_hip_csr_plan* pl)
   auto add = [&](int arr, int first, int rows) {
     const int lead = first & (V - 1); // alignment slack in front
     const int pieces = (lead + rows + per_piece - 1) / per_piece;
-    g.arr[w] = arr;
     g.first[w] = first;
-    g.pieces[w] = pieces;
     g.last[w] = (lead + rows - 1) / V;
-    g.lds[w] = entries;
+    g.lds[w] = entries | arr; // entries: a multiple of per_piece >= 128
     entries += pieces * per_piece;
     ++w;
-    return g.lds[w - 1] + lead; // slot entry of row r0 + first
+    return sdia_win_lds(g.lds[w - 1]) + lead; // slot entry of row r0 + first
   };
   for (int k = 0; k < g.nd; ++k) {
     g.U[k] = pl->sdia_U[k];
@@ -505,12 +509,15 @@ SdiaGeom sdia_geom(const spmv_hip_csr_plan* pl)
   g.nt_ring = m & 1;
   g.nt_store = (m >> 4) & 1;
   for (int j = 0; j < w; ++j) {
-    if (g.arr[j] == g.nd)
-      g.nt[j] = (m >> 1) & 1;
-    else if (g.U[g.arr[j]] < kRows)
-      g.nt[j] = (m >> 2) & 1;
+    const int arr = sdia_win_arr(g.lds[j]);
+    int nt;
+    if (arr == g.nd)
+      nt = (m >> 1) & 1;
+    else if (g.U[arr] < kRows)
+      nt = (m >> 2) & 1;
     else
-      g.nt[j] = (m >> 3) & 1;
+      nt = (m >> 3) & 1;
+    g.lds[j] |= nt << 2;
   }
   return g;
 }
@@ -659,7 +666,7 @@ int sdia_fill(spmv_hip_csr_plan* pl, bool general, const T* values,
 {
   const SdiaGeom g = sdia_geom<T>(pl);
   for (int j = 0; j < g.nwin; ++j)
-    if (g.pieces[j] > kBlock / 64)
+    if ((g.last[j] >> 6) + 1 > kBlock / 64)
       return SPMV_HIP_ENOTSUP;
   if (sdia_lds_bytes<T>(g) > 150 * 1024)
     return SPMV_HIP_ENOTSUP;
