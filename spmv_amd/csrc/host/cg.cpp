@@ -18,6 +18,7 @@
 // synchronisations for the same step (cuda/cg.cuda.cu:101-151).
 #include "cg.h"
 
+#include <algorithm>
 #include <cmath>
 #include <stdexcept>
 
@@ -308,7 +309,9 @@ int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
   }
 
   // final state: {done, kstop} and the squared-residual history
-  std::vector<double> rr(kmax + 1, 0.0);
+  // (the device history has the WORKSPACE's capacity, which an earlier solve
+  // with a larger kmax may have set: the copy is that long)
+  std::vector<double> rr((size_t)std::max(kmax, w.kmax_cap) + 1, 0.0);
   throw_on_error(spmv_hip_cg_ws_read_async(w.ws, w.flags, rr.data(), nullptr),
                  "spmv_hip_cg_ws_read_async");
   double true_rr = -1.0;

@@ -633,6 +633,28 @@ def _cg_vs_oracle(exec_, comm, n, symmetric, rhs, consume_modes, threads=1,
     exec_.free(d_b), exec_.free(d_x)
 
 
+def test_cg_workspace_reused_with_smaller_kmax(exec_, comm):
+    """A workspace sized by a long solve serves shorter ones: the residual
+    history on the device keeps the workspace's capacity, so the host copy
+    must too (this overflowed a host vector once)."""
+    n = 64
+    N = n ** 3
+    rp, ci, va = oracle.poisson3d(n)
+    b = oracle.csr_spmv(rp, ci, va, np.ones(N))
+    A = host.Matrix.create_poisson3d(comm, exec_, n, False, host.P2P_NONBLOCKING)
+    d_b, d_x = exec_.alloc(N), exec_.alloc(N)
+    exec_.copy_from_host(d_b, b)
+    ws = host.CgWorkspace(exec_)
+    k1, h1, _, _ = host.cg_ex(comm, exec_, A, d_b, d_x, 300, 1e-12, ws, history=True)
+    for kmax in (7, 1, 40):
+        k2, h2, _, _ = host.cg_ex(comm, exec_, A, d_b, d_x, kmax, 1e-12, ws,
+                                  history=True)
+        assert k2 == min(kmax, k1) and np.array_equal(h2, h1[:k2 + 1]), kmax
+    ws.close()
+    A.close()
+    exec_.free(d_b), exec_.free(d_x)
+
+
 @pytest.mark.parametrize("symmetric", [False, True])
 @pytest.mark.parametrize("rhs", ["A*ones", "gaussian"])
 def test_cg_128_cubed_vs_oracle(exec_, comm, symmetric, rhs):
