@@ -207,6 +207,13 @@ def kernel_of(A, symmetric):
         return ("csr_sym_window_kernel<double> (LDS window + global atomics)",
                 algo, algo)
     algo = nnz * 12 + (rows + 1) * 4 + y_x  # SURVEY 8d B_csr
+    if A.plan_get("sdia") and A.plan_get("sdia_general") == 2:
+        nd = A.plan_get("sdia_offsets")
+        return ("csr_sym_dia_kernel<double, general order, full> (lattice matrix "
+                "that is not symmetric: the plan keeps ALL its values by offset, "
+                "windows by LDS-DMA, no index stream, rows summed in the CSR "
+                "kernel's order: bit-exact; fused p.Ap)",
+                algo, rows * (8 * (2 * nd + 1) + 1) + y_x)
     if A.plan_get("sdia"):
         nd = A.plan_get("sdia_offsets")
         return ("csr_sym_dia_kernel<double, general order> (the general matrix "

@@ -184,13 +184,15 @@ int spmv_hip_csr_plan_destroy(spmv_hip_csr_plan* plan);
  * cuSPARSE descriptor of cuda/csr_kernels.cu binds the values there too).
  *   symmetric plan   in the symmetric lattice form (<= 3 constant lower
  *                    offsets); pass values and diagonal
- *   general plan     (diagonal = NULL) in the lattice form, square, and
- *                    SYMMETRIC entry for entry and bit for bit with <= 3
- *                    distinct |col - row| > 0 -- checked on the device here.
- *                    The kernel then reads only the lower half and the
- *                    diagonal (49 instead of 73 B per row of a 7-point matrix)
- *                    and sums each row in the general kernel's own order:
- *                    same bits as csr_kernels.cpp:41-51.
+ *   general plan     (diagonal = NULL) in the lattice form, square, with <= 3
+ *                    distinct |col - row| > 0.  If the device check finds the
+ *                    matrix SYMMETRIC entry for entry and bit for bit, the
+ *                    plan keeps the lower half and the diagonal only (49
+ *                    instead of 73 B per row of a 7-point matrix); if not,
+ *                    ALL values by offset (the "full" form: the bytes of the
+ *                    CSR values, no index stream, no row pointer).  Either
+ *                    way the kernel sums each row in the general kernel's own
+ *                    order: same bits as csr_kernels.cpp:41-51.
  * Anything else: SPMV_HIP_ENOTSUP, nothing changes.  Costs (offsets + 1) * 8 B
  * per row of device memory.  A launch that passes these very `values` (and
  * `diagonal`) pointers takes the diagonal-form kernel; a launch with other
@@ -241,7 +243,8 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value);
  * "lattice_d1", "lattice_d2" (row distance of the next grid line / plane when
  * the matrix is a 3-D lattice, else 0), "zwalk", "zwalk_segments",
  * "zwalk_grid", "lat_chain", "sdia_chain", "sdia_nt", "sdia_offsets" (lower
- * offsets of the baked copy), "sdia_general" (baked from a general matrix), "sdia_mixed" (fp32 copy);
+ * offsets of the baked copy), "sdia_general" (baked from a general matrix: 1 = symmetric, half stored; 2 =
+ * full form), "sdia_mixed" (fp32 copy);
  * "blocks_per_cu", "nontemporal"; "plan_us" (wall time of plan creation, its
  * analysis kernels included) and "plan_kib" (device memory the plan owns). */
 int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,

@@ -176,8 +176,10 @@ struct spmv_hip_csr_plan {
   int sdia = 0;                   // use it (plan_set "sdia")
   int sdia_nd = 0;                // lower offsets ...
   int sdia_U[3] = {0, 0, 0};      // ... their row distances, descending
-  int sdia_general = 0;           // baked from a GENERAL matrix found symmetric:
-                                  // the kernel sums in the general order
+  int sdia_general = 0;           // baked from a GENERAL matrix (the kernel sums
+                                  // in the general order): 1 = found symmetric,
+                                  // lower half stored; 2 = not symmetric, FULL
+                                  // form with arrays for the upper entries too
   // ... and the fp32 copy for the mixed-precision SpMV (general, fp64 plans)
   void* sdia32_val = nullptr;
   uint8_t* sdia32_cmask = nullptr;

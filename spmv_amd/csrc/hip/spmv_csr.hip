@@ -1406,10 +1406,12 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
       b += 48 * nrb + n;
     if (plan->slat_mask)
       b += n;
+    const int64_t narr
+        = plan->sdia_general == 2 ? 2 * plan->sdia_nd + 1 : plan->sdia_nd + 1;
     if (plan->sdia_val)
-      b += (int64_t)(plan->sdia_nd + 1) * plan->sdia_len * plan->sdia_elem + n;
+      b += narr * plan->sdia_len * plan->sdia_elem + n;
     if (plan->sdia32_val)
-      b += (int64_t)(plan->sdia_nd + 1) * plan->sdia_len * 4 + n;
+      b += narr * plan->sdia_len * 4 + n;
     if (plan->t_ptr)
       b += 4 * (n + 1) + 8 * nnz;
     if (plan->zw_table)

@@ -73,8 +73,9 @@ struct SdiaGeom {
   int last[kSdiaMaxWin];  // last 16-byte chunk the window needs (its 1-KiB
                           // DMA pieces, <= 4: one per wave, = last / 64 + 1)
   int lds[kSdiaMaxWin];   // entry offset of the window inside a slot (a
-                          // multiple of 128) | array of the window (bits 0-1,
-                          // nd = diagonal) | non-temporal (bit 2)
+                          // multiple of 128) | array of the window (bits 0-2:
+                          // lower k, nd = diagonal, nd + 1 + k = upper k of
+                          // the FULL form) | non-temporal (bit 3)
   int own_idx[kSdiaMaxOff]; // slot entry of v_k[r0]      (+ lane = own entry)
   int col_idx[kSdiaMaxOff]; // slot entry of v_k[r0 + U_k] (+ lane = column entry)
   int d_idx;              // slot entry of d[r0]
@@ -82,12 +83,14 @@ struct SdiaGeom {
   // Plane chain (RING kernels): when the farthest offset is a whole number of
   // row blocks, offset 0 has no windows in the slots; its planes live in a
   // ring of four 256-row buffers behind the slots (see the kernel)
-  int chain_blocks;       // U[0] / 256, 0 = no ring
+  int chain_blocks;       // U[0] / 256 when that is whole (x is handed from
+                          // plane to plane), else 0
+  int ring;               // ... and the offset-0 value planes live in the ring
   int ring_off;           // entry offset of the ring
   int nt_ring, nt_store;  // non-temporal: the ring planes, the y stores
 };
-__host__ __device__ inline int sdia_win_arr(int lds) { return lds & 3; }
-__host__ __device__ inline int sdia_win_nt(int lds) { return (lds >> 2) & 1; }
+__host__ __device__ inline int sdia_win_arr(int lds) { return lds & 7; }
+__host__ __device__ inline int sdia_win_nt(int lds) { return (lds >> 3) & 1; }
 __host__ __device__ inline int sdia_win_lds(int lds) { return lds & ~127; }
 
 template <typename T>
@@ -253,8 +256,8 @@ __global__ __launch_bounds__(kBlock) void csr_sym_dia_kernel(
     __syncthreads();
     const int nxt = order_slot_decode(ord, nxt_raw);
     const int nn_raw = order_slot_raw(ord, it + 2 * stride, num_slots);
-    const bool chain
-        = RING && cur >= 0 && nxt >= 0 && nxt - cur == g.chain_blocks;
+    const bool chain = g.chain_blocks > 0 && cur >= 0 && nxt >= 0
+                       && nxt - cur == g.chain_blocks;
     if (nxt >= 0) {
       issue(nxt, slot ^ 1);
       if constexpr (RING) {
@@ -420,10 +423,12 @@ __device__ __forceinline__ bool same_bits(T a, T b)
     return __float_as_int(a) == __float_as_int(b);
 }
 
-// pass 2: fill the arrays and the mask; every off-diagonal entry (i, c) must
-// have its mirror (c, i) with the same bits.  (Ascending columns without
-// repeats are what the lattice form, a precondition, already guarantees.)
-template <typename T>
+// pass 2: fill the arrays and the mask.  Half form: every off-diagonal entry
+// (i, c) must have its mirror (c, i) with the same bits, only the lower entries
+// are stored.  FULL form: no such demand, the upper entries go to arrays of
+// their own (nd + 1 + k).  (Ascending columns without repeats are what the
+// lattice form, a precondition, already guarantees.)
+template <typename T, bool FULL>
 __global__ __launch_bounds__(kBlock) void sdia_bake_general_kernel(
     int32_t num_rows, int nd, int u0, int u1, int u2,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
@@ -444,7 +449,7 @@ __global__ __launch_bounds__(kBlock) void sdia_bake_general_kernel(
       const int64_t u = c < i ? i - c : c - i;
       const int k = u == u0 ? 0 : (u == u1 ? 1 : (u == u2 ? 2 : -1));
       bool ok = k >= 0 && k < nd && c < num_rows;
-      if (ok) {
+      if (ok && !FULL) {
         ok = false;
         for (int32_t jj = rowptr[c]; jj < rowptr[c + 1]; ++jj)
           if (colind[jj] == i)
@@ -458,6 +463,8 @@ __global__ __launch_bounds__(kBlock) void sdia_bake_general_kernel(
         sval[(int64_t)k * arr_len + i] = v;
         cm |= 1u << k;
       } else {
+        if (FULL)
+          sval[(int64_t)(nd + 1 + k) * arr_len + i] = v;
         cm |= 1u << (4 + k);
       }
     }
@@ -484,13 +491,22 @@ SdiaGeom sdia_geom(const spmv_hip_csr_plan* pl)
     ++w;
     return sdia_win_lds(g.lds[w - 1]) + lead; // slot entry of row r0 + first
   };
+  // FULL form (a general matrix that is NOT symmetric): the upper entries have
+  // arrays of their own, every array is read through its own window only
+  const bool full = pl->sdia_general == 2;
   for (int k = 0; k < g.nd; ++k) {
     g.U[k] = pl->sdia_U[k];
     if (k == 0 && pl->sdia_chain && g.U[0] >= kRows && g.U[0] % kRows == 0) {
-      g.chain_blocks = g.U[0] / kRows; // offset 0 lives in the ring
-      continue;
+      g.chain_blocks = g.U[0] / kRows;
+      if (!full) { // offset 0 lives in the ring
+        g.ring = 1;
+        continue;
+      }
     }
-    if (g.U[k] < kRows) { // the column window overlaps the own one: extend it
+    if (full) {
+      g.own_idx[k] = add(k, 0, kRows);
+      g.col_idx[k] = add(g.nd + 1 + k, 0, kRows);
+    } else if (g.U[k] < kRows) { // the column window overlaps the own one
       g.own_idx[k] = add(k, 0, kRows + g.U[k]);
       g.col_idx[k] = g.own_idx[k] + g.U[k];
     } else {
@@ -513,11 +529,11 @@ SdiaGeom sdia_geom(const spmv_hip_csr_plan* pl)
     int nt;
     if (arr == g.nd)
       nt = (m >> 1) & 1;
-    else if (g.U[arr] < kRows)
+    else if (g.U[arr > g.nd ? arr - g.nd - 1 : arr] < kRows)
       nt = (m >> 2) & 1;
     else
       nt = (m >> 3) & 1;
-    g.lds[j] |= nt << 2;
+    g.lds[j] |= nt << 3;
   }
   return g;
 }
@@ -525,7 +541,7 @@ SdiaGeom sdia_geom(const spmv_hip_csr_plan* pl)
 template <typename T>
 size_t sdia_lds_bytes(const SdiaGeom& g)
 {
-  return ((size_t)2 * g.slot_entries + (g.chain_blocks ? 4 * kRows : 0))
+  return ((size_t)2 * g.slot_entries + (g.ring ? 4 * kRows : 0))
          * sizeof(T);
 }
 
@@ -582,12 +598,12 @@ int sdia_launch(const spmv_hip_csr_plan* pl, hipStream_t st, const TV* sval,
       return SPMV_HIP_ENOTSUP; /* mixed precision: general storage only */     \
   } while (0)
   if (dot.partials) {
-    if (g.chain_blocks)
+    if (g.ring)
       SPMV_SDIA(true, true);
     else
       SPMV_SDIA(true, false);
   } else {
-    if (g.chain_blocks)
+    if (g.ring)
       SPMV_SDIA(false, true);
     else
       SPMV_SDIA(false, false);
@@ -673,7 +689,8 @@ int sdia_fill(spmv_hip_csr_plan* pl, bool general, const T* values,
   const int32_t n = pl->num_rows;
   // every window of every row block stays inside its array
   const int64_t len = (((int64_t)n + kRows - 1) / kRows) * kRows + 2 * kRows;
-  const size_t bytes = (size_t)(g.nd + 1) * len * sizeof(T);
+  const int narr = pl->sdia_general == 2 ? 2 * g.nd + 1 : g.nd + 1;
+  const size_t bytes = (size_t)narr * len * sizeof(T);
   void* sval = nullptr;
   uint8_t* cm = nullptr;
   int32_t* d_fail = nullptr;
@@ -689,11 +706,16 @@ int sdia_fill(spmv_hip_csr_plan* pl, bool general, const T* values,
     e = hipMemsetAsync(d_fail, 0, sizeof(int32_t), st);
   if (e == hipSuccess) {
     const int grid = spmv_grid_for(pl->ctx, n, kBlock);
-    if (general)
-      hipLaunchKernelGGL((sdia_bake_general_kernel<T>), dim3(grid), dim3(kBlock),
-                         0, st, n, g.nd, g.U[0], g.U[1], g.U[2], pl->rowptr0,
-                         pl->colind0, values, len, static_cast<T*>(sval), cm,
-                         d_fail);
+    if (general && pl->sdia_general == 2)
+      hipLaunchKernelGGL((sdia_bake_general_kernel<T, true>), dim3(grid),
+                         dim3(kBlock), 0, st, n, g.nd, g.U[0], g.U[1], g.U[2],
+                         pl->rowptr0, pl->colind0, values, len,
+                         static_cast<T*>(sval), cm, d_fail);
+    else if (general)
+      hipLaunchKernelGGL((sdia_bake_general_kernel<T, false>), dim3(grid),
+                         dim3(kBlock), 0, st, n, g.nd, g.U[0], g.U[1], g.U[2],
+                         pl->rowptr0, pl->colind0, values, len,
+                         static_cast<T*>(sval), cm, d_fail);
     else
       hipLaunchKernelGGL((sdia_bake_kernel<T>), dim3(grid), dim3(kBlock), 0, st,
                          n, g.nd, g.U[0], g.U[1], g.U[2], pl->rowptr0,
@@ -758,10 +780,19 @@ int sdia_bake(spmv_hip_csr_plan* pl, const T* values, const T* diagonal,
   uint8_t* cm = nullptr;
   int64_t len = 0;
   {
-    const int rc = sdia_fill<T>(pl, general, values, diagonal, st, &sval, &cm,
-                                &len);
-    if (rc != SPMV_HIP_OK)
+    // general storage: the half form when the matrix is symmetric bit for
+    // bit, else the full form (the geometry reads the mode from the plan)
+    pl->sdia_general = general ? 1 : 0;
+    int rc = sdia_fill<T>(pl, general, values, diagonal, st, &sval, &cm, &len);
+    if (rc == SPMV_HIP_ENOTSUP && general) {
+      pl->sdia_general = 2;
+      rc = sdia_fill<T>(pl, general, values, diagonal, st, &sval, &cm, &len);
+    }
+    if (rc != SPMV_HIP_OK) {
+      pl->sdia_general = 0;
+      pl->sdia_nd = 0;
       return rc;
+    }
   }
   const SdiaGeom g = sdia_geom<T>(pl);
   pl->sdia_val = sval;
@@ -770,7 +801,6 @@ int sdia_bake(spmv_hip_csr_plan* pl, const T* values, const T* diagonal,
   pl->sdia_elem = (int)sizeof(T);
   pl->sdia_values0 = values;
   pl->sdia_diag0 = diagonal;
-  pl->sdia_general = general ? 1 : 0;
   pl->sdia = 1;
   pl->plan_us += (int)std::chrono::duration_cast<std::chrono::microseconds>(
                      std::chrono::steady_clock::now() - t_begin)

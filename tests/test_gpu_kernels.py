@@ -1320,15 +1320,17 @@ def test_general_matrix_found_symmetric_takes_the_diagonal_form(lat_ctx, dtype):
         blk.free()
 
 
-def test_general_matrix_that_is_not_symmetric_is_not_baked(lat_ctx):
-    """One value off by an ulp, a sign of zero, a missing mirror entry, a fourth
-    offset, a rectangular block: the device check refuses, the plan keeps
-    running the lattice kernel on the caller's arrays."""
+def test_general_matrix_that_is_not_symmetric_takes_the_full_diagonal_form(lat_ctx):
+    """One value off by an ulp, a sign of zero, a missing mirror entry, or
+    values that are simply not symmetric: the device check refuses the HALF
+    form and the plan keeps ALL values by offset (full form, arrays for the
+    upper entries too) -- the bits of the general reference loop, all orders,
+    mixed-precision copy included.  A fourth offset or a rectangular block: no
+    diagonal form at all, the lattice kernel keeps running."""
     ctx = lat_ctx
     rng = np.random.default_rng(100)
     N = 6000
     rp, ci, va = _symmetric_general_csr(rng, N, [-700, -30, -1])
-    x = rng.uniform(-1, 1, N)
     cases = []
     v2 = va.copy()
     j = int(rp[3000])  # first entry of a middle row: a lower one
@@ -1341,29 +1343,77 @@ def test_general_matrix_that_is_not_symmetric_is_not_baked(lat_ctx):
     jm = int(rp[c]) + int(np.nonzero(ci[rp[c]:rp[c + 1]] == r)[0][0])
     v3[jl], v3[jm] = 0.0, -0.0
     cases.append(("signed_zero", rp, ci, v3, N))
-    # drop one upper entry: pattern no longer symmetric
-    keep = np.ones(len(ci), bool)
+    keep = np.ones(len(ci), bool)  # drop one upper entry: pattern not symmetric
     keep[jm] = False
     rp4 = np.concatenate([[0], np.cumsum(np.bincount(
         np.repeat(np.arange(N), np.diff(rp))[keep], minlength=N))]).astype(np.int32)
     cases.append(("missing_mirror", rp4, ci[keep], va[keep], N))
-    cases.append(("four", *_symmetric_general_csr(rng, N, [-700, -30, -2, -1]), N))
+    # plain non-symmetric stencils: 3-D lattice (chain), far / odd offsets with
+    # drops, one-sided (upwind) pattern
+    for n in (16, 33):
+        prp, pci, _ = poisson.poisson3d_csr(n)
+        cases.append((f"poisson{n}", prp, pci.astype(np.int32),
+                      rng.uniform(-1, 1, len(pci)), n ** 3))
+    cases.append(("far3", *_stencil_csr(rng, 9001, [-2000, -300, -1, 0, 1, 300, 2000],
+                                        drop=0.3), 9001))
+    cases.append(("upwind", *_stencil_csr(rng, 7013, [-1001, -257, -1, 0, 1]), 7013))
     for name, rp_, ci_, va_, n_ in cases:
-        blk = hip.CsrBlock(ctx, n_, n_, rp_, ci_.astype(np.int32), va_, None, False,
+        ci_ = ci_.astype(np.int32)
+        x = rng.uniform(-1, 1, n_)
+        y0 = rng.uniform(-1, 1, n_)
+        blk = hip.CsrBlock(ctx, n_, n_, rp_, ci_, va_, None, False,
                            hip.ALGO_ROWBLOCK)
-        with pytest.raises(Exception):
-            blk.bake()
-        assert blk.get("sdia") == 0, name
-        dx, dy = ctx.upload(x), ctx.upload(np.full(n_, np.nan))
-        blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
-        assert np.array_equal(dy.numpy(),
-                              oracle.csr_spmv(rp_, ci_.astype(np.int32), va_, x)), name
-        dx.free(), dy.free()
+        blk.bake()
+        assert blk.get("sdia") == 1 and blk.get("sdia_general") == 2, name
+        va32 = va_.astype(np.float32)
+        d32 = ctx.upload(va32, np.float32)
+        hip.call("spmv_hip_csr_plan_bake_values_f32f64", ctx.h, blk.plan, d32.ptr,
+                 None)
+        dx = ctx.upload(x)
+        part = ctx.empty(ctx.dot_partials_len, np.float64)
+        for alpha, beta in ((1.0, 0.0), (-1.5, 0.5)):
+            y_ref = oracle.csr_spmv(rp_, ci_, va_, x, alpha, beta, y0)
+            y32_ref = oracle.csr_spmv(rp_, ci_, va32.astype(np.float64), x, alpha,
+                                      beta, y0)
+            for knobs in (dict(), dict(zwalk_segments=0), dict(sdia_chain=0),
+                          dict(sdia_chain=1, slat_blocks_per_cu=2, zwalk_segments=3),
+                          dict(sdia=0), dict(sdia=1, zwalk=0)):
+                for k, v in knobs.items():
+                    blk.set(k, v)
+                dy = ctx.upload(np.full(n_, np.nan) if beta == 0 else y0)
+                dot = beta == 0
+                blk.mult(alpha, dx.ptr, beta, dy.ptr,
+                         dot_partials=part.ptr if dot else None)
+                assert np.array_equal(dy.numpy(), y_ref), (name, alpha, knobs)
+                if dot:
+                    want = float(np.dot(x, y_ref))
+                    got = float(np.sum(part.numpy()))
+                    assert abs(got - want) <= 1e-12 * (np.abs(x) @ np.abs(y_ref))
+                dy.free()
+                dy = ctx.upload(np.full(n_, np.nan) if beta == 0 else y0)
+                hip.call("spmv_hip_csr_spmv_f32f64", ctx.h, blk.plan, n_, n_,
+                         blk.nnz, blk.rowptr.ptr, blk.colind.ptr, d32.ptr,
+                         float(alpha), dx.ptr, float(beta), dy.ptr, None, None)
+                assert np.array_equal(dy.numpy(), y32_ref), (name, "mixed", knobs)
+                dy.free()
+        for b_ in (d32, dx, part):
+            b_.free()
         blk.free()
-    # rectangular (a block with a ghost tail)
+    # four distinct offsets, and a rectangular block: no diagonal form
+    x = rng.uniform(-1, 1, N)
+    rp_, ci_, va_ = _symmetric_general_csr(rng, N, [-700, -30, -2, -1])
+    blk = hip.CsrBlock(ctx, N, N, rp_, ci_, va_, None, False, hip.ALGO_ROWBLOCK)
+    with pytest.raises(Exception):
+        blk.bake()
+    assert blk.get("sdia") == 0
+    dx, dy = ctx.upload(x), ctx.upload(np.full(N, np.nan))
+    blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+    assert np.array_equal(dy.numpy(), oracle.csr_spmv(rp_, ci_, va_, x))
+    dx.free(), dy.free()
+    blk.free()
     rpr, cir, var = _stencil_csr(rng, 3000, [-5, 0, 5])
-    blk = hip.CsrBlock(ctx, 3000, 3005, rpr, np.minimum(cir, 3004).astype(np.int32),
-                       var, None, False, hip.ALGO_ROWBLOCK)
+    blk = hip.CsrBlock(ctx, 3000, 3005, rpr, cir.astype(np.int32), var, None, False,
+                       hip.ALGO_ROWBLOCK)
     with pytest.raises(Exception):
         blk.bake()
     blk.free()

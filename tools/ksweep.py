@@ -28,6 +28,8 @@ def main():
                     help="symmetric storage (lower block + diagonal)")
     ap.add_argument("--bake", action="store_true",
                     help="general storage: let the plan find the matrix symmetric")
+    ap.add_argument("--asym", action="store_true",
+                    help="general storage, made non-symmetric: the FULL diagonal form")
     ap.add_argument("--out", default=None)
     ap.add_argument("--calib", action="store_true",
                     help="also time plain streaming kernels on this box")
@@ -40,7 +42,9 @@ def main():
                                   with_diagonal=True)
     else:
         blk = hip.poisson3d_block(ctx, n, 0, N, hip.PART_ALL)
-    if args.symmetric or args.bake:
+    if args.asym:  # one entry changed: the matrix is no longer symmetric
+        ctx.copy_h2d(blk.values.ptr + 8 * 12345, np.array([-1.25, -1.5, -1.75]))
+    if args.symmetric or args.bake or args.asym:
         blk.bake()  # the diagonal form; knob sdia=0 runs the CSR-order kernel
     x, y = ctx.empty(N, np.float64), ctx.empty(N, np.float64)
     ctx.fill_gaussian(N, 0, N, x.ptr)
