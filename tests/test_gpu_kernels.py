@@ -1655,6 +1655,21 @@ def test_diagonal_form_fuzz(lat_ctx):
             assert np.array_equal(dy.numpy(), y_ref), (trial, N, offs, drop, knobs)
             dy.free()
         blk.free()
+        # the same pattern with values that are NOT symmetric: the full form
+        va_ns = rng.uniform(-1, 1, len(va))
+        blk = hip.CsrBlock(ctx, N, N, rp, ci, va_ns, None, False, hip.ALGO_ROWBLOCK)
+        blk.bake()
+        offdiag = bool((ci != np.repeat(np.arange(N), np.diff(rp))).any())
+        assert blk.get("sdia_general") == (2 if offdiag else 1), (trial, N, offs)
+        y_ns = oracle.csr_spmv(rp, ci, va_ns, x, alpha, beta, y0)
+        for knobs in (dict(), dict(zwalk_segments=int(rng.integers(0, 4)))):
+            for k, v in knobs.items():
+                blk.set(k, v)
+            dy = ctx.upload(np.full(N, np.nan) if beta == 0 else y0)
+            blk.mult(alpha, dx.ptr, beta, dy.ptr)
+            assert np.array_equal(dy.numpy(), y_ns), (trial, N, offs, "full", knobs)
+            dy.free()
+        blk.free()
         # symmetric storage of the same matrix (needs a full diagonal)
         if ddrop == 0.0:
             lrp, lci, lva, dg = lower_split(rp, ci, va)
