@@ -286,14 +286,17 @@ def timed_spmv(exec_, A, N, _lib, reps):
 
 
 def spmv_record(exec_, comm, host, _lib, n, symmetric, reps, lattice=True,
-                bake=True):
-    """one plain-SpMV sub-record on the n^3 matrix in the given storage/form"""
+                bake=True, skew_ppm=0):
+    """one plain-SpMV sub-record on the n^3 matrix in the given storage/form
+    (skew_ppm: the generator's non-symmetric variant of the matrix)"""
     ctx = exec_.context
     if not lattice:
         _lib.call("spmv_hip_ctx_set_option", ctx, b"lat_min_nnz", 1 << 62)
     if not bake:
         _lib.call("spmv_hip_ctx_set_option", ctx, b"bake_general", 0)
+    _lib.call("spmv_hip_ctx_set_option", ctx, b"poisson_skew_ppm", skew_ppm)
     A = host.Matrix.create_poisson3d(comm, exec_, n, symmetric, host.P2P_BLOCKING)
+    _lib.call("spmv_hip_ctx_set_option", ctx, b"poisson_skew_ppm", 0)
     if not lattice:
         _lib.call("spmv_hip_ctx_set_option", ctx, b"lat_min_nnz", 1 << 20)
     if not bake:
@@ -302,7 +305,7 @@ def spmv_record(exec_, comm, host, _lib, n, symmetric, reps, lattice=True,
     ms = timed_spmv(exec_, A, N, _lib, reps)
     kernel, algo, req = kernel_of(A, symmetric)
     rec = {"workload": f"poisson3d_{n}^3_{'symmetric-csr' if symmetric else 'csr'}"
-                       "_fp64_spmv",
+                       "_fp64_spmv" + (f"_skew{skew_ppm}ppm" if skew_ppm else ""),
            "rows": N, "nnz_stored": A.blocks()["local"][2], "kernel": kernel,
            "ms_per_apply": ms, "applies_timed": reps,
            "algorithmic_bytes": algo, "GB/s": algo / ms / 1e6,
@@ -633,9 +636,13 @@ def main():
                 ws2.close()
                 As.close()
                 exec_.free(d_b), exec_.free(d_x)
-                # the lattice form: what a lattice matrix that is NOT symmetric
-                # gets (same matrix, symmetry check switched off)
+                # a lattice matrix that is NOT symmetric (the generator's skewed
+                # variant: lower neighbours -1.001, upper -0.999): the full
+                # diagonal form; and the CSR-order lattice kernel (no baked
+                # copy of the values) on the Poisson matrix itself
                 if not (args.no_lattice or args.no_lx or args.no_bake):
+                    out["csr_nonsymmetric_spmv"] = spmv_record(
+                        exec_, self_comm, host, _lib, n, False, 20, skew_ppm=1000)
                     out["csr_lattice_spmv"] = spmv_record(
                         exec_, self_comm, host, _lib, n, False, 20, bake=False)
                 # the LX form: what a CSR matrix WITHOUT lattice structure gets

@@ -61,7 +61,13 @@ int spmv_hip_synchronize(spmv_hip_ctx* ctx); /* whole device */
 /* tuning options of a context; EINVAL for an unknown key.
  *   "blas1_nt_min_elems": the CG vector kernels stream vectors of at least
  *   this many elements past the caches (non-temporal loads and stores);
- *   shorter vectors stay cached between kernels.  Default 2^24. */
+ *   shorter vectors stay cached between kernels.  Default 2^24.
+ *   "lat_min_nnz", "lx_min_nnz", "lx_max_x_bytes": from how many entries (up to
+ *   how large an x) plans build the lattice / LX forms.
+ *   "bake_general": 0 = plan_bake_values on a general plan always returns
+ *   SPMV_HIP_ENOTSUP (the CSR-order kernels on the caller's values).
+ *   "poisson_skew_ppm": the device generator below writes a NON-symmetric
+ *   variant (lower neighbours -1 - s, upper -1 + s, s = value * 1e-6). */
 int spmv_hip_ctx_set_option(spmv_hip_ctx* ctx, const char* key, int64_t value);
 /*   "lx_min_nnz": csr_plan_create builds the LX form of a general matrix
  *   (LDS-staged x windows + 16-bit column offsets, 2 B per entry of extra

@@ -29,6 +29,10 @@ struct spmv_hip_ctx {
   // plan_bake_values on a GENERAL plan looks for a symmetric matrix and keeps
   // its lower half by offset ("bake_general"; 0: always SPMV_HIP_ENOTSUP)
   int bake_general = 1;
+  // the device Poisson generator's non-symmetric variant ("poisson_skew_ppm":
+  // lower neighbours -1 - s, upper -1 + s, s = value * 1e-6; 0 = the Poisson
+  // matrix).  For measurements of kernels on matrices that are not symmetric.
+  int poisson_skew_ppm = 0;
 };
 
 #define SPMV_CHECK_HIP(expr)                                                   \

@@ -79,10 +79,12 @@ __global__ __launch_bounds__(kBlock) void poisson_count_kernel(Geom g, int part,
   }
 }
 
+// skew != 0: a NON-symmetric variant for measurements (convection-diffusion
+// like): lower neighbours -1 - skew, upper neighbours -1 + skew
 __global__ __launch_bounds__(kBlock) void poisson_fill_kernel(
     Geom g, int part, const int32_t* __restrict__ rowptr,
     int32_t* __restrict__ colind, double* __restrict__ values,
-    double* __restrict__ diagonal)
+    double* __restrict__ diagonal, double skew)
 {
   const int64_t nrows = g.r1 - g.r0;
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nrows;
@@ -100,7 +102,8 @@ __global__ __launch_bounds__(kBlock) void poisson_fill_kernel(
         if (owned != (pass == 0) || !keep(part, i, cols[e], g.r0, g.r1))
           continue;
         colind[pos] = local_col(g, cols[e]);
-        values[pos] = (cols[e] == i) ? 6.0 : -1.0;
+        values[pos] = (cols[e] == i) ? 6.0
+                                     : (cols[e] < i ? -1.0 - skew : -1.0 + skew);
         ++pos;
       }
     if (diagonal)
@@ -221,7 +224,7 @@ int spmv_hip_poisson3d_fill_f64(spmv_hip_ctx* ctx, int32_t n,
   const int grid = spmv_grid_for(ctx, nrows, kBlock);
   hipLaunchKernelGGL(poisson_fill_kernel, dim3(grid), dim3(kBlock), 0,
                      spmv_stream(ctx, stream), g, part, rowptr, colind, values,
-                     diagonal);
+                     diagonal, 1e-6 * (double)ctx->poisson_skew_ppm);
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;
 }

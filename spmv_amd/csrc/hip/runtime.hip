@@ -100,6 +100,11 @@ int spmv_hip_ctx_set_option(spmv_hip_ctx* ctx, const char* key, int64_t value)
     ctx->lat_min_nnz = value;
     return SPMV_HIP_OK;
   }
+  if (!strcmp(key, "poisson_skew_ppm")) {
+    SPMV_REQUIRE(value >= 0 && value < 1000000);
+    ctx->poisson_skew_ppm = (int)value;
+    return SPMV_HIP_OK;
+  }
   if (!strcmp(key, "bake_general")) {
     SPMV_REQUIRE(value == 0 || value == 1);
     ctx->bake_general = (int)value;

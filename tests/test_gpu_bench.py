@@ -63,6 +63,9 @@ def test_bench_single_gpu_line():
     assert d["plan"]["form"]["sdia"] == 1 and "general order" in d["roofline"]["kernel"]
     lat = d["csr_lattice_spmv"]["form"]
     assert lat["lat"] == 1 and lat["sdia"] == 0
+    # ... and a matrix that is not symmetric keeps all its values by offset
+    ns = d["csr_nonsymmetric_spmv"]
+    assert ns["form"]["sdia"] == 1 and "full" in ns["kernel"]
     assert d["north_star_spmv"]["form"]["lat"] == 1
     mp = d["mixed_precision_cg"]
     assert mp["mixed"]["final_true_rel_residual"] < 1.001e-10

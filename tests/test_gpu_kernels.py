@@ -396,6 +396,16 @@ def test_device_poisson_matches_host(ctx, n, P):
                 assert np.array_equal(blk.diagonal.numpy(), sym["diagonal"])
             blk.free()
         assert np.array_equal(sym["remote"][1], split["remote"][1])
+    # the generator's non-symmetric variant (ctx option "poisson_skew_ppm"):
+    # lower neighbours -1 - s, upper -1 + s; takes the FULL diagonal form
+    ctx.set_option("poisson_skew_ppm", 250000)
+    blk = hip.poisson3d_block(ctx, n, 0, N, hip.PART_ALL)
+    ctx.set_option("poisson_skew_ppm", 0)
+    rows = np.repeat(np.arange(N), np.diff(grp))
+    want = np.where(gci == rows, 6.0, np.where(gci < rows, -1.25, -0.75))
+    assert np.array_equal(blk.colind.numpy(), gci)
+    assert np.array_equal(blk.values.numpy(), want)
+    blk.free()
 
 
 # ---------------------------------------------------------------------------
