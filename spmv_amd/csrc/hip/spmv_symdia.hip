@@ -428,12 +428,13 @@ __device__ __forceinline__ bool same_bits(T a, T b)
 // are stored.  FULL form: no such demand, the upper entries go to arrays of
 // their own (nd + 1 + k).  (Ascending columns without repeats are what the
 // lattice form, a precondition, already guarantees.)
-template <typename T, bool FULL>
+// STORE = false: the checks only (is the half form possible?), nothing written.
+template <typename T, bool FULL, bool STORE>
 __global__ __launch_bounds__(kBlock) void sdia_bake_general_kernel(
     int32_t num_rows, int nd, int u0, int u1, int u2,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
     const T* __restrict__ values, int64_t arr_len, T* __restrict__ sval,
-    uint8_t* __restrict__ cmask, int32_t* __restrict__ fail)
+    uint8_t* __restrict__ cmask, int32_t* __restrict__ fail, int check_mirrors)
 {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < num_rows;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -442,14 +443,15 @@ __global__ __launch_bounds__(kBlock) void sdia_bake_general_kernel(
       const int64_t c = colind[j];
       const T v = values[j];
       if (c == i) {
-        sval[(int64_t)nd * arr_len + i] = v;
+        if (STORE)
+          sval[(int64_t)nd * arr_len + i] = v;
         cm |= 8u;
         continue;
       }
       const int64_t u = c < i ? i - c : c - i;
       const int k = u == u0 ? 0 : (u == u1 ? 1 : (u == u2 ? 2 : -1));
       bool ok = k >= 0 && k < nd && c < num_rows;
-      if (ok && !FULL) {
+      if (ok && !FULL && check_mirrors) {
         ok = false;
         for (int32_t jj = rowptr[c]; jj < rowptr[c + 1]; ++jj)
           if (colind[jj] == i)
@@ -460,15 +462,17 @@ __global__ __launch_bounds__(kBlock) void sdia_bake_general_kernel(
         continue;
       }
       if (c < i) {
-        sval[(int64_t)k * arr_len + i] = v;
+        if (STORE)
+          sval[(int64_t)k * arr_len + i] = v;
         cm |= 1u << k;
       } else {
-        if (FULL)
+        if (FULL && STORE)
           sval[(int64_t)(nd + 1 + k) * arr_len + i] = v;
         cm |= 1u << (4 + k);
       }
     }
-    cmask[i] = (uint8_t)cm;
+    if (STORE)
+      cmask[i] = (uint8_t)cm;
   }
 }
 
@@ -707,15 +711,15 @@ int sdia_fill(spmv_hip_csr_plan* pl, bool general, const T* values,
   if (e == hipSuccess) {
     const int grid = spmv_grid_for(pl->ctx, n, kBlock);
     if (general && pl->sdia_general == 2)
-      hipLaunchKernelGGL((sdia_bake_general_kernel<T, true>), dim3(grid),
+      hipLaunchKernelGGL((sdia_bake_general_kernel<T, true, true>), dim3(grid),
                          dim3(kBlock), 0, st, n, g.nd, g.U[0], g.U[1], g.U[2],
                          pl->rowptr0, pl->colind0, values, len,
-                         static_cast<T*>(sval), cm, d_fail);
-    else if (general)
-      hipLaunchKernelGGL((sdia_bake_general_kernel<T, false>), dim3(grid),
+                         static_cast<T*>(sval), cm, d_fail, 0);
+    else if (general) // (the mirrors were checked by sdia_is_symmetric)
+      hipLaunchKernelGGL((sdia_bake_general_kernel<T, false, true>), dim3(grid),
                          dim3(kBlock), 0, st, n, g.nd, g.U[0], g.U[1], g.U[2],
                          pl->rowptr0, pl->colind0, values, len,
-                         static_cast<T*>(sval), cm, d_fail);
+                         static_cast<T*>(sval), cm, d_fail, 0);
     else
       hipLaunchKernelGGL((sdia_bake_kernel<T>), dim3(grid), dim3(kBlock), 0, st,
                          n, g.nd, g.U[0], g.U[1], g.U[2], pl->rowptr0,
@@ -738,6 +742,36 @@ int sdia_fill(spmv_hip_csr_plan* pl, bool general, const T* values,
   *out_cmask = cm;
   *out_len = len;
   return SPMV_HIP_OK;
+}
+
+// general plan: can the HALF form hold this matrix (offsets in pl->sdia_U,
+// every entry with its mirror, bit for bit)?  Nothing is allocated or written.
+template <typename T>
+int sdia_is_symmetric(spmv_hip_csr_plan* pl, const T* values, hipStream_t st,
+                      bool* yes)
+{
+  int32_t* d_fail = nullptr;
+  int32_t h_fail = 1;
+  hipError_t e = hipMalloc(&d_fail, sizeof(int32_t));
+  if (e == hipSuccess)
+    e = hipMemsetAsync(d_fail, 0, sizeof(int32_t), st);
+  if (e == hipSuccess) {
+    const int grid = spmv_grid_for(pl->ctx, pl->num_rows, kBlock);
+    hipLaunchKernelGGL((sdia_bake_general_kernel<T, false, false>), dim3(grid),
+                       dim3(kBlock), 0, st, pl->num_rows, pl->sdia_nd,
+                       pl->sdia_U[0], pl->sdia_U[1], pl->sdia_U[2], pl->rowptr0,
+                       pl->colind0, values, (int64_t)0, (T*)nullptr,
+                       (uint8_t*)nullptr, d_fail, 1);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(&h_fail, d_fail, sizeof(int32_t), hipMemcpyDeviceToHost,
+                       st);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st);
+  (void)hipFree(d_fail);
+  *yes = h_fail == 0;
+  return e == hipSuccess ? SPMV_HIP_OK : static_cast<int>(e);
 }
 
 template <typename T>
@@ -781,13 +815,17 @@ int sdia_bake(spmv_hip_csr_plan* pl, const T* values, const T* diagonal,
   int64_t len = 0;
   {
     // general storage: the half form when the matrix is symmetric bit for
-    // bit, else the full form (the geometry reads the mode from the plan)
-    pl->sdia_general = general ? 1 : 0;
-    int rc = sdia_fill<T>(pl, general, values, diagonal, st, &sval, &cm, &len);
-    if (rc == SPMV_HIP_ENOTSUP && general) {
-      pl->sdia_general = 2;
-      rc = sdia_fill<T>(pl, general, values, diagonal, st, &sval, &cm, &len);
+    // bit (checked first, without allocating), else the full form (the
+    // geometry reads the mode from the plan)
+    pl->sdia_general = 0;
+    int rc = SPMV_HIP_OK;
+    if (general) {
+      bool symmetric = false;
+      rc = sdia_is_symmetric<T>(pl, values, st, &symmetric);
+      pl->sdia_general = symmetric ? 1 : 2;
     }
+    if (rc == SPMV_HIP_OK)
+      rc = sdia_fill<T>(pl, general, values, diagonal, st, &sval, &cm, &len);
     if (rc != SPMV_HIP_OK) {
       pl->sdia_general = 0;
       pl->sdia_nd = 0;
@@ -833,6 +871,16 @@ int sdia_bake_mixed(spmv_hip_csr_plan* pl, const float* values32, hipStream_t st
   if (!pl->sdia_val || !pl->sdia_general || pl->sdia_elem != 8)
     return SPMV_HIP_ENOTSUP;
   const auto t_begin = std::chrono::steady_clock::now();
+  if (pl->sdia_general == 1) {
+    // the half form needs THESE values symmetric too (the caller's fp32 array
+    // is normally the rounded fp64 one, but nothing says so)
+    bool symmetric = false;
+    const int rcs = sdia_is_symmetric<float>(pl, values32, st, &symmetric);
+    if (rcs != SPMV_HIP_OK)
+      return rcs;
+    if (!symmetric)
+      return SPMV_HIP_ENOTSUP;
+  }
   void* sval = nullptr;
   uint8_t* cm = nullptr;
   int64_t len = 0;

@@ -1617,6 +1617,20 @@ def test_mixed_precision_on_the_diagonal_form_bit_exact(lat_ctx):
         assert np.array_equal(dy.numpy(), oracle.csr_spmv(rp, ci, va, x)), name
         hip.call("spmv_hip_csr_plan_bake_values_f32f64", ctx.h, blk.plan, None, None)
         assert blk.get("sdia_mixed") == 0
+        # an fp32 array that is NOT symmetric cannot ride on the half form
+        bad = va32.copy()
+        bad[int(rp[N // 2])] *= np.float32(1.5)
+        dbad = ctx.upload(bad, np.float32)
+        with pytest.raises(Exception):
+            hip.call("spmv_hip_csr_plan_bake_values_f32f64", ctx.h, blk.plan,
+                     dbad.ptr, None)
+        assert blk.get("sdia_mixed") == 0
+        hip.call("spmv_hip_csr_spmv_f32f64", ctx.h, blk.plan, N, N, blk.nnz,
+                 blk.rowptr.ptr, blk.colind.ptr, dbad.ptr, 1.0, dx.ptr, 0.0,
+                 dy.ptr, None, None)
+        assert np.array_equal(dy.numpy(), oracle.csr_spmv(
+            rp, ci, bad.astype(np.float64), x)), name
+        dbad.free()
         for b in (d32, dx, part, other, dy):
             b.free()
         blk.free()
