@@ -1643,10 +1643,12 @@ def test_diagonal_form_fuzz(lat_ctx):
     diagonal -- through BOTH storages of the diagonal form, forced plane-walk
     tables included: bit-exact against the oracle's general / symmetric loops."""
     ctx = lat_ctx
-    rng = np.random.default_rng(2026)
+    # SPMV_FUZZ_SEED / SPMV_FUZZ_TRIALS: other seeds, longer runs (by hand)
+    rng = np.random.default_rng(int(os.environ.get("SPMV_FUZZ_SEED", "2026")))
+    trials = int(os.environ.get("SPMV_FUZZ_TRIALS", "60"))
     sizes = [1, 2, 255, 256, 257, 511, 512, 513, 1000, 4096, 5000, 20000, 65536, 70001]
     done = 0
-    for trial in range(60):
+    for trial in range(trials):
         N = int(sizes[trial % len(sizes)] if trial < 28 else rng.integers(300, 60000))
         nd = int(rng.integers(1, 4))
         pool = [1, 2, 3, 63, 64, 65, 255, 256, 257, 512, 768, 1024, 2048, 4096]
@@ -1666,8 +1668,19 @@ def test_diagonal_form_fuzz(lat_ctx):
         # general storage: lattice form + device symmetry check
         blk = hip.CsrBlock(ctx, N, N, rp, ci, va, None, False, hip.ALGO_ROWBLOCK)
         assert blk.get("lat") == 1, (trial, N, offs)
-        blk.bake()
-        assert blk.get("sdia") == 1 and blk.get("sdia_offsets") == len(offs)
+        # the offsets that really occur (drops and short matrices lose some)
+        have = sorted(set(np.abs(ci - np.repeat(np.arange(N), np.diff(rp)))) - {0})
+        if not have:  # diagonal only: nothing for the diagonal form to do
+            with pytest.raises(Exception):
+                blk.bake()
+            blk.free()
+            continue
+        try:
+            blk.bake()
+        except Exception as e:
+            raise AssertionError((trial, N, offs, have, drop, ddrop, str(e)))
+        assert blk.get("sdia") == 1 and blk.get("sdia_offsets") == len(have), (
+            trial, N, offs, have)
         dx = ctx.upload(x)
         y_ref = oracle.csr_spmv(rp, ci, va, x, alpha, beta, y0)
         for knobs in (dict(), dict(zwalk_segments=int(rng.integers(0, 4))),
@@ -1712,4 +1725,4 @@ def test_diagonal_form_fuzz(lat_ctx):
                 sb.free()
         dx.free()
         done += 1
-    assert done >= 45
+    assert done >= 0.75 * trials
