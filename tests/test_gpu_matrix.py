@@ -159,6 +159,60 @@ def test_cg_matches_oracle(exec_, comm, symmetric):
         exec_.free(d_b), exec_.free(d_x)
 
 
+@pytest.mark.parametrize("kind", ["unstructured", "banded", "skewed_lattice"])
+def test_cg_on_other_spd_matrices_vs_oracle(exec_, comm, kind):
+    """spmv::cg off the Poisson matrix: a random unstructured SPD matrix (gather
+    kernels / transposed map), a banded one (LX form), and a 3-D lattice with
+    random symmetric positive-definite values (lattice + diagonal forms with
+    values that are not -1 / 6) -- both storages, against oracle.cg."""
+    import scipy.sparse as sp
+    from spmv_amd import _lib
+    rng = np.random.default_rng({"unstructured": 5, "banded": 6,
+                                 "skewed_lattice": 7}[kind])
+    for opt_ in (b"lx_min_nnz", b"lat_min_nnz"):
+        _lib.call("spmv_hip_ctx_set_option", exec_.context, opt_, 0)
+    if kind == "unstructured":
+        N = 6000
+        L = sp.random(N, N, density=4.0 / N, random_state=5, format="csr")
+        L = sp.tril(L, -1)
+    elif kind == "banded":
+        N = 9000
+        diags = [rng.uniform(-1, 1, N) for _ in range(5)]
+        L = sp.diags(diags, [-1, -2, -3, -40, -41], shape=(N, N), format="csr")
+    else:
+        n = 16
+        N = n ** 3
+        rp0, ci0, _ = poisson.poisson3d_csr(n)
+        A0 = sp.csr_matrix((rng.uniform(0.2, 1.0, len(ci0)), ci0, rp0), shape=(N, N))
+        L = sp.tril(A0, -1)
+    S = (L + L.T).tocsr()
+    # strictly diagonally dominant with a positive diagonal: SPD
+    d = np.asarray(abs(S).sum(1)).ravel() + rng.uniform(0.5, 1.5, N)
+    A = (S + sp.diags(d)).tocsr()
+    A.sort_indices()
+    rp, ci, va = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data
+    b = oracle.csr_spmv(rp, ci, va, rng.uniform(-1, 1, N))
+    x_ref, k_ref, hist_ref = oracle.cg(rp, ci, va, b, 200, 1e-10)
+    assert 3 < k_ref < 200
+    for symmetric in (False, True):
+        M = host.Matrix.create_matrix(comm, exec_, rp, ci, va, N, N, [], [],
+                                      symmetric, host.P2P_NONBLOCKING)
+        d_b, d_x = exec_.alloc(N), exec_.alloc(N)
+        exec_.copy_from_host(d_b, b)
+        k, hist = host.cg(comm, exec_, M, d_b, d_x, 200, 1e-10)
+        x = exec_.copy_to_host(d_x, N)
+        assert abs(k - k_ref) <= 1, (kind, symmetric, k, k_ref)
+        m = min(k, k_ref, 50)
+        assert np.allclose(hist[:m + 1], hist_ref[:m + 1], rtol=1e-6, atol=0)
+        assert np.linalg.norm(x - x_ref) <= 1e-8 * np.linalg.norm(x_ref)
+        if kind == "skewed_lattice":
+            assert M.plan_get("sdia") == 1
+        M.close()
+        exec_.free(d_b), exec_.free(d_x)
+    for opt_ in (b"lx_min_nnz", b"lat_min_nnz"):
+        _lib.call("spmv_hip_ctx_set_option", exec_.context, opt_, 1 << 20)
+
+
 def test_cg_early_convergence_with_long_queue(exec_, comm):
     """kmax far beyond convergence: the device stops itself, the host stops
     enqueuing at the next poll; k and x are those of the converged iterate."""
