@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--set", nargs="*", default=[], help="knob=value ...")
     ap.add_argument("--no-lat", action="store_true",
                     help="no lattice form: the plan takes the LX form")
+    ap.add_argument("--asym", action="store_true",
+                    help="general storage, made non-symmetric: the full diagonal form")
     ap.add_argument("--no-bake", action="store_true",
                     help="no baked copy: the CSR-order lattice kernels")
     ap.add_argument("--no-lx", action="store_true",
@@ -37,6 +39,8 @@ def main():
     n, N = args.n, args.n ** 3
     part = hip.PART_LOCAL_LOWER if args.symmetric else hip.PART_ALL
     blk = hip.poisson3d_block(ctx, n, 0, N, part, with_diagonal=args.symmetric)
+    if args.asym:  # three entries changed: the matrix is no longer symmetric
+        ctx.copy_h2d(blk.values.ptr + 8 * 12345, np.array([-1.25, -1.5, -1.75]))
     if not args.no_bake and not (args.no_lat or args.no_lx):
         blk.bake()  # diagonal form (general: the matrix is found symmetric)
     for kv in args.set:
