@@ -73,6 +73,21 @@ def test_bench_single_gpu_line():
     assert mp["x_rel_diff"] < 1e-7
 
 
+def test_bench_without_the_symmetry_check():
+    """--no-bake: the line of a lattice matrix whose values stay in CSR order
+    (the CSR-order lattice kernel; DESIGN.md section 7, 'reading the headline')."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"),
+                          "--grid", "128", "--steps", "10", "--warmup", "2",
+                          "--no-bake", "--no-extras", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = _line(res.stdout)
+    _check(d, 1, 10, 2)
+    assert d["plan"]["form"]["sdia"] == 0 and d["plan"]["form"]["lat"] == 1
+    assert "csr_lattice_kernel" in d["roofline"]["kernel"]
+    assert d["roofline"]["frac_requested"] <= d["roofline"]["frac"]
+
+
 def test_bench_two_rank_rehearsal():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
