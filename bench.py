@@ -16,6 +16,17 @@ whole job; `roofline` describes the dominant kernel (the local-block CSR
 SpMV), timed live with HIP events on its own stream inside the timed region;
 `cpu_baseline` is the oracle's OpenMP SpMV + CG (= the reference's CPU path,
 restated) on the host cores this job may use, rank 0 at N = 1 only.
+
+Pricing.  Every `frac` in the line is PHYSICAL: the bytes the kernel's data
+format makes it load and store per launch (`requested_bytes_per_launch`) over
+the measured launch time over the 8 TB/s HBM peak, so it cannot exceed 1.  The
+plans re-encode the CSR arrays at set-up time (16-bit column offsets, no index
+stream at all for lattice matrices, half the values for symmetric ones), so
+the same launch also has a CSR-EQUIVALENT rate -- SURVEY 8d's algorithmic CSR
+bytes (12 B per entry, row pointer, x, y) over the same time: what a kernel
+streaming the caller's CSR arrays would have to sustain to be as fast.  That
+figure is reported as `csr_equivalent_gbs` / `frac_csr_equivalent` and may
+exceed the peak; it is a speed-up statement, not a bandwidth.
 """
 import argparse
 import json
@@ -84,6 +95,10 @@ def parse():
     ap.add_argument("--mixed-grid", type=int, default=216,
                     help="grid of the mixed-precision CG sub-record (512 takes "
                          "~15 s more)")
+    ap.add_argument("--stencil27-grid", type=int, default=256,
+                    help="grid of the 27-point sub-record")
+    ap.add_argument("--unstructured-rows", type=int, default=10_000_000,
+                    help="rows of the unstructured sub-record")
     ap.add_argument("--blas1-nt-min", type=int, default=None,
                     help="override the context option blas1_nt_min_elems "
                          "(experiments)")
@@ -181,6 +196,63 @@ def cpu_baseline(args, n_gpu, rows_gpu, host):
     return out
 
 
+def oracle_parity_checks(exec_, comm, host, _lib):
+    """Part of the cpu_baseline leg (the only place bench.py may call the
+    oracle): oracle-sized instances of the sub-records' matrices through the
+    product path, compared bit for bit with the oracle's reference loop
+    (csr_kernels.cpp:41-51) -- the same checks tests/test_gpu_matrix.py makes."""
+    import numpy as np
+    import oracle
+    from spmv_amd import poisson
+    ctx = exec_.context
+    out = {}
+
+    def run(A, x):
+        N = len(x)
+        d_x, d_y = exec_.alloc(N), exec_.alloc(N)
+        exec_.copy_from_host(d_x, x)
+        exec_.memset(d_y, 0xFF, 8 * N)
+        A.mult(d_x, d_y)
+        y = exec_.copy_to_host(d_y, N)
+        exec_.free(d_x), exec_.free(d_y)
+        return y
+    try:
+        n = 33
+        rp, ci, va = poisson.stencil27_csr(n)
+        x = oracle.gaussian_x_fast(n ** 3) + 0.25
+        y_ref = oracle.csr_spmv(rp, ci.astype(np.int32), va, x)
+        for k, v in ((b"poisson_stencil", 27), (b"lat_min_nnz", 0),
+                     (b"lx_min_nnz", 0)):
+            _lib.call("spmv_hip_ctx_set_option", ctx, k, v)
+        try:
+            A = host.Matrix.create_poisson3d(comm, exec_, n, False,
+                                             host.P2P_BLOCKING)
+        finally:
+            for k, v in ((b"poisson_stencil", 7), (b"lat_min_nnz", 1 << 20),
+                         (b"lx_min_nnz", 1 << 20)):
+                _lib.call("spmv_hip_ctx_set_option", ctx, k, v)
+        out["stencil27_33^3"] = {"kernel": kernel_of(A, False)[0].split(" ")[0],
+                                 "bit_exact_vs_oracle":
+                                     bool(np.array_equal(run(A, x), y_ref))}
+        A.close()
+        N = 300_000
+        rp, ci, va = poisson.unstructured_csr(N)
+        x = oracle.gaussian_x_fast(N) + 0.25
+        y_ref = oracle.csr_spmv(rp, ci, va, x)
+        _lib.call("spmv_hip_ctx_set_option", ctx, b"lx_min_nnz", 0)
+        try:
+            A = host.Matrix.create_unstructured(comm, exec_, N)
+        finally:
+            _lib.call("spmv_hip_ctx_set_option", ctx, b"lx_min_nnz", 1 << 20)
+        out["unstructured_300000"] = {
+            "kernel": kernel_of(A, False)[0].split(" ")[0],
+            "bit_exact_vs_oracle": bool(np.array_equal(run(A, x), y_ref))}
+        A.close()
+    except Exception as e:  # extras only
+        out["error"] = repr(e)
+    return out
+
+
 # ---------------------------------------------------------------------------
 # what the local block's plan turned into, and the bytes that form moves
 # ---------------------------------------------------------------------------
@@ -241,25 +313,48 @@ def plan_record(A):
                      ("lat", "lx", "slat", "sdia", "sym_det", "zwalk")}}
 
 
-def pmc_traffic(kernel_name, n, world):
-    """HBM-side bytes per launch of this kernel from the committed PMC passes
-    (profiles/): a constant of an EARLIER run on another box, returned with its
-    source, or (None, None) when no pass covers this kernel and grid."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
-    if world != 1 or not os.path.exists(path):
+def pmc_traffic(record, kernel_name, n, world):
+    """HBM-side bytes per launch of this record's kernel from the committed PMC
+    passes (profiles/): a constant of an EARLIER run on another box, returned
+    with its source, or (None, None) when no pass covers it.  Round 3's summary
+    is keyed by bench record; round 2's by kernel name and grid."""
+    if world != 1:
         return None, None
     try:
-        for rec in json.load(open(path))["kernels"]:
-            if rec["grid"] == n and kernel_name.startswith(rec["kernel_prefix"]):
+        path = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+        if os.path.exists(path):
+            rec = json.load(open(path)).get("records", {}).get(record)
+            if rec and rec.get("grid") == n:
                 return rec["fabric_bytes_per_launch"], rec["source"]
+        path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+        if record in ("main", "symmetric") and os.path.exists(path):
+            for rec in json.load(open(path))["kernels"]:
+                if rec["grid"] == n and kernel_name.startswith(rec["kernel_prefix"]):
+                    return rec["fabric_bytes_per_launch"], rec["source"]
     except Exception:
         pass
     return None, None
 
 
-def timed_spmv(exec_, A, N, _lib, reps):
+def price(ms, algo_bytes, req_bytes, traffic=None):
+    """the roofline fields of one launch (see the module docstring)"""
+    gbs = req_bytes / ms / 1e6
+    out = {"GB/s": gbs, "frac": gbs / HBM_PEAK_GBS,
+           "requested_bytes": req_bytes, "frac_requested": gbs / HBM_PEAK_GBS,
+           "algorithmic_bytes": algo_bytes,
+           "csr_equivalent_gbs": algo_bytes / ms / 1e6,
+           "frac_csr_equivalent": algo_bytes / ms / 1e6 / HBM_PEAK_GBS}
+    if traffic:
+        out["traffic"] = traffic
+        out["frac_traffic"] = traffic / ms / 1e6 / HBM_PEAK_GBS
+    return out
+
+
+def timed_spmv(exec_, A, N, _lib, reps, crosscheck=False):
     """plain y = A x applies (demos/spmv.cpp:73-96 protocol), best of 3 rounds
-    of `reps`, HIP events on the executor's stream"""
+    of `reps`, HIP events on the executor's stream.  crosscheck: afterwards the
+    same product with the plan switched to the one-lane-per-row kernel (the
+    reference loop verbatim) -- returns (ms, bit_equal)."""
     import ctypes as C
     ctx = exec_.context
     d_x, d_y = exec_.alloc(N), exec_.alloc(N)
@@ -281,38 +376,68 @@ def timed_spmv(exec_, A, N, _lib, reps):
         best = ms.value / reps if best is None else min(best, ms.value / reps)
     _lib.call("spmv_hip_event_destroy", ctx, e0)
     _lib.call("spmv_hip_event_destroy", ctx, e1)
+    same = None
+    if crosscheck:
+        import numpy as np
+        y = exec_.copy_to_host(d_y, N)
+        A.plan_set("algo", 3)  # SPMV_HIP_ALGO_SCALAR
+        exec_.memset(d_y, 0xFF, 8 * N)
+        A.mult(d_x, d_y)
+        same = bool(np.array_equal(y, exec_.copy_to_host(d_y, N))
+                    and np.isfinite(y).all())
     exec_.free(d_x), exec_.free(d_y)
-    return best
+    return (best, same) if crosscheck else best
 
 
 def spmv_record(exec_, comm, host, _lib, n, symmetric, reps, lattice=True,
-                bake=True, skew_ppm=0):
+                bake=True, skew_ppm=0, lx=True, record=None, stencil=7):
     """one plain-SpMV sub-record on the n^3 matrix in the given storage/form
-    (skew_ppm: the generator's non-symmetric variant of the matrix)"""
+    (skew_ppm: the generator's non-symmetric variant of the matrix; stencil 27:
+    the 27-point operator)"""
     ctx = exec_.context
+    opts = {b"poisson_skew_ppm": (skew_ppm, 0), b"poisson_stencil": (stencil, 7)}
     if not lattice:
-        _lib.call("spmv_hip_ctx_set_option", ctx, b"lat_min_nnz", 1 << 62)
+        opts[b"lat_min_nnz"] = (1 << 62, 1 << 20)
+    if not lx:
+        opts[b"lx_min_nnz"] = (1 << 62, 1 << 20)
     if not bake:
-        _lib.call("spmv_hip_ctx_set_option", ctx, b"bake_general", 0)
-    _lib.call("spmv_hip_ctx_set_option", ctx, b"poisson_skew_ppm", skew_ppm)
-    A = host.Matrix.create_poisson3d(comm, exec_, n, symmetric, host.P2P_BLOCKING)
-    _lib.call("spmv_hip_ctx_set_option", ctx, b"poisson_skew_ppm", 0)
-    if not lattice:
-        _lib.call("spmv_hip_ctx_set_option", ctx, b"lat_min_nnz", 1 << 20)
-    if not bake:
-        _lib.call("spmv_hip_ctx_set_option", ctx, b"bake_general", 1)
-    N = n ** 3
-    ms = timed_spmv(exec_, A, N, _lib, reps)
-    kernel, algo, req = kernel_of(A, symmetric)
-    rec = {"workload": f"poisson3d_{n}^3_{'symmetric-csr' if symmetric else 'csr'}"
-                       "_fp64_spmv" + (f"_skew{skew_ppm}ppm" if skew_ppm else ""),
-           "rows": N, "nnz_stored": A.blocks()["local"][2], "kernel": kernel,
-           "ms_per_apply": ms, "applies_timed": reps,
-           "algorithmic_bytes": algo, "GB/s": algo / ms / 1e6,
-           "frac": algo / ms / 1e6 / HBM_PEAK_GBS,
-           "requested_bytes": req, "frac_requested": req / ms / 1e6 / HBM_PEAK_GBS}
-    rec.update(plan_record(A))
+        opts[b"bake_general"] = (0, 1)
+    for k, (v, _) in opts.items():
+        _lib.call("spmv_hip_ctx_set_option", ctx, k, v)
+    try:
+        A = host.Matrix.create_poisson3d(comm, exec_, n, symmetric,
+                                         host.P2P_BLOCKING)
+    finally:
+        for k, (_, d) in opts.items():
+            _lib.call("spmv_hip_ctx_set_option", ctx, k, d)
+    name = f"poisson3d_{n}^3" if stencil == 7 else f"stencil27_{n}^3"
+    rec = matrix_spmv_record(
+        exec_, A, _lib, symmetric, reps, record, n,
+        f"{name}_{'symmetric-csr' if symmetric else 'csr'}_fp64_spmv"
+        + (f"_skew{skew_ppm}ppm" if skew_ppm else ""), crosscheck=stencil != 7)
     A.close()
+    return rec
+
+
+def matrix_spmv_record(exec_, A, _lib, symmetric, reps, record, grid, workload,
+                       crosscheck=False):
+    rows, cols, nnz = A.blocks()["local"]
+    kernel, algo, req = kernel_of(A, symmetric)  # before any plan_set
+    plan = plan_record(A)
+    r = timed_spmv(exec_, A, rows, _lib, reps, crosscheck)
+    ms, same = r if crosscheck else (r, None)
+    traffic, source = pmc_traffic(record, kernel, grid, 1)
+    rec = {"workload": workload, "rows": rows, "nnz_stored": nnz,
+           "kernel": kernel, "ms_per_apply": ms, "applies_timed": reps}
+    rec.update(price(ms, algo, req, traffic))
+    if traffic:
+        rec["traffic_source"] = source
+    if same is not None:
+        rec["crosscheck"] = {"against": "csr_scalar_kernel (one lane per row, the "
+                                        "reference loop of csr_kernels.cpp:41-51 "
+                                        "verbatim) on the same matrix and x",
+                             "bit_equal": same}
+    rec.update(plan)
     return rec
 
 
@@ -425,7 +550,11 @@ def main():
     if args.no_lx:
         _lib.call("spmv_hip_ctx_set_option", ctx, b"lx_min_nnz", 1 << 62)
     cm = getattr(host, args.cm.upper())
+    exec_.synchronize()
+    t_create = time.perf_counter()
     A = host.Matrix.create_poisson3d(comm, exec_, n, args.symmetric, cm)
+    exec_.synchronize()
+    t_create = time.perf_counter() - t_create  # generator + upload-free plan
     l2g = A.col_map()
     M = l2g.local_size()
     blocks = A.blocks()
@@ -503,10 +632,11 @@ def main():
                          dtype=torch.float64, device=dev_t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, spmv_ms_avg = float(t[0]), float(t[1])
-        bsum = torch.tensor([kernel_bytes, iter_bytes], dtype=torch.float64,
-                            device=dev_t)
+        bsum = torch.tensor([kernel_bytes, iter_bytes, requested_bytes],
+                            dtype=torch.float64, device=dev_t)
         dist.all_reduce(bsum, op=dist.ReduceOp.SUM)
         kernel_bytes_all, iter_bytes_all = float(bsum[0]), float(bsum[1])
+        requested_all = float(bsum[2])
         shape = torch.zeros(world, 3, dtype=torch.float64, device=dev_t)
         shape[rank] = torch.tensor(mine, dtype=torch.float64)
         dist.all_reduce(shape, op=dist.ReduceOp.SUM)
@@ -514,11 +644,12 @@ def main():
     else:
         spmv_ms_avg = spmv_ms / max(spmv_launches, 1)
         kernel_bytes_all, iter_bytes_all = kernel_bytes, iter_bytes
+        requested_all = requested_bytes
         per_rank = [mine]
 
     if rank == 0:
-        achieved = kernel_bytes / (spmv_ms_avg * 1e-3) / 1e9
-        traffic, traffic_source = pmc_traffic(kernel, n, world)
+        traffic, traffic_source = pmc_traffic("main", kernel, n, world)
+        pr = price(spmv_ms_avg, kernel_bytes, requested_bytes, traffic)
         k10 = float(hist[min(10, len(hist) - 1)] / hist[0])
         resid = {"k10": k10, "kK": float(hist[-1] / hist[0])}
         if n == 512 and len(hist) > 10:
@@ -547,27 +678,34 @@ def main():
                        "partition": f"row-slab x{world}",
                        "halo": args.cm + " (RCCL send/recv on a side stream)"
                        if world > 1 else "none (1 rank)"},
-            "roofline": {"bound": "hbm", "achieved": achieved,
+            # PHYSICAL roofline of the dominant kernel: the bytes its data
+            # format makes it load and store per launch / the launch time
+            # measured live (HIP events on the kernel's stream) / 8 TB/s
+            "roofline": {"bound": "hbm", "achieved": pr["GB/s"],
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         # the same launches priced with the bytes this form of
-                         # the kernel really loads and stores (no index stream)
+                         "frac": pr["frac"],
+                         "bytes_per_launch": requested_bytes,
                          "requested_bytes_per_launch": requested_bytes,
-                         "frac_requested": requested_bytes
-                         / (spmv_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "frac_requested": pr["frac"],
                          "traffic": traffic, "traffic_source": traffic_source,
                          # ... and with the bytes the PMC passes saw cross the
                          # fabric: what the HBM side is really asked to do
-                         "frac_traffic": (traffic / (spmv_ms_avg * 1e-3) / 1e9
-                                          / HBM_PEAK_GBS) if traffic else None,
-                         "note": ("frac prices the ALGORITHMIC CSR bytes of "
-                                  "SURVEY 8d (12 B per entry, row pointer, x, y) "
-                                  "as the contract asks; the kernel named below "
-                                  "moves fewer (requested_bytes_per_launch, "
-                                  "traffic), so frac may exceed 1 -- the HBM-side "
-                                  "utilisation is frac_traffic"),
-                         "kernel": kernel,
+                         "frac_traffic": pr.get("frac_traffic"),
+                         # the same launch priced as if it had streamed the
+                         # caller's CSR arrays (12 B per entry, row
+                         # pointer, x, y): a speed-up statement, may exceed peak
                          "algorithmic_bytes_per_launch": kernel_bytes,
+                         "csr_equivalent_gbs": pr["csr_equivalent_gbs"],
+                         "frac_csr_equivalent": pr["frac_csr_equivalent"],
+                         "note": ("achieved / frac price the bytes the plan's "
+                                  "format of the matrix makes compulsory "
+                                  "(bytes_per_launch); csr_equivalent_gbs prices "
+                                  "SURVEY 8d's CSR bytes over the same time and "
+                                  "is not a bandwidth; sub-records "
+                                  "csr_lx_spmv / csr_rowblock_spmv / "
+                                  "unstructured_spmv are the kernels a matrix "
+                                  "without lattice structure gets"),
+                         "kernel": kernel,
                          "avg_launch_ms": spmv_ms_avg,
                          "launches_timed": spmv_launches},
             # ||r_k|| / ||r_0|| from the device-side history: after 10
@@ -580,9 +718,12 @@ def main():
             # (9 vectors of 8 B per row)
             "cg_gbs_per_gpu": iter_bytes / (elapsed / args.steps) / 1e9,
             # all ranks together: sum of bytes / time of the slowest rank
-            "spmv_gbs_aggregate": kernel_bytes_all / (spmv_ms_avg * 1e-3) / 1e9,
+            "spmv_gbs_aggregate": requested_all / (spmv_ms_avg * 1e-3) / 1e9,
+            "spmv_csr_equivalent_gbs_aggregate":
+                kernel_bytes_all / (spmv_ms_avg * 1e-3) / 1e9,
             "cg_gbs_aggregate": iter_bytes_all / (elapsed / args.steps) / 1e9,
             "plan": plan_record(A),
+            "matrix_create_ms": t_create * 1e3,
         }
         if world > 1:
             out["halo_selfcheck"] = halo_selfcheck
@@ -601,6 +742,37 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_extras:
             self_comm = comm
+            # Time to solution by the reference demo's protocol
+            # (demos/cg.cpp:64-72: max_its = 100, rtol = 1e-10, wall clock
+            # around cg(), which allocates its work vectors inside): plan
+            # creation INCLUDED -- what one solve costs a caller who builds the
+            # matrix, solves once and leaves.
+            if True:
+                exec_.synchronize()
+                t0 = time.perf_counter()
+                At = host.Matrix.create_poisson3d(self_comm, exec_, n,
+                                                  args.symmetric, cm)
+                exec_.synchronize()
+                t_mat = time.perf_counter() - t0
+                d_b, d_x = exec_.alloc(N), exec_.alloc(N)
+                _lib.call("spmv_hip_fill_gaussian_f64", ctx, N, 0, N, d_b, None)
+                exec_.synchronize()
+                t0 = time.perf_counter()
+                k100, _ = host.cg(self_comm, exec_, At, d_b, d_x, 100, 1e-10,
+                                  history=False)
+                exec_.synchronize()
+                t_cg = time.perf_counter() - t0
+                plan_ms = At.plan_get("plan_us") / 1e3
+                out["time_to_solution"] = {
+                    "protocol": "demos/cg.cpp:64-72 (max_its 100, rtol 1e-10, "
+                                "wall clock around cg(); work vectors allocated "
+                                "inside) + plan creation",
+                    "iterations": k100, "cg_ms": t_cg * 1e3, "plan_ms": plan_ms,
+                    "total_ms": t_cg * 1e3 + plan_ms,
+                    "iters_per_s_incl_plan": k100 / (t_cg + plan_ms * 1e-3),
+                    "matrix_generate_and_plan_ms": t_mat * 1e3}
+                At.close()
+                exec_.free(d_b), exec_.free(d_x)
             # BASELINE configs[3]: symmetric storage at the same size, the CG
             # loop on it and its kernel
             if not args.symmetric:
@@ -619,48 +791,81 @@ def main():
                 el2 = time.perf_counter() - t0
                 kern2, algo2, req2 = kernel_of(As, True)
                 ms2 /= max(l2, 1)
+                tr2, src2 = pmc_traffic("symmetric", kern2, n, world)
                 out["symmetric"] = {
                     "workload": f"poisson3d_{n}^3_symmetric-csr_fp64_cg",
                     "iters/s": steps / el2, "steps": steps, "kernel": kern2,
-                    "avg_launch_ms": ms2, "algorithmic_bytes_per_launch": algo2,
-                    "GB/s": algo2 / ms2 / 1e6,
-                    "frac": algo2 / ms2 / 1e6 / HBM_PEAK_GBS,
-                    "requested_bytes_per_launch": req2,
-                    "frac_requested": req2 / ms2 / 1e6 / HBM_PEAK_GBS,
+                    "avg_launch_ms": ms2,
                     "parity": "bit-exact vs the oracle (atomic-free)"
                     if "atomic-free" in kern2 else "tolerance (atomics)",
                     "cg_rel_residual_k10": float(h2[min(10, len(h2) - 1)] / h2[0])}
-                (out["symmetric"]["traffic"],
-                 out["symmetric"]["traffic_source"]) = pmc_traffic(kern2, n, world)
+                # algorithmic bytes here = SURVEY 8d's B_sym (lower entries at
+                # 12 B, row pointer, diagonal, x, y)
+                out["symmetric"].update(price(ms2, algo2, req2, tr2))
+                out["symmetric"]["traffic_source"] = src2
                 out["symmetric"].update(plan_record(As))
                 ws2.close()
                 As.close()
                 exec_.free(d_b), exec_.free(d_x)
+                rec = lambda name, *a, **kw: spmv_record(  # noqa: E731
+                    exec_, self_comm, host, _lib, *a, record=name, **kw)
                 # a lattice matrix that is NOT symmetric (the generator's skewed
                 # variant: lower neighbours -1.001, upper -0.999): the full
                 # diagonal form; and the CSR-order lattice kernel (no baked
                 # copy of the values) on the Poisson matrix itself
                 if not (args.no_lattice or args.no_lx or args.no_bake):
-                    out["csr_nonsymmetric_spmv"] = spmv_record(
-                        exec_, self_comm, host, _lib, n, False, 20, skew_ppm=1000)
-                    out["csr_lattice_spmv"] = spmv_record(
-                        exec_, self_comm, host, _lib, n, False, 20, bake=False)
-                # the LX form: what a CSR matrix WITHOUT lattice structure gets
-                # (same matrix, lattice analysis switched off)
+                    out["csr_nonsymmetric_spmv"] = rec(
+                        "csr_nonsymmetric_spmv", n, False, 20, skew_ppm=1000)
+                    out["csr_lattice_spmv"] = rec("csr_lattice_spmv", n, False,
+                                                  20, bake=False)
+                # What a CSR matrix WITHOUT lattice structure gets, on the same
+                # matrix with the lattice analysis switched off: the LX form
+                # (banded matrices: x windows staged in LDS) and the plain
+                # row-block gather kernel (everything else)
                 if not (args.no_lattice or args.no_lx):
-                    out["csr_lx_spmv"] = spmv_record(exec_, self_comm, host, _lib,
-                                                     n, False, 20, lattice=False)
-            # BASELINE north_star: plain SpMV on the ~10 M-row matrix
+                    out["csr_lx_spmv"] = rec("csr_lx_spmv", n, False, 20,
+                                             lattice=False)
+                    out["csr_rowblock_spmv"] = rec("csr_rowblock_spmv", n, False,
+                                                   20, lattice=False, lx=False)
             if not args.symmetric:
-                out["north_star_spmv"] = spmv_record(exec_, self_comm, host, _lib,
-                                                     216, False, 200)
-                out["north_star_spmv"]["frac_of_8TBs"] = \
-                    out["north_star_spmv"]["frac"]
+                rec = lambda name, *a, **kw: spmv_record(  # noqa: E731
+                    exec_, self_comm, host, _lib, *a, record=name, **kw)
+                # BASELINE north_star: plain SpMV on the ~10 M-row matrix: the
+                # default plan, and the CSR-order kernels next to it
+                out["north_star_spmv"] = rec("north_star_spmv", 216, False, 200)
+                out["north_star_lattice_spmv"] = rec(
+                    "north_star_lattice_spmv", 216, False, 200, bake=False)
+                out["north_star_lx_spmv"] = rec(
+                    "north_star_lx_spmv", 216, False, 200, lattice=False)
+                out["north_star_rowblock_spmv"] = rec(
+                    "north_star_rowblock_spmv", 216, False, 200, lattice=False,
+                    lx=False)
+                # Matrices that are NOT the 7-point stencil.  (a) the 27-point
+                # operator on a 256^3 grid (HPCG's matrix; 16.8 M rows, 449 M
+                # entries); (b) a seeded unstructured matrix (10 M rows, 7
+                # entries per row: 90 % within 2,048 columns of the diagonal,
+                # 10 % anywhere) -- no lattice, column windows too wide to
+                # stage.  Each is cross-checked in this run against the
+                # one-lane-per-row kernel; the oracle-sized instances are in
+                # tests/test_gpu_matrix.py and cpu_baseline.parity_checks.
+                out["stencil27_spmv"] = rec("stencil27_spmv", args.stencil27_grid,
+                                            False, 20, stencil=27)
+                Au = host.Matrix.create_unstructured(self_comm, exec_,
+                                                     args.unstructured_rows)
+                out["unstructured_spmv"] = matrix_spmv_record(
+                    exec_, Au, _lib, False, 50, "unstructured_spmv",
+                    args.unstructured_rows,
+                    f"unstructured_{args.unstructured_rows}rows_7per_row_band2048_"
+                    "far10pct_csr_fp64_spmv", crosscheck=True)
+                Au.close()
                 # mixed-precision CG against pure fp64, to 1e-10
                 out["mixed_precision_cg"] = mixed_precision_record(
                     exec_, self_comm, host, _lib, args.mixed_grid)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, n, N, host_cores)
+            if not args.no_extras:
+                out["cpu_baseline"]["parity_checks"] = oracle_parity_checks(
+                    exec_, comm, host, _lib)
         print(json.dumps(out), flush=True)
 
     comm.close()

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SPMV_HIP_ABI_VERSION 1
+#define SPMV_HIP_ABI_VERSION 2
 
 enum {
   SPMV_HIP_OK = 0,
@@ -67,7 +67,10 @@ int spmv_hip_synchronize(spmv_hip_ctx* ctx); /* whole device */
  *   "bake_general": 0 = plan_bake_values on a general plan always returns
  *   SPMV_HIP_ENOTSUP (the CSR-order kernels on the caller's values).
  *   "poisson_skew_ppm": the device generator below writes a NON-symmetric
- *   variant (lower neighbours -1 - s, upper -1 + s, s = value * 1e-6). */
+ *   variant (lower neighbours -1 - s, upper -1 + s, s = value * 1e-6).
+ *   "poisson_stencil": 7 (default) or 27 -- the generator writes the 27-point
+ *   operator (all neighbours with |dx|,|dy|,|dz| <= 1; diagonal 26,
+ *   off-diagonal -1); its row slabs must be whole planes. */
 int spmv_hip_ctx_set_option(spmv_hip_ctx* ctx, const char* key, int64_t value);
 /*   "lx_min_nnz": csr_plan_create builds the LX form of a general matrix
  *   (LDS-staged x windows + 16-bit column offsets, 2 B per entry of extra
@@ -256,6 +259,19 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value);
 int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
                           int* value);
 
+/* out = alpha * A * in + beta * out  (CSRSpMV<T>::run, csr_kernels.cpp:20-52),
+ * every row summed left to right, mul and add rounded separately: bit-identical
+ * to the reference loops on finite data, with ONE defined difference:
+ *   beta == 0 means `out` is WRITE-ONLY -- the kernels store alpha*sum and never
+ *   read out[i] (the reference computes alpha*sum + 0*out[i] on a
+ *   buffer cg.cpp:40 never initialises, so a NaN/Inf there would poison it).
+ *   Consequence for the sign of zero: where alpha*sum is -0.0 the reference's
+ *   "+ 0*out[i]" turns it into +0.0 (for out[i] >= +0) while this library
+ *   returns -0.0.  The two compare equal (np.array_equal, ==); only the sign
+ *   bit differs, and only for rows whose sum is an exact negative zero.
+ * dot_partials (may be NULL; general fp64 and symmetric fp64): the launch also
+ * leaves spmv_hip_dot_partials_len() partial sums of in . (alpha * A * in),
+ * the block's share of p.Ap in CG (cg.cpp:63). */
 int spmv_hip_csr_spmv_f64(spmv_hip_ctx* ctx, const spmv_hip_csr_plan* plan,
                           int32_t num_rows, int32_t num_cols,
                           int64_t num_non_zeros, const int32_t* rowptr,
@@ -333,9 +349,17 @@ int spmv_hip_cg_ws_rr(spmv_hip_cg_ws* ws, int k, double** slot);
 int spmv_hip_cg_ws_pAp(spmv_hip_cg_ws* ws, int k, double** slot);
 int spmv_hip_cg_ws_partials(spmv_hip_cg_ws* ws, double** partials);
 int spmv_hip_cg_ws_done_flag(spmv_hip_cg_ws* ws, const int32_t** done);
-/* copies {done, kstop} and rr[0..kmax] to the host (async on stream) */
+/* kmax the workspace was created with: its history holds kmax + 1 doubles */
+int spmv_hip_cg_ws_capacity(const spmv_hip_cg_ws* ws, int* kmax);
+/* copies {done, kstop} (2 x int32) and rr[0..kmax] to the host (async on
+ * stream).  `host_rr_len` = doubles the caller's `host_rr` can take: fewer than
+ * kmax + 1 (spmv_hip_cg_ws_capacity) -> SPMV_HIP_EINVAL, nothing is copied.
+ * Either destination may be NULL (then it is skipped; host_rr_len ignored).
+ * (ABI 2: the length argument is new -- ABI 1 wrote kmax + 1 doubles into
+ * whatever it was given.) */
 int spmv_hip_cg_ws_read_async(spmv_hip_cg_ws* ws, int32_t* host_done_kstop,
-                              double* host_rr, void* stream);
+                              double* host_rr, size_t host_rr_len,
+                              void* stream);
 
 /* x += alpha p ; r -= alpha Ap ; partials of r.r   (cg.cpp:66-73)
  * alpha = (s*s)/pAp[k] with s = sqrt(rr[k-1]), evaluated on the device. */
@@ -429,6 +453,19 @@ int spmv_hip_poisson3d_fill_f64(spmv_hip_ctx* ctx, int32_t n,
 /* number of ghost columns below / above the owned range for this row block */
 int spmv_hip_poisson3d_ghosts(int32_t n, int64_t row_begin, int64_t row_end,
                               int64_t* ghosts_below, int64_t* ghosts_above);
+/* Seeded unstructured test matrix, generated on the device (not in the
+ * reference: a synthetic input for measuring the general kernels on a matrix
+ * WITHOUT lattice or narrow-band structure).  Square, `per_row` (1..32)
+ * entries per row; each entry's column is, with probability far_permille/1000,
+ * anywhere, otherwise within `band` columns of the diagonal; columns ascending
+ * within a row (repeats possible), values uniform in [-1, 1).  rowptr takes
+ * num_rows + 1, colind / values num_rows * per_row entries.  The numpy twin is
+ * spmv_amd/poisson.py:unstructured_csr. */
+int spmv_hip_unstructured_fill_f64(spmv_hip_ctx* ctx, int64_t num_rows,
+                                   int per_row, int64_t band, int far_permille,
+                                   uint64_t seed, int32_t* rowptr,
+                                   int32_t* colind, double* values,
+                                   void* stream);
 /* x_i = exp(-10 (5 (i/N - 1/2))^2), i = i_begin.. (demos/spmv.cpp:63-67) */
 int spmv_hip_fill_gaussian_f64(spmv_hip_ctx* ctx, int64_t N, int64_t i_begin,
                                int64_t count, double* x, void* stream);

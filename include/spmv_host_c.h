@@ -105,6 +105,12 @@ int spmvh_matrix_create(spmvh_comm* comm, spmvh_exec* exec,
                         spmvh_matrix** A);
 int spmvh_matrix_create_poisson3d(spmvh_comm* comm, spmvh_exec* exec, int32_t n,
                                   int symmetric, int cm, spmvh_matrix** A);
+/* seeded unstructured test matrix generated on the device (one rank, general
+ * storage; spmv_hip_unstructured_fill_f64) */
+int spmvh_matrix_create_unstructured(spmvh_comm* comm, spmvh_exec* exec,
+                                     int64_t nrows, int per_row, int64_t band,
+                                     int far_permille, uint64_t seed,
+                                     spmvh_matrix** A);
 /* The Poisson matrix on a 3-D block partition (the reference
  * partitions by row slabs only, read_petsc.cpp:20-37): px * py * pz boxes,
  * rank = ix + px (iy + py iz), rank-major global numbering (a box's points are

@@ -111,7 +111,8 @@ _PROTOS = {
     "spmv_hip_cg_ws_pAp": ([vp, C.c_int, P(vp)], C.c_int),
     "spmv_hip_cg_ws_partials": ([vp, P(vp)], C.c_int),
     "spmv_hip_cg_ws_done_flag": ([vp, P(vp)], C.c_int),
-    "spmv_hip_cg_ws_read_async": ([vp, vp, vp, vp], C.c_int),
+    "spmv_hip_cg_ws_read_async": ([vp, vp, vp, C.c_size_t, vp], C.c_int),
+    "spmv_hip_cg_ws_capacity": ([vp, vp], C.c_int),
     "spmv_hip_cg_update_xr_f64": ([vp, vp, C.c_int, i64, vp, vp, vp, vp, vp],
                                   C.c_int),
     "spmv_hip_cg_update_p_f64": ([vp, vp, C.c_int, i64, vp, vp, vp], C.c_int),
@@ -127,6 +128,8 @@ _PROTOS = {
     "spmv_hip_poisson3d_fill_f64": ([vp, i32, i64, i64, C.c_int, vp, vp, vp,
                                      vp, vp], C.c_int),
     "spmv_hip_poisson3d_ghosts": ([i32, i64, i64, P(i64), P(i64)], C.c_int),
+    "spmv_hip_unstructured_fill_f64": ([vp, i64, C.c_int, i64, C.c_int,
+                                        C.c_uint64, vp, vp, vp, vp], C.c_int),
     "spmv_hip_fill_gaussian_f64": ([vp, i64, i64, i64, vp, vp], C.c_int),
     "spmv_hip_fill_const_f64": ([vp, i64, f64, vp, vp], C.c_int),
     "spmv_hip_comm_unique_id": ([vp], C.c_int),

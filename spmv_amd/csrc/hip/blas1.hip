@@ -926,10 +926,19 @@ int spmv_hip_cg_ws_done_flag(spmv_hip_cg_ws* ws, const int32_t** done)
   return SPMV_HIP_OK;
 }
 
+int spmv_hip_cg_ws_capacity(const spmv_hip_cg_ws* ws, int* kmax)
+{
+  SPMV_REQUIRE(ws && kmax);
+  *kmax = ws->kmax;
+  return SPMV_HIP_OK;
+}
+
 int spmv_hip_cg_ws_read_async(spmv_hip_cg_ws* ws, int32_t* host_done_kstop,
-                              double* host_rr, void* stream)
+                              double* host_rr, size_t host_rr_len, void* stream)
 {
   SPMV_REQUIRE(ws);
+  // checked before anything is enqueued: a short buffer gets nothing at all
+  SPMV_REQUIRE(!host_rr || host_rr_len >= (size_t)ws->kmax + 1);
   SPMV_SET_DEVICE(ws->ctx);
   hipStream_t st = spmv_stream(ws->ctx, stream);
   if (host_done_kstop)

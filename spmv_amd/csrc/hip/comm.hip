@@ -89,10 +89,46 @@ int spmv_hip_comm_create(spmv_hip_ctx* ctx, int nranks, int rank,
   }
   c->red = c->comm;
   if (nranks > 1) {
-    // collective over the parent: every rank is in this call right now
+    // A second communicator for the scalar all-reduces (RCCL serialises the
+    // operations of ONE communicator, which would tie the halo stream to the
+    // compute stream).  The split is collective over the parent: every rank is
+    // in this call right now.  Its OUTCOME must be collective too -- ranks that
+    // fell back to the parent while others use the split would issue their
+    // all-reduces on different communicators and hang -- so the ranks agree
+    // on it with a MIN all-reduce over the parent; if that fails the parent
+    // itself is unusable and creation fails.
     ncclComm_t red = nullptr;
-    if (ncclCommSplit(c->comm, 0, rank, &red, nullptr) == ncclSuccess && red)
-      c->red = red;
+    const ncclResult_t rs = ncclCommSplit(c->comm, 0, rank, &red, nullptr);
+    int32_t ok = (rs == ncclSuccess && red) ? 1 : 0;
+    int32_t* d_ok = nullptr;
+    hipError_t e = hipMalloc(&d_ok, sizeof(int32_t));
+    if (e == hipSuccess)
+      e = hipMemcpy(d_ok, &ok, sizeof(int32_t), hipMemcpyHostToDevice);
+    ncclResult_t ra = ncclSuccess;
+    if (e == hipSuccess) {
+      ra = ncclAllReduce(d_ok, d_ok, 1, ncclInt32, ncclMin, c->comm, nullptr);
+      if (ra == ncclSuccess)
+        e = hipStreamSynchronize(nullptr);
+      if (ra == ncclSuccess && e == hipSuccess)
+        e = hipMemcpy(&ok, d_ok, sizeof(int32_t), hipMemcpyDeviceToHost);
+    }
+    ncclResult_t async = ncclSuccess;
+    if (ra == ncclSuccess)
+      ra = ncclCommGetAsyncError(c->comm, &async);
+    (void)hipFree(d_ok);
+    if (e != hipSuccess || ra != ncclSuccess || async != ncclSuccess) {
+      if (red)
+        (void)ncclCommDestroy(red);
+      (void)ncclCommDestroy(c->comm);
+      delete c;
+      return e != hipSuccess
+                 ? static_cast<int>(e)
+                 : 10000 + static_cast<int>(ra != ncclSuccess ? ra : async);
+    }
+    if (ok)
+      c->red = red; // on every rank
+    else if (red)
+      (void)ncclCommDestroy(red); // on every rank: the parent serves both
   }
   *out = c;
   return SPMV_HIP_OK;

@@ -33,6 +33,9 @@ struct spmv_hip_ctx {
   // lower neighbours -1 - s, upper -1 + s, s = value * 1e-6; 0 = the Poisson
   // matrix).  For measurements of kernels on matrices that are not symmetric.
   int poisson_skew_ppm = 0;
+  // ... and its stencil ("poisson_stencil": 7, or 27 = all neighbours with
+  // |dx|, |dy|, |dz| <= 1, diagonal 26, off-diagonal -1: HPCG's operator)
+  int poisson_stencil = 7;
 };
 
 #define SPMV_CHECK_HIP(expr)                                                   \

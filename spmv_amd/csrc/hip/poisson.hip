@@ -10,6 +10,11 @@
 // Grid n^3, natural ordering i = x + n (y + n z), diagonal 6, off-diagonal
 // -1, neighbours outside the grid dropped.  Within a row, entries are stored
 // in ascending local column order (owned columns, then ghosts).
+//
+// Context option "poisson_stencil" = 27: the 27-point operator on the same
+// grid (all neighbours with |dx|, |dy|, |dz| <= 1; diagonal 26, off-diagonal
+// -1 -- HPCG's matrix), for measurements of the kernels on wider stencils.
+// Its row slabs must be whole planes (or the whole matrix).
 #include "common.h"
 
 #include <hipcub/hipcub.hpp>
@@ -17,8 +22,11 @@
 namespace
 {
 
+constexpr int kMaxStencil = 27;
+
 struct Geom {
   int32_t n;
+  int32_t points; // 7 or 27
   int64_t n2, N;
   int64_t r0, r1;       // owned global rows (= owned global columns)
   int64_t gb_start, gb; // ghosts below: [gb_start, r0), gb of them
@@ -51,6 +59,17 @@ __device__ inline int stencil(const Geom& g, int64_t i, int64_t* cols)
 {
   const int64_t x = i % g.n, y = (i / g.n) % g.n, z = i / g.n2;
   int c = 0;
+  if (g.points == 27) {
+    // (dz, dy, dx) in lexicographic order = ascending index for n >= 3
+    for (int dz = -1; dz <= 1; ++dz)
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int64_t xx = x + dx, yy = y + dy, zz = z + dz;
+          if (xx >= 0 && xx < g.n && yy >= 0 && yy < g.n && zz >= 0 && zz < g.n)
+            cols[c++] = i + dz * g.n2 + dy * (int64_t)g.n + dx;
+        }
+    return c;
+  }
   if (z > 0) cols[c++] = i - g.n2;
   if (y > 0) cols[c++] = i - g.n;
   if (x > 0) cols[c++] = i - 1;
@@ -69,7 +88,7 @@ __global__ __launch_bounds__(kBlock) void poisson_count_kernel(Geom g, int part,
        k += (int64_t)gridDim.x * blockDim.x) {
     int cnt = 0;
     if (k < nrows) {
-      int64_t cols[7];
+      int64_t cols[kMaxStencil];
       const int64_t i = g.r0 + k;
       const int c = stencil(g, i, cols);
       for (int e = 0; e < c; ++e)
@@ -87,9 +106,10 @@ __global__ __launch_bounds__(kBlock) void poisson_fill_kernel(
     double* __restrict__ diagonal, double skew)
 {
   const int64_t nrows = g.r1 - g.r0;
+  const double diag = g.points == 27 ? 26.0 : 6.0;
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nrows;
        k += (int64_t)gridDim.x * blockDim.x) {
-    int64_t cols[7];
+    int64_t cols[kMaxStencil];
     const int64_t i = g.r0 + k;
     const int c = stencil(g, i, cols);
     // Entries are stored in ascending LOCAL column order, as create_matrix
@@ -102,19 +122,77 @@ __global__ __launch_bounds__(kBlock) void poisson_fill_kernel(
         if (owned != (pass == 0) || !keep(part, i, cols[e], g.r0, g.r1))
           continue;
         colind[pos] = local_col(g, cols[e]);
-        values[pos] = (cols[e] == i) ? 6.0
+        values[pos] = (cols[e] == i) ? diag
                                      : (cols[e] < i ? -1.0 - skew : -1.0 + skew);
         ++pos;
       }
     if (diagonal)
-      diagonal[k] = 6.0;
+      diagonal[k] = diag;
   }
 }
 
-int make_geom(int32_t n, int64_t r0, int64_t r1, Geom* g)
+// ---------------------------------------------------------------------------
+// Seeded UNSTRUCTURED test matrix (measurements of the general kernels on a
+// matrix without lattice or narrow-band structure; spmv_amd/poisson.py holds
+// the numpy twin the tests compare with).  Square, `per_row` entries in every
+// row; entry e = row * per_row + k draws h = mix64((e + 1) * GOLDEN + seed):
+// with probability far_permille / 1000 a column anywhere, otherwise one within
+// `band` columns of the diagonal; clipped into range, sorted ascending within
+// the row (repeats stay: legal CSR, the reference loop adds them).  Values
+// uniform in [-1, 1) from a second draw, assigned by position after the sort.
+// ---------------------------------------------------------------------------
+__host__ __device__ inline uint64_t mix64(uint64_t z) // splitmix64 finaliser
+{
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+constexpr int kMaxPerRow = 32;
+
+__global__ __launch_bounds__(kBlock) void unstructured_fill_kernel(
+    int64_t nrows, int per_row, int64_t band, int far_permille, uint64_t seed,
+    int32_t* __restrict__ rowptr, int32_t* __restrict__ colind,
+    double* __restrict__ values)
+{
+  constexpr uint64_t kGolden = 0x9E3779B97F4A7C15ull;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= nrows;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    rowptr[i] = (int32_t)(i * per_row);
+    if (i == nrows)
+      break;
+    int32_t c[kMaxPerRow];
+    for (int k = 0; k < per_row; ++k) {
+      const uint64_t e = (uint64_t)(i * per_row + k);
+      const uint64_t h = mix64((e + 1) * kGolden + seed);
+      const bool far = (int)(h % 1000u) < far_permille;
+      const uint64_t r = h >> 10;
+      int64_t col = far ? (int64_t)(r % (uint64_t)nrows)
+                        : i - band + (int64_t)(r % (uint64_t)(2 * band + 1));
+      col = col < 0 ? 0 : (col >= nrows ? nrows - 1 : col);
+      // insertion into the sorted prefix
+      int j = k;
+      while (j > 0 && c[j - 1] > (int32_t)col) {
+        c[j] = c[j - 1];
+        --j;
+      }
+      c[j] = (int32_t)col;
+    }
+    for (int k = 0; k < per_row; ++k) {
+      const uint64_t e = (uint64_t)(i * per_row + k);
+      colind[e] = c[k];
+      const uint64_t h2 = mix64((e + 1) * kGolden + seed + 1);
+      values[e] = (double)(h2 >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+    }
+  }
+}
+
+int make_geom(int32_t n, int64_t r0, int64_t r1, Geom* g, int points = 7)
 {
   if (n < 1 || n > 1290) // n^3 rows must fit the int32 local index space
     return SPMV_HIP_ERANGE;
+  if (points != 7 && points != 27)
+    return SPMV_HIP_EINVAL;
   const int64_t n2 = (int64_t)n * n, N = n2 * n;
   if (r0 < 0 || r1 < r0 || r1 > N)
     return SPMV_HIP_EINVAL;
@@ -123,7 +201,12 @@ int make_geom(int32_t n, int64_t r0, int64_t r1, Geom* g)
   const bool whole = (r0 == 0 && r1 == N);
   if (!whole && (r1 - r0) < n2)
     return SPMV_HIP_ENOTSUP;
+  // 27 points: the index order of a row's neighbours needs n >= 3, and the
+  // ghost sets are whole planes only for plane-aligned slabs
+  if (points == 27 && (n < 3 || (!whole && (r0 % n2 != 0 || r1 % n2 != 0))))
+    return SPMV_HIP_ENOTSUP;
   g->n = n;
+  g->points = points;
   g->n2 = n2;
   g->N = N;
   g->r0 = r0;
@@ -162,11 +245,11 @@ int spmv_hip_poisson3d_count(spmv_hip_ctx* ctx, int32_t n, int64_t row_begin,
   SPMV_REQUIRE(rowptr && part >= SPMV_HIP_PART_ALL
                && part <= SPMV_HIP_PART_LOCAL_LOWER);
   Geom g;
-  int rc = make_geom(n, row_begin, row_end, &g);
+  int rc = make_geom(n, row_begin, row_end, &g, ctx->poisson_stencil);
   if (rc)
     return rc;
   const int64_t nrows = g.r1 - g.r0;
-  if (7 * nrows > INT32_MAX)
+  if ((int64_t)g.points * nrows > INT32_MAX)
     return SPMV_HIP_ERANGE; // int32 rowptr (csr_kernels.h:28)
   hipStream_t st = spmv_stream(ctx, stream);
   const int grid = spmv_grid_for(ctx, nrows + 1, kBlock);
@@ -204,7 +287,7 @@ int spmv_hip_poisson3d_fill_f64(spmv_hip_ctx* ctx, int32_t n,
   SPMV_REQUIRE(rowptr && part >= SPMV_HIP_PART_ALL
                && part <= SPMV_HIP_PART_LOCAL_LOWER);
   Geom g;
-  int rc = make_geom(n, row_begin, row_end, &g);
+  int rc = make_geom(n, row_begin, row_end, &g, ctx->poisson_stencil);
   if (rc)
     return rc;
   const int64_t nrows = g.r1 - g.r0;
@@ -225,6 +308,25 @@ int spmv_hip_poisson3d_fill_f64(spmv_hip_ctx* ctx, int32_t n,
   hipLaunchKernelGGL(poisson_fill_kernel, dim3(grid), dim3(kBlock), 0,
                      spmv_stream(ctx, stream), g, part, rowptr, colind, values,
                      diagonal, 1e-6 * (double)ctx->poisson_skew_ppm);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_unstructured_fill_f64(spmv_hip_ctx* ctx, int64_t num_rows,
+                                   int per_row, int64_t band, int far_permille,
+                                   uint64_t seed, int32_t* rowptr,
+                                   int32_t* colind, double* values, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(num_rows >= 1 && per_row >= 1 && per_row <= kMaxPerRow
+               && band >= 0 && far_permille >= 0 && far_permille <= 1000
+               && rowptr && colind && values);
+  if (num_rows > INT32_MAX || num_rows * per_row > INT32_MAX)
+    return SPMV_HIP_ERANGE; // int32 rowptr (csr_kernels.h:28)
+  const int grid = spmv_grid_for(ctx, num_rows + 1, kBlock);
+  hipLaunchKernelGGL(unstructured_fill_kernel, dim3(grid), dim3(kBlock), 0,
+                     spmv_stream(ctx, stream), num_rows, per_row, band,
+                     far_permille, seed, rowptr, colind, values);
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;
 }

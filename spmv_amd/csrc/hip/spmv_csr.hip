@@ -521,10 +521,10 @@ __global__ __launch_bounds__(kBlock) void lx_build_kernel(
 // ---------------------------------------------------------------------------
 // SCALAR kernel: one lane per row, the reference loop verbatim.
 // ---------------------------------------------------------------------------
-template <typename T, bool DOT>
+template <typename TV, typename T, bool DOT>
 __global__ __launch_bounds__(kBlock) void csr_scalar_kernel(
     int32_t num_rows, const int32_t* __restrict__ rowptr,
-    const int32_t* __restrict__ colind, const T* __restrict__ values, T alpha,
+    const int32_t* __restrict__ colind, const TV* __restrict__ values, T alpha,
     const T* __restrict__ in, T beta, T* __restrict__ out,
     DotOut dot)
 {
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(kBlock) void csr_scalar_kernel(
        i < num_rows; i += (int64_t)gridDim.x * blockDim.x) {
     T sum = 0;
     for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j)
-      sum += values[j] * in[colind[j]];
+      sum += (T)values[j] * in[colind[j]];
     const T c = alpha * sum;
     T y = c;
     if (beta != T(0))
@@ -589,10 +589,10 @@ struct NonEmptyRow {
 // ---------------------------------------------------------------------------
 // VECTOR kernel: LPR lanes per row, strided walk + shuffle reduction.
 // ---------------------------------------------------------------------------
-template <typename T, int LPR, bool DOT>
+template <typename TV, typename T, int LPR, bool DOT>
 __global__ __launch_bounds__(kBlock) void csr_vector_kernel(
     int32_t num_rows, const int32_t* __restrict__ rowptr,
-    const int32_t* __restrict__ colind, const T* __restrict__ values, T alpha,
+    const int32_t* __restrict__ colind, const TV* __restrict__ values, T alpha,
     const T* __restrict__ in, T beta, T* __restrict__ out,
     DotOut dot)
 {
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(kBlock) void csr_vector_kernel(
     if (i < num_rows) {
       const int32_t lo = rowptr[i], hi = rowptr[i + 1];
       for (int32_t j = lo + sub; j < hi; j += LPR)
-        sum += values[j] * in[colind[j]];
+        sum += (T)values[j] * in[colind[j]];
     }
 #pragma unroll
     for (int off = LPR / 2; off > 0; off >>= 1)
@@ -723,10 +723,10 @@ int launch_rowblock(const spmv_hip_csr_plan* pl, hipStream_t st,
 #undef SPMV_RB
 }
 
-template <typename T, bool DOT>
+template <typename TV, typename T, bool DOT>
 int launch_vector(const spmv_hip_csr_plan* pl, hipStream_t st,
                   const int32_t* rowptr, const int32_t* colind,
-                  const T* values, T alpha, const T* in, T beta, T* out,
+                  const TV* values, T alpha, const T* in, T beta, T* out,
                   DotOut dot)
 {
   const int lpr = pl->lanes_per_row;
@@ -735,8 +735,8 @@ int launch_vector(const spmv_hip_csr_plan* pl, hipStream_t st,
   if (grid > nblk)
     grid = (int)(nblk < 1 ? 1 : nblk);
 #define SPMV_VEC(L)                                                            \
-  hipLaunchKernelGGL((csr_vector_kernel<T, L, DOT>), dim3(grid), dim3(kBlock), \
-                     0, st, pl->num_rows, rowptr, colind, values, alpha, in,   \
+  hipLaunchKernelGGL((csr_vector_kernel<TV, T, L, DOT>), dim3(grid),             \
+                     dim3(kBlock), 0, st, pl->num_rows, rowptr, colind, values, alpha, in, \
                      beta, out, dot)
   switch (lpr) {
   case 4: SPMV_VEC(4); break;
@@ -750,14 +750,14 @@ int launch_vector(const spmv_hip_csr_plan* pl, hipStream_t st,
   return SPMV_HIP_OK;
 }
 
-template <typename T, bool DOT>
+template <typename TV, typename T, bool DOT>
 int launch_scalar(const spmv_hip_csr_plan* pl, hipStream_t st,
                   const int32_t* rowptr, const int32_t* colind,
-                  const T* values, T alpha, const T* in, T beta, T* out,
+                  const TV* values, T alpha, const T* in, T beta, T* out,
                   DotOut dot)
 {
   const int grid = spmv_grid_for(pl->ctx, pl->num_rows, kBlock);
-  hipLaunchKernelGGL((csr_scalar_kernel<T, DOT>), dim3(grid), dim3(kBlock), 0,
+  hipLaunchKernelGGL((csr_scalar_kernel<TV, T, DOT>), dim3(grid), dim3(kBlock), 0,
                      st, pl->num_rows, rowptr, colind, values, alpha, in, beta,
                      out, dot);
   SPMV_CHECK_LAUNCH();
@@ -796,11 +796,11 @@ int run_general(const spmv_hip_csr_plan* pl, hipStream_t st,
 {
   switch (pl->algo) {
   case SPMV_HIP_ALGO_VECTOR:
-    return launch_vector<T, DOT>(pl, st, rowptr, colind, values, alpha, in,
-                                 beta, out, dot);
+    return launch_vector<T, T, DOT>(pl, st, rowptr, colind, values, alpha, in,
+                                    beta, out, dot);
   case SPMV_HIP_ALGO_SCALAR:
-    return launch_scalar<T, DOT>(pl, st, rowptr, colind, values, alpha, in,
-                                 beta, out, dot);
+    return launch_scalar<T, T, DOT>(pl, st, rowptr, colind, values, alpha, in,
+                                    beta, out, dot);
   case SPMV_HIP_ALGO_ROWLIST:
     return launch_rowlist<T, T, DOT>(pl, st, rowptr, colind, values, alpha, in,
                                   beta, out, dot);
@@ -949,7 +949,8 @@ int build_lx(spmv_hip_csr_plan* pl, const int32_t* rowptr,
 }
 
 // Mixed precision: fp32 `values`, fp64 vectors and arithmetic.
-// General blocks only; lattice form, plain row blocks, row list.
+// General blocks only, every algorithm a general plan can have: diagonal and
+// lattice forms, plain row blocks, row list, vector, scalar.
 template <bool DOT>
 int run_mixed(const spmv_hip_csr_plan* pl, hipStream_t st,
                      const int32_t* rowptr, const int32_t* colind,
@@ -959,8 +960,12 @@ int run_mixed(const spmv_hip_csr_plan* pl, hipStream_t st,
   if (pl->algo == SPMV_HIP_ALGO_ROWLIST)
     return launch_rowlist<float, double, DOT>(pl, st, rowptr, colind, values,
                                               alpha, in, beta, out, dot);
-  if (pl->algo != SPMV_HIP_ALGO_ROWBLOCK)
-    return SPMV_HIP_ENOTSUP;
+  if (pl->algo == SPMV_HIP_ALGO_VECTOR)
+    return launch_vector<float, double, DOT>(pl, st, rowptr, colind, values,
+                                             alpha, in, beta, out, dot);
+  if (pl->algo == SPMV_HIP_ALGO_SCALAR)
+    return launch_scalar<float, double, DOT>(pl, st, rowptr, colind, values,
+                                             alpha, in, beta, out, dot);
   // the plan's fp32 copy of a symmetric matrix's lower half (spmv_symdia.hip)
   if (pl->sdia && pl->sdia32_val && values == pl->sdia32_values0)
     return spmv_sdia_run_f32f64(pl, st, alpha, in, beta, out,

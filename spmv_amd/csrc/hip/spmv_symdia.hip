@@ -56,6 +56,8 @@
 #include "csr_plan.h"
 #include "lat_dma.h"
 
+static void sdia_free_arrays(spmv_hip_csr_plan* pl);
+
 namespace
 {
 
@@ -781,31 +783,49 @@ int sdia_bake(spmv_hip_csr_plan* pl, const T* values, const T* diagonal,
   SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
   const auto t_begin = std::chrono::steady_clock::now();
   const bool had = pl->sdia_val != nullptr;
-  spmv_sdia_free(pl);
+  SPMV_REQUIRE((values == nullptr && diagonal == nullptr)
+               || (values
+                   && (pl->symmetric ? diagonal != nullptr : diagonal == nullptr)));
+  // An earlier copy goes first (its pointers may be the ones passed again).
+  // The plane-walk table is tied to the kernel the plan runs: with a baked
+  // copy it is the diagonal-form kernel's, otherwise the one plan creation
+  // built for the CSR-order lattice kernel.  Every exit that does not install
+  // a new copy must therefore leave the CSR-order kernel's table: untouched
+  // when there was no copy (`had` false), rebuilt when there was one.
+  sdia_free_arrays(pl);
+  auto unchanged = [&](int rc) {
+    if (had) {
+      spmv_zwalk_free(pl);
+      pl->zw_d2 = 0;
+      const int rw = sdia_restore_walk(pl);
+      if (rw != SPMV_HIP_OK)
+        return rw;
+    }
+    return rc;
+  };
   if (values == nullptr && diagonal == nullptr) // dropped
-    return had ? sdia_restore_walk(pl) : SPMV_HIP_OK;
+    return unchanged(SPMV_HIP_OK);
   const bool general = !pl->symmetric;
-  SPMV_REQUIRE(values && (general ? diagonal == nullptr : diagonal != nullptr));
   if (pl->nnz == 0)
-    return SPMV_HIP_ENOTSUP;
+    return unchanged(SPMV_HIP_ENOTSUP);
   if (general) {
     // rests on the lattice form (ascending columns without repeats, a row
     // block's worth of structure) of a square matrix
     if (!pl->ctx->bake_general || !pl->lat_tab || pl->num_rows != pl->num_cols)
-      return SPMV_HIP_ENOTSUP;
+      return unchanged(SPMV_HIP_ENOTSUP);
     int nd = 0, U[kSdiaMaxOff] = {0, 0, 0};
     const int rc = sdia_general_offsets(pl, st, &nd, U);
     if (rc != SPMV_HIP_OK)
-      return rc;
+      return unchanged(rc);
     if (nd == 0)
-      return SPMV_HIP_ENOTSUP;
+      return unchanged(SPMV_HIP_ENOTSUP);
     pl->sdia_nd = nd;
     for (int k = 0; k < kSdiaMaxOff; ++k)
       pl->sdia_U[k] = U[k];
   } else {
     // rests on the symmetric lattice analysis
     if (!pl->slat_mask)
-      return SPMV_HIP_ENOTSUP;
+      return unchanged(SPMV_HIP_ENOTSUP);
     pl->sdia_nd = pl->slat_nd;
     for (int k = 0; k < kSdiaMaxOff; ++k)
       pl->sdia_U[k] = -pl->slat_D[k];
@@ -829,7 +849,7 @@ int sdia_bake(spmv_hip_csr_plan* pl, const T* values, const T* diagonal,
     if (rc != SPMV_HIP_OK) {
       pl->sdia_general = 0;
       pl->sdia_nd = 0;
-      return rc;
+      return unchanged(rc);
     }
   }
   const SdiaGeom g = sdia_geom<T>(pl);
@@ -901,6 +921,14 @@ int sdia_bake_mixed(spmv_hip_csr_plan* pl, const float* values32, hipStream_t st
 
 void spmv_sdia_free(spmv_hip_csr_plan* pl)
 {
+  sdia_free_arrays(pl);
+  spmv_zwalk_free(pl);
+  pl->zw_d2 = 0;
+}
+
+// the baked copies alone; the plane-walk table is the caller's business
+static void sdia_free_arrays(spmv_hip_csr_plan* pl)
+{
   (void)hipFree(pl->sdia_val);
   (void)hipFree(pl->sdia_cmask);
   (void)hipFree(pl->sdia32_val);
@@ -916,8 +944,6 @@ void spmv_sdia_free(spmv_hip_csr_plan* pl)
   pl->sdia = 0;
   pl->sdia_general = 0;
   pl->sdia_nd = 0;
-  spmv_zwalk_free(pl);
-  pl->zw_d2 = 0;
 }
 
 int spmv_sdia_grid(const spmv_hip_csr_plan* pl)

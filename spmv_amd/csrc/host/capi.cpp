@@ -326,6 +326,20 @@ int spmvh_matrix_create_poisson3d(spmvh_comm* comm, spmvh_exec* exec, int32_t n,
   });
 }
 
+int spmvh_matrix_create_unstructured(spmvh_comm* comm, spmvh_exec* exec,
+                                     int64_t nrows, int per_row, int64_t band,
+                                     int far_permille, uint64_t seed,
+                                     spmvh_matrix** A)
+{
+  return guarded([&] {
+    require(comm && exec && A, "NULL argument");
+    auto m = std::make_unique<spmvh_matrix>();
+    m->A.reset(Matrix<double>::create_unstructured(
+        comm->comm, exec->hip, nrows, per_row, band, far_permille, seed));
+    *A = m.release();
+  });
+}
+
 int spmvh_matrix_create_poisson3d_boxes(spmvh_comm* comm, spmvh_exec* exec,
                                         int32_t n, int px, int py, int pz,
                                         int symmetric, int cm, spmvh_matrix** A)

@@ -137,6 +137,13 @@ int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
   throw_on_error(spmv_hip_dot_partials_len(ctx, &len),
                  "spmv_hip_dot_partials_len");
 
+  { // x is the iterate from the first kernel on (cg.h): it cannot share b
+    const uintptr_t xb = reinterpret_cast<uintptr_t>(x),
+                    bb = reinterpret_cast<uintptr_t>(b);
+    const uintptr_t bytes = (uintptr_t)M * sizeof(double);
+    if (M > 0 && xb < bb + bytes && bb < xb + bytes)
+      throw std::runtime_error("cg: x overlaps b (x is updated in place)");
+  }
   CgWorkspace own(exec);
   CgWorkspace& w = workspace ? *workspace : own;
   w.ensure(M, N_padded, kmax, len);
@@ -299,7 +306,7 @@ int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
         stopped = w.flags[0] != 0;
       }
       if (!stopped) {
-        throw_on_error(spmv_hip_cg_ws_read_async(w.ws, w.flags, nullptr,
+        throw_on_error(spmv_hip_cg_ws_read_async(w.ws, w.flags, nullptr, 0,
                                                  nullptr),
                        "spmv_hip_cg_ws_read_async");
         exec.record_event(w.poll_event, w.stream);
@@ -310,9 +317,13 @@ int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
 
   // final state: {done, kstop} and the squared-residual history
   // (the device history has the WORKSPACE's capacity, which an earlier solve
-  // with a larger kmax may have set: the copy is that long)
-  std::vector<double> rr((size_t)std::max(kmax, w.kmax_cap) + 1, 0.0);
-  throw_on_error(spmv_hip_cg_ws_read_async(w.ws, w.flags, rr.data(), nullptr),
+  // with a larger kmax may have set: the copy is that long, and the C ABI
+  // refuses a shorter destination)
+  int cap = 0;
+  throw_on_error(spmv_hip_cg_ws_capacity(w.ws, &cap), "spmv_hip_cg_ws_capacity");
+  std::vector<double> rr((size_t)std::max(kmax, cap) + 1, 0.0);
+  throw_on_error(spmv_hip_cg_ws_read_async(w.ws, w.flags, rr.data(), rr.size(),
+                                           nullptr),
                  "spmv_hip_cg_ws_read_async");
   double true_rr = -1.0;
   if (mixed) {

@@ -86,6 +86,16 @@ struct CgStats {
 // declared convergence.  Kernels issued after convergence are no-ops, so x
 // is exactly the iterate of the returned k.
 //
+// `x` IS the iterate (cg.cpp keeps a padded work vector and copies it out at
+// the end, :89): it is zeroed at the start of the solve and updated in place
+// from iteration 1 on, so
+//   * `x` must not overlap `b` (std::runtime_error; the reference would
+//     tolerate x == b because it writes x only once, after the loop), and
+//   * if the solve throws, `x` holds whatever iterate had been reached --
+//     unlike the reference it is not left untouched.
+// (An `x` that is not 16-byte aligned, and every mixed-precision solve, go
+// through the workspace's own vector and one copy at the end instead.)
+//
 // If rnorm_history != nullptr it receives ||r_0||, ..., ||r_k||.
 int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
        const double* b, double* x, int kmax, double rtol,

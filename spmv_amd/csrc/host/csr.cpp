@@ -233,17 +233,25 @@ void CSRMatrix<T>::enable_mixed() const
   auto* hip = dynamic_cast<const HipExecutor*>(this->_exec.get());
   if (!hip)
     return;
-  _values32 = this->_exec->template alloc<float>(this->_num_non_zeros);
   if constexpr (std::is_same<T, double>::value) {
-    throw_on_error(spmv_hip_convert_f64_f32(hip->context(),
-                                            this->_num_non_zeros, _values,
-                                            _values32, nullptr),
-                   "spmv_hip_convert_f64_f32");
-    // a block that runs the diagonal form keeps an fp32 copy by offset too
-    const int rc = spmv_hip_csr_plan_bake_values_f32f64(
-        hip->context(), _op.plan(), _values32, nullptr);
-    if (rc != SPMV_HIP_ENOTSUP)
-      throw_on_error(rc, "spmv_hip_csr_plan_bake_values_f32f64");
+    float* v32 = this->_exec->template alloc<float>(this->_num_non_zeros);
+    try {
+      throw_on_error(spmv_hip_convert_f64_f32(hip->context(),
+                                              this->_num_non_zeros, _values, v32,
+                                              nullptr),
+                     "spmv_hip_convert_f64_f32");
+      // a block that runs the diagonal form keeps an fp32 copy by offset too
+      const int rc = spmv_hip_csr_plan_bake_values_f32f64(
+          hip->context(), _op.plan(), v32, nullptr);
+      if (rc != SPMV_HIP_ENOTSUP)
+        throw_on_error(rc, "spmv_hip_csr_plan_bake_values_f32f64");
+    } catch (...) { // nothing half-enabled, nothing leaked
+      (void)spmv_hip_csr_plan_bake_values_f32f64(hip->context(), _op.plan(),
+                                                 nullptr, nullptr);
+      this->_exec->free(v32);
+      throw;
+    }
+    _values32 = v32;
   }
 }
 

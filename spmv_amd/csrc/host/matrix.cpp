@@ -587,6 +587,51 @@ Matrix<T>* Matrix<T>::create_poisson3d(std::shared_ptr<const Comm> comm,
   }
 }
 
+template <typename T>
+Matrix<T>* Matrix<T>::create_unstructured(std::shared_ptr<const Comm> comm,
+                                          std::shared_ptr<DeviceExecutor> exec,
+                                          int64_t nrows, int per_row,
+                                          int64_t band, int far_permille,
+                                          uint64_t seed)
+{
+  if constexpr (!std::is_same<T, double>::value) {
+    throw std::runtime_error("create_unstructured is available for double only");
+  } else {
+    auto* hip = dynamic_cast<HipExecutor*>(exec.get());
+    if (!hip)
+      throw std::runtime_error("create_unstructured needs a HipExecutor");
+    if (comm->size() != 1)
+      throw std::runtime_error("create_unstructured: one rank only");
+    if (nrows < 1 || per_row < 1 || nrows * per_row > INT32_MAX)
+      throw std::runtime_error("create_unstructured: size out of range");
+    DeviceBlock b;
+    b.nnz = nrows * per_row;
+    b.rowptr = hip->alloc<int32_t>(nrows + 1);
+    b.colind = hip->alloc<int32_t>(b.nnz);
+    b.values = hip->alloc<double>(b.nnz);
+    throw_on_error(spmv_hip_unstructured_fill_f64(hip->context(), nrows, per_row,
+                                                  band, far_permille, seed,
+                                                  b.rowptr, b.colind, b.values,
+                                                  nullptr),
+                   "spmv_hip_unstructured_fill_f64");
+    const int32_t n32 = static_cast<int32_t>(nrows);
+    auto col_map = std::make_shared<L2GMap>(comm, n32, std::vector<int64_t>(),
+                                            exec);
+    auto row_map = std::make_shared<L2GMap>(comm, n32, std::vector<int64_t>(),
+                                            exec);
+    std::unique_ptr<Matrix<T>> A(new Matrix<T>());
+    A->_exec = exec;
+    A->_col_map = col_map;
+    A->_row_map = row_map;
+    A->_symmetric = false;
+    using Adopt = typename CSRMatrix<T>::AdoptDevice;
+    A->_mat_local.reset(new CSRMatrix<T>(Adopt{}, exec, n32, n32, b.nnz, b.rowptr,
+                                         b.colind, b.values, nullptr, false));
+    A->_nnz = b.nnz;
+    return A.release();
+  }
+}
+
 // ---------------------------------------------------------------------------
 // 3-D block partition of the Poisson matrix
 // ---------------------------------------------------------------------------

@@ -121,6 +121,13 @@ public:
       int32_t n, bool symmetric = false,
       CommunicationModel cm = CommunicationModel::collective_blocking);
 
+  // Seeded unstructured test matrix generated on the device
+  // (spmv_hip_unstructured_fill_f64): one rank only, general storage, ONE
+  // block.  A synthetic input for measurements, like create_poisson3d.
+  static Matrix<T>* create_unstructured(
+      std::shared_ptr<const Comm> comm, std::shared_ptr<DeviceExecutor> exec,
+      int64_t nrows, int per_row, int64_t band, int far_permille, uint64_t seed);
+
   // The same matrix on a 3-D BLOCK partition (the reference has
   // row slabs only): the n^3 grid is cut into px * py * pz boxes (sizes by the
   // even rule per axis), rank = ix + px (iy + py iz) owns one box, and the

@@ -57,6 +57,8 @@ _PROTOS = {
     "spmvh_split_create_dist": [vp, vp, vp, vp, i64, i64, vp, i64, vp, i64,
                                 C.c_int, C.c_int, PTR(vp), PTR(i64)],
     "spmvh_matrix_create_poisson3d": [vp, vp, i32, C.c_int, C.c_int, PTR(vp)],
+    "spmvh_matrix_create_unstructured": [vp, vp, i64, C.c_int, i64, C.c_int,
+                                         C.c_uint64, PTR(vp)],
     "spmvh_matrix_create_poisson3d_boxes": [vp, vp, i32, C.c_int, C.c_int,
                                             C.c_int, C.c_int, C.c_int, PTR(vp)],
     "spmvh_poisson3d_box_rows": [i32, C.c_int, C.c_int, C.c_int, C.c_int, vp,
@@ -368,6 +370,16 @@ class Matrix:
         h = vp()
         call("spmvh_matrix_create_poisson3d", comm.h, exec_.h, n,
              int(symmetric), cm, C.byref(h))
+        return cls(h)
+
+    @classmethod
+    def create_unstructured(cls, comm, exec_, nrows, per_row=7, band=2048,
+                            far_permille=100, seed=0x5EED0003):
+        """Seeded unstructured test matrix, generated on the device (one rank;
+        numpy twin: spmv_amd.poisson.unstructured_csr)."""
+        h = vp()
+        call("spmvh_matrix_create_unstructured", comm.h, exec_.h, int(nrows),
+             int(per_row), int(band), int(far_permille), int(seed), C.byref(h))
         return cls(h)
 
     @classmethod

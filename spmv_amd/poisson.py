@@ -1,4 +1,5 @@
-"""Host-side 3-D 7-point Poisson generator (numpy).
+"""Host-side generators of the synthetic inputs (numpy): the 3-D 7-point
+Poisson matrix, the 27-point operator, a seeded unstructured matrix.
 
 Not in the reference (demos/CreateA.cpp is a 1-D
 tridiagonal generator); this is the build's own synthetic input, used for the
@@ -28,6 +29,78 @@ def poisson3d_csr(n, row_begin=0, row_end=None, dtype=np.float64):
     if rowptr[-1] > np.iinfo(np.int32).max:
         raise OverflowError("nnz exceeds the int32 row pointer of the format")
     return rowptr.astype(np.int32), cols, np.ascontiguousarray(vals)
+
+
+def stencil27_csr(n, dtype=np.float64):
+    """The 27-point operator on the same grid (all neighbours with |dx|, |dy|,
+    |dz| <= 1; diagonal 26, off-diagonal -1: HPCG's matrix), columns ascending
+    within a row -- the host twin of the device generator with the context
+    option "poisson_stencil" = 27.  Returns (rowptr int32, colind int64,
+    values)."""
+    assert n >= 3
+    N = n ** 3
+    i = np.arange(N, dtype=np.int64)
+    x, y, z = i % n, (i // n) % n, i // (n * n)
+    offs, valid = [], []
+    for dz in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                offs.append(dz * n * n + dy * n + dx)
+                valid.append((x + dx >= 0) & (x + dx < n) & (y + dy >= 0)
+                             & (y + dy < n) & (z + dz >= 0) & (z + dz < n))
+    offs = np.array(offs, dtype=np.int64)
+    valid = np.stack(valid, axis=1)
+    cols = (i[:, None] + offs[None, :])[valid]
+    vals = np.broadcast_to(np.where(offs == 0, 26.0, -1.0).astype(dtype),
+                           valid.shape)[valid]
+    rowptr = np.zeros(N + 1, np.int64)
+    np.cumsum(valid.sum(axis=1), out=rowptr[1:])
+    if rowptr[-1] > np.iinfo(np.int32).max:
+        raise OverflowError("nnz exceeds the int32 row pointer of the format")
+    return rowptr.astype(np.int32), cols, np.ascontiguousarray(vals)
+
+
+def stencil27_nnz(n):
+    return (3 * n - 2) ** 3
+
+
+def _mix64(z):
+    """splitmix64 finaliser on uint64 arrays (wrapping arithmetic)"""
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def unstructured_csr(nrows, per_row=7, band=2048, far_permille=100,
+                     seed=0x5EED0003):
+    """The seeded unstructured test matrix: numpy twin of the device generator
+    spmv_hip_unstructured_fill_f64 (same hash, same columns, same values).
+    Square, `per_row` entries per row; far_permille / 1000 of them anywhere, the
+    rest within `band` columns of the diagonal; columns ascending within a row
+    (repeats are kept: legal CSR, the reference loop just adds them), values
+    uniform in [-1, 1).  No row block has constant column offsets and its
+    column windows are mostly too wide to stage in LDS -- the shape of a badly
+    ordered FEM matrix.  Returns (rowptr int32, colind int32, values)."""
+    N = int(nrows)
+    if N * per_row > np.iinfo(np.int32).max:
+        raise OverflowError("nnz exceeds the int32 row pointer of the format")
+    golden = np.uint64(0x9E3779B97F4A7C15)
+    with np.errstate(over="ignore"):
+        e1 = (np.arange(N * per_row, dtype=np.uint64) + np.uint64(1)) * golden
+        h = _mix64(e1 + np.uint64(seed))
+        far = (h % np.uint64(1000)).astype(np.int64) < far_permille
+        r = h >> np.uint64(10)
+        i = np.repeat(np.arange(N, dtype=np.int64), per_row)
+        near = i - band + (r % np.uint64(2 * band + 1)).astype(np.int64)
+        cols = np.where(far, (r % np.uint64(N)).astype(np.int64), near)
+        del h, r, near, far, i
+        np.clip(cols, 0, N - 1, out=cols)
+        cols = cols.astype(np.int32).reshape(N, per_row)
+        cols.sort(axis=1)
+        h2 = _mix64(e1 + np.uint64(seed + 1))
+        vals = (h2 >> np.uint64(11)).astype(np.float64) * (2.0 / 9007199254740992.0) - 1.0
+    rowptr = (np.arange(N + 1, dtype=np.int64) * per_row).astype(np.int32)
+    return rowptr, cols.reshape(-1), vals
 
 
 def poisson3d_nnz(n):

@@ -408,6 +408,28 @@ def test_device_poisson_matches_host(ctx, n, P):
     blk.free()
 
 
+def test_unstructured_generator_matches_numpy_twin(ctx):
+    """spmv_hip_unstructured_fill_f64 (the benchmark's matrix without lattice
+    structure) against spmv_amd.poisson.unstructured_csr: same arrays."""
+    for N, per_row, band, far in ((1, 1, 0, 0), (777, 5, 16, 500),
+                                  (50_000, 7, 2048, 100), (3000, 32, 100, 1000)):
+        rp, ci, va = poisson.unstructured_csr(N, per_row, band, far, seed=99 + N)
+        d_rp = ctx.empty(N + 1, np.int32)
+        d_ci = ctx.empty(N * per_row, np.int32)
+        d_va = ctx.empty(N * per_row, np.float64)
+        hip.call("spmv_hip_unstructured_fill_f64", ctx.h, N, per_row, band, far,
+                 99 + N, d_rp.ptr, d_ci.ptr, d_va.ptr, None)
+        assert np.array_equal(d_rp.numpy(), rp)
+        assert np.array_equal(d_ci.numpy(), ci)
+        assert np.array_equal(d_va.numpy(), va)
+        assert np.all(np.diff(ci.reshape(N, per_row), axis=1) >= 0)
+        for b in (d_rp, d_ci, d_va):
+            b.free()
+    with pytest.raises(Exception):
+        hip.call("spmv_hip_unstructured_fill_f64", ctx.h, 10, 33, 5, 0, 1, 1, 1,
+                 1, None)
+
+
 # ---------------------------------------------------------------------------
 # CG building blocks: drive the kernels exactly as spmv::cg does and compare
 # with the oracle's CG (cg.cpp:21-98)
@@ -445,8 +467,20 @@ def gpu_cg(ctx, blk, b, kmax, rtol, fused_dot=True, regrouped=False):
                      None)
     flags = np.zeros(2, np.int32)
     rr = np.zeros(kmax + 1)
+    # a destination shorter than the device history is refused at the boundary
+    # (ABI 2), and nothing is written
+    short = np.full(kmax, -7.0)
+    with pytest.raises(Exception):
+        hip.call("spmv_hip_cg_ws_read_async", ws,
+                 flags.ctypes.data_as(C.c_void_p),
+                 short.ctypes.data_as(C.c_void_p), kmax, None)
+    ctx.stream_sync()
+    assert np.all(short == -7.0)
+    cap = C.c_int()
+    hip.call("spmv_hip_cg_ws_capacity", ws, C.byref(cap))
+    assert cap.value == kmax
     hip.call("spmv_hip_cg_ws_read_async", ws, flags.ctypes.data_as(C.c_void_p),
-             rr.ctypes.data_as(C.c_void_p), None)
+             rr.ctypes.data_as(C.c_void_p), kmax + 1, None)
     ctx.stream_sync()
     xs = x.numpy()
     hip.call("spmv_hip_cg_ws_destroy", ws)
@@ -1566,6 +1600,94 @@ def test_mixed_precision_spmv_bit_exact(lat_ctx):
         for b in (d32, dx, part):
             b.free()
         blk.free()
+
+
+def test_mixed_precision_vector_and_scalar_plans(ctx):
+    """A general plan with long rows takes the VECTOR kernel (AUTO above 64
+    entries per row); spmv_f32f64 must run on it -- and on SCALAR -- instead of
+    returning ENOTSUP (CgOptions::mixed on e.g. a 3-D elasticity matrix)."""
+    rng = np.random.default_rng(131)
+    nrows, ncols = 2000, 2300
+    rp, ci, _ = random_csr(rng, nrows, ncols, 90)
+    va = rng.uniform(-1, 1, len(ci))
+    va32 = va.astype(np.float32)
+    x = rng.uniform(-1, 1, ncols)
+    y0 = rng.uniform(-1, 1, nrows)
+    for algo in (hip.ALGO_AUTO, hip.ALGO_VECTOR, hip.ALGO_SCALAR):
+        blk = hip.CsrBlock(ctx, nrows, ncols, rp, ci, va, None, False, algo)
+        if algo == hip.ALGO_AUTO:
+            assert blk.algo == hip.ALGO_VECTOR
+        d32, dx = ctx.upload(va32, np.float32), ctx.upload(x)
+        for alpha, beta in ((1.0, 0.0), (-0.5, 0.75)):
+            y_ref = oracle.csr_spmv(rp, ci, va32.astype(np.float64), x, alpha,
+                                    beta, y0)
+            dy = ctx.upload(np.full(nrows, np.nan) if beta == 0 else y0)
+            hip.call("spmv_hip_csr_spmv_f32f64", ctx.h, blk.plan, nrows, ncols,
+                     blk.nnz, blk.rowptr.ptr, blk.colind.ptr, d32.ptr,
+                     float(alpha), dx.ptr, float(beta), dy.ptr, None, None)
+            y = dy.numpy()
+            if blk.algo == hip.ALGO_SCALAR:
+                assert np.array_equal(y, y_ref), (algo, alpha, beta)
+            else:  # another summation order
+                bound = (16 + np.diff(rp)) * U * abs_bound(
+                    rp, ci, va32.astype(np.float64), x, alpha, beta, y0)
+                assert np.all(np.abs(y - y_ref) <= bound + 1e-300), (algo, alpha)
+            dy.free()
+        for b in (d32, dx):
+            b.free()
+        blk.free()
+
+
+def test_bake_that_does_not_apply_leaves_the_plan_as_it_was(lat_ctx):
+    """plan_bake_values on a plan that cannot take the diagonal form returns
+    ENOTSUP and changes NOTHING -- in particular the plane-walk table that plan
+    creation built for the CSR-order lattice kernel stays (it was dropped
+    once); after a successful bake is dropped again, the table is the lattice
+    kernel's again."""
+    ctx = lat_ctx
+    rng = np.random.default_rng(7)
+    n = 40  # planes of 1600 rows; a table for so small a lattice needs forcing
+    N = n ** 3
+    # 8 offsets, 4 of them lower: lattice form yes, diagonal form no (> 3)
+    offs = [-n * n, -n, -2, -1, 0, 1, n, n * n]
+    rp, ci, va = _stencil_csr(rng, N, offs)
+    x = rng.uniform(-1, 1, N)
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    blk = hip.CsrBlock(ctx, N, N, rp, ci, va, None, False, hip.ALGO_ROWBLOCK)
+    assert blk.get("lat") == 1
+    blk.set("zwalk_segments", 2)  # force a table
+    before = (blk.get("zwalk"), blk.get("zwalk_grid"), blk.get("zwalk_segments"))
+    assert before[0] == 1 and before[1] > 0
+    with pytest.raises(Exception):
+        blk.bake()
+    assert blk.get("sdia") == 0
+    assert (blk.get("zwalk"), blk.get("zwalk_grid"),
+            blk.get("zwalk_segments")) == before
+    dx, dy = ctx.upload(x), ctx.upload(np.full(N, np.nan))
+    blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+    assert np.array_equal(dy.numpy(), y_ref)
+    blk.free()
+    # a matrix that CAN be baked: bake, then drop -> the lattice kernel's table
+    rp, ci, va = poisson.poisson3d_csr(n)
+    ci = ci.astype(np.int32)
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    blk = hip.CsrBlock(ctx, N, N, rp, ci, va, None, False, hip.ALGO_ROWBLOCK)
+    blk.set("zwalk_segments", 2)
+    lat_grid = blk.get("zwalk_grid")
+    blk.bake()
+    assert blk.get("sdia") == 1
+    blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+    assert np.array_equal(dy.numpy(), y_ref)
+    blk.bake(drop=True)
+    assert blk.get("sdia") == 0
+    # the restored table is the unforced choice for this small lattice (none)
+    # or the lattice kernel's -- never the diagonal form's
+    assert blk.get("zwalk_grid") in (0, lat_grid)
+    blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+    assert np.array_equal(dy.numpy(), y_ref)
+    for b in (dx, dy):
+        b.free()
+    blk.free()
 
 
 def test_mixed_precision_on_the_diagonal_form_bit_exact(lat_ctx):
