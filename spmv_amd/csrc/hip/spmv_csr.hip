@@ -245,8 +245,13 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_lx_kernel(
   const int t = threadIdx.x;
   double dot_acc = 0.0;
   const int num_slots = order_slots(ord);
+  // with an order table the entry of the NEXT slot is requested a whole row
+  // block ahead: a look-up that has to be waited for stalls the workgroup at
+  // the top of every block
+  int rb_raw = order_slot_raw(ord, blockIdx.x, num_slots);
   for (int it = blockIdx.x; it < num_slots; it += gridDim.x) {
-    const int rb = order_row_block(ord, it);
+    const int rb = order_slot_decode(ord, rb_raw);
+    rb_raw = order_slot_raw(ord, it + gridDim.x, num_slots);
     if (rb < 0)
       continue; // uniform per workgroup
     const int32_t r0 = rb * kRows;
@@ -646,11 +651,8 @@ int launch_rowblock_x(const spmv_hip_csr_plan* pl, hipStream_t st, int grid,
   return SPMV_HIP_OK;
 }
 
-template <typename T, bool DOT>
-int launch_rowblock(const spmv_hip_csr_plan* pl, hipStream_t st,
-                    const int32_t* rowptr, const int32_t* colind,
-                    const T* values, T alpha, const T* in, T beta, T* out,
-                    DotOut dot)
+// launch grid of the row-block kernels (plain and LX)
+int rowblock_grid(const spmv_hip_csr_plan* pl)
 {
   const int nrb = (pl->num_rows + kRows - 1) / kRows;
   int grid = pl->ctx->num_cus * pl->blocks_per_cu;
@@ -663,6 +665,17 @@ int launch_rowblock(const spmv_hip_csr_plan* pl, hipStream_t st,
   // slots it with equal it % 8 must stay on one XCD (XCD groups)
   if (grid >= 8)
     grid -= grid % 8;
+  return grid;
+}
+
+template <typename T, bool DOT>
+int launch_rowblock(const spmv_hip_csr_plan* pl, hipStream_t st,
+                    const int32_t* rowptr, const int32_t* colind,
+                    const T* values, T alpha, const T* in, T beta, T* out,
+                    DotOut dot)
+{
+  const int nrb = (pl->num_rows + kRows - 1) / kRows;
+  const int grid = rowblock_grid(pl);
   const bool al = aligned16(values) && aligned16(colind);
   // the plan's own copy of a symmetric matrix's lower half (spmv_symdia.hip)
   if (pl->sdia && pl->sdia_val && pl->sdia_general
@@ -682,11 +695,16 @@ int launch_rowblock(const spmv_hip_csr_plan* pl, hipStream_t st,
   }
   if (pl->lx && al && aligned16(in)) {
     LxView lx{pl->lx_lidx, pl->lx_tab};
+    RowBlockOrder lx_ord = pl->row_block_order(nrb);
+    if (pl->zwalk && pl->zw_table && pl->zw_grid == grid) {
+      lx_ord.table = pl->zw_table; // plane-walk order (build_lx)
+      lx_ord.num_slots = pl->zw_slots;
+    }
 #define SPMV_LX(NT, CH)                                                        \
   hipLaunchKernelGGL((csr_rowblock_lx_kernel<T, NT, DOT, CH>), dim3(grid),     \
                      dim3(kBlock), 0, st, pl->num_rows, pl->num_cols, pl->nnz, \
                      rowptr, colind, values, lx, alpha, in, beta, out, dot,    \
-                     pl->row_block_order(nrb))
+                     lx_ord)
     if (pl->nontemporal) {
       if (pl->lx_chunks == 2)
         SPMV_LX(true, 2);
@@ -945,6 +963,32 @@ int build_lx(spmv_hip_csr_plan* pl, const int32_t* rowptr,
   // Cache (216^3: 0.170 vs 0.176 ms), but 1.3-1.8 % slower than the plain
   // order once it does not (512^3)
   pl->xcd_group = pl->nontemporal ? 16 : 0;
+  // Far column windows at a constant distance (the matrix of a 3-D grid whose
+  // values or boundary rows keep it out of the lattice form): walk the row
+  // blocks plane by plane, so that the far windows of a block are the ones
+  // its workgroup -- or a neighbour on the same XCD -- staged one step before.
+  int32_t rec[kLxRec];
+  if (hipMemcpy(rec, pl->lx_tab + (size_t)(nrb / 2) * kLxRec, sizeof(rec),
+                hipMemcpyDeviceToHost)
+          == hipSuccess
+      && rec[0] >= 3) {
+    const int64_t r0 = (int64_t)(nrb / 2) * kRows;
+    int64_t pos[kLxMaxWin];
+    int np = 0;
+    for (int k = 0; k < rec[0]; ++k)
+      if (rec[1 + k] - r0 > kLxGap)
+        pos[np++] = rec[1 + k] - r0; // window starts ascend
+    // line distance = the nearest far window, plane distance = the farthest
+    if (np >= 2 && pos[0] >= 8 && pos[np - 1] % pos[0] == 0
+        && pos[np - 1] / pos[0] >= 16) {
+      pl->lattice_d1 = (int)pos[0];
+      pl->lattice_d2 = (int)pos[np - 1];
+      const int rc = spmv_zwalk_order_build(pl, pl->lattice_d2,
+                                            rowblock_grid(pl), 0, false);
+      if (rc != SPMV_HIP_OK)
+        return rc;
+    }
+  }
   return SPMV_HIP_OK;
 }
 
@@ -1009,7 +1053,9 @@ int spmv_walk_grid(const spmv_hip_csr_plan* pl)
 {
   if (pl->sdia && pl->sdia_val)
     return spmv_sdia_grid(pl);
-  return pl->symmetric ? spmv_slat_grid(pl) : spmv_lat_grid(pl);
+  if (pl->symmetric)
+    return spmv_slat_grid(pl);
+  return pl->lat_tab ? spmv_lat_grid(pl) : rowblock_grid(pl);
 }
 
 void spmv_zwalk_free(spmv_hip_csr_plan* pl)
@@ -1313,6 +1359,9 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
   } else if (!strcmp(key, "blocks_per_cu")) {
     SPMV_REQUIRE(value >= 1 && value <= kBlocksPerCU);
     plan->blocks_per_cu = value;
+    if (plan->zw_table && plan->lx_lidx && !plan->lat_tab) // tied to the grid
+      return spmv_zwalk_order_build(plan, plan->zw_d2, spmv_walk_grid(plan), 0,
+                                    true);
   } else if (!strcmp(key, "lx")) {
     // 1 needs the LX form built at plan creation (or by "lx_build")
     SPMV_REQUIRE(value == 0 || plan->lx_lidx);
@@ -1354,7 +1403,8 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
   } else if (!strcmp(key, "zwalk_segments")) {
     // (re)build the plane-walk table of the plan's lattice kernel with `value`
     // runs along the plane axis (0 = choose), whatever the size
-    SPMV_REQUIRE(value >= 0 && (plan->slat_mask || plan->lat_tab)
+    SPMV_REQUIRE(value >= 0
+                 && (plan->slat_mask || plan->lat_tab || plan->lx_lidx)
                  && plan->zw_d2 > 0);
     return spmv_zwalk_order_build(plan, plan->zw_d2, spmv_walk_grid(plan), value,
                                   true);

@@ -30,12 +30,20 @@ def main():
                     help="general storage: let the plan find the matrix symmetric")
     ap.add_argument("--asym", action="store_true",
                     help="general storage, made non-symmetric: the FULL diagonal form")
+    ap.add_argument("--no-lat", action="store_true",
+                    help="no lattice analysis: the LX form")
+    ap.add_argument("--no-lx", action="store_true",
+                    help="... nor the LX form: the plain row-block kernel")
     ap.add_argument("--out", default=None)
     ap.add_argument("--calib", action="store_true",
                     help="also time plain streaming kernels on this box")
     args = ap.parse_args()
     ctx = hip.Context(0)
     ctx.set_option("lx_max_x_bytes", 1 << 62)  # build the LX form at any size
+    if args.no_lat or args.no_lx:
+        ctx.set_option("lat_min_nnz", 1 << 62)
+    if args.no_lx:
+        ctx.set_option("lx_min_nnz", 1 << 62)
     n, N = args.n, args.n ** 3
     if args.symmetric:
         blk = hip.poisson3d_block(ctx, n, 0, N, hip.PART_LOCAL_LOWER,

@@ -18,7 +18,8 @@ declare -A CGROUPS=(
   [sq]="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"
   [tcp]="TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum"
 )
-for g in fetch write ea tcc sq tcp; do
+# PMC_GROUPS="ea write" runs a subset of the passes
+for g in ${PMC_GROUPS:-fetch write ea tcc sq tcp}; do
   rm -rf "/tmp/pmc_${TAG}_$g"
   rocprofv3 --pmc ${CGROUPS[$g]} --kernel-trace --output-format csv \
       -d "/tmp/pmc_${TAG}_$g" -o p -- python3 "$ROOT/tools/prof_spmv.py" "$@" \
