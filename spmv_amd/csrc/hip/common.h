@@ -22,6 +22,10 @@ struct spmv_hip_ctx {
   // ... and only while x (num_cols * 8 bytes) is at most this large
   // ("lx_max_x_bytes"; no limit by default)
   int64_t lx_max_x_bytes = INT64_MAX;
+  // ... in the layout of the LDS-DMA kernel (spmv_lxw.hip: values, offsets and
+  // x windows by LDS-DMA one row block ahead; "lx_dma", 0 = the register-staged
+  // kernel's layout)
+  int lx_dma = 1;
   // plans try the lattice form (constant column offsets per row block, no
   // index stream) for general matrices with at least this many entries
   // ("lat_min_nnz")

@@ -112,6 +112,22 @@ __device__ __forceinline__ int order_slot_decode(const RowBlockOrder& ord,
 }
 #endif
 
+// LX form (spmv_csr.hip: register-staged kernel; spmv_lxw.hip: LDS-DMA kernel)
+constexpr int kLxMaxWin = 16;
+constexpr int kLxRec = 36;   // ints per row-block record (1 + 16 + 17, padded)
+constexpr int kLxCap = 1344; // staged x elements per row block (10.5 KiB fp64)
+constexpr int kLxGap = 16;   // columns closer than this share a window
+// ... the DMA kernel's own record (one per row block):
+//   [0] number of windows, or -1 = direct (global gather)
+//   [1] first entry of the block's span in `values`   [2] its entry count
+//   [3] number of staged pieces
+//   [kLxwPieces0 + p]  first column of piece p (kLxwPiece elements each)
+constexpr int kLxwPiece = 128;     // staged elements per piece
+constexpr int kLxwMaxPieces = 16;  // 2048 staged elements (16 KiB fp64)
+constexpr int kLxwPieces0 = 4;
+constexpr int kLxwRec = 20;        // ints per record (4 + 16)
+constexpr int kLxwAlign = 4;       // window starts: multiples of 4 columns
+
 template <typename T>
 static inline bool aligned16(const T* p)
 {
@@ -200,7 +216,7 @@ struct spmv_hip_csr_plan {
   const int32_t* colind0 = nullptr;
   bool structure_baked() const
   {
-    return row_list || lx_lidx || lat_tab || slat_mask || t_ptr;
+    return row_list || lx_lidx || lat_tab || slat_mask || t_ptr || lxw_rec;
   }
   // ROWBLOCK "LX" form: LDS-staged x windows + 16-bit local column indices
   // (csr_rowblock_lx_kernel); built by plan_create when most row blocks qualify
@@ -211,6 +227,15 @@ struct spmv_hip_csr_plan {
                          // 2 = half the barriers, measured +7-8 % at every size
   int lx_staged = 0;     // row blocks that take the staged path
   int lx_blocks = 0;     // row blocks analysed
+  // ... and its LDS-DMA kernel (spmv_lxw.hip): values, 16-bit offsets and x
+  // windows arrive by LDS-DMA one row block ahead; built when the context
+  // option "lx_dma" is on (the staged layout differs: windows padded to whole
+  // DMA pieces)
+  int32_t* lxw_rec = nullptr; // kLxwRec ints per row block
+  int lxw = 0;                // use it (plan_set "lxw")
+  int lxw_max_cnt = 0;        // most entries in a staged row block
+  int lxw_max_pieces = 0;     // most staged pieces of a row block
+  int lxw_blocks_per_cu = 0;  // 0 = what the LDS footprint allows
   // Lattice form (spmv_lat.hip): every row block's columns are row + one of
   // <= 8 constant offsets => no index stream, values arrive by LDS-DMA
   int32_t* lat_tab = nullptr;  // kLatRec ints per row block: count, offsets
@@ -301,6 +326,16 @@ int spmv_sdia_run_f64(const spmv_hip_csr_plan* pl, hipStream_t st, double alpha,
                       const double* in, double beta, double* out, DotOut dot);
 int spmv_sdia_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st, float alpha,
                       const float* in, float beta, float* out);
+// spmv_lxw.hip
+int spmv_lxw_grid(const spmv_hip_csr_plan* pl, int elem_bytes);
+int spmv_lxw_run_f64(const spmv_hip_csr_plan* pl, hipStream_t st,
+                     const int32_t* rowptr, const int32_t* colind,
+                     const double* values, double alpha, const double* in,
+                     double beta, double* out, DotOut dot);
+int spmv_lxw_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st,
+                     const int32_t* rowptr, const int32_t* colind,
+                     const float* values, float alpha, const float* in,
+                     float beta, float* out);
 // spmv_lat.hip
 int spmv_lat_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
                    const int32_t* colind);

@@ -105,6 +105,11 @@ int spmv_hip_ctx_set_option(spmv_hip_ctx* ctx, const char* key, int64_t value)
     ctx->poisson_skew_ppm = (int)value;
     return SPMV_HIP_OK;
   }
+  if (!strcmp(key, "lx_dma")) {
+    SPMV_REQUIRE(value == 0 || value == 1);
+    ctx->lx_dma = (int)value;
+    return SPMV_HIP_OK;
+  }
   if (!strcmp(key, "poisson_stencil")) {
     SPMV_REQUIRE(value == 7 || value == 27);
     ctx->poisson_stencil = (int)value;

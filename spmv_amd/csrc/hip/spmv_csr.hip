@@ -210,10 +210,6 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_kernel(
 // One record per row block, fetched unconditionally next to the row pointer:
 // nothing in the block's prologue depends on an earlier load.
 // ---------------------------------------------------------------------------
-constexpr int kLxMaxWin = 16;
-constexpr int kLxRec = 36;   // ints per row-block record (1 + 16 + 17, padded)
-constexpr int kLxCap = 1344; // staged x elements per row block (10.5 KiB fp64)
-constexpr int kLxGap = 16;   // columns closer than this share a window
 
 struct LxView {
   const uint16_t* lidx;
@@ -415,16 +411,24 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_lx_kernel(
     spmv_dot_epilogue(dot, dot_acc, s_red);
 }
 
-// Plan-time analysis for the LX kernel: one workgroup per row block sorts the
+// Plan-time analysis for the LX kernels: one workgroup per row block sorts the
 // block's column indices, cuts them into windows (gap > kLxGap), and writes the
 // windows and every entry's offset into the staged buffer.  Blocks with more
-// than 256*ITEMS entries, more than kLxMaxWin windows or more than kLxCap
+// than 256*ITEMS entries, more than kLxMaxWin windows or more than `cap`
 // staged elements are marked direct (nwin = -1).
+//   align   window starts are multiples of this many columns (2: the register
+//           kernel's pair loads; 4: 16-byte LDS-DMA chunks of fp64 AND fp32 x)
+//   pad     every window occupies a multiple of this many staged elements
+//           (2, or kLxwPiece = whole DMA pieces)
+//   wrec    != nullptr: also the record of the DMA kernel (spmv_lxw.hip):
+//           span, piece list; stat[0] / stat[1] collect the largest entry count
+//           and piece count of a staged block
 template <int ITEMS>
 __global__ __launch_bounds__(kBlock) void lx_build_kernel(
-    int32_t num_rows, const int32_t* __restrict__ rowptr,
+    int32_t num_rows, int32_t num_cols, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ colind, uint16_t* __restrict__ lidx,
-    int32_t* __restrict__ tab, int num_row_blocks, int end_bit)
+    int32_t* __restrict__ tab, int num_row_blocks, int end_bit, int align,
+    int pad, int cap, int32_t* __restrict__ wrec, int32_t* __restrict__ stat)
 {
   using Sort = hipcub::BlockRadixSort<int32_t, kBlock, ITEMS, int32_t>;
   using Scan = hipcub::BlockScan<int32_t, kBlock>;
@@ -437,12 +441,21 @@ __global__ __launch_bounds__(kBlock) void lx_build_kernel(
   __shared__ int32_t s_ws[kLxMaxWin], s_we[kLxMaxWin], s_wo[kLxMaxWin + 1];
   __shared__ int s_direct;
   const int t = threadIdx.x;
+  // columns from here on cannot be fetched as whole aligned 16-byte chunks
+  const int32_t col_limit = wrec ? (num_cols & ~(align - 1)) : INT32_MAX;
   for (int rb = blockIdx.x; rb < num_row_blocks; rb += gridDim.x) {
     const int32_t r0 = rb * kRows;
     const int nr = min(kRows, num_rows - r0);
     const int32_t a = rowptr[r0], b = rowptr[r0 + nr];
     const int cnt = b - a;
+    int32_t* wr = wrec ? wrec + (int64_t)rb * kLxwRec : nullptr;
     __syncthreads(); // previous block done with the shared arrays
+    if (wr && t == 0) {
+      wr[0] = -1; // direct unless the analysis below succeeds
+      wr[1] = a;
+      wr[2] = cnt;
+      wr[3] = 0;
+    }
     if (cnt > CAP) {
       if (t == 0)
         tab[(int64_t)rb * kLxRec] = -1;
@@ -472,21 +485,22 @@ __global__ __launch_bounds__(kBlock) void lx_build_kernel(
     }
     int32_t total_windows = 0;
     Scan(tmp.scan).InclusiveSum(flag, wid, total_windows);
-    if (total_windows > kLxMaxWin) {
+    if (total_windows > kLxMaxWin
+        || (cnt > 0 && s_key[cnt - 1] >= col_limit)) {
       if (t == 0)
         tab[(int64_t)rb * kLxRec] = -1;
-      continue; // uniform (block-wide aggregate)
+      continue; // uniform (block-wide aggregate / shared value)
     }
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
       const int idx = t * ITEMS + i;
       if (idx < cnt) {
         if (flag[i])
-          s_ws[wid[i] - 1] = key[i] & ~1;
+          s_ws[wid[i] - 1] = key[i] & ~(align - 1);
         // last entry of its window: end of data or the next key starts one
         const bool last = idx == cnt - 1 || s_key[idx + 1] - key[i] > kLxGap;
         if (last)
-          s_we[wid[i] - 1] = (key[i] + 2) & ~1;
+          s_we[wid[i] - 1] = (key[i] + align) & ~(align - 1);
       }
     }
     __syncthreads();
@@ -494,10 +508,10 @@ __global__ __launch_bounds__(kBlock) void lx_build_kernel(
       int off = 0;
       for (int k = 0; k < total_windows; ++k) {
         s_wo[k] = off;
-        off += s_we[k] - s_ws[k];
+        off += (s_we[k] - s_ws[k] + pad - 1) & ~(pad - 1);
       }
       s_wo[total_windows] = off;
-      if (off > kLxCap)
+      if (off > cap)
         s_direct = 1;
     }
     __syncthreads();
@@ -520,6 +534,18 @@ __global__ __launch_bounds__(kBlock) void lx_build_kernel(
       rec[1 + kLxMaxWin + t] = s_wo[t];
     if (t == 0)
       rec[0] = total_windows;
+    if (wr && t == 0) {
+      // the staged buffer as DMA pieces of kLxwPiece elements: source column
+      // of each (pad == kLxwPiece: windows start at piece boundaries)
+      int np = 0;
+      for (int k = 0; k < total_windows; ++k)
+        for (int c = s_ws[k]; c < s_we[k]; c += kLxwPiece)
+          wr[kLxwPieces0 + np++] = c;
+      wr[0] = total_windows;
+      wr[3] = np; // = s_wo[total_windows] / kLxwPiece <= cap / kLxwPiece
+      atomicMax(&stat[0], cnt);
+      atomicMax(&stat[1], np);
+    }
   }
 }
 
@@ -692,6 +718,14 @@ int launch_rowblock(const spmv_hip_csr_plan* pl, hipStream_t st,
                               DOT ? dot : DotOut());
     else
       return spmv_lat_run_f32(pl, st, rowptr, values, alpha, in, beta, out);
+  }
+  if (pl->lx && pl->lxw && pl->lxw_rec && al && aligned16(in)) {
+    if constexpr (sizeof(T) == 8)
+      return spmv_lxw_run_f64(pl, st, rowptr, colind, values, alpha, in, beta,
+                              out, DOT ? dot : DotOut());
+    else
+      return spmv_lxw_run_f32(pl, st, rowptr, colind, values, alpha, in, beta,
+                              out);
   }
   if (pl->lx && al && aligned16(in)) {
     LxView lx{pl->lx_lidx, pl->lx_tab};
@@ -872,9 +906,12 @@ void free_lx(spmv_hip_csr_plan* pl)
 {
   (void)hipFree(pl->lx_lidx);
   (void)hipFree(pl->lx_tab);
+  (void)hipFree(pl->lxw_rec);
   pl->lx_lidx = nullptr;
   pl->lx_tab = nullptr;
+  pl->lxw_rec = nullptr;
   pl->lx = pl->lx_staged = pl->lx_blocks = 0;
+  pl->lxw = pl->lxw_max_cnt = pl->lxw_max_pieces = 0;
 }
 
 struct IsStagedRecord {
@@ -907,6 +944,25 @@ int build_lx(spmv_hip_csr_plan* pl, const int32_t* rowptr,
     free_lx(pl);
     return e == hipErrorOutOfMemory ? SPMV_HIP_OK : static_cast<int>(e);
   }
+  // The LDS-DMA kernel's layout (windows padded to whole DMA pieces) when the
+  // context asks for it and the matrix has at least one aligned chunk of x
+  const bool dma = pl->ctx->lx_dma && pl->num_cols >= kLxwAlign;
+  int32_t* d_stat = nullptr;
+  if (dma) {
+    e = hipMalloc(&pl->lxw_rec, sizeof(int32_t) * (size_t)nrb * kLxwRec);
+    if (e == hipSuccess)
+      e = hipMalloc(&d_stat, 2 * sizeof(int32_t));
+    if (e == hipSuccess)
+      e = hipMemsetAsync(d_stat, 0, 2 * sizeof(int32_t), st);
+    if (e != hipSuccess) {
+      (void)hipFree(d_stat);
+      free_lx(pl);
+      return e == hipErrorOutOfMemory ? SPMV_HIP_OK : static_cast<int>(e);
+    }
+  }
+  const int align = dma ? kLxwAlign : 2;
+  const int pad = dma ? kLxwPiece : 2;
+  const int cap = dma ? kLxwMaxPieces * kLxwPiece : kLxCap;
   int end_bit = 1;
   while (end_bit < 31 && ((int64_t)1 << end_bit) < pl->num_cols)
     ++end_bit;
@@ -915,13 +971,18 @@ int build_lx(spmv_hip_csr_plan* pl, const int32_t* rowptr,
   const double avg = (double)pl->nnz / pl->num_rows;
   if (avg <= 6.0)
     hipLaunchKernelGGL(lx_build_kernel<8>, dim3(grid), dim3(kBlock), 0, st,
-                       pl->num_rows, rowptr, colind, pl->lx_lidx, pl->lx_tab, nrb,
-                       end_bit);
+                       pl->num_rows, pl->num_cols, rowptr, colind, pl->lx_lidx,
+                       pl->lx_tab, nrb, end_bit, align, pad, cap, pl->lxw_rec,
+                       d_stat);
   else
     hipLaunchKernelGGL(lx_build_kernel<16>, dim3(grid), dim3(kBlock), 0, st,
-                       pl->num_rows, rowptr, colind, pl->lx_lidx, pl->lx_tab, nrb,
-                       end_bit);
+                       pl->num_rows, pl->num_cols, rowptr, colind, pl->lx_lidx,
+                       pl->lx_tab, nrb, end_bit, align, pad, cap, pl->lxw_rec,
+                       d_stat);
   e = hipGetLastError();
+  int32_t h_stat[2] = {0, 0};
+  if (dma && e == hipSuccess)
+    e = hipMemcpyAsync(h_stat, d_stat, sizeof(h_stat), hipMemcpyDeviceToHost, st);
   // how many row blocks are staged?
   int32_t* d_count = nullptr;
   void* tmp = nullptr;
@@ -947,18 +1008,22 @@ int build_lx(spmv_hip_csr_plan* pl, const int32_t* rowptr,
     e = hipStreamSynchronize(st);
   (void)hipFree(tmp);
   (void)hipFree(d_count);
+  (void)hipFree(d_stat);
   if (e != hipSuccess) {
     free_lx(pl);
     return static_cast<int>(e);
   }
   pl->lx_blocks = nrb;
   pl->lx_staged = staged;
+  pl->lxw_max_cnt = h_stat[0];
+  pl->lxw_max_pieces = h_stat[1];
   if ((int64_t)staged * 2 < nrb) { // mostly direct blocks: not worth the memory
     free_lx(pl);
     pl->lx_blocks = nrb;
     return SPMV_HIP_OK;
   }
   pl->lx = 1;
+  pl->lxw = pl->lxw_rec != nullptr;
   // XCD grouping with staged x: still +3.5 % while x lives in the Infinity
   // Cache (216^3: 0.170 vs 0.176 ms), but 1.3-1.8 % slower than the plain
   // order once it does not (512^3)
@@ -967,26 +1032,36 @@ int build_lx(spmv_hip_csr_plan* pl, const int32_t* rowptr,
   // values or boundary rows keep it out of the lattice form): walk the row
   // blocks plane by plane, so that the far windows of a block are the ones
   // its workgroup -- or a neighbour on the same XCD -- staged one step before.
-  int32_t rec[kLxRec];
-  if (hipMemcpy(rec, pl->lx_tab + (size_t)(nrb / 2) * kLxRec, sizeof(rec),
-                hipMemcpyDeviceToHost)
-          == hipSuccess
-      && rec[0] >= 3) {
-    const int64_t r0 = (int64_t)(nrb / 2) * kRows;
-    int64_t pos[kLxMaxWin];
-    int np = 0;
-    for (int k = 0; k < rec[0]; ++k)
-      if (rec[1 + k] - r0 > kLxGap)
-        pos[np++] = rec[1 + k] - r0; // window starts ascend
-    // line distance = the nearest far window, plane distance = the farthest
-    if (np >= 2 && pos[0] >= 8 && pos[np - 1] % pos[0] == 0
-        && pos[np - 1] / pos[0] >= 16) {
-      pl->lattice_d1 = (int)pos[0];
-      pl->lattice_d2 = (int)pos[np - 1];
-      const int rc = spmv_zwalk_order_build(pl, pl->lattice_d2,
-                                            rowblock_grid(pl), 0, false);
-      if (rc != SPMV_HIP_OK)
-        return rc;
+  // Plane distance = the farthest column above and below the diagonal in a
+  // row block in the middle of the matrix, when the two agree.
+  {
+    const int mid = nrb / 2;
+    const int32_t r0 = mid * kRows;
+    const int nr = std::min(kRows, pl->num_rows - r0);
+    std::vector<int32_t> rp(nr + 1), ci;
+    hipError_t em = hipMemcpy(rp.data(), rowptr + r0, sizeof(int32_t) * (nr + 1),
+                              hipMemcpyDeviceToHost);
+    const int64_t cnt = em == hipSuccess ? (int64_t)rp[nr] - rp[0] : 0;
+    if (cnt > 0 && cnt <= 65536) {
+      ci.resize((size_t)cnt);
+      em = hipMemcpy(ci.data(), colind + rp[0], sizeof(int32_t) * (size_t)cnt,
+                     hipMemcpyDeviceToHost);
+      int64_t up = 0, down = 0;
+      if (em == hipSuccess)
+        for (int i = 0; i < nr; ++i)
+          for (int32_t j = rp[i]; j < rp[i + 1]; ++j) {
+            const int64_t d = (int64_t)ci[(size_t)(j - rp[0])] - (r0 + i);
+            up = d > up ? d : up;
+            down = -d > down ? -d : down;
+          }
+      if (up == down && up >= 2 * kRows && up <= INT32_MAX) {
+        pl->lattice_d1 = 0;
+        pl->lattice_d2 = (int)up;
+        const int rc = spmv_zwalk_order_build(pl, pl->lattice_d2,
+                                              spmv_walk_grid(pl), 0, false);
+        if (rc != SPMV_HIP_OK)
+          return rc;
+      }
     }
   }
   return SPMV_HIP_OK;
@@ -1055,7 +1130,9 @@ int spmv_walk_grid(const spmv_hip_csr_plan* pl)
     return spmv_sdia_grid(pl);
   if (pl->symmetric)
     return spmv_slat_grid(pl);
-  return pl->lat_tab ? spmv_lat_grid(pl) : rowblock_grid(pl);
+  if (pl->lat_tab)
+    return spmv_lat_grid(pl);
+  return (pl->lxw && pl->lxw_rec) ? spmv_lxw_grid(pl, 8) : rowblock_grid(pl);
 }
 
 void spmv_zwalk_free(spmv_hip_csr_plan* pl)
@@ -1366,6 +1443,19 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
     // 1 needs the LX form built at plan creation (or by "lx_build")
     SPMV_REQUIRE(value == 0 || plan->lx_lidx);
     plan->lx = value != 0;
+  } else if (!strcmp(key, "lxw")) {
+    // the LDS-DMA kernel of the LX form (needs its records: ctx "lx_dma")
+    SPMV_REQUIRE(value == 0 || plan->lxw_rec);
+    plan->lxw = value != 0;
+    if (plan->zw_table && plan->lx_lidx && !plan->lat_tab) // another grid
+      return spmv_zwalk_order_build(plan, plan->zw_d2, spmv_walk_grid(plan), 0,
+                                    true);
+  } else if (!strcmp(key, "lxw_blocks_per_cu")) {
+    SPMV_REQUIRE(value >= 0 && value <= kBlocksPerCU);
+    plan->lxw_blocks_per_cu = value;
+    if (plan->zw_table && plan->lxw_rec && plan->lxw && !plan->lat_tab)
+      return spmv_zwalk_order_build(plan, plan->zw_d2, spmv_walk_grid(plan), 0,
+                                    true);
   } else if (!strcmp(key, "lx_chunks")) {
     SPMV_REQUIRE(value == 1 || value == 2);
     plan->lx_chunks = value;
@@ -1457,6 +1547,8 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
       b += 4 * (int64_t)plan->num_listed;
     if (plan->lx_lidx)
       b += 2 * (nnz + 8) + 4 * nrb * kLxRec;
+    if (plan->lxw_rec)
+      b += 4 * nrb * kLxwRec;
     if (plan->lat_tab)
       b += 48 * nrb + n;
     if (plan->slat_mask)
@@ -1501,6 +1593,8 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
     *value = plan->lat_blocks;
   else if (!strcmp(key, "lx"))
     *value = plan->lx;
+  else if (!strcmp(key, "lxw"))
+    *value = plan->lxw && plan->lxw_rec ? 1 : 0;
   else if (!strcmp(key, "lx_staged"))
     *value = plan->lx_staged;
   else if (!strcmp(key, "lx_blocks"))

@@ -251,11 +251,27 @@ __global__ __launch_bounds__(kBlock) void csr_sym_dia_kernel(
   SdiaRegs<T> qA = sdia_loads<T>(cur, g, t, num_rows, cmask, in, beta, out,
                                  false, qB);
   int slot = 0;
+  // y is stored ONE STEP LATE, right behind the next step's wait: that wait
+  // covers everything the wave has in flight, stores included, and a store
+  // issued at the end of a step would be waited for at once -- its whole round
+  // trip exposed in every step (csr_lxw_kernel measured it: a fifth of the time)
+  T y_late = T(0);
+  int32_t i_late = -1;
+  auto store_late = [&]() {
+    if (i_late >= 0) {
+      if (g.nt_store) // uniform
+        __builtin_nontemporal_store(y_late, out + i_late);
+      else
+        out[i_late] = y_late;
+    }
+    i_late = -1;
+  };
   auto step = [&](const SdiaRegs<T>& q, SdiaRegs<T>& qn) {
     // everything of this block has landed, all waves have left the previous
     // one (the builtin, not asm: see csr_lattice_kernel)
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
     __syncthreads();
+    store_late();
     const int nxt = order_slot_decode(ord, nxt_raw);
     const int nn_raw = order_slot_raw(ord, it + 2 * stride, num_slots);
     const bool chain = g.chain_blocks > 0 && cur >= 0 && nxt >= 0
@@ -326,10 +342,8 @@ __global__ __launch_bounds__(kBlock) void csr_sym_dia_kernel(
             cy += term;
           }
       }
-      if (g.nt_store) // uniform
-        __builtin_nontemporal_store(y, out + i);
-      else
-        out[i] = y;
+      y_late = y;
+      i_late = i;
       if constexpr (DOT) // in . (alpha A in): the finished row without beta y0
         dot_acc += (double)q.xi * (double)cy;
     }
@@ -353,6 +367,7 @@ __global__ __launch_bounds__(kBlock) void csr_sym_dia_kernel(
       break;
     step(qB, qA);
   }
+  store_late();
   if constexpr (DOT)
     spmv_dot_epilogue(dot, dot_acc, s_red);
 }

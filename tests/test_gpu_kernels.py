@@ -817,25 +817,88 @@ def test_lx_form_bit_exact(lx_ctx, dtype):
         if name == "banded_mixed":
             assert 0 < blk.get("lx_staged") < nrb  # some blocks stay direct
         else:
-            assert blk.get("lx_staged") == nrb
+            # (the DMA layout fetches x in aligned 16-byte chunks: the row
+            # blocks that touch the last ncols % 4 columns stay direct)
+            assert nrb - blk.get("lx_staged") <= (0 if ncols % 4 == 0 else 3)
+        assert blk.get("lxw") == 1, name  # the LDS-DMA kernel is the default
         dx = ctx.upload(x, dtype)
         for alpha, beta in ((1.0, 0.0), (-0.5, 0.0), (2.0, 1.0), (1.0, -0.25)):
             y_ref = oracle.csr_spmv(rp, ci, va, x, alpha, beta, y0)  # f32-aware
             for nt in (0, 1):
                 blk.set("nontemporal", nt)
-                for lx in (1, 0):  # with and without the form: same bits
+                # the DMA kernel, the register-staged kernel on the same
+                # (padded) layout, and the plain gather kernel: same bits
+                for lx, lxw in ((1, 1), (1, 0), (0, 0)):
                     blk.set("lx", lx)
+                    blk.set("lxw", lxw)
                     dy = ctx.upload(np.full(nrows, np.nan, dtype) if beta == 0
                                     else y0, dtype)
                     blk.mult(alpha, dx.ptr, beta, dy.ptr)
                     y = dy.numpy()
                     dy.free()
-                    if lx == 1:
-                        y_lx = y
-                    else:
-                        assert np.array_equal(y, y_lx), (name, alpha, beta, nt)
-                    assert np.array_equal(y, y_ref), (name, alpha, beta, nt, lx)
+                    assert np.array_equal(y, y_ref), (name, alpha, beta, nt, lx,
+                                                      lxw)
         dx.free()
+        blk.free()
+    # the register-staged kernel's own layout (context option lx_dma = 0)
+    ctx.set_option("lx_dma", 0)
+    rp, ci, va = _banded_mixed(rng, 5000)
+    va = va.astype(dtype)
+    x = rng.uniform(-1, 1, 5000).astype(dtype)
+    blk = hip.CsrBlock(ctx, 5000, 5000, rp, ci, va, None, False,
+                       hip.ALGO_ROWBLOCK, dtype)
+    ctx.set_option("lx_dma", 1)
+    assert blk.get("lx") == 1 and blk.get("lxw") == 0
+    with pytest.raises(Exception):
+        blk.set("lxw", 1)  # its records were not built
+    dx, dy = ctx.upload(x, dtype), ctx.upload(np.full(5000, np.nan, dtype), dtype)
+    blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+    assert np.array_equal(dy.numpy(), oracle.csr_spmv(rp, ci, va, x))
+    for b in (dx, dy):
+        b.free()
+    blk.free()
+
+
+@pytest.mark.parametrize("n", [32, 33, 48])
+def test_lxw_plane_walk_bit_exact(lx_ctx, n):
+    """The LX form's DMA kernel on 3-D grids in the plane-walk order (forced
+    tables with 1-3 runs; planes of whole row blocks for n = 32, 48, ragged
+    ones for n = 33) -- random values and a third of the entries dropped, so no
+    row block repeats its neighbour.  Same bits as the oracle with every
+    combination, fused dot included."""
+    ctx = lx_ctx
+    rng = np.random.default_rng(500 + n)
+    N = n ** 3
+    offs = [-n * n, -n, -1, 0, 1, n, n * n]
+    for drop in (0.0, 0.3):
+        rp, ci, va = _stencil_csr(rng, N, offs, drop=drop)
+        x = rng.uniform(-1, 1, N)
+        y0 = rng.uniform(-1, 1, N)
+        blk = hip.CsrBlock(ctx, N, N, rp, ci, va, None, False, hip.ALGO_ROWBLOCK)
+        assert blk.get("lx") == 1 and blk.get("lxw") == 1 and blk.get("lat") == 0
+        assert blk.get("lattice_d2") == n * n
+        dx = ctx.upload(x)
+        part = ctx.empty(ctx.dot_partials_len, np.float64)
+        for alpha, beta in ((1.0, 0.0), (-0.5, 0.75)):
+            y_ref = oracle.csr_spmv(rp, ci, va, x, alpha, beta, y0)
+            for knobs in (dict(), dict(zwalk_segments=1), dict(zwalk_segments=2),
+                          dict(zwalk_segments=3), dict(zwalk=0),
+                          dict(zwalk=1, lxw_blocks_per_cu=1),
+                          dict(lxw_blocks_per_cu=0), dict(lxw=0), dict(lxw=1)):
+                for k, v in knobs.items():
+                    blk.set(k, v)
+                dy = ctx.upload(np.full(N, np.nan) if beta == 0 else y0)
+                dot = beta == 0
+                blk.mult(alpha, dx.ptr, beta, dy.ptr,
+                         dot_partials=part.ptr if dot else None)
+                assert np.array_equal(dy.numpy(), y_ref), (n, drop, alpha, knobs)
+                if dot:
+                    want = float(np.dot(x, y_ref))
+                    got = float(np.sum(part.numpy()))
+                    assert abs(got - want) <= 1e-12 * (np.abs(x) @ np.abs(y_ref))
+                dy.free()
+        for b in (dx, part):
+            b.free()
         blk.free()
 
 
