@@ -279,6 +279,13 @@ def kernel_of(A, symmetric):
         return ("csr_sym_window_kernel<double> (LDS window + global atomics)",
                 algo, algo)
     algo = nnz * 12 + (rows + 1) * 4 + y_x  # SURVEY 8d B_csr
+    if A.plan_get("wdia"):
+        K = A.plan_get("wdia_offsets")
+        return (f"csr_wdia_kernel<double> (wide diagonal form: the matrix sits on "
+                f"{K} diagonals; the plan keeps its values by offset and a 32-bit "
+                "presence mask per row; every load coalesced, no index stream, "
+                "rows summed in the CSR kernel's order: bit-exact; fused p.Ap)",
+                algo, rows * (8 * K + 4) + y_x)
     if A.plan_get("sdia") and A.plan_get("sdia_general") == 2:
         nd = A.plan_get("sdia_offsets")
         return ("csr_sym_dia_kernel<double, general order, full> (lattice matrix "
@@ -299,6 +306,11 @@ def kernel_of(A, symmetric):
                 "offsets per row block, values by LDS-DMA one block ahead, no "
                 "index stream; fused p.Ap)",
                 algo, nnz * 8 + rows * 1 + nrb * 48 + y_x)
+    if A.plan_get("lx") and A.plan_get("lxw"):
+        return ("csr_lxw_kernel<double> (LX form, LDS-DMA kernel: values, 16-bit "
+                "column offsets and x windows arrive by LDS-DMA one row block "
+                "ahead; fused p.Ap)",
+                algo, nnz * 10 + (rows + 1) * 4 + nrb * 80 + y_x)
     if A.plan_get("lx"):
         return ("csr_rowblock_lx_kernel<double> (LX form: x windows staged in "
                 "LDS, 16-bit column offsets; fused p.Ap)",
@@ -310,7 +322,8 @@ def plan_record(A):
     return {"plan_ms": A.plan_get("plan_us") / 1e3,
             "plan_extra_bytes": A.plan_get("plan_kib") * 1024,
             "form": {k: A.plan_get(k) for k in
-                     ("lat", "lx", "slat", "sdia", "sym_det", "zwalk")}}
+                     ("lat", "lx", "lxw", "wdia", "slat", "sdia", "sym_det",
+                      "zwalk")}}
 
 
 def pmc_traffic(record, kernel_name, n, world):

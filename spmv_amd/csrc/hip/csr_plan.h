@@ -128,6 +128,9 @@ constexpr int kLxwPieces0 = 4;
 constexpr int kLxwRec = 20;        // ints per record (4 + 16)
 constexpr int kLxwAlign = 4;       // window starts: multiples of 4 columns
 
+// Wide diagonal form (spmv_wdia.hip): up to this many distinct col - row
+constexpr int kWdiaMaxOff = 32;
+
 template <typename T>
 static inline bool aligned16(const T* p)
 {
@@ -204,6 +207,19 @@ struct spmv_hip_csr_plan {
   // non-temporal streams (bit mask, see sdia_geom).  512^3: ring planes and
   // diagonal -0.5 %, y stores +-0, the far windows two workgroups share +10 %
   int sdia_nt = 3;
+  // Wide diagonal form (spmv_wdia.hip): a general matrix on <= 32 diagonals
+  // that the diagonal form above refused (more than 3 lower offsets): the
+  // plan's copy of the values by offset + a 32-bit presence mask per row
+  void* wdia_val = nullptr;       // wdia_K arrays of wdia_len entries
+  uint32_t* wdia_mask = nullptr;
+  int64_t wdia_len = 0;
+  int wdia_elem = 0;              // sizeof the baked value type
+  int wdia_K = 0;
+  int32_t wdia_D[kWdiaMaxOff] = {};
+  const void* wdia_values0 = nullptr;
+  int wdia = 0;                   // use it (plan_set "wdia")
+  int wdia_xcd_group = 4;         // consecutive row blocks per XCD (0 = off;
+                                  // 27-point 256^3: 0.820 -> 0.803 ms)
   int32_t* row_list = nullptr; // ROWLIST: device list of non-empty rows
   int32_t num_listed = 0;
   int nt_store = 0; // non-temporal y stores
@@ -216,7 +232,8 @@ struct spmv_hip_csr_plan {
   const int32_t* colind0 = nullptr;
   bool structure_baked() const
   {
-    return row_list || lx_lidx || lat_tab || slat_mask || t_ptr || lxw_rec;
+    return row_list || lx_lidx || lat_tab || slat_mask || t_ptr || lxw_rec
+           || wdia_val;
   }
   // ROWBLOCK "LX" form: LDS-staged x windows + 16-bit local column indices
   // (csr_rowblock_lx_kernel); built by plan_create when most row blocks qualify
@@ -336,6 +353,16 @@ int spmv_lxw_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st,
                      const int32_t* rowptr, const int32_t* colind,
                      const float* values, float alpha, const float* in,
                      float beta, float* out);
+// spmv_wdia.hip
+void spmv_wdia_free(spmv_hip_csr_plan* pl);
+int spmv_wdia_bake_f64(spmv_hip_csr_plan* pl, const double* values,
+                       hipStream_t st); // values == nullptr: drop the copy
+int spmv_wdia_bake_f32(spmv_hip_csr_plan* pl, const float* values,
+                       hipStream_t st);
+int spmv_wdia_run_f64(const spmv_hip_csr_plan* pl, hipStream_t st, double alpha,
+                      const double* in, double beta, double* out, DotOut dot);
+int spmv_wdia_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st, float alpha,
+                      const float* in, float beta, float* out);
 // spmv_lat.hip
 int spmv_lat_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
                    const int32_t* colind);

@@ -712,6 +712,15 @@ int launch_rowblock(const spmv_hip_csr_plan* pl, hipStream_t st,
     else
       return spmv_sdia_run_f32(pl, st, alpha, in, beta, out);
   }
+  // the plan's own copy by offset of a matrix on <= 32 diagonals
+  if (pl->wdia && pl->wdia_val && pl->wdia_elem == (int)sizeof(T)
+      && values == pl->wdia_values0) {
+    if constexpr (sizeof(T) == 8)
+      return spmv_wdia_run_f64(pl, st, alpha, in, beta, out,
+                               DOT ? dot : DotOut());
+    else
+      return spmv_wdia_run_f32(pl, st, alpha, in, beta, out);
+  }
   if (pl->lat && aligned16(values)) {
     if constexpr (sizeof(T) == 8)
       return spmv_lat_run_f64(pl, st, rowptr, values, alpha, in, beta, out,
@@ -1339,13 +1348,15 @@ int spmv_hip_csr_plan_destroy(spmv_hip_csr_plan* plan)
 {
   if (plan
       && (plan->row_list || plan->lx_lidx || plan->lat_tab || plan->t_ptr
-          || plan->slat_mask || plan->zw_table)) {
+          || plan->slat_mask || plan->zw_table || plan->wdia_val
+          || plan->sdia_val)) {
     (void)hipSetDevice(plan->ctx->device);
     (void)hipFree(plan->row_list);
     free_lx(plan);
     spmv_lat_free(plan);
     spmv_symt_free(plan);
     spmv_sdia_free(plan);
+    spmv_wdia_free(plan);
     spmv_slat_free(plan);
     spmv_zwalk_free(plan);
   }
@@ -1359,7 +1370,17 @@ int spmv_hip_csr_plan_bake_values_f64(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan
 {
   SPMV_SET_DEVICE(ctx);
   SPMV_REQUIRE(plan && plan->ctx == ctx);
-  return spmv_sdia_bake_f64(plan, values, diagonal, spmv_stream(ctx, stream));
+  hipStream_t st = spmv_stream(ctx, stream);
+  int rc = spmv_sdia_bake_f64(plan, values, diagonal, st);
+  // a general matrix the diagonal form refuses (more than three lower
+  // offsets, no lattice form): the wide diagonal form, up to 32 diagonals
+  if (!plan->symmetric && (rc == SPMV_HIP_ENOTSUP || values == nullptr)) {
+    const int rw = spmv_wdia_bake_f64(plan, values, st);
+    rc = values == nullptr ? (rw != SPMV_HIP_OK ? rw : rc) : rw;
+  } else if (!plan->symmetric && rc == SPMV_HIP_OK) {
+    (void)spmv_wdia_bake_f64(plan, nullptr, st); // superseded
+  }
+  return rc;
 }
 
 int spmv_hip_csr_plan_bake_values_f32(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan,
@@ -1368,7 +1389,15 @@ int spmv_hip_csr_plan_bake_values_f32(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan
 {
   SPMV_SET_DEVICE(ctx);
   SPMV_REQUIRE(plan && plan->ctx == ctx);
-  return spmv_sdia_bake_f32(plan, values, diagonal, spmv_stream(ctx, stream));
+  hipStream_t st = spmv_stream(ctx, stream);
+  int rc = spmv_sdia_bake_f32(plan, values, diagonal, st);
+  if (!plan->symmetric && (rc == SPMV_HIP_ENOTSUP || values == nullptr)) {
+    const int rw = spmv_wdia_bake_f32(plan, values, st);
+    rc = values == nullptr ? (rw != SPMV_HIP_OK ? rw : rc) : rw;
+  } else if (!plan->symmetric && rc == SPMV_HIP_OK) {
+    (void)spmv_wdia_bake_f32(plan, nullptr, st);
+  }
+  return rc;
 }
 
 int spmv_hip_csr_plan_bake_values_f32f64(spmv_hip_ctx* ctx,
@@ -1472,6 +1501,12 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
     if (plan->zw_table && plan->sdia_val)
       return spmv_zwalk_order_build(plan, plan->zw_d2, spmv_walk_grid(plan), 0,
                                     true);
+  } else if (!strcmp(key, "wdia")) {
+    SPMV_REQUIRE(value == 0 || plan->wdia_val);
+    plan->wdia = value != 0;
+  } else if (!strcmp(key, "wdia_xcd_group")) {
+    SPMV_REQUIRE(value >= 0 && value <= 4096);
+    plan->wdia_xcd_group = value;
   } else if (!strcmp(key, "slat_blocks_per_cu")) {
     SPMV_REQUIRE(value >= 1 && value <= kBlocksPerCU);
     plan->slat_blocks_per_cu = value;
@@ -1536,6 +1571,10 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
     *value = plan->slat;
   else if (!strcmp(key, "sdia"))
     *value = plan->sdia && plan->sdia_val ? 1 : 0;
+  else if (!strcmp(key, "wdia"))
+    *value = plan->wdia && plan->wdia_val ? 1 : 0;
+  else if (!strcmp(key, "wdia_offsets"))
+    *value = plan->wdia_val ? plan->wdia_K : 0;
   else if (!strcmp(key, "plan_us"))
     *value = plan->plan_us;
   else if (!strcmp(key, "plan_kib")) {
@@ -1559,6 +1598,8 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
       b += narr * plan->sdia_len * plan->sdia_elem + n;
     if (plan->sdia32_val)
       b += narr * plan->sdia_len * 4 + n;
+    if (plan->wdia_val)
+      b += (int64_t)plan->wdia_K * plan->wdia_len * plan->wdia_elem + 4 * n;
     if (plan->t_ptr)
       b += 4 * (n + 1) + 8 * nnz;
     if (plan->zw_table)

@@ -1,0 +1,356 @@
+// Wide diagonal form of the general CSR SpMV (gfx950 / MI355X): matrices whose
+// entries sit on at most 32 diagonals -- 2-D 9-point, 3-D 19- and 27-point
+// stencils (HPCG's operator), any constant-offset stencil too wide for the
+// lattice form (8 offsets per row block) and the diagonal form proper (3 lower
+// offsets, spmv_symdia.hip).
+//
+// Stands behind the same CSRSpMV<T>::init/run hook as the other general
+// kernels (spmv/csr_kernels.h:26-78); arithmetic and summation order are those
+// of spmv/csr_kernels.cpp:41-51, so results are bit-identical to the oracle.
+//
+// spmv_hip_csr_plan_bake_values_* on a general plan that the diagonal form
+// refused looks (on the device) for
+//   * the set of distinct `col - row` over the whole matrix: at most 32,
+//   * every row's entries in strictly ascending column order (then "walk the
+//     set bits of the row's mask from k = 0 up" IS the row's left-to-right
+//     order of csr_kernels.cpp:46-47),
+//   * at least half of the rows x offsets slots filled,
+// and keeps its own copy of the values BY OFFSET: K arrays v_k[i] = A(i, i +
+// D_k), zero where a row has no such entry, plus one 32-bit presence mask per
+// row.  The kernel then needs neither `colind` nor the row pointer: lane = row,
+// every load -- v_k[i], x[i + D_k], the mask -- is coalesced and independent of
+// every other, issued eight offsets at a time; 8 B per entry + 4 B per row
+// instead of 12 B per entry + 4 B per row (27-point, 256^3: 3.96 GB per SpMV
+// instead of 5.79 GB).  A product is added only where the mask bit is set: an
+// absent entry contributes nothing, not 0 * x (x may be Inf or NaN there, and
+// a sum of -0.0 must stay -0.0).
+//
+// No LDS, no barriers: the x loads of neighbouring offsets (dx = -1, 0, +1 of a
+// stencil) hit the same lines in L1, those of neighbouring grid lines and
+// planes the L2 -- the persistent grid sweeps the rows front by front.
+//
+// Measured (MI355X, same process, alternating): 27-point 256^3 (16.8 M rows,
+// 449 M entries) 0.80-0.82 ms against 1.07 ms for the row-block gather kernel
+// the matrix took before (160^3: 0.216 against 0.298); 3.96 GB per launch =
+// 4.9 TB/s.  On the 7-point matrix the LDS-DMA diagonal forms stay ahead
+// (512^3: 2.16-2.30 ms here against 1.74 for the full diagonal form and 1.32
+// for the half form), which is why this form only takes what they refuse.
+#include "csr_plan.h"
+
+#include <chrono>
+#include <new>
+
+namespace
+{
+
+struct WdiaOffsets {
+  int32_t D[kWdiaMaxOff]; // ascending; D[k] = 0 beyond K
+};
+
+// TV = type of the baked values (what is streamed), T = type of x, y and of
+// the arithmetic.
+template <typename TV, typename T, bool DOT>
+__global__ __launch_bounds__(kBlock) void csr_wdia_kernel(
+    int32_t num_rows, int32_t num_cols, int64_t arr_len, int K, WdiaOffsets off,
+    const TV* __restrict__ sval, const uint32_t* __restrict__ mask, T alpha,
+    const T* __restrict__ in, T beta, T* __restrict__ out, DotOut dot,
+    RowBlockOrder ord)
+{
+  __shared__ double s_red[kBlock / 64];
+  const int t = threadIdx.x;
+  double dot_acc = 0.0;
+  const int num_slots = order_slots(ord);
+  for (int it = blockIdx.x; it < num_slots; it += gridDim.x) {
+    const int rb = order_row_block(ord, it);
+    if (rb < 0)
+      continue; // uniform
+    const int64_t i = (int64_t)rb * kRows + t;
+    if (i >= num_rows)
+      continue;
+    const uint32_t m = mask[i];
+    T y0 = T(0), x_own = T(0);
+    if (beta != T(0))
+      y0 = out[i];
+    if constexpr (DOT)
+      x_own = in[i];
+    T sum = 0;
+    // eight offsets at a time: sixteen independent loads in flight per lane
+    for (int k0 = 0; k0 < K; k0 += 8) {
+      T v[8], x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j;
+        v[j] = T(0);
+        x[j] = T(0);
+        if (k < K) { // uniform
+          // unconditional (no dependence on the mask load); a column the row
+          // does not have is clamped into range and its product never added
+          int64_t c = i + off.D[k];
+          c = c < 0 ? 0 : (c >= num_cols ? (int64_t)num_cols - 1 : c);
+          v[j] = (T)sval[(int64_t)k * arr_len + i];
+          x[j] = in[c];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if ((m >> (k0 + j)) & 1u) // csr_kernels.cpp:46-47, left to right
+          sum += v[j] * x[j];
+    }
+    const T c = alpha * sum;
+    T y = c;
+    if (beta != T(0))
+      y = c + beta * y0;
+    out[i] = y;
+    if constexpr (DOT)
+      dot_acc += (double)x_own * (double)c;
+  }
+  if constexpr (DOT)
+    spmv_dot_epilogue(dot, dot_acc, s_red);
+}
+
+// pass 1: the set of distinct col - row (capacity kWdiaMaxOff; INT32_MIN =
+// free slot).  Slots are always probed from 0, so a value can only ever sit in
+// one slot (a probe that started anywhere else could insert a second copy
+// behind a free slot).
+__global__ __launch_bounds__(kBlock) void wdia_offsets_kernel(
+    int32_t num_rows, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ colind, int32_t* __restrict__ set,
+    int32_t* __restrict__ fail)
+{
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < num_rows;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    if (*fail) // somebody found a 33rd offset: nothing left to learn
+      return;
+    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+      const int64_t d64 = (int64_t)colind[j] - i;
+      if (d64 <= INT32_MIN || d64 > INT32_MAX) {
+        atomicOr(fail, 1);
+        continue;
+      }
+      const int32_t d = (int32_t)d64;
+      bool placed = false;
+      for (int s = 0; s < kWdiaMaxOff && !placed; ++s) {
+        int32_t cur = set[s];
+        if (cur == INT32_MIN)
+          cur = atomicCAS(set + s, INT32_MIN, d);
+        placed = (cur == d || cur == INT32_MIN);
+      }
+      if (!placed)
+        atomicOr(fail, 1);
+    }
+  }
+}
+
+// pass 2: fill the arrays and the masks; fail = a row whose columns do not
+// ascend strictly
+template <typename T>
+__global__ __launch_bounds__(kBlock) void wdia_bake_kernel(
+    int32_t num_rows, int K, WdiaOffsets off, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ colind, const T* __restrict__ values,
+    int64_t arr_len, T* __restrict__ sval, uint32_t* __restrict__ mask,
+    int32_t* __restrict__ fail)
+{
+  __shared__ int32_t s_D[kWdiaMaxOff]; // indexed per lane below
+  if (threadIdx.x < kWdiaMaxOff)
+    s_D[threadIdx.x] = off.D[threadIdx.x];
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < num_rows;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t m = 0;
+    int prev = -1;
+    bool bad = false;
+    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+      const int32_t d = (int32_t)((int64_t)colind[j] - i);
+      int k = prev + 1; // ascending columns: the search resumes where it was
+      while (k < K && s_D[k] != d)
+        ++k;
+      if (k >= K) {
+        bad = true;
+        break;
+      }
+      sval[(int64_t)k * arr_len + i] = values[j];
+      m |= 1u << k;
+      prev = k;
+    }
+    if (bad)
+      atomicOr(fail, 1);
+    mask[i] = m;
+  }
+}
+
+void wdia_free_arrays(spmv_hip_csr_plan* pl)
+{
+  (void)hipFree(pl->wdia_val);
+  (void)hipFree(pl->wdia_mask);
+  pl->wdia_val = nullptr;
+  pl->wdia_mask = nullptr;
+  pl->wdia_values0 = nullptr;
+  pl->wdia_len = 0;
+  pl->wdia_elem = 0;
+  pl->wdia_K = 0;
+  pl->wdia = 0;
+}
+
+int wdia_grid(const spmv_hip_csr_plan* pl)
+{
+  const int nrb = (pl->num_rows + kRows - 1) / kRows;
+  int grid = pl->ctx->num_cus * kBlocksPerCU;
+  if (grid > pl->ctx->dot_blocks)
+    grid = pl->ctx->dot_blocks;
+  if (grid > nrb)
+    grid = nrb;
+  if (grid < 1)
+    grid = 1;
+  if (grid >= 8)
+    grid -= grid % 8;
+  return grid;
+}
+
+template <typename T>
+int wdia_bake(spmv_hip_csr_plan* pl, const T* values, hipStream_t st)
+{
+  SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
+  wdia_free_arrays(pl);
+  if (values == nullptr)
+    return SPMV_HIP_OK; // dropped
+  if (pl->symmetric || !pl->ctx->bake_general || pl->nnz == 0
+      || pl->algo != SPMV_HIP_ALGO_ROWBLOCK || pl->nnz < pl->ctx->lat_min_nnz)
+    return SPMV_HIP_ENOTSUP;
+  const auto t_begin = std::chrono::steady_clock::now();
+  const int32_t n = pl->num_rows;
+  // pass 1: the offsets
+  int32_t h_set[kWdiaMaxOff + 1];
+  for (int s = 0; s < kWdiaMaxOff; ++s)
+    h_set[s] = INT32_MIN;
+  h_set[kWdiaMaxOff] = 0; // fail flag
+  int32_t* d_set = nullptr;
+  hipError_t e = hipMalloc(&d_set, sizeof(h_set));
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(d_set, h_set, sizeof(h_set), hipMemcpyHostToDevice, st);
+  const int grid = spmv_grid_for(pl->ctx, n, kBlock);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(wdia_offsets_kernel, dim3(grid), dim3(kBlock), 0, st, n,
+                       pl->rowptr0, pl->colind0, d_set, d_set + kWdiaMaxOff);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(h_set, d_set, sizeof(h_set), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st);
+  if (e != hipSuccess) {
+    (void)hipFree(d_set);
+    return static_cast<int>(e);
+  }
+  WdiaOffsets off;
+  int K = 0;
+  for (int s = 0; s < kWdiaMaxOff; ++s)
+    if (h_set[s] != INT32_MIN)
+      off.D[K++] = h_set[s];
+  // worth the memory only while the arrays are mostly full
+  if (h_set[kWdiaMaxOff] || K == 0 || (double)pl->nnz < 0.5 * (double)K * n) {
+    (void)hipFree(d_set);
+    return SPMV_HIP_ENOTSUP;
+  }
+  for (int a = 1; a < K; ++a) // insertion sort, ascending
+    for (int b = a; b > 0 && off.D[b] < off.D[b - 1]; --b) {
+      const int32_t tmp = off.D[b];
+      off.D[b] = off.D[b - 1];
+      off.D[b - 1] = tmp;
+    }
+  for (int k = K; k < kWdiaMaxOff; ++k)
+    off.D[k] = 0;
+  // pass 2: the copy by offset
+  const int64_t len = (((int64_t)n + kRows - 1) / kRows) * kRows;
+  const size_t bytes = (size_t)K * len * sizeof(T);
+  void* sval = nullptr;
+  uint32_t* msk = nullptr;
+  int32_t h_fail = 0;
+  e = hipMalloc(&sval, bytes);
+  if (e == hipSuccess)
+    e = hipMalloc(&msk, sizeof(uint32_t) * (size_t)n);
+  if (e == hipSuccess)
+    e = hipMemsetAsync(sval, 0, bytes, st);
+  if (e == hipSuccess)
+    e = hipMemsetAsync(d_set + kWdiaMaxOff, 0, sizeof(int32_t), st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL((wdia_bake_kernel<T>), dim3(grid), dim3(kBlock), 0, st, n,
+                       K, off, pl->rowptr0, pl->colind0, values, len,
+                       static_cast<T*>(sval), msk, d_set + kWdiaMaxOff);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(&h_fail, d_set + kWdiaMaxOff, sizeof(int32_t),
+                       hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st);
+  (void)hipFree(d_set);
+  if (e != hipSuccess || h_fail) {
+    (void)hipFree(sval);
+    (void)hipFree(msk);
+    if (e == hipErrorOutOfMemory)
+      (void)hipGetLastError(); // the CSR-order kernels keep running
+    return (e != hipSuccess && e != hipErrorOutOfMemory) ? static_cast<int>(e)
+                                                         : SPMV_HIP_ENOTSUP;
+  }
+  pl->wdia_val = sval;
+  pl->wdia_mask = msk;
+  pl->wdia_len = len;
+  pl->wdia_elem = (int)sizeof(T);
+  pl->wdia_K = K;
+  for (int k = 0; k < kWdiaMaxOff; ++k)
+    pl->wdia_D[k] = off.D[k];
+  pl->wdia_values0 = values;
+  pl->wdia = 1;
+  pl->plan_us += (int)std::chrono::duration_cast<std::chrono::microseconds>(
+                     std::chrono::steady_clock::now() - t_begin)
+                     .count();
+  return SPMV_HIP_OK;
+}
+
+template <typename T, bool DOT>
+int wdia_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
+                T beta, T* out, DotOut dot)
+{
+  const int nrb = (pl->num_rows + kRows - 1) / kRows;
+  WdiaOffsets off;
+  for (int k = 0; k < kWdiaMaxOff; ++k)
+    off.D[k] = pl->wdia_D[k];
+  RowBlockOrder ord = pl->row_block_order(nrb);
+  ord.xcd_group = pl->wdia_xcd_group;
+  hipLaunchKernelGGL((csr_wdia_kernel<T, T, DOT>), dim3(wdia_grid(pl)),
+                     dim3(kBlock), 0, st, pl->num_rows, pl->num_cols,
+                     pl->wdia_len, pl->wdia_K, off,
+                     static_cast<const T*>(pl->wdia_val), pl->wdia_mask, alpha,
+                     in, beta, out, dot, ord);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+} // namespace
+
+void spmv_wdia_free(spmv_hip_csr_plan* pl) { wdia_free_arrays(pl); }
+
+int spmv_wdia_bake_f64(spmv_hip_csr_plan* pl, const double* values,
+                       hipStream_t st)
+{
+  return wdia_bake<double>(pl, values, st);
+}
+
+int spmv_wdia_bake_f32(spmv_hip_csr_plan* pl, const float* values, hipStream_t st)
+{
+  return wdia_bake<float>(pl, values, st);
+}
+
+int spmv_wdia_run_f64(const spmv_hip_csr_plan* pl, hipStream_t st, double alpha,
+                      const double* in, double beta, double* out, DotOut dot)
+{
+  if (dot.partials)
+    return wdia_launch<double, true>(pl, st, alpha, in, beta, out, dot);
+  return wdia_launch<double, false>(pl, st, alpha, in, beta, out, dot);
+}
+
+int spmv_wdia_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st, float alpha,
+                      const float* in, float beta, float* out)
+{
+  return wdia_launch<float, false>(pl, st, alpha, in, beta, out, DotOut());
+}

@@ -76,8 +76,9 @@ def test_bench_single_gpu_line():
     assert ns["form"]["sdia"] == 1 and "full" in ns["kernel"]
     assert d["north_star_spmv"]["form"]["lat"] == 1
     # the kernels of matrices WITHOUT lattice structure, measured and checked
-    assert d["csr_rowblock_spmv"]["form"] == dict(lat=0, lx=0, slat=0, sdia=0,
-                                                  sym_det=0, zwalk=0)
+    assert d["csr_rowblock_spmv"]["form"] == dict(lat=0, lx=0, lxw=0, wdia=0,
+                                                  slat=0, sdia=0, sym_det=0,
+                                                  zwalk=0)
     for k in ("north_star_lattice_spmv", "north_star_lx_spmv",
               "north_star_rowblock_spmv"):
         assert d[k]["rows"] == 216 ** 3 and d[k]["form"]["sdia"] == 0

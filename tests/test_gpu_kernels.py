@@ -1435,7 +1435,7 @@ def test_general_matrix_that_is_not_symmetric_takes_the_full_diagonal_form(lat_c
     values that are simply not symmetric: the device check refuses the HALF
     form and the plan keeps ALL values by offset (full form, arrays for the
     upper entries too) -- the bits of the general reference loop, all orders,
-    mixed-precision copy included.  A fourth offset or a rectangular block: no
+    mixed-precision copy included.  A fourth offset or a rectangular block: not
     diagonal form at all, the lattice kernel keeps running."""
     ctx = lat_ctx
     rng = np.random.default_rng(100)
@@ -1509,23 +1509,30 @@ def test_general_matrix_that_is_not_symmetric_takes_the_full_diagonal_form(lat_c
         for b_ in (d32, dx, part):
             b_.free()
         blk.free()
-    # four distinct offsets, and a rectangular block: no diagonal form
+    # four distinct offsets, and a rectangular block: not the diagonal form
+    # proper -- the WIDE diagonal form (spmv_wdia.hip) takes them
     x = rng.uniform(-1, 1, N)
     rp_, ci_, va_ = _symmetric_general_csr(rng, N, [-700, -30, -2, -1])
     blk = hip.CsrBlock(ctx, N, N, rp_, ci_, va_, None, False, hip.ALGO_ROWBLOCK)
-    with pytest.raises(Exception):
-        blk.bake()
-    assert blk.get("sdia") == 0
+    blk.bake()
+    assert blk.get("sdia") == 0 and blk.get("wdia") == 1
+    assert blk.get("wdia_offsets") == 9
     dx, dy = ctx.upload(x), ctx.upload(np.full(N, np.nan))
     blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
     assert np.array_equal(dy.numpy(), oracle.csr_spmv(rp_, ci_, va_, x))
     dx.free(), dy.free()
     blk.free()
     rpr, cir, var = _stencil_csr(rng, 3000, [-5, 0, 5])
+    xr = rng.uniform(-1, 1, 3005)
     blk = hip.CsrBlock(ctx, 3000, 3005, rpr, cir.astype(np.int32), var, None, False,
                        hip.ALGO_ROWBLOCK)
-    with pytest.raises(Exception):
-        blk.bake()
+    blk.bake()
+    assert blk.get("sdia") == 0 and blk.get("wdia") == 1
+    dx, dy = ctx.upload(xr), ctx.upload(np.full(3000, np.nan))
+    blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+    assert np.array_equal(dy.numpy(), oracle.csr_spmv(rpr, cir.astype(np.int32),
+                                                      var, xr))
+    dx.free(), dy.free()
     blk.free()
 
 
@@ -1605,6 +1612,115 @@ def test_plane_walk_order_is_a_permutation_of_the_work(lat_ctx, n):
     with pytest.raises(Exception):
         blk.set("zwalk_segments", 4)
     blk.free()
+
+
+# ---------------------------------------------------------------------------
+# Wide diagonal form (spmv_wdia.hip): general matrices on <= 32 diagonals
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_wide_diagonal_form_bit_exact(lat_ctx, dtype):
+    """plan_bake_values on a general matrix too wide for the diagonal form
+    proper: 27-point and 2-D 9-point stencils, 19 random offsets with a third
+    of the entries dropped, 32 offsets (the limit).  Same bits as the oracle's
+    general loop, any alpha / beta, fused dot; other value pointers take the
+    CSR-order kernels; the copy can be dropped."""
+    ctx = lat_ctx
+    rng = np.random.default_rng(271)
+    cases = []
+    for n in (7, 12):
+        rp, ci, va = poisson.stencil27_csr(n)
+        cases.append((f"stencil27_{n}", rp, ci.astype(np.int32), va, n ** 3, 27))
+    m = 70  # 2-D 9-point on a 70 x 70 grid
+    offs9 = [dy * m + dx for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+    rp, ci, va = _stencil_csr(rng, m * m, offs9)
+    cases.append(("nine_point_2d", rp, ci, va, m * m, 9))
+    offs19 = sorted(int(o) for o in rng.choice(np.arange(-1500, 1500), 19,
+                                               replace=False))
+    rp, ci, va = _stencil_csr(rng, 9001, offs19, drop=0.3)
+    cases.append(("nineteen_random", rp, ci, va, 9001, 19))
+    offs32 = list(range(-16, 16))
+    rp, ci, va = _stencil_csr(rng, 2000, offs32, drop=0.1)
+    cases.append(("thirty_two", rp, ci, va, 2000, 32))
+    for name, rp, ci, va, N, K in cases:
+        va = rng.uniform(-1, 1, len(ci)).astype(dtype)
+        x = rng.uniform(-1, 1, N).astype(dtype)
+        y0 = rng.uniform(-1, 1, N).astype(dtype)
+        blk = hip.CsrBlock(ctx, N, N, rp, ci, va, None, False, hip.ALGO_ROWBLOCK,
+                           dtype)
+        assert blk.get("lat") == 0, name  # more than 8 offsets per row block
+        try:
+            blk.bake()
+        except Exception as e:
+            raise AssertionError(name) from e
+        assert blk.get("wdia") == 1 and blk.get("sdia") == 0, name
+        assert blk.get("wdia_offsets") == K, name
+        dx = ctx.upload(x, dtype)
+        other = ctx.upload(va, dtype)  # same values, another array
+        part = ctx.empty(ctx.dot_partials_len, np.float64)
+        for alpha, beta in ((1.0, 0.0), (-0.5, 0.0), (2.0, 1.0), (1.0, -0.25)):
+            y_ref = oracle.csr_spmv(rp, ci, va, x, alpha, beta, y0)
+            for knobs in (dict(), dict(wdia_xcd_group=4), dict(wdia=0),
+                          dict(wdia=1, wdia_xcd_group=0)):
+                for k, v in knobs.items():
+                    blk.set(k, v)
+                dy = ctx.upload(np.full(N, np.nan, dtype) if beta == 0 else y0,
+                                dtype)
+                dot = beta == 0 and dtype == np.float64
+                blk.mult(alpha, dx.ptr, beta, dy.ptr,
+                         dot_partials=part.ptr if dot else None)
+                assert np.array_equal(dy.numpy(), y_ref), (name, alpha, beta, knobs)
+                if dot:
+                    want = float(np.dot(x, y_ref))
+                    got = float(np.sum(part.numpy()))
+                    assert abs(got - want) <= 1e-12 * (np.abs(x) @ np.abs(y_ref))
+                dy.free()
+        # another value array of the same shape: the CSR-order kernels
+        y_ref = oracle.csr_spmv(rp, ci, va, x)
+        dy = ctx.upload(np.full(N, np.nan, dtype), dtype)
+        name_fn = ("spmv_hip_csr_spmv_f64" if dtype == np.float64
+                   else "spmv_hip_csr_spmv_f32")
+        args = [ctx.h, blk.plan, N, N, blk.nnz, blk.rowptr.ptr, blk.colind.ptr,
+                other.ptr, None, 1.0, dx.ptr, 0.0, dy.ptr]
+        hip.call(name_fn, *(args + ([None, None] if dtype == np.float64
+                                    else [None])))
+        assert np.array_equal(dy.numpy(), y_ref), name
+        blk.bake(drop=True)
+        assert blk.get("wdia") == 0
+        blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+        assert np.array_equal(dy.numpy(), y_ref), name
+        for b in (dx, dy, other, part):
+            b.free()
+        blk.free()
+
+
+def test_wide_diagonal_form_is_refused_when_it_does_not_apply(lat_ctx):
+    """33 diagonals, a row with a repeated column, a row whose columns do not
+    ascend, arrays that would be mostly zeros: ENOTSUP, the CSR-order kernels
+    keep running."""
+    ctx = lat_ctx
+    rng = np.random.default_rng(272)
+    N = 3000
+    cases = [("33", *_stencil_csr(rng, N, list(range(-16, 17))))]
+    rp, ci, va = _stencil_csr(rng, N, list(range(-6, 7)))
+    ci2 = ci.copy()
+    j = int(rp[1500])
+    ci2[j + 1] = ci2[j]  # a repeated column
+    cases.append(("repeat", rp, ci2, va))
+    ci3 = ci.copy()
+    ci3[j], ci3[j + 1] = ci3[j + 1], ci3[j]  # not ascending
+    cases.append(("unsorted", rp, ci3, va))
+    cases.append(("sparse", *_stencil_csr(rng, N, list(range(-6, 7)), drop=0.7)))
+    for name, rp, ci, va in cases:
+        x = rng.uniform(-1, 1, N)
+        blk = hip.CsrBlock(ctx, N, N, rp, ci, va, None, False, hip.ALGO_ROWBLOCK)
+        with pytest.raises(Exception):
+            blk.bake()
+        assert blk.get("wdia") == 0 and blk.get("sdia") == 0, name
+        dx, dy = ctx.upload(x), ctx.upload(np.full(N, np.nan))
+        blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+        assert np.array_equal(dy.numpy(), oracle.csr_spmv(rp, ci, va, x)), name
+        dx.free(), dy.free()
+        blk.free()
 
 
 # ---------------------------------------------------------------------------
@@ -1711,9 +1827,11 @@ def test_bake_that_does_not_apply_leaves_the_plan_as_it_was(lat_ctx):
     rng = np.random.default_rng(7)
     n = 40  # planes of 1600 rows; a table for so small a lattice needs forcing
     N = n ** 3
-    # 8 offsets, 4 of them lower: lattice form yes, diagonal form no (> 3)
+    # 8 offsets, 4 of them lower: lattice form yes, diagonal form no (> 3);
+    # three fifths of the entries dropped: too sparse for the wide diagonal
+    # form as well (it wants half of its slots filled)
     offs = [-n * n, -n, -2, -1, 0, 1, n, n * n]
-    rp, ci, va = _stencil_csr(rng, N, offs)
+    rp, ci, va = _stencil_csr(rng, N, offs, drop=0.6)
     x = rng.uniform(-1, 1, N)
     y_ref = oracle.csr_spmv(rp, ci, va, x)
     blk = hip.CsrBlock(ctx, N, N, rp, ci, va, None, False, hip.ALGO_ROWBLOCK)
@@ -1723,7 +1841,7 @@ def test_bake_that_does_not_apply_leaves_the_plan_as_it_was(lat_ctx):
     assert before[0] == 1 and before[1] > 0
     with pytest.raises(Exception):
         blk.bake()
-    assert blk.get("sdia") == 0
+    assert blk.get("sdia") == 0 and blk.get("wdia") == 0
     assert (blk.get("zwalk"), blk.get("zwalk_grid"),
             blk.get("zwalk_segments")) == before
     dx, dy = ctx.upload(x), ctx.upload(np.full(N, np.nan))

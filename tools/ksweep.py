@@ -34,6 +34,8 @@ def main():
                     help="no lattice analysis: the LX form")
     ap.add_argument("--no-lx", action="store_true",
                     help="... nor the LX form: the plain row-block kernel")
+    ap.add_argument("--stencil27", action="store_true",
+                    help="the 27-point operator instead of the 7-point one")
     ap.add_argument("--out", default=None)
     ap.add_argument("--calib", action="store_true",
                     help="also time plain streaming kernels on this box")
@@ -45,6 +47,8 @@ def main():
     if args.no_lx:
         ctx.set_option("lx_min_nnz", 1 << 62)
     n, N = args.n, args.n ** 3
+    if args.stencil27:
+        ctx.set_option("poisson_stencil", 27)
     if args.symmetric:
         blk = hip.poisson3d_block(ctx, n, 0, N, hip.PART_LOCAL_LOWER,
                                   with_diagonal=True)

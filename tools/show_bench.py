@@ -1,0 +1,31 @@
+"""Prints the headline numbers of a bench.py JSON line (a log file)."""
+import json
+import sys
+
+for ln in open(sys.argv[1]):
+    if ln.startswith("{"):
+        d = json.loads(ln)
+print("value %.1f it/s  ms/step %.3f" % (d["value"], d["ms_per_step"]))
+r = d["roofline"]
+print("main: %.4f ms frac %.3f csr_eq %.3f traffic_frac %s" % (
+    r["avg_launch_ms"], r["frac"], r["frac_csr_equivalent"], r.get("frac_traffic")))
+if "time_to_solution" in d:
+    t = d["time_to_solution"]
+    print("tts: total %.1f ms (cg %.1f + plan %.1f), create %.1f" % (
+        t["total_ms"], t["cg_ms"], t["plan_ms"], t["matrix_generate_and_plan_ms"]))
+print("plan", d["plan"]["plan_ms"], d.get("matrix_create_ms"))
+for k, v in d.items():
+    if isinstance(v, dict) and "ms_per_apply" in v:
+        print("%-26s rows %9d ms %.4f frac %.3f csr_eq %.3f plan %.1f ms %s %s" % (
+            k, v["rows"], v["ms_per_apply"], v["frac"], v["frac_csr_equivalent"],
+            v["plan_ms"], v.get("crosscheck", {}).get("bit_equal", ""),
+            v["kernel"].split(" ")[0]))
+if "symmetric" in d:
+    s = d["symmetric"]
+    print("symmetric: %.4f ms frac %.3f it/s %.1f plan %.1f" % (
+        s["avg_launch_ms"], s["frac"], s["iters/s"], s["plan_ms"]))
+if "mixed_precision_cg" in d:
+    print("mixed speedup", d["mixed_precision_cg"]["speedup"])
+if "cpu_baseline" in d:
+    c = d["cpu_baseline"]
+    print("cpu", c["value"], c.get("parity_checks"))
