@@ -453,6 +453,22 @@ int spmv_hip_poisson3d_fill_f64(spmv_hip_ctx* ctx, int32_t n,
 /* number of ghost columns below / above the owned range for this row block */
 int spmv_hip_poisson3d_ghosts(int32_t n, int64_t row_begin, int64_t row_end,
                               int64_t* ghosts_below, int64_t* ghosts_above);
+/* The same matrix on ONE BOX of a 3-D block partition: rows =
+ * the box's points (first[], len[] per axis; x fastest) in the rank-major
+ * numbering of Matrix::create_poisson3d_boxes; owned columns 0 .. box points,
+ * ghost columns behind them = the points one step outside the faces that have
+ * a neighbour box, face by face in the order -z -y -x +x +y +z (ascending
+ * global id), inside a face in the order of its two in-face coordinates.
+ * box_count with rowptr == NULL only reports the number of ghosts. */
+int spmv_hip_poisson3d_box_count(spmv_hip_ctx* ctx, int32_t n,
+                                 const int32_t first[3], const int32_t len[3],
+                                 int part, int32_t* rowptr, int64_t* host_nnz,
+                                 int64_t* num_ghosts, void* stream);
+int spmv_hip_poisson3d_box_fill_f64(spmv_hip_ctx* ctx, int32_t n,
+                                    const int32_t first[3], const int32_t len[3],
+                                    int part, const int32_t* rowptr,
+                                    int32_t* colind, double* values,
+                                    double* diagonal, void* stream);
 /* Seeded unstructured test matrix, generated on the device (not in the
  * reference: a synthetic input for measuring the general kernels on a matrix
  * WITHOUT lattice or narrow-band structure).  Square, `per_row` (1..32)

@@ -128,6 +128,10 @@ _PROTOS = {
     "spmv_hip_poisson3d_fill_f64": ([vp, i32, i64, i64, C.c_int, vp, vp, vp,
                                      vp, vp], C.c_int),
     "spmv_hip_poisson3d_ghosts": ([i32, i64, i64, P(i64), P(i64)], C.c_int),
+    "spmv_hip_poisson3d_box_count": ([vp, i32, vp, vp, C.c_int, vp, P(i64), P(i64),
+                                      vp], C.c_int),
+    "spmv_hip_poisson3d_box_fill_f64": ([vp, i32, vp, vp, C.c_int, vp, vp, vp, vp,
+                                         vp], C.c_int),
     "spmv_hip_unstructured_fill_f64": ([vp, i64, C.c_int, i64, C.c_int,
                                         C.c_uint64, vp, vp, vp, vp], C.c_int),
     "spmv_hip_fill_gaussian_f64": ([vp, i64, i64, i64, vp, vp], C.c_int),

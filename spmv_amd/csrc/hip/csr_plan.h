@@ -128,6 +128,10 @@ constexpr int kLxwPieces0 = 4;
 constexpr int kLxwRec = 20;        // ints per record (4 + 16)
 constexpr int kLxwAlign = 4;       // window starts: multiples of 4 columns
 
+// Lattice form (spmv_lat.hip)
+constexpr int kLatMaxOff = 8; // offsets per row block = mask bits
+constexpr int kLatRec = 12;   // ints per row-block record: count, 3 pad, offsets
+                              // (the offsets 16-byte aligned: one scalar load)
 // Wide diagonal form (spmv_wdia.hip): up to this many distinct col - row
 constexpr int kWdiaMaxOff = 32;
 

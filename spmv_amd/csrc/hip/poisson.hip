@@ -187,6 +187,126 @@ __global__ __launch_bounds__(kBlock) void unstructured_fill_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// The 7-point matrix on ONE BOX of a 3-D block partition (SURVEY 8f n4;
+// Matrix::create_poisson3d_boxes): rows = the box's points, x fastest, in the
+// rank-major global numbering (a rank's points are consecutive), so owned
+// columns are `row + {-lx ly, -lx, -1, 0, 1, lx, lx ly}` and the ghost columns
+// are the points one step outside the six faces.  Sorted by global id the
+// ghosts come face by face -- the neighbour ranks ascend in the order -z, -y,
+// -x, +x, +y, +z -- and inside a face in the neighbour's own local order,
+// which is the order of the two in-face coordinates: closed-form local column
+// numbers, no search.  Entry order within a row: owned columns ascending,
+// then ghost columns ascending, as create_matrix leaves them.
+// ---------------------------------------------------------------------------
+struct BoxGeom {
+  int32_t n;             // global grid
+  int32_t f[3], l[3];    // first point and extents of the box
+  int32_t has[6];        // a neighbour box behind face -z -y -x +x +y +z
+  int64_t ghost_base[6]; // first ghost (0-based) of that face
+  int64_t nloc, nghost;
+};
+
+__host__ __device__ inline int box_entries(const BoxGeom& g, int64_t k, int part,
+                                           int32_t* col, double* val, double skew)
+{
+  const int64_t lx = g.l[0], ly = g.l[1];
+  const int64_t x = k % lx, y = (k / lx) % ly, z = k / (lx * ly);
+  // stencil order = ascending column within each group (owned / ghost)
+  const int64_t delta[7] = {-lx * ly, -lx, -1, 0, 1, lx, lx * ly};
+  const bool inside[7] = {z > 0, y > 0, x > 0, true, x < lx - 1, y < ly - 1,
+                          z < g.l[2] - 1};
+  const int face[7] = {0, 1, 2, -1, 3, 4, 5};
+  // in-face index of the point behind each face
+  const int64_t inface[6] = {x + lx * y, x + lx * z, y + ly * z,
+                             y + ly * z, x + lx * z, x + lx * y};
+  int c = 0;
+  for (int pass = 0; pass < 2; ++pass)
+    for (int e = 0; e < 7; ++e) {
+      const bool owned = inside[e];
+      if (owned != (pass == 0))
+        continue;
+      if (!owned && !g.has[face[e]])
+        continue; // outside the global grid: dropped
+      const bool lower = e < 3;
+      bool keep_it;
+      switch (part) {
+      case SPMV_HIP_PART_ALL: keep_it = true; break;
+      case SPMV_HIP_PART_LOCAL: keep_it = owned; break;
+      case SPMV_HIP_PART_REMOTE: keep_it = !owned; break;
+      default: keep_it = owned && lower; break; // LOCAL_LOWER
+      }
+      if (!keep_it)
+        continue;
+      if (col) {
+        col[c] = owned ? (int32_t)(k + delta[e])
+                       : (int32_t)(g.nloc + g.ghost_base[face[e]]
+                                   + inface[face[e]]);
+        val[c] = e == 3 ? 6.0 : (lower ? -1.0 - skew : -1.0 + skew);
+      }
+      ++c;
+    }
+  return c;
+}
+
+__global__ __launch_bounds__(kBlock) void box_count_kernel(BoxGeom g, int part,
+                                                           int32_t* counts)
+{
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k <= g.nloc;
+       k += (int64_t)gridDim.x * blockDim.x)
+    counts[k] = k < g.nloc ? box_entries(g, k, part, nullptr, nullptr, 0.0) : 0;
+}
+
+__global__ __launch_bounds__(kBlock) void box_fill_kernel(
+    BoxGeom g, int part, const int32_t* __restrict__ rowptr,
+    int32_t* __restrict__ colind, double* __restrict__ values,
+    double* __restrict__ diagonal, double skew)
+{
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < g.nloc;
+       k += (int64_t)gridDim.x * blockDim.x) {
+    int32_t col[7];
+    double val[7];
+    const int c = box_entries(g, k, part, col, val, skew);
+    const int64_t pos = rowptr[k];
+    for (int e = 0; e < c; ++e) {
+      colind[pos + e] = col[e];
+      values[pos + e] = val[e];
+    }
+    if (diagonal)
+      diagonal[k] = 6.0;
+  }
+}
+
+int make_box(int32_t n, const int32_t first[3], const int32_t len[3], BoxGeom* g)
+{
+  if (n < 1 || !first || !len)
+    return SPMV_HIP_EINVAL;
+  for (int a = 0; a < 3; ++a) {
+    if (first[a] < 0 || len[a] < 1 || (int64_t)first[a] + len[a] > n)
+      return SPMV_HIP_EINVAL;
+    g->f[a] = first[a];
+    g->l[a] = len[a];
+  }
+  g->n = n;
+  g->nloc = (int64_t)len[0] * len[1] * len[2];
+  const int64_t area[6] = {(int64_t)len[0] * len[1], (int64_t)len[0] * len[2],
+                           (int64_t)len[1] * len[2], (int64_t)len[1] * len[2],
+                           (int64_t)len[0] * len[2], (int64_t)len[0] * len[1]};
+  const int axis[6] = {2, 1, 0, 0, 1, 2};
+  int64_t base = 0;
+  for (int s = 0; s < 6; ++s) {
+    const int a = axis[s];
+    g->has[s] = s < 3 ? first[a] > 0 : first[a] + len[a] < n;
+    g->ghost_base[s] = base;
+    if (g->has[s])
+      base += area[s];
+  }
+  g->nghost = base;
+  if (g->nloc + g->nghost > INT32_MAX || 7 * g->nloc > INT32_MAX)
+    return SPMV_HIP_ERANGE; // int32 columns and row pointer (csr_kernels.h:28)
+  return SPMV_HIP_OK;
+}
+
 int make_geom(int32_t n, int64_t r0, int64_t r1, Geom* g, int points = 7)
 {
   if (n < 1 || n > 1290) // n^3 rows must fit the int32 local index space
@@ -327,6 +447,76 @@ int spmv_hip_unstructured_fill_f64(spmv_hip_ctx* ctx, int64_t num_rows,
   hipLaunchKernelGGL(unstructured_fill_kernel, dim3(grid), dim3(kBlock), 0,
                      spmv_stream(ctx, stream), num_rows, per_row, band,
                      far_permille, seed, rowptr, colind, values);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_poisson3d_box_count(spmv_hip_ctx* ctx, int32_t n,
+                                 const int32_t first[3], const int32_t len[3],
+                                 int part, int32_t* rowptr, int64_t* host_nnz,
+                                 int64_t* num_ghosts, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(part >= SPMV_HIP_PART_ALL && part <= SPMV_HIP_PART_LOCAL_LOWER);
+  BoxGeom g;
+  int rc = make_box(n, first, len, &g);
+  if (rc)
+    return rc;
+  if (num_ghosts)
+    *num_ghosts = g.nghost;
+  if (!rowptr) // geometry query only
+    return SPMV_HIP_OK;
+  hipStream_t st = spmv_stream(ctx, stream);
+  const int grid = spmv_grid_for(ctx, g.nloc + 1, kBlock);
+  hipLaunchKernelGGL(box_count_kernel, dim3(grid), dim3(kBlock), 0, st, g, part,
+                     rowptr);
+  SPMV_CHECK_LAUNCH();
+  void* tmp = nullptr;
+  size_t tmp_bytes = 0;
+  SPMV_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(
+      nullptr, tmp_bytes, rowptr, rowptr, (int)(g.nloc + 1), st));
+  SPMV_CHECK_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+  hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, rowptr, rowptr,
+                                                  (int)(g.nloc + 1), st);
+  int32_t total = 0;
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(&total, rowptr + g.nloc, sizeof(int32_t),
+                       hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st);
+  (void)hipFree(tmp);
+  if (e != hipSuccess)
+    return static_cast<int>(e);
+  if (host_nnz)
+    *host_nnz = total;
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_poisson3d_box_fill_f64(spmv_hip_ctx* ctx, int32_t n,
+                                    const int32_t first[3], const int32_t len[3],
+                                    int part, const int32_t* rowptr,
+                                    int32_t* colind, double* values,
+                                    double* diagonal, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(rowptr && part >= SPMV_HIP_PART_ALL
+               && part <= SPMV_HIP_PART_LOCAL_LOWER);
+  BoxGeom g;
+  int rc = make_box(n, first, len, &g);
+  if (rc)
+    return rc;
+  if (!colind || !values) { // only if the part is empty (REMOTE on one rank)
+    int32_t total = 0;
+    SPMV_CHECK_HIP(hipMemcpy(&total, rowptr + g.nloc, sizeof(int32_t),
+                             hipMemcpyDeviceToHost));
+    SPMV_REQUIRE(total == 0);
+    if (!diagonal)
+      return SPMV_HIP_OK;
+  }
+  const int grid = spmv_grid_for(ctx, g.nloc, kBlock);
+  hipLaunchKernelGGL(box_fill_kernel, dim3(grid), dim3(kBlock), 0,
+                     spmv_stream(ctx, stream), g, part, rowptr, colind, values,
+                     diagonal, 1e-6 * (double)ctx->poisson_skew_ppm);
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;
 }

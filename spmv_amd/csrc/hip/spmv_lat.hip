@@ -62,9 +62,6 @@
 namespace
 {
 
-constexpr int kLatMaxOff = 8; // offsets per row block = mask bits
-constexpr int kLatRec = 12;   // ints per row-block record: count, 3 pad, offsets
-                              // (the offsets 16-byte aligned: one scalar load)
 // LDS slot for one row block's values: 256 rows x 8 entries plus the slack of
 // the 16-byte alignment of the first DMA piece, in whole 1-KiB DMA pieces
 constexpr int kLatSlotBytes = (kRows * kLatMaxOff * 8 + 1024);

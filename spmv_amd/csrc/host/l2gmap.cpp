@@ -112,6 +112,20 @@ L2GMap::L2GMap(std::shared_ptr<const Comm> comm, std::int64_t local_size,
     _direct_offset[i] = _recv_count[i] > 0 ? seg[0] : 0;
   }
 
+  // the argument lists of the grouped exchange, once: update() runs inside
+  // every CG iteration and must not build vectors there
+  {
+    const auto nn = static_cast<std::ptrdiff_t>(_neighbours.size());
+    _x_send_count.assign(_recv_count.begin(), _recv_count.begin() + nn);
+    _x_send_offset = _direct_send
+                         ? _direct_offset
+                         : std::vector<std::int32_t>(_recv_offset.begin(),
+                                                     _recv_offset.begin() + nn);
+    _x_recv_count.assign(_send_count.begin(), _send_count.begin() + nn);
+    _x_recv_offset.assign(_send_offset.begin(), _send_offset.begin() + nn);
+    _x_packed_offset.assign(_recv_offset.begin(), _recv_offset.begin() + nn);
+  }
+
   if (_num_indices > 0) { // :473-478
     _indexbuf = _exec->alloc<std::int32_t>(_num_indices);
     _exec->copy_from<std::int32_t>(_indexbuf, _exec->get_host(),
@@ -176,7 +190,6 @@ void L2GMap::start_exchange(T* vec) const
   _hip->stream_wait_event(_comm_stream, _ev_ready);
 
   const void* send_base = vec;
-  const std::vector<std::int32_t>* send_offs = &_direct_offset;
   if (!_direct_send) {
     const size_t need = sizeof(T) * static_cast<size_t>(_num_indices > 0 ? _num_indices : 1);
     if (_send_buf == nullptr || _send_buf_bytes < need) { // :607-614
@@ -195,20 +208,13 @@ void L2GMap::start_exchange(T* vec) const
     }
     _hip->set_stream(compute);
     send_base = _send_buf;
-    send_offs = &_recv_offset;
   }
   // receive straight into the ghost tail (:624-628), send packed or direct
-  // data (:630-634); one grouped call, ordered on the comm stream
-  std::vector<std::int32_t> soffs(send_offs->begin(),
-                                  send_offs->begin() + _neighbours.size());
-  std::vector<std::int32_t> scnt(_recv_count.begin(),
-                                 _recv_count.begin() + _neighbours.size());
-  std::vector<std::int32_t> rcnt(_send_count.begin(),
-                                 _send_count.begin() + _neighbours.size());
-  std::vector<std::int32_t> roffs(_send_offset.begin(),
-                                  _send_offset.begin() + _neighbours.size());
-  _comm->neighbor_exchange(sizeof(T), _neighbours, send_base, scnt, soffs, vec,
-                           rcnt, roffs, _comm_stream);
+  // data (:630-634); one grouped call, ordered on the comm stream; the
+  // argument lists were built with the plan
+  _comm->neighbor_exchange(sizeof(T), _neighbours, send_base, _x_send_count,
+                           _x_send_offset, vec, _x_recv_count, _x_recv_offset,
+                           _comm_stream);
   _hip->record_event(_ev_done, _comm_stream);
 }
 
@@ -258,14 +264,10 @@ void L2GMap::reverse_update(T* vec) const
   _hip->record_event(_ev_ready, compute);
   _hip->stream_wait_event(_comm_stream, _ev_ready);
   const size_t nn = _neighbours.size();
-  std::vector<std::int32_t> scnt(_send_count.begin(), _send_count.begin() + nn);
-  std::vector<std::int32_t> soffs(_send_offset.begin(),
-                                  _send_offset.begin() + nn);
-  std::vector<std::int32_t> rcnt(_recv_count.begin(), _recv_count.begin() + nn);
-  std::vector<std::int32_t> roffs(_recv_offset.begin(),
-                                  _recv_offset.begin() + nn);
-  _comm->neighbor_exchange(sizeof(T), _neighbours, vec, scnt, soffs, _send_buf,
-                           rcnt, roffs, _comm_stream);
+  // the forward lists with the roles swapped
+  _comm->neighbor_exchange(sizeof(T), _neighbours, vec, _x_recv_count,
+                           _x_recv_offset, _send_buf, _x_send_count,
+                           _x_packed_offset, _comm_stream);
   _hip->record_event(_ev_done, _comm_stream);
   _hip->stream_wait_event(compute, _ev_done);
   const T* staged = static_cast<const T*>(_send_buf);

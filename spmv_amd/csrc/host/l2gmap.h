@@ -97,6 +97,12 @@ private:
   bool _direct_send = false;
   std::vector<std::int32_t> _direct_offset;
 
+  // argument lists of the grouped exchange (one entry per neighbour), built
+  // with the plan: what this rank sends (counts, offsets into the vector or
+  // the packed buffer) and receives (counts, offsets into the ghost tail)
+  std::vector<std::int32_t> _x_send_count, _x_send_offset, _x_packed_offset;
+  std::vector<std::int32_t> _x_recv_count, _x_recv_offset;
+
   mutable void* _send_buf = nullptr; // lazily allocated (L2GMap.cpp:607-614)
   mutable size_t _send_buf_bytes = 0;
   void* _comm_stream = nullptr;

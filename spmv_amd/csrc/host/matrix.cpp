@@ -761,6 +761,30 @@ typename Matrix<T>::BoxRows Matrix<T>::poisson3d_box_rows(int32_t n, int px,
   return out;
 }
 
+namespace
+{
+DeviceBlock generate_box_block(HipExecutor& hip, int32_t n, const int32_t f[3],
+                               const int32_t l[3], int part, bool with_diagonal)
+{
+  DeviceBlock b;
+  const int64_t nrows = (int64_t)l[0] * l[1] * l[2];
+  b.rowptr = hip.alloc<int32_t>(nrows + 1);
+  throw_on_error(spmv_hip_poisson3d_box_count(hip.context(), n, f, l, part,
+                                              b.rowptr, &b.nnz, nullptr,
+                                              nullptr),
+                 "spmv_hip_poisson3d_box_count");
+  b.colind = hip.alloc<int32_t>(b.nnz);
+  b.values = hip.alloc<double>(b.nnz);
+  if (with_diagonal)
+    b.diagonal = hip.alloc<double>(nrows);
+  throw_on_error(spmv_hip_poisson3d_box_fill_f64(hip.context(), n, f, l, part,
+                                                 b.rowptr, b.colind, b.values,
+                                                 b.diagonal, nullptr),
+                 "spmv_hip_poisson3d_box_fill_f64");
+  return b;
+}
+} // namespace
+
 template <typename T>
 Matrix<T>* Matrix<T>::create_poisson3d_boxes(std::shared_ptr<const Comm> comm,
                                              std::shared_ptr<DeviceExecutor> exec,
@@ -771,10 +795,106 @@ Matrix<T>* Matrix<T>::create_poisson3d_boxes(std::shared_ptr<const Comm> comm,
   if (px * py * pz != comm->size())
     throw std::runtime_error(
         "create_poisson3d_boxes: px * py * pz must equal the number of ranks");
-  BoxRows b = poisson3d_box_rows(n, px, py, pz, comm->rank());
-  return create_matrix(comm, exec, b.rows.rowptr.data(), b.rows.colind.data(),
-                       b.rows.values.data(), b.rows.rows, b.rows.rows, {},
-                       b.col_ghosts, symmetric, cm);
+  auto* hip = dynamic_cast<HipExecutor*>(exec.get());
+  if constexpr (!std::is_same<T, double>::value) {
+    hip = nullptr;
+  }
+  if (!hip) { // rows on the host, through create_matrix
+    BoxRows b = poisson3d_box_rows(n, px, py, pz, comm->rank());
+    return create_matrix(comm, exec, b.rows.rowptr.data(), b.rows.colind.data(),
+                         b.rows.values.data(), b.rows.rows, b.rows.rows, {},
+                         b.col_ghosts, symmetric, cm);
+  }
+  if constexpr (std::is_same<T, double>::value) {
+    // The blocks are generated on the device (spmv_hip_poisson3d_box_*); the
+    // host only lists the ghost columns -- the points behind the six faces, in
+    // ascending global id: face by face (the neighbour ranks ascend in the
+    // order -z -y -x +x +y +z), inside a face in the neighbour's local order.
+    if (n < 1 || px < 1 || py < 1 || pz < 1 || px > n || py > n || pz > n)
+      throw std::runtime_error("create_poisson3d_boxes: bad partition");
+    const int P[3] = {px, py, pz};
+    auto box_of = [&](int r, int64_t first[3], int64_t len[3]) {
+      const int i[3] = {r % px, (r / px) % py, r / (px * py)};
+      for (int a = 0; a < 3; ++a)
+        axis_part(n, P[a], i[a], &first[a], &len[a]);
+    };
+    const int nranks = px * py * pz, me = comm->rank();
+    std::vector<int64_t> offset(nranks + 1, 0);
+    for (int r = 0; r < nranks; ++r) {
+      int64_t f[3], l[3];
+      box_of(r, f, l);
+      offset[r + 1] = offset[r] + l[0] * l[1] * l[2];
+    }
+    int64_t f[3], l[3];
+    box_of(me, f, l);
+    const int dr[6] = {-px * py, -px, -1, 1, px, px * py};
+    const int axis[6] = {2, 1, 0, 0, 1, 2};
+    std::vector<int64_t> ghosts;
+    for (int s = 0; s < 6; ++s) {
+      const int a = axis[s];
+      const bool has = s < 3 ? f[a] > 0 : f[a] + l[a] < n;
+      if (!has)
+        continue;
+      const int rn = me + dr[s];
+      int64_t fn[3], ln[3];
+      box_of(rn, fn, ln);
+      // the neighbour's layer that touches this box, its other two
+      // coordinates running over the shared face (u fastest)
+      const int64_t fixed = s < 3 ? ln[a] - 1 : 0;
+      const int u = a == 0 ? 1 : 0, v = a == 2 ? 1 : 2; // in-face axes, u < v
+      for (int64_t cv = 0; cv < l[v]; ++cv)
+        for (int64_t cu = 0; cu < l[u]; ++cu) {
+          int64_t c[3];
+          c[a] = fixed;
+          c[u] = cu;
+          c[v] = cv;
+          ghosts.push_back(offset[rn] + c[0] + ln[0] * (c[1] + ln[1] * c[2]));
+        }
+    }
+    const int64_t nloc = l[0] * l[1] * l[2];
+    if (nloc + (int64_t)ghosts.size() > INT32_MAX)
+      throw std::runtime_error("create_poisson3d_boxes: box too large");
+    const int32_t nrows = static_cast<int32_t>(nloc);
+    const int32_t ncols_all = static_cast<int32_t>(nloc + (int64_t)ghosts.size());
+    const int32_t f32[3] = {(int32_t)f[0], (int32_t)f[1], (int32_t)f[2]};
+    const int32_t l32[3] = {(int32_t)l[0], (int32_t)l[1], (int32_t)l[2]};
+
+    auto col_map = std::make_shared<L2GMap>(comm, nrows, ghosts, exec, cm);
+    auto row_map = std::make_shared<L2GMap>(comm, nrows, std::vector<int64_t>(),
+                                            exec);
+    std::unique_ptr<Matrix<T>> A(new Matrix<T>());
+    A->_exec = exec;
+    A->_col_map = col_map;
+    A->_row_map = row_map;
+    A->_symmetric = symmetric;
+    using Adopt = typename CSRMatrix<T>::AdoptDevice;
+    auto adopt = [&](const DeviceBlock& b, int32_t ncols, bool sym) {
+      return new CSRMatrix<T>(Adopt{}, exec, nrows, ncols, b.nnz, b.rowptr,
+                              b.colind, b.values, b.diagonal, sym);
+    };
+    auto gen = [&](int part, bool diag) {
+      return generate_box_block(*hip, n, f32, l32, part, diag);
+    };
+    if (symmetric) {
+      DeviceBlock L = gen(SPMV_HIP_PART_LOCAL_LOWER, true);
+      DeviceBlock R = gen(SPMV_HIP_PART_REMOTE, false);
+      A->_mat_local.reset(adopt(L, ncols_all, true));
+      A->_mat_remote.reset(adopt(R, ncols_all, false));
+      A->_nnz = 2 * L.nnz + R.nnz + nrows; // Matrix.cpp:443-444
+    } else if (nonblocking(cm)) {
+      DeviceBlock L = gen(SPMV_HIP_PART_LOCAL, false);
+      DeviceBlock R = gen(SPMV_HIP_PART_REMOTE, false);
+      A->_mat_local.reset(adopt(L, nrows, false));
+      A->_mat_remote.reset(adopt(R, ncols_all, false));
+      A->_nnz = L.nnz + R.nnz;
+    } else {
+      DeviceBlock B = gen(SPMV_HIP_PART_ALL, false);
+      A->_mat_local.reset(adopt(B, ncols_all, false));
+      A->_nnz = B.nnz;
+    }
+    return A.release();
+  }
+  return nullptr; // not reached
 }
 
 template class Matrix<float>;

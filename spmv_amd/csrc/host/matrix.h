@@ -135,7 +135,8 @@ public:
   // x-fastest order -- so that every rank still owns one contiguous row range,
   // as L2GMap requires.  The halo is the six faces of the box (surface, not
   // two full planes); it goes through the general pack / exchange path.  The
-  // rows are generated on the host and handed to create_matrix.
+  // blocks are generated on the device (spmv_hip_poisson3d_box_*; fp32 and
+  // host executors: rows on the host, handed to create_matrix).
   static Matrix<T>* create_poisson3d_boxes(
       std::shared_ptr<const Comm> comm, std::shared_ptr<DeviceExecutor> exec,
       int32_t n, int px, int py, int pz, bool symmetric = false,

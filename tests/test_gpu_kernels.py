@@ -408,6 +408,69 @@ def test_device_poisson_matches_host(ctx, n, P):
     blk.free()
 
 
+@pytest.mark.parametrize("n,parts", [(6, (2, 2, 2)), (7, (3, 2, 1)),
+                                     (9, (1, 2, 4)), (5, (1, 1, 1)),
+                                     (8, (4, 1, 2))])
+def test_device_box_generator_matches_host_rows(ctx, n, parts):
+    """spmv_hip_poisson3d_box_* (the blocks of Matrix::create_poisson3d_boxes,
+    generated on the device) against the host generator
+    Matrix::poisson3d_box_rows for every rank of the partition: same ghost
+    count, same rows (as sets of (column, value): the host lists a row by
+    GLOBAL column, the device in create_matrix's local order), columns
+    ascending within a row, and the LOCAL / REMOTE / LOCAL_LOWER parts the
+    matching subsets."""
+    from spmv_amd import host
+
+    def axis_part(n, p, i):
+        q, rem = divmod(n, p)
+        return i * q + min(i, rem), q + (1 if i < rem else 0)
+
+    px, py, pz = parts
+    for rank in range(px * py * pz):
+        rp_h, ci_h, va_h, ghosts, _, box = host.poisson3d_box_rows(n, parts, rank)
+        idx = (rank % px, (rank // px) % py, rank // (px * py))
+        fl = [axis_part(n, p, i) for p, i in zip(parts, idx)]
+        first = np.array([f for f, _ in fl], np.int32)
+        length = np.array([l for _, l in fl], np.int32)
+        assert tuple(length) == tuple(box)
+        nloc = int(np.prod(length))
+        fp, lp = first.ctypes.data_as(C.c_void_p), length.ctypes.data_as(C.c_void_p)
+        ng = C.c_int64()
+        hip.call("spmv_hip_poisson3d_box_count", ctx.h, n, fp, lp, hip.PART_ALL,
+                 None, None, C.byref(ng), None)
+        assert ng.value == len(ghosts)
+        got = {}
+        for part in (hip.PART_ALL, hip.PART_LOCAL, hip.PART_REMOTE,
+                     hip.PART_LOCAL_LOWER):
+            d_rp = ctx.empty(nloc + 1, np.int32)
+            nnz = C.c_int64()
+            hip.call("spmv_hip_poisson3d_box_count", ctx.h, n, fp, lp, part,
+                     d_rp.ptr, C.byref(nnz), None, None)
+            d_ci = ctx.empty(max(nnz.value, 1), np.int32)
+            d_va = ctx.empty(max(nnz.value, 1), np.float64)
+            d_dg = ctx.empty(nloc, np.float64)
+            hip.call("spmv_hip_poisson3d_box_fill_f64", ctx.h, n, fp, lp, part,
+                     d_rp.ptr, d_ci.ptr, d_va.ptr, d_dg.ptr, None)
+            got[part] = (d_rp.numpy(), d_ci.numpy()[:nnz.value],
+                         d_va.numpy()[:nnz.value])
+            assert np.all(d_dg.numpy() == 6.0)
+            for b in (d_rp, d_ci, d_va, d_dg):
+                b.free()
+        rp, ci, va = got[hip.PART_ALL]
+        assert np.array_equal(rp, rp_h)
+        for i in range(nloc):
+            dev = list(zip(ci[rp[i]:rp[i + 1]], va[rp[i]:rp[i + 1]]))
+            assert [c for c, _ in dev] == sorted(c for c, _ in dev), (rank, i)
+            hst = sorted(zip(ci_h[rp_h[i]:rp_h[i + 1]], va_h[rp_h[i]:rp_h[i + 1]]))
+            assert dev == hst, (rank, i)
+            for part, pred in ((hip.PART_LOCAL, lambda c: c < nloc),
+                               (hip.PART_REMOTE, lambda c: c >= nloc),
+                               (hip.PART_LOCAL_LOWER, lambda c: c < i)):
+                prp, pci, pva = got[part]
+                sub = list(zip(pci[prp[i]:prp[i + 1]], pva[prp[i]:prp[i + 1]]))
+                assert sub == [(c, v) for c, v in dev if pred(c)], (rank, i, part)
+
+
 def test_unstructured_generator_matches_numpy_twin(ctx):
     """spmv_hip_unstructured_fill_f64 (the benchmark's matrix without lattice
     structure) against spmv_amd.poisson.unstructured_csr: same arrays."""
