@@ -18,11 +18,12 @@ declare -A CGROUPS=(
   [sq]="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"
   [tcp]="TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum"
 )
-# PMC_GROUPS="ea write" runs a subset of the passes
+# PMC_GROUPS="ea write" runs a subset of the passes; PMC_SCRIPT=tools/prof_matrix.py
+# profiles the non-Poisson test matrices instead
 for g in ${PMC_GROUPS:-fetch write ea tcc sq tcp}; do
   rm -rf "/tmp/pmc_${TAG}_$g"
   rocprofv3 --pmc ${CGROUPS[$g]} --kernel-trace --output-format csv \
-      -d "/tmp/pmc_${TAG}_$g" -o p -- python3 "$ROOT/tools/prof_spmv.py" "$@" \
+      -d "/tmp/pmc_${TAG}_$g" -o p -- python3 "$ROOT/${PMC_SCRIPT:-tools/prof_spmv.py}" "$@" \
       > "/tmp/pmc_${TAG}_$g.log" 2>&1
   f=$(find "/tmp/pmc_${TAG}_$g" -name "*counter_collection.csv" | head -1)
   cp "$f" "$OUT/${TAG}_${g}_counter_collection.csv"

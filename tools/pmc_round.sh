@@ -1,0 +1,31 @@
+#!/bin/bash
+# All PMC passes behind bench.py's `traffic` fields, one record after the other
+# (run through gpurun; ~5 minutes), and the rocprofv3 kernel statistics of the
+# bench command itself.
+#   tools/pmc_round.sh r03
+set -euo pipefail
+R="$1"
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+OUT="$ROOT/gpurun_out/pmc_$R"
+export PMC_GROUPS="${PMC_GROUPS:-ea write tcc}"
+run() { # record grid script args...
+  local rec="$1" grid="$2" script="$3"; shift 3
+  PMC_SCRIPT="$script" "$ROOT/tools/pmc_passes.sh" "$OUT/$rec" "$rec" "$@"
+  python3 "$ROOT/tools/pmc_to_profiles.py" "$OUT/$rec" "$R" --grid "$grid" \
+      --record "$rec" --out-dir "$ROOT/gpurun_out/profiles_$R"
+}
+run main 512 tools/prof_spmv.py --n 512 --reps 6 --dot
+run symmetric 512 tools/prof_spmv.py --n 512 --reps 6 --dot --symmetric
+run csr_nonsymmetric_spmv 512 tools/prof_spmv.py --n 512 --reps 6 --asym
+run csr_lattice_spmv 512 tools/prof_spmv.py --n 512 --reps 6 --no-bake
+run csr_lx_spmv 512 tools/prof_spmv.py --n 512 --reps 6 --no-lat
+run csr_rowblock_spmv 512 tools/prof_spmv.py --n 512 --reps 6 --no-lx
+run stencil27_spmv 256 tools/prof_matrix.py --kind stencil27 --n 256
+run unstructured_spmv 10000000 tools/prof_matrix.py --kind unstructured --rows 10000000
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/rp_$R
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$R -o bench -- \
+    python3 "$ROOT/bench.py" --no-cpu-baseline > "$ROOT/gpurun_out/${R}_bench_under_rocprof.log" 2>&1
+cp "$(find /tmp/rp_$R -name '*kernel_stats.csv' | head -1)" \
+   "$ROOT/gpurun_out/${R}_rocprof_bench_n512_kernel_stats.csv"
+echo "pmc round $R done"

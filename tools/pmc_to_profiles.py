@@ -22,20 +22,36 @@ def main():
     ap.add_argument("round_tag")
     ap.add_argument("--grid", type=int, default=512)
     ap.add_argument("--note", default="")
+    ap.add_argument("--out-dir", default=os.path.join(ROOT, "profiles"),
+                    help="where the CSVs and the summary go (on a GPU box: a "
+                         "directory under gpurun_out/, copied to profiles/ later)")
+    ap.add_argument("--record", default=None,
+                    help="also file the (single) SpMV kernel of this directory "
+                         "under this bench.py record name: what bench.py looks "
+                         "up for the record's `traffic`")
     args = ap.parse_args()
     summ = json.loads(subprocess.check_output(
         [sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), args.pmc_dir]))
-    out_path = os.path.join(ROOT, "profiles", f"{args.round_tag}_pmc_summary.json")
+    os.makedirs(args.out_dir, exist_ok=True)
+    out_path = os.path.join(args.out_dir, f"{args.round_tag}_pmc_summary.json")
     doc = json.load(open(out_path)) if os.path.exists(out_path) else {"kernels": []}
+    doc.setdefault("kernels", [])
+    doc.setdefault("records", {})
+    doc.setdefault("note", "fabric bytes per launch from rocprofv3 PMC passes (one "
+                   "counter group per pass): reads = TCC_EA0_RDREQ_sum x 128 B "
+                   "(calibrated on the streaming dot product in the same passes), "
+                   "writes = WRITE_SIZE x 1 KiB; Infinity-Cache hits are counted")
     for tag, kernels in summ.items():
         files = []
         for f in sorted(glob.glob(os.path.join(args.pmc_dir, f"{tag}_*_counter_collection.csv"))):
             grp = os.path.basename(f).split("_")[-3]
             dst = f"{args.round_tag}_pmc_{tag}_{grp}_n{args.grid}.csv"
-            shutil.copy(f, os.path.join(ROOT, "profiles", dst))
+            shutil.copy(f, os.path.join(args.out_dir, dst))
             files.append(grp)
         for kname, c in kernels.items():
             if not kname.startswith("csr_"):
+                continue
+            if "TCC_EA0_RDREQ_sum" not in c or "WRITE_SIZE" not in c:
                 continue
             rd = c["TCC_EA0_RDREQ_sum"] * 128.0
             wr = c["WRITE_SIZE"] * 1024.0
@@ -49,7 +65,8 @@ def main():
                 "TCC_REQ": c.get("TCC_REQ_sum"), "TCC_HIT": c.get("TCC_HIT_sum"),
                 "TCC_MISS": c.get("TCC_MISS_sum"),
                 "avg_ea_read_latency_cycles":
-                    c["TCC_EA0_RDREQ_LEVEL_sum"] / c["TCC_EA0_RDREQ_sum"],
+                    (c["TCC_EA0_RDREQ_LEVEL_sum"] / c["TCC_EA0_RDREQ_sum"]
+                     if "TCC_EA0_RDREQ_LEVEL_sum" in c else None),
                 "ms_profiled": c["_ms_profiled"],
                 "source": f"profiles/{args.round_tag}_pmc_{tag}_{{{','.join(files)}}}"
                           f"_n{args.grid}.csv" + (f" ({args.note})" if args.note else ""),
@@ -57,6 +74,8 @@ def main():
             doc["kernels"] = [k for k in doc["kernels"]
                               if not (k["kernel_prefix"] == kname
                                       and k["grid"] == args.grid)] + [rec]
+            if args.record:
+                doc["records"][args.record] = rec
     json.dump(doc, open(out_path, "w"), indent=1)
     print("updated", out_path)
 
