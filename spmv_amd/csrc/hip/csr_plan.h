@@ -104,6 +104,28 @@ __device__ __forceinline__ int order_slot_raw(const RowBlockOrder& ord, int it,
   o.num_row_blocks = INT32_MAX; // bounds are checked by decode
   return order_row_block(o, it);
 }
+// The same with the SOURCE of the entry fixed at compile time (TAB: the order
+// table).  The two sources must not share a register in one kernel: a table
+// entry is a loaded value, and before the computed alternative may overwrite
+// that register the compiler waits for every load in flight -- including the
+// LDS-DMA pieces a step has just issued, which serialises the step (found in
+// round 3: it cost the lattice kernels their prefetch whenever no table was
+// in use).
+template <bool TAB>
+__device__ __forceinline__ int order_slot_raw_t(const RowBlockOrder& ord, int it,
+                                                int num_slots)
+{
+  if (it >= num_slots)
+    return -1;
+  if constexpr (TAB) {
+    return ord.table[it];
+  } else {
+    RowBlockOrder o = ord;
+    o.table = nullptr;
+    o.num_row_blocks = INT32_MAX; // bounds are checked by decode
+    return order_row_block(o, it);
+  }
+}
 __device__ __forceinline__ int order_slot_decode(const RowBlockOrder& ord,
                                                  int raw)
 {

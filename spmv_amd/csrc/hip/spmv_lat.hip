@@ -96,7 +96,59 @@ struct LatRegs {
 struct LatBlock {
   int rb;       // row block, -1 = none
   int64_t a, b; // its span in `values`
+  // the block's record (uniform): where a zero offset sits, the entries in
+  // front of the waves 1..3, the offsets
+  int k0;
+  int32_t c12, c3;
+  i32x8 D;
 };
+
+// A block's record and span travel as ONE vector load (lane l < 12: word l of
+// the record; lanes 12, 13: the row pointer at the block's first row and
+// behind its last) issued a whole step before they are needed, and are taken
+// apart with v_readlane right behind the step's wait.  Scalar loads would
+// share their counter with the LDS reads of the row sums, which then wait for
+// a record coming from HBM (see csr_lxw_kernel).
+__device__ __forceinline__ int32_t lat_fetch(int rb, int32_t num_rows,
+                                             const int32_t* __restrict__ rowptr,
+                                             const int32_t* __restrict__ tab)
+{
+  int32_t w = 0;
+  if (rb >= 0) {
+    const int l = (int)(threadIdx.x & 63);
+    const int32_t r0 = rb * kRows;
+    const int nr = min(kRows, num_rows - r0);
+    const int32_t* p = l < kLatRec ? tab + (int64_t)rb * kLatRec + l
+                                   : rowptr + (l == kLatRec ? r0 : r0 + nr);
+    if (l <= kLatRec + 1)
+      w = *p;
+  }
+  return w;
+}
+
+__device__ __forceinline__ LatBlock lat_decode(int rb, int32_t w)
+{
+  LatBlock blk;
+  blk.rb = -1;
+  blk.a = blk.b = 0;
+  blk.k0 = 0;
+  blk.c12 = blk.c3 = 0;
+#pragma unroll
+  for (int k = 0; k < kLatMaxOff; ++k)
+    blk.D[k] = 0;
+  if (rb >= 0) {
+    blk.rb = rb;
+    blk.k0 = __builtin_amdgcn_readlane(w, 1);
+    blk.c12 = __builtin_amdgcn_readlane(w, 2);
+    blk.c3 = __builtin_amdgcn_readlane(w, 3);
+#pragma unroll
+    for (int k = 0; k < kLatMaxOff; ++k)
+      blk.D[k] = __builtin_amdgcn_readlane(w, 4 + k);
+    blk.a = __builtin_amdgcn_readlane(w, kLatRec);
+    blk.b = __builtin_amdgcn_readlane(w, kLatRec + 1);
+  }
+  return blk;
+}
 
 // Plane chain (`chain` > 0, uniform): the block lies exactly `chain` rows -- one
 // lattice plane -- behind `prev_rb`, whose loads are `prev`.  Then its x[r]
@@ -105,9 +157,9 @@ struct LatBlock {
 template <typename T, bool DOT>
 __device__ __forceinline__ LatRegs<T> lat_loads(
     const LatBlock& blk, int t, int32_t num_rows, int32_t num_cols,
-    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ tab,
     const uint8_t* __restrict__ mask, const T* __restrict__ in, T beta,
-    const T* __restrict__ out, int chain, int prev_rb, const LatRegs<T>& prev)
+    const T* __restrict__ out, int chain, const LatBlock& pblk,
+    const LatRegs<T>& prev)
 {
   LatRegs<T> g;
   g.wbase = 0;
@@ -122,18 +174,15 @@ __device__ __forceinline__ LatRegs<T> lat_loads(
   const int32_t r0 = blk.rb * kRows;
   const int32_t r = r0 + t;
   if (r < num_rows) {
-    // the block's record: one 16-byte and one 32-byte scalar load
-    const int32_t* rec = tab + (int64_t)blk.rb * kLatRec;
-    const i32x8 D = *reinterpret_cast<const i32x8*>(rec + 4);
-    g.k0 = rec[1]; // position of a zero offset in D, or -1
-    const int32_t c12 = rec[2], c3 = rec[3];
+    const i32x8 D = blk.D;
+    g.k0 = blk.k0; // position of a zero offset in D, or -1
+    const int32_t c12 = blk.c12, c3 = blk.c3;
     const int w = t >> 6;
     g.wbase = w == 0 ? 0 : (w == 1 ? (c12 & 0xffff) : (w == 2 ? (c12 >> 16) : c3));
     g.m = mask[r];
     T x_ahead = T(0), x_here = prev.x_own;
     if (chain > 0) { // what the previous block holds for this one
-      const i32x8 Dp = *reinterpret_cast<const i32x8*>(
-          tab + (int64_t)prev_rb * kLatRec + 4);
+      const i32x8 Dp = pblk.D;
       bool have_ahead = false, have_here = prev.k0 < 0 && DOT;
 #pragma unroll
       for (int k = 0; k < kLatMaxOff; ++k) {
@@ -171,25 +220,10 @@ __device__ __forceinline__ LatRegs<T> lat_loads(
   return g;
 }
 
-// row block rb (-1: an empty slot) and its span in `values`: two scalar loads
-__device__ __forceinline__ LatBlock lat_block(int rb, int32_t num_rows,
-                                              const int32_t* __restrict__ rowptr)
-{
-  LatBlock blk{-1, 0, 0};
-  if (rb >= 0) {
-    const int32_t r0 = rb * kRows;
-    const int nr = min(kRows, num_rows - r0);
-    blk.rb = rb;
-    blk.a = rowptr[r0];
-    blk.b = rowptr[r0 + nr];
-  }
-  return blk;
-}
-
 // TV = type of `values` (what is streamed), T = type of x, y and of all the
 // arithmetic.  TV = float with T = double is the mixed-precision SpMV (SURVEY
 // 8f n3): half the matrix bytes, every product and sum still in fp64.
-template <typename TV, typename T, bool DOT, bool NT>
+template <typename TV, typename T, bool DOT, bool NT, bool TAB>
 __global__ __launch_bounds__(kBlock) void csr_lattice_kernel(
     int32_t num_rows, int32_t num_cols, int64_t nnz,
     const int32_t* __restrict__ rowptr, const TV* __restrict__ values,
@@ -213,22 +247,30 @@ __global__ __launch_bounds__(kBlock) void csr_lattice_kernel(
   // has landed; its span is fetched in the current step), and the one after
   // that (table entry requested in the current step).
   int it = blockIdx.x;
-  LatBlock cur = lat_block(
-      order_slot_decode(ord, order_slot_raw(ord, it, num_slots)), num_rows,
-      rowptr);
-  LatBlock nxt = lat_block(
-      order_slot_decode(ord, order_slot_raw(ord, it + stride, num_slots)),
-      num_rows, rowptr);
-  int nn_raw = order_slot_raw(ord, it + 2 * stride, num_slots);
+  LatBlock cur;
+  int nxt_rb;
+  int32_t nxt_w; // the next block's record, in flight
+  {
+    const int rb0 = order_slot_decode(ord, order_slot_raw_t<TAB>(ord, it, num_slots));
+    nxt_rb = order_slot_decode(ord, order_slot_raw_t<TAB>(ord, it + stride, num_slots));
+    const int32_t w0 = lat_fetch(rb0, num_rows, rowptr, tab);
+    nxt_w = lat_fetch(nxt_rb, num_rows, rowptr, tab);
+    cur = lat_decode(rb0, w0);
+  }
+  int nn_raw = order_slot_raw_t<TAB>(ord, it + 2 * stride, num_slots);
   if (cur.rb >= 0 && cur.b > cur.a)
     lat_issue_dma<TV, NT>(values, nnz, cur.a & ~(int64_t)(V - 1), cur.b, s_val,
                           t);
   LatRegs<T> gB;
   gB.k0 = 0;
   gB.x_own = T(0);
-  LatRegs<T> gA = lat_loads<T, DOT>(cur, t, num_rows, num_cols, rowptr, tab,
-                                    mask, in, beta, out, 0, 0, gB);
+  LatRegs<T> gA = lat_loads<T, DOT>(cur, t, num_rows, num_cols, mask, in, beta,
+                                    out, 0, cur, gB);
   int slot = 0;
+  // y is stored one step late, right behind the next step's wait (which
+  // covers stores too): see csr_lxw_kernel
+  T y_late = T(0);
+  int32_t r_late = -1;
   // one step: sums block `cur` out of registers g, loads block `nxt` into gn
   auto step = [&](const LatRegs<T>& g, LatRegs<T>& gn) {
     // Everything this wave has in flight (block k's DMA pieces and loads, the
@@ -239,6 +281,10 @@ __global__ __launch_bounds__(kBlock) void csr_lattice_kernel(
     // the DMA pieces issued there.)
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
     __syncthreads();
+    if (r_late >= 0)
+      out[r_late] = y_late;
+    r_late = -1;
+    const LatBlock nxt = lat_decode(nxt_rb, nxt_w);
     if (nxt.rb >= 0 && nxt.b > nxt.a)
       lat_issue_dma<TV, NT>(values, nnz, nxt.a & ~(int64_t)(V - 1), nxt.b,
                             s_val + (slot ^ 1) * SLOT, t);
@@ -247,13 +293,13 @@ __global__ __launch_bounds__(kBlock) void csr_lattice_kernel(
                        && (nxt.rb - cur.rb) * kRows == chain_rows)
                           ? chain_rows
                           : 0;
-    gn = lat_loads<T, DOT>(nxt, t, num_rows, num_cols, rowptr, tab, mask, in,
-                           beta, out, chain, cur.rb, g);
+    gn = lat_loads<T, DOT>(nxt, t, num_rows, num_cols, mask, in, beta, out,
+                           chain, cur, g);
     // the block after the next one: its table entry has landed with the wait
-    // above; the row-pointer loads (scalar) are needed an iteration from now
-    const LatBlock nn = lat_block(order_slot_decode(ord, nn_raw), num_rows,
-                                  rowptr);
-    const int nnn_raw = order_slot_raw(ord, it + 3 * stride, num_slots);
+    // above; its record is needed a step from now
+    const int nn_rb = order_slot_decode(ord, nn_raw);
+    const int32_t nn_w = lat_fetch(nn_rb, num_rows, rowptr, tab);
+    const int nnn_raw = order_slot_raw_t<TAB>(ord, it + 3 * stride, num_slots);
     const int32_t r = cur.rb * kRows + t;
     if (cur.rb >= 0 && r < num_rows) {
       // the row's first entry: block start + entries of the earlier waves +
@@ -287,7 +333,8 @@ __global__ __launch_bounds__(kBlock) void csr_lattice_kernel(
       T y = c;
       if (beta != T(0))
         y = c + beta * g.y0;
-      out[r] = y;
+      y_late = y;
+      r_late = r;
       if constexpr (DOT) {
         T xo = g.x_own;
 #pragma unroll
@@ -299,7 +346,8 @@ __global__ __launch_bounds__(kBlock) void csr_lattice_kernel(
     }
     slot ^= 1;
     cur = nxt;
-    nxt = nn;
+    nxt_rb = nn_rb;
+    nxt_w = nn_w;
     nn_raw = nnn_raw;
     it += stride;
   };
@@ -311,6 +359,8 @@ __global__ __launch_bounds__(kBlock) void csr_lattice_kernel(
       break;
     step(gB, gA);
   }
+  if (r_late >= 0)
+    out[r_late] = y_late;
   if constexpr (DOT)
     spmv_dot_epilogue(dot, dot_acc, s_red);
 }
@@ -460,16 +510,15 @@ int lat_launch(const spmv_hip_csr_plan* pl, hipStream_t st,
                           && pl->lattice_d2 % kRows == 0)
                              ? pl->lattice_d2
                              : 0;
-  if (pl->nontemporal)
-    hipLaunchKernelGGL((csr_lattice_kernel<TV, T, DOT, true>), dim3(grid),
-                       dim3(kBlock), 0, st, pl->num_rows, pl->num_cols, pl->nnz,
-                       rowptr, values, pl->lat_tab, pl->lat_mask, alpha, in,
-                       beta, out, dot, ord, chain_rows);
-  else
-    hipLaunchKernelGGL((csr_lattice_kernel<TV, T, DOT, false>), dim3(grid),
-                       dim3(kBlock), 0, st, pl->num_rows, pl->num_cols, pl->nnz,
-                       rowptr, values, pl->lat_tab, pl->lat_mask, alpha, in,
-                       beta, out, dot, ord, chain_rows);
+  auto kern = ord.table
+                  ? (pl->nontemporal ? csr_lattice_kernel<TV, T, DOT, true, true>
+                                     : csr_lattice_kernel<TV, T, DOT, false, true>)
+                  : (pl->nontemporal
+                         ? csr_lattice_kernel<TV, T, DOT, true, false>
+                         : csr_lattice_kernel<TV, T, DOT, false, false>);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, st, pl->num_rows,
+                     pl->num_cols, pl->nnz, rowptr, values, pl->lat_tab,
+                     pl->lat_mask, alpha, in, beta, out, dot, ord, chain_rows);
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;
 }

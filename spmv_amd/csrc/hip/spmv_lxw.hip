@@ -221,18 +221,7 @@ __global__ __launch_bounds__(kBlock) void csr_lxw_kernel(
   };
 
   // slot -> row block (raw: before the bounds check of order_slot_decode)
-  auto slot_raw = [&](int i) {
-    if (i >= num_slots)
-      return -1;
-    if constexpr (TAB) {
-      return ord.table[i];
-    } else {
-      RowBlockOrder o = ord;
-      o.table = nullptr;
-      o.num_row_blocks = INT32_MAX;
-      return order_row_block(o, i);
-    }
-  };
+  auto slot_raw = [&](int i) { return order_slot_raw_t<TAB>(ord, i, num_slots); };
   int it = blockIdx.x;
   LxwBlock cur;
   int nxt_rb;

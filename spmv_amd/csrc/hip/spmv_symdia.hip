@@ -171,7 +171,8 @@ __device__ __forceinline__ SdiaRegs<T> sdia_loads(
 // TV = type of the baked values (what is streamed), T = type of x, y and of all
 // the arithmetic.  TV = float with T = double is the mixed-precision SpMV
 //  on the diagonal form: 17 instead of 33 B of matrix data per row.
-template <typename TV, typename T, bool DOT, bool RING, bool GEN>
+// TAB: the row-block order comes from a table (see order_slot_raw_t).
+template <typename TV, typename T, bool DOT, bool RING, bool GEN, bool TAB>
 __global__ __launch_bounds__(kBlock) void csr_sym_dia_kernel(
     int32_t num_rows, int64_t arr_len, const TV* __restrict__ sval,
     const uint8_t* __restrict__ cmask, T alpha, const T* __restrict__ in, T beta,
@@ -236,8 +237,8 @@ __global__ __launch_bounds__(kBlock) void csr_sym_dia_kernel(
   int R0 = 0, R1 = 1, R2 = 2, R3 = 3; // ring: own, far, free, free
 
   int it = blockIdx.x;
-  int cur = order_slot_decode(ord, order_slot_raw(ord, it, num_slots));
-  int nxt_raw = order_slot_raw(ord, it + stride, num_slots);
+  int cur = order_slot_decode(ord, order_slot_raw_t<TAB>(ord, it, num_slots));
+  int nxt_raw = order_slot_raw_t<TAB>(ord, it + stride, num_slots);
   if (cur >= 0) {
     issue(cur, 0);
     if constexpr (RING) {
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(kBlock) void csr_sym_dia_kernel(
     __syncthreads();
     store_late();
     const int nxt = order_slot_decode(ord, nxt_raw);
-    const int nn_raw = order_slot_raw(ord, it + 2 * stride, num_slots);
+    const int nn_raw = order_slot_raw_t<TAB>(ord, it + 2 * stride, num_slots);
     const bool chain = g.chain_blocks > 0 && cur >= 0 && nxt >= 0
                        && nxt - cur == g.chain_blocks;
     if (nxt >= 0) {
@@ -632,20 +633,27 @@ int sdia_launch(const spmv_hip_csr_plan* pl, hipStream_t st, const TV* sval,
     ord.table = pl->zw_table;
     ord.num_slots = pl->zw_slots;
   }
-#define SPMV_SDIA(DOTV, RINGV)                                                 \
+#define SPMV_SDIA_T(DOTV, RINGV, TABV)                                         \
   do {                                                                         \
     if (pl->sdia_general)                                                      \
-      hipLaunchKernelGGL((csr_sym_dia_kernel<TV, T, DOTV, RINGV, true>),       \
+      hipLaunchKernelGGL((csr_sym_dia_kernel<TV, T, DOTV, RINGV, true, TABV>), \
                          dim3(grid), dim3(kBlock), lds, st, pl->num_rows,      \
                          pl->sdia_len, sval, cmask, alpha, in, beta, out, dot, \
                          ord, g);                                              \
     else if constexpr (sizeof(TV) == sizeof(T))                                \
-      hipLaunchKernelGGL((csr_sym_dia_kernel<TV, T, DOTV, RINGV, false>),      \
+      hipLaunchKernelGGL((csr_sym_dia_kernel<TV, T, DOTV, RINGV, false, TABV>),\
                          dim3(grid), dim3(kBlock), lds, st, pl->num_rows,      \
                          pl->sdia_len, sval, cmask, alpha, in, beta, out, dot, \
                          ord, g);                                              \
     else                                                                       \
       return SPMV_HIP_ENOTSUP; /* mixed precision: general storage only */     \
+  } while (0)
+#define SPMV_SDIA(DOTV, RINGV)                                                 \
+  do {                                                                         \
+    if (ord.table)                                                             \
+      SPMV_SDIA_T(DOTV, RINGV, true);                                          \
+    else                                                                       \
+      SPMV_SDIA_T(DOTV, RINGV, false);                                         \
   } while (0)
   if (dot.partials) {
     if (g.ring)
@@ -659,6 +667,7 @@ int sdia_launch(const spmv_hip_csr_plan* pl, hipStream_t st, const TV* sval,
       SPMV_SDIA(false, false);
   }
 #undef SPMV_SDIA
+#undef SPMV_SDIA_T
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;
 }
