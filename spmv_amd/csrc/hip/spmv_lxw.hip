@@ -58,7 +58,10 @@
 // Dropped after measuring: copying the two window pieces a block shares with
 // its predecessor in the plane walk inside LDS instead of fetching them again
 // (plan-time inheritance table; 11.93 against 12.04 GB of fabric reads -- the
-// L2 already served them -- and 1-7 % slower).
+// L2 already served them -- and 1-7 % slower); the values two row blocks ahead
+// instead of one (three value slots, 75 KiB per workgroup, still two per CU:
+// 2.51 against 2.54 ms at 512^3, 3 % slower at 128^3 and 384^3 -- the bytes a
+// workgroup has in flight are not what bounds the kernel either).
 #include "csr_plan.h"
 #include "lat_dma.h"
 
