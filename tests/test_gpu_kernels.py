@@ -1756,6 +1756,58 @@ def test_wide_diagonal_form_bit_exact(lat_ctx, dtype):
         blk.free()
 
 
+def test_wide_diagonal_form_fuzz(lat_ctx):
+    """Random offset sets (4-32 offsets anywhere up to the matrix size), sizes
+    around the row-block boundaries, rectangular blocks, random drops, empty
+    rows: whatever the wide diagonal form accepts it must compute bit-exactly;
+    what it refuses stays on the CSR-order kernels, bit-exact too."""
+    ctx = lat_ctx
+    rng = np.random.default_rng(int(os.environ.get("SPMV_FUZZ_SEED", "3303")))
+    sizes = [1, 2, 255, 256, 257, 511, 513, 1000, 4097, 20000]
+    taken = 0
+    for case in range(int(os.environ.get("SPMV_FUZZ_TRIALS", "40"))):
+        N = int(rng.choice(sizes))
+        K = int(rng.integers(4, 33))
+        span = max(2, int(rng.choice([8, 40, N // 3 + 2, N])))
+        offs = sorted(set(int(o) for o in rng.integers(-span, span + 1, K)))
+        drop = float(rng.choice([0.0, 0.1, 0.4]))
+        rp, ci, va = _stencil_csr(rng, N, offs, drop=drop)
+        ncols = N + int(rng.choice([0, 0, 7]))  # sometimes a few spare columns
+        if len(ci) == 0:
+            continue
+        if rng.random() < 0.3:  # a stretch of empty rows
+            lo = int(rng.integers(0, N))
+            hi = min(N, lo + int(rng.integers(1, 300)))
+            keep = np.ones(len(ci), bool)
+            keep[rp[lo]:rp[hi]] = False
+            cnt = np.diff(rp)
+            cnt[lo:hi] = 0
+            rp = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+            ci, va = ci[keep], va[keep]
+            if len(ci) == 0:
+                continue
+        x = rng.uniform(-1, 1, ncols)
+        y0 = rng.uniform(-1, 1, N)
+        alpha, beta = float(rng.choice([1.0, -0.5])), float(rng.choice([0.0, 0.75]))
+        y_ref = oracle.csr_spmv(rp, ci, va, x, alpha, beta, y0)
+        blk = hip.CsrBlock(ctx, N, ncols, rp, ci, va, None, False,
+                           hip.ALGO_ROWBLOCK)
+        try:
+            blk.bake()
+        except Exception:
+            pass
+        taken += blk.get("wdia")
+        dx = ctx.upload(x)
+        dy = ctx.upload(np.full(N, np.nan) if beta == 0 else y0)
+        blk.mult(alpha, dx.ptr, beta, dy.ptr)
+        assert np.array_equal(dy.numpy(), y_ref), (case, N, offs, drop,
+                                                   blk.get("wdia"),
+                                                   blk.get("sdia"))
+        dx.free(), dy.free()
+        blk.free()
+    assert taken >= 5  # the form is exercised, not just refused
+
+
 def test_wide_diagonal_form_is_refused_when_it_does_not_apply(lat_ctx):
     """33 diagonals, a row with a repeated column, a row whose columns do not
     ascend, arrays that would be mostly zeros: ENOTSUP, the CSR-order kernels

@@ -634,3 +634,34 @@ def test_plane_walk_table(n, grid, segments):
                 assert mine == list(range(mine[0], mine[0] + 8))
     with pytest.raises(Exception):
         _zwalk_table(rows, 0, grid)
+
+
+def test_synthetic_generators_numpy_twins():
+    """spmv_amd/poisson.py: the 27-point operator against an independent
+    scipy construction (Kronecker sums of 1-D neighbour matrices), and the
+    seeded unstructured matrix's promises (shape, sorted rows, share of far
+    entries, determinism) -- the GPU tests compare the device generators with
+    these twins array for array."""
+    import scipy.sparse as sp
+    from spmv_amd import poisson
+    for n in (3, 4, 7):
+        rp, ci, va = poisson.stencil27_csr(n)
+        A = sp.csr_matrix((va, ci, rp), shape=(n ** 3, n ** 3))
+        t1 = sp.diags([np.ones(n - 1), np.ones(n), np.ones(n - 1)], [-1, 0, 1])
+        B = sp.kron(sp.kron(t1, t1), t1).tocsr()  # 1 wherever |dx|,|dy|,|dz| <= 1
+        want = (27.0 * sp.identity(n ** 3) - B).tocsr()  # diag 26, neighbours -1
+        assert abs(A - want).max() == 0
+        assert len(va) == poisson.stencil27_nnz(n)
+        assert np.all(np.diff(ci)[np.diff(np.repeat(np.arange(n ** 3),
+                                                    np.diff(rp))) == 0] > 0)
+    N = 20000
+    rp, ci, va = poisson.unstructured_csr(N)
+    rp2, ci2, va2 = poisson.unstructured_csr(N)
+    assert np.array_equal(ci, ci2) and np.array_equal(va, va2)
+    assert np.array_equal(rp, np.arange(N + 1) * 7) and len(ci) == 7 * N
+    rows = ci.reshape(N, 7)
+    assert np.all(np.diff(rows, axis=1) >= 0) and rows.min() >= 0 and rows.max() < N
+    far = np.abs(rows - np.arange(N)[:, None]) > 2048
+    assert 0.05 < far.mean() < 0.12 and -1 <= va.min() and va.max() < 1
+    assert not np.array_equal(ci, poisson.unstructured_csr(N, seed=1)[1])
+
