@@ -16,10 +16,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=512)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--skew", type=int, default=0,
+                    help="poisson_skew_ppm: a matrix that is NOT symmetric")
     args = ap.parse_args()
     exec_ = host.HipExecutor(0)
     comm = host.Comm.self_comm()
-    for symmetric in (False, True):
+    if args.skew:
+        from spmv_amd import _lib
+        _lib.call("spmv_hip_ctx_set_option", exec_.context, b"poisson_skew_ppm",
+                  args.skew)
+    for symmetric in ((False,) if args.skew else (False, True)):
         for rep in range(args.reps):
             exec_.synchronize()
             t0 = time.perf_counter()
