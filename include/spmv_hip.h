@@ -38,7 +38,9 @@ enum {
   SPMV_HIP_EINVAL = -1,   /* bad argument (null handle, negative size, ...) */
   SPMV_HIP_ENOMEM = -2,   /* host allocation failed                         */
   SPMV_HIP_ENOTSUP = -3,  /* feature not available in this build           */
-  SPMV_HIP_ERANGE = -4    /* size exceeds a 32-bit index the format fixes  */
+  SPMV_HIP_ERANGE = -4,   /* size exceeds a 32-bit index the format fixes  */
+  SPMV_HIP_EPEER = -5     /* one-sided halo: a neighbour did not answer in
+                             time (an earlier exchange of this window failed) */
 };
 
 typedef struct spmv_hip_ctx spmv_hip_ctx;           /* one GPU             */
@@ -487,6 +489,40 @@ int spmv_hip_fill_gaussian_f64(spmv_hip_ctx* ctx, int64_t N, int64_t i_begin,
                                int64_t count, double* x, void* stream);
 int spmv_hip_fill_const_f64(spmv_hip_ctx* ctx, int64_t count, double value,
                             double* x, void* stream);
+
+/* ---- one-sided halo: peer stores into a neighbour's window -----------------
+ * The reference's onesided_put_* models (MPI_Put into a window,
+ * L2GMap.cpp:645-682).  Every rank owns a window = a staging buffer for its
+ * ghost tail (stage_bytes, sized for 8-byte elements) + flag words; it is
+ * exported as a HIP IPC handle (ranks in other processes) and by address (ranks
+ * that are threads of this process).  A rank connects each neighbour once
+ * (where its data goes in the neighbour's staging buffer, which slot it has in
+ * the neighbour's flags, which segments it sends / receives; offsets and
+ * counts in ELEMENTS), then every exchange is one kernel launch on `stream`:
+ * signal "my segment is free", wait for the neighbour's, store the send
+ * segment into the neighbour's window, raise its data flag, wait for mine, copy
+ * the staging buffer into `ghost_tail`.  Waits are bounded (about 4 s): a
+ * neighbour that does not answer makes THIS and every later exchange of the
+ * window fail with SPMV_HIP_EPEER (put_status) instead of hanging.
+ * Validated on one device only (processes sharing a GPU through IPC, and
+ * threads); see spmv_amd/csrc/hip/put.hip. */
+#define SPMV_HIP_IPC_HANDLE_BYTES 64
+#define SPMV_HIP_PUT_MAX_PEERS 16
+typedef struct spmv_hip_put spmv_hip_put;
+int spmv_hip_put_create(spmv_hip_ctx* ctx, size_t stage_bytes,
+                        spmv_hip_put** put, void* ipc_handle,
+                        uint64_t* raw_address, int64_t* process_id);
+int spmv_hip_put_connect(spmv_hip_put* put, int k, const void* peer_ipc_handle,
+                         uint64_t peer_raw_address, int64_t peer_process_id,
+                         size_t peer_stage_bytes, int32_t dst_offset,
+                         int32_t slot_at_peer, int32_t send_offset,
+                         int32_t send_count, int32_t recv_offset,
+                         int32_t recv_count);
+int spmv_hip_put_finish(spmv_hip_put* put);
+int spmv_hip_put_exchange(spmv_hip_ctx* ctx, spmv_hip_put* put, size_t elem_bytes,
+                          const void* send_buf, void* ghost_tail, void* stream);
+int spmv_hip_put_status(const spmv_hip_put* put, int* failed);
+int spmv_hip_put_destroy(spmv_hip_put* put);
 
 /* ---- RCCL transport (L2GMap::update p2p models, L2GMap.cpp:564-642;
  *      MPI_Allreduce in cg.cpp:49,65,75) ---------------------------------- */

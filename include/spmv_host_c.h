@@ -197,6 +197,9 @@ int spmvh_l2g_sizes(spmvh_matrix* A, int32_t* local_size, int32_t* num_ghosts,
                     int64_t* global_size, int64_t* global_offset,
                     int* overlapping, int* num_neighbours, int* num_indices,
                     int* packs);
+/* 1 = the halo of A.col_map() moves by peer stores into the neighbours'
+ * windows (onesided_put_* models on several ranks; include/spmv_hip.h) */
+int spmvh_l2g_onesided(spmvh_matrix* A, int* onesided);
 int spmvh_l2g_ghosts(spmvh_matrix* A, int64_t* ghosts);
 /* plan arrays: neighbours[nn], send_count[nn], recv_count[nn],
  * send_offset[nn+1], recv_offset[nn+1], indexbuf[num_indices] */

@@ -132,6 +132,13 @@ _PROTOS = {
                                       vp], C.c_int),
     "spmv_hip_poisson3d_box_fill_f64": ([vp, i32, vp, vp, C.c_int, vp, vp, vp, vp,
                                          vp], C.c_int),
+    "spmv_hip_put_create": ([vp, sz, P(vp), vp, P(C.c_uint64), P(i64)], C.c_int),
+    "spmv_hip_put_connect": ([vp, C.c_int, vp, C.c_uint64, i64, sz, i32, i32, i32,
+                              i32, i32, i32], C.c_int),
+    "spmv_hip_put_finish": ([vp], C.c_int),
+    "spmv_hip_put_exchange": ([vp, vp, sz, vp, vp, vp], C.c_int),
+    "spmv_hip_put_status": ([vp, P(C.c_int)], C.c_int),
+    "spmv_hip_put_destroy": ([vp], C.c_int),
     "spmv_hip_unstructured_fill_f64": ([vp, i64, C.c_int, i64, C.c_int,
                                         C.c_uint64, vp, vp, vp, vp], C.c_int),
     "spmv_hip_fill_gaussian_f64": ([vp, i64, i64, i64, vp, vp], C.c_int),

@@ -1,0 +1,308 @@
+// One-sided halo: peer stores over xGMI instead of RCCL send/recv.
+//
+// The reference's onesided_put_* communication models move the ghosts with
+// MPI_Put into a window of the neighbour's memory (spmv/L2GMap.cpp:645-682).
+// The equivalent on one node of MI355X: every rank owns a WINDOW -- a staging
+// buffer for its ghost tail plus two flag words per neighbour -- exported as a
+// HIP IPC memory handle (one process per GPU) or shared by address (ranks that
+// are threads of one process); a neighbour maps it once, at plan time, and
+// from then on an exchange is ONE kernel launch per rank:
+//
+//   workgroups (k, 0..G) serve neighbour k
+//   (a) tell k "my staging segment for you is free again"      flag store
+//   (b) wait for k's "your segment in my window is free"        flag poll
+//   (c) store my send segment into k's window                   peer stores
+//       system-scope fence; the last of the G workgroups raises
+//       k's "data of this epoch has landed" flag                flag store
+//   (d) wait for k's data flag, copy my staging segment into    flag poll,
+//       the ghost tail of the vector                            local copy
+//
+// Flags carry the EPOCH (a counter of exchanges, monotonic), so nothing is ever
+// reset and a late reader of an old epoch cannot be confused.  Every wait is
+// bounded (about 4 s of wall clock): a peer that died makes the exchange fail
+// (error word in pinned host memory, reported by the next call), not hang.
+// The staging hop costs one local copy of the ghost tail (2-4 MB at 512^3 over
+// 8 ranks) and buys a registration that happens once per L2GMap instead of
+// once per vector: the window never moves, whatever vector is exchanged.
+//
+// Validated on ONE device only (1-GPU boxes): ranks as processes that share
+// GPU 0 through IPC handles (tests/mp_gpu_worker.py) and ranks as threads of
+// one process (tests/thread_world.py).  What a single device cannot show --
+// how stores into a PEER's HBM interact with that peer's L2 -- is handled
+// conservatively: flags and staged data are read with system-scope loads that
+// bypass the caches, data is published with a system-scope fence before the
+// flag.
+#include "common.h"
+
+#include <cstring>
+#include <new>
+#include <unistd.h>
+
+struct PutPeer {
+  char* dst;            // the neighbour's staging buffer (mapped)
+  uint64_t* peer_flags; // ... and its flag words
+  int32_t dst_off;      // where my data goes there (elements)
+  int32_t slot_at_peer; // which neighbour slot I am there
+  int32_t send_off, send_count; // my segment in the send buffer (elements)
+  int32_t recv_off, recv_count; // the neighbour's segment in MY staging buffer
+};
+
+struct spmv_hip_put {
+  spmv_hip_ctx* ctx = nullptr;
+  char* window = nullptr; // staging | data flags | free flags | counters
+  size_t stage_bytes = 0;
+  int num_peers = 0;
+  PutPeer host_tab[SPMV_HIP_PUT_MAX_PEERS];
+  void* mapped[SPMV_HIP_PUT_MAX_PEERS]; // IPC mappings to close (or null)
+  PutPeer* dev_tab = nullptr;
+  int32_t* host_err = nullptr; // pinned, device-visible
+  uint64_t epoch = 0;
+};
+
+namespace
+{
+
+constexpr int kPutGroup = 8; // workgroups per neighbour
+constexpr unsigned long long kPutTimeoutTicks = 400000000ull; // 100 MHz: 4 s
+
+__device__ __forceinline__ uint64_t* put_flags(char* window, size_t stage_bytes)
+{
+  return reinterpret_cast<uint64_t*>(window + stage_bytes);
+}
+
+// thread 0 polls, the workgroup follows; false = timed out
+__device__ __forceinline__ bool put_wait(const uint64_t* flag, uint64_t epoch,
+                                         int32_t* err)
+{
+  __shared__ int s_ok;
+  if (threadIdx.x == 0) {
+    const unsigned long long t0 = wall_clock64();
+    int ok = 1;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+           < epoch) {
+      __builtin_amdgcn_s_sleep(16);
+      if (wall_clock64() - t0 > kPutTimeoutTicks) {
+        ok = 0;
+        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+    s_ok = ok;
+  }
+  __syncthreads();
+  const bool ok = s_ok != 0;
+  __syncthreads(); // s_ok may be written again by the next wait
+  // what the flag announced was written before it: order this workgroup's
+  // later loads behind the poll
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  return ok;
+}
+
+// WORD = uint64_t (fp64) or uint32_t (fp32)
+template <typename WORD>
+__global__ __launch_bounds__(kBlock) void put_exchange_kernel(
+    const PutPeer* __restrict__ tab, const char* __restrict__ send_buf,
+    char* __restrict__ ghost_tail, char* window, size_t stage_bytes,
+    uint64_t epoch, int32_t* err)
+{
+  const int k = blockIdx.x / kPutGroup, g = blockIdx.x % kPutGroup;
+  const PutPeer p = tab[k];
+  uint64_t* my_flags = put_flags(window, stage_bytes);
+  uint64_t* my_data_flag = my_flags + k;
+  uint64_t* my_free_flag = my_flags + SPMV_HIP_PUT_MAX_PEERS + k;
+  unsigned* my_counter
+      = reinterpret_cast<unsigned*>(my_flags + 2 * SPMV_HIP_PUT_MAX_PEERS) + k;
+  const int t = threadIdx.x;
+  // (a) the previous exchange's launch copied my staging segment out (stream
+  // order): the neighbour may fill it again
+  if (g == 0 && t == 0)
+    __hip_atomic_store(p.peer_flags + SPMV_HIP_PUT_MAX_PEERS + p.slot_at_peer,
+                       epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  // (b) ... and so may I, once it says the same
+  if (!put_wait(my_free_flag, epoch, err))
+    return;
+  // (c) my segment -> the neighbour's window
+  {
+    const WORD* src = reinterpret_cast<const WORD*>(send_buf) + p.send_off;
+    WORD* dst = reinterpret_cast<WORD*>(p.dst) + p.dst_off;
+    for (int64_t i = (int64_t)g * kBlock + t; i < p.send_count;
+         i += (int64_t)kPutGroup * kBlock)
+      dst[i] = src[i];
+  }
+  __threadfence_system(); // my stores are out before anybody sees the flag
+  __syncthreads();
+  if (t == 0) {
+    const unsigned done = atomicAdd(my_counter, 1u) + 1u;
+    if (done % kPutGroup == 0) // the last of this neighbour's workgroups
+      __hip_atomic_store(p.peer_flags + p.slot_at_peer, epoch, __ATOMIC_RELEASE,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  // (d) the neighbour's data -> the ghost tail (loads that bypass the caches:
+  // the lines were written by another agent)
+  if (!put_wait(my_data_flag, epoch, err))
+    return;
+  {
+    const WORD* src = reinterpret_cast<const WORD*>(window) + p.recv_off;
+    WORD* dst = reinterpret_cast<WORD*>(ghost_tail) + p.recv_off;
+    for (int64_t i = (int64_t)g * kBlock + t; i < p.recv_count;
+         i += (int64_t)kPutGroup * kBlock)
+      dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+size_t put_window_bytes(size_t stage_bytes)
+{
+  return stage_bytes + sizeof(uint64_t) * 3 * SPMV_HIP_PUT_MAX_PEERS;
+}
+
+} // namespace
+
+extern "C" {
+
+int spmv_hip_put_create(spmv_hip_ctx* ctx, size_t stage_bytes,
+                        spmv_hip_put** put, void* ipc_handle,
+                        uint64_t* raw_address, int64_t* process_id)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(put && ipc_handle && raw_address && process_id);
+  static_assert(sizeof(hipIpcMemHandle_t) <= SPMV_HIP_IPC_HANDLE_BYTES,
+                "handle size");
+  spmv_hip_put* p = new (std::nothrow) spmv_hip_put;
+  if (!p)
+    return SPMV_HIP_ENOMEM;
+  p->ctx = ctx;
+  p->stage_bytes = (stage_bytes + 255) & ~(size_t)255;
+  for (int k = 0; k < SPMV_HIP_PUT_MAX_PEERS; ++k)
+    p->mapped[k] = nullptr;
+  const size_t bytes = put_window_bytes(p->stage_bytes);
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->window), bytes);
+  if (e == hipSuccess)
+    e = hipMemset(p->window, 0, bytes);
+  if (e == hipSuccess)
+    e = hipHostMalloc(reinterpret_cast<void**>(&p->host_err), sizeof(int32_t),
+                      hipHostMallocMapped);
+  hipIpcMemHandle_t h;
+  if (e == hipSuccess) {
+    *p->host_err = 0;
+    e = hipIpcGetMemHandle(&h, p->window);
+  }
+  if (e != hipSuccess) {
+    (void)hipFree(p->window);
+    (void)hipHostFree(p->host_err);
+    delete p;
+    return static_cast<int>(e);
+  }
+  memset(ipc_handle, 0, SPMV_HIP_IPC_HANDLE_BYTES);
+  memcpy(ipc_handle, &h, sizeof(h));
+  *raw_address = reinterpret_cast<uint64_t>(p->window);
+  *process_id = (int64_t)getpid();
+  *put = p;
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_put_connect(spmv_hip_put* put, int k, const void* peer_ipc_handle,
+                         uint64_t peer_raw_address, int64_t peer_process_id,
+                         size_t peer_stage_bytes, int32_t dst_offset,
+                         int32_t slot_at_peer, int32_t send_offset,
+                         int32_t send_count, int32_t recv_offset,
+                         int32_t recv_count)
+{
+  SPMV_REQUIRE(put && k >= 0 && k < SPMV_HIP_PUT_MAX_PEERS && peer_ipc_handle
+               && slot_at_peer >= 0 && slot_at_peer < SPMV_HIP_PUT_MAX_PEERS
+               && dst_offset >= 0 && send_offset >= 0 && send_count >= 0
+               && recv_offset >= 0 && recv_count >= 0);
+  SPMV_SET_DEVICE(put->ctx);
+  char* base = nullptr;
+  if (peer_process_id == (int64_t)getpid()) {
+    // a rank of this process (threads): one address space
+    base = reinterpret_cast<char*>(peer_raw_address);
+  } else {
+    hipIpcMemHandle_t h;
+    memcpy(&h, peer_ipc_handle, sizeof(h));
+    void* m = nullptr;
+    SPMV_CHECK_HIP(hipIpcOpenMemHandle(&m, h, hipIpcMemLazyEnablePeerAccess));
+    put->mapped[k] = m;
+    base = static_cast<char*>(m);
+  }
+  const size_t peer_stage = (peer_stage_bytes + 255) & ~(size_t)255;
+  PutPeer& pp = put->host_tab[k];
+  pp.dst = base;
+  pp.peer_flags = reinterpret_cast<uint64_t*>(base + peer_stage);
+  pp.dst_off = dst_offset;
+  pp.slot_at_peer = slot_at_peer;
+  pp.send_off = send_offset;
+  pp.send_count = send_count;
+  pp.recv_off = recv_offset;
+  pp.recv_count = recv_count;
+  if (k + 1 > put->num_peers)
+    put->num_peers = k + 1;
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_put_finish(spmv_hip_put* put)
+{
+  SPMV_REQUIRE(put && put->num_peers > 0);
+  SPMV_SET_DEVICE(put->ctx);
+  (void)hipFree(put->dev_tab);
+  put->dev_tab = nullptr;
+  SPMV_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&put->dev_tab),
+                           sizeof(PutPeer) * put->num_peers));
+  SPMV_CHECK_HIP(hipMemcpy(put->dev_tab, put->host_tab,
+                           sizeof(PutPeer) * put->num_peers,
+                           hipMemcpyHostToDevice));
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_put_exchange(spmv_hip_ctx* ctx, spmv_hip_put* put, size_t elem_bytes,
+                          const void* send_buf, void* ghost_tail, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(put && put->ctx == ctx && put->dev_tab && send_buf && ghost_tail
+               && (elem_bytes == 4 || elem_bytes == 8));
+  if (*put->host_err) // an earlier exchange timed out: the ghosts are not valid
+    return SPMV_HIP_EPEER;
+  hipStream_t st = spmv_stream(ctx, stream);
+  const uint64_t epoch = ++put->epoch;
+  const dim3 grid(put->num_peers * kPutGroup), block(kBlock);
+  int32_t* dev_err = nullptr;
+  SPMV_CHECK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&dev_err),
+                                         put->host_err, 0));
+  if (elem_bytes == 8)
+    hipLaunchKernelGGL(put_exchange_kernel<uint64_t>, grid, block, 0, st,
+                       put->dev_tab, static_cast<const char*>(send_buf),
+                       static_cast<char*>(ghost_tail), put->window,
+                       put->stage_bytes, epoch, dev_err);
+  else
+    hipLaunchKernelGGL(put_exchange_kernel<uint32_t>, grid, block, 0, st,
+                       put->dev_tab, static_cast<const char*>(send_buf),
+                       static_cast<char*>(ghost_tail), put->window,
+                       put->stage_bytes, epoch, dev_err);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_put_status(const spmv_hip_put* put, int* failed)
+{
+  SPMV_REQUIRE(put && failed);
+  *failed = *put->host_err != 0;
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_put_destroy(spmv_hip_put* put)
+{
+  if (!put)
+    return SPMV_HIP_OK;
+  (void)hipSetDevice(put->ctx->device);
+  (void)hipDeviceSynchronize(); // no exchange still runs
+  for (int k = 0; k < SPMV_HIP_PUT_MAX_PEERS; ++k)
+    if (put->mapped[k])
+      (void)hipIpcCloseMemHandle(put->mapped[k]);
+  (void)hipFree(put->dev_tab);
+  (void)hipFree(put->window);
+  (void)hipHostFree(put->host_err);
+  delete put;
+  return SPMV_HIP_OK;
+}
+
+} // extern "C"

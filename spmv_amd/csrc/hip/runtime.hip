@@ -24,6 +24,8 @@ const char* spmv_hip_error_string(int code)
     return "spmv_hip: not supported in this build";
   if (code == SPMV_HIP_ERANGE)
     return "spmv_hip: size exceeds 32-bit index range";
+  if (code == SPMV_HIP_EPEER)
+    return "spmv_hip: one-sided halo: a neighbour did not answer in time";
   if (code >= 10000)
     return "spmv_hip: RCCL error (code - 10000 = ncclResult_t)";
   if (code > 0)

@@ -684,6 +684,14 @@ int spmvh_l2g_sizes(spmvh_matrix* A, int32_t* local_size, int32_t* num_ghosts,
   });
 }
 
+int spmvh_l2g_onesided(spmvh_matrix* A, int* onesided)
+{
+  return guarded([&] {
+    require(A && onesided, "NULL argument");
+    *onesided = A->A->col_map()->onesided() ? 1 : 0;
+  });
+}
+
 int spmvh_l2g_ghosts(spmvh_matrix* A, int64_t* ghosts)
 {
   return guarded([&] {

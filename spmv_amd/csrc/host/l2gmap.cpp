@@ -1,6 +1,8 @@
 // L2GMap: see l2gmap.h.  Plan construction follows spmv/L2GMap.cpp:346-479.
 #include "l2gmap.h"
 
+#include "spmv_hip.h"
+
 #include <algorithm>
 #include <stdexcept>
 
@@ -138,10 +140,100 @@ L2GMap::L2GMap(std::shared_ptr<const Comm> comm, std::int64_t local_size,
     _ev_ready = _hip->create_event();
     _ev_done = _hip->create_event();
   }
+  if (_hip && P > 1
+      && (_cm == CommunicationModel::onesided_put_active
+          || _cm == CommunicationModel::onesided_put_passive))
+    setup_put(local_size);
+}
+
+// The one-sided models: every rank creates its window, the ranks exchange
+// {process, address, IPC handle, neighbour list, where each neighbour's data
+// goes in the ghost tail}, and each connects its neighbours.  Collective, like
+// the rest of the plan; the put path is used only if EVERY rank could set it
+// up (a rank that fell back alone would wait for stores that never come).
+void L2GMap::setup_put(std::int64_t local_size)
+{
+  struct Record {
+    std::int64_t pid = 0;
+    std::uint64_t raw = 0;
+    unsigned char handle[SPMV_HIP_IPC_HANDLE_BYTES] = {};
+    std::int64_t stage_bytes = 0;
+    std::int32_t ok = 0, nn = 0;
+    std::int32_t nbr[SPMV_HIP_PUT_MAX_PEERS] = {};
+    std::int32_t ghost_off[SPMV_HIP_PUT_MAX_PEERS] = {};
+  };
+  Record mine;
+  const std::size_t nn = _neighbours.size();
+  spmv_hip_put* put = nullptr;
+  mine.stage_bytes = 8 * static_cast<std::int64_t>(_ghosts.size() > 0 ? _ghosts.size() : 1);
+  if (nn <= SPMV_HIP_PUT_MAX_PEERS
+      && spmv_hip_put_create(_hip->context(), (size_t)mine.stage_bytes, &put,
+                             mine.handle, &mine.raw, &mine.pid)
+             == SPMV_HIP_OK) {
+    mine.ok = 1;
+    mine.nn = static_cast<std::int32_t>(nn);
+    for (std::size_t i = 0; i < nn; ++i) {
+      mine.nbr[i] = _neighbours[i];
+      mine.ghost_off[i]
+          = _x_recv_offset[i] - static_cast<std::int32_t>(local_size);
+    }
+  }
+  const int P = _comm->size();
+  std::vector<Record> all(P);
+  _comm->allgather(&mine, all.data(), sizeof(Record));
+  bool everybody = true;
+  for (const Record& r : all)
+    everybody = everybody && r.ok;
+  int rc = everybody ? SPMV_HIP_OK : SPMV_HIP_ENOTSUP;
+  for (std::size_t i = 0; i < nn && rc == SPMV_HIP_OK; ++i) {
+    const Record& peer = all[_neighbours[i]];
+    int slot = -1;
+    for (int k = 0; k < peer.nn; ++k)
+      if (peer.nbr[k] == _rank)
+        slot = k;
+    if (slot < 0) { // the neighbour relation is symmetric (:390-412)
+      rc = SPMV_HIP_EINVAL;
+      break;
+    }
+    rc = spmv_hip_put_connect(put, static_cast<int>(i), peer.handle, peer.raw,
+                              peer.pid, (size_t)peer.stage_bytes,
+                              peer.ghost_off[slot], slot, _x_send_offset[i],
+                              _x_send_count[i],
+                              _x_recv_offset[i]
+                                  - static_cast<std::int32_t>(local_size),
+                              _x_recv_count[i]);
+  }
+  if (rc == SPMV_HIP_OK && nn > 0)
+    rc = spmv_hip_put_finish(put);
+  // agree on the outcome: one rank that could not connect sends everybody
+  // back to the two-sided exchange
+  const std::int32_t my_ok = rc == SPMV_HIP_OK ? 1 : 0;
+  std::vector<std::int32_t> oks = _comm->allgather_value<std::int32_t>(my_ok);
+  bool all_ok = true;
+  for (std::int32_t o : oks)
+    all_ok = all_ok && o;
+  if (all_ok && nn > 0) {
+    _put = put;
+  } else {
+    spmv_hip_put_destroy(put);
+    _put = nullptr;
+  }
 }
 
 L2GMap::~L2GMap()
 {
+  if (_put) {
+    // a neighbour may still be storing into this rank's window (its side of
+    // the last exchange): every rank arrives here before anybody frees
+    try {
+      if (_comm_stream)
+        _hip->synchronize_stream(_comm_stream);
+      (void)_comm->allgather_value<std::int32_t>(0);
+    } catch (...) {
+    }
+    spmv_hip_put_destroy(_put);
+    _put = nullptr;
+  }
   try {
     if (_hip) {
       if (_comm_stream)
@@ -212,9 +304,15 @@ void L2GMap::start_exchange(T* vec) const
   // receive straight into the ghost tail (:624-628), send packed or direct
   // data (:630-634); one grouped call, ordered on the comm stream; the
   // argument lists were built with the plan
-  _comm->neighbor_exchange(sizeof(T), _neighbours, send_base, _x_send_count,
-                           _x_send_offset, vec, _x_recv_count, _x_recv_offset,
-                           _comm_stream);
+  if (_put) // one-sided models: peer stores, one launch
+    throw_on_error(spmv_hip_put_exchange(_hip->context(), _put, sizeof(T),
+                                         send_base, vec + local_size(),
+                                         _comm_stream),
+                   "spmv_hip_put_exchange");
+  else
+    _comm->neighbor_exchange(sizeof(T), _neighbours, send_base, _x_send_count,
+                             _x_send_offset, vec, _x_recv_count, _x_recv_offset,
+                             _comm_stream);
   _hip->record_event(_ev_done, _comm_stream);
 }
 

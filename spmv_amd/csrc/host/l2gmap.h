@@ -27,6 +27,8 @@
 #include "comm.h"
 #include "executor.h"
 
+struct spmv_hip_put;
+
 namespace spmv
 {
 
@@ -72,6 +74,9 @@ public:
   const std::vector<std::int32_t>& recv_offset() const { return _recv_offset; }
   const std::vector<std::int32_t>& indexbuf() const { return _indexbuf_host; }
   bool packs() const { return !_direct_send; }
+  // the halo moves by peer stores into the neighbours' windows (the
+  // onesided_put_* models, when every rank could set its window up)
+  bool onesided() const { return _put != nullptr; }
 
 private:
   std::shared_ptr<const Comm> _comm;
@@ -102,6 +107,12 @@ private:
   // the packed buffer) and receives (counts, offsets into the ghost tail)
   std::vector<std::int32_t> _x_send_count, _x_send_offset, _x_packed_offset;
   std::vector<std::int32_t> _x_recv_count, _x_recv_offset;
+
+  // one-sided models (L2GMap.cpp:645-682): this rank's window and its
+  // connections to the neighbours' (libspmv_hip.so, put.hip); null = the
+  // two-sided exchange
+  spmv_hip_put* _put = nullptr;
+  void setup_put(std::int64_t local_size);
 
   mutable void* _send_buf = nullptr; // lazily allocated (L2GMap.cpp:607-614)
   mutable size_t _send_buf_bytes = 0;

@@ -85,6 +85,7 @@ _PROTOS = {
     "spmvh_l2g_sizes": [vp, PTR(i32), PTR(i32), PTR(i64), PTR(i64),
                         PTR(C.c_int), PTR(C.c_int), PTR(C.c_int), PTR(C.c_int)],
     "spmvh_l2g_ghosts": [vp, vp],
+    "spmvh_l2g_onesided": [vp, vp],
     "spmvh_l2g_plan": [vp, vp, vp, vp, vp, vp, vp],
     "spmvh_l2g_global_to_local": [vp, i64, PTR(i32)],
     "spmvh_l2g_create": [vp, vp, C.c_int, i64, vp, i64, C.c_int, PTR(vp)],
@@ -321,6 +322,12 @@ class ColMapView:
 
     def overlapping(self):
         return self._overlapping
+
+    def onesided(self):
+        """the halo moves by peer stores (onesided_put_* models, > 1 rank)"""
+        v = C.c_int()
+        call("spmvh_l2g_onesided", self.A.h, C.byref(v))
+        return bool(v.value)
 
     def ghosts(self):
         g = np.zeros(self._num_ghosts, np.int64)

@@ -3,6 +3,12 @@ import sys
 
 import pytest
 
+# Tests that run several ranks as THREADS of this process give every rank its
+# own streams; the HIP runtime multiplexes a process's streams onto a few
+# hardware queues (four by default), where a kernel that polls for a neighbour
+# can sit in front of the neighbour's kernel.  More queues, before HIP starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

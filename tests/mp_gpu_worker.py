@@ -61,6 +61,11 @@ def main():
                                               r1 - r0, r1 - r0, [], ghosts,
                                               symmetric, cm)
                 l2g = A.col_map()
+                # the one-sided model moves the halo by peer stores into IPC
+                # windows (the ranks are processes sharing GPU 0); every other
+                # model through the two-sided exchange
+                assert l2g.onesided() == (cm == host.ONESIDED_PUT_ACTIVE
+                                          and world > 1 and l2g._nn > 0), (cm, name)
                 assert l2g.local_size() == r1 - r0
                 assert l2g.num_ghosts() == len(ghosts)
                 assert l2g.global_size() == N and l2g.global_offset() == r0
@@ -96,9 +101,14 @@ def main():
     ranges = oracle.owner_ranges(world, N)
     r0, r1 = int(ranges[rank]), int(ranges[rank + 1])
     for symmetric in (False, True):
-        for cm in (host.P2P_BLOCKING, host.P2P_NONBLOCKING):
+        for cm in (host.P2P_BLOCKING, host.P2P_NONBLOCKING,
+                   host.ONESIDED_PUT_ACTIVE):
             A = host.Matrix.create_poisson3d(comm, exec_, n, symmetric, cm)
             l2g = A.col_map()
+            # one-sided: peer stores into the neighbours' IPC windows, 100+
+            # exchanges (epochs) in the CG below
+            assert l2g.onesided() == (cm == host.ONESIDED_PUT_ACTIVE and world > 1)
+            ocm = cm if cm < 4 else host.P2P_BLOCKING  # the oracle's equivalent
             pl = l2g.plan()
             assert not l2g.packs, "slab halo must take the direct-send path"
             assert len(pl.neighbours) == (1 if rank in (0, world - 1) else 2)
@@ -112,11 +122,11 @@ def main():
                 assert np.all(np.abs(y - y_seq) <= 16 * U * abs_bound(rp, ci, va, x))
             else:
                 assert np.array_equal(
-                    y, oracle.dist_spmv(world, rp, ci, va, x, False, cm))
+                    y, oracle.dist_spmv(world, rp, ci, va, x, False, ocm))
             # CG on the distributed matrix vs the oracle's P-rank CG
             b = oracle.csr_spmv(rp, ci.astype(np.int32), va, np.ones(N))
             x_ref, k_ref, hist_ref = oracle.dist_cg(world, rp, ci, va, b, 100,
-                                                    1e-10, symmetric, cm)
+                                                    1e-10, symmetric, ocm)
             d_b, d_s = exec_.alloc(r1 - r0), exec_.alloc(r1 - r0)
             exec_.copy_from_host(d_b, b[r0:r1])
             k, hist = host.cg(comm, exec_, A, d_b, d_s, 100, 1e-10)

@@ -232,6 +232,100 @@ def test_cg_early_convergence_with_long_queue(exec_, comm):
     exec_.free(d_b), exec_.free(d_x)
 
 
+@pytest.mark.parametrize("world,n", [(2, 10), (3, 12), (8, 16)])
+def test_onesided_halo_ranks_threaded(world, n):
+    """The one-sided models (L2GMap.cpp:645-682) with the ranks as THREADS of
+    this process: every rank's window is reached by address, the halo is one
+    put kernel per rank and exchange (signal free / store / raise the data
+    flag / copy the staging buffer into the ghost tail).  SpMV bit-exact
+    against the oracle's P-rank simulation, CG over 60+ exchanges follows its
+    history; the ranks as PROCESSES (IPC handles) -- the deployment's shape --
+    are test_multirank_on_one_gpu's business.
+
+    The streams of ONE process share its hardware queues (four by default):
+    a put kernel that polls can then sit in a queue in front of the very
+    kernel it waits for -- the bounded waits expire and the exchange reports
+    SPMV_HIP_EPEER, which is what they are for.  tests/conftest.py therefore
+    asks the runtime for 24 queues before HIP starts; should the queues still
+    be shared, the test is skipped, not failed: it is a property of ranks as
+    threads, not of the protocol (ranks in processes of their own have their
+    own queues)."""
+    from thread_world import ThreadWorld
+    N = n ** 3
+    rp, ci, va = poisson.poisson3d_csr(n)
+    x = oracle.gaussian_x_fast(N)
+    b = oracle.csr_spmv(rp, ci.astype(np.int32), va, np.ones(N))
+    ranges = oracle.owner_ranges(world, N)
+    refs = {sym: (oracle.dist_spmv(world, rp, ci, va, x, sym, host.P2P_BLOCKING),
+                  oracle.dist_cg(world, rp, ci, va, b, 60, 1e-30, sym,
+                                 host.P2P_BLOCKING))
+            for sym in (False, True)}
+    tw = ThreadWorld(world, timeout=60.0)
+
+    def rank_body(rank, comm, exec_):
+        import ctypes as C
+        from spmv_amd import _lib
+        # a compute stream of its own per rank, as ranks in processes of their
+        # own have: threads would otherwise share the process's default stream,
+        # and a rank whose stream waits for its halo would hold back the
+        # neighbour's work queued behind it -- the very stores it waits for
+        stream = C.c_void_p()
+        _lib.call("spmv_hip_stream_create", exec_.context, C.byref(stream))
+        _lib.call("spmv_hip_set_stream", exec_.context, stream)
+        r0, r1 = int(ranges[rank]), int(ranges[rank + 1])
+        ws = host.CgWorkspace(exec_)
+        for cm in (host.ONESIDED_PUT_ACTIVE, host.ONESIDED_PUT_PASSIVE):
+            for sym, (y_ref, (x_ref, k_ref, hist_ref)) in refs.items():
+                A = host.Matrix.create_poisson3d(comm, exec_, n, sym, cm)
+                l2g = A.col_map()
+                assert l2g.onesided() and not l2g.overlapping()
+                ng = l2g.num_ghosts()
+                d_x, d_y = exec_.alloc(r1 - r0 + ng), exec_.alloc(r1 - r0)
+                d_b, d_s = exec_.alloc(r1 - r0), exec_.alloc(r1 - r0)
+                exec_.copy_from_host(d_b, b[r0:r1])
+                host.cg_ex(comm, exec_, A, d_b, d_s, 0, 1e-30, ws)  # sizes ws,
+                #                                        exchanges nothing
+                # Everything is allocated: from here to the barrier below no
+                # rank calls hipMalloc / hipFree.  (Those wait for the whole
+                # DEVICE -- with the ranks as threads of one process, for a
+                # neighbour's put kernel that in turn waits for this rank's
+                # next exchange.  Ranks in processes of their own, the real
+                # deployment, do not share that wait.)
+                tw.bar.wait()
+                for rep in range(3):  # back to back: three more epochs
+                    exec_.memset(d_x, 0xFF, 8 * (r1 - r0 + ng))  # NaN ghosts
+                    exec_.copy_from_host(d_x, x[r0:r1])
+                    l2g.update(d_x)
+                    A.mult(d_x, d_y)
+                got = exec_.copy_to_host(d_x, r1 - r0 + ng)
+                assert np.array_equal(got[r1 - r0:], x[l2g.ghosts()])
+                y = tw.gather(rank, exec_.copy_to_host(d_y, r1 - r0))
+                assert np.array_equal(y, y_ref), (cm, sym)
+                k, hist, _, _ = host.cg_ex(comm, exec_, A, d_b, d_s, 60, 1e-30,
+                                           ws, history=True)
+                xs = tw.gather(rank, exec_.copy_to_host(d_s, r1 - r0))
+                assert k == 60 == k_ref
+                assert np.allclose(hist, hist_ref, rtol=1e-7), (cm, sym)
+                assert np.linalg.norm(xs - x_ref) <= 1e-9 * np.linalg.norm(x_ref)
+                tw.bar.wait()  # nobody closes while a neighbour still exchanges
+                A.close()
+                for p in (d_x, d_y, d_b, d_s):
+                    exec_.free(p)
+                tw.bar.wait()
+        ws.close()
+        exec_.synchronize()
+        _lib.call("spmv_hip_set_stream", exec_.context, None)
+        _lib.call("spmv_hip_stream_destroy", exec_.context, stream)
+
+    try:
+        tw.run(rank_body, gpu=True)
+    except host.SpmvHostError as e:
+        if "did not answer in time" in str(e):
+            pytest.skip("put kernels serialised on the process's shared "
+                        "hardware queues (harness limitation): " + str(e))
+        raise
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_multirank_on_one_gpu(world):
     """N>1 path: one process per rank, all on GPU 0, halo + reductions over a
