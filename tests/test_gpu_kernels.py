@@ -471,6 +471,79 @@ def test_device_box_generator_matches_host_rows(ctx, n, parts):
                 assert sub == [(c, v) for c, v in dev if pred(c)], (rank, i, part)
 
 
+def _put_window(ctx, stage_bytes):
+    put = C.c_void_p()
+    handle = (C.c_ubyte * 64)()
+    raw, pid = C.c_uint64(), C.c_int64()
+    hip.call("spmv_hip_put_create", ctx.h, stage_bytes, C.byref(put), handle,
+             C.byref(raw), C.byref(pid))
+    return put, handle, raw.value, pid.value
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_put_exchange_with_itself(ctx, dtype):
+    """The one-sided halo's kernel at unit level (include/spmv_hip.h,
+    spmv_hip_put_*): a window connected to ITSELF in two slots -- slot 0 sends
+    into slot 1's segment and the other way round -- goes through the whole
+    protocol (free flags, stores, data flags, staging -> ghost tail) for several
+    epochs; every epoch delivers that epoch's data."""
+    n0, n1 = 1000, 37  # elements of the two segments
+    esz = np.dtype(dtype).itemsize
+    put, handle, raw, pid = _put_window(ctx, 8 * (n0 + n1))
+    # slot k: send segment k of the send buffer to where the OTHER slot reads
+    hip.call("spmv_hip_put_connect", put, 0, handle, raw, pid, 8 * (n0 + n1),
+             n0, 1, 0, n1, 0, n0)        # my n1 items -> segment [n0, n0 + n1)
+    hip.call("spmv_hip_put_connect", put, 1, handle, raw, pid, 8 * (n0 + n1),
+             0, 0, n1, n0, n0, n1)       # my n0 items -> segment [0, n0)
+    hip.call("spmv_hip_put_finish", put)
+    rng = np.random.default_rng(5)
+    ghost = ctx.upload(np.full(n0 + n1, np.nan, dtype), dtype)
+    for epoch in range(4):
+        send = rng.uniform(-1, 1, n0 + n1).astype(dtype)
+        d_send = ctx.upload(send, dtype)
+        hip.call("spmv_hip_put_exchange", ctx.h, put, esz, d_send.ptr, ghost.ptr,
+                 None)
+        ctx.stream_sync()
+        failed = C.c_int()
+        hip.call("spmv_hip_put_status", put, C.byref(failed))
+        assert failed.value == 0
+        got = ghost.numpy()
+        # slot 0 sent send[0:n1] to [n0, n0+n1); slot 1 sent send[n1:] to [0, n0)
+        assert np.array_equal(got[n0:], send[:n1]), epoch
+        assert np.array_equal(got[:n0], send[n1:]), epoch
+        d_send.free()
+    ghost.free()
+    hip.call("spmv_hip_put_destroy", put)
+
+
+def test_put_exchange_times_out_instead_of_hanging(ctx):
+    """A neighbour that never answers: the bounded waits of the put kernel end
+    after about 4 s, the window reports the failure, and every later exchange
+    returns SPMV_HIP_EPEER at once -- the GPU is never left with a kernel that
+    polls for ever."""
+    import time
+    n = 64
+    put, handle, raw, pid = _put_window(ctx, 8 * n)
+    # connected to itself in the WRONG slot: it signals slot 3, waits on slot 0
+    hip.call("spmv_hip_put_connect", put, 0, handle, raw, pid, 8 * n, 0, 3, 0, n,
+             0, n)
+    hip.call("spmv_hip_put_finish", put)
+    send, ghost = ctx.upload(np.ones(n)), ctx.upload(np.zeros(n))
+    t0 = time.perf_counter()
+    hip.call("spmv_hip_put_exchange", ctx.h, put, 8, send.ptr, ghost.ptr, None)
+    ctx.stream_sync()
+    waited = time.perf_counter() - t0
+    assert 2.0 < waited < 20.0, waited
+    failed = C.c_int()
+    hip.call("spmv_hip_put_status", put, C.byref(failed))
+    assert failed.value == 1
+    assert np.all(ghost.numpy() == 0.0)  # nothing was delivered
+    with pytest.raises(Exception, match="did not answer"):
+        hip.call("spmv_hip_put_exchange", ctx.h, put, 8, send.ptr, ghost.ptr, None)
+    send.free(), ghost.free()
+    hip.call("spmv_hip_put_destroy", put)
+
+
 def test_unstructured_generator_matches_numpy_twin(ctx):
     """spmv_hip_unstructured_fill_f64 (the benchmark's matrix without lattice
     structure) against spmv_amd.poisson.unstructured_csr: same arrays."""
