@@ -65,7 +65,11 @@ def parse():
                          "main line (the default line carries it as a "
                          "sub-record)")
     ap.add_argument("--cm", default="p2p_nonblocking",
-                    choices=["p2p_blocking", "p2p_nonblocking"])
+                    choices=["p2p_blocking", "p2p_nonblocking",
+                             "onesided_put_active"],
+                    help="halo model; onesided_put_active: peer stores into "
+                         "IPC-mapped windows instead of RCCL send/recv "
+                         "(DESIGN.md section 6; never yet run over xGMI)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="main line only: no symmetric / LX / 216^3 sub-records")
@@ -689,7 +693,10 @@ def main():
                        "rows": N, "nnz": poisson.poisson3d_nnz(n),
                        "storage": "symmetric-csr" if args.symmetric else "csr",
                        "partition": f"row-slab x{world}",
-                       "halo": args.cm + " (RCCL send/recv on a side stream)"
+                       "halo": (args.cm + (" (peer stores into IPC windows, "
+                                            "one put kernel per exchange)"
+                                            if l2g.onesided() else
+                                            " (RCCL send/recv on a side stream)"))
                        if world > 1 else "none (1 rank)"},
             # PHYSICAL roofline of the dominant kernel: the bytes its data
             # format makes it load and store per launch / the launch time

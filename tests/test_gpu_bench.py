@@ -144,6 +144,34 @@ def test_bench_two_rank_rehearsal():
     assert abs(d["cg_rel_residual"]["k10"] - k10) <= 1e-10 * k10
 
 
+def test_bench_two_rank_rehearsal_onesided_halo():
+    """The same rehearsal with --cm onesided_put_active: the two ranks are
+    processes sharing GPU 0, the halo moves by peer stores into IPC-mapped
+    windows (one put kernel per exchange), and the run lands on the same
+    residual."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    res = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+         "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus",
+         "2", "--steps", "10", "--warmup", "2", "--grid", "64", "--transport",
+         "gloo", "--cm", "onesided_put_active"],
+        capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    d = _line(res.stdout)
+    _check(d, 2, 10, 2)
+    assert "peer stores" in d["config"]["halo"] and d["halo_selfcheck"] == "ok"
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"),
+                          "--grid", "64", "--steps", "10", "--warmup", "2",
+                          "--no-cpu-baseline", "--no-extras"],
+                         capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-3000:]
+    k10 = _line(one.stdout)["cg_rel_residual"]["k10"]
+    assert abs(d["cg_rel_residual"]["k10"] - k10) <= 1e-10 * k10
+
+
 def _gpu_count():
     import torch
     return torch.cuda.device_count()  # does not initialise the GPU
