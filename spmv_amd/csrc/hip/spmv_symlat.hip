@@ -222,11 +222,18 @@ __global__ __launch_bounds__(kBlock) void csr_sym_lattice_kernel(
                                  beta, out);
   SlatRegs<T> qB;
   int slot = 0;
+  // y is stored one step late, right behind the next step's wait (which
+  // covers stores too): see csr_lxw_kernel
+  T y_late = T(0);
+  int32_t i_late = -1;
   auto step = [&](const SlatRegs<T>& q, SlatRegs<T>& qn) {
     // everything of block k has landed; all waves have left block k-1 (see
     // csr_lattice_kernel for why this is the builtin)
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
     __syncthreads();
+    if (i_late >= 0)
+      out[i_late] = y_late;
+    i_late = -1;
     if (nxt.rb >= 0)
       issue(nxt, slot ^ 1);
     qn = slat_loads<T>(nxt, g, t, num_rows, rowptr, mask, diagonal, in, beta,
@@ -274,7 +281,8 @@ __global__ __launch_bounds__(kBlock) void csr_sym_lattice_kernel(
           y += term;
           cy += term;
         }
-      out[i] = y;
+      y_late = y;
+      i_late = i;
       if constexpr (DOT) // in . (alpha A in): the finished row without beta y0
         dot_acc += (double)q.xi * (double)cy;
     }
@@ -289,6 +297,8 @@ __global__ __launch_bounds__(kBlock) void csr_sym_lattice_kernel(
       break;
     step(qB, qA);
   }
+  if (i_late >= 0)
+    out[i_late] = y_late;
   if constexpr (DOT)
     spmv_dot_epilogue(dot, dot_acc, s_red);
 }
