@@ -243,6 +243,8 @@ struct spmv_hip_csr_plan {
   int wdia_K = 0;
   int32_t wdia_D[kWdiaMaxOff] = {};
   const void* wdia_values0 = nullptr;
+  void* wdia32_val = nullptr;     // ... and the fp32 copy of the mixed SpMV
+  const void* wdia32_values0 = nullptr;
   int wdia = 0;                   // use it (plan_set "wdia")
   int wdia_xcd_group = 4;         // consecutive row blocks per XCD (0 = off;
                                   // 27-point 256^3: 0.820 -> 0.803 ms)
@@ -389,6 +391,11 @@ int spmv_wdia_run_f64(const spmv_hip_csr_plan* pl, hipStream_t st, double alpha,
                       const double* in, double beta, double* out, DotOut dot);
 int spmv_wdia_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st, float alpha,
                       const float* in, float beta, float* out);
+int spmv_wdia_bake_f32f64(spmv_hip_csr_plan* pl, const float* values32,
+                          hipStream_t st); // fp32 copy for the mixed SpMV
+int spmv_wdia_run_f32f64(const spmv_hip_csr_plan* pl, hipStream_t st,
+                         double alpha, const double* in, double beta,
+                         double* out, DotOut dot);
 // spmv_lat.hip
 int spmv_lat_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
                    const int32_t* colind);

@@ -1098,6 +1098,10 @@ int run_mixed(const spmv_hip_csr_plan* pl, hipStream_t st,
   if (pl->sdia && pl->sdia32_val && values == pl->sdia32_values0)
     return spmv_sdia_run_f32f64(pl, st, alpha, in, beta, out,
                                 DOT ? dot : DotOut());
+  // ... or of a matrix in the wide diagonal form (spmv_wdia.hip)
+  if (pl->wdia && pl->wdia32_val && values == pl->wdia32_values0)
+    return spmv_wdia_run_f32f64(pl, st, alpha, in, beta, out,
+                                DOT ? dot : DotOut());
   if (pl->lat && aligned16(values))
     return spmv_lat_run_f32f64(pl, st, rowptr, values, alpha, in, beta, out,
                                DOT ? dot : DotOut());
@@ -1406,7 +1410,13 @@ int spmv_hip_csr_plan_bake_values_f32f64(spmv_hip_ctx* ctx,
 {
   SPMV_SET_DEVICE(ctx);
   SPMV_REQUIRE(plan && plan->ctx == ctx);
-  return spmv_sdia_bake_f32f64(plan, values32, spmv_stream(ctx, stream));
+  hipStream_t st = spmv_stream(ctx, stream);
+  // whichever form holds the fp64 values by offset gets its fp32 twin
+  if (plan->wdia_val && !plan->sdia_val)
+    return spmv_wdia_bake_f32f64(plan, values32, st);
+  if (values32 == nullptr)
+    (void)spmv_wdia_bake_f32f64(plan, nullptr, st);
+  return spmv_sdia_bake_f32f64(plan, values32, st);
 }
 
 int spmv_hip_zwalk_table(int32_t num_rows, int64_t plane_rows, int grid,
@@ -1600,6 +1610,8 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
       b += narr * plan->sdia_len * 4 + n;
     if (plan->wdia_val)
       b += (int64_t)plan->wdia_K * plan->wdia_len * plan->wdia_elem + 4 * n;
+    if (plan->wdia32_val)
+      b += (int64_t)plan->wdia_K * plan->wdia_len * 4;
     if (plan->t_ptr)
       b += 4 * (n + 1) + 8 * nnz;
     if (plan->zw_table)
@@ -1612,6 +1624,8 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
     *value = plan->sdia_val ? plan->sdia_general : 0;
   else if (!strcmp(key, "sdia_mixed"))
     *value = plan->sdia32_val ? 1 : 0;
+  else if (!strcmp(key, "wdia_mixed"))
+    *value = plan->wdia32_val ? 1 : 0;
   else if (!strcmp(key, "sdia_chain"))
     *value = plan->sdia_chain;
   else if (!strcmp(key, "sdia_nt"))

@@ -180,6 +180,9 @@ __global__ __launch_bounds__(kBlock) void wdia_bake_kernel(
 
 void wdia_free_arrays(spmv_hip_csr_plan* pl)
 {
+  (void)hipFree(pl->wdia32_val);
+  pl->wdia32_val = nullptr;
+  pl->wdia32_values0 = nullptr;
   (void)hipFree(pl->wdia_val);
   (void)hipFree(pl->wdia_mask);
   pl->wdia_val = nullptr;
@@ -307,9 +310,70 @@ int wdia_bake(spmv_hip_csr_plan* pl, const T* values, hipStream_t st)
   return SPMV_HIP_OK;
 }
 
-template <typename T, bool DOT>
-int wdia_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
-                T beta, T* out, DotOut dot)
+// The fp32 copy of the mixed-precision SpMV (fp64 plans whose values are baked
+// by offset): the same arrays filled from the caller's fp32 values; the masks
+// -- the structure -- are those of the fp64 copy.
+int wdia_bake_mixed(spmv_hip_csr_plan* pl, const float* values32, hipStream_t st)
+{
+  SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
+  (void)hipFree(pl->wdia32_val);
+  pl->wdia32_val = nullptr;
+  pl->wdia32_values0 = nullptr;
+  if (values32 == nullptr)
+    return SPMV_HIP_OK; // dropped
+  if (!pl->wdia_val || pl->wdia_elem != 8)
+    return SPMV_HIP_ENOTSUP;
+  const auto t_begin = std::chrono::steady_clock::now();
+  WdiaOffsets off;
+  for (int k = 0; k < kWdiaMaxOff; ++k)
+    off.D[k] = pl->wdia_D[k];
+  const int32_t n = pl->num_rows;
+  const size_t bytes = (size_t)pl->wdia_K * pl->wdia_len * sizeof(float);
+  void* sval = nullptr;
+  uint32_t* msk = nullptr; // rewritten with the same bits: the kernel's output
+  int32_t* d_fail = nullptr;
+  int32_t h_fail = 0;
+  hipError_t e = hipMalloc(&sval, bytes);
+  if (e == hipSuccess)
+    e = hipMalloc(&msk, sizeof(uint32_t) * (size_t)n);
+  if (e == hipSuccess)
+    e = hipMalloc(&d_fail, sizeof(int32_t));
+  if (e == hipSuccess)
+    e = hipMemsetAsync(sval, 0, bytes, st);
+  if (e == hipSuccess)
+    e = hipMemsetAsync(d_fail, 0, sizeof(int32_t), st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL((wdia_bake_kernel<float>), dim3(spmv_grid_for(pl->ctx, n, kBlock)),
+                       dim3(kBlock), 0, st, n, pl->wdia_K, off, pl->rowptr0,
+                       pl->colind0, values32, pl->wdia_len,
+                       static_cast<float*>(sval), msk, d_fail);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(&h_fail, d_fail, sizeof(int32_t), hipMemcpyDeviceToHost,
+                       st);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st);
+  (void)hipFree(d_fail);
+  (void)hipFree(msk);
+  if (e != hipSuccess || h_fail) {
+    (void)hipFree(sval);
+    if (e == hipErrorOutOfMemory)
+      (void)hipGetLastError();
+    return (e != hipSuccess && e != hipErrorOutOfMemory) ? static_cast<int>(e)
+                                                         : SPMV_HIP_ENOTSUP;
+  }
+  pl->wdia32_val = sval;
+  pl->wdia32_values0 = values32;
+  pl->plan_us += (int)std::chrono::duration_cast<std::chrono::microseconds>(
+                     std::chrono::steady_clock::now() - t_begin)
+                     .count();
+  return SPMV_HIP_OK;
+}
+
+template <typename TV, typename T, bool DOT>
+int wdia_launch(const spmv_hip_csr_plan* pl, hipStream_t st, const TV* sval,
+                T alpha, const T* in, T beta, T* out, DotOut dot)
 {
   const int nrb = (pl->num_rows + kRows - 1) / kRows;
   WdiaOffsets off;
@@ -317,10 +381,9 @@ int wdia_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* i
     off.D[k] = pl->wdia_D[k];
   RowBlockOrder ord = pl->row_block_order(nrb);
   ord.xcd_group = pl->wdia_xcd_group;
-  hipLaunchKernelGGL((csr_wdia_kernel<T, T, DOT>), dim3(wdia_grid(pl)),
+  hipLaunchKernelGGL((csr_wdia_kernel<TV, T, DOT>), dim3(wdia_grid(pl)),
                      dim3(kBlock), 0, st, pl->num_rows, pl->num_cols,
-                     pl->wdia_len, pl->wdia_K, off,
-                     static_cast<const T*>(pl->wdia_val), pl->wdia_mask, alpha,
+                     pl->wdia_len, pl->wdia_K, off, sval, pl->wdia_mask, alpha,
                      in, beta, out, dot, ord);
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;
@@ -341,16 +404,37 @@ int spmv_wdia_bake_f32(spmv_hip_csr_plan* pl, const float* values, hipStream_t s
   return wdia_bake<float>(pl, values, st);
 }
 
+int spmv_wdia_bake_f32f64(spmv_hip_csr_plan* pl, const float* values32,
+                          hipStream_t st)
+{
+  return wdia_bake_mixed(pl, values32, st);
+}
+
 int spmv_wdia_run_f64(const spmv_hip_csr_plan* pl, hipStream_t st, double alpha,
                       const double* in, double beta, double* out, DotOut dot)
 {
+  const double* sv = static_cast<const double*>(pl->wdia_val);
   if (dot.partials)
-    return wdia_launch<double, true>(pl, st, alpha, in, beta, out, dot);
-  return wdia_launch<double, false>(pl, st, alpha, in, beta, out, dot);
+    return wdia_launch<double, double, true>(pl, st, sv, alpha, in, beta, out,
+                                             dot);
+  return wdia_launch<double, double, false>(pl, st, sv, alpha, in, beta, out, dot);
+}
+
+int spmv_wdia_run_f32f64(const spmv_hip_csr_plan* pl, hipStream_t st,
+                         double alpha, const double* in, double beta,
+                         double* out, DotOut dot)
+{
+  const float* sv = static_cast<const float*>(pl->wdia32_val);
+  if (dot.partials)
+    return wdia_launch<float, double, true>(pl, st, sv, alpha, in, beta, out,
+                                            dot);
+  return wdia_launch<float, double, false>(pl, st, sv, alpha, in, beta, out, dot);
 }
 
 int spmv_wdia_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st, float alpha,
                       const float* in, float beta, float* out)
 {
-  return wdia_launch<float, false>(pl, st, alpha, in, beta, out, DotOut());
+  return wdia_launch<float, float, false>(
+      pl, st, static_cast<const float*>(pl->wdia_val), alpha, in, beta, out,
+      DotOut());
 }

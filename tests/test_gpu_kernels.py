@@ -1810,6 +1810,28 @@ def test_wide_diagonal_form_bit_exact(lat_ctx, dtype):
                     got = float(np.sum(part.numpy()))
                     assert abs(got - want) <= 1e-12 * (np.abs(x) @ np.abs(y_ref))
                 dy.free()
+        if dtype == np.float64:
+            # mixed precision: the fp32 copy by offset (plan_bake_values_f32f64)
+            va32 = va.astype(np.float32)
+            d32 = ctx.upload(va32, np.float32)
+            hip.call("spmv_hip_csr_plan_bake_values_f32f64", ctx.h, blk.plan,
+                     d32.ptr, None)
+            assert blk.get("wdia_mixed") == 1, name
+            y32_ref = oracle.csr_spmv(rp, ci, va32.astype(np.float64), x, -0.5,
+                                      0.75, y0)
+            for vals in (d32, ctx.upload(va32, np.float32)):  # baked / another
+                dy = ctx.upload(y0)
+                hip.call("spmv_hip_csr_spmv_f32f64", ctx.h, blk.plan, N, N,
+                         blk.nnz, blk.rowptr.ptr, blk.colind.ptr, vals.ptr, -0.5,
+                         dx.ptr, 0.75, dy.ptr, None, None)
+                assert np.array_equal(dy.numpy(), y32_ref), name
+                dy.free()
+                if vals is not d32:
+                    vals.free()
+            hip.call("spmv_hip_csr_plan_bake_values_f32f64", ctx.h, blk.plan,
+                     None, None)
+            assert blk.get("wdia_mixed") == 0
+            d32.free()
         # another value array of the same shape: the CSR-order kernels
         y_ref = oracle.csr_spmv(rp, ci, va, x)
         dy = ctx.upload(np.full(N, np.nan, dtype), dtype)

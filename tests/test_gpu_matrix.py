@@ -595,6 +595,15 @@ def test_27_point_stencil_device_generator_and_kernels(exec_, comm):
             exec_.memset(d_y, 0xFF, 8 * N)
             A.mult(d_x, d_y)
             assert np.array_equal(exec_.copy_to_host(d_y, N), y_ref), (n, opts)
+            if A.plan_get("wdia"):
+                # mixed precision on the wide diagonal form: the values (26,
+                # -1) are exact in fp32, so the fp32 copy gives the same bits
+                assert A.enable_mixed() and A.plan_get("wdia_mixed") == 1
+                A.use_mixed(True)
+                exec_.memset(d_y, 0xFF, 8 * N)
+                A.mult(d_x, d_y)
+                A.use_mixed(False)
+                assert np.array_equal(exec_.copy_to_host(d_y, N), y_ref), n
             A.close()
             exec_.free(d_x), exec_.free(d_y)
     n = 160
