@@ -21,8 +21,10 @@ Pricing.  Every `frac` in the line is PHYSICAL: the bytes the kernel's data
 format makes it load and store per launch (`requested_bytes_per_launch`) over
 the measured launch time over the 8 TB/s HBM peak, so it cannot exceed 1.  The
 plans re-encode the CSR arrays at set-up time (16-bit column offsets, no index
-stream at all for lattice matrices, half the values for symmetric ones), so
-the same launch also has a CSR-EQUIVALENT rate -- SURVEY 8d's algorithmic CSR
+stream at all for lattice matrices, half the values for symmetric ones, NO
+values where every diagonal is constant -- the Poisson matrix; sub-record
+`value_stream_spmv` and `--no-const` time the same matrix with its values
+streamed), so the same launch also has a CSR-EQUIVALENT rate -- SURVEY 8d's algorithmic CSR
 bytes (12 B per entry, row pointer, x, y) over the same time: what a kernel
 streaming the caller's CSR arrays would have to sustain to be as fast.  That
 figure is reported as `csr_equivalent_gbs` / `frac_csr_equivalent` and may
@@ -94,6 +96,10 @@ def parse():
     ap.add_argument("--no-bake", action="store_true",
                     help="no plan-time symmetry check of the general matrix: the "
                          "lattice kernel on the caller's CSR values (experiments)")
+    ap.add_argument("--no-const", action="store_true",
+                    help="stream the matrix values even though every diagonal of "
+                         "the Poisson matrix is constant: the diagonal form as a "
+                         "lattice matrix with varying coefficients gets it")
     ap.add_argument("--no-lx", action="store_true",
                     help="with --no-lattice: the plain gather kernel")
     ap.add_argument("--mixed-grid", type=int, default=216,
@@ -266,6 +272,13 @@ def kernel_of(A, symmetric):
     y_x = rows * 8 + cols * 8
     if symmetric:
         algo = rows * 8 * 3 + (rows + 1) * 4 + nnz * 12  # SURVEY 8d B_sym
+        if A.plan_get("sdia") and A.plan_get("sdia_const"):
+            return ("csr_const_dia_kernel<double> (symmetric storage whose "
+                    "diagonals are constant bit for bit: the plan keeps one "
+                    "number per diagonal and a mask byte per row, no values are "
+                    "streamed; same products and sums in the reference's order, "
+                    "atomic-free, bit-exact)",
+                    algo, rows * 1 + y_x)
         if A.plan_get("sdia"):
             nd = A.plan_get("sdia_offsets")
             return ("csr_sym_dia_kernel<double> (symmetric diagonal form: the "
@@ -283,6 +296,23 @@ def kernel_of(A, symmetric):
         return ("csr_sym_window_kernel<double> (LDS window + global atomics)",
                 algo, algo)
     algo = nnz * 12 + (rows + 1) * 4 + y_x  # SURVEY 8d B_csr
+    if A.plan_get("wdia") and A.plan_get("wdia_const"):
+        K = A.plan_get("wdia_offsets")
+        return (f"csr_wdia_kernel<double, constant> (wide diagonal form: the "
+                f"matrix sits on {K} diagonals and every one of them is constant "
+                "bit for bit; the plan keeps one number per diagonal and a 32-bit "
+                "presence mask per row, no values are streamed; rows summed in "
+                "the CSR kernel's order: bit-exact; fused p.Ap)",
+                algo, rows * 4 + y_x)
+    if A.plan_get("wdia") and A.plan_get("wdia_half"):
+        K = A.plan_get("wdia_offsets")
+        return (f"csr_wdia_kernel<double, half> (wide diagonal form: the matrix "
+                f"sits on {K} diagonals and was found symmetric bit for bit; the "
+                f"plan keeps the values of the {(K + 1) // 2} diagonals <= 0 and a "
+                "32-bit presence mask per row, an upper entry is read as the "
+                "lower entry of its column's row; rows summed in the CSR "
+                "kernel's order: bit-exact; fused p.Ap)",
+                algo, rows * (8 * ((K + 1) // 2) + 4) + y_x)
     if A.plan_get("wdia"):
         K = A.plan_get("wdia_offsets")
         return (f"csr_wdia_kernel<double> (wide diagonal form: the matrix sits on "
@@ -290,6 +320,14 @@ def kernel_of(A, symmetric):
                 "presence mask per row; every load coalesced, no index stream, "
                 "rows summed in the CSR kernel's order: bit-exact; fused p.Ap)",
                 algo, rows * (8 * K + 4) + y_x)
+    if A.plan_get("sdia") and A.plan_get("sdia_const"):
+        return ("csr_const_dia_kernel<double, general order> (every diagonal of "
+                "the matrix is constant bit for bit: the plan keeps one number "
+                "per diagonal and a mask byte per row, no values are streamed; "
+                "the kernel does the CSR kernel's multiplications and additions "
+                "in its order with the constant in a register: bit-exact; fused "
+                "p.Ap)",
+                algo, rows * 1 + y_x)
     if A.plan_get("sdia") and A.plan_get("sdia_general") == 2:
         nd = A.plan_get("sdia_offsets")
         return ("csr_sym_dia_kernel<double, general order, full> (lattice matrix "
@@ -326,8 +364,8 @@ def plan_record(A):
     return {"plan_ms": A.plan_get("plan_us") / 1e3,
             "plan_extra_bytes": A.plan_get("plan_kib") * 1024,
             "form": {k: A.plan_get(k) for k in
-                     ("lat", "lx", "lxw", "wdia", "slat", "sdia", "sym_det",
-                      "zwalk")}}
+                     ("lat", "lx", "lxw", "wdia", "wdia_const", "slat", "sdia",
+                      "sdia_const", "sym_det", "zwalk")}}
 
 
 def pmc_traffic(record, kernel_name, n, world):
@@ -407,7 +445,8 @@ def timed_spmv(exec_, A, N, _lib, reps, crosscheck=False):
 
 
 def spmv_record(exec_, comm, host, _lib, n, symmetric, reps, lattice=True,
-                bake=True, skew_ppm=0, lx=True, record=None, stencil=7):
+                bake=True, skew_ppm=0, lx=True, record=None, stencil=7,
+                const=True):
     """one plain-SpMV sub-record on the n^3 matrix in the given storage/form
     (skew_ppm: the generator's non-symmetric variant of the matrix; stencil 27:
     the 27-point operator)"""
@@ -419,6 +458,8 @@ def spmv_record(exec_, comm, host, _lib, n, symmetric, reps, lattice=True,
         opts[b"lx_min_nnz"] = (1 << 62, 1 << 20)
     if not bake:
         opts[b"bake_general"] = (0, 1)
+    if not const:  # stream the values even where the diagonals are constant
+        opts[b"const_diagonals"] = (0, 1)
     for k, (v, _) in opts.items():
         _lib.call("spmv_hip_ctx_set_option", ctx, k, v)
     try:
@@ -431,7 +472,8 @@ def spmv_record(exec_, comm, host, _lib, n, symmetric, reps, lattice=True,
     rec = matrix_spmv_record(
         exec_, A, _lib, symmetric, reps, record, n,
         f"{name}_{'symmetric-csr' if symmetric else 'csr'}_fp64_spmv"
-        + (f"_skew{skew_ppm}ppm" if skew_ppm else ""), crosscheck=stencil != 7)
+        + (f"_skew{skew_ppm}ppm" if skew_ppm else "")
+        + ("" if const else "_values_streamed"), crosscheck=stencil != 7)
     A.close()
     return rec
 
@@ -564,6 +606,8 @@ def main():
         _lib.call("spmv_hip_ctx_set_option", ctx, b"lat_min_nnz", 1 << 62)
     if args.no_bake:
         _lib.call("spmv_hip_ctx_set_option", ctx, b"bake_general", 0)
+    if args.no_const:
+        _lib.call("spmv_hip_ctx_set_option", ctx, b"const_diagonals", 0)
     if args.no_lx:
         _lib.call("spmv_hip_ctx_set_option", ctx, b"lx_min_nnz", 1 << 62)
     cm = getattr(host, args.cm.upper())
@@ -722,9 +766,11 @@ def main():
                                   "(bytes_per_launch); csr_equivalent_gbs prices "
                                   "SURVEY 8d's CSR bytes over the same time and "
                                   "is not a bandwidth; sub-records "
+                                  "value_stream_spmv (lattice matrix whose "
+                                  "coefficients vary: the values are streamed), "
                                   "csr_lx_spmv / csr_rowblock_spmv / "
-                                  "unstructured_spmv are the kernels a matrix "
-                                  "without lattice structure gets"),
+                                  "unstructured_spmv (no lattice structure) are "
+                                  "the kernels other matrices get"),
                          "kernel": kernel,
                          "avg_launch_ms": spmv_ms_avg,
                          "launches_timed": spmv_launches},
@@ -834,8 +880,20 @@ def main():
                 # diagonal form; and the CSR-order lattice kernel (no baked
                 # copy of the values) on the Poisson matrix itself
                 if not (args.no_lattice or args.no_lx or args.no_bake):
+                    # the kernels that STREAM the values (what a lattice matrix
+                    # with varying coefficients gets), on the same matrix with
+                    # the constant-diagonal detection switched off: the half
+                    # diagonal form (symmetric matrix), symmetric storage, and
+                    # the full diagonal form on the skewed variant
+                    if not args.no_const:
+                        out["value_stream_spmv"] = rec(
+                            "value_stream_spmv", n, False, 20, const=False)
+                        out["symmetric_value_stream_spmv"] = rec(
+                            "symmetric_value_stream_spmv", n, True, 20,
+                            const=False)
                     out["csr_nonsymmetric_spmv"] = rec(
-                        "csr_nonsymmetric_spmv", n, False, 20, skew_ppm=1000)
+                        "csr_nonsymmetric_spmv", n, False, 20, skew_ppm=1000,
+                        const=False)
                     out["csr_lattice_spmv"] = rec("csr_lattice_spmv", n, False,
                                                   20, bake=False)
                 # What a CSR matrix WITHOUT lattice structure gets, on the same
@@ -853,6 +911,8 @@ def main():
                 # BASELINE north_star: plain SpMV on the ~10 M-row matrix: the
                 # default plan, and the CSR-order kernels next to it
                 out["north_star_spmv"] = rec("north_star_spmv", 216, False, 200)
+                out["north_star_value_stream_spmv"] = rec(
+                    "north_star_value_stream_spmv", 216, False, 200, const=False)
                 out["north_star_lattice_spmv"] = rec(
                     "north_star_lattice_spmv", 216, False, 200, bake=False)
                 out["north_star_lx_spmv"] = rec(
@@ -870,6 +930,11 @@ def main():
                 # tests/test_gpu_matrix.py and cpu_baseline.parity_checks.
                 out["stencil27_spmv"] = rec("stencil27_spmv", args.stencil27_grid,
                                             False, 20, stencil=27)
+                # ... with its values streamed (26 / -1 are constants too): the
+                # half form, the matrix being symmetric
+                out["stencil27_value_stream_spmv"] = rec(
+                    "stencil27_value_stream_spmv", args.stencil27_grid, False, 20,
+                    stencil=27, const=False)
                 Au = host.Matrix.create_unstructured(self_comm, exec_,
                                                      args.unstructured_rows)
                 out["unstructured_spmv"] = matrix_spmv_record(

@@ -68,6 +68,9 @@ int spmv_hip_synchronize(spmv_hip_ctx* ctx); /* whole device */
  *   how large an x) plans build the lattice / LX forms.
  *   "bake_general": 0 = plan_bake_values on a general plan always returns
  *   SPMV_HIP_ENOTSUP (the CSR-order kernels on the caller's values).
+ *   "wdia_half": 0 = the wide diagonal form (a baked copy of a general matrix
+ *   with <= 32 diagonals) keeps every diagonal even when it finds the matrix
+ *   symmetric bit for bit; default 1 = then only the diagonals <= 0.
  *   "poisson_skew_ppm": the device generator below writes a NON-symmetric
  *   variant (lower neighbours -1 - s, upper -1 + s, s = value * 1e-6).
  *   "poisson_stencil": 7 (default) or 27 -- the generator writes the 27-point

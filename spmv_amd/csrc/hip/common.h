@@ -33,6 +33,13 @@ struct spmv_hip_ctx {
   // plan_bake_values on a GENERAL plan looks for a symmetric matrix and keeps
   // its lower half by offset ("bake_general"; 0: always SPMV_HIP_ENOTSUP)
   int bake_general = 1;
+  // ... and the wide diagonal form keeps only the offsets <= 0 of a matrix it
+  // finds symmetric bit for bit ("wdia_half"; 0: always all offsets)
+  int wdia_half = 1;
+  // the diagonal forms keep ONE number per diagonal and no copy of the values
+  // when every diagonal of the matrix is constant, bit for bit
+  // ("const_diagonals"; 0: always stream the values)
+  int const_diagonals = 1;
   // the device Poisson generator's non-symmetric variant ("poisson_skew_ppm":
   // lower neighbours -1 - s, upper -1 + s, s = value * 1e-6; 0 = the Poisson
   // matrix).  For measurements of kernels on matrices that are not symmetric.

@@ -225,6 +225,11 @@ struct spmv_hip_csr_plan {
                                   // in the general order): 1 = found symmetric,
                                   // lower half stored; 2 = not symmetric, FULL
                                   // form with arrays for the upper entries too
+  // CONSTANT diagonals: no copy of the values -- the mask and one number per
+  // diagonal (lower k | diagonal | upper k; sdia_val is a 64-byte marker)
+  int sdia_const = 0;
+  double sdia_cval[7] = {};
+  double sdia32_cval[7] = {}; // ... of the fp32 values of the mixed SpMV
   // ... and the fp32 copy for the mixed-precision SpMV (general, fp64 plans)
   void* sdia32_val = nullptr;
   uint8_t* sdia32_cmask = nullptr;
@@ -241,7 +246,21 @@ struct spmv_hip_csr_plan {
   int64_t wdia_len = 0;
   int wdia_elem = 0;              // sizeof the baked value type
   int wdia_K = 0;
+  int wdia_narr = 0;              // arrays kept: K (full) or the offsets <= 0
+                                  // (HALF form: the matrix is symmetric)
   int32_t wdia_D[kWdiaMaxOff] = {};
+  int32_t wdia_A[kWdiaMaxOff] = {}; // array and row shift of offset k
+  int32_t wdia_S[kWdiaMaxOff] = {};
+  int wdia_const = 0;               // constant diagonals: no arrays, one number
+  double wdia_cval[kWdiaMaxOff] = {};   // per offset (wdia_val is a marker)
+  double wdia32_cval[kWdiaMaxOff] = {}; // ... of the mixed SpMV's fp32 values
+  // its own plane-walk table (the offsets' widest cluster = the plane distance;
+  // the half form reads the plane ahead and finds it in the L2 one step later)
+  int32_t* wdia_zw_table = nullptr;
+  int wdia_zw_slots = 0, wdia_zw_grid = 0, wdia_zw_segments = 0;
+  int64_t wdia_d2 = 0;
+  int wdia_zwalk = 1; // use it (plan_set "wdia_zwalk")
+  int wdia_blocks_per_cu = kBlocksPerCU;
   const void* wdia_values0 = nullptr;
   void* wdia32_val = nullptr;     // ... and the fp32 copy of the mixed SpMV
   const void* wdia32_values0 = nullptr;
@@ -341,6 +360,11 @@ void spmv_symt_free(spmv_hip_csr_plan* pl);
 int spmv_zwalk_order_build(spmv_hip_csr_plan* pl, int64_t d2, int grid,
                            int segments, bool force);
 void spmv_zwalk_free(spmv_hip_csr_plan* pl);
+// the same table for a kernel that keeps its own (device array, hipFree; null
+// when the lattice is too small for one to pay)
+int spmv_zwalk_table_device(const spmv_hip_csr_plan* pl, int64_t d2, int grid,
+                            int segments, bool force, int32_t** table,
+                            int* slots, int* segs);
 int spmv_walk_grid(const spmv_hip_csr_plan* pl); // grid of the plan's lattice kernel
 // spmv_symlat.hip
 int spmv_slat_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
@@ -383,6 +407,7 @@ int spmv_lxw_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st,
                      float beta, float* out);
 // spmv_wdia.hip
 void spmv_wdia_free(spmv_hip_csr_plan* pl);
+int spmv_wdia_walk_build(spmv_hip_csr_plan* pl, int segments, bool force);
 int spmv_wdia_bake_f64(spmv_hip_csr_plan* pl, const double* values,
                        hipStream_t st); // values == nullptr: drop the copy
 int spmv_wdia_bake_f32(spmv_hip_csr_plan* pl, const float* values,

@@ -117,6 +117,16 @@ int spmv_hip_ctx_set_option(spmv_hip_ctx* ctx, const char* key, int64_t value)
     ctx->poisson_stencil = (int)value;
     return SPMV_HIP_OK;
   }
+  if (!strcmp(key, "const_diagonals")) {
+    SPMV_REQUIRE(value == 0 || value == 1);
+    ctx->const_diagonals = (int)value;
+    return SPMV_HIP_OK;
+  }
+  if (!strcmp(key, "wdia_half")) {
+    SPMV_REQUIRE(value == 0 || value == 1);
+    ctx->wdia_half = (int)value;
+    return SPMV_HIP_OK;
+  }
   if (!strcmp(key, "bake_general")) {
     SPMV_REQUIRE(value == 0 || value == 1);
     ctx->bake_general = (int)value;

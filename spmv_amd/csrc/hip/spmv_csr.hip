@@ -1225,6 +1225,29 @@ static bool zwalk_table(int32_t num_rows, int64_t d2, int grid, int segments,
   return true;
 }
 
+int spmv_zwalk_table_device(const spmv_hip_csr_plan* pl, int64_t d2, int grid,
+                            int segments, bool force, int32_t** d_table,
+                            int* slots, int* segs)
+{
+  *d_table = nullptr;
+  *slots = *segs = 0;
+  SPMV_REQUIRE(d2 > 0 && grid > 0 && segments >= 0);
+  std::vector<int32_t> table;
+  if (!zwalk_table(pl->num_rows, d2, grid, segments, force, &table, segs))
+    return SPMV_HIP_OK;
+  SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
+  SPMV_CHECK_HIP(hipMalloc(d_table, sizeof(int32_t) * table.size()));
+  hipError_t e = hipMemcpy(*d_table, table.data(), sizeof(int32_t) * table.size(),
+                           hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(*d_table);
+    *d_table = nullptr;
+    return static_cast<int>(e);
+  }
+  *slots = (int)table.size();
+  return SPMV_HIP_OK;
+}
+
 int spmv_zwalk_order_build(spmv_hip_csr_plan* pl, int64_t d2, int grid,
                            int segments, bool force)
 {
@@ -1514,6 +1537,18 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
   } else if (!strcmp(key, "wdia")) {
     SPMV_REQUIRE(value == 0 || plan->wdia_val);
     plan->wdia = value != 0;
+  } else if (!strcmp(key, "wdia_blocks_per_cu")) {
+    SPMV_REQUIRE(value >= 1 && value <= kBlocksPerCU);
+    plan->wdia_blocks_per_cu = value;
+    if (plan->wdia_val && plan->wdia_zw_table) // the table is tied to the grid
+      return spmv_wdia_walk_build(plan, 0, true);
+  } else if (!strcmp(key, "wdia_zwalk")) {
+    SPMV_REQUIRE(value == 0 || value == 1);
+    plan->wdia_zwalk = value;
+  } else if (!strcmp(key, "wdia_zwalk_segments")) {
+    // (re)build the wide diagonal form's plane-walk table, whatever the size
+    SPMV_REQUIRE(value >= 0 && plan->wdia_val && plan->wdia_d2 > 0);
+    return spmv_wdia_walk_build(plan, value, true);
   } else if (!strcmp(key, "wdia_xcd_group")) {
     SPMV_REQUIRE(value >= 0 && value <= 4096);
     plan->wdia_xcd_group = value;
@@ -1606,12 +1641,12 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
         = plan->sdia_general == 2 ? 2 * plan->sdia_nd + 1 : plan->sdia_nd + 1;
     if (plan->sdia_val)
       b += narr * plan->sdia_len * plan->sdia_elem + n;
-    if (plan->sdia32_val)
+    if (plan->sdia32_val && !plan->sdia_const)
       b += narr * plan->sdia_len * 4 + n;
     if (plan->wdia_val)
-      b += (int64_t)plan->wdia_K * plan->wdia_len * plan->wdia_elem + 4 * n;
-    if (plan->wdia32_val)
-      b += (int64_t)plan->wdia_K * plan->wdia_len * 4;
+      b += (int64_t)plan->wdia_narr * plan->wdia_len * plan->wdia_elem + 4 * n;
+    if (plan->wdia32_val && !plan->wdia_const)
+      b += (int64_t)plan->wdia_narr * plan->wdia_len * 4;
     if (plan->t_ptr)
       b += 4 * (n + 1) + 8 * nnz;
     if (plan->zw_table)
@@ -1624,6 +1659,21 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
     *value = plan->sdia_val ? plan->sdia_general : 0;
   else if (!strcmp(key, "sdia_mixed"))
     *value = plan->sdia32_val ? 1 : 0;
+  else if (!strcmp(key, "sdia_const"))
+    *value = plan->sdia_val ? plan->sdia_const : 0;
+  else if (!strcmp(key, "wdia_zwalk"))
+    *value = plan->wdia_val && plan->wdia_zwalk && plan->wdia_zw_table ? 1 : 0;
+  else if (!strcmp(key, "wdia_zwalk_segments"))
+    *value = plan->wdia_zw_table ? plan->wdia_zw_segments : 0;
+  else if (!strcmp(key, "wdia_d2"))
+    *value = plan->wdia_val ? plan->wdia_d2 : 0;
+  else if (!strcmp(key, "wdia_const"))
+    *value = plan->wdia_val ? plan->wdia_const : 0;
+  else if (!strcmp(key, "wdia_half"))
+    *value = plan->wdia_val && !plan->wdia_const
+                     && plan->wdia_narr < plan->wdia_K
+                 ? 1
+                 : 0;
   else if (!strcmp(key, "wdia_mixed"))
     *value = plan->wdia32_val ? 1 : 0;
   else if (!strcmp(key, "sdia_chain"))

@@ -52,6 +52,7 @@
 // LDS slots, all value windows of the NEXT row block by LDS-DMA, x / mask / y0
 // of the next block into registers, one barrier per block.
 #include <chrono>
+#include <cstring>
 
 #include "csr_plan.h"
 #include "lat_dma.h"
@@ -373,6 +374,181 @@ __global__ __launch_bounds__(kBlock) void csr_sym_dia_kernel(
     spmv_dot_epilogue(dot, dot_acc, s_red);
 }
 
+// ---------------------------------------------------------------------------
+// CONSTANT diagonals: every entry of a diagonal has the same bits (the 7-point
+// Poisson operator, any constant-coefficient stencil).  The bake keeps the
+// mask byte per row and ONE number per diagonal; the kernel reads no matrix
+// values at all -- 17 B per row (x, y, mask) instead of 49 -- and does the same
+// multiplications and additions in the same order with the constant in a
+// register.  No LDS, no barriers: x, mask and y0 of the next row block are
+// loaded into registers while the current one is summed; the plane chain hands
+// x from plane to plane as in the value-streaming kernel.
+// ---------------------------------------------------------------------------
+struct SdiaConsts {
+  double c[2 * kSdiaMaxOff + 1]; // lower k | diagonal (nd) | upper (nd + 1 + k)
+};
+
+template <typename T, bool DOT, bool GEN, bool TAB>
+__global__ __launch_bounds__(kBlock) void csr_const_dia_kernel(
+    int32_t num_rows, const uint8_t* __restrict__ cmask, T alpha,
+    const T* __restrict__ in, T beta, T* __restrict__ out, DotOut dot,
+    RowBlockOrder ord, SdiaGeom g, SdiaConsts cv)
+{
+  __shared__ double s_red[kBlock / 64];
+  const int t = threadIdx.x;
+  const int stride = gridDim.x;
+  const int num_slots = order_slots(ord);
+  double dot_acc = 0.0;
+  T vl[kSdiaMaxOff], vu[kSdiaMaxOff];
+#pragma unroll
+  for (int k = 0; k < kSdiaMaxOff; ++k) {
+    vl[k] = k < g.nd ? (T)cv.c[k] : T(0);
+    vu[k] = k < g.nd ? (T)cv.c[g.nd + 1 + k] : T(0);
+  }
+  const T d = (T)cv.c[g.nd];
+
+  int it = blockIdx.x;
+  int cur = order_slot_decode(ord, order_slot_raw_t<TAB>(ord, it, num_slots));
+  int nxt_raw = order_slot_raw_t<TAB>(ord, it + stride, num_slots);
+  SdiaRegs<T> qB;
+  qB.xi = T(0);
+  qB.xu[0] = T(0);
+  SdiaRegs<T> qA = sdia_loads<T>(cur, g, t, num_rows, cmask, in, beta, out,
+                                 false, qB);
+  auto step = [&](const SdiaRegs<T>& q, SdiaRegs<T>& qn) {
+    const int nxt = order_slot_decode(ord, nxt_raw);
+    const int nn_raw = order_slot_raw_t<TAB>(ord, it + 2 * stride, num_slots);
+    const bool chain = g.chain_blocks > 0 && cur >= 0 && nxt >= 0
+                       && nxt - cur == g.chain_blocks;
+    qn = sdia_loads<T>(nxt, g, t, num_rows, cmask, in, beta, out, chain, q);
+    const int32_t i = cur * kRows + t;
+    if (cur >= 0 && i < num_rows) {
+      T y, cy;
+      if constexpr (GEN) {
+        T sum = 0; // csr_kernels.cpp:45
+#pragma unroll
+        for (int k = 0; k < kSdiaMaxOff; ++k)
+          if (k < g.nd && ((q.cm >> k) & 1u)) // :46-47, ascending column
+            sum += vl[k] * q.xl[k];
+        if ((q.cm >> 3) & 1u)
+          sum += d * q.xi;
+#pragma unroll
+        for (int k = kSdiaMaxOff - 1; k >= 0; --k)
+          if (k < g.nd && ((q.cm >> (4 + k)) & 1u))
+            sum += vu[k] * q.xu[k];
+        cy = alpha * sum; // :49
+        y = cy;
+        if (beta != T(0))
+          y = cy + beta * q.y0;
+      } else {
+        T sum = d * q.xi; // csr_kernels.cpp:28
+#pragma unroll
+        for (int k = 0; k < kSdiaMaxOff; ++k)
+          if (k < g.nd && ((q.cm >> k) & 1u)) // :34, left to right
+            sum += vl[k] * q.xl[k];
+        const T c = alpha * sum; // :39
+        y = c, cy = c;
+        if (beta != T(0))
+          y = c + beta * q.y0;
+        // the column's entries in ascending row order: nearest row first
+#pragma unroll
+        for (int k = kSdiaMaxOff - 1; k >= 0; --k)
+          if (k < g.nd && ((q.cm >> (4 + k)) & 1u)) { // :35
+            const T term = (alpha * vu[k]) * q.xu[k];
+            y += term;
+            cy += term;
+          }
+      }
+      if (g.nt_store) // uniform
+        __builtin_nontemporal_store(y, out + i);
+      else
+        out[i] = y;
+      if constexpr (DOT)
+        dot_acc += (double)q.xi * (double)cy;
+    }
+    cur = nxt;
+    nxt_raw = nn_raw;
+    it += stride;
+  };
+  while (it < num_slots) {
+    step(qA, qB);
+    if (it >= num_slots)
+      break;
+    step(qB, qA);
+  }
+  if constexpr (DOT)
+    spmv_dot_epilogue(dot, dot_acc, s_red);
+}
+
+// Is every diagonal constant?  Pass 1 (VERIFY = false) picks, per diagonal, the
+// bits of whichever entry gets there first; pass 2 compares every entry with
+// its diagonal's pick and stops at the first difference.  Slots as SdiaConsts.
+// GENERAL: entries are classified by col - row (offsets u0 > u1 > u2); else
+// symmetric storage: row i holds its lower entries in ascending column order
+// (mask bit k set = offset k present) and `diagonal[i]`.
+struct SdiaConstProbe {
+  unsigned long long bits[2 * kSdiaMaxOff + 1];
+  int seen[2 * kSdiaMaxOff + 1];
+  int fail;
+};
+
+template <typename T>
+__device__ __forceinline__ unsigned long long value_bits(T v)
+{
+  if constexpr (sizeof(T) == 8)
+    return (unsigned long long)__double_as_longlong(v);
+  else
+    return (unsigned long long)(unsigned)__float_as_int(v);
+}
+
+template <typename T, bool GENERAL, bool VERIFY>
+__global__ __launch_bounds__(kBlock) void sdia_const_kernel(
+    int32_t num_rows, int nd, int u0, int u1, int u2,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
+    const uint8_t* __restrict__ mask, const T* __restrict__ values,
+    const T* __restrict__ diagonal, SdiaConstProbe* __restrict__ pr)
+{
+  auto visit = [&](int slot, T v) {
+    const unsigned long long b = value_bits(v);
+    if constexpr (VERIFY) {
+      if (pr->bits[slot] != b && !*(volatile int*)&pr->fail)
+        atomicOr(&pr->fail, 1);
+    } else {
+      if (*(volatile int*)&pr->seen[slot] == 0
+          && atomicCAS(&pr->seen[slot], 0, 1) == 0)
+        pr->bits[slot] = b;
+    }
+  };
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < num_rows;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    if (*(volatile int*)&pr->fail)
+      return;
+    if constexpr (GENERAL) {
+      for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+        const int64_t c = colind[j];
+        if (c == i) {
+          visit(nd, values[j]);
+          continue;
+        }
+        const int64_t u = c < i ? i - c : c - i;
+        const int k = u == u0 ? 0 : (u == u1 ? 1 : (u == u2 ? 2 : -1));
+        if (k < 0 || k >= nd) {
+          atomicOr(&pr->fail, 1);
+          return;
+        }
+        visit(c < i ? k : nd + 1 + k, values[j]);
+      }
+    } else {
+      const unsigned m = mask[i];
+      int32_t j = rowptr[i];
+      for (int k = 0; k < nd; ++k)
+        if ((m >> k) & 1u)
+          visit(k, values[j++]);
+      visit(nd, diagonal[i]);
+    }
+  }
+}
+
 // values in CSR order -> one array per offset (+ the diagonal), zero where a
 // row has no entry; combined mask byte
 template <typename T>
@@ -391,12 +567,14 @@ __global__ __launch_bounds__(kBlock) void sdia_bake_kernel(
       T v = T(0);
       if ((m >> k) & 1u)
         v = values[j++];
-      sval[(int64_t)k * arr_len + i] = v;
+      if (sval) // (null: the mask only -- constant diagonals)
+        sval[(int64_t)k * arr_len + i] = v;
       const int64_t r = i + (k == 0 ? u0 : (k == 1 ? u1 : u2));
       if (r < num_rows && ((mask[r] >> k) & 1u))
         cm |= 1u << (4 + k);
     }
-    sval[(int64_t)nd * arr_len + i] = diagonal[i];
+    if (sval)
+      sval[(int64_t)nd * arr_len + i] = diagonal[i];
     cmask[i] = (uint8_t)(cm | 8u);
   }
 }
@@ -495,7 +673,7 @@ __global__ __launch_bounds__(kBlock) void sdia_bake_general_kernel(
       const int64_t c = colind[j];
       const T v = values[j];
       if (c == i) {
-        if (STORE)
+        if (STORE && sval)
           sval[(int64_t)nd * arr_len + i] = v;
         cm |= 8u;
         continue;
@@ -515,11 +693,11 @@ __global__ __launch_bounds__(kBlock) void sdia_bake_general_kernel(
         continue;
       }
       if (c < i) {
-        if (STORE)
+        if (STORE && sval)
           sval[(int64_t)k * arr_len + i] = v;
         cm |= 1u << k;
       } else {
-        if (FULL && STORE)
+        if (FULL && STORE && sval)
           sval[(int64_t)(nd + 1 + k) * arr_len + i] = v;
         cm |= 1u << (4 + k);
       }
@@ -610,6 +788,8 @@ int sdia_grid(const spmv_hip_csr_plan* pl)
   const int nrb = (pl->num_rows + kRows - 1) / kRows;
   const size_t lds = sdia_lds_bytes<T>(g);
   int per_cu = (int)((160 * 1024) / (lds + 64));
+  if (pl->sdia_const) // no LDS: as many workgroups as the registers allow
+    per_cu = kBlocksPerCU;
   per_cu = per_cu > pl->slat_blocks_per_cu ? pl->slat_blocks_per_cu : per_cu;
   per_cu = per_cu < 1 ? 1 : per_cu;
   int grid = pl->ctx->num_cus * per_cu;
@@ -624,11 +804,64 @@ int sdia_grid(const spmv_hip_csr_plan* pl)
 
 // `sval` / `cmask`: the baked copy to stream (the plan's native one, or the
 // fp32 copy of the mixed-precision SpMV)
+// the constant-diagonal kernel (`cv`: the plan's constants, or those of the
+// fp32 values of the mixed-precision SpMV)
+template <typename T>
+int sdia_const_launch(const spmv_hip_csr_plan* pl, hipStream_t st,
+                      const double* cvals, T alpha, const T* in, T beta, T* out,
+                      DotOut dot)
+{
+  SdiaGeom g = sdia_geom<T>(pl);
+  const int nrb = (pl->num_rows + kRows - 1) / kRows;
+  const int grid = sdia_grid<T>(pl);
+  RowBlockOrder ord = pl->row_block_order(nrb);
+  ord.xcd_group = pl->lat_xcd_group;
+  if (pl->zwalk && pl->zw_table && pl->zw_grid == grid) {
+    ord.table = pl->zw_table;
+    ord.num_slots = pl->zw_slots;
+  }
+  SdiaConsts cv;
+  for (int a = 0; a < 2 * kSdiaMaxOff + 1; ++a)
+    cv.c[a] = cvals[a];
+#define SPMV_CDIA(DOTV, GENV)                                                  \
+  do {                                                                         \
+    if (ord.table)                                                             \
+      hipLaunchKernelGGL((csr_const_dia_kernel<T, DOTV, GENV, true>),          \
+                         dim3(grid), dim3(kBlock), 0, st, pl->num_rows,        \
+                         pl->sdia_cmask, alpha, in, beta, out, dot, ord, g,    \
+                         cv);                                                  \
+    else                                                                       \
+      hipLaunchKernelGGL((csr_const_dia_kernel<T, DOTV, GENV, false>),         \
+                         dim3(grid), dim3(kBlock), 0, st, pl->num_rows,        \
+                         pl->sdia_cmask, alpha, in, beta, out, dot, ord, g,    \
+                         cv);                                                  \
+  } while (0)
+  if (dot.partials) {
+    if (pl->sdia_general)
+      SPMV_CDIA(true, true);
+    else
+      SPMV_CDIA(true, false);
+  } else {
+    if (pl->sdia_general)
+      SPMV_CDIA(false, true);
+    else
+      SPMV_CDIA(false, false);
+  }
+#undef SPMV_CDIA
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
 template <typename TV, typename T>
 int sdia_launch(const spmv_hip_csr_plan* pl, hipStream_t st, const TV* sval,
                 const uint8_t* cmask, T alpha, const T* in, T beta, T* out,
                 DotOut dot)
 {
+  if (pl->sdia_const)
+    return sdia_const_launch<T>(pl, st,
+                                sizeof(TV) == sizeof(T) ? pl->sdia_cval
+                                                        : pl->sdia32_cval,
+                                alpha, in, beta, out, dot);
   const SdiaGeom g = sdia_geom<TV>(pl);
   const int nrb = (pl->num_rows + kRows - 1) / kRows;
   const size_t lds = sdia_lds_bytes<TV>(g);
@@ -842,6 +1075,124 @@ int sdia_is_symmetric(spmv_hip_csr_plan* pl, const T* values, hipStream_t st,
   return e == hipSuccess ? SPMV_HIP_OK : static_cast<int>(e);
 }
 
+// Are the diagonals constant (offsets in pl->sdia_nd / sdia_U)?  Two passes
+// over the values, nothing allocated but the 120-byte probe record.
+template <typename T>
+int sdia_const_probe(spmv_hip_csr_plan* pl, bool general, const T* values,
+                     const T* diagonal, hipStream_t st, bool* yes, double* cvals)
+{
+  *yes = false;
+  SdiaConstProbe* d_pr = nullptr;
+  SdiaConstProbe h_pr;
+  hipError_t e = hipMalloc(&d_pr, sizeof(SdiaConstProbe));
+  if (e == hipSuccess)
+    e = hipMemsetAsync(d_pr, 0, sizeof(SdiaConstProbe), st);
+  if (e == hipSuccess) {
+    const int grid = spmv_grid_for(pl->ctx, pl->num_rows, kBlock);
+    const int nd = pl->sdia_nd, u0 = pl->sdia_U[0], u1 = pl->sdia_U[1],
+              u2 = pl->sdia_U[2];
+    if (general) {
+      hipLaunchKernelGGL((sdia_const_kernel<T, true, false>), dim3(grid),
+                         dim3(kBlock), 0, st, pl->num_rows, nd, u0, u1, u2,
+                         pl->rowptr0, pl->colind0, (const uint8_t*)nullptr,
+                         values, diagonal, d_pr);
+      hipLaunchKernelGGL((sdia_const_kernel<T, true, true>), dim3(grid),
+                         dim3(kBlock), 0, st, pl->num_rows, nd, u0, u1, u2,
+                         pl->rowptr0, pl->colind0, (const uint8_t*)nullptr,
+                         values, diagonal, d_pr);
+    } else {
+      hipLaunchKernelGGL((sdia_const_kernel<T, false, false>), dim3(grid),
+                         dim3(kBlock), 0, st, pl->num_rows, nd, u0, u1, u2,
+                         pl->rowptr0, pl->colind0, pl->slat_mask, values,
+                         diagonal, d_pr);
+      hipLaunchKernelGGL((sdia_const_kernel<T, false, true>), dim3(grid),
+                         dim3(kBlock), 0, st, pl->num_rows, nd, u0, u1, u2,
+                         pl->rowptr0, pl->colind0, pl->slat_mask, values,
+                         diagonal, d_pr);
+    }
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(&h_pr, d_pr, sizeof(SdiaConstProbe), hipMemcpyDeviceToHost,
+                       st);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st);
+  (void)hipFree(d_pr);
+  if (e != hipSuccess)
+    return static_cast<int>(e);
+  if (h_pr.fail)
+    return SPMV_HIP_OK;
+  for (int a = 0; a < 2 * kSdiaMaxOff + 1; ++a) {
+    cvals[a] = 0.0;
+    if (!h_pr.seen[a])
+      continue;
+    if constexpr (sizeof(T) == 8) {
+      double v;
+      memcpy(&v, &h_pr.bits[a], sizeof(v));
+      cvals[a] = v;
+    } else {
+      const unsigned b = (unsigned)h_pr.bits[a];
+      float v;
+      memcpy(&v, &b, sizeof(v));
+      cvals[a] = (double)v; // exact
+    }
+  }
+  if (!general) // the column entries ARE the lower entries
+    for (int k = 0; k < pl->sdia_nd; ++k)
+      cvals[pl->sdia_nd + 1 + k] = cvals[k];
+  *yes = true;
+  return SPMV_HIP_OK;
+}
+
+// ... then the plan keeps the mask byte per row and the constants
+template <typename T>
+int sdia_fill_const(spmv_hip_csr_plan* pl, bool general, const T* values,
+                    const T* diagonal, hipStream_t st, void** out_val,
+                    uint8_t** out_cmask)
+{
+  const int32_t n = pl->num_rows;
+  const SdiaGeom g = sdia_geom<T>(pl);
+  void* tag = nullptr; // the "baked" marker every other check looks at
+  uint8_t* cm = nullptr;
+  int32_t* d_fail = nullptr;
+  int32_t h_fail = 0;
+  hipError_t e = hipMalloc(&tag, 64);
+  if (e == hipSuccess)
+    e = hipMalloc(&cm, (size_t)n);
+  if (e == hipSuccess)
+    e = hipMalloc(&d_fail, sizeof(int32_t));
+  if (e == hipSuccess)
+    e = hipMemsetAsync(d_fail, 0, sizeof(int32_t), st);
+  if (e == hipSuccess) {
+    const int grid = spmv_grid_for(pl->ctx, n, kBlock);
+    if (general)
+      hipLaunchKernelGGL((sdia_bake_general_kernel<T, true, true>), dim3(grid),
+                         dim3(kBlock), 0, st, n, g.nd, g.U[0], g.U[1], g.U[2],
+                         pl->rowptr0, pl->colind0, values, (int64_t)0,
+                         (T*)nullptr, cm, d_fail, 0);
+    else
+      hipLaunchKernelGGL((sdia_bake_kernel<T>), dim3(grid), dim3(kBlock), 0, st,
+                         n, g.nd, g.U[0], g.U[1], g.U[2], pl->rowptr0,
+                         pl->slat_mask, values, diagonal, (int64_t)0,
+                         (T*)nullptr, cm);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(&h_fail, d_fail, sizeof(int32_t), hipMemcpyDeviceToHost,
+                       st);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st);
+  (void)hipFree(d_fail);
+  if (e != hipSuccess || h_fail) {
+    (void)hipFree(tag);
+    (void)hipFree(cm);
+    return e != hipSuccess ? static_cast<int>(e) : SPMV_HIP_ENOTSUP;
+  }
+  *out_val = tag;
+  *out_cmask = cm;
+  return SPMV_HIP_OK;
+}
+
 template <typename T>
 int sdia_bake(spmv_hip_csr_plan* pl, const T* values, const T* diagonal,
               hipStream_t st)
@@ -904,14 +1255,29 @@ int sdia_bake(spmv_hip_csr_plan* pl, const T* values, const T* diagonal,
     // bit (checked first, without allocating), else the full form (the
     // geometry reads the mode from the plan)
     pl->sdia_general = 0;
+    pl->sdia_const = 0;
     int rc = SPMV_HIP_OK;
-    if (general) {
-      bool symmetric = false;
-      rc = sdia_is_symmetric<T>(pl, values, st, &symmetric);
-      pl->sdia_general = symmetric ? 1 : 2;
+    // constant diagonals first: no copy of the values at all (and no need
+    // for symmetry -- the upper diagonals have constants of their own)
+    bool is_const = false;
+    if (pl->ctx->const_diagonals)
+      rc = sdia_const_probe<T>(pl, general, values, diagonal, st, &is_const,
+                               pl->sdia_cval);
+    if (rc == SPMV_HIP_OK && is_const) {
+      pl->sdia_general = general ? 2 : 0;
+      pl->sdia_const = 1; // (sdia_grid reads it)
+      rc = sdia_fill_const<T>(pl, general, values, diagonal, st, &sval, &cm);
+      if (rc != SPMV_HIP_OK)
+        pl->sdia_const = 0;
+    } else {
+      if (rc == SPMV_HIP_OK && general) {
+        bool symmetric = false;
+        rc = sdia_is_symmetric<T>(pl, values, st, &symmetric);
+        pl->sdia_general = symmetric ? 1 : 2;
+      }
+      if (rc == SPMV_HIP_OK)
+        rc = sdia_fill<T>(pl, general, values, diagonal, st, &sval, &cm, &len);
     }
-    if (rc == SPMV_HIP_OK)
-      rc = sdia_fill<T>(pl, general, values, diagonal, st, &sval, &cm, &len);
     if (rc != SPMV_HIP_OK) {
       pl->sdia_general = 0;
       pl->sdia_nd = 0;
@@ -957,6 +1323,22 @@ int sdia_bake_mixed(spmv_hip_csr_plan* pl, const float* values32, hipStream_t st
   if (!pl->sdia_val || !pl->sdia_general || pl->sdia_elem != 8)
     return SPMV_HIP_ENOTSUP;
   const auto t_begin = std::chrono::steady_clock::now();
+  if (pl->sdia_const) {
+    // constant diagonals: the fp32 array must have them too (its own constants)
+    bool is_const = false;
+    const int rcc = sdia_const_probe<float>(pl, true, values32, nullptr, st,
+                                            &is_const, pl->sdia32_cval);
+    if (rcc != SPMV_HIP_OK)
+      return rcc;
+    if (!is_const)
+      return SPMV_HIP_ENOTSUP;
+    SPMV_CHECK_HIP(hipMalloc(&pl->sdia32_val, 64)); // the "baked" marker
+    pl->sdia32_values0 = values32;
+    pl->plan_us += (int)std::chrono::duration_cast<std::chrono::microseconds>(
+                       std::chrono::steady_clock::now() - t_begin)
+                       .count();
+    return SPMV_HIP_OK;
+  }
   if (pl->sdia_general == 1) {
     // the half form needs THESE values symmetric too (the caller's fp32 array
     // is normally the rounded fp64 one, but nothing says so)
@@ -1007,6 +1389,7 @@ static void sdia_free_arrays(spmv_hip_csr_plan* pl)
   pl->sdia_values0 = pl->sdia_diag0 = nullptr;
   pl->sdia_len = 0;
   pl->sdia_elem = 0;
+  pl->sdia_const = 0;
   pl->sdia = 0;
   pl->sdia_general = 0;
   pl->sdia_nd = 0;

@@ -38,6 +38,7 @@
 #include "csr_plan.h"
 
 #include <chrono>
+#include <cstring>
 #include <new>
 
 namespace
@@ -45,16 +46,28 @@ namespace
 
 struct WdiaOffsets {
   int32_t D[kWdiaMaxOff]; // ascending; D[k] = 0 beyond K
+  // where the entry of offset k sits: array A[k], row i + S[k].  Full form:
+  // A[k] = k, S[k] = 0.  HALF form (a matrix found symmetric bit for bit): only
+  // the arrays of the offsets <= 0 exist, and the upper entry (i, i + d) is read
+  // as the lower entry of row i + d: A[k] = the array of -d, S[k] = d.
+  int32_t A[kWdiaMaxOff];
+  int32_t S[kWdiaMaxOff];
 };
 
 // TV = type of the baked values (what is streamed), T = type of x, y and of
 // the arithmetic.
-template <typename TV, typename T, bool DOT>
+// CONST: every diagonal is constant bit for bit -- the entry of offset k is
+// cv.c[k] wherever the mask has it; no values are loaded (`sval` is unused).
+struct WdiaConsts {
+  double c[kWdiaMaxOff];
+};
+
+template <typename TV, typename T, bool DOT, bool CONST>
 __global__ __launch_bounds__(kBlock) void csr_wdia_kernel(
     int32_t num_rows, int32_t num_cols, int64_t arr_len, int K, WdiaOffsets off,
     const TV* __restrict__ sval, const uint32_t* __restrict__ mask, T alpha,
     const T* __restrict__ in, T beta, T* __restrict__ out, DotOut dot,
-    RowBlockOrder ord)
+    RowBlockOrder ord, WdiaConsts cv)
 {
   __shared__ double s_red[kBlock / 64];
   const int t = threadIdx.x;
@@ -87,7 +100,13 @@ __global__ __launch_bounds__(kBlock) void csr_wdia_kernel(
           // does not have is clamped into range and its product never added
           int64_t c = i + off.D[k];
           c = c < 0 ? 0 : (c >= num_cols ? (int64_t)num_cols - 1 : c);
-          v[j] = (T)sval[(int64_t)k * arr_len + i];
+          if constexpr (CONST) {
+            v[j] = (T)cv.c[k];
+          } else {
+            int64_t r = i + off.S[k];
+            r = r < arr_len ? r : arr_len - 1;
+            v[j] = (T)sval[(int64_t)off.A[k] * arr_len + r];
+          }
           x[j] = in[c];
         }
       }
@@ -141,14 +160,164 @@ __global__ __launch_bounds__(kBlock) void wdia_offsets_kernel(
   }
 }
 
-// pass 2: fill the arrays and the masks; fail = a row whose columns do not
-// ascend strictly
+// Is the matrix symmetric, entry for entry and bit for bit?  (Rows ascend -- the
+// bake pass checks that; an unsorted row merely fails the search here and the
+// matrix takes the full form's checks.)  Stops at the first mismatch.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void wdia_bake_kernel(
+__global__ __launch_bounds__(kBlock) void wdia_symmetry_kernel(
+    int32_t num_rows, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ colind, const T* __restrict__ values,
+    int32_t* __restrict__ fail)
+{
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < num_rows;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    if (*(volatile int32_t*)fail)
+      return;
+    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+      const int32_t c = colind[j];
+      if (c == i)
+        continue;
+      bool ok = c >= 0 && c < num_rows;
+      if (ok) {
+        int32_t lo = rowptr[c], hi = rowptr[c + 1]; // binary search for i
+        while (lo < hi) {
+          const int32_t mid = lo + (hi - lo) / 2;
+          if (colind[mid] < (int32_t)i)
+            lo = mid + 1;
+          else
+            hi = mid;
+        }
+        ok = lo < rowptr[c + 1] && colind[lo] == (int32_t)i;
+        if (ok) {
+          const T a = values[j], b = values[lo];
+          if constexpr (sizeof(T) == 8)
+            ok = __double_as_longlong(a) == __double_as_longlong(b);
+          else
+            ok = __float_as_int(a) == __float_as_int(b);
+        }
+      }
+      if (!ok) {
+        if (!*(volatile int32_t*)fail)
+          atomicOr(fail, 1);
+        return;
+      }
+    }
+  }
+}
+
+// Is every diagonal constant, bit for bit?  Pass 1 (VERIFY = false) picks,
+// per offset, the bits of whichever entry gets there first; pass 2 compares
+// every entry with its offset's pick and stops at the first difference.  (A
+// row whose columns do not ascend fails here and again, for good, in the bake
+// pass.)
+struct WdiaConstProbe {
+  unsigned long long bits[kWdiaMaxOff];
+  int seen[kWdiaMaxOff];
+  int fail;
+};
+
+template <typename T, bool VERIFY>
+__global__ __launch_bounds__(kBlock) void wdia_const_kernel(
     int32_t num_rows, int K, WdiaOffsets off, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ colind, const T* __restrict__ values,
-    int64_t arr_len, T* __restrict__ sval, uint32_t* __restrict__ mask,
-    int32_t* __restrict__ fail)
+    WdiaConstProbe* __restrict__ pr)
+{
+  __shared__ int32_t s_D[kWdiaMaxOff];
+  if (threadIdx.x < kWdiaMaxOff)
+    s_D[threadIdx.x] = off.D[threadIdx.x];
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < num_rows;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    if (*(volatile int*)&pr->fail)
+      return;
+    int prev = -1;
+    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+      const int32_t d = (int32_t)((int64_t)colind[j] - i);
+      int k = prev + 1;
+      while (k < K && s_D[k] != d)
+        ++k;
+      if (k >= K) {
+        atomicOr(&pr->fail, 1);
+        return;
+      }
+      unsigned long long b;
+      if constexpr (sizeof(T) == 8)
+        b = (unsigned long long)__double_as_longlong(values[j]);
+      else
+        b = (unsigned long long)(unsigned)__float_as_int(values[j]);
+      if constexpr (VERIFY) {
+        if (pr->bits[k] != b) {
+          atomicOr(&pr->fail, 1);
+          return;
+        }
+      } else {
+        if (*(volatile int*)&pr->seen[k] == 0
+            && atomicCAS(&pr->seen[k], 0, 1) == 0)
+          pr->bits[k] = b;
+      }
+      prev = k;
+    }
+  }
+}
+
+template <typename T>
+int wdia_const_probe(const spmv_hip_csr_plan* pl, int K, const WdiaOffsets& off,
+                     const T* values, hipStream_t st, bool* yes, double* cvals)
+{
+  *yes = false;
+  WdiaConstProbe* d_pr = nullptr;
+  WdiaConstProbe h_pr;
+  hipError_t e = hipMalloc(&d_pr, sizeof(WdiaConstProbe));
+  if (e == hipSuccess)
+    e = hipMemsetAsync(d_pr, 0, sizeof(WdiaConstProbe), st);
+  if (e == hipSuccess) {
+    const int grid = spmv_grid_for(pl->ctx, pl->num_rows, kBlock);
+    hipLaunchKernelGGL((wdia_const_kernel<T, false>), dim3(grid), dim3(kBlock), 0,
+                       st, pl->num_rows, K, off, pl->rowptr0, pl->colind0, values,
+                       d_pr);
+    hipLaunchKernelGGL((wdia_const_kernel<T, true>), dim3(grid), dim3(kBlock), 0,
+                       st, pl->num_rows, K, off, pl->rowptr0, pl->colind0, values,
+                       d_pr);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(&h_pr, d_pr, sizeof(WdiaConstProbe), hipMemcpyDeviceToHost,
+                       st);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st);
+  (void)hipFree(d_pr);
+  if (e != hipSuccess)
+    return static_cast<int>(e);
+  if (h_pr.fail)
+    return SPMV_HIP_OK;
+  for (int k = 0; k < kWdiaMaxOff; ++k) {
+    cvals[k] = 0.0;
+    if (k >= K || !h_pr.seen[k])
+      continue;
+    if constexpr (sizeof(T) == 8) {
+      double v;
+      memcpy(&v, &h_pr.bits[k], sizeof(v));
+      cvals[k] = v;
+    } else {
+      const unsigned b = (unsigned)h_pr.bits[k];
+      float v;
+      memcpy(&v, &b, sizeof(v));
+      cvals[k] = (double)v; // exact
+    }
+  }
+  *yes = true;
+  return SPMV_HIP_OK;
+}
+
+// pass 2: fill the arrays and the masks; fail = a row whose columns do not
+// ascend strictly.  Only the offsets k < narr have arrays (half form: the
+// offsets <= 0).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void wdia_bake_kernel(
+    int32_t num_rows, int K, int narr, WdiaOffsets off,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
+    const T* __restrict__ values, int64_t arr_len, T* __restrict__ sval,
+    uint32_t* __restrict__ mask, int32_t* __restrict__ fail)
 {
   __shared__ int32_t s_D[kWdiaMaxOff]; // indexed per lane below
   if (threadIdx.x < kWdiaMaxOff)
@@ -168,7 +337,8 @@ __global__ __launch_bounds__(kBlock) void wdia_bake_kernel(
         bad = true;
         break;
       }
-      sval[(int64_t)k * arr_len + i] = values[j];
+      if (k < narr)
+        sval[(int64_t)k * arr_len + i] = values[j];
       m |= 1u << k;
       prev = k;
     }
@@ -191,13 +361,19 @@ void wdia_free_arrays(spmv_hip_csr_plan* pl)
   pl->wdia_len = 0;
   pl->wdia_elem = 0;
   pl->wdia_K = 0;
+  pl->wdia_narr = 0;
+  pl->wdia_const = 0;
   pl->wdia = 0;
+  (void)hipFree(pl->wdia_zw_table);
+  pl->wdia_zw_table = nullptr;
+  pl->wdia_zw_slots = pl->wdia_zw_grid = pl->wdia_zw_segments = 0;
+  pl->wdia_d2 = 0;
 }
 
 int wdia_grid(const spmv_hip_csr_plan* pl)
 {
   const int nrb = (pl->num_rows + kRows - 1) / kRows;
-  int grid = pl->ctx->num_cus * kBlocksPerCU;
+  int grid = pl->ctx->num_cus * pl->wdia_blocks_per_cu;
   if (grid > pl->ctx->dot_blocks)
     grid = pl->ctx->dot_blocks;
   if (grid > nrb)
@@ -262,13 +438,73 @@ int wdia_bake(spmv_hip_csr_plan* pl, const T* values, hipStream_t st)
     }
   for (int k = K; k < kWdiaMaxOff; ++k)
     off.D[k] = 0;
+  // HALF form?  The offsets must mirror each other and the matrix must be
+  // symmetric entry for entry, bit for bit (device check, stops at the first
+  // mismatch); then only the arrays of the offsets <= 0 are kept
+  int narr = K;
+  for (int k = 0; k < kWdiaMaxOff; ++k) {
+    off.A[k] = k < K ? k : 0;
+    off.S[k] = 0;
+  }
+  // constant diagonals: no arrays at all, whatever the symmetry
+  bool is_const = false;
+  if (pl->ctx->const_diagonals) {
+    const int rcc = wdia_const_probe<T>(pl, K, off, values, st, &is_const,
+                                        pl->wdia_cval);
+    if (rcc != SPMV_HIP_OK) {
+      (void)hipFree(d_set);
+      return rcc;
+    }
+    if (is_const)
+      narr = 0;
+  }
+  bool mirrored = !is_const && pl->ctx->wdia_half
+                  && pl->num_rows == pl->num_cols;
+  for (int k = 0; k < K && mirrored; ++k) {
+    bool found = false;
+    for (int q = 0; q < K; ++q)
+      found = found || off.D[q] == -off.D[k];
+    mirrored = found;
+  }
+  if (mirrored && K > 1) {
+    int32_t h_asym = 1;
+    if (e == hipSuccess)
+      e = hipMemsetAsync(d_set + kWdiaMaxOff, 0, sizeof(int32_t), st);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL((wdia_symmetry_kernel<T>), dim3(grid), dim3(kBlock), 0,
+                         st, n, pl->rowptr0, pl->colind0, values,
+                         d_set + kWdiaMaxOff);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(&h_asym, d_set + kWdiaMaxOff, sizeof(int32_t),
+                         hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess)
+      e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+      (void)hipFree(d_set);
+      return static_cast<int>(e);
+    }
+    if (!h_asym) {
+      narr = 0;
+      while (narr < K && off.D[narr] <= 0)
+        ++narr; // D ascends: the offsets <= 0 come first
+      for (int k = narr; k < K; ++k) {
+        int q = 0;
+        while (off.D[q] != -off.D[k])
+          ++q;
+        off.A[k] = q;
+        off.S[k] = off.D[k];
+      }
+    }
+  }
   // pass 2: the copy by offset
   const int64_t len = (((int64_t)n + kRows - 1) / kRows) * kRows;
-  const size_t bytes = (size_t)K * len * sizeof(T);
+  const size_t bytes = (size_t)narr * len * sizeof(T);
   void* sval = nullptr;
   uint32_t* msk = nullptr;
   int32_t h_fail = 0;
-  e = hipMalloc(&sval, bytes);
+  e = hipMalloc(&sval, bytes > 0 ? bytes : 64); // (constant: a marker only)
   if (e == hipSuccess)
     e = hipMalloc(&msk, sizeof(uint32_t) * (size_t)n);
   if (e == hipSuccess)
@@ -277,7 +513,7 @@ int wdia_bake(spmv_hip_csr_plan* pl, const T* values, hipStream_t st)
     e = hipMemsetAsync(d_set + kWdiaMaxOff, 0, sizeof(int32_t), st);
   if (e == hipSuccess) {
     hipLaunchKernelGGL((wdia_bake_kernel<T>), dim3(grid), dim3(kBlock), 0, st, n,
-                       K, off, pl->rowptr0, pl->colind0, values, len,
+                       K, narr, off, pl->rowptr0, pl->colind0, values, len,
                        static_cast<T*>(sval), msk, d_set + kWdiaMaxOff);
     e = hipGetLastError();
   }
@@ -300,10 +536,48 @@ int wdia_bake(spmv_hip_csr_plan* pl, const T* values, hipStream_t st)
   pl->wdia_len = len;
   pl->wdia_elem = (int)sizeof(T);
   pl->wdia_K = K;
-  for (int k = 0; k < kWdiaMaxOff; ++k)
+  pl->wdia_narr = narr;
+  pl->wdia_const = is_const ? 1 : 0;
+  for (int k = 0; k < kWdiaMaxOff; ++k) {
     pl->wdia_D[k] = off.D[k];
+    pl->wdia_A[k] = off.A[k];
+    pl->wdia_S[k] = off.S[k];
+  }
   pl->wdia_values0 = values;
   pl->wdia = 1;
+  // plane distance of a 3-D stencil: the middle of the widest cluster of
+  // |offsets| (27-point: n^2 - n - 1 ... n^2 + n + 1 -> n^2)
+  {
+    int64_t a[kWdiaMaxOff];
+    int na = 0;
+    int64_t amax = 0;
+    for (int k = 0; k < K; ++k) {
+      const int64_t v = off.D[k] < 0 ? -(int64_t)off.D[k] : (int64_t)off.D[k];
+      amax = v > amax ? v : amax;
+    }
+    for (int k = 0; k < K; ++k) {
+      const int64_t v = off.D[k] < 0 ? -(int64_t)off.D[k] : (int64_t)off.D[k];
+      bool seen = false;
+      for (int q = 0; q < na; ++q)
+        seen = seen || a[q] == v;
+      if (!seen && v * 2 > amax)
+        a[na++] = v;
+    }
+    for (int p = 1; p < na; ++p) // insertion sort, <= 32 values
+      for (int q = p; q > 0 && a[q - 1] > a[q]; --q) {
+        const int64_t tmp = a[q];
+        a[q] = a[q - 1];
+        a[q - 1] = tmp;
+      }
+    pl->wdia_d2 = na > 0 ? a[na / 2] : 0;
+  }
+  if (pl->wdia_d2 > 0) {
+    const int rw = spmv_wdia_walk_build(pl, 0, false);
+    if (rw != SPMV_HIP_OK) {
+      wdia_free_arrays(pl);
+      return rw;
+    }
+  }
   pl->plan_us += (int)std::chrono::duration_cast<std::chrono::microseconds>(
                      std::chrono::steady_clock::now() - t_begin)
                      .count();
@@ -325,10 +599,54 @@ int wdia_bake_mixed(spmv_hip_csr_plan* pl, const float* values32, hipStream_t st
     return SPMV_HIP_ENOTSUP;
   const auto t_begin = std::chrono::steady_clock::now();
   WdiaOffsets off;
-  for (int k = 0; k < kWdiaMaxOff; ++k)
+  for (int k = 0; k < kWdiaMaxOff; ++k) {
     off.D[k] = pl->wdia_D[k];
+    off.A[k] = pl->wdia_A[k];
+    off.S[k] = pl->wdia_S[k];
+  }
   const int32_t n = pl->num_rows;
-  const size_t bytes = (size_t)pl->wdia_K * pl->wdia_len * sizeof(float);
+  if (pl->wdia_const) {
+    // constant diagonals: the fp32 array must have them too (its own constants)
+    bool is_const = false;
+    const int rcc = wdia_const_probe<float>(pl, pl->wdia_K, off, values32, st,
+                                            &is_const, pl->wdia32_cval);
+    if (rcc != SPMV_HIP_OK)
+      return rcc;
+    if (!is_const)
+      return SPMV_HIP_ENOTSUP;
+    SPMV_CHECK_HIP(hipMalloc(&pl->wdia32_val, 64)); // the "baked" marker
+    pl->wdia32_values0 = values32;
+    pl->plan_us += (int)std::chrono::duration_cast<std::chrono::microseconds>(
+                       std::chrono::steady_clock::now() - t_begin)
+                       .count();
+    return SPMV_HIP_OK;
+  }
+  if (pl->wdia_narr < pl->wdia_K) {
+    // the half form needs THESE values symmetric too (nothing says the fp32
+    // array is the rounded fp64 one)
+    int32_t* d_asym = nullptr;
+    int32_t h_asym = 1;
+    hipError_t es = hipMalloc(&d_asym, sizeof(int32_t));
+    if (es == hipSuccess)
+      es = hipMemsetAsync(d_asym, 0, sizeof(int32_t), st);
+    if (es == hipSuccess) {
+      hipLaunchKernelGGL((wdia_symmetry_kernel<float>),
+                         dim3(spmv_grid_for(pl->ctx, n, kBlock)), dim3(kBlock), 0,
+                         st, n, pl->rowptr0, pl->colind0, values32, d_asym);
+      es = hipGetLastError();
+    }
+    if (es == hipSuccess)
+      es = hipMemcpyAsync(&h_asym, d_asym, sizeof(int32_t),
+                          hipMemcpyDeviceToHost, st);
+    if (es == hipSuccess)
+      es = hipStreamSynchronize(st);
+    (void)hipFree(d_asym);
+    if (es != hipSuccess)
+      return static_cast<int>(es);
+    if (h_asym)
+      return SPMV_HIP_ENOTSUP;
+  }
+  const size_t bytes = (size_t)pl->wdia_narr * pl->wdia_len * sizeof(float);
   void* sval = nullptr;
   uint32_t* msk = nullptr; // rewritten with the same bits: the kernel's output
   int32_t* d_fail = nullptr;
@@ -344,8 +662,8 @@ int wdia_bake_mixed(spmv_hip_csr_plan* pl, const float* values32, hipStream_t st
     e = hipMemsetAsync(d_fail, 0, sizeof(int32_t), st);
   if (e == hipSuccess) {
     hipLaunchKernelGGL((wdia_bake_kernel<float>), dim3(spmv_grid_for(pl->ctx, n, kBlock)),
-                       dim3(kBlock), 0, st, n, pl->wdia_K, off, pl->rowptr0,
-                       pl->colind0, values32, pl->wdia_len,
+                       dim3(kBlock), 0, st, n, pl->wdia_K, pl->wdia_narr, off,
+                       pl->rowptr0, pl->colind0, values32, pl->wdia_len,
                        static_cast<float*>(sval), msk, d_fail);
     e = hipGetLastError();
   }
@@ -377,14 +695,31 @@ int wdia_launch(const spmv_hip_csr_plan* pl, hipStream_t st, const TV* sval,
 {
   const int nrb = (pl->num_rows + kRows - 1) / kRows;
   WdiaOffsets off;
-  for (int k = 0; k < kWdiaMaxOff; ++k)
+  for (int k = 0; k < kWdiaMaxOff; ++k) {
     off.D[k] = pl->wdia_D[k];
+    off.A[k] = pl->wdia_A[k];
+    off.S[k] = pl->wdia_S[k];
+  }
   RowBlockOrder ord = pl->row_block_order(nrb);
   ord.xcd_group = pl->wdia_xcd_group;
-  hipLaunchKernelGGL((csr_wdia_kernel<TV, T, DOT>), dim3(wdia_grid(pl)),
-                     dim3(kBlock), 0, st, pl->num_rows, pl->num_cols,
-                     pl->wdia_len, pl->wdia_K, off, sval, pl->wdia_mask, alpha,
-                     in, beta, out, dot, ord);
+  const int grid = wdia_grid(pl);
+  if (pl->wdia_zwalk && pl->wdia_zw_table && pl->wdia_zw_grid == grid) {
+    ord.table = pl->wdia_zw_table;
+    ord.num_slots = pl->wdia_zw_slots;
+  }
+  WdiaConsts cv;
+  for (int k = 0; k < kWdiaMaxOff; ++k)
+    cv.c[k] = sizeof(TV) == sizeof(T) ? pl->wdia_cval[k] : pl->wdia32_cval[k];
+  if (pl->wdia_const)
+    hipLaunchKernelGGL((csr_wdia_kernel<TV, T, DOT, true>), dim3(grid),
+                       dim3(kBlock), 0, st, pl->num_rows, pl->num_cols,
+                       pl->wdia_len, pl->wdia_K, off, sval, pl->wdia_mask, alpha,
+                       in, beta, out, dot, ord, cv);
+  else
+    hipLaunchKernelGGL((csr_wdia_kernel<TV, T, DOT, false>), dim3(grid),
+                       dim3(kBlock), 0, st, pl->num_rows, pl->num_cols,
+                       pl->wdia_len, pl->wdia_K, off, sval, pl->wdia_mask, alpha,
+                       in, beta, out, dot, ord, cv);
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;
 }
@@ -392,6 +727,24 @@ int wdia_launch(const spmv_hip_csr_plan* pl, hipStream_t st, const TV* sval,
 } // namespace
 
 void spmv_wdia_free(spmv_hip_csr_plan* pl) { wdia_free_arrays(pl); }
+
+int spmv_wdia_walk_build(spmv_hip_csr_plan* pl, int segments, bool force)
+{
+  if (pl->wdia_zw_table) {
+    SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
+    SPMV_CHECK_HIP(hipDeviceSynchronize()); // no launch still reads the old one
+    (void)hipFree(pl->wdia_zw_table);
+    pl->wdia_zw_table = nullptr;
+    pl->wdia_zw_slots = pl->wdia_zw_grid = pl->wdia_zw_segments = 0;
+  }
+  const int grid = wdia_grid(pl);
+  const int rc = spmv_zwalk_table_device(pl, pl->wdia_d2, grid, segments, force,
+                                         &pl->wdia_zw_table, &pl->wdia_zw_slots,
+                                         &pl->wdia_zw_segments);
+  if (rc == SPMV_HIP_OK && pl->wdia_zw_table)
+    pl->wdia_zw_grid = grid;
+  return rc;
+}
 
 int spmv_wdia_bake_f64(spmv_hip_csr_plan* pl, const double* values,
                        hipStream_t st)

@@ -67,8 +67,20 @@ def test_bench_single_gpu_line():
     sym = d["symmetric"]
     assert sym["frac"] > 0 and sym["iters/s"] > 0 and "atomic-free" in sym["kernel"]
     assert d["csr_lx_spmv"]["form"]["lx"] == 1 and d["csr_lx_spmv"]["form"]["lat"] == 0
-    # the general Poisson matrix is symmetric: the plan keeps its lower half
-    assert d["plan"]["form"]["sdia"] == 1 and "general order" in d["roofline"]["kernel"]
+    # every diagonal of the Poisson matrix is constant: no values are streamed
+    assert d["plan"]["form"]["sdia"] == 1 and d["plan"]["form"]["sdia_const"] == 1
+    assert "csr_const_dia_kernel<double, general order>" in d["roofline"]["kernel"]
+    assert d["roofline"]["bytes_per_launch"] == 17 * 64 ** 3
+    # (symmetric storage of 64^3 is below the lattice analysis' size: the
+    # transposed map; tests/test_gpu_matrix.py covers the larger grids)
+    # ... the same matrix with its values streamed (what a lattice matrix with
+    # varying coefficients gets): symmetric, so the plan keeps its lower half
+    vs, svs = d["value_stream_spmv"], d["symmetric_value_stream_spmv"]
+    assert vs["form"]["sdia"] == 1 and vs["form"]["sdia_const"] == 0
+    assert "csr_sym_dia_kernel<double, general order>" in vs["kernel"]
+    assert svs["form"]["sdia_const"] == 0 and "csr_sym_dia_kernel" in svs["kernel"]
+    assert d["north_star_spmv"]["form"]["sdia_const"] == 1
+    assert d["north_star_value_stream_spmv"]["form"]["sdia_const"] == 0
     lat = d["csr_lattice_spmv"]["form"]
     assert lat["lat"] == 1 and lat["sdia"] == 0
     # ... and a matrix that is not symmetric keeps all its values by offset
@@ -77,8 +89,8 @@ def test_bench_single_gpu_line():
     assert d["north_star_spmv"]["form"]["lat"] == 1
     # the kernels of matrices WITHOUT lattice structure, measured and checked
     assert d["csr_rowblock_spmv"]["form"] == dict(lat=0, lx=0, lxw=0, wdia=0,
-                                                  slat=0, sdia=0, sym_det=0,
-                                                  zwalk=0)
+                                                  wdia_const=0, slat=0, sdia=0,
+                                                  sdia_const=0, sym_det=0, zwalk=0)
     for k in ("north_star_lattice_spmv", "north_star_lx_spmv",
               "north_star_rowblock_spmv"):
         assert d[k]["rows"] == 216 ** 3 and d[k]["form"]["sdia"] == 0
@@ -87,7 +99,11 @@ def test_bench_single_gpu_line():
     s27, un = d["stencil27_spmv"], d["unstructured_spmv"]
     assert s27["rows"] == 40 ** 3 and s27["nnz_stored"] == (3 * 40 - 2) ** 3
     assert un["rows"] == 200000 and un["nnz_stored"] == 7 * 200000
-    for r in (s27, un):
+    s27v = d["stencil27_value_stream_spmv"]
+    assert s27["form"]["wdia_const"] == 1 and "constant" in s27["kernel"]
+    assert s27v["form"]["wdia"] == 1 and s27v["form"]["wdia_const"] == 0
+    assert "half" in s27v["kernel"]
+    for r in (s27, s27v, un):
         assert r["crosscheck"]["bit_equal"] is True and r["frac"] > 0
     pc = c["parity_checks"]
     assert "error" not in pc, pc
@@ -114,6 +130,20 @@ def test_bench_without_the_symmetry_check():
     assert d["plan"]["form"]["sdia"] == 0 and d["plan"]["form"]["lat"] == 1
     assert "csr_lattice_kernel" in d["roofline"]["kernel"]
     assert d["roofline"]["frac"] <= d["roofline"]["frac_csr_equivalent"]
+
+
+def test_bench_with_the_values_streamed():
+    """--no-const: the headline of a lattice matrix whose coefficients vary (the
+    half diagonal form streams the lower values)."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"),
+                          "--grid", "128", "--steps", "10", "--warmup", "2",
+                          "--no-const", "--no-extras", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = _line(res.stdout)
+    _check(d, 1, 10, 2)
+    assert d["plan"]["form"]["sdia"] == 1 and d["plan"]["form"]["sdia_const"] == 0
+    assert "csr_sym_dia_kernel<double, general order>" in d["roofline"]["kernel"]
 
 
 def test_bench_two_rank_rehearsal():

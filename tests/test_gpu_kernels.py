@@ -1127,11 +1127,17 @@ def test_lx_fuzz_banded(lx_ctx):
 # Lattice form (spmv_lat.hip): constant column offsets per row block, values by
 # LDS-DMA one row block ahead, no index stream.  Same bits as the oracle.
 # ---------------------------------------------------------------------------
-@pytest.fixture()
-def lat_ctx():
+@pytest.fixture(params=["values", "const"])
+def lat_ctx(request):
+    """Every lattice / diagonal-form test runs twice: with the value-streaming
+    kernels only ("values": ctx option const_diagonals = 0) and with the
+    constant-diagonal kernels allowed ("const", the default) -- the Poisson
+    cases then take them, the random-valued ones cannot."""
     c = hip.Context(0)
     c.set_option("lat_min_nnz", 0)  # try the form on small test matrices too
     c.set_option("lx_min_nnz", 0)
+    c.set_option("const_diagonals", 1 if request.param == "const" else 0)
+    c.const_mode = request.param == "const"
     yield c
     c.close()
 
@@ -1409,7 +1415,9 @@ def test_symmetric_diagonal_form_bit_exact(lat_ctx, dtype):
         kib0 = blk.get("plan_kib")
         blk.bake()
         assert blk.get("sdia") == 1, name
-        assert blk.get("plan_kib") > kib0
+        assert blk.get("plan_kib") >= kib0
+        if not ctx.const_mode:
+            assert blk.get("sdia_const") == 0 and blk.get("plan_kib") > kib0
         dx = ctx.upload(x, dtype)
         part = ctx.empty(ctx.dot_partials_len, np.float64)
         for alpha, beta in ((1.0, 0.0), (-0.5, 0.0), (2.0, 1.0), (1.0, -0.25)):
@@ -1751,6 +1759,170 @@ def test_plane_walk_order_is_a_permutation_of_the_work(lat_ctx, n):
 
 
 # ---------------------------------------------------------------------------
+# Constant diagonals (spmv_symdia.hip, csr_const_dia_kernel): the bake keeps the
+# mask byte per row and ONE number per diagonal, no copy of the values
+# ---------------------------------------------------------------------------
+def _const_diag_csr(rng, N, offsets, consts, drop=0.0, dtype=np.float64):
+    """_stencil_csr with the value of an entry fixed by its diagonal."""
+    rp, ci, _ = _stencil_csr(rng, N, offsets, drop=drop)
+    rows = np.repeat(np.arange(N), np.diff(rp))
+    lut = dict(zip(offsets, consts))
+    va = np.array([lut[int(d)] for d in (ci.astype(np.int64) - rows)], dtype)
+    return rp, ci, va
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_constant_diagonals_bit_exact(dtype):
+    """Every diagonal constant, bit for bit (the Poisson operator; any
+    constant-coefficient stencil, symmetric or not, entries missing anywhere):
+    the plan keeps no values, the kernel multiplies by the constant -- the same
+    products and sums in the same order, so the same bits as the oracle for
+    general and symmetric storage, any alpha / beta, fused dot, every order
+    knob.  One entry off by an ulp: the value-streaming form, as before."""
+    ctx = hip.Context(0)
+    ctx.set_option("lat_min_nnz", 0)
+    ctx.set_option("lx_min_nnz", 0)
+    rng = np.random.default_rng(1207)
+    third = 1.0 / 3.0  # not representable: fp32 constants differ from fp64 ones
+    cases = []
+    for n in (4, 9, 16, 32, 33):
+        rp, ci, va = poisson.poisson3d_csr(n)
+        cases.append((f"poisson{n}", rp, ci.astype(np.int32), va, n ** 3, True))
+    cases.append(("tridiag", *_const_diag_csr(rng, 70001, [-1, 0, 1],
+                                              [0.1, 0.8, 0.1]), 70001, True))
+    offs = [-2000, -300, -1, 0, 1, 300, 2000]
+    cases.append(("far3_sym", *_const_diag_csr(
+        rng, 9001, offs, [-third, 0.7, -1.1, 5.3, -1.1, 0.7, -third], drop=0.0),
+        9001, True))
+    cases.append(("far3_skew_holes", *_const_diag_csr(
+        rng, 9001, offs, [-1.25, 0.7, -1.1, 5.3, -0.9, 0.6, -0.75], drop=0.3),
+        9001, False))
+    cases.append(("odd", *_const_diag_csr(
+        rng, 7013, [-1001, -257, -255, 0, 255, 257, 1001],
+        [third, 2.0, -3.0, 9.0, 4.0, -5.0, 6.0], drop=0.2), 7013, False))
+    cases.append(("short", *_const_diag_csr(
+        rng, 700, [-650, -3, 3, 650], [1.5, -2.5, -2.5, 1.5], drop=0.1), 700, False))
+    for name, rp, ci, va, N, symmetric in cases:
+        va = va.astype(dtype)
+        x = rng.uniform(-1, 1, N).astype(dtype)
+        y0 = rng.uniform(-1, 1, N).astype(dtype)
+        storages = [("general", rp, ci, va, None)]
+        if symmetric:
+            lrp, lci, lva, dg = lower_split(rp, ci, va)
+            storages.append(("symmetric", lrp, lci, lva.astype(dtype),
+                             np.asarray(dg).astype(dtype)))
+        for sname, srp, sci, sva, sdg in storages:
+            sym = sdg is not None
+            for variant in ("const", "ulp"):
+                v2 = sva.copy()
+                if variant == "ulp":
+                    j = len(v2) // 2
+                    v2[j] = np.nextafter(v2[j], dtype(100.0))
+                    if not sym and symmetric:
+                        continue  # (would only break the symmetry as well)
+                blk = hip.CsrBlock(ctx, N, N, srp, sci, v2, sdg, sym,
+                                   hip.ALGO_AUTO if sym else hip.ALGO_ROWBLOCK, dtype)
+                kib0 = blk.get("plan_kib")
+                blk.bake()
+                tag = (name, sname, variant)
+                assert blk.get("sdia") == 1, tag
+                assert blk.get("sdia_const") == (1 if variant == "const" else 0), tag
+                if variant == "const":  # the mask and the walk table, nothing else
+                    assert blk.get("plan_kib") - kib0 <= N // 1024 + 2 \
+                        + 4 * blk.get("zwalk_grid") + 64, tag
+                ref = ((lambda a, b: oracle.csr_spmv_sym(srp, sci, v2, sdg, x, a, b, y0))
+                       if sym else
+                       (lambda a, b: oracle.csr_spmv(srp, sci, v2, x, a, b, y0)))
+                dx = ctx.upload(x, dtype)
+                part = ctx.empty(ctx.dot_partials_len, np.float64)
+                for alpha, beta in ((1.0, 0.0), (-0.5, 0.0), (2.0, 1.0), (1.0, -0.25)):
+                    y_ref = ref(alpha, beta)
+                    for knobs in (dict(), dict(slat_blocks_per_cu=1),
+                                  dict(lat_xcd_group=3), dict(sdia=0),
+                                  dict(sdia=1, slat_blocks_per_cu=8, lat_xcd_group=0),
+                                  dict(zwalk_segments=0), dict(zwalk_segments=1),
+                                  dict(slat_blocks_per_cu=2, zwalk_segments=3),
+                                  dict(sdia_chain=0, sdia_nt=31),
+                                  dict(sdia_chain=1, zwalk_segments=2, sdia_nt=0),
+                                  dict(zwalk=0)):
+                        for k, v in knobs.items():
+                            blk.set(k, v)
+                        dy = ctx.upload(np.full(N, np.nan, dtype) if beta == 0 else y0,
+                                        dtype)
+                        dot = dtype == np.float64 and beta == 0.0
+                        blk.mult(alpha, dx.ptr, beta, dy.ptr,
+                                 dot_partials=part.ptr if dot else None)
+                        y = dy.numpy()
+                        dy.free()
+                        assert np.array_equal(y, y_ref), (tag, alpha, beta, knobs)
+                        if dot:
+                            want = float(np.dot(x.astype(np.float64), y_ref))
+                            got = float(np.sum(part.numpy()))
+                            scale = float(np.abs(x) @ np.abs(y_ref)) + 1e-300
+                            assert abs(got - want) <= 1e-12 * scale, (tag, knobs)
+                if variant == "const" and not sym and dtype == np.float64:
+                    # mixed precision: the fp32 array has constants of its own
+                    va32 = v2.astype(np.float32)
+                    d32 = ctx.upload(va32, np.float32)
+                    hip.call("spmv_hip_csr_plan_bake_values_f32f64", ctx.h, blk.plan,
+                             d32.ptr, None)
+                    assert blk.get("sdia_mixed") == 1, tag
+                    y32 = oracle.csr_spmv(srp, sci, va32.astype(np.float64), x, -0.5,
+                                          0.75, y0)
+                    dy = ctx.upload(y0)
+                    hip.call("spmv_hip_csr_spmv_f32f64", ctx.h, blk.plan, N, N,
+                             blk.nnz, blk.rowptr.ptr, blk.colind.ptr, d32.ptr, -0.5,
+                             dx.ptr, 0.75, dy.ptr, None, None)
+                    assert np.array_equal(dy.numpy(), y32), tag
+                    bad = va32.copy()  # not constant: refused, CSR-order kernels
+                    bad[len(bad) // 3] = np.nextafter(bad[len(bad) // 3],
+                                                      np.float32(100.0))
+                    dbad = ctx.upload(bad, np.float32)
+                    with pytest.raises(Exception):
+                        hip.call("spmv_hip_csr_plan_bake_values_f32f64", ctx.h,
+                                 blk.plan, dbad.ptr, None)
+                    assert blk.get("sdia_mixed") == 0
+                    dy2 = ctx.upload(y0)
+                    hip.call("spmv_hip_csr_spmv_f32f64", ctx.h, blk.plan, N, N,
+                             blk.nnz, blk.rowptr.ptr, blk.colind.ptr, dbad.ptr, -0.5,
+                             dx.ptr, 0.75, dy2.ptr, None, None)
+                    assert np.array_equal(dy2.numpy(), oracle.csr_spmv(
+                        srp, sci, bad.astype(np.float64), x, -0.5, 0.75, y0)), tag
+                    for b in (d32, dbad, dy, dy2):
+                        b.free()
+                if variant == "const":
+                    # stale by contract until baked again; other pointers never
+                    # use the constants; the constants can be dropped
+                    v3 = (v2 * dtype(1.5)).astype(dtype)
+                    ctx.copy_h2d(blk.values.ptr, v3)
+                    dy = ctx.upload(np.full(N, np.nan, dtype), dtype)
+                    blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+                    old = (oracle.csr_spmv_sym(srp, sci, v2, sdg, x) if sym
+                           else oracle.csr_spmv(srp, sci, v2, x))
+                    new = (oracle.csr_spmv_sym(srp, sci, v3, sdg, x) if sym
+                           else oracle.csr_spmv(srp, sci, v3, x))
+                    assert np.array_equal(dy.numpy(), old), tag
+                    blk.bake()
+                    assert blk.get("sdia_const") == 1, tag
+                    blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+                    assert np.array_equal(dy.numpy(), new), tag
+                    other = ctx.upload(v2, dtype)
+                    keep = blk.values
+                    blk.values = other
+                    blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+                    assert np.array_equal(dy.numpy(), old), tag
+                    blk.values = keep
+                    blk.bake(drop=True)
+                    assert blk.get("sdia") == 0 and blk.get("sdia_const") == 0
+                    blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+                    assert np.array_equal(dy.numpy(), new), tag
+                    other.free(), dy.free()
+                dx.free(), part.free()
+                blk.free()
+    ctx.close()
+
+
+# ---------------------------------------------------------------------------
 # Wide diagonal form (spmv_wdia.hip): general matrices on <= 32 diagonals
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -1849,6 +2021,217 @@ def test_wide_diagonal_form_bit_exact(lat_ctx, dtype):
         for b in (dx, dy, other, part):
             b.free()
         blk.free()
+
+
+def test_wide_diagonal_half_form_bit_exact(lat_ctx):
+    """A general matrix the bake finds symmetric entry for entry, bit for bit,
+    keeps only its diagonals <= 0 (the upper entry (i, i+d) is read as the
+    lower entry of row i+d): same bits as the oracle's general loop.  One value
+    off by an ulp, or one entry without its mirror, and the full form is kept.
+    The fp32 copy of the mixed SpMV must be symmetric itself."""
+    import scipy.sparse as sp
+    ctx = lat_ctx
+    rng = np.random.default_rng(273)
+    cases = []
+    for n in (7, 12):
+        rp, ci, va = poisson.stencil27_csr(n)
+        cases.append((f"stencil27_{n}", rp, ci.astype(np.int32), va, n ** 3, 27))
+    for name, N, offs, drop in (("nine", 4900, [0, 1, 69, 70, 71], 0.0),
+                                ("ragged", 9001, [0, 3, 17, 256, 700, 1499], 0.3),
+                                ("sixteen_upper", 3000, list(range(0, 16)), 0.1)):
+        rp, ci, va = _stencil_csr(rng, N, offs, drop=drop)
+        A = sp.csr_matrix((rng.uniform(-1, 1, len(ci)), ci, rp), shape=(N, N))
+        S = (A + A.T).tocsr()
+        S.sort_indices()
+        cases.append((name, S.indptr.astype(np.int32), S.indices.astype(np.int32),
+                      S.data.copy(), N, 2 * len(offs) - 1))
+    for name, rp, ci, va, N, K in cases:
+        x = rng.uniform(-1, 1, N)
+        y0 = rng.uniform(-1, 1, N)
+        for variant in ("symmetric", "ulp", "hole", "option_off"):
+            rp_v, ci_v, va_v = rp, ci, va.copy()
+            if variant == "ulp":
+                j = int(rp[N // 2]) + 1
+                j = j if ci[j] != N // 2 else j + 1
+                va_v[j] = np.nextafter(va_v[j], 2.0)
+            if variant == "hole":  # drop one off-diagonal entry, keep its mirror
+                i = N // 3
+                j = int(rp[i])
+                assert ci[j] != i
+                keep = np.ones(len(ci), bool)
+                keep[j] = False
+                cnt = np.diff(rp)
+                cnt[i] -= 1
+                rp_v = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+                ci_v, va_v = ci[keep], va_v[keep]
+            ctx.set_option("wdia_half", 0 if variant == "option_off" else 1)
+            blk = hip.CsrBlock(ctx, N, N, rp_v, ci_v, va_v, None, False,
+                               hip.ALGO_ROWBLOCK)
+            try:
+                blk.bake()
+            finally:
+                ctx.set_option("wdia_half", 1)
+            assert blk.get("wdia") == 1, (name, variant)
+            assert blk.get("wdia_offsets") == K, (name, variant)
+            const = ctx.const_mode and name.startswith("stencil27") \
+                and variant != "ulp"  # (26 / -1 on every diagonal)
+            assert blk.get("wdia_const") == (1 if const else 0), (name, variant)
+            assert blk.get("wdia_half") == (1 if variant == "symmetric"
+                                            and not const else 0), (name, variant)
+            dx = ctx.upload(x)
+            part = ctx.empty(ctx.dot_partials_len, np.float64)
+            for alpha, beta in ((1.0, 0.0), (-0.5, 0.0), (2.0, 1.0), (1.0, -0.25)):
+                y_ref = oracle.csr_spmv(rp_v, ci_v, va_v, x, alpha, beta, y0)
+                for grp in (4, 0):
+                    blk.set("wdia_xcd_group", grp)
+                    dy = ctx.upload(np.full(N, np.nan) if beta == 0 else y0)
+                    blk.mult(alpha, dx.ptr, beta, dy.ptr,
+                             dot_partials=part.ptr if beta == 0 else None)
+                    assert np.array_equal(dy.numpy(), y_ref), (name, variant,
+                                                               alpha, beta, grp)
+                    if beta == 0:
+                        want = float(np.dot(x, y_ref))
+                        got = float(np.sum(part.numpy()))
+                        assert abs(got - want) <= 1e-12 * (np.abs(x) @ np.abs(y_ref))
+                    dy.free()
+            if variant == "symmetric":
+                va32 = va_v.astype(np.float32)  # rounding keeps the symmetry
+                d32 = ctx.upload(va32, np.float32)
+                hip.call("spmv_hip_csr_plan_bake_values_f32f64", ctx.h, blk.plan,
+                         d32.ptr, None)
+                assert blk.get("wdia_mixed") == 1, name
+                y32_ref = oracle.csr_spmv(rp_v, ci_v, va32.astype(np.float64), x,
+                                          -0.5, 0.75, y0)
+                dy = ctx.upload(y0)
+                hip.call("spmv_hip_csr_spmv_f32f64", ctx.h, blk.plan, N, N,
+                         blk.nnz, blk.rowptr.ptr, blk.colind.ptr, d32.ptr, -0.5,
+                         dx.ptr, 0.75, dy.ptr, None, None)
+                assert np.array_equal(dy.numpy(), y32_ref), name
+                # an fp32 array that is not symmetric: refused, the CSR-order
+                # mixed kernels run on it
+                bad = va32.copy()
+                j = int(rp_v[N // 2])
+                j = j if ci_v[j] != N // 2 else j + 1
+                bad[j] = np.nextafter(bad[j], np.float32(2.0))
+                dbad = ctx.upload(bad, np.float32)
+                with pytest.raises(Exception):
+                    hip.call("spmv_hip_csr_plan_bake_values_f32f64", ctx.h,
+                             blk.plan, dbad.ptr, None)
+                ybad_ref = oracle.csr_spmv(rp_v, ci_v, bad.astype(np.float64), x,
+                                           -0.5, 0.75, y0)
+                dy2 = ctx.upload(y0)
+                hip.call("spmv_hip_csr_spmv_f32f64", ctx.h, blk.plan, N, N,
+                         blk.nnz, blk.rowptr.ptr, blk.colind.ptr, dbad.ptr, -0.5,
+                         dx.ptr, 0.75, dy2.ptr, None, None)
+                assert np.array_equal(dy2.numpy(), ybad_ref), name
+                for b in (dy, dy2, d32, dbad):
+                    b.free()
+            dx.free(), part.free()
+            blk.free()
+
+
+def test_wide_diagonal_form_constant_diagonals_bit_exact():
+    """More than three lower offsets, every diagonal constant (HPCG's 27-point
+    operator, a 2-D 9-point stencil, 19 offsets with a third of the entries
+    missing): the plan keeps the 32-bit mask per row and one number per
+    diagonal; same bits as the oracle, every knob; one value off by an ulp and
+    the values are streamed as before."""
+    ctx = hip.Context(0)
+    ctx.set_option("lat_min_nnz", 0)
+    ctx.set_option("lx_min_nnz", 0)
+    rng = np.random.default_rng(2707)
+    third = 1.0 / 3.0
+    cases = []
+    for n in (7, 12, 33):
+        rp, ci, va = poisson.stencil27_csr(n)
+        cases.append((f"stencil27_{n}", rp, ci.astype(np.int32), va, n ** 3, 27))
+    m = 70
+    offs9 = [dy * m + dx for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+    cases.append(("nine_point_2d", *_const_diag_csr(
+        rng, m * m, offs9, [third * (k + 1) for k in range(9)]), m * m, 9))
+    offs19 = sorted(int(o) for o in rng.choice(np.arange(-1500, 1500), 19,
+                                               replace=False))
+    cases.append(("nineteen_holes", *_const_diag_csr(
+        rng, 9001, offs19, list(rng.uniform(-2, 2, 19)), drop=0.3), 9001, 19))
+    for name, rp, ci, va, N, K in cases:
+        x = rng.uniform(-1, 1, N)
+        y0 = rng.uniform(-1, 1, N)
+        for variant in ("const", "ulp"):
+            v2 = va.copy()
+            if variant == "ulp":
+                v2[len(v2) // 2] = np.nextafter(v2[len(v2) // 2], 100.0)
+            blk = hip.CsrBlock(ctx, N, N, rp, ci, v2, None, False,
+                               hip.ALGO_ROWBLOCK)
+            kib0 = blk.get("plan_kib")
+            blk.bake()
+            tag = (name, variant)
+            assert blk.get("wdia") == 1 and blk.get("wdia_offsets") == K, tag
+            assert blk.get("wdia_const") == (1 if variant == "const" else 0), tag
+            if variant == "const":
+                assert blk.get("plan_kib") - kib0 <= 4 * N // 1024 + 2 + 64, tag
+            dx = ctx.upload(x)
+            part = ctx.empty(ctx.dot_partials_len, np.float64)
+            for alpha, beta in ((1.0, 0.0), (-0.5, 0.0), (2.0, 1.0), (1.0, -0.25)):
+                y_ref = oracle.csr_spmv(rp, ci, v2, x, alpha, beta, y0)
+                for knobs in (dict(), dict(wdia_xcd_group=0), dict(wdia=0),
+                              dict(wdia=1, wdia_xcd_group=4),
+                              dict(wdia_zwalk_segments=0),
+                              dict(wdia_zwalk_segments=3, wdia_blocks_per_cu=2),
+                              dict(wdia_zwalk=0), dict(wdia_zwalk=1)):
+                    for k, v in knobs.items():
+                        blk.set(k, v)
+                    dy = ctx.upload(np.full(N, np.nan) if beta == 0 else y0)
+                    blk.mult(alpha, dx.ptr, beta, dy.ptr,
+                             dot_partials=part.ptr if beta == 0 else None)
+                    assert np.array_equal(dy.numpy(), y_ref), (tag, alpha, beta, knobs)
+                    if beta == 0:
+                        want = float(np.dot(x, y_ref))
+                        got = float(np.sum(part.numpy()))
+                        assert abs(got - want) <= 1e-12 * (np.abs(x) @ np.abs(y_ref))
+                    dy.free()
+            if variant == "const":
+                va32 = v2.astype(np.float32)
+                d32 = ctx.upload(va32, np.float32)
+                hip.call("spmv_hip_csr_plan_bake_values_f32f64", ctx.h, blk.plan,
+                         d32.ptr, None)
+                assert blk.get("wdia_mixed") == 1, tag
+                dy = ctx.upload(y0)
+                hip.call("spmv_hip_csr_spmv_f32f64", ctx.h, blk.plan, N, N, blk.nnz,
+                         blk.rowptr.ptr, blk.colind.ptr, d32.ptr, -0.5, dx.ptr,
+                         0.75, dy.ptr, None, None)
+                assert np.array_equal(dy.numpy(), oracle.csr_spmv(
+                    rp, ci, va32.astype(np.float64), x, -0.5, 0.75, y0)), tag
+                bad = va32.copy()
+                bad[len(bad) // 3] = np.nextafter(bad[len(bad) // 3],
+                                                  np.float32(100.0))
+                dbad = ctx.upload(bad, np.float32)
+                with pytest.raises(Exception):
+                    hip.call("spmv_hip_csr_plan_bake_values_f32f64", ctx.h,
+                             blk.plan, dbad.ptr, None)
+                assert blk.get("wdia_mixed") == 0
+                hip.call("spmv_hip_csr_spmv_f32f64", ctx.h, blk.plan, N, N, blk.nnz,
+                         blk.rowptr.ptr, blk.colind.ptr, dbad.ptr, 1.0, dx.ptr,
+                         0.0, dy.ptr, None, None)
+                assert np.array_equal(dy.numpy(), oracle.csr_spmv(
+                    rp, ci, bad.astype(np.float64), x)), tag
+                # stale by contract; another pointer; dropped
+                v3 = v2 * 1.5
+                ctx.copy_h2d(blk.values.ptr, v3)
+                blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+                assert np.array_equal(dy.numpy(), oracle.csr_spmv(rp, ci, v2, x)), tag
+                blk.bake()
+                assert blk.get("wdia_const") == 1
+                blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+                assert np.array_equal(dy.numpy(), oracle.csr_spmv(rp, ci, v3, x)), tag
+                blk.bake(drop=True)
+                assert blk.get("wdia") == 0 and blk.get("wdia_const") == 0
+                blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+                assert np.array_equal(dy.numpy(), oracle.csr_spmv(rp, ci, v3, x)), tag
+                for b in (d32, dbad, dy):
+                    b.free()
+            dx.free(), part.free()
+            blk.free()
+    ctx.close()
 
 
 def test_wide_diagonal_form_fuzz(lat_ctx):

@@ -36,6 +36,9 @@ def main():
                     help="... nor the LX form: the plain row-block kernel")
     ap.add_argument("--stencil27", action="store_true",
                     help="the 27-point operator instead of the 7-point one")
+    ap.add_argument("--set", nargs="*", default=[], help="ctx option=value ...")
+    ap.add_argument("--get", nargs="*", default=[],
+                    help="plan keys to print once the plan is built and baked")
     ap.add_argument("--out", default=None)
     ap.add_argument("--calib", action="store_true",
                     help="also time plain streaming kernels on this box")
@@ -46,6 +49,8 @@ def main():
         ctx.set_option("lat_min_nnz", 1 << 62)
     if args.no_lx:
         ctx.set_option("lx_min_nnz", 1 << 62)
+    for kv in args.set:
+        ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     n, N = args.n, args.n ** 3
     if args.stencil27:
         ctx.set_option("poisson_stencil", 27)
@@ -58,6 +63,8 @@ def main():
         ctx.copy_h2d(blk.values.ptr + 8 * 12345, np.array([-1.25, -1.5, -1.75]))
     if args.symmetric or args.bake or args.asym:
         blk.bake()  # the diagonal form; knob sdia=0 runs the CSR-order kernel
+    if args.get:
+        print(json.dumps(dict(plan={k: blk.get(k) for k in args.get})), flush=True)
     x, y = ctx.empty(N, np.float64), ctx.empty(N, np.float64)
     ctx.fill_gaussian(N, 0, N, x.ptr)
     part = ctx.empty(ctx.dot_partials_len, np.float64)

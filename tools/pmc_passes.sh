@@ -14,6 +14,7 @@ declare -A CGROUPS=(
   [fetch]="FETCH_SIZE"
   [write]="WRITE_SIZE TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum"
   [ea]="TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_EA0_RDREQ_LEVEL_sum"
+  [ea32]="TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum"
   [tcc]="TCC_HIT_sum TCC_MISS_sum TCC_TAG_STALL_sum TCC_REQ_sum"
   [sq]="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"
   [tcp]="TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum"
