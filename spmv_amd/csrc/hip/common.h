@@ -40,6 +40,9 @@ struct spmv_hip_ctx {
   // when every diagonal of the matrix is constant, bit for bit
   // ("const_diagonals"; 0: always stream the values)
   int const_diagonals = 1;
+  // ... with this many lattice lines per lane where the lattice is 3-D
+  // ("const_tile": 1, 2 or 4)
+  int const_tile = 4;
   // the device Poisson generator's non-symmetric variant ("poisson_skew_ppm":
   // lower neighbours -1 - s, upper -1 + s, s = value * 1e-6; 0 = the Poisson
   // matrix).  For measurements of kernels on matrices that are not symmetric.

@@ -230,6 +230,12 @@ struct spmv_hip_csr_plan {
   int sdia_const = 0;
   double sdia_cval[7] = {};
   double sdia32_cval[7] = {}; // ... of the fp32 values of the mixed SpMV
+  // ... of a 3-D lattice: R lines per lane (csr_const_dia_tile_kernel), with a
+  // plane-walk table of its own over the kernel's index space
+  int sdia_tile = 0;          // R in use (0 / 1: the one-line kernel)
+  int sdia_tile_blocks_per_cu = 4;
+  int32_t* sdia_tile_table = nullptr;
+  int sdia_tile_slots = 0, sdia_tile_grid = 0, sdia_tile_segments = 0;
   // ... and the fp32 copy for the mixed-precision SpMV (general, fp64 plans)
   void* sdia32_val = nullptr;
   uint8_t* sdia32_cmask = nullptr;
@@ -362,9 +368,9 @@ int spmv_zwalk_order_build(spmv_hip_csr_plan* pl, int64_t d2, int grid,
 void spmv_zwalk_free(spmv_hip_csr_plan* pl);
 // the same table for a kernel that keeps its own (device array, hipFree; null
 // when the lattice is too small for one to pay)
-int spmv_zwalk_table_device(const spmv_hip_csr_plan* pl, int64_t d2, int grid,
-                            int segments, bool force, int32_t** table,
-                            int* slots, int* segs);
+int spmv_zwalk_table_device(const spmv_hip_csr_plan* pl, int64_t rows,
+                            int64_t d2, int grid, int segments, bool force,
+                            int32_t** table, int* slots, int* segs);
 int spmv_walk_grid(const spmv_hip_csr_plan* pl); // grid of the plan's lattice kernel
 // spmv_symlat.hip
 int spmv_slat_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
@@ -381,6 +387,7 @@ int spmv_slat_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st,
                       float beta, float* out);
 // spmv_symdia.hip
 void spmv_sdia_free(spmv_hip_csr_plan* pl);
+int spmv_sdia_tile_build(spmv_hip_csr_plan* pl, int R, int segments, bool force);
 int spmv_sdia_bake_f64(spmv_hip_csr_plan* pl, const double* values,
                        const double* diagonal, hipStream_t st);
 int spmv_sdia_bake_f32(spmv_hip_csr_plan* pl, const float* values,

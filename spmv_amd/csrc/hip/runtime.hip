@@ -122,6 +122,11 @@ int spmv_hip_ctx_set_option(spmv_hip_ctx* ctx, const char* key, int64_t value)
     ctx->const_diagonals = (int)value;
     return SPMV_HIP_OK;
   }
+  if (!strcmp(key, "const_tile")) {
+    SPMV_REQUIRE(value == 1 || value == 2 || value == 4);
+    ctx->const_tile = (int)value;
+    return SPMV_HIP_OK;
+  }
   if (!strcmp(key, "wdia_half")) {
     SPMV_REQUIRE(value == 0 || value == 1);
     ctx->wdia_half = (int)value;

@@ -1225,15 +1225,16 @@ static bool zwalk_table(int32_t num_rows, int64_t d2, int grid, int segments,
   return true;
 }
 
-int spmv_zwalk_table_device(const spmv_hip_csr_plan* pl, int64_t d2, int grid,
-                            int segments, bool force, int32_t** d_table,
-                            int* slots, int* segs)
+int spmv_zwalk_table_device(const spmv_hip_csr_plan* pl, int64_t rows,
+                            int64_t d2, int grid, int segments, bool force,
+                            int32_t** d_table, int* slots, int* segs)
 {
   *d_table = nullptr;
   *slots = *segs = 0;
-  SPMV_REQUIRE(d2 > 0 && grid > 0 && segments >= 0);
+  SPMV_REQUIRE(rows > 0 && rows <= INT32_MAX && d2 > 0 && grid > 0
+               && segments >= 0);
   std::vector<int32_t> table;
-  if (!zwalk_table(pl->num_rows, d2, grid, segments, force, &table, segs))
+  if (!zwalk_table((int32_t)rows, d2, grid, segments, force, &table, segs))
     return SPMV_HIP_OK;
   SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
   SPMV_CHECK_HIP(hipMalloc(d_table, sizeof(int32_t) * table.size()));
@@ -1558,6 +1559,20 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
     if (plan->zw_table && (plan->slat_mask || plan->sdia_val)) // tied to the grid
       return spmv_zwalk_order_build(plan, plan->zw_d2, spmv_walk_grid(plan), 0,
                                     true);
+  } else if (!strcmp(key, "sdia_tile")) {
+    // lines per lane of the constant-diagonal kernel (1, 2, 4)
+    SPMV_REQUIRE((value == 1 || value == 2 || value == 4) && plan->sdia_val
+                 && plan->sdia_const);
+    return spmv_sdia_tile_build(plan, value, 0, false);
+  } else if (!strcmp(key, "sdia_tile_segments")) {
+    SPMV_REQUIRE(value >= 0 && plan->sdia_tile > 1);
+    return spmv_sdia_tile_build(plan, plan->sdia_tile, value, true);
+  } else if (!strcmp(key, "sdia_tile_blocks_per_cu")) {
+    SPMV_REQUIRE(value >= 1 && value <= kBlocksPerCU);
+    plan->sdia_tile_blocks_per_cu = value;
+    if (plan->sdia_tile > 1)
+      return spmv_sdia_tile_build(plan, plan->sdia_tile, 0,
+                                  plan->sdia_tile_table != nullptr);
   } else if (!strcmp(key, "sdia_nt")) {
     SPMV_REQUIRE(value >= 0 && value < 32);
     plan->sdia_nt = value;
@@ -1659,6 +1674,10 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
     *value = plan->sdia_val ? plan->sdia_general : 0;
   else if (!strcmp(key, "sdia_mixed"))
     *value = plan->sdia32_val ? 1 : 0;
+  else if (!strcmp(key, "sdia_tile"))
+    *value = plan->sdia_val ? plan->sdia_tile : 0;
+  else if (!strcmp(key, "sdia_tile_walk"))
+    *value = plan->sdia_val && plan->sdia_tile_table ? plan->sdia_tile_segments : 0;
   else if (!strcmp(key, "sdia_const"))
     *value = plan->sdia_val ? plan->sdia_const : 0;
   else if (!strcmp(key, "wdia_zwalk"))

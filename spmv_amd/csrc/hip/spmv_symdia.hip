@@ -480,6 +480,222 @@ __global__ __launch_bounds__(kBlock) void csr_const_dia_kernel(
     spmv_dot_epilogue(dot, dot_acc, s_red);
 }
 
+// ---------------------------------------------------------------------------
+// Constant diagonals, R lattice lines per lane.  The kernel above asks the L2
+// for three new line sets of x per row block (the plane ahead and both
+// neighbour lines; own row and the plane behind are handed on by the chain) and
+// it is the number of those requests, not the bytes behind them, that bounds
+// it (PMC: 36 M requests per launch at 512^3, 57 in flight per CU on average,
+// 1.8 GB through the fabric in 0.79 ms).  Here a lane owns R rows one LINE
+// apart -- rows i0, i0 + U1, ..., i0 + (R-1) U1 with U1 the middle offset -- so
+// the neighbour lines of the inner rows are the lane's own registers and only
+// the two outer ones are loaded: (R + 2) / R line sets per row block of the
+// plane ahead and the lines around, instead of 3.
+//
+// Index space: lines are runs of U1 consecutive rows; R consecutive lines form
+// a tuple; work item j = tuple * U1 + position stands for the rows
+// (tuple * R + r) * U1 + position, r < R.  256 consecutive j are a block; the
+// order table walks the blocks of j-space plane by plane (a plane is U0 / R
+// items when U0 is a multiple of R U1; then a block U0 / R items ahead holds
+// the same lattice column one plane on, and the chain applies).
+//
+// Measured at 512^3 (MI355X): one line per lane 0.80 ms, R = 2 0.67, R = 4 0.60
+// (PMC, R = 4: 25.1 M L2 read requests instead of 36.3 M, 67 in flight per CU,
+// 1.66 GB + 1.07 GB through the fabric = 4.6 TB/s).  Tried and dropped: x[i-+1]
+// from the neighbour lanes by shuffle with loads at the wave and line
+// boundaries only -- 0.70 instead of 0.60 (those loads fetch the row's own
+// lines, which the neighbour lines' workgroups need in the L2 anyway).
+// ---------------------------------------------------------------------------
+struct SdiaTileGeom {
+  int U0, U1, U2;     // row distances, descending (nd = 3)
+  int64_t NJ;         // work items
+  int chain_blocks;   // blocks of j-space per plane when whole, else 0
+  int nt_store;
+  double rcp_u1;
+};
+
+template <typename T, int R>
+struct SdiaTileRegs {
+  unsigned cm[R];
+  T xi[R], xl0[R], xu0[R], xl2[R], xu2[R], y0[R];
+  T x_below, x_above; // x[i_0 - U1], x[i_{R-1} + U1]
+  int64_t i0;         // first row of the lane, -1 = none
+};
+
+template <typename T, int R>
+__device__ __forceinline__ SdiaTileRegs<T, R> sdia_tile_loads(
+    int jb, const SdiaTileGeom& g, int t, int32_t num_rows,
+    const uint8_t* __restrict__ cmask, const T* __restrict__ in, T beta,
+    const T* __restrict__ out, bool chain, const SdiaTileRegs<T, R>& prev)
+{
+  SdiaTileRegs<T, R> q;
+  q.i0 = -1;
+  q.x_below = q.x_above = T(0);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    q.cm[r] = 0;
+    q.xi[r] = q.xl0[r] = q.xu0[r] = q.xl2[r] = q.xu2[r] = q.y0[r] = T(0);
+  }
+  if (jb < 0)
+    return q;
+  const int64_t j = (int64_t)jb * kRows + t;
+  if (j >= g.NJ)
+    return q;
+  // tuple and position: j / U1 by reciprocal, one step of correction
+  int64_t tup = (int64_t)((double)j * g.rcp_u1);
+  int64_t pos = j - tup * g.U1;
+  if (pos < 0) {
+    --tup;
+    pos += g.U1;
+  } else if (pos >= g.U1) {
+    ++tup;
+    pos -= g.U1;
+  }
+  const int64_t i0 = tup * R * g.U1 + pos;
+  if (i0 >= num_rows)
+    return q;
+  q.i0 = i0;
+  const int64_t last = (int64_t)num_rows - 1;
+  auto at = [&](int64_t c) { // clamped: what the row does not have is not used
+    return in[c < 0 ? 0 : (c > last ? last : c)];
+  };
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t i = i0 + (int64_t)r * g.U1;
+    const bool have = i <= last;
+    const int64_t ic = have ? i : last;
+    q.cm[r] = have ? cmask[ic] : 0u;
+    if (chain) { // uniform
+      q.xi[r] = prev.xu0[r];
+      q.xl0[r] = prev.xi[r];
+    } else {
+      q.xi[r] = in[ic];
+      q.xl0[r] = at(i - g.U0);
+    }
+    q.xu0[r] = at(i + g.U0);
+    q.xl2[r] = at(i - g.U2);
+    q.xu2[r] = at(i + g.U2);
+    if (beta != T(0))
+      q.y0[r] = out[ic];
+  }
+  q.x_below = at(i0 - g.U1);
+  q.x_above = at(i0 + (int64_t)R * g.U1);
+  return q;
+}
+
+template <typename T, bool DOT, bool GEN, bool TAB, int R>
+__global__ __launch_bounds__(kBlock) void csr_const_dia_tile_kernel(
+    int32_t num_rows, const uint8_t* __restrict__ cmask, T alpha,
+    const T* __restrict__ in, T beta, T* __restrict__ out, DotOut dot,
+    RowBlockOrder ord, SdiaTileGeom g, SdiaConsts cv)
+{
+  __shared__ double s_red[kBlock / 64];
+  const int t = threadIdx.x;
+  const int stride = gridDim.x;
+  const int num_slots = order_slots(ord);
+  double dot_acc = 0.0;
+  // slots of SdiaConsts with nd = 3: lower 0 1 2 | diagonal 3 | upper 4 5 6
+  const T vl0 = (T)cv.c[0], vl1 = (T)cv.c[1], vl2 = (T)cv.c[2];
+  const T d = (T)cv.c[3];
+  const T vu0 = (T)cv.c[4], vu1 = (T)cv.c[5], vu2 = (T)cv.c[6];
+
+  int it = blockIdx.x;
+  int cur = order_slot_decode(ord, order_slot_raw_t<TAB>(ord, it, num_slots));
+  int nxt_raw = order_slot_raw_t<TAB>(ord, it + stride, num_slots);
+  SdiaTileRegs<T, R> qB;
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    qB.xi[r] = qB.xu0[r] = T(0);
+  SdiaTileRegs<T, R> qA = sdia_tile_loads<T, R>(cur, g, t, num_rows, cmask, in,
+                                                beta, out, false, qB);
+  auto step = [&](const SdiaTileRegs<T, R>& q, SdiaTileRegs<T, R>& qn) {
+    const int nxt = order_slot_decode(ord, nxt_raw);
+    const int nn_raw = order_slot_raw_t<TAB>(ord, it + 2 * stride, num_slots);
+    const bool chain = g.chain_blocks > 0 && cur >= 0 && nxt >= 0
+                       && nxt - cur == g.chain_blocks;
+    qn = sdia_tile_loads<T, R>(nxt, g, t, num_rows, cmask, in, beta, out, chain,
+                               q);
+    if (cur >= 0 && q.i0 >= 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int64_t i = q.i0 + (int64_t)r * g.U1;
+        if (i < num_rows) {
+          const unsigned cm = q.cm[r];
+          const T xl1 = r > 0 ? q.xi[r > 0 ? r - 1 : 0] : q.x_below;
+          const T xu1 = r < R - 1 ? q.xi[r < R - 1 ? r + 1 : 0] : q.x_above;
+          T y, cy;
+          if constexpr (GEN) {
+            T sum = 0; // csr_kernels.cpp:45; :46-47 in ascending column order
+            if (cm & 1u)
+              sum += vl0 * q.xl0[r];
+            if (cm & 2u)
+              sum += vl1 * xl1;
+            if (cm & 4u)
+              sum += vl2 * q.xl2[r];
+            if (cm & 8u)
+              sum += d * q.xi[r];
+            if (cm & 64u)
+              sum += vu2 * q.xu2[r];
+            if (cm & 32u)
+              sum += vu1 * xu1;
+            if (cm & 16u)
+              sum += vu0 * q.xu0[r];
+            cy = alpha * sum; // :49
+            y = cy;
+            if (beta != T(0))
+              y = cy + beta * q.y0[r];
+          } else {
+            T sum = d * q.xi[r]; // csr_kernels.cpp:28; :34 left to right
+            if (cm & 1u)
+              sum += vl0 * q.xl0[r];
+            if (cm & 2u)
+              sum += vl1 * xl1;
+            if (cm & 4u)
+              sum += vl2 * q.xl2[r];
+            const T c = alpha * sum; // :39
+            y = c, cy = c;
+            if (beta != T(0))
+              y = c + beta * q.y0[r];
+            // the column's entries in ascending row order: nearest row first
+            if (cm & 64u) { // :35
+              const T term = (alpha * vu2) * q.xu2[r];
+              y += term;
+              cy += term;
+            }
+            if (cm & 32u) {
+              const T term = (alpha * vu1) * xu1;
+              y += term;
+              cy += term;
+            }
+            if (cm & 16u) {
+              const T term = (alpha * vu0) * q.xu0[r];
+              y += term;
+              cy += term;
+            }
+          }
+          if (g.nt_store) // uniform
+            __builtin_nontemporal_store(y, out + i);
+          else
+            out[i] = y;
+          if constexpr (DOT)
+            dot_acc += (double)q.xi[r] * (double)cy;
+        }
+      }
+    }
+    cur = nxt;
+    nxt_raw = nn_raw;
+    it += stride;
+  };
+  while (it < num_slots) {
+    step(qA, qB);
+    if (it >= num_slots)
+      break;
+    step(qB, qA);
+  }
+  if constexpr (DOT)
+    spmv_dot_epilogue(dot, dot_acc, s_red);
+}
+
 // Is every diagonal constant?  Pass 1 (VERIFY = false) picks, per diagonal, the
 // bits of whichever entry gets there first; pass 2 compares every entry with
 // its diagonal's pick and stops at the first difference.  Slots as SdiaConsts.
@@ -804,6 +1020,80 @@ int sdia_grid(const spmv_hip_csr_plan* pl)
 
 // `sval` / `cmask`: the baked copy to stream (the plan's native one, or the
 // fp32 copy of the mixed-precision SpMV)
+// j-space of the tile kernel: work items, blocks, launch grid
+int64_t sdia_tile_items(const spmv_hip_csr_plan* pl, int R)
+{
+  const int64_t u1 = pl->sdia_U[1];
+  const int64_t lines = ((int64_t)pl->num_rows + u1 - 1) / u1;
+  return ((lines + R - 1) / R) * u1;
+}
+
+int sdia_tile_grid(const spmv_hip_csr_plan* pl)
+{
+  const int64_t nrb = (sdia_tile_items(pl, pl->sdia_tile) + kRows - 1) / kRows;
+  int64_t grid = (int64_t)pl->ctx->num_cus * pl->sdia_tile_blocks_per_cu;
+  if (grid > pl->ctx->dot_blocks)
+    grid = pl->ctx->dot_blocks;
+  if (grid > nrb)
+    grid = nrb;
+  if (grid >= 8)
+    grid -= grid % 8;
+  return grid < 1 ? 1 : (int)grid;
+}
+
+template <typename T, int R>
+int sdia_tile_launch(const spmv_hip_csr_plan* pl, hipStream_t st,
+                     const SdiaConsts& cv, T alpha, const T* in, T beta, T* out,
+                     DotOut dot)
+{
+  SdiaTileGeom g;
+  g.U0 = pl->sdia_U[0];
+  g.U1 = pl->sdia_U[1];
+  g.U2 = pl->sdia_U[2];
+  g.NJ = sdia_tile_items(pl, R);
+  g.rcp_u1 = 1.0 / (double)g.U1;
+  g.nt_store = (pl->sdia_nt >> 4) & 1;
+  g.chain_blocks = 0;
+  if (pl->sdia_chain && g.U0 % ((int64_t)R * g.U1) == 0
+      && (g.U0 / R) % kRows == 0)
+    g.chain_blocks = g.U0 / R / kRows;
+  const int grid = sdia_tile_grid(pl);
+  const int nrb = (int)((g.NJ + kRows - 1) / kRows);
+  RowBlockOrder ord = pl->row_block_order(nrb);
+  ord.xcd_group = pl->lat_xcd_group;
+  if (pl->zwalk && pl->sdia_tile_table && pl->sdia_tile_grid == grid) {
+    ord.table = pl->sdia_tile_table;
+    ord.num_slots = pl->sdia_tile_slots;
+  }
+#define SPMV_CTILE(DOTV, GENV)                                                 \
+  do {                                                                         \
+    if (ord.table)                                                             \
+      hipLaunchKernelGGL((csr_const_dia_tile_kernel<T, DOTV, GENV, true, R>),  \
+                         dim3(grid), dim3(kBlock), 0, st, pl->num_rows,        \
+                         pl->sdia_cmask, alpha, in, beta, out, dot, ord, g,    \
+                         cv);                                                  \
+    else                                                                       \
+      hipLaunchKernelGGL((csr_const_dia_tile_kernel<T, DOTV, GENV, false, R>), \
+                         dim3(grid), dim3(kBlock), 0, st, pl->num_rows,        \
+                         pl->sdia_cmask, alpha, in, beta, out, dot, ord, g,    \
+                         cv);                                                  \
+  } while (0)
+  if (dot.partials) {
+    if (pl->sdia_general)
+      SPMV_CTILE(true, true);
+    else
+      SPMV_CTILE(true, false);
+  } else {
+    if (pl->sdia_general)
+      SPMV_CTILE(false, true);
+    else
+      SPMV_CTILE(false, false);
+  }
+#undef SPMV_CTILE
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
 // the constant-diagonal kernel (`cv`: the plan's constants, or those of the
 // fp32 values of the mixed-precision SpMV)
 template <typename T>
@@ -811,6 +1101,14 @@ int sdia_const_launch(const spmv_hip_csr_plan* pl, hipStream_t st,
                       const double* cvals, T alpha, const T* in, T beta, T* out,
                       DotOut dot)
 {
+  if (pl->sdia_tile > 1) {
+    SdiaConsts tcv;
+    for (int a = 0; a < 2 * kSdiaMaxOff + 1; ++a)
+      tcv.c[a] = cvals[a];
+    if (pl->sdia_tile == 2)
+      return sdia_tile_launch<T, 2>(pl, st, tcv, alpha, in, beta, out, dot);
+    return sdia_tile_launch<T, 4>(pl, st, tcv, alpha, in, beta, out, dot);
+  }
   SdiaGeom g = sdia_geom<T>(pl);
   const int nrb = (pl->num_rows + kRows - 1) / kRows;
   const int grid = sdia_grid<T>(pl);
@@ -1304,7 +1602,11 @@ int sdia_bake(spmv_hip_csr_plan* pl, const T* values, const T* diagonal,
   pl->slat_blocks_per_cu = 4;
   // the plane-walk order makes that true for every size (planes = the
   // farthest offset apart)
-  return spmv_zwalk_order_build(pl, g.U[0], sdia_grid<T>(pl), 0, false);
+  const int rw = spmv_zwalk_order_build(pl, g.U[0], sdia_grid<T>(pl), 0, false);
+  if (rw != SPMV_HIP_OK || !pl->sdia_const)
+    return rw;
+  // constant diagonals of a 3-D lattice: several lines per lane
+  return spmv_sdia_tile_build(pl, pl->ctx->const_tile, 0, false);
 }
 
 // The fp32 copy of the mixed-precision SpMV (general plans whose fp64 values
@@ -1367,6 +1669,36 @@ int sdia_bake_mixed(spmv_hip_csr_plan* pl, const float* values32, hipStream_t st
 
 } // namespace
 
+// (Re)build the tile kernel's geometry and plane-walk table: R lines per lane
+// (1 = the one-line kernel), `segments` runs along the plane axis (0 = choose).
+// Needs the constant form of a lattice with three lower offsets.
+int spmv_sdia_tile_build(spmv_hip_csr_plan* pl, int R, int segments, bool force)
+{
+  SPMV_REQUIRE(R == 1 || R == 2 || R == 4);
+  if (pl->sdia_tile_table) {
+    SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
+    SPMV_CHECK_HIP(hipDeviceSynchronize()); // no launch still reads the old one
+    (void)hipFree(pl->sdia_tile_table);
+    pl->sdia_tile_table = nullptr;
+  }
+  pl->sdia_tile_slots = pl->sdia_tile_grid = pl->sdia_tile_segments = 0;
+  pl->sdia_tile = 0;
+  if (R == 1 || !pl->sdia_const || pl->sdia_nd != 3
+      || pl->sdia_U[1] >= (1 << 23))
+    return SPMV_HIP_OK;
+  pl->sdia_tile = R;
+  const int64_t u0 = pl->sdia_U[0], u1 = pl->sdia_U[1];
+  if (u0 % (R * u1) != 0)
+    return SPMV_HIP_OK; // planes do not line up in j-space: the plain order
+  const int grid = sdia_tile_grid(pl);
+  const int rc = spmv_zwalk_table_device(
+      pl, sdia_tile_items(pl, R), u0 / R, grid, segments, force,
+      &pl->sdia_tile_table, &pl->sdia_tile_slots, &pl->sdia_tile_segments);
+  if (rc == SPMV_HIP_OK && pl->sdia_tile_table)
+    pl->sdia_tile_grid = grid;
+  return rc;
+}
+
 void spmv_sdia_free(spmv_hip_csr_plan* pl)
 {
   sdia_free_arrays(pl);
@@ -1390,6 +1722,10 @@ static void sdia_free_arrays(spmv_hip_csr_plan* pl)
   pl->sdia_len = 0;
   pl->sdia_elem = 0;
   pl->sdia_const = 0;
+  (void)hipFree(pl->sdia_tile_table);
+  pl->sdia_tile_table = nullptr;
+  pl->sdia_tile_slots = pl->sdia_tile_grid = pl->sdia_tile_segments = 0;
+  pl->sdia_tile = 0;
   pl->sdia = 0;
   pl->sdia_general = 0;
   pl->sdia_nd = 0;

@@ -738,7 +738,8 @@ int spmv_wdia_walk_build(spmv_hip_csr_plan* pl, int segments, bool force)
     pl->wdia_zw_slots = pl->wdia_zw_grid = pl->wdia_zw_segments = 0;
   }
   const int grid = wdia_grid(pl);
-  const int rc = spmv_zwalk_table_device(pl, pl->wdia_d2, grid, segments, force,
+  const int rc = spmv_zwalk_table_device(pl, pl->num_rows, pl->wdia_d2, grid,
+                                         segments, force,
                                          &pl->wdia_zw_table, &pl->wdia_zw_slots,
                                          &pl->wdia_zw_segments);
   if (rc == SPMV_HIP_OK && pl->wdia_zw_table)

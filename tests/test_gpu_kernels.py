@@ -1844,9 +1844,22 @@ def test_constant_diagonals_bit_exact(dtype):
                                   dict(slat_blocks_per_cu=2, zwalk_segments=3),
                                   dict(sdia_chain=0, sdia_nt=31),
                                   dict(sdia_chain=1, zwalk_segments=2, sdia_nt=0),
-                                  dict(zwalk=0)):
+                                  dict(zwalk=0), dict(zwalk=1, sdia_tile=1),
+                                  dict(sdia_tile=2), dict(sdia_tile=2,
+                                                          sdia_tile_segments=3),
+                                  dict(sdia_tile=4, sdia_tile_segments=0),
+                                  dict(sdia_tile_blocks_per_cu=1, sdia_chain=0),
+                                  dict(sdia_tile_blocks_per_cu=8, sdia_chain=1,
+                                       sdia_nt=16)):
+                        tile_knobs = any(k.startswith("sdia_tile") for k in knobs)
+                        if tile_knobs and not (variant == "const"
+                                               and blk.get("sdia_offsets") == 3):
+                            continue  # the tile kernel: constant 3-D lattices
                         for k, v in knobs.items():
                             blk.set(k, v)
+                        if "sdia_tile" in knobs:
+                            assert blk.get("sdia_tile") == (
+                                knobs["sdia_tile"] if knobs["sdia_tile"] > 1 else 0)
                         dy = ctx.upload(np.full(N, np.nan, dtype) if beta == 0 else y0,
                                         dtype)
                         dot = dtype == np.float64 and beta == 0.0
