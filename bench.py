@@ -273,7 +273,10 @@ def kernel_of(A, symmetric):
     if symmetric:
         algo = rows * 8 * 3 + (rows + 1) * 4 + nnz * 12  # SURVEY 8d B_sym
         if A.plan_get("sdia") and A.plan_get("sdia_const"):
-            return ("csr_const_dia_kernel<double> (symmetric storage whose "
+            R = A.plan_get("sdia_tile")
+            name = (f"csr_const_dia_tile_kernel<double, {R} lattice lines per lane>"
+                    if R > 1 else "csr_const_dia_kernel<double>")
+            return (name + " (symmetric storage whose "
                     "diagonals are constant bit for bit: the plan keeps one "
                     "number per diagonal and a mask byte per row, no values are "
                     "streamed; same products and sums in the reference's order, "
@@ -321,7 +324,11 @@ def kernel_of(A, symmetric):
                 "rows summed in the CSR kernel's order: bit-exact; fused p.Ap)",
                 algo, rows * (8 * K + 4) + y_x)
     if A.plan_get("sdia") and A.plan_get("sdia_const"):
-        return ("csr_const_dia_kernel<double, general order> (every diagonal of "
+        R = A.plan_get("sdia_tile")
+        name = (f"csr_const_dia_tile_kernel<double, general order, {R} lattice "
+                "lines per lane>" if R > 1
+                else "csr_const_dia_kernel<double, general order>")
+        return (name + " (every diagonal of "
                 "the matrix is constant bit for bit: the plan keeps one number "
                 "per diagonal and a mask byte per row, no values are streamed; "
                 "the kernel does the CSR kernel's multiplications and additions "

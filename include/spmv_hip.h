@@ -68,6 +68,14 @@ int spmv_hip_synchronize(spmv_hip_ctx* ctx); /* whole device */
  *   how large an x) plans build the lattice / LX forms.
  *   "bake_general": 0 = plan_bake_values on a general plan always returns
  *   SPMV_HIP_ENOTSUP (the CSR-order kernels on the caller's values).
+ *   "const_diagonals": 1 (default) = plan_bake_values looks whether every
+ *   diagonal of a lattice matrix is constant, bit for bit (constant-coefficient
+ *   stencils: the Poisson operators); then the plan keeps ONE number per
+ *   diagonal and the per-row presence mask instead of a copy of the values, and
+ *   the kernel multiplies by that number -- same products, same sums, same
+ *   order, same bits.  0 = always keep (and stream) the values.
+ *   "const_tile": lattice lines per lane of that kernel on 3-D lattices (1, 2
+ *   or 4; default 4).
  *   "wdia_half": 0 = the wide diagonal form (a baked copy of a general matrix
  *   with <= 32 diagonals) keeps every diagonal even when it finds the matrix
  *   symmetric bit for bit; default 1 = then only the diagonals <= 0.
@@ -207,8 +215,15 @@ int spmv_hip_csr_plan_destroy(spmv_hip_csr_plan* plan);
  *                    CSR values, no index stream, no row pointer).  Either
  *                    way the kernel sums each row in the general kernel's own
  *                    order: same bits as csr_kernels.cpp:41-51.
+ *                    A general matrix on MORE diagonals (<= 32: 27-point
+ *                    stencils) takes the "wide diagonal form": values by
+ *                    offset + a 32-bit presence mask per row; only the
+ *                    diagonals <= 0 when the matrix is symmetric bit for bit.
+ *   constant diagonals  (either storage; ctx option "const_diagonals") when
+ *                    every diagonal is constant, bit for bit, the plan keeps
+ *                    no values at all: one number per diagonal + the mask.
  * Anything else: SPMV_HIP_ENOTSUP, nothing changes.  Costs (offsets + 1) * 8 B
- * per row of device memory.  A launch that passes these very `values` (and
+ * per row of device memory (constant diagonals: 1 or 4 B per row).  A launch that passes these very `values` (and
  * `diagonal`) pointers takes the diagonal-form kernel; a launch with other
  * pointers takes the CSR-order kernels as before.  CONTRACT: whoever rewrites
  * the baked arrays in place bakes again (or drops the copy: values = NULL). */

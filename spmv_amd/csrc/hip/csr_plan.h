@@ -233,7 +233,7 @@ struct spmv_hip_csr_plan {
   // ... of a 3-D lattice: R lines per lane (csr_const_dia_tile_kernel), with a
   // plane-walk table of its own over the kernel's index space
   int sdia_tile = 0;          // R in use (0 / 1: the one-line kernel)
-  int sdia_tile_blocks_per_cu = 4;
+  int sdia_tile_blocks_per_cu = 8; // (R = 4: four resident, the rest queue)
   int32_t* sdia_tile_table = nullptr;
   int sdia_tile_slots = 0, sdia_tile_grid = 0, sdia_tile_segments = 0;
   // ... and the fp32 copy for the mixed-precision SpMV (general, fp64 plans)

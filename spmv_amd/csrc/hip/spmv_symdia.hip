@@ -504,7 +504,12 @@ __global__ __launch_bounds__(kBlock) void csr_const_dia_kernel(
 // 1.66 GB + 1.07 GB through the fabric = 4.6 TB/s).  Tried and dropped: x[i-+1]
 // from the neighbour lanes by shuffle with loads at the wave and line
 // boundaries only -- 0.70 instead of 0.60 (those loads fetch the row's own
-// lines, which the neighbour lines' workgroups need in the L2 anyway).
+// lines, which the neighbour lines' workgroups need in the L2 anyway); a
+// clamp-free 32-bit index path and test-free sums for the blocks and waves
+// inside the lattice -- no change: with every load and store removed the kernel
+// takes 0.37 ms (its instructions), under the 0.60 the memory side needs.
+// Ablations (0.65 on that box): without the x[i -+ 1] loads 0.56, without the
+// outer neighbour lines 0.61, without both 0.50, without the stores 0.55.
 // ---------------------------------------------------------------------------
 struct SdiaTileGeom {
   int U0, U1, U2;     // row distances, descending (nd = 3)

@@ -69,7 +69,8 @@ def test_bench_single_gpu_line():
     assert d["csr_lx_spmv"]["form"]["lx"] == 1 and d["csr_lx_spmv"]["form"]["lat"] == 0
     # every diagonal of the Poisson matrix is constant: no values are streamed
     assert d["plan"]["form"]["sdia"] == 1 and d["plan"]["form"]["sdia_const"] == 1
-    assert "csr_const_dia_kernel<double, general order>" in d["roofline"]["kernel"]
+    assert "csr_const_dia_tile_kernel<double, general order, 4 lattice lines" \
+        in d["roofline"]["kernel"]
     assert d["roofline"]["bytes_per_launch"] == 17 * 64 ** 3
     # (symmetric storage of 64^3 is below the lattice analysis' size: the
     # transposed map; tests/test_gpu_matrix.py covers the larger grids)

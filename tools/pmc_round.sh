@@ -16,11 +16,14 @@ run() { # record grid script args...
 }
 run main 512 tools/prof_spmv.py --n 512 --reps 6 --dot
 run symmetric 512 tools/prof_spmv.py --n 512 --reps 6 --dot --symmetric
+run value_stream_spmv 512 tools/prof_spmv.py --n 512 --reps 6 --ctx const_diagonals=0
+run symmetric_value_stream_spmv 512 tools/prof_spmv.py --n 512 --reps 6 --symmetric --ctx const_diagonals=0
 run csr_nonsymmetric_spmv 512 tools/prof_spmv.py --n 512 --reps 6 --asym
 run csr_lattice_spmv 512 tools/prof_spmv.py --n 512 --reps 6 --no-bake
 run csr_lx_spmv 512 tools/prof_spmv.py --n 512 --reps 6 --no-lat
 run csr_rowblock_spmv 512 tools/prof_spmv.py --n 512 --reps 6 --no-lx
 run stencil27_spmv 256 tools/prof_matrix.py --kind stencil27 --n 256
+run stencil27_value_stream_spmv 256 tools/prof_matrix.py --kind stencil27 --n 256 --set const_diagonals=0
 run unstructured_spmv 10000000 tools/prof_matrix.py --kind unstructured --rows 10000000
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/rp_$R

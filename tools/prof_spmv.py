@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--symmetric", action="store_true")
     ap.add_argument("--dot", action="store_true")
     ap.add_argument("--set", nargs="*", default=[], help="knob=value ...")
+    ap.add_argument("--ctx", nargs="*", default=[],
+                    help="context option=value ... (e.g. const_diagonals=0)")
     ap.add_argument("--no-lat", action="store_true",
                     help="no lattice form: the plan takes the LX form")
     ap.add_argument("--asym", action="store_true",
@@ -32,6 +34,8 @@ def main():
                     help="neither: the plain gather kernel")
     args = ap.parse_args()
     ctx = hip.Context(0)
+    for kv in args.ctx:
+        ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     if args.no_lat or args.no_lx:
         ctx.set_option("lat_min_nnz", 1 << 62)
     if args.no_lx:
