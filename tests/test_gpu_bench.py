@@ -79,7 +79,7 @@ def test_bench_single_gpu_line():
     vs, svs = d["value_stream_spmv"], d["symmetric_value_stream_spmv"]
     assert vs["form"]["sdia"] == 1 and vs["form"]["sdia_const"] == 0
     assert "csr_sym_dia_kernel<double, general order>" in vs["kernel"]
-    assert svs["form"]["sdia_const"] == 0 and "csr_sym_dia_kernel" in svs["kernel"]
+    assert svs["form"]["sdia_const"] == 0 and "atomic-free" in svs["kernel"]
     assert d["north_star_spmv"]["form"]["sdia_const"] == 1
     assert d["north_star_value_stream_spmv"]["form"]["sdia_const"] == 0
     lat = d["csr_lattice_spmv"]["form"]
