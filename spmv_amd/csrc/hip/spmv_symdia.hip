@@ -724,11 +724,15 @@ __device__ __forceinline__ unsigned long long value_bits(T v)
 
 template <typename T, bool GENERAL, bool VERIFY>
 __global__ __launch_bounds__(kBlock) void sdia_const_kernel(
-    int32_t num_rows, int nd, int u0, int u1, int u2,
+    int32_t num_rows /* to look at */, int32_t total_rows, int nd, int u0,
+    int u1, int u2,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
     const uint8_t* __restrict__ mask, const T* __restrict__ values,
-    const T* __restrict__ diagonal, SdiaConstProbe* __restrict__ pr)
+    const T* __restrict__ diagonal, SdiaConstProbe* __restrict__ pr,
+    uint8_t* __restrict__ cmask_out)
 {
+  // (pass 2 also writes the kernel's mask byte -- own bits 0..2, diagonal 3,
+  // column / upper bits 4..6 -- when given somewhere to put it)
   auto visit = [&](int slot, T v) {
     const unsigned long long b = value_bits(v);
     if constexpr (VERIFY) {
@@ -744,29 +748,39 @@ __global__ __launch_bounds__(kBlock) void sdia_const_kernel(
        i += (int64_t)gridDim.x * blockDim.x) {
     if (*(volatile int*)&pr->fail)
       return;
+    unsigned cm = 0;
     if constexpr (GENERAL) {
       for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
         const int64_t c = colind[j];
         if (c == i) {
           visit(nd, values[j]);
+          cm |= 8u;
           continue;
         }
         const int64_t u = c < i ? i - c : c - i;
         const int k = u == u0 ? 0 : (u == u1 ? 1 : (u == u2 ? 2 : -1));
-        if (k < 0 || k >= nd) {
+        if (k < 0 || k >= nd || c >= total_rows) {
           atomicOr(&pr->fail, 1);
           return;
         }
         visit(c < i ? k : nd + 1 + k, values[j]);
+        cm |= 1u << (c < i ? k : 4 + k);
       }
     } else {
       const unsigned m = mask[i];
       int32_t j = rowptr[i];
-      for (int k = 0; k < nd; ++k)
+      cm = m | 8u;
+      for (int k = 0; k < nd; ++k) {
         if ((m >> k) & 1u)
           visit(k, values[j++]);
+        const int64_t r = i + (k == 0 ? u0 : (k == 1 ? u1 : u2));
+        if (VERIFY && r < total_rows && ((mask[r] >> k) & 1u))
+          cm |= 1u << (4 + k);
+      }
       visit(nd, diagonal[i]);
     }
+    if (VERIFY && cmask_out)
+      cmask_out[i] = (uint8_t)cm;
   }
 }
 
@@ -1382,7 +1396,8 @@ int sdia_is_symmetric(spmv_hip_csr_plan* pl, const T* values, hipStream_t st,
 // over the values, nothing allocated but the 120-byte probe record.
 template <typename T>
 int sdia_const_probe(spmv_hip_csr_plan* pl, bool general, const T* values,
-                     const T* diagonal, hipStream_t st, bool* yes, double* cvals)
+                     const T* diagonal, hipStream_t st, bool* yes, double* cvals,
+                     uint8_t* cmask_out)
 {
   *yes = false;
   SdiaConstProbe* d_pr = nullptr;
@@ -1394,24 +1409,35 @@ int sdia_const_probe(spmv_hip_csr_plan* pl, bool general, const T* values,
     const int grid = spmv_grid_for(pl->ctx, pl->num_rows, kBlock);
     const int nd = pl->sdia_nd, u0 = pl->sdia_U[0], u1 = pl->sdia_U[1],
               u2 = pl->sdia_U[2];
+    // pass 1 looks at the first few planes only (every diagonal of a lattice
+    // shows up there); a diagonal it has not seen makes pass 2 fail unless its
+    // entries are +0.0 -- the values are streamed then, nothing is lost but
+    // the shortcut
+    const int64_t prefix = 4 * (int64_t)u0 + 4096;
+    const int32_t pick_rows
+        = prefix < pl->num_rows ? (int32_t)prefix : pl->num_rows;
     if (general) {
       hipLaunchKernelGGL((sdia_const_kernel<T, true, false>), dim3(grid),
-                         dim3(kBlock), 0, st, pl->num_rows, nd, u0, u1, u2,
+                         dim3(kBlock), 0, st, pick_rows, pl->num_rows, nd, u0, u1,
+                         u2,
                          pl->rowptr0, pl->colind0, (const uint8_t*)nullptr,
-                         values, diagonal, d_pr);
+                         values, diagonal, d_pr, (uint8_t*)nullptr);
       hipLaunchKernelGGL((sdia_const_kernel<T, true, true>), dim3(grid),
-                         dim3(kBlock), 0, st, pl->num_rows, nd, u0, u1, u2,
+                         dim3(kBlock), 0, st, pl->num_rows, pl->num_rows, nd, u0,
+                         u1, u2,
                          pl->rowptr0, pl->colind0, (const uint8_t*)nullptr,
-                         values, diagonal, d_pr);
+                         values, diagonal, d_pr, cmask_out);
     } else {
       hipLaunchKernelGGL((sdia_const_kernel<T, false, false>), dim3(grid),
-                         dim3(kBlock), 0, st, pl->num_rows, nd, u0, u1, u2,
+                         dim3(kBlock), 0, st, pick_rows, pl->num_rows, nd, u0, u1,
+                         u2,
                          pl->rowptr0, pl->colind0, pl->slat_mask, values,
-                         diagonal, d_pr);
+                         diagonal, d_pr, (uint8_t*)nullptr);
       hipLaunchKernelGGL((sdia_const_kernel<T, false, true>), dim3(grid),
-                         dim3(kBlock), 0, st, pl->num_rows, nd, u0, u1, u2,
+                         dim3(kBlock), 0, st, pl->num_rows, pl->num_rows, nd, u0,
+                         u1, u2,
                          pl->rowptr0, pl->colind0, pl->slat_mask, values,
-                         diagonal, d_pr);
+                         diagonal, d_pr, cmask_out);
     }
     e = hipGetLastError();
   }
@@ -1444,55 +1470,6 @@ int sdia_const_probe(spmv_hip_csr_plan* pl, bool general, const T* values,
     for (int k = 0; k < pl->sdia_nd; ++k)
       cvals[pl->sdia_nd + 1 + k] = cvals[k];
   *yes = true;
-  return SPMV_HIP_OK;
-}
-
-// ... then the plan keeps the mask byte per row and the constants
-template <typename T>
-int sdia_fill_const(spmv_hip_csr_plan* pl, bool general, const T* values,
-                    const T* diagonal, hipStream_t st, void** out_val,
-                    uint8_t** out_cmask)
-{
-  const int32_t n = pl->num_rows;
-  const SdiaGeom g = sdia_geom<T>(pl);
-  void* tag = nullptr; // the "baked" marker every other check looks at
-  uint8_t* cm = nullptr;
-  int32_t* d_fail = nullptr;
-  int32_t h_fail = 0;
-  hipError_t e = hipMalloc(&tag, 64);
-  if (e == hipSuccess)
-    e = hipMalloc(&cm, (size_t)n);
-  if (e == hipSuccess)
-    e = hipMalloc(&d_fail, sizeof(int32_t));
-  if (e == hipSuccess)
-    e = hipMemsetAsync(d_fail, 0, sizeof(int32_t), st);
-  if (e == hipSuccess) {
-    const int grid = spmv_grid_for(pl->ctx, n, kBlock);
-    if (general)
-      hipLaunchKernelGGL((sdia_bake_general_kernel<T, true, true>), dim3(grid),
-                         dim3(kBlock), 0, st, n, g.nd, g.U[0], g.U[1], g.U[2],
-                         pl->rowptr0, pl->colind0, values, (int64_t)0,
-                         (T*)nullptr, cm, d_fail, 0);
-    else
-      hipLaunchKernelGGL((sdia_bake_kernel<T>), dim3(grid), dim3(kBlock), 0, st,
-                         n, g.nd, g.U[0], g.U[1], g.U[2], pl->rowptr0,
-                         pl->slat_mask, values, diagonal, (int64_t)0,
-                         (T*)nullptr, cm);
-    e = hipGetLastError();
-  }
-  if (e == hipSuccess)
-    e = hipMemcpyAsync(&h_fail, d_fail, sizeof(int32_t), hipMemcpyDeviceToHost,
-                       st);
-  if (e == hipSuccess)
-    e = hipStreamSynchronize(st);
-  (void)hipFree(d_fail);
-  if (e != hipSuccess || h_fail) {
-    (void)hipFree(tag);
-    (void)hipFree(cm);
-    return e != hipSuccess ? static_cast<int>(e) : SPMV_HIP_ENOTSUP;
-  }
-  *out_val = tag;
-  *out_cmask = cm;
   return SPMV_HIP_OK;
 }
 
@@ -1563,15 +1540,25 @@ int sdia_bake(spmv_hip_csr_plan* pl, const T* values, const T* diagonal,
     // constant diagonals first: no copy of the values at all (and no need
     // for symmetry -- the upper diagonals have constants of their own)
     bool is_const = false;
-    if (pl->ctx->const_diagonals)
-      rc = sdia_const_probe<T>(pl, general, values, diagonal, st, &is_const,
-                               pl->sdia_cval);
+    if (pl->ctx->const_diagonals) {
+      // (the second pass writes the mask byte on the way: one pass fewer)
+      hipError_t ea = hipMalloc(&cm, (size_t)pl->num_rows);
+      if (ea == hipSuccess)
+        ea = hipMalloc(&sval, 64); // the "baked" marker every check looks at
+      rc = ea == hipSuccess ? SPMV_HIP_OK : static_cast<int>(ea);
+      if (rc == SPMV_HIP_OK)
+        rc = sdia_const_probe<T>(pl, general, values, diagonal, st, &is_const,
+                                 pl->sdia_cval, cm);
+      if (rc != SPMV_HIP_OK || !is_const) {
+        (void)hipFree(cm);
+        (void)hipFree(sval);
+        cm = nullptr;
+        sval = nullptr;
+      }
+    }
     if (rc == SPMV_HIP_OK && is_const) {
       pl->sdia_general = general ? 2 : 0;
       pl->sdia_const = 1; // (sdia_grid reads it)
-      rc = sdia_fill_const<T>(pl, general, values, diagonal, st, &sval, &cm);
-      if (rc != SPMV_HIP_OK)
-        pl->sdia_const = 0;
     } else {
       if (rc == SPMV_HIP_OK && general) {
         bool symmetric = false;
@@ -1634,7 +1621,7 @@ int sdia_bake_mixed(spmv_hip_csr_plan* pl, const float* values32, hipStream_t st
     // constant diagonals: the fp32 array must have them too (its own constants)
     bool is_const = false;
     const int rcc = sdia_const_probe<float>(pl, true, values32, nullptr, st,
-                                            &is_const, pl->sdia32_cval);
+                                            &is_const, pl->sdia32_cval, nullptr);
     if (rcc != SPMV_HIP_OK)
       return rcc;
     if (!is_const)

@@ -220,8 +220,9 @@ template <typename T, bool VERIFY>
 __global__ __launch_bounds__(kBlock) void wdia_const_kernel(
     int32_t num_rows, int K, WdiaOffsets off, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ colind, const T* __restrict__ values,
-    WdiaConstProbe* __restrict__ pr)
+    WdiaConstProbe* __restrict__ pr, uint32_t* __restrict__ mask_out)
 {
+  // (pass 2 also writes the presence mask when given somewhere to put it)
   __shared__ int32_t s_D[kWdiaMaxOff];
   if (threadIdx.x < kWdiaMaxOff)
     s_D[threadIdx.x] = off.D[threadIdx.x];
@@ -231,6 +232,7 @@ __global__ __launch_bounds__(kBlock) void wdia_const_kernel(
     if (*(volatile int*)&pr->fail)
       return;
     int prev = -1;
+    uint32_t m = 0;
     for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
       const int32_t d = (int32_t)((int64_t)colind[j] - i);
       int k = prev + 1;
@@ -240,6 +242,7 @@ __global__ __launch_bounds__(kBlock) void wdia_const_kernel(
         atomicOr(&pr->fail, 1);
         return;
       }
+      m |= 1u << k;
       unsigned long long b;
       if constexpr (sizeof(T) == 8)
         b = (unsigned long long)__double_as_longlong(values[j]);
@@ -257,12 +260,15 @@ __global__ __launch_bounds__(kBlock) void wdia_const_kernel(
       }
       prev = k;
     }
+    if (VERIFY && mask_out)
+      mask_out[i] = m;
   }
 }
 
 template <typename T>
 int wdia_const_probe(const spmv_hip_csr_plan* pl, int K, const WdiaOffsets& off,
-                     const T* values, hipStream_t st, bool* yes, double* cvals)
+                     const T* values, hipStream_t st, bool* yes, double* cvals,
+                     uint32_t* mask_out)
 {
   *yes = false;
   WdiaConstProbe* d_pr = nullptr;
@@ -272,12 +278,23 @@ int wdia_const_probe(const spmv_hip_csr_plan* pl, int K, const WdiaOffsets& off,
     e = hipMemsetAsync(d_pr, 0, sizeof(WdiaConstProbe), st);
   if (e == hipSuccess) {
     const int grid = spmv_grid_for(pl->ctx, pl->num_rows, kBlock);
+    // pass 1 looks at the first few planes only (every diagonal of a stencil
+    // shows up there); a diagonal it has not seen makes pass 2 fail unless its
+    // entries are +0.0 -- then the values are streamed, as before
+    int64_t far = 0;
+    for (int k = 0; k < K; ++k) {
+      const int64_t a = off.D[k] < 0 ? -(int64_t)off.D[k] : (int64_t)off.D[k];
+      far = a > far ? a : far;
+    }
+    const int64_t prefix = 4 * far + 4096;
+    const int32_t pick_rows
+        = prefix < pl->num_rows ? (int32_t)prefix : pl->num_rows;
     hipLaunchKernelGGL((wdia_const_kernel<T, false>), dim3(grid), dim3(kBlock), 0,
-                       st, pl->num_rows, K, off, pl->rowptr0, pl->colind0, values,
-                       d_pr);
+                       st, pick_rows, K, off, pl->rowptr0, pl->colind0, values,
+                       d_pr, (uint32_t*)nullptr);
     hipLaunchKernelGGL((wdia_const_kernel<T, true>), dim3(grid), dim3(kBlock), 0,
                        st, pl->num_rows, K, off, pl->rowptr0, pl->colind0, values,
-                       d_pr);
+                       d_pr, mask_out);
     e = hipGetLastError();
   }
   if (e == hipSuccess)
@@ -448,11 +465,19 @@ int wdia_bake(spmv_hip_csr_plan* pl, const T* values, hipStream_t st)
   }
   // constant diagonals: no arrays at all, whatever the symmetry
   bool is_const = false;
+  uint32_t* msk = nullptr;
+  e = hipMalloc(&msk, sizeof(uint32_t) * (size_t)n);
+  if (e != hipSuccess) {
+    (void)hipFree(d_set);
+    return static_cast<int>(e);
+  }
   if (pl->ctx->const_diagonals) {
+    // (its second pass writes the masks on the way)
     const int rcc = wdia_const_probe<T>(pl, K, off, values, st, &is_const,
-                                        pl->wdia_cval);
+                                        pl->wdia_cval, msk);
     if (rcc != SPMV_HIP_OK) {
       (void)hipFree(d_set);
+      (void)hipFree(msk);
       return rcc;
     }
     if (is_const)
@@ -483,6 +508,7 @@ int wdia_bake(spmv_hip_csr_plan* pl, const T* values, hipStream_t st)
       e = hipStreamSynchronize(st);
     if (e != hipSuccess) {
       (void)hipFree(d_set);
+      (void)hipFree(msk);
       return static_cast<int>(e);
     }
     if (!h_asym) {
@@ -502,26 +528,24 @@ int wdia_bake(spmv_hip_csr_plan* pl, const T* values, hipStream_t st)
   const int64_t len = (((int64_t)n + kRows - 1) / kRows) * kRows;
   const size_t bytes = (size_t)narr * len * sizeof(T);
   void* sval = nullptr;
-  uint32_t* msk = nullptr;
   int32_t h_fail = 0;
   e = hipMalloc(&sval, bytes > 0 ? bytes : 64); // (constant: a marker only)
-  if (e == hipSuccess)
-    e = hipMalloc(&msk, sizeof(uint32_t) * (size_t)n);
-  if (e == hipSuccess)
+  if (e == hipSuccess && !is_const) {
     e = hipMemsetAsync(sval, 0, bytes, st);
-  if (e == hipSuccess)
-    e = hipMemsetAsync(d_set + kWdiaMaxOff, 0, sizeof(int32_t), st);
-  if (e == hipSuccess) {
-    hipLaunchKernelGGL((wdia_bake_kernel<T>), dim3(grid), dim3(kBlock), 0, st, n,
-                       K, narr, off, pl->rowptr0, pl->colind0, values, len,
-                       static_cast<T*>(sval), msk, d_set + kWdiaMaxOff);
-    e = hipGetLastError();
+    if (e == hipSuccess)
+      e = hipMemsetAsync(d_set + kWdiaMaxOff, 0, sizeof(int32_t), st);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL((wdia_bake_kernel<T>), dim3(grid), dim3(kBlock), 0, st,
+                         n, K, narr, off, pl->rowptr0, pl->colind0, values, len,
+                         static_cast<T*>(sval), msk, d_set + kWdiaMaxOff);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(&h_fail, d_set + kWdiaMaxOff, sizeof(int32_t),
+                         hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess)
+      e = hipStreamSynchronize(st);
   }
-  if (e == hipSuccess)
-    e = hipMemcpyAsync(&h_fail, d_set + kWdiaMaxOff, sizeof(int32_t),
-                       hipMemcpyDeviceToHost, st);
-  if (e == hipSuccess)
-    e = hipStreamSynchronize(st);
   (void)hipFree(d_set);
   if (e != hipSuccess || h_fail) {
     (void)hipFree(sval);
@@ -609,7 +633,7 @@ int wdia_bake_mixed(spmv_hip_csr_plan* pl, const float* values32, hipStream_t st
     // constant diagonals: the fp32 array must have them too (its own constants)
     bool is_const = false;
     const int rcc = wdia_const_probe<float>(pl, pl->wdia_K, off, values32, st,
-                                            &is_const, pl->wdia32_cval);
+                                            &is_const, pl->wdia32_cval, nullptr);
     if (rcc != SPMV_HIP_OK)
       return rcc;
     if (!is_const)
