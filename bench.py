@@ -880,6 +880,47 @@ def main():
                 ws2.close()
                 As.close()
                 exec_.free(d_b), exec_.free(d_x)
+                # The same CG with the matrix values STREAMED (constant-diagonal
+                # detection off): what the loop costs on a lattice matrix whose
+                # coefficients vary -- the half diagonal form of rounds 2-3
+                if not (args.no_const or args.no_bake or args.no_lattice
+                        or args.no_lx):
+                    _lib.call("spmv_hip_ctx_set_option", ctx, b"const_diagonals", 0)
+                    try:
+                        Av = host.Matrix.create_poisson3d(self_comm, exec_, n,
+                                                          False, cm)
+                    finally:
+                        _lib.call("spmv_hip_ctx_set_option", ctx,
+                                  b"const_diagonals", 1)
+                    d_b, d_x = exec_.alloc(N), exec_.alloc(N)
+                    _lib.call("spmv_hip_fill_gaussian_f64", ctx, N, 0, N, d_b, None)
+                    ws3 = host.CgWorkspace(exec_)
+                    steps = min(args.steps, 20)
+                    host.cg_ex(self_comm, exec_, Av, d_b, d_x, 3, 0.0, ws3)
+                    ws3.reserve_timing(steps)
+                    exec_.synchronize()
+                    t0 = time.perf_counter()
+                    _, h3, ms3, l3 = host.cg_ex(self_comm, exec_, Av, d_b, d_x,
+                                                steps, 0.0, ws3, time_spmv=True,
+                                                history=True)
+                    exec_.synchronize()
+                    el3 = time.perf_counter() - t0
+                    kern3, algo3, req3 = kernel_of(Av, False)
+                    ms3 /= max(l3, 1)
+                    tr3, src3 = pmc_traffic("value_stream_spmv", kern3, n, world)
+                    out["value_stream_cg"] = {
+                        "workload": f"poisson3d_{n}^3_csr_fp64_cg_values_streamed",
+                        "iters/s": steps / el3, "steps": steps,
+                        "ms_per_step": el3 / steps * 1e3, "kernel": kern3,
+                        "avg_launch_ms": ms3,
+                        "cg_rel_residual_k10":
+                            float(h3[min(10, len(h3) - 1)] / h3[0])}
+                    out["value_stream_cg"].update(price(ms3, algo3, req3, tr3))
+                    out["value_stream_cg"]["traffic_source"] = src3
+                    out["value_stream_cg"].update(plan_record(Av))
+                    ws3.close()
+                    Av.close()
+                    exec_.free(d_b), exec_.free(d_x)
                 rec = lambda name, *a, **kw: spmv_record(  # noqa: E731
                     exec_, self_comm, host, _lib, *a, record=name, **kw)
                 # a lattice matrix that is NOT symmetric (the generator's skewed

@@ -80,6 +80,10 @@ def test_bench_single_gpu_line():
     assert vs["form"]["sdia"] == 1 and vs["form"]["sdia_const"] == 0
     assert "csr_sym_dia_kernel<double, general order>" in vs["kernel"]
     assert svs["form"]["sdia_const"] == 0 and "atomic-free" in svs["kernel"]
+    vcg = d["value_stream_cg"]
+    assert vcg["form"]["sdia_const"] == 0 and vcg["iters/s"] > 0
+    assert "csr_sym_dia_kernel<double, general order>" in vcg["kernel"]
+    assert abs(vcg["cg_rel_residual_k10"] / d["cg_rel_residual"]["k10"] - 1) < 1e-9
     assert d["north_star_spmv"]["form"]["sdia_const"] == 1
     assert d["north_star_value_stream_spmv"]["form"]["sdia_const"] == 0
     lat = d["csr_lattice_spmv"]["form"]

@@ -24,6 +24,10 @@ if "symmetric" in d:
     s = d["symmetric"]
     print("symmetric: %.4f ms frac %.3f it/s %.1f plan %.1f" % (
         s["avg_launch_ms"], s["frac"], s["iters/s"], s["plan_ms"]))
+if "value_stream_cg" in d:
+    s = d["value_stream_cg"]
+    print("values streamed: %.4f ms frac %.3f it/s %.1f plan %.1f" % (
+        s["avg_launch_ms"], s["frac"], s["iters/s"], s["plan_ms"]))
 if "mixed_precision_cg" in d:
     print("mixed speedup", d["mixed_precision_cg"]["speedup"])
 if "cpu_baseline" in d:
