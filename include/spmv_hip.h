@@ -259,6 +259,12 @@ int spmv_hip_zwalk_table(int32_t num_rows, int64_t plane_rows, int grid,
  *   "slat" "slat_blocks_per_cu"          symmetric lattice form
  *   "sdia" "sdia_chain" "sdia_nt"        symmetric diagonal form (baked plans):
  *                  on/off, plane chain on/off, non-temporal streams (bit mask)
+ *   "sdia_tile" "sdia_tile_segments" "sdia_tile_blocks_per_cu"   constant
+ *                  diagonals on a 3-D lattice: lattice lines per lane (1, 2,
+ *                  4), its own plane-walk table, workgroups per CU
+ *   "lxw" "lxw_blocks_per_cu"            LX form: the LDS-DMA kernel on/off
+ *   "wdia" "wdia_xcd_group" "wdia_blocks_per_cu" "wdia_zwalk"
+ *   "wdia_zwalk_segments"                wide diagonal form (baked plans)
  *   "zwalk" "zwalk_segments"             plane-walk row-block order of the
  *                  three lattice kernels (every workgroup walks a 256-row
  *                  column of the lattice from plane to plane): use the table;
@@ -273,7 +279,10 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value);
  * the matrix is a 3-D lattice, else 0), "zwalk", "zwalk_segments",
  * "zwalk_grid", "lat_chain", "sdia_chain", "sdia_nt", "sdia_offsets" (lower
  * offsets of the baked copy), "sdia_general" (baked from a general matrix: 1 = symmetric, half stored; 2 =
- * full form), "sdia_mixed" (fp32 copy);
+ * full form), "sdia_mixed" (fp32 copy), "sdia_const" (constant diagonals: no
+ * values kept), "sdia_tile" (lines per lane in use), "sdia_tile_walk"; "lxw";
+ * "wdia", "wdia_offsets", "wdia_half", "wdia_const", "wdia_mixed", "wdia_d2",
+ * "wdia_zwalk", "wdia_zwalk_segments";
  * "blocks_per_cu", "nontemporal"; "plan_us" (wall time of plan creation, its
  * analysis kernels included) and "plan_kib" (device memory the plan owns). */
 int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,

@@ -2638,3 +2638,102 @@ def test_diagonal_form_fuzz(lat_ctx):
         dx.free()
         done += 1
     assert done >= 0.75 * trials
+
+
+def test_constant_diagonals_fuzz():
+    """Random offset sets (1-3 lower offsets anywhere between 1 and the matrix
+    size: lines shorter than a wave, lines longer than the matrix, planes that
+    are no whole number of lines), random holes, random constants, symmetric
+    and skewed, sizes around the row-block boundaries -- through the
+    constant-diagonal kernels with 1, 2 and 4 lines per lane, plain and forced
+    plane-walk orders, both storages: bit-exact against the oracle's loops."""
+    ctx = hip.Context(0)
+    ctx.set_option("lat_min_nnz", 0)
+    ctx.set_option("lx_min_nnz", 0)
+    rng = np.random.default_rng(int(os.environ.get("SPMV_FUZZ_SEED", "4711")))
+    trials = int(os.environ.get("SPMV_FUZZ_TRIALS", "60"))
+    sizes = [1, 2, 255, 256, 257, 511, 512, 513, 1000, 4096, 5000, 20000, 65536, 70001]
+    done = tiled = 0
+    for trial in range(trials):
+        N = int(sizes[trial % len(sizes)] if trial < 28 else rng.integers(300, 60000))
+        nd = int(rng.integers(1, 4)) if trial % 3 else 3
+        pool = [1, 2, 3, 4, 5, 63, 64, 65, 255, 256, 257, 512, 768, 1024, 2048, 4096]
+        pool += [int(v) for v in rng.integers(1, max(2, N), 6)]
+        lows = sorted({int(o) for o in rng.choice(pool, nd) if o < N}, reverse=True)
+        if not lows:
+            continue
+        symmetric = bool(trial % 2)
+        offs = [-u for u in lows] + [0] + [u for u in reversed(lows)]
+        cl = list(rng.uniform(-2, 2, len(lows)))
+        cu = list(reversed(cl)) if symmetric else list(rng.uniform(-2, 2, len(lows)))
+        consts = cl + [float(rng.uniform(3, 9))] + cu
+        drop = float(rng.choice([0.0, 0.0, 0.3]))
+        rp, ci, va = _const_diag_csr(rng, N, offs, consts, drop=drop)
+        if len(va) == 0:
+            continue
+        rows = np.repeat(np.arange(N), np.diff(rp))
+        have = sorted(set(np.abs(ci - rows)) - {0})
+        x = rng.uniform(-1, 1, N)
+        y0 = rng.uniform(-1, 1, N)
+        alpha, beta = (1.0, 0.0) if trial % 4 < 2 else (-1.5, 0.5)
+        blk = hip.CsrBlock(ctx, N, N, rp, ci, va, None, False, hip.ALGO_ROWBLOCK)
+        if not have:
+            blk.free()
+            continue
+        blk.bake()
+        tag = (trial, N, lows, drop, symmetric)
+        assert blk.get("sdia") == 1 and blk.get("sdia_const") == 1, tag
+        three = blk.get("sdia_offsets") == 3
+        dx = ctx.upload(x)
+        part = ctx.empty(ctx.dot_partials_len, np.float64)
+        y_ref = oracle.csr_spmv(rp, ci, va, x, alpha, beta, y0)
+        knob_sets = [dict(), dict(zwalk_segments=int(rng.integers(0, 4))),
+                     dict(slat_blocks_per_cu=int(rng.integers(1, 5)))]
+        if three:
+            tiled += 1
+            knob_sets += [dict(sdia_tile=1), dict(sdia_tile=2),
+                          dict(sdia_tile=4, sdia_tile_blocks_per_cu=int(
+                              rng.integers(1, 9))),
+                          dict(sdia_tile=int(rng.choice([2, 4])), sdia_chain=int(
+                              rng.integers(0, 2)))]
+        for knobs in knob_sets:
+            for k, v in knobs.items():
+                blk.set(k, v)
+            if three and "sdia_tile" in knobs and knobs["sdia_tile"] > 1 \
+                    and rng.random() < 0.5:
+                blk.set("sdia_tile_segments", int(rng.integers(0, 4)))
+            dy = ctx.upload(np.full(N, np.nan) if beta == 0 else y0)
+            blk.mult(alpha, dx.ptr, beta, dy.ptr,
+                     dot_partials=part.ptr if beta == 0 else None)
+            assert np.array_equal(dy.numpy(), y_ref), (tag, knobs)
+            if beta == 0:
+                want = float(np.dot(x, y_ref))
+                got = float(np.sum(part.numpy()))
+                assert abs(got - want) <= 1e-12 * (np.abs(x) @ np.abs(y_ref) + 1e-300)
+            dy.free()
+        blk.free()
+        # symmetric storage of the same matrix (needs the whole diagonal and
+        # equal constants above and below)
+        if symmetric and drop == 0.0:
+            lrp, lci, lva, dg = lower_split(rp, ci, va)
+            if len(lva):
+                sb = hip.CsrBlock(ctx, N, N, lrp, lci, lva, dg, True)
+                if sb.get("slat") == 1:
+                    sb.bake()
+                    assert sb.get("sdia_const") == 1, tag
+                    ys = oracle.csr_spmv_sym(lrp, lci, lva, dg, x, alpha, beta, y0)
+                    ks = [dict(), dict(zwalk_segments=int(rng.integers(0, 4)))]
+                    if sb.get("sdia_offsets") == 3:
+                        ks += [dict(sdia_tile=1), dict(sdia_tile=2), dict(sdia_tile=4)]
+                    for knobs in ks:
+                        for k, v in knobs.items():
+                            sb.set(k, v)
+                        dy = ctx.upload(np.full(N, np.nan) if beta == 0 else y0)
+                        sb.mult(alpha, dx.ptr, beta, dy.ptr)
+                        assert np.array_equal(dy.numpy(), ys), (tag, "sym", knobs)
+                        dy.free()
+                sb.free()
+        dx.free(), part.free()
+        done += 1
+    assert done >= 0.7 * trials and tiled >= 10
+    ctx.close()
