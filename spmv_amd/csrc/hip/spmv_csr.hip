@@ -543,8 +543,11 @@ __global__ __launch_bounds__(kBlock) void lx_build_kernel(
           wr[kLxwPieces0 + np++] = c;
       wr[0] = total_windows;
       wr[3] = np; // = s_wo[total_windows] / kLxwPiece <= cap / kLxwPiece
-      atomicMax(&stat[0], cnt);
-      atomicMax(&stat[1], np);
+      // (read first: an atomic per row block on one address is milliseconds)
+      if (cnt > *(volatile int*)&stat[0])
+        atomicMax(&stat[0], cnt);
+      if (np > *(volatile int*)&stat[1])
+        atomicMax(&stat[1], np);
     }
   }
 }

@@ -395,6 +395,9 @@ __global__ __launch_bounds__(kBlock) void lat_build_kernel(
   const int t = threadIdx.x;
   constexpr int64_t kAlign = 4; // widest 16-byte chunk (fp32): entries
   constexpr int64_t kSlotEntries = kLatSlotBytes / 8;
+  int ok_mine = 0; // thread 0: row blocks this workgroup found in the form (one
+                   // atomic per workgroup: half a million on one address took
+                   // 4 of the kernel's 7 ms at 512^3)
   for (int rb = blockIdx.x; rb < num_row_blocks; rb += gridDim.x) {
     const int32_t r0 = rb * kRows;
     const int nr = min(kRows, num_rows - r0);
@@ -485,11 +488,13 @@ __global__ __launch_bounds__(kBlock) void lat_build_kernel(
       rec[2] = c1 | (c2 << 16); // <= 2176 each (slot check above)
       rec[3] = c3;
       if (!fail)
-        atomicAdd(ok_count, 1);
+        ++ok_mine;
     }
     if (t < kLatMaxOff)
       rec[4 + t] = t < nd ? s_D[t] : 0;
   }
+  if (t == 0 && ok_mine)
+    atomicAdd(ok_count, ok_mine);
 }
 
 template <typename TV, typename T, bool DOT>
