@@ -299,6 +299,15 @@ def kernel_of(A, symmetric):
         return ("csr_sym_window_kernel<double> (LDS window + global atomics)",
                 algo, algo)
     algo = nnz * 12 + (rows + 1) * 4 + y_x  # SURVEY 8d B_csr
+    if A.plan_get("wdia") and A.plan_get("wdia_const") and A.plan_get("wdia_box"):
+        R = A.plan_get("wdia_box")
+        return (f"csr_box27_const_kernel<double, {R} lattice lines per lane> (a "
+                "27-point box stencil whose diagonals are constant bit for bit: "
+                "the plan keeps 27 numbers and a 32-bit presence mask per row, no "
+                "values are streamed; a lane keeps the lines around its rows in "
+                "registers and hands them on from plane to plane; rows summed in "
+                "the CSR kernel's order: bit-exact; fused p.Ap)",
+                algo, rows * 4 + y_x)
     if A.plan_get("wdia") and A.plan_get("wdia_const"):
         K = A.plan_get("wdia_offsets")
         return (f"csr_wdia_kernel<double, constant> (wide diagonal form: the "
@@ -514,13 +523,21 @@ def mixed_precision_record(exec_, comm, host, _lib, n, rtol=1e-10, kmax=6000):
     import numpy as np
     N = n ** 3
     ctx = exec_.context
-    # both legs on the plan's default kernel, the diagonal form: fp64 copy of
-    # the values against the fp32 copy (33 against 17 B of matrix data per row)
-    A = host.Matrix.create_poisson3d(comm, exec_, n, False, host.P2P_NONBLOCKING)
+    # both legs on the diagonal form WITH its values streamed (constant-diagonal
+    # detection off -- with it no matrix value is read in either precision and
+    # there is nothing for fp32 to save): fp64 copy of the values against the
+    # fp32 copy (33 against 17 B of matrix data per row)
+    _lib.call("spmv_hip_ctx_set_option", ctx, b"const_diagonals", 0)
+    try:
+        A = host.Matrix.create_poisson3d(comm, exec_, n, False,
+                                         host.P2P_NONBLOCKING)
+    finally:
+        _lib.call("spmv_hip_ctx_set_option", ctx, b"const_diagonals", 1)
     d_b, d_x = exec_.alloc(N), exec_.alloc(N)
     _lib.call("spmv_hip_fill_gaussian_f64", ctx, N, 0, N, d_b, None)
     ws = host.CgWorkspace(exec_)
-    rec = {"workload": f"poisson3d_{n}^3_csr_cg_to_{rtol:g}", "rows": N}
+    rec = {"workload": f"poisson3d_{n}^3_csr_cg_to_{rtol:g}_values_streamed",
+           "rows": N}
     sols = {}
     for name in ("fp64", "mixed"):
         for rep in range(2):  # first pass: warm-up (fp32 copy, workspace)

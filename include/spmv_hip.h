@@ -265,6 +265,9 @@ int spmv_hip_zwalk_table(int32_t num_rows, int64_t plane_rows, int grid,
  *   "lxw" "lxw_blocks_per_cu"            LX form: the LDS-DMA kernel on/off
  *   "wdia" "wdia_xcd_group" "wdia_blocks_per_cu" "wdia_zwalk"
  *   "wdia_zwalk_segments"                wide diagonal form (baked plans)
+ *   "wdia_box" "wdia_box_segments" "wdia_box_blocks_per_cu"   constant
+ *                  27-point box stencils: lattice lines per lane (0 = the
+ *                  general kernel, 2, 4), its plane-walk table, workgroups/CU
  *   "zwalk" "zwalk_segments"             plane-walk row-block order of the
  *                  three lattice kernels (every workgroup walks a 256-row
  *                  column of the lattice from plane to plane): use the table;
@@ -281,7 +284,7 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value);
  * offsets of the baked copy), "sdia_general" (baked from a general matrix: 1 = symmetric, half stored; 2 =
  * full form), "sdia_mixed" (fp32 copy), "sdia_const" (constant diagonals: no
  * values kept), "sdia_tile" (lines per lane in use), "sdia_tile_walk"; "lxw";
- * "wdia", "wdia_offsets", "wdia_half", "wdia_const", "wdia_mixed", "wdia_d2",
+ * "wdia", "wdia_offsets", "wdia_half", "wdia_const", "wdia_box", "wdia_mixed", "wdia_d2",
  * "wdia_zwalk", "wdia_zwalk_segments";
  * "blocks_per_cu", "nontemporal"; "plan_us" (wall time of plan creation, its
  * analysis kernels included) and "plan_kib" (device memory the plan owns). */

@@ -260,6 +260,13 @@ struct spmv_hip_csr_plan {
   int wdia_const = 0;               // constant diagonals: no arrays, one number
   double wdia_cval[kWdiaMaxOff] = {};   // per offset (wdia_val is a marker)
   double wdia32_cval[kWdiaMaxOff] = {}; // ... of the mixed SpMV's fp32 values
+  // ... a constant 27-point box stencil: R lattice lines per lane
+  // (csr_box27_const_kernel), with its own plane-walk table
+  int wdia_box = 0; // R in use (0: the general kernel)
+  int wdia_box_P = 0, wdia_box_L = 0;
+  int wdia_box_blocks_per_cu = 8;
+  int32_t* wdia_box_table = nullptr;
+  int wdia_box_slots = 0, wdia_box_grid = 0, wdia_box_segments = 0;
   // its own plane-walk table (the offsets' widest cluster = the plane distance;
   // the half form reads the plane ahead and finds it in the L2 one step later)
   int32_t* wdia_zw_table = nullptr;
@@ -415,6 +422,7 @@ int spmv_lxw_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st,
 // spmv_wdia.hip
 void spmv_wdia_free(spmv_hip_csr_plan* pl);
 int spmv_wdia_walk_build(spmv_hip_csr_plan* pl, int segments, bool force);
+int spmv_wdia_box_build(spmv_hip_csr_plan* pl, int R, int segments, bool force);
 int spmv_wdia_bake_f64(spmv_hip_csr_plan* pl, const double* values,
                        hipStream_t st); // values == nullptr: drop the copy
 int spmv_wdia_bake_f32(spmv_hip_csr_plan* pl, const float* values,

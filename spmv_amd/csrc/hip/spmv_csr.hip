@@ -1541,6 +1541,20 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
   } else if (!strcmp(key, "wdia")) {
     SPMV_REQUIRE(value == 0 || plan->wdia_val);
     plan->wdia = value != 0;
+  } else if (!strcmp(key, "wdia_box")) {
+    // lines per lane of the constant 27-point box kernel (0 = general kernel)
+    SPMV_REQUIRE((value == 0 || value == 2 || value == 4) && plan->wdia_val
+                 && plan->wdia_const);
+    return spmv_wdia_box_build(plan, value, 0, false);
+  } else if (!strcmp(key, "wdia_box_segments")) {
+    SPMV_REQUIRE(value >= 0 && plan->wdia_box > 1);
+    return spmv_wdia_box_build(plan, plan->wdia_box, value, true);
+  } else if (!strcmp(key, "wdia_box_blocks_per_cu")) {
+    SPMV_REQUIRE(value >= 1 && value <= kBlocksPerCU);
+    plan->wdia_box_blocks_per_cu = value;
+    if (plan->wdia_box > 1)
+      return spmv_wdia_box_build(plan, plan->wdia_box, 0,
+                                 plan->wdia_box_table != nullptr);
   } else if (!strcmp(key, "wdia_blocks_per_cu")) {
     SPMV_REQUIRE(value >= 1 && value <= kBlocksPerCU);
     plan->wdia_blocks_per_cu = value;
@@ -1689,6 +1703,8 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
     *value = plan->wdia_zw_table ? plan->wdia_zw_segments : 0;
   else if (!strcmp(key, "wdia_d2"))
     *value = plan->wdia_val ? plan->wdia_d2 : 0;
+  else if (!strcmp(key, "wdia_box"))
+    *value = plan->wdia_val ? plan->wdia_box : 0;
   else if (!strcmp(key, "wdia_const"))
     *value = plan->wdia_val ? plan->wdia_const : 0;
   else if (!strcmp(key, "wdia_half"))

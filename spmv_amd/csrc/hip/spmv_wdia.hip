@@ -127,6 +127,173 @@ __global__ __launch_bounds__(kBlock) void csr_wdia_kernel(
     spmv_dot_epilogue(dot, dot_acc, s_red);
 }
 
+// ---------------------------------------------------------------------------
+// Constant 27-point BOX stencils (offsets a P + b L + c, a, b, c in -1..1: P the
+// plane and L the line distance; HPCG's operator), R lattice lines per lane.
+// The kernel above asks the L2 for nine line sets of x per row block (three
+// lines in each of three planes; the loads at c = -+1 hit the L1) and, like
+// every kernel here, is bound by the requests a CU keeps in flight: 256^3 in
+// 0.29 ms although only 0.4 GB cross the fabric.  Here a lane owns R rows one
+// line apart and keeps, per plane, the R + 2 lines around them in registers
+// (x at c = -1, 0, +1 each); walking from plane to plane it loads ONE plane of
+// (R + 2) x 3 values per step and hands the other two on: (R + 2) / R line sets
+// per row block instead of 9.  Index space and plane-walk table are those of
+// csr_const_dia_tile_kernel (spmv_symdia.hip): work item j = tuple * L +
+// position stands for the rows (tuple * R + r) * L + position.
+// Rows are summed in ascending column order = (a, b, c) lexicographic, a term
+// only where the row's mask has it: the bits of csr_kernels.cpp:41-51.
+// ---------------------------------------------------------------------------
+struct BoxGeom {
+  int P, L;         // plane and line distance (rows)
+  int64_t NJ;       // work items
+  int chain_blocks; // blocks of j-space per plane when whole, else 0
+  double rcp_l;
+};
+
+template <typename T, bool DOT, bool TAB, int R>
+__global__ __launch_bounds__(kBlock) void csr_box27_const_kernel(
+    int32_t num_rows, const uint32_t* __restrict__ mask, T alpha,
+    const T* __restrict__ in, T beta, T* __restrict__ out, DotOut dot,
+    RowBlockOrder ord, BoxGeom g, WdiaConsts cv)
+{
+  __shared__ double s_red[kBlock / 64];
+  const int t = threadIdx.x;
+  const int stride = gridDim.x;
+  const int num_slots = order_slots(ord);
+  const int64_t last = (int64_t)num_rows - 1;
+  double dot_acc = 0.0;
+  // X[a][b][c]: x at plane a - 1, line b - 1 (relative to the lane's first
+  // row), column offset c - 1
+  T X[3][R + 2][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < R + 2; ++b)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        X[a][b][c] = T(0);
+  auto at = [&](int64_t col) { // clamped: what a row does not have is not used
+    return in[col < 0 ? 0 : (col > last ? last : col)];
+  };
+  auto load_plane = [&](int a, int64_t i0) {
+#pragma unroll
+    for (int b = 0; b < R + 2; ++b) {
+      const int64_t base = i0 + (int64_t)(a - 1) * g.P + (int64_t)(b - 1) * g.L;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        X[a][b][c] = at(base + (c - 1));
+    }
+  };
+  int it = blockIdx.x;
+  int cur = order_slot_decode(ord, order_slot_raw_t<TAB>(ord, it, num_slots));
+  int nxt_raw = order_slot_raw_t<TAB>(ord, it + stride, num_slots);
+  int prev = -1; // block of the step before (its planes are in X when chained)
+  while (it < num_slots) {
+    const int nxt = order_slot_decode(ord, nxt_raw);
+    nxt_raw = order_slot_raw_t<TAB>(ord, it + 2 * stride, num_slots);
+    if (cur >= 0) { // uniform
+      const bool chain = g.chain_blocks > 0 && prev >= 0
+                         && cur - prev == g.chain_blocks;
+      const int64_t j = (int64_t)cur * kRows + t;
+      // tuple and position: j / L by reciprocal, one step of correction
+      int64_t tup = (int64_t)((double)j * g.rcp_l);
+      int64_t pos = j - tup * g.L;
+      if (pos < 0) {
+        --tup;
+        pos += g.L;
+      } else if (pos >= g.L) {
+        ++tup;
+        pos -= g.L;
+      }
+      const int64_t i0 = tup * R * g.L + pos;
+      const bool live = j < g.NJ && i0 <= last;
+      uint32_t m[R];
+      T y0[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int64_t i = i0 + (int64_t)r * g.L;
+        m[r] = live && i <= last ? mask[i] : 0u;
+        y0[r] = T(0);
+        if (beta != T(0) && live && i <= last)
+          y0[r] = out[i];
+      }
+      if (live) {
+        if (!chain) { // uniform: a jump of the walk -- all three planes
+          load_plane(0, i0);
+          load_plane(1, i0);
+        }
+        load_plane(2, i0);
+      }
+      // waves whose rows all have all 27 entries (everything but the faces of
+      // the grid): the same sums without the tests -- the kernel is bound by
+      // its instructions now
+      bool full = live;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        full = full && m[r] == 0x7ffffffu;
+      if (__all(full)) { // uniform
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int64_t i = i0 + (int64_t)r * g.L;
+          T sum = 0;
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+              for (int c = 0; c < 3; ++c)
+                sum += (T)cv.c[9 * a + 3 * b + c] * X[a][r + b][c];
+          const T cy = alpha * sum;
+          T y = cy;
+          if (beta != T(0))
+            y = cy + beta * y0[r];
+          out[i] = y;
+          if constexpr (DOT)
+            dot_acc += (double)X[1][r + 1][1] * (double)cy;
+        }
+      } else
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int64_t i = i0 + (int64_t)r * g.L;
+        if (live && i <= last) {
+          T sum = 0; // csr_kernels.cpp:45
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                const int k = 9 * a + 3 * b + c;
+                if ((m[r] >> k) & 1u) // :46-47, ascending column
+                  sum += (T)cv.c[k] * X[a][r + b][c];
+              }
+          const T cy = alpha * sum; // :49
+          T y = cy;
+          if (beta != T(0))
+            y = cy + beta * y0[r];
+          out[i] = y;
+          if constexpr (DOT)
+            dot_acc += (double)X[1][r + 1][1] * (double)cy;
+        }
+      }
+      // hand the planes on: what was the plane ahead is the row's own plane
+      // one step later
+#pragma unroll
+      for (int b = 0; b < R + 2; ++b)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          X[0][b][c] = X[1][b][c];
+          X[1][b][c] = X[2][b][c];
+        }
+    }
+    prev = cur;
+    cur = nxt;
+    it += stride;
+  }
+  if constexpr (DOT)
+    spmv_dot_epilogue(dot, dot_acc, s_red);
+}
+
 // pass 1: the set of distinct col - row (capacity kWdiaMaxOff; INT32_MIN =
 // free slot).  Slots are always probed from 0, so a value can only ever sit in
 // one slot (a probe that started anywhere else could insert a second copy
@@ -381,6 +548,10 @@ void wdia_free_arrays(spmv_hip_csr_plan* pl)
   pl->wdia_narr = 0;
   pl->wdia_const = 0;
   pl->wdia = 0;
+  (void)hipFree(pl->wdia_box_table);
+  pl->wdia_box_table = nullptr;
+  pl->wdia_box_slots = pl->wdia_box_grid = pl->wdia_box_segments = 0;
+  pl->wdia_box = 0;
   (void)hipFree(pl->wdia_zw_table);
   pl->wdia_zw_table = nullptr;
   pl->wdia_zw_slots = pl->wdia_zw_grid = pl->wdia_zw_segments = 0;
@@ -602,6 +773,13 @@ int wdia_bake(spmv_hip_csr_plan* pl, const T* values, hipStream_t st)
       return rw;
     }
   }
+  if (is_const) { // a constant 27-point box: several lines per lane
+    const int rb = spmv_wdia_box_build(pl, pl->ctx->const_tile, 0, false);
+    if (rb != SPMV_HIP_OK) {
+      wdia_free_arrays(pl);
+      return rb;
+    }
+  }
   pl->plan_us += (int)std::chrono::duration_cast<std::chrono::microseconds>(
                      std::chrono::steady_clock::now() - t_begin)
                      .count();
@@ -713,6 +891,58 @@ int wdia_bake_mixed(spmv_hip_csr_plan* pl, const float* values32, hipStream_t st
   return SPMV_HIP_OK;
 }
 
+// j-space of the box kernel: work items and launch grid
+int64_t box_items(const spmv_hip_csr_plan* pl, int R)
+{
+  const int64_t l = pl->wdia_box_L;
+  const int64_t lines = ((int64_t)pl->num_rows + l - 1) / l;
+  return ((lines + R - 1) / R) * l;
+}
+
+int box_grid(const spmv_hip_csr_plan* pl)
+{
+  const int64_t nrb = (box_items(pl, pl->wdia_box) + kRows - 1) / kRows;
+  int64_t grid = (int64_t)pl->ctx->num_cus * pl->wdia_box_blocks_per_cu;
+  if (grid > pl->ctx->dot_blocks)
+    grid = pl->ctx->dot_blocks;
+  if (grid > nrb)
+    grid = nrb;
+  if (grid >= 8)
+    grid -= grid % 8;
+  return grid < 1 ? 1 : (int)grid;
+}
+
+template <typename T, bool DOT, int R>
+int box_launch(const spmv_hip_csr_plan* pl, hipStream_t st, const WdiaConsts& cv,
+               T alpha, const T* in, T beta, T* out, DotOut dot)
+{
+  BoxGeom g;
+  g.P = pl->wdia_box_P;
+  g.L = pl->wdia_box_L;
+  g.NJ = box_items(pl, R);
+  g.rcp_l = 1.0 / (double)g.L;
+  g.chain_blocks = 0;
+  if (g.P % ((int64_t)R * g.L) == 0 && (g.P / R) % kRows == 0)
+    g.chain_blocks = g.P / R / kRows;
+  const int grid = box_grid(pl);
+  const int nrb = (int)((g.NJ + kRows - 1) / kRows);
+  RowBlockOrder ord = pl->row_block_order(nrb);
+  ord.xcd_group = pl->wdia_xcd_group;
+  if (pl->wdia_zwalk && pl->wdia_box_table && pl->wdia_box_grid == grid) {
+    ord.table = pl->wdia_box_table;
+    ord.num_slots = pl->wdia_box_slots;
+    hipLaunchKernelGGL((csr_box27_const_kernel<T, DOT, true, R>), dim3(grid),
+                       dim3(kBlock), 0, st, pl->num_rows, pl->wdia_mask, alpha, in,
+                       beta, out, dot, ord, g, cv);
+  } else {
+    hipLaunchKernelGGL((csr_box27_const_kernel<T, DOT, false, R>), dim3(grid),
+                       dim3(kBlock), 0, st, pl->num_rows, pl->wdia_mask, alpha, in,
+                       beta, out, dot, ord, g, cv);
+  }
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
 template <typename TV, typename T, bool DOT>
 int wdia_launch(const spmv_hip_csr_plan* pl, hipStream_t st, const TV* sval,
                 T alpha, const T* in, T beta, T* out, DotOut dot)
@@ -734,6 +964,11 @@ int wdia_launch(const spmv_hip_csr_plan* pl, hipStream_t st, const TV* sval,
   WdiaConsts cv;
   for (int k = 0; k < kWdiaMaxOff; ++k)
     cv.c[k] = sizeof(TV) == sizeof(T) ? pl->wdia_cval[k] : pl->wdia32_cval[k];
+  if (pl->wdia_const && pl->wdia_box > 1) {
+    if (pl->wdia_box == 2)
+      return box_launch<T, DOT, 2>(pl, st, cv, alpha, in, beta, out, dot);
+    return box_launch<T, DOT, 4>(pl, st, cv, alpha, in, beta, out, dot);
+  }
   if (pl->wdia_const)
     hipLaunchKernelGGL((csr_wdia_kernel<TV, T, DOT, true>), dim3(grid),
                        dim3(kBlock), 0, st, pl->num_rows, pl->num_cols,
@@ -815,4 +1050,43 @@ int spmv_wdia_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st, float alpha,
   return wdia_launch<float, float, false>(
       pl, st, static_cast<const float*>(pl->wdia_val), alpha, in, beta, out,
       DotOut());
+}
+
+// Is the offset set a 27-point box a P + b L + c (a, b, c in -1..1, sorted
+// order = (a, b, c) lexicographic)?  Then (re)build the box kernel's geometry
+// and plane-walk table: R lines per lane (0 or 1 = the general kernel).
+int spmv_wdia_box_build(spmv_hip_csr_plan* pl, int R, int segments, bool force)
+{
+  SPMV_REQUIRE(R == 0 || R == 1 || R == 2 || R == 4);
+  if (pl->wdia_box_table) {
+    SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
+    SPMV_CHECK_HIP(hipDeviceSynchronize()); // no launch still reads the old one
+    (void)hipFree(pl->wdia_box_table);
+    pl->wdia_box_table = nullptr;
+  }
+  pl->wdia_box_slots = pl->wdia_box_grid = pl->wdia_box_segments = 0;
+  pl->wdia_box = 0;
+  if (R <= 1 || !pl->wdia_const || pl->wdia_K != 27
+      || pl->num_rows != pl->num_cols)
+    return SPMV_HIP_OK;
+  const int64_t P = pl->wdia_D[22], L = pl->wdia_D[16];
+  if (L < 3 || P <= 2 * L + 2 || L >= (1 << 23))
+    return SPMV_HIP_OK;
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b)
+      for (int c = 0; c < 3; ++c)
+        if (pl->wdia_D[9 * a + 3 * b + c] != (a - 1) * P + (b - 1) * L + (c - 1))
+          return SPMV_HIP_OK;
+  pl->wdia_box = R;
+  pl->wdia_box_P = (int)P;
+  pl->wdia_box_L = (int)L;
+  if (P % (R * L) != 0)
+    return SPMV_HIP_OK; // planes do not line up in j-space: the plain order
+  const int grid = box_grid(pl);
+  const int rc = spmv_zwalk_table_device(
+      pl, box_items(pl, R), P / R, grid, segments, force, &pl->wdia_box_table,
+      &pl->wdia_box_slots, &pl->wdia_box_segments);
+  if (rc == SPMV_HIP_OK && pl->wdia_box_table)
+    pl->wdia_box_grid = grid;
+  return rc;
 }

@@ -105,7 +105,7 @@ def test_bench_single_gpu_line():
     assert s27["rows"] == 40 ** 3 and s27["nnz_stored"] == (3 * 40 - 2) ** 3
     assert un["rows"] == 200000 and un["nnz_stored"] == 7 * 200000
     s27v = d["stencil27_value_stream_spmv"]
-    assert s27["form"]["wdia_const"] == 1 and "constant" in s27["kernel"]
+    assert s27["form"]["wdia_const"] == 1 and "csr_box27_const_kernel" in s27["kernel"]
     assert s27v["form"]["wdia"] == 1 and s27v["form"]["wdia_const"] == 0
     assert "half" in s27v["kernel"]
     for r in (s27, s27v, un):

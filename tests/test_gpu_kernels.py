@@ -2155,9 +2155,16 @@ def test_wide_diagonal_form_constant_diagonals_bit_exact():
     rng = np.random.default_rng(2707)
     third = 1.0 / 3.0
     cases = []
-    for n in (7, 12, 33):
+    # (n = 16: planes of whole line tuples; n = 32: whole row blocks too, so
+    # the box kernel hands its planes on from step to step)
+    for n in (7, 12, 16, 32, 33):
         rp, ci, va = poisson.stencil27_csr(n)
         cases.append((f"stencil27_{n}", rp, ci.astype(np.int32), va, n ** 3, 27))
+    box = [a * 400 + b * 20 + c for a in (-1, 0, 1) for b in (-1, 0, 1)
+           for c in (-1, 0, 1)]
+    cases.append(("box_holes", *_const_diag_csr(
+        rng, 20 * 20 * 23, box, list(rng.uniform(-2, 2, 27)), drop=0.25),
+        20 * 20 * 23, 27))
     m = 70
     offs9 = [dy * m + dx for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
     cases.append(("nine_point_2d", *_const_diag_csr(
@@ -2181,7 +2188,11 @@ def test_wide_diagonal_form_constant_diagonals_bit_exact():
             assert blk.get("wdia") == 1 and blk.get("wdia_offsets") == K, tag
             assert blk.get("wdia_const") == (1 if variant == "const" else 0), tag
             if variant == "const":
-                assert blk.get("plan_kib") - kib0 <= 4 * N // 1024 + 2 + 64, tag
+                assert blk.get("plan_kib") - kib0 <= 4 * N // 1024 + 2 + 64 \
+                    + 4 * blk.get("zwalk_grid") + 64, tag
+            # the 27-point boxes take the box kernel (4 lines per lane)
+            is_box = variant == "const" and K == 27
+            assert blk.get("wdia_box") == (4 if is_box else 0), tag
             dx = ctx.upload(x)
             part = ctx.empty(ctx.dot_partials_len, np.float64)
             for alpha, beta in ((1.0, 0.0), (-0.5, 0.0), (2.0, 1.0), (1.0, -0.25)):
@@ -2190,7 +2201,16 @@ def test_wide_diagonal_form_constant_diagonals_bit_exact():
                               dict(wdia=1, wdia_xcd_group=4),
                               dict(wdia_zwalk_segments=0),
                               dict(wdia_zwalk_segments=3, wdia_blocks_per_cu=2),
-                              dict(wdia_zwalk=0), dict(wdia_zwalk=1)):
+                              dict(wdia_zwalk=0), dict(wdia_zwalk=1),
+                              dict(wdia_box=0), dict(wdia_box=2),
+                              dict(wdia_box=2, wdia_box_segments=3),
+                              dict(wdia_box=4, wdia_box_segments=0),
+                              dict(wdia_box=4, wdia_box_blocks_per_cu=1,
+                                   wdia_zwalk=0),
+                              dict(wdia_box=4, wdia_box_blocks_per_cu=8,
+                                   wdia_zwalk=1)):
+                    if any(k.startswith("wdia_box") for k in knobs) and not is_box:
+                        continue
                     for k, v in knobs.items():
                         blk.set(k, v)
                     dy = ctx.upload(np.full(N, np.nan) if beta == 0 else y0)
