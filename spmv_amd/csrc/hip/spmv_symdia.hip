@@ -485,7 +485,8 @@ __global__ __launch_bounds__(kBlock) void csr_const_dia_kernel(
 // for three new line sets of x per row block (the plane ahead and both
 // neighbour lines; own row and the plane behind are handed on by the chain) and
 // it is the number of those requests, not the bytes behind them, that bounds
-// it (PMC: 36 M requests per launch at 512^3, 57 in flight per CU on average,
+// it (PMC: 36 M requests per launch at 512^3, 57 in flight per CU on average
+// whatever the prefetch depth,
 // 1.8 GB through the fabric in 0.79 ms).  Here a lane owns R rows one LINE
 // apart -- rows i0, i0 + U1, ..., i0 + (R-1) U1 with U1 the middle offset -- so
 // the neighbour lines of the inner rows are the lane's own registers and only
