@@ -515,6 +515,9 @@ __global__ __launch_bounds__(kBlock) void csr_const_dia_kernel(
 struct SdiaTileGeom {
   int U0, U1, U2;     // row distances, descending (nd = 3)
   int64_t NJ;         // work items
+  int block;          // work items per workgroup and step: 256, or the largest
+                      // divisor of a plane's items in 192..256 (216^3: 243) so
+                      // that planes are whole blocks and the chain applies
   int chain_blocks;   // blocks of j-space per plane when whole, else 0
   int nt_store;
   double rcp_u1;
@@ -542,9 +545,9 @@ __device__ __forceinline__ SdiaTileRegs<T, R> sdia_tile_loads(
     q.cm[r] = 0;
     q.xi[r] = q.xl0[r] = q.xu0[r] = q.xl2[r] = q.xu2[r] = q.y0[r] = T(0);
   }
-  if (jb < 0)
+  if (jb < 0 || t >= g.block)
     return q;
-  const int64_t j = (int64_t)jb * kRows + t;
+  const int64_t j = (int64_t)jb * g.block + t;
   if (j >= g.NJ)
     return q;
   // tuple and position: j / U1 by reciprocal, one step of correction
@@ -1048,9 +1051,23 @@ int64_t sdia_tile_items(const spmv_hip_csr_plan* pl, int R)
   return ((lines + R - 1) / R) * u1;
 }
 
+// work items per workgroup and step (see SdiaTileGeom::block)
+int sdia_tile_block(const spmv_hip_csr_plan* pl, int R)
+{
+  const int64_t u0 = pl->sdia_U[0], u1 = pl->sdia_U[1];
+  if (u0 % ((int64_t)R * u1) != 0)
+    return kRows;
+  const int64_t plane = u0 / R;
+  for (int b = kRows; b >= 192; --b)
+    if (plane % b == 0)
+      return b;
+  return kRows;
+}
+
 int sdia_tile_grid(const spmv_hip_csr_plan* pl)
 {
-  const int64_t nrb = (sdia_tile_items(pl, pl->sdia_tile) + kRows - 1) / kRows;
+  const int block = sdia_tile_block(pl, pl->sdia_tile);
+  const int64_t nrb = (sdia_tile_items(pl, pl->sdia_tile) + block - 1) / block;
   int64_t grid = (int64_t)pl->ctx->num_cus * pl->sdia_tile_blocks_per_cu;
   if (grid > pl->ctx->dot_blocks)
     grid = pl->ctx->dot_blocks;
@@ -1073,12 +1090,13 @@ int sdia_tile_launch(const spmv_hip_csr_plan* pl, hipStream_t st,
   g.NJ = sdia_tile_items(pl, R);
   g.rcp_u1 = 1.0 / (double)g.U1;
   g.nt_store = (pl->sdia_nt >> 4) & 1;
+  g.block = sdia_tile_block(pl, R);
   g.chain_blocks = 0;
   if (pl->sdia_chain && g.U0 % ((int64_t)R * g.U1) == 0
-      && (g.U0 / R) % kRows == 0)
-    g.chain_blocks = g.U0 / R / kRows;
+      && (g.U0 / R) % g.block == 0)
+    g.chain_blocks = g.U0 / R / g.block;
   const int grid = sdia_tile_grid(pl);
-  const int nrb = (int)((g.NJ + kRows - 1) / kRows);
+  const int nrb = (int)((g.NJ + g.block - 1) / g.block);
   RowBlockOrder ord = pl->row_block_order(nrb);
   ord.xcd_group = pl->lat_xcd_group;
   if (pl->zwalk && pl->sdia_tile_table && pl->sdia_tile_grid == grid) {
@@ -1684,9 +1702,17 @@ int spmv_sdia_tile_build(spmv_hip_csr_plan* pl, int R, int segments, bool force)
   if (u0 % (R * u1) != 0)
     return SPMV_HIP_OK; // planes do not line up in j-space: the plain order
   const int grid = sdia_tile_grid(pl);
+  // the table builder counts in blocks of 256 rows: hand it the block counts
+  // (blocks of `block` items; a plane is whole blocks or the blocks are 256)
+  const int block = sdia_tile_block(pl, R);
+  const int64_t nblocks = (sdia_tile_items(pl, R) + block - 1) / block;
+  const int64_t plane = u0 / R;
+  const int64_t rows_eq = block == kRows ? sdia_tile_items(pl, R)
+                                         : nblocks * kRows;
+  const int64_t plane_eq = block == kRows ? plane : plane / block * kRows;
   const int rc = spmv_zwalk_table_device(
-      pl, sdia_tile_items(pl, R), u0 / R, grid, segments, force,
-      &pl->sdia_tile_table, &pl->sdia_tile_slots, &pl->sdia_tile_segments);
+      pl, rows_eq, plane_eq, grid, segments, force, &pl->sdia_tile_table,
+      &pl->sdia_tile_slots, &pl->sdia_tile_segments);
   if (rc == SPMV_HIP_OK && pl->sdia_tile_table)
     pl->sdia_tile_grid = grid;
   return rc;

@@ -146,6 +146,9 @@ __global__ __launch_bounds__(kBlock) void csr_wdia_kernel(
 struct BoxGeom {
   int P, L;         // plane and line distance (rows)
   int64_t NJ;       // work items
+  int block;        // work items per workgroup and step: 256, or the largest
+                    // divisor of a plane's items in 192..256, so that planes
+                    // are whole blocks and can be handed on
   int chain_blocks; // blocks of j-space per plane when whole, else 0
   double rcp_l;
 };
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(kBlock) void csr_box27_const_kernel(
     if (cur >= 0) { // uniform
       const bool chain = g.chain_blocks > 0 && prev >= 0
                          && cur - prev == g.chain_blocks;
-      const int64_t j = (int64_t)cur * kRows + t;
+      const int64_t j = (int64_t)cur * g.block + t;
       // tuple and position: j / L by reciprocal, one step of correction
       int64_t tup = (int64_t)((double)j * g.rcp_l);
       int64_t pos = j - tup * g.L;
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(kBlock) void csr_box27_const_kernel(
         pos -= g.L;
       }
       const int64_t i0 = tup * R * g.L + pos;
-      const bool live = j < g.NJ && i0 <= last;
+      const bool live = t < g.block && j < g.NJ && i0 <= last;
       uint32_t m[R];
       T y0[R];
 #pragma unroll
@@ -899,9 +902,22 @@ int64_t box_items(const spmv_hip_csr_plan* pl, int R)
   return ((lines + R - 1) / R) * l;
 }
 
+int box_block(const spmv_hip_csr_plan* pl, int R)
+{
+  const int64_t P = pl->wdia_box_P, L = pl->wdia_box_L;
+  if (P % ((int64_t)R * L) != 0)
+    return kRows;
+  const int64_t plane = P / R;
+  for (int b = kRows; b >= 192; --b)
+    if (plane % b == 0)
+      return b;
+  return kRows;
+}
+
 int box_grid(const spmv_hip_csr_plan* pl)
 {
-  const int64_t nrb = (box_items(pl, pl->wdia_box) + kRows - 1) / kRows;
+  const int block = box_block(pl, pl->wdia_box);
+  const int64_t nrb = (box_items(pl, pl->wdia_box) + block - 1) / block;
   int64_t grid = (int64_t)pl->ctx->num_cus * pl->wdia_box_blocks_per_cu;
   if (grid > pl->ctx->dot_blocks)
     grid = pl->ctx->dot_blocks;
@@ -921,11 +937,12 @@ int box_launch(const spmv_hip_csr_plan* pl, hipStream_t st, const WdiaConsts& cv
   g.L = pl->wdia_box_L;
   g.NJ = box_items(pl, R);
   g.rcp_l = 1.0 / (double)g.L;
+  g.block = box_block(pl, R);
   g.chain_blocks = 0;
-  if (g.P % ((int64_t)R * g.L) == 0 && (g.P / R) % kRows == 0)
-    g.chain_blocks = g.P / R / kRows;
+  if (g.P % ((int64_t)R * g.L) == 0 && (g.P / R) % g.block == 0)
+    g.chain_blocks = g.P / R / g.block;
   const int grid = box_grid(pl);
-  const int nrb = (int)((g.NJ + kRows - 1) / kRows);
+  const int nrb = (int)((g.NJ + g.block - 1) / g.block);
   RowBlockOrder ord = pl->row_block_order(nrb);
   ord.xcd_group = pl->wdia_xcd_group;
   if (pl->wdia_zwalk && pl->wdia_box_table && pl->wdia_box_grid == grid) {
@@ -1083,8 +1100,13 @@ int spmv_wdia_box_build(spmv_hip_csr_plan* pl, int R, int segments, bool force)
   if (P % (R * L) != 0)
     return SPMV_HIP_OK; // planes do not line up in j-space: the plain order
   const int grid = box_grid(pl);
+  // the table builder counts in blocks of 256 rows: hand it the block counts
+  const int block = box_block(pl, R);
+  const int64_t nblocks = (box_items(pl, R) + block - 1) / block;
+  const int64_t rows_eq = block == kRows ? box_items(pl, R) : nblocks * kRows;
+  const int64_t plane_eq = block == kRows ? P / R : P / R / block * kRows;
   const int rc = spmv_zwalk_table_device(
-      pl, box_items(pl, R), P / R, grid, segments, force, &pl->wdia_box_table,
+      pl, rows_eq, plane_eq, grid, segments, force, &pl->wdia_box_table,
       &pl->wdia_box_slots, &pl->wdia_box_segments);
   if (rc == SPMV_HIP_OK && pl->wdia_box_table)
     pl->wdia_box_grid = grid;

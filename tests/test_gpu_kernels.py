@@ -1785,7 +1785,9 @@ def test_constant_diagonals_bit_exact(dtype):
     rng = np.random.default_rng(1207)
     third = 1.0 / 3.0  # not representable: fp32 constants differ from fp64 ones
     cases = []
-    for n in (4, 9, 16, 32, 33):
+    # (n = 28: a plane is 196 / 392 work items of the tile kernel -- it then
+    # works in blocks of 196 so that planes stay whole blocks)
+    for n in (4, 9, 16, 28, 32, 33):
         rp, ci, va = poisson.poisson3d_csr(n)
         cases.append((f"poisson{n}", rp, ci.astype(np.int32), va, n ** 3, True))
     cases.append(("tridiag", *_const_diag_csr(rng, 70001, [-1, 0, 1],
@@ -2157,7 +2159,8 @@ def test_wide_diagonal_form_constant_diagonals_bit_exact():
     cases = []
     # (n = 16: planes of whole line tuples; n = 32: whole row blocks too, so
     # the box kernel hands its planes on from step to step)
-    for n in (7, 12, 16, 32, 33):
+    # ... n = 28: planes of 196 work items -- blocks of 196 instead of 256)
+    for n in (7, 12, 16, 28, 32, 33):
         rp, ci, va = poisson.stencil27_csr(n)
         cases.append((f"stencil27_{n}", rp, ci.astype(np.int32), va, n ** 3, 27))
     box = [a * 400 + b * 20 + c for a in (-1, 0, 1) for b in (-1, 0, 1)
