@@ -514,6 +514,30 @@ int spmv_hip_unstructured_fill_f64(spmv_hip_ctx* ctx, int64_t num_rows,
                                    uint64_t seed, int32_t* rowptr,
                                    int32_t* colind, double* values,
                                    void* stream);
+/* Seeded FEM-like test matrix, generated on the device (not in the reference:
+ * a synthetic input with the row-length distribution and column layout of an
+ * unstructured 3-D mesh matrix in a bandwidth-reducing order -- what
+ * read_petsc_binary_matrix, spmv/read_petsc.cpp:40-228, typically delivers).
+ * Square; short rows of min_len..max_len entries (skewed to the short side) in
+ * three clusters around row - layer, row, row + layer, each within +-jitter
+ * columns; tail_permille / 1000 of the rows are LONG: tail_min..tail_max
+ * entries, one per tail_stride columns around the row.  Columns strictly
+ * ascending, the diagonal always present (= entries of the row + 1, the other
+ * values uniform in [-1, 1)).  fem_count writes the row pointer (num_rows + 1)
+ * and reports the entry count (SPMV_HIP_ERANGE beyond int32); fem_fill writes
+ * colind / values.  The numpy twin is spmv_amd/poisson.py:fem_like_csr. */
+typedef struct spmv_hip_fem_params {
+  int64_t num_rows;
+  int32_t min_len, max_len;
+  int32_t layer, jitter;
+  int32_t tail_permille, tail_min, tail_max, tail_stride;
+  uint64_t seed;
+} spmv_hip_fem_params;
+int spmv_hip_fem_count(spmv_hip_ctx* ctx, const spmv_hip_fem_params* params,
+                       int32_t* rowptr, int64_t* host_nnz, void* stream);
+int spmv_hip_fem_fill_f64(spmv_hip_ctx* ctx, const spmv_hip_fem_params* params,
+                          int64_t num_non_zeros, const int32_t* rowptr,
+                          int32_t* colind, double* values, void* stream);
 /* x_i = exp(-10 (5 (i/N - 1/2))^2), i = i_begin.. (demos/spmv.cpp:63-67) */
 int spmv_hip_fill_gaussian_f64(spmv_hip_ctx* ctx, int64_t N, int64_t i_begin,
                                int64_t count, double* x, void* stream);

@@ -111,6 +111,12 @@ int spmvh_matrix_create_unstructured(spmvh_comm* comm, spmvh_exec* exec,
                                      int64_t nrows, int per_row, int64_t band,
                                      int far_permille, uint64_t seed,
                                      spmvh_matrix** A);
+/* seeded FEM-like test matrix generated on the device (one rank, general
+ * storage; spmv_hip_fem_count / spmv_hip_fem_fill_f64) */
+struct spmv_hip_fem_params; /* include/spmv_hip.h */
+int spmvh_matrix_create_fem_like(spmvh_comm* comm, spmvh_exec* exec,
+                                 const struct spmv_hip_fem_params* params,
+                                 spmvh_matrix** A);
 /* The Poisson matrix on a 3-D block partition (the reference
  * partitions by row slabs only, read_petsc.cpp:20-37): px * py * pz boxes,
  * rank = ix + px (iy + py iz), rank-major global numbering (a box's points are

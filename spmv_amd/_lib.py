@@ -141,6 +141,8 @@ _PROTOS = {
     "spmv_hip_put_destroy": ([vp], C.c_int),
     "spmv_hip_unstructured_fill_f64": ([vp, i64, C.c_int, i64, C.c_int,
                                         C.c_uint64, vp, vp, vp, vp], C.c_int),
+    "spmv_hip_fem_count": ([vp, vp, vp, P(i64), vp], C.c_int),
+    "spmv_hip_fem_fill_f64": ([vp, vp, i64, vp, vp, vp, vp], C.c_int),
     "spmv_hip_fill_gaussian_f64": ([vp, i64, i64, i64, vp, vp], C.c_int),
     "spmv_hip_fill_const_f64": ([vp, i64, f64, vp, vp], C.c_int),
     "spmv_hip_comm_unique_id": ([vp], C.c_int),

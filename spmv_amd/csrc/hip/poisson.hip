@@ -188,6 +188,159 @@ __global__ __launch_bounds__(kBlock) void unstructured_fill_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// Seeded FEM-LIKE test matrix: ragged rows (and optionally a tail of very long
+// ones) in a bandwidth-reducing order -- the shape of an unstructured 3-D mesh
+// matrix after RCM: a row's columns sit in its own level set and the two
+// adjacent ones.  Not in the reference; a synthetic input for the general
+// kernels on what the PETSc reader delivers (read_petsc.cpp:40-228).  The
+// numpy twin (spmv_amd/poisson.py:fem_like_csr) follows this text line by line.
+//
+//   h_row(i) = mix64((i + 1) G + seed);  u = bits 16..31 of h_row
+//   tail row  (tail_permille > 0 and h_row mod 1000 < tail_permille):
+//     n = tail_min + (h_row >> 32) mod (tail_max - tail_min + 1) entries in ONE
+//     window of n * tail_stride columns centred on the row (moved inside the
+//     matrix), one entry per stride-wide slot
+//   short row: n = min_len + (span * ((u^3 + 2^16 u^2) / 2) >> 48),
+//     span = max_len - min_len + 1 (skewed to the short side: mean = min_len +
+//     0.29 span); 3n/10 entries around row - layer, 3n/10 around row + layer,
+//     the rest around the row itself, each cluster in a window of 2 * jitter
+//     columns, one entry per slot of (2 jitter / cluster entries) columns; a
+//     side cluster is dropped when its window leaves the matrix or when the
+//     centre window had to be moved inside the matrix
+//   entry e (global position) in slot k of a window starting at lo, stride s:
+//     column lo + k s + mix64((e + 1) G + seed + 1) mod s -- strictly ascending,
+//     no repeats; the slot that holds the row's own column gets exactly it
+//   values: diagonal = entries of the row + 1, others uniform in [-1, 1) from
+//     mix64((e + 1) G + seed + 2)
+// ---------------------------------------------------------------------------
+struct FemRow {
+  int32_t n[3];   // entries per cluster (lower, centre, upper); tail: centre only
+  int64_t lo[3];  // first column of each cluster's window
+  int32_t s[3];   // slot width
+  int32_t kdiag;  // slot of the centre cluster that holds the diagonal
+};
+
+__host__ __device__ inline FemRow fem_row(const spmv_hip_fem_params& p, int64_t i)
+{
+  constexpr uint64_t kGolden = 0x9E3779B97F4A7C15ull;
+  const uint64_t h = mix64((uint64_t)(i + 1) * kGolden + p.seed);
+  FemRow r;
+  r.n[0] = r.n[2] = 0;
+  r.lo[0] = r.lo[2] = 0;
+  r.s[0] = r.s[2] = 1;
+  const int64_t N = p.num_rows;
+  if (p.tail_permille > 0 && (int)(h % 1000u) < p.tail_permille) {
+    const int32_t n
+        = p.tail_min + (int32_t)((h >> 32) % (uint64_t)(p.tail_max - p.tail_min + 1));
+    const int64_t W = (int64_t)n * p.tail_stride;
+    int64_t lo = i - W / 2;
+    lo = lo < 0 ? 0 : (lo > N - W ? N - W : lo);
+    r.n[1] = n;
+    r.lo[1] = lo;
+    r.s[1] = p.tail_stride;
+  } else {
+    const uint64_t u = (h >> 16) & 0xFFFFu;
+    const uint64_t f = (u * u * u + (u * u << 16)) >> 1; // < 2^48
+    const int32_t n = p.min_len
+                      + (int32_t)(((uint64_t)(p.max_len - p.min_len + 1) * f) >> 48);
+    const int64_t W = 2 * (int64_t)p.jitter;
+    int32_t n0 = (3 * n) / 10, n2 = (3 * n) / 10;
+    const int32_t n1 = n - n0 - n2;
+    // (a centre window moved inside the matrix would reach into the far one)
+    if (i - p.layer - p.jitter < 0 || i + p.jitter > N)
+      n0 = 0;
+    if (i + p.layer + p.jitter > N || i - p.jitter < 0)
+      n2 = 0;
+    int64_t lo1 = i - p.jitter;
+    lo1 = lo1 < 0 ? 0 : (lo1 > N - W ? N - W : lo1);
+    r.n[0] = n0;
+    r.n[1] = n1;
+    r.n[2] = n2;
+    r.lo[0] = i - p.layer - p.jitter;
+    r.lo[1] = lo1;
+    r.lo[2] = i + p.layer - p.jitter;
+    r.s[0] = n0 ? (int32_t)(W / n0) : 1;
+    r.s[1] = (int32_t)(W / n1);
+    r.s[2] = n2 ? (int32_t)(W / n2) : 1;
+  }
+  const int64_t kd = (i - r.lo[1]) / r.s[1];
+  r.kdiag = (int32_t)(kd < r.n[1] - 1 ? kd : r.n[1] - 1);
+  return r;
+}
+
+__global__ __launch_bounds__(kBlock) void fem_count_kernel(spmv_hip_fem_params p,
+                                                           int32_t* __restrict__ rowptr)
+{
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+       i <= p.num_rows; i += (int64_t)gridDim.x * blockDim.x) {
+    int32_t n = 0;
+    if (i < p.num_rows) {
+      const FemRow r = fem_row(p, i);
+      n = r.n[0] + r.n[1] + r.n[2];
+    }
+    rowptr[i] = n;
+  }
+}
+
+// one lane per ENTRY (rows differ in length by three orders of magnitude): the
+// row of entry e is found by bisection of the row pointer
+__global__ __launch_bounds__(kBlock) void fem_fill_kernel(
+    spmv_hip_fem_params p, int64_t nnz, const int32_t* __restrict__ rowptr,
+    int32_t* __restrict__ colind, double* __restrict__ values)
+{
+  constexpr uint64_t kGolden = 0x9E3779B97F4A7C15ull;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    int64_t lo = 0, hi = p.num_rows; // last row with rowptr[row] <= e
+    while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)rowptr[mid] <= e)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    const int64_t i = lo;
+    const FemRow r = fem_row(p, i);
+    int32_t k = (int32_t)(e - rowptr[i]);
+    int c = 0;
+    while (k >= r.n[c]) {
+      k -= r.n[c];
+      ++c;
+    }
+    const uint64_t h1 = mix64((uint64_t)(e + 1) * kGolden + p.seed + 1);
+    const uint64_t h2 = mix64((uint64_t)(e + 1) * kGolden + p.seed + 2);
+    int64_t col = r.lo[c] + (int64_t)k * r.s[c] + (int64_t)(h1 % (uint64_t)r.s[c]);
+    double v = (double)(h2 >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+    if (c == 1 && k == r.kdiag) {
+      col = i;
+      v = (double)(r.n[0] + r.n[1] + r.n[2]) + 1.0;
+    }
+    colind[e] = (int32_t)col;
+    values[e] = v;
+  }
+}
+
+struct ToI64 {
+  __host__ __device__ int64_t operator()(int32_t v) const { return v; }
+};
+
+int fem_params_ok(const spmv_hip_fem_params& p)
+{
+  SPMV_REQUIRE(p.num_rows >= 1 && p.num_rows <= INT32_MAX);
+  SPMV_REQUIRE(p.min_len >= 1 && p.max_len >= p.min_len && p.max_len <= 1024);
+  SPMV_REQUIRE(p.jitter >= 1 && p.layer >= 2 * p.jitter
+               && 2 * (int64_t)p.jitter <= p.num_rows);
+  // every cluster gets at least one column per entry
+  SPMV_REQUIRE(p.max_len <= 2 * p.jitter);
+  SPMV_REQUIRE(p.tail_permille >= 0 && p.tail_permille <= 1000);
+  if (p.tail_permille > 0)
+    SPMV_REQUIRE(p.tail_min >= 1 && p.tail_max >= p.tail_min
+                 && p.tail_stride >= 1
+                 && (int64_t)p.tail_max * p.tail_stride <= p.num_rows);
+  return SPMV_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------
 // The 7-point matrix on ONE BOX of a 3-D block partition (SURVEY 8f n4;
 // Matrix::create_poisson3d_boxes): rows = the box's points, x fastest, in the
 // rank-major global numbering (a rank's points are consecutive), so owned
@@ -447,6 +600,82 @@ int spmv_hip_unstructured_fill_f64(spmv_hip_ctx* ctx, int64_t num_rows,
   hipLaunchKernelGGL(unstructured_fill_kernel, dim3(grid), dim3(kBlock), 0,
                      spmv_stream(ctx, stream), num_rows, per_row, band,
                      far_permille, seed, rowptr, colind, values);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_fem_count(spmv_hip_ctx* ctx, const spmv_hip_fem_params* params,
+                       int32_t* rowptr, int64_t* host_nnz, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(params && rowptr && host_nnz);
+  const spmv_hip_fem_params p = *params;
+  int rc = fem_params_ok(p);
+  if (rc)
+    return rc;
+  hipStream_t st = spmv_stream(ctx, stream);
+  const int grid = spmv_grid_for(ctx, p.num_rows + 1, kBlock);
+  hipLaunchKernelGGL(fem_count_kernel, dim3(grid), dim3(kBlock), 0, st, p,
+                     rowptr);
+  SPMV_CHECK_LAUNCH();
+  // the lengths are summed in 64 bits first: the row pointer of the format is
+  // int32 (csr_kernels.h:28) and a tail of long rows can exceed it
+  int64_t* d_total = nullptr;
+  void* tmp = nullptr;
+  size_t tmp_bytes = 0, tb2 = 0;
+  const int n1 = (int)(p.num_rows + 1);
+  SPMV_CHECK_HIP(hipMalloc(&d_total, sizeof(int64_t)));
+  hipError_t e = hipcub::DeviceReduce::Sum(
+      nullptr, tmp_bytes,
+      hipcub::TransformInputIterator<int64_t, ToI64, const int32_t*>(rowptr,
+                                                                     ToI64()),
+      d_total, n1, st);
+  if (e == hipSuccess)
+    e = hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, rowptr, rowptr, n1, st);
+  if (tb2 > tmp_bytes)
+    tmp_bytes = tb2;
+  if (e == hipSuccess)
+    e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16);
+  if (e == hipSuccess)
+    e = hipcub::DeviceReduce::Sum(
+        tmp, tmp_bytes,
+        hipcub::TransformInputIterator<int64_t, ToI64, const int32_t*>(rowptr,
+                                                                       ToI64()),
+        d_total, n1, st);
+  int64_t total = 0;
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(&total, d_total, sizeof(int64_t), hipMemcpyDeviceToHost,
+                       st);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st);
+  if (e == hipSuccess && total <= INT32_MAX) {
+    e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, rowptr, rowptr, n1, st);
+    if (e == hipSuccess)
+      e = hipStreamSynchronize(st);
+  }
+  (void)hipFree(tmp);
+  (void)hipFree(d_total);
+  if (e != hipSuccess)
+    return static_cast<int>(e);
+  *host_nnz = total;
+  return total > INT32_MAX ? SPMV_HIP_ERANGE : SPMV_HIP_OK;
+}
+
+int spmv_hip_fem_fill_f64(spmv_hip_ctx* ctx, const spmv_hip_fem_params* params,
+                          int64_t num_non_zeros, const int32_t* rowptr,
+                          int32_t* colind, double* values, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(params && rowptr && colind && values && num_non_zeros >= 1
+               && num_non_zeros <= INT32_MAX);
+  const spmv_hip_fem_params p = *params;
+  int rc = fem_params_ok(p);
+  if (rc)
+    return rc;
+  const int grid = spmv_grid_for(ctx, num_non_zeros, kBlock);
+  hipLaunchKernelGGL(fem_fill_kernel, dim3(grid), dim3(kBlock), 0,
+                     spmv_stream(ctx, stream), p, num_non_zeros, rowptr, colind,
+                     values);
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;
 }

@@ -632,6 +632,59 @@ Matrix<T>* Matrix<T>::create_unstructured(std::shared_ptr<const Comm> comm,
   }
 }
 
+template <typename T>
+Matrix<T>* Matrix<T>::create_fem_like(std::shared_ptr<const Comm> comm,
+                                      std::shared_ptr<DeviceExecutor> exec,
+                                      const spmv_hip_fem_params& params)
+{
+  if constexpr (!std::is_same<T, double>::value) {
+    throw std::runtime_error("create_fem_like is available for double only");
+  } else {
+    auto* hip = dynamic_cast<HipExecutor*>(exec.get());
+    if (!hip)
+      throw std::runtime_error("create_fem_like needs a HipExecutor");
+    if (comm->size() != 1)
+      throw std::runtime_error("create_fem_like: one rank only");
+    if (params.num_rows < 1 || params.num_rows > INT32_MAX)
+      throw std::runtime_error("create_fem_like: size out of range");
+    const int64_t nrows = params.num_rows;
+    DeviceBlock b;
+    b.rowptr = hip->alloc<int32_t>(nrows + 1);
+    try {
+      throw_on_error(spmv_hip_fem_count(hip->context(), &params, b.rowptr, &b.nnz,
+                                        nullptr),
+                     "spmv_hip_fem_count");
+      b.colind = hip->alloc<int32_t>(b.nnz);
+      b.values = hip->alloc<double>(b.nnz);
+      throw_on_error(spmv_hip_fem_fill_f64(hip->context(), &params, b.nnz,
+                                           b.rowptr, b.colind, b.values, nullptr),
+                     "spmv_hip_fem_fill_f64");
+    } catch (...) {
+      hip->free(b.rowptr);
+      if (b.colind)
+        hip->free(b.colind);
+      if (b.values)
+        hip->free(b.values);
+      throw;
+    }
+    const int32_t n32 = static_cast<int32_t>(nrows);
+    auto col_map = std::make_shared<L2GMap>(comm, n32, std::vector<int64_t>(),
+                                            exec);
+    auto row_map = std::make_shared<L2GMap>(comm, n32, std::vector<int64_t>(),
+                                            exec);
+    std::unique_ptr<Matrix<T>> A(new Matrix<T>());
+    A->_exec = exec;
+    A->_col_map = col_map;
+    A->_row_map = row_map;
+    A->_symmetric = false;
+    using Adopt = typename CSRMatrix<T>::AdoptDevice;
+    A->_mat_local.reset(new CSRMatrix<T>(Adopt{}, exec, n32, n32, b.nnz, b.rowptr,
+                                         b.colind, b.values, nullptr, false));
+    A->_nnz = b.nnz;
+    return A.release();
+  }
+}
+
 // ---------------------------------------------------------------------------
 // 3-D block partition of the Poisson matrix
 // ---------------------------------------------------------------------------

@@ -15,6 +15,8 @@
 #include <memory>
 #include <vector>
 
+struct spmv_hip_fem_params; // include/spmv_hip.h
+
 #include "comm.h"
 #include "csr.h"
 #include "l2gmap.h"
@@ -127,6 +129,13 @@ public:
   static Matrix<T>* create_unstructured(
       std::shared_ptr<const Comm> comm, std::shared_ptr<DeviceExecutor> exec,
       int64_t nrows, int per_row, int64_t band, int far_permille, uint64_t seed);
+
+  // Seeded FEM-like test matrix generated on the device (spmv_hip_fem_count /
+  // _fill_f64: ragged rows, optionally a tail of very long ones, in a
+  // bandwidth-reducing order): one rank only, general storage, ONE block.
+  static Matrix<T>* create_fem_like(std::shared_ptr<const Comm> comm,
+                                    std::shared_ptr<DeviceExecutor> exec,
+                                    const spmv_hip_fem_params& params);
 
   // The same matrix on a 3-D BLOCK partition (the reference has
   // row slabs only): the n^3 grid is cut into px * py * pz boxes (sizes by the

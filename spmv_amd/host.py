@@ -59,6 +59,7 @@ _PROTOS = {
     "spmvh_matrix_create_poisson3d": [vp, vp, i32, C.c_int, C.c_int, PTR(vp)],
     "spmvh_matrix_create_unstructured": [vp, vp, i64, C.c_int, i64, C.c_int,
                                          C.c_uint64, PTR(vp)],
+    "spmvh_matrix_create_fem_like": [vp, vp, vp, PTR(vp)],
     "spmvh_matrix_create_poisson3d_boxes": [vp, vp, i32, C.c_int, C.c_int,
                                             C.c_int, C.c_int, C.c_int, PTR(vp)],
     "spmvh_poisson3d_box_rows": [i32, C.c_int, C.c_int, C.c_int, C.c_int, vp,
@@ -115,6 +116,15 @@ for _n, _a in _PROTOS.items():
     _f.argtypes = _a
     _f.restype = C.c_int
 HOST_SYMBOLS = tuple(_PROTOS) + ("spmvh_last_error",)
+
+
+class FemParams(C.Structure):
+    """spmv_hip_fem_params (include/spmv_hip.h)"""
+    _fields_ = [("num_rows", C.c_int64), ("min_len", C.c_int32),
+                ("max_len", C.c_int32), ("layer", C.c_int32),
+                ("jitter", C.c_int32), ("tail_permille", C.c_int32),
+                ("tail_min", C.c_int32), ("tail_max", C.c_int32),
+                ("tail_stride", C.c_int32), ("seed", C.c_uint64)]
 
 
 class SpmvHostError(RuntimeError):
@@ -387,6 +397,18 @@ class Matrix:
         h = vp()
         call("spmvh_matrix_create_unstructured", comm.h, exec_.h, int(nrows),
              int(per_row), int(band), int(far_permille), int(seed), C.byref(h))
+        return cls(h)
+
+    @classmethod
+    def create_fem_like(cls, comm, exec_, nrows, **params):
+        """Seeded FEM-like test matrix (ragged rows, optional tail of very long
+        rows, bandwidth-reducing order), generated on the device (one rank;
+        numpy twin and parameters: spmv_amd.poisson.fem_like_csr)."""
+        from .poisson import fem_params
+        h = vp()
+        p = FemParams(**fem_params(nrows, **params))
+        call("spmvh_matrix_create_fem_like", comm.h, exec_.h, C.byref(p),
+             C.byref(h))
         return cls(h)
 
     @classmethod

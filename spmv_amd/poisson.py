@@ -103,6 +103,97 @@ def unstructured_csr(nrows, per_row=7, band=2048, far_permille=100,
     return rowptr, cols.reshape(-1), vals
 
 
+def fem_params(nrows, min_len=5, max_len=40, layer=None, jitter=512,
+               tail_permille=0, tail_min=200, tail_max=2000, tail_stride=16,
+               seed=0x5EED0004):
+    """Parameters of the FEM-like test matrix (spmv_hip_fem_params).  `layer`
+    defaults to the level-set width of a 3-D mesh of nrows points in a
+    bandwidth-reducing order, nrows^(2/3), at least 2 * jitter."""
+    N = int(nrows)
+    if layer is None:
+        layer = max(2 * jitter, int(round(N ** (2.0 / 3.0))))
+    return dict(num_rows=N, min_len=int(min_len), max_len=int(max_len),
+                layer=int(layer), jitter=int(jitter),
+                tail_permille=int(tail_permille), tail_min=int(tail_min),
+                tail_max=int(tail_max), tail_stride=int(tail_stride),
+                seed=int(seed))
+
+
+def fem_like_csr(nrows, **params):
+    """The seeded FEM-like test matrix: numpy twin of the device generator
+    (spmv_hip_fem_count / spmv_hip_fem_fill_f64, spmv_amd/csrc/hip/poisson.hip;
+    the construction is described there and followed here line by line).
+    Ragged rows of min_len..max_len entries in three clusters (row - layer, row,
+    row + layer, each within +-jitter), tail_permille / 1000 of the rows LONG
+    (tail_min..tail_max entries, one per tail_stride columns); columns strictly
+    ascending, diagonal always present.  Returns (rowptr int32, colind int32,
+    values)."""
+    p = fem_params(nrows, **params)
+    N = p["num_rows"]
+    golden = np.uint64(0x9E3779B97F4A7C15)
+    seed = np.uint64(p["seed"])
+    J, L = p["jitter"], p["layer"]
+    W = 2 * J
+    assert p["max_len"] <= W and L >= W and W <= N
+    with np.errstate(over="ignore"):
+        i = np.arange(N, dtype=np.int64)
+        h = _mix64((i.astype(np.uint64) + np.uint64(1)) * golden + seed)
+        tail = np.zeros(N, dtype=bool)
+        if p["tail_permille"] > 0:
+            assert p["tail_max"] * p["tail_stride"] <= N
+            tail = (h % np.uint64(1000)).astype(np.int64) < p["tail_permille"]
+        u = (h >> np.uint64(16)) & np.uint64(0xFFFF)
+        f = (u * u * u + ((u * u) << np.uint64(16))) >> np.uint64(1)
+        span = np.uint64(p["max_len"] - p["min_len"] + 1)
+        n = p["min_len"] + ((span * f) >> np.uint64(48)).astype(np.int64)
+        n0 = (3 * n) // 10
+        n2 = (3 * n) // 10
+        n1 = n - n0 - n2
+        n0[(i - L - J < 0) | (i + J > N)] = 0
+        n2[(i + L + J > N) | (i - J < 0)] = 0
+        lo1 = np.clip(i - J, 0, N - W)
+        lo0 = i - L - J
+        lo2 = i + L - J
+        s0 = np.where(n0 > 0, W // np.maximum(n0, 1), 1)
+        s1 = W // n1
+        s2 = np.where(n2 > 0, W // np.maximum(n2, 1), 1)
+        if tail.any():
+            nt = p["tail_min"] + ((h >> np.uint64(32)) % np.uint64(
+                p["tail_max"] - p["tail_min"] + 1)).astype(np.int64)
+            Wt = nt * p["tail_stride"]
+            lot = np.clip(i - Wt // 2, 0, N - Wt)
+            n0[tail] = 0
+            n2[tail] = 0
+            n1[tail] = nt[tail]
+            lo1[tail] = lot[tail]
+            s1[tail] = p["tail_stride"]
+        kd = np.minimum((i - lo1) // s1, n1 - 1)
+        lens = n0 + n1 + n2
+        rowptr = np.zeros(N + 1, dtype=np.int64)
+        np.cumsum(lens, out=rowptr[1:])
+        nnz = int(rowptr[-1])
+        if nnz > np.iinfo(np.int32).max:
+            raise OverflowError("nnz exceeds the int32 row pointer of the format")
+        e = np.arange(nnz, dtype=np.int64)
+        row = np.repeat(i, lens)
+        k = e - rowptr[row]
+        c0 = k < n0[row]
+        c2 = k >= (n0 + n1)[row]
+        c1 = ~(c0 | c2)
+        kk = np.where(c0, k, np.where(c1, k - n0[row], k - (n0 + n1)[row]))
+        lo = np.where(c0, lo0[row], np.where(c1, lo1[row], lo2[row]))
+        s = np.where(c0, s0[row], np.where(c1, s1[row], s2[row]))
+        e1 = (e.astype(np.uint64) + np.uint64(1)) * golden
+        h1 = _mix64(e1 + seed + np.uint64(1))
+        h2 = _mix64(e1 + seed + np.uint64(2))
+        col = lo + kk * s + (h1 % s.astype(np.uint64)).astype(np.int64)
+        val = (h2 >> np.uint64(11)).astype(np.float64) * (2.0 / 9007199254740992.0) - 1.0
+        diag = c1 & (kk == kd[row])
+        col[diag] = row[diag]
+        val[diag] = lens[row][diag].astype(np.float64) + 1.0
+    return rowptr.astype(np.int32), col.astype(np.int32), val
+
+
 def poisson3d_nnz(n):
     return 7 * n ** 3 - 6 * n ** 2
 

@@ -566,6 +566,47 @@ def test_unstructured_generator_matches_numpy_twin(ctx):
                  1, None)
 
 
+FEM_KINDS = {"fem": dict(), "fem_tail": dict(tail_permille=10),
+             "fem81": dict(min_len=81, max_len=81),
+             "fem_odd": dict(min_len=1, max_len=9, jitter=8, layer=50,
+                             tail_permille=200, tail_min=30, tail_max=90,
+                             tail_stride=3, seed=7)}
+
+
+@pytest.mark.parametrize("kind", list(FEM_KINDS))
+def test_fem_like_generator_matches_numpy_twin(ctx, kind):
+    """spmv_hip_fem_count / spmv_hip_fem_fill_f64 (ragged rows, optional tail of
+    very long rows, bandwidth-reducing order) against
+    spmv_amd.poisson.fem_like_csr: same arrays; columns strictly ascending and
+    the diagonal in every row."""
+    from spmv_amd.host import FemParams
+    for N in ((300, 4097) if kind == "fem_odd" else (40_000, 300_000)):
+        kw = FEM_KINDS[kind]
+        rp, ci, va = poisson.fem_like_csr(N, **kw)
+        prm = FemParams(**poisson.fem_params(N, **kw))
+        d_rp = ctx.empty(N + 1, np.int32)
+        nnz = C.c_int64()
+        hip.call("spmv_hip_fem_count", ctx.h, C.byref(prm), d_rp.ptr,
+                 C.byref(nnz), None)
+        assert nnz.value == len(ci) and np.array_equal(d_rp.numpy(), rp)
+        d_ci, d_va = ctx.empty(nnz.value, np.int32), ctx.empty(nnz.value, np.float64)
+        hip.call("spmv_hip_fem_fill_f64", ctx.h, C.byref(prm), nnz.value,
+                 d_rp.ptr, d_ci.ptr, d_va.ptr, None)
+        assert np.array_equal(d_ci.numpy(), ci)
+        assert np.array_equal(d_va.numpy(), va)
+        inner = np.ones(len(ci), bool)
+        inner[rp[:-1][np.diff(rp) > 0]] = False   # first entry of each row
+        assert np.all(np.diff(ci.astype(np.int64))[inner[1:]] > 0)
+        rows = np.repeat(np.arange(N), np.diff(rp))
+        assert np.array_equal(np.bincount(rows[ci == rows], minlength=N),
+                              np.ones(N, np.int64))
+        for b in (d_rp, d_ci, d_va):
+            b.free()
+    bad = FemParams(**poisson.fem_params(1000, max_len=40, jitter=8, layer=16))
+    with pytest.raises(Exception):  # a cluster window narrower than its entries
+        hip.call("spmv_hip_fem_count", ctx.h, C.byref(bad), 1, C.byref(nnz), None)
+
+
 # ---------------------------------------------------------------------------
 # CG building blocks: drive the kernels exactly as spmv::cg does and compare
 # with the oracle's CG (cg.cpp:21-98)
