@@ -43,6 +43,15 @@ struct spmv_hip_ctx {
   // ... with this many lattice lines per lane where the lattice is 3-D
   // ("const_tile": 1, 2 or 4)
   int const_tile = 4;
+  // plans build the sliced jagged form (spmv_sjds.hip) for general matrices
+  // with at least this many entries that take neither the lattice nor the LX
+  // form ("sj_min_nnz")
+  int64_t sj_min_nnz = (int64_t)1 << 20;
+  // ... staging at most this many 16-column chunks of x per block
+  // ("sj_max_chunks", <= 448: 56 KiB of fp64)
+  int sj_max_chunks = 448;
+  // ... with this many slices per block ("sj_wpb": 4, 8, 16; 0 = choose)
+  int sj_wpb = 0;
   // the device Poisson generator's non-symmetric variant ("poisson_skew_ppm":
   // lower neighbours -1 - s, upper -1 + s, s = value * 1e-6; 0 = the Poisson
   // matrix).  For measurements of kernels on matrices that are not symmetric.

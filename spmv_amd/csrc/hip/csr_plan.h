@@ -5,6 +5,7 @@
 //   spmv_lat.hip   lattice form: constant column offsets per row block
 //   spmv_symlat.hip  the same idea for the symmetric storage
 //   spmv_symdia.hip  ... with the values re-laid out by offset (baked copy)
+//   spmv_sjds.hip    sliced jagged form: ragged / long rows, x staged in LDS
 #pragma once
 
 #include "common.h"
@@ -280,6 +281,24 @@ struct spmv_hip_csr_plan {
   int wdia = 0;                   // use it (plan_set "wdia")
   int wdia_xcd_group = 4;         // consecutive row blocks per XCD (0 = off;
                                   // 27-point 256^3: 0.820 -> 0.803 ms)
+  // Sliced jagged form (spmv_sjds.hip): general matrices without lattice
+  // structure -- slices of 64 rows stored as jagged diagonals (lane = row), x
+  // staged in LDS per block of sj_wpb slices, 16-bit column codes
+  int32_t* sj_lenperm = nullptr; // per jagged lane: (row length << 6) | row in slice
+  int32_t* sj_blk = nullptr;     // per block: staged chunks, 32-bit codes?
+  int32_t* sj_chunks = nullptr;  // per block: sj_stride chunk numbers
+  unsigned char* sj_codes = nullptr; // column codes in jagged order
+  void* sj_val = nullptr;        // the values in jagged order (plan_bake_values)
+  const void* sj_values0 = nullptr;
+  int sj_elem = 0;               // sizeof the baked value type
+  int sj = 0;                    // use it (plan_set "sjds")
+  int sj_wpb = 0;                // slices (waves) per block: 4, 8, 16
+  int sj_nblk = 0, sj_maxk = 0, sj_stride = 0, sj_wide_alloc = 0;
+  int64_t sj_far = 0, sj_sumk = 0; // entries gathered from memory; staged chunks
+  int32_t* sj_long_rows = nullptr; // rows the slices leave out (one wave each)
+  int sj_nlong = 0, sj_long_thr = 0;
+  int sj_blocks_per_cu = 0;      // 0 = what the LDS footprint allows
+  int sj_xcd_group = 8;          // consecutive blocks per XCD (0 = off)
   int32_t* row_list = nullptr; // ROWLIST: device list of non-empty rows
   int32_t num_listed = 0;
   int nt_store = 0; // non-temporal y stores
@@ -293,7 +312,7 @@ struct spmv_hip_csr_plan {
   bool structure_baked() const
   {
     return row_list || lx_lidx || lat_tab || slat_mask || t_ptr || lxw_rec
-           || wdia_val;
+           || wdia_val || sj_lenperm;
   }
   // ROWBLOCK "LX" form: LDS-staged x windows + 16-bit local column indices
   // (csr_rowblock_lx_kernel); built by plan_create when most row blocks qualify
@@ -436,6 +455,17 @@ int spmv_wdia_bake_f32f64(spmv_hip_csr_plan* pl, const float* values32,
 int spmv_wdia_run_f32f64(const spmv_hip_csr_plan* pl, hipStream_t st,
                          double alpha, const double* in, double beta,
                          double* out, DotOut dot);
+// spmv_sjds.hip
+int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
+                    const int32_t* colind, int wpb_force);
+void spmv_sjds_free(spmv_hip_csr_plan* pl);
+int spmv_sjds_bake_f64(spmv_hip_csr_plan* pl, const double* values,
+                       hipStream_t st); // values == nullptr: drop the copy
+int spmv_sjds_bake_f32(spmv_hip_csr_plan* pl, const float* values, hipStream_t st);
+int spmv_sjds_run_f64(const spmv_hip_csr_plan* pl, hipStream_t st, double alpha,
+                      const double* in, double beta, double* out, DotOut dot);
+int spmv_sjds_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st, float alpha,
+                      const float* in, float beta, float* out);
 // spmv_lat.hip
 int spmv_lat_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
                    const int32_t* colind);

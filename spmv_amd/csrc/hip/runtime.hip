@@ -132,6 +132,21 @@ int spmv_hip_ctx_set_option(spmv_hip_ctx* ctx, const char* key, int64_t value)
     ctx->wdia_half = (int)value;
     return SPMV_HIP_OK;
   }
+  if (!strcmp(key, "sj_min_nnz")) {
+    SPMV_REQUIRE(value >= 0);
+    ctx->sj_min_nnz = value;
+    return SPMV_HIP_OK;
+  }
+  if (!strcmp(key, "sj_max_chunks")) {
+    SPMV_REQUIRE(value >= 8 && value <= 448);
+    ctx->sj_max_chunks = (int)value;
+    return SPMV_HIP_OK;
+  }
+  if (!strcmp(key, "sj_wpb")) {
+    SPMV_REQUIRE(value == 0 || value == 4 || value == 8 || value == 16);
+    ctx->sj_wpb = (int)value;
+    return SPMV_HIP_OK;
+  }
   if (!strcmp(key, "bake_general")) {
     SPMV_REQUIRE(value == 0 || value == 1);
     ctx->bake_general = (int)value;

@@ -724,6 +724,15 @@ int launch_rowblock(const spmv_hip_csr_plan* pl, hipStream_t st,
     else
       return spmv_wdia_run_f32(pl, st, alpha, in, beta, out);
   }
+  // the plan's own copy in sliced jagged order (ragged / long rows)
+  if (pl->sj && pl->sj_val && pl->sj_elem == (int)sizeof(T)
+      && values == pl->sj_values0 && aligned16(in) && pl->num_cols >= 2) {
+    if constexpr (sizeof(T) == 8)
+      return spmv_sjds_run_f64(pl, st, alpha, in, beta, out,
+                               DOT ? dot : DotOut());
+    else
+      return spmv_sjds_run_f32(pl, st, alpha, in, beta, out);
+  }
   if (pl->lat && aligned16(values)) {
     if constexpr (sizeof(T) == 8)
       return spmv_lat_run_f64(pl, st, rowptr, values, alpha, in, beta, out,
@@ -1311,8 +1320,11 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
     // only the non-empty ones (the remote block of a partitioned matrix)
     if (!symmetric && num_non_zeros > 0 && num_non_zeros * 4 < num_rows)
       algo = SPMV_HIP_ALGO_ROWLIST;
-    else
-      algo = (avg <= 64.0) ? SPMV_HIP_ALGO_ROWBLOCK : SPMV_HIP_ALGO_VECTOR;
+    else // long rows: the sliced jagged form (below) where it is built,
+         // else a sub-wavefront per row
+      algo = (avg <= 64.0 || num_non_zeros >= ctx->sj_min_nnz)
+                 ? SPMV_HIP_ALGO_ROWBLOCK
+                 : SPMV_HIP_ALGO_VECTOR;
   }
   if (algo < SPMV_HIP_ALGO_ROWBLOCK || algo > SPMV_HIP_ALGO_ROWLIST
       || (algo == SPMV_HIP_ALGO_ROWLIST && (symmetric || num_non_zeros == 0))) {
@@ -1348,6 +1360,12 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
     if (rc == SPMV_HIP_OK && !pl->lat && num_non_zeros >= ctx->lx_min_nnz
         && avg <= 16.0 && (int64_t)num_cols * 8 <= ctx->lx_max_x_bytes)
       rc = build_lx(pl, rowptr, colind);
+    // Neither: the sliced jagged form (spmv_sjds.hip) -- ragged rows, more
+    // than 16 entries per row, column windows too wide for the LX form.  The
+    // structure now, the values with plan_bake_values.
+    if (rc == SPMV_HIP_OK && !pl->lat && !pl->lx
+        && num_non_zeros >= ctx->sj_min_nnz)
+      rc = spmv_sjds_build(pl, rowptr, colind, ctx->sj_wpb);
     if (rc != SPMV_HIP_OK) {
       spmv_hip_csr_plan_destroy(pl);
       return rc;
@@ -1380,7 +1398,7 @@ int spmv_hip_csr_plan_destroy(spmv_hip_csr_plan* plan)
   if (plan
       && (plan->row_list || plan->lx_lidx || plan->lat_tab || plan->t_ptr
           || plan->slat_mask || plan->zw_table || plan->wdia_val
-          || plan->sdia_val)) {
+          || plan->sdia_val || plan->sj_lenperm)) {
     (void)hipSetDevice(plan->ctx->device);
     (void)hipFree(plan->row_list);
     free_lx(plan);
@@ -1388,6 +1406,7 @@ int spmv_hip_csr_plan_destroy(spmv_hip_csr_plan* plan)
     spmv_symt_free(plan);
     spmv_sdia_free(plan);
     spmv_wdia_free(plan);
+    spmv_sjds_free(plan);
     spmv_slat_free(plan);
     spmv_zwalk_free(plan);
   }
@@ -1411,6 +1430,13 @@ int spmv_hip_csr_plan_bake_values_f64(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan
   } else if (!plan->symmetric && rc == SPMV_HIP_OK) {
     (void)spmv_wdia_bake_f64(plan, nullptr, st); // superseded
   }
+  // a plan in the sliced jagged form keeps its own copy of the values in that
+  // order (the diagonal forms never coexist with it)
+  if (!plan->symmetric && plan->sj_lenperm
+      && (values == nullptr || rc == SPMV_HIP_ENOTSUP)) {
+    const int rj = spmv_sjds_bake_f64(plan, values, st);
+    rc = values == nullptr ? (rj != SPMV_HIP_OK ? rj : rc) : rj;
+  }
   return rc;
 }
 
@@ -1427,6 +1453,11 @@ int spmv_hip_csr_plan_bake_values_f32(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan
     rc = values == nullptr ? (rw != SPMV_HIP_OK ? rw : rc) : rw;
   } else if (!plan->symmetric && rc == SPMV_HIP_OK) {
     (void)spmv_wdia_bake_f32(plan, nullptr, st);
+  }
+  if (!plan->symmetric && plan->sj_lenperm
+      && (values == nullptr || rc == SPMV_HIP_ENOTSUP)) {
+    const int rj = spmv_sjds_bake_f32(plan, values, st);
+    rc = values == nullptr ? (rj != SPMV_HIP_OK ? rj : rc) : rj;
   }
   return rc;
 }
@@ -1538,6 +1569,15 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
     if (plan->zw_table && plan->sdia_val)
       return spmv_zwalk_order_build(plan, plan->zw_d2, spmv_walk_grid(plan), 0,
                                     true);
+  } else if (!strcmp(key, "sjds")) {
+    SPMV_REQUIRE(value == 0 || plan->sj_val);
+    plan->sj = value != 0;
+  } else if (!strcmp(key, "sj_blocks_per_cu")) {
+    SPMV_REQUIRE(value >= 0 && value <= kBlocksPerCU);
+    plan->sj_blocks_per_cu = value;
+  } else if (!strcmp(key, "sj_xcd_group")) {
+    SPMV_REQUIRE(value >= 0 && value <= 4096);
+    plan->sj_xcd_group = value;
   } else if (!strcmp(key, "wdia")) {
     SPMV_REQUIRE(value == 0 || plan->wdia_val);
     plan->wdia = value != 0;
@@ -1648,6 +1688,28 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
     *value = plan->slat;
   else if (!strcmp(key, "sdia"))
     *value = plan->sdia && plan->sdia_val ? 1 : 0;
+  else if (!strcmp(key, "sjds"))
+    *value = plan->sj && plan->sj_val ? 1 : 0;
+  else if (!strcmp(key, "sj_built"))
+    *value = plan->sj_lenperm ? 1 : 0;
+  else if (!strcmp(key, "sj_wpb"))
+    *value = plan->sj_lenperm ? plan->sj_wpb : 0;
+  else if (!strcmp(key, "sj_max_chunks"))
+    *value = plan->sj_lenperm ? plan->sj_maxk : 0;
+  else if (!strcmp(key, "sj_far_permille"))
+    *value = plan->sj_lenperm && plan->nnz > 0
+                 ? (int)((plan->sj_far * 1000 + plan->nnz - 1) / plan->nnz)
+                 : 0;
+  else if (!strcmp(key, "sj_staged_bytes_per_entry_x100"))
+    *value = plan->sj_lenperm && plan->nnz > 0
+                 ? (int)(plan->sj_sumk * 12800 / plan->nnz)
+                 : 0;
+  else if (!strcmp(key, "sj_long_rows"))
+    *value = plan->sj_lenperm ? plan->sj_nlong : 0;
+  else if (!strcmp(key, "sj_wide"))
+    *value = plan->sj_lenperm ? plan->sj_wide_alloc : 0;
+  else if (!strcmp(key, "sj_blocks_per_cu"))
+    *value = plan->sj_blocks_per_cu;
   else if (!strcmp(key, "wdia"))
     *value = plan->wdia && plan->wdia_val ? 1 : 0;
   else if (!strcmp(key, "wdia_offsets"))
@@ -1679,6 +1741,12 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
       b += (int64_t)plan->wdia_narr * plan->wdia_len * plan->wdia_elem + 4 * n;
     if (plan->wdia32_val && !plan->wdia_const)
       b += (int64_t)plan->wdia_narr * plan->wdia_len * 4;
+    if (plan->sj_lenperm)
+      b += 4 * ((n + 63) / 64 * 64) + 8 * (int64_t)plan->sj_nblk
+           + 4 * (int64_t)plan->sj_nblk * plan->sj_stride
+           + (plan->sj_wide_alloc ? 4 : 2) * nnz + 4 * (int64_t)plan->sj_nlong;
+    if (plan->sj_val)
+      b += (int64_t)plan->sj_elem * nnz;
     if (plan->t_ptr)
       b += 4 * (n + 1) + 8 * nnz;
     if (plan->zw_table)

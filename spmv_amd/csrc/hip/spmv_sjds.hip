@@ -1,0 +1,1224 @@
+// Sliced jagged form ("SJDS") of a general CSR matrix for gfx950 (MI355X):
+// the kernel for matrices WITHOUT lattice structure -- ragged rows, FEM
+// matrices with 15-80 entries per row, a tail of rows with thousands of
+// entries -- behind CSRSpMV<T>::run (spmv/csr_kernels.cpp:41-51).
+//
+// What the row-block gather kernel (spmv_csr.hip) pays for on such matrices is
+// the gather itself: one lane per ENTRY means 64 lanes of a wave ask for 64
+// different 128-byte lines of x, and every one of them is a request to the L2
+// (10 M rows x 15 entries: 150 M requests, the L2's whole request rate for
+// half a millisecond).  Here
+//
+//   * lane = ROW.  The plan re-lays the matrix out (plan_bake_values: the
+//     plan's own copy of the values; spmv_hip_csr_plan_values_changed after an
+//     update in place) in slices of 64 consecutive rows, each slice stored as
+//     jagged diagonals: the slice's rows sorted by length (descending, stable),
+//     then entry k of every row that has one, side by side.  Step k of a wave
+//     is one coalesced load of the values and one of the column codes by the
+//     first cnt_k lanes; nothing is padded, the arrays have exactly nnz
+//     entries and a slice occupies the span of its rows in CSR.  A lane adds
+//     its own row's products in the row's order: the bits of the reference
+//     loop, no LDS parking of products, no barrier inside a slice.
+//   * x comes from LDS.  Per block of WPB slices (256, 512 or 1024 rows) the
+//     plan lists the 16-column chunks (128 B) of x the block's entries touch
+//     -- up to 448 of them, nearest to the diagonal first -- and rewrites every
+//     column as a 16-bit index into the staged copy.  Entries outside the list
+//     ("far") keep their column and are gathered from memory; a block that has
+//     any uses 32-bit codes.  Staging is coalesced 16-byte loads, shared by all
+//     rows of the block; the gather becomes an LDS read.
+//   * long rows.  A row with more than four times the average length (and
+//     more than 96 entries) stays out of the slices: the kernel's first phase
+//     gives each such row to one WAVE, which streams it from the caller's CSR
+//     arrays 64 entries at a time (two loads ahead), multiplies in parallel
+//     and adds the products to the row's sum one by one in order (v_readlane
+//     + add) -- the reference's bits.  Inside a slice the same take-over
+//     happens past the second-longest row, where only lane 0 is still active.
+//
+// Bytes per launch: nnz * (8 + 2) + rows * (4 + 8) + x (+ the chunk lists)
+// against CSR's nnz * 12 + rows * 12 + x.
+#include "csr_plan.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <chrono>
+
+namespace
+{
+
+constexpr int kSjChunk = 16;       // columns per staged chunk
+constexpr int kSjSpanWords = 2048; // bitmap words of the plan analysis: 65,536
+                                   // chunks = 2^20 columns around the block
+constexpr int kSjU = 8;            // steps per load group (two groups in flight)
+constexpr int kSjTailMin = 48;     // entries past the second-longest row from
+                                   // which the wave takes lane 0's row over
+constexpr int kSjLongMin = 96;     // LONG rows: more than 4 x the average and
+                                   // more than this many entries
+constexpr uint32_t kSjLongFlag = 0x80000000u; // ... marked in their lenperm word
+
+// ---------------------------------------------------------------------------
+// plan time
+// ---------------------------------------------------------------------------
+struct SjSel {
+  int32_t lo; // first chunk of the bitmap's span
+  int32_t wa, wb; // selected bitmap words (inclusive)
+  int32_t K;  // selected chunks
+};
+
+// Which chunks of x does the block of rows [r0, r1) touch?  Bitmap over the
+// 2^16 chunks around the block's diagonal position; when more than kcap are
+// set, the words nearest to the diagonal are kept.  All 256 threads call it;
+// s_bits[kSjSpanWords], s_pre[kSjSpanWords + 1].
+__device__ SjSel sj_select(int32_t r0, int32_t r1, int32_t num_cols,
+                           const int32_t* __restrict__ rowptr,
+                           const int32_t* __restrict__ colind, int kcap,
+                           int long_thr, uint32_t* s_bits, int32_t* s_pre,
+                           SjSel* s_sel)
+{
+  using Scan = hipcub::BlockScan<int32_t, kBlock>;
+  __shared__ typename Scan::TempStorage s_scan;
+  constexpr int kSpan = kSjSpanWords * 32;
+  const int t = threadIdx.x;
+  const int32_t nchunks = (num_cols + kSjChunk - 1) / kSjChunk;
+  int32_t cc = (int32_t)(((int64_t)r0 + r1) / 2 / kSjChunk);
+  int32_t lo = cc - kSpan / 2;
+  if (lo > nchunks - kSpan)
+    lo = nchunks - kSpan;
+  if (lo < 0)
+    lo = 0;
+  for (int w = t; w < kSjSpanWords; w += kBlock)
+    s_bits[w] = 0u;
+  __syncthreads();
+  // one lane per row; LONG rows are not part of the slices (phase 0 of the
+  // kernel takes them), so they do not choose chunks
+  for (int32_t row = r0 + t; row < r1; row += kBlock) {
+    const int32_t a = rowptr[row], b = rowptr[row + 1];
+    if (b - a > long_thr)
+      continue;
+    for (int32_t e = a; e < b; ++e) {
+      const int32_t rel = colind[e] / kSjChunk - lo;
+      if (rel >= 0 && rel < kSpan)
+        atomicOr(&s_bits[rel >> 5], 1u << (rel & 31));
+    }
+  }
+  __syncthreads();
+  // exclusive prefix of the words' popcounts (8 consecutive words per thread)
+  constexpr int kPer = kSjSpanWords / kBlock;
+  int32_t mine = 0;
+#pragma unroll
+  for (int q = 0; q < kPer; ++q)
+    mine += __popc(s_bits[t * kPer + q]);
+  int32_t before = 0, total = 0;
+  Scan(s_scan).ExclusiveSum(mine, before, total);
+#pragma unroll
+  for (int q = 0; q < kPer; ++q) {
+    s_pre[t * kPer + q] = before;
+    before += __popc(s_bits[t * kPer + q]);
+  }
+  if (t == 0)
+    s_pre[kSjSpanWords] = total;
+  __syncthreads();
+  if (t == 0) {
+    SjSel s;
+    s.lo = lo;
+    s.wa = 0;
+    s.wb = kSjSpanWords - 1;
+    s.K = total;
+    if (total > kcap) {
+      int32_t cw = (cc - lo) >> 5;
+      cw = cw < 0 ? 0 : (cw > kSjSpanWords - 1 ? kSjSpanWords - 1 : cw);
+      int rlo = 0, rhi = kSjSpanWords - 1; // largest radius that fits
+      while (rlo < rhi) {
+        const int mid = (rlo + rhi + 1) >> 1;
+        const int wa = cw - mid < 0 ? 0 : cw - mid;
+        const int wb = cw + mid > kSjSpanWords - 1 ? kSjSpanWords - 1 : cw + mid;
+        if (s_pre[wb + 1] - s_pre[wa] <= kcap)
+          rlo = mid;
+        else
+          rhi = mid - 1;
+      }
+      s.wa = cw - rlo < 0 ? 0 : cw - rlo;
+      s.wb = cw + rlo > kSjSpanWords - 1 ? kSjSpanWords - 1 : cw + rlo;
+      s.K = s_pre[s.wb + 1] - s_pre[s.wa];
+      if (s.K > kcap) { // one word alone holds at most 32 <= kcap chunks
+        s.wb = s.wa - 1;
+        s.K = 0;
+      }
+    }
+    *s_sel = s;
+  }
+  __syncthreads();
+  return *s_sel;
+}
+
+// staged index of column `col`, or -1 = far
+__device__ __forceinline__ int32_t sj_index(const SjSel& s, const uint32_t* s_bits,
+                                           const int32_t* s_pre, int32_t col)
+{
+  const int32_t rel = col / kSjChunk - s.lo;
+  const int32_t w = rel >> 5;
+  if (rel < 0 || w < s.wa || w > s.wb)
+    return -1;
+  if (!((s_bits[w] >> (rel & 31)) & 1u))
+    return -1;
+  const int32_t rank
+      = s_pre[w] - s_pre[s.wa] + __popc(s_bits[w] & ((1u << (rel & 31)) - 1u));
+  return rank * kSjChunk + (col & (kSjChunk - 1));
+}
+
+// pass 1: per block the number of chunks kept and of far entries
+template <int R>
+__global__ __launch_bounds__(kBlock) void sj_count_kernel(
+    int32_t num_rows, int32_t num_cols, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ colind, int kcap, int long_thr,
+    int32_t* __restrict__ blk_k, int32_t* __restrict__ blk_far)
+{
+  __shared__ uint32_t s_bits[kSjSpanWords];
+  __shared__ int32_t s_pre[kSjSpanWords + 1];
+  __shared__ SjSel s_sel;
+  __shared__ int32_t s_far;
+  const int nblk = (num_rows + R - 1) / R;
+  for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
+    const int32_t r0 = b * R;
+    const int32_t r1 = min(r0 + R, num_rows);
+    if (threadIdx.x == 0)
+      s_far = 0;
+    const SjSel sel = sj_select(r0, r1, num_cols, rowptr, colind, kcap, long_thr,
+                                s_bits, s_pre, &s_sel);
+    int32_t far = 0;
+    for (int32_t row = r0 + threadIdx.x; row < r1; row += kBlock) {
+      const int32_t a = rowptr[row], e1 = rowptr[row + 1];
+      if (e1 - a > long_thr)
+        continue;
+      for (int32_t e = a; e < e1; ++e)
+        far += sj_index(sel, s_bits, s_pre, colind[e]) < 0 ? 1 : 0;
+    }
+    if (far)
+      atomicAdd(&s_far, far);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      blk_k[b] = sel.K;
+      blk_far[b] = s_far;
+    }
+    __syncthreads();
+  }
+}
+
+// max and sums of the two per-block arrays: out = {max K, sum K, sum far,
+// blocks with far entries}
+__global__ __launch_bounds__(1024) void sj_stats_kernel(
+    int nblk, const int32_t* __restrict__ blk_k, const int32_t* __restrict__ blk_far,
+    int64_t* __restrict__ out)
+{
+  using Red = hipcub::BlockReduce<int64_t, 1024>;
+  __shared__ typename Red::TempStorage tmp;
+  int64_t mx = 0, sk = 0, sf = 0, nf = 0;
+  for (int b = threadIdx.x; b < nblk; b += 1024) {
+    const int64_t k = blk_k[b], f = blk_far[b];
+    mx = k > mx ? k : mx;
+    sk += k;
+    sf += f;
+    nf += f > 0 ? 1 : 0;
+  }
+  mx = Red(tmp).Reduce(mx, hipcub::Max());
+  __syncthreads();
+  sk = Red(tmp).Sum(sk);
+  __syncthreads();
+  sf = Red(tmp).Sum(sf);
+  __syncthreads();
+  nf = Red(tmp).Sum(nf);
+  if (threadIdx.x == 0) {
+    out[0] = mx;
+    out[1] = sk;
+    out[2] = sf;
+    out[3] = nf;
+  }
+}
+
+// the slice's rows in jagged order: lane rho gets the row (0..63 within the
+// slice) with the rho-th largest length (ties: the lower row first)
+__device__ __forceinline__ void sj_sort_slice(int32_t len, int lane, int32_t* my_len,
+                                              int* my_row)
+{
+  int rank = 0;
+  for (int j = 0; j < 64; ++j) {
+    const int32_t lj = __shfl(len, j, 64);
+    rank += (lj > len || (lj == len && j < lane)) ? 1 : 0;
+  }
+  int32_t ml = 0;
+  int mr = 0;
+  for (int j = 0; j < 64; ++j) {
+    const int rj = __shfl(rank, j, 64);
+    const int32_t lj = __shfl(len, j, 64);
+    if (rj == lane) {
+      ml = lj;
+      mr = j;
+    }
+  }
+  *my_len = ml;
+  *my_row = mr;
+}
+
+// pass 2: chunk lists, the (length, row) word of every jagged lane, and the
+// column codes in jagged order
+template <int R>
+__global__ __launch_bounds__(kBlock) void sj_fill_kernel(
+    int32_t num_rows, int32_t num_cols, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ colind, int kcap, int long_thr, int stride,
+    int wide_alloc, const int32_t* __restrict__ blk_far, int32_t* __restrict__ blk,
+    int32_t* __restrict__ chunks, int32_t* __restrict__ lenperm,
+    unsigned char* __restrict__ codes)
+{
+  __shared__ uint32_t s_bits[kSjSpanWords];
+  __shared__ int32_t s_pre[kSjSpanWords + 1];
+  __shared__ SjSel s_sel;
+  const int nblk = (num_rows + R - 1) / R;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
+    const int32_t r0 = b * R;
+    const int32_t r1 = min(r0 + R, num_rows);
+    const SjSel sel = sj_select(r0, r1, num_cols, rowptr, colind, kcap, long_thr,
+                                s_bits, s_pre, &s_sel);
+    for (int w = sel.wa + threadIdx.x; w <= sel.wb; w += kBlock) {
+      uint32_t bits = s_bits[w];
+      int32_t rank = s_pre[w] - s_pre[sel.wa];
+      while (bits) {
+        const int bit = __ffs(bits) - 1;
+        chunks[(int64_t)b * stride + rank] = sel.lo + w * 32 + bit;
+        ++rank;
+        bits &= bits - 1;
+      }
+    }
+    // the list is padded with its last chunk up to the stride: the kernel
+    // loads list entries before it knows the block's count
+    __syncthreads();
+    for (int c = sel.K + threadIdx.x; c < stride; c += kBlock)
+      chunks[(int64_t)b * stride + c]
+          = sel.K > 0 ? chunks[(int64_t)b * stride + sel.K - 1] : 0;
+    const int wide = blk_far[b] > 0 ? 1 : 0;
+    if (threadIdx.x == 0) {
+      blk[2 * b] = sel.K;
+      blk[2 * b + 1] = wide;
+    }
+    const int64_t a_b = rowptr[r0];
+    uint16_t* c16 = reinterpret_cast<uint16_t*>(codes + (wide_alloc ? 4 : 2) * a_b);
+    uint32_t* c32 = reinterpret_cast<uint32_t*>(codes + 4 * a_b);
+    for (int sl = wave; sl < R / 64; sl += kBlock / 64) {
+      const int32_t s0 = r0 + sl * 64;
+      if (s0 >= num_rows)
+        break;
+      const int32_t row = s0 + lane;
+      int32_t len = row < num_rows ? rowptr[row + 1] - rowptr[row] : 0;
+      const bool is_long = len > long_thr; // not in the slice: length 0, marked
+      len = is_long ? 0 : len;
+      int32_t mylen;
+      int myrow;
+      sj_sort_slice(len, lane, &mylen, &myrow);
+      const bool my_long = __shfl((int)is_long, myrow, 64) != 0;
+      lenperm[s0 + lane]
+          = (int32_t)(((uint32_t)mylen << 6) | (uint32_t)myrow
+                      | (my_long ? kSjLongFlag : 0u));
+      const int32_t src0 = s0 + myrow < num_rows ? rowptr[s0 + myrow] : 0;
+      const int32_t maxlen = __shfl(mylen, 0, 64);
+      int64_t off = (int64_t)rowptr[s0] - a_b; // within the block's span
+      for (int32_t k = 0; k < maxlen; ++k) {
+        const bool act = k < mylen;
+        const int cnt = __popcll(__ballot(act));
+        if (act) {
+          const int32_t col = colind[src0 + k];
+          const int32_t idx = sj_index(sel, s_bits, s_pre, col);
+          if (wide)
+            c32[off + lane] = idx >= 0 ? (uint32_t)idx : (0x80000000u | (uint32_t)col);
+          else
+            c16[off + lane] = (uint16_t)idx;
+        }
+        off += cnt;
+      }
+    }
+    __syncthreads(); // the bitmap is reused by the next block
+  }
+}
+
+// the plan's copy of the values in jagged order (one wave per slice)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void sj_bake_kernel(
+    int32_t num_rows, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ lenperm, const T* __restrict__ values,
+    T* __restrict__ sval)
+{
+  const int lane = threadIdx.x & 63;
+  const int64_t nsl = ((int64_t)num_rows + 63) / 64;
+  const int64_t wid = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * kBlock) >> 6;
+  for (int64_t s = wid; s < nsl; s += nw) {
+    const int32_t s0 = (int32_t)(s * 64);
+    const int32_t lp = lenperm[s0 + lane];
+    const int32_t mylen = (int32_t)(((uint32_t)lp & ~kSjLongFlag) >> 6);
+    const int32_t myrow = s0 + (lp & 63);
+    const int64_t src0 = myrow < num_rows ? rowptr[myrow] : 0;
+    const int32_t maxlen = __shfl(mylen, 0, 64);
+    int64_t off = rowptr[s0];
+    for (int32_t k = 0; k < maxlen; ++k) {
+      const bool act = k < mylen;
+      const int cnt = __popcll(__ballot(act));
+      if (act)
+        sval[off + lane] = values[src0 + k];
+      off += cnt;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// the SpMV kernel
+// ---------------------------------------------------------------------------
+template <typename T>
+struct SjArgs {
+  int32_t num_rows, num_cols;
+  int32_t nblk;
+  int32_t maxk;      // staged chunks the LDS buffer holds
+  int32_t stride;    // chunk-list entries per block
+  int32_t wide_alloc;
+  const int32_t* rowptr;  // the caller's: slice s spans [rowptr[64 s], ...)
+  const int32_t* lenperm;
+  const int32_t* blk;     // per block: chunks, wide
+  const int32_t* chunks;
+  const unsigned char* codes;
+  const T* val;           // jagged order
+  // long rows (phase 0): straight from the caller's CSR arrays
+  int32_t nlong;
+  const int32_t* long_rows;
+  const int32_t* colind;
+  const T* values;
+};
+
+template <typename T>
+__device__ __forceinline__ T sj_readlane(T v, int j);
+template <>
+__device__ __forceinline__ double sj_readlane<double>(double v, int j)
+{
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), j);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
+  return __hiloint2double(hi, lo);
+}
+template <>
+__device__ __forceinline__ float sj_readlane<float>(float v, int j)
+{
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
+}
+
+// One slice.  `vb`, `cb`: the block's span of the values / codes (indices
+// relative to it, `last` the last valid one); off = the slice's first entry;
+// mylen = this lane's row length (lanes sorted by it, descending).  Returns the
+// lane's row sum.
+template <typename T, typename CODE, bool WIDE>
+__device__ __forceinline__ T sj_slice(const T* __restrict__ vb,
+                                      const CODE* __restrict__ cb, int64_t off,
+                                      int64_t last, int32_t mylen, int lane,
+                                      const T* __restrict__ s_x,
+                                      const T* __restrict__ in)
+{
+  const int32_t maxlen = __builtin_amdgcn_readlane(mylen, 0);
+  const int32_t len1 = __builtin_amdgcn_readlane(mylen, 1);
+  // the jagged part ends at the second-longest row when lane 0's row goes on
+  // for long enough to be worth taking over by the whole wave
+  const int32_t kmain = (maxlen - len1 >= kSjTailMin) ? len1 : maxlen;
+  const int32_t mymain = mylen < kmain ? mylen : kmain;
+  T sum = T(0);
+  T va[kSjU], vc[kSjU];
+  CODE ca[kSjU], cc[kSjU];
+
+  // Every load below is UNCONDITIONAL (inactive lanes re-read the step's first
+  // entry, clamped into the block's span) and every use a select: with
+  // branches around the loads the compiler waits for ALL loads in flight at
+  // each join, and the two groups no longer overlap.
+#define SJ_ISSUE(V, C, K0)                                                     \
+  _Pragma("unroll") for (int u = 0; u < kSjU; ++u)                             \
+  {                                                                            \
+    const bool act = (K0) + u < mymain;                                        \
+    const int cnt = __popcll(__ballot(act));                                   \
+    int64_t j = off + (act ? lane : 0);                                        \
+    j = j < last ? j : last;                                                   \
+    V[u] = vb[j];                                                              \
+    C[u] = cb[j];                                                              \
+    off += cnt;                                                                \
+  }
+#define SJ_CONSUME(V, C, K0)                                                   \
+  {                                                                            \
+    T xs[kSjU];                                                                \
+    if constexpr (WIDE) {                                                      \
+      T xg[kSjU];                                                              \
+      _Pragma("unroll") for (int u = 0; u < kSjU; ++u)                         \
+      {                                                                        \
+        const uint32_t c = (uint32_t)C[u];                                     \
+        const bool far = (c >> 31) != 0 && (K0) + u < mymain;                  \
+        xg[u] = in[far ? (c & 0x7fffffffu) : 0u];                              \
+      }                                                                        \
+      T xl[kSjU];                                                              \
+      _Pragma("unroll") for (int u = 0; u < kSjU; ++u)                         \
+      {                                                                        \
+        const uint32_t c = (uint32_t)C[u];                                     \
+        xl[u] = s_x[(c >> 31) ? 0u : c];                                       \
+      }                                                                        \
+      /* all eight LDS reads are wanted whatever the codes say: without this \
+         the compiler moves each read under its own test, and every join    \
+         waits for everything in flight */                                  \
+      static_assert(kSjU == 8, "eight operands below");                        \
+      asm volatile("" ::"v"(xl[0]), "v"(xl[1]), "v"(xl[2]), "v"(xl[3]),        \
+                   "v"(xl[4]), "v"(xl[5]), "v"(xl[6]), "v"(xl[7]));            \
+      _Pragma("unroll") for (int u = 0; u < kSjU; ++u)                         \
+      {                                                                        \
+        const uint32_t c = (uint32_t)C[u];                                     \
+        xs[u] = (c >> 31) ? xg[u] : xl[u];                                     \
+      }                                                                        \
+    } else {                                                                   \
+      _Pragma("unroll") for (int u = 0; u < kSjU; ++u) xs[u] = s_x[C[u]];      \
+    }                                                                          \
+    _Pragma("unroll") for (int u = 0; u < kSjU; ++u)                           \
+    {                                                                          \
+      const T nxt = sum + V[u] * xs[u];                                        \
+      sum = (K0) + u < mymain ? nxt : sum;                                     \
+    }                                                                          \
+  }
+
+  if (maxlen > 0) {
+    SJ_ISSUE(va, ca, 0)
+    int32_t k = 0;
+    for (; k + 2 * kSjU < kmain; k += 2 * kSjU) {
+      SJ_ISSUE(vc, cc, k + kSjU)
+      SJ_CONSUME(va, ca, k)
+      SJ_ISSUE(va, ca, k + 2 * kSjU)
+      SJ_CONSUME(vc, cc, k + kSjU)
+    }
+    SJ_ISSUE(vc, cc, k + kSjU)
+    SJ_CONSUME(va, ca, k)
+    SJ_CONSUME(vc, cc, k + kSjU)
+  }
+#undef SJ_ISSUE
+#undef SJ_CONSUME
+
+  if (kmain < maxlen) {
+    // lane 0's row goes on alone: its remaining entries are contiguous.  The
+    // wave loads and multiplies 64 at a time; the products are added to the
+    // row's sum one by one, in order (every lane computes the same sum).
+    const int32_t rem = maxlen - kmain;
+    T t = sj_readlane<T>(sum, 0);
+    for (int32_t j0 = 0; j0 < rem; j0 += 64) {
+      const int32_t j = j0 + lane;
+      int64_t jj = off + (j < rem ? j : 0);
+      jj = jj < last ? jj : last;
+      const T v = vb[jj];
+      T x;
+      if constexpr (WIDE) {
+        const uint32_t c = (uint32_t)cb[jj];
+        const T xg = in[(c >> 31) ? (c & 0x7fffffffu) : 0u];
+        const T xl = s_x[(c >> 31) ? 0u : c];
+        x = (c >> 31) ? xg : xl;
+      } else {
+        x = s_x[cb[jj]];
+      }
+      const T p = v * x; // lanes past the row's end: never added
+      const int n = rem - j0 < 64 ? rem - j0 : 64;
+      if (n == 64) {
+#pragma unroll
+        for (int q = 0; q < 64; ++q)
+          t += sj_readlane<T>(p, q);
+      } else {
+        for (int q = 0; q < n; ++q)
+          t += sj_readlane<T>(p, q);
+      }
+    }
+    if (lane == 0)
+      sum = t;
+  }
+  return sum;
+}
+
+// EIGHT long rows by one wave, eight lanes each: lane l of a group reads entries
+// 8 s + l of its row (64 + 32 bytes per row and step, straight from the
+// caller's CSR arrays), the group's eight products are added to the row's sum
+// one by one in the row's order (every lane of the group keeps the sum).
+// Values and columns travel two steps ahead, x one step ahead.  [a, b) = the
+// lane's row (b == a: no row); returns the row's sum.
+constexpr int kSjLpr = 8;
+constexpr int kSjLU = 4; // steps per load group of the long-row phase
+template <typename T>
+__device__ __forceinline__ T sj_long_rows8(const T* __restrict__ val,
+                                          const int32_t* __restrict__ col,
+                                          int64_t a, int64_t b, int lane,
+                                          const T* __restrict__ in)
+{
+  const int l = lane & (kSjLpr - 1);
+  const int32_t len = (int32_t)(b - a);
+  int32_t maxlen = len; // over the wave's eight rows
+#pragma unroll
+  for (int o = 32; o >= kSjLpr; o >>= 1) {
+    const int32_t other = __shfl_xor(maxlen, o, 64);
+    maxlen = other > maxlen ? other : maxlen;
+  }
+  maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+  const int64_t last = b > a ? b - 1 : a; // (no row: a valid address all the same)
+  auto at = [&](int32_t s) {
+    const int64_t e = a + (int64_t)s * kSjLpr + l;
+    return e < last ? e : last;
+  };
+  // groups of kSjLU steps: values and columns two groups ahead, x one group
+  // ahead -- each trip through the loop waits for loads issued a trip ago
+  constexpr int U = kSjLU;
+  T vA[U], vB[U], vC[U], xA[U], xB[U];
+  int32_t cB[U], cC[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    vA[u] = val[at(u)];
+    cB[u] = col[at(u)]; // (group 0's columns, used at once)
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    xA[u] = in[cB[u]];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    vB[u] = val[at(U + u)];
+    cB[u] = col[at(U + u)];
+  }
+  T t = T(0);
+  for (int32_t s = 0; s * kSjLpr < maxlen; s += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      vC[u] = val[at(s + 2 * U + u)];
+      cC[u] = col[at(s + 2 * U + u)];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      xB[u] = in[cB[u]];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const T p = vA[u] * xA[u];
+      T pj[kSjLpr];
+#pragma unroll
+      for (int j = 0; j < kSjLpr; ++j)
+        pj[j] = __shfl(p, j, kSjLpr);
+#pragma unroll
+      for (int j = 0; j < kSjLpr; ++j) {
+        const T nxt = t + pj[j];
+        t = (s + u) * kSjLpr + j < len ? nxt : t;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      vA[u] = vB[u];
+      xA[u] = xB[u];
+      vB[u] = vC[u];
+      cB[u] = cC[u];
+    }
+  }
+  return t;
+}
+
+template <typename T, int WPB, bool DOT>
+__global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
+    SjArgs<T> A, T alpha, const T* __restrict__ in, T beta, T* __restrict__ out,
+    DotOut dot, RowBlockOrder ord)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  T* s_x = reinterpret_cast<T*>(s_raw);
+  __shared__ double s_red[WPB];
+  constexpr int NT = 64 * WPB;
+  constexpr int R = 64 * WPB;
+  typedef T pair_t __attribute__((ext_vector_type(2)));
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int part = t & 7, cg = t >> 3;
+  constexpr int CG = NT / 8;
+  double dot_acc = 0.0;
+  // phase 0: the long rows (sorted by length), eight per wave and step,
+  // strided over all waves of the grid
+  // (the list is sorted by length: odd rounds are dealt in reverse, so that a
+  // wave's rounds add up to about the same number of steps)
+  const int nwaves = gridDim.x * WPB, nitems = (A.nlong + 7) / 8;
+  for (int r = 0; r * nwaves < nitems; ++r) {
+    const int w = blockIdx.x * WPB + wave;
+    const int i = (r * nwaves + ((r & 1) ? nwaves - 1 - w : w)) * 8;
+    if (i >= A.nlong)
+      continue; // (uniform per wave)
+    const int g = i + (lane >> 3);
+    const bool have_row = g < A.nlong;
+    const int32_t row = A.long_rows[have_row ? g : A.nlong - 1];
+    const int64_t ra = A.rowptr[row];
+    const int64_t rb = have_row ? (int64_t)A.rowptr[row + 1] : ra;
+    const T sum = sj_long_rows8<T>(A.values, A.colind, ra, rb, lane, in);
+    if (have_row && (lane & 7) == 0) {
+      const T c = alpha * sum;
+      T y = c;
+      if (beta != T(0))
+        y = c + beta * out[row];
+      out[row] = y;
+      if constexpr (DOT)
+        dot_acc += (double)in[row] * (double)c;
+    }
+  }
+  const int num_slots = order_slots(ord);
+  // the chunk numbers of a block are requested a whole block ahead (the lists
+  // are padded to the stride, so the request does not need the block's count)
+  int32_t ch[4];
+  auto request_chunks = [&](int bb) {
+    const int32_t* cl = A.chunks + (int64_t)bb * A.stride;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int c = cg + m * CG;
+      ch[m] = cl[c < A.stride ? c : A.stride - 1];
+    }
+  };
+  {
+    const int b0 = blockIdx.x < num_slots ? order_row_block(ord, blockIdx.x) : -1;
+    if (b0 >= 0)
+      request_chunks(b0);
+  }
+  for (int it = blockIdx.x; it < num_slots; it += gridDim.x) {
+    const int b = order_row_block(ord, it);
+    const int itn = it + gridDim.x;
+    const int bn = itn < num_slots ? order_row_block(ord, itn) : -1;
+    if (b < 0) { // uniform per workgroup
+      if (bn >= 0)
+        request_chunks(bn);
+      continue;
+    }
+    const int K = A.blk[2 * b];
+    const int wide = A.blk[2 * b + 1];
+    const int32_t r0 = b * R;
+    const int32_t s0 = r0 + wave * 64;
+    // the slice's own loads first: they do not depend on the staged x
+    // (a slice past the end of the matrix reads the last one's, unused)
+    const bool have = s0 < A.num_rows;
+    const int32_t s0c = have ? s0 : ((A.num_rows - 1) / 64) * 64;
+    const uint32_t lpw = (uint32_t)A.lenperm[s0c + lane];
+    const int32_t lp = (int32_t)(lpw & ~kSjLongFlag);
+    const bool in_slice = (lpw & kSjLongFlag) == 0; // else phase 0 wrote its y
+    const int32_t sbase = A.rowptr[s0c];
+    const int32_t a_b = A.rowptr[r0];
+    const int32_t e_b = A.rowptr[r0 + R < A.num_rows ? r0 + R : A.num_rows];
+    const int32_t myrow = s0c + (lp & 63);
+    const int32_t myrow_c = myrow < A.num_rows ? myrow : A.num_rows - 1;
+    T x_own = T(0), y0 = T(0);
+    if constexpr (DOT)
+      x_own = in[myrow_c];
+    if (beta != T(0))
+      y0 = out[myrow_c];
+    const int32_t* cl = A.chunks + (int64_t)b * A.stride;
+    // the block's chunks of x: 8 lanes per chunk, 2 elements per lane, four
+    // chunks per lane in flight; lanes past the list repeat its last chunk
+    __syncthreads(); // the previous block's slices are done with s_x
+    for (int c0 = cg; c0 < K; c0 += 4 * CG) {
+      pair_t xv[4];
+      const int64_t cmax = ((int64_t)A.num_cols - 2) & ~(int64_t)1;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int64_t col = (int64_t)ch[m] * kSjChunk + part * 2;
+        xv[m] = *reinterpret_cast<const pair_t*>(in + (col < cmax ? col : cmax));
+        if (col + 1 == A.num_cols) // an odd number of columns: the last one
+          xv[m][0] = in[col];
+      }
+      int32_t chn[4];
+      if (c0 + 4 * CG < K) { // (uniform) the next round's chunk numbers
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int c = c0 + 4 * CG + m * CG;
+          chn[m] = cl[c < K ? c : K - 1];
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int c = c0 + m * CG;
+        *reinterpret_cast<pair_t*>(&s_x[(c < K ? c : K - 1) * kSjChunk + part * 2])
+            = xv[m];
+      }
+      if (c0 + 4 * CG < K) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          ch[m] = chn[m];
+      }
+    }
+    if (bn >= 0) // the next block's chunk numbers: back by the time they are used
+      request_chunks(bn);
+    __syncthreads();
+    if (have) {
+      const int32_t mylen = lp >> 6;
+      const T* vb = A.val + a_b;
+      const int64_t off = (int64_t)sbase - a_b;
+      const int64_t last = (int64_t)e_b - a_b - 1; // (a block without entries:
+      T sum;                                       //  its slices load nothing)
+      if (wide) {
+        const uint32_t* cb = reinterpret_cast<const uint32_t*>(A.codes + 4 * (int64_t)a_b);
+        sum = sj_slice<T, uint32_t, true>(vb, cb, off, last, mylen, lane, s_x, in);
+      } else {
+        const uint16_t* cb = reinterpret_cast<const uint16_t*>(
+            A.codes + (A.wide_alloc ? 4 : 2) * (int64_t)a_b);
+        sum = sj_slice<T, uint16_t, false>(vb, cb, off, last, mylen, lane, s_x, in);
+      }
+      if (myrow < A.num_rows && in_slice) {
+        const T c = alpha * sum;
+        T y = c;
+        if (beta != T(0))
+          y = c + beta * y0;
+        out[myrow] = y;
+        if constexpr (DOT)
+          dot_acc += (double)x_own * (double)c;
+      }
+    }
+  }
+  if constexpr (DOT) {
+    // the workgroup's partial (fixed tree: deterministic), the array's unused
+    // tail cleared -- spmv_dot_epilogue for WPB waves
+    double v = dot_acc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+      v += __shfl_down(v, o, 64);
+    if (lane == 0)
+      s_red[wave] = v;
+    __syncthreads();
+    if (t == 0) {
+      double r = 0.0;
+#pragma unroll
+      for (int w = 0; w < WPB; ++w)
+        r += s_red[w];
+      dot.partials[blockIdx.x] = r;
+    }
+    for (int i = gridDim.x + blockIdx.x * NT + t; i < dot.len; i += gridDim.x * NT)
+      dot.partials[i] = 0.0;
+  }
+}
+
+struct SjStats {
+  int64_t maxk = 0, sumk = 0, far = 0, far_blocks = 0;
+};
+
+template <int R>
+int sj_count(spmv_hip_csr_plan* pl, const int32_t* rowptr, const int32_t* colind,
+             int kcap, int long_thr, int32_t* d_k, int32_t* d_far,
+             int64_t* d_stats, SjStats* st, hipStream_t stream)
+{
+  const int nblk = (pl->num_rows + R - 1) / R;
+  const int grid = spmv_grid_for(pl->ctx, nblk, 1);
+  hipLaunchKernelGGL((sj_count_kernel<R>), dim3(grid), dim3(kBlock), 0, stream,
+                     pl->num_rows, pl->num_cols, rowptr, colind, kcap, long_thr, d_k,
+                     d_far);
+  SPMV_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sj_stats_kernel, dim3(1), dim3(1024), 0, stream, nblk, d_k,
+                     d_far, d_stats);
+  SPMV_CHECK_LAUNCH();
+  int64_t h[4] = {0, 0, 0, 0};
+  SPMV_CHECK_HIP(hipMemcpyAsync(h, d_stats, sizeof(h), hipMemcpyDeviceToHost, stream));
+  SPMV_CHECK_HIP(hipStreamSynchronize(stream));
+  st->maxk = h[0];
+  st->sumk = h[1];
+  st->far = h[2];
+  st->far_blocks = h[3];
+  return SPMV_HIP_OK;
+}
+
+// workgroups of a CU that fit `lds` bytes each, and the waves they bring
+int sj_wgs_per_cu(int wpb, int64_t lds)
+{
+  int wgs = (int)((160 * 1024 - 2048) / (lds > 1 ? lds : 1));
+  const int by_waves = 32 / wpb;
+  wgs = wgs < by_waves ? wgs : by_waves;
+  return wgs < 1 ? 1 : wgs;
+}
+
+template <typename T, int WPB, bool DOT>
+int sj_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
+              T beta, T* out, DotOut dot)
+{
+  SjArgs<T> A;
+  A.num_rows = pl->num_rows;
+  A.num_cols = pl->num_cols;
+  A.nblk = pl->sj_nblk;
+  A.maxk = pl->sj_maxk;
+  A.stride = pl->sj_stride;
+  A.wide_alloc = pl->sj_wide_alloc;
+  A.rowptr = pl->rowptr0;
+  A.lenperm = pl->sj_lenperm;
+  A.blk = pl->sj_blk;
+  A.chunks = pl->sj_chunks;
+  A.codes = pl->sj_codes;
+  A.val = static_cast<const T*>(pl->sj_val);
+  A.nlong = pl->sj_nlong;
+  A.long_rows = pl->sj_long_rows;
+  A.colind = pl->colind0;
+  A.values = static_cast<const T*>(pl->sj_values0);
+  const size_t lds = (size_t)pl->sj_maxk * kSjChunk * sizeof(T) + 16;
+  int wgs = pl->sj_blocks_per_cu > 0 ? pl->sj_blocks_per_cu
+                                     : sj_wgs_per_cu(WPB, (int64_t)lds + 64);
+  int grid = pl->ctx->num_cus * wgs;
+  if (grid > pl->ctx->dot_blocks)
+    grid = pl->ctx->dot_blocks;
+  if (grid > pl->sj_nblk)
+    grid = pl->sj_nblk;
+  if (grid >= 8)
+    grid -= grid % 8; // slots it with equal it % 8 stay on one XCD
+  if (grid < 1)
+    grid = 1;
+  RowBlockOrder ord;
+  ord.table = nullptr;
+  ord.num_slots = 0;
+  ord.xcd_group = grid >= 8 ? pl->sj_xcd_group : 0;
+  ord.num_row_blocks = pl->sj_nblk;
+  ord.nt_store = 0;
+  hipLaunchKernelGGL((csr_sjds_kernel<T, WPB, DOT>), dim3(grid), dim3(64 * WPB),
+                     lds, st, A, alpha, in, beta, out, dot, ord);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+template <typename T, bool DOT>
+int sj_run(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
+           T beta, T* out, DotOut dot)
+{
+  switch (pl->sj_wpb) {
+  case 4: return sj_launch<T, 4, DOT>(pl, st, alpha, in, beta, out, dot);
+  case 8: return sj_launch<T, 8, DOT>(pl, st, alpha, in, beta, out, dot);
+  default: return sj_launch<T, 16, DOT>(pl, st, alpha, in, beta, out, dot);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void sj_row_len_kernel(
+    int count, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rows,
+    int32_t* __restrict__ len)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += gridDim.x * blockDim.x)
+    len[i] = rowptr[rows[i] + 1] - rowptr[rows[i]];
+}
+
+struct SjIsLong {
+  const int32_t* rowptr;
+  int thr;
+  __device__ bool operator()(int i) const
+  {
+    return rowptr[i + 1] - rowptr[i] > thr;
+  }
+};
+struct SjLongCount {
+  const int32_t* rowptr;
+  int thr;
+  __device__ int operator()(int i) const
+  {
+    return rowptr[i + 1] - rowptr[i] > thr ? 1 : 0;
+  }
+};
+
+// ascending list of the rows longer than thr (SPMV_HIP_ENOMEM: no memory)
+int sj_build_long_list(spmv_hip_csr_plan* pl, const int32_t* rowptr, int thr,
+                       hipStream_t st)
+{
+  const int n = pl->num_rows;
+  hipcub::CountingInputIterator<int32_t> first(0);
+  hipcub::TransformInputIterator<int, SjLongCount,
+                                 hipcub::CountingInputIterator<int32_t>>
+      ones(first, SjLongCount{rowptr, thr});
+  int32_t* d_count = nullptr;
+  void* tmp = nullptr;
+  size_t tb = 0, tb2 = 0;
+  int32_t count = 0;
+  hipError_t e = hipMalloc(&d_count, sizeof(int32_t));
+  if (e == hipSuccess)
+    e = hipcub::DeviceReduce::Sum(nullptr, tb, ones, d_count, n, st);
+  if (e == hipSuccess)
+    e = hipMalloc(&tmp, tb ? tb : 16);
+  if (e == hipSuccess)
+    e = hipcub::DeviceReduce::Sum(tmp, tb, ones, d_count, n, st);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(&count, d_count, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st);
+  (void)hipFree(tmp);
+  tmp = nullptr;
+  if (e == hipSuccess && count > 0) {
+    e = hipMalloc(&pl->sj_long_rows, sizeof(int32_t) * (size_t)count);
+    SjIsLong pred{rowptr, thr};
+    if (e == hipSuccess)
+      e = hipcub::DeviceSelect::If(nullptr, tb2, first, pl->sj_long_rows, d_count, n,
+                                   pred, st);
+    if (e == hipSuccess)
+      e = hipMalloc(&tmp, tb2 ? tb2 : 16);
+    if (e == hipSuccess)
+      e = hipcub::DeviceSelect::If(tmp, tb2, first, pl->sj_long_rows, d_count, n,
+                                   pred, st);
+    if (e == hipSuccess)
+      e = hipStreamSynchronize(st);
+    // ... sorted by length, descending (stable: ties keep the row order), so
+    // that the eight rows a wave takes together end together
+    int32_t *d_len = nullptr, *d_len2 = nullptr, *d_rows2 = nullptr;
+    void* tmp2 = nullptr;
+    size_t tb3 = 0;
+    if (e == hipSuccess)
+      e = hipMalloc(&d_len, sizeof(int32_t) * (size_t)count);
+    if (e == hipSuccess)
+      e = hipMalloc(&d_len2, sizeof(int32_t) * (size_t)count);
+    if (e == hipSuccess)
+      e = hipMalloc(&d_rows2, sizeof(int32_t) * (size_t)count);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(sj_row_len_kernel, dim3(spmv_grid_for(pl->ctx, count, kBlock)),
+                         dim3(kBlock), 0, st, count, rowptr, pl->sj_long_rows, d_len);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+      e = hipcub::DeviceRadixSort::SortPairsDescending(
+          nullptr, tb3, d_len, d_len2, pl->sj_long_rows, d_rows2, count, 0, 32, st);
+    if (e == hipSuccess)
+      e = hipMalloc(&tmp2, tb3 ? tb3 : 16);
+    if (e == hipSuccess)
+      e = hipcub::DeviceRadixSort::SortPairsDescending(
+          tmp2, tb3, d_len, d_len2, pl->sj_long_rows, d_rows2, count, 0, 32, st);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(pl->sj_long_rows, d_rows2, sizeof(int32_t) * (size_t)count,
+                         hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess)
+      e = hipStreamSynchronize(st);
+    (void)hipFree(d_len);
+    (void)hipFree(d_len2);
+    (void)hipFree(d_rows2);
+    (void)hipFree(tmp2);
+  }
+  (void)hipFree(tmp);
+  (void)hipFree(d_count);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? SPMV_HIP_ENOMEM : static_cast<int>(e);
+  }
+  pl->sj_nlong = count;
+  return SPMV_HIP_OK;
+}
+
+template <typename T>
+int sj_bake(spmv_hip_csr_plan* pl, const T* values, hipStream_t st)
+{
+  SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
+  if (values == nullptr) { // drop the copy
+    SPMV_CHECK_HIP(hipDeviceSynchronize());
+    (void)hipFree(pl->sj_val);
+    pl->sj_val = nullptr;
+    pl->sj_values0 = nullptr;
+    pl->sj_elem = 0;
+    return SPMV_HIP_OK;
+  }
+  if (!pl->sj_lenperm || pl->symmetric || pl->nnz == 0)
+    return SPMV_HIP_ENOTSUP;
+  const auto t_begin = std::chrono::steady_clock::now();
+  if (pl->sj_val && pl->sj_elem != (int)sizeof(T)) {
+    SPMV_CHECK_HIP(hipDeviceSynchronize());
+    (void)hipFree(pl->sj_val);
+    pl->sj_val = nullptr;
+  }
+  if (!pl->sj_val) {
+    const hipError_t e = hipMalloc(&pl->sj_val, sizeof(T) * (size_t)pl->nnz);
+    if (e != hipSuccess) {
+      pl->sj_val = nullptr;
+      (void)hipGetLastError();
+      return e == hipErrorOutOfMemory ? SPMV_HIP_ENOTSUP : static_cast<int>(e);
+    }
+  }
+  const int64_t nsl = ((int64_t)pl->num_rows + 63) / 64;
+  const int grid = spmv_grid_for(pl->ctx, nsl, kBlock / 64);
+  hipLaunchKernelGGL((sj_bake_kernel<T>), dim3(grid), dim3(kBlock), 0, st,
+                     pl->num_rows, pl->rowptr0, pl->sj_lenperm, values,
+                     static_cast<T*>(pl->sj_val));
+  SPMV_CHECK_LAUNCH();
+  SPMV_CHECK_HIP(hipStreamSynchronize(st));
+  pl->sj_elem = (int)sizeof(T);
+  pl->sj_values0 = values;
+  pl->sj = 1;
+  pl->plan_us += (int)std::chrono::duration_cast<std::chrono::microseconds>(
+                     std::chrono::steady_clock::now() - t_begin)
+                     .count();
+  return SPMV_HIP_OK;
+}
+
+} // namespace
+
+void spmv_sjds_free(spmv_hip_csr_plan* pl)
+{
+  (void)hipFree(pl->sj_lenperm);
+  (void)hipFree(pl->sj_blk);
+  (void)hipFree(pl->sj_chunks);
+  (void)hipFree(pl->sj_codes);
+  (void)hipFree(pl->sj_val);
+  (void)hipFree(pl->sj_long_rows);
+  pl->sj_long_rows = nullptr;
+  pl->sj_nlong = 0;
+  pl->sj_lenperm = pl->sj_blk = pl->sj_chunks = nullptr;
+  pl->sj_codes = nullptr;
+  pl->sj_val = nullptr;
+  pl->sj_values0 = nullptr;
+  pl->sj = pl->sj_elem = 0;
+}
+
+// Build the structure (everything but the values).  wpb_force: 4, 8, 16, or 0
+// = choose.  Leaves the plan without the form (SPMV_HIP_OK) when it does not
+// pay: no memory, or most entries far.
+int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
+                    const int32_t* colind, int wpb_force)
+{
+  SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
+  hipStream_t st = pl->ctx->stream;
+  const int n = pl->num_rows;
+  if (n < 64 || pl->nnz < 1)
+    return SPMV_HIP_OK;
+  const int kcap = pl->ctx->sj_max_chunks;
+  // long rows: more than four times the average length, and more than 96
+  int thr = (int)(pl->nnz * 4 / n);
+  thr = thr > kSjLongMin ? thr : kSjLongMin;
+  const int nblk4 = (n + 255) / 256;
+  int32_t *d_k = nullptr, *d_far = nullptr;
+  int64_t* d_stats = nullptr;
+  hipError_t e = hipMalloc(&d_k, sizeof(int32_t) * (size_t)nblk4);
+  if (e == hipSuccess)
+    e = hipMalloc(&d_far, sizeof(int32_t) * (size_t)nblk4);
+  if (e == hipSuccess)
+    e = hipMalloc(&d_stats, sizeof(int64_t) * 4);
+  auto cleanup = [&]() {
+    (void)hipFree(d_k);
+    (void)hipFree(d_far);
+    (void)hipFree(d_stats);
+  };
+  if (e != hipSuccess) {
+    cleanup();
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? SPMV_HIP_OK : static_cast<int>(e);
+  }
+  // Candidates: 4, 8 or 16 slices share one staged copy of x.  More rows per
+  // copy = fewer staged bytes per entry, but a larger copy (fewer workgroups
+  // per CU) and more rows waiting at each of the block's two barriers.  Cost =
+  // bytes per entry: the matrix stream, the staged chunks (L2 traffic, priced
+  // at a third), a 64-byte sector per far entry; a candidate that leaves a CU
+  // fewer than 16 waves pays in proportion.
+  const int cand[3] = {4, 8, 16};
+  int best = 0;
+  double best_cost = 0.0;
+  SjStats best_st;
+  for (int ci = 0; ci < 3; ++ci) {
+    const int wpb = cand[ci];
+    if (wpb_force && wpb != wpb_force)
+      continue;
+    if (!wpb_force && n < 64 * wpb * 8) // too few blocks for this size
+      continue;
+    SjStats s;
+    int rc;
+    if (wpb == 4)
+      rc = sj_count<256>(pl, rowptr, colind, kcap, thr, d_k, d_far, d_stats, &s, st);
+    else if (wpb == 8)
+      rc = sj_count<512>(pl, rowptr, colind, kcap, thr, d_k, d_far, d_stats, &s, st);
+    else
+      rc = sj_count<1024>(pl, rowptr, colind, kcap, thr, d_k, d_far, d_stats, &s, st);
+    if (rc != SPMV_HIP_OK) {
+      cleanup();
+      return rc;
+    }
+    const int64_t lds = s.maxk * kSjChunk * 8 + 128;
+    const int waves = sj_wgs_per_cu(wpb, lds) * wpb;
+    double cost = (s.far > 0 ? 12.0 : 10.0)
+                  + (double)s.sumk * 128.0 / 3.0 / (double)pl->nnz
+                  + 64.0 * (double)s.far / (double)pl->nnz;
+    if (waves < 16)
+      cost *= 16.0 / waves;
+    if (!best || cost < best_cost) {
+      best = wpb;
+      best_cost = cost;
+      best_st = s;
+    }
+  }
+  if (!best) // a matrix too small for any candidate: the smallest
+    best = wpb_force ? wpb_force : 4;
+  {
+    // the per-block far counts the fill pass reads must be the chosen
+    // candidate's: count it (again) last
+    const int rc
+        = best == 4
+              ? sj_count<256>(pl, rowptr, colind, kcap, thr, d_k, d_far, d_stats, &best_st, st)
+          : best == 8
+              ? sj_count<512>(pl, rowptr, colind, kcap, thr, d_k, d_far, d_stats, &best_st, st)
+              : sj_count<1024>(pl, rowptr, colind, kcap, thr, d_k, d_far, d_stats,
+                               &best_st, st);
+    if (rc != SPMV_HIP_OK) {
+      cleanup();
+      return rc;
+    }
+  }
+  // nearly all entries far: the form buys nothing
+  if (best_st.far * 10 > pl->nnz * 9 && !wpb_force) {
+    cleanup();
+    return SPMV_HIP_OK;
+  }
+  const int R = 64 * best;
+  const int nblk = (n + R - 1) / R;
+  const int stride = best_st.maxk > 0 ? (int)((best_st.maxk + 7) / 8 * 8) : 8;
+  const int wide_alloc = best_st.far > 0 ? 1 : 0;
+  const size_t n_pad = (size_t)((n + 63) / 64) * 64;
+  e = hipMalloc(&pl->sj_blk, sizeof(int32_t) * 2 * (size_t)nblk);
+  if (e == hipSuccess)
+    e = hipMalloc(&pl->sj_chunks, sizeof(int32_t) * (size_t)nblk * stride);
+  if (e == hipSuccess)
+    e = hipMalloc(&pl->sj_lenperm, sizeof(int32_t) * n_pad);
+  if (e == hipSuccess)
+    e = hipMalloc(&pl->sj_codes, (size_t)(wide_alloc ? 4 : 2) * (size_t)pl->nnz + 16);
+  if (e == hipSuccess) {
+    const int grid = spmv_grid_for(pl->ctx, nblk, 1);
+#define SJ_FILL(RR)                                                            \
+  hipLaunchKernelGGL((sj_fill_kernel<RR>), dim3(grid), dim3(kBlock), 0, st, n,  \
+                     pl->num_cols, rowptr, colind, kcap, thr, stride,          \
+                     wide_alloc,                                               \
+                     d_far, pl->sj_blk, pl->sj_chunks, pl->sj_lenperm,         \
+                     pl->sj_codes)
+    if (best == 4)
+      SJ_FILL(256);
+    else if (best == 8)
+      SJ_FILL(512);
+    else
+      SJ_FILL(1024);
+#undef SJ_FILL
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st);
+  cleanup();
+  if (e != hipSuccess) {
+    spmv_sjds_free(pl);
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? SPMV_HIP_OK : static_cast<int>(e);
+  }
+  {
+    const int rc = sj_build_long_list(pl, rowptr, thr, st);
+    if (rc != SPMV_HIP_OK) {
+      spmv_sjds_free(pl);
+      return rc == SPMV_HIP_ENOMEM ? SPMV_HIP_OK : rc;
+    }
+  }
+  pl->sj_long_thr = thr;
+  pl->sj_wpb = best;
+  pl->sj_nblk = nblk;
+  pl->sj_maxk = (int)best_st.maxk > 0 ? (int)best_st.maxk : 1;
+  pl->sj_stride = stride;
+  pl->sj_wide_alloc = wide_alloc;
+  pl->sj_far = best_st.far;
+  pl->sj_sumk = best_st.sumk;
+  return SPMV_HIP_OK;
+}
+
+int spmv_sjds_bake_f64(spmv_hip_csr_plan* pl, const double* values, hipStream_t st)
+{
+  return sj_bake<double>(pl, values, st);
+}
+int spmv_sjds_bake_f32(spmv_hip_csr_plan* pl, const float* values, hipStream_t st)
+{
+  return sj_bake<float>(pl, values, st);
+}
+
+int spmv_sjds_run_f64(const spmv_hip_csr_plan* pl, hipStream_t st, double alpha,
+                      const double* in, double beta, double* out, DotOut dot)
+{
+  if (dot.partials)
+    return sj_run<double, true>(pl, st, alpha, in, beta, out, dot);
+  return sj_run<double, false>(pl, st, alpha, in, beta, out, dot);
+}
+
+int spmv_sjds_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st, float alpha,
+                      const float* in, float beta, float* out)
+{
+  return sj_run<float, false>(pl, st, alpha, in, beta, out, DotOut());
+}

@@ -566,6 +566,127 @@ def test_unstructured_generator_matches_numpy_twin(ctx):
                  1, None)
 
 
+# ---------------------------------------------------------------------------
+# Sliced jagged form (spmv_sjds.hip): ragged / long rows, x staged in LDS
+# ---------------------------------------------------------------------------
+@pytest.fixture()
+def sj_ctx():
+    c = hip.Context(0)
+    c.set_option("sj_min_nnz", 0)       # build the form for small matrices too
+    c.set_option("lx_min_nnz", 1 << 62)  # ... instead of the LX form
+    c.set_option("lat_min_nnz", 1 << 62)
+    yield c
+    c.close()
+
+
+def _sj_cases():
+    rng = np.random.default_rng(0x5EED0042)
+    cases = {}
+    # random ragged matrices: unsorted, repeated columns, empty rows, rows far
+    # longer than a slice is wide (the wave takes them over), rectangular
+    for name, (nr, nc, avg, nlong, llen) in dict(
+            tiny=(64, 64, 3, 0, 0), ragged=(1500, 1500, 9, 2, 700),
+            long_rows=(700, 5000, 20, 3, 5000), wide=(4000, 900, 40, 1, 100),
+            dense_rows=(300, 300, 120, 0, 0), odd=(1027, 3001, 6, 5, 130)).items():
+        cases[name] = random_csr(rng, nr, nc, avg, long_rows=nlong, long_len=llen)
+    # FEM-like: clusters around the diagonal (everything staged, 16-bit codes)
+    cases["fem"] = poisson.fem_like_csr(6000, jitter=64, layer=400)
+    cases["fem_tail"] = poisson.fem_like_csr(9000, jitter=64, layer=500,
+                                             tail_permille=20, tail_min=100,
+                                             tail_max=900, tail_stride=4)
+    # columns spread over 3 M: beyond the plan's bitmap span -> far entries
+    rp, ci, va = random_csr(rng, 2000, 3_000_000, 8)
+    near = rng.random(len(ci)) < 0.7  # ... the rest near enough to be staged
+    ci[near] = rng.integers(0, 4000, int(near.sum())).astype(np.int32)
+    cases["far"] = (rp, ci, va)
+    return cases
+
+
+@pytest.mark.parametrize("wpb", [4, 8, 16, 0])
+def test_sliced_jagged_form_bit_exact(sj_ctx, wpb):
+    """csr_sjds_kernel against oracle.csr_spmv (csr_kernels.cpp:41-51), every
+    element identical: slices of 4 / 8 / 16 waves (0 = the plan's choice),
+    staged and far entries (a chunk budget of 8 forces most entries far),
+    alpha / beta, fused dot, fp32; other value arrays than the baked one and a
+    dropped copy take the CSR-order kernels."""
+    ctx = sj_ctx
+    ctx.set_option("sj_wpb", wpb)
+    part = ctx.empty(ctx.dot_partials_len, np.float64)
+    for name, (rp, ci, va) in _sj_cases().items():
+        nr = len(rp) - 1
+        nc = int(ci.max()) + 1 if len(ci) else 1
+        nc = {"long_rows": 5000, "wide": 900, "odd": 3001,
+              "far": 3_000_000}.get(name, max(nc, nr))
+        rng = np.random.default_rng(len(ci))
+        x = rng.uniform(-1, 1, nc)
+        y0 = rng.uniform(-1, 1, nr)
+        # (left to choose, the plan does not build the form when most entries
+        # would be far)
+        for budget in ((448, 8) if wpb else (448,)):
+            ctx.set_option("sj_max_chunks", budget)
+            blk = hip.CsrBlock(ctx, nr, nc, rp, ci, va, None, False)
+            assert blk.get("sj_built") == 1 and blk.get("sjds") == 0, name
+            blk.bake()
+            assert blk.get("sjds") == 1 and blk.get("lx") == 0
+            if wpb:
+                assert blk.get("sj_wpb") == wpb
+            if name == "far" or (budget == 8 and nc > 1000):
+                assert blk.get("sj_far_permille") > 0 and blk.get("sj_wide") == 1
+            if name == "fem" and budget == 448:
+                assert blk.get("sj_far_permille") == 0 and blk.get("sj_wide") == 0
+            if name == "fem_tail" and budget == 448:
+                # the long rows stay out of the slices (one wave each): the
+                # short rows are staged entirely
+                assert blk.get("sj_far_permille") == 0 and blk.get("sj_wide") == 0
+                assert blk.get("sj_long_rows") > 50
+            if name in ("ragged", "long_rows", "odd"):
+                assert blk.get("sj_long_rows") >= 2
+            dx = ctx.upload(x)
+            for alpha, beta in ((1.0, 0.0), (-0.75, 0.0), (2.5, -0.5)):
+                y_ref = oracle.csr_spmv(rp, ci, va, x, alpha, beta, y0)
+                dy = ctx.upload(np.full(nr, np.nan) if beta == 0 else y0)
+                dot = beta == 0 and nr == nc
+                blk.mult(alpha, dx.ptr, beta, dy.ptr,
+                         dot_partials=part.ptr if dot else None)
+                assert np.array_equal(dy.numpy(), y_ref), (name, budget, alpha)
+                if dot:
+                    want = float(np.dot(x, alpha * oracle.csr_spmv(rp, ci, va, x)))
+                    got = float(np.sum(part.numpy()))
+                    assert abs(got - want) <= 1e-11 * (np.abs(x) @ np.abs(y_ref) + 1)
+                dy.free()
+            # the plan's copy is tied to the array it was made from
+            other = ctx.upload(2.0 * va)
+            keep, blk.values = blk.values, other
+            dy = ctx.upload(np.full(nr, np.nan))
+            blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+            assert np.array_equal(dy.numpy(), oracle.csr_spmv(rp, ci, 2.0 * va, x))
+            blk.values = keep
+            blk.bake(drop=True)
+            assert blk.get("sjds") == 0 and blk.get("sj_built") == 1
+            blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+            assert np.array_equal(dy.numpy(), oracle.csr_spmv(rp, ci, va, x))
+            for b in (dx, dy, other):
+                b.free()
+            blk.free()
+        ctx.set_option("sj_max_chunks", 448)
+    part.free()
+    # fp32
+    rp, ci, va = poisson.fem_like_csr(5000, jitter=64, layer=300, tail_permille=30,
+                                      tail_min=70, tail_max=400, tail_stride=2)
+    va32 = va.astype(np.float32)
+    x32 = np.random.default_rng(3).uniform(-1, 1, 5000).astype(np.float32)
+    blk = hip.CsrBlock(ctx, 5000, 5000, rp, ci, va32, None, False,
+                       dtype=np.float32)
+    blk.bake()
+    assert blk.get("sjds") == 1
+    dx, dy = ctx.upload(x32), ctx.upload(np.full(5000, np.nan, np.float32))
+    blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+    assert np.array_equal(dy.numpy(), oracle.csr_spmv(rp, ci, va32, x32))
+    for b in (dx, dy):
+        b.free()
+    blk.free()
+
+
 FEM_KINDS = {"fem": dict(), "fem_tail": dict(tail_permille=10),
              "fem81": dict(min_len=81, max_len=81),
              "fem_odd": dict(min_len=1, max_len=9, jitter=8, layer=50,
