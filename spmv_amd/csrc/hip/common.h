@@ -52,6 +52,8 @@ struct spmv_hip_ctx {
   int sj_max_chunks = 448;
   // ... with this many slices per block ("sj_wpb": 4, 8, 16; 0 = choose)
   int sj_wpb = 0;
+  // ... and this many entries per lane and step ("sj_unit": 1, 2, 4; 0 = choose)
+  int sj_unit = 0;
   // the device Poisson generator's non-symmetric variant ("poisson_skew_ppm":
   // lower neighbours -1 - s, upper -1 + s, s = value * 1e-6; 0 = the Poisson
   // matrix).  For measurements of kernels on matrices that are not symmetric.

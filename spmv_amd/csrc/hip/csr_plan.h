@@ -292,11 +292,15 @@ struct spmv_hip_csr_plan {
   const void* sj_values0 = nullptr;
   int sj_elem = 0;               // sizeof the baked value type
   int sj = 0;                    // use it (plan_set "sjds")
+  uint32_t* sj_ubase = nullptr;  // first unit of every slice (+ the total)
+  int sj_unit = 1;               // entries per lane and step (1, 2, 4)
+  int64_t sj_units = 0;          // units in the jagged arrays
   int sj_wpb = 0;                // slices (waves) per block: 4, 8, 16
   int sj_nblk = 0, sj_maxk = 0, sj_stride = 0, sj_wide_alloc = 0;
   int64_t sj_far = 0, sj_sumk = 0; // entries gathered from memory; staged chunks
   int32_t* sj_long_rows = nullptr; // rows the slices leave out (one wave each)
   int sj_nlong = 0, sj_long_thr = 0;
+  int sj_phases = 3;             // measurement only: 1 = long rows, 2 = slices
   int sj_blocks_per_cu = 0;      // 0 = what the LDS footprint allows
   int sj_xcd_group = 8;          // consecutive blocks per XCD (0 = off)
   int32_t* row_list = nullptr; // ROWLIST: device list of non-empty rows
@@ -457,7 +461,7 @@ int spmv_wdia_run_f32f64(const spmv_hip_csr_plan* pl, hipStream_t st,
                          double* out, DotOut dot);
 // spmv_sjds.hip
 int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
-                    const int32_t* colind, int wpb_force);
+                    const int32_t* colind, int wpb_force, int unit_force);
 void spmv_sjds_free(spmv_hip_csr_plan* pl);
 int spmv_sjds_bake_f64(spmv_hip_csr_plan* pl, const double* values,
                        hipStream_t st); // values == nullptr: drop the copy

@@ -147,6 +147,11 @@ int spmv_hip_ctx_set_option(spmv_hip_ctx* ctx, const char* key, int64_t value)
     ctx->sj_wpb = (int)value;
     return SPMV_HIP_OK;
   }
+  if (!strcmp(key, "sj_unit")) {
+    SPMV_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4);
+    ctx->sj_unit = (int)value;
+    return SPMV_HIP_OK;
+  }
   if (!strcmp(key, "bake_general")) {
     SPMV_REQUIRE(value == 0 || value == 1);
     ctx->bake_general = (int)value;

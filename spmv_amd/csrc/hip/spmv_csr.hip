@@ -1365,7 +1365,7 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
     // structure now, the values with plan_bake_values.
     if (rc == SPMV_HIP_OK && !pl->lat && !pl->lx
         && num_non_zeros >= ctx->sj_min_nnz)
-      rc = spmv_sjds_build(pl, rowptr, colind, ctx->sj_wpb);
+      rc = spmv_sjds_build(pl, rowptr, colind, ctx->sj_wpb, ctx->sj_unit);
     if (rc != SPMV_HIP_OK) {
       spmv_hip_csr_plan_destroy(pl);
       return rc;
@@ -1572,6 +1572,9 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
   } else if (!strcmp(key, "sjds")) {
     SPMV_REQUIRE(value == 0 || plan->sj_val);
     plan->sj = value != 0;
+  } else if (!strcmp(key, "sj_phases")) { // ablation for measurements only
+    SPMV_REQUIRE(value >= 1 && value <= 3);
+    plan->sj_phases = value;
   } else if (!strcmp(key, "sj_blocks_per_cu")) {
     SPMV_REQUIRE(value >= 0 && value <= kBlocksPerCU);
     plan->sj_blocks_per_cu = value;
@@ -1694,6 +1697,8 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
     *value = plan->sj_lenperm ? 1 : 0;
   else if (!strcmp(key, "sj_wpb"))
     *value = plan->sj_lenperm ? plan->sj_wpb : 0;
+  else if (!strcmp(key, "sj_unit"))
+    *value = plan->sj_lenperm ? plan->sj_unit : 0;
   else if (!strcmp(key, "sj_max_chunks"))
     *value = plan->sj_lenperm ? plan->sj_maxk : 0;
   else if (!strcmp(key, "sj_far_permille"))
@@ -1744,9 +1749,10 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
     if (plan->sj_lenperm)
       b += 4 * ((n + 63) / 64 * 64) + 8 * (int64_t)plan->sj_nblk
            + 4 * (int64_t)plan->sj_nblk * plan->sj_stride
-           + (plan->sj_wide_alloc ? 4 : 2) * nnz + 4 * (int64_t)plan->sj_nlong;
+           + (plan->sj_wide_alloc ? 4 : 2) * plan->sj_units * plan->sj_unit
+           + 4 * (int64_t)plan->sj_nlong + 4 * ((n + 63) / 64 + 1);
     if (plan->sj_val)
-      b += (int64_t)plan->sj_elem * nnz;
+      b += (int64_t)plan->sj_elem * plan->sj_units * plan->sj_unit;
     if (plan->t_ptr)
       b += 4 * (n + 1) + 8 * nnz;
     if (plan->zw_table)

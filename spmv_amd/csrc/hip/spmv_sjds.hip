@@ -13,12 +13,15 @@
 //     plan's own copy of the values; spmv_hip_csr_plan_values_changed after an
 //     update in place) in slices of 64 consecutive rows, each slice stored as
 //     jagged diagonals: the slice's rows sorted by length (descending, stable),
-//     then entry k of every row that has one, side by side.  Step k of a wave
-//     is one coalesced load of the values and one of the column codes by the
-//     first cnt_k lanes; nothing is padded, the arrays have exactly nnz
-//     entries and a slice occupies the span of its rows in CSR.  A lane adds
-//     its own row's products in the row's order: the bits of the reference
-//     loop, no LDS parking of products, no barrier inside a slice.
+//     then UNIT k (E = 1, 2 or 4 consecutive entries) of every row that has
+//     one, side by side.  Step k of a wave is one coalesced load of the values
+//     (8 E bytes per lane) and one of the column codes by the first cnt_k
+//     lanes; rows are padded to whole units only.  A lane adds its own row's
+//     products in the row's order: the bits of the reference loop, no LDS
+//     parking of products, no barrier inside a slice.  The step's address is
+//     scalar arithmetic (slice base + units so far) plus a constant per-lane
+//     offset: what limited the first version of this kernel was the number of
+//     vector instructions per entry, not bytes.
 //   * x comes from LDS.  Per block of WPB slices (256, 512 or 1024 rows) the
 //     plan lists the 16-column chunks (128 B) of x the block's entries touch
 //     -- up to 448 of them, nearest to the diagonal first -- and rewrites every
@@ -28,11 +31,13 @@
 //     rows of the block; the gather becomes an LDS read.
 //   * long rows.  A row with more than four times the average length (and
 //     more than 96 entries) stays out of the slices: the kernel's first phase
-//     gives each such row to one WAVE, which streams it from the caller's CSR
-//     arrays 64 entries at a time (two loads ahead), multiplies in parallel
-//     and adds the products to the row's sum one by one in order (v_readlane
-//     + add) -- the reference's bits.  Inside a slice the same take-over
-//     happens past the second-longest row, where only lane 0 is still active.
+//     gives eight such rows to one wave, eight lanes each, streamed from the
+//     caller's CSR arrays (values and columns two load groups ahead, x one);
+//     a group's eight products are added to the row's sum one by one in the
+//     row's order -- the reference's bits.  The rows are taken in ROW order
+//     (neighbours share their x lines in the L2), sorted by length only inside
+//     runs of 64.  Inside a slice, past the second-longest row, the wave takes
+//     over lane 0's row 64 entries at a time (v_readlane + add).
 //
 // Bytes per launch: nnz * (8 + 2) + rows * (4 + 8) + x (+ the chunk lists)
 // against CSR's nnz * 12 + rows * 12 + x.
@@ -48,12 +53,21 @@ namespace
 constexpr int kSjChunk = 16;       // columns per staged chunk
 constexpr int kSjSpanWords = 2048; // bitmap words of the plan analysis: 65,536
                                    // chunks = 2^20 columns around the block
-constexpr int kSjU = 8;            // steps per load group (two groups in flight)
+constexpr int kSjGroup = 8;        // entries per lane and load group (two groups
+                                   // in flight): 8 / E steps
 constexpr int kSjTailMin = 48;     // entries past the second-longest row from
                                    // which the wave takes lane 0's row over
 constexpr int kSjLongMin = 96;     // LONG rows: more than 4 x the average and
                                    // more than this many entries
 constexpr uint32_t kSjLongFlag = 0x80000000u; // ... marked in their lenperm word
+constexpr int kSjSlack = 128;      // units of slack behind the jagged arrays: a
+                                   // step past a slice's end reads, never uses
+
+// E consecutive entries of a row: one aligned load
+template <typename X, int E>
+struct __attribute__((aligned(sizeof(X) * E))) SjUnit {
+  X e[E];
+};
 
 // ---------------------------------------------------------------------------
 // plan time
@@ -234,6 +248,29 @@ __global__ __launch_bounds__(1024) void sj_stats_kernel(
   }
 }
 
+// units (E entries each) every slice of 64 rows needs: its short rows, each
+// padded to whole units
+__global__ __launch_bounds__(kBlock) void sj_units_kernel(
+    int32_t num_rows, const int32_t* __restrict__ rowptr, int long_thr, int E,
+    uint32_t* __restrict__ units)
+{
+  const int lane = threadIdx.x & 63;
+  const int64_t nsl = ((int64_t)num_rows + 63) / 64;
+  const int64_t wid = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * kBlock) >> 6;
+  for (int64_t s = wid; s <= nsl; s += nw) { // (entry nsl: 0, the scan's total)
+    const int64_t row = s * 64 + lane;
+    int32_t len = (s < nsl && row < num_rows) ? rowptr[row + 1] - rowptr[row] : 0;
+    len = len > long_thr ? 0 : len;
+    uint32_t u = (uint32_t)((len + E - 1) / E);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+      u += __shfl_down(u, o, 64);
+    if (lane == 0)
+      units[s] = u;
+  }
+}
+
 // the slice's rows in jagged order: lane rho gets the row (0..63 within the
 // slice) with the rho-th largest length (ties: the lower row first)
 __device__ __forceinline__ void sj_sort_slice(int32_t len, int lane, int32_t* my_len,
@@ -259,12 +296,13 @@ __device__ __forceinline__ void sj_sort_slice(int32_t len, int lane, int32_t* my
 }
 
 // pass 2: chunk lists, the (length, row) word of every jagged lane, and the
-// column codes in jagged order
+// column codes in jagged order (ubase: first unit of every slice)
 template <int R>
 __global__ __launch_bounds__(kBlock) void sj_fill_kernel(
     int32_t num_rows, int32_t num_cols, const int32_t* __restrict__ rowptr,
-    const int32_t* __restrict__ colind, int kcap, int long_thr, int stride,
-    int wide_alloc, const int32_t* __restrict__ blk_far, int32_t* __restrict__ blk,
+    const int32_t* __restrict__ colind, int kcap, int long_thr, int E, int stride,
+    int wide_alloc, const int32_t* __restrict__ blk_far,
+    const uint32_t* __restrict__ ubase, int32_t* __restrict__ blk,
     int32_t* __restrict__ chunks, int32_t* __restrict__ lenperm,
     unsigned char* __restrict__ codes)
 {
@@ -299,7 +337,10 @@ __global__ __launch_bounds__(kBlock) void sj_fill_kernel(
       blk[2 * b] = sel.K;
       blk[2 * b + 1] = wide;
     }
-    const int64_t a_b = rowptr[r0];
+    // the block's codes start at entry E * ubase[first slice]: 16-bit codes, or
+    // 32-bit ones when the block has far entries (a plan with any wide block
+    // reserves 4 bytes per entry everywhere)
+    const int64_t a_b = (int64_t)ubase[r0 / 64] * E;
     uint16_t* c16 = reinterpret_cast<uint16_t*>(codes + (wide_alloc ? 4 : 2) * a_b);
     uint32_t* c32 = reinterpret_cast<uint32_t*>(codes + 4 * a_b);
     for (int sl = wave; sl < R / 64; sl += kBlock / 64) {
@@ -318,20 +359,28 @@ __global__ __launch_bounds__(kBlock) void sj_fill_kernel(
           = (int32_t)(((uint32_t)mylen << 6) | (uint32_t)myrow
                       | (my_long ? kSjLongFlag : 0u));
       const int32_t src0 = s0 + myrow < num_rows ? rowptr[s0 + myrow] : 0;
-      const int32_t maxlen = __shfl(mylen, 0, 64);
-      int64_t off = (int64_t)rowptr[s0] - a_b; // within the block's span
-      for (int32_t k = 0; k < maxlen; ++k) {
-        const bool act = k < mylen;
+      const int32_t myu = (mylen + E - 1) / E;
+      const int32_t maxu = __shfl(myu, 0, 64);
+      int64_t off = (int64_t)ubase[s0 / 64] * E - a_b; // entries, in the block
+      for (int32_t k = 0; k < maxu; ++k) {
+        const bool act = k < myu;
         const int cnt = __popcll(__ballot(act));
         if (act) {
-          const int32_t col = colind[src0 + k];
-          const int32_t idx = sj_index(sel, s_bits, s_pre, col);
-          if (wide)
-            c32[off + lane] = idx >= 0 ? (uint32_t)idx : (0x80000000u | (uint32_t)col);
-          else
-            c16[off + lane] = (uint16_t)idx;
+          for (int q = 0; q < E; ++q) {
+            int32_t idx = 0; // a unit's padding: a valid code, never used
+            int32_t col = 0;
+            if (k * E + q < mylen) {
+              col = colind[src0 + k * E + q];
+              idx = sj_index(sel, s_bits, s_pre, col);
+            }
+            const int64_t at = off + (int64_t)lane * E + q;
+            if (wide)
+              c32[at] = idx >= 0 ? (uint32_t)idx : (0x80000000u | (uint32_t)col);
+            else
+              c16[at] = (uint16_t)idx;
+          }
         }
-        off += cnt;
+        off += (int64_t)cnt * E;
       }
     }
     __syncthreads(); // the bitmap is reused by the next block
@@ -342,8 +391,8 @@ __global__ __launch_bounds__(kBlock) void sj_fill_kernel(
 template <typename T>
 __global__ __launch_bounds__(kBlock) void sj_bake_kernel(
     int32_t num_rows, const int32_t* __restrict__ rowptr,
-    const int32_t* __restrict__ lenperm, const T* __restrict__ values,
-    T* __restrict__ sval)
+    const int32_t* __restrict__ lenperm, const uint32_t* __restrict__ ubase, int E,
+    const T* __restrict__ values, T* __restrict__ sval)
 {
   const int lane = threadIdx.x & 63;
   const int64_t nsl = ((int64_t)num_rows + 63) / 64;
@@ -355,15 +404,30 @@ __global__ __launch_bounds__(kBlock) void sj_bake_kernel(
     const int32_t mylen = (int32_t)(((uint32_t)lp & ~kSjLongFlag) >> 6);
     const int32_t myrow = s0 + (lp & 63);
     const int64_t src0 = myrow < num_rows ? rowptr[myrow] : 0;
-    const int32_t maxlen = __shfl(mylen, 0, 64);
-    int64_t off = rowptr[s0];
-    for (int32_t k = 0; k < maxlen; ++k) {
-      const bool act = k < mylen;
+    const int32_t myu = (mylen + E - 1) / E;
+    const int32_t maxu = __shfl(myu, 0, 64);
+    int64_t off = (int64_t)ubase[s] * E;
+    for (int32_t k = 0; k < maxu; ++k) {
+      const bool act = k < myu;
       const int cnt = __popcll(__ballot(act));
       if (act)
-        sval[off + lane] = values[src0 + k];
-      off += cnt;
+        for (int q = 0; q < E; ++q)
+          sval[off + (int64_t)lane * E + q]
+              = k * E + q < mylen ? values[src0 + k * E + q] : T(0);
+      off += (int64_t)cnt * E;
     }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void sj_long_key_kernel(
+    int count, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rows,
+    uint64_t* __restrict__ key)
+{
+  // runs of 64 consecutive long rows, inside a run the longest first
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += gridDim.x * blockDim.x) {
+    const uint32_t len = (uint32_t)(rowptr[rows[i] + 1] - rowptr[rows[i]]);
+    key[i] = ((uint64_t)(i >> 6) << 32) | (uint64_t)(0xFFFFFFFFu - len);
   }
 }
 
@@ -377,13 +441,15 @@ struct SjArgs {
   int32_t maxk;      // staged chunks the LDS buffer holds
   int32_t stride;    // chunk-list entries per block
   int32_t wide_alloc;
-  const int32_t* rowptr;  // the caller's: slice s spans [rowptr[64 s], ...)
+  const int32_t* rowptr;  // the caller's (long rows)
+  const uint32_t* ubase;  // first unit of every slice
   const int32_t* lenperm;
   const int32_t* blk;     // per block: chunks, wide
   const int32_t* chunks;
   const unsigned char* codes;
   const T* val;           // jagged order
   // long rows (phase 0): straight from the caller's CSR arrays
+  int32_t phases; // measurement only (plan_set "sj_phases"): 1 = long rows, 2 = slices
   int32_t nlong;
   const int32_t* long_rows;
   const int32_t* colind;
@@ -405,115 +471,128 @@ __device__ __forceinline__ float sj_readlane<float>(float v, int j)
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
 }
 
-// One slice.  `vb`, `cb`: the block's span of the values / codes (indices
-// relative to it, `last` the last valid one); off = the slice's first entry;
-// mylen = this lane's row length (lanes sorted by it, descending).  Returns the
-// lane's row sum.
-template <typename T, typename CODE, bool WIDE>
-__device__ __forceinline__ T sj_slice(const T* __restrict__ vb,
-                                      const CODE* __restrict__ cb, int64_t off,
-                                      int64_t last, int32_t mylen, int lane,
+// One slice.  vs / cs: the slice's first unit of values / codes (uniform);
+// mylen = this lane's row length in entries (lanes sorted by it, descending).
+// Returns the lane's row sum.
+//
+// Every load is UNCONDITIONAL (an inactive lane re-reads the step's first
+// unit; a step past the slice's end reads into the arrays' slack) and every
+// use a select: with branches around the loads the compiler waits for ALL
+// loads in flight at each join, and the two groups no longer overlap.  The
+// step's address is the uniform `vs + off` plus the lane's own constant: no
+// vector arithmetic per step but one select.
+template <typename T, typename CODE, bool WIDE, int E>
+__device__ __forceinline__ T sj_slice(const SjUnit<T, E>* __restrict__ vs,
+                                      const SjUnit<CODE, E>* __restrict__ cs,
+                                      int32_t mylen, int lane,
                                       const T* __restrict__ s_x,
                                       const T* __restrict__ in)
 {
+  constexpr int U = kSjGroup / E; // steps per group
+  const int32_t myu = (mylen + E - 1) / E;
+  const int32_t maxu = __builtin_amdgcn_readlane(myu, 0);
+  const int32_t u1 = __builtin_amdgcn_readlane(myu, 1);
   const int32_t maxlen = __builtin_amdgcn_readlane(mylen, 0);
-  const int32_t len1 = __builtin_amdgcn_readlane(mylen, 1);
   // the jagged part ends at the second-longest row when lane 0's row goes on
   // for long enough to be worth taking over by the whole wave
-  const int32_t kmain = (maxlen - len1 >= kSjTailMin) ? len1 : maxlen;
-  const int32_t mymain = mylen < kmain ? mylen : kmain;
+  const int32_t kmain = (maxlen - u1 * E >= kSjTailMin) ? u1 : maxu; // units
+  const int32_t mymain = myu < kmain ? myu : kmain;
   T sum = T(0);
-  T va[kSjU], vc[kSjU];
-  CODE ca[kSjU], cc[kSjU];
+  SjUnit<T, E> va[U], vc[U];
+  SjUnit<CODE, E> ca[U], cc[U];
+  uint32_t off = 0; // units behind the slice's first (uniform)
 
-  // Every load below is UNCONDITIONAL (inactive lanes re-read the step's first
-  // entry, clamped into the block's span) and every use a select: with
-  // branches around the loads the compiler waits for ALL loads in flight at
-  // each join, and the two groups no longer overlap.
 #define SJ_ISSUE(V, C, K0)                                                     \
-  _Pragma("unroll") for (int u = 0; u < kSjU; ++u)                             \
+  _Pragma("unroll") for (int u = 0; u < U; ++u)                                \
   {                                                                            \
     const bool act = (K0) + u < mymain;                                        \
     const int cnt = __popcll(__ballot(act));                                   \
-    int64_t j = off + (act ? lane : 0);                                        \
-    j = j < last ? j : last;                                                   \
-    V[u] = vb[j];                                                              \
-    C[u] = cb[j];                                                              \
+    const int li = act ? lane : 0;                                             \
+    V[u] = (vs + off)[li];                                                     \
+    C[u] = (cs + off)[li];                                                     \
     off += cnt;                                                                \
   }
 #define SJ_CONSUME(V, C, K0)                                                   \
   {                                                                            \
-    T xs[kSjU];                                                                \
+    T xs[U][E];                                                                \
     if constexpr (WIDE) {                                                      \
-      T xg[kSjU];                                                              \
-      _Pragma("unroll") for (int u = 0; u < kSjU; ++u)                         \
+      T xg[U][E], xl[U][E];                                                    \
+      _Pragma("unroll") for (int u = 0; u < U; ++u)                            \
+          _Pragma("unroll") for (int q = 0; q < E; ++q)                        \
       {                                                                        \
-        const uint32_t c = (uint32_t)C[u];                                     \
-        const bool far = (c >> 31) != 0 && (K0) + u < mymain;                  \
-        xg[u] = in[far ? (c & 0x7fffffffu) : 0u];                              \
+        const uint32_t c = (uint32_t)C[u].e[q];                                \
+        const bool far = (c >> 31) != 0 && ((K0) + u) * E + q < mylen;         \
+        xg[u][q] = in[far ? (c & 0x7fffffffu) : 0u];                           \
       }                                                                        \
-      T xl[kSjU];                                                              \
-      _Pragma("unroll") for (int u = 0; u < kSjU; ++u)                         \
+      _Pragma("unroll") for (int u = 0; u < U; ++u)                            \
+          _Pragma("unroll") for (int q = 0; q < E; ++q)                        \
       {                                                                        \
-        const uint32_t c = (uint32_t)C[u];                                     \
-        xl[u] = s_x[(c >> 31) ? 0u : c];                                       \
+        const uint32_t c = (uint32_t)C[u].e[q];                                \
+        xl[u][q] = s_x[(c >> 31) ? 0u : c];                                    \
       }                                                                        \
-      /* all eight LDS reads are wanted whatever the codes say: without this \
-         the compiler moves each read under its own test, and every join    \
-         waits for everything in flight */                                  \
-      static_assert(kSjU == 8, "eight operands below");                        \
-      asm volatile("" ::"v"(xl[0]), "v"(xl[1]), "v"(xl[2]), "v"(xl[3]),        \
-                   "v"(xl[4]), "v"(xl[5]), "v"(xl[6]), "v"(xl[7]));            \
-      _Pragma("unroll") for (int u = 0; u < kSjU; ++u)                         \
+      /* all LDS reads are wanted whatever the codes say: without this the  \
+         compiler moves each read under its own test, and every join waits  \
+         for everything in flight */                                        \
+      static_assert(U * E == 8, "eight operands below");                       \
+      asm volatile("" ::"v"(xl[0][0]), "v"(xl[(1 / E) % U][1 % E]),            \
+                   "v"(xl[(2 / E) % U][2 % E]), "v"(xl[(3 / E) % U][3 % E]),   \
+                   "v"(xl[(4 / E) % U][4 % E]), "v"(xl[(5 / E) % U][5 % E]),   \
+                   "v"(xl[(6 / E) % U][6 % E]), "v"(xl[(7 / E) % U][7 % E]));  \
+      _Pragma("unroll") for (int u = 0; u < U; ++u)                            \
+          _Pragma("unroll") for (int q = 0; q < E; ++q)                        \
       {                                                                        \
-        const uint32_t c = (uint32_t)C[u];                                     \
-        xs[u] = (c >> 31) ? xg[u] : xl[u];                                     \
+        const uint32_t c = (uint32_t)C[u].e[q];                                \
+        xs[u][q] = (c >> 31) ? xg[u][q] : xl[u][q];                            \
       }                                                                        \
     } else {                                                                   \
-      _Pragma("unroll") for (int u = 0; u < kSjU; ++u) xs[u] = s_x[C[u]];      \
+      _Pragma("unroll") for (int u = 0; u < U; ++u)                            \
+          _Pragma("unroll") for (int q = 0; q < E; ++q) xs[u][q]               \
+          = s_x[C[u].e[q]];                                                    \
     }                                                                          \
-    _Pragma("unroll") for (int u = 0; u < kSjU; ++u)                           \
+    _Pragma("unroll") for (int u = 0; u < U; ++u)                              \
+        _Pragma("unroll") for (int q = 0; q < E; ++q)                          \
     {                                                                          \
-      const T nxt = sum + V[u] * xs[u];                                        \
-      sum = (K0) + u < mymain ? nxt : sum;                                     \
+      const T nxt = sum + V[u].e[q] * xs[u][q];                                \
+      const bool use = (K0) + u < mymain && ((K0) + u) * E + q < mylen;        \
+      sum = use ? nxt : sum;                                                   \
     }                                                                          \
   }
 
-  if (maxlen > 0) {
+  if (maxu > 0) {
     SJ_ISSUE(va, ca, 0)
     int32_t k = 0;
-    for (; k + 2 * kSjU < kmain; k += 2 * kSjU) {
-      SJ_ISSUE(vc, cc, k + kSjU)
+    for (; k + 2 * U < kmain; k += 2 * U) {
+      SJ_ISSUE(vc, cc, k + U)
       SJ_CONSUME(va, ca, k)
-      SJ_ISSUE(va, ca, k + 2 * kSjU)
-      SJ_CONSUME(vc, cc, k + kSjU)
+      SJ_ISSUE(va, ca, k + 2 * U)
+      SJ_CONSUME(vc, cc, k + U)
     }
-    SJ_ISSUE(vc, cc, k + kSjU)
+    SJ_ISSUE(vc, cc, k + U)
     SJ_CONSUME(va, ca, k)
-    SJ_CONSUME(vc, cc, k + kSjU)
+    SJ_CONSUME(vc, cc, k + U)
   }
 #undef SJ_ISSUE
 #undef SJ_CONSUME
 
-  if (kmain < maxlen) {
+  if (kmain < maxu) {
     // lane 0's row goes on alone: its remaining entries are contiguous.  The
     // wave loads and multiplies 64 at a time; the products are added to the
     // row's sum one by one, in order (every lane computes the same sum).
-    const int32_t rem = maxlen - kmain;
+    const int32_t rem = maxlen - kmain * E;
+    const T* vt = reinterpret_cast<const T*>(vs + off);
+    const CODE* ct = reinterpret_cast<const CODE*>(cs + off);
     T t = sj_readlane<T>(sum, 0);
     for (int32_t j0 = 0; j0 < rem; j0 += 64) {
-      const int32_t j = j0 + lane;
-      int64_t jj = off + (j < rem ? j : 0);
-      jj = jj < last ? jj : last;
-      const T v = vb[jj];
+      const int32_t j = j0 + lane < rem ? j0 + lane : 0;
+      const T v = vt[j];
       T x;
       if constexpr (WIDE) {
-        const uint32_t c = (uint32_t)cb[jj];
+        const uint32_t c = (uint32_t)ct[j];
         const T xg = in[(c >> 31) ? (c & 0x7fffffffu) : 0u];
         const T xl = s_x[(c >> 31) ? 0u : c];
         x = (c >> 31) ? xg : xl;
       } else {
-        x = s_x[cb[jj]];
+        x = s_x[ct[j]];
       }
       const T p = v * x; // lanes past the row's end: never added
       const int n = rem - j0 < 64 ? rem - j0 : 64;
@@ -536,8 +615,8 @@ __device__ __forceinline__ T sj_slice(const T* __restrict__ vb,
 // 8 s + l of its row (64 + 32 bytes per row and step, straight from the
 // caller's CSR arrays), the group's eight products are added to the row's sum
 // one by one in the row's order (every lane of the group keeps the sum).
-// Values and columns travel two steps ahead, x one step ahead.  [a, b) = the
-// lane's row (b == a: no row); returns the row's sum.
+// Values and columns travel two load groups ahead, x one.  [a, b) = the lane's
+// row (b == a: no row); returns the row's sum.
 constexpr int kSjLpr = 8;
 constexpr int kSjLU = 4; // steps per load group of the long-row phase
 template <typename T>
@@ -560,8 +639,6 @@ __device__ __forceinline__ T sj_long_rows8(const T* __restrict__ val,
     const int64_t e = a + (int64_t)s * kSjLpr + l;
     return e < last ? e : last;
   };
-  // groups of kSjLU steps: values and columns two groups ahead, x one group
-  // ahead -- each trip through the loop waits for loads issued a trip ago
   constexpr int U = kSjLU;
   T vA[U], vB[U], vC[U], xA[U], xB[U];
   int32_t cB[U], cC[U];
@@ -612,7 +689,7 @@ __device__ __forceinline__ T sj_long_rows8(const T* __restrict__ val,
   return t;
 }
 
-template <typename T, int WPB, bool DOT>
+template <typename T, int WPB, int E, bool DOT>
 __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
     SjArgs<T> A, T alpha, const T* __restrict__ in, T beta, T* __restrict__ out,
     DotOut dot, RowBlockOrder ord)
@@ -627,30 +704,33 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
   const int part = t & 7, cg = t >> 3;
   constexpr int CG = NT / 8;
   double dot_acc = 0.0;
-  // phase 0: the long rows (sorted by length), eight per wave and step,
-  // strided over all waves of the grid
-  // (the list is sorted by length: odd rounds are dealt in reverse, so that a
-  // wave's rounds add up to about the same number of steps)
-  const int nwaves = gridDim.x * WPB, nitems = (A.nlong + 7) / 8;
-  for (int r = 0; r * nwaves < nitems; ++r) {
-    const int w = blockIdx.x * WPB + wave;
-    const int i = (r * nwaves + ((r & 1) ? nwaves - 1 - w : w)) * 8;
-    if (i >= A.nlong)
-      continue; // (uniform per wave)
-    const int g = i + (lane >> 3);
-    const bool have_row = g < A.nlong;
-    const int32_t row = A.long_rows[have_row ? g : A.nlong - 1];
-    const int64_t ra = A.rowptr[row];
-    const int64_t rb = have_row ? (int64_t)A.rowptr[row + 1] : ra;
-    const T sum = sj_long_rows8<T>(A.values, A.colind, ra, rb, lane, in);
-    if (have_row && (lane & 7) == 0) {
-      const T c = alpha * sum;
-      T y = c;
-      if (beta != T(0))
-        y = c + beta * out[row];
-      out[row] = y;
-      if constexpr (DOT)
-        dot_acc += (double)in[row] * (double)c;
+  // phase 0: the long rows, eight per wave and step.  The list is in row order
+  // (sorted by length inside runs of 64): a workgroup takes a contiguous run
+  // of items, workgroups of one XCD neighbouring runs -- rows close to each
+  // other read the same lines of x.
+  if (A.phases & 1) {
+    const int nitems = (A.nlong + 7) / 8;
+    const int g8 = gridDim.x >= 8 && (gridDim.x & 7) == 0;
+    const int chunk = g8 ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)
+                         : blockIdx.x;
+    const int per = (nitems + gridDim.x - 1) / gridDim.x;
+    const int i1 = min((chunk + 1) * per, nitems);
+    for (int item = chunk * per + wave; item < i1; item += WPB) {
+      const int g = item * 8 + (lane >> 3);
+      const bool have_row = g < A.nlong;
+      const int32_t row = A.long_rows[have_row ? g : A.nlong - 1];
+      const int64_t ra = A.rowptr[row];
+      const int64_t rb = have_row ? (int64_t)A.rowptr[row + 1] : ra;
+      const T sum = sj_long_rows8<T>(A.values, A.colind, ra, rb, lane, in);
+      if (have_row && (lane & 7) == 0) {
+        const T c = alpha * sum;
+        T y = c;
+        if (beta != T(0))
+          y = c + beta * out[row];
+        out[row] = y;
+        if constexpr (DOT)
+          dot_acc += (double)in[row] * (double)c;
+      }
     }
   }
   const int num_slots = order_slots(ord);
@@ -670,7 +750,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
     if (b0 >= 0)
       request_chunks(b0);
   }
-  for (int it = blockIdx.x; it < num_slots; it += gridDim.x) {
+  for (int it = blockIdx.x; it < num_slots && (A.phases & 2); it += gridDim.x) {
     const int b = order_row_block(ord, it);
     const int itn = it + gridDim.x;
     const int bn = itn < num_slots ? order_row_block(ord, itn) : -1;
@@ -690,9 +770,12 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
     const uint32_t lpw = (uint32_t)A.lenperm[s0c + lane];
     const int32_t lp = (int32_t)(lpw & ~kSjLongFlag);
     const bool in_slice = (lpw & kSjLongFlag) == 0; // else phase 0 wrote its y
-    const int32_t sbase = A.rowptr[s0c];
-    const int32_t a_b = A.rowptr[r0];
-    const int32_t e_b = A.rowptr[r0 + R < A.num_rows ? r0 + R : A.num_rows];
+    // (uniform per wave, and told so: the slice's base pointers then live in
+    // scalar registers and a step's address costs no vector arithmetic)
+    const uint32_t ub_slice
+        = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.ubase[s0c / 64]);
+    const uint32_t ub_block
+        = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.ubase[r0 / 64]);
     const int32_t myrow = s0c + (lp & 63);
     const int32_t myrow_c = myrow < A.num_rows ? myrow : A.num_rows - 1;
     T x_own = T(0), y0 = T(0);
@@ -739,17 +822,20 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
     __syncthreads();
     if (have) {
       const int32_t mylen = lp >> 6;
-      const T* vb = A.val + a_b;
-      const int64_t off = (int64_t)sbase - a_b;
-      const int64_t last = (int64_t)e_b - a_b - 1; // (a block without entries:
-      T sum;                                       //  its slices load nothing)
+      const SjUnit<T, E>* vs = reinterpret_cast<const SjUnit<T, E>*>(A.val) + ub_slice;
+      const int64_t a_b = (int64_t)ub_block * E;
+      T sum;
       if (wide) {
-        const uint32_t* cb = reinterpret_cast<const uint32_t*>(A.codes + 4 * (int64_t)a_b);
-        sum = sj_slice<T, uint32_t, true>(vb, cb, off, last, mylen, lane, s_x, in);
+        const SjUnit<uint32_t, E>* cs
+            = reinterpret_cast<const SjUnit<uint32_t, E>*>(A.codes + 4 * a_b)
+              + (ub_slice - ub_block);
+        sum = sj_slice<T, uint32_t, true, E>(vs, cs, mylen, lane, s_x, in);
       } else {
-        const uint16_t* cb = reinterpret_cast<const uint16_t*>(
-            A.codes + (A.wide_alloc ? 4 : 2) * (int64_t)a_b);
-        sum = sj_slice<T, uint16_t, false>(vb, cb, off, last, mylen, lane, s_x, in);
+        const SjUnit<uint16_t, E>* cs
+            = reinterpret_cast<const SjUnit<uint16_t, E>*>(
+                  A.codes + (A.wide_alloc ? 4 : 2) * a_b)
+              + (ub_slice - ub_block);
+        sum = sj_slice<T, uint16_t, false, E>(vs, cs, mylen, lane, s_x, in);
       }
       if (myrow < A.num_rows && in_slice) {
         const T c = alpha * sum;
@@ -812,16 +898,17 @@ int sj_count(spmv_hip_csr_plan* pl, const int32_t* rowptr, const int32_t* colind
   return SPMV_HIP_OK;
 }
 
-// workgroups of a CU that fit `lds` bytes each, and the waves they bring
+// workgroups of a CU that fit `lds` bytes each, and the waves they bring (the
+// kernel's registers allow 16 waves per CU)
 int sj_wgs_per_cu(int wpb, int64_t lds)
 {
   int wgs = (int)((160 * 1024 - 2048) / (lds > 1 ? lds : 1));
-  const int by_waves = 32 / wpb;
+  const int by_waves = 16 / wpb;
   wgs = wgs < by_waves ? wgs : by_waves;
   return wgs < 1 ? 1 : wgs;
 }
 
-template <typename T, int WPB, bool DOT>
+template <typename T, int WPB, int E, bool DOT>
 int sj_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
               T beta, T* out, DotOut dot)
 {
@@ -833,11 +920,13 @@ int sj_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
   A.stride = pl->sj_stride;
   A.wide_alloc = pl->sj_wide_alloc;
   A.rowptr = pl->rowptr0;
+  A.ubase = pl->sj_ubase;
   A.lenperm = pl->sj_lenperm;
   A.blk = pl->sj_blk;
   A.chunks = pl->sj_chunks;
   A.codes = pl->sj_codes;
   A.val = static_cast<const T*>(pl->sj_val);
+  A.phases = pl->sj_phases;
   A.nlong = pl->sj_nlong;
   A.long_rows = pl->sj_long_rows;
   A.colind = pl->colind0;
@@ -860,30 +949,32 @@ int sj_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
   ord.xcd_group = grid >= 8 ? pl->sj_xcd_group : 0;
   ord.num_row_blocks = pl->sj_nblk;
   ord.nt_store = 0;
-  hipLaunchKernelGGL((csr_sjds_kernel<T, WPB, DOT>), dim3(grid), dim3(64 * WPB),
+  hipLaunchKernelGGL((csr_sjds_kernel<T, WPB, E, DOT>), dim3(grid), dim3(64 * WPB),
                      lds, st, A, alpha, in, beta, out, dot, ord);
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;
+}
+
+template <typename T, int E, bool DOT>
+int sj_run_e(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
+             T beta, T* out, DotOut dot)
+{
+  switch (pl->sj_wpb) {
+  case 4: return sj_launch<T, 4, E, DOT>(pl, st, alpha, in, beta, out, dot);
+  case 8: return sj_launch<T, 8, E, DOT>(pl, st, alpha, in, beta, out, dot);
+  default: return sj_launch<T, 16, E, DOT>(pl, st, alpha, in, beta, out, dot);
+  }
 }
 
 template <typename T, bool DOT>
 int sj_run(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
            T beta, T* out, DotOut dot)
 {
-  switch (pl->sj_wpb) {
-  case 4: return sj_launch<T, 4, DOT>(pl, st, alpha, in, beta, out, dot);
-  case 8: return sj_launch<T, 8, DOT>(pl, st, alpha, in, beta, out, dot);
-  default: return sj_launch<T, 16, DOT>(pl, st, alpha, in, beta, out, dot);
+  switch (pl->sj_unit) {
+  case 1: return sj_run_e<T, 1, DOT>(pl, st, alpha, in, beta, out, dot);
+  case 2: return sj_run_e<T, 2, DOT>(pl, st, alpha, in, beta, out, dot);
+  default: return sj_run_e<T, 4, DOT>(pl, st, alpha, in, beta, out, dot);
   }
-}
-
-__global__ __launch_bounds__(kBlock) void sj_row_len_kernel(
-    int count, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rows,
-    int32_t* __restrict__ len)
-{
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count;
-       i += gridDim.x * blockDim.x)
-    len[i] = rowptr[rows[i] + 1] - rowptr[rows[i]];
 }
 
 struct SjIsLong {
@@ -903,7 +994,8 @@ struct SjLongCount {
   }
 };
 
-// ascending list of the rows longer than thr (SPMV_HIP_ENOMEM: no memory)
+// the rows longer than thr, ascending, sorted by length inside runs of 64
+// (SPMV_HIP_ENOMEM: no memory)
 int sj_build_long_list(spmv_hip_csr_plan* pl, const int32_t* rowptr, int thr,
                        hipStream_t st)
 {
@@ -942,37 +1034,41 @@ int sj_build_long_list(spmv_hip_csr_plan* pl, const int32_t* rowptr, int thr,
                                    pred, st);
     if (e == hipSuccess)
       e = hipStreamSynchronize(st);
-    // ... sorted by length, descending (stable: ties keep the row order), so
-    // that the eight rows a wave takes together end together
-    int32_t *d_len = nullptr, *d_len2 = nullptr, *d_rows2 = nullptr;
+    // ... inside runs of 64 the longest first, so that the eight rows a wave
+    // takes together end together and still are neighbours
+    uint64_t *d_key = nullptr, *d_key2 = nullptr;
+    int32_t* d_rows2 = nullptr;
     void* tmp2 = nullptr;
     size_t tb3 = 0;
     if (e == hipSuccess)
-      e = hipMalloc(&d_len, sizeof(int32_t) * (size_t)count);
+      e = hipMalloc(&d_key, sizeof(uint64_t) * (size_t)count);
     if (e == hipSuccess)
-      e = hipMalloc(&d_len2, sizeof(int32_t) * (size_t)count);
+      e = hipMalloc(&d_key2, sizeof(uint64_t) * (size_t)count);
     if (e == hipSuccess)
       e = hipMalloc(&d_rows2, sizeof(int32_t) * (size_t)count);
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(sj_row_len_kernel, dim3(spmv_grid_for(pl->ctx, count, kBlock)),
-                         dim3(kBlock), 0, st, count, rowptr, pl->sj_long_rows, d_len);
+      hipLaunchKernelGGL(sj_long_key_kernel,
+                         dim3(spmv_grid_for(pl->ctx, count, kBlock)), dim3(kBlock), 0,
+                         st, count, rowptr, pl->sj_long_rows, d_key);
       e = hipGetLastError();
     }
     if (e == hipSuccess)
-      e = hipcub::DeviceRadixSort::SortPairsDescending(
-          nullptr, tb3, d_len, d_len2, pl->sj_long_rows, d_rows2, count, 0, 32, st);
+      e = hipcub::DeviceRadixSort::SortPairs(nullptr, tb3, d_key, d_key2,
+                                             pl->sj_long_rows, d_rows2, count, 0, 64,
+                                             st);
     if (e == hipSuccess)
       e = hipMalloc(&tmp2, tb3 ? tb3 : 16);
     if (e == hipSuccess)
-      e = hipcub::DeviceRadixSort::SortPairsDescending(
-          tmp2, tb3, d_len, d_len2, pl->sj_long_rows, d_rows2, count, 0, 32, st);
+      e = hipcub::DeviceRadixSort::SortPairs(tmp2, tb3, d_key, d_key2,
+                                             pl->sj_long_rows, d_rows2, count, 0, 64,
+                                             st);
     if (e == hipSuccess)
       e = hipMemcpyAsync(pl->sj_long_rows, d_rows2, sizeof(int32_t) * (size_t)count,
                          hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess)
       e = hipStreamSynchronize(st);
-    (void)hipFree(d_len);
-    (void)hipFree(d_len2);
+    (void)hipFree(d_key);
+    (void)hipFree(d_key2);
     (void)hipFree(d_rows2);
     (void)hipFree(tmp2);
   }
@@ -1007,8 +1103,14 @@ int sj_bake(spmv_hip_csr_plan* pl, const T* values, hipStream_t st)
     pl->sj_val = nullptr;
   }
   if (!pl->sj_val) {
-    const hipError_t e = hipMalloc(&pl->sj_val, sizeof(T) * (size_t)pl->nnz);
+    const size_t entries = (size_t)(pl->sj_units + kSjSlack) * pl->sj_unit;
+    hipError_t e = hipMalloc(&pl->sj_val, sizeof(T) * entries);
+    if (e == hipSuccess) // the slack is read (never used): keep it finite
+      e = hipMemsetAsync(static_cast<T*>(pl->sj_val)
+                             + (size_t)pl->sj_units * pl->sj_unit,
+                         0, sizeof(T) * (size_t)kSjSlack * pl->sj_unit, st);
     if (e != hipSuccess) {
+      (void)hipFree(pl->sj_val);
       pl->sj_val = nullptr;
       (void)hipGetLastError();
       return e == hipErrorOutOfMemory ? SPMV_HIP_ENOTSUP : static_cast<int>(e);
@@ -1017,8 +1119,8 @@ int sj_bake(spmv_hip_csr_plan* pl, const T* values, hipStream_t st)
   const int64_t nsl = ((int64_t)pl->num_rows + 63) / 64;
   const int grid = spmv_grid_for(pl->ctx, nsl, kBlock / 64);
   hipLaunchKernelGGL((sj_bake_kernel<T>), dim3(grid), dim3(kBlock), 0, st,
-                     pl->num_rows, pl->rowptr0, pl->sj_lenperm, values,
-                     static_cast<T*>(pl->sj_val));
+                     pl->num_rows, pl->rowptr0, pl->sj_lenperm, pl->sj_ubase,
+                     pl->sj_unit, values, static_cast<T*>(pl->sj_val));
   SPMV_CHECK_LAUNCH();
   SPMV_CHECK_HIP(hipStreamSynchronize(st));
   pl->sj_elem = (int)sizeof(T);
@@ -1040,6 +1142,8 @@ void spmv_sjds_free(spmv_hip_csr_plan* pl)
   (void)hipFree(pl->sj_codes);
   (void)hipFree(pl->sj_val);
   (void)hipFree(pl->sj_long_rows);
+  (void)hipFree(pl->sj_ubase);
+  pl->sj_ubase = nullptr;
   pl->sj_long_rows = nullptr;
   pl->sj_nlong = 0;
   pl->sj_lenperm = pl->sj_blk = pl->sj_chunks = nullptr;
@@ -1050,10 +1154,11 @@ void spmv_sjds_free(spmv_hip_csr_plan* pl)
 }
 
 // Build the structure (everything but the values).  wpb_force: 4, 8, 16, or 0
-// = choose.  Leaves the plan without the form (SPMV_HIP_OK) when it does not
-// pay: no memory, or most entries far.
+// = choose; unit_force: 1, 2, 4 entries per lane and step, or 0 = choose.
+// Leaves the plan without the form (SPMV_HIP_OK) when it does not pay: no
+// memory, or nearly all entries far.
 int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
-                    const int32_t* colind, int wpb_force)
+                    const int32_t* colind, int wpb_force, int unit_force)
 {
   SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
   hipStream_t st = pl->ctx->stream;
@@ -1064,7 +1169,12 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
   // long rows: more than four times the average length, and more than 96
   int thr = (int)(pl->nnz * 4 / n);
   thr = thr > kSjLongMin ? thr : kSjLongMin;
+  // entries per lane and step: a unit's padding (half a unit per row) against
+  // the instructions of a step
+  const double avg = (double)pl->nnz / n;
+  const int E = unit_force ? unit_force : (avg >= 24.0 ? 4 : (avg >= 5.0 ? 2 : 1));
   const int nblk4 = (n + 255) / 256;
+  const int64_t nsl = ((int64_t)n + 63) / 64;
   int32_t *d_k = nullptr, *d_far = nullptr;
   int64_t* d_stats = nullptr;
   hipError_t e = hipMalloc(&d_k, sizeof(int32_t) * (size_t)nblk4);
@@ -1145,26 +1255,56 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
     cleanup();
     return SPMV_HIP_OK;
   }
+  // first unit of every slice: scan of the slices' unit counts
+  uint32_t total_units = 0;
+  {
+    void* tmp = nullptr;
+    size_t tb = 0;
+    e = hipMalloc(&pl->sj_ubase, sizeof(uint32_t) * (size_t)(nsl + 1));
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(sj_units_kernel, dim3(spmv_grid_for(pl->ctx, nsl + 1, 4)),
+                         dim3(kBlock), 0, st, n, rowptr, thr, E, pl->sj_ubase);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+      e = hipcub::DeviceScan::ExclusiveSum(nullptr, tb, pl->sj_ubase, pl->sj_ubase,
+                                           (int)(nsl + 1), st);
+    if (e == hipSuccess)
+      e = hipMalloc(&tmp, tb ? tb : 16);
+    if (e == hipSuccess)
+      e = hipcub::DeviceScan::ExclusiveSum(tmp, tb, pl->sj_ubase, pl->sj_ubase,
+                                           (int)(nsl + 1), st);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(&total_units, pl->sj_ubase + nsl, sizeof(uint32_t),
+                         hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess)
+      e = hipStreamSynchronize(st);
+    (void)hipFree(tmp);
+  }
   const int R = 64 * best;
   const int nblk = (n + R - 1) / R;
   const int stride = best_st.maxk > 0 ? (int)((best_st.maxk + 7) / 8 * 8) : 8;
   const int wide_alloc = best_st.far > 0 ? 1 : 0;
-  const size_t n_pad = (size_t)((n + 63) / 64) * 64;
-  e = hipMalloc(&pl->sj_blk, sizeof(int32_t) * 2 * (size_t)nblk);
+  const size_t n_pad = (size_t)nsl * 64;
+  const size_t code_bytes
+      = (size_t)(wide_alloc ? 4 : 2) * ((size_t)total_units + kSjSlack) * E;
+  if (e == hipSuccess)
+    e = hipMalloc(&pl->sj_blk, sizeof(int32_t) * 2 * (size_t)nblk);
   if (e == hipSuccess)
     e = hipMalloc(&pl->sj_chunks, sizeof(int32_t) * (size_t)nblk * stride);
   if (e == hipSuccess)
     e = hipMalloc(&pl->sj_lenperm, sizeof(int32_t) * n_pad);
   if (e == hipSuccess)
-    e = hipMalloc(&pl->sj_codes, (size_t)(wide_alloc ? 4 : 2) * (size_t)pl->nnz + 16);
+    e = hipMalloc(&pl->sj_codes, code_bytes);
+  if (e == hipSuccess) // (the slack's codes must be valid LDS indices: 0)
+    e = hipMemsetAsync(pl->sj_codes, 0, code_bytes, st);
   if (e == hipSuccess) {
     const int grid = spmv_grid_for(pl->ctx, nblk, 1);
 #define SJ_FILL(RR)                                                            \
   hipLaunchKernelGGL((sj_fill_kernel<RR>), dim3(grid), dim3(kBlock), 0, st, n,  \
-                     pl->num_cols, rowptr, colind, kcap, thr, stride,          \
-                     wide_alloc,                                               \
-                     d_far, pl->sj_blk, pl->sj_chunks, pl->sj_lenperm,         \
-                     pl->sj_codes)
+                     pl->num_cols, rowptr, colind, kcap, thr, E, stride,       \
+                     wide_alloc, d_far, pl->sj_ubase, pl->sj_blk,              \
+                     pl->sj_chunks, pl->sj_lenperm, pl->sj_codes)
     if (best == 4)
       SJ_FILL(256);
     else if (best == 8)
@@ -1190,6 +1330,8 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
     }
   }
   pl->sj_long_thr = thr;
+  pl->sj_unit = E;
+  pl->sj_units = total_units;
   pl->sj_wpb = best;
   pl->sj_nblk = nblk;
   pl->sj_maxk = (int)best_st.maxk > 0 ? (int)best_st.maxk : 1;

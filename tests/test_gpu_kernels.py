@@ -602,15 +602,19 @@ def _sj_cases():
     return cases
 
 
-@pytest.mark.parametrize("wpb", [4, 8, 16, 0])
-def test_sliced_jagged_form_bit_exact(sj_ctx, wpb):
+@pytest.mark.parametrize("wpb,unit", [(4, 1), (8, 2), (16, 4), (4, 4), (16, 1),
+                                      (0, 0)])
+def test_sliced_jagged_form_bit_exact(sj_ctx, wpb, unit):
     """csr_sjds_kernel against oracle.csr_spmv (csr_kernels.cpp:41-51), every
-    element identical: slices of 4 / 8 / 16 waves (0 = the plan's choice),
-    staged and far entries (a chunk budget of 8 forces most entries far),
-    alpha / beta, fused dot, fp32; other value arrays than the baked one and a
-    dropped copy take the CSR-order kernels."""
+    element identical: blocks of 4 / 8 / 16 slices, 1 / 2 / 4 entries per lane
+    and step (0 = the plan's choice), staged and far entries (a chunk budget of
+    8 forces most entries far), long rows (the 8-lanes-per-row phase) and rows
+    the wave takes over inside a slice, alpha / beta, fused dot, fp32; other
+    value arrays than the baked one and a dropped copy take the CSR-order
+    kernels."""
     ctx = sj_ctx
     ctx.set_option("sj_wpb", wpb)
+    ctx.set_option("sj_unit", unit)
     part = ctx.empty(ctx.dot_partials_len, np.float64)
     for name, (rp, ci, va) in _sj_cases().items():
         nr = len(rp) - 1
@@ -629,7 +633,7 @@ def test_sliced_jagged_form_bit_exact(sj_ctx, wpb):
             blk.bake()
             assert blk.get("sjds") == 1 and blk.get("lx") == 0
             if wpb:
-                assert blk.get("sj_wpb") == wpb
+                assert blk.get("sj_wpb") == wpb and blk.get("sj_unit") == unit
             if name == "far" or (budget == 8 and nc > 1000):
                 assert blk.get("sj_far_permille") > 0 and blk.get("sj_wide") == 1
             if name == "fem" and budget == 448:
