@@ -109,6 +109,15 @@ def parse():
                     help="grid of the 27-point sub-record")
     ap.add_argument("--unstructured-rows", type=int, default=10_000_000,
                     help="rows of the unstructured sub-record")
+    ap.add_argument("--fem-rows", type=int, default=10_000_000,
+                    help="rows of the ragged-row (FEM-like) sub-records")
+    ap.add_argument("--petsc-matrix", default=None,
+                    help="PETSc binary matrix file (spmv/read_petsc.cpp:40-228, as "
+                         "demos/cg.cpp:47 reads it): the main line's matrix instead "
+                         "of the generated Poisson matrix")
+    ap.add_argument("--petsc-rhs", default=None,
+                    help="PETSc binary vector file for the right-hand side "
+                         "(demos/cg.cpp:51); default: the Gaussian vector")
     ap.add_argument("--blas1-nt-min", type=int, default=None,
                     help="override the context option blas1_nt_min_elems "
                          "(experiments)")
@@ -192,6 +201,10 @@ def cpu_baseline(args, n_gpu, rows_gpu, host):
                         "GB/s": nbytes / r["spmv_s_per_apply"] / 1e9,
                         "bytes": "algorithmic CSR bytes, as for the GPU"},
            "cg_rel_residual_after": r["rel_residual"],
+           # the same system as the GPU line (Gaussian right-hand side): compare
+           # with the line's cg_rel_residual.k10 when the grids are the same
+           "cg_rel_residual_k10": r["rel_residual_k10"] or None,
+           "rhs": "b_i = exp(-10 (5 (i/N - 1/2))^2), as the GPU line",
            "host": host}
     try:  # BASELINE configs[0]: the 1-thread ReferenceExecutor loop at 128^3
         import numpy as np
@@ -364,6 +377,25 @@ def kernel_of(A, symmetric):
                 "offsets per row block, values by LDS-DMA one block ahead, no "
                 "index stream; fused p.Ap)",
                 algo, nnz * 8 + rows * 1 + nrb * 48 + y_x)
+    if A.plan_get("sjds"):
+        E, wpb = A.plan_get("sj_unit"), A.plan_get("sj_wpb")
+        stored = nnz * A.plan_get("sj_pad_permille") // 1000  # short rows, padded
+        code = 4 if A.plan_get("sj_wide") else 2
+        staged = nnz * A.plan_get("sj_staged_bytes_per_entry_x100") // 100
+        nlong = A.plan_get("sj_long_rows")
+        return (f"csr_sjds_kernel<double, {wpb} slices per block, {E} entries per "
+                "lane and step> (sliced jagged form: lane = row in 64-row slices "
+                "stored as jagged diagonals, the plan's copy of the values and "
+                f"{8 * code}-bit column codes, x staged in LDS per block"
+                + (f", {nlong} long rows by 8-lane groups from the CSR arrays"
+                   if nlong else "")
+                + "; rows summed in the CSR kernel's order: bit-exact; fused p.Ap)",
+                # the padded short rows (long rows: their CSR entries, counted in
+                # `stored` at 12 B below is close enough: their share of the
+                # values copy is never read), lenperm + slice bases, x, y, the
+                # staged chunks (served by the L2s)
+                algo, stored * (8 + code) + rows * 4 + (rows // 64 + 1) * 4
+                + y_x + staged)
     if A.plan_get("lx") and A.plan_get("lxw"):
         return ("csr_lxw_kernel<double> (LX form, LDS-DMA kernel: values, 16-bit "
                 "column offsets and x windows arrive by LDS-DMA one row block "
@@ -380,8 +412,8 @@ def plan_record(A):
     return {"plan_ms": A.plan_get("plan_us") / 1e3,
             "plan_extra_bytes": A.plan_get("plan_kib") * 1024,
             "form": {k: A.plan_get(k) for k in
-                     ("lat", "lx", "lxw", "wdia", "wdia_const", "slat", "sdia",
-                      "sdia_const", "sym_det", "zwalk")}}
+                     ("lat", "lx", "lxw", "sjds", "wdia", "wdia_const", "slat",
+                      "sdia", "sdia_const", "sym_det", "zwalk")}}
 
 
 def pmc_traffic(record, kernel_name, n, world):
@@ -392,11 +424,12 @@ def pmc_traffic(record, kernel_name, n, world):
     if world != 1:
         return None, None
     try:
-        path = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
-        if os.path.exists(path):
-            rec = json.load(open(path)).get("records", {}).get(record)
-            if rec and rec.get("grid") == n:
-                return rec["fabric_bytes_per_launch"], rec["source"]
+        for rnd in ("r04", "r03"):
+            path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary.json")
+            if os.path.exists(path):
+                rec = json.load(open(path)).get("records", {}).get(record)
+                if rec and rec.get("grid") == n:
+                    return rec["fabric_bytes_per_launch"], rec["source"]
         path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
         if record in ("main", "symmetric") and os.path.exists(path):
             for rec in json.load(open(path))["kernels"]:
@@ -462,7 +495,7 @@ def timed_spmv(exec_, A, N, _lib, reps, crosscheck=False):
 
 def spmv_record(exec_, comm, host, _lib, n, symmetric, reps, lattice=True,
                 bake=True, skew_ppm=0, lx=True, record=None, stencil=7,
-                const=True):
+                const=True, sj=True):
     """one plain-SpMV sub-record on the n^3 matrix in the given storage/form
     (skew_ppm: the generator's non-symmetric variant of the matrix; stencil 27:
     the 27-point operator)"""
@@ -472,6 +505,8 @@ def spmv_record(exec_, comm, host, _lib, n, symmetric, reps, lattice=True,
         opts[b"lat_min_nnz"] = (1 << 62, 1 << 20)
     if not lx:
         opts[b"lx_min_nnz"] = (1 << 62, 1 << 20)
+    if not sj:  # nor the sliced jagged form: the plain row-block gather kernel
+        opts[b"sj_min_nnz"] = (1 << 62, 1 << 20)
     if not bake:
         opts[b"bake_general"] = (0, 1)
     if not const:  # stream the values even where the diagonals are constant
@@ -637,20 +672,43 @@ def main():
     cm = getattr(host, args.cm.upper())
     exec_.synchronize()
     t_create = time.perf_counter()
-    A = host.Matrix.create_poisson3d(comm, exec_, n, args.symmetric, cm)
+    if args.petsc_matrix:
+        # the reference demos' input path (demos/cg.cpp:47-51, demos/spmv.cpp:43):
+        # every rank reads its row slab of the file (spmv/read_petsc.cpp:40-228)
+        A = host.read_petsc_binary_matrix(args.petsc_matrix, comm, exec_,
+                                          args.symmetric, cm)
+    else:
+        A = host.Matrix.create_poisson3d(comm, exec_, n, args.symmetric, cm)
     exec_.synchronize()
     t_create = time.perf_counter() - t_create  # generator + upload-free plan
     l2g = A.col_map()
     M = l2g.local_size()
     blocks = A.blocks()
+    nnz_global = poisson.poisson3d_nnz(n)
+    if args.petsc_matrix:
+        n = 0  # no grid: none of the Poisson-only records below applies
+        args.no_extras = True
+        N, nnz_global = M, A.non_zeros()
+        if world > 1:
+            tot = torch.tensor([M, A.non_zeros()], dtype=torch.float64,
+                               device="cpu" if rehearsal else "cuda")
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            N, nnz_global = int(tot[0]), int(tot[1])
 
     # RHS b = Gaussian bump (demos/spmv.cpp:63-67) -- resident before timing
     if args.blas1_nt_min is not None:
         _lib.call("spmv_hip_ctx_set_option", ctx, b"blas1_nt_min_elems",
                   args.blas1_nt_min)
-    d_b, d_x = exec_.alloc(M), exec_.alloc(M)
-    _lib.call("spmv_hip_fill_gaussian_f64", ctx, N, l2g.global_offset(), M, d_b,
-              None)
+    d_x = exec_.alloc(M)
+    if args.petsc_rhs:
+        d_b, m_b = host.read_petsc_binary_vector(comm, exec_, args.petsc_rhs)
+        if m_b != M:
+            raise SystemExit(f"rank {rank}: {args.petsc_rhs} gives {m_b} local "
+                             f"entries, the matrix has {M} local rows")
+    else:
+        d_b = exec_.alloc(M)
+        _lib.call("spmv_hip_fill_gaussian_f64", ctx, N, l2g.global_offset(), M,
+                  d_b, None)
     ws = host.CgWorkspace(exec_)
     exec_.synchronize()
 
@@ -757,8 +815,10 @@ def main():
             "dtype": "f64",
             "data": "synthetic" + (" (REHEARSAL: gloo transport, shared GPU)"
                                    if rehearsal else ""),
-            "config": {"workload": f"poisson3d_{n}^3_csr_fp64_cg",
-                       "rows": N, "nnz": poisson.poisson3d_nnz(n),
+            "config": {"workload": (f"poisson3d_{n}^3_csr_fp64_cg" if n else
+                                    "petsc_binary_matrix_csr_fp64_cg: "
+                                    + os.path.basename(args.petsc_matrix)),
+                       "rows": N, "nnz": nnz_global,
                        "storage": "symmetric-csr" if args.symmetric else "csr",
                        "partition": f"row-slab x{world}",
                        "halo": (args.cm + (" (peer stores into IPC windows, "
@@ -969,7 +1029,92 @@ def main():
                     out["csr_lx_spmv"] = rec("csr_lx_spmv", n, False, 20,
                                              lattice=False)
                     out["csr_rowblock_spmv"] = rec("csr_rowblock_spmv", n, False,
-                                                   20, lattice=False, lx=False)
+                                                   20, lattice=False, lx=False,
+                                                   sj=False)
+                    # ... and the sliced jagged form on this matrix (7 entries
+                    # per row are too few for it: the LX form is the AUTO choice)
+                    out["csr_sjds_spmv"] = rec("csr_sjds_spmv", n, False, 20,
+                                               lattice=False, lx=False)
+            if not args.symmetric and not (args.no_lattice or args.no_lx):
+                # THE GENERAL-CSR LINE, kept inside `roofline` (the block the
+                # driver stores): the same matrix and the same CG loop with the
+                # plan-time lattice analysis switched off -- what a CSR matrix
+                # of this shape WITHOUT stencil structure gets from the AUTO
+                # plan (the LX form: values + 16-bit column offsets streamed, x
+                # windows staged in LDS).  frac = SURVEY 8d's CSR bytes / time.
+                _lib.call("spmv_hip_ctx_set_option", ctx, b"lat_min_nnz", 1 << 62)
+                try:
+                    Ag = host.Matrix.create_poisson3d(self_comm, exec_, n, False,
+                                                      cm)
+                finally:
+                    _lib.call("spmv_hip_ctx_set_option", ctx, b"lat_min_nnz",
+                              1 << 20)
+                d_b, d_x = exec_.alloc(N), exec_.alloc(N)
+                _lib.call("spmv_hip_fill_gaussian_f64", ctx, N, 0, N, d_b, None)
+                ws4 = host.CgWorkspace(exec_)
+                steps = min(args.steps, 30)
+                host.cg_ex(self_comm, exec_, Ag, d_b, d_x, 3, 0.0, ws4)
+                ws4.reserve_timing(steps)
+                exec_.synchronize()
+                t0 = time.perf_counter()
+                _, h4, ms4, l4 = host.cg_ex(self_comm, exec_, Ag, d_b, d_x, steps,
+                                            0.0, ws4, time_spmv=True, history=True)
+                exec_.synchronize()
+                el4 = time.perf_counter() - t0
+                kern4, algo4, req4 = kernel_of(Ag, False)
+                ms4 /= max(l4, 1)
+                tr4, src4 = pmc_traffic("csr_order", kern4, n, world)
+                out["roofline"]["csr_order"] = {
+                    "what": "the kernel the AUTO plan picks for this matrix with "
+                            "the lattice analysis (and with it every stencil "
+                            "form) switched off, inside the same CG loop",
+                    "kernel": kern4.split(" (")[0], "ms_per_apply": ms4,
+                    "launches_timed": l4,
+                    "algorithmic_bytes_per_launch": algo4,
+                    "achieved": algo4 / ms4 / 1e6, "unit": "GB/s",
+                    "frac": algo4 / ms4 / 1e6 / HBM_PEAK_GBS,
+                    "requested_bytes_per_launch": req4,
+                    "frac_requested": req4 / ms4 / 1e6 / HBM_PEAK_GBS,
+                    "traffic": tr4, "traffic_source": src4,
+                    "cg_rel_residual_k10": float(h4[min(10, len(h4) - 1)] / h4[0]),
+                    "plan_ms": Ag.plan_get("plan_us") / 1e3}
+                out["roofline"]["general_cg_iters_per_s"] = steps / el4
+                ws4.close()
+                Ag.close()
+                exec_.free(d_b), exec_.free(d_x)
+            if not args.symmetric:
+                # RAGGED ROWS (what the PETSc reader typically delivers): seeded
+                # FEM-like matrices, 10 M rows -- row lengths 5-40 in three
+                # clusters of columns (a bandwidth-reducing order); the same with
+                # a 1 % tail of 200-2000-entry rows; 81 entries in every row.
+                # The AUTO plan takes the sliced jagged form; cross-checked here
+                # against the one-lane-per-row kernel, oracle-sized instances in
+                # tests/test_gpu_matrix.py.  Summary inside `roofline`.
+                ragged = {}
+                for name, kw in (("fem_spmv", dict()),
+                                 ("fem_tail_spmv", dict(tail_permille=10)),
+                                 ("fem81_spmv", dict(min_len=81, max_len=81))):
+                    Af = host.Matrix.create_fem_like(self_comm, exec_,
+                                                     args.fem_rows, **kw)
+                    r = matrix_spmv_record(
+                        exec_, Af, _lib, False, 30, name, args.fem_rows,
+                        f"fem_like_{args.fem_rows}rows_"
+                        + ("len81" if kw.get("min_len") else "len5-40")
+                        + ("_tail1pct_200-2000" if kw.get("tail_permille") else "")
+                        + "_csr_fp64_spmv", crosscheck=True)
+                    r["avg_row"] = r["nnz_stored"] / r["rows"]
+                    out[name] = r
+                    ragged[name] = {"ms_per_apply": r["ms_per_apply"],
+                                    "frac": r["frac_csr_equivalent"],
+                                    "kernel": r["kernel"].split(" (")[0],
+                                    "bit_equal_one_lane_per_row":
+                                        r["crosscheck"]["bit_equal"],
+                                    "plan_ms": r["plan_ms"],
+                                    "traffic": r.get("traffic")}
+                    Af.close()
+                out["roofline"]["ragged"] = dict(
+                    ragged, note="frac = SURVEY 8d CSR bytes (12 B per entry, row "
+                                 "pointer, x, y) / launch time / 8 TB/s")
             if not args.symmetric:
                 rec = lambda name, *a, **kw: spmv_record(  # noqa: E731
                     exec_, self_comm, host, _lib, *a, record=name, **kw)
@@ -984,7 +1129,7 @@ def main():
                     "north_star_lx_spmv", 216, False, 200, lattice=False)
                 out["north_star_rowblock_spmv"] = rec(
                     "north_star_rowblock_spmv", 216, False, 200, lattice=False,
-                    lx=False)
+                    lx=False, sj=False)
                 # Matrices that are NOT the 7-point stencil.  (a) the 27-point
                 # operator on a 256^3 grid (HPCG's matrix; 16.8 M rows, 449 M
                 # entries); (b) a seeded unstructured matrix (10 M rows, 7
@@ -1008,6 +1153,14 @@ def main():
                     f"unstructured_{args.unstructured_rows}rows_7per_row_band2048_"
                     "far10pct_csr_fp64_spmv", crosscheck=True)
                 Au.close()
+                if "ragged" in out["roofline"]:
+                    r = out["unstructured_spmv"]
+                    out["roofline"]["ragged"]["unstructured_spmv"] = {
+                        "ms_per_apply": r["ms_per_apply"],
+                        "frac": r["frac_csr_equivalent"],
+                        "kernel": r["kernel"].split(" (")[0],
+                        "bit_equal_one_lane_per_row": r["crosscheck"]["bit_equal"],
+                        "plan_ms": r["plan_ms"], "traffic": r.get("traffic")}
                 # mixed-precision CG against pure fp64, to 1e-10
                 out["mixed_precision_cg"] = mixed_precision_record(
                     exec_, self_comm, host, _lib, args.mixed_grid)

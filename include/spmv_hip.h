@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SPMV_HIP_ABI_VERSION 2
+#define SPMV_HIP_ABI_VERSION 3
 
 enum {
   SPMV_HIP_OK = 0,
@@ -226,13 +226,36 @@ int spmv_hip_csr_plan_destroy(spmv_hip_csr_plan* plan);
  * per row of device memory (constant diagonals: 1 or 4 B per row).  A launch that passes these very `values` (and
  * `diagonal`) pointers takes the diagonal-form kernel; a launch with other
  * pointers takes the CSR-order kernels as before.  CONTRACT: whoever rewrites
- * the baked arrays in place bakes again (or drops the copy: values = NULL). */
+ * the baked arrays in place calls spmv_hip_csr_plan_values_changed (or bakes
+ * again, or drops the copy: values = NULL).  A general plan that took neither
+ * the lattice nor the LX form (ragged rows, more than 16 entries per row) keeps
+ * its copy in the SLICED JAGGED order instead (spmv_sjds.hip): 64-row slices
+ * as jagged diagonals + 16-bit column codes into an LDS-staged copy of x. */
 int spmv_hip_csr_plan_bake_values_f64(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan,
                                       const double* values,
                                       const double* diagonal, void* stream);
 int spmv_hip_csr_plan_bake_values_f32(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan,
                                       const float* values, const float* diagonal,
                                       void* stream);
+/* The caller has REWRITTEN the baked `values` (and `diagonal`) arrays in place
+ * -- a time step with new coefficients on the same sparsity, the common use of
+ * a raw C ABI; the reference's CSRMatrix is immutable (csr_matrix.cpp:22-59)
+ * and needs no such call.  Refreshes every copy the plan keeps, from the
+ * pointers it was baked with, in `stream` order (the call returns after the
+ * refresh has completed):
+ *   sliced jagged form   the copy is rewritten in place, nothing is allocated;
+ *   diagonal forms       the checks run again on the new values (constant
+ *                        diagonals? still symmetric?) and the copy is rebuilt
+ *                        in the form they allow; a matrix the forms no longer
+ *                        hold falls back to the CSR-order kernels;
+ *   fp32 copies of the mixed SpMV likewise.
+ * A plan without a baked copy: nothing to do.  SPMV_HIP_OK in all these cases
+ * -- launches with the same pointers then return the NEW matrix's product.
+ * Without this call they return the OLD one (the copy is the plan's own): the
+ * contract of plan_bake_values.  plan_get "values_changed_us" = what the last
+ * call cost. */
+int spmv_hip_csr_plan_values_changed(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan,
+                                     void* stream);
 /* ... and the fp32 copy for spmv_hip_csr_spmv_f32f64 (mixed precision) on a
  * general fp64 plan whose values are baked: `values32` is the caller's fp32
  * copy of the CSR values (the same device check runs on its bits).  Launches
@@ -555,11 +578,18 @@ int spmv_hip_fill_const_f64(spmv_hip_ctx* ctx, int64_t count, double value,
  * counts in ELEMENTS), then every exchange is one kernel launch on `stream`:
  * signal "my segment is free", wait for the neighbour's, store the send
  * segment into the neighbour's window, raise its data flag, wait for mine, copy
- * the staging buffer into `ghost_tail`.  Waits are bounded (about 4 s): a
- * neighbour that does not answer makes THIS and every later exchange of the
- * window fail with SPMV_HIP_EPEER (put_status) instead of hanging.
- * Validated on one device only (processes sharing a GPU through IPC, and
- * threads); see spmv_amd/csrc/hip/put.hip. */
+ * the staging buffer into `ghost_tail`.  Waits are bounded (ctx option
+ * "put_timeout_ms", 60 s by default): a neighbour that does not answer leaves
+ * NaN in its ghost segment, and the context's next synchronisation
+ * (spmv_hip_synchronize / stream_synchronize / event_synchronize) as well as
+ * every later exchange of the window return SPMV_HIP_EPEER instead of hanging
+ * or handing stale ghosts to the SpMV.
+ * The window is FINE-GRAINED device memory where the runtime can export that
+ * over IPC (put_fine_grained; peers on other devices store into it while the
+ * owner's kernel polls); a coarse-grained window only connects peers on the
+ * same device (put_connect: SPMV_HIP_ENOTSUP otherwise -- L2GMap then keeps
+ * the two-sided exchange).  Validated on one device only (processes sharing a
+ * GPU through IPC, and threads); see spmv_amd/csrc/hip/put.hip. */
 #define SPMV_HIP_IPC_HANDLE_BYTES 64
 #define SPMV_HIP_PUT_MAX_PEERS 16
 typedef struct spmv_hip_put spmv_hip_put;
@@ -571,7 +601,8 @@ int spmv_hip_put_connect(spmv_hip_put* put, int k, const void* peer_ipc_handle,
                          size_t peer_stage_bytes, int32_t dst_offset,
                          int32_t slot_at_peer, int32_t send_offset,
                          int32_t send_count, int32_t recv_offset,
-                         int32_t recv_count);
+                         int32_t recv_count, int peer_fine_grained);
+int spmv_hip_put_fine_grained(const spmv_hip_put* put, int* fine_grained);
 int spmv_hip_put_finish(spmv_hip_put* put);
 int spmv_hip_put_exchange(spmv_hip_ctx* ctx, spmv_hip_put* put, size_t elem_bytes,
                           const void* send_buf, void* ghost_tail, void* stream);

@@ -28,6 +28,7 @@ _lib = None
 class BaselineResult(C.Structure):
     _fields_ = [("spmv_s_per_apply", C.c_double), ("cg_loop_s", C.c_double),
                 ("setup_s", C.c_double), ("rel_residual", C.c_double),
+                ("rel_residual_k10", C.c_double),
                 ("cg_iters", C.c_int), ("threads", C.c_int)]
 
 _i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")

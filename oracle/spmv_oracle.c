@@ -567,15 +567,21 @@ int oracle_cpu_baseline(int32_t n, int threads, int spmv_reps, int cg_iters,
       if (xx < n - 1) { colind[pos] = (int32_t)(i + 1); values[pos++] = -1.0; }
       if (yy < n - 1) { colind[pos] = (int32_t)(i + n); values[pos++] = -1.0; }
       if (zz < n - 1) { colind[pos] = (int32_t)(i + n2); values[pos++] = -1.0; }
-      b[i] = 1.0;
+      /* the right-hand side of the GPU line: the reference's Gaussian vector
+         (demos/spmv.cpp:63-67), so that the residual after 10 iterations can
+         be read beside the GPU's */
+      const double z = (double)i / (double)N;
+      const double u = 5 * (z - 0.5);
+      b[i] = exp(-10 * (u * u));
       x[i] = 0.0;
-      r[i] = 1.0; /* cg.cpp:44-45: r = p = b */
-      p[i] = 1.0;
+      r[i] = b[i]; /* cg.cpp:44-45: r = p = b */
+      p[i] = b[i];
       Ap[i] = 0.0;
     }
   }
   res->setup_s = now_s() - t0;
   res->threads = nt;
+  res->rel_residual_k10 = 0.0;
   /* SpMV: 1 warm-up + reps timed (demos/spmv.cpp:73-96) */
   oracle_omp_spmv(plan, (int32_t)N, nnz, rowptr, colind, values, NULL, 1.0, p,
                   0.0, Ap);
@@ -600,6 +606,8 @@ int oracle_cpu_baseline(int32_t n, int threads, int spmv_reps, int cg_iters,
     double rnorm_new = sqrt(omp_ddot(N, r, r, nt));
     double beta = (rnorm_new * rnorm_new) / (rnorm_old * rnorm_old);
     rnorm_old = rnorm_new;
+    if (k == 10)
+      res->rel_residual_k10 = rnorm_new / rnorm0;
     omp_dscal(N, beta, p, nt);
     omp_daxpy(N, 1.0, r, p, nt);
   }

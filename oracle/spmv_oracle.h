@@ -118,6 +118,7 @@ typedef struct {
   double cg_loop_s;
   double setup_s;
   double rel_residual;
+  double rel_residual_k10; /* after 10 iterations (0 when fewer were run) */
   int cg_iters;
   int threads;
 } oracle_baseline_result;

@@ -81,6 +81,7 @@ _PROTOS = {
     "spmv_hip_csr_plan_bake_values_f64": ([vp, vp, vp, vp, vp], C.c_int),
     "spmv_hip_csr_plan_bake_values_f32": ([vp, vp, vp, vp, vp], C.c_int),
     "spmv_hip_csr_plan_bake_values_f32f64": ([vp, vp, vp, vp], C.c_int),
+    "spmv_hip_csr_plan_values_changed": ([vp, vp, vp], C.c_int),
     "spmv_hip_csr_plan_algo": ([vp, P(C.c_int)], C.c_int),
     "spmv_hip_csr_plan_set": ([vp, C.c_char_p, C.c_int], C.c_int),
     "spmv_hip_csr_plan_get": ([vp, C.c_char_p, P(C.c_int)], C.c_int),
@@ -134,7 +135,8 @@ _PROTOS = {
                                          vp], C.c_int),
     "spmv_hip_put_create": ([vp, sz, P(vp), vp, P(C.c_uint64), P(i64)], C.c_int),
     "spmv_hip_put_connect": ([vp, C.c_int, vp, C.c_uint64, i64, sz, i32, i32, i32,
-                              i32, i32, i32], C.c_int),
+                              i32, i32, i32, C.c_int], C.c_int),
+    "spmv_hip_put_fine_grained": ([vp, P(C.c_int)], C.c_int),
     "spmv_hip_put_finish": ([vp], C.c_int),
     "spmv_hip_put_exchange": ([vp, vp, sz, vp, vp, vp], C.c_int),
     "spmv_hip_put_status": ([vp, P(C.c_int)], C.c_int),

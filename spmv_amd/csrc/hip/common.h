@@ -54,6 +54,10 @@ struct spmv_hip_ctx {
   int sj_wpb = 0;
   // ... and this many entries per lane and step ("sj_unit": 1, 2, 4; 0 = choose)
   int sj_unit = 0;
+  // one-sided halo: how long a put kernel polls for its neighbour before the
+  // exchange fails with SPMV_HIP_EPEER ("put_timeout_ms")
+  int put_timeout_ms = 60000;
+  const int32_t* watched[16] = {}; // error words of the put windows (see below)
   // the device Poisson generator's non-symmetric variant ("poisson_skew_ppm":
   // lower neighbours -1 - s, upper -1 + s, s = value * 1e-6; 0 = the Poisson
   // matrix).  For measurements of kernels on matrices that are not symmetric.
@@ -62,6 +66,11 @@ struct spmv_hip_ctx {
   // |dx|, |dy|, |dz| <= 1, diagonal 26, off-diagonal -1: HPCG's operator)
   int poisson_stencil = 7;
 };
+
+// error words (pinned host memory, written by kernels) the context looks at
+// whenever the host synchronises: a non-zero one = SPMV_HIP_EPEER
+void spmv_ctx_watch(spmv_hip_ctx* ctx, const int32_t* word, bool add);
+int spmv_ctx_check_watched(const spmv_hip_ctx* ctx);
 
 #define SPMV_CHECK_HIP(expr)                                                   \
   do {                                                                         \

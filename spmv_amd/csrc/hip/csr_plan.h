@@ -307,6 +307,7 @@ struct spmv_hip_csr_plan {
   int32_t num_listed = 0;
   int nt_store = 0; // non-temporal y stores
   int plan_us = 0;  // wall time of plan creation (analysis kernels included)
+  int values_changed_us = 0; // ... of the last spmv_hip_csr_plan_values_changed
   // The arrays the plan analysed.  Every form beyond the plain gather kernels
   // bakes their CONTENT in (offsets, masks, row lists, transposed map), so a
   // launch with other arrays of the same shape would silently use the wrong

@@ -687,6 +687,8 @@ int spmv_hip_poisson3d_box_count(spmv_hip_ctx* ctx, int32_t n,
 {
   SPMV_SET_DEVICE(ctx);
   SPMV_REQUIRE(part >= SPMV_HIP_PART_ALL && part <= SPMV_HIP_PART_LOCAL_LOWER);
+  if (ctx->poisson_stencil != 7) // the box generator knows the 7-point matrix only
+    return SPMV_HIP_ENOTSUP;
   BoxGeom g;
   int rc = make_box(n, first, len, &g);
   if (rc)
@@ -730,6 +732,8 @@ int spmv_hip_poisson3d_box_fill_f64(spmv_hip_ctx* ctx, int32_t n,
   SPMV_SET_DEVICE(ctx);
   SPMV_REQUIRE(rowptr && part >= SPMV_HIP_PART_ALL
                && part <= SPMV_HIP_PART_LOCAL_LOWER);
+  if (ctx->poisson_stencil != 7)
+    return SPMV_HIP_ENOTSUP;
   BoxGeom g;
   int rc = make_box(n, first, len, &g);
   if (rc)

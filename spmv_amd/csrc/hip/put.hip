@@ -19,19 +19,20 @@
 //
 // Flags carry the EPOCH (a counter of exchanges, monotonic), so nothing is ever
 // reset and a late reader of an old epoch cannot be confused.  Every wait is
-// bounded (about 4 s of wall clock): a peer that died makes the exchange fail
-// (error word in pinned host memory, reported by the next call), not hang.
+// bounded (ctx option "put_timeout_ms", 60 s by default): a peer that died
+// makes the exchange fail -- the ghost segment is filled with NaN, the error
+// word in pinned host memory makes the context's next synchronisation point
+// (and every later exchange) return SPMV_HIP_EPEER -- not hang.
 // The staging hop costs one local copy of the ghost tail (2-4 MB at 512^3 over
 // 8 ranks) and buys a registration that happens once per L2GMap instead of
 // once per vector: the window never moves, whatever vector is exchanged.
 //
 // Validated on ONE device only (1-GPU boxes): ranks as processes that share
 // GPU 0 through IPC handles (tests/mp_gpu_worker.py) and ranks as threads of
-// one process (tests/thread_world.py).  What a single device cannot show --
-// how stores into a PEER's HBM interact with that peer's L2 -- is handled
-// conservatively: flags and staged data are read with system-scope loads that
-// bypass the caches, data is published with a system-scope fence before the
-// flag.
+// one process (tests/thread_world.py).  For peers on OTHER devices the window
+// is fine-grained memory (a peer's stores become visible to the owner's running
+// kernel), flags and staged data are read with system-scope loads that bypass
+// the caches, data is published with a system-scope fence before the flag.
 #include "common.h"
 
 #include <cstring>
@@ -57,13 +58,13 @@ struct spmv_hip_put {
   PutPeer* dev_tab = nullptr;
   int32_t* host_err = nullptr; // pinned, device-visible
   uint64_t epoch = 0;
+  int fine_grained = 0; // the window is fine-grained (uncached) device memory
 };
 
 namespace
 {
 
 constexpr int kPutGroup = 8; // workgroups per neighbour
-constexpr unsigned long long kPutTimeoutTicks = 400000000ull; // 100 MHz: 4 s
 
 __device__ __forceinline__ uint64_t* put_flags(char* window, size_t stage_bytes)
 {
@@ -72,7 +73,8 @@ __device__ __forceinline__ uint64_t* put_flags(char* window, size_t stage_bytes)
 
 // thread 0 polls, the workgroup follows; false = timed out
 __device__ __forceinline__ bool put_wait(const uint64_t* flag, uint64_t epoch,
-                                         int32_t* err)
+                                         int32_t* err,
+                                         unsigned long long timeout_ticks)
 {
   __shared__ int s_ok;
   if (threadIdx.x == 0) {
@@ -81,7 +83,7 @@ __device__ __forceinline__ bool put_wait(const uint64_t* flag, uint64_t epoch,
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
            < epoch) {
       __builtin_amdgcn_s_sleep(16);
-      if (wall_clock64() - t0 > kPutTimeoutTicks) {
+      if (wall_clock64() - t0 > timeout_ticks) {
         ok = 0;
         __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
@@ -103,7 +105,7 @@ template <typename WORD>
 __global__ __launch_bounds__(kBlock) void put_exchange_kernel(
     const PutPeer* __restrict__ tab, const char* __restrict__ send_buf,
     char* __restrict__ ghost_tail, char* window, size_t stage_bytes,
-    uint64_t epoch, int32_t* err)
+    uint64_t epoch, int32_t* err, unsigned long long timeout_ticks)
 {
   const int k = blockIdx.x / kPutGroup, g = blockIdx.x % kPutGroup;
   const PutPeer p = tab[k];
@@ -118,9 +120,21 @@ __global__ __launch_bounds__(kBlock) void put_exchange_kernel(
   if (g == 0 && t == 0)
     __hip_atomic_store(p.peer_flags + SPMV_HIP_PUT_MAX_PEERS + p.slot_at_peer,
                        epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  // A wait that times out leaves this neighbour's ghost segment filled with
+  // NaN: a failed exchange must not look like a valid one to the SpMV that
+  // consumes the ghosts (the host reports SPMV_HIP_EPEER at its next
+  // synchronisation point).
+  auto poison = [&]() {
+    WORD* dst = reinterpret_cast<WORD*>(ghost_tail) + p.recv_off;
+    for (int64_t i = (int64_t)g * kBlock + t; i < p.recv_count;
+         i += (int64_t)kPutGroup * kBlock)
+      dst[i] = ~WORD(0); // all ones: a NaN in either width
+  };
   // (b) ... and so may I, once it says the same
-  if (!put_wait(my_free_flag, epoch, err))
+  if (!put_wait(my_free_flag, epoch, err, timeout_ticks)) {
+    poison();
     return;
+  }
   // (c) my segment -> the neighbour's window
   {
     const WORD* src = reinterpret_cast<const WORD*>(send_buf) + p.send_off;
@@ -139,8 +153,10 @@ __global__ __launch_bounds__(kBlock) void put_exchange_kernel(
   }
   // (d) the neighbour's data -> the ghost tail (loads that bypass the caches:
   // the lines were written by another agent)
-  if (!put_wait(my_data_flag, epoch, err))
+  if (!put_wait(my_data_flag, epoch, err, timeout_ticks)) {
+    poison();
     return;
+  }
   {
     const WORD* src = reinterpret_cast<const WORD*>(window) + p.recv_off;
     WORD* dst = reinterpret_cast<WORD*>(ghost_tail) + p.recv_off;
@@ -176,16 +192,36 @@ int spmv_hip_put_create(spmv_hip_ctx* ctx, size_t stage_bytes,
   for (int k = 0; k < SPMV_HIP_PUT_MAX_PEERS; ++k)
     p->mapped[k] = nullptr;
   const size_t bytes = put_window_bytes(p->stage_bytes);
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->window), bytes);
+  // The window is written by PEER devices while a kernel of the owner polls
+  // it: that is only defined for fine-grained (uncached) memory -- plain
+  // hipMalloc memory is coarse-grained, the owner's L2 may keep serving a
+  // stale flag or stale staged data (RCCL allocates its peer-written buffers
+  // the same way).  Where the runtime cannot export such memory over IPC the
+  // window falls back to hipMalloc and is marked: it then serves ranks on the
+  // SAME device only (spmv_hip_put_connect refuses anything else).
+  hipIpcMemHandle_t h;
+  hipError_t e = hipExtMallocWithFlags(reinterpret_cast<void**>(&p->window), bytes,
+                                       hipDeviceMallocFinegrained);
+  if (e == hipSuccess)
+    e = hipIpcGetMemHandle(&h, p->window);
+  if (e == hipSuccess) {
+    p->fine_grained = 1;
+  } else {
+    (void)hipGetLastError();
+    (void)hipFree(p->window);
+    p->window = nullptr;
+    e = hipMalloc(reinterpret_cast<void**>(&p->window), bytes);
+    if (e == hipSuccess)
+      e = hipIpcGetMemHandle(&h, p->window);
+  }
   if (e == hipSuccess)
     e = hipMemset(p->window, 0, bytes);
   if (e == hipSuccess)
     e = hipHostMalloc(reinterpret_cast<void**>(&p->host_err), sizeof(int32_t),
                       hipHostMallocMapped);
-  hipIpcMemHandle_t h;
   if (e == hipSuccess) {
     *p->host_err = 0;
-    e = hipIpcGetMemHandle(&h, p->window);
+    spmv_ctx_watch(ctx, p->host_err, true);
   }
   if (e != hipSuccess) {
     (void)hipFree(p->window);
@@ -206,17 +242,37 @@ int spmv_hip_put_connect(spmv_hip_put* put, int k, const void* peer_ipc_handle,
                          size_t peer_stage_bytes, int32_t dst_offset,
                          int32_t slot_at_peer, int32_t send_offset,
                          int32_t send_count, int32_t recv_offset,
-                         int32_t recv_count)
+                         int32_t recv_count, int peer_fine_grained)
 {
   SPMV_REQUIRE(put && k >= 0 && k < SPMV_HIP_PUT_MAX_PEERS && peer_ipc_handle
                && slot_at_peer >= 0 && slot_at_peer < SPMV_HIP_PUT_MAX_PEERS
                && dst_offset >= 0 && send_offset >= 0 && send_count >= 0
                && recv_offset >= 0 && recv_count >= 0);
   SPMV_SET_DEVICE(put->ctx);
+  // my segments stay inside the two staging buffers (8-byte elements at most)
+  SPMV_REQUIRE(((size_t)dst_offset + (size_t)send_count) * 8
+                   <= ((peer_stage_bytes + 255) & ~(size_t)255)
+               && ((size_t)recv_offset + (size_t)recv_count) * 8 <= put->stage_bytes);
+  const bool peer_fine = peer_fine_grained != 0;
   char* base = nullptr;
   if (peer_process_id == (int64_t)getpid()) {
-    // a rank of this process (threads): one address space
+    // a rank of this process (threads): one address space.  On ANOTHER device
+    // the window must be fine-grained and this device needs peer access to it.
     base = reinterpret_cast<char*>(peer_raw_address);
+    hipPointerAttribute_t attr;
+    SPMV_CHECK_HIP(hipPointerGetAttributes(&attr, base));
+    if (attr.device != put->ctx->device) {
+      if (!peer_fine || !put->fine_grained)
+        return SPMV_HIP_ENOTSUP;
+      int can = 0;
+      SPMV_CHECK_HIP(hipDeviceCanAccessPeer(&can, put->ctx->device, attr.device));
+      if (!can)
+        return SPMV_HIP_ENOTSUP;
+      const hipError_t ep = hipDeviceEnablePeerAccess(attr.device, 0);
+      if (ep != hipSuccess && ep != hipErrorPeerAccessAlreadyEnabled)
+        return static_cast<int>(ep);
+      (void)hipGetLastError();
+    }
   } else {
     hipIpcMemHandle_t h;
     memcpy(&h, peer_ipc_handle, sizeof(h));
@@ -224,6 +280,13 @@ int spmv_hip_put_connect(spmv_hip_put* put, int k, const void* peer_ipc_handle,
     SPMV_CHECK_HIP(hipIpcOpenMemHandle(&m, h, hipIpcMemLazyEnablePeerAccess));
     put->mapped[k] = m;
     base = static_cast<char*>(m);
+    // a coarse-grained window of another process is only safe on this device
+    if (!peer_fine || !put->fine_grained) {
+      hipPointerAttribute_t attr;
+      SPMV_CHECK_HIP(hipPointerGetAttributes(&attr, m));
+      if (attr.device != put->ctx->device)
+        return SPMV_HIP_ENOTSUP;
+    }
   }
   const size_t peer_stage = (peer_stage_bytes + 255) & ~(size_t)255;
   PutPeer& pp = put->host_tab[k];
@@ -265,6 +328,9 @@ int spmv_hip_put_exchange(spmv_hip_ctx* ctx, spmv_hip_put* put, size_t elem_byte
   hipStream_t st = spmv_stream(ctx, stream);
   const uint64_t epoch = ++put->epoch;
   const dim3 grid(put->num_peers * kPutGroup), block(kBlock);
+  // wall_clock64 ticks at 100 MHz
+  const unsigned long long ticks
+      = (unsigned long long)ctx->put_timeout_ms * 100000ull;
   int32_t* dev_err = nullptr;
   SPMV_CHECK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&dev_err),
                                          put->host_err, 0));
@@ -272,13 +338,20 @@ int spmv_hip_put_exchange(spmv_hip_ctx* ctx, spmv_hip_put* put, size_t elem_byte
     hipLaunchKernelGGL(put_exchange_kernel<uint64_t>, grid, block, 0, st,
                        put->dev_tab, static_cast<const char*>(send_buf),
                        static_cast<char*>(ghost_tail), put->window,
-                       put->stage_bytes, epoch, dev_err);
+                       put->stage_bytes, epoch, dev_err, ticks);
   else
     hipLaunchKernelGGL(put_exchange_kernel<uint32_t>, grid, block, 0, st,
                        put->dev_tab, static_cast<const char*>(send_buf),
                        static_cast<char*>(ghost_tail), put->window,
-                       put->stage_bytes, epoch, dev_err);
+                       put->stage_bytes, epoch, dev_err, ticks);
   SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_put_fine_grained(const spmv_hip_put* put, int* fine_grained)
+{
+  SPMV_REQUIRE(put && fine_grained);
+  *fine_grained = put->fine_grained;
   return SPMV_HIP_OK;
 }
 
@@ -298,6 +371,7 @@ int spmv_hip_put_destroy(spmv_hip_put* put)
   for (int k = 0; k < SPMV_HIP_PUT_MAX_PEERS; ++k)
     if (put->mapped[k])
       (void)hipIpcCloseMemHandle(put->mapped[k]);
+  spmv_ctx_watch(put->ctx, put->host_err, false);
   (void)hipFree(put->dev_tab);
   (void)hipFree(put->window);
   (void)hipHostFree(put->host_err);

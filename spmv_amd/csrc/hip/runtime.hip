@@ -8,6 +8,29 @@
 #include <cstring>
 #include <new>
 
+// The put windows' error words (put.hip): a put kernel that gave up waiting for
+// its neighbour leaves NaN ghosts and sets its word; the host learns of it at
+// the next point where it waits for the device anyway.
+void spmv_ctx_watch(spmv_hip_ctx* ctx, const int32_t* word, bool add)
+{
+  for (auto& w : ctx->watched) {
+    if (add && w == nullptr) {
+      w = word;
+      return;
+    }
+    if (!add && w == word)
+      w = nullptr;
+  }
+}
+
+int spmv_ctx_check_watched(const spmv_hip_ctx* ctx)
+{
+  for (const int32_t* w : ctx->watched)
+    if (w && *reinterpret_cast<const volatile int32_t*>(w))
+      return SPMV_HIP_EPEER;
+  return SPMV_HIP_OK;
+}
+
 extern "C" {
 
 int spmv_hip_abi_version(void) { return SPMV_HIP_ABI_VERSION; }
@@ -152,6 +175,11 @@ int spmv_hip_ctx_set_option(spmv_hip_ctx* ctx, const char* key, int64_t value)
     ctx->sj_unit = (int)value;
     return SPMV_HIP_OK;
   }
+  if (!strcmp(key, "put_timeout_ms")) {
+    SPMV_REQUIRE(value >= 1 && value <= 3600000);
+    ctx->put_timeout_ms = (int)value;
+    return SPMV_HIP_OK;
+  }
   if (!strcmp(key, "bake_general")) {
     SPMV_REQUIRE(value == 0 || value == 1);
     ctx->bake_general = (int)value;
@@ -164,7 +192,7 @@ int spmv_hip_synchronize(spmv_hip_ctx* ctx)
 {
   SPMV_SET_DEVICE(ctx);
   SPMV_CHECK_HIP(hipDeviceSynchronize());
-  return SPMV_HIP_OK;
+  return spmv_ctx_check_watched(ctx);
 }
 
 // ---- streams / events ------------------------------------------------------
@@ -207,7 +235,7 @@ int spmv_hip_stream_synchronize(spmv_hip_ctx* ctx, void* stream)
 {
   SPMV_SET_DEVICE(ctx);
   SPMV_CHECK_HIP(hipStreamSynchronize(spmv_stream(ctx, stream)));
-  return SPMV_HIP_OK;
+  return spmv_ctx_check_watched(ctx);
 }
 
 int spmv_hip_set_stream(spmv_hip_ctx* ctx, void* stream)
@@ -257,7 +285,7 @@ int spmv_hip_event_synchronize(spmv_hip_ctx* ctx, void* event)
   SPMV_SET_DEVICE(ctx);
   SPMV_REQUIRE(event);
   SPMV_CHECK_HIP(hipEventSynchronize(static_cast<hipEvent_t>(event)));
-  return SPMV_HIP_OK;
+  return spmv_ctx_check_watched(ctx);
 }
 
 int spmv_hip_stream_wait_event(spmv_hip_ctx* ctx, void* stream, void* event)

@@ -1477,6 +1477,58 @@ int spmv_hip_csr_plan_bake_values_f32f64(spmv_hip_ctx* ctx,
   return spmv_sdia_bake_f32f64(plan, values32, st);
 }
 
+int spmv_hip_csr_plan_values_changed(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan,
+                                     void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(plan && plan->ctx == ctx);
+  hipStream_t st = spmv_stream(ctx, stream);
+  const auto t_begin = std::chrono::steady_clock::now();
+  const int plan_us0 = plan->plan_us;
+  int rc = SPMV_HIP_OK;
+  // the sliced jagged copy: rewritten in place
+  if (plan->sj_val && plan->sj_values0) {
+    rc = plan->sj_elem == 8
+             ? spmv_sjds_bake_f64(plan, static_cast<const double*>(plan->sj_values0), st)
+             : spmv_sjds_bake_f32(plan, static_cast<const float*>(plan->sj_values0), st);
+  }
+  // the diagonal forms: the device checks decide the form again (a matrix
+  // they no longer hold: ENOTSUP = back to the CSR-order kernels, which is a
+  // correct outcome of this call)
+  if (rc == SPMV_HIP_OK && (plan->sdia_val || plan->wdia_val)) {
+    const void* v32 = plan->sdia32_values0 ? plan->sdia32_values0
+                                           : plan->wdia32_values0;
+    if (plan->sdia_val ? plan->sdia_elem == 8 : plan->wdia_elem == 8) {
+      const double* v = static_cast<const double*>(
+          plan->sdia_val ? plan->sdia_values0 : plan->wdia_values0);
+      const double* d = static_cast<const double*>(plan->sdia_val ? plan->sdia_diag0
+                                                                  : nullptr);
+      rc = spmv_hip_csr_plan_bake_values_f64(ctx, plan, v, d, stream);
+      if (rc == SPMV_HIP_OK && v32) {
+        rc = spmv_hip_csr_plan_bake_values_f32f64(
+            ctx, plan, static_cast<const float*>(v32), stream);
+        if (rc == SPMV_HIP_ENOTSUP)
+          rc = SPMV_HIP_OK;
+      }
+    } else {
+      const float* v = static_cast<const float*>(
+          plan->sdia_val ? plan->sdia_values0 : plan->wdia_values0);
+      const float* d = static_cast<const float*>(plan->sdia_val ? plan->sdia_diag0
+                                                                 : nullptr);
+      rc = spmv_hip_csr_plan_bake_values_f32(ctx, plan, v, d, stream);
+    }
+    if (rc == SPMV_HIP_ENOTSUP)
+      rc = SPMV_HIP_OK;
+  }
+  SPMV_CHECK_HIP(hipStreamSynchronize(st));
+  plan->plan_us = plan_us0; // (the bakes added themselves: not plan creation)
+  plan->values_changed_us
+      = (int)std::chrono::duration_cast<std::chrono::microseconds>(
+            std::chrono::steady_clock::now() - t_begin)
+            .count();
+  return rc;
+}
+
 int spmv_hip_zwalk_table(int32_t num_rows, int64_t plane_rows, int grid,
                          int segments, int32_t* table, int64_t capacity,
                          int64_t* num_slots, int* segments_out)
@@ -1709,6 +1761,10 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
     *value = plan->sj_lenperm && plan->nnz > 0
                  ? (int)(plan->sj_sumk * 12800 / plan->nnz)
                  : 0;
+  else if (!strcmp(key, "sj_pad_permille")) // entries of padding per 1000 stored
+    *value = plan->sj_lenperm && plan->nnz > 0
+                 ? (int)((plan->sj_units * plan->sj_unit * 1000) / plan->nnz)
+                 : 0;
   else if (!strcmp(key, "sj_long_rows"))
     *value = plan->sj_lenperm ? plan->sj_nlong : 0;
   else if (!strcmp(key, "sj_wide"))
@@ -1721,6 +1777,8 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
     *value = plan->wdia_val ? plan->wdia_K : 0;
   else if (!strcmp(key, "plan_us"))
     *value = plan->plan_us;
+  else if (!strcmp(key, "values_changed_us"))
+    *value = plan->values_changed_us;
   else if (!strcmp(key, "plan_kib")) {
     // device memory the plan owns beyond the caller's CSR arrays
     const int64_t n = plan->num_rows, nnz = plan->nnz;

@@ -1172,7 +1172,10 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
   // entries per lane and step: a unit's padding (half a unit per row) against
   // the instructions of a step
   const double avg = (double)pl->nnz / n;
-  const int E = unit_force ? unit_force : (avg >= 24.0 ? 4 : (avg >= 5.0 ? 2 : 1));
+  // (measured, 10 M rows: lengths 5-40 0.55 / 0.41 / 0.44 ms with 1 / 2 / 4
+  // entries per step; 81 per row 1.38 / 1.37 / 1.38; 7 per row 0.357 / 0.355 /
+  // 0.349)
+  const int E = unit_force ? unit_force : (avg >= 4.0 ? 2 : 1);
   const int nblk4 = (n + 255) / 256;
   const int64_t nsl = ((int64_t)n + 63) / 64;
   int32_t *d_k = nullptr, *d_far = nullptr;

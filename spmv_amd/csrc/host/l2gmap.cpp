@@ -158,7 +158,7 @@ void L2GMap::setup_put(std::int64_t local_size)
     std::uint64_t raw = 0;
     unsigned char handle[SPMV_HIP_IPC_HANDLE_BYTES] = {};
     std::int64_t stage_bytes = 0;
-    std::int32_t ok = 0, nn = 0;
+    std::int32_t ok = 0, nn = 0, fine = 0;
     std::int32_t nbr[SPMV_HIP_PUT_MAX_PEERS] = {};
     std::int32_t ghost_off[SPMV_HIP_PUT_MAX_PEERS] = {};
   };
@@ -171,6 +171,9 @@ void L2GMap::setup_put(std::int64_t local_size)
                              mine.handle, &mine.raw, &mine.pid)
              == SPMV_HIP_OK) {
     mine.ok = 1;
+    int fine = 0;
+    (void)spmv_hip_put_fine_grained(put, &fine);
+    mine.fine = fine;
     mine.nn = static_cast<std::int32_t>(nn);
     for (std::size_t i = 0; i < nn; ++i) {
       mine.nbr[i] = _neighbours[i];
@@ -201,7 +204,7 @@ void L2GMap::setup_put(std::int64_t local_size)
                               _x_send_count[i],
                               _x_recv_offset[i]
                                   - static_cast<std::int32_t>(local_size),
-                              _x_recv_count[i]);
+                              _x_recv_count[i], peer.fine);
   }
   if (rc == SPMV_HIP_OK && nn > 0)
     rc = spmv_hip_put_finish(put);
@@ -212,6 +215,10 @@ void L2GMap::setup_put(std::int64_t local_size)
   bool all_ok = true;
   for (std::int32_t o : oks)
     all_ok = all_ok && o;
+  // what every rank knows to be the same everywhere: the destructor's barrier
+  // is keyed on it, not on this rank's own window (a rank without neighbours
+  // has none, yet must take part)
+  _put_agreed = all_ok;
   if (all_ok && nn > 0) {
     _put = put;
   } else {
@@ -222,16 +229,21 @@ void L2GMap::setup_put(std::int64_t local_size)
 
 L2GMap::~L2GMap()
 {
-  if (_put) {
+  if (_put_agreed) {
     // a neighbour may still be storing into this rank's window (its side of
-    // the last exchange): every rank arrives here before anybody frees
+    // the last exchange): every rank arrives here before anybody frees --
+    // EVERY rank of the communicator, also one that has no window of its own
     try {
-      if (_comm_stream)
+      if (_comm_stream && _put)
         _hip->synchronize_stream(_comm_stream);
+    } catch (...) { // (a timed-out exchange: the barrier is still owed)
+    }
+    try {
       (void)_comm->allgather_value<std::int32_t>(0);
     } catch (...) {
     }
-    spmv_hip_put_destroy(_put);
+    if (_put)
+      spmv_hip_put_destroy(_put);
     _put = nullptr;
   }
   try {

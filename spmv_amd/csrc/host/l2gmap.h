@@ -112,6 +112,7 @@ private:
   // connections to the neighbours' (libspmv_hip.so, put.hip); null = the
   // two-sided exchange
   spmv_hip_put* _put = nullptr;
+  bool _put_agreed = false; // every rank set its window up (same on all ranks)
   void setup_put(std::int64_t local_size);
 
   mutable void* _send_buf = nullptr; // lazily allocated (L2GMap.cpp:607-614)

@@ -50,6 +50,15 @@ class Buffer:
     def at(self, offset):
         return self.ptr + offset * np.dtype(self.dtype).itemsize
 
+    def write(self, arr):
+        """Blocking host->device copy INTO this allocation (same length)."""
+        arr = np.ascontiguousarray(arr, dtype=self.dtype)
+        assert arr.size == self.count
+        if self.nbytes:
+            call("spmv_hip_copy_h2d_async", self.ctx.h, self.ptr,
+                 arr.ctypes.data_as(C.c_void_p), self.nbytes, None)
+            self.ctx.stream_sync()
+
 
 class Context:
     """spmv_hip_ctx: one GPU."""
@@ -217,6 +226,11 @@ class CsrBlock:
                 else "spmv_hip_csr_plan_bake_values_f32")
         call(name, self.ctx.h, self.plan, None if drop else _p(self.values),
              None if drop else _p(self.diagonal), None)
+
+    def values_changed(self):
+        """spmv_hip_csr_plan_values_changed: the baked arrays were rewritten in
+        place; refresh the plan's copies."""
+        call("spmv_hip_csr_plan_values_changed", self.ctx.h, self.plan, None)
 
     def set(self, key, value):
         call("spmv_hip_csr_plan_set", self.plan, key.encode(), int(value))

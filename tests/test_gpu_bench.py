@@ -53,7 +53,7 @@ def test_bench_single_gpu_line():
                           "--grid", "64", "--steps", "20", "--warmup", "3",
                           "--cpu-n", "32", "--cpu-iters", "3", "--mixed-grid",
                           "48", "--stencil27-grid", "40", "--unstructured-rows",
-                          "200000"],
+                          "200000", "--fem-rows", "200000"],
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
     d = _line(res.stdout)
@@ -93,9 +93,31 @@ def test_bench_single_gpu_line():
     assert ns["form"]["sdia"] == 1 and "full" in ns["kernel"]
     assert d["north_star_spmv"]["form"]["lat"] == 1
     # the kernels of matrices WITHOUT lattice structure, measured and checked
-    assert d["csr_rowblock_spmv"]["form"] == dict(lat=0, lx=0, lxw=0, wdia=0,
-                                                  wdia_const=0, slat=0, sdia=0,
-                                                  sdia_const=0, sym_det=0, zwalk=0)
+    assert d["csr_rowblock_spmv"]["form"] == dict(lat=0, lx=0, lxw=0, sjds=0,
+                                                  wdia=0, wdia_const=0, slat=0,
+                                                  sdia=0, sdia_const=0, sym_det=0,
+                                                  zwalk=0)
+    assert d["csr_sjds_spmv"]["form"]["sjds"] == 1
+    # the general-CSR line inside `roofline` (the block the driver keeps): the
+    # AUTO plan without the lattice analysis, same CG loop, SURVEY 8d's bytes
+    co = r_ = d["roofline"]["csr_order"]
+    assert "csr_lxw_kernel" in co["kernel"] and 0 < co["frac"] <= 1.5
+    assert abs(co["frac"] - co["algorithmic_bytes_per_launch"] / co["ms_per_apply"]
+               / 1e6 / 8000.0) < 1e-9
+    assert co["algorithmic_bytes_per_launch"] == d["roofline"][
+        "algorithmic_bytes_per_launch"]
+    assert abs(co["cg_rel_residual_k10"] / d["cg_rel_residual"]["k10"] - 1) < 1e-9
+    assert d["roofline"]["general_cg_iters_per_s"] > 0
+    # ragged rows: the sliced jagged form, bit-equal to the reference loop
+    rg = d["roofline"]["ragged"]
+    for k in ("fem_spmv", "fem_tail_spmv", "fem81_spmv", "unstructured_spmv"):
+        assert rg[k]["bit_equal_one_lane_per_row"] is True and rg[k]["frac"] > 0
+        assert d[k]["rows"] == 200000 and d[k]["crosscheck"]["bit_equal"] is True
+    for k in ("fem_spmv", "fem_tail_spmv", "fem81_spmv"):
+        assert "csr_sjds_kernel" in rg[k]["kernel"] and d[k]["form"]["sjds"] == 1
+    assert 13 < d["fem_spmv"]["avg_row"] < 17 and d["fem81_spmv"]["avg_row"] > 79
+    assert d["fem_tail_spmv"]["avg_row"] > 20
+    assert c["cg_rel_residual_k10"] is None or c["cg_rel_residual_k10"] > 0
     for k in ("north_star_lattice_spmv", "north_star_lx_spmv",
               "north_star_rowblock_spmv"):
         assert d[k]["rows"] == 216 ** 3 and d[k]["form"]["sdia"] == 0

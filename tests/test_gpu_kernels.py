@@ -492,9 +492,9 @@ def test_put_exchange_with_itself(ctx, dtype):
     put, handle, raw, pid = _put_window(ctx, 8 * (n0 + n1))
     # slot k: send segment k of the send buffer to where the OTHER slot reads
     hip.call("spmv_hip_put_connect", put, 0, handle, raw, pid, 8 * (n0 + n1),
-             n0, 1, 0, n1, 0, n0)        # my n1 items -> segment [n0, n0 + n1)
+             n0, 1, 0, n1, 0, n0, 1)     # my n1 items -> segment [n0, n0 + n1)
     hip.call("spmv_hip_put_connect", put, 1, handle, raw, pid, 8 * (n0 + n1),
-             0, 0, n1, n0, n0, n1)       # my n0 items -> segment [0, n0)
+             0, 0, n1, n0, n0, n1, 1)    # my n0 items -> segment [0, n0)
     hip.call("spmv_hip_put_finish", put)
     rng = np.random.default_rng(5)
     ghost = ctx.upload(np.full(n0 + n1, np.nan, dtype), dtype)
@@ -526,22 +526,37 @@ def test_put_exchange_times_out_instead_of_hanging(ctx):
     put, handle, raw, pid = _put_window(ctx, 8 * n)
     # connected to itself in the WRONG slot: it signals slot 3, waits on slot 0
     hip.call("spmv_hip_put_connect", put, 0, handle, raw, pid, 8 * n, 0, 3, 0, n,
-             0, n)
+             0, n, 1)
     hip.call("spmv_hip_put_finish", put)
+    # a segment outside the staging buffers is refused at connect time
+    with pytest.raises(Exception):
+        hip.call("spmv_hip_put_connect", put, 1, handle, raw, pid, 8 * n, 1, 3, 0,
+                 n, 0, n, 1)
+    ctx.set_option("put_timeout_ms", 3000)  # (the default is a minute)
     send, ghost = ctx.upload(np.ones(n)), ctx.upload(np.zeros(n))
     t0 = time.perf_counter()
     hip.call("spmv_hip_put_exchange", ctx.h, put, 8, send.ptr, ghost.ptr, None)
-    ctx.stream_sync()
+    # the host learns of it where it waits for the device anyway
+    with pytest.raises(Exception, match="did not answer"):
+        ctx.stream_sync()
     waited = time.perf_counter() - t0
     assert 2.0 < waited < 20.0, waited
     failed = C.c_int()
     hip.call("spmv_hip_put_status", put, C.byref(failed))
     assert failed.value == 1
-    assert np.all(ghost.numpy() == 0.0)  # nothing was delivered
+    # nothing was delivered, and the ghosts cannot be taken for valid ones: NaN
+    out = np.empty(n)
+    hip.call("spmv_hip_copy_d2h_async", ctx.h, out.ctypes.data_as(C.c_void_p),
+             ghost.ptr, 8 * n, None)
+    with pytest.raises(Exception, match="did not answer"):
+        ctx.synchronize()
+    assert np.all(np.isnan(out))
     with pytest.raises(Exception, match="did not answer"):
         hip.call("spmv_hip_put_exchange", ctx.h, put, 8, send.ptr, ghost.ptr, None)
+    hip.call("spmv_hip_put_destroy", put)  # ... until the window is gone
+    ctx.set_option("put_timeout_ms", 60000)
+    ctx.stream_sync()
     send.free(), ghost.free()
-    hip.call("spmv_hip_put_destroy", put)
 
 
 def test_unstructured_generator_matches_numpy_twin(ctx):
@@ -689,6 +704,107 @@ def test_sliced_jagged_form_bit_exact(sj_ctx, wpb, unit):
     for b in (dx, dy):
         b.free()
     blk.free()
+
+
+def test_plan_values_changed_after_updates_in_place():
+    """spmv_hip_csr_plan_values_changed: a caller that keeps the sparsity and
+    rewrites the coefficients IN PLACE (time stepping) -- three updates on every
+    form that keeps its own copy of the values, each followed by the call, each
+    product identical to the oracle's on the new values; without the call the
+    copy is stale by contract (the old product), and a plan without a copy needs
+    no call.  Forms: sliced jagged (ragged rows), half / full / constant
+    diagonal form behind the general SpMV, symmetric storage, wide diagonal
+    form; values that change the form on the way (constant -> varying ->
+    constant, symmetric -> not symmetric)."""
+    ctx = hip.Context(0)
+    for k in ("sj_min_nnz", "lat_min_nnz", "lx_min_nnz"):
+        ctx.set_option(k, 0)
+    rng = np.random.default_rng(0xC0EFF)
+    n = 12
+    N = n ** 3
+    prp, pci, pva = poisson.poisson3d_csr(n)
+    pci = pci.astype(np.int32)
+
+    def sym_values(scale):  # symmetric, varying coefficients on the 7-point lattice
+        rows = np.repeat(np.arange(N), np.diff(prp))
+        lo, hi = np.minimum(rows, pci), np.maximum(rows, pci)
+        h = (lo * 1000003 + hi * 7919) % 1021
+        return np.where(rows == pci, 6.0 * scale, -(1.0 + h / 1021.0) * scale)
+
+    cases = []
+    # (name, rowptr, colind, [values per step], symmetric storage?, expect form)
+    frp, fci, fva = poisson.fem_like_csr(5000, jitter=64, layer=300,
+                                         tail_permille=20, tail_min=100,
+                                         tail_max=400, tail_stride=2)
+    cases.append(("sjds", frp, fci, [fva, -0.5 * fva, rng.uniform(-1, 1, len(fva)),
+                                     fva * 3.0], False, dict(sjds=1)))
+    cases.append(("half_diagonal", prp, pci,
+                  [sym_values(1.0), sym_values(0.25), sym_values(-2.0),
+                   sym_values(7.0)], False, dict(sdia=1)))
+    cases.append(("const_to_varying_and_back", prp, pci,
+                  [pva, sym_values(1.0), 2.0 * pva,
+                   rng.uniform(-1, 1, len(pva))], False, dict(sdia=1)))
+    o27 = sorted(a * n * n + b * n + c for a in (-1, 0, 1) for b in (-1, 0, 1)
+                 for c in (-1, 0, 1))
+    wrp, wci, wva = _stencil_csr(rng, N, o27, drop=0.1)
+    cases.append(("wide_diagonal", wrp, wci,
+                  [wva, 0.5 * wva, rng.uniform(-1, 1, len(wva)), -wva], False,
+                  dict(wdia=1)))
+    lrp, lci, lva0, ldg0 = lower_split(prp, pci, sym_values(1.0))
+    cases.append(("symmetric_storage", lrp, lci,
+                  [(lower_split(prp, pci, sym_values(s))[2],
+                    lower_split(prp, pci, sym_values(s))[3])
+                   for s in (1.0, 0.5, -3.0, 2.0)], True, dict(sdia=1)))
+    for name, rp, ci, steps, symmetric, form in cases:
+        nr = len(rp) - 1
+        x = rng.uniform(-1, 1, nr)
+        v0 = steps[0]
+        blk = hip.CsrBlock(ctx, nr, nr, rp, ci, v0[0] if symmetric else v0,
+                           v0[1] if symmetric else None, symmetric)
+        blk.bake()
+        for k, v in form.items():
+            assert blk.get(k) == v, (name, k)
+        dx, dy = ctx.upload(x), ctx.upload(np.full(nr, np.nan))
+
+        def ref(v):
+            if symmetric:
+                return oracle.csr_spmv_sym(rp, ci, v[0], v[1], x)
+            return oracle.csr_spmv(rp, ci, v, x)
+        blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+        assert np.array_equal(dy.numpy(), ref(v0)), name
+        for step, v in enumerate(steps[1:], 1):
+            if symmetric:
+                blk.values.write(v[0])
+                blk.diagonal.write(v[1])
+            else:
+                blk.values.write(v)
+            if step == 1:  # stale by contract: the plan's own copy is the old one
+                blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+                assert np.array_equal(dy.numpy(), ref(v0)), name
+            blk.values_changed()
+            assert blk.get("values_changed_us") > 0
+            blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+            assert np.array_equal(dy.numpy(), ref(v)), (name, step)
+        if name == "const_to_varying_and_back":
+            assert blk.get("sdia") == 1 and blk.get("sdia_general") == 2
+        for b in (dx, dy):
+            b.free()
+        blk.free()
+    # a plan without a copy: the call does nothing, launches read the caller's
+    # arrays as they are
+    ctx.set_option("sj_min_nnz", 1 << 62)
+    rp, ci, va = random_csr(rng, 700, 700, 9)
+    blk = hip.CsrBlock(ctx, 700, 700, rp, ci, va, None, False)
+    x = rng.uniform(-1, 1, 700)
+    dx, dy = ctx.upload(x), ctx.upload(np.full(700, np.nan))
+    blk.values.write(2.0 * va)
+    blk.values_changed()
+    blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+    assert np.array_equal(dy.numpy(), oracle.csr_spmv(rp, ci, 2.0 * va, x))
+    for b in (dx, dy):
+        b.free()
+    blk.free()
+    ctx.close()
 
 
 FEM_KINDS = {"fem": dict(), "fem_tail": dict(tail_permille=10),

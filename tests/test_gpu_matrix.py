@@ -26,6 +26,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EPS = np.finfo(float).eps
 CMS = [host.P2P_BLOCKING, host.P2P_NONBLOCKING, host.COLLECTIVE_BLOCKING,
        host.COLLECTIVE_NONBLOCKING]
+# the seeded FEM-like matrices of the ragged-row records (spmv_amd.poisson)
+FEM_KINDS = {"fem": dict(), "fem_tail": dict(tail_permille=10),
+             "fem81": dict(min_len=81, max_len=81)}
 
 
 @pytest.fixture(scope="module")
@@ -394,6 +397,36 @@ def test_read_petsc_binary(exec_, comm, tmp_path, symmetric):
     exec_.free(d_b), exec_.free(d_x)
 
 
+@pytest.mark.parametrize("kind", ["fem", "fem_tail"])
+def test_petsc_file_of_a_ragged_matrix_one_million_rows(exec_, comm, tmp_path, kind):
+    """demos/spmv.cpp:43 / demos/cg.cpp:47-51 on a file of the size the reader
+    is for: tools/write_petsc.py writes the 1 M-row FEM-like matrix (ragged rows;
+    with a tail of 200-2000-entry rows) as a PETSc binary file, the product
+    reads it (spmv/read_petsc.cpp:40-228), builds the distributed matrix and
+    multiplies -- every element identical to the oracle's loop on the same
+    arrays; the plan is the sliced jagged form."""
+    N = 1_000_000
+    fa = tmp_path / "A.dat"
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "write_petsc.py"),
+                          "--kind", kind, "--rows", str(N), "--out", str(fa)],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    rp, ci, va = poisson.fem_like_csr(N, **FEM_KINDS[kind])
+    x = oracle.gaussian_x_fast(N) + 0.25
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    A = host.read_petsc_binary_matrix(fa, comm, exec_, False, host.P2P_NONBLOCKING)
+    assert A.rows() == N and A.non_zeros() == len(va)
+    assert A.plan_get("sjds") == 1
+    d_x, d_y = exec_.alloc(N), exec_.alloc(N)
+    exec_.copy_from_host(d_x, x)
+    exec_.memset(d_y, 0xFF, 8 * N)
+    A.col_map().update(d_x)
+    A.mult(d_x, d_y)
+    assert np.array_equal(exec_.copy_to_host(d_y, N), y_ref)
+    A.close()
+    exec_.free(d_x), exec_.free(d_y)
+
+
 @pytest.mark.parametrize("symmetric", [False, True])
 def test_matrix_fp32(exec_, comm, symmetric):
     """Matrix<float>: the fp32 visitors of the executor interface
@@ -519,20 +552,23 @@ def test_full_size_kernels_agree_bit_for_bit(exec_, comm, n):
         # per-row kernel (the reference loop verbatim) on the same matrix with
         # the lattice analysis switched off: 64-bit offsets into 7.5 GB of
         # values, row blocks beyond 2^19, the persistent grids.  Same bits.
+        off = 1 << 62
         for name, opts, form in (
-                ("lx", {b"lat_min_nnz": 1 << 62}, dict(lat=0, lx=1)),
-                ("rowblock", {b"lat_min_nnz": 1 << 62, b"lx_min_nnz": 1 << 62},
-                 dict(lat=0, lx=0)),
-                ("scalar", {b"lat_min_nnz": 1 << 62, b"lx_min_nnz": 1 << 62},
-                 dict(lat=0, lx=0))):
+                ("lx", {b"lat_min_nnz": off}, dict(lat=0, lx=1, sjds=0)),
+                ("sjds", {b"lat_min_nnz": off, b"lx_min_nnz": off},
+                 dict(lat=0, lx=0, sjds=1)),
+                ("rowblock", {b"lat_min_nnz": off, b"lx_min_nnz": off,
+                              b"sj_min_nnz": off}, dict(lat=0, lx=0, sjds=0)),
+                ("scalar", {b"lat_min_nnz": off, b"lx_min_nnz": off,
+                            b"sj_min_nnz": off}, dict(lat=0, lx=0, sjds=0))):
             for k, v in opts.items():
                 _lib.call("spmv_hip_ctx_set_option", ctx, k, v)
             try:
                 B = host.Matrix.create_poisson3d(comm, exec_, n, False,
                                                  host.P2P_NONBLOCKING)
             finally:
-                _lib.call("spmv_hip_ctx_set_option", ctx, b"lat_min_nnz", 1 << 20)
-                _lib.call("spmv_hip_ctx_set_option", ctx, b"lx_min_nnz", 1 << 20)
+                for k in (b"lat_min_nnz", b"lx_min_nnz", b"sj_min_nnz"):
+                    _lib.call("spmv_hip_ctx_set_option", ctx, k, 1 << 20)
             for key, want in form.items():
                 assert B.plan_get(key) == want, (name, key)
             assert B.plan_get("sdia") == 0
@@ -549,7 +585,7 @@ def _with_ctx_options(exec_, opts, fn):
     """run fn() with context options set, restore the defaults afterwards"""
     from spmv_amd import _lib
     defaults = {b"lat_min_nnz": 1 << 20, b"lx_min_nnz": 1 << 20,
-                b"poisson_stencil": 7, b"bake_general": 1}
+                b"sj_min_nnz": 1 << 20, b"poisson_stencil": 7, b"bake_general": 1}
     for k, v in opts.items():
         _lib.call("spmv_hip_ctx_set_option", exec_.context, k, v)
     try:
@@ -559,15 +595,17 @@ def _with_ctx_options(exec_, opts, fn):
             _lib.call("spmv_hip_ctx_set_option", exec_.context, k, defaults[k])
 
 
-@pytest.mark.parametrize("form", ["lx", "rowblock"])
+@pytest.mark.parametrize("form", ["lx", "sjds", "rowblock"])
 def test_spmv_production_size_csr_order_kernels(exec_, comm, form):
     """BASELINE configs[1] SpMV leg on the kernels a matrix WITHOUT lattice
     structure gets (the default plans of the Poisson matrix are the lattice /
     diagonal forms): 128^3 and the north-star 216^3 with the reference's
     Gaussian x, every element identical to csr_kernels.cpp:41-51."""
     opts = {b"lat_min_nnz": 1 << 62}
-    if form == "rowblock":
+    if form in ("rowblock", "sjds"):
         opts[b"lx_min_nnz"] = 1 << 62
+    if form == "rowblock":
+        opts[b"sj_min_nnz"] = 1 << 62
     for n in (128, 216):
         N = n ** 3
         rp, ci, va = oracle.poisson3d(n)
@@ -578,6 +616,7 @@ def test_spmv_production_size_csr_order_kernels(exec_, comm, form):
             comm, exec_, n, False, host.P2P_NONBLOCKING))
         assert A.plan_get("lat") == 0 and A.plan_get("sdia") == 0
         assert A.plan_get("lx") == (1 if form == "lx" else 0)
+        assert A.plan_get("sjds") == (1 if form == "sjds" else 0)
         d_x, d_y = exec_.alloc(N), exec_.alloc(N)
         exec_.copy_from_host(d_x, x)
         exec_.memset(d_y, 0xFF, 8 * N)
@@ -686,10 +725,6 @@ def test_unstructured_matrix_all_general_kernels(exec_, comm):
         exec_.free(d_x), exec_.free(d_y)
 
 
-FEM_KINDS = {"fem": dict(), "fem_tail": dict(tail_permille=10),
-             "fem81": dict(min_len=81, max_len=81)}
-
-
 @pytest.mark.parametrize("kind", list(FEM_KINDS))
 def test_fem_like_matrix_all_general_kernels(exec_, comm, kind):
     """The seeded FEM-like matrices of the benchmark's ragged-row records
@@ -709,15 +744,15 @@ def test_fem_like_matrix_all_general_kernels(exec_, comm, kind):
             bound = (16 + np.diff(rp)) * U * abs_bound(rp, ci, va, x)
         d_x, d_y = exec_.alloc(N), exec_.alloc(N)
         exec_.copy_from_host(d_x, x)
-        for name, opts in (("scalar", {b"lx_min_nnz": 1 << 62}),
-                           ("rowblock", {b"lx_min_nnz": 1 << 62}),
-                           ("vector", {b"lx_min_nnz": 1 << 62}),
-                           ("default", {})):
-            A = _with_ctx_options(exec_, opts,
-                                  lambda: host.Matrix.create_fem_like(
-                                      comm, exec_, N, **FEM_KINDS[kind]))
+        for name in ("scalar", "rowblock", "vector", "default"):
+            A = host.Matrix.create_fem_like(comm, exec_, N, **FEM_KINDS[kind])
             assert A.plan_get("lat") == 0 and A.plan_get("sdia") == 0
+            # the default plan of these matrices is the sliced jagged form
+            assert A.plan_get("sjds") == 1 and A.plan_get("lx") == 0
+            if kind == "fem_tail":
+                assert A.plan_get("sj_long_rows") > N // 200
             if name in ("scalar", "rowblock", "vector"):
+                A.plan_set("sjds", 0)
                 A.plan_set("algo", {"rowblock": 1, "vector": 2, "scalar": 3}[name])
             exec_.memset(d_y, 0xFF, 8 * N)
             A.mult(d_x, d_y)
@@ -725,8 +760,7 @@ def test_fem_like_matrix_all_general_kernels(exec_, comm, kind):
             if y_ref is None:
                 y_ref = y  # the scalar kernel's
                 assert np.isfinite(y).all() and np.abs(y).max() > 0
-            vector = name == "vector" or (name == "default"
-                                          and A.plan_get("algo") == 2)
+            vector = name == "vector"
             if vector and bound is not None:
                 assert np.all(np.abs(y - y_ref) <= bound), (N, name)
             elif not vector:

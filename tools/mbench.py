@@ -29,6 +29,9 @@ FORM_KEYS = ("algo", "lat", "lx", "lxw", "wdia", "sdia", "sjds", "sj_wpb", "sj_u
 
 
 def make(kind, rows, comm, exec_):
+    if kind.startswith("poisson"):  # poisson512: the 7-point matrix, general
+        return host.Matrix.create_poisson3d(comm, exec_, int(kind[7:]), False,
+                                            host.P2P_BLOCKING)
     if kind == "unstructured":
         return host.Matrix.create_unstructured(comm, exec_, rows)
     return host.Matrix.create_fem_like(comm, exec_, rows, **KINDS[kind])
