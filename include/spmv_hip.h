@@ -251,8 +251,9 @@ int spmv_hip_csr_plan_bake_values_f32(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan
  *   fp32 copies of the mixed SpMV likewise.
  * A plan without a baked copy: nothing to do.  SPMV_HIP_OK in all these cases
  * -- launches with the same pointers then return the NEW matrix's product.
- * Without this call they return the OLD one (the copy is the plan's own): the
- * contract of plan_bake_values.  plan_get "values_changed_us" = what the last
+ * Without this call they return the OLD one (the copy is the plan's own; the
+ * sliced jagged form, which reads its long rows from the caller's arrays, a
+ * mixture of the two): the contract of plan_bake_values.  plan_get "values_changed_us" = what the last
  * call cost. */
 int spmv_hip_csr_plan_values_changed(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan,
                                      void* stream);

@@ -778,7 +778,10 @@ def test_plan_values_changed_after_updates_in_place():
                 blk.diagonal.write(v[1])
             else:
                 blk.values.write(v)
-            if step == 1:  # stale by contract: the plan's own copy is the old one
+            if step == 1 and name != "sjds":
+                # stale by contract: the plan's own copy is the old one (the
+                # sliced jagged form reads its long rows from the caller's
+                # arrays: neither product until the call)
                 blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
                 assert np.array_equal(dy.numpy(), ref(v0)), name
             blk.values_changed()
