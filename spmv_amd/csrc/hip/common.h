@@ -48,8 +48,8 @@ struct spmv_hip_ctx {
   // form ("sj_min_nnz")
   int64_t sj_min_nnz = (int64_t)1 << 20;
   // ... staging at most this many 16-column chunks of x per block
-  // ("sj_max_chunks", <= 448: 56 KiB of fp64)
-  int sj_max_chunks = 448;
+  // ("sj_max_chunks", <= 432: 54 KiB of fp64)
+  int sj_max_chunks = 432;
   // ... with this many slices per block ("sj_wpb": 4, 8, 16; 0 = choose)
   int sj_wpb = 0;
   // ... and this many entries per lane and step ("sj_unit": 1, 2, 4; 0 = choose)

@@ -300,6 +300,8 @@ struct spmv_hip_csr_plan {
   int64_t sj_far = 0, sj_sumk = 0; // entries gathered from memory; staged chunks
   int32_t* sj_long_rows = nullptr; // rows the slices leave out (one wave each)
   int sj_nlong = 0, sj_long_thr = 0;
+  int sj_long_sorted = 0; // their columns ascend: x by LDS panels
+  int sj_long_panels = 1; // use that (plan_set "sj_long_panels")
   int sj_phases = 3;             // measurement only: 1 = long rows, 2 = slices
   int sj_blocks_per_cu = 0;      // 0 = what the LDS footprint allows
   int sj_xcd_group = 8;          // consecutive blocks per XCD (0 = off)

@@ -161,7 +161,7 @@ int spmv_hip_ctx_set_option(spmv_hip_ctx* ctx, const char* key, int64_t value)
     return SPMV_HIP_OK;
   }
   if (!strcmp(key, "sj_max_chunks")) {
-    SPMV_REQUIRE(value >= 8 && value <= 448);
+    SPMV_REQUIRE(value >= 8 && value <= 432);
     ctx->sj_max_chunks = (int)value;
     return SPMV_HIP_OK;
   }

@@ -1627,6 +1627,9 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
   } else if (!strcmp(key, "sj_phases")) { // ablation for measurements only
     SPMV_REQUIRE(value >= 1 && value <= 3);
     plan->sj_phases = value;
+  } else if (!strcmp(key, "sj_long_panels")) {
+    SPMV_REQUIRE(value == 0 || value == 1);
+    plan->sj_long_panels = value;
   } else if (!strcmp(key, "sj_blocks_per_cu")) {
     SPMV_REQUIRE(value >= 0 && value <= kBlocksPerCU);
     plan->sj_blocks_per_cu = value;
@@ -1765,6 +1768,8 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
     *value = plan->sj_lenperm && plan->nnz > 0
                  ? (int)((plan->sj_units * plan->sj_unit * 1000) / plan->nnz)
                  : 0;
+  else if (!strcmp(key, "sj_long_panels"))
+    *value = plan->sj_lenperm && plan->sj_long_sorted && plan->sj_long_panels ? 1 : 0;
   else if (!strcmp(key, "sj_long_rows"))
     *value = plan->sj_lenperm ? plan->sj_nlong : 0;
   else if (!strcmp(key, "sj_wide"))

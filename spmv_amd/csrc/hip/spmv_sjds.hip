@@ -24,7 +24,7 @@
 //     vector instructions per entry, not bytes.
 //   * x comes from LDS.  Per block of WPB slices (256, 512 or 1024 rows) the
 //     plan lists the 16-column chunks (128 B) of x the block's entries touch
-//     -- up to 448 of them, nearest to the diagonal first -- and rewrites every
+//     -- up to 432 of them, nearest to the diagonal first -- and rewrites every
 //     column as a 16-bit index into the staged copy.  Entries outside the list
 //     ("far") keep their column and are gathered from memory; a block that has
 //     any uses 32-bit codes.  Staging is coalesced 16-byte loads, shared by all
@@ -63,6 +63,16 @@ constexpr uint32_t kSjLongFlag = 0x80000000u; // ... marked in their lenperm wor
 constexpr int kSjSlack = 128;      // units of slack behind the jagged arrays: a
                                    // step past a slice's end reads, never uses
 
+// LONG rows (the long-row kernel takes them, the slices leave them out): more
+// than `thr` entries -- and not within kSjLongPad entries of the arrays' end,
+// so that the kernel's loads may run past a row's end without a clamp
+constexpr int kSjLongPad = 160;
+__host__ __device__ __forceinline__ bool sj_is_long(int32_t a, int32_t b, int thr,
+                                                    int64_t nnz)
+{
+  return b - a > thr && (int64_t)b + kSjLongPad <= nnz;
+}
+
 // E consecutive entries of a row: one aligned load
 template <typename X, int E>
 struct __attribute__((aligned(sizeof(X) * E))) SjUnit {
@@ -85,8 +95,8 @@ struct SjSel {
 __device__ SjSel sj_select(int32_t r0, int32_t r1, int32_t num_cols,
                            const int32_t* __restrict__ rowptr,
                            const int32_t* __restrict__ colind, int kcap,
-                           int long_thr, uint32_t* s_bits, int32_t* s_pre,
-                           SjSel* s_sel)
+                           int long_thr, int64_t nnz, uint32_t* s_bits,
+                           int32_t* s_pre, SjSel* s_sel)
 {
   using Scan = hipcub::BlockScan<int32_t, kBlock>;
   __shared__ typename Scan::TempStorage s_scan;
@@ -106,7 +116,7 @@ __device__ SjSel sj_select(int32_t r0, int32_t r1, int32_t num_cols,
   // kernel takes them), so they do not choose chunks
   for (int32_t row = r0 + t; row < r1; row += kBlock) {
     const int32_t a = rowptr[row], b = rowptr[row + 1];
-    if (b - a > long_thr)
+    if (sj_is_long(a, b, long_thr, nnz))
       continue;
     for (int32_t e = a; e < b; ++e) {
       const int32_t rel = colind[e] / kSjChunk - lo;
@@ -183,7 +193,7 @@ __device__ __forceinline__ int32_t sj_index(const SjSel& s, const uint32_t* s_bi
 template <int R>
 __global__ __launch_bounds__(kBlock) void sj_count_kernel(
     int32_t num_rows, int32_t num_cols, const int32_t* __restrict__ rowptr,
-    const int32_t* __restrict__ colind, int kcap, int long_thr,
+    const int32_t* __restrict__ colind, int kcap, int long_thr, int64_t nnz,
     int32_t* __restrict__ blk_k, int32_t* __restrict__ blk_far)
 {
   __shared__ uint32_t s_bits[kSjSpanWords];
@@ -197,11 +207,11 @@ __global__ __launch_bounds__(kBlock) void sj_count_kernel(
     if (threadIdx.x == 0)
       s_far = 0;
     const SjSel sel = sj_select(r0, r1, num_cols, rowptr, colind, kcap, long_thr,
-                                s_bits, s_pre, &s_sel);
+                                nnz, s_bits, s_pre, &s_sel);
     int32_t far = 0;
     for (int32_t row = r0 + threadIdx.x; row < r1; row += kBlock) {
       const int32_t a = rowptr[row], e1 = rowptr[row + 1];
-      if (e1 - a > long_thr)
+      if (sj_is_long(a, e1, long_thr, nnz))
         continue;
       for (int32_t e = a; e < e1; ++e)
         far += sj_index(sel, s_bits, s_pre, colind[e]) < 0 ? 1 : 0;
@@ -251,8 +261,8 @@ __global__ __launch_bounds__(1024) void sj_stats_kernel(
 // units (E entries each) every slice of 64 rows needs: its short rows, each
 // padded to whole units
 __global__ __launch_bounds__(kBlock) void sj_units_kernel(
-    int32_t num_rows, const int32_t* __restrict__ rowptr, int long_thr, int E,
-    uint32_t* __restrict__ units)
+    int32_t num_rows, const int32_t* __restrict__ rowptr, int long_thr, int64_t nnz,
+    int E, uint32_t* __restrict__ units)
 {
   const int lane = threadIdx.x & 63;
   const int64_t nsl = ((int64_t)num_rows + 63) / 64;
@@ -260,8 +270,11 @@ __global__ __launch_bounds__(kBlock) void sj_units_kernel(
   const int64_t nw = ((int64_t)gridDim.x * kBlock) >> 6;
   for (int64_t s = wid; s <= nsl; s += nw) { // (entry nsl: 0, the scan's total)
     const int64_t row = s * 64 + lane;
-    int32_t len = (s < nsl && row < num_rows) ? rowptr[row + 1] - rowptr[row] : 0;
-    len = len > long_thr ? 0 : len;
+    int32_t len = 0;
+    if (s < nsl && row < num_rows) {
+      const int32_t a = rowptr[row], b = rowptr[row + 1];
+      len = sj_is_long(a, b, long_thr, nnz) ? 0 : b - a;
+    }
     uint32_t u = (uint32_t)((len + E - 1) / E);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
@@ -300,8 +313,8 @@ __device__ __forceinline__ void sj_sort_slice(int32_t len, int lane, int32_t* my
 template <int R>
 __global__ __launch_bounds__(kBlock) void sj_fill_kernel(
     int32_t num_rows, int32_t num_cols, const int32_t* __restrict__ rowptr,
-    const int32_t* __restrict__ colind, int kcap, int long_thr, int E, int stride,
-    int wide_alloc, const int32_t* __restrict__ blk_far,
+    const int32_t* __restrict__ colind, int kcap, int long_thr, int64_t nnz, int E,
+    int stride, int wide_alloc, const int32_t* __restrict__ blk_far,
     const uint32_t* __restrict__ ubase, int32_t* __restrict__ blk,
     int32_t* __restrict__ chunks, int32_t* __restrict__ lenperm,
     unsigned char* __restrict__ codes)
@@ -315,7 +328,7 @@ __global__ __launch_bounds__(kBlock) void sj_fill_kernel(
     const int32_t r0 = b * R;
     const int32_t r1 = min(r0 + R, num_rows);
     const SjSel sel = sj_select(r0, r1, num_cols, rowptr, colind, kcap, long_thr,
-                                s_bits, s_pre, &s_sel);
+                                nnz, s_bits, s_pre, &s_sel);
     for (int w = sel.wa + threadIdx.x; w <= sel.wb; w += kBlock) {
       uint32_t bits = s_bits[w];
       int32_t rank = s_pre[w] - s_pre[sel.wa];
@@ -348,9 +361,13 @@ __global__ __launch_bounds__(kBlock) void sj_fill_kernel(
       if (s0 >= num_rows)
         break;
       const int32_t row = s0 + lane;
-      int32_t len = row < num_rows ? rowptr[row + 1] - rowptr[row] : 0;
-      const bool is_long = len > long_thr; // not in the slice: length 0, marked
-      len = is_long ? 0 : len;
+      int32_t len = 0;
+      bool is_long = false; // not in the slice: length 0, marked
+      if (row < num_rows) {
+        const int32_t ra = rowptr[row], rb = rowptr[row + 1];
+        is_long = sj_is_long(ra, rb, long_thr, nnz);
+        len = is_long ? 0 : rb - ra;
+      }
       int32_t mylen;
       int myrow;
       sj_sort_slice(len, lane, &mylen, &myrow);
@@ -451,6 +468,7 @@ struct SjArgs {
   // long rows (phase 0): straight from the caller's CSR arrays
   int32_t phases; // measurement only (plan_set "sj_phases"): 1 = long rows, 2 = slices
   int32_t nlong;
+  int32_t long_sorted; // every long row's columns ascend: x by panels
   const int32_t* long_rows;
   const int32_t* colind;
   const T* values;
@@ -689,6 +707,197 @@ __device__ __forceinline__ T sj_long_rows8(const T* __restrict__ val,
   return t;
 }
 
+// The LONG rows (a launch of its own behind the slices' kernel: its registers
+// are its own).  WPB waves per workgroup, eight rows per wave.
+template <typename T, int WPB, bool DOT>
+__global__ __launch_bounds__(64 * WPB) void csr_sjds_long_kernel(
+    SjArgs<T> A, T alpha, const T* __restrict__ in, T beta, T* __restrict__ out,
+    DotOut dot, int dot_slot0)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  T* s_x = reinterpret_cast<T*>(s_raw);
+  __shared__ double s_red[WPB];
+  constexpr int NT = 64 * WPB;
+  typedef T pair_t __attribute__((ext_vector_type(2)));
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  double dot_acc = 0.0;
+  // phase 0: the long rows, eight per wave (eight lanes each).  The list is in
+  // row order (sorted by length inside runs of 64): a workgroup takes a
+  // contiguous run of SUPERGROUPS of 8 WPB rows, workgroups of one XCD
+  // neighbouring runs.
+  //
+  // PANELS (the plan found every long row's columns ascending): a long row's
+  // entries sit one per cache line over a window far wider than a slice's --
+  // gathered from memory each entry drags a line of x through the L2 (110 M
+  // lines for the 1 % tail of the benchmark's matrix: 1.0 ms, twice the rest
+  // of the product).  The rows of a supergroup are neighbours, their windows
+  // overlap: the workgroup walks the columns they span in panels of x that
+  // fit the LDS buffer, stages each panel once with coalesced loads, and every
+  // row adds the products of ITS entries inside the panel -- ascending
+  // columns, so the row's own order, the reference's bits.
+  {
+    __shared__ int32_t s_cmin, s_cmax;
+    __shared__ __attribute__((aligned(16))) T s_scr[WPB * 64]; // per wave: products
+    const int nitems = (A.nlong + 7) / 8;
+    const int nsg = (nitems + WPB - 1) / WPB;
+    const int g8 = gridDim.x >= 8 && (gridDim.x & 7) == 0;
+    const int chunk = g8 ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)
+                         : blockIdx.x;
+    // (balanced contiguous runs: the first nsg mod grid workgroups take one more)
+    const int per = nsg / gridDim.x, rem = nsg % gridDim.x;
+    const int sg0 = chunk * per + min(chunk, rem);
+    const int sg1 = sg0 + per + (chunk < rem ? 1 : 0);
+    const int panel = A.maxk * kSjChunk; // columns of x the LDS buffer holds
+    for (int sg = sg0; sg < sg1; ++sg) { // uniform per workgroup
+      const int item = sg * WPB + wave;
+      const int g = item * 8 + (lane >> 3);
+      const bool have_row = g < A.nlong;
+      const int32_t row = A.long_rows[have_row ? g : A.nlong - 1];
+      const int64_t ra = A.rowptr[row];
+      const int64_t rb = have_row ? (int64_t)A.rowptr[row + 1] : ra;
+      T sum;
+      bool by_panels = A.long_sorted != 0;
+      int32_t cmin = 0, cmax = -1;
+      if (by_panels) { // (uniform) the columns the supergroup spans
+        if (t == 0) {
+          s_cmin = INT32_MAX;
+          s_cmax = -1;
+        }
+        __syncthreads();
+        if (have_row && rb > ra && (lane & 7) == 0) {
+          atomicMin(&s_cmin, A.colind[ra]);
+          atomicMax(&s_cmax, A.colind[rb - 1]);
+        }
+        __syncthreads();
+        cmin = s_cmin & ~(kSjChunk - 1);
+        cmax = s_cmax;
+        __syncthreads();
+        // a span of more than 64 panels: the rows are not neighbours in x
+        by_panels = cmax >= cmin && (int64_t)cmax - cmin < (int64_t)64 * panel;
+      }
+      if (!by_panels) {
+        sum = sj_long_rows8<T>(A.values, A.colind, ra, rb, lane, in);
+      } else {
+        const int l = lane & 7;
+        int64_t e = ra; // the row's first entry not yet added (same in its 8 lanes)
+        T acc = T(0);
+        for (int64_t p0 = cmin; p0 <= cmax; p0 += panel) {
+          // stage x[p0, p0 + panel): 2 elements per lane and round
+          const int64_t cend = (int64_t)A.num_cols;
+          const int64_t clast = (cend - 2) & ~(int64_t)1;
+          for (int64_t q = 2 * t; q < panel; q += 2 * NT) {
+            const int64_t col = p0 + q;
+            pair_t xv = *reinterpret_cast<const pair_t*>(
+                in + (col < clast ? col : clast));
+            if (col + 1 == cend)
+              xv[0] = in[col];
+            *reinterpret_cast<pair_t*>(&s_x[q]) = xv;
+          }
+          __syncthreads();
+          const int64_t pend = p0 + panel;
+          // the row's entries below pend, eight steps of eight per trip: the
+          // loads assume whole steps (a step the panel's end cuts short ends
+          // the trip early; what was loaded past it is loaded again with the
+          // next panel)
+          // (the NEXT trip's loads are issued before this trip's sums, assuming
+          // it ends whole; a trip the panel's end cuts short drops them)
+          constexpr int U = 8;
+          T v[U], vn[U];
+          int32_t c[U], cn[U];
+          // (no clamps: a long row ends at least kSjLongPad entries before the
+          // arrays do -- sj_is_long -- and what lies past its end is never used;
+          // one address per stream and trip, the steps at immediate offsets)
+          static_assert(2 * U * 8 + 8 <= kSjLongPad, "loads past a row's end");
+          {
+            const T* vp = A.values + e + l;
+            const int32_t* cp = A.colind + e + l;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              v[u] = vp[u * 8];
+              c[u] = cp[u * 8];
+            }
+          }
+          bool more = true;
+          while (__any(more)) {
+            {
+              const T* vp = A.values + e + l + U * 8;
+              const int32_t* cp = A.colind + e + l + U * 8;
+#pragma unroll
+              for (int u = 0; u < U; ++u) {
+                vn[u] = vp[u * 8];
+                cn[u] = cp[u * 8];
+              }
+            }
+            bool open = more; // this group's steps so far were whole
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              const int64_t i = e + l; // (e advances with the steps)
+              const bool ok = open && i < rb && c[u] < pend;
+              const T x = s_x[ok ? (int32_t)(c[u] - p0) : 0];
+              // a lane without an entry contributes +0.0: the sum starts at
+              // +0.0 and can never become -0.0, so adding it changes no bit
+              const T pr = ok ? v[u] * x : T(0);
+              // valid lanes are a prefix of the group: ascending columns
+              const uint64_t bal = __ballot(ok);
+              const int nv = __popcll((bal >> (lane & ~7)) & 0xFFull);
+              // the group's eight products through the wave's LDS scratch (one
+              // store, four broadcast loads) and onto the sum one by one
+              T* scr = s_scr + wave * 64;
+              scr[lane] = pr;
+              typedef T vec2 __attribute__((ext_vector_type(2)));
+              const vec2* gp = reinterpret_cast<const vec2*>(scr + (lane & ~7));
+              const vec2 q0 = gp[0], q1 = gp[1], q2 = gp[2], q3 = gp[3];
+              acc += q0[0];
+              acc += q0[1];
+              acc += q1[0];
+              acc += q1[1];
+              acc += q2[0];
+              acc += q2[1];
+              acc += q3[0];
+              acc += q3[1];
+              e += nv;
+              open = open && nv == 8;
+            }
+            more = open;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              v[u] = vn[u];
+              c[u] = cn[u];
+            }
+          }
+          __syncthreads(); // everybody is done with this panel
+        }
+        sum = acc;
+      }
+      if (have_row && (lane & 7) == 0) {
+        const T c = alpha * sum;
+        T y = c;
+        if (beta != T(0))
+          y = c + beta * out[row];
+        out[row] = y;
+        if constexpr (DOT)
+          dot_acc += (double)in[row] * (double)c;
+      }
+    }
+  }
+  if constexpr (DOT) {
+    double v = dot_acc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+      v += __shfl_down(v, o, 64);
+    if (lane == 0)
+      s_red[wave] = v;
+    __syncthreads();
+    if (t == 0) {
+      double r = 0.0;
+#pragma unroll
+      for (int w = 0; w < WPB; ++w)
+        r += s_red[w];
+      dot.partials[dot_slot0 + blockIdx.x] = r; // behind the slices' partials
+    }
+  }
+}
+
 template <typename T, int WPB, int E, bool DOT>
 __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
     SjArgs<T> A, T alpha, const T* __restrict__ in, T beta, T* __restrict__ out,
@@ -704,35 +913,6 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
   const int part = t & 7, cg = t >> 3;
   constexpr int CG = NT / 8;
   double dot_acc = 0.0;
-  // phase 0: the long rows, eight per wave and step.  The list is in row order
-  // (sorted by length inside runs of 64): a workgroup takes a contiguous run
-  // of items, workgroups of one XCD neighbouring runs -- rows close to each
-  // other read the same lines of x.
-  if (A.phases & 1) {
-    const int nitems = (A.nlong + 7) / 8;
-    const int g8 = gridDim.x >= 8 && (gridDim.x & 7) == 0;
-    const int chunk = g8 ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)
-                         : blockIdx.x;
-    const int per = (nitems + gridDim.x - 1) / gridDim.x;
-    const int i1 = min((chunk + 1) * per, nitems);
-    for (int item = chunk * per + wave; item < i1; item += WPB) {
-      const int g = item * 8 + (lane >> 3);
-      const bool have_row = g < A.nlong;
-      const int32_t row = A.long_rows[have_row ? g : A.nlong - 1];
-      const int64_t ra = A.rowptr[row];
-      const int64_t rb = have_row ? (int64_t)A.rowptr[row + 1] : ra;
-      const T sum = sj_long_rows8<T>(A.values, A.colind, ra, rb, lane, in);
-      if (have_row && (lane & 7) == 0) {
-        const T c = alpha * sum;
-        T y = c;
-        if (beta != T(0))
-          y = c + beta * out[row];
-        out[row] = y;
-        if constexpr (DOT)
-          dot_acc += (double)in[row] * (double)c;
-      }
-    }
-  }
   const int num_slots = order_slots(ord);
   // the chunk numbers of a block are requested a whole block ahead (the lists
   // are padded to the stride, so the request does not need the block's count)
@@ -882,8 +1062,8 @@ int sj_count(spmv_hip_csr_plan* pl, const int32_t* rowptr, const int32_t* colind
   const int nblk = (pl->num_rows + R - 1) / R;
   const int grid = spmv_grid_for(pl->ctx, nblk, 1);
   hipLaunchKernelGGL((sj_count_kernel<R>), dim3(grid), dim3(kBlock), 0, stream,
-                     pl->num_rows, pl->num_cols, rowptr, colind, kcap, long_thr, d_k,
-                     d_far);
+                     pl->num_rows, pl->num_cols, rowptr, colind, kcap, long_thr, pl->nnz,
+                     d_k, d_far);
   SPMV_CHECK_LAUNCH();
   hipLaunchKernelGGL(sj_stats_kernel, dim3(1), dim3(1024), 0, stream, nblk, d_k,
                      d_far, d_stats);
@@ -928,6 +1108,7 @@ int sj_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
   A.val = static_cast<const T*>(pl->sj_val);
   A.phases = pl->sj_phases;
   A.nlong = pl->sj_nlong;
+  A.long_sorted = pl->sj_long_sorted && pl->sj_long_panels;
   A.long_rows = pl->sj_long_rows;
   A.colind = pl->colind0;
   A.values = static_cast<const T*>(pl->sj_values0);
@@ -949,9 +1130,34 @@ int sj_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
   ord.xcd_group = grid >= 8 ? pl->sj_xcd_group : 0;
   ord.num_row_blocks = pl->sj_nblk;
   ord.nt_store = 0;
-  hipLaunchKernelGGL((csr_sjds_kernel<T, WPB, E, DOT>), dim3(grid), dim3(64 * WPB),
-                     lds, st, A, alpha, in, beta, out, dot, ord);
-  SPMV_CHECK_LAUNCH();
+  if (A.phases & 2) {
+    hipLaunchKernelGGL((csr_sjds_kernel<T, WPB, E, DOT>), dim3(grid), dim3(64 * WPB),
+                       lds, st, A, alpha, in, beta, out, dot, ord);
+    SPMV_CHECK_LAUNCH();
+  }
+  if (pl->sj_nlong > 0 && (A.phases & 1)) {
+    // the long rows: 8-wave workgroups, 64 rows each (the kernel needs ~180
+    // registers: 8 waves per CU, i.e. one such workgroup; 4-wave workgroups
+    // measured no faster); their dot
+    // partials go behind the slices' (whose kernel cleared the array's tail)
+    constexpr int LW = 8;
+    const int nsg = ((pl->sj_nlong + 7) / 8 + LW - 1) / LW;
+    int lwgs = (int)((160 * 1024 - 2048) / ((int64_t)lds + LW * 512 + 256));
+    lwgs = lwgs < 1 ? 1 : (lwgs > 4 ? 4 : lwgs);
+    int lgrid = pl->ctx->num_cus * lwgs;
+    if (lgrid > nsg)
+      lgrid = nsg;
+    if (DOT && lgrid > pl->ctx->dot_blocks - grid)
+      lgrid = pl->ctx->dot_blocks - grid;
+    if (lgrid >= 8)
+      lgrid -= lgrid % 8;
+    if (lgrid < 1)
+      lgrid = 1;
+    hipLaunchKernelGGL((csr_sjds_long_kernel<T, LW, DOT>), dim3(lgrid), dim3(64 * LW),
+                       lds, st, A, alpha, in, beta, out, dot,
+                       (A.phases & 2) ? grid : 0);
+    SPMV_CHECK_LAUNCH();
+  }
   return SPMV_HIP_OK;
 }
 
@@ -977,33 +1183,53 @@ int sj_run(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
   }
 }
 
+// do the columns of every listed row ascend strictly?  (*bad raised if not)
+__global__ __launch_bounds__(kBlock) void sj_long_sorted_kernel(
+    int count, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
+    const int32_t* __restrict__ rows, int32_t* __restrict__ bad)
+{
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * kBlock) >> 6;
+  for (int64_t i = wid; i < count; i += nw) {
+    const int32_t a = rowptr[rows[i]], b = rowptr[rows[i] + 1];
+    bool ok = true;
+    for (int32_t e = a + lane; e + 1 < b; e += 64)
+      ok = ok && colind[e] < colind[e + 1];
+    if (!ok)
+      *bad = 1; // (any value: no atomic needed)
+  }
+}
+
 struct SjIsLong {
   const int32_t* rowptr;
   int thr;
+  int64_t nnz;
   __device__ bool operator()(int i) const
   {
-    return rowptr[i + 1] - rowptr[i] > thr;
+    return sj_is_long(rowptr[i], rowptr[i + 1], thr, nnz);
   }
 };
 struct SjLongCount {
   const int32_t* rowptr;
   int thr;
+  int64_t nnz;
   __device__ int operator()(int i) const
   {
-    return rowptr[i + 1] - rowptr[i] > thr ? 1 : 0;
+    return sj_is_long(rowptr[i], rowptr[i + 1], thr, nnz) ? 1 : 0;
   }
 };
 
 // the rows longer than thr, ascending, sorted by length inside runs of 64
 // (SPMV_HIP_ENOMEM: no memory)
-int sj_build_long_list(spmv_hip_csr_plan* pl, const int32_t* rowptr, int thr,
-                       hipStream_t st)
+int sj_build_long_list(spmv_hip_csr_plan* pl, const int32_t* rowptr,
+                       const int32_t* colind, int thr, hipStream_t st)
 {
   const int n = pl->num_rows;
   hipcub::CountingInputIterator<int32_t> first(0);
   hipcub::TransformInputIterator<int, SjLongCount,
                                  hipcub::CountingInputIterator<int32_t>>
-      ones(first, SjLongCount{rowptr, thr});
+      ones(first, SjLongCount{rowptr, thr, pl->nnz});
   int32_t* d_count = nullptr;
   void* tmp = nullptr;
   size_t tb = 0, tb2 = 0;
@@ -1023,7 +1249,7 @@ int sj_build_long_list(spmv_hip_csr_plan* pl, const int32_t* rowptr, int thr,
   tmp = nullptr;
   if (e == hipSuccess && count > 0) {
     e = hipMalloc(&pl->sj_long_rows, sizeof(int32_t) * (size_t)count);
-    SjIsLong pred{rowptr, thr};
+    SjIsLong pred{rowptr, thr, pl->nnz};
     if (e == hipSuccess)
       e = hipcub::DeviceSelect::If(nullptr, tb2, first, pl->sj_long_rows, d_count, n,
                                    pred, st);
@@ -1065,8 +1291,22 @@ int sj_build_long_list(spmv_hip_csr_plan* pl, const int32_t* rowptr, int thr,
     if (e == hipSuccess)
       e = hipMemcpyAsync(pl->sj_long_rows, d_rows2, sizeof(int32_t) * (size_t)count,
                          hipMemcpyDeviceToDevice, st);
+    // ascending columns in every long row?  (d_count is free to be the flag)
+    int32_t h_bad = 1;
+    if (e == hipSuccess)
+      e = hipMemsetAsync(d_count, 0, sizeof(int32_t), st);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(sj_long_sorted_kernel,
+                         dim3(spmv_grid_for(pl->ctx, count, kBlock / 64)),
+                         dim3(kBlock), 0, st, count, rowptr, colind,
+                         pl->sj_long_rows, d_count);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(&h_bad, d_count, sizeof(int32_t), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess)
       e = hipStreamSynchronize(st);
+    pl->sj_long_sorted = h_bad ? 0 : 1;
     (void)hipFree(d_key);
     (void)hipFree(d_key2);
     (void)hipFree(d_rows2);
@@ -1266,7 +1506,8 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
     e = hipMalloc(&pl->sj_ubase, sizeof(uint32_t) * (size_t)(nsl + 1));
     if (e == hipSuccess) {
       hipLaunchKernelGGL(sj_units_kernel, dim3(spmv_grid_for(pl->ctx, nsl + 1, 4)),
-                         dim3(kBlock), 0, st, n, rowptr, thr, E, pl->sj_ubase);
+                         dim3(kBlock), 0, st, n, rowptr, thr, pl->nnz, E,
+                         pl->sj_ubase);
       e = hipGetLastError();
     }
     if (e == hipSuccess)
@@ -1305,7 +1546,7 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
     const int grid = spmv_grid_for(pl->ctx, nblk, 1);
 #define SJ_FILL(RR)                                                            \
   hipLaunchKernelGGL((sj_fill_kernel<RR>), dim3(grid), dim3(kBlock), 0, st, n,  \
-                     pl->num_cols, rowptr, colind, kcap, thr, E, stride,       \
+                     pl->num_cols, rowptr, colind, kcap, thr, pl->nnz, E, stride, \
                      wide_alloc, d_far, pl->sj_ubase, pl->sj_blk,              \
                      pl->sj_chunks, pl->sj_lenperm, pl->sj_codes)
     if (best == 4)
@@ -1326,7 +1567,7 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
     return e == hipErrorOutOfMemory ? SPMV_HIP_OK : static_cast<int>(e);
   }
   {
-    const int rc = sj_build_long_list(pl, rowptr, thr, st);
+    const int rc = sj_build_long_list(pl, rowptr, colind, thr, st);
     if (rc != SPMV_HIP_OK) {
       spmv_sjds_free(pl);
       return rc == SPMV_HIP_ENOMEM ? SPMV_HIP_OK : rc;

@@ -641,7 +641,7 @@ def test_sliced_jagged_form_bit_exact(sj_ctx, wpb, unit):
         y0 = rng.uniform(-1, 1, nr)
         # (left to choose, the plan does not build the form when most entries
         # would be far)
-        for budget in ((448, 8) if wpb else (448,)):
+        for budget in ((432, 8) if wpb else (432,)):
             ctx.set_option("sj_max_chunks", budget)
             blk = hip.CsrBlock(ctx, nr, nc, rp, ci, va, None, False)
             assert blk.get("sj_built") == 1 and blk.get("sjds") == 0, name
@@ -651,15 +651,17 @@ def test_sliced_jagged_form_bit_exact(sj_ctx, wpb, unit):
                 assert blk.get("sj_wpb") == wpb and blk.get("sj_unit") == unit
             if name == "far" or (budget == 8 and nc > 1000):
                 assert blk.get("sj_far_permille") > 0 and blk.get("sj_wide") == 1
-            if name == "fem" and budget == 448:
+            if name == "fem" and budget == 432:
                 assert blk.get("sj_far_permille") == 0 and blk.get("sj_wide") == 0
-            if name == "fem_tail" and budget == 448:
+            if name == "fem_tail" and budget == 432:
                 # the long rows stay out of the slices (one wave each): the
                 # short rows are staged entirely
                 assert blk.get("sj_far_permille") == 0 and blk.get("sj_wide") == 0
                 assert blk.get("sj_long_rows") > 50
+                assert blk.get("sj_long_panels") == 1  # ascending columns
             if name in ("ragged", "long_rows", "odd"):
                 assert blk.get("sj_long_rows") >= 2
+                assert blk.get("sj_long_panels") == 0  # ... not here: gathered
             dx = ctx.upload(x)
             for alpha, beta in ((1.0, 0.0), (-0.75, 0.0), (2.5, -0.5)):
                 y_ref = oracle.csr_spmv(rp, ci, va, x, alpha, beta, y0)
@@ -673,6 +675,13 @@ def test_sliced_jagged_form_bit_exact(sj_ctx, wpb, unit):
                     got = float(np.sum(part.numpy()))
                     assert abs(got - want) <= 1e-11 * (np.abs(x) @ np.abs(y_ref) + 1)
                 dy.free()
+            if name == "fem_tail":  # the same rows gathered instead
+                blk.set("sj_long_panels", 0)
+                dy = ctx.upload(np.full(nr, np.nan))
+                blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+                assert np.array_equal(dy.numpy(), oracle.csr_spmv(rp, ci, va, x))
+                dy.free()
+                blk.set("sj_long_panels", 1)
             # the plan's copy is tied to the array it was made from
             other = ctx.upload(2.0 * va)
             keep, blk.values = blk.values, other
@@ -687,7 +696,7 @@ def test_sliced_jagged_form_bit_exact(sj_ctx, wpb, unit):
             for b in (dx, dy, other):
                 b.free()
             blk.free()
-        ctx.set_option("sj_max_chunks", 448)
+        ctx.set_option("sj_max_chunks", 432)
     part.free()
     # fp32
     rp, ci, va = poisson.fem_like_csr(5000, jitter=64, layer=300, tail_permille=30,
