@@ -523,8 +523,21 @@ struct SdiaTileGeom {
   double rcp_u1;
 };
 
+#ifdef SPMV_PROBE_FOLD
+// MEASUREMENT BUILD ONLY (tools/ab_build.sh B -DSPMV_PROBE_FOLD; DESIGN.md
+// "folding the x / p update into the SpMV"): the memory traffic of a kernel
+// that also computed p = r + beta p for its stencil neighbours and wrote p and
+// x -- a second vector read at every address x is read at, one more row vector
+// read, two more written -- without the arithmetic.  Results stay those of the
+// plain kernel (the extra loads only feed a test that never holds).
+__device__ double* g_probe_fold[3];
+#endif
+
 template <typename T, int R>
 struct SdiaTileRegs {
+#ifdef SPMV_PROBE_FOLD
+  T junk;
+#endif
   unsigned cm[R];
   T xi[R], xl0[R], xu0[R], xl2[R], xu2[R], y0[R];
   T x_below, x_above; // x[i_0 - U1], x[i_{R-1} + U1]
@@ -565,9 +578,20 @@ __device__ __forceinline__ SdiaTileRegs<T, R> sdia_tile_loads(
     return q;
   q.i0 = i0;
   const int64_t last = (int64_t)num_rows - 1;
+#ifdef SPMV_PROBE_FOLD
+  const T* in2 = reinterpret_cast<const T*>(g_probe_fold[0]);
+  const T* xv = reinterpret_cast<const T*>(g_probe_fold[1]);
+  T junk = T(0);
+  auto at = [&](int64_t c) {
+    const int64_t cc = c < 0 ? 0 : (c > last ? last : c);
+    junk += in2[cc];
+    return in[cc];
+  };
+#else
   auto at = [&](int64_t c) { // clamped: what the row does not have is not used
     return in[c < 0 ? 0 : (c > last ? last : c)];
   };
+#endif
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int64_t i = i0 + (int64_t)r * g.U1;
@@ -579,8 +603,14 @@ __device__ __forceinline__ SdiaTileRegs<T, R> sdia_tile_loads(
       q.xl0[r] = prev.xi[r];
     } else {
       q.xi[r] = in[ic];
+#ifdef SPMV_PROBE_FOLD
+      junk += in2[ic];
+#endif
       q.xl0[r] = at(i - g.U0);
     }
+#ifdef SPMV_PROBE_FOLD
+    junk += xv[ic];
+#endif
     q.xu0[r] = at(i + g.U0);
     q.xl2[r] = at(i - g.U2);
     q.xu2[r] = at(i + g.U2);
@@ -589,6 +619,9 @@ __device__ __forceinline__ SdiaTileRegs<T, R> sdia_tile_loads(
   }
   q.x_below = at(i0 - g.U1);
   q.x_above = at(i0 + (int64_t)R * g.U1);
+#ifdef SPMV_PROBE_FOLD
+  q.junk = junk;
+#endif
   return q;
 }
 
@@ -682,6 +715,12 @@ __global__ __launch_bounds__(kBlock) void csr_const_dia_tile_kernel(
               cy += term;
             }
           }
+#ifdef SPMV_PROBE_FOLD
+          reinterpret_cast<T*>(g_probe_fold[1])[i] = q.xi[r]; // "x"
+          reinterpret_cast<T*>(g_probe_fold[2])[i] = q.xl2[r]; // "p"
+          if (q.junk == T(1.2345e30)) // (never: the buffers hold zeros)
+            y = q.junk;
+#endif
           if (g.nt_store) // uniform
             __builtin_nontemporal_store(y, out + i);
           else
@@ -1095,6 +1134,21 @@ int sdia_tile_launch(const spmv_hip_csr_plan* pl, hipStream_t st,
   if (pl->sdia_chain && g.U0 % ((int64_t)R * g.U1) == 0
       && (g.U0 / R) % g.block == 0)
     g.chain_blocks = g.U0 / R / g.block;
+#ifdef SPMV_PROBE_FOLD
+  {
+    static double* bufs[3] = {nullptr, nullptr, nullptr};
+    static int64_t have_rows = 0;
+    if (have_rows < pl->num_rows) {
+      for (auto& b : bufs) {
+        (void)hipFree(b);
+        SPMV_CHECK_HIP(hipMalloc(&b, sizeof(double) * ((size_t)pl->num_rows + 64)));
+        SPMV_CHECK_HIP(hipMemset(b, 0, sizeof(double) * ((size_t)pl->num_rows + 64)));
+      }
+      have_rows = pl->num_rows;
+      SPMV_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_probe_fold), bufs, sizeof(bufs)));
+    }
+  }
+#endif
   const int grid = sdia_tile_grid(pl);
   const int nrb = (int)((g.NJ + g.block - 1) / g.block);
   RowBlockOrder ord = pl->row_block_order(nrb);

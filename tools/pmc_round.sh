@@ -25,6 +25,10 @@ run csr_rowblock_spmv 512 tools/prof_spmv.py --n 512 --reps 6 --no-lx
 run stencil27_spmv 256 tools/prof_matrix.py --kind stencil27 --n 256
 run stencil27_value_stream_spmv 256 tools/prof_matrix.py --kind stencil27 --n 256 --set const_diagonals=0
 run unstructured_spmv 10000000 tools/prof_matrix.py --kind unstructured --rows 10000000
+run fem_spmv 10000000 tools/prof_matrix.py --kind fem --rows 10000000
+run fem_tail_spmv 10000000 tools/prof_matrix.py --kind fem_tail --rows 10000000
+run fem81_spmv 10000000 tools/prof_matrix.py --kind fem81 --rows 10000000
+run csr_order 512 tools/prof_spmv.py --n 512 --reps 6 --no-lat --dot
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/rp_$R
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$R -o bench -- \

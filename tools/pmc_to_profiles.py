@@ -41,6 +41,7 @@ def main():
                    "counter group per pass): reads = TCC_EA0_RDREQ_sum x 128 B "
                    "(calibrated on the streaming dot product in the same passes), "
                    "writes = WRITE_SIZE x 1 KiB; Infinity-Cache hits are counted")
+    filed = False
     for tag, kernels in summ.items():
         files = []
         for f in sorted(glob.glob(os.path.join(args.pmc_dir, f"{tag}_*_counter_collection.csv"))):
@@ -75,7 +76,24 @@ def main():
                               if not (k["kernel_prefix"] == kname
                                       and k["grid"] == args.grid)] + [rec]
             if args.record:
+                # a record whose product takes two launches (the sliced jagged
+                # form with long rows): the bytes of both, the kernels named
+                prev = doc["records"].get(args.record) if filed else None
+                if prev:
+                    rec = dict(rec)
+                    for k in ("fabric_read_bytes", "write_bytes",
+                              "fabric_bytes_per_launch", "TCC_EA0_RDREQ", "TCC_REQ",
+                              "TCC_HIT", "TCC_MISS", "ms_profiled"):
+                        if rec.get(k) is None or prev.get(k) is None:
+                            continue
+                        if isinstance(rec[k], dict):  # per-pass durations
+                            rec[k] = {p_: rec[k][p_] + prev[k].get(p_, 0.0)
+                                      for p_ in rec[k]}
+                        else:
+                            rec[k] = rec[k] + prev[k]
+                    rec["kernel_prefix"] = prev["kernel_prefix"] + " + " + kname
                 doc["records"][args.record] = rec
+                filed = True
     json.dump(doc, open(out_path, "w"), indent=1)
     print("updated", out_path)
 

@@ -14,7 +14,8 @@ from spmv_amd import _lib, host  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--kind", default="unstructured",
-                    choices=["unstructured", "stencil27"])
+                    choices=["unstructured", "stencil27", "fem", "fem_tail",
+                             "fem81"])
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--n", type=int, default=256)
     ap.add_argument("--reps", type=int, default=6)
@@ -28,6 +29,11 @@ def main():
         _lib.call("spmv_hip_ctx_set_option", ctx, k.encode(), int(v))
     if args.kind == "unstructured":
         A = host.Matrix.create_unstructured(comm, exec_, args.rows)
+        N = args.rows
+    elif args.kind.startswith("fem"):
+        kw = {"fem": dict(), "fem_tail": dict(tail_permille=10),
+              "fem81": dict(min_len=81, max_len=81)}[args.kind]
+        A = host.Matrix.create_fem_like(comm, exec_, args.rows, **kw)
         N = args.rows
     else:
         _lib.call("spmv_hip_ctx_set_option", ctx, b"poisson_stencil", 27)
