@@ -330,11 +330,68 @@ __global__ __launch_bounds__(kBlock) void wdia_offsets_kernel(
   }
 }
 
-// Is the matrix symmetric, entry for entry and bit for bit?  (Rows ascend -- the
+// Is the matrix symmetric, entry for entry and bit for bit?  Asked of the arrays
+// by offset (all K of them baked, masks written): the entry (i, i + D_k), D_k <
+// 0, and its mirror (i + D_k, i) = offset -D_k of row i + D_k must both be
+// there or both be missing, with the same bits.  One coalesced pass (lane =
+// row) that stops at the first mismatch -- the CSR arrays are not touched (the
+// earlier check searched every entry's mirror in its row: 46 ms for the
+// 27-point matrix at 256^3, more than the rest of the plan together).
+// mir[k] = the array of -D_k.
+struct WdiaMirror {
+  int32_t q[kWdiaMaxOff];
+};
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void wdia_array_symmetry_kernel(
+    int32_t num_rows, int K, WdiaOffsets off, WdiaMirror mir, int64_t arr_len,
+    const T* __restrict__ sval, const uint32_t* __restrict__ mask,
+    int32_t* __restrict__ fail)
+{
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < num_rows;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    if (*(volatile int32_t*)fail)
+      return;
+    const uint32_t m = mask[i];
+    bool ok = true;
+    for (int k = 0; k < K && off.D[k] < 0; ++k) { // uniform
+      const int64_t r = i + off.D[k]; // the mirror's row (and this entry's column)
+      const int q = mir.q[k];
+      const bool mine = (m >> k) & 1u;
+      bool theirs = false;
+      if (r >= 0)
+        theirs = (mask[r] >> q) & 1u;
+      if (mine != theirs) {
+        ok = false;
+        break;
+      }
+      if (mine) {
+        const T a = sval[(int64_t)k * arr_len + i];
+        const T b = sval[(int64_t)q * arr_len + r];
+        if constexpr (sizeof(T) == 8)
+          ok = __double_as_longlong(a) == __double_as_longlong(b);
+        else
+          ok = __float_as_int(a) == __float_as_int(b);
+        if (!ok)
+          break;
+      }
+    }
+    // ... and an upper entry whose mirror row lies before row 0 cannot be
+    // (column >= num_rows is excluded by the square shape): nothing to check
+    if (!ok) {
+      if (!*(volatile int32_t*)fail)
+        atomicOr(fail, 1);
+      return;
+    }
+  }
+}
+
+// The same question asked of the CSR arrays (a binary search per entry: slow;
+// only the fp32 copy of the mixed SpMV still asks it this way).  (Rows ascend -- the
 // bake pass checks that; an unsorted row merely fails the search here and the
 // matrix takes the full form's checks.)  Stops at the first mismatch.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void wdia_symmetry_kernel(
+__global__ __launch_bounds__(kBlock) void wdia_symmetry_csr_kernel(
     int32_t num_rows, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ colind, const T* __restrict__ values,
     int32_t* __restrict__ fail)
@@ -665,39 +722,7 @@ int wdia_bake(spmv_hip_csr_plan* pl, const T* values, hipStream_t st)
       found = found || off.D[q] == -off.D[k];
     mirrored = found;
   }
-  if (mirrored && K > 1) {
-    int32_t h_asym = 1;
-    if (e == hipSuccess)
-      e = hipMemsetAsync(d_set + kWdiaMaxOff, 0, sizeof(int32_t), st);
-    if (e == hipSuccess) {
-      hipLaunchKernelGGL((wdia_symmetry_kernel<T>), dim3(grid), dim3(kBlock), 0,
-                         st, n, pl->rowptr0, pl->colind0, values,
-                         d_set + kWdiaMaxOff);
-      e = hipGetLastError();
-    }
-    if (e == hipSuccess)
-      e = hipMemcpyAsync(&h_asym, d_set + kWdiaMaxOff, sizeof(int32_t),
-                         hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess)
-      e = hipStreamSynchronize(st);
-    if (e != hipSuccess) {
-      (void)hipFree(d_set);
-      (void)hipFree(msk);
-      return static_cast<int>(e);
-    }
-    if (!h_asym) {
-      narr = 0;
-      while (narr < K && off.D[narr] <= 0)
-        ++narr; // D ascends: the offsets <= 0 come first
-      for (int k = narr; k < K; ++k) {
-        int q = 0;
-        while (off.D[q] != -off.D[k])
-          ++q;
-        off.A[k] = q;
-        off.S[k] = off.D[k];
-      }
-    }
-  }
+  const bool try_half = mirrored && K > 1; // decided on the baked arrays below
   // pass 2: the copy by offset
   const int64_t len = (((int64_t)n + kRows - 1) / kRows) * kRows;
   const size_t bytes = (size_t)narr * len * sizeof(T);
@@ -719,6 +744,57 @@ int wdia_bake(spmv_hip_csr_plan* pl, const T* values, hipStream_t st)
                          hipMemcpyDeviceToHost, st);
     if (e == hipSuccess)
       e = hipStreamSynchronize(st);
+    // HALF form?  The offsets mirror each other (try_half); is the matrix
+    // symmetric entry for entry, bit for bit?  One coalesced pass over the
+    // arrays just baked; if so only the arrays of the offsets <= 0 are kept
+    // (they come first: D ascends) and an upper entry is read as the lower
+    // entry of its column's row.
+    if (e == hipSuccess && !h_fail && try_half) {
+      WdiaMirror mir;
+      for (int k = 0; k < kWdiaMaxOff; ++k) {
+        mir.q[k] = 0;
+        for (int q = 0; q < K && k < K; ++q)
+          if (off.D[q] == -off.D[k])
+            mir.q[k] = q;
+      }
+      int32_t h_asym = 1;
+      e = hipMemsetAsync(d_set + kWdiaMaxOff, 0, sizeof(int32_t), st);
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL((wdia_array_symmetry_kernel<T>), dim3(grid), dim3(kBlock),
+                           0, st, n, K, off, mir, len, static_cast<const T*>(sval),
+                           msk, d_set + kWdiaMaxOff);
+        e = hipGetLastError();
+      }
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(&h_asym, d_set + kWdiaMaxOff, sizeof(int32_t),
+                           hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess)
+        e = hipStreamSynchronize(st);
+      if (e == hipSuccess && !h_asym) {
+        int nh = 0;
+        while (nh < K && off.D[nh] <= 0)
+          ++nh;
+        void* half = nullptr;
+        const size_t hbytes = (size_t)nh * len * sizeof(T);
+        hipError_t eh = hipMalloc(&half, hbytes);
+        if (eh == hipSuccess)
+          eh = hipMemcpyAsync(half, sval, hbytes, hipMemcpyDeviceToDevice, st);
+        if (eh == hipSuccess)
+          eh = hipStreamSynchronize(st);
+        if (eh == hipSuccess) {
+          (void)hipFree(sval);
+          sval = half;
+          narr = nh;
+          for (int k = narr; k < K; ++k) {
+            off.A[k] = mir.q[k];
+            off.S[k] = off.D[k];
+          }
+        } else { // no room for the compact copy: the full form serves
+          (void)hipFree(half);
+          (void)hipGetLastError();
+        }
+      }
+    }
   }
   (void)hipFree(d_set);
   if (e != hipSuccess || h_fail) {
@@ -835,7 +911,7 @@ int wdia_bake_mixed(spmv_hip_csr_plan* pl, const float* values32, hipStream_t st
     if (es == hipSuccess)
       es = hipMemsetAsync(d_asym, 0, sizeof(int32_t), st);
     if (es == hipSuccess) {
-      hipLaunchKernelGGL((wdia_symmetry_kernel<float>),
+      hipLaunchKernelGGL((wdia_symmetry_csr_kernel<float>),
                          dim3(spmv_grid_for(pl->ctx, n, kBlock)), dim3(kBlock), 0,
                          st, n, pl->rowptr0, pl->colind0, values32, d_asym);
       es = hipGetLastError();
