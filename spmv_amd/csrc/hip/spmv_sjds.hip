@@ -469,6 +469,7 @@ struct SjArgs {
   int32_t phases; // measurement only (plan_set "sj_phases"): 1 = long rows, 2 = slices
   int32_t nlong;
   int32_t long_sorted; // every long row's columns ascend: x by panels
+  int32_t long_panel;  // ... of this many columns
   const int32_t* long_rows;
   const int32_t* colind;
   const T* values;
@@ -636,6 +637,10 @@ __device__ __forceinline__ T sj_slice(const SjUnit<T, E>* __restrict__ vs,
 // Values and columns travel two load groups ahead, x one.  [a, b) = the lane's
 // row (b == a: no row); returns the row's sum.
 constexpr int kSjLpr = 8;
+#ifndef SJ_PANEL_U
+#define SJ_PANEL_U 4
+#endif
+constexpr int kSjPanelU = SJ_PANEL_U; // steps per trip of the panel walk
 constexpr int kSjLU = 4; // steps per load group of the long-row phase
 template <typename T>
 __device__ __forceinline__ T sj_long_rows8(const T* __restrict__ val,
@@ -709,7 +714,7 @@ __device__ __forceinline__ T sj_long_rows8(const T* __restrict__ val,
 
 // The LONG rows (a launch of its own behind the slices' kernel: its registers
 // are its own).  WPB waves per workgroup, eight rows per wave.
-template <typename T, int WPB, bool DOT>
+template <typename T, int WPB, bool DOT, bool PANELS>
 __global__ __launch_bounds__(64 * WPB) void csr_sjds_long_kernel(
     SjArgs<T> A, T alpha, const T* __restrict__ in, T beta, T* __restrict__ out,
     DotOut dot, int dot_slot0)
@@ -747,7 +752,7 @@ __global__ __launch_bounds__(64 * WPB) void csr_sjds_long_kernel(
     const int per = nsg / gridDim.x, rem = nsg % gridDim.x;
     const int sg0 = chunk * per + min(chunk, rem);
     const int sg1 = sg0 + per + (chunk < rem ? 1 : 0);
-    const int panel = A.maxk * kSjChunk; // columns of x the LDS buffer holds
+    const int panel = A.long_panel; // columns of x the LDS buffer holds
     for (int sg = sg0; sg < sg1; ++sg) { // uniform per workgroup
       const int item = sg * WPB + wave;
       const int g = item * 8 + (lane >> 3);
@@ -756,9 +761,10 @@ __global__ __launch_bounds__(64 * WPB) void csr_sjds_long_kernel(
       const int64_t ra = A.rowptr[row];
       const int64_t rb = have_row ? (int64_t)A.rowptr[row + 1] : ra;
       T sum;
-      bool by_panels = A.long_sorted != 0;
+      bool by_panels = PANELS; // (an instantiation per path: the two together
+                               //  need 180 registers)
       int32_t cmin = 0, cmax = -1;
-      if (by_panels) { // (uniform) the columns the supergroup spans
+      if constexpr (PANELS) { // (uniform) the columns the supergroup spans
         if (t == 0) {
           s_cmin = INT32_MAX;
           s_cmax = -1;
@@ -775,8 +781,13 @@ __global__ __launch_bounds__(64 * WPB) void csr_sjds_long_kernel(
         // a span of more than 64 panels: the rows are not neighbours in x
         by_panels = cmax >= cmin && (int64_t)cmax - cmin < (int64_t)64 * panel;
       }
-      if (!by_panels) {
+      if constexpr (!PANELS) {
         sum = sj_long_rows8<T>(A.values, A.colind, ra, rb, lane, in);
+      } else if (!by_panels) { // rows that are not neighbours in x: rare, slow
+        sum = T(0);
+        if ((lane & 7) == 0)
+          for (int64_t i = ra; i < rb; ++i)
+            sum += A.values[i] * in[A.colind[i]];
       } else {
         const int l = lane & 7;
         int64_t e = ra; // the row's first entry not yet added (same in its 8 lanes)
@@ -801,7 +812,7 @@ __global__ __launch_bounds__(64 * WPB) void csr_sjds_long_kernel(
           // next panel)
           // (the NEXT trip's loads are issued before this trip's sums, assuming
           // it ends whole; a trip the panel's end cuts short drops them)
-          constexpr int U = 8;
+          constexpr int U = kSjPanelU;
           T v[U], vn[U];
           int32_t c[U], cn[U];
           // (no clamps: a long row ends at least kSjLongPad entries before the
@@ -1136,13 +1147,25 @@ int sj_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
     SPMV_CHECK_LAUNCH();
   }
   if (pl->sj_nlong > 0 && (A.phases & 1)) {
-    // the long rows: 8-wave workgroups, 64 rows each (the kernel needs ~180
-    // registers: 8 waves per CU, i.e. one such workgroup; 4-wave workgroups
-    // measured no faster); their dot
+    // the long rows: 8-wave workgroups, 64 rows each; their dot
     // partials go behind the slices' (whose kernel cleared the array's tail)
-    constexpr int LW = 8;
+#ifndef SJ_LONG_WAVES
+#define SJ_LONG_WAVES 8
+#endif
+    constexpr int LW = SJ_LONG_WAVES;
     const int nsg = ((pl->sj_nlong + 7) / 8 + LW - 1) / LW;
-    int lwgs = (int)((160 * 1024 - 2048) / ((int64_t)lds + LW * 512 + 256));
+#ifndef SJ_PANEL_COLS
+#define SJ_PANEL_COLS 7680
+#endif
+    // panels of 7680 columns (60 KiB of fp64), trips of 4 steps (103
+    // registers: 16 waves per CU, two workgroups).  Measured on the 1 % tail of
+    // the benchmark's matrix (110 M entries), same box: panels of 2048 / 4096 /
+    // 6144 / 7680 / 9216 columns 0.60 / 0.52 / 0.48 / 0.44 / 0.44 ms; trips of
+    // 8 steps (180 registers, one workgroup per CU) 0.58; 16-wave workgroups
+    // with panels of 12288 / 16384 columns 0.50 / 0.49
+    A.long_panel = SJ_PANEL_COLS;
+    const size_t llds = (size_t)A.long_panel * sizeof(T) + 16;
+    int lwgs = (int)((160 * 1024 - 2048) / ((int64_t)llds + LW * 512 + 256));
     lwgs = lwgs < 1 ? 1 : (lwgs > 4 ? 4 : lwgs);
     int lgrid = pl->ctx->num_cus * lwgs;
     if (lgrid > nsg)
@@ -1153,9 +1176,26 @@ int sj_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
       lgrid -= lgrid % 8;
     if (lgrid < 1)
       lgrid = 1;
-    hipLaunchKernelGGL((csr_sjds_long_kernel<T, LW, DOT>), dim3(lgrid), dim3(64 * LW),
-                       lds, st, A, alpha, in, beta, out, dot,
-                       (A.phases & 2) ? grid : 0);
+    if (llds > 64 * 1024) { // more dynamic LDS than a launch gets by default
+      static bool raised = false;
+      if (!raised) {
+        SPMV_CHECK_HIP(hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&csr_sjds_long_kernel<T, LW, DOT, true>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds));
+        SPMV_CHECK_HIP(hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&csr_sjds_long_kernel<T, LW, DOT, false>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds));
+        raised = true;
+      }
+    }
+    if (A.long_sorted)
+      hipLaunchKernelGGL((csr_sjds_long_kernel<T, LW, DOT, true>), dim3(lgrid),
+                         dim3(64 * LW), llds, st, A, alpha, in, beta, out, dot,
+                         (A.phases & 2) ? grid : 0);
+    else
+      hipLaunchKernelGGL((csr_sjds_long_kernel<T, LW, DOT, false>), dim3(lgrid),
+                         dim3(64 * LW), llds, st, A, alpha, in, beta, out, dot,
+                         (A.phases & 2) ? grid : 0);
     SPMV_CHECK_LAUNCH();
   }
   return SPMV_HIP_OK;
