@@ -499,23 +499,42 @@ struct DeviceBlock {
   int64_t nnz = 0;
 };
 
+// a generator that throws half-way gives its arrays back
+void release(HipExecutor& hip, DeviceBlock& b)
+{
+  if (b.rowptr)
+    hip.free(b.rowptr);
+  if (b.colind)
+    hip.free(b.colind);
+  if (b.values)
+    hip.free(b.values);
+  if (b.diagonal)
+    hip.free(b.diagonal);
+  b = DeviceBlock();
+}
+
 DeviceBlock generate_block(HipExecutor& hip, int32_t n, int64_t r0, int64_t r1,
                            int part, bool with_diagonal)
 {
   DeviceBlock b;
   const int64_t nrows = r1 - r0;
-  b.rowptr = hip.alloc<int32_t>(nrows + 1);
-  throw_on_error(spmv_hip_poisson3d_count(hip.context(), n, r0, r1, part,
-                                          b.rowptr, &b.nnz, nullptr),
-                 "spmv_hip_poisson3d_count");
-  b.colind = hip.alloc<int32_t>(b.nnz);
-  b.values = hip.alloc<double>(b.nnz);
-  if (with_diagonal)
-    b.diagonal = hip.alloc<double>(nrows);
-  throw_on_error(spmv_hip_poisson3d_fill_f64(hip.context(), n, r0, r1, part,
-                                             b.rowptr, b.colind, b.values,
-                                             b.diagonal, nullptr),
-                 "spmv_hip_poisson3d_fill_f64");
+  try {
+    b.rowptr = hip.alloc<int32_t>(nrows + 1);
+    throw_on_error(spmv_hip_poisson3d_count(hip.context(), n, r0, r1, part,
+                                            b.rowptr, &b.nnz, nullptr),
+                   "spmv_hip_poisson3d_count");
+    b.colind = hip.alloc<int32_t>(b.nnz);
+    b.values = hip.alloc<double>(b.nnz);
+    if (with_diagonal)
+      b.diagonal = hip.alloc<double>(nrows);
+    throw_on_error(spmv_hip_poisson3d_fill_f64(hip.context(), n, r0, r1, part,
+                                               b.rowptr, b.colind, b.values,
+                                               b.diagonal, nullptr),
+                   "spmv_hip_poisson3d_fill_f64");
+  } catch (...) {
+    release(hip, b);
+    throw;
+  }
   return b;
 }
 
@@ -606,14 +625,19 @@ Matrix<T>* Matrix<T>::create_unstructured(std::shared_ptr<const Comm> comm,
       throw std::runtime_error("create_unstructured: size out of range");
     DeviceBlock b;
     b.nnz = nrows * per_row;
-    b.rowptr = hip->alloc<int32_t>(nrows + 1);
-    b.colind = hip->alloc<int32_t>(b.nnz);
-    b.values = hip->alloc<double>(b.nnz);
-    throw_on_error(spmv_hip_unstructured_fill_f64(hip->context(), nrows, per_row,
-                                                  band, far_permille, seed,
-                                                  b.rowptr, b.colind, b.values,
-                                                  nullptr),
-                   "spmv_hip_unstructured_fill_f64");
+    try {
+      b.rowptr = hip->alloc<int32_t>(nrows + 1);
+      b.colind = hip->alloc<int32_t>(b.nnz);
+      b.values = hip->alloc<double>(b.nnz);
+      throw_on_error(spmv_hip_unstructured_fill_f64(hip->context(), nrows, per_row,
+                                                    band, far_permille, seed,
+                                                    b.rowptr, b.colind, b.values,
+                                                    nullptr),
+                     "spmv_hip_unstructured_fill_f64");
+    } catch (...) {
+      release(*hip, b);
+      throw;
+    }
     const int32_t n32 = static_cast<int32_t>(nrows);
     auto col_map = std::make_shared<L2GMap>(comm, n32, std::vector<int64_t>(),
                                             exec);
@@ -649,8 +673,8 @@ Matrix<T>* Matrix<T>::create_fem_like(std::shared_ptr<const Comm> comm,
       throw std::runtime_error("create_fem_like: size out of range");
     const int64_t nrows = params.num_rows;
     DeviceBlock b;
-    b.rowptr = hip->alloc<int32_t>(nrows + 1);
     try {
+      b.rowptr = hip->alloc<int32_t>(nrows + 1);
       throw_on_error(spmv_hip_fem_count(hip->context(), &params, b.rowptr, &b.nnz,
                                         nullptr),
                      "spmv_hip_fem_count");
@@ -660,11 +684,7 @@ Matrix<T>* Matrix<T>::create_fem_like(std::shared_ptr<const Comm> comm,
                                            b.rowptr, b.colind, b.values, nullptr),
                      "spmv_hip_fem_fill_f64");
     } catch (...) {
-      hip->free(b.rowptr);
-      if (b.colind)
-        hip->free(b.colind);
-      if (b.values)
-        hip->free(b.values);
+      release(*hip, b);
       throw;
     }
     const int32_t n32 = static_cast<int32_t>(nrows);
@@ -821,19 +841,24 @@ DeviceBlock generate_box_block(HipExecutor& hip, int32_t n, const int32_t f[3],
 {
   DeviceBlock b;
   const int64_t nrows = (int64_t)l[0] * l[1] * l[2];
-  b.rowptr = hip.alloc<int32_t>(nrows + 1);
-  throw_on_error(spmv_hip_poisson3d_box_count(hip.context(), n, f, l, part,
-                                              b.rowptr, &b.nnz, nullptr,
-                                              nullptr),
-                 "spmv_hip_poisson3d_box_count");
-  b.colind = hip.alloc<int32_t>(b.nnz);
-  b.values = hip.alloc<double>(b.nnz);
-  if (with_diagonal)
-    b.diagonal = hip.alloc<double>(nrows);
-  throw_on_error(spmv_hip_poisson3d_box_fill_f64(hip.context(), n, f, l, part,
-                                                 b.rowptr, b.colind, b.values,
-                                                 b.diagonal, nullptr),
-                 "spmv_hip_poisson3d_box_fill_f64");
+  try {
+    b.rowptr = hip.alloc<int32_t>(nrows + 1);
+    throw_on_error(spmv_hip_poisson3d_box_count(hip.context(), n, f, l, part,
+                                                b.rowptr, &b.nnz, nullptr,
+                                                nullptr),
+                   "spmv_hip_poisson3d_box_count");
+    b.colind = hip.alloc<int32_t>(b.nnz);
+    b.values = hip.alloc<double>(b.nnz);
+    if (with_diagonal)
+      b.diagonal = hip.alloc<double>(nrows);
+    throw_on_error(spmv_hip_poisson3d_box_fill_f64(hip.context(), n, f, l, part,
+                                                   b.rowptr, b.colind, b.values,
+                                                   b.diagonal, nullptr),
+                   "spmv_hip_poisson3d_box_fill_f64");
+  } catch (...) {
+    release(hip, b);
+    throw;
+  }
   return b;
 }
 } // namespace

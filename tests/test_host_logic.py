@@ -665,3 +665,51 @@ def test_synthetic_generators_numpy_twins():
     assert 0.05 < far.mean() < 0.12 and -1 <= va.min() and va.max() < 1
     assert not np.array_equal(ci, poisson.unstructured_csr(N, seed=1)[1])
 
+
+
+def test_fem_like_matrix_twin_properties_and_petsc_writer(tmp_path):
+    """The numpy twin of the FEM-like test matrices (the ragged-row records of
+    bench.py; the device generator is compared with it array by array in the
+    GPU tests): row lengths in range and skewed to the short side, a 1 % tail
+    of long rows where asked for, columns strictly ascending and in range, the
+    diagonal in every row; tools/write_petsc.py writes it in the reference's
+    file format (spmv/read_petsc.cpp:60-121: big-endian, magic 1211216) -- the
+    oracle's restatement of the reader returns the same arrays."""
+    import subprocess
+    N = 60_000
+    for kw, lo, hi in ((dict(), 5, 40), (dict(tail_permille=10), 5, 2000),
+                       (dict(min_len=81, max_len=81), 81, 81)):
+        rp, ci, va = poisson.fem_like_csr(N, **kw)
+        lens = np.diff(rp)
+        assert lens.max() <= hi and lens.min() >= 1
+        interior = lens[2100:-2100]  # (edge rows lose a side cluster)
+        if not kw.get("tail_permille"):
+            assert interior.min() >= lo
+        if kw == dict():
+            assert 13 < lens.mean() < 17 and np.median(lens) < lens.mean()
+        if kw.get("tail_permille"):
+            long_rows = lens >= 200
+            assert 0.005 < long_rows.mean() < 0.015
+        first = np.zeros(len(ci), bool)
+        first[rp[:-1][lens > 0]] = True
+        assert np.all(np.diff(ci.astype(np.int64))[~first[1:]] > 0)
+        assert ci.min() >= 0 and ci.max() < N
+        rows = np.repeat(np.arange(N), lens)
+        assert np.array_equal(np.bincount(rows[ci == rows], minlength=N),
+                              np.ones(N, np.int64))
+        assert np.array_equal(va[ci == rows], lens + 1.0)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fa, fb = tmp_path / "A.dat", tmp_path / "b.dat"
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "write_petsc.py"),
+                          "--kind", "fem_tail", "--rows", str(N), "--out", str(fa),
+                          "--rhs", str(fb)], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    rp, ci, va = poisson.fem_like_csr(N, tail_permille=10)
+    for size in (1, 3):
+        parts = [oracle.petsc_io.read_matrix_rows(fa, r, size) for r in range(size)]
+        assert sum(len(p["values"]) for p in parts) == len(va)
+        assert np.array_equal(np.concatenate([p["values"] for p in parts]), va)
+    one = oracle.petsc_io.read_matrix_rows(fa, 0, 1)
+    assert np.array_equal(one["rowptr"], rp) and np.array_equal(one["colind"], ci)
+    b = oracle.petsc_io.read_vector(fb, 0, 1)
+    assert np.allclose(b, oracle.csr_spmv(rp, ci, va, np.ones(N)), rtol=1e-12)
