@@ -292,6 +292,8 @@ struct spmv_hip_csr_plan {
   const void* sj_values0 = nullptr;
   int sj_elem = 0;               // sizeof the baked value type
   int sj = 0;                    // use it (plan_set "sjds")
+  bool sj_wanted = false;        // plan_bake_values builds it when the diagonal
+                                 // forms refuse the matrix
   uint32_t* sj_ubase = nullptr;  // first unit of every slice (+ the total)
   int sj_unit = 1;               // entries per lane and step (1, 2, 4)
   int64_t sj_units = 0;          // units in the jagged arrays

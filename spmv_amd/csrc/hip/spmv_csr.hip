@@ -1361,11 +1361,11 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
         && avg <= 16.0 && (int64_t)num_cols * 8 <= ctx->lx_max_x_bytes)
       rc = build_lx(pl, rowptr, colind);
     // Neither: the sliced jagged form (spmv_sjds.hip) -- ragged rows, more
-    // than 16 entries per row, column windows too wide for the LX form.  The
-    // structure now, the values with plan_bake_values.
-    if (rc == SPMV_HIP_OK && !pl->lat && !pl->lx
-        && num_non_zeros >= ctx->sj_min_nnz)
-      rc = spmv_sjds_build(pl, rowptr, colind, ctx->sj_wpb, ctx->sj_unit);
+    // than 16 entries per row, column windows too wide for the LX form -- is
+    // built by plan_bake_values, structure and values together, once the
+    // diagonal forms have refused the matrix (a 27-point stencil has 27
+    // entries per row too, and its analysis would be 50 ms for nothing).
+    pl->sj_wanted = !pl->lat && !pl->lx && num_non_zeros >= ctx->sj_min_nnz;
     if (rc != SPMV_HIP_OK) {
       spmv_hip_csr_plan_destroy(pl);
       return rc;
@@ -1432,6 +1432,18 @@ int spmv_hip_csr_plan_bake_values_f64(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan
   }
   // a plan in the sliced jagged form keeps its own copy of the values in that
   // order (the diagonal forms never coexist with it)
+  if (!plan->symmetric && values && rc == SPMV_HIP_ENOTSUP && plan->sj_wanted
+      && !plan->sj_lenperm) {
+    // the structure of the sliced jagged form, now that it is known to be used
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rb = spmv_sjds_build(plan, plan->rowptr0, plan->colind0,
+                                   ctx->sj_wpb, ctx->sj_unit);
+    if (rb != SPMV_HIP_OK)
+      return rb;
+    plan->plan_us += (int)std::chrono::duration_cast<std::chrono::microseconds>(
+                         std::chrono::steady_clock::now() - t0)
+                         .count();
+  }
   if (!plan->symmetric && plan->sj_lenperm
       && (values == nullptr || rc == SPMV_HIP_ENOTSUP)) {
     const int rj = spmv_sjds_bake_f64(plan, values, st);
@@ -1453,6 +1465,18 @@ int spmv_hip_csr_plan_bake_values_f32(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan
     rc = values == nullptr ? (rw != SPMV_HIP_OK ? rw : rc) : rw;
   } else if (!plan->symmetric && rc == SPMV_HIP_OK) {
     (void)spmv_wdia_bake_f32(plan, nullptr, st);
+  }
+  if (!plan->symmetric && values && rc == SPMV_HIP_ENOTSUP && plan->sj_wanted
+      && !plan->sj_lenperm) {
+    // the structure of the sliced jagged form, now that it is known to be used
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rb = spmv_sjds_build(plan, plan->rowptr0, plan->colind0,
+                                   ctx->sj_wpb, ctx->sj_unit);
+    if (rb != SPMV_HIP_OK)
+      return rb;
+    plan->plan_us += (int)std::chrono::duration_cast<std::chrono::microseconds>(
+                         std::chrono::steady_clock::now() - t0)
+                         .count();
   }
   if (!plan->symmetric && plan->sj_lenperm
       && (values == nullptr || rc == SPMV_HIP_ENOTSUP)) {

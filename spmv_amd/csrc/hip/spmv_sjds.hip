@@ -1458,16 +1458,19 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
   const int E = unit_force ? unit_force : (avg >= 4.0 ? 2 : 1);
   const int nblk4 = (n + 255) / 256;
   const int64_t nsl = ((int64_t)n + 63) / 64;
-  int32_t *d_k = nullptr, *d_far = nullptr;
+  int32_t* d_k = nullptr;
+  int32_t* d_far3[3] = {nullptr, nullptr, nullptr}; // per candidate: the fill
+                                                    // pass reads the winner's
   int64_t* d_stats = nullptr;
   hipError_t e = hipMalloc(&d_k, sizeof(int32_t) * (size_t)nblk4);
-  if (e == hipSuccess)
-    e = hipMalloc(&d_far, sizeof(int32_t) * (size_t)nblk4);
+  for (int ci = 0; ci < 3 && e == hipSuccess; ++ci)
+    e = hipMalloc(&d_far3[ci], sizeof(int32_t) * (size_t)nblk4);
   if (e == hipSuccess)
     e = hipMalloc(&d_stats, sizeof(int64_t) * 4);
   auto cleanup = [&]() {
     (void)hipFree(d_k);
-    (void)hipFree(d_far);
+    for (int32_t* p : d_far3)
+      (void)hipFree(p);
     (void)hipFree(d_stats);
   };
   if (e != hipSuccess) {
@@ -1482,9 +1485,18 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
   // at a third), a 64-byte sector per far entry; a candidate that leaves a CU
   // fewer than 16 waves pays in proportion.
   const int cand[3] = {4, 8, 16};
-  int best = 0;
+  int best = 0, best_ci = 0;
   double best_cost = 0.0;
   SjStats best_st;
+  auto count = [&](int wpb, int ci, SjStats* s) {
+    return wpb == 4 ? sj_count<256>(pl, rowptr, colind, kcap, thr, d_k, d_far3[ci],
+                                    d_stats, s, st)
+           : wpb == 8
+               ? sj_count<512>(pl, rowptr, colind, kcap, thr, d_k, d_far3[ci], d_stats,
+                               s, st)
+               : sj_count<1024>(pl, rowptr, colind, kcap, thr, d_k, d_far3[ci],
+                                d_stats, s, st);
+  };
   for (int ci = 0; ci < 3; ++ci) {
     const int wpb = cand[ci];
     if (wpb_force && wpb != wpb_force)
@@ -1492,13 +1504,7 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
     if (!wpb_force && n < 64 * wpb * 8) // too few blocks for this size
       continue;
     SjStats s;
-    int rc;
-    if (wpb == 4)
-      rc = sj_count<256>(pl, rowptr, colind, kcap, thr, d_k, d_far, d_stats, &s, st);
-    else if (wpb == 8)
-      rc = sj_count<512>(pl, rowptr, colind, kcap, thr, d_k, d_far, d_stats, &s, st);
-    else
-      rc = sj_count<1024>(pl, rowptr, colind, kcap, thr, d_k, d_far, d_stats, &s, st);
+    const int rc = count(wpb, ci, &s);
     if (rc != SPMV_HIP_OK) {
       cleanup();
       return rc;
@@ -1512,27 +1518,21 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
       cost *= 16.0 / waves;
     if (!best || cost < best_cost) {
       best = wpb;
+      best_ci = ci;
       best_cost = cost;
       best_st = s;
     }
   }
-  if (!best) // a matrix too small for any candidate: the smallest
+  if (!best) { // a matrix too small for any candidate: the smallest
     best = wpb_force ? wpb_force : 4;
-  {
-    // the per-block far counts the fill pass reads must be the chosen
-    // candidate's: count it (again) last
-    const int rc
-        = best == 4
-              ? sj_count<256>(pl, rowptr, colind, kcap, thr, d_k, d_far, d_stats, &best_st, st)
-          : best == 8
-              ? sj_count<512>(pl, rowptr, colind, kcap, thr, d_k, d_far, d_stats, &best_st, st)
-              : sj_count<1024>(pl, rowptr, colind, kcap, thr, d_k, d_far, d_stats,
-                               &best_st, st);
+    best_ci = 0;
+    const int rc = count(best, best_ci, &best_st);
     if (rc != SPMV_HIP_OK) {
       cleanup();
       return rc;
     }
   }
+  int32_t* d_far = d_far3[best_ci];
   // nearly all entries far: the form buys nothing
   if (best_st.far * 10 > pl->nnz * 9 && !wpb_force) {
     cleanup();

@@ -35,6 +35,12 @@
 // 4.9 TB/s.  On the 7-point matrix the LDS-DMA diagonal forms stay ahead
 // (512^3: 2.16-2.30 ms here against 1.74 for the full diagonal form and 1.32
 // for the half form), which is why this form only takes what they refuse.
+//
+// Measured and dropped (round 4): x through an LDS ring of three plane windows
+// (27-point 256^3 in the plane-walk order: a workgroup keeps the windows of two
+// planes and loads one new window of 256 + 2 W contiguous elements per step,
+// all 27 x operands from LDS) -- bit-exact, and 0.81-0.82 ms against 0.68-0.69:
+// the two barriers per row block cost more than the x requests they save.
 #include "csr_plan.h"
 
 #include <chrono>
