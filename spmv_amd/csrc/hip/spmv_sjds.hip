@@ -1162,7 +1162,11 @@ int sj_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
     // the benchmark's matrix (110 M entries), same box: panels of 2048 / 4096 /
     // 6144 / 7680 / 9216 columns 0.60 / 0.52 / 0.48 / 0.44 / 0.44 ms; trips of
     // 8 steps (180 registers, one workgroup per CU) 0.58; 16-wave workgroups
-    // with panels of 12288 / 16384 columns 0.50 / 0.49
+    // with panels of 12288 / 16384 columns 0.50 / 0.49; loads three trips ahead
+    // in a ring of four register sets 0.45-0.57.  The launch FORKED onto a
+    // helper stream beside the slices' (independent rows of y): 1.03 ms for
+    // the pair against 0.85 one after the other -- the two persistent grids
+    // take each other's CUs
     A.long_panel = SJ_PANEL_COLS;
     const size_t llds = (size_t)A.long_panel * sizeof(T) + 16;
     int lwgs = (int)((160 * 1024 - 2048) / ((int64_t)llds + LW * 512 + 256));
