@@ -264,6 +264,9 @@ struct spmv_hip_csr_plan {
   // ... a constant 27-point box stencil: R lattice lines per lane
   // (csr_box27_const_kernel), with its own plane-walk table
   int wdia_box = 0; // R in use (0: the general kernel)
+  int wdia_hbox = 0;      // half form of a box with varying values: the marched
+                          // kernel (csr_box27_half_kernel) takes it
+  int wdia_hbox_segs = 0; // runs of planes (0: about one unit per CU)
   int wdia_box_P = 0, wdia_box_L = 0;
   int wdia_box_blocks_per_cu = 8;
   int32_t* wdia_box_table = nullptr;
@@ -451,6 +454,7 @@ int spmv_lxw_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st,
 void spmv_wdia_free(spmv_hip_csr_plan* pl);
 int spmv_wdia_walk_build(spmv_hip_csr_plan* pl, int segments, bool force);
 int spmv_wdia_box_build(spmv_hip_csr_plan* pl, int R, int segments, bool force);
+int spmv_wdia_hbox_build(spmv_hip_csr_plan* pl, int on);
 int spmv_wdia_bake_f64(spmv_hip_csr_plan* pl, const double* values,
                        hipStream_t st); // values == nullptr: drop the copy
 int spmv_wdia_bake_f32(spmv_hip_csr_plan* pl, const float* values,

@@ -1668,6 +1668,14 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
     SPMV_REQUIRE((value == 0 || value == 2 || value == 4) && plan->wdia_val
                  && plan->wdia_const);
     return spmv_wdia_box_build(plan, value, 0, false);
+  } else if (!strcmp(key, "wdia_hbox")) {
+    // the marched kernel for the half form of a 27-point box (0 = the general
+    // wide diagonal kernel)
+    SPMV_REQUIRE((value == 0 || value == 1) && plan->wdia_val);
+    return spmv_wdia_hbox_build(plan, value);
+  } else if (!strcmp(key, "wdia_hbox_segs")) {
+    SPMV_REQUIRE(value >= 0 && value <= 4096);
+    plan->wdia_hbox_segs = value;
   } else if (!strcmp(key, "wdia_box_segments")) {
     SPMV_REQUIRE(value >= 0 && plan->wdia_box > 1);
     return spmv_wdia_box_build(plan, plan->wdia_box, value, true);
@@ -1802,6 +1810,8 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
     *value = plan->sj_blocks_per_cu;
   else if (!strcmp(key, "wdia"))
     *value = plan->wdia && plan->wdia_val ? 1 : 0;
+  else if (!strcmp(key, "wdia_hbox"))
+    *value = plan->wdia && plan->wdia_val ? plan->wdia_hbox : 0;
   else if (!strcmp(key, "wdia_offsets"))
     *value = plan->wdia_val ? plan->wdia_K : 0;
   else if (!strcmp(key, "plan_us"))

@@ -46,6 +46,7 @@
 #include <chrono>
 #include <cstring>
 #include <new>
+#include <type_traits>
 
 namespace
 {
@@ -301,6 +302,281 @@ __global__ __launch_bounds__(kBlock) void csr_box27_const_kernel(
   }
   if constexpr (DOT)
     spmv_dot_epilogue(dot, dot_acc, s_red);
+}
+
+// ---------------------------------------------------------------------------
+// 27-point BOX stencils with VARYING coefficients in the HALF form (a matrix
+// found symmetric bit for bit: 13 lower arrays + the diagonal), tiles of 1024
+// rows marched DOWN the planes with the planes' values handed on through LDS.
+//
+// The general kernel above reads the upper entry (i, i + d) as the lower entry
+// of row i + d.  For the nine offsets a plane ahead that is a second read of
+// every element of nine arrays one plane-walk step after the first -- 4 MB per
+// XCD and step of streamed values lie between the two, more than its L2 holds:
+// 23 array reads per row cross the fabric instead of 14 (PMC: 3.09 GB at 256^3
+// for 1.88 GB of values).  Here a workgroup (1024 lanes, lane = row, one per
+// CU) owns the rows [s, s + 1024) of every plane of a run of planes and walks
+// them from the top plane down:
+//   * the lane's own 14 values of plane q are loaded ONCE, a step ahead; the
+//     four in-plane arrays go to LDS at the start of step q (their upper use:
+//     row i's entry (i, i + d) is the value of lane t + d), the nine
+//     plane-to-plane arrays at its end -- step q - 1 reads them as ITS upper
+//     entries (offset P + e: the value of lane t + e one plane up);
+//   * what lies outside the tile (|e|, d <= L + 1 rows at one end) the lanes at
+//     that end load for themselves: 4 + 4 registers, 9 (L + 1) / 1024 extra
+//     array reads per row (2.3 at L = 256);
+//   * x through a ring of three plane windows (1024 + 2 (L + 1) elements
+//     each), one new window per step: all 27 operands from LDS.
+// 16.3 array reads per row instead of 23, 1.5 instead of 3 of x.  Two barriers
+// per step; the loads of the next plane (26 per lane) are in flight across
+// them.  Rows are summed in ascending column order, a term only where the
+// row's mask has it: the bits of csr_kernels.cpp:41-51.  Everything is
+// addressed by INDEX (clamped where nobody needs it), so the result does not
+// depend on the matrix actually being a box grid -- only the traffic does.
+// ---------------------------------------------------------------------------
+constexpr int kHbT = 1024; // rows per tile = lanes per workgroup
+
+template <typename TV>
+struct HalfBoxArrays {
+  const TV* a[14]; // the 13 lower arrays and the diagonal, each a kernel argument
+                   // of its own: scalar base + the lane's 32-bit byte offset
+};
+
+struct HalfBoxGeom {
+  int P, L;    // plane and line distance (rows)
+  int tiles;   // tiles per plane
+  int planes;  // ceil(rows / P)
+  int segs;    // runs of planes
+  int seg_len; // planes per run
+  int W;       // x window: kHbT + 2 (L + 1)
+};
+
+template <typename TV, typename T, bool DOT, bool BETA>
+__global__ __launch_bounds__(kHbT) void csr_box27_half_kernel(
+    int32_t num_rows, int32_t arr_len, HalfBoxArrays<TV> base_,
+    const uint32_t* __restrict__ mask, T alpha, const T* __restrict__ in, T beta,
+    T* __restrict__ out, DotOut dot, HalfBoxGeom g)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char hb_lds[];
+  const TV* const* base = base_.a;
+  TV* const s_far = reinterpret_cast<TV*>(hb_lds);        // [9][kHbT]: arrays 0..8
+  TV* const s_near = s_far + 9 * kHbT;                    // [5][kHbT]: arrays 9..13
+  T* const s_x = reinterpret_cast<T*>(s_near + 5 * kHbT); // [3][W]
+  double* const s_red = reinterpret_cast<double*>(s_x + 3 * g.W); // [16]
+  const int t = threadIdx.x;
+  const int P = g.P, L = g.L, W = g.W;
+  // (rows and array length below 2^29: every index fits an int, every byte
+  // offset 32 bits -- one offset register serves the 14 loads of a row, the
+  // arrays' bases are scalars)
+  const int last_row = num_rows - 1;
+  const int last_arr = arr_len - 1;
+  double dot_acc = 0.0;
+  // offsets of the nine positions of a plane, (b, c) lexicographic
+  int eo[9];
+#pragma unroll
+  for (int b = 0; b < 3; ++b)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      eo[3 * b + c] = (b - 1) * L + (c - 1);
+  // what this lane loads for itself (outside the tile).  Upper far entries k =
+  // 18 + m (m = 0..8): array 8 - m, shift eo[m]; the lanes at the low end lack m
+  // = 0..3 (eo < 0), those at the high end m = 5..8.  Upper near entries k = 14
+  // + j: array 12 - j, shift dn[j] = 1, L - 1, L, L + 1.
+  const bool hi = __builtin_amdgcn_readfirstlane(t >> 9) != 0; // per wave
+  int dn[4];
+  bool he_need[4], hn_need[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = hi ? eo[5 + j] : eo[j];
+    he_need[j] = hi ? (t + e >= kHbT) : (t + e < 0);
+    dn[j] = eo[5 + j];
+    hn_need[j] = t + dn[j] >= kHbT;
+  }
+  auto at = [](const auto* base, int idx) { // scalar base + 32-bit byte offset
+    using E = std::remove_cv_t<std::remove_pointer_t<decltype(base)>>;
+    const uint32_t off = (uint32_t)idx * (uint32_t)sizeof(E);
+    return *reinterpret_cast<const E*>(reinterpret_cast<const char*>(base) + off);
+  };
+  auto clamp_arr = [&](int r) { return r < 0 ? 0 : (r > last_arr ? last_arr : r); };
+  auto clamp_col = [&](int c) { return c < 0 ? 0 : (c > last_row ? last_row : c); };
+  // the loads of step q, in two groups.  Main: own values of plane q, x window
+  // of plane q - 1, mask.  Edge: outside far values of plane q + 1, outside
+  // near values of plane q (a lane that needs none reads element 0).
+  auto load_main = [&](int q, int s, bool last, TV (&C)[14], T (&XW)[2],
+                       uint32_t& m) {
+    const int row = last ? 0 : q * P + s + t;
+    const int r = clamp_arr(row);
+#pragma unroll
+    for (int a = 0; a < 14; ++a)
+      C[a] = at(base[a], r);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int w = t + j * kHbT;
+      XW[j] = at(in, last ? 0 : clamp_col((q - 1) * P + s - (L + 1) + w));
+    }
+    m = at(mask, clamp_col(row));
+  };
+  auto load_edge = [&](int q, int s, bool last, TV (&HE)[4], TV (&HN)[4]) {
+    const int row = q * P + s + t;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = hi ? eo[5 + j] : eo[j];
+      // (a select, not a branch around the load: told to the compiler by hiding
+      // the index)
+      int ie = he_need[j] && !last ? clamp_arr(row + P + e) : 0;
+      int in_ = hn_need[j] && !last ? clamp_arr(row + dn[j]) : 0;
+      asm volatile("" : "+v"(ie), "+v"(in_));
+      HE[j] = at(hi ? base[3 - j] : base[8 - j], ie);
+      HN[j] = at(base[12 - j], in_);
+    }
+  };
+  // One step: the set `N` (loaded a step ago) becomes the step's own; the
+  // in-plane arrays, the diagonal and the x window of plane q - 1 go to LDS;
+  // the loads of step q - 1 are issued; the rows of plane q are computed
+  // (COMPUTE; the first step of a run only prepares); the plane-to-plane
+  // arrays go to LDS for the step below.  Straight-line code, every load
+  // unconditional (`last`: nothing below to load -- element 0): the compiler's
+  // counts of loads in flight stay exact and no wait covers more than it must.
+  TV C[14], N[14], HE[4], HN[4];
+  T XW[2];
+  uint32_t mN;
+  auto step = [&](int q, int s, bool last, auto compute_tag) {
+    constexpr bool COMPUTE = decltype(compute_tag)::value;
+#pragma unroll
+    for (int a = 0; a < 14; ++a)
+      C[a] = N[a];
+    const uint32_t mq = mN;
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+      s_near[a * kHbT + t] = C[9 + a];
+    {
+      T* const ring = s_x + ((q + 2) % 3) * W; // (q - 1) mod 3
+      ring[t] = XW[0];
+      if (t + kHbT < W)
+        ring[t + kHbT] = XW[1];
+    }
+    __syncthreads();
+    const int i = q * P + s + t;
+    const bool live = s + t < P && i <= last_row;
+    T y0 = T(0);
+    if constexpr (COMPUTE && BETA) {
+      // (before the loads of the next step and waited for at once: the counter
+      // of loads in flight is in order)
+      y0 = at(out, clamp_col(i));
+      asm volatile("" : "+v"(y0));
+    }
+    load_main(q - 1, s, last, N, XW, mN);
+    if constexpr (COMPUTE) {
+      const uint32_t mm = live ? mq : 0u;
+      const T* const xl = s_x + ((q + 2) % 3) * W + t + L + 1; // plane q - 1
+      const T* const xc = s_x + (q % 3) * W + t + L + 1;
+      const T* const xu = s_x + ((q + 1) % 3) * W + t + L + 1;
+      T sum = 0; // csr_kernels.cpp:45
+      // (the groups one after the other, each sum finished before the next
+      // group's LDS reads: with all 41 reads of a row hoisted to the top the
+      // loads in flight no longer fit the registers)
+#pragma unroll
+      for (int k = 0; k < 9; ++k) { // plane below: own values
+        const T p = (T)C[k] * xl[eo[k]];
+        sum = ((mm >> k) & 1u) ? sum + p : sum;
+      }
+      asm volatile("" : "+v"(sum)::"memory");
+#pragma unroll
+      for (int k = 9; k < 13; ++k) { // this plane, before the diagonal
+        const T p = (T)s_near[(k - 9) * kHbT + t] * xc[eo[k - 9]];
+        sum = ((mm >> k) & 1u) ? sum + p : sum;
+      }
+      {
+        const T p = (T)s_near[4 * kHbT + t] * xc[0];
+        sum = ((mm >> 13) & 1u) ? sum + p : sum;
+      }
+      asm volatile("" : "+v"(sum)::"memory");
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { // this plane, after it: lane t + d's value
+        int src = t + dn[j];
+        src = src > kHbT - 1 ? kHbT - 1 : src;
+        const TV vs = s_near[(3 - j) * kHbT + src];
+        const T p = (T)(hn_need[j] ? HN[j] : vs) * xc[dn[j]];
+        sum = ((mm >> (14 + j)) & 1u) ? sum + p : sum;
+      }
+      asm volatile("" : "+v"(sum)::"memory");
+#pragma unroll
+      for (int mi = 0; mi < 9; ++mi) { // plane above: lane t + e's value there
+        if (mi == 5)
+          asm volatile("" : "+v"(sum)::"memory");
+        int src = t + eo[mi];
+        src = src < 0 ? 0 : (src > kHbT - 1 ? kHbT - 1 : src);
+        const TV vs = s_far[(8 - mi) * kHbT + src];
+        TV v = vs;
+        if (mi < 4)
+          v = (!hi && he_need[mi]) ? HE[mi] : vs;
+        else if (mi > 4)
+          v = (hi && he_need[mi - 5]) ? HE[mi - 5] : vs;
+        const T p = (T)v * xu[eo[mi]];
+        sum = ((mm >> (18 + mi)) & 1u) ? sum + p : sum;
+      }
+      asm volatile("" : "+v"(sum)::"memory");
+      const T cy = alpha * sum; // :49
+      T y = cy;
+      if constexpr (BETA)
+        y = cy + beta * y0;
+      if (live) {
+        out[i] = y;
+        if constexpr (DOT)
+          dot_acc += (double)xc[0] * (double)cy;
+      }
+    }
+    // the edge values of the step below, now that this step's are used
+    load_edge(q - 1, s, last, HE, HN);
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 9; ++a) // plane q's plane-to-plane arrays for step q - 1
+      s_far[a * kHbT + t] = C[a];
+  };
+  const int units = g.tiles * g.segs;
+  int u = blockIdx.x;
+  if ((gridDim.x & 7) == 0) // neighbouring tiles on one XCD (halo lines in its L2)
+    u = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  for (; u < units; u += gridDim.x) {
+    const int tile = u % g.tiles, seg = u / g.tiles;
+    const int za = seg * g.seg_len;
+    const int zb = za + g.seg_len < g.planes ? za + g.seg_len : g.planes;
+    if (za >= zb)
+      continue; // uniform
+    const int s = tile * kHbT;
+    __syncthreads(); // the unit before has done with the LDS
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { // the window of plane zb
+      const int w = t + j * kHbT;
+      if (w < W)
+        s_x[(zb % 3) * W + w] = at(in, clamp_col(zb * P + s - (L + 1) + w));
+    }
+    load_main(zb, s, false, N, XW, mN);
+    load_edge(zb, s, false, HE, HN);
+    step(zb, s, false, std::false_type()); // plane zb's values to LDS only
+    for (int q = zb - 1; q >= za; --q)
+      step(q, s, q == za, std::true_type());
+  }
+  if constexpr (DOT) {
+    __syncthreads();
+    double v = dot_acc;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+      v += __shfl_down(v, off, 64);
+    if ((t & 63) == 0)
+      s_red[t >> 6] = v;
+    __syncthreads();
+    if (t == 0) {
+      double r = 0.0;
+#pragma unroll
+      for (int w = 0; w < kHbT / 64; ++w)
+        r += s_red[w];
+      dot.partials[blockIdx.x] = r;
+    }
+    for (int i = gridDim.x + blockIdx.x * blockDim.x + t; i < dot.len;
+         i += gridDim.x * blockDim.x)
+      dot.partials[i] = 0.0;
+  }
 }
 
 // pass 1: the set of distinct col - row (capacity kWdiaMaxOff; INT32_MIN =
@@ -618,6 +894,7 @@ void wdia_free_arrays(spmv_hip_csr_plan* pl)
   pl->wdia_box_table = nullptr;
   pl->wdia_box_slots = pl->wdia_box_grid = pl->wdia_box_segments = 0;
   pl->wdia_box = 0;
+  pl->wdia_hbox = 0;
   (void)hipFree(pl->wdia_zw_table);
   pl->wdia_zw_table = nullptr;
   pl->wdia_zw_slots = pl->wdia_zw_grid = pl->wdia_zw_segments = 0;
@@ -858,6 +1135,13 @@ int wdia_bake(spmv_hip_csr_plan* pl, const T* values, hipStream_t st)
       return rw;
     }
   }
+  if (!is_const && narr < K) {
+    const int rh = spmv_wdia_hbox_build(pl, 1);
+    if (rh != SPMV_HIP_OK) {
+      wdia_free_arrays(pl);
+      return rh;
+    }
+  }
   if (is_const) { // a constant 27-point box: several lines per lane
     const int rb = spmv_wdia_box_build(pl, pl->ctx->const_tile, 0, false);
     if (rb != SPMV_HIP_OK) {
@@ -1042,10 +1326,67 @@ int box_launch(const spmv_hip_csr_plan* pl, hipStream_t st, const WdiaConsts& cv
   return SPMV_HIP_OK;
 }
 
+// The marched half-box kernel: geometry, LDS footprint, launch.
+HalfBoxGeom hbox_geom(const spmv_hip_csr_plan* pl)
+{
+  HalfBoxGeom g;
+  g.P = pl->wdia_box_P;
+  g.L = pl->wdia_box_L;
+  g.tiles = (g.P + kHbT - 1) / kHbT;
+  g.planes = (int)(((int64_t)pl->num_rows + g.P - 1) / g.P);
+  // runs of planes: about one unit per CU, no run shorter than 8 planes (the
+  // run's first step loads a plane it does not compute)
+  int segs = pl->wdia_hbox_segs;
+  if (segs <= 0) {
+    segs = (pl->ctx->num_cus + g.tiles / 2) / g.tiles;
+    const int most = g.planes / 8;
+    segs = segs > most ? most : segs;
+  }
+  segs = segs < 1 ? 1 : (segs > g.planes ? g.planes : segs);
+  g.seg_len = (g.planes + segs - 1) / segs;
+  g.segs = (g.planes + g.seg_len - 1) / g.seg_len;
+  g.W = kHbT + 2 * (g.L + 1);
+  return g;
+}
+
+size_t hbox_lds(const HalfBoxGeom& g, size_t tv, size_t t)
+{
+  return 14 * (size_t)kHbT * tv + 3 * (size_t)g.W * t + 16 * sizeof(double);
+}
+
+template <typename TV, typename T, bool DOT>
+int hbox_launch(const spmv_hip_csr_plan* pl, hipStream_t st, const TV* sval,
+                T alpha, const T* in, T beta, T* out, DotOut dot)
+{
+  const HalfBoxGeom g = hbox_geom(pl);
+  const size_t lds = hbox_lds(g, sizeof(TV), sizeof(T));
+  int grid = g.tiles * g.segs;
+  if (grid > pl->ctx->num_cus)
+    grid = pl->ctx->num_cus;
+  if (grid > pl->ctx->dot_blocks)
+    grid = pl->ctx->dot_blocks;
+  auto kern = beta != T(0) ? csr_box27_half_kernel<TV, T, DOT, true>
+                           : csr_box27_half_kernel<TV, T, DOT, false>;
+  SPMV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds));
+  HalfBoxArrays<TV> arrays;
+  for (int a = 0; a < 14; ++a)
+    arrays.a[a] = sval + (int64_t)a * pl->wdia_len;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kHbT), lds, st, pl->num_rows,
+                     (int32_t)pl->wdia_len, arrays, pl->wdia_mask, alpha, in, beta,
+                     out, dot, g);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
 template <typename TV, typename T, bool DOT>
 int wdia_launch(const spmv_hip_csr_plan* pl, hipStream_t st, const TV* sval,
                 T alpha, const T* in, T beta, T* out, DotOut dot)
 {
+  if (pl->wdia_hbox && !pl->wdia_const && pl->wdia_narr == 14
+      && pl->num_rows == pl->num_cols)
+    return hbox_launch<TV, T, DOT>(pl, st, sval, alpha, in, beta, out, dot);
   const int nrb = (pl->num_rows + kRows - 1) / kRows;
   WdiaOffsets off;
   for (int k = 0; k < kWdiaMaxOff; ++k) {
@@ -1193,4 +1534,39 @@ int spmv_wdia_box_build(spmv_hip_csr_plan* pl, int R, int segments, bool force)
   if (rc == SPMV_HIP_OK && pl->wdia_box_table)
     pl->wdia_box_grid = grid;
   return rc;
+}
+
+// HALF form of a 27-point box a P + b L + c with varying coefficients: may the
+// marched kernel (csr_box27_half_kernel) take it?  Lines of at most 511 rows
+// (the two ends of a tile must not overlap, the x ring must fit the LDS), planes
+// of at least a tile, at least 8 planes.
+int spmv_wdia_hbox_build(spmv_hip_csr_plan* pl, int on)
+{
+  pl->wdia_hbox = 0;
+  if (!on || !pl->wdia_val || pl->wdia_const || pl->wdia_K != 27
+      || pl->wdia_narr != 14 || pl->num_rows != pl->num_cols)
+    return SPMV_HIP_OK;
+  const int64_t P = pl->wdia_D[22], L = pl->wdia_D[16];
+  if (L < 3 || L > 511 || P <= 2 * L + 2 || P < kHbT || P > (1 << 26)
+      || (int64_t)pl->num_rows < 8 * P || pl->wdia_len >= (1 << 29) - (1 << 27))
+    return SPMV_HIP_OK;
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b)
+      for (int c = 0; c < 3; ++c)
+        if (pl->wdia_D[9 * a + 3 * b + c] != (a - 1) * P + (b - 1) * L + (c - 1))
+          return SPMV_HIP_OK;
+  for (int k = 14; k < 27; ++k) // the half form's map: entry k = array 26 - k
+    if (pl->wdia_A[k] != 26 - k || pl->wdia_S[k] != pl->wdia_D[k])
+      return SPMV_HIP_OK;
+  int lds_max = 0;
+  SPMV_CHECK_HIP(hipDeviceGetAttribute(
+      &lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, pl->ctx->device));
+  pl->wdia_box_P = (int)P;
+  pl->wdia_box_L = (int)L;
+  const HalfBoxGeom g = hbox_geom(pl);
+  if (hbox_lds(g, (size_t)pl->wdia_elem, (size_t)pl->wdia_elem) > (size_t)lds_max
+      || hbox_lds(g, 4, 8) > (size_t)lds_max)
+    return SPMV_HIP_OK;
+  pl->wdia_hbox = 1;
+  return SPMV_HIP_OK;
 }

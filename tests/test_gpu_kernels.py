@@ -2442,6 +2442,109 @@ def test_wide_diagonal_half_form_bit_exact(lat_ctx):
             blk.free()
 
 
+def _sym_box_csr(rng, N, P, L, drop):
+    """Symmetric matrix (bit for bit) on the 27 offsets a P + b L + c of a box
+    stencil, N rows (not necessarily whole planes), a share `drop` of the
+    mirrored pairs missing."""
+    import scipy.sparse as sp
+    up = sorted(a * P + b * L + c for a in (0, 1) for b in (-1, 0, 1)
+                for c in (-1, 0, 1) if a * P + b * L + c >= 0)
+    assert len(up) == 14
+    rp, ci, va = _stencil_csr(rng, N, up, drop=drop)
+    A = sp.csr_matrix((va, ci, rp), shape=(N, N))
+    S = (A + A.T).tocsr()
+    S.sort_indices()
+    return (S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.copy())
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_box27_half_marched_kernel_bit_exact(dtype):
+    """27-point box stencils with VARYING coefficients, symmetric bit for bit:
+    the half form's marched kernel (csr_box27_half_kernel: tiles of 1024 rows
+    walked down the planes, plane values handed on through LDS, x from a ring of
+    plane windows).  Same bits as the oracle for whole boxes, planes that are
+    not whole tiles, row counts that are not whole planes, missing entries, runs
+    of planes of every length, alpha / beta, the fused dot, the fp32 copy of the
+    mixed SpMV -- and as the general wide diagonal kernel on the same plan."""
+    ctx = hip.Context(0)
+    ctx.set_option("lat_min_nnz", 0)
+    ctx.set_option("lx_min_nnz", 0)
+    ctx.set_option("const_diagonals", 0)
+    rng = np.random.default_rng(0xB0C5)
+    #        name            P      L    rows               drop
+    shapes = [("box_32x32x9", 1024, 32, 1024 * 9, 0.0),
+              ("box_40x30x10", 1200, 40, 1200 * 10, 0.0),   # tiles of 1024 + 176
+              ("box_64x50x8", 3200, 64, 3200 * 8, 0.15),    # holes
+              ("ragged_end", 2048, 100, 2048 * 9 + 777, 0.05),
+              ("long_lines", 5080, 508, 5080 * 8 + 3, 0.0)]  # the longest lines the LDS holds
+    for name, P, L, N, drop in shapes:
+        rp, ci, va = _sym_box_csr(rng, N, P, L, drop)
+        va = va.astype(dtype)  # (rounding keeps the symmetry)
+        x = rng.uniform(-1, 1, N).astype(dtype)
+        y0 = rng.uniform(-1, 1, N).astype(dtype)
+        blk = hip.CsrBlock(ctx, N, N, rp, ci, va, None, False, hip.ALGO_ROWBLOCK,
+                           dtype)
+        blk.bake()
+        assert blk.get("wdia") == 1 and blk.get("wdia_offsets") == 27, name
+        assert blk.get("wdia_half") == 1 and blk.get("wdia_const") == 0, name
+        assert blk.get("wdia_hbox") == 1, name
+        dx = ctx.upload(x, dtype)
+        part = ctx.empty(ctx.dot_partials_len, np.float64)
+        planes = -(-N // P)
+        for alpha, beta in ((1.0, 0.0), (-0.5, 0.0), (2.0, 1.0), (1.0, -0.25)):
+            y_ref = oracle.csr_spmv(rp, ci, va, x, alpha, beta, y0)
+            for knobs in (dict(), dict(wdia_hbox_segs=1), dict(wdia_hbox_segs=2),
+                          dict(wdia_hbox_segs=3), dict(wdia_hbox_segs=planes),
+                          dict(wdia_hbox=0), dict(wdia_hbox=1, wdia_hbox_segs=0)):
+                for k, v in knobs.items():
+                    blk.set(k, v)
+                dy = ctx.upload(np.full(N, np.nan, dtype) if beta == 0 else y0,
+                                dtype)
+                use_dot = beta == 0 and dtype == np.float64
+                blk.mult(alpha, dx.ptr, beta, dy.ptr,
+                         dot_partials=part.ptr if use_dot else None)
+                y = dy.numpy()
+                assert np.array_equal(y, y_ref), (
+                    name, alpha, beta, knobs, int(np.sum(y != y_ref)),
+                    np.flatnonzero(y != y_ref)[:8])
+                if use_dot:
+                    want = float(np.dot(x, y_ref))
+                    got = float(np.sum(part.numpy()))
+                    assert abs(got - want) <= 1e-12 * (np.abs(x) @ np.abs(y_ref)), (
+                        name, knobs)
+                dy.free()
+        assert blk.get("wdia_hbox") == 1
+        if dtype == np.float64:
+            va32 = va.astype(np.float32)
+            d32 = ctx.upload(va32, np.float32)
+            hip.call("spmv_hip_csr_plan_bake_values_f32f64", ctx.h, blk.plan,
+                     d32.ptr, None)
+            assert blk.get("wdia_mixed") == 1, name
+            y32_ref = oracle.csr_spmv(rp, ci, va32.astype(np.float64), x, -0.5, 0.75,
+                                      y0)
+            dy = ctx.upload(y0)
+            hip.call("spmv_hip_csr_spmv_f32f64", ctx.h, blk.plan, N, N, blk.nnz,
+                     blk.rowptr.ptr, blk.colind.ptr, d32.ptr, -0.5, dx.ptr, 0.75,
+                     dy.ptr, None, None)
+            assert np.array_equal(dy.numpy(), y32_ref), name
+            dy.free(), d32.free()
+        dx.free(), part.free()
+        blk.free()
+    # what the marched kernel does not take: fewer than 8 planes, planes smaller
+    # than a tile, lines longer than 511 rows -- the general kernel keeps them
+    for name, P, L, N in (("few_planes", 1024, 32, 1024 * 7),
+                          ("small_planes", 900, 30, 900 * 12),
+                          ("long_lines", 5632, 512, 5632 * 8)):
+        rp, ci, va = _sym_box_csr(rng, N, P, L, 0.0)
+        blk = hip.CsrBlock(ctx, N, N, rp, ci, va.astype(dtype), None, False,
+                           hip.ALGO_ROWBLOCK, dtype)
+        blk.bake()
+        assert blk.get("wdia") == 1 and blk.get("wdia_half") == 1, name
+        assert blk.get("wdia_hbox") == 0, name
+        blk.free()
+    ctx.close()
+
+
 def test_wide_diagonal_form_constant_diagonals_bit_exact():
     """More than three lower offsets, every diagonal constant (HPCG's 27-point
     operator, a 2-D 9-point stencil, 19 offsets with a third of the entries

@@ -23,7 +23,7 @@ KINDS = {
     "fem81": dict(min_len=81, max_len=81),
 }
 ALGO = {"rowblock": 1, "vector": 2, "scalar": 3}
-FORM_KEYS = ("algo", "lat", "lx", "lxw", "wdia", "sdia", "sjds", "sj_wpb", "sj_unit",
+FORM_KEYS = ("algo", "lat", "lx", "lxw", "wdia", "wdia_half", "wdia_hbox", "sdia", "sjds", "sj_wpb", "sj_unit",
              "sj_max_chunks", "sj_far_permille", "sj_staged_bytes_per_entry_x100",
              "sj_wide", "sj_long_rows", "lx_staged", "lx_blocks", "blocks_per_cu", "nontemporal")
 
