@@ -329,6 +329,15 @@ def kernel_of(A, symmetric):
                 "presence mask per row, no values are streamed; rows summed in "
                 "the CSR kernel's order: bit-exact; fused p.Ap)",
                 algo, rows * 4 + y_x)
+    if A.plan_get("wdia") and A.plan_get("wdia_half") and A.plan_get("wdia_hbox"):
+        return ("csr_box27_half_kernel<double> (27-point box with varying "
+                "coefficients, found symmetric bit for bit: the half form -- 13 "
+                "lower diagonals + the diagonal + a 32-bit mask per row -- walked "
+                "down the planes in tiles of 1024 rows, the plane's values handed "
+                "on through LDS (the upper entries are the plane above's lower "
+                "ones), x from an LDS ring of three plane windows; rows summed in "
+                "the CSR kernel's order: bit-exact; fused p.Ap)",
+                algo, rows * (8 * 14 + 4) + y_x)
     if A.plan_get("wdia") and A.plan_get("wdia_half"):
         K = A.plan_get("wdia_offsets")
         return (f"csr_wdia_kernel<double, half> (wide diagonal form: the matrix "
@@ -412,7 +421,7 @@ def plan_record(A):
     return {"plan_ms": A.plan_get("plan_us") / 1e3,
             "plan_extra_bytes": A.plan_get("plan_kib") * 1024,
             "form": {k: A.plan_get(k) for k in
-                     ("lat", "lx", "lxw", "sjds", "wdia", "wdia_const", "slat",
+                     ("lat", "lx", "lxw", "sjds", "wdia", "wdia_const", "wdia_hbox", "slat",
                       "sdia", "sdia_const", "sym_det", "zwalk")}}
 
 

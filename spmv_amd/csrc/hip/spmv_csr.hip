@@ -1300,6 +1300,12 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
   SPMV_REQUIRE(ctx && plan && num_rows >= 0 && num_cols >= 0
                && num_non_zeros >= 0);
   SPMV_REQUIRE(num_non_zeros == 0 || (rowptr && colind));
+  // (the plan's clock counts the plan's work, not kernels of the caller still
+  // running on the stream -- a device-side generator's fill, say)
+  if (num_non_zeros > 0) {
+    SPMV_SET_DEVICE(ctx);
+    SPMV_CHECK_HIP(hipStreamSynchronize(spmv_stream(ctx, nullptr)));
+  }
   const auto t_begin = std::chrono::steady_clock::now();
   // rowptr is int32 in the reference format (csr_kernels.h:28)
   if (num_non_zeros > INT32_MAX)
@@ -1421,6 +1427,8 @@ int spmv_hip_csr_plan_bake_values_f64(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan
   SPMV_SET_DEVICE(ctx);
   SPMV_REQUIRE(plan && plan->ctx == ctx);
   hipStream_t st = spmv_stream(ctx, stream);
+  if (values) // (as in plan_create: the caller's kernels are not plan time)
+    SPMV_CHECK_HIP(hipStreamSynchronize(st));
   int rc = spmv_sdia_bake_f64(plan, values, diagonal, st);
   // a general matrix the diagonal form refuses (more than three lower
   // offsets, no lattice form): the wide diagonal form, up to 32 diagonals
@@ -1459,6 +1467,8 @@ int spmv_hip_csr_plan_bake_values_f32(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan
   SPMV_SET_DEVICE(ctx);
   SPMV_REQUIRE(plan && plan->ctx == ctx);
   hipStream_t st = spmv_stream(ctx, stream);
+  if (values)
+    SPMV_CHECK_HIP(hipStreamSynchronize(st));
   int rc = spmv_sdia_bake_f32(plan, values, diagonal, st);
   if (!plan->symmetric && (rc == SPMV_HIP_ENOTSUP || values == nullptr)) {
     const int rw = spmv_wdia_bake_f32(plan, values, st);
@@ -1672,7 +1682,12 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
     // the marched kernel for the half form of a 27-point box (0 = the general
     // wide diagonal kernel)
     SPMV_REQUIRE((value == 0 || value == 1) && plan->wdia_val);
-    return spmv_wdia_hbox_build(plan, value);
+    const int rh = spmv_wdia_hbox_build(plan, value);
+    if (rh != SPMV_HIP_OK)
+      return rh;
+    if (!plan->wdia_hbox && plan->wdia_d2 > 0 && !plan->wdia_zw_table)
+      return spmv_wdia_walk_build(plan, 0, false); // the general kernel's order
+    return SPMV_HIP_OK;
   } else if (!strcmp(key, "wdia_hbox_segs")) {
     SPMV_REQUIRE(value >= 0 && value <= 4096);
     plan->wdia_hbox_segs = value;

@@ -44,6 +44,8 @@
 #include "csr_plan.h"
 
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <type_traits>
@@ -579,37 +581,73 @@ __global__ __launch_bounds__(kHbT) void csr_box27_half_kernel(
   }
 }
 
+// The row of entry j among the rows whose pointers sit in s_rp[0..nr]: the
+// largest r with s_rp[r] <= j (empty rows are skipped over).
+__device__ __forceinline__ int wdia_row_of(const int32_t* s_rp, int nr, int32_t j)
+{
+  int lo = 0, hi = nr; // s_rp[lo] <= j < s_rp[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (s_rp[mid] <= j)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
 // pass 1: the set of distinct col - row (capacity kWdiaMaxOff; INT32_MIN =
-// free slot).  Slots are always probed from 0, so a value can only ever sit in
-// one slot (a probe that started anywhere else could insert a second copy
-// behind a free slot).
+// free slot).  Lane = ENTRY (coalesced reads of colind; the row by bisection in
+// the block's slice of the row pointer), the set kept per workgroup in LDS and
+// merged into the global one at the end -- the first version (lane = row, the
+// global set probed per entry) took 9.9 ms of the 27-point plan at 256^3.
+// Slots are always probed from 0, so a value can only ever sit in one slot (a
+// probe that started anywhere else could insert a second copy behind a free
+// slot).
+__device__ __forceinline__ bool wdia_set_insert(int32_t* set, int32_t d)
+{
+  for (int s = 0; s < kWdiaMaxOff; ++s) {
+    int32_t cur = set[s];
+    if (cur == INT32_MIN)
+      cur = atomicCAS(set + s, INT32_MIN, d);
+    if (cur == d || cur == INT32_MIN)
+      return true;
+  }
+  return false;
+}
+
 __global__ __launch_bounds__(kBlock) void wdia_offsets_kernel(
     int32_t num_rows, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ colind, int32_t* __restrict__ set,
     int32_t* __restrict__ fail)
 {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < num_rows;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    if (*fail) // somebody found a 33rd offset: nothing left to learn
-      return;
-    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
-      const int64_t d64 = (int64_t)colind[j] - i;
-      if (d64 <= INT32_MIN || d64 > INT32_MAX) {
-        atomicOr(fail, 1);
-        continue;
-      }
-      const int32_t d = (int32_t)d64;
-      bool placed = false;
-      for (int s = 0; s < kWdiaMaxOff && !placed; ++s) {
-        int32_t cur = set[s];
-        if (cur == INT32_MIN)
-          cur = atomicCAS(set + s, INT32_MIN, d);
-        placed = (cur == d || cur == INT32_MIN);
-      }
-      if (!placed)
+  __shared__ int32_t s_rp[kRows + 1];
+  __shared__ int32_t s_set[kWdiaMaxOff];
+  const int t = threadIdx.x;
+  if (t < kWdiaMaxOff)
+    s_set[t] = INT32_MIN;
+  const int nrb = (num_rows + kRows - 1) / kRows;
+  for (int rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+    if (*(volatile int32_t*)fail) // somebody found a 33rd offset
+      break;
+    const int r0 = rb * kRows;
+    const int nr = num_rows - r0 < kRows ? num_rows - r0 : kRows;
+    __syncthreads();
+    for (int r = t; r <= nr; r += kBlock)
+      s_rp[r] = rowptr[r0 + r];
+    __syncthreads();
+    const int32_t j0 = s_rp[0], j1 = s_rp[nr];
+    for (int32_t j = j0 + t; j < j1; j += kBlock) {
+      const int r = wdia_row_of(s_rp, nr, j);
+      const int64_t d64 = (int64_t)colind[j] - (r0 + r);
+      if (d64 <= INT32_MIN || d64 > INT32_MAX
+          || !wdia_set_insert(s_set, (int32_t)d64))
         atomicOr(fail, 1);
     }
   }
+  __syncthreads();
+  if (t < kWdiaMaxOff && s_set[t] != INT32_MIN && !wdia_set_insert(set, s_set[t]))
+    atomicOr(fail, 1);
 }
 
 // Is the matrix symmetric, entry for entry and bit for bit?  Asked of the arrays
@@ -836,8 +874,16 @@ int wdia_const_probe(const spmv_hip_csr_plan* pl, int K, const WdiaOffsets& off,
 }
 
 // pass 2: fill the arrays and the masks; fail = a row whose columns do not
-// ascend strictly.  Only the offsets k < narr have arrays (half form: the
-// offsets <= 0).
+// ascend strictly, or an offset outside the set.  Only the offsets k < narr
+// have arrays (half form: the offsets <= 0).  Tiles of 128 rows: the tile's
+// entries are read in ENTRY order (coalesced; row and offset by bisection in
+// LDS) into an LDS image [offset][row], which then goes out row-contiguous,
+// zeros where a row has no such entry -- the arrays need no memset, and both
+// sides of the transposition are coalesced (lane = row on both sides: 14.4 ms
+// of the 27-point plan at 256^3, every load instruction 64 different lines).
+constexpr int kWdiaTile = 128;
+constexpr int kWdiaTileStride = kWdiaTile + 1; // (offset, row) -> distinct banks
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void wdia_bake_kernel(
     int32_t num_rows, int K, int narr, WdiaOffsets off,
@@ -845,33 +891,60 @@ __global__ __launch_bounds__(kBlock) void wdia_bake_kernel(
     const T* __restrict__ values, int64_t arr_len, T* __restrict__ sval,
     uint32_t* __restrict__ mask, int32_t* __restrict__ fail)
 {
-  __shared__ int32_t s_D[kWdiaMaxOff]; // indexed per lane below
-  if (threadIdx.x < kWdiaMaxOff)
-    s_D[threadIdx.x] = off.D[threadIdx.x];
-  __syncthreads();
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < num_rows;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    uint32_t m = 0;
-    int prev = -1;
-    bool bad = false;
-    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
-      const int32_t d = (int32_t)((int64_t)colind[j] - i);
-      int k = prev + 1; // ascending columns: the search resumes where it was
-      while (k < K && s_D[k] != d)
-        ++k;
-      if (k >= K) {
-        bad = true;
-        break;
+  __shared__ int32_t s_D[kWdiaMaxOff];
+  __shared__ int32_t s_rp[kWdiaTile + 1];
+  __shared__ uint32_t s_mask[kWdiaTile];
+  __shared__ T s_img[kWdiaMaxOff * kWdiaTileStride];
+  const int t = threadIdx.x;
+  if (t < kWdiaMaxOff)
+    s_D[t] = off.D[t];
+  const int ntiles = (int)(arr_len / kWdiaTile); // arr_len: whole blocks of 256
+  bool bad = false;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int r0 = tile * kWdiaTile;
+    int nr = num_rows - r0;
+    nr = nr < 0 ? 0 : (nr > kWdiaTile ? kWdiaTile : nr);
+    __syncthreads(); // the image of the tile before is out
+    for (int r = t; r <= nr; r += kBlock)
+      s_rp[r] = rowptr[r0 + r];
+    if (t < kWdiaTile)
+      s_mask[t] = 0u;
+    for (int e = t; e < narr * kWdiaTileStride; e += kBlock)
+      s_img[e] = T(0);
+    __syncthreads();
+    const int32_t j0 = nr > 0 ? s_rp[0] : 0, j1 = nr > 0 ? s_rp[nr] : 0;
+    for (int32_t j = j0 + t; j < j1; j += kBlock) {
+      const int r = wdia_row_of(s_rp, nr, j);
+      const int32_t c = colind[j];
+      const int64_t d64 = (int64_t)c - (r0 + r);
+      // the offset's place in the ascending set
+      int lo = 0, hi = K;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((int64_t)s_D[mid] < d64)
+          lo = mid + 1;
+        else
+          hi = mid;
       }
-      if (k < narr)
-        sval[(int64_t)k * arr_len + i] = values[j];
-      m |= 1u << k;
-      prev = k;
+      if (lo >= K || (int64_t)s_D[lo] != d64
+          || (j > s_rp[r] && colind[j - 1] >= c)) { // csr_kernels.cpp:46-47 order
+        bad = true;
+        continue;
+      }
+      atomicOr(&s_mask[r], 1u << lo);
+      if (lo < narr)
+        s_img[lo * kWdiaTileStride + r] = values[j];
     }
-    if (bad)
-      atomicOr(fail, 1);
-    mask[i] = m;
+    __syncthreads();
+    for (int e = t; e < narr * kWdiaTile; e += kBlock) {
+      const int k = e / kWdiaTile, r = e % kWdiaTile;
+      sval[(int64_t)k * arr_len + r0 + r] = s_img[k * kWdiaTileStride + r];
+    }
+    if (t < nr)
+      mask[r0 + t] = s_mask[t];
   }
+  if (bad)
+    atomicOr(fail, 1);
 }
 
 void wdia_free_arrays(spmv_hip_csr_plan* pl)
@@ -927,6 +1000,19 @@ int wdia_bake(spmv_hip_csr_plan* pl, const T* values, hipStream_t st)
       || pl->algo != SPMV_HIP_ALGO_ROWBLOCK || pl->nnz < pl->ctx->lat_min_nnz)
     return SPMV_HIP_ENOTSUP;
   const auto t_begin = std::chrono::steady_clock::now();
+  // SPMV_WDIA_TRACE=1: the phases' wall times on stderr (each ends with a stream
+  // synchronisation, so the sum exceeds the untraced plan)
+  const bool trace = getenv("SPMV_WDIA_TRACE") != nullptr;
+  auto t_lap = t_begin;
+  auto lap = [&](const char* what) {
+    if (!trace)
+      return;
+    (void)hipStreamSynchronize(st);
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[wdia_bake] %-28s %8.3f ms\n", what,
+            std::chrono::duration<double, std::milli>(now - t_lap).count());
+    t_lap = now;
+  };
   const int32_t n = pl->num_rows;
   // pass 1: the offsets
   int32_t h_set[kWdiaMaxOff + 1];
@@ -951,6 +1037,7 @@ int wdia_bake(spmv_hip_csr_plan* pl, const T* values, hipStream_t st)
     (void)hipFree(d_set);
     return static_cast<int>(e);
   }
+  lap("offsets");
   WdiaOffsets off;
   int K = 0;
   for (int s = 0; s < kWdiaMaxOff; ++s)
@@ -997,6 +1084,7 @@ int wdia_bake(spmv_hip_csr_plan* pl, const T* values, hipStream_t st)
     if (is_const)
       narr = 0;
   }
+  lap("mask alloc + const probe");
   bool mirrored = !is_const && pl->ctx->wdia_half
                   && pl->num_rows == pl->num_cols;
   for (int k = 0; k < K && mirrored; ++k) {
@@ -1012,10 +1100,10 @@ int wdia_bake(spmv_hip_csr_plan* pl, const T* values, hipStream_t st)
   void* sval = nullptr;
   int32_t h_fail = 0;
   e = hipMalloc(&sval, bytes > 0 ? bytes : 64); // (constant: a marker only)
+  lap("alloc arrays");
   if (e == hipSuccess && !is_const) {
-    e = hipMemsetAsync(sval, 0, bytes, st);
-    if (e == hipSuccess)
-      e = hipMemsetAsync(d_set + kWdiaMaxOff, 0, sizeof(int32_t), st);
+    // (the bake kernel writes every element of the arrays, zeros included)
+    e = hipMemsetAsync(d_set + kWdiaMaxOff, 0, sizeof(int32_t), st);
     if (e == hipSuccess) {
       hipLaunchKernelGGL((wdia_bake_kernel<T>), dim3(grid), dim3(kBlock), 0, st,
                          n, K, narr, off, pl->rowptr0, pl->colind0, values, len,
@@ -1027,6 +1115,7 @@ int wdia_bake(spmv_hip_csr_plan* pl, const T* values, hipStream_t st)
                          hipMemcpyDeviceToHost, st);
     if (e == hipSuccess)
       e = hipStreamSynchronize(st);
+    lap("bake");
     // HALF form?  The offsets mirror each other (try_half); is the matrix
     // symmetric entry for entry, bit for bit?  One coalesced pass over the
     // arrays just baked; if so only the arrays of the offsets <= 0 are kept
@@ -1053,6 +1142,7 @@ int wdia_bake(spmv_hip_csr_plan* pl, const T* values, hipStream_t st)
                            hipMemcpyDeviceToHost, st);
       if (e == hipSuccess)
         e = hipStreamSynchronize(st);
+      lap("symmetry check");
       if (e == hipSuccess && !h_asym) {
         int nh = 0;
         while (nh < K && off.D[nh] <= 0)
@@ -1064,8 +1154,10 @@ int wdia_bake(spmv_hip_csr_plan* pl, const T* values, hipStream_t st)
           eh = hipMemcpyAsync(half, sval, hbytes, hipMemcpyDeviceToDevice, st);
         if (eh == hipSuccess)
           eh = hipStreamSynchronize(st);
+        lap("alloc + copy half");
         if (eh == hipSuccess) {
           (void)hipFree(sval);
+          lap("free full");
           sval = half;
           narr = nh;
           for (int k = narr; k < K; ++k) {
@@ -1128,18 +1220,21 @@ int wdia_bake(spmv_hip_csr_plan* pl, const T* values, hipStream_t st)
       }
     pl->wdia_d2 = na > 0 ? a[na / 2] : 0;
   }
-  if (pl->wdia_d2 > 0) {
-    const int rw = spmv_wdia_walk_build(pl, 0, false);
-    if (rw != SPMV_HIP_OK) {
-      wdia_free_arrays(pl);
-      return rw;
-    }
-  }
-  if (!is_const && narr < K) {
+  lap("bookkeeping");
+  if (!is_const && narr < K) { // a box in the half form: the marched kernel
     const int rh = spmv_wdia_hbox_build(pl, 1);
     if (rh != SPMV_HIP_OK) {
       wdia_free_arrays(pl);
       return rh;
+    }
+  }
+  // (the plane-walk table of the general kernel: 17 ms at 256^3 -- built only
+  // where that kernel runs; plan_set "wdia_hbox" = 0 builds it on demand)
+  if (pl->wdia_d2 > 0 && !pl->wdia_hbox) {
+    const int rw = spmv_wdia_walk_build(pl, 0, false);
+    if (rw != SPMV_HIP_OK) {
+      wdia_free_arrays(pl);
+      return rw;
     }
   }
   if (is_const) { // a constant 27-point box: several lines per lane
@@ -1149,6 +1244,7 @@ int wdia_bake(spmv_hip_csr_plan* pl, const T* values, hipStream_t st)
       return rb;
     }
   }
+  lap("walk table / box geometry");
   pl->plan_us += (int)std::chrono::duration_cast<std::chrono::microseconds>(
                      std::chrono::steady_clock::now() - t_begin)
                      .count();
@@ -1227,8 +1323,6 @@ int wdia_bake_mixed(spmv_hip_csr_plan* pl, const float* values32, hipStream_t st
     e = hipMalloc(&msk, sizeof(uint32_t) * (size_t)n);
   if (e == hipSuccess)
     e = hipMalloc(&d_fail, sizeof(int32_t));
-  if (e == hipSuccess)
-    e = hipMemsetAsync(sval, 0, bytes, st);
   if (e == hipSuccess)
     e = hipMemsetAsync(d_fail, 0, sizeof(int32_t), st);
   if (e == hipSuccess) {
