@@ -641,6 +641,15 @@ constexpr int kSjLpr = 8;
 #define SJ_PANEL_U 4
 #endif
 constexpr int kSjPanelU = SJ_PANEL_U; // steps per trip of the panel walk
+#ifndef SJ_LONG_SETS
+#define SJ_LONG_SETS 1
+#endif
+// sets of eight rows per wave that share the staged panels.  Measured on the
+// 1 % tail (same box, alternating builds): 1 / 2 / 4 sets 0.44 / 0.48 / 0.57 ms --
+// half the x staged per entry does not pay for the longer walk per panel (121
+// / 146 registers): the kernel is bound by the latency of its trips, not by
+// the panels' bytes
+constexpr int kSjLongSets = SJ_LONG_SETS;
 constexpr int kSjLU = 4; // steps per load group of the long-row phase
 template <typename T>
 __device__ __forceinline__ T sj_long_rows8(const T* __restrict__ val,
@@ -743,8 +752,11 @@ __global__ __launch_bounds__(64 * WPB) void csr_sjds_long_kernel(
   {
     __shared__ int32_t s_cmin, s_cmax;
     __shared__ __attribute__((aligned(16))) T s_scr[WPB * 64]; // per wave: products
+    // RS sets of eight rows per wave: a supergroup is 8 WPB RS rows that share
+    // the staged panels (kSjLongSets)
+    constexpr int RS = kSjLongSets;
     const int nitems = (A.nlong + 7) / 8;
-    const int nsg = (nitems + WPB - 1) / WPB;
+    const int nsg = (nitems + WPB * RS - 1) / (WPB * RS);
     const int g8 = gridDim.x >= 8 && (gridDim.x & 7) == 0;
     const int chunk = g8 ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)
                          : blockIdx.x;
@@ -754,13 +766,20 @@ __global__ __launch_bounds__(64 * WPB) void csr_sjds_long_kernel(
     const int sg1 = sg0 + per + (chunk < rem ? 1 : 0);
     const int panel = A.long_panel; // columns of x the LDS buffer holds
     for (int sg = sg0; sg < sg1; ++sg) { // uniform per workgroup
-      const int item = sg * WPB + wave;
-      const int g = item * 8 + (lane >> 3);
-      const bool have_row = g < A.nlong;
-      const int32_t row = A.long_rows[have_row ? g : A.nlong - 1];
-      const int64_t ra = A.rowptr[row];
-      const int64_t rb = have_row ? (int64_t)A.rowptr[row + 1] : ra;
-      T sum;
+      bool have_row[RS];
+      int32_t row[RS];
+      int64_t ra[RS], rb[RS];
+      T sum[RS];
+#pragma unroll
+      for (int h = 0; h < RS; ++h) {
+        const int item = (sg * RS + h) * WPB + wave;
+        const int g = item * 8 + (lane >> 3);
+        have_row[h] = g < A.nlong;
+        row[h] = A.long_rows[have_row[h] ? g : A.nlong - 1];
+        ra[h] = A.rowptr[row[h]];
+        rb[h] = have_row[h] ? (int64_t)A.rowptr[row[h] + 1] : ra[h];
+        sum[h] = T(0);
+      }
       bool by_panels = PANELS; // (an instantiation per path: the two together
                                //  need 180 registers)
       int32_t cmin = 0, cmax = -1;
@@ -770,10 +789,12 @@ __global__ __launch_bounds__(64 * WPB) void csr_sjds_long_kernel(
           s_cmax = -1;
         }
         __syncthreads();
-        if (have_row && rb > ra && (lane & 7) == 0) {
-          atomicMin(&s_cmin, A.colind[ra]);
-          atomicMax(&s_cmax, A.colind[rb - 1]);
-        }
+#pragma unroll
+        for (int h = 0; h < RS; ++h)
+          if (have_row[h] && rb[h] > ra[h] && (lane & 7) == 0) {
+            atomicMin(&s_cmin, A.colind[ra[h]]);
+            atomicMax(&s_cmax, A.colind[rb[h] - 1]);
+          }
         __syncthreads();
         cmin = s_cmin & ~(kSjChunk - 1);
         cmax = s_cmax;
@@ -782,16 +803,21 @@ __global__ __launch_bounds__(64 * WPB) void csr_sjds_long_kernel(
         by_panels = cmax >= cmin && (int64_t)cmax - cmin < (int64_t)64 * panel;
       }
       if constexpr (!PANELS) {
-        sum = sj_long_rows8<T>(A.values, A.colind, ra, rb, lane, in);
+#pragma unroll
+        for (int h = 0; h < RS; ++h)
+          sum[h] = sj_long_rows8<T>(A.values, A.colind, ra[h], rb[h], lane, in);
       } else if (!by_panels) { // rows that are not neighbours in x: rare, slow
-        sum = T(0);
-        if ((lane & 7) == 0)
-          for (int64_t i = ra; i < rb; ++i)
-            sum += A.values[i] * in[A.colind[i]];
+#pragma unroll
+        for (int h = 0; h < RS; ++h)
+          if ((lane & 7) == 0)
+            for (int64_t i = ra[h]; i < rb[h]; ++i)
+              sum[h] += A.values[i] * in[A.colind[i]];
       } else {
         const int l = lane & 7;
-        int64_t e = ra; // the row's first entry not yet added (same in its 8 lanes)
-        T acc = T(0);
+        int64_t e[RS]; // the row's first entry not yet added (same in its 8 lanes)
+#pragma unroll
+        for (int h = 0; h < RS; ++h)
+          e[h] = ra[h];
         for (int64_t p0 = cmin; p0 <= cmax; p0 += panel) {
           // stage x[p0, p0 + panel): 2 elements per lane and round
           const int64_t cend = (int64_t)A.num_cols;
@@ -806,89 +832,98 @@ __global__ __launch_bounds__(64 * WPB) void csr_sjds_long_kernel(
           }
           __syncthreads();
           const int64_t pend = p0 + panel;
-          // the row's entries below pend, eight steps of eight per trip: the
+          // the row's entries below pend, four steps of eight per trip: the
           // loads assume whole steps (a step the panel's end cuts short ends
           // the trip early; what was loaded past it is loaded again with the
           // next panel)
           // (the NEXT trip's loads are issued before this trip's sums, assuming
           // it ends whole; a trip the panel's end cuts short drops them)
           constexpr int U = kSjPanelU;
-          T v[U], vn[U];
-          int32_t c[U], cn[U];
           // (no clamps: a long row ends at least kSjLongPad entries before the
           // arrays do -- sj_is_long -- and what lies past its end is never used;
           // one address per stream and trip, the steps at immediate offsets)
           static_assert(2 * U * 8 + 8 <= kSjLongPad, "loads past a row's end");
-          {
-            const T* vp = A.values + e + l;
-            const int32_t* cp = A.colind + e + l;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-              v[u] = vp[u * 8];
-              c[u] = cp[u * 8];
-            }
-          }
-          bool more = true;
-          while (__any(more)) {
+          for (int h = 0; h < RS; ++h) {
+            T v[U], vn[U];
+            int32_t c[U], cn[U];
+            int64_t eh = e[h];
+            const int64_t rbh = rb[h];
+            T acc = sum[h];
             {
-              const T* vp = A.values + e + l + U * 8;
-              const int32_t* cp = A.colind + e + l + U * 8;
+              const T* vp = A.values + eh + l;
+              const int32_t* cp = A.colind + eh + l;
 #pragma unroll
               for (int u = 0; u < U; ++u) {
-                vn[u] = vp[u * 8];
-                cn[u] = cp[u * 8];
+                v[u] = vp[u * 8];
+                c[u] = cp[u * 8];
               }
             }
-            bool open = more; // this group's steps so far were whole
+            bool more = true;
+            while (__any(more)) {
+              {
+                const T* vp = A.values + eh + l + U * 8;
+                const int32_t* cp = A.colind + eh + l + U * 8;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-              const int64_t i = e + l; // (e advances with the steps)
-              const bool ok = open && i < rb && c[u] < pend;
-              const T x = s_x[ok ? (int32_t)(c[u] - p0) : 0];
-              // a lane without an entry contributes +0.0: the sum starts at
-              // +0.0 and can never become -0.0, so adding it changes no bit
-              const T pr = ok ? v[u] * x : T(0);
-              // valid lanes are a prefix of the group: ascending columns
-              const uint64_t bal = __ballot(ok);
-              const int nv = __popcll((bal >> (lane & ~7)) & 0xFFull);
-              // the group's eight products through the wave's LDS scratch (one
-              // store, four broadcast loads) and onto the sum one by one
-              T* scr = s_scr + wave * 64;
-              scr[lane] = pr;
-              typedef T vec2 __attribute__((ext_vector_type(2)));
-              const vec2* gp = reinterpret_cast<const vec2*>(scr + (lane & ~7));
-              const vec2 q0 = gp[0], q1 = gp[1], q2 = gp[2], q3 = gp[3];
-              acc += q0[0];
-              acc += q0[1];
-              acc += q1[0];
-              acc += q1[1];
-              acc += q2[0];
-              acc += q2[1];
-              acc += q3[0];
-              acc += q3[1];
-              e += nv;
-              open = open && nv == 8;
-            }
-            more = open;
+                for (int u = 0; u < U; ++u) {
+                  vn[u] = vp[u * 8];
+                  cn[u] = cp[u * 8];
+                }
+              }
+              bool open = more; // this group's steps so far were whole
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-              v[u] = vn[u];
-              c[u] = cn[u];
+              for (int u = 0; u < U; ++u) {
+                const int64_t i = eh + l; // (eh advances with the steps)
+                const bool ok = open && i < rbh && c[u] < pend;
+                const T x = s_x[ok ? (int32_t)(c[u] - p0) : 0];
+                // a lane without an entry contributes +0.0: the sum starts at
+                // +0.0 and can never become -0.0, so adding it changes no bit
+                const T pr = ok ? v[u] * x : T(0);
+                // valid lanes are a prefix of the group: ascending columns
+                const uint64_t bal = __ballot(ok);
+                const int nv = __popcll((bal >> (lane & ~7)) & 0xFFull);
+                // the group's eight products through the wave's LDS scratch (one
+                // store, four broadcast loads) and onto the sum one by one
+                T* scr = s_scr + wave * 64;
+                scr[lane] = pr;
+                typedef T vec2 __attribute__((ext_vector_type(2)));
+                const vec2* gp = reinterpret_cast<const vec2*>(scr + (lane & ~7));
+                const vec2 q0 = gp[0], q1 = gp[1], q2 = gp[2], q3 = gp[3];
+                acc += q0[0];
+                acc += q0[1];
+                acc += q1[0];
+                acc += q1[1];
+                acc += q2[0];
+                acc += q2[1];
+                acc += q3[0];
+                acc += q3[1];
+                eh += nv;
+                open = open && nv == 8;
+              }
+              more = open;
+#pragma unroll
+              for (int u = 0; u < U; ++u) {
+                v[u] = vn[u];
+                c[u] = cn[u];
+              }
             }
+            e[h] = eh;
+            sum[h] = acc;
           }
           __syncthreads(); // everybody is done with this panel
         }
-        sum = acc;
       }
-      if (have_row && (lane & 7) == 0) {
-        const T c = alpha * sum;
-        T y = c;
-        if (beta != T(0))
-          y = c + beta * out[row];
-        out[row] = y;
-        if constexpr (DOT)
-          dot_acc += (double)in[row] * (double)c;
-      }
+#pragma unroll
+      for (int h = 0; h < RS; ++h)
+        if (have_row[h] && (lane & 7) == 0) {
+          const T c = alpha * sum[h];
+          T y = c;
+          if (beta != T(0))
+            y = c + beta * out[row[h]];
+          out[row[h]] = y;
+          if constexpr (DOT)
+            dot_acc += (double)in[row[h]] * (double)c;
+        }
     }
   }
   if constexpr (DOT) {
@@ -1153,7 +1188,7 @@ int sj_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
 #define SJ_LONG_WAVES 8
 #endif
     constexpr int LW = SJ_LONG_WAVES;
-    const int nsg = ((pl->sj_nlong + 7) / 8 + LW - 1) / LW;
+    const int nsg = ((pl->sj_nlong + 7) / 8 + LW * kSjLongSets - 1) / (LW * kSjLongSets);
 #ifndef SJ_PANEL_COLS
 #define SJ_PANEL_COLS 7680
 #endif
