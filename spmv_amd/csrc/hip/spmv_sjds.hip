@@ -436,15 +436,27 @@ __global__ __launch_bounds__(kBlock) void sj_bake_kernel(
   }
 }
 
+// The long rows keep their row order (neighbours in x share the staged panels)
+// and are sorted by length inside runs of 2^6 = one workgroup's 64 rows.
+// Measured on the 1 % tail (same box): runs of 16 / 32 / 64 / 128 / 256 / 1024
+// rows 0.45 / 0.44 / 0.44 / 0.48 / 0.58 / 1.24 ms -- what the longer runs gain in
+// waves that end together they lose several times over in panels (the rows of
+// a workgroup are no longer neighbours); 4-wave workgroups 0.50-0.65.
+#ifndef SJ_LONG_RUN_SHIFT
+#define SJ_LONG_RUN_SHIFT 6
+#endif
+constexpr int kSjLongRunShift = SJ_LONG_RUN_SHIFT;
+
 __global__ __launch_bounds__(kBlock) void sj_long_key_kernel(
     int count, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rows,
     uint64_t* __restrict__ key)
 {
-  // runs of 64 consecutive long rows, inside a run the longest first
+  // runs of 2^kSjLongRunShift consecutive long rows, inside a run the longest first
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count;
        i += gridDim.x * blockDim.x) {
     const uint32_t len = (uint32_t)(rowptr[rows[i] + 1] - rowptr[rows[i]]);
-    key[i] = ((uint64_t)(i >> 6) << 32) | (uint64_t)(0xFFFFFFFFu - len);
+    key[i] = ((uint64_t)(i >> kSjLongRunShift) << 32)
+             | (uint64_t)(0xFFFFFFFFu - len);
   }
 }
 
