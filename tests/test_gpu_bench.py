@@ -94,7 +94,8 @@ def test_bench_single_gpu_line():
     assert d["north_star_spmv"]["form"]["lat"] == 1
     # the kernels of matrices WITHOUT lattice structure, measured and checked
     assert d["csr_rowblock_spmv"]["form"] == dict(lat=0, lx=0, lxw=0, sjds=0,
-                                                  wdia=0, wdia_const=0, slat=0,
+                                                  wdia=0, wdia_const=0, wdia_hbox=0,
+                                                  slat=0,
                                                   sdia=0, sdia_const=0, sym_det=0,
                                                   zwalk=0)
     assert d["csr_sjds_spmv"]["form"]["sjds"] == 1
