@@ -307,6 +307,16 @@ struct spmv_hip_csr_plan {
   int sj_nlong = 0, sj_long_thr = 0;
   int sj_long_sorted = 0; // their columns ascend: x by LDS panels
   int sj_long_panels = 1; // use that (plan_set "sj_long_panels")
+  // ... by the table-driven kernel (csr_sjds_longt_kernel): per supergroup of
+  // long rows its first column and number of panels, per row and panel
+  // boundary the row's first entry at or behind it
+  int32_t* sj_lt_cmin = nullptr;
+  int32_t* sj_lt_np = nullptr;
+  int64_t* sj_lt_off = nullptr;
+  int32_t* sj_lt_tab = nullptr;
+  int64_t sj_lt_entries = 0;
+  int sj_lt_nsg = 0;
+  int sj_long_table = 1;  // use that (plan_set "sj_long_table")
   int sj_phases = 3;             // measurement only: 1 = long rows, 2 = slices
   int sj_blocks_per_cu = 0;      // 0 = what the LDS footprint allows
   int sj_xcd_group = 8;          // consecutive blocks per XCD (0 = off)

@@ -1664,6 +1664,9 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
   } else if (!strcmp(key, "sj_long_panels")) {
     SPMV_REQUIRE(value == 0 || value == 1);
     plan->sj_long_panels = value;
+  } else if (!strcmp(key, "sj_long_table")) {
+    SPMV_REQUIRE(value == 0 || value == 1);
+    plan->sj_long_table = value;
   } else if (!strcmp(key, "sj_blocks_per_cu")) {
     SPMV_REQUIRE(value >= 0 && value <= kBlocksPerCU);
     plan->sj_blocks_per_cu = value;
@@ -1817,6 +1820,13 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
                  : 0;
   else if (!strcmp(key, "sj_long_panels"))
     *value = plan->sj_lenperm && plan->sj_long_sorted && plan->sj_long_panels ? 1 : 0;
+  else if (!strcmp(key, "sj_long_table"))
+    *value = plan->sj_lenperm && plan->sj_long_sorted && plan->sj_long_panels
+                     && plan->sj_lt_tab && plan->sj_long_table
+                 ? 1
+                 : 0;
+  else if (!strcmp(key, "sj_long_table_kib"))
+    *value = (int)((plan->sj_lt_entries * 4 + (int64_t)plan->sj_lt_nsg * 16) / 1024);
   else if (!strcmp(key, "sj_long_rows"))
     *value = plan->sj_lenperm ? plan->sj_nlong : 0;
   else if (!strcmp(key, "sj_wide"))
@@ -1862,7 +1872,8 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
       b += 4 * ((n + 63) / 64 * 64) + 8 * (int64_t)plan->sj_nblk
            + 4 * (int64_t)plan->sj_nblk * plan->sj_stride
            + (plan->sj_wide_alloc ? 4 : 2) * plan->sj_units * plan->sj_unit
-           + 4 * (int64_t)plan->sj_nlong + 4 * ((n + 63) / 64 + 1);
+           + 4 * (int64_t)plan->sj_nlong + 4 * ((n + 63) / 64 + 1)
+           + 4 * plan->sj_lt_entries + 16 * (int64_t)plan->sj_lt_nsg;
     if (plan->sj_val)
       b += (int64_t)plan->sj_elem * plan->sj_units * plan->sj_unit;
     if (plan->t_ptr)

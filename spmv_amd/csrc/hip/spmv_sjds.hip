@@ -442,8 +442,16 @@ __global__ __launch_bounds__(kBlock) void sj_bake_kernel(
 // rows 0.45 / 0.44 / 0.44 / 0.48 / 0.58 / 1.24 ms -- what the longer runs gain in
 // waves that end together they lose several times over in panels (the rows of
 // a workgroup are no longer neighbours); 4-wave workgroups 0.50-0.65.
+// The table-driven kernel (csr_sjds_longt_kernel) takes supergroups of 64 RS
+// rows, an 8-lane group RS of them: the runs are its supergroups.
+#ifndef SJ_LT_RS
+#define SJ_LT_RS 2
+#endif
+constexpr int kSjLtRS = SJ_LT_RS;        // rows per group and supergroup
+constexpr int kSjLtRun = 64 * kSjLtRS;   // rows per supergroup
+static_assert(kSjLtRS == 1 || kSjLtRS == 2 || kSjLtRS == 4, "run = 64, 128 or 256 rows");
 #ifndef SJ_LONG_RUN_SHIFT
-#define SJ_LONG_RUN_SHIFT 6
+#define SJ_LONG_RUN_SHIFT (kSjLtRS == 1 ? 6 : kSjLtRS == 2 ? 7 : 8)
 #endif
 constexpr int kSjLongRunShift = SJ_LONG_RUN_SHIFT;
 
@@ -485,6 +493,11 @@ struct SjArgs {
   const int32_t* long_rows;
   const int32_t* colind;
   const T* values;
+  // the table-driven long-row kernel (csr_sjds_longt_kernel)
+  const int32_t* lt_cmin;
+  const int32_t* lt_np;
+  const int64_t* lt_off;
+  const int32_t* lt_tab;
 };
 
 template <typename T>
@@ -956,6 +969,289 @@ __global__ __launch_bounds__(64 * WPB) void csr_sjds_long_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// The LONG rows whose columns ascend, table-driven ("marched" through panels).
+//
+// What the kernel above spends its time on (ISA + timings):
+// the panel's staging loop ran one load at a time (load, wait, LDS write: the
+// panel size was a run-time number and the loop not unrolled); every step of
+// eight entries took a trip through LDS for the products (one store, four
+// 16-byte broadcast reads per lane) on top of the read of x; the eight rows of
+// a wave walked a panel in lockstep, the waves of a workgroup met at the
+// panel's barrier -- so a panel cost what its LONGEST row cost (row lengths
+// 200 ... 2000: about half the lanes idle); and a step the panel's end cut short
+// dropped what had been loaded past it.  Here
+//
+//   * the plan knows where every row crosses every panel boundary
+//     (sj_lt_fill_kernel: one bisection per row and boundary), so a row's
+//     range inside a panel is known before anything is loaded: loads run a
+//     trip ahead whatever the columns are, nothing is loaded twice, and `ok`
+//     is an index comparison;
+//   * an 8-lane group owns RS rows of the supergroup (64 RS rows sorted by
+//     length, dealt in serpentine order: the longest with the shortest) and
+//     walks them ONE AFTER THE OTHER inside a panel, independently of the
+//     other groups of its wave: a panel costs a group the SUM of its rows'
+//     entries there, and the sums are alike;
+//   * a lane loads FOUR consecutive entries of the trip's 32 (16-byte loads:
+//     one 256-byte piece of the values per group instead of four 64-byte
+//     ones); the row's sum travels down the group's lanes by DPP (row_shr:1):
+//     in round r lane r adds its four products to the sum it was handed, in
+//     entry order -- the reference's bits (csr_kernels.cpp:41-51), no LDS, no
+//     broadcasts (every lane executes all 32 additions; only the one holding
+//     the true sum matters);
+//   * the panel (a compile-time size) is requested in one go -- eight 16-byte
+//     loads per lane in flight -- before the barrier that frees the buffer.
+// ---------------------------------------------------------------------------
+constexpr int kSjLtMaxPanels = 64;       // wider supergroups: rows one by one
+#ifndef SJ_LT_PANEL_COLS
+#define SJ_LT_PANEL_COLS 8192
+#endif
+// columns of x per panel: 64 KiB of fp64, two workgroups per CU; a multiple of
+// the 1024 columns one round of the workgroup's 16-byte loads stages
+constexpr int kSjLtPanel = SJ_LT_PANEL_COLS;
+constexpr int kSjLtEpl = 4;               // entries per lane and trip
+constexpr int kSjLtTrip = 8 * kSjLtEpl;   // ... per group and trip
+static_assert(kSjLtTrip * 2 + 8 <= kSjLongPad, "loads past a row's end");
+static_assert(kSjLtPanel % 1024 == 0, "whole staging rounds");
+
+template <typename X, int N>
+struct __attribute__((packed, aligned(sizeof(X)))) SjPack {
+  X e[N];
+};
+
+// DPP move within rows of 16 lanes: lanes without a source keep `old`
+template <int CTRL>
+__device__ __forceinline__ double sj_dpp(double old, double src)
+{
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src),
+                                             CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src),
+                                             CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ float sj_dpp(float old, float src)
+{
+  return __int_as_float(__builtin_amdgcn_update_dpp(
+      __float_as_int(old), __float_as_int(src), CTRL, 0xF, 0xF, false));
+}
+constexpr int kDppRowShr1 = 0x111; // lane l <- lane l - 1
+constexpr int kDppRowShl7 = 0x107; // lane l <- lane l + 7
+
+template <typename T, bool DOT>
+__global__ __launch_bounds__(512, 4) void csr_sjds_longt_kernel(
+    SjArgs<T> A, T alpha, const T* __restrict__ in, T beta, T* __restrict__ out,
+    DotOut dot, int dot_slot0)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  T* s_x = reinterpret_cast<T*>(s_raw);
+  __shared__ double s_red[8];
+  constexpr int NT = 512, RS = kSjLtRS, RUN = kSjLtRun, PANEL = kSjLtPanel;
+  constexpr int EPL = kSjLtEpl, TRIP = kSjLtTrip;
+  constexpr int NST = PANEL / 2 / NT; // staging loads per lane
+  typedef T pair_t __attribute__((ext_vector_type(2)));
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l = lane & 7, g = wave * 8 + (lane >> 3);
+  double dot_acc = 0.0;
+  const int nsg = (A.nlong + RUN - 1) / RUN;
+  // contiguous runs of supergroups per workgroup, workgroups of one XCD
+  // neighbouring runs (the first nsg mod grid workgroups take one more)
+  const int g8 = gridDim.x >= 8 && (gridDim.x & 7) == 0;
+  const int chunk = g8 ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)
+                       : blockIdx.x;
+  const int per = nsg / gridDim.x, rem = nsg % gridDim.x;
+  const int sg0 = chunk * per + min(chunk, rem);
+  const int sg1 = sg0 + per + (chunk < rem ? 1 : 0);
+  const int64_t cend = (int64_t)A.num_cols;
+  for (int sg = sg0; sg < sg1; ++sg) { // uniform per workgroup
+    // the group's rows: ranks g, 127 - g, 128 + g, ... of the supergroup
+    int32_t slot[RS], row[RS];
+    bool have[RS];
+    T acc[RS];
+#pragma unroll
+    for (int j = 0; j < RS; ++j) {
+      slot[j] = 64 * j + ((j & 1) ? 63 - g : g);
+      const int li = sg * RUN + slot[j];
+      have[j] = li < A.nlong;
+      row[j] = A.long_rows[have[j] ? li : A.nlong - 1];
+      acc[j] = T(0);
+    }
+    const int np = A.lt_np[sg];
+    if (np == 0) { // a supergroup whose rows are not neighbours in x: rare, slow
+      if (l == 0) {
+#pragma unroll
+        for (int j = 0; j < RS; ++j)
+          if (have[j]) {
+            const int64_t a = A.rowptr[row[j]], b = A.rowptr[row[j] + 1];
+            T sum = T(0);
+            for (int64_t i = a; i < b; ++i)
+              sum += A.values[i] * in[A.colind[i]];
+            acc[j] = sum;
+          }
+      }
+    } else {
+      const int32_t cmin = A.lt_cmin[sg];
+      const int32_t* tab = A.lt_tab + A.lt_off[sg];
+      int32_t lo[RS], hi[RS];
+#pragma unroll
+      for (int j = 0; j < RS; ++j) {
+        lo[j] = tab[slot[j]];
+        hi[j] = tab[RUN + slot[j]];
+      }
+      for (int p = 0; p < np; ++p) {
+        const int32_t p0 = cmin + p * PANEL; // (<= the supergroup's last column)
+        // the boundary behind the next panel: back by the time it is needed
+        int32_t hin[RS];
+        {
+          const int pn = p + 2 <= np ? p + 2 : np;
+#pragma unroll
+          for (int j = 0; j < RS; ++j)
+            hin[j] = tab[(int64_t)pn * RUN + slot[j]];
+        }
+        // the group's trips in this panel: row 0's range, then row 1's, ...
+        // state = (row j, first entry pos, the range's end); j == RS: done
+        auto settle = [&](int& j, int32_t& pos, int32_t& end) {
+#pragma unroll
+          for (int q = 0; q < RS; ++q) {
+            const bool ex = pos >= end && j < RS;
+            j += ex ? 1 : 0;
+            int32_t nl = 0, nh = 0;
+#pragma unroll
+            for (int r = 1; r < RS; ++r) {
+              nl = j == r ? lo[r] : nl;
+              nh = j == r ? hi[r] : nh;
+            }
+            pos = ex ? nl : pos;
+            end = ex ? nh : end;
+          }
+        };
+        SjPack<T, EPL> vA, vB;
+        SjPack<int32_t, EPL> cA, cB;
+        auto issue = [&](SjPack<T, EPL>& v, SjPack<int32_t, EPL>& c, int32_t pos) {
+          // (no clamp: a long row ends kSjLongPad entries before the arrays do;
+          // a finished group reads entries 0 ...)
+          const int64_t e = (int64_t)pos + EPL * l;
+          v = *reinterpret_cast<const SjPack<T, EPL>*>(A.values + e);
+          c = *reinterpret_cast<const SjPack<int32_t, EPL>*>(A.colind + e);
+        };
+        auto consume = [&](const SjPack<T, EPL>& v, const SjPack<int32_t, EPL>& c,
+                           int j, int32_t pos, int32_t end) {
+          T pr[EPL], xs[EPL];
+#pragma unroll
+          for (int k = 0; k < EPL; ++k) {
+            const bool ok = pos + EPL * l + k < end;
+            xs[k] = s_x[ok ? c.e[k] - p0 : 0];
+          }
+          // (every LDS read is wanted whatever `ok` says: left to itself the
+          // compiler moves each read under its own test, and every join waits
+          // for everything in flight)
+          static_assert(EPL == 4, "four operands below");
+          asm volatile("" ::"v"(xs[0]), "v"(xs[1]), "v"(xs[2]), "v"(xs[3]));
+#pragma unroll
+          for (int k = 0; k < EPL; ++k) {
+            const bool ok = pos + EPL * l + k < end;
+            // a lane without an entry contributes +0.0: the sum starts at +0.0
+            // and can never become -0.0, so adding it changes no bit
+            const T prod = v.e[k] * xs[k];
+            pr[k] = ok ? prod : T(0);
+          }
+          T tsum = acc[0];
+#pragma unroll
+          for (int r = 1; r < RS; ++r)
+            tsum = j == r ? acc[r] : tsum;
+          // the sum walks down the group's lanes: in round r lane r holds it
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            T s = tsum;
+#pragma unroll
+            for (int k = 0; k < EPL; ++k)
+              s += pr[k];
+            tsum = r < 7 ? sj_dpp<kDppRowShr1>(s, s) : sj_dpp<kDppRowShl7>(s, s);
+          }
+          // (lane 0 of the group has it; the others' copies are never used)
+#pragma unroll
+          for (int r = 0; r < RS; ++r)
+            acc[r] = j == r ? tsum : acc[r];
+        };
+        int jc = 0;
+        int32_t posc = lo[0], endc = hi[0];
+        settle(jc, posc, endc);
+        issue(vA, cA, posc);
+        int jn = jc;
+        int32_t posn = posc + TRIP, endn = endc;
+        settle(jn, posn, endn);
+        // the panel: every load in flight before the barrier that frees the buffer
+        pair_t xv[NST];
+#pragma unroll
+        for (int m = 0; m < NST; ++m) {
+          const int q = 2 * t + 2 * NT * m;
+          const int64_t col = (int64_t)p0 + q;
+          // (an odd number of columns: the last one comes as the second element
+          // of the pair in front of it -- no branch around a load)
+          const SjPack<T, 2> ld = *reinterpret_cast<const SjPack<T, 2>*>(
+              in + (col < cend - 2 ? col : cend - 2));
+          xv[m][0] = col == cend - 1 ? ld.e[1] : ld.e[0];
+          xv[m][1] = ld.e[1];
+        }
+        __syncthreads(); // everybody is done with the previous panel
+#pragma unroll
+        for (int m = 0; m < NST; ++m)
+          *reinterpret_cast<pair_t*>(&s_x[2 * t + 2 * NT * m]) = xv[m];
+        __syncthreads();
+        while (__any(jc < RS)) {
+          issue(vB, cB, posn);
+          consume(vA, cA, jc, posc, endc);
+          jc = jn, posc = posn, endc = endn;
+          posn += TRIP;
+          settle(jn, posn, endn);
+          if (!__any(jc < RS))
+            break;
+          issue(vA, cA, posn);
+          consume(vB, cB, jc, posc, endc);
+          jc = jn, posc = posn, endc = endn;
+          posn += TRIP;
+          settle(jn, posn, endn);
+        }
+#pragma unroll
+        for (int j = 0; j < RS; ++j) {
+          lo[j] = hi[j];
+          hi[j] = hin[j];
+        }
+      }
+    }
+    if (l == 0) {
+#pragma unroll
+      for (int j = 0; j < RS; ++j)
+        if (have[j]) {
+          const T c = alpha * acc[j];
+          T y = c;
+          if (beta != T(0))
+            y = c + beta * out[row[j]];
+          out[row[j]] = y;
+          if constexpr (DOT)
+            dot_acc += (double)in[row[j]] * (double)c;
+        }
+    }
+  }
+  if constexpr (DOT) {
+    double v = dot_acc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+      v += __shfl_down(v, o, 64);
+    if (lane == 0)
+      s_red[wave] = v;
+    __syncthreads();
+    if (t == 0) {
+      double r = 0.0;
+#pragma unroll
+      for (int w = 0; w < 8; ++w)
+        r += s_red[w];
+      dot.partials[dot_slot0 + blockIdx.x] = r; // behind the slices' partials
+    }
+  }
+}
+
 template <typename T, int WPB, int E, bool DOT>
 __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
     SjArgs<T> A, T alpha, const T* __restrict__ in, T beta, T* __restrict__ out,
@@ -1170,6 +1466,10 @@ int sj_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
   A.long_rows = pl->sj_long_rows;
   A.colind = pl->colind0;
   A.values = static_cast<const T*>(pl->sj_values0);
+  A.lt_cmin = pl->sj_lt_cmin;
+  A.lt_np = pl->sj_lt_np;
+  A.lt_off = pl->sj_lt_off;
+  A.lt_tab = pl->sj_lt_tab;
   const size_t lds = (size_t)pl->sj_maxk * kSjChunk * sizeof(T) + 16;
   int wgs = pl->sj_blocks_per_cu > 0 ? pl->sj_blocks_per_cu
                                      : sj_wgs_per_cu(WPB, (int64_t)lds + 64);
@@ -1193,7 +1493,34 @@ int sj_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
                        lds, st, A, alpha, in, beta, out, dot, ord);
     SPMV_CHECK_LAUNCH();
   }
-  if (pl->sj_nlong > 0 && (A.phases & 1)) {
+  if (pl->sj_nlong > 0 && (A.phases & 1) && A.long_sorted && pl->sj_lt_tab
+      && pl->sj_long_table) {
+    // the long rows by the table-driven kernel: 8-wave workgroups, two per CU,
+    // contiguous runs of supergroups; dot partials behind the slices'
+    const int nsg = pl->sj_lt_nsg;
+    const size_t llds = (size_t)kSjLtPanel * sizeof(T);
+    int lgrid = pl->ctx->num_cus * 2;
+    if (lgrid > nsg)
+      lgrid = nsg;
+    if (DOT && lgrid > pl->ctx->dot_blocks - grid)
+      lgrid = pl->ctx->dot_blocks - grid;
+    if (lgrid >= 8)
+      lgrid -= lgrid % 8;
+    if (lgrid < 1)
+      lgrid = 1;
+    if (llds > 48 * 1024) { // more dynamic LDS than a launch gets by default
+      static bool raised = false;
+      if (!raised) {
+        SPMV_CHECK_HIP(hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&csr_sjds_longt_kernel<T, DOT>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds));
+        raised = true;
+      }
+    }
+    hipLaunchKernelGGL((csr_sjds_longt_kernel<T, DOT>), dim3(lgrid), dim3(512), llds,
+                       st, A, alpha, in, beta, out, dot, (A.phases & 2) ? grid : 0);
+    SPMV_CHECK_LAUNCH();
+  } else if (pl->sj_nlong > 0 && (A.phases & 1)) {
     // the long rows: 8-wave workgroups, 64 rows each; their dot
     // partials go behind the slices' (whose kernel cleared the array's tail)
 #ifndef SJ_LONG_WAVES
@@ -1413,6 +1740,165 @@ int sj_build_long_list(spmv_hip_csr_plan* pl, const int32_t* rowptr,
   return SPMV_HIP_OK;
 }
 
+
+// --- the table of the table-driven long-row kernel --------------------------
+// per supergroup (run of kSjLtRun long rows): the columns it spans -> its first
+// column (a multiple of 16), its number of panels (0: more than
+// kSjLtMaxPanels, the rows are not neighbours in x) and its table entries
+__global__ __launch_bounds__(kBlock) void sj_lt_span_kernel(
+    int nlong, int nsg, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ colind, const int32_t* __restrict__ rows,
+    int32_t* __restrict__ cmin_out, int32_t* __restrict__ np_out,
+    int64_t* __restrict__ cnt_out)
+{
+  const int lane = threadIdx.x & 63;
+  const int wid = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int nw = (gridDim.x * kBlock) >> 6;
+  for (int sg = wid; sg < nsg; sg += nw) {
+    int32_t mn = INT32_MAX, mx = -1;
+    for (int s = lane; s < kSjLtRun; s += 64) {
+      const int li = sg * kSjLtRun + s;
+      if (li < nlong) {
+        const int32_t a = rowptr[rows[li]], b = rowptr[rows[li] + 1];
+        if (b > a) {
+          mn = min(mn, colind[a]);
+          mx = max(mx, colind[b - 1]);
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mn = min(mn, __shfl_xor(mn, o, 64));
+      mx = max(mx, __shfl_xor(mx, o, 64));
+    }
+    if (lane == 0) {
+      int32_t cmin = 0, np = 0;
+      if (mx >= 0) {
+        cmin = mn & ~(kSjChunk - 1);
+        const int64_t n = ((int64_t)mx - cmin) / kSjLtPanel + 1;
+        np = n <= kSjLtMaxPanels ? (int32_t)n : 0;
+      }
+      cmin_out[sg] = cmin;
+      np_out[sg] = np;
+      cnt_out[sg] = np ? (int64_t)(np + 1) * kSjLtRun : 0;
+    }
+    if (sg == 0 && lane == 0)
+      cnt_out[nsg] = 0;
+  }
+}
+
+// per row (slot of its supergroup) and panel boundary p = 0 ... np: the row's
+// first entry whose column is >= cmin + p * panel (p = 0: the row's first
+// entry; p = np: its end); slots past the list: empty ranges
+__global__ __launch_bounds__(kBlock) void sj_lt_fill_kernel(
+    int nlong, int nsg, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ colind, const int32_t* __restrict__ rows,
+    const int32_t* __restrict__ cmin_in, const int32_t* __restrict__ np_in,
+    const int64_t* __restrict__ off, int32_t* __restrict__ tab)
+{
+  for (int sg = blockIdx.x; sg < nsg; sg += gridDim.x) {
+    const int np = np_in[sg];
+    if (np == 0)
+      continue;
+    const int32_t cmin = cmin_in[sg];
+    int32_t* out = tab + off[sg];
+    for (int idx = threadIdx.x; idx < (np + 1) * kSjLtRun; idx += kBlock) {
+      const int p = idx / kSjLtRun, s = idx % kSjLtRun;
+      const int li = sg * kSjLtRun + s;
+      int32_t res = 0;
+      if (li < nlong) {
+        const int32_t a = rowptr[rows[li]], b = rowptr[rows[li] + 1];
+        if (p == 0) {
+          res = a;
+        } else if (p == np) {
+          res = b;
+        } else {
+          const int64_t target = (int64_t)cmin + (int64_t)p * kSjLtPanel;
+          int32_t x = a, y = b; // first entry in [a, b) with colind >= target
+          while (x < y) {
+            const int32_t mid = x + ((y - x) >> 1);
+            if ((int64_t)colind[mid] < target)
+              x = mid + 1;
+            else
+              y = mid;
+          }
+          res = x;
+        }
+      }
+      out[idx] = res;
+    }
+  }
+}
+
+void sj_lt_free(spmv_hip_csr_plan* pl)
+{
+  (void)hipFree(pl->sj_lt_cmin);
+  (void)hipFree(pl->sj_lt_np);
+  (void)hipFree(pl->sj_lt_off);
+  (void)hipFree(pl->sj_lt_tab);
+  pl->sj_lt_cmin = pl->sj_lt_np = pl->sj_lt_tab = nullptr;
+  pl->sj_lt_off = nullptr;
+  pl->sj_lt_entries = 0;
+  pl->sj_lt_nsg = 0;
+}
+
+// (no memory: the plan stays without the table and the older kernel runs)
+int sj_build_long_table(spmv_hip_csr_plan* pl, const int32_t* rowptr,
+                        const int32_t* colind, hipStream_t st)
+{
+  const int nlong = pl->sj_nlong;
+  if (nlong <= 0 || !pl->sj_long_sorted)
+    return SPMV_HIP_OK;
+  const int nsg = (nlong + kSjLtRun - 1) / kSjLtRun;
+  void* tmp = nullptr;
+  size_t tb = 0;
+  int64_t total = 0;
+  hipError_t e = hipMalloc(&pl->sj_lt_cmin, sizeof(int32_t) * (size_t)nsg);
+  if (e == hipSuccess)
+    e = hipMalloc(&pl->sj_lt_np, sizeof(int32_t) * (size_t)nsg);
+  if (e == hipSuccess)
+    e = hipMalloc(&pl->sj_lt_off, sizeof(int64_t) * (size_t)(nsg + 1));
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(sj_lt_span_kernel, dim3(spmv_grid_for(pl->ctx, nsg, kBlock / 64)),
+                       dim3(kBlock), 0, st, nlong, nsg, rowptr, colind,
+                       pl->sj_long_rows, pl->sj_lt_cmin, pl->sj_lt_np, pl->sj_lt_off);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess)
+    e = hipcub::DeviceScan::ExclusiveSum(nullptr, tb, pl->sj_lt_off, pl->sj_lt_off,
+                                         nsg + 1, st);
+  if (e == hipSuccess)
+    e = hipMalloc(&tmp, tb ? tb : 16);
+  if (e == hipSuccess)
+    e = hipcub::DeviceScan::ExclusiveSum(tmp, tb, pl->sj_lt_off, pl->sj_lt_off,
+                                         nsg + 1, st);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(&total, pl->sj_lt_off + nsg, sizeof(int64_t),
+                       hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st);
+  (void)hipFree(tmp);
+  if (e == hipSuccess)
+    e = hipMalloc(&pl->sj_lt_tab, sizeof(int32_t) * (size_t)(total > 0 ? total : 1));
+  if (e == hipSuccess && total > 0) {
+    hipLaunchKernelGGL(sj_lt_fill_kernel, dim3(spmv_grid_for(pl->ctx, nsg, 1)),
+                       dim3(kBlock), 0, st, nlong, nsg, rowptr, colind,
+                       pl->sj_long_rows, pl->sj_lt_cmin, pl->sj_lt_np, pl->sj_lt_off,
+                       pl->sj_lt_tab);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st);
+  if (e != hipSuccess) {
+    sj_lt_free(pl);
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? SPMV_HIP_OK : static_cast<int>(e);
+  }
+  pl->sj_lt_entries = total;
+  pl->sj_lt_nsg = nsg;
+  return SPMV_HIP_OK;
+}
+
 template <typename T>
 int sj_bake(spmv_hip_csr_plan* pl, const T* values, hipStream_t st)
 {
@@ -1474,6 +1960,7 @@ void spmv_sjds_free(spmv_hip_csr_plan* pl)
   (void)hipFree(pl->sj_val);
   (void)hipFree(pl->sj_long_rows);
   (void)hipFree(pl->sj_ubase);
+  sj_lt_free(pl);
   pl->sj_ubase = nullptr;
   pl->sj_long_rows = nullptr;
   pl->sj_nlong = 0;
@@ -1662,6 +2149,11 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
     if (rc != SPMV_HIP_OK) {
       spmv_sjds_free(pl);
       return rc == SPMV_HIP_ENOMEM ? SPMV_HIP_OK : rc;
+    }
+    const int rc2 = sj_build_long_table(pl, rowptr, colind, st);
+    if (rc2 != SPMV_HIP_OK) {
+      spmv_sjds_free(pl);
+      return rc2;
     }
   }
   pl->sj_long_thr = thr;

@@ -718,6 +718,112 @@ def test_sliced_jagged_form_bit_exact(sj_ctx, wpb, unit):
     blk.free()
 
 
+def _long_row_matrix(rng, nr, nc, long_rows, short_avg=6):
+    """Short random rows plus the given long rows (row -> sorted, strictly
+    ascending column array)."""
+    lens = rng.integers(1, 2 * short_avg, nr)
+    for r, cols in long_rows.items():
+        lens[r] = len(cols)
+    rp = np.zeros(nr + 1, np.int64)
+    np.cumsum(lens, out=rp[1:])
+    ci = np.empty(rp[-1], np.int32)
+    for r in range(nr):
+        if r in long_rows:
+            ci[rp[r]:rp[r + 1]] = long_rows[r]
+        else:
+            lo = max(0, min(nc - 64, r - 32))
+            ci[rp[r]:rp[r + 1]] = np.sort(rng.choice(
+                np.arange(lo, min(nc, lo + 64)), lens[r], replace=False))
+    va = rng.uniform(-1, 1, rp[-1])
+    return rp.astype(np.int32), ci, va
+
+
+def test_long_rows_table_kernel_bit_exact(sj_ctx):
+    """csr_sjds_longt_kernel (long rows with ascending columns, marched through
+    LDS panels of x by the plan's table of panel crossings) against
+    oracle.csr_spmv (csr_kernels.cpp:41-51), every element identical; the same
+    rows by the older panel kernel (sj_long_table = 0) and gathered
+    (sj_long_panels = 0).  Cases: rows spanning several panels in supergroups
+    of neighbours (the benchmark's tail, scaled down), a partial last
+    supergroup, fewer long rows than one group, rows that are NOT neighbours
+    (more than 64 panels: the rows go one by one), an odd number of columns
+    with long rows that end at the last one, ranges that end a panel exactly at
+    its boundary, alpha / beta, the fused dot, fp32."""
+    ctx = sj_ctx
+    rng = np.random.default_rng(0x10C6)
+    cases = {}
+    # the benchmark's tail, scaled down: 1200 long rows of 100 ... 2000 entries,
+    # one per 16 columns (up to 32,000 columns: four panels of 8192)
+    cases["tail"] = poisson.fem_like_csr(40_000, jitter=64, layer=1200,
+                                         tail_permille=30, tail_min=100,
+                                         tail_max=2000, tail_stride=16)
+    # 200 long rows: one full supergroup of 128 and a partial one
+    cases["tail_partial"] = poisson.fem_like_csr(20_001, jitter=64, layer=700,
+                                                 tail_permille=10, tail_min=300,
+                                                 tail_max=1200, tail_stride=16)
+    # three long rows only; one of them ends at the last (odd) column, one has
+    # an entry at every column of a panel boundary's neighbourhood
+    nc = 30_001
+    cases["few"] = _long_row_matrix(rng, 3000, nc, {
+        5: np.arange(0, 20_000, 7, dtype=np.int32),
+        1500: np.arange(nc - 2500, nc, dtype=np.int32),
+        2900: np.concatenate([np.arange(8192 - 200, 8192 + 200),
+                              np.arange(16_384 - 1, 16_384 + 130)]).astype(np.int32)})
+    # long rows that are not neighbours in x: columns over 3 M (> 64 panels)
+    nc_far = 3_000_001
+    far = {r: np.sort(rng.choice(nc_far, 400 + 37 * k, replace=False)).astype(np.int32)
+           for k, r in enumerate(range(100, 2000, 190))}
+    far[1990] = np.arange(nc_far - 300, nc_far, dtype=np.int32)
+    cases["not_neighbours"] = _long_row_matrix(rng, 2000, nc_far, far)
+    part = ctx.empty(ctx.dot_partials_len, np.float64)
+    for name, (rp, ci, va) in cases.items():
+        nr = len(rp) - 1
+        ncols = {"few": nc, "not_neighbours": nc_far}.get(name, nr)
+        x = rng.uniform(-1, 1, ncols)
+        y0 = rng.uniform(-1, 1, nr)
+        blk = hip.CsrBlock(ctx, nr, ncols, rp, ci, va, None, False)
+        blk.bake()
+        assert blk.get("sjds") == 1, name
+        assert blk.get("sj_long_rows") >= 3, name
+        assert blk.get("sj_long_panels") == 1 and blk.get("sj_long_table") == 1, name
+        dx = ctx.upload(x)
+        for alpha, beta in ((1.0, 0.0), (-0.75, 0.0), (2.5, -0.5)):
+            y_ref = oracle.csr_spmv(rp, ci, va, x, alpha, beta, y0)
+            for knobs in (dict(sj_long_table=1), dict(sj_long_table=0),
+                          dict(sj_long_panels=0)):
+                for k, v in knobs.items():
+                    blk.set(k, v)
+                dy = ctx.upload(np.full(nr, np.nan) if beta == 0 else y0)
+                dot = beta == 0 and nr == ncols
+                blk.mult(alpha, dx.ptr, beta, dy.ptr,
+                         dot_partials=part.ptr if dot else None)
+                assert np.array_equal(dy.numpy(), y_ref), (name, knobs, alpha)
+                if dot:
+                    want = float(np.dot(x, alpha * oracle.csr_spmv(rp, ci, va, x)))
+                    got = float(np.sum(part.numpy()))
+                    assert abs(got - want) <= 1e-11 * (np.abs(x) @ np.abs(y_ref) + 1)
+                dy.free()
+                blk.set("sj_long_panels", 1)
+                blk.set("sj_long_table", 1)
+        dx.free()
+        blk.free()
+    part.free()
+    # fp32
+    rp, ci, va = cases["tail_partial"]
+    nr = len(rp) - 1
+    va32 = va.astype(np.float32)
+    x32 = rng.uniform(-1, 1, nr).astype(np.float32)
+    blk = hip.CsrBlock(ctx, nr, nr, rp, ci, va32, None, False, dtype=np.float32)
+    blk.bake()
+    assert blk.get("sjds") == 1 and blk.get("sj_long_table") == 1
+    dx, dy = ctx.upload(x32), ctx.upload(np.full(nr, np.nan, np.float32))
+    blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+    assert np.array_equal(dy.numpy(), oracle.csr_spmv(rp, ci, va32, x32))
+    for b in (dx, dy):
+        b.free()
+    blk.free()
+
+
 def test_plan_values_changed_after_updates_in_place():
     """spmv_hip_csr_plan_values_changed: a caller that keeps the sparsity and
     rewrites the coefficients IN PLACE (time stepping) -- three updates on every
