@@ -443,15 +443,21 @@ __global__ __launch_bounds__(kBlock) void sj_bake_kernel(
 // waves that end together they lose several times over in panels (the rows of
 // a workgroup are no longer neighbours); 4-wave workgroups 0.50-0.65.
 // The table-driven kernel (csr_sjds_longt_kernel) takes supergroups of 64 RS
-// rows, an 8-lane group RS of them: the runs are its supergroups.
+// rows, an 8-lane group RS of them (RS = 1: see the measurements there): the
+// runs are its supergroups.
 #ifndef SJ_LT_RS
-#define SJ_LT_RS 2
+#define SJ_LT_RS 1
 #endif
+#ifndef SJ_LT_G
+#define SJ_LT_G 8
+#endif
+#define SJ_LT_G_ SJ_LT_G
 constexpr int kSjLtRS = SJ_LT_RS;        // rows per group and supergroup
-constexpr int kSjLtRun = 64 * kSjLtRS;   // rows per supergroup
-static_assert(kSjLtRS == 1 || kSjLtRS == 2 || kSjLtRS == 4, "run = 64, 128 or 256 rows");
+constexpr int kSjLtRun = 512 / SJ_LT_G_ * kSjLtRS; // rows per supergroup
+static_assert(kSjLtRun == 64 || kSjLtRun == 128 || kSjLtRun == 256 || kSjLtRun == 512,
+              "runs of 64 ... 512 rows");
 #ifndef SJ_LONG_RUN_SHIFT
-#define SJ_LONG_RUN_SHIFT (kSjLtRS == 1 ? 6 : kSjLtRS == 2 ? 7 : 8)
+#define SJ_LONG_RUN_SHIFT (kSjLtRun == 64 ? 6 : kSjLtRun == 128 ? 7 : kSjLtRun == 256 ? 8 : 9)
 #endif
 constexpr int kSjLongRunShift = SJ_LONG_RUN_SHIFT;
 
@@ -973,14 +979,11 @@ __global__ __launch_bounds__(64 * WPB) void csr_sjds_long_kernel(
 // ---------------------------------------------------------------------------
 // The LONG rows whose columns ascend, table-driven ("marched" through panels).
 //
-// What the kernel above spends its time on (ISA + timings):
-// the panel's staging loop ran one load at a time (load, wait, LDS write: the
-// panel size was a run-time number and the loop not unrolled); every step of
-// eight entries took a trip through LDS for the products (one store, four
-// 16-byte broadcast reads per lane) on top of the read of x; the eight rows of
-// a wave walked a panel in lockstep, the waves of a workgroup met at the
-// panel's barrier -- so a panel cost what its LONGEST row cost (row lengths
-// 200 ... 2000: about half the lanes idle); and a step the panel's end cut short
+// What the kernel above spends its time on (ISA + timings): the panel's staging
+// loop ran one load at a time (load, wait, LDS write: the panel size was a
+// run-time number and the loop not unrolled); every step of eight entries took
+// a trip through LDS for the products (one store, four 16-byte broadcast reads
+// per lane) on top of the read of x; and a step the panel's end cut short
 // dropped what had been loaded past it.  Here
 //
 //   * the plan knows where every row crosses every panel boundary
@@ -988,20 +991,33 @@ __global__ __launch_bounds__(64 * WPB) void csr_sjds_long_kernel(
 //     range inside a panel is known before anything is loaded: loads run a
 //     trip ahead whatever the columns are, nothing is loaded twice, and `ok`
 //     is an index comparison;
-//   * an 8-lane group owns RS rows of the supergroup (64 RS rows sorted by
-//     length, dealt in serpentine order: the longest with the shortest) and
-//     walks them ONE AFTER THE OTHER inside a panel, independently of the
-//     other groups of its wave: a panel costs a group the SUM of its rows'
-//     entries there, and the sums are alike;
 //   * a lane loads FOUR consecutive entries of the trip's 32 (16-byte loads:
-//     one 256-byte piece of the values per group instead of four 64-byte
-//     ones); the row's sum travels down the group's lanes by DPP (row_shr:1):
+//     one 256-byte piece of the values per row instead of four 64-byte ones);
+//     the row's sum travels down the group's eight lanes by DPP (row_shr:1):
 //     in round r lane r adds its four products to the sum it was handed, in
 //     entry order -- the reference's bits (csr_kernels.cpp:41-51), no LDS, no
 //     broadcasts (every lane executes all 32 additions; only the one holding
 //     the true sum matters);
 //   * the panel (a compile-time size) is requested in one go -- eight 16-byte
 //     loads per lane in flight -- before the barrier that frees the buffer.
+//
+// Measured on the 1 % tail of the benchmark's matrix (110 M entries in 100 k
+// rows; same box, alternating builds; the older kernel 0.447 ms):
+//   rows per 8-lane group, walked one after the other inside a panel and dealt
+//   in serpentine order (SJ_LT_RS)             1 / 2 / 4: 0.352 / 0.375 / 0.534 ms
+//   lanes per row x entries per lane (SJ_LT_G x SJ_LT_EPL)
+//                      8 x 4 / 8 x 8 / 4 x 8 / 4 x 4 / 2 x 8: 0.343 / 0.356 /
+//                                                        0.415 / 0.414 / 0.69
+//   trips of loads in flight (SJ_LT_DEPTH)                   1 / 2: 0.375 / 0.376
+//   supergroups from an atomic queue instead of static runs: 0.367 against 0.355
+//   the matrix loaded non-temporally (nt):                   0.458 against 0.352
+// -- whatever makes a supergroup wider (more rows: more panels, more staged x)
+// loses.  A build with clocks in it (SJ_LT_PROBE) shows where the time goes:
+// 1.03 us per trip of a wave whether its neighbours are busy or idle, 0.34 us
+// with the loads of the matrix taken out (SJ_LT_PROBE_NOLOAD; without the
+// additions or without the LDS reads: within 10 %); workgroups with three and
+// with four supergroups end together.  The kernel is bound by the stream of
+// the matrix: 1.32 GB of values and columns + 0.5 GB of panels in 0.33-0.35 ms.
 // ---------------------------------------------------------------------------
 constexpr int kSjLtMaxPanels = 64;       // wider supergroups: rows one by one
 #ifndef SJ_LT_PANEL_COLS
@@ -1010,9 +1026,20 @@ constexpr int kSjLtMaxPanels = 64;       // wider supergroups: rows one by one
 // columns of x per panel: 64 KiB of fp64, two workgroups per CU; a multiple of
 // the 1024 columns one round of the workgroup's 16-byte loads stages
 constexpr int kSjLtPanel = SJ_LT_PANEL_COLS;
-constexpr int kSjLtEpl = 4;               // entries per lane and trip
-constexpr int kSjLtTrip = 8 * kSjLtEpl;   // ... per group and trip
-static_assert(kSjLtTrip * 2 + 8 <= kSjLongPad, "loads past a row's end");
+#ifndef SJ_LT_G
+#define SJ_LT_G 8
+#endif
+#ifndef SJ_LT_EPL
+#define SJ_LT_EPL 4
+#endif
+constexpr int kSjLtG = SJ_LT_G;           // lanes per row (a power of two <= 16)
+constexpr int kSjLtEpl = SJ_LT_EPL;       // entries per lane and trip (4 or 8)
+#ifndef SJ_LT_DEPTH
+#define SJ_LT_DEPTH 1
+#endif
+constexpr int kSjLtDepth = SJ_LT_DEPTH;   // trips of loads in flight ahead
+constexpr int kSjLtTrip = kSjLtG * kSjLtEpl; // ... per group and trip
+static_assert(kSjLtTrip * (kSjLtDepth + 1) + 8 <= kSjLongPad, "loads past a row's end");
 static_assert(kSjLtPanel % 1024 == 0, "whole staging rounds");
 
 template <typename X, int N>
@@ -1037,7 +1064,8 @@ __device__ __forceinline__ float sj_dpp(float old, float src)
       __float_as_int(old), __float_as_int(src), CTRL, 0xF, 0xF, false));
 }
 constexpr int kDppRowShr1 = 0x111; // lane l <- lane l - 1
-constexpr int kDppRowShl7 = 0x107; // lane l <- lane l + 7
+constexpr int kDppRowShlBack = 0x100 + kSjLtG - 1; // lane l <- lane l + G - 1
+static_assert(kSjLtG == 2 || kSjLtG == 4 || kSjLtG == 8 || kSjLtG == 16, "DPP rows");
 
 template <typename T, bool DOT>
 __global__ __launch_bounds__(512, 4) void csr_sjds_longt_kernel(
@@ -1052,7 +1080,8 @@ __global__ __launch_bounds__(512, 4) void csr_sjds_longt_kernel(
   constexpr int NST = PANEL / 2 / NT; // staging loads per lane
   typedef T pair_t __attribute__((ext_vector_type(2)));
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int l = lane & 7, g = wave * 8 + (lane >> 3);
+  constexpr int G = kSjLtG, NG = 512 / G; // lanes per row, groups per workgroup
+  const int l = lane & (G - 1), g = wave * (64 / G) + lane / G;
   double dot_acc = 0.0;
   const int nsg = (A.nlong + RUN - 1) / RUN;
   // contiguous runs of supergroups per workgroup, workgroups of one XCD
@@ -1064,14 +1093,18 @@ __global__ __launch_bounds__(512, 4) void csr_sjds_longt_kernel(
   const int sg0 = chunk * per + min(chunk, rem);
   const int sg1 = sg0 + per + (chunk < rem ? 1 : 0);
   const int64_t cend = (int64_t)A.num_cols;
+#ifdef SJ_LT_PROBE
+  long long pr_stage = 0, pr_loop = 0, pr_trips = 0, pr_panels = 0;
+  const long long pr_begin = wall_clock64();
+#endif
   for (int sg = sg0; sg < sg1; ++sg) { // uniform per workgroup
-    // the group's rows: ranks g, 127 - g, 128 + g, ... of the supergroup
+    // the group's rows: rank g of the supergroup (RS > 1: g, 2 NG - 1 - g, ...)
     int32_t slot[RS], row[RS];
     bool have[RS];
     T acc[RS];
 #pragma unroll
     for (int j = 0; j < RS; ++j) {
-      slot[j] = 64 * j + ((j & 1) ? 63 - g : g);
+      slot[j] = NG * j + ((j & 1) ? NG - 1 - g : g);
       const int li = sg * RUN + slot[j];
       have[j] = li < A.nlong;
       row[j] = A.long_rows[have[j] ? li : A.nlong - 1];
@@ -1126,12 +1159,19 @@ __global__ __launch_bounds__(512, 4) void csr_sjds_longt_kernel(
             end = ex ? nh : end;
           }
         };
-        SjPack<T, EPL> vA, vB;
-        SjPack<int32_t, EPL> cA, cB;
+        // D trips of loads in flight ahead of the one being consumed: a ring of
+        // D + 1 register sets, the loop unrolled over it
+        constexpr int D = kSjLtDepth;
+        SjPack<T, EPL> vv[D + 1];
+        SjPack<int32_t, EPL> cc[D + 1];
         auto issue = [&](SjPack<T, EPL>& v, SjPack<int32_t, EPL>& c, int32_t pos) {
           // (no clamp: a long row ends kSjLongPad entries before the arrays do;
           // a finished group reads entries 0 ...)
+#ifdef SJ_LT_PROBE_NOLOAD
+          const int64_t e = EPL * l + (pos & 1);
+#else
           const int64_t e = (int64_t)pos + EPL * l;
+#endif
           v = *reinterpret_cast<const SjPack<T, EPL>*>(A.values + e);
           c = *reinterpret_cast<const SjPack<int32_t, EPL>*>(A.colind + e);
         };
@@ -1141,13 +1181,20 @@ __global__ __launch_bounds__(512, 4) void csr_sjds_longt_kernel(
 #pragma unroll
           for (int k = 0; k < EPL; ++k) {
             const bool ok = pos + EPL * l + k < end;
+#ifdef SJ_LT_PROBE_NOLDS
+            xs[k] = (T)(ok ? c.e[k] - p0 : 0);
+#else
             xs[k] = s_x[ok ? c.e[k] - p0 : 0];
+#endif
           }
           // (every LDS read is wanted whatever `ok` says: left to itself the
           // compiler moves each read under its own test, and every join waits
           // for everything in flight)
-          static_assert(EPL == 4, "four operands below");
+          static_assert(EPL == 4 || EPL == 8, "the operands below");
           asm volatile("" ::"v"(xs[0]), "v"(xs[1]), "v"(xs[2]), "v"(xs[3]));
+          if constexpr (EPL == 8)
+            asm volatile("" ::"v"(xs[4 % EPL]), "v"(xs[5 % EPL]), "v"(xs[6 % EPL]),
+                         "v"(xs[7 % EPL]));
 #pragma unroll
           for (int k = 0; k < EPL; ++k) {
             const bool ok = pos + EPL * l + k < end;
@@ -1161,26 +1208,38 @@ __global__ __launch_bounds__(512, 4) void csr_sjds_longt_kernel(
           for (int r = 1; r < RS; ++r)
             tsum = j == r ? acc[r] : tsum;
           // the sum walks down the group's lanes: in round r lane r holds it
+#ifdef SJ_LT_PROBE_NOCHAIN
+          tsum += (pr[0] + pr[1]) + (pr[2] + pr[3]);
+#else
 #pragma unroll
-          for (int r = 0; r < 8; ++r) {
+          for (int r = 0; r < G; ++r) {
             T s = tsum;
 #pragma unroll
             for (int k = 0; k < EPL; ++k)
               s += pr[k];
-            tsum = r < 7 ? sj_dpp<kDppRowShr1>(s, s) : sj_dpp<kDppRowShl7>(s, s);
+            tsum = r < G - 1 ? sj_dpp<kDppRowShr1>(s, s) : sj_dpp<kDppRowShlBack>(s, s);
           }
+#endif
           // (lane 0 of the group has it; the others' copies are never used)
 #pragma unroll
           for (int r = 0; r < RS; ++r)
             acc[r] = j == r ? tsum : acc[r];
         };
-        int jc = 0;
-        int32_t posc = lo[0], endc = hi[0];
-        settle(jc, posc, endc);
-        issue(vA, cA, posc);
-        int jn = jc;
-        int32_t posn = posc + TRIP, endn = endc;
-        settle(jn, posn, endn);
+        int jq[D + 1];
+        int32_t posq[D + 1], endq[D + 1];
+        jq[0] = 0, posq[0] = lo[0], endq[0] = hi[0];
+        settle(jq[0], posq[0], endq[0]);
+#pragma unroll
+        for (int d = 1; d <= D; ++d) {
+          jq[d] = jq[d - 1], posq[d] = posq[d - 1] + TRIP, endq[d] = endq[d - 1];
+          settle(jq[d], posq[d], endq[d]);
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+          issue(vv[d], cc[d], posq[d]);
+#ifdef SJ_LT_PROBE
+        const long long pc0 = wall_clock64();
+#endif
         // the panel: every load in flight before the barrier that frees the buffer
         pair_t xv[NST];
 #pragma unroll
@@ -1199,20 +1258,35 @@ __global__ __launch_bounds__(512, 4) void csr_sjds_longt_kernel(
         for (int m = 0; m < NST; ++m)
           *reinterpret_cast<pair_t*>(&s_x[2 * t + 2 * NT * m]) = xv[m];
         __syncthreads();
-        while (__any(jc < RS)) {
-          issue(vB, cB, posn);
-          consume(vA, cA, jc, posc, endc);
-          jc = jn, posc = posn, endc = endn;
-          posn += TRIP;
-          settle(jn, posn, endn);
-          if (!__any(jc < RS))
-            break;
-          issue(vA, cA, posn);
-          consume(vB, cB, jc, posc, endc);
-          jc = jn, posc = posn, endc = endn;
-          posn += TRIP;
-          settle(jn, posn, endn);
+#ifdef SJ_LT_PROBE
+        const long long pc1 = wall_clock64();
+        int ptrips = 0;
+#endif
+        bool go = __any(jq[0] < RS);
+        while (go) {
+#pragma unroll
+          for (int u = 0; u <= D; ++u) {
+            if (go) { // (uniform) slot u is consumed, slot u + D (mod D + 1) is free
+              issue(vv[(u + D) % (D + 1)], cc[(u + D) % (D + 1)], posq[D]);
+              consume(vv[u], cc[u], jq[0], posq[0], endq[0]);
+#pragma unroll
+              for (int d = 0; d < D; ++d)
+                jq[d] = jq[d + 1], posq[d] = posq[d + 1], endq[d] = endq[d + 1];
+              posq[D] += TRIP;
+              settle(jq[D], posq[D], endq[D]);
+              go = __any(jq[0] < RS);
+#ifdef SJ_LT_PROBE
+              ++ptrips;
+#endif
+            }
+          }
         }
+#ifdef SJ_LT_PROBE
+        {
+          const long long pc2 = wall_clock64();
+          pr_stage += pc1 - pc0, pr_loop += pc2 - pc1, pr_trips += ptrips, ++pr_panels;
+        }
+#endif
 #pragma unroll
         for (int j = 0; j < RS; ++j) {
           lo[j] = hi[j];
@@ -1234,6 +1308,14 @@ __global__ __launch_bounds__(512, 4) void csr_sjds_longt_kernel(
         }
     }
   }
+#ifdef SJ_LT_PROBE
+  // (100 MHz ticks) per wave 0 and 7 of a few workgroups
+  if (lane == 0 && (wave == 0 || wave == 7)
+      && (blockIdx.x == 0 || blockIdx.x == 3 || blockIdx.x == 300 || blockIdx.x == 509))
+    printf("LTPROBE wg %d wave %d sgs %d panels %lld trips %lld stage %lld loop %lld total %lld\n",
+           (int)blockIdx.x, wave, sg1 - sg0, pr_panels, pr_trips, pr_stage, pr_loop,
+           wall_clock64() - pr_begin);
+#endif
   if constexpr (DOT) {
     double v = dot_acc;
 #pragma unroll

@@ -757,7 +757,7 @@ def test_long_rows_table_kernel_bit_exact(sj_ctx):
     cases["tail"] = poisson.fem_like_csr(40_000, jitter=64, layer=1200,
                                          tail_permille=30, tail_min=100,
                                          tail_max=2000, tail_stride=16)
-    # 200 long rows: one full supergroup of 128 and a partial one
+    # 210 long rows: three full supergroups of 64 and a partial one
     cases["tail_partial"] = poisson.fem_like_csr(20_001, jitter=64, layer=700,
                                                  tail_permille=10, tail_min=300,
                                                  tail_max=1200, tail_stride=16)
