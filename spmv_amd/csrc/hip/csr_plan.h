@@ -317,6 +317,12 @@ struct spmv_hip_csr_plan {
   int64_t sj_lt_entries = 0;
   int sj_lt_nsg = 0;
   int sj_long_table = 1;  // use that (plan_set "sj_long_table")
+  // symmetric storage of a matrix without lattice structure: the strictly
+  // lower block in the sliced jagged form (the fields above) and its transpose
+  // (rows = the transposed map's t_ptr / t_row) in a plan of its own
+  spmv_hip_csr_plan* sjt = nullptr;
+  const void* sj_diag0 = nullptr;
+  int sym_sj = 0;         // both are baked
   int sj_phases = 3;             // measurement only: 1 = long rows, 2 = slices
   int sj_blocks_per_cu = 0;      // 0 = what the LDS footprint allows
   int sj_xcd_group = 8;          // consecutive blocks per XCD (0 = off)
@@ -480,11 +486,20 @@ int spmv_wdia_run_f32f64(const spmv_hip_csr_plan* pl, hipStream_t st,
                          double* out, DotOut dot);
 // spmv_sjds.hip
 int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
-                    const int32_t* colind, int wpb_force, int unit_force);
+                    const int32_t* colind, int wpb_force, int unit_force,
+                    int no_long);
 void spmv_sjds_free(spmv_hip_csr_plan* pl);
+// values == nullptr: drop the copy; map: entry e is values[map[e]]
 int spmv_sjds_bake_f64(spmv_hip_csr_plan* pl, const double* values,
-                       hipStream_t st); // values == nullptr: drop the copy
-int spmv_sjds_bake_f32(spmv_hip_csr_plan* pl, const float* values, hipStream_t st);
+                       const int32_t* map, hipStream_t st);
+int spmv_sjds_bake_f32(spmv_hip_csr_plan* pl, const float* values, const int32_t* map,
+                       hipStream_t st);
+int spmv_sjds_run_sym_f64(const spmv_hip_csr_plan* pl, hipStream_t st,
+                          const double* diagonal, double alpha, const double* in,
+                          double beta, double* out, DotOut dot);
+int spmv_sjds_run_sym_f32(const spmv_hip_csr_plan* pl, hipStream_t st,
+                          const float* diagonal, float alpha, const float* in,
+                          float beta, float* out);
 int spmv_sjds_run_f64(const spmv_hip_csr_plan* pl, hipStream_t st, double alpha,
                       const double* in, double beta, double* out, DotOut dot);
 int spmv_sjds_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st, float alpha,

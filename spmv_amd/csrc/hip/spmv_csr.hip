@@ -1290,6 +1290,76 @@ int spmv_zwalk_order_build(spmv_hip_csr_plan* pl, int64_t d2, int grid,
   return SPMV_HIP_OK;
 }
 
+// Symmetric storage of a matrix without lattice structure (FEM matrices, what
+// read_petsc_binary_matrix delivers with symmetric = true): both blocks of the
+// reference's loop (csr_kernels.cpp:26-40) in the sliced jagged form -- the
+// strictly lower block as stored, its transpose through the transposed map.
+// ENOTSUP: the form does not apply (the transposed-map kernel stays).
+template <typename T>
+static int sym_sj_bake(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan, const T* values,
+                       const T* diagonal, hipStream_t st)
+{
+  auto bake = [&](spmv_hip_csr_plan* p, const T* v, const int32_t* map) {
+    if constexpr (sizeof(T) == 8)
+      return spmv_sjds_bake_f64(p, v, map, st);
+    else
+      return spmv_sjds_bake_f32(p, v, map, st);
+  };
+  if (values == nullptr) { // drop the copies
+    plan->sym_sj = 0;
+    plan->sj_diag0 = nullptr;
+    if (plan->sjt && plan->sjt->sj_lenperm)
+      (void)bake(plan->sjt, nullptr, nullptr);
+    return plan->sj_lenperm ? bake(plan, nullptr, nullptr) : SPMV_HIP_ENOTSUP;
+  }
+  if (!plan->symmetric || !plan->sym_det || !plan->t_ptr || plan->slat
+      || plan->nnz < ctx->sj_min_nnz || plan->num_rows < 64 || !diagonal)
+    return SPMV_HIP_ENOTSUP;
+  const auto t0 = std::chrono::steady_clock::now();
+  if (!plan->sj_lenperm) {
+    const int rb = spmv_sjds_build(plan, plan->rowptr0, plan->colind0, ctx->sj_wpb, 2, 1);
+    if (rb != SPMV_HIP_OK)
+      return rb;
+    if (!plan->sj_lenperm)
+      return SPMV_HIP_ENOTSUP;
+  }
+  if (!plan->sjt) {
+    spmv_hip_csr_plan* ch = new (std::nothrow) spmv_hip_csr_plan;
+    if (!ch)
+      return SPMV_HIP_ENOMEM;
+    ch->ctx = ctx;
+    ch->num_rows = plan->num_rows;
+    ch->num_cols = plan->num_cols;
+    ch->nnz = plan->nnz;
+    ch->symmetric = false;
+    ch->rowptr0 = plan->t_ptr;
+    ch->colind0 = plan->t_row;
+    const int rb = spmv_sjds_build(ch, plan->t_ptr, plan->t_row, ctx->sj_wpb, 2, 1);
+    if (rb != SPMV_HIP_OK || !ch->sj_lenperm) {
+      spmv_sjds_free(ch);
+      delete ch;
+      return rb != SPMV_HIP_OK ? rb : SPMV_HIP_ENOTSUP;
+    }
+    plan->sjt = ch;
+  }
+  plan->plan_us += (int)std::chrono::duration_cast<std::chrono::microseconds>(
+                       std::chrono::steady_clock::now() - t0)
+                       .count();
+  int rc = bake(plan, values, nullptr);
+  if (rc == SPMV_HIP_OK) {
+    rc = bake(plan->sjt, values, plan->t_pos);
+    plan->plan_us += plan->sjt->plan_us; // (the child's bake counted itself there)
+    plan->sjt->plan_us = 0;
+  }
+  if (rc != SPMV_HIP_OK) {
+    plan->sym_sj = 0;
+    return rc;
+  }
+  plan->sj_diag0 = diagonal;
+  plan->sym_sj = 1;
+  return SPMV_HIP_OK;
+}
+
 extern "C" {
 
 int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
@@ -1401,6 +1471,12 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
 
 int spmv_hip_csr_plan_destroy(spmv_hip_csr_plan* plan)
 {
+  if (plan && plan->sjt) {
+    (void)hipSetDevice(plan->ctx->device);
+    spmv_sjds_free(plan->sjt);
+    delete plan->sjt;
+    plan->sjt = nullptr;
+  }
   if (plan
       && (plan->row_list || plan->lx_lidx || plan->lat_tab || plan->t_ptr
           || plan->slat_mask || plan->zw_table || plan->wdia_val
@@ -1445,7 +1521,7 @@ int spmv_hip_csr_plan_bake_values_f64(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan
     // the structure of the sliced jagged form, now that it is known to be used
     const auto t0 = std::chrono::steady_clock::now();
     const int rb = spmv_sjds_build(plan, plan->rowptr0, plan->colind0,
-                                   ctx->sj_wpb, ctx->sj_unit);
+                                   ctx->sj_wpb, ctx->sj_unit, 0);
     if (rb != SPMV_HIP_OK)
       return rb;
     plan->plan_us += (int)std::chrono::duration_cast<std::chrono::microseconds>(
@@ -1454,7 +1530,13 @@ int spmv_hip_csr_plan_bake_values_f64(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan
   }
   if (!plan->symmetric && plan->sj_lenperm
       && (values == nullptr || rc == SPMV_HIP_ENOTSUP)) {
-    const int rj = spmv_sjds_bake_f64(plan, values, st);
+    const int rj = spmv_sjds_bake_f64(plan, values, nullptr, st);
+    rc = values == nullptr ? (rj != SPMV_HIP_OK ? rj : rc) : rj;
+  }
+  // symmetric storage without lattice structure: both blocks sliced jagged
+  if (plan->symmetric && (values == nullptr ? plan->sj_lenperm != nullptr
+                                            : rc == SPMV_HIP_ENOTSUP)) {
+    const int rj = sym_sj_bake<double>(ctx, plan, values, diagonal, st);
     rc = values == nullptr ? (rj != SPMV_HIP_OK ? rj : rc) : rj;
   }
   return rc;
@@ -1481,7 +1563,7 @@ int spmv_hip_csr_plan_bake_values_f32(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan
     // the structure of the sliced jagged form, now that it is known to be used
     const auto t0 = std::chrono::steady_clock::now();
     const int rb = spmv_sjds_build(plan, plan->rowptr0, plan->colind0,
-                                   ctx->sj_wpb, ctx->sj_unit);
+                                   ctx->sj_wpb, ctx->sj_unit, 0);
     if (rb != SPMV_HIP_OK)
       return rb;
     plan->plan_us += (int)std::chrono::duration_cast<std::chrono::microseconds>(
@@ -1490,7 +1572,12 @@ int spmv_hip_csr_plan_bake_values_f32(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan
   }
   if (!plan->symmetric && plan->sj_lenperm
       && (values == nullptr || rc == SPMV_HIP_ENOTSUP)) {
-    const int rj = spmv_sjds_bake_f32(plan, values, st);
+    const int rj = spmv_sjds_bake_f32(plan, values, nullptr, st);
+    rc = values == nullptr ? (rj != SPMV_HIP_OK ? rj : rc) : rj;
+  }
+  if (plan->symmetric && (values == nullptr ? plan->sj_lenperm != nullptr
+                                            : rc == SPMV_HIP_ENOTSUP)) {
+    const int rj = sym_sj_bake<float>(ctx, plan, values, diagonal, st);
     rc = values == nullptr ? (rj != SPMV_HIP_OK ? rj : rc) : rj;
   }
   return rc;
@@ -1523,8 +1610,19 @@ int spmv_hip_csr_plan_values_changed(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan,
   // the sliced jagged copy: rewritten in place
   if (plan->sj_val && plan->sj_values0) {
     rc = plan->sj_elem == 8
-             ? spmv_sjds_bake_f64(plan, static_cast<const double*>(plan->sj_values0), st)
-             : spmv_sjds_bake_f32(plan, static_cast<const float*>(plan->sj_values0), st);
+             ? spmv_sjds_bake_f64(plan, static_cast<const double*>(plan->sj_values0),
+                                  nullptr, st)
+             : spmv_sjds_bake_f32(plan, static_cast<const float*>(plan->sj_values0),
+                                  nullptr, st);
+    // (symmetric storage: the transposed block's copy from the same values)
+    if (rc == SPMV_HIP_OK && plan->sjt && plan->sjt->sj_val)
+      rc = plan->sj_elem == 8
+               ? spmv_sjds_bake_f64(plan->sjt,
+                                    static_cast<const double*>(plan->sj_values0),
+                                    plan->t_pos, st)
+               : spmv_sjds_bake_f32(plan->sjt,
+                                    static_cast<const float*>(plan->sj_values0),
+                                    plan->t_pos, st);
   }
   // the diagonal forms: the device checks decide the form again (a matrix
   // they no longer hold: ENOTSUP = back to the CSR-order kernels, which is a
@@ -1798,6 +1896,11 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
     *value = plan->sdia && plan->sdia_val ? 1 : 0;
   else if (!strcmp(key, "sjds"))
     *value = plan->sj && plan->sj_val ? 1 : 0;
+  else if (!strcmp(key, "sym_sj")) // symmetric storage, both blocks sliced jagged
+    *value = plan->symmetric && plan->sym_sj && plan->sj && plan->sj_val && plan->sjt
+                     && plan->sjt->sj_val
+                 ? 1
+                 : 0;
   else if (!strcmp(key, "sj_built"))
     *value = plan->sj_lenperm ? 1 : 0;
   else if (!strcmp(key, "sj_wpb"))
@@ -1876,6 +1979,15 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
            + 4 * plan->sj_lt_entries + 16 * (int64_t)plan->sj_lt_nsg;
     if (plan->sj_val)
       b += (int64_t)plan->sj_elem * plan->sj_units * plan->sj_unit;
+    if (plan->sjt && plan->sjt->sj_lenperm) { // the transposed block's structure
+      const spmv_hip_csr_plan* c = plan->sjt;
+      b += 4 * ((n + 63) / 64 * 64) + 8 * (int64_t)c->sj_nblk
+           + 4 * (int64_t)c->sj_nblk * c->sj_stride
+           + (c->sj_wide_alloc ? 4 : 2) * c->sj_units * c->sj_unit
+           + 4 * ((n + 63) / 64 + 1);
+      if (c->sj_val)
+        b += (int64_t)c->sj_elem * c->sj_units * c->sj_unit;
+    }
     if (plan->t_ptr)
       b += 4 * (n + 1) + 8 * nnz;
     if (plan->zw_table)

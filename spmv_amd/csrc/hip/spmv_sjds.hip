@@ -409,8 +409,11 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void sj_bake_kernel(
     int32_t num_rows, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ lenperm, const uint32_t* __restrict__ ubase, int E,
-    const T* __restrict__ values, T* __restrict__ sval)
+    const T* __restrict__ values, const int32_t* __restrict__ map,
+    T* __restrict__ sval)
 {
+  // map (symmetric storage, the transposed block): entry e of the plan's CSR
+  // arrays is values[map[e]]
   const int lane = threadIdx.x & 63;
   const int64_t nsl = ((int64_t)num_rows + 63) / 64;
   const int64_t wid = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
@@ -430,7 +433,9 @@ __global__ __launch_bounds__(kBlock) void sj_bake_kernel(
       if (act)
         for (int q = 0; q < E; ++q)
           sval[off + (int64_t)lane * E + q]
-              = k * E + q < mylen ? values[src0 + k * E + q] : T(0);
+              = k * E + q < mylen
+                    ? values[map ? (int64_t)map[src0 + k * E + q] : src0 + k * E + q]
+                    : T(0);
       off += (int64_t)cnt * E;
     }
   }
@@ -531,12 +536,17 @@ __device__ __forceinline__ float sj_readlane<float>(float v, int j)
 // loads in flight at each join, and the two groups no longer overlap.  The
 // step's address is the uniform `vs + off` plus the lane's own constant: no
 // vector arithmetic per step but one select.
-template <typename T, typename CODE, bool WIDE, int E>
+//
+// MODE (symmetric storage, csr_kernels.cpp:26-40 seen from the row): 0 = a
+// general matrix; 1 = the strictly lower block, the sum starts at d_i x_i;
+// 2 = its transpose, the sum starts at the y the lower pass left and every
+// product is fl(fl(alpha v) x) -- the reference's out[col] += alpha * val * in[i].
+template <typename T, typename CODE, bool WIDE, int E, int MODE>
 __device__ __forceinline__ T sj_slice(const SjUnit<T, E>* __restrict__ vs,
                                       const SjUnit<CODE, E>* __restrict__ cs,
                                       int32_t mylen, int lane,
                                       const T* __restrict__ s_x,
-                                      const T* __restrict__ in)
+                                      const T* __restrict__ in, T init, T alpha)
 {
   constexpr int U = kSjGroup / E; // steps per group
   const int32_t myu = (mylen + E - 1) / E;
@@ -547,7 +557,7 @@ __device__ __forceinline__ T sj_slice(const SjUnit<T, E>* __restrict__ vs,
   // for long enough to be worth taking over by the whole wave
   const int32_t kmain = (maxlen - u1 * E >= kSjTailMin) ? u1 : maxu; // units
   const int32_t mymain = myu < kmain ? myu : kmain;
-  T sum = T(0);
+  T sum = init;
   SjUnit<T, E> va[U], vc[U];
   SjUnit<CODE, E> ca[U], cc[U];
   uint32_t off = 0; // units behind the slice's first (uniform)
@@ -602,7 +612,8 @@ __device__ __forceinline__ T sj_slice(const SjUnit<T, E>* __restrict__ vs,
     _Pragma("unroll") for (int u = 0; u < U; ++u)                              \
         _Pragma("unroll") for (int q = 0; q < E; ++q)                          \
     {                                                                          \
-      const T nxt = sum + V[u].e[q] * xs[u][q];                                \
+      const T vq = MODE == 2 ? alpha * V[u].e[q] : V[u].e[q];                  \
+      const T nxt = sum + vq * xs[u][q];                                       \
       const bool use = (K0) + u < mymain && ((K0) + u) * E + q < mylen;        \
       sum = use ? nxt : sum;                                                   \
     }                                                                          \
@@ -644,7 +655,8 @@ __device__ __forceinline__ T sj_slice(const SjUnit<T, E>* __restrict__ vs,
       } else {
         x = s_x[ct[j]];
       }
-      const T p = v * x; // lanes past the row's end: never added
+      const T p = (MODE == 2 ? alpha * v : v) * x; // lanes past the row's end:
+                                                   // never added
       const int n = rem - j0 < 64 ? rem - j0 : 64;
       if (n == 64) {
 #pragma unroll
@@ -1334,10 +1346,10 @@ __global__ __launch_bounds__(512, 4) void csr_sjds_longt_kernel(
   }
 }
 
-template <typename T, int WPB, int E, bool DOT>
+template <typename T, int WPB, int E, bool DOT, int MODE>
 __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
     SjArgs<T> A, T alpha, const T* __restrict__ in, T beta, T* __restrict__ out,
-    DotOut dot, RowBlockOrder ord)
+    DotOut dot, RowBlockOrder ord, const T* __restrict__ diagonal)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   T* s_x = reinterpret_cast<T*>(s_raw);
@@ -1394,11 +1406,15 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
         = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.ubase[r0 / 64]);
     const int32_t myrow = s0c + (lp & 63);
     const int32_t myrow_c = myrow < A.num_rows ? myrow : A.num_rows - 1;
-    T x_own = T(0), y0 = T(0);
-    if constexpr (DOT)
+    T x_own = T(0), y0 = T(0), init = T(0);
+    if constexpr (DOT || MODE == 1)
       x_own = in[myrow_c];
-    if (beta != T(0))
+    if (beta != T(0) && MODE != 2)
       y0 = out[myrow_c];
+    if constexpr (MODE == 1)
+      init = diagonal[myrow_c] * x_own;
+    if constexpr (MODE == 2)
+      init = out[myrow_c];
     const int32_t* cl = A.chunks + (int64_t)b * A.stride;
     // the block's chunks of x: 8 lanes per chunk, 2 elements per lane, four
     // chunks per lane in flight; lanes past the list repeat its last chunk
@@ -1445,18 +1461,20 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
         const SjUnit<uint32_t, E>* cs
             = reinterpret_cast<const SjUnit<uint32_t, E>*>(A.codes + 4 * a_b)
               + (ub_slice - ub_block);
-        sum = sj_slice<T, uint32_t, true, E>(vs, cs, mylen, lane, s_x, in);
+        sum = sj_slice<T, uint32_t, true, E, MODE>(vs, cs, mylen, lane, s_x, in, init,
+                                                   alpha);
       } else {
         const SjUnit<uint16_t, E>* cs
             = reinterpret_cast<const SjUnit<uint16_t, E>*>(
                   A.codes + (A.wide_alloc ? 4 : 2) * a_b)
               + (ub_slice - ub_block);
-        sum = sj_slice<T, uint16_t, false, E>(vs, cs, mylen, lane, s_x, in);
+        sum = sj_slice<T, uint16_t, false, E, MODE>(vs, cs, mylen, lane, s_x, in, init,
+                                                    alpha);
       }
       if (myrow < A.num_rows && in_slice) {
-        const T c = alpha * sum;
+        const T c = MODE == 2 ? sum : alpha * sum;
         T y = c;
-        if (beta != T(0))
+        if (beta != T(0) && MODE != 2)
           y = c + beta * y0;
         out[myrow] = y;
         if constexpr (DOT)
@@ -1524,9 +1542,9 @@ int sj_wgs_per_cu(int wpb, int64_t lds)
   return wgs < 1 ? 1 : wgs;
 }
 
-template <typename T, int WPB, int E, bool DOT>
+template <typename T, int WPB, int E, bool DOT, int MODE = 0>
 int sj_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
-              T beta, T* out, DotOut dot)
+              T beta, T* out, DotOut dot, const T* diagonal = nullptr)
 {
   SjArgs<T> A;
   A.num_rows = pl->num_rows;
@@ -1571,10 +1589,13 @@ int sj_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
   ord.num_row_blocks = pl->sj_nblk;
   ord.nt_store = 0;
   if (A.phases & 2) {
-    hipLaunchKernelGGL((csr_sjds_kernel<T, WPB, E, DOT>), dim3(grid), dim3(64 * WPB),
-                       lds, st, A, alpha, in, beta, out, dot, ord);
+    hipLaunchKernelGGL((csr_sjds_kernel<T, WPB, E, DOT, MODE>), dim3(grid),
+                       dim3(64 * WPB), lds, st, A, alpha, in, beta, out, dot, ord,
+                       diagonal);
     SPMV_CHECK_LAUNCH();
   }
+  if constexpr (MODE != 0) // (symmetric storage: built without long rows)
+    return pl->sj_nlong > 0 ? SPMV_HIP_EINVAL : SPMV_HIP_OK;
   if (pl->sj_nlong > 0 && (A.phases & 1) && A.long_sorted && pl->sj_lt_tab
       && pl->sj_long_table) {
     // the long rows by the table-driven kernel: 8-wave workgroups, two per CU,
@@ -1982,7 +2003,7 @@ int sj_build_long_table(spmv_hip_csr_plan* pl, const int32_t* rowptr,
 }
 
 template <typename T>
-int sj_bake(spmv_hip_csr_plan* pl, const T* values, hipStream_t st)
+int sj_bake(spmv_hip_csr_plan* pl, const T* values, const int32_t* map, hipStream_t st)
 {
   SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
   if (values == nullptr) { // drop the copy
@@ -1993,7 +2014,7 @@ int sj_bake(spmv_hip_csr_plan* pl, const T* values, hipStream_t st)
     pl->sj_elem = 0;
     return SPMV_HIP_OK;
   }
-  if (!pl->sj_lenperm || pl->symmetric || pl->nnz == 0)
+  if (!pl->sj_lenperm || pl->nnz == 0)
     return SPMV_HIP_ENOTSUP;
   const auto t_begin = std::chrono::steady_clock::now();
   if (pl->sj_val && pl->sj_elem != (int)sizeof(T)) {
@@ -2019,7 +2040,7 @@ int sj_bake(spmv_hip_csr_plan* pl, const T* values, hipStream_t st)
   const int grid = spmv_grid_for(pl->ctx, nsl, kBlock / 64);
   hipLaunchKernelGGL((sj_bake_kernel<T>), dim3(grid), dim3(kBlock), 0, st,
                      pl->num_rows, pl->rowptr0, pl->sj_lenperm, pl->sj_ubase,
-                     pl->sj_unit, values, static_cast<T*>(pl->sj_val));
+                     pl->sj_unit, values, map, static_cast<T*>(pl->sj_val));
   SPMV_CHECK_LAUNCH();
   SPMV_CHECK_HIP(hipStreamSynchronize(st));
   pl->sj_elem = (int)sizeof(T);
@@ -2057,9 +2078,17 @@ void spmv_sjds_free(spmv_hip_csr_plan* pl)
 // = choose; unit_force: 1, 2, 4 entries per lane and step, or 0 = choose.
 // Leaves the plan without the form (SPMV_HIP_OK) when it does not pay: no
 // memory, or nearly all entries far.
+// no_long (the two blocks of symmetric storage, whose kernel modes exist for
+// the slices only): no row leaves the slices, blocks of 8 or 16 slices, two
+// entries per lane and step.
 int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
-                    const int32_t* colind, int wpb_force, int unit_force)
+                    const int32_t* colind, int wpb_force, int unit_force, int no_long)
 {
+  if (no_long) {
+    unit_force = 2;
+    if (wpb_force != 8 && wpb_force != 16)
+      wpb_force = 0;
+  }
   SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
   hipStream_t st = pl->ctx->stream;
   const int n = pl->num_rows;
@@ -2069,6 +2098,8 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
   // long rows: more than four times the average length, and more than 96
   int thr = (int)(pl->nnz * 4 / n);
   thr = thr > kSjLongMin ? thr : kSjLongMin;
+  if (no_long)
+    thr = INT32_MAX;
   // entries per lane and step: a unit's padding (half a unit per row) against
   // the instructions of a step
   const double avg = (double)pl->nnz / n;
@@ -2121,6 +2152,8 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
     const int wpb = cand[ci];
     if (wpb_force && wpb != wpb_force)
       continue;
+    if (no_long && wpb == 4)
+      continue;
     if (!wpb_force && n < 64 * wpb * 8) // too few blocks for this size
       continue;
     SjStats s;
@@ -2144,8 +2177,8 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
     }
   }
   if (!best) { // a matrix too small for any candidate: the smallest
-    best = wpb_force ? wpb_force : 4;
-    best_ci = 0;
+    best = wpb_force ? wpb_force : (no_long ? 8 : 4);
+    best_ci = best == 4 ? 0 : best == 8 ? 1 : 2;
     const int rc = count(best, best_ci, &best_st);
     if (rc != SPMV_HIP_OK) {
       cleanup();
@@ -2251,13 +2284,59 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
   return SPMV_HIP_OK;
 }
 
-int spmv_sjds_bake_f64(spmv_hip_csr_plan* pl, const double* values, hipStream_t st)
+int spmv_sjds_bake_f64(spmv_hip_csr_plan* pl, const double* values,
+                       const int32_t* map, hipStream_t st)
 {
-  return sj_bake<double>(pl, values, st);
+  return sj_bake<double>(pl, values, map, st);
 }
-int spmv_sjds_bake_f32(spmv_hip_csr_plan* pl, const float* values, hipStream_t st)
+int spmv_sjds_bake_f32(spmv_hip_csr_plan* pl, const float* values, const int32_t* map,
+                       hipStream_t st)
 {
-  return sj_bake<float>(pl, values, st);
+  return sj_bake<float>(pl, values, map, st);
+}
+
+// Symmetric storage (csr_kernels.cpp:26-40) in two passes over two sliced
+// jagged structures: the strictly lower block (the plan's own; y = alpha (d x
+// + L x) + beta y) and its transpose (plan->sjt; y += the column's entries in
+// the reference's order).  The fused dot belongs to the second pass.
+namespace
+{
+template <typename T, int MODE, bool DOT>
+int sj_run_mode(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
+                T beta, T* out, DotOut dot, const T* diagonal)
+{
+  if (pl->sj_unit != 2)
+    return SPMV_HIP_EINVAL;
+  if (pl->sj_wpb == 8)
+    return sj_launch<T, 8, 2, DOT, MODE>(pl, st, alpha, in, beta, out, dot, diagonal);
+  if (pl->sj_wpb == 16)
+    return sj_launch<T, 16, 2, DOT, MODE>(pl, st, alpha, in, beta, out, dot, diagonal);
+  return SPMV_HIP_EINVAL;
+}
+template <typename T, bool DOT>
+int sj_run_sym(const spmv_hip_csr_plan* pl, hipStream_t st, const T* diagonal, T alpha,
+               const T* in, T beta, T* out, DotOut dot)
+{
+  int rc = sj_run_mode<T, 1, false>(pl, st, alpha, in, beta, out, DotOut(), diagonal);
+  if (rc == SPMV_HIP_OK)
+    rc = sj_run_mode<T, 2, DOT>(pl->sjt, st, alpha, in, T(0), out, dot, nullptr);
+  return rc;
+}
+} // namespace
+
+int spmv_sjds_run_sym_f64(const spmv_hip_csr_plan* pl, hipStream_t st,
+                          const double* diagonal, double alpha, const double* in,
+                          double beta, double* out, DotOut dot)
+{
+  if (dot.partials)
+    return sj_run_sym<double, true>(pl, st, diagonal, alpha, in, beta, out, dot);
+  return sj_run_sym<double, false>(pl, st, diagonal, alpha, in, beta, out, dot);
+}
+int spmv_sjds_run_sym_f32(const spmv_hip_csr_plan* pl, hipStream_t st,
+                          const float* diagonal, float alpha, const float* in,
+                          float beta, float* out)
+{
+  return sj_run_sym<float, false>(pl, st, diagonal, alpha, in, beta, out, DotOut());
 }
 
 int spmv_sjds_run_f64(const spmv_hip_csr_plan* pl, hipStream_t st, double alpha,

@@ -458,6 +458,15 @@ int run_symmetric(const spmv_hip_csr_plan* pl, hipStream_t st,
       return spmv_slat_run_f32(pl, st, rowptr, values, diagonal, alpha, in, beta,
                                out);
   }
+  // no lattice structure (FEM matrices): both blocks in the sliced jagged form
+  if (pl->sym_sj && pl->sj && pl->sj_val && pl->sjt && pl->sjt->sj_val
+      && pl->sj_elem == (int)sizeof(T) && values == pl->sj_values0
+      && diagonal == pl->sj_diag0 && aligned16(in) && pl->num_cols >= 2) {
+    if constexpr (sizeof(T) == 8)
+      return spmv_sjds_run_sym_f64(pl, st, diagonal, alpha, in, beta, out, dot);
+    else
+      return spmv_sjds_run_sym_f32(pl, st, diagonal, alpha, in, beta, out);
+  }
   if (pl->sym_det && pl->t_ptr) {
     const int nrb = (n + kRows - 1) / kRows;
     int grid = pl->ctx->num_cus * pl->blocks_per_cu;

@@ -824,6 +824,121 @@ def test_long_rows_table_kernel_bit_exact(sj_ctx):
     blk.free()
 
 
+def _sym_lower_cases():
+    """(rowptr, colind, values, diagonal) of strictly lower blocks without lattice
+    structure: the lower part of the FEM-like matrix, the same with a few long
+    rows and one long COLUMN (a long row of the transposed block), random
+    ragged rows with unsorted columns and empty rows."""
+    rng = np.random.default_rng(0x51A3)
+    cases = {}
+    for name, kw in (("fem", dict()),
+                     ("fem_tail", dict(tail_permille=5, tail_min=150, tail_max=600,
+                                       tail_stride=3))):
+        rp, ci, va = poisson.fem_like_csr(7000, jitter=64, layer=400, **kw)
+        cases[name] = lower_split(rp, ci, va)
+    nr = 5000
+    lens = rng.integers(0, 14, nr)
+    lens[0] = 0
+    lens[rng.integers(1, nr, 200)] = 0
+    lens = np.minimum(lens, np.arange(nr))
+    rp = np.zeros(nr + 1, np.int64)
+    np.cumsum(lens, out=rp[1:])
+    ci = np.empty(rp[-1], np.int32)
+    for r in range(nr):
+        if lens[r]:
+            ci[rp[r]:rp[r + 1]] = rng.permutation(
+                rng.choice(r, lens[r], replace=False))  # unsorted, below the diagonal
+    # a long column: every row from 1000 on has an entry in column 7
+    add = np.arange(1000, nr)
+    rows = np.concatenate([np.repeat(np.arange(nr), lens), add])
+    cols = np.concatenate([ci, np.full(len(add), 7, np.int32)])
+    order = np.argsort(rows, kind="stable")
+    rows, cols = rows[order], cols[order]
+    rp2 = np.zeros(nr + 1, np.int64)
+    np.add.at(rp2, rows + 1, 1)
+    rp2 = np.cumsum(rp2)
+    va = rng.uniform(-1, 1, len(cols))
+    cases["ragged_long_column"] = (rp2.astype(np.int32), cols.astype(np.int32), va,
+                                   rng.uniform(1, 2, nr))
+    return cases
+
+
+@pytest.mark.parametrize("wpb", [0, 8, 16])
+def test_symmetric_storage_sliced_jagged_bit_exact(sj_ctx, wpb):
+    """Symmetric storage of matrices WITHOUT lattice structure: both blocks of
+    the reference's loop (csr_kernels.cpp:26-40) in the sliced jagged form --
+    the strictly lower block as stored (sum starts at d_i x_i) and its transpose
+    (y_i += fl(fl(alpha v) x_r) in ascending (r, j)) -- against
+    oracle.csr_spmv_sym, every element identical; any alpha / beta, the fused
+    dot, fp32, coefficients rewritten in place, and the transposed-map kernel
+    (sjds = 0) on the same plan."""
+    ctx = sj_ctx
+    ctx.set_option("sj_wpb", wpb)
+    part = ctx.empty(ctx.dot_partials_len, np.float64)
+    rng = np.random.default_rng(77)
+    for name, (rp, ci, va, dg) in _sym_lower_cases().items():
+        nr = len(rp) - 1
+        x = rng.uniform(-1, 1, nr)
+        y0 = rng.uniform(-1, 1, nr)
+        blk = hip.CsrBlock(ctx, nr, nr, rp, ci, va, dg, True)
+        assert blk.get("sym_sj") == 0
+        blk.bake()
+        assert blk.get("sym_sj") == 1 and blk.get("sjds") == 1, name
+        if wpb:
+            assert blk.get("sj_wpb") == wpb
+        dx = ctx.upload(x)
+        for alpha, beta in ((1.0, 0.0), (-0.75, 0.0), (2.5, -0.5)):
+            y_ref = oracle.csr_spmv_sym(rp, ci, va, dg, x, alpha, beta, y0)
+            for sjds in (1, 0):  # ... and the transposed-map kernel
+                blk.set("sjds", sjds)
+                dy = ctx.upload(np.full(nr, np.nan) if beta == 0 else y0)
+                blk.mult(alpha, dx.ptr, beta, dy.ptr,
+                         dot_partials=part.ptr if beta == 0 else None)
+                assert np.array_equal(dy.numpy(), y_ref), (name, alpha, sjds)
+                if beta == 0:
+                    want = float(np.dot(x, y_ref))
+                    got = float(np.sum(part.numpy()))
+                    assert abs(got - want) <= 1e-11 * (np.abs(x) @ np.abs(y_ref) + 1)
+                dy.free()
+            blk.set("sjds", 1)
+        # coefficients rewritten in place
+        for scale in (-0.5, 3.0):
+            va2, dg2 = scale * va + 0.25, dg * scale
+            blk.values.write(va2)
+            blk.diagonal.write(dg2)
+            blk.values_changed()
+            assert blk.get("sym_sj") == 1
+            dy = ctx.upload(np.full(nr, np.nan))
+            blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+            assert np.array_equal(dy.numpy(),
+                                  oracle.csr_spmv_sym(rp, ci, va2, dg2, x)), (name, scale)
+            dy.free()
+        # a dropped copy: the transposed-map kernel again
+        blk.bake(drop=True)
+        assert blk.get("sym_sj") == 0 and blk.get("sjds") == 0
+        dy = ctx.upload(np.full(nr, np.nan))
+        blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+        assert np.array_equal(dy.numpy(), oracle.csr_spmv_sym(rp, ci, va2, dg2, x))
+        for b in (dx, dy):
+            b.free()
+        blk.free()
+    part.free()
+    # fp32
+    rp, ci, va, dg = _sym_lower_cases()["fem"]
+    nr = len(rp) - 1
+    va32, dg32 = va.astype(np.float32), dg.astype(np.float32)
+    x32 = rng.uniform(-1, 1, nr).astype(np.float32)
+    blk = hip.CsrBlock(ctx, nr, nr, rp, ci, va32, dg32, True, dtype=np.float32)
+    blk.bake()
+    assert blk.get("sym_sj") == 1
+    dx, dy = ctx.upload(x32), ctx.upload(np.full(nr, np.nan, np.float32))
+    blk.mult(-1.5, dx.ptr, 0.0, dy.ptr)
+    assert np.array_equal(dy.numpy(), oracle.csr_spmv_sym(rp, ci, va32, dg32, x32, -1.5))
+    for b in (dx, dy):
+        b.free()
+    blk.free()
+
+
 def test_plan_values_changed_after_updates_in_place():
     """spmv_hip_csr_plan_values_changed: a caller that keeps the sparsity and
     rewrites the coefficients IN PLACE (time stepping) -- three updates on every
