@@ -306,6 +306,16 @@ def kernel_of(A, symmetric):
                     "and column value windows by LDS-DMA, no index stream, "
                     "atomic-free, bit-exact)",
                     algo, nnz * 8 + rows * (4 + 1 + 8) + y_x)
+        if A.plan_get("sym_sj"):
+            wpb = A.plan_get("sj_wpb")
+            return (f"csr_sjds_kernel<double, {wpb} slices per block, symmetric "
+                    "storage> (no lattice structure: the strictly lower block and "
+                    "its transpose both in the sliced jagged form -- the plan's "
+                    "copies of the values and 16-bit column codes, x staged in LDS "
+                    "-- two passes: y = alpha (d x + L x) + beta y, then the "
+                    "column's entries added in the reference's order; atomic-free, "
+                    "bit-exact; fused p.Ap)",
+                    algo, nnz * 20 + rows * (8 + 8 + 8 + 24 + 8) + 2 * cols * 8)
         if A.plan_get("sym_det"):
             return ("csr_symt_kernel<double> (transposed map, atomic-free, "
                     "bit-exact)", algo, algo + (rows + 1) * 4 + nnz * 8)
@@ -421,8 +431,8 @@ def plan_record(A):
     return {"plan_ms": A.plan_get("plan_us") / 1e3,
             "plan_extra_bytes": A.plan_get("plan_kib") * 1024,
             "form": {k: A.plan_get(k) for k in
-                     ("lat", "lx", "lxw", "sjds", "wdia", "wdia_const", "wdia_hbox", "slat",
-                      "sdia", "sdia_const", "sym_det", "zwalk")}}
+                     ("lat", "lx", "lxw", "sjds", "sym_sj", "wdia", "wdia_const",
+                      "wdia_hbox", "slat", "sdia", "sdia_const", "sym_det", "zwalk")}}
 
 
 def pmc_traffic(record, kernel_name, n, world):
@@ -493,7 +503,10 @@ def timed_spmv(exec_, A, N, _lib, reps, crosscheck=False):
     if crosscheck:
         import numpy as np
         y = exec_.copy_to_host(d_y, N)
-        A.plan_set("algo", 3)  # SPMV_HIP_ALGO_SCALAR
+        if crosscheck == "symt":  # symmetric storage: the transposed-map kernel
+            A.plan_set("sjds", 0)
+        else:
+            A.plan_set("algo", 3)  # SPMV_HIP_ALGO_SCALAR
         exec_.memset(d_y, 0xFF, 8 * N)
         A.mult(d_x, d_y)
         same = bool(np.array_equal(y, exec_.copy_to_host(d_y, N))
@@ -552,9 +565,13 @@ def matrix_spmv_record(exec_, A, _lib, symmetric, reps, record, grid, workload,
     if traffic:
         rec["traffic_source"] = source
     if same is not None:
-        rec["crosscheck"] = {"against": "csr_scalar_kernel (one lane per row, the "
-                                        "reference loop of csr_kernels.cpp:41-51 "
-                                        "verbatim) on the same matrix and x",
+        rec["crosscheck"] = {"against": ("csr_symt_kernel (transposed map: the "
+                                         "reference loop of csr_kernels.cpp:26-40 "
+                                         "seen from the row) on the same matrix "
+                                         "and x" if crosscheck == "symt" else
+                                         "csr_scalar_kernel (one lane per row, the "
+                                         "reference loop of csr_kernels.cpp:41-51 "
+                                         "verbatim) on the same matrix and x"),
                              "bit_equal": same}
     rec.update(plan)
     return rec
@@ -1121,6 +1138,27 @@ def main():
                                     "plan_ms": r["plan_ms"],
                                     "traffic": r.get("traffic")}
                     Af.close()
+                # ... and the first of them in SYMMETRIC storage (its strictly
+                # lower part + diagonal, as create_matrix(symmetric = true) keeps
+                # it): both blocks sliced jagged; priced with SURVEY 8d's B_sym
+                Af = host.Matrix.create_fem_like(self_comm, exec_, args.fem_rows,
+                                                 symmetric=True)
+                r = matrix_spmv_record(
+                    exec_, Af, _lib, True, 30, "fem_sym_spmv", args.fem_rows,
+                    f"fem_like_{args.fem_rows}rows_len5-40_lower+diag_symmetric_"
+                    "storage_fp64_spmv", crosscheck="symt")
+                out["fem_sym_spmv"] = r
+                ragged["fem_sym_spmv"] = {
+                    "ms_per_apply": r["ms_per_apply"],
+                    "frac": r["frac_csr_equivalent"],
+                    "frac_note": "SURVEY 8d B_sym (12 B per stored lower entry, "
+                                 "row pointer, diagonal, x, y) / time / 8 TB/s; the "
+                                 "kernel streams 20 B per stored entry",
+                    "frac_requested": r["frac_requested"],
+                    "kernel": r["kernel"].split(" (")[0],
+                    "bit_equal_transposed_map_kernel": r["crosscheck"]["bit_equal"],
+                    "plan_ms": r["plan_ms"], "traffic": r.get("traffic")}
+                Af.close()
                 out["roofline"]["ragged"] = dict(
                     ragged, note="frac = SURVEY 8d CSR bytes (12 B per entry, row "
                                  "pointer, x, y) / launch time / 8 TB/s")

@@ -562,6 +562,23 @@ int spmv_hip_fem_count(spmv_hip_ctx* ctx, const spmv_hip_fem_params* params,
 int spmv_hip_fem_fill_f64(spmv_hip_ctx* ctx, const spmv_hip_fem_params* params,
                           int64_t num_non_zeros, const int32_t* rowptr,
                           int32_t* colind, double* values, void* stream);
+/* Symmetric storage from a square general CSR block on the device, by the
+ * reference's rule (spmv/Matrix.cpp:337-349: entries below the diagonal stay in
+ * the block in their order, entries on the diagonal are summed into the
+ * diagonal array, entries above it are dropped: the matrix is taken to be
+ * symmetric).  lower_split_count writes the new row pointer (num_rows + 1) and
+ * reports its entry count; lower_split_fill writes colind / values / diagonal.
+ * (The reference splits on the host, inside create_matrix.) */
+int spmv_hip_csr_lower_split_count(spmv_hip_ctx* ctx, int32_t num_rows,
+                                   const int32_t* rowptr, const int32_t* colind,
+                                   int32_t* lower_rowptr, int64_t* host_nnz,
+                                   void* stream);
+int spmv_hip_csr_lower_split_fill_f64(spmv_hip_ctx* ctx, int32_t num_rows,
+                                      const int32_t* rowptr, const int32_t* colind,
+                                      const double* values,
+                                      const int32_t* lower_rowptr,
+                                      int32_t* lower_colind, double* lower_values,
+                                      double* diagonal, void* stream);
 /* x_i = exp(-10 (5 (i/N - 1/2))^2), i = i_begin.. (demos/spmv.cpp:63-67) */
 int spmv_hip_fill_gaussian_f64(spmv_hip_ctx* ctx, int64_t N, int64_t i_begin,
                                int64_t count, double* x, void* stream);

@@ -117,6 +117,11 @@ struct spmv_hip_fem_params; /* include/spmv_hip.h */
 int spmvh_matrix_create_fem_like(spmvh_comm* comm, spmvh_exec* exec,
                                  const struct spmv_hip_fem_params* params,
                                  spmvh_matrix** A);
+/* ... its strictly lower part + diagonal in symmetric storage
+ * (spmv_hip_csr_lower_split_*) */
+int spmvh_matrix_create_fem_like_sym(spmvh_comm* comm, spmvh_exec* exec,
+                                     const struct spmv_hip_fem_params* params,
+                                     spmvh_matrix** A);
 /* The Poisson matrix on a 3-D block partition (the reference
  * partitions by row slabs only, read_petsc.cpp:20-37): px * py * pz boxes,
  * rank = ix + px (iy + py iz), rank-major global numbering (a box's points are

@@ -145,6 +145,9 @@ _PROTOS = {
                                         C.c_uint64, vp, vp, vp, vp], C.c_int),
     "spmv_hip_fem_count": ([vp, vp, vp, P(i64), vp], C.c_int),
     "spmv_hip_fem_fill_f64": ([vp, vp, i64, vp, vp, vp, vp], C.c_int),
+    "spmv_hip_csr_lower_split_count": ([vp, i32, vp, vp, vp, P(i64), vp], C.c_int),
+    "spmv_hip_csr_lower_split_fill_f64": ([vp, i32, vp, vp, vp, vp, vp, vp, vp, vp],
+                                          C.c_int),
     "spmv_hip_fill_gaussian_f64": ([vp, i64, i64, i64, vp, vp], C.c_int),
     "spmv_hip_fill_const_f64": ([vp, i64, f64, vp, vp], C.c_int),
     "spmv_hip_comm_unique_id": ([vp], C.c_int),

@@ -268,6 +268,62 @@ __host__ __device__ inline FemRow fem_row(const spmv_hip_fem_params& p, int64_t 
   return r;
 }
 
+// symmetric storage from a general block (Matrix.cpp:337-349): entries below
+// the diagonal per row ...
+__global__ __launch_bounds__(kBlock) void lower_count_kernel(
+    int32_t num_rows, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ colind, int32_t* __restrict__ lower_rowptr)
+{
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= num_rows;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int32_t n = 0;
+    if (i < num_rows)
+      for (int32_t e = rowptr[i]; e < rowptr[i + 1]; ++e)
+        n += colind[e] < (int32_t)i ? 1 : 0;
+    lower_rowptr[i] = n;
+  }
+}
+
+// ... kept in their order (one wave per row: a prefix count per 64 entries),
+// the diagonal entries summed in their order
+__global__ __launch_bounds__(kBlock) void lower_fill_kernel(
+    int32_t num_rows, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ colind, const double* __restrict__ values,
+    const int32_t* __restrict__ lower_rowptr, int32_t* __restrict__ lower_colind,
+    double* __restrict__ lower_values, double* __restrict__ diagonal)
+{
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * kBlock) >> 6;
+  for (int64_t i = wid; i < num_rows; i += nw) {
+    const int32_t a = rowptr[i], b = rowptr[i + 1];
+    int32_t dst = lower_rowptr[i];
+    double d = 0.0;
+    for (int32_t e0 = a; e0 < b; e0 += 64) {
+      const int32_t e = e0 + lane;
+      const int32_t c = e < b ? colind[e] : INT32_MAX;
+      const double v = e < b ? values[e] : 0.0;
+      const bool low = c < (int32_t)i;
+      const uint64_t m = __ballot(low);
+      if (low) {
+        const int32_t at = dst + __popcll(m & ((1ull << lane) - 1ull));
+        lower_colind[at] = c;
+        lower_values[at] = v;
+      }
+      dst += __popcll(m);
+      // the diagonal entries of these 64, added in entry order
+      uint64_t dm = __ballot(c == (int32_t)i);
+      while (dm) {
+        const int j = __ffsll((long long)dm) - 1;
+        d += __shfl(v, j, 64);
+        dm &= dm - 1;
+      }
+    }
+    if (lane == 0)
+      diagonal[i] = d;
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void fem_count_kernel(spmv_hip_fem_params p,
                                                            int32_t* __restrict__ rowptr)
 {
@@ -676,6 +732,58 @@ int spmv_hip_fem_fill_f64(spmv_hip_ctx* ctx, const spmv_hip_fem_params* params,
   hipLaunchKernelGGL(fem_fill_kernel, dim3(grid), dim3(kBlock), 0,
                      spmv_stream(ctx, stream), p, num_non_zeros, rowptr, colind,
                      values);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_csr_lower_split_count(spmv_hip_ctx* ctx, int32_t num_rows,
+                                   const int32_t* rowptr, const int32_t* colind,
+                                   int32_t* lower_rowptr, int64_t* host_nnz,
+                                   void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(num_rows >= 0 && rowptr && lower_rowptr && host_nnz);
+  hipStream_t st = spmv_stream(ctx, stream);
+  const int n1 = num_rows + 1;
+  hipLaunchKernelGGL(lower_count_kernel, dim3(spmv_grid_for(ctx, n1, kBlock)),
+                     dim3(kBlock), 0, st, num_rows, rowptr, colind, lower_rowptr);
+  SPMV_CHECK_LAUNCH();
+  void* tmp = nullptr;
+  size_t tb = 0;
+  hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, tb, lower_rowptr,
+                                                  lower_rowptr, n1, st);
+  if (e == hipSuccess)
+    e = hipMalloc(&tmp, tb ? tb : 16);
+  if (e == hipSuccess)
+    e = hipcub::DeviceScan::ExclusiveSum(tmp, tb, lower_rowptr, lower_rowptr, n1, st);
+  int32_t total = 0;
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(&total, lower_rowptr + num_rows, sizeof(int32_t),
+                       hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st);
+  (void)hipFree(tmp);
+  if (e != hipSuccess)
+    return static_cast<int>(e);
+  *host_nnz = total; // (a subset of an int32-indexed block)
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_csr_lower_split_fill_f64(spmv_hip_ctx* ctx, int32_t num_rows,
+                                      const int32_t* rowptr, const int32_t* colind,
+                                      const double* values,
+                                      const int32_t* lower_rowptr,
+                                      int32_t* lower_colind, double* lower_values,
+                                      double* diagonal, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(num_rows >= 0 && rowptr && lower_rowptr && diagonal);
+  if (num_rows == 0)
+    return SPMV_HIP_OK;
+  hipLaunchKernelGGL(lower_fill_kernel, dim3(spmv_grid_for(ctx, num_rows, kBlock / 64)),
+                     dim3(kBlock), 0, spmv_stream(ctx, stream), num_rows, rowptr,
+                     colind, values, lower_rowptr, lower_colind, lower_values,
+                     diagonal);
   SPMV_CHECK_LAUNCH();
   return SPMV_HIP_OK;
 }

@@ -352,6 +352,19 @@ int spmvh_matrix_create_fem_like(spmvh_comm* comm, spmvh_exec* exec,
   });
 }
 
+int spmvh_matrix_create_fem_like_sym(spmvh_comm* comm, spmvh_exec* exec,
+                                     const struct spmv_hip_fem_params* params,
+                                     spmvh_matrix** A)
+{
+  return guarded([&] {
+    require(comm && exec && A && params, "NULL argument");
+    auto m = std::make_unique<spmvh_matrix>();
+    m->A.reset(
+        Matrix<double>::create_fem_like(comm->comm, exec->hip, *params, true));
+    *A = m.release();
+  });
+}
+
 int spmvh_matrix_create_poisson3d_boxes(spmvh_comm* comm, spmvh_exec* exec,
                                         int32_t n, int px, int py, int pz,
                                         int symmetric, int cm, spmvh_matrix** A)

@@ -659,7 +659,8 @@ Matrix<T>* Matrix<T>::create_unstructured(std::shared_ptr<const Comm> comm,
 template <typename T>
 Matrix<T>* Matrix<T>::create_fem_like(std::shared_ptr<const Comm> comm,
                                       std::shared_ptr<DeviceExecutor> exec,
-                                      const spmv_hip_fem_params& params)
+                                      const spmv_hip_fem_params& params,
+                                      bool symmetric)
 {
   if constexpr (!std::is_same<T, double>::value) {
     throw std::runtime_error("create_fem_like is available for double only");
@@ -688,6 +689,30 @@ Matrix<T>* Matrix<T>::create_fem_like(std::shared_ptr<const Comm> comm,
       throw;
     }
     const int32_t n32 = static_cast<int32_t>(nrows);
+    if (symmetric) { // strictly lower block + diagonal of the generated matrix
+      DeviceBlock l;
+      try {
+        l.rowptr = hip->alloc<int32_t>(nrows + 1);
+        throw_on_error(spmv_hip_csr_lower_split_count(hip->context(), n32, b.rowptr,
+                                                      b.colind, l.rowptr, &l.nnz,
+                                                      nullptr),
+                       "spmv_hip_csr_lower_split_count");
+        l.colind = hip->alloc<int32_t>(l.nnz > 0 ? l.nnz : 1);
+        l.values = hip->alloc<double>(l.nnz > 0 ? l.nnz : 1);
+        l.diagonal = hip->alloc<double>(nrows);
+        throw_on_error(spmv_hip_csr_lower_split_fill_f64(
+                           hip->context(), n32, b.rowptr, b.colind, b.values, l.rowptr,
+                           l.colind, l.values, l.diagonal, nullptr),
+                       "spmv_hip_csr_lower_split_fill_f64");
+        hip->synchronize();
+      } catch (...) {
+        release(*hip, l);
+        release(*hip, b);
+        throw;
+      }
+      release(*hip, b);
+      b = l;
+    }
     auto col_map = std::make_shared<L2GMap>(comm, n32, std::vector<int64_t>(),
                                             exec);
     auto row_map = std::make_shared<L2GMap>(comm, n32, std::vector<int64_t>(),
@@ -696,11 +721,16 @@ Matrix<T>* Matrix<T>::create_fem_like(std::shared_ptr<const Comm> comm,
     A->_exec = exec;
     A->_col_map = col_map;
     A->_row_map = row_map;
-    A->_symmetric = false;
+    A->_symmetric = symmetric;
     using Adopt = typename CSRMatrix<T>::AdoptDevice;
     A->_mat_local.reset(new CSRMatrix<T>(Adopt{}, exec, n32, n32, b.nnz, b.rowptr,
-                                         b.colind, b.values, nullptr, false));
+                                         b.colind, b.values, b.diagonal, symmetric));
     A->_nnz = b.nnz;
+    if (symmetric) { // symmetric storage always has its (here: empty) remote block
+      A->_mat_remote.reset(new CSRMatrix<T>(Adopt{}, exec, n32, n32, 0, nullptr,
+                                            nullptr, nullptr, nullptr, false));
+      A->_nnz = 2 * b.nnz + n32; // Matrix.cpp:443-444
+    }
     return A.release();
   }
 }

@@ -132,10 +132,13 @@ public:
 
   // Seeded FEM-like test matrix generated on the device (spmv_hip_fem_count /
   // _fill_f64: ragged rows, optionally a tail of very long ones, in a
-  // bandwidth-reducing order): one rank only, general storage, ONE block.
+  // bandwidth-reducing order): one rank only, ONE block.  symmetric: the
+  // strictly lower part and the diagonal of that matrix in symmetric storage
+  // (spmv_hip_csr_lower_split_*: the rule of Matrix.cpp:337-349 on the device).
   static Matrix<T>* create_fem_like(std::shared_ptr<const Comm> comm,
                                     std::shared_ptr<DeviceExecutor> exec,
-                                    const spmv_hip_fem_params& params);
+                                    const spmv_hip_fem_params& params,
+                                    bool symmetric = false);
 
   // The same matrix on a 3-D BLOCK partition (the reference has
   // row slabs only): the n^3 grid is cut into px * py * pz boxes (sizes by the

@@ -60,6 +60,7 @@ _PROTOS = {
     "spmvh_matrix_create_unstructured": [vp, vp, i64, C.c_int, i64, C.c_int,
                                          C.c_uint64, PTR(vp)],
     "spmvh_matrix_create_fem_like": [vp, vp, vp, PTR(vp)],
+    "spmvh_matrix_create_fem_like_sym": [vp, vp, vp, PTR(vp)],
     "spmvh_matrix_create_poisson3d_boxes": [vp, vp, i32, C.c_int, C.c_int,
                                             C.c_int, C.c_int, C.c_int, PTR(vp)],
     "spmvh_poisson3d_box_rows": [i32, C.c_int, C.c_int, C.c_int, C.c_int, vp,
@@ -400,14 +401,16 @@ class Matrix:
         return cls(h)
 
     @classmethod
-    def create_fem_like(cls, comm, exec_, nrows, **params):
+    def create_fem_like(cls, comm, exec_, nrows, symmetric=False, **params):
         """Seeded FEM-like test matrix (ragged rows, optional tail of very long
         rows, bandwidth-reducing order), generated on the device (one rank;
-        numpy twin and parameters: spmv_amd.poisson.fem_like_csr)."""
+        numpy twin and parameters: spmv_amd.poisson.fem_like_csr).  symmetric:
+        its strictly lower part + diagonal in symmetric storage."""
         from .poisson import fem_params
         h = vp()
         p = FemParams(**fem_params(nrows, **params))
-        call("spmvh_matrix_create_fem_like", comm.h, exec_.h, C.byref(p),
+        call("spmvh_matrix_create_fem_like_sym" if symmetric
+             else "spmvh_matrix_create_fem_like", comm.h, exec_.h, C.byref(p),
              C.byref(h))
         return cls(h)
 

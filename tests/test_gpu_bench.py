@@ -94,8 +94,8 @@ def test_bench_single_gpu_line():
     assert d["north_star_spmv"]["form"]["lat"] == 1
     # the kernels of matrices WITHOUT lattice structure, measured and checked
     assert d["csr_rowblock_spmv"]["form"] == dict(lat=0, lx=0, lxw=0, sjds=0,
-                                                  wdia=0, wdia_const=0, wdia_hbox=0,
-                                                  slat=0,
+                                                  sym_sj=0, wdia=0, wdia_const=0,
+                                                  wdia_hbox=0, slat=0,
                                                   sdia=0, sdia_const=0, sym_det=0,
                                                   zwalk=0)
     assert d["csr_sjds_spmv"]["form"]["sjds"] == 1
@@ -111,6 +111,12 @@ def test_bench_single_gpu_line():
     assert d["roofline"]["general_cg_iters_per_s"] > 0
     # ragged rows: the sliced jagged form, bit-equal to the reference loop
     rg = d["roofline"]["ragged"]
+    # ... and in symmetric storage both blocks of it, bit-equal to the
+    # transposed-map kernel
+    fs = rg["fem_sym_spmv"]
+    assert fs["bit_equal_transposed_map_kernel"] is True and fs["frac"] > 0
+    assert d["fem_sym_spmv"]["form"]["sym_sj"] == 1 and "symmetric" in fs["kernel"]
+    assert 5 < d["fem_sym_spmv"]["nnz_stored"] / d["fem_sym_spmv"]["rows"] < 9
     for k in ("fem_spmv", "fem_tail_spmv", "fem81_spmv", "unstructured_spmv"):
         assert rg[k]["bit_equal_one_lane_per_row"] is True and rg[k]["frac"] > 0
         assert d[k]["rows"] == 200000 and d[k]["crosscheck"]["bit_equal"] is True

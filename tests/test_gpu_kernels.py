@@ -1084,6 +1084,42 @@ def test_fem_like_generator_matches_numpy_twin(ctx, kind):
         hip.call("spmv_hip_fem_count", ctx.h, C.byref(bad), 1, C.byref(nnz), None)
 
 
+def test_lower_split_on_the_device_matches_the_host_rule(ctx):
+    """spmv_hip_csr_lower_split_count / _fill_f64 (symmetric storage from a
+    general block: entries below the diagonal kept in order, diagonal entries
+    summed, the rest dropped -- spmv/Matrix.cpp:337-349) against the numpy
+    restatement tests/util.py:lower_split: same arrays.  Ragged rows, repeated
+    diagonal entries, unsorted columns, rows longer than a wave, empty rows."""
+    rng = np.random.default_rng(0x10E5)
+    cases = [poisson.fem_like_csr(5000, jitter=64, layer=300, tail_permille=20,
+                                  tail_min=100, tail_max=400, tail_stride=2),
+             random_csr(rng, 1500, 1500, 9, long_rows=3, long_len=700)]
+    rp, ci, va = random_csr(rng, 800, 800, 12)
+    rows = np.repeat(np.arange(800), np.diff(rp))
+    ci = ci.copy()
+    hit = rng.random(len(ci)) < 0.15   # repeated entries ON the diagonal
+    ci[hit] = rows[hit]
+    cases.append((rp, ci.astype(np.int32), va))
+    for rp, ci, va in cases:
+        n = len(rp) - 1
+        lrp, lci, lva, ldg = lower_split(rp, ci, va)
+        d_rp, d_ci, d_va = ctx.upload(rp, np.int32), ctx.upload(ci, np.int32), ctx.upload(va)
+        o_rp = ctx.empty(n + 1, np.int32)
+        nnz = C.c_int64()
+        hip.call("spmv_hip_csr_lower_split_count", ctx.h, n, d_rp.ptr, d_ci.ptr,
+                 o_rp.ptr, C.byref(nnz), None)
+        assert nnz.value == len(lci) and np.array_equal(o_rp.numpy(), lrp)
+        o_ci = ctx.empty(max(nnz.value, 1), np.int32)
+        o_va, o_dg = ctx.empty(max(nnz.value, 1), np.float64), ctx.empty(n, np.float64)
+        hip.call("spmv_hip_csr_lower_split_fill_f64", ctx.h, n, d_rp.ptr, d_ci.ptr,
+                 d_va.ptr, o_rp.ptr, o_ci.ptr, o_va.ptr, o_dg.ptr, None)
+        assert np.array_equal(o_ci.numpy()[:nnz.value], lci)
+        assert np.array_equal(o_va.numpy()[:nnz.value], lva)
+        assert np.array_equal(o_dg.numpy(), ldg)
+        for b in (d_rp, d_ci, d_va, o_rp, o_ci, o_va, o_dg):
+            b.free()
+
+
 # ---------------------------------------------------------------------------
 # CG building blocks: drive the kernels exactly as spmv::cg does and compare
 # with the oracle's CG (cg.cpp:21-98)
