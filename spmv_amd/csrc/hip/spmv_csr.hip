@@ -1452,10 +1452,21 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
     // lower triangular): the symmetric lattice form when the matrix has it,
     // else the transposed map
     int rc = SPMV_HIP_OK;
+    const bool trace = getenv("SPMV_PLAN_TRACE") != nullptr;
+    auto mark = [&](const char* what) {
+      if (trace)
+        fprintf(stderr, "plan_create %-10s %8.3f ms\n", what,
+                std::chrono::duration<double, std::milli>(
+                    std::chrono::steady_clock::now() - t_begin)
+                    .count());
+    };
+    mark("begin");
     if (num_non_zeros >= ctx->lat_min_nnz)
       rc = spmv_slat_build(pl, rowptr, colind);
+    mark("slat");
     if (rc == SPMV_HIP_OK && !pl->slat)
       rc = spmv_symt_build(pl, rowptr, colind);
+    mark("symt");
     if (rc != SPMV_HIP_OK) {
       spmv_hip_csr_plan_destroy(pl);
       return rc;

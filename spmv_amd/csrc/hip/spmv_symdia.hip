@@ -52,6 +52,8 @@
 // LDS slots, all value windows of the NEXT row block by LDS-DMA, x / mask / y0
 // of the next block into registers, one barrier per block.
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "csr_plan.h"
@@ -1552,6 +1554,15 @@ int sdia_bake(spmv_hip_csr_plan* pl, const T* values, const T* diagonal,
 {
   SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
   const auto t_begin = std::chrono::steady_clock::now();
+  // SPMV_PLAN_TRACE=1: the phases' wall times on stderr
+  const bool trace = getenv("SPMV_PLAN_TRACE") != nullptr;
+  auto mark = [&](const char* what) {
+    if (trace)
+      fprintf(stderr, "sdia_bake %-12s %8.3f ms\n", what,
+              std::chrono::duration<double, std::milli>(
+                  std::chrono::steady_clock::now() - t_begin)
+                  .count());
+  };
   const bool had = pl->sdia_val != nullptr;
   SPMV_REQUIRE((values == nullptr && diagonal == nullptr)
                || (values
@@ -1563,6 +1574,7 @@ int sdia_bake(spmv_hip_csr_plan* pl, const T* values, const T* diagonal,
   // a new copy must therefore leave the CSR-order kernel's table: untouched
   // when there was no copy (`had` false), rebuilt when there was one.
   sdia_free_arrays(pl);
+  mark("freed");
   auto unchanged = [&](int rc) {
     if (had) {
       spmv_zwalk_free(pl);
@@ -1633,13 +1645,16 @@ int sdia_bake(spmv_hip_csr_plan* pl, const T* values, const T* diagonal,
       pl->sdia_general = general ? 2 : 0;
       pl->sdia_const = 1; // (sdia_grid reads it)
     } else {
+      mark("const probe");
       if (rc == SPMV_HIP_OK && general) {
         bool symmetric = false;
         rc = sdia_is_symmetric<T>(pl, values, st, &symmetric);
         pl->sdia_general = symmetric ? 1 : 2;
       }
+      mark("symmetry");
       if (rc == SPMV_HIP_OK)
         rc = sdia_fill<T>(pl, general, values, diagonal, st, &sval, &cm, &len);
+      mark("fill");
     }
     if (rc != SPMV_HIP_OK) {
       pl->sdia_general = 0;

@@ -28,6 +28,7 @@ run unstructured_spmv 10000000 tools/prof_matrix.py --kind unstructured --rows 1
 run fem_spmv 10000000 tools/prof_matrix.py --kind fem --rows 10000000
 run fem_tail_spmv 10000000 tools/prof_matrix.py --kind fem_tail --rows 10000000
 run fem81_spmv 10000000 tools/prof_matrix.py --kind fem81 --rows 10000000
+run fem_sym_spmv 10000000 tools/prof_matrix.py --kind fem_sym --rows 10000000
 run csr_order 512 tools/prof_spmv.py --n 512 --reps 6 --no-lat --dot
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/rp_$R

@@ -15,7 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--kind", default="unstructured",
                     choices=["unstructured", "stencil27", "fem", "fem_tail",
-                             "fem81"])
+                             "fem81", "fem_sym"])
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--n", type=int, default=256)
     ap.add_argument("--reps", type=int, default=6)
@@ -32,7 +32,8 @@ def main():
         N = args.rows
     elif args.kind.startswith("fem"):
         kw = {"fem": dict(), "fem_tail": dict(tail_permille=10),
-              "fem81": dict(min_len=81, max_len=81)}[args.kind]
+              "fem81": dict(min_len=81, max_len=81),
+              "fem_sym": dict(symmetric=True)}[args.kind]
         A = host.Matrix.create_fem_like(comm, exec_, args.rows, **kw)
         N = args.rows
     else:
