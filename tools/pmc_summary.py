@@ -14,7 +14,16 @@ KEEP = ("csr_", "dot_partial", "fill_const")
 
 
 def short(name):
-    for k in ("csr_sjds_long_kernel", "csr_sjds_kernel", "csr_box27_half_kernel", "csr_box27_const_kernel", "csr_const_dia_tile_kernel", "csr_const_dia_kernel", "csr_lxw_kernel",
+    # the two passes of symmetric storage in the sliced jagged form are launches
+    # of one template (its last argument: 1 = lower block, 2 = transposed block)
+    if "csr_sjds_kernel<" in name:
+        args = name.split("csr_sjds_kernel<", 1)[1].split(">(", 1)[0]
+        mode = args.rsplit(",", 1)[-1].strip()
+        if mode == "1":
+            return "csr_sjds_kernel sym lower"
+        if mode == "2":
+            return "csr_sjds_kernel sym transposed"
+    for k in ("csr_sjds_longt_kernel", "csr_sjds_long_kernel", "csr_sjds_kernel", "csr_box27_half_kernel", "csr_box27_const_kernel", "csr_const_dia_tile_kernel", "csr_const_dia_kernel", "csr_lxw_kernel",
               "csr_wdia_kernel", "csr_lattice_kernel", "csr_sym_lattice_kernel", "csr_sym_dia_kernel", "csr_rowblock_lx_kernel",
               "csr_rowblock_kernel", "csr_symt_kernel", "csr_sym_window_kernel",
               "dot_partial_kernel", "fill_const_kernel"):
