@@ -54,6 +54,10 @@ struct spmv_hip_ctx {
   int sj_wpb = 0;
   // ... and this many entries per lane and step ("sj_unit": 1, 2, 4; 0 = choose)
   int sj_unit = 0;
+  // symmetric storage takes the sliced jagged form only while the long rows
+  // of its two blocks (which stay inside the slices there) hold at most this
+  // share of the entries ("sym_sj_long_permille")
+  int sym_sj_long_permille = 50;
   // one-sided halo: how long a put kernel polls for its neighbour before the
   // exchange fails with SPMV_HIP_EPEER ("put_timeout_ms")
   int put_timeout_ms = 60000;

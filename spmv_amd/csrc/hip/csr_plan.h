@@ -489,6 +489,8 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
                     const int32_t* colind, int wpb_force, int unit_force,
                     int no_long);
 void spmv_sjds_free(spmv_hip_csr_plan* pl);
+int spmv_sjds_long_entries(spmv_hip_ctx* ctx, int32_t num_rows, int64_t nnz,
+                           const int32_t* rowptr, int64_t* entries, hipStream_t st);
 // values == nullptr: drop the copy; map: entry e is values[map[e]]
 int spmv_sjds_bake_f64(spmv_hip_csr_plan* pl, const double* values,
                        const int32_t* map, hipStream_t st);

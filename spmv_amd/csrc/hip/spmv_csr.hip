@@ -1317,6 +1317,18 @@ static int sym_sj_bake(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan, const T* valu
     return SPMV_HIP_ENOTSUP;
   const auto t0 = std::chrono::steady_clock::now();
   if (!plan->sj_lenperm) {
+    // long rows stay inside the slices in this form (and a slice runs as long
+    // as its longest row): a matrix with more than a few of them -- rows of
+    // the lower block, or columns = rows of its transpose -- keeps the
+    // transposed-map kernel
+    int64_t la = 0, lb = 0;
+    int rl = spmv_sjds_long_entries(ctx, plan->num_rows, plan->nnz, plan->rowptr0, &la, st);
+    if (rl == SPMV_HIP_OK)
+      rl = spmv_sjds_long_entries(ctx, plan->num_rows, plan->nnz, plan->t_ptr, &lb, st);
+    if (rl != SPMV_HIP_OK)
+      return rl;
+    if ((la + lb) * 1000 > (int64_t)ctx->sym_sj_long_permille * 2 * plan->nnz)
+      return SPMV_HIP_ENOTSUP;
     const int rb = spmv_sjds_build(plan, plan->rowptr0, plan->colind0, ctx->sj_wpb, 2, 1);
     if (rb != SPMV_HIP_OK)
       return rb;

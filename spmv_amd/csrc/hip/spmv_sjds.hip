@@ -2054,6 +2054,54 @@ int sj_bake(spmv_hip_csr_plan* pl, const T* values, const int32_t* map, hipStrea
 
 } // namespace
 
+namespace
+{
+struct SjLongEntries {
+  const int32_t* rowptr;
+  int thr;
+  int64_t nnz;
+  __device__ int64_t operator()(int i) const
+  {
+    const int32_t a = rowptr[i], b = rowptr[i + 1];
+    return sj_is_long(a, b, thr, nnz) ? (int64_t)(b - a) : 0;
+  }
+};
+} // namespace
+
+// entries in the rows the general form would take out of the slices as LONG
+// (more than four times the average and more than 96 entries)
+int spmv_sjds_long_entries(spmv_hip_ctx* ctx, int32_t num_rows, int64_t nnz,
+                           const int32_t* rowptr, int64_t* entries, hipStream_t st)
+{
+  *entries = 0;
+  if (num_rows < 1 || nnz < 1)
+    return SPMV_HIP_OK;
+  int thr = (int)(nnz * 4 / num_rows);
+  thr = thr > kSjLongMin ? thr : kSjLongMin;
+  hipcub::CountingInputIterator<int32_t> first(0);
+  hipcub::TransformInputIterator<int64_t, SjLongEntries,
+                                 hipcub::CountingInputIterator<int32_t>>
+      it(first, SjLongEntries{rowptr, thr, nnz});
+  int64_t* d_sum = nullptr;
+  void* tmp = nullptr;
+  size_t tb = 0;
+  hipError_t e = hipMalloc(&d_sum, sizeof(int64_t));
+  if (e == hipSuccess)
+    e = hipcub::DeviceReduce::Sum(nullptr, tb, it, d_sum, num_rows, st);
+  if (e == hipSuccess)
+    e = hipMalloc(&tmp, tb ? tb : 16);
+  if (e == hipSuccess)
+    e = hipcub::DeviceReduce::Sum(tmp, tb, it, d_sum, num_rows, st);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(entries, d_sum, sizeof(int64_t), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st);
+  (void)hipFree(tmp);
+  (void)hipFree(d_sum);
+  (void)ctx;
+  return e == hipSuccess ? SPMV_HIP_OK : static_cast<int>(e);
+}
+
 void spmv_sjds_free(spmv_hip_csr_plan* pl)
 {
   (void)hipFree(pl->sj_lenperm);
