@@ -293,6 +293,8 @@ struct spmv_hip_csr_plan {
   unsigned char* sj_codes = nullptr; // column codes in jagged order
   void* sj_val = nullptr;        // the values in jagged order (plan_bake_values)
   const void* sj_values0 = nullptr;
+  void* sj_val32 = nullptr;      // ... and their fp32 twin (plan_bake_values_f32f64:
+  const void* sj32_values0 = nullptr; // the mixed-precision SpMV)
   int sj_elem = 0;               // sizeof the baked value type
   int sj = 0;                    // use it (plan_set "sjds")
   bool sj_wanted = false;        // plan_bake_values builds it when the diagonal
@@ -496,6 +498,9 @@ int spmv_sjds_bake_f64(spmv_hip_csr_plan* pl, const double* values,
                        const int32_t* map, hipStream_t st);
 int spmv_sjds_bake_f32(spmv_hip_csr_plan* pl, const float* values, const int32_t* map,
                        hipStream_t st);
+int spmv_sjds_bake_f32f64(spmv_hip_csr_plan* pl, const float* values32, hipStream_t st);
+int spmv_sjds_run_f32f64(const spmv_hip_csr_plan* pl, hipStream_t st, double alpha,
+                         const double* in, double beta, double* out, DotOut dot);
 int spmv_sjds_run_sym_f64(const spmv_hip_csr_plan* pl, hipStream_t st,
                           const double* diagonal, double alpha, const double* in,
                           double beta, double* out, DotOut dot);

@@ -1114,6 +1114,10 @@ int run_mixed(const spmv_hip_csr_plan* pl, hipStream_t st,
   if (pl->wdia && pl->wdia32_val && values == pl->wdia32_values0)
     return spmv_wdia_run_f32f64(pl, st, alpha, in, beta, out,
                                 DOT ? dot : DotOut());
+  // ... or in sliced jagged order (spmv_sjds.hip)
+  if (pl->sj && pl->sj_val32 && values == pl->sj32_values0 && aligned16(in)
+      && pl->num_cols >= 2)
+    return spmv_sjds_run_f32f64(pl, st, alpha, in, beta, out, DOT ? dot : DotOut());
   if (pl->lat && aligned16(values))
     return spmv_lat_run_f32f64(pl, st, rowptr, values, alpha, in, beta, out,
                                DOT ? dot : DotOut());
@@ -1613,11 +1617,16 @@ int spmv_hip_csr_plan_bake_values_f32f64(spmv_hip_ctx* ctx,
   SPMV_SET_DEVICE(ctx);
   SPMV_REQUIRE(plan && plan->ctx == ctx);
   hipStream_t st = spmv_stream(ctx, stream);
-  // whichever form holds the fp64 values by offset gets its fp32 twin
+  // whichever form holds the fp64 values (by offset, in jagged order) gets
+  // its fp32 twin
+  if (plan->sj_val && !plan->symmetric && !plan->sdia_val && !plan->wdia_val)
+    return spmv_sjds_bake_f32f64(plan, values32, st);
   if (plan->wdia_val && !plan->sdia_val)
     return spmv_wdia_bake_f32f64(plan, values32, st);
-  if (values32 == nullptr)
+  if (values32 == nullptr) {
     (void)spmv_wdia_bake_f32f64(plan, nullptr, st);
+    (void)spmv_sjds_bake_f32f64(plan, nullptr, st);
+  }
   return spmv_sdia_bake_f32f64(plan, values32, st);
 }
 
@@ -1637,6 +1646,10 @@ int spmv_hip_csr_plan_values_changed(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan,
                                   nullptr, st)
              : spmv_sjds_bake_f32(plan, static_cast<const float*>(plan->sj_values0),
                                   nullptr, st);
+    // (the fp32 twin of the mixed SpMV)
+    if (rc == SPMV_HIP_OK && plan->sj_val32 && plan->sj32_values0)
+      rc = spmv_sjds_bake_f32f64(plan, static_cast<const float*>(plan->sj32_values0),
+                                 st);
     // (symmetric storage: the transposed block's copy from the same values)
     if (rc == SPMV_HIP_OK && plan->sjt && plan->sjt->sj_val)
       rc = plan->sj_elem == 8
@@ -1924,6 +1937,8 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
                      && plan->sjt->sj_val
                  ? 1
                  : 0;
+  else if (!strcmp(key, "sj_mixed")) // the fp32 twin of the jagged copy is baked
+    *value = plan->sj && plan->sj_val32 ? 1 : 0;
   else if (!strcmp(key, "sj_built"))
     *value = plan->sj_lenperm ? 1 : 0;
   else if (!strcmp(key, "sj_wpb"))
@@ -2002,6 +2017,8 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
            + 4 * plan->sj_lt_entries + 16 * (int64_t)plan->sj_lt_nsg;
     if (plan->sj_val)
       b += (int64_t)plan->sj_elem * plan->sj_units * plan->sj_unit;
+    if (plan->sj_val32)
+      b += 4 * plan->sj_units * plan->sj_unit;
     if (plan->sjt && plan->sjt->sj_lenperm) { // the transposed block's structure
       const spmv_hip_csr_plan* c = plan->sjt;
       b += 4 * ((n + 63) / 64 * 64) + 8 * (int64_t)c->sj_nblk

@@ -46,6 +46,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <chrono>
+#include <type_traits>
 
 namespace
 {
@@ -482,7 +483,9 @@ __global__ __launch_bounds__(kBlock) void sj_long_key_kernel(
 // ---------------------------------------------------------------------------
 // the SpMV kernel
 // ---------------------------------------------------------------------------
-template <typename T>
+// TV: the type of the stored values (fp32 under fp64 vectors and arithmetic:
+// the mixed-precision SpMV)
+template <typename T, typename TV = T>
 struct SjArgs {
   int32_t num_rows, num_cols;
   int32_t nblk;
@@ -495,7 +498,7 @@ struct SjArgs {
   const int32_t* blk;     // per block: chunks, wide
   const int32_t* chunks;
   const unsigned char* codes;
-  const T* val;           // jagged order
+  const TV* val;          // jagged order
   // long rows (phase 0): straight from the caller's CSR arrays
   int32_t phases; // measurement only (plan_set "sj_phases"): 1 = long rows, 2 = slices
   int32_t nlong;
@@ -503,7 +506,7 @@ struct SjArgs {
   int32_t long_panel;  // ... of this many columns
   const int32_t* long_rows;
   const int32_t* colind;
-  const T* values;
+  const TV* values;
   // the table-driven long-row kernel (csr_sjds_longt_kernel)
   const int32_t* lt_cmin;
   const int32_t* lt_np;
@@ -541,8 +544,8 @@ __device__ __forceinline__ float sj_readlane<float>(float v, int j)
 // general matrix; 1 = the strictly lower block, the sum starts at d_i x_i;
 // 2 = its transpose, the sum starts at the y the lower pass left and every
 // product is fl(fl(alpha v) x) -- the reference's out[col] += alpha * val * in[i].
-template <typename T, typename CODE, bool WIDE, int E, int MODE>
-__device__ __forceinline__ T sj_slice(const SjUnit<T, E>* __restrict__ vs,
+template <typename T, typename TV, typename CODE, bool WIDE, int E, int MODE>
+__device__ __forceinline__ T sj_slice(const SjUnit<TV, E>* __restrict__ vs,
                                       const SjUnit<CODE, E>* __restrict__ cs,
                                       int32_t mylen, int lane,
                                       const T* __restrict__ s_x,
@@ -558,7 +561,7 @@ __device__ __forceinline__ T sj_slice(const SjUnit<T, E>* __restrict__ vs,
   const int32_t kmain = (maxlen - u1 * E >= kSjTailMin) ? u1 : maxu; // units
   const int32_t mymain = myu < kmain ? myu : kmain;
   T sum = init;
-  SjUnit<T, E> va[U], vc[U];
+  SjUnit<TV, E> va[U], vc[U];
   SjUnit<CODE, E> ca[U], cc[U];
   uint32_t off = 0; // units behind the slice's first (uniform)
 
@@ -612,7 +615,7 @@ __device__ __forceinline__ T sj_slice(const SjUnit<T, E>* __restrict__ vs,
     _Pragma("unroll") for (int u = 0; u < U; ++u)                              \
         _Pragma("unroll") for (int q = 0; q < E; ++q)                          \
     {                                                                          \
-      const T vq = MODE == 2 ? alpha * V[u].e[q] : V[u].e[q];                  \
+      const T vq = MODE == 2 ? alpha * (T)V[u].e[q] : (T)V[u].e[q];            \
       const T nxt = sum + vq * xs[u][q];                                       \
       const bool use = (K0) + u < mymain && ((K0) + u) * E + q < mylen;        \
       sum = use ? nxt : sum;                                                   \
@@ -640,12 +643,12 @@ __device__ __forceinline__ T sj_slice(const SjUnit<T, E>* __restrict__ vs,
     // wave loads and multiplies 64 at a time; the products are added to the
     // row's sum one by one, in order (every lane computes the same sum).
     const int32_t rem = maxlen - kmain * E;
-    const T* vt = reinterpret_cast<const T*>(vs + off);
+    const TV* vt = reinterpret_cast<const TV*>(vs + off);
     const CODE* ct = reinterpret_cast<const CODE*>(cs + off);
     T t = sj_readlane<T>(sum, 0);
     for (int32_t j0 = 0; j0 < rem; j0 += 64) {
       const int32_t j = j0 + lane < rem ? j0 + lane : 0;
-      const T v = vt[j];
+      const T v = (T)vt[j];
       T x;
       if constexpr (WIDE) {
         const uint32_t c = (uint32_t)ct[j];
@@ -694,8 +697,8 @@ constexpr int kSjPanelU = SJ_PANEL_U; // steps per trip of the panel walk
 // the panels' bytes
 constexpr int kSjLongSets = SJ_LONG_SETS;
 constexpr int kSjLU = 4; // steps per load group of the long-row phase
-template <typename T>
-__device__ __forceinline__ T sj_long_rows8(const T* __restrict__ val,
+template <typename T, typename TV>
+__device__ __forceinline__ T sj_long_rows8(const TV* __restrict__ val,
                                           const int32_t* __restrict__ col,
                                           int64_t a, int64_t b, int lane,
                                           const T* __restrict__ in)
@@ -766,9 +769,9 @@ __device__ __forceinline__ T sj_long_rows8(const T* __restrict__ val,
 
 // The LONG rows (a launch of its own behind the slices' kernel: its registers
 // are its own).  WPB waves per workgroup, eight rows per wave.
-template <typename T, int WPB, bool DOT, bool PANELS>
+template <typename T, typename TV, int WPB, bool DOT, bool PANELS>
 __global__ __launch_bounds__(64 * WPB) void csr_sjds_long_kernel(
-    SjArgs<T> A, T alpha, const T* __restrict__ in, T beta, T* __restrict__ out,
+    SjArgs<T, TV> A, T alpha, const T* __restrict__ in, T beta, T* __restrict__ out,
     DotOut dot, int dot_slot0)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
@@ -848,7 +851,7 @@ __global__ __launch_bounds__(64 * WPB) void csr_sjds_long_kernel(
       if constexpr (!PANELS) {
 #pragma unroll
         for (int h = 0; h < RS; ++h)
-          sum[h] = sj_long_rows8<T>(A.values, A.colind, ra[h], rb[h], lane, in);
+          sum[h] = sj_long_rows8<T, TV>(A.values, A.colind, ra[h], rb[h], lane, in);
       } else if (!by_panels) { // rows that are not neighbours in x: rare, slow
 #pragma unroll
         for (int h = 0; h < RS; ++h)
@@ -894,7 +897,7 @@ __global__ __launch_bounds__(64 * WPB) void csr_sjds_long_kernel(
             const int64_t rbh = rb[h];
             T acc = sum[h];
             {
-              const T* vp = A.values + eh + l;
+              const TV* vp = A.values + eh + l;
               const int32_t* cp = A.colind + eh + l;
 #pragma unroll
               for (int u = 0; u < U; ++u) {
@@ -905,7 +908,7 @@ __global__ __launch_bounds__(64 * WPB) void csr_sjds_long_kernel(
             bool more = true;
             while (__any(more)) {
               {
-                const T* vp = A.values + eh + l + U * 8;
+                const TV* vp = A.values + eh + l + U * 8;
                 const int32_t* cp = A.colind + eh + l + U * 8;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -1079,9 +1082,9 @@ constexpr int kDppRowShr1 = 0x111; // lane l <- lane l - 1
 constexpr int kDppRowShlBack = 0x100 + kSjLtG - 1; // lane l <- lane l + G - 1
 static_assert(kSjLtG == 2 || kSjLtG == 4 || kSjLtG == 8 || kSjLtG == 16, "DPP rows");
 
-template <typename T, bool DOT>
+template <typename T, typename TV, bool DOT>
 __global__ __launch_bounds__(512, 4) void csr_sjds_longt_kernel(
-    SjArgs<T> A, T alpha, const T* __restrict__ in, T beta, T* __restrict__ out,
+    SjArgs<T, TV> A, T alpha, const T* __restrict__ in, T beta, T* __restrict__ out,
     DotOut dot, int dot_slot0)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
@@ -1174,9 +1177,9 @@ __global__ __launch_bounds__(512, 4) void csr_sjds_longt_kernel(
         // D trips of loads in flight ahead of the one being consumed: a ring of
         // D + 1 register sets, the loop unrolled over it
         constexpr int D = kSjLtDepth;
-        SjPack<T, EPL> vv[D + 1];
+        SjPack<TV, EPL> vv[D + 1];
         SjPack<int32_t, EPL> cc[D + 1];
-        auto issue = [&](SjPack<T, EPL>& v, SjPack<int32_t, EPL>& c, int32_t pos) {
+        auto issue = [&](SjPack<TV, EPL>& v, SjPack<int32_t, EPL>& c, int32_t pos) {
           // (no clamp: a long row ends kSjLongPad entries before the arrays do;
           // a finished group reads entries 0 ...)
 #ifdef SJ_LT_PROBE_NOLOAD
@@ -1184,10 +1187,10 @@ __global__ __launch_bounds__(512, 4) void csr_sjds_longt_kernel(
 #else
           const int64_t e = (int64_t)pos + EPL * l;
 #endif
-          v = *reinterpret_cast<const SjPack<T, EPL>*>(A.values + e);
+          v = *reinterpret_cast<const SjPack<TV, EPL>*>(A.values + e);
           c = *reinterpret_cast<const SjPack<int32_t, EPL>*>(A.colind + e);
         };
-        auto consume = [&](const SjPack<T, EPL>& v, const SjPack<int32_t, EPL>& c,
+        auto consume = [&](const SjPack<TV, EPL>& v, const SjPack<int32_t, EPL>& c,
                            int j, int32_t pos, int32_t end) {
           T pr[EPL], xs[EPL];
 #pragma unroll
@@ -1212,7 +1215,7 @@ __global__ __launch_bounds__(512, 4) void csr_sjds_longt_kernel(
             const bool ok = pos + EPL * l + k < end;
             // a lane without an entry contributes +0.0: the sum starts at +0.0
             // and can never become -0.0, so adding it changes no bit
-            const T prod = v.e[k] * xs[k];
+            const T prod = (T)v.e[k] * xs[k];
             pr[k] = ok ? prod : T(0);
           }
           T tsum = acc[0];
@@ -1346,9 +1349,9 @@ __global__ __launch_bounds__(512, 4) void csr_sjds_longt_kernel(
   }
 }
 
-template <typename T, int WPB, int E, bool DOT, int MODE>
+template <typename T, typename TV, int WPB, int E, bool DOT, int MODE>
 __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
-    SjArgs<T> A, T alpha, const T* __restrict__ in, T beta, T* __restrict__ out,
+    SjArgs<T, TV> A, T alpha, const T* __restrict__ in, T beta, T* __restrict__ out,
     DotOut dot, RowBlockOrder ord, const T* __restrict__ diagonal)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
@@ -1454,22 +1457,23 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
     __syncthreads();
     if (have) {
       const int32_t mylen = lp >> 6;
-      const SjUnit<T, E>* vs = reinterpret_cast<const SjUnit<T, E>*>(A.val) + ub_slice;
+      const SjUnit<TV, E>* vs
+          = reinterpret_cast<const SjUnit<TV, E>*>(A.val) + ub_slice;
       const int64_t a_b = (int64_t)ub_block * E;
       T sum;
       if (wide) {
         const SjUnit<uint32_t, E>* cs
             = reinterpret_cast<const SjUnit<uint32_t, E>*>(A.codes + 4 * a_b)
               + (ub_slice - ub_block);
-        sum = sj_slice<T, uint32_t, true, E, MODE>(vs, cs, mylen, lane, s_x, in, init,
-                                                   alpha);
+        sum = sj_slice<T, TV, uint32_t, true, E, MODE>(vs, cs, mylen, lane, s_x, in,
+                                                       init, alpha);
       } else {
         const SjUnit<uint16_t, E>* cs
             = reinterpret_cast<const SjUnit<uint16_t, E>*>(
                   A.codes + (A.wide_alloc ? 4 : 2) * a_b)
               + (ub_slice - ub_block);
-        sum = sj_slice<T, uint16_t, false, E, MODE>(vs, cs, mylen, lane, s_x, in, init,
-                                                    alpha);
+        sum = sj_slice<T, TV, uint16_t, false, E, MODE>(vs, cs, mylen, lane, s_x, in,
+                                                        init, alpha);
       }
       if (myrow < A.num_rows && in_slice) {
         const T c = MODE == 2 ? sum : alpha * sum;
@@ -1542,11 +1546,12 @@ int sj_wgs_per_cu(int wpb, int64_t lds)
   return wgs < 1 ? 1 : wgs;
 }
 
-template <typename T, int WPB, int E, bool DOT, int MODE = 0>
+template <typename T, int WPB, int E, bool DOT, int MODE = 0, typename TV = T>
 int sj_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
               T beta, T* out, DotOut dot, const T* diagonal = nullptr)
 {
-  SjArgs<T> A;
+  constexpr bool kMixed = !std::is_same<T, TV>::value; // the fp32 copy of the values
+  SjArgs<T, TV> A;
   A.num_rows = pl->num_rows;
   A.num_cols = pl->num_cols;
   A.nblk = pl->sj_nblk;
@@ -1559,13 +1564,13 @@ int sj_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
   A.blk = pl->sj_blk;
   A.chunks = pl->sj_chunks;
   A.codes = pl->sj_codes;
-  A.val = static_cast<const T*>(pl->sj_val);
+  A.val = static_cast<const TV*>(kMixed ? pl->sj_val32 : pl->sj_val);
   A.phases = pl->sj_phases;
   A.nlong = pl->sj_nlong;
   A.long_sorted = pl->sj_long_sorted && pl->sj_long_panels;
   A.long_rows = pl->sj_long_rows;
   A.colind = pl->colind0;
-  A.values = static_cast<const T*>(pl->sj_values0);
+  A.values = static_cast<const TV*>(kMixed ? pl->sj32_values0 : pl->sj_values0);
   A.lt_cmin = pl->sj_lt_cmin;
   A.lt_np = pl->sj_lt_np;
   A.lt_off = pl->sj_lt_off;
@@ -1589,7 +1594,7 @@ int sj_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
   ord.num_row_blocks = pl->sj_nblk;
   ord.nt_store = 0;
   if (A.phases & 2) {
-    hipLaunchKernelGGL((csr_sjds_kernel<T, WPB, E, DOT, MODE>), dim3(grid),
+    hipLaunchKernelGGL((csr_sjds_kernel<T, TV, WPB, E, DOT, MODE>), dim3(grid),
                        dim3(64 * WPB), lds, st, A, alpha, in, beta, out, dot, ord,
                        diagonal);
     SPMV_CHECK_LAUNCH();
@@ -1615,12 +1620,12 @@ int sj_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
       static bool raised = false;
       if (!raised) {
         SPMV_CHECK_HIP(hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&csr_sjds_longt_kernel<T, DOT>),
+            reinterpret_cast<const void*>(&csr_sjds_longt_kernel<T, TV, DOT>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds));
         raised = true;
       }
     }
-    hipLaunchKernelGGL((csr_sjds_longt_kernel<T, DOT>), dim3(lgrid), dim3(512), llds,
+    hipLaunchKernelGGL((csr_sjds_longt_kernel<T, TV, DOT>), dim3(lgrid), dim3(512), llds,
                        st, A, alpha, in, beta, out, dot, (A.phases & 2) ? grid : 0);
     SPMV_CHECK_LAUNCH();
   } else if (pl->sj_nlong > 0 && (A.phases & 1)) {
@@ -1661,20 +1666,20 @@ int sj_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
       static bool raised = false;
       if (!raised) {
         SPMV_CHECK_HIP(hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&csr_sjds_long_kernel<T, LW, DOT, true>),
+            reinterpret_cast<const void*>(&csr_sjds_long_kernel<T, TV, LW, DOT, true>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds));
         SPMV_CHECK_HIP(hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&csr_sjds_long_kernel<T, LW, DOT, false>),
+            reinterpret_cast<const void*>(&csr_sjds_long_kernel<T, TV, LW, DOT, false>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds));
         raised = true;
       }
     }
     if (A.long_sorted)
-      hipLaunchKernelGGL((csr_sjds_long_kernel<T, LW, DOT, true>), dim3(lgrid),
+      hipLaunchKernelGGL((csr_sjds_long_kernel<T, TV, LW, DOT, true>), dim3(lgrid),
                          dim3(64 * LW), llds, st, A, alpha, in, beta, out, dot,
                          (A.phases & 2) ? grid : 0);
     else
-      hipLaunchKernelGGL((csr_sjds_long_kernel<T, LW, DOT, false>), dim3(lgrid),
+      hipLaunchKernelGGL((csr_sjds_long_kernel<T, TV, LW, DOT, false>), dim3(lgrid),
                          dim3(64 * LW), llds, st, A, alpha, in, beta, out, dot,
                          (A.phases & 2) ? grid : 0);
     SPMV_CHECK_LAUNCH();
@@ -1682,25 +1687,25 @@ int sj_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
   return SPMV_HIP_OK;
 }
 
-template <typename T, int E, bool DOT>
+template <typename T, int E, bool DOT, typename TV = T>
 int sj_run_e(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
              T beta, T* out, DotOut dot)
 {
   switch (pl->sj_wpb) {
-  case 4: return sj_launch<T, 4, E, DOT>(pl, st, alpha, in, beta, out, dot);
-  case 8: return sj_launch<T, 8, E, DOT>(pl, st, alpha, in, beta, out, dot);
-  default: return sj_launch<T, 16, E, DOT>(pl, st, alpha, in, beta, out, dot);
+  case 4: return sj_launch<T, 4, E, DOT, 0, TV>(pl, st, alpha, in, beta, out, dot);
+  case 8: return sj_launch<T, 8, E, DOT, 0, TV>(pl, st, alpha, in, beta, out, dot);
+  default: return sj_launch<T, 16, E, DOT, 0, TV>(pl, st, alpha, in, beta, out, dot);
   }
 }
 
-template <typename T, bool DOT>
+template <typename T, bool DOT, typename TV = T>
 int sj_run(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
            T beta, T* out, DotOut dot)
 {
   switch (pl->sj_unit) {
-  case 1: return sj_run_e<T, 1, DOT>(pl, st, alpha, in, beta, out, dot);
-  case 2: return sj_run_e<T, 2, DOT>(pl, st, alpha, in, beta, out, dot);
-  default: return sj_run_e<T, 4, DOT>(pl, st, alpha, in, beta, out, dot);
+  case 1: return sj_run_e<T, 1, DOT, TV>(pl, st, alpha, in, beta, out, dot);
+  case 2: return sj_run_e<T, 2, DOT, TV>(pl, st, alpha, in, beta, out, dot);
+  default: return sj_run_e<T, 4, DOT, TV>(pl, st, alpha, in, beta, out, dot);
   }
 }
 
@@ -2109,6 +2114,9 @@ void spmv_sjds_free(spmv_hip_csr_plan* pl)
   (void)hipFree(pl->sj_chunks);
   (void)hipFree(pl->sj_codes);
   (void)hipFree(pl->sj_val);
+  (void)hipFree(pl->sj_val32);
+  pl->sj_val32 = nullptr;
+  pl->sj32_values0 = nullptr;
   (void)hipFree(pl->sj_long_rows);
   (void)hipFree(pl->sj_ubase);
   sj_lt_free(pl);
@@ -2341,6 +2349,62 @@ int spmv_sjds_bake_f32(spmv_hip_csr_plan* pl, const float* values, const int32_t
                        hipStream_t st)
 {
   return sj_bake<float>(pl, values, map, st);
+}
+
+// Mixed precision: the fp32 twin of the jagged copy (fp64 vectors and
+// arithmetic; the long rows read the caller's fp32 CSR values).  values32 ==
+// nullptr drops it.
+int spmv_sjds_bake_f32f64(spmv_hip_csr_plan* pl, const float* values32, hipStream_t st)
+{
+  SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
+  if (values32 == nullptr) {
+    if (pl->sj_val32) {
+      SPMV_CHECK_HIP(hipDeviceSynchronize());
+      (void)hipFree(pl->sj_val32);
+    }
+    pl->sj_val32 = nullptr;
+    pl->sj32_values0 = nullptr;
+    return SPMV_HIP_OK;
+  }
+  if (!pl->sj_lenperm || !pl->sj_val || pl->sj_elem != 8 || pl->symmetric
+      || pl->nnz == 0)
+    return SPMV_HIP_ENOTSUP;
+  const auto t_begin = std::chrono::steady_clock::now();
+  if (!pl->sj_val32) {
+    const size_t entries = (size_t)(pl->sj_units + kSjSlack) * pl->sj_unit;
+    hipError_t e = hipMalloc(&pl->sj_val32, sizeof(float) * entries);
+    if (e == hipSuccess)
+      e = hipMemsetAsync(static_cast<float*>(pl->sj_val32)
+                             + (size_t)pl->sj_units * pl->sj_unit,
+                         0, sizeof(float) * (size_t)kSjSlack * pl->sj_unit, st);
+    if (e != hipSuccess) {
+      (void)hipFree(pl->sj_val32);
+      pl->sj_val32 = nullptr;
+      (void)hipGetLastError();
+      return e == hipErrorOutOfMemory ? SPMV_HIP_ENOTSUP : static_cast<int>(e);
+    }
+  }
+  const int64_t nsl = ((int64_t)pl->num_rows + 63) / 64;
+  const int grid = spmv_grid_for(pl->ctx, nsl, kBlock / 64);
+  hipLaunchKernelGGL((sj_bake_kernel<float>), dim3(grid), dim3(kBlock), 0, st,
+                     pl->num_rows, pl->rowptr0, pl->sj_lenperm, pl->sj_ubase,
+                     pl->sj_unit, values32, (const int32_t*)nullptr,
+                     static_cast<float*>(pl->sj_val32));
+  SPMV_CHECK_LAUNCH();
+  SPMV_CHECK_HIP(hipStreamSynchronize(st));
+  pl->sj32_values0 = values32;
+  pl->plan_us += (int)std::chrono::duration_cast<std::chrono::microseconds>(
+                     std::chrono::steady_clock::now() - t_begin)
+                     .count();
+  return SPMV_HIP_OK;
+}
+
+int spmv_sjds_run_f32f64(const spmv_hip_csr_plan* pl, hipStream_t st, double alpha,
+                         const double* in, double beta, double* out, DotOut dot)
+{
+  if (dot.partials)
+    return sj_run<double, true, float>(pl, st, alpha, in, beta, out, dot);
+  return sj_run<double, false, float>(pl, st, alpha, in, beta, out, dot);
 }
 
 // Symmetric storage (csr_kernels.cpp:26-40) in two passes over two sliced

@@ -951,6 +951,92 @@ def test_symmetric_storage_sliced_jagged_bit_exact(sj_ctx, wpb):
     blk.free()
 
 
+def test_mixed_precision_sliced_jagged_bit_exact(sj_ctx):
+    """plan_bake_values_f32f64 on a plan in the sliced jagged form: the fp32 twin
+    of the jagged copy (and, for the long rows, the caller's fp32 CSR values).
+    spmv_f32f64 with the baked pointer = the reference loop
+    (csr_kernels.cpp:41-51) on the fp32-rounded values in fp64, bit for bit:
+    slices, long rows by panels (table-driven) and gathered, far entries, fused
+    dot; another pointer takes the CSR-order kernels; both copies follow an
+    update in place."""
+    ctx = sj_ctx
+    rng = np.random.default_rng(0x3264)
+    cases = {"fem": poisson.fem_like_csr(6000, jitter=64, layer=400),
+             "fem_tail": poisson.fem_like_csr(30_000, jitter=64, layer=900,
+                                              tail_permille=20, tail_min=100,
+                                              tail_max=1500, tail_stride=16),
+             "ragged": random_csr(rng, 1500, 1500, 9, long_rows=2, long_len=700)}
+    rp, ci, va = random_csr(rng, 2000, 3_000_000, 8)
+    near = rng.random(len(ci)) < 0.7
+    ci[near] = rng.integers(0, 4000, int(near.sum())).astype(np.int32)
+    cases["far"] = (rp, ci, va)
+    part = ctx.empty(ctx.dot_partials_len, np.float64)
+    for name, (rp, ci, va) in cases.items():
+        nr = len(rp) - 1
+        nc = 3_000_000 if name == "far" else nr
+        va32 = va.astype(np.float32)
+        x = rng.uniform(-1, 1, nc)
+        y0 = rng.uniform(-1, 1, nr)
+        blk = hip.CsrBlock(ctx, nr, nc, rp, ci, va, None, False)
+        d32 = ctx.upload(va32, np.float32)
+        blk.bake()
+        assert blk.get("sjds") == 1 and blk.get("sj_mixed") == 0, name
+        hip.call("spmv_hip_csr_plan_bake_values_f32f64", ctx.h, blk.plan, d32.ptr, None)
+        assert blk.get("sj_mixed") == 1, name
+        if name == "fem_tail":
+            assert blk.get("sj_long_rows") > 100 and blk.get("sj_long_table") == 1
+        dx = ctx.upload(x)
+        other = ctx.upload(va32, np.float32)
+
+        def mixed(vals, alpha, beta, dot):
+            dy = ctx.upload(np.full(nr, np.nan) if beta == 0 else y0)
+            hip.call("spmv_hip_csr_spmv_f32f64", ctx.h, blk.plan, nr, nc, blk.nnz,
+                     blk.rowptr.ptr, blk.colind.ptr, vals.ptr, float(alpha), dx.ptr,
+                     float(beta), dy.ptr, part.ptr if dot else None, None)
+            y = dy.numpy()
+            dy.free()
+            return y
+        for alpha, beta in ((1.0, 0.0), (-0.5, 0.75)):
+            y_ref = oracle.csr_spmv(rp, ci, va32.astype(np.float64), x, alpha, beta, y0)
+            for vals, knobs in ((d32, dict()), (d32, dict(sj_long_table=0)),
+                                (d32, dict(sj_long_panels=0)), (other, dict())):
+                for k, v in knobs.items():
+                    blk.set(k, v)
+                dot = beta == 0 and nr == nc
+                assert np.array_equal(mixed(vals, alpha, beta, dot), y_ref), \
+                    (name, alpha, knobs, vals is other)
+                if dot:
+                    want = float(np.dot(x, y_ref))
+                    got = float(np.sum(part.numpy()))
+                    assert abs(got - want) <= 1e-11 * (np.abs(x) @ np.abs(y_ref) + 1)
+                blk.set("sj_long_table", 1)
+                blk.set("sj_long_panels", 1)
+        # the fp64 SpMV of the same plan is untouched
+        dy = ctx.upload(np.full(nr, np.nan))
+        blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+        assert np.array_equal(dy.numpy(), oracle.csr_spmv(rp, ci, va, x)), name
+        # both copies follow an update in place
+        va2 = rng.uniform(-1, 1, len(va))
+        blk.values.write(va2)
+        d32.write(va2.astype(np.float32))
+        blk.values_changed()
+        assert blk.get("sj_mixed") == 1
+        assert np.array_equal(
+            mixed(d32, 1.0, 0.0, False),
+            oracle.csr_spmv(rp, ci, va2.astype(np.float32).astype(np.float64), x))
+        blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+        assert np.array_equal(dy.numpy(), oracle.csr_spmv(rp, ci, va2, x)), name
+        hip.call("spmv_hip_csr_plan_bake_values_f32f64", ctx.h, blk.plan, None, None)
+        assert blk.get("sj_mixed") == 0
+        assert np.array_equal(
+            mixed(d32, 1.0, 0.0, False),
+            oracle.csr_spmv(rp, ci, va2.astype(np.float32).astype(np.float64), x))
+        for b in (dx, dy, d32, other):
+            b.free()
+        blk.free()
+    part.free()
+
+
 def test_plan_values_changed_after_updates_in_place():
     """spmv_hip_csr_plan_values_changed: a caller that keeps the sparsity and
     rewrites the coefficients IN PLACE (time stepping) -- three updates on every
