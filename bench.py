@@ -503,6 +503,7 @@ def timed_spmv(exec_, A, N, _lib, reps, crosscheck=False):
     if crosscheck:
         import numpy as np
         y = exec_.copy_to_host(d_y, N)
+        algo0 = A.plan_get("algo")
         if crosscheck == "symt":  # symmetric storage: the transposed-map kernel
             A.plan_set("sjds", 0)
         else:
@@ -518,6 +519,9 @@ def timed_spmv(exec_, A, N, _lib, reps, crosscheck=False):
                 A.mult(d_x, d_y)
             exec_.synchronize()
             timed_spmv.other_ms = (time.perf_counter() - t0) * 1e3 / 5
+            A.plan_set("sjds", 1)
+        else:
+            A.plan_set("algo", algo0)
     exec_.free(d_x), exec_.free(d_y)
     return (best, same) if crosscheck else best
 
@@ -1144,6 +1148,23 @@ def main():
                                         r["crosscheck"]["bit_equal"],
                                     "plan_ms": r["plan_ms"],
                                     "traffic": r.get("traffic")}
+                    if name == "fem_spmv":
+                        # ... the same product with the fp32 copy of the values
+                        # (CgOptions::mixed: fp64 vectors and arithmetic)
+                        Af.enable_mixed()
+                        Af.use_mixed(True)
+                        ms32 = timed_spmv(exec_, Af, args.fem_rows, _lib, 30)
+                        Af.use_mixed(False)
+                        ragged["fem_mixed_spmv"] = {
+                            "ms_per_apply": ms32,
+                            "speedup_over_fp64": r["ms_per_apply"] / ms32,
+                            "kernel": ("csr_sjds_kernel<double, float values>"
+                                       if Af.plan_get("sj_mixed")
+                                       else "CSR-order fp32 values"),
+                            "requested_bytes": r["nnz_stored"] * 6
+                                               + r["rows"] * 12 + r["rows"] * 8,
+                            "frac_requested": (r["nnz_stored"] * 6 + r["rows"] * 20)
+                                              / ms32 / 1e6 / HBM_PEAK_GBS}
                     Af.close()
                 # ... and the first of them in SYMMETRIC storage (its strictly
                 # lower part + diagonal, as create_matrix(symmetric = true) keeps

@@ -117,6 +117,8 @@ def test_bench_single_gpu_line():
     assert fs["bit_equal_transposed_map_kernel"] is True and fs["frac"] > 0
     assert d["fem_sym_spmv"]["form"]["sym_sj"] == 1 and "symmetric" in fs["kernel"]
     assert 5 < d["fem_sym_spmv"]["nnz_stored"] / d["fem_sym_spmv"]["rows"] < 9
+    assert rg["fem_mixed_spmv"]["ms_per_apply"] > 0
+    assert "float values" in rg["fem_mixed_spmv"]["kernel"]
     for k in ("fem_spmv", "fem_tail_spmv", "fem81_spmv", "unstructured_spmv"):
         assert rg[k]["bit_equal_one_lane_per_row"] is True and rg[k]["frac"] > 0
         assert d[k]["rows"] == 200000 and d[k]["crosscheck"]["bit_equal"] is True
