@@ -1187,6 +1187,28 @@ def main():
                     "bit_equal_transposed_map_kernel": r["crosscheck"]["bit_equal"],
                     "transposed_map_kernel_ms": getattr(timed_spmv, "other_ms", None),
                     "plan_ms": r["plan_ms"], "traffic": r.get("traffic")}
+                # ... and CG on it (strictly diagonally dominant: SPD), the
+                # reference's loop (cg.cpp:21-98) end to end on a matrix without
+                # stencil structure: 3 launches per iteration + the second pass
+                Nf = args.fem_rows
+                d_b, d_x = exec_.alloc(Nf), exec_.alloc(Nf)
+                _lib.call("spmv_hip_fill_gaussian_f64", ctx, Nf, 0, Nf, d_b, None)
+                wsf = host.CgWorkspace(exec_)
+                stepsf = min(args.steps, 30)
+                host.cg_ex(self_comm, exec_, Af, d_b, d_x, 3, 0.0, wsf)
+                exec_.synchronize()
+                t0 = time.perf_counter()
+                _, hf, _, _ = host.cg_ex(self_comm, exec_, Af, d_b, d_x, stepsf, 0.0,
+                                         wsf, history=True)
+                exec_.synchronize()
+                elf = time.perf_counter() - t0
+                ragged["fem_sym_cg"] = {
+                    "iters/s": stepsf / elf, "iterations": stepsf,
+                    "rel_residual_after": float(hf[-1] / hf[0]),
+                    "what": "cg() on the 10 M-row FEM-like matrix in symmetric "
+                            "storage, Gaussian right-hand side"}
+                wsf.close()
+                exec_.free(d_b), exec_.free(d_x)
                 Af.close()
                 out["roofline"]["ragged"] = dict(
                     ragged, note="frac = SURVEY 8d CSR bytes (12 B per entry, row "

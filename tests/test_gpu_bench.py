@@ -117,6 +117,7 @@ def test_bench_single_gpu_line():
     assert fs["bit_equal_transposed_map_kernel"] is True and fs["frac"] > 0
     assert d["fem_sym_spmv"]["form"]["sym_sj"] == 1 and "symmetric" in fs["kernel"]
     assert 5 < d["fem_sym_spmv"]["nnz_stored"] / d["fem_sym_spmv"]["rows"] < 9
+    assert rg["fem_sym_cg"]["iters/s"] > 0 and rg["fem_sym_cg"]["rel_residual_after"] < 1e-3
     assert rg["fem_mixed_spmv"]["ms_per_apply"] > 0
     assert "float values" in rg["fem_mixed_spmv"]["kernel"]
     for k in ("fem_spmv", "fem_tail_spmv", "fem81_spmv", "unstructured_spmv"):
