@@ -66,6 +66,12 @@ def parse():
                     help="symmetric-CSR storage (BASELINE configs[3]) as the "
                          "main line (the default line carries it as a "
                          "sub-record)")
+    ap.add_argument("--peer-reduce", action="store_true",
+                    help="N > 1: the two scalar reductions of a CG iteration by the "
+                         "deterministic peer reduction (Comm::enable_peer_reduce: "
+                         "one single-wave kernel per rank, values added in rank "
+                         "order) instead of RCCL's all-reduce.  Opt-in: validated "
+                         "on one device only")
     ap.add_argument("--cm", default="p2p_nonblocking",
                     choices=["p2p_blocking", "p2p_nonblocking",
                              "onesided_put_active"],
@@ -690,6 +696,11 @@ def main():
                              f"{rccl['nranks']}, expected {rank} of {world}")
     else:
         comm = host.Comm.self_comm()
+    if args.peer_reduce and args.cm.startswith("onesided"):
+        raise SystemExit("--peer-reduce goes with the two-sided halo models (the "
+                         "pair with the one-sided halo is not validated)")
+    peer_reduce = bool(world > 1 and args.peer_reduce
+                       and comm.enable_peer_reduce(exec_))
 
     def barrier():
         if world > 1:
@@ -921,6 +932,9 @@ def main():
                 out["rccl"] = {k_: rccl[k_] for k_ in
                                ("nranks", "version", "lib_path",
                                 "separate_reduction_comm")}
+            out["cg_scalar_reductions"] = (
+                "peer windows, added in rank order (spmv_hip_reduce_*)"
+                if peer_reduce else "the transport's all-reduce")
     # the main matrix is no longer needed: make room for the sub-records
     ws.close()
     A.close()
@@ -1154,13 +1168,30 @@ def main():
                         Af.enable_mixed()
                         Af.use_mixed(True)
                         ms32 = timed_spmv(exec_, Af, args.fem_rows, _lib, 30)
+
+                        def product():
+                            Nf_ = args.fem_rows
+                            d_x, d_y = exec_.alloc(Nf_), exec_.alloc(Nf_)
+                            _lib.call("spmv_hip_fill_gaussian_f64", ctx, Nf_, 0, Nf_,
+                                      d_x, None)
+                            exec_.memset(d_y, 0xFF, 8 * Nf_)
+                            Af.mult(d_x, d_y)
+                            y = exec_.copy_to_host(d_y, Nf_)
+                            exec_.free(d_x), exec_.free(d_y)
+                            return y
+                        y_sj = product()
+                        mixed_form = Af.plan_get("sj_mixed")
+                        Af.plan_set("sjds", 0)  # the CSR-order kernel, fp32 values
+                        same32 = bool(np.array_equal(y_sj, product())
+                                      and np.isfinite(y_sj).all())
+                        Af.plan_set("sjds", 1)
                         Af.use_mixed(False)
                         ragged["fem_mixed_spmv"] = {
                             "ms_per_apply": ms32,
                             "speedup_over_fp64": r["ms_per_apply"] / ms32,
                             "kernel": ("csr_sjds_kernel<double, float values>"
-                                       if Af.plan_get("sj_mixed")
-                                       else "CSR-order fp32 values"),
+                                       if mixed_form else "CSR-order fp32 values"),
+                            "bit_equal_csr_order_kernel": same32,
                             "requested_bytes": r["nnz_stored"] * 6
                                                + r["rows"] * 12 + r["rows"] * 8,
                             "frac_requested": (r["nnz_stored"] * 6 + r["rows"] * 20)

@@ -627,6 +627,40 @@ int spmv_hip_put_exchange(spmv_hip_ctx* ctx, spmv_hip_put* put, size_t elem_byte
 int spmv_hip_put_status(const spmv_hip_put* put, int* failed);
 int spmv_hip_put_destroy(spmv_hip_put* put);
 
+/* ---- deterministic peer reduction of the CG scalars -------------------------
+ * The two MPI_Allreduce of cg() (cg.cpp:65,75; and :49) move ONE double each.
+ * Instead of a ring all-reduce (two RCCL launches per iteration, a summation
+ * order that is RCCL's business) every rank owns a small window, exported like
+ * the put windows above; a reduction is one single-wave kernel per rank on
+ * `stream`: store my value(s) and the epoch into my slot of EVERY rank's window
+ * (system-scope release), wait for every rank's slot in mine, add the values in
+ * RANK ORDER -- the same bits on every rank, run after run -- and write the sum
+ * over `inout`.  count <= SPMV_HIP_REDUCE_MAX_COUNT doubles; nranks <=
+ * SPMV_HIP_REDUCE_MAX_RANKS.  Slots are double-buffered by the epoch's parity
+ * (a rank cannot be two reductions ahead of a peer: the one in between needs
+ * that peer's value).  Waits are bounded like the put kernels' ("put_timeout_ms":
+ * NaN in `inout`, SPMV_HIP_EPEER at the context's next synchronisation).  Every
+ * rank connects every other rank (reduce_connect) before the first reduction.
+ * Same memory rules as the put windows; validated on one device only (ranks as
+ * threads: 2 / 3 / 8, and the 8-rank 512^3 rehearsal; ranks as processes over
+ * IPC handles), with the two-sided halo models -- the pair with the one-sided
+ * halo is not validated.  With ranks as THREADS of one process nothing that
+ * waits for the whole device (hipMalloc, hipFree) may run between a rank's
+ * reduction and its peers': size the CG workspace first. */
+#define SPMV_HIP_REDUCE_MAX_RANKS 64
+#define SPMV_HIP_REDUCE_MAX_COUNT 4
+typedef struct spmv_hip_reduce spmv_hip_reduce;
+int spmv_hip_reduce_create(spmv_hip_ctx* ctx, int nranks, int rank,
+                           spmv_hip_reduce** reduce, void* ipc_handle,
+                           uint64_t* raw_address, int64_t* process_id,
+                           int* fine_grained);
+int spmv_hip_reduce_connect(spmv_hip_reduce* reduce, int peer_rank,
+                            const void* peer_ipc_handle, uint64_t peer_raw_address,
+                            int64_t peer_process_id, int peer_fine_grained);
+int spmv_hip_reduce_sum_f64(spmv_hip_ctx* ctx, spmv_hip_reduce* reduce,
+                            double* inout, int count, void* stream);
+int spmv_hip_reduce_destroy(spmv_hip_reduce* reduce);
+
 /* ---- RCCL transport (L2GMap::update p2p models, L2GMap.cpp:564-642;
  *      MPI_Allreduce in cg.cpp:49,65,75) ---------------------------------- */
 #define SPMV_HIP_UNIQUE_ID_BYTES 128

@@ -91,6 +91,12 @@ int spmvh_comm_callback(int rank, int nranks, spmvh_allgather_fn allgather,
 int spmvh_comm_rccl_info(spmvh_comm* comm, int out[4], char* lib_path,
                          int lib_path_len);
 int spmvh_comm_destroy(spmvh_comm* comm);
+/* the deterministic peer reduction of the CG scalars (Comm::enable_peer_reduce:
+ * collective; *ok = 0: some rank cannot reach some window, the transport's
+ * all-reduce stays) and one reduction through it (Comm::reduce_sum) */
+int spmvh_comm_enable_peer_reduce(spmvh_comm* comm, spmvh_exec* exec, int* ok);
+int spmvh_comm_reduce_sum(spmvh_comm* comm, double* device_inout, int count,
+                          void* stream);
 
 /* ---- matrix: Matrix<double>::create_matrix / create_poisson3d --------------- */
 /* rowptr has nrows_local + num_row_ghosts + 1 entries: the extra rows hold

@@ -141,6 +141,11 @@ _PROTOS = {
     "spmv_hip_put_exchange": ([vp, vp, sz, vp, vp, vp], C.c_int),
     "spmv_hip_put_status": ([vp, P(C.c_int)], C.c_int),
     "spmv_hip_put_destroy": ([vp], C.c_int),
+    "spmv_hip_reduce_create": ([vp, C.c_int, C.c_int, P(vp), vp, P(C.c_uint64), P(i64),
+                                P(C.c_int)], C.c_int),
+    "spmv_hip_reduce_connect": ([vp, C.c_int, vp, C.c_uint64, i64, C.c_int], C.c_int),
+    "spmv_hip_reduce_sum_f64": ([vp, vp, vp, C.c_int, vp], C.c_int),
+    "spmv_hip_reduce_destroy": ([vp], C.c_int),
     "spmv_hip_unstructured_fill_f64": ([vp, i64, C.c_int, i64, C.c_int,
                                         C.c_uint64, vp, vp, vp, vp], C.c_int),
     "spmv_hip_fem_count": ([vp, vp, vp, P(i64), vp], C.c_int),

@@ -379,4 +379,255 @@ int spmv_hip_put_destroy(spmv_hip_put* put)
   return SPMV_HIP_OK;
 }
 
+
+// ---------------------------------------------------------------------------
+// Deterministic peer reduction of the CG scalars (include/spmv_hip.h)
+// ---------------------------------------------------------------------------
+} // extern "C"
+
+struct ReduceSlot { // one rank's contribution to one reduction (64 bytes)
+  uint64_t epoch;
+  double v[SPMV_HIP_REDUCE_MAX_COUNT];
+  uint64_t pad[7 - SPMV_HIP_REDUCE_MAX_COUNT];
+};
+static_assert(sizeof(ReduceSlot) == 64, "slot size");
+
+struct spmv_hip_reduce {
+  spmv_hip_ctx* ctx = nullptr;
+  int nranks = 0, rank = 0;
+  ReduceSlot* window = nullptr; // [2 parities][MAX_RANKS]
+  ReduceSlot* host_peers[SPMV_HIP_REDUCE_MAX_RANKS]; // every rank's window
+  void* mapped[SPMV_HIP_REDUCE_MAX_RANKS];
+  ReduceSlot** dev_peers = nullptr;
+  bool tab_dirty = true;
+  int32_t* host_err = nullptr;
+  int32_t* dev_err = nullptr; // its device address
+  uint64_t epoch = 0;
+  int fine_grained = 0;
+};
+
+namespace
+{
+
+__global__ __launch_bounds__(64) void peer_reduce_kernel(
+    ReduceSlot* const* __restrict__ peers, int nranks, int me, uint64_t epoch,
+    double* __restrict__ inout, int count, int32_t* err,
+    unsigned long long timeout_ticks)
+{
+  __shared__ double s_v[SPMV_HIP_REDUCE_MAX_RANKS][SPMV_HIP_REDUCE_MAX_COUNT];
+  __shared__ int s_fail;
+  const int t = threadIdx.x;
+  const int par = (int)(epoch & 1u) * SPMV_HIP_REDUCE_MAX_RANKS;
+  if (t == 0)
+    s_fail = 0;
+  __syncthreads();
+  if (t < nranks) {
+    // my contribution into my slot of rank t's window (t == me: my own)
+    ReduceSlot* dst = peers[t] + par + me;
+    for (int c = 0; c < count; ++c)
+      __hip_atomic_store(&dst->v[c], inout[c], __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); // the values before the epoch
+    __hip_atomic_store(&dst->epoch, epoch, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+    // rank t's contribution in MY window
+    const ReduceSlot* src = peers[me] + par + t;
+    const unsigned long long t0 = wall_clock64();
+    bool ok = true;
+    while (__hip_atomic_load(&src->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+           < epoch) {
+      __builtin_amdgcn_s_sleep(4);
+      if (wall_clock64() - t0 > timeout_ticks) {
+        ok = false;
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    if (ok) {
+      for (int c = 0; c < count; ++c)
+        s_v[t][c] = __hip_atomic_load(&src->v[c], __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+      s_fail = 1;
+      __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  __syncthreads();
+  if (t < count) {
+    double sum = 0.0; // rank order: the same bits on every rank
+    for (int r = 0; r < nranks; ++r)
+      sum += s_v[r][t];
+    inout[t] = s_fail ? __builtin_nan("") : sum;
+  }
+}
+
+} // namespace
+
+extern "C" {
+
+int spmv_hip_reduce_create(spmv_hip_ctx* ctx, int nranks, int rank,
+                           spmv_hip_reduce** reduce, void* ipc_handle,
+                           uint64_t* raw_address, int64_t* process_id,
+                           int* fine_grained)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(reduce && ipc_handle && raw_address && process_id && fine_grained
+               && nranks >= 1 && nranks <= SPMV_HIP_REDUCE_MAX_RANKS && rank >= 0
+               && rank < nranks);
+  spmv_hip_reduce* r = new (std::nothrow) spmv_hip_reduce;
+  if (!r)
+    return SPMV_HIP_ENOMEM;
+  r->ctx = ctx;
+  r->nranks = nranks;
+  r->rank = rank;
+  for (int k = 0; k < SPMV_HIP_REDUCE_MAX_RANKS; ++k) {
+    r->host_peers[k] = nullptr;
+    r->mapped[k] = nullptr;
+  }
+  const size_t bytes = sizeof(ReduceSlot) * 2 * SPMV_HIP_REDUCE_MAX_RANKS;
+  // (fine-grained where the runtime exports that over IPC: see put_create)
+  hipIpcMemHandle_t h;
+  hipError_t e = hipExtMallocWithFlags(reinterpret_cast<void**>(&r->window), bytes,
+                                       hipDeviceMallocFinegrained);
+  if (e == hipSuccess)
+    e = hipIpcGetMemHandle(&h, r->window);
+  if (e == hipSuccess) {
+    r->fine_grained = 1;
+  } else {
+    (void)hipGetLastError();
+    (void)hipFree(r->window);
+    r->window = nullptr;
+    e = hipMalloc(reinterpret_cast<void**>(&r->window), bytes);
+    if (e == hipSuccess)
+      e = hipIpcGetMemHandle(&h, r->window);
+  }
+  if (e == hipSuccess)
+    e = hipMemset(r->window, 0, bytes);
+  if (e == hipSuccess)
+    e = hipMalloc(reinterpret_cast<void**>(&r->dev_peers),
+                  sizeof(ReduceSlot*) * SPMV_HIP_REDUCE_MAX_RANKS);
+  if (e == hipSuccess)
+    e = hipHostMalloc(reinterpret_cast<void**>(&r->host_err), sizeof(int32_t),
+                      hipHostMallocMapped);
+  if (e != hipSuccess) {
+    (void)hipFree(r->window);
+    (void)hipFree(r->dev_peers);
+    delete r;
+    return static_cast<int>(e);
+  }
+  *r->host_err = 0;
+  spmv_ctx_watch(ctx, r->host_err, true);
+  (void)hipHostGetDevicePointer(reinterpret_cast<void**>(&r->dev_err), r->host_err, 0);
+  r->host_peers[rank] = r->window;
+  if (nranks == 1) { // (nobody to connect)
+    (void)hipMemcpy(r->dev_peers, r->host_peers, sizeof(ReduceSlot*),
+                    hipMemcpyHostToDevice);
+    r->tab_dirty = false;
+  }
+  memset(ipc_handle, 0, SPMV_HIP_IPC_HANDLE_BYTES);
+  memcpy(ipc_handle, &h, sizeof(h));
+  *raw_address = reinterpret_cast<uint64_t>(r->window);
+  *process_id = (int64_t)getpid();
+  *fine_grained = r->fine_grained;
+  *reduce = r;
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_reduce_connect(spmv_hip_reduce* reduce, int peer_rank,
+                            const void* peer_ipc_handle, uint64_t peer_raw_address,
+                            int64_t peer_process_id, int peer_fine_grained)
+{
+  SPMV_REQUIRE(reduce && peer_ipc_handle && peer_rank >= 0
+               && peer_rank < reduce->nranks && peer_rank != reduce->rank
+               && !reduce->host_peers[peer_rank]);
+  SPMV_SET_DEVICE(reduce->ctx);
+  const bool fine = peer_fine_grained != 0 && reduce->fine_grained != 0;
+  ReduceSlot* base = nullptr;
+  if (peer_process_id == (int64_t)getpid()) { // a thread of this process
+    base = reinterpret_cast<ReduceSlot*>(peer_raw_address);
+    hipPointerAttribute_t attr;
+    SPMV_CHECK_HIP(hipPointerGetAttributes(&attr, base));
+    if (attr.device != reduce->ctx->device) {
+      if (!fine)
+        return SPMV_HIP_ENOTSUP;
+      int can = 0;
+      SPMV_CHECK_HIP(hipDeviceCanAccessPeer(&can, reduce->ctx->device, attr.device));
+      if (!can)
+        return SPMV_HIP_ENOTSUP;
+      const hipError_t ep = hipDeviceEnablePeerAccess(attr.device, 0);
+      if (ep != hipSuccess && ep != hipErrorPeerAccessAlreadyEnabled)
+        return static_cast<int>(ep);
+      (void)hipGetLastError();
+    }
+  } else {
+    hipIpcMemHandle_t h;
+    memcpy(&h, peer_ipc_handle, sizeof(h));
+    void* m = nullptr;
+    SPMV_CHECK_HIP(hipIpcOpenMemHandle(&m, h, hipIpcMemLazyEnablePeerAccess));
+    reduce->mapped[peer_rank] = m;
+    base = static_cast<ReduceSlot*>(m);
+    if (!fine) { // a coarse-grained window is only safe on this device
+      hipPointerAttribute_t attr;
+      SPMV_CHECK_HIP(hipPointerGetAttributes(&attr, m));
+      if (attr.device != reduce->ctx->device)
+        return SPMV_HIP_ENOTSUP;
+    }
+  }
+  reduce->host_peers[peer_rank] = base;
+  reduce->tab_dirty = true;
+  // the table goes to the device HERE, at set-up time, once it is complete: a
+  // synchronous copy inside the first reduction would wait for every stream of
+  // the process -- with ranks as threads, for a peer's reduction kernel that
+  // in turn waits for this rank's
+  bool complete = true;
+  for (int k = 0; k < reduce->nranks; ++k)
+    complete = complete && reduce->host_peers[k] != nullptr;
+  if (complete) {
+    SPMV_CHECK_HIP(hipMemcpy(reduce->dev_peers, reduce->host_peers,
+                             sizeof(ReduceSlot*) * reduce->nranks,
+                             hipMemcpyHostToDevice));
+    reduce->tab_dirty = false;
+  }
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_reduce_sum_f64(spmv_hip_ctx* ctx, spmv_hip_reduce* reduce,
+                            double* inout, int count, void* stream)
+{
+  SPMV_SET_DEVICE(ctx);
+  SPMV_REQUIRE(reduce && reduce->ctx == ctx && inout && count >= 1
+               && count <= SPMV_HIP_REDUCE_MAX_COUNT);
+  for (int k = 0; k < reduce->nranks; ++k)
+    SPMV_REQUIRE(reduce->host_peers[k] != nullptr); // every rank connected
+  if (*reduce->host_err)
+    return SPMV_HIP_EPEER;
+  hipStream_t st = spmv_stream(ctx, stream);
+  SPMV_REQUIRE(!reduce->tab_dirty);
+  const uint64_t epoch = ++reduce->epoch;
+  const unsigned long long ticks
+      = (unsigned long long)ctx->put_timeout_ms * 100000ull;
+  hipLaunchKernelGGL(peer_reduce_kernel, dim3(1), dim3(64), 0, st,
+                     reduce->dev_peers, reduce->nranks, reduce->rank, epoch, inout,
+                     count, reduce->dev_err, ticks);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_reduce_destroy(spmv_hip_reduce* reduce)
+{
+  if (!reduce)
+    return SPMV_HIP_OK;
+  (void)hipSetDevice(reduce->ctx->device);
+  (void)hipDeviceSynchronize(); // no reduction of mine still runs
+  for (int k = 0; k < SPMV_HIP_REDUCE_MAX_RANKS; ++k)
+    if (reduce->mapped[k])
+      (void)hipIpcCloseMemHandle(reduce->mapped[k]);
+  spmv_ctx_watch(reduce->ctx, reduce->host_err, false);
+  (void)hipFree(reduce->dev_peers);
+  (void)hipFree(reduce->window);
+  (void)hipHostFree(reduce->host_err);
+  delete reduce;
+  return SPMV_HIP_OK;
+}
+
 } // extern "C"

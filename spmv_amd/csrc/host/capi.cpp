@@ -286,7 +286,28 @@ int spmvh_comm_callback(int rank, int nranks, spmvh_allgather_fn allgather,
 
 int spmvh_comm_destroy(spmvh_comm* comm)
 {
-  return guarded([&] { delete comm; });
+  return guarded([&] {
+    if (comm && comm->comm)
+      comm->comm->close_peer_reduce(); // (collective; a no-op without it)
+    delete comm;
+  });
+}
+
+int spmvh_comm_enable_peer_reduce(spmvh_comm* comm, spmvh_exec* exec, int* ok)
+{
+  return guarded([&] {
+    require(comm && exec && ok && exec->hip, "NULL argument / not a HipExecutor");
+    *ok = comm->comm->enable_peer_reduce(*exec->hip) ? 1 : 0;
+  });
+}
+
+int spmvh_comm_reduce_sum(spmvh_comm* comm, double* device_inout, int count,
+                          void* stream)
+{
+  return guarded([&] {
+    require(comm && device_inout && count >= 1, "NULL argument");
+    comm->comm->reduce_sum(device_inout, static_cast<size_t>(count), stream);
+  });
 }
 
 // ---- matrix -------------------------------------------------------------------------

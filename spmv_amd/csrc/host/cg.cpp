@@ -192,7 +192,7 @@ int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
   // rnorm0 (cg.cpp:47-50)
   throw_on_error(spmv_hip_cg_reduce_rr(ctx, w.ws, 0, nullptr),
                  "spmv_hip_cg_reduce_rr");
-  comm.allreduce_sum(slot(true, 0), 1, w.stream);
+  comm.reduce_sum(slot(true, 0), 1, w.stream);
 
   const bool consume = opt.consumer_reductions && comm.size() == 1;
   // whatever happens below, leave the matrix in fp64 mode
@@ -237,7 +237,7 @@ int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
         throw_on_error(spmv_hip_cg_reduce_pAp(ctx, w.ws, k, nullptr),
                        "spmv_hip_cg_reduce_pAp");
       }
-      comm.allreduce_sum(slot(false, k), 1, w.stream);
+      comm.reduce_sum(slot(false, k), 1, w.stream);
       throw_on_error(spmv_hip_cg_update_xr_f64(ctx, w.ws, k, M, w.p, w.Ap, xi,
                                                w.r, nullptr),
                      "spmv_hip_cg_update_xr_f64");
@@ -249,7 +249,7 @@ int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
                      "spmv_hip_cg_residual_f64");
       throw_on_error(spmv_hip_cg_reduce_rr(ctx, w.ws, k, nullptr),
                      "spmv_hip_cg_reduce_rr");
-      comm.allreduce_sum(slot(true, k), 1, w.stream);
+      comm.reduce_sum(slot(true, k), 1, w.stream);
       throw_on_error(spmv_hip_cg_update_p_f64(ctx, w.ws, k, M, w.r, w.p,
                                               nullptr),
                      "spmv_hip_cg_update_p_f64");
@@ -280,7 +280,7 @@ int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
         throw_on_error(spmv_hip_cg_reduce_pAp(ctx, w.ws, k, nullptr),
                        "spmv_hip_cg_reduce_pAp");
       }
-      comm.allreduce_sum(slot(false, k), 1, w.stream); // cg.cpp:65
+      comm.reduce_sum(slot(false, k), 1, w.stream); // cg.cpp:65
       // r -= alpha Ap with the r.r partials (cg.cpp:66,70,73); the x update
       // of :69 rides with the p update below so p is read once per iteration
       throw_on_error(spmv_hip_cg_update_r_f64(ctx, w.ws, k, M, w.Ap, w.r,
@@ -290,7 +290,7 @@ int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
                      "spmv_hip_cg_reduce_rr");
     }
     if (!consume && !replace) {
-      comm.allreduce_sum(slot(true, k), 1, w.stream); // cg.cpp:75
+      comm.reduce_sum(slot(true, k), 1, w.stream); // cg.cpp:75
       // x += alpha p ; stop test ; p = beta p + r   (cg.cpp:69,77-85)
       throw_on_error(spmv_hip_cg_update_xp_f64(ctx, w.ws, k, M, w.r, xi, w.p,
                                                nullptr),
@@ -336,7 +336,7 @@ int cg(const Comm& comm, HipExecutor& exec, const Matrix<double>& A,
                    "spmv_hip_cg_residual_f64");
     throw_on_error(spmv_hip_reduce_partials_f64(ctx, partials, w.dot2, nullptr),
                    "spmv_hip_reduce_partials_f64");
-    comm.allreduce_sum(w.dot2, 1, w.stream);
+    comm.reduce_sum(w.dot2, 1, w.stream);
     throw_on_error(spmv_hip_copy_d2h_async(ctx, &true_rr, w.dot2,
                                            sizeof(double), nullptr),
                    "spmv_hip_copy_d2h_async");

@@ -51,6 +51,86 @@ Comm::allgatherv_bytes(const void* mine, size_t num_bytes) const
   return out;
 }
 
+// ---- deterministic peer reduction ------------------------------------------------
+namespace
+{
+struct ReduceCard { // what a rank tells the others about its window
+  unsigned char handle[SPMV_HIP_IPC_HANDLE_BYTES];
+  uint64_t address;
+  int64_t pid;
+  int32_t fine, ok;
+};
+} // namespace
+
+bool Comm::enable_peer_reduce(const HipExecutor& exec) const
+{
+  if (_reduce)
+    return true;
+  const int P = size(), me = rank();
+  if (P == 1)
+    return false; // nothing to reduce
+  ReduceCard mine;
+  std::memset(&mine, 0, sizeof(mine));
+  spmv_hip_reduce* r = nullptr;
+  int fine = 0;
+  int rc = P <= SPMV_HIP_REDUCE_MAX_RANKS
+               ? spmv_hip_reduce_create(exec.context(), P, me, &r, mine.handle,
+                                        &mine.address, &mine.pid, &fine)
+               : SPMV_HIP_ENOTSUP;
+  mine.fine = fine;
+  mine.ok = rc == SPMV_HIP_OK ? 1 : 0;
+  // (every rank takes part in both collectives whatever happened to it)
+  std::vector<ReduceCard> cards = allgather_value<ReduceCard>(mine);
+  int32_t good = mine.ok;
+  for (int p = 0; p < P && good; ++p)
+    good = cards[p].ok;
+  for (int p = 0; p < P && good; ++p) {
+    if (p == me)
+      continue;
+    rc = spmv_hip_reduce_connect(r, p, cards[p].handle, cards[p].address,
+                                 cards[p].pid, cards[p].fine);
+    if (rc != SPMV_HIP_OK)
+      good = 0;
+  }
+  std::vector<int32_t> all = allgather_value<int32_t>(good);
+  for (int p = 0; p < P; ++p)
+    good = good && all[p];
+  if (!good) {
+    if (r)
+      spmv_hip_reduce_destroy(r);
+    return false;
+  }
+  _reduce = r;
+  _reduce_ctx = exec.context();
+  return true;
+}
+
+void Comm::close_peer_reduce() const
+{
+  if (!_reduce)
+    return;
+  // nobody still stores into a window that is about to go: every rank's last
+  // reduction has completed when its kernel has (stream order), and a rank
+  // arrives here after synchronising -- the allgather is the barrier
+  spmv_hip_synchronize(_reduce_ctx);
+  int32_t token = 1;
+  (void)allgather_value<int32_t>(token);
+  spmv_hip_reduce_destroy(_reduce);
+  _reduce = nullptr;
+  _reduce_ctx = nullptr;
+}
+
+void Comm::reduce_sum(double* device_inout, size_t count, void* stream) const
+{
+  if (_reduce && count <= SPMV_HIP_REDUCE_MAX_COUNT) {
+    throw_on_error(spmv_hip_reduce_sum_f64(_reduce_ctx, _reduce, device_inout,
+                                           static_cast<int>(count), stream),
+                   "spmv_hip_reduce_sum_f64");
+    return;
+  }
+  allreduce_sum(device_inout, count, stream);
+}
+
 // ---- SelfComm ----------------------------------------------------------------
 void SelfComm::allgather(const void* send, void* recv, size_t bytes) const
 {
@@ -85,7 +165,14 @@ RcclComm::RcclComm(const HipExecutor& exec, int nranks, int rank,
                  "spmv_hip_comm_create");
 }
 
-RcclComm::~RcclComm() { spmv_hip_comm_destroy(_comm); }
+RcclComm::~RcclComm()
+{
+  try { // (collective, like the destruction of the communicator itself)
+    close_peer_reduce();
+  } catch (...) {
+  }
+  spmv_hip_comm_destroy(_comm);
+}
 
 void RcclComm::allgather(const void* send, void* recv, size_t bytes) const
 {

@@ -26,6 +26,8 @@
 #include <vector>
 
 struct spmv_hip_comm;
+struct spmv_hip_reduce;
+struct spmv_hip_ctx;
 
 namespace spmv
 {
@@ -73,6 +75,20 @@ public:
   virtual void allreduce_sum(double* device_inout, size_t count,
                              void* stream) const = 0;
 
+  // ---- deterministic peer reduction of the CG scalars (opt-in) -------------
+  // cg() reduces through reduce_sum(): the transport's allreduce_sum() unless
+  // enable_peer_reduce() has set up the peer windows (spmv_hip_reduce_*: one
+  // single-wave kernel per rank and reduction, values added in rank order --
+  // the same bits on every rank and in every run, no RCCL launch).  Both calls
+  // are COLLECTIVE over the communicator; close_peer_reduce() before the
+  // communicator (or the executor) goes away -- derived destructors do.
+  // Returns false (and stays on allreduce_sum) when some rank cannot reach
+  // some other rank's window.
+  bool enable_peer_reduce(const HipExecutor& exec) const;
+  void close_peer_reduce() const;
+  bool peer_reduce() const { return _reduce != nullptr; }
+  void reduce_sum(double* device_inout, size_t count, void* stream) const;
+
   // ---- helpers built on allgather (host, setup only) ----------------------
   template <typename T>
   std::vector<T> allgather_value(const T& v) const
@@ -87,6 +103,10 @@ public:
   // byte-level variant: out[r] = rank r's buffer
   std::vector<std::vector<unsigned char>>
   allgatherv_bytes(const void* mine, size_t num_bytes) const;
+
+private:
+  mutable spmv_hip_reduce* _reduce = nullptr;
+  mutable spmv_hip_ctx* _reduce_ctx = nullptr;
 };
 
 class SelfComm final : public Comm

@@ -46,6 +46,8 @@ _PROTOS = {
     "spmvh_comm_callback": [C.c_int, C.c_int, ALLGATHER_FN, EXCHANGE_FN,
                             ALLREDUCE_FN, vp, PTR(vp)],
     "spmvh_comm_destroy": [vp],
+    "spmvh_comm_enable_peer_reduce": [vp, vp, PTR(C.c_int)],
+    "spmvh_comm_reduce_sum": [vp, vp, C.c_int, vp],
     "spmvh_matrix_create": [vp, vp, vp, vp, vp, i64, i64, vp, i64, vp, i64,
                             C.c_int, C.c_int, PTR(vp)],
     "spmvh_matrix_f32_create": [vp, vp, vp, vp, vp, i64, i64, vp, i64, vp, i64,
@@ -239,6 +241,16 @@ class Comm:
         h = vp()
         call("spmvh_comm_callback", rank, nranks, ag, ex, ar, None, C.byref(h))
         return cls(h, keep=(ag, ex, ar))
+
+    def enable_peer_reduce(self, exec_):
+        """Comm::enable_peer_reduce (collective): cg() then reduces its scalars
+        through peer windows, added in rank order; False = not available."""
+        ok = C.c_int()
+        call("spmvh_comm_enable_peer_reduce", self.h, exec_.h, C.byref(ok))
+        return bool(ok.value)
+
+    def reduce_sum(self, device_ptr, count=1, stream=None):
+        call("spmvh_comm_reduce_sum", self.h, device_ptr, int(count), stream)
 
     def close(self):
         if self.h:

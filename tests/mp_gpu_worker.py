@@ -226,6 +226,40 @@ def main():
             A.close()
             for ptr in (d_v, d_x, d_y):
                 exec_.free(ptr)
+    # the deterministic peer reduction of the CG scalars, the ranks being
+    # PROCESSES: windows reached through IPC handles.  Sums in rank order: the
+    # same bits on every rank; cg() through it follows the same history as
+    # through the transport's all-reduce (which sums in rank order here too)
+    n = 8
+    N = n ** 3
+    rp, ci, va = poisson.poisson3d_csr(n)
+    b = oracle.csr_spmv(rp, ci.astype(np.int32), va, np.ones(N))
+    ranges = oracle.owner_ranges(world, N)
+    r0, r1 = int(ranges[rank]), int(ranges[rank + 1])
+    A = host.Matrix.create_poisson3d(comm, exec_, n, False, host.P2P_BLOCKING)
+    d_b, d_s = exec_.alloc(r1 - r0), exec_.alloc(r1 - r0)
+    exec_.copy_from_host(d_b, b[r0:r1])
+    k0, hist0, _, _ = host.cg_ex(comm, exec_, A, d_b, d_s, 40, 1e-30, history=True)
+    assert comm.enable_peer_reduce(exec_) is (world > 1)
+    if world > 1:
+        d_v = exec_.alloc(3)
+        vals = np.random.default_rng(99).uniform(-1, 1, (30, world, 3))
+        vals[5, :, 0] = [1e16 * (-1) ** p for p in range(world)]
+        for rnd in range(30):
+            exec_.copy_from_host(d_v, vals[rnd, rank])
+            comm.reduce_sum(d_v, 3 if rnd % 2 else 1)
+            got = exec_.copy_to_host(d_v, 3)
+            want = np.zeros(3)
+            for p in range(world):
+                want += vals[rnd, p]
+            ncmp = 3 if rnd % 2 else 1
+            assert np.array_equal(got[:ncmp], want[:ncmp]), (rnd, got, want)
+        exec_.free(d_v)
+        k1, hist1, _, _ = host.cg_ex(comm, exec_, A, d_b, d_s, 40, 1e-30,
+                                     history=True)
+        assert k1 == k0 and np.array_equal(hist1, hist0)
+    A.close()
+    exec_.free(d_b), exec_.free(d_s)
     comm.close()
     exec_.close()
     print(f"rank {rank}/{world}: multirank OK", flush=True)

@@ -120,6 +120,7 @@ def test_bench_single_gpu_line():
     assert rg["fem_sym_cg"]["iters/s"] > 0 and rg["fem_sym_cg"]["rel_residual_after"] < 1e-3
     assert rg["fem_mixed_spmv"]["ms_per_apply"] > 0
     assert "float values" in rg["fem_mixed_spmv"]["kernel"]
+    assert rg["fem_mixed_spmv"]["bit_equal_csr_order_kernel"] is True
     for k in ("fem_spmv", "fem_tail_spmv", "fem81_spmv", "unstructured_spmv"):
         assert rg[k]["bit_equal_one_lane_per_row"] is True and rg[k]["frac"] > 0
         assert d[k]["rows"] == 200000 and d[k]["crosscheck"]["bit_equal"] is True

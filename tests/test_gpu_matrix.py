@@ -330,6 +330,76 @@ def test_onesided_halo_ranks_threaded(world, n):
     tw.run(rank_body, gpu=True)
 
 
+@pytest.mark.parametrize("world,model", [(2, "P2P_BLOCKING"), (3, "P2P_NONBLOCKING"),
+                                         (8, "P2P_BLOCKING"), (8, "P2P_NONBLOCKING")])
+def test_peer_reduce_ranks_threaded(world, model):
+    """The deterministic peer reduction of the CG scalars (spmv_hip_reduce_*,
+    Comm::enable_peer_reduce / reduce_sum) with the ranks as THREADS of this
+    process: one single-wave kernel per rank and reduction, every rank's value
+    stored into every rank's window, added in rank order.  The same bits on
+    every rank, equal to the left-to-right sum in rank order (a case that
+    cancels at 1e16 included), 1 and 3 values per reduction, 60 reductions back
+    to back; cg() through it follows, bit for bit, the history it has through
+    the transport's all-reduce (which adds in rank order here too)."""
+    from thread_world import ThreadWorld
+    queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    if queues < 2 * world + 2:
+        pytest.skip(f"GPU_MAX_HW_QUEUES={queues} pinned by the environment: "
+                    f"{world} threaded ranks need {2 * world + 2} queues")
+    n = 10 if world < 8 else 16
+    N = n ** 3
+    rp, ci, va = poisson.poisson3d_csr(n)
+    b = oracle.csr_spmv(rp, ci.astype(np.int32), va, np.ones(N))
+    ranges = oracle.owner_ranges(world, N)
+    rounds = 60
+    vals = np.random.default_rng(5).uniform(-1, 1, (rounds, world, 3))
+    vals[7, :, 0] = [1e16 * (-1) ** p for p in range(world)]
+    vals[7, world - 1, 0] += 1.0
+    want = np.zeros((rounds, 3))
+    for rnd in range(rounds):
+        for p in range(world):  # left to right in rank order
+            want[rnd] += vals[rnd, p]
+    tw = ThreadWorld(world, timeout=60.0)
+
+    def rank_body(rank, comm, exec_):
+        import ctypes as C
+        from spmv_amd import _lib
+        stream = C.c_void_p()  # a compute stream of its own per rank
+        _lib.call("spmv_hip_stream_create", exec_.context, C.byref(stream))
+        _lib.call("spmv_hip_set_stream", exec_.context, stream)
+        r0, r1 = int(ranges[rank]), int(ranges[rank + 1])
+        # (a stuck wait -- a reduction kernel parked in front of the kernel it
+        # waits for -- fails in 20 s instead of 60)
+        _lib.call("spmv_hip_ctx_set_option", exec_.context, b"put_timeout_ms", 20000)
+        A = host.Matrix.create_poisson3d(comm, exec_, n, False, getattr(host, model))
+        ws = host.CgWorkspace(exec_)
+        d_b, d_s, d_v = exec_.alloc(r1 - r0), exec_.alloc(r1 - r0), exec_.alloc(3)
+        exec_.copy_from_host(d_b, b[r0:r1])
+        k0, hist0, _, _ = host.cg_ex(comm, exec_, A, d_b, d_s, 40, 1e-30, ws,
+                                     history=True)
+        assert comm.enable_peer_reduce(exec_)
+        tw.bar.wait()  # (no hipMalloc / hipFree between here and the last wait)
+        for rnd in range(rounds):
+            exec_.copy_from_host(d_v, vals[rnd, rank])
+            cnt = 3 if rnd % 2 else 1
+            comm.reduce_sum(d_v, cnt)
+            got = exec_.copy_to_host(d_v, 3)
+            assert np.array_equal(got[:cnt], want[rnd, :cnt]), (rank, rnd, got)
+        k1, hist1, _, _ = host.cg_ex(comm, exec_, A, d_b, d_s, 40, 1e-30, ws,
+                                     history=True)
+        assert k1 == k0 and np.array_equal(hist1, hist0), rank
+        exec_.synchronize()
+        tw.bar.wait()
+        ws.close()
+        A.close()
+        for p in (d_b, d_s, d_v):
+            exec_.free(p)
+        _lib.call("spmv_hip_set_stream", exec_.context, None)
+        _lib.call("spmv_hip_stream_destroy", exec_.context, stream)
+
+    tw.run(rank_body, gpu=True)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_multirank_on_one_gpu(world):
     """N>1 path: one process per rank, all on GPU 0, halo + reductions over a

@@ -45,11 +45,19 @@ def main():
                     choices=["p2p_blocking", "p2p_nonblocking",
                              "onesided_put_active"])
     ap.add_argument("--symmetric", action="store_true")
+    ap.add_argument("--peer-reduce", action="store_true",
+                    help="the CG scalars by the deterministic peer reduction "
+                         "(Comm::enable_peer_reduce) instead of the transport's "
+                         "all-reduce")
     args = ap.parse_args()
+    if args.peer_reduce and args.cm.startswith("onesided"):
+        # the pair does not complete with the ranks as threads (two sets of
+        # polling kernels on one process's hardware queues): not offered
+        raise SystemExit("--peer-reduce goes with the two-sided halo models")
     P, n = args.ranks, args.grid
     N = n ** 3
     cm = getattr(host, args.cm.upper())
-    tw = ThreadWorld(P, timeout=600.0)
+    tw = ThreadWorld(P, timeout=120.0 if args.peer_reduce else 600.0)
     ranks = [None] * P
     t_all = time.perf_counter()
 
@@ -89,6 +97,14 @@ def main():
                   None)
         ws = host.CgWorkspace(exec_)
         host.cg_ex(comm, exec_, A, d_b, d_x, 0, 1e-30, ws)  # sizes the workspace
+        if args.peer_reduce:
+            # AFTER the workspace exists: hipMalloc / hipFree wait for the whole
+            # device -- with the ranks as threads of one process, for a peer's
+            # reduction kernel that in turn waits for this rank's (ranks in
+            # processes of their own do not share that wait).  A stuck wait
+            # fails in 20 s.
+            _lib.call("spmv_hip_ctx_set_option", ctx, b"put_timeout_ms", 20000)
+            rec["peer_reduce"] = bool(comm.enable_peer_reduce(exec_))
         tw.bar.wait()
         t0 = time.perf_counter()
         k, hist, _, _ = host.cg_ex(comm, exec_, A, d_b, d_x, args.steps, 0.0, ws,
@@ -126,6 +142,7 @@ def main():
                                                    for r in ranks)),
            "remote_block_algo": sorted({r.get("remote_algo") for r in ranks}),
            "onesided_put_path": bool(all(r["onesided"] for r in ranks)),
+           "peer_reduce": bool(all(r.get("peer_reduce") for r in ranks)),
            "ranks": [{k: r[k] for k in ("rank", "rows", "ghosts", "neighbours")}
                      for r in ranks],
            "wall_s": time.perf_counter() - t_all}
