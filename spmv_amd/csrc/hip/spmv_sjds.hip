@@ -1381,6 +1381,10 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
     if (b0 >= 0)
       request_chunks(b0);
   }
+#ifdef SJ_PROBE
+  long long pr_wait = 0, pr_stage = 0, pr_bar = 0, pr_slice = 0, pr_blocks = 0;
+  const long long pr_begin = wall_clock64();
+#endif
   for (int it = blockIdx.x; it < num_slots && (A.phases & 2); it += gridDim.x) {
     const int b = order_row_block(ord, it);
     const int itn = it + gridDim.x;
@@ -1421,7 +1425,13 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
     const int32_t* cl = A.chunks + (int64_t)b * A.stride;
     // the block's chunks of x: 8 lanes per chunk, 2 elements per lane, four
     // chunks per lane in flight; lanes past the list repeat its last chunk
+#ifdef SJ_PROBE
+    const long long pq0 = wall_clock64();
+#endif
     __syncthreads(); // the previous block's slices are done with s_x
+#ifdef SJ_PROBE
+    const long long pq1 = wall_clock64();
+#endif
     for (int c0 = cg; c0 < K; c0 += 4 * CG) {
       pair_t xv[4];
       const int64_t cmax = ((int64_t)A.num_cols - 2) & ~(int64_t)1;
@@ -1454,7 +1464,13 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
     }
     if (bn >= 0) // the next block's chunk numbers: back by the time they are used
       request_chunks(bn);
+#ifdef SJ_PROBE
+    const long long pq2 = wall_clock64();
+#endif
     __syncthreads();
+#ifdef SJ_PROBE
+    const long long pq3 = wall_clock64();
+#endif
     if (have) {
       const int32_t mylen = lp >> 6;
       const SjUnit<TV, E>* vs
@@ -1485,7 +1501,22 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
           dot_acc += (double)x_own * (double)c;
       }
     }
+#ifdef SJ_PROBE
+    {
+      const long long pq4 = wall_clock64();
+      pr_wait += pq1 - pq0, pr_stage += pq2 - pq1, pr_bar += pq3 - pq2,
+          pr_slice += pq4 - pq3, ++pr_blocks;
+    }
+#endif
   }
+#ifdef SJ_PROBE
+  // (100 MHz ticks) waves 0 and WPB - 1 of a few workgroups
+  if (lane == 0 && (wave == 0 || wave == WPB - 1)
+      && (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 200))
+    printf("SJPROBE wg %d wave %d blocks %lld wait %lld stage %lld barrier %lld slice %lld total %lld\n",
+           (int)blockIdx.x, wave, pr_blocks, pr_wait, pr_stage, pr_bar, pr_slice,
+           wall_clock64() - pr_begin);
+#endif
   if constexpr (DOT) {
     // the workgroup's partial (fixed tree: deterministic), the array's unused
     // tail cleared -- spmv_dot_epilogue for WPB waves
