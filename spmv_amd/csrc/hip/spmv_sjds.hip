@@ -1026,6 +1026,8 @@ __global__ __launch_bounds__(64 * WPB) void csr_sjds_long_kernel(
 //   trips of loads in flight (SJ_LT_DEPTH)                   1 / 2: 0.375 / 0.376
 //   supergroups from an atomic queue instead of static runs: 0.367 against 0.355
 //   the matrix loaded non-temporally (nt):                   0.458 against 0.352
+//   an XCD's workgroups on consecutive supergroups (interleaved) instead of
+//   contiguous runs per workgroup:                    0.331-0.339 against 0.343-0.351
 // -- whatever makes a supergroup wider (more rows: more panels, more staged x)
 // loses.  A build with clocks in it (SJ_LT_PROBE) shows where the time goes:
 // 1.03 us per trip of a wave whether its neighbours are busy or idle, 0.34 us
@@ -1099,20 +1101,38 @@ __global__ __launch_bounds__(512, 4) void csr_sjds_longt_kernel(
   const int l = lane & (G - 1), g = wave * (64 / G) + lane / G;
   double dot_acc = 0.0;
   const int nsg = (A.nlong + RUN - 1) / RUN;
-  // contiguous runs of supergroups per workgroup, workgroups of one XCD
-  // neighbouring runs (the first nsg mod grid workgroups take one more)
+#ifndef SJ_LT_INTERLEAVE
+#define SJ_LT_INTERLEAVE 1
+#endif
+  // An XCD (blockIdx mod 8: its own L2) takes a contiguous eighth of the
+  // supergroups, and its G workgroups take them INTERLEAVED (j, j + G, ...): at
+  // any time they walk G consecutive supergroups, whose panels of x overlap
+  // (neighbours shift by 64 long rows' worth of columns) and meet in that L2.
+  // (Contiguous runs per workgroup, SJ_LT_INTERLEAVE = 0: a workgroup's next
+  // supergroup finds its predecessor's panels evicted by the matrix stream.)
   const int g8 = gridDim.x >= 8 && (gridDim.x & 7) == 0;
-  const int chunk = g8 ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)
-                       : blockIdx.x;
-  const int per = nsg / gridDim.x, rem = nsg % gridDim.x;
-  const int sg0 = chunk * per + min(chunk, rem);
-  const int sg1 = sg0 + per + (chunk < rem ? 1 : 0);
+  int sg0, sg1, sgstep;
+  if (g8 && SJ_LT_INTERLEAVE) {
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3, G = gridDim.x >> 3;
+    const int per8 = nsg / 8, rem8 = nsg % 8;
+    const int lo = x * per8 + min(x, rem8);
+    sg0 = lo + j;
+    sg1 = lo + per8 + (x < rem8 ? 1 : 0);
+    sgstep = G;
+  } else {
+    const int chunk = g8 ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)
+                         : blockIdx.x;
+    const int per = nsg / gridDim.x, rem = nsg % gridDim.x;
+    sg0 = chunk * per + min(chunk, rem);
+    sg1 = sg0 + per + (chunk < rem ? 1 : 0);
+    sgstep = 1;
+  }
   const int64_t cend = (int64_t)A.num_cols;
 #ifdef SJ_LT_PROBE
   long long pr_stage = 0, pr_loop = 0, pr_trips = 0, pr_panels = 0;
   const long long pr_begin = wall_clock64();
 #endif
-  for (int sg = sg0; sg < sg1; ++sg) { // uniform per workgroup
+  for (int sg = sg0; sg < sg1; sg += sgstep) { // uniform per workgroup
     // the group's rows: rank g of the supergroup (RS > 1: g, 2 NG - 1 - g, ...)
     int32_t slot[RS], row[RS];
     bool have[RS];
@@ -1328,7 +1348,8 @@ __global__ __launch_bounds__(512, 4) void csr_sjds_longt_kernel(
   if (lane == 0 && (wave == 0 || wave == 7)
       && (blockIdx.x == 0 || blockIdx.x == 3 || blockIdx.x == 300 || blockIdx.x == 509))
     printf("LTPROBE wg %d wave %d sgs %d panels %lld trips %lld stage %lld loop %lld total %lld\n",
-           (int)blockIdx.x, wave, sg1 - sg0, pr_panels, pr_trips, pr_stage, pr_loop,
+           (int)blockIdx.x, wave, (sg1 - sg0 + sgstep - 1) / sgstep, pr_panels, pr_trips,
+           pr_stage, pr_loop,
            wall_clock64() - pr_begin);
 #endif
   if constexpr (DOT) {
