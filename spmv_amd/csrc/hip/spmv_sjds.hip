@@ -1668,15 +1668,8 @@ int sj_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
       lgrid -= lgrid % 8;
     if (lgrid < 1)
       lgrid = 1;
-    if (llds > 48 * 1024) { // more dynamic LDS than a launch gets by default
-      static bool raised = false;
-      if (!raised) {
-        SPMV_CHECK_HIP(hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&csr_sjds_longt_kernel<T, TV, DOT>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds));
-        raised = true;
-      }
-    }
+    // (more dynamic LDS than a launch gets by default: the attribute was
+    // raised when the table was built, on the plan's device)
     hipLaunchKernelGGL((csr_sjds_longt_kernel<T, TV, DOT>), dim3(lgrid), dim3(512), llds,
                        st, A, alpha, in, beta, out, dot, (A.phases & 2) ? grid : 0);
     SPMV_CHECK_LAUNCH();
@@ -2002,6 +1995,23 @@ void sj_lt_free(spmv_hip_csr_plan* pl)
   pl->sj_lt_nsg = 0;
 }
 
+// the table-driven kernel's panel exceeds the dynamic LDS a launch gets by
+// default: raise the limit for every instantiation, on the current device
+int sj_lt_raise_lds()
+{
+#define SJ_LT_RAISE(...)                                                       \
+  SPMV_CHECK_HIP(hipFuncSetAttribute(                                          \
+      reinterpret_cast<const void*>(&csr_sjds_longt_kernel<__VA_ARGS__>),      \
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kSjLtPanel * sizeof(double))))
+  SJ_LT_RAISE(double, double, false);
+  SJ_LT_RAISE(double, double, true);
+  SJ_LT_RAISE(double, float, false);
+  SJ_LT_RAISE(double, float, true);
+  SJ_LT_RAISE(float, float, false);
+#undef SJ_LT_RAISE
+  return SPMV_HIP_OK;
+}
+
 // (no memory: the plan stays without the table and the older kernel runs)
 int sj_build_long_table(spmv_hip_csr_plan* pl, const int32_t* rowptr,
                         const int32_t* colind, hipStream_t st)
@@ -2056,7 +2066,7 @@ int sj_build_long_table(spmv_hip_csr_plan* pl, const int32_t* rowptr,
   }
   pl->sj_lt_entries = total;
   pl->sj_lt_nsg = nsg;
-  return SPMV_HIP_OK;
+  return sj_lt_raise_lds();
 }
 
 template <typename T>

@@ -459,7 +459,7 @@ int run_symmetric(const spmv_hip_csr_plan* pl, hipStream_t st,
                                out);
   }
   // no lattice structure (FEM matrices): both blocks in the sliced jagged form
-  if (pl->sym_sj && pl->sj && pl->sj_val && pl->sjt && pl->sjt->sj_val
+  if (pl->sym_det && pl->sym_sj && pl->sj && pl->sj_val && pl->sjt && pl->sjt->sj_val
       && pl->sj_elem == (int)sizeof(T) && values == pl->sj_values0
       && diagonal == pl->sj_diag0 && aligned16(in) && pl->num_cols >= 2) {
     if constexpr (sizeof(T) == 8)
