@@ -315,13 +315,14 @@ def kernel_of(A, symmetric):
         if A.plan_get("sym_sj"):
             wpb = A.plan_get("sj_wpb")
             return (f"csr_sjds_kernel<double, {wpb} slices per block, symmetric "
-                    "storage> (no lattice structure: the strictly lower block and "
-                    "its transpose both in the sliced jagged form -- the plan's "
-                    "copies of the values and 16-bit column codes, x staged in LDS "
-                    "-- two passes: y = alpha (d x + L x) + beta y, then the "
-                    "column's entries added in the reference's order; atomic-free, "
-                    "bit-exact; fused p.Ap)",
-                    algo, nnz * 20 + rows * (8 + 8 + 8 + 24 + 8) + 2 * cols * 8)
+                    "storage> (no lattice structure: the merged matrix -- per row "
+                    "its stored lower entries, then its column's entries in the "
+                    "reference's order -- in the sliced jagged form: the plan's "
+                    "copy of the values and 16-bit column codes, x staged in LDS; "
+                    "one pass, the sum turning into y = alpha (d x + L x) + beta y "
+                    "where the column's entries begin; atomic-free, bit-exact; "
+                    "fused p.Ap)",
+                    algo, nnz * 20 + rows * (4 + 8 + 8 + 8 + 8) + cols * 8)
         if A.plan_get("sym_det"):
             return ("csr_symt_kernel<double> (transposed map, atomic-free, "
                     "bit-exact)", algo, algo + (rows + 1) * 4 + nnz * 8)

@@ -319,12 +319,17 @@ struct spmv_hip_csr_plan {
   int64_t sj_lt_entries = 0;
   int sj_lt_nsg = 0;
   int sj_long_table = 1;  // use that (plan_set "sj_long_table")
-  // symmetric storage of a matrix without lattice structure: the strictly
-  // lower block in the sliced jagged form (the fields above) and its transpose
-  // (rows = the transposed map's t_ptr / t_row) in a plan of its own
+  // symmetric storage of a matrix without lattice structure: the MERGED matrix
+  // (a row's stored lower entries followed by its column's entries in the
+  // reference's order; the transposed map delivers those) in the sliced jagged
+  // form, in a plan of its own; its CSR arrays and the positions of its values
+  // in the caller's array are this plan's
   spmv_hip_csr_plan* sjt = nullptr;
+  int32_t* sjv_ptr = nullptr;
+  int32_t* sjv_col = nullptr;
+  int32_t* sjv_map = nullptr;
   const void* sj_diag0 = nullptr;
-  int sym_sj = 0;         // both are baked
+  int sym_sj = 0;         // its copy of the values is baked
   int sj_phases = 3;             // measurement only: 1 = long rows, 2 = slices
   int sj_blocks_per_cu = 0;      // 0 = what the LDS footprint allows
   int sj_xcd_group = 8;          // consecutive blocks per XCD (0 = off)
@@ -501,6 +506,8 @@ int spmv_sjds_bake_f32(spmv_hip_csr_plan* pl, const float* values, const int32_t
 int spmv_sjds_bake_f32f64(spmv_hip_csr_plan* pl, const float* values32, hipStream_t st);
 int spmv_sjds_run_f32f64(const spmv_hip_csr_plan* pl, hipStream_t st, double alpha,
                          const double* in, double beta, double* out, DotOut dot);
+int spmv_sjds_sym_merge(const spmv_hip_csr_plan* pl, int32_t** vptr, int32_t** vcol,
+                        int32_t** vmap, hipStream_t st);
 int spmv_sjds_run_sym_f64(const spmv_hip_csr_plan* pl, hipStream_t st,
                           const double* diagonal, double alpha, const double* in,
                           double beta, double* out, DotOut dot);

@@ -1295,9 +1295,10 @@ int spmv_zwalk_order_build(spmv_hip_csr_plan* pl, int64_t d2, int grid,
 }
 
 // Symmetric storage of a matrix without lattice structure (FEM matrices, what
-// read_petsc_binary_matrix delivers with symmetric = true): both blocks of the
-// reference's loop (csr_kernels.cpp:26-40) in the sliced jagged form -- the
-// strictly lower block as stored, its transpose through the transposed map.
+// read_petsc_binary_matrix delivers with symmetric = true): the reference's
+// loop (csr_kernels.cpp:26-40) seen from the row, in the sliced jagged form of
+// the MERGED matrix -- per row its stored lower entries, then the entries of
+// its column in the reference's order (the transposed map has them).
 // ENOTSUP: the form does not apply (the transposed-map kernel stays).
 template <typename T>
 static int sym_sj_bake(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan, const T* values,
@@ -1309,18 +1310,18 @@ static int sym_sj_bake(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan, const T* valu
     else
       return spmv_sjds_bake_f32(p, v, map, st);
   };
-  if (values == nullptr) { // drop the copies
+  if (values == nullptr) { // drop the copy
     plan->sym_sj = 0;
+    plan->sj = 0;
     plan->sj_diag0 = nullptr;
-    if (plan->sjt && plan->sjt->sj_lenperm)
-      (void)bake(plan->sjt, nullptr, nullptr);
-    return plan->sj_lenperm ? bake(plan, nullptr, nullptr) : SPMV_HIP_ENOTSUP;
+    return plan->sjt && plan->sjt->sj_lenperm ? bake(plan->sjt, nullptr, nullptr)
+                                              : SPMV_HIP_ENOTSUP;
   }
   if (!plan->symmetric || !plan->sym_det || !plan->t_ptr || plan->slat
       || plan->nnz < ctx->sj_min_nnz || plan->num_rows < 64 || !diagonal)
     return SPMV_HIP_ENOTSUP;
   const auto t0 = std::chrono::steady_clock::now();
-  if (!plan->sj_lenperm) {
+  if (!plan->sjt) {
     // long rows stay inside the slices in this form (and a slice runs as long
     // as its longest row): a matrix with more than a few of them -- rows of
     // the lower block, or columns = rows of its transpose -- keeps the
@@ -1333,27 +1334,36 @@ static int sym_sj_bake(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan, const T* valu
       return rl;
     if ((la + lb) * 1000 > (int64_t)ctx->sym_sj_long_permille * 2 * plan->nnz)
       return SPMV_HIP_ENOTSUP;
-    const int rb = spmv_sjds_build(plan, plan->rowptr0, plan->colind0, ctx->sj_wpb, 2, 1);
-    if (rb != SPMV_HIP_OK)
-      return rb;
-    if (!plan->sj_lenperm)
-      return SPMV_HIP_ENOTSUP;
-  }
-  if (!plan->sjt) {
+    // the merged matrix: per row its lower entries, then its column's
+    const int rm = spmv_sjds_sym_merge(plan, &plan->sjv_ptr, &plan->sjv_col,
+                                       &plan->sjv_map, st);
+    if (rm != SPMV_HIP_OK)
+      return rm == SPMV_HIP_ENOMEM ? SPMV_HIP_ENOTSUP : rm;
     spmv_hip_csr_plan* ch = new (std::nothrow) spmv_hip_csr_plan;
-    if (!ch)
-      return SPMV_HIP_ENOMEM;
-    ch->ctx = ctx;
-    ch->num_rows = plan->num_rows;
-    ch->num_cols = plan->num_cols;
-    ch->nnz = plan->nnz;
-    ch->symmetric = false;
-    ch->rowptr0 = plan->t_ptr;
-    ch->colind0 = plan->t_row;
-    const int rb = spmv_sjds_build(ch, plan->t_ptr, plan->t_row, ctx->sj_wpb, 2, 1);
+    int rb = ch ? SPMV_HIP_OK : SPMV_HIP_ENOMEM;
+    if (ch) {
+      ch->ctx = ctx;
+      ch->num_rows = plan->num_rows;
+      ch->num_cols = plan->num_cols;
+      ch->nnz = 2 * plan->nnz;
+      ch->symmetric = false;
+      ch->rowptr0 = plan->sjv_ptr;
+      ch->colind0 = plan->sjv_col;
+      rb = spmv_sjds_build(ch, plan->sjv_ptr, plan->sjv_col, ctx->sj_wpb, 2, 1);
+    }
+    // (the columns were for the analysis only: the kernel reads its codes)
+    (void)hipFree(plan->sjv_col);
+    plan->sjv_col = nullptr;
+    if (ch)
+      ch->colind0 = nullptr;
     if (rb != SPMV_HIP_OK || !ch->sj_lenperm) {
-      spmv_sjds_free(ch);
-      delete ch;
+      if (ch) {
+        spmv_sjds_free(ch);
+        delete ch;
+      }
+      (void)hipFree(plan->sjv_ptr);
+      (void)hipFree(plan->sjv_map);
+      plan->sjv_ptr = plan->sjv_map = nullptr;
       return rb != SPMV_HIP_OK ? rb : SPMV_HIP_ENOTSUP;
     }
     plan->sjt = ch;
@@ -1361,18 +1371,16 @@ static int sym_sj_bake(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan, const T* valu
   plan->plan_us += (int)std::chrono::duration_cast<std::chrono::microseconds>(
                        std::chrono::steady_clock::now() - t0)
                        .count();
-  int rc = bake(plan, values, nullptr);
-  if (rc == SPMV_HIP_OK) {
-    rc = bake(plan->sjt, values, plan->t_pos);
-    plan->plan_us += plan->sjt->plan_us; // (the child's bake counted itself there)
-    plan->sjt->plan_us = 0;
-  }
+  const int rc = bake(plan->sjt, values, plan->sjv_map);
+  plan->plan_us += plan->sjt->plan_us; // (the bake counted itself there)
+  plan->sjt->plan_us = 0;
   if (rc != SPMV_HIP_OK) {
     plan->sym_sj = 0;
     return rc;
   }
   plan->sj_diag0 = diagonal;
   plan->sym_sj = 1;
+  plan->sj = 1;
   return SPMV_HIP_OK;
 }
 
@@ -1503,6 +1511,10 @@ int spmv_hip_csr_plan_destroy(spmv_hip_csr_plan* plan)
     spmv_sjds_free(plan->sjt);
     delete plan->sjt;
     plan->sjt = nullptr;
+    (void)hipFree(plan->sjv_ptr);
+    (void)hipFree(plan->sjv_col);
+    (void)hipFree(plan->sjv_map);
+    plan->sjv_ptr = plan->sjv_col = plan->sjv_map = nullptr;
   }
   if (plan
       && (plan->row_list || plan->lx_lidx || plan->lat_tab || plan->t_ptr
@@ -1561,7 +1573,7 @@ int spmv_hip_csr_plan_bake_values_f64(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan
     rc = values == nullptr ? (rj != SPMV_HIP_OK ? rj : rc) : rj;
   }
   // symmetric storage without lattice structure: both blocks sliced jagged
-  if (plan->symmetric && (values == nullptr ? plan->sj_lenperm != nullptr
+  if (plan->symmetric && (values == nullptr ? plan->sjt != nullptr
                                             : rc == SPMV_HIP_ENOTSUP)) {
     const int rj = sym_sj_bake<double>(ctx, plan, values, diagonal, st);
     rc = values == nullptr ? (rj != SPMV_HIP_OK ? rj : rc) : rj;
@@ -1602,7 +1614,7 @@ int spmv_hip_csr_plan_bake_values_f32(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan
     const int rj = spmv_sjds_bake_f32(plan, values, nullptr, st);
     rc = values == nullptr ? (rj != SPMV_HIP_OK ? rj : rc) : rj;
   }
-  if (plan->symmetric && (values == nullptr ? plan->sj_lenperm != nullptr
+  if (plan->symmetric && (values == nullptr ? plan->sjt != nullptr
                                             : rc == SPMV_HIP_ENOTSUP)) {
     const int rj = sym_sj_bake<float>(ctx, plan, values, diagonal, st);
     rc = values == nullptr ? (rj != SPMV_HIP_OK ? rj : rc) : rj;
@@ -1650,15 +1662,15 @@ int spmv_hip_csr_plan_values_changed(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan,
     if (rc == SPMV_HIP_OK && plan->sj_val32 && plan->sj32_values0)
       rc = spmv_sjds_bake_f32f64(plan, static_cast<const float*>(plan->sj32_values0),
                                  st);
-    // (symmetric storage: the transposed block's copy from the same values)
-    if (rc == SPMV_HIP_OK && plan->sjt && plan->sjt->sj_val)
-      rc = plan->sj_elem == 8
-               ? spmv_sjds_bake_f64(plan->sjt,
-                                    static_cast<const double*>(plan->sj_values0),
-                                    plan->t_pos, st)
-               : spmv_sjds_bake_f32(plan->sjt,
-                                    static_cast<const float*>(plan->sj_values0),
-                                    plan->t_pos, st);
+  }
+  // (symmetric storage: the merged matrix's copy)
+  if (rc == SPMV_HIP_OK && plan->sjt && plan->sjt->sj_val && plan->sjt->sj_values0) {
+    const void* v0 = plan->sjt->sj_values0;
+    rc = plan->sjt->sj_elem == 8
+             ? spmv_sjds_bake_f64(plan->sjt, static_cast<const double*>(v0),
+                                  plan->sjv_map, st)
+             : spmv_sjds_bake_f32(plan->sjt, static_cast<const float*>(v0),
+                                  plan->sjv_map, st);
   }
   // the diagonal forms: the device checks decide the form again (a matrix
   // they no longer hold: ENOTSUP = back to the CSR-order kernels, which is a
@@ -1790,7 +1802,7 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
       return spmv_zwalk_order_build(plan, plan->zw_d2, spmv_walk_grid(plan), 0,
                                     true);
   } else if (!strcmp(key, "sjds")) {
-    SPMV_REQUIRE(value == 0 || plan->sj_val);
+    SPMV_REQUIRE(value == 0 || plan->sj_val || (plan->sjt && plan->sjt->sj_val));
     plan->sj = value != 0;
   } else if (!strcmp(key, "sj_phases")) { // ablation for measurements only
     SPMV_REQUIRE(value >= 1 && value <= 3);
@@ -1931,22 +1943,25 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
   else if (!strcmp(key, "sdia"))
     *value = plan->sdia && plan->sdia_val ? 1 : 0;
   else if (!strcmp(key, "sjds"))
-    *value = plan->sj && plan->sj_val ? 1 : 0;
+    *value = plan->sj && (plan->sj_val || (plan->sjt && plan->sjt->sj_val)) ? 1 : 0;
   else if (!strcmp(key, "sym_sj")) // symmetric storage, both blocks sliced jagged
-    *value = plan->symmetric && plan->sym_sj && plan->sj && plan->sj_val && plan->sjt
+    *value = plan->symmetric && plan->sym_sj && plan->sj && plan->sjt
                      && plan->sjt->sj_val
                  ? 1
                  : 0;
   else if (!strcmp(key, "sj_mixed")) // the fp32 twin of the jagged copy is baked
     *value = plan->sj && plan->sj_val32 ? 1 : 0;
   else if (!strcmp(key, "sj_built"))
-    *value = plan->sj_lenperm ? 1 : 0;
-  else if (!strcmp(key, "sj_wpb"))
-    *value = plan->sj_lenperm ? plan->sj_wpb : 0;
+    *value = plan->sj_lenperm || (plan->sjt && plan->sjt->sj_lenperm) ? 1 : 0;
+  else if (!strcmp(key, "sj_wpb")) // (symmetric storage: the merged matrix's)
+    *value = plan->sj_lenperm ? plan->sj_wpb
+             : plan->sjt && plan->sjt->sj_lenperm ? plan->sjt->sj_wpb : 0;
   else if (!strcmp(key, "sj_unit"))
-    *value = plan->sj_lenperm ? plan->sj_unit : 0;
+    *value = plan->sj_lenperm ? plan->sj_unit
+             : plan->sjt && plan->sjt->sj_lenperm ? plan->sjt->sj_unit : 0;
   else if (!strcmp(key, "sj_max_chunks"))
-    *value = plan->sj_lenperm ? plan->sj_maxk : 0;
+    *value = plan->sj_lenperm ? plan->sj_maxk
+             : plan->sjt && plan->sjt->sj_lenperm ? plan->sjt->sj_maxk : 0;
   else if (!strcmp(key, "sj_far_permille"))
     *value = plan->sj_lenperm && plan->nnz > 0
                  ? (int)((plan->sj_far * 1000 + plan->nnz - 1) / plan->nnz)
@@ -2019,8 +2034,9 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
       b += (int64_t)plan->sj_elem * plan->sj_units * plan->sj_unit;
     if (plan->sj_val32)
       b += 4 * plan->sj_units * plan->sj_unit;
-    if (plan->sjt && plan->sjt->sj_lenperm) { // the transposed block's structure
+    if (plan->sjt && plan->sjt->sj_lenperm) { // symmetric storage: the merged matrix
       const spmv_hip_csr_plan* c = plan->sjt;
+      b += 4 * (n + 1) + 8 * nnz; // its row pointer, the positions of its values
       b += 4 * ((n + 63) / 64 * 64) + 8 * (int64_t)c->sj_nblk
            + 4 * (int64_t)c->sj_nblk * c->sj_stride
            + (c->sj_wide_alloc ? 4 : 2) * c->sj_units * c->sj_unit

@@ -540,16 +540,22 @@ __device__ __forceinline__ float sj_readlane<float>(float v, int j)
 // step's address is the uniform `vs + off` plus the lane's own constant: no
 // vector arithmetic per step but one select.
 //
-// MODE (symmetric storage, csr_kernels.cpp:26-40 seen from the row): 0 = a
-// general matrix; 1 = the strictly lower block, the sum starts at d_i x_i;
-// 2 = its transpose, the sum starts at the y the lower pass left and every
-// product is fl(fl(alpha v) x) -- the reference's out[col] += alpha * val * in[i].
+// MODE 0 = a general matrix.  MODE 3 = symmetric storage (csr_kernels.cpp:26-40
+// seen from the row): the lane's "row" is the row's nlow stored (lower) entries
+// followed by the entries of its COLUMN in the reference's order (ascending
+// (r, j)); the sum starts at d_i x_i and takes the lower products as they are;
+// where the column's entries begin it TURNS into y_i = fl(alpha sum + beta y0_i)
+// and every further product is fl(fl(alpha v) x) -- the reference's
+// out[col] += alpha * val * in[i].  Returns y_i.  (No wave take-over of a long
+// row there: the turn would fall inside it.)
 template <typename T, typename TV, typename CODE, bool WIDE, int E, int MODE>
 __device__ __forceinline__ T sj_slice(const SjUnit<TV, E>* __restrict__ vs,
                                       const SjUnit<CODE, E>* __restrict__ cs,
                                       int32_t mylen, int lane,
                                       const T* __restrict__ s_x,
-                                      const T* __restrict__ in, T init, T alpha)
+                                      const T* __restrict__ in, T init, T alpha,
+                                      int32_t nlow = 0, T by0 = T(0),
+                                      bool has_beta = false)
 {
   constexpr int U = kSjGroup / E; // steps per group
   const int32_t myu = (mylen + E - 1) / E;
@@ -558,7 +564,8 @@ __device__ __forceinline__ T sj_slice(const SjUnit<TV, E>* __restrict__ vs,
   const int32_t maxlen = __builtin_amdgcn_readlane(mylen, 0);
   // the jagged part ends at the second-longest row when lane 0's row goes on
   // for long enough to be worth taking over by the whole wave
-  const int32_t kmain = (maxlen - u1 * E >= kSjTailMin) ? u1 : maxu; // units
+  const int32_t kmain
+      = (MODE == 0 && maxlen - u1 * E >= kSjTailMin) ? u1 : maxu; // units
   const int32_t mymain = myu < kmain ? myu : kmain;
   T sum = init;
   SjUnit<TV, E> va[U], vc[U];
@@ -615,9 +622,16 @@ __device__ __forceinline__ T sj_slice(const SjUnit<TV, E>* __restrict__ vs,
     _Pragma("unroll") for (int u = 0; u < U; ++u)                              \
         _Pragma("unroll") for (int q = 0; q < E; ++q)                          \
     {                                                                          \
-      const T vq = MODE == 2 ? alpha * (T)V[u].e[q] : (T)V[u].e[q];            \
+      const int32_t kk = ((K0) + u) * E + q;                                   \
+      T vq = (T)V[u].e[q];                                                     \
+      if constexpr (MODE == 3) {                                               \
+        const T as = alpha * sum;                                              \
+        const T turned = has_beta ? as + by0 : as;                             \
+        sum = (kk == nlow && kk < mylen) ? turned : sum;                       \
+        vq = kk >= nlow ? alpha * vq : vq;                                     \
+      }                                                                        \
       const T nxt = sum + vq * xs[u][q];                                       \
-      const bool use = (K0) + u < mymain && ((K0) + u) * E + q < mylen;        \
+      const bool use = (K0) + u < mymain && kk < mylen;                        \
       sum = use ? nxt : sum;                                                   \
     }                                                                          \
   }
@@ -658,8 +672,7 @@ __device__ __forceinline__ T sj_slice(const SjUnit<TV, E>* __restrict__ vs,
       } else {
         x = s_x[ct[j]];
       }
-      const T p = (MODE == 2 ? alpha * v : v) * x; // lanes past the row's end:
-                                                   // never added
+      const T p = v * x; // lanes past the row's end: never added
       const int n = rem - j0 < 64 ? rem - j0 : 64;
       if (n == 64) {
 #pragma unroll
@@ -672,6 +685,11 @@ __device__ __forceinline__ T sj_slice(const SjUnit<TV, E>* __restrict__ vs,
     }
     if (lane == 0)
       sum = t;
+  }
+  if constexpr (MODE == 3) { // a row without column entries turns at its end
+    const T as = alpha * sum;
+    const T turned = has_beta ? as + by0 : as;
+    sum = nlow == mylen ? turned : sum;
   }
   return sum;
 }
@@ -1373,7 +1391,8 @@ __global__ __launch_bounds__(512, 4) void csr_sjds_longt_kernel(
 template <typename T, typename TV, int WPB, int E, bool DOT, int MODE>
 __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
     SjArgs<T, TV> A, T alpha, const T* __restrict__ in, T beta, T* __restrict__ out,
-    DotOut dot, RowBlockOrder ord, const T* __restrict__ diagonal)
+    DotOut dot, RowBlockOrder ord, const T* __restrict__ diagonal,
+    const int32_t* __restrict__ low_rowptr)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   T* s_x = reinterpret_cast<T*>(s_raw);
@@ -1435,14 +1454,15 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
     const int32_t myrow = s0c + (lp & 63);
     const int32_t myrow_c = myrow < A.num_rows ? myrow : A.num_rows - 1;
     T x_own = T(0), y0 = T(0), init = T(0);
-    if constexpr (DOT || MODE == 1)
+    int32_t nlow = 0;
+    if constexpr (DOT || MODE == 3)
       x_own = in[myrow_c];
-    if (beta != T(0) && MODE != 2)
+    if (beta != T(0))
       y0 = out[myrow_c];
-    if constexpr (MODE == 1)
+    if constexpr (MODE == 3) {
       init = diagonal[myrow_c] * x_own;
-    if constexpr (MODE == 2)
-      init = out[myrow_c];
+      nlow = low_rowptr[myrow_c + 1] - low_rowptr[myrow_c];
+    }
     const int32_t* cl = A.chunks + (int64_t)b * A.stride;
     // the block's chunks of x: 8 lanes per chunk, 2 elements per lane, four
     // chunks per lane in flight; lanes past the list repeat its last chunk
@@ -1503,19 +1523,21 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
             = reinterpret_cast<const SjUnit<uint32_t, E>*>(A.codes + 4 * a_b)
               + (ub_slice - ub_block);
         sum = sj_slice<T, TV, uint32_t, true, E, MODE>(vs, cs, mylen, lane, s_x, in,
-                                                       init, alpha);
+                                                       init, alpha, nlow, beta * y0,
+                                                       beta != T(0));
       } else {
         const SjUnit<uint16_t, E>* cs
             = reinterpret_cast<const SjUnit<uint16_t, E>*>(
                   A.codes + (A.wide_alloc ? 4 : 2) * a_b)
               + (ub_slice - ub_block);
         sum = sj_slice<T, TV, uint16_t, false, E, MODE>(vs, cs, mylen, lane, s_x, in,
-                                                        init, alpha);
+                                                        init, alpha, nlow, beta * y0,
+                                                        beta != T(0));
       }
       if (myrow < A.num_rows && in_slice) {
-        const T c = MODE == 2 ? sum : alpha * sum;
+        const T c = MODE == 3 ? sum : alpha * sum;
         T y = c;
-        if (beta != T(0) && MODE != 2)
+        if (beta != T(0) && MODE != 3)
           y = c + beta * y0;
         out[myrow] = y;
         if constexpr (DOT)
@@ -1600,7 +1622,8 @@ int sj_wgs_per_cu(int wpb, int64_t lds)
 
 template <typename T, int WPB, int E, bool DOT, int MODE = 0, typename TV = T>
 int sj_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
-              T beta, T* out, DotOut dot, const T* diagonal = nullptr)
+              T beta, T* out, DotOut dot, const T* diagonal = nullptr,
+              const int32_t* low_rowptr = nullptr)
 {
   constexpr bool kMixed = !std::is_same<T, TV>::value; // the fp32 copy of the values
   SjArgs<T, TV> A;
@@ -1648,7 +1671,7 @@ int sj_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
   if (A.phases & 2) {
     hipLaunchKernelGGL((csr_sjds_kernel<T, TV, WPB, E, DOT, MODE>), dim3(grid),
                        dim3(64 * WPB), lds, st, A, alpha, in, beta, out, dot, ord,
-                       diagonal);
+                       diagonal, low_rowptr);
     SPMV_CHECK_LAUNCH();
   }
   if constexpr (MODE != 0) // (symmetric storage: built without long rows)
@@ -2469,34 +2492,113 @@ int spmv_sjds_run_f32f64(const spmv_hip_csr_plan* pl, hipStream_t st, double alp
   return sj_run<double, false, float>(pl, st, alpha, in, beta, out, dot);
 }
 
-// Symmetric storage (csr_kernels.cpp:26-40) in two passes over two sliced
-// jagged structures: the strictly lower block (the plan's own; y = alpha (d x
-// + L x) + beta y) and its transpose (plan->sjt; y += the column's entries in
-// the reference's order).  The fused dot belongs to the second pass.
+// Symmetric storage (csr_kernels.cpp:26-40) in ONE pass over ONE sliced jagged
+// structure (plan->sjt): the "rows" of the merged matrix -- a row's stored lower
+// entries followed by the entries of its column in the reference's order
+// (spmv_sjds_sym_merge) -- by the slices' kernel in MODE 3.
 namespace
 {
-template <typename T, int MODE, bool DOT>
-int sj_run_mode(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
-                T beta, T* out, DotOut dot, const T* diagonal)
-{
-  if (pl->sj_unit != 2)
-    return SPMV_HIP_EINVAL;
-  if (pl->sj_wpb == 8)
-    return sj_launch<T, 8, 2, DOT, MODE>(pl, st, alpha, in, beta, out, dot, diagonal);
-  if (pl->sj_wpb == 16)
-    return sj_launch<T, 16, 2, DOT, MODE>(pl, st, alpha, in, beta, out, dot, diagonal);
-  return SPMV_HIP_EINVAL;
-}
 template <typename T, bool DOT>
 int sj_run_sym(const spmv_hip_csr_plan* pl, hipStream_t st, const T* diagonal, T alpha,
                const T* in, T beta, T* out, DotOut dot)
 {
-  int rc = sj_run_mode<T, 1, false>(pl, st, alpha, in, beta, out, DotOut(), diagonal);
-  if (rc == SPMV_HIP_OK)
-    rc = sj_run_mode<T, 2, DOT>(pl->sjt, st, alpha, in, T(0), out, dot, nullptr);
-  return rc;
+  const spmv_hip_csr_plan* m = pl->sjt;
+  if (m->sj_unit != 2)
+    return SPMV_HIP_EINVAL;
+  if (m->sj_wpb == 8)
+    return sj_launch<T, 8, 2, DOT, 3>(m, st, alpha, in, beta, out, dot, diagonal,
+                                      pl->rowptr0);
+  if (m->sj_wpb == 16)
+    return sj_launch<T, 16, 2, DOT, 3>(m, st, alpha, in, beta, out, dot, diagonal,
+                                       pl->rowptr0);
+  return SPMV_HIP_EINVAL;
+}
+
+// lengths of the merged rows (+ a zero behind them, for the scan)
+__global__ __launch_bounds__(kBlock) void sj_sym_len_kernel(
+    int32_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ t_ptr,
+    int32_t* __restrict__ vptr)
+{
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i <= n;
+       i += (int64_t)gridDim.x * kBlock)
+    vptr[i] = i < n ? (rowptr[i + 1] - rowptr[i]) + (t_ptr[i + 1] - t_ptr[i]) : 0;
+}
+
+// columns of the merged rows and where their values are in the caller's array
+// (one wave per row)
+__global__ __launch_bounds__(kBlock) void sj_sym_merge_kernel(
+    int32_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
+    const int32_t* __restrict__ t_ptr, const int32_t* __restrict__ t_row,
+    const int32_t* __restrict__ t_pos, const int32_t* __restrict__ vptr,
+    int32_t* __restrict__ vcol, int32_t* __restrict__ vmap)
+{
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * kBlock) >> 6;
+  for (int64_t i = wid; i < n; i += nw) {
+    const int32_t a = rowptr[i], nl = rowptr[i + 1] - a;
+    const int32_t ta = t_ptr[i], nu = t_ptr[i + 1] - ta;
+    const int32_t d = vptr[i];
+    for (int32_t k = lane; k < nl; k += 64) {
+      vcol[d + k] = colind[a + k];
+      vmap[d + k] = a + k;
+    }
+    for (int32_t k = lane; k < nu; k += 64) {
+      vcol[d + nl + k] = t_row[ta + k];
+      vmap[d + nl + k] = t_pos[ta + k];
+    }
+  }
 }
 } // namespace
+
+// The merged matrix of a symmetric plan with its transposed map: row pointer,
+// columns and value positions, owned by the caller (hipFree).  ENOMEM: no memory.
+int spmv_sjds_sym_merge(const spmv_hip_csr_plan* pl, int32_t** vptr, int32_t** vcol,
+                        int32_t** vmap, hipStream_t st)
+{
+  const int32_t n = pl->num_rows;
+  const int64_t nnz2 = 2 * pl->nnz;
+  if (nnz2 > INT32_MAX)
+    return SPMV_HIP_ENOTSUP;
+  *vptr = *vcol = *vmap = nullptr;
+  void* tmp = nullptr;
+  size_t tb = 0;
+  hipError_t e = hipMalloc(vptr, sizeof(int32_t) * ((size_t)n + 1));
+  if (e == hipSuccess)
+    e = hipMalloc(vcol, sizeof(int32_t) * (size_t)nnz2);
+  if (e == hipSuccess)
+    e = hipMalloc(vmap, sizeof(int32_t) * (size_t)nnz2);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(sj_sym_len_kernel, dim3(spmv_grid_for(pl->ctx, n + 1, kBlock)),
+                       dim3(kBlock), 0, st, n, pl->rowptr0, pl->t_ptr, *vptr);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess)
+    e = hipcub::DeviceScan::ExclusiveSum(nullptr, tb, *vptr, *vptr, n + 1, st);
+  if (e == hipSuccess)
+    e = hipMalloc(&tmp, tb ? tb : 16);
+  if (e == hipSuccess)
+    e = hipcub::DeviceScan::ExclusiveSum(tmp, tb, *vptr, *vptr, n + 1, st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(sj_sym_merge_kernel,
+                       dim3(spmv_grid_for(pl->ctx, n, kBlock / 64)), dim3(kBlock), 0, st,
+                       n, pl->rowptr0, pl->colind0, pl->t_ptr, pl->t_row, pl->t_pos,
+                       *vptr, *vcol, *vmap);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st);
+  (void)hipFree(tmp);
+  if (e != hipSuccess) {
+    (void)hipFree(*vptr);
+    (void)hipFree(*vcol);
+    (void)hipFree(*vmap);
+    *vptr = *vcol = *vmap = nullptr;
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? SPMV_HIP_ENOMEM : static_cast<int>(e);
+  }
+  return SPMV_HIP_OK;
+}
 
 int spmv_sjds_run_sym_f64(const spmv_hip_csr_plan* pl, hipStream_t st,
                           const double* diagonal, double alpha, const double* in,

@@ -458,9 +458,9 @@ int run_symmetric(const spmv_hip_csr_plan* pl, hipStream_t st,
       return spmv_slat_run_f32(pl, st, rowptr, values, diagonal, alpha, in, beta,
                                out);
   }
-  // no lattice structure (FEM matrices): both blocks in the sliced jagged form
-  if (pl->sym_det && pl->sym_sj && pl->sj && pl->sj_val && pl->sjt && pl->sjt->sj_val
-      && pl->sj_elem == (int)sizeof(T) && values == pl->sj_values0
+  // no lattice structure (FEM matrices): the merged matrix in the sliced jagged form
+  if (pl->sym_det && pl->sym_sj && pl->sj && pl->sjt && pl->sjt->sj_val
+      && pl->sjt->sj_elem == (int)sizeof(T) && values == pl->sjt->sj_values0
       && diagonal == pl->sj_diag0 && aligned16(in) && pl->num_cols >= 2) {
     if constexpr (sizeof(T) == 8)
       return spmv_sjds_run_sym_f64(pl, st, diagonal, alpha, in, beta, out, dot);

@@ -865,13 +865,14 @@ def _sym_lower_cases():
 
 @pytest.mark.parametrize("wpb", [0, 8, 16])
 def test_symmetric_storage_sliced_jagged_bit_exact(sj_ctx, wpb):
-    """Symmetric storage of matrices WITHOUT lattice structure: both blocks of
-    the reference's loop (csr_kernels.cpp:26-40) in the sliced jagged form --
-    the strictly lower block as stored (sum starts at d_i x_i) and its transpose
-    (y_i += fl(fl(alpha v) x_r) in ascending (r, j)) -- against
-    oracle.csr_spmv_sym, every element identical; any alpha / beta, the fused
-    dot, fp32, coefficients rewritten in place, and the transposed-map kernel
-    (sjds = 0) on the same plan."""
+    """Symmetric storage of matrices WITHOUT lattice structure: the reference's
+    loop (csr_kernels.cpp:26-40) seen from the row, in the sliced jagged form of
+    the MERGED matrix -- a row's stored lower entries (sum starts at d_i x_i),
+    then the entries of its column in ascending (r, j), where the sum turns into
+    y_i = fl(alpha sum + beta y0_i) and every product into fl(fl(alpha v) x_r)
+    -- against oracle.csr_spmv_sym, every element identical; any alpha / beta,
+    the fused dot, fp32, coefficients rewritten in place, and the
+    transposed-map kernel (sjds = 0) on the same plan."""
     ctx = sj_ctx
     ctx.set_option("sj_wpb", wpb)
     part = ctx.empty(ctx.dot_partials_len, np.float64)
