@@ -23,6 +23,8 @@ def short(name):
             return "csr_sjds_kernel sym lower"
         if mode == "2":
             return "csr_sjds_kernel sym transposed"
+        if mode == "3":
+            return "csr_sjds_kernel sym merged"
     for k in ("csr_sjds_longt_kernel", "csr_sjds_long_kernel", "csr_sjds_kernel", "csr_box27_half_kernel", "csr_box27_const_kernel", "csr_const_dia_tile_kernel", "csr_const_dia_kernel", "csr_lxw_kernel",
               "csr_wdia_kernel", "csr_lattice_kernel", "csr_sym_lattice_kernel", "csr_sym_dia_kernel", "csr_rowblock_lx_kernel",
               "csr_rowblock_kernel", "csr_symt_kernel", "csr_sym_window_kernel",
