@@ -494,6 +494,20 @@ def test_petsc_file_of_a_ragged_matrix_one_million_rows(exec_, comm, tmp_path, k
     A.mult(d_x, d_y)
     assert np.array_equal(exec_.copy_to_host(d_y, N), y_ref)
     A.close()
+    # ... and read with symmetric = true (demos/cg.cpp:47: the reader keeps the
+    # strictly lower part and the diagonal, Matrix.cpp:337-349): the merged
+    # matrix in the sliced jagged form where the long rows leave room for it,
+    # else the transposed map -- the reference's symmetric loop bit for bit
+    from util import lower_split
+    lrp, lci, lva, ldg = lower_split(rp, ci, va)
+    A = host.read_petsc_binary_matrix(fa, comm, exec_, True, host.P2P_NONBLOCKING)
+    assert A.symmetric() and A.rows() == N
+    assert A.plan_get("sym_sj") == (1 if kind == "fem" else 0)
+    exec_.memset(d_y, 0xFF, 8 * N)
+    A.mult(d_x, d_y)
+    assert np.array_equal(exec_.copy_to_host(d_y, N),
+                          oracle.csr_spmv_sym(lrp, lci, lva, ldg, x))
+    A.close()
     exec_.free(d_x), exec_.free(d_y)
 
 
