@@ -316,6 +316,9 @@ struct spmv_hip_csr_plan {
   int32_t* sj_lt_np = nullptr;
   int64_t* sj_lt_off = nullptr;
   int32_t* sj_lt_tab = nullptr;
+  uint16_t* sj_lt_codes = nullptr; // the listed rows' columns: positions in their panels
+  int64_t* sj_lt_coff = nullptr;   // ... per listed row its first code
+  int64_t sj_lt_codes_n = 0;
   int64_t sj_lt_entries = 0;
   int sj_lt_nsg = 0;
   int sj_long_table = 1;  // use that (plan_set "sj_long_table")

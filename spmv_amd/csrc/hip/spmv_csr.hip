@@ -2029,7 +2029,8 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
            + 4 * (int64_t)plan->sj_nblk * plan->sj_stride
            + (plan->sj_wide_alloc ? 4 : 2) * plan->sj_units * plan->sj_unit
            + 4 * (int64_t)plan->sj_nlong + 4 * ((n + 63) / 64 + 1)
-           + 4 * plan->sj_lt_entries + 16 * (int64_t)plan->sj_lt_nsg;
+           + 4 * plan->sj_lt_entries + 16 * (int64_t)plan->sj_lt_nsg
+           + 2 * plan->sj_lt_codes_n + 8 * (int64_t)plan->sj_nlong;
     if (plan->sj_val)
       b += (int64_t)plan->sj_elem * plan->sj_units * plan->sj_unit;
     if (plan->sj_val32)

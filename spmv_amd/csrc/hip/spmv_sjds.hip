@@ -512,6 +512,8 @@ struct SjArgs {
   const int32_t* lt_np;
   const int64_t* lt_off;
   const int32_t* lt_tab;
+  const uint16_t* lt_codes; // per entry of the listed rows: column - its panel's first
+  const int64_t* lt_coff;   // per listed row: its first code
 };
 
 template <typename T>
@@ -1023,7 +1025,9 @@ __global__ __launch_bounds__(64 * WPB) void csr_sjds_long_kernel(
 //     (sj_lt_fill_kernel: one bisection per row and boundary), so a row's
 //     range inside a panel is known before anything is loaded: loads run a
 //     trip ahead whatever the columns are, nothing is loaded twice, and `ok`
-//     is an index comparison;
+//     is an index comparison; with the panels fixed at plan time the plan also
+//     keeps every entry's column as a 16-bit position inside its panel (2
+//     instead of 4 bytes per entry streamed, and no subtraction);
 //   * a lane loads FOUR consecutive entries of the trip's 32 (16-byte loads:
 //     one 256-byte piece of the values per row instead of four 64-byte ones);
 //     the row's sum travels down the group's eight lanes by DPP (row_shr:1):
@@ -1046,6 +1050,8 @@ __global__ __launch_bounds__(64 * WPB) void csr_sjds_long_kernel(
 //   the matrix loaded non-temporally (nt):                   0.458 against 0.352
 //   an XCD's workgroups on consecutive supergroups (interleaved) instead of
 //   contiguous runs per workgroup:                    0.331-0.339 against 0.343-0.351
+//   the columns as 16-bit panel positions (the plan's own array, SJ_LT_CODES)
+//   instead of the caller's colind:                          0.294 against 0.328
 // -- whatever makes a supergroup wider (more rows: more panels, more staged x)
 // loses.  A build with clocks in it (SJ_LT_PROBE) shows where the time goes:
 // 1.03 us per trip of a wave whether its neighbours are busy or idle, 0.34 us
@@ -1074,6 +1080,14 @@ constexpr int kSjLtEpl = SJ_LT_EPL;       // entries per lane and trip (4 or 8)
 #endif
 constexpr int kSjLtDepth = SJ_LT_DEPTH;   // trips of loads in flight ahead
 constexpr int kSjLtTrip = kSjLtG * kSjLtEpl; // ... per group and trip
+#ifndef SJ_LT_CODES
+#define SJ_LT_CODES 1
+#endif
+// the long rows' columns as 16-bit positions inside their panel (the plan's own
+// array, 2 B per entry) instead of the caller's 4-byte colind: 10 instead of 12
+// bytes per entry streamed
+constexpr bool kSjLtCodes = SJ_LT_CODES != 0;
+static_assert(kSjLtPanel <= 65536, "16-bit panel positions");
 static_assert(kSjLtTrip * (kSjLtDepth + 1) + 8 <= kSjLongPad, "loads past a row's end");
 static_assert(kSjLtPanel % 1024 == 0, "whole staging rounds");
 
@@ -1180,10 +1194,16 @@ __global__ __launch_bounds__(512, 4) void csr_sjds_longt_kernel(
       const int32_t cmin = A.lt_cmin[sg];
       const int32_t* tab = A.lt_tab + A.lt_off[sg];
       int32_t lo[RS], hi[RS];
+      int64_t cb[RS]; // the row's codes: entry e's is at lt_codes[cb + e]
 #pragma unroll
       for (int j = 0; j < RS; ++j) {
         lo[j] = tab[slot[j]];
         hi[j] = tab[RUN + slot[j]];
+        cb[j] = 0;
+        if constexpr (kSjLtCodes) {
+          const int li = sg * RUN + slot[j];
+          cb[j] = A.lt_coff[li < A.nlong ? li : A.nlong - 1] - lo[j];
+        }
       }
       for (int p = 0; p < np; ++p) {
         const int32_t p0 = cmin + p * PANEL; // (<= the supergroup's last column)
@@ -1215,9 +1235,11 @@ __global__ __launch_bounds__(512, 4) void csr_sjds_longt_kernel(
         // D trips of loads in flight ahead of the one being consumed: a ring of
         // D + 1 register sets, the loop unrolled over it
         constexpr int D = kSjLtDepth;
+        typedef typename std::conditional<kSjLtCodes, uint16_t, int32_t>::type code_t;
         SjPack<TV, EPL> vv[D + 1];
-        SjPack<int32_t, EPL> cc[D + 1];
-        auto issue = [&](SjPack<TV, EPL>& v, SjPack<int32_t, EPL>& c, int32_t pos) {
+        SjPack<code_t, EPL> cc[D + 1];
+        auto issue = [&](SjPack<TV, EPL>& v, SjPack<code_t, EPL>& c, int32_t pos,
+                         int j) {
           // (no clamp: a long row ends kSjLongPad entries before the arrays do;
           // a finished group reads entries 0 ...)
 #ifdef SJ_LT_PROBE_NOLOAD
@@ -1226,18 +1248,31 @@ __global__ __launch_bounds__(512, 4) void csr_sjds_longt_kernel(
           const int64_t e = (int64_t)pos + EPL * l;
 #endif
           v = *reinterpret_cast<const SjPack<TV, EPL>*>(A.values + e);
-          c = *reinterpret_cast<const SjPack<int32_t, EPL>*>(A.colind + e);
+          if constexpr (kSjLtCodes) {
+            int64_t base = cb[0];
+#pragma unroll
+            for (int r = 1; r < RS; ++r)
+              base = j == r ? cb[r] : base;
+            // (a finished group reads the array's first codes)
+            const int64_t ce = j < RS ? base + e : (int64_t)EPL * l;
+            c = *reinterpret_cast<const SjPack<code_t, EPL>*>(
+                reinterpret_cast<const code_t*>(A.lt_codes) + ce);
+          } else {
+            c = *reinterpret_cast<const SjPack<code_t, EPL>*>(
+                reinterpret_cast<const code_t*>(A.colind) + e);
+          }
         };
-        auto consume = [&](const SjPack<TV, EPL>& v, const SjPack<int32_t, EPL>& c,
+        auto consume = [&](const SjPack<TV, EPL>& v, const SjPack<code_t, EPL>& c,
                            int j, int32_t pos, int32_t end) {
           T pr[EPL], xs[EPL];
 #pragma unroll
           for (int k = 0; k < EPL; ++k) {
             const bool ok = pos + EPL * l + k < end;
+            const int32_t xi = kSjLtCodes ? (int32_t)c.e[k] : (int32_t)c.e[k] - p0;
 #ifdef SJ_LT_PROBE_NOLDS
-            xs[k] = (T)(ok ? c.e[k] - p0 : 0);
+            xs[k] = (T)(ok ? xi : 0);
 #else
-            xs[k] = s_x[ok ? c.e[k] - p0 : 0];
+            xs[k] = s_x[ok ? xi : 0];
 #endif
           }
           // (every LDS read is wanted whatever `ok` says: left to itself the
@@ -1289,7 +1324,7 @@ __global__ __launch_bounds__(512, 4) void csr_sjds_longt_kernel(
         }
 #pragma unroll
         for (int d = 0; d < D; ++d)
-          issue(vv[d], cc[d], posq[d]);
+          issue(vv[d], cc[d], posq[d], jq[d]);
 #ifdef SJ_LT_PROBE
         const long long pc0 = wall_clock64();
 #endif
@@ -1320,7 +1355,7 @@ __global__ __launch_bounds__(512, 4) void csr_sjds_longt_kernel(
 #pragma unroll
           for (int u = 0; u <= D; ++u) {
             if (go) { // (uniform) slot u is consumed, slot u + D (mod D + 1) is free
-              issue(vv[(u + D) % (D + 1)], cc[(u + D) % (D + 1)], posq[D]);
+              issue(vv[(u + D) % (D + 1)], cc[(u + D) % (D + 1)], posq[D], jq[D]);
               consume(vv[u], cc[u], jq[0], posq[0], endq[0]);
 #pragma unroll
               for (int d = 0; d < D; ++d)
@@ -1650,6 +1685,8 @@ int sj_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
   A.lt_np = pl->sj_lt_np;
   A.lt_off = pl->sj_lt_off;
   A.lt_tab = pl->sj_lt_tab;
+  A.lt_codes = pl->sj_lt_codes;
+  A.lt_coff = pl->sj_lt_coff;
   const size_t lds = (size_t)pl->sj_maxk * kSjChunk * sizeof(T) + 16;
   int wgs = pl->sj_blocks_per_cu > 0 ? pl->sj_blocks_per_cu
                                      : sj_wgs_per_cu(WPB, (int64_t)lds + 64);
@@ -2006,8 +2043,43 @@ __global__ __launch_bounds__(kBlock) void sj_lt_fill_kernel(
   }
 }
 
+// lengths of the listed rows (+ a zero behind them, for the scan)
+__global__ __launch_bounds__(kBlock) void sj_lt_len_kernel(
+    int nlong, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rows,
+    int64_t* __restrict__ coff)
+{
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i <= nlong; i += gridDim.x * kBlock)
+    coff[i] = i < nlong ? (int64_t)(rowptr[rows[i] + 1] - rowptr[rows[i]]) : 0;
+}
+
+// every entry's column as its position inside its panel (one wave per row;
+// supergroups that are not walked by panels keep zeros)
+__global__ __launch_bounds__(kBlock) void sj_lt_codes_kernel(
+    int nlong, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
+    const int32_t* __restrict__ rows, const int32_t* __restrict__ cmin_in,
+    const int32_t* __restrict__ np_in, const int64_t* __restrict__ coff,
+    uint16_t* __restrict__ codes)
+{
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * kBlock) >> 6;
+  for (int64_t li = wid; li < nlong; li += nw) {
+    const int sg = (int)(li / kSjLtRun);
+    const int32_t a = rowptr[rows[li]], b = rowptr[rows[li] + 1];
+    const int32_t cmin = cmin_in[sg];
+    const bool by_panels = np_in[sg] > 0;
+    uint16_t* out = codes + coff[li];
+    for (int32_t e = a + lane; e < b; e += 64)
+      out[e - a] = by_panels ? (uint16_t)((colind[e] - cmin) % kSjLtPanel) : (uint16_t)0;
+  }
+}
+
 void sj_lt_free(spmv_hip_csr_plan* pl)
 {
+  (void)hipFree(pl->sj_lt_codes);
+  (void)hipFree(pl->sj_lt_coff);
+  pl->sj_lt_codes = nullptr;
+  pl->sj_lt_coff = nullptr;
   (void)hipFree(pl->sj_lt_cmin);
   (void)hipFree(pl->sj_lt_np);
   (void)hipFree(pl->sj_lt_off);
@@ -2082,12 +2154,55 @@ int sj_build_long_table(spmv_hip_csr_plan* pl, const int32_t* rowptr,
   }
   if (e == hipSuccess)
     e = hipStreamSynchronize(st);
+  // the rows' columns as 16-bit panel positions (kSjLtCodes)
+  int64_t ncodes = 0;
+  if (e == hipSuccess && kSjLtCodes) {
+    void* tmp2 = nullptr;
+    size_t tb2 = 0;
+    e = hipMalloc(&pl->sj_lt_coff, sizeof(int64_t) * ((size_t)nlong + 1));
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(sj_lt_len_kernel, dim3(spmv_grid_for(pl->ctx, nlong + 1, kBlock)),
+                         dim3(kBlock), 0, st, nlong, rowptr, pl->sj_long_rows,
+                         pl->sj_lt_coff);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+      e = hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, pl->sj_lt_coff, pl->sj_lt_coff,
+                                           nlong + 1, st);
+    if (e == hipSuccess)
+      e = hipMalloc(&tmp2, tb2 ? tb2 : 16);
+    if (e == hipSuccess)
+      e = hipcub::DeviceScan::ExclusiveSum(tmp2, tb2, pl->sj_lt_coff, pl->sj_lt_coff,
+                                           nlong + 1, st);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(&ncodes, pl->sj_lt_coff + nlong, sizeof(int64_t),
+                         hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess)
+      e = hipStreamSynchronize(st);
+    (void)hipFree(tmp2);
+    // (loads run up to two trips past a row's end: slack behind the last row)
+    const size_t nalloc = (size_t)ncodes + 4 * kSjLtTrip * (kSjLtDepth + 1);
+    if (e == hipSuccess)
+      e = hipMalloc(&pl->sj_lt_codes, sizeof(uint16_t) * nalloc);
+    if (e == hipSuccess)
+      e = hipMemsetAsync(pl->sj_lt_codes, 0, sizeof(uint16_t) * nalloc, st);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(sj_lt_codes_kernel,
+                         dim3(spmv_grid_for(pl->ctx, nlong, kBlock / 64)), dim3(kBlock), 0,
+                         st, nlong, rowptr, colind, pl->sj_long_rows, pl->sj_lt_cmin,
+                         pl->sj_lt_np, pl->sj_lt_coff, pl->sj_lt_codes);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+      e = hipStreamSynchronize(st);
+  }
   if (e != hipSuccess) {
     sj_lt_free(pl);
     (void)hipGetLastError();
     return e == hipErrorOutOfMemory ? SPMV_HIP_OK : static_cast<int>(e);
   }
   pl->sj_lt_entries = total;
+  pl->sj_lt_codes_n = ncodes;
   pl->sj_lt_nsg = nsg;
   return sj_lt_raise_lds();
 }
