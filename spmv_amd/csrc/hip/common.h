@@ -54,6 +54,9 @@ struct spmv_hip_ctx {
   int sj_wpb = 0;
   // ... and this many entries per lane and step ("sj_unit": 1, 2, 4; 0 = choose)
   int sj_unit = 0;
+  // blocks of 16 slices sorted by length across the block, two slices per wave
+  // ("sj_sigma"; 0: every slice sorted for itself, one slice per wave)
+  int sj_sigma = 1;
   // symmetric storage takes the sliced jagged form only while the long rows
   // of its two blocks (which stay inside the slices there) hold at most this
   // share of the entries ("sym_sj_long_permille")

@@ -303,6 +303,8 @@ struct spmv_hip_csr_plan {
   int sj_unit = 1;               // entries per lane and step (1, 2, 4)
   int64_t sj_units = 0;          // units in the jagged arrays
   int sj_wpb = 0;                // slices (waves) per block: 4, 8, 16
+  int sj_sigma = 0;              // 16-slice blocks sorted by length across the block,
+                                 // a wave takes two slices (spmv_sjds.hip)
   int sj_nblk = 0, sj_maxk = 0, sj_stride = 0, sj_wide_alloc = 0;
   int64_t sj_far = 0, sj_sumk = 0; // entries gathered from memory; staged chunks
   int32_t* sj_long_rows = nullptr; // rows the slices leave out (one wave each)

@@ -1956,6 +1956,9 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
   else if (!strcmp(key, "sj_wpb")) // (symmetric storage: the merged matrix's)
     *value = plan->sj_lenperm ? plan->sj_wpb
              : plan->sjt && plan->sjt->sj_lenperm ? plan->sjt->sj_wpb : 0;
+  else if (!strcmp(key, "sj_sigma"))
+    *value = plan->sj_lenperm ? plan->sj_sigma
+             : plan->sjt && plan->sjt->sj_lenperm ? plan->sjt->sj_sigma : 0;
   else if (!strcmp(key, "sj_unit"))
     *value = plan->sj_lenperm ? plan->sj_unit
              : plan->sjt && plan->sjt->sj_lenperm ? plan->sjt->sj_unit : 0;

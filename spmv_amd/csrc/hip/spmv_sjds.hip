@@ -285,6 +285,60 @@ __global__ __launch_bounds__(kBlock) void sj_units_kernel(
   }
 }
 
+// SIGMA layout (blocks of 1024 rows = 16 slices): the rows are sorted by length
+// across the whole BLOCK, so that a slice holds rows of (nearly) one length --
+// a slice runs as many steps as its longest row, and with rows of 5 ... 40
+// entries side by side that is 2.5 times the average.  The kernel then gives a
+// wave TWO slices, the k-th longest and the k-th shortest.  Per block (one
+// workgroup): the (length, row in block) word of every sorted position -- the
+// length from bit 10 up -- and the units of its 16 slices.
+constexpr int kSjSigRows = 1024;
+constexpr int kSjSigBits = 10;
+__global__ __launch_bounds__(kBlock) void sj_sigma_kernel(
+    int32_t num_rows, const int32_t* __restrict__ rowptr, int long_thr, int64_t nnz,
+    int E, int32_t* __restrict__ lenperm, uint32_t* __restrict__ units)
+{
+  __shared__ int32_t s_len[kSjSigRows];
+  __shared__ uint32_t s_units[kSjSigRows / 64];
+  const int nblk = (num_rows + kSjSigRows - 1) / kSjSigRows;
+  for (int b = blockIdx.x; b <= nblk; b += gridDim.x) {
+    if (b == nblk) { // the scan's total
+      if (threadIdx.x == 0)
+        units[(int64_t)nblk * (kSjSigRows / 64)] = 0;
+      continue;
+    }
+    const int32_t r0 = b * kSjSigRows;
+    for (int i = threadIdx.x; i < kSjSigRows; i += kBlock) {
+      int32_t v = 0; // bit 30: a LONG row (not in the slices: length 0, marked)
+      if (r0 + i < num_rows) {
+        const int32_t ra = rowptr[r0 + i], rb = rowptr[r0 + i + 1];
+        v = sj_is_long(ra, rb, long_thr, nnz) ? (1 << 30) : rb - ra;
+      }
+      s_len[i] = v;
+    }
+    if (threadIdx.x < kSjSigRows / 64)
+      s_units[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < kSjSigRows; i += kBlock) {
+      const int32_t vi = s_len[i];
+      const int32_t li = vi & ~(1 << 30);
+      int rank = 0; // longer rows first, ties: the lower row first
+      for (int j = 0; j < kSjSigRows; ++j) {
+        const int32_t lj = s_len[j] & ~(1 << 30);
+        rank += (lj > li || (lj == li && j < i)) ? 1 : 0;
+      }
+      lenperm[(int64_t)r0 + rank]
+          = (int32_t)(((uint32_t)li << kSjSigBits) | (uint32_t)i
+                      | ((vi >> 30) & 1 ? kSjLongFlag : 0u));
+      atomicAdd(&s_units[rank / 64], (uint32_t)((li + E - 1) / E));
+    }
+    __syncthreads();
+    if (threadIdx.x < kSjSigRows / 64)
+      units[(int64_t)b * (kSjSigRows / 64) + threadIdx.x] = s_units[threadIdx.x];
+    __syncthreads();
+  }
+}
+
 // the slice's rows in jagged order: lane rho gets the row (0..63 within the
 // slice) with the rho-th largest length (ties: the lower row first)
 __device__ __forceinline__ void sj_sort_slice(int32_t len, int lane, int32_t* my_len,
@@ -318,7 +372,7 @@ __global__ __launch_bounds__(kBlock) void sj_fill_kernel(
     int stride, int wide_alloc, const int32_t* __restrict__ blk_far,
     const uint32_t* __restrict__ ubase, int32_t* __restrict__ blk,
     int32_t* __restrict__ chunks, int32_t* __restrict__ lenperm,
-    unsigned char* __restrict__ codes)
+    unsigned char* __restrict__ codes, int sigma)
 {
   __shared__ uint32_t s_bits[kSjSpanWords];
   __shared__ int32_t s_pre[kSjSpanWords + 1];
@@ -359,24 +413,31 @@ __global__ __launch_bounds__(kBlock) void sj_fill_kernel(
     uint32_t* c32 = reinterpret_cast<uint32_t*>(codes + 4 * a_b);
     for (int sl = wave; sl < R / 64; sl += kBlock / 64) {
       const int32_t s0 = r0 + sl * 64;
-      if (s0 >= num_rows)
+      if (s0 >= num_rows && !sigma)
         break;
-      const int32_t row = s0 + lane;
-      int32_t len = 0;
-      bool is_long = false; // not in the slice: length 0, marked
-      if (row < num_rows) {
-        const int32_t ra = rowptr[row], rb = rowptr[row + 1];
-        is_long = sj_is_long(ra, rb, long_thr, nnz);
-        len = is_long ? 0 : rb - ra;
+      int32_t mylen, src0;
+      if (sigma) { // (sj_sigma_kernel sorted the block and wrote the words)
+        const uint32_t w = (uint32_t)lenperm[s0 + lane] & ~kSjLongFlag;
+        mylen = (int32_t)(w >> kSjSigBits);
+        const int32_t grow = r0 + (int32_t)(w & (kSjSigRows - 1));
+        src0 = grow < num_rows ? rowptr[grow] : 0;
+      } else {
+        const int32_t row = s0 + lane;
+        int32_t len = 0;
+        bool is_long = false; // not in the slice: length 0, marked
+        if (row < num_rows) {
+          const int32_t ra = rowptr[row], rb = rowptr[row + 1];
+          is_long = sj_is_long(ra, rb, long_thr, nnz);
+          len = is_long ? 0 : rb - ra;
+        }
+        int myrow;
+        sj_sort_slice(len, lane, &mylen, &myrow);
+        const bool my_long = __shfl((int)is_long, myrow, 64) != 0;
+        lenperm[s0 + lane]
+            = (int32_t)(((uint32_t)mylen << 6) | (uint32_t)myrow
+                        | (my_long ? kSjLongFlag : 0u));
+        src0 = s0 + myrow < num_rows ? rowptr[s0 + myrow] : 0;
       }
-      int32_t mylen;
-      int myrow;
-      sj_sort_slice(len, lane, &mylen, &myrow);
-      const bool my_long = __shfl((int)is_long, myrow, 64) != 0;
-      lenperm[s0 + lane]
-          = (int32_t)(((uint32_t)mylen << 6) | (uint32_t)myrow
-                      | (my_long ? kSjLongFlag : 0u));
-      const int32_t src0 = s0 + myrow < num_rows ? rowptr[s0 + myrow] : 0;
       const int32_t myu = (mylen + E - 1) / E;
       const int32_t maxu = __shfl(myu, 0, 64);
       int64_t off = (int64_t)ubase[s0 / 64] * E - a_b; // entries, in the block
@@ -411,19 +472,22 @@ __global__ __launch_bounds__(kBlock) void sj_bake_kernel(
     int32_t num_rows, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ lenperm, const uint32_t* __restrict__ ubase, int E,
     const T* __restrict__ values, const int32_t* __restrict__ map,
-    T* __restrict__ sval)
+    T* __restrict__ sval, int rbits)
 {
   // map (symmetric storage, the transposed block): entry e of the plan's CSR
   // arrays is values[map[e]]
   const int lane = threadIdx.x & 63;
-  const int64_t nsl = ((int64_t)num_rows + 63) / 64;
+  const int64_t nsl = rbits == 6 ? ((int64_t)num_rows + 63) / 64
+                                 : (((int64_t)num_rows + (1 << rbits) - 1) >> rbits)
+                                       << (rbits - 6);
   const int64_t wid = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * kBlock) >> 6;
   for (int64_t s = wid; s < nsl; s += nw) {
     const int32_t s0 = (int32_t)(s * 64);
+    // (rbits = 6: the row inside its slice; 10: inside its block of 1024 rows)
     const int32_t lp = lenperm[s0 + lane];
-    const int32_t mylen = (int32_t)(((uint32_t)lp & ~kSjLongFlag) >> 6);
-    const int32_t myrow = s0 + (lp & 63);
+    const int32_t mylen = (int32_t)(((uint32_t)lp & ~kSjLongFlag) >> rbits);
+    const int32_t myrow = (s0 & ~((1 << rbits) - 1)) + (lp & ((1 << rbits) - 1));
     const int64_t src0 = myrow < num_rows ? rowptr[myrow] : 0;
     const int32_t myu = (mylen + E - 1) / E;
     const int32_t maxu = __shfl(myu, 0, 64);
@@ -1423,7 +1487,9 @@ __global__ __launch_bounds__(512, 4) void csr_sjds_longt_kernel(
   }
 }
 
-template <typename T, typename TV, int WPB, int E, bool DOT, int MODE>
+// SIG (sigma layout, WPB = 8): blocks of 1024 rows sorted by length across the
+// block, a wave takes the slices `wave` and `15 - wave` one after the other.
+template <typename T, typename TV, int WPB, int E, bool DOT, int MODE, bool SIG = false>
 __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
     SjArgs<T, TV> A, T alpha, const T* __restrict__ in, T beta, T* __restrict__ out,
     DotOut dot, RowBlockOrder ord, const T* __restrict__ diagonal,
@@ -1433,7 +1499,10 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
   T* s_x = reinterpret_cast<T*>(s_raw);
   __shared__ double s_red[WPB];
   constexpr int NT = 64 * WPB;
-  constexpr int R = 64 * WPB;
+  constexpr int SPW = SIG ? 2 : 1;      // slices per wave and block
+  constexpr int R = 64 * WPB * SPW;     // rows per block
+  constexpr int RB = SIG ? kSjSigBits : 6; // the row's bits in its (length, row) word
+  static_assert(!SIG || R == kSjSigRows, "sigma blocks are 1024 rows");
   typedef T pair_t __attribute__((ext_vector_type(2)));
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int part = t & 7, cg = t >> 3;
@@ -1472,31 +1541,41 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
     const int K = A.blk[2 * b];
     const int wide = A.blk[2 * b + 1];
     const int32_t r0 = b * R;
-    const int32_t s0 = r0 + wave * 64;
-    // the slice's own loads first: they do not depend on the staged x
-    // (a slice past the end of the matrix reads the last one's, unused)
-    const bool have = s0 < A.num_rows;
-    const int32_t s0c = have ? s0 : ((A.num_rows - 1) / 64) * 64;
-    const uint32_t lpw = (uint32_t)A.lenperm[s0c + lane];
-    const int32_t lp = (int32_t)(lpw & ~kSjLongFlag);
-    const bool in_slice = (lpw & kSjLongFlag) == 0; // else phase 0 wrote its y
+    // the slices' own loads first: they do not depend on the staged x
+    // (a slice past the end of the matrix reads the last one's, unused).  The
+    // sigma layout gives the wave the slices `wave` and `2 WPB - 1 - wave` of
+    // the block (sorted by length across the block: the longest rows with the
+    // shortest), every slice of the block being there.
+    bool have[SPW], in_slice[SPW];
+    int32_t lp[SPW], myrow[SPW], nlow[SPW];
+    uint32_t ub_slice[SPW];
+    T x_own[SPW], y0[SPW], init[SPW];
     // (uniform per wave, and told so: the slice's base pointers then live in
     // scalar registers and a step's address costs no vector arithmetic)
-    const uint32_t ub_slice
-        = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.ubase[s0c / 64]);
     const uint32_t ub_block
         = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.ubase[r0 / 64]);
-    const int32_t myrow = s0c + (lp & 63);
-    const int32_t myrow_c = myrow < A.num_rows ? myrow : A.num_rows - 1;
-    T x_own = T(0), y0 = T(0), init = T(0);
-    int32_t nlow = 0;
-    if constexpr (DOT || MODE == 3)
-      x_own = in[myrow_c];
-    if (beta != T(0))
-      y0 = out[myrow_c];
-    if constexpr (MODE == 3) {
-      init = diagonal[myrow_c] * x_own;
-      nlow = low_rowptr[myrow_c + 1] - low_rowptr[myrow_c];
+#pragma unroll
+    for (int h = 0; h < SPW; ++h) {
+      const int sl = h == 0 ? wave : 2 * WPB - 1 - wave;
+      const int32_t s0 = r0 + sl * 64;
+      have[h] = SIG || s0 < A.num_rows;
+      const int32_t s0c = have[h] ? s0 : ((A.num_rows - 1) / 64) * 64;
+      const uint32_t lpw = (uint32_t)A.lenperm[s0c + lane];
+      lp[h] = (int32_t)(lpw & ~kSjLongFlag);
+      in_slice[h] = (lpw & kSjLongFlag) == 0; // else phase 0 wrote its y
+      ub_slice[h] = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.ubase[s0c / 64]);
+      myrow[h] = (SIG ? r0 : s0c) + (lp[h] & ((1 << RB) - 1));
+      const int32_t myrow_c = myrow[h] < A.num_rows ? myrow[h] : A.num_rows - 1;
+      x_own[h] = y0[h] = init[h] = T(0);
+      nlow[h] = 0;
+      if constexpr (DOT || MODE == 3)
+        x_own[h] = in[myrow_c];
+      if (beta != T(0))
+        y0[h] = out[myrow_c];
+      if constexpr (MODE == 3) {
+        init[h] = diagonal[myrow_c] * x_own[h];
+        nlow[h] = low_rowptr[myrow_c + 1] - low_rowptr[myrow_c];
+      }
     }
     const int32_t* cl = A.chunks + (int64_t)b * A.stride;
     // the block's chunks of x: 8 lanes per chunk, 2 elements per lane, four
@@ -1547,36 +1626,39 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
 #ifdef SJ_PROBE
     const long long pq3 = wall_clock64();
 #endif
-    if (have) {
-      const int32_t mylen = lp >> 6;
+#pragma unroll
+    for (int h = 0; h < SPW; ++h) {
+      if (!have[h])
+        continue;
+      const int32_t mylen = lp[h] >> RB;
       const SjUnit<TV, E>* vs
-          = reinterpret_cast<const SjUnit<TV, E>*>(A.val) + ub_slice;
+          = reinterpret_cast<const SjUnit<TV, E>*>(A.val) + ub_slice[h];
       const int64_t a_b = (int64_t)ub_block * E;
       T sum;
       if (wide) {
         const SjUnit<uint32_t, E>* cs
             = reinterpret_cast<const SjUnit<uint32_t, E>*>(A.codes + 4 * a_b)
-              + (ub_slice - ub_block);
+              + (ub_slice[h] - ub_block);
         sum = sj_slice<T, TV, uint32_t, true, E, MODE>(vs, cs, mylen, lane, s_x, in,
-                                                       init, alpha, nlow, beta * y0,
-                                                       beta != T(0));
+                                                       init[h], alpha, nlow[h],
+                                                       beta * y0[h], beta != T(0));
       } else {
         const SjUnit<uint16_t, E>* cs
             = reinterpret_cast<const SjUnit<uint16_t, E>*>(
                   A.codes + (A.wide_alloc ? 4 : 2) * a_b)
-              + (ub_slice - ub_block);
+              + (ub_slice[h] - ub_block);
         sum = sj_slice<T, TV, uint16_t, false, E, MODE>(vs, cs, mylen, lane, s_x, in,
-                                                        init, alpha, nlow, beta * y0,
-                                                        beta != T(0));
+                                                        init[h], alpha, nlow[h],
+                                                        beta * y0[h], beta != T(0));
       }
-      if (myrow < A.num_rows && in_slice) {
+      if (myrow[h] < A.num_rows && in_slice[h]) {
         const T c = MODE == 3 ? sum : alpha * sum;
         T y = c;
         if (beta != T(0) && MODE != 3)
-          y = c + beta * y0;
-        out[myrow] = y;
+          y = c + beta * y0[h];
+        out[myrow[h]] = y;
         if constexpr (DOT)
-          dot_acc += (double)x_own * (double)c;
+          dot_acc += (double)x_own[h] * (double)c;
       }
     }
 #ifdef SJ_PROBE
@@ -1655,7 +1737,8 @@ int sj_wgs_per_cu(int wpb, int64_t lds)
   return wgs < 1 ? 1 : wgs;
 }
 
-template <typename T, int WPB, int E, bool DOT, int MODE = 0, typename TV = T>
+template <typename T, int WPB, int E, bool DOT, int MODE = 0, typename TV = T,
+          bool SIG = false>
 int sj_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
               T beta, T* out, DotOut dot, const T* diagonal = nullptr,
               const int32_t* low_rowptr = nullptr)
@@ -1706,7 +1789,7 @@ int sj_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
   ord.num_row_blocks = pl->sj_nblk;
   ord.nt_store = 0;
   if (A.phases & 2) {
-    hipLaunchKernelGGL((csr_sjds_kernel<T, TV, WPB, E, DOT, MODE>), dim3(grid),
+    hipLaunchKernelGGL((csr_sjds_kernel<T, TV, WPB, E, DOT, MODE, SIG>), dim3(grid),
                        dim3(64 * WPB), lds, st, A, alpha, in, beta, out, dot, ord,
                        diagonal, low_rowptr);
     SPMV_CHECK_LAUNCH();
@@ -1799,7 +1882,10 @@ int sj_run_e(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
   switch (pl->sj_wpb) {
   case 4: return sj_launch<T, 4, E, DOT, 0, TV>(pl, st, alpha, in, beta, out, dot);
   case 8: return sj_launch<T, 8, E, DOT, 0, TV>(pl, st, alpha, in, beta, out, dot);
-  default: return sj_launch<T, 16, E, DOT, 0, TV>(pl, st, alpha, in, beta, out, dot);
+  default:
+    if (pl->sj_sigma) // blocks of 1024 rows sorted across the block: 8 waves, 2 slices each
+      return sj_launch<T, 8, E, DOT, 0, TV, true>(pl, st, alpha, in, beta, out, dot);
+    return sj_launch<T, 16, E, DOT, 0, TV>(pl, st, alpha, in, beta, out, dot);
   }
 }
 
@@ -2245,7 +2331,8 @@ int sj_bake(spmv_hip_csr_plan* pl, const T* values, const int32_t* map, hipStrea
   const int grid = spmv_grid_for(pl->ctx, nsl, kBlock / 64);
   hipLaunchKernelGGL((sj_bake_kernel<T>), dim3(grid), dim3(kBlock), 0, st,
                      pl->num_rows, pl->rowptr0, pl->sj_lenperm, pl->sj_ubase,
-                     pl->sj_unit, values, map, static_cast<T*>(pl->sj_val));
+                     pl->sj_unit, values, map, static_cast<T*>(pl->sj_val),
+                     pl->sj_sigma ? kSjSigBits : 6);
   SPMV_CHECK_LAUNCH();
   SPMV_CHECK_HIP(hipStreamSynchronize(st));
   pl->sj_elem = (int)sizeof(T);
@@ -2447,28 +2534,41 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
     cleanup();
     return SPMV_HIP_OK;
   }
+  // The SIGMA layout (blocks of 16 slices sorted by length across the block,
+  // two slices per wave: sj_sigma_kernel) for blocks of 1024 rows; `nsl` then
+  // counts the slices of whole blocks.
+  const int sigma = (best == 16 && pl->ctx->sj_sigma) ? 1 : 0;
+  const int64_t nsl_all = sigma ? (((int64_t)n + kSjSigRows - 1) / kSjSigRows) * 16 : nsl;
   // first unit of every slice: scan of the slices' unit counts
   uint32_t total_units = 0;
   {
     void* tmp = nullptr;
     size_t tb = 0;
-    e = hipMalloc(&pl->sj_ubase, sizeof(uint32_t) * (size_t)(nsl + 1));
+    e = hipMalloc(&pl->sj_ubase, sizeof(uint32_t) * (size_t)(nsl_all + 1));
+    if (e == hipSuccess)
+      e = hipMalloc(&pl->sj_lenperm, sizeof(int32_t) * (size_t)nsl_all * 64);
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(sj_units_kernel, dim3(spmv_grid_for(pl->ctx, nsl + 1, 4)),
-                         dim3(kBlock), 0, st, n, rowptr, thr, pl->nnz, E,
-                         pl->sj_ubase);
+      if (sigma)
+        hipLaunchKernelGGL(sj_sigma_kernel,
+                           dim3(spmv_grid_for(pl->ctx, nsl_all / 16 + 1, 1)), dim3(kBlock),
+                           0, st, n, rowptr, thr, pl->nnz, E, pl->sj_lenperm,
+                           pl->sj_ubase);
+      else
+        hipLaunchKernelGGL(sj_units_kernel, dim3(spmv_grid_for(pl->ctx, nsl + 1, 4)),
+                           dim3(kBlock), 0, st, n, rowptr, thr, pl->nnz, E,
+                           pl->sj_ubase);
       e = hipGetLastError();
     }
     if (e == hipSuccess)
       e = hipcub::DeviceScan::ExclusiveSum(nullptr, tb, pl->sj_ubase, pl->sj_ubase,
-                                           (int)(nsl + 1), st);
+                                           (int)(nsl_all + 1), st);
     if (e == hipSuccess)
       e = hipMalloc(&tmp, tb ? tb : 16);
     if (e == hipSuccess)
       e = hipcub::DeviceScan::ExclusiveSum(tmp, tb, pl->sj_ubase, pl->sj_ubase,
-                                           (int)(nsl + 1), st);
+                                           (int)(nsl_all + 1), st);
     if (e == hipSuccess)
-      e = hipMemcpyAsync(&total_units, pl->sj_ubase + nsl, sizeof(uint32_t),
+      e = hipMemcpyAsync(&total_units, pl->sj_ubase + nsl_all, sizeof(uint32_t),
                          hipMemcpyDeviceToHost, st);
     if (e == hipSuccess)
       e = hipStreamSynchronize(st);
@@ -2478,15 +2578,12 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
   const int nblk = (n + R - 1) / R;
   const int stride = best_st.maxk > 0 ? (int)((best_st.maxk + 7) / 8 * 8) : 8;
   const int wide_alloc = best_st.far > 0 ? 1 : 0;
-  const size_t n_pad = (size_t)nsl * 64;
   const size_t code_bytes
       = (size_t)(wide_alloc ? 4 : 2) * ((size_t)total_units + kSjSlack) * E;
   if (e == hipSuccess)
     e = hipMalloc(&pl->sj_blk, sizeof(int32_t) * 2 * (size_t)nblk);
   if (e == hipSuccess)
     e = hipMalloc(&pl->sj_chunks, sizeof(int32_t) * (size_t)nblk * stride);
-  if (e == hipSuccess)
-    e = hipMalloc(&pl->sj_lenperm, sizeof(int32_t) * n_pad);
   if (e == hipSuccess)
     e = hipMalloc(&pl->sj_codes, code_bytes);
   if (e == hipSuccess) // (the slack's codes must be valid LDS indices: 0)
@@ -2497,7 +2594,7 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
   hipLaunchKernelGGL((sj_fill_kernel<RR>), dim3(grid), dim3(kBlock), 0, st, n,  \
                      pl->num_cols, rowptr, colind, kcap, thr, pl->nnz, E, stride, \
                      wide_alloc, d_far, pl->sj_ubase, pl->sj_blk,              \
-                     pl->sj_chunks, pl->sj_lenperm, pl->sj_codes)
+                     pl->sj_chunks, pl->sj_lenperm, pl->sj_codes, sigma)
     if (best == 4)
       SJ_FILL(256);
     else if (best == 8)
@@ -2531,6 +2628,7 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
   pl->sj_unit = E;
   pl->sj_units = total_units;
   pl->sj_wpb = best;
+  pl->sj_sigma = sigma;
   pl->sj_nblk = nblk;
   pl->sj_maxk = (int)best_st.maxk > 0 ? (int)best_st.maxk : 1;
   pl->sj_stride = stride;
@@ -2589,7 +2687,7 @@ int spmv_sjds_bake_f32f64(spmv_hip_csr_plan* pl, const float* values32, hipStrea
   hipLaunchKernelGGL((sj_bake_kernel<float>), dim3(grid), dim3(kBlock), 0, st,
                      pl->num_rows, pl->rowptr0, pl->sj_lenperm, pl->sj_ubase,
                      pl->sj_unit, values32, (const int32_t*)nullptr,
-                     static_cast<float*>(pl->sj_val32));
+                     static_cast<float*>(pl->sj_val32), pl->sj_sigma ? kSjSigBits : 6);
   SPMV_CHECK_LAUNCH();
   SPMV_CHECK_HIP(hipStreamSynchronize(st));
   pl->sj32_values0 = values32;
@@ -2623,6 +2721,9 @@ int sj_run_sym(const spmv_hip_csr_plan* pl, hipStream_t st, const T* diagonal, T
   if (m->sj_wpb == 8)
     return sj_launch<T, 8, 2, DOT, 3>(m, st, alpha, in, beta, out, dot, diagonal,
                                       pl->rowptr0);
+  if (m->sj_wpb == 16 && m->sj_sigma)
+    return sj_launch<T, 8, 2, DOT, 3, T, true>(m, st, alpha, in, beta, out, dot, diagonal,
+                                               pl->rowptr0);
   if (m->sj_wpb == 16)
     return sj_launch<T, 16, 2, DOT, 3>(m, st, alpha, in, beta, out, dot, diagonal,
                                        pl->rowptr0);

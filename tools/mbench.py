@@ -21,6 +21,8 @@ KINDS = {
     "fem": dict(),
     "fem_tail": dict(tail_permille=10),
     "fem81": dict(min_len=81, max_len=81),
+    "fem15": dict(min_len=15, max_len=15),  # the mean of "fem", every row alike
+    "fem22": dict(min_len=5, max_len=40, seed=0x5EED0004),
 }
 ALGO = {"rowblock": 1, "vector": 2, "scalar": 3}
 FORM_KEYS = ("algo", "lat", "lx", "lxw", "wdia", "wdia_half", "wdia_hbox", "sdia", "sjds", "sj_wpb", "sj_unit",
