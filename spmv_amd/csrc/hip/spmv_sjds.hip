@@ -22,6 +22,16 @@
 //     scalar arithmetic (slice base + units so far) plus a constant per-lane
 //     offset: what limited the first version of this kernel was the number of
 //     vector instructions per entry, not bytes.
+//     SIGMA layout (blocks of 1024 rows whose rows average fewer than 48
+//     entries): a slice runs as many steps as its LONGEST row -- with lengths
+//     5 ... 40 side by side 2.5 times the average, and the slices' phase is three
+//     quarters of the kernel (a build with clocks in it, -DSJ_PROBE; rows of
+//     one length: 0.35 instead of 0.43 ms).  There the rows are sorted by
+//     length across the whole BLOCK (the staged copy of x is the block's
+//     anyway), a slice holds rows of nearly one length, and a wave of the
+//     8-wave workgroup takes TWO slices, the k-th longest and the k-th
+//     shortest: every wave the same work, two workgroups per CU.  Lengths 5-40:
+//     0.443 -> 0.360 ms; 7 in every row: 0.371 -> 0.329.
 //   * x comes from LDS.  Per block of WPB slices (256, 512 or 1024 rows) the
 //     plan lists the 16-column chunks (128 B) of x the block's entries touch
 //     -- up to 432 of them, nearest to the diagonal first -- and rewrites every
@@ -2537,7 +2547,10 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
   // The SIGMA layout (blocks of 16 slices sorted by length across the block,
   // two slices per wave: sj_sigma_kernel) for blocks of 1024 rows; `nsl` then
   // counts the slices of whole blocks.
-  const int sigma = (best == 16 && pl->ctx->sj_sigma) ? 1 : 0;
+  // (measured, 10 M rows, same box: lengths 5-40 0.443 -> 0.360 ms, 7 in every
+  // row 0.371 -> 0.329; 81 in every row 1.37 -> 1.40: nothing to sort there, and
+  // the 16-wave workgroup streams long slices a little better)
+  const int sigma = (best == 16 && pl->ctx->sj_sigma && avg < 48.0) ? 1 : 0;
   const int64_t nsl_all = sigma ? (((int64_t)n + kSjSigRows - 1) / kSjSigRows) * 16 : nsl;
   // first unit of every slice: scan of the slices' unit counts
   uint32_t total_units = 0;

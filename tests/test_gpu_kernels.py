@@ -617,9 +617,9 @@ def _sj_cases():
     return cases
 
 
-@pytest.mark.parametrize("wpb,unit", [(4, 1), (8, 2), (16, 4), (4, 4), (16, 1),
-                                      (0, 0)])
-def test_sliced_jagged_form_bit_exact(sj_ctx, wpb, unit):
+@pytest.mark.parametrize("wpb,unit,sigma", [(4, 1, 1), (8, 2, 1), (16, 4, 1), (4, 4, 1),
+                                            (16, 1, 1), (16, 2, 0), (0, 0, 1)])
+def test_sliced_jagged_form_bit_exact(sj_ctx, wpb, unit, sigma):
     """csr_sjds_kernel against oracle.csr_spmv (csr_kernels.cpp:41-51), every
     element identical: blocks of 4 / 8 / 16 slices, 1 / 2 / 4 entries per lane
     and step (0 = the plan's choice), staged and far entries (a chunk budget of
@@ -630,6 +630,10 @@ def test_sliced_jagged_form_bit_exact(sj_ctx, wpb, unit):
     ctx = sj_ctx
     ctx.set_option("sj_wpb", wpb)
     ctx.set_option("sj_unit", unit)
+    # blocks of 16 slices: sorted by length across the block, two slices per wave
+    # (the sigma layout, where the rows average fewer than 48 entries) -- or
+    # every slice sorted for itself
+    ctx.set_option("sj_sigma", sigma)
     part = ctx.empty(ctx.dot_partials_len, np.float64)
     for name, (rp, ci, va) in _sj_cases().items():
         nr = len(rp) - 1
@@ -652,6 +656,8 @@ def test_sliced_jagged_form_bit_exact(sj_ctx, wpb, unit):
             assert blk.get("lx") == 0
             if wpb:
                 assert blk.get("sj_wpb") == wpb and blk.get("sj_unit") == unit
+                assert blk.get("sj_sigma") == (
+                    1 if wpb == 16 and sigma and len(ci) < 48 * nr else 0), name
             if name == "far" or (budget == 8 and nc > 1000):
                 assert blk.get("sj_far_permille") > 0 and blk.get("sj_wide") == 1
             if name == "fem" and budget == 432:

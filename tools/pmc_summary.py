@@ -17,8 +17,9 @@ def short(name):
     # the two passes of symmetric storage in the sliced jagged form are launches
     # of one template (its last argument: 1 = lower block, 2 = transposed block)
     if "csr_sjds_kernel<" in name:
-        args = name.split("csr_sjds_kernel<", 1)[1].split(">(", 1)[0]
-        mode = args.rsplit(",", 1)[-1].strip()
+        args = name.split("csr_sjds_kernel<", 1)[1].split(">(", 1)[0].split(",")
+        # <T, TV, WPB, E, DOT, MODE, SIG>
+        mode = args[5].strip() if len(args) > 5 else "0"
         if mode == "1":
             return "csr_sjds_kernel sym lower"
         if mode == "2":
