@@ -1556,6 +1556,10 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
     // sigma layout gives the wave the slices `wave` and `2 WPB - 1 - wave` of
     // the block (sorted by length across the block: the longest rows with the
     // shortest), every slice of the block being there.
+    // (symmetric storage with alpha = 1, beta = 0 -- Matrix::mult, cg(): 1 * s is
+    // s and fl(1 * v) is v, so nothing turns: the merged row's products are
+    // added to d_i x_i as they are, the plain slice with a starting value)
+    const bool sym_plain = MODE == 3 && alpha == T(1) && beta == T(0);
     bool have[SPW], in_slice[SPW];
     int32_t lp[SPW], myrow[SPW], nlow[SPW];
     uint32_t ub_slice[SPW];
@@ -1584,7 +1588,8 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
         y0[h] = out[myrow_c];
       if constexpr (MODE == 3) {
         init[h] = diagonal[myrow_c] * x_own[h];
-        nlow[h] = low_rowptr[myrow_c + 1] - low_rowptr[myrow_c];
+        if (!sym_plain)
+          nlow[h] = low_rowptr[myrow_c + 1] - low_rowptr[myrow_c];
       }
     }
     const int32_t* cl = A.chunks + (int64_t)b * A.stride;
@@ -1649,17 +1654,25 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
         const SjUnit<uint32_t, E>* cs
             = reinterpret_cast<const SjUnit<uint32_t, E>*>(A.codes + 4 * a_b)
               + (ub_slice[h] - ub_block);
-        sum = sj_slice<T, TV, uint32_t, true, E, MODE>(vs, cs, mylen, lane, s_x, in,
-                                                       init[h], alpha, nlow[h],
-                                                       beta * y0[h], beta != T(0));
+        if (sym_plain)
+          sum = sj_slice<T, TV, uint32_t, true, E, 0>(vs, cs, mylen, lane, s_x, in,
+                                                      init[h], alpha);
+        else
+          sum = sj_slice<T, TV, uint32_t, true, E, MODE>(vs, cs, mylen, lane, s_x, in,
+                                                         init[h], alpha, nlow[h],
+                                                         beta * y0[h], beta != T(0));
       } else {
         const SjUnit<uint16_t, E>* cs
             = reinterpret_cast<const SjUnit<uint16_t, E>*>(
                   A.codes + (A.wide_alloc ? 4 : 2) * a_b)
               + (ub_slice[h] - ub_block);
-        sum = sj_slice<T, TV, uint16_t, false, E, MODE>(vs, cs, mylen, lane, s_x, in,
-                                                        init[h], alpha, nlow[h],
-                                                        beta * y0[h], beta != T(0));
+        if (sym_plain)
+          sum = sj_slice<T, TV, uint16_t, false, E, 0>(vs, cs, mylen, lane, s_x, in,
+                                                       init[h], alpha);
+        else
+          sum = sj_slice<T, TV, uint16_t, false, E, MODE>(vs, cs, mylen, lane, s_x, in,
+                                                          init[h], alpha, nlow[h],
+                                                          beta * y0[h], beta != T(0));
       }
       if (myrow[h] < A.num_rows && in_slice[h]) {
         const T c = MODE == 3 ? sum : alpha * sum;
