@@ -1579,9 +1579,13 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
       in_slice[h] = (lpw & kSjLongFlag) == 0; // else phase 0 wrote its y
       ub_slice[h] = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.ubase[s0c / 64]);
       myrow[h] = (SIG ? r0 : s0c) + (lp[h] & ((1 << RB) - 1));
-      const int32_t myrow_c = myrow[h] < A.num_rows ? myrow[h] : A.num_rows - 1;
       x_own[h] = y0[h] = init[h] = T(0);
       nlow[h] = 0;
+      // (symmetric storage: the second slice's row data are loaded when its
+      // turn comes -- both sets live across the first slice cost spills)
+      if (MODE == 3 && h > 0)
+        continue;
+      const int32_t myrow_c = myrow[h] < A.num_rows ? myrow[h] : A.num_rows - 1;
       if constexpr (DOT || MODE == 3)
         x_own[h] = in[myrow_c];
       if (beta != T(0))
@@ -1645,6 +1649,15 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
     for (int h = 0; h < SPW; ++h) {
       if (!have[h])
         continue;
+      if (MODE == 3 && h > 0) {
+        const int32_t myrow_c = myrow[h] < A.num_rows ? myrow[h] : A.num_rows - 1;
+        x_own[h] = in[myrow_c];
+        if (beta != T(0))
+          y0[h] = out[myrow_c];
+        init[h] = diagonal[myrow_c] * x_own[h];
+        if (!sym_plain)
+          nlow[h] = low_rowptr[myrow_c + 1] - low_rowptr[myrow_c];
+      }
       const int32_t mylen = lp[h] >> RB;
       const SjUnit<TV, E>* vs
           = reinterpret_cast<const SjUnit<TV, E>*>(A.val) + ub_slice[h];
