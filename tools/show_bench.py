@@ -33,3 +33,10 @@ if "mixed_precision_cg" in d:
 if "cpu_baseline" in d:
     c = d["cpu_baseline"]
     print("cpu", c["value"], c.get("parity_checks"))
+rg = d.get("roofline", {}).get("ragged", {})
+for k, v in rg.items():
+    if isinstance(v, dict):
+        print("ragged %-18s %s" % (k, {a: (round(b, 4) if isinstance(b, float) else b)
+                                        for a, b in v.items()
+                                        if a in ("ms_per_apply", "frac", "iters/s",
+                                                 "speedup_over_fp64")}))
