@@ -176,7 +176,7 @@ int spmv_hip_ctx_set_option(spmv_hip_ctx* ctx, const char* key, int64_t value)
     return SPMV_HIP_OK;
   }
   if (!strcmp(key, "sj_sigma")) {
-    SPMV_REQUIRE(value == 0 || value == 1);
+    SPMV_REQUIRE(value >= 0 && value <= 2); // 2: whatever the rows' average length
     ctx->sj_sigma = (int)value;
     return SPMV_HIP_OK;
   }

@@ -22,8 +22,8 @@
 //     scalar arithmetic (slice base + units so far) plus a constant per-lane
 //     offset: what limited the first version of this kernel was the number of
 //     vector instructions per entry, not bytes.
-//     SIGMA layout (blocks of 1024 rows whose rows average fewer than 48
-//     entries): a slice runs as many steps as its LONGEST row -- with lengths
+//     SIGMA layout (blocks of 1024 rows, unless the rows are long and all
+//     alike): a slice runs as many steps as its LONGEST row -- with lengths
 //     5 ... 40 side by side 2.5 times the average, and the slices' phase is three
 //     quarters of the kernel (a build with clocks in it, -DSJ_PROBE; rows of
 //     one length: 0.35 instead of 0.43 ms).  There the rows are sorted by
@@ -2385,6 +2385,16 @@ int sj_bake(spmv_hip_csr_plan* pl, const T* values, const int32_t* map, hipStrea
 
 namespace
 {
+struct SjShortLen { // length of a row that stays in the slices (a long one: 0)
+  const int32_t* rowptr;
+  int thr;
+  int64_t nnz;
+  __device__ int32_t operator()(int i) const
+  {
+    const int32_t a = rowptr[i], b = rowptr[i + 1];
+    return sj_is_long(a, b, thr, nnz) ? 0 : b - a;
+  }
+};
 struct SjLongEntries {
   const int32_t* rowptr;
   int thr;
@@ -2579,7 +2589,43 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
   // (measured, 10 M rows, same box: lengths 5-40 0.443 -> 0.360 ms, 7 in every
   // row 0.371 -> 0.329; 81 in every row 1.37 -> 1.40: nothing to sort there, and
   // the 16-wave workgroup streams long slices a little better)
-  const int sigma = (best == 16 && pl->ctx->sj_sigma && avg < 48.0) ? 1 : 0;
+  // ... and ragged rows of any length gain (same box, 5 M rows: lengths 20-80
+  // 0.395 -> 0.366 ms, 40-120 0.593 -> 0.573): the layout is left only for rows
+  // that are long AND (nearly) all alike -- the longest row that stays in the
+  // slices within 10 % of the average
+  int sigma = 0;
+  if (best == 16 && pl->ctx->sj_sigma) {
+    sigma = 1;
+    if (pl->ctx->sj_sigma == 1 && avg >= 48.0) {
+      hipcub::CountingInputIterator<int32_t> first(0);
+      hipcub::TransformInputIterator<int32_t, SjShortLen,
+                                     hipcub::CountingInputIterator<int32_t>>
+          lens(first, SjShortLen{rowptr, thr, pl->nnz});
+      int32_t* d_max = nullptr;
+      void* tmpm = nullptr;
+      size_t tbm = 0;
+      int32_t h_max = 0;
+      hipError_t em = hipMalloc(&d_max, sizeof(int32_t));
+      if (em == hipSuccess)
+        em = hipcub::DeviceReduce::Max(nullptr, tbm, lens, d_max, n, st);
+      if (em == hipSuccess)
+        em = hipMalloc(&tmpm, tbm ? tbm : 16);
+      if (em == hipSuccess)
+        em = hipcub::DeviceReduce::Max(tmpm, tbm, lens, d_max, n, st);
+      if (em == hipSuccess)
+        em = hipMemcpyAsync(&h_max, d_max, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+      if (em == hipSuccess)
+        em = hipStreamSynchronize(st);
+      (void)hipFree(tmpm);
+      (void)hipFree(d_max);
+      if (em != hipSuccess) {
+        (void)hipGetLastError();
+        h_max = 0;
+      }
+      if ((double)h_max <= 1.1 * avg)
+        sigma = 0;
+    }
+  }
   const int64_t nsl_all = sigma ? (((int64_t)n + kSjSigRows - 1) / kSjSigRows) * 16 : nsl;
   // first unit of every slice: scan of the slices' unit counts
   uint32_t total_units = 0;

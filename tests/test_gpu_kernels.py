@@ -631,8 +631,7 @@ def test_sliced_jagged_form_bit_exact(sj_ctx, wpb, unit, sigma):
     ctx.set_option("sj_wpb", wpb)
     ctx.set_option("sj_unit", unit)
     # blocks of 16 slices: sorted by length across the block, two slices per wave
-    # (the sigma layout, where the rows average fewer than 48 entries) -- or
-    # every slice sorted for itself
+    # (the sigma layout) -- or every slice sorted for itself
     ctx.set_option("sj_sigma", sigma)
     part = ctx.empty(ctx.dot_partials_len, np.float64)
     for name, (rp, ci, va) in _sj_cases().items():
@@ -656,8 +655,8 @@ def test_sliced_jagged_form_bit_exact(sj_ctx, wpb, unit, sigma):
             assert blk.get("lx") == 0
             if wpb:
                 assert blk.get("sj_wpb") == wpb and blk.get("sj_unit") == unit
-                assert blk.get("sj_sigma") == (
-                    1 if wpb == 16 and sigma and len(ci) < 48 * nr else 0), name
+                # (the sigma layout: left only for rows that are long AND alike)
+                assert blk.get("sj_sigma") == (1 if wpb == 16 and sigma else 0), name
             if name == "far" or (budget == 8 and nc > 1000):
                 assert blk.get("sj_far_permille") > 0 and blk.get("sj_wide") == 1
             if name == "fem" and budget == 432:

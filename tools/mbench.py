@@ -22,10 +22,11 @@ KINDS = {
     "fem_tail": dict(tail_permille=10),
     "fem81": dict(min_len=81, max_len=81),
     "fem15": dict(min_len=15, max_len=15),  # the mean of "fem", every row alike
-    "fem22": dict(min_len=5, max_len=40, seed=0x5EED0004),
+    "fem_long": dict(min_len=40, max_len=120),  # ragged AND long
+    "fem_mid": dict(min_len=20, max_len=80),
 }
 ALGO = {"rowblock": 1, "vector": 2, "scalar": 3}
-FORM_KEYS = ("algo", "lat", "lx", "lxw", "wdia", "wdia_half", "wdia_hbox", "sdia", "sjds", "sj_wpb", "sj_unit",
+FORM_KEYS = ("algo", "lat", "lx", "lxw", "wdia", "wdia_half", "wdia_hbox", "sdia", "sjds", "sj_wpb", "sj_unit", "sj_sigma",
              "sj_max_chunks", "sj_far_permille", "sj_staged_bytes_per_entry_x100",
              "sj_wide", "sj_long_rows", "lx_staged", "lx_blocks", "blocks_per_cu", "nontemporal")
 
