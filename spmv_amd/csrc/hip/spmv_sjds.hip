@@ -2498,7 +2498,7 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
   // (measured, 10 M rows: lengths 5-40 0.55 / 0.41 / 0.44 ms with 1 / 2 / 4
   // entries per step; 81 per row 1.38 / 1.37 / 1.38; 7 per row 0.357 / 0.355 /
   // 0.349)
-  const int E = unit_force ? unit_force : (avg >= 4.0 ? 2 : 1);
+  int E = unit_force ? unit_force : (avg >= 4.0 ? 2 : 1);
   const int nblk4 = (n + 255) / 256;
   const int64_t nsl = ((int64_t)n + 63) / 64;
   int32_t* d_k = nullptr;
@@ -2595,6 +2595,12 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
   // (measured, 10 M rows, same box: lengths 5-40 0.443 -> 0.360 ms, 7 in every
   // row 0.371 -> 0.329; 81 in every row 1.37 -> 1.40: nothing to sort there, and
   // the 16-wave workgroup streams long slices a little better)
+  // many far entries (5 % or more: 32-bit codes in practically every block):
+  // four entries per step -- 16-byte loads of the codes (sigma layout, 7 per
+  // row with 9 % far entries: 0.328 -> 0.317 ms; without far entries two per
+  // step are better, 0.349 against 0.364)
+  if (!unit_force && avg >= 4.0 && best_st.far * 20 >= pl->nnz)
+    E = 4;
   // ... and ragged rows of any length gain (same box, 5 M rows: lengths 20-80
   // 0.395 -> 0.366 ms, 40-120 0.593 -> 0.573): the layout is left only for rows
   // that are long AND (nearly) all alike -- the longest row that stays in the
