@@ -124,6 +124,11 @@ def parse():
     ap.add_argument("--petsc-rhs", default=None,
                     help="PETSc binary vector file for the right-hand side "
                          "(demos/cg.cpp:51); default: the Gaussian vector")
+    ap.add_argument("--detail", default=None,
+                    help="where the full record goes (every sub-record, plan "
+                         "costs, cross-checks, notes); default "
+                         "gpurun_out/bench_detail.json.  stdout carries ONE "
+                         "compact line (<= 6 KB) made from it")
     ap.add_argument("--blas1-nt-min", type=int, default=None,
                     help="override the context option blas1_nt_min_elems "
                          "(experiments)")
@@ -202,6 +207,10 @@ def cpu_baseline(args, n_gpu, rows_gpu, host):
                       f"use, OMP_PLACES=cores OMP_PROC_BIND=spread"
                       + ("" if n == n_gpu else
                          f"; scaled by rows {N}/{rows_gpu} to {n_gpu}^3")),
+           "sample_short": (f"oracle OpenMP CG on the {n}^3 Poisson matrix, "
+                            f"{r['cg_iters']} iterations in {r['cg_loop_s']:.2f} s, "
+                            f"{threads} threads"
+                            + ("" if n == n_gpu else f", scaled by rows to {n_gpu}^3")),
            "spmv_omp": {"grid": n, "threads": threads,
                         "ms_per_apply": r["spmv_s_per_apply"] * 1e3,
                         "GB/s": nbytes / r["spmv_s_per_apply"] / 1e9,
@@ -435,8 +444,11 @@ def kernel_of(A, symmetric):
 
 
 def plan_record(A):
+    rows, cols, nnz = A.blocks()["local"]
     return {"plan_ms": A.plan_get("plan_us") / 1e3,
             "plan_extra_bytes": A.plan_get("plan_kib") * 1024,
+            # the caller's CSR arrays the plan's memory comes on top of
+            "csr_bytes": nnz * 12 + (rows + 1) * 4,
             "form": {k: A.plan_get(k) for k in
                      ("lat", "lx", "lxw", "sjds", "sym_sj", "wdia", "wdia_const",
                       "wdia_hbox", "slat", "sdia", "sdia_const", "sym_det", "zwalk")}}
@@ -510,7 +522,7 @@ def timed_spmv(exec_, A, N, _lib, reps, crosscheck=False):
     if crosscheck:
         import numpy as np
         y = exec_.copy_to_host(d_y, N)
-        algo0 = A.plan_get("algo")
+        algo0, sjds0 = A.plan_get("algo"), A.plan_get("sjds")
         if crosscheck == "symt":  # symmetric storage: the transposed-map kernel
             A.plan_set("sjds", 0)
         else:
@@ -526,7 +538,8 @@ def timed_spmv(exec_, A, N, _lib, reps, crosscheck=False):
                 A.mult(d_x, d_y)
             exec_.synchronize()
             timed_spmv.other_ms = (time.perf_counter() - t0) * 1e3 / 5
-            A.plan_set("sjds", 1)
+            if sjds0:
+                A.plan_set("sjds", sjds0)
         else:
             A.plan_set("algo", algo0)
     exec_.free(d_x), exec_.free(d_y)
@@ -655,14 +668,146 @@ def mixed_precision_record(exec_, comm, host, _lib, n, rtol=1e-10, kmax=6000):
     return rec
 
 
+# ---------------------------------------------------------------------------
+# the line the driver reads: contract keys + roofline + cpu_baseline, <= 6 KB;
+# everything else lives in the detail file
+# ---------------------------------------------------------------------------
+LINE_MAX = 6144
+
+
+def sig(x, n=6):
+    """a float with n significant digits (None stays None)"""
+    return None if x is None else float(f"{float(x):.{n}g}")
+
+
+def kname(kernel):
+    """the kernel's name without its description"""
+    return kernel.split(" (")[0]
+
+
+def compact_line(out, detail_path):
+    r = out["roofline"]
+    line = {k: out[k] for k in
+            ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+             "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = out["config"]
+    roof = {"bound": r["bound"], "achieved": sig(r["achieved"]), "peak": r["peak"],
+            "unit": r["unit"], "frac": sig(r["frac"]),
+            "traffic": r["traffic"], "frac_traffic": sig(r["frac_traffic"]),
+            "kernel": kname(r["kernel"]), "avg_launch_ms": sig(r["avg_launch_ms"]),
+            "launches_timed": r["launches_timed"],
+            "bytes_per_launch": r["bytes_per_launch"],
+            "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
+            "frac_csr_equivalent": sig(r["frac_csr_equivalent"])}
+    co = r.get("csr_order")
+    if co:
+        roof["csr_order"] = {"kernel": kname(co["kernel"]),
+                             "ms_per_apply": sig(co["ms_per_apply"]),
+                             "frac": sig(co["frac"]), "traffic": co["traffic"]}
+        roof["general_cg_iters_per_s"] = sig(r["general_cg_iters_per_s"])
+    if "north_star_rowblock_spmv" in out:
+        # 216^3 (the north star's 10 M rows), priced with SURVEY 8d's B_csr
+        ns = {"rows": out["north_star_rowblock_spmv"]["rows"]}
+        for key, rec in (("rowblock", "north_star_rowblock_spmv"),
+                         ("lx", "north_star_lx_spmv"),
+                         ("default", "north_star_spmv")):
+            ns[key + "_ms"] = sig(out[rec]["ms_per_apply"])
+            ns[key + "_frac"] = sig(out[rec]["frac_csr_equivalent"])
+        roof["north_star"] = ns
+    if "csr_rowblock_spmv" in out:
+        roof["csr_rowblock"] = [sig(out["csr_rowblock_spmv"]["ms_per_apply"]),
+                                sig(out["csr_rowblock_spmv"]["frac_csr_equivalent"])]
+    if "ragged" in r:
+        # name: [ms per apply, frac of SURVEY 8d's bytes (B_sym for *_sym_*)]
+        roof["ragged"] = {k: [sig(v["ms_per_apply"]), sig(v["frac"])]
+                          for k, v in r["ragged"].items()
+                          if isinstance(v, dict) and "frac" in v}
+        cg = r["ragged"].get("fem_sym_cg")
+        if cg:
+            roof["ragged"]["fem_sym_cg_iters_per_s"] = sig(cg["iters/s"])
+    if "plan" in out and r["algorithmic_bytes_per_launch"]:
+        roof["plan_extra_over_csr_bytes"] = sig(
+            out["plan"]["plan_extra_bytes"] / out["plan"]["csr_bytes"], 3)
+    line["roofline"] = roof
+    line["cg_rel_residual"] = {k: v for k, v in out["cg_rel_residual"].items()
+                               if k in ("k10", "k10_ok")}
+    if "symmetric" in out:  # BASELINE configs[3]
+        s_ = out["symmetric"]
+        line["symmetric"] = {"iters_per_s": sig(s_["iters/s"]),
+                             "kernel": kname(s_["kernel"]),
+                             "avg_launch_ms": sig(s_["avg_launch_ms"]),
+                             "frac": sig(s_["frac"]),
+                             "frac_of_B_sym": sig(s_["frac_csr_equivalent"])}
+    for k in ("halo_selfcheck", "rccl", "cg_scalar_reductions", "launcher"):
+        if k in out:
+            line[k] = out[k]
+    if "ranks" in out:  # per rank: [neighbours, ghosts, rows]
+        line["ranks"] = [[r_["neighbours"], r_["ghosts"], r_["rows"]]
+                         for r_ in out["ranks"]]
+    c = out.get("cpu_baseline")
+    if c:
+        line["cpu_baseline"] = {
+            "value": sig(c["value"]), "unit": c["unit"], "cores": c["cores"],
+            "kind": c["kind"], "sample": c["sample_short"],
+            "spmv_omp_gbs": sig(c["spmv_omp"]["GB/s"]),
+            "k10": c["cg_rel_residual_k10"]}
+        pc = c.get("parity_checks")
+        if pc:
+            line["cpu_baseline"]["parity_checks_bit_exact"] = bool(
+                "error" not in pc and all(v["bit_exact_vs_oracle"]
+                                          for v in pc.values()))
+    line["detail"] = detail_path
+    return line
+
+
+def emit(out, args):
+    """detail -> file (+ stderr, prefixed so that no other line starts with a
+    brace), then the compact line, last, on stdout"""
+    path = args.detail or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+    shown = os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+    try:
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+    except OSError as e:
+        shown = f"not written ({e.strerror})"
+    print("bench_detail " + json.dumps(out), file=sys.stderr, flush=True)
+    text = json.dumps(compact_line(out, shown), separators=(",", ":"))
+    if len(text) > LINE_MAX:
+        raise SystemExit(f"bench line is {len(text)} bytes (> {LINE_MAX}): the "
+                         "driver would not parse it")
+    print(text, flush=True)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as
+    CHILD processes through torch.distributed.run and wait.  This parent has
+    made no HIP / torch.cuda call (torch is not even imported) and never
+    does; nothing that touched a GPU is ever re-exec'd.  Rank 0's line goes to
+    the inherited stdout; a failing child gives a non-zero exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, SPMV_BENCH_LAUNCHER="self")
+    print(f"bench.py: no WORLD_SIZE in the environment, starting {args.gpus} "
+          f"ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch "
-                         "N>1 through torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # before torch is imported: with OMP_PROC_BIND set, the first OpenMP runtime
     # that starts pins this thread to one core and the mask would read "1 core"
     host_cores = usable_cores()
@@ -679,8 +824,7 @@ def main():
     exec_ = host.HipExecutor(dev)
     rccl = None
     if world > 1 and rehearsal:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import dist_util  # gloo-backed CallbackComm transport (tests/)
+        from spmv_amd import gloo_transport as dist_util  # CallbackComm over gloo
         dist.init_process_group("gloo", rank=rank, world_size=world)
         ex, ar = dist_util.make_device_transport(exec_.context)
         comm = host.Comm.callback(rank, world, dist_util.make_allgather(world),
@@ -924,6 +1068,8 @@ def main():
             "plan": plan_record(A),
             "matrix_create_ms": t_create * 1e3,
         }
+        if os.environ.get("SPMV_BENCH_LAUNCHER"):
+            out["launcher"] = "bench.py started its own ranks (child processes)"
         if world > 1:
             out["halo_selfcheck"] = halo_selfcheck
             out["ranks"] = [{"rank": r, "neighbours": int(v[0]),
@@ -1206,7 +1352,10 @@ def main():
                 r = matrix_spmv_record(
                     exec_, Af, _lib, True, 30, "fem_sym_spmv", args.fem_rows,
                     f"fem_like_{args.fem_rows}rows_len5-40_lower+diag_symmetric_"
-                    "storage_fp64_spmv", crosscheck="symt")
+                    "storage_fp64_spmv",
+                    # (nothing to compare where the merged form was refused and
+                    # the transposed-map kernel is the plan's own)
+                    crosscheck="symt" if Af.plan_get("sym_sj") else False)
                 out["fem_sym_spmv"] = r
                 ragged["fem_sym_spmv"] = {
                     "ms_per_apply": r["ms_per_apply"],
@@ -1216,8 +1365,11 @@ def main():
                                  "kernel streams 20 B per stored entry",
                     "frac_requested": r["frac_requested"],
                     "kernel": r["kernel"].split(" (")[0],
-                    "bit_equal_transposed_map_kernel": r["crosscheck"]["bit_equal"],
-                    "transposed_map_kernel_ms": getattr(timed_spmv, "other_ms", None),
+                    "bit_equal_transposed_map_kernel":
+                        r.get("crosscheck", {}).get("bit_equal"),
+                    "transposed_map_kernel_ms":
+                        getattr(timed_spmv, "other_ms", None)
+                        if "crosscheck" in r else r["ms_per_apply"],
                     "plan_ms": r["plan_ms"], "traffic": r.get("traffic")}
                 # ... and CG on it (strictly diagonally dominant: SPD), the
                 # reference's loop (cg.cpp:21-98) end to end on a matrix without
@@ -1241,6 +1393,31 @@ def main():
                             "storage, Gaussian right-hand side"}
                 wsf.close()
                 exec_.free(d_b), exec_.free(d_x)
+                Af.close()
+                # ... and the matrix with the 1 % tail of 200-2000-entry rows in
+                # symmetric storage: long rows AND long columns of the stored
+                # lower part (Matrix.cpp:337-349 on a FEM matrix with a dense-ish
+                # tail); beside its general-storage time above
+                Af = host.Matrix.create_fem_like(self_comm, exec_, args.fem_rows,
+                                                 symmetric=True, tail_permille=10)
+                r = matrix_spmv_record(
+                    exec_, Af, _lib, True, 30, "fem_tail_sym_spmv", args.fem_rows,
+                    f"fem_like_{args.fem_rows}rows_len5-40_tail1pct_200-2000_"
+                    "lower+diag_symmetric_storage_fp64_spmv",
+                    crosscheck="symt" if Af.plan_get("sym_sj") else False)
+                out["fem_tail_sym_spmv"] = r
+                ragged["fem_tail_sym_spmv"] = {
+                    "ms_per_apply": r["ms_per_apply"],
+                    "frac": r["frac_csr_equivalent"],
+                    "over_general_storage": r["ms_per_apply"]
+                                            / ragged["fem_tail_spmv"]["ms_per_apply"],
+                    "kernel": r["kernel"].split(" (")[0],
+                    "bit_equal_transposed_map_kernel":
+                        r.get("crosscheck", {}).get("bit_equal"),
+                    "transposed_map_kernel_ms":
+                        getattr(timed_spmv, "other_ms", None)
+                        if "crosscheck" in r else r["ms_per_apply"],
+                    "plan_ms": r["plan_ms"], "traffic": r.get("traffic")}
                 Af.close()
                 out["roofline"]["ragged"] = dict(
                     ragged, note="frac = SURVEY 8d CSR bytes (12 B per entry, row "
@@ -1299,7 +1476,7 @@ def main():
             if not args.no_extras:
                 out["cpu_baseline"]["parity_checks"] = oracle_parity_checks(
                     exec_, comm, host, _lib)
-        print(json.dumps(out), flush=True)
+        emit(out, args)
 
     comm.close()
     exec_.close()

@@ -1,5 +1,8 @@
-"""torch.distributed (gloo) transport for spmv::CallbackComm, used by the
-multi-process tests.  On a GPU box the device callbacks stage through host
+"""torch.distributed (gloo) transport for spmv::CallbackComm: the shape of the
+callbacks an MPI application hands to Comm::callback,
+written over torch.distributed.  Used by `bench.py --transport gloo` (the
+rehearsal of the N-rank run on a 1-GPU box -- never a benchmark result) and by
+the multi-process tests.  On a GPU box the device callbacks stage through host
 memory, so several ranks can share ONE GPU; this exercises every line of the
 C++ multi-rank logic (plan, pack / direct send, local+remote split, stream
 events, CG reductions) without RCCL, which needs one GPU per rank.
@@ -41,7 +44,7 @@ def make_device_transport(ctx_handle):
     """neighbor_exchange / allreduce_sum on DEVICE pointers, staged through
     the host and gloo.  Blocking, but stream-correct: it first drains the
     stream it was asked to run on."""
-    from spmv_amd import _lib
+    from . import _lib
 
     def d2h(ptr, nbytes, stream):
         buf = np.empty(nbytes, np.uint8)

@@ -2,7 +2,7 @@
 
 Every rank drives the C++ Matrix / L2GMap / cg on GPU 0 exactly as
 tests/test_spmv_cuda.cpp does on rank r of an MPI job; the transport is a
-CallbackComm over torch.distributed gloo (tests/dist_util.py).  Results are
+CallbackComm over torch.distributed gloo (spmv_amd/gloo_transport.py).  Results are
 compared with the oracle's P-rank simulation.
 """
 import os
@@ -13,7 +13,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-import dist_util  # noqa: E402
+from spmv_amd import gloo_transport as dist_util  # noqa: E402
 import oracle  # noqa: E402
 from spmv_amd import host, poisson  # noqa: E402
 from util import U, abs_bound, assembled_inputs  # noqa: E402

@@ -13,7 +13,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-import dist_util  # noqa: E402
+from spmv_amd import gloo_transport as dist_util  # noqa: E402
 import oracle  # noqa: E402
 from spmv_amd import host, poisson  # noqa: E402
 from util import assembled_inputs, box_partition, permute_csr  # noqa: E402

@@ -14,50 +14,97 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup",
             "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
             "dtype", "data", "config", "roofline"]
+LINE_MAX = 6144  # what the driver parses; BENCH_r04's 29,947-byte line it could not
 
 
 def _line(out):
+    """the ONE line on stdout that starts with a brace: the compact record"""
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out[-2000:]
+    assert out.rstrip().endswith(lines[0]), "the line must come last"
+    assert len(lines[0]) <= LINE_MAX, len(lines[0])
     return json.loads(lines[0])
 
 
-def _check(d, n_gpus, steps, warmup):
+def _run(args, tmp_path, launcher=(), timeout=600):
+    """bench.py with its detail file under tmp_path -> (line, detail)"""
+    detail = str(tmp_path / "detail.json")
+    res = subprocess.run([sys.executable, *launcher, os.path.join(ROOT, "bench.py"),
+                          *args, "--detail", detail],
+                         capture_output=True, text=True, timeout=timeout)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    # stderr carries the detail too, never as a line starting with a brace
+    assert not [ln for ln in res.stderr.splitlines() if ln.startswith("{")]
+    line = _line(res.stdout)
+    assert line["detail"] == detail
+    return line, json.load(open(detail))
+
+
+def _rel(a, b):
+    return abs(a - b) <= 2e-5 * abs(b)
+
+
+def _check(line, d, n_gpus, steps, warmup):
     for k in REQUIRED:
-        assert k in d, k
-    assert d["n_gpus"] == n_gpus and d["steps"] == steps and d["warmup"] == warmup
-    assert d["unit"] == "iters/s" and d["higher_is_better"] is True
-    assert d["dtype"] == "f64" and d["vs_baseline"] is None
-    assert "workload" in d["config"] and "model" not in d["config"]
-    assert abs(d["value"] - steps / (d["ms_per_step"] * steps / 1e3)) < 1e-6 * d["value"]
-    r = d["roofline"]
-    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert r["launches_timed"] == steps and r["avg_launch_ms"] > 0
+        assert k in line and k in d, k
+        if k != "roofline":
+            assert line[k] == d[k], k
+    assert line["n_gpus"] == n_gpus and line["steps"] == steps
+    assert line["warmup"] == warmup
+    assert line["unit"] == "iters/s" and line["higher_is_better"] is True
+    assert line["dtype"] == "f64" and line["vs_baseline"] is None
+    assert "workload" in line["config"] and "model" not in line["config"]
+    assert abs(line["value"] - 1e3 / line["ms_per_step"]) < 1e-6 * line["value"]
+    c = line["roofline"]
+    assert c["bound"] == "hbm" and c["peak"] == 8000.0 and c["unit"] == "GB/s"
+    assert " " not in c["kernel"].split("<")[0]  # a name, not a paragraph
+    assert _rel(c["frac"], c["achieved"] / c["peak"])
+    assert c["launches_timed"] == steps and c["avg_launch_ms"] > 0
     # physical: the bytes the kernel's format moves over the measured time
-    assert abs(r["achieved"] - r["bytes_per_launch"] / r["avg_launch_ms"] / 1e6) \
-        < 1e-9 * r["achieved"]
-    assert r["frac_requested"] == r["frac"] and r["frac"] > 0
-    # ... and the CSR-equivalent figure under its own name (may exceed 1)
-    assert r["algorithmic_bytes_per_launch"] >= r["bytes_per_launch"]
-    assert abs(r["csr_equivalent_gbs"] - r["algorithmic_bytes_per_launch"]
-               / r["avg_launch_ms"] / 1e6) < 1e-9 * r["csr_equivalent_gbs"]
+    assert _rel(c["achieved"], c["bytes_per_launch"] / c["avg_launch_ms"] / 1e6)
+    assert c["algorithmic_bytes_per_launch"] >= c["bytes_per_launch"]
+    assert _rel(c["frac_csr_equivalent"], c["algorithmic_bytes_per_launch"]
+                / c["avg_launch_ms"] / 1e6 / 8000.0)
+    assert (c["traffic"] is None) == (c["frac_traffic"] is None)
+    # ... the detail file: the same numbers at full precision, with the notes
+    r = d["roofline"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "note" in r
+    assert _rel(c["frac"], r["frac"]) and _rel(c["avg_launch_ms"], r["avg_launch_ms"])
     assert (r["traffic"] is None) == (r["traffic_source"] is None)
-    assert (r["traffic"] is None) == (r["frac_traffic"] is None) and "note" in r
-    assert d["cg_rel_residual"]["k10"] > 0 and d["cg_rel_residual"]["kK"] > 0
+    assert line["cg_rel_residual"]["k10"] == d["cg_rel_residual"]["k10"] > 0
+    assert d["cg_rel_residual"]["kK"] > 0
     assert d["plan"]["plan_ms"] >= 0 and d["plan"]["plan_extra_bytes"] >= 0
+    assert d["plan"]["csr_bytes"] > 0
 
 
-def test_bench_single_gpu_line():
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"),
-                          "--grid", "64", "--steps", "20", "--warmup", "3",
-                          "--cpu-n", "32", "--cpu-iters", "3", "--mixed-grid",
-                          "48", "--stencil27-grid", "40", "--unstructured-rows",
-                          "200000", "--fem-rows", "200000"],
-                         capture_output=True, text=True, timeout=600)
-    assert res.returncode == 0, res.stderr[-3000:]
-    d = _line(res.stdout)
-    _check(d, 1, 20, 3)
+def test_bench_single_gpu_line(tmp_path):
+    line, d = _run(["--grid", "64", "--steps", "20", "--warmup", "3",
+                    "--cpu-n", "32", "--cpu-iters", "3", "--mixed-grid",
+                    "48", "--stencil27-grid", "40", "--unstructured-rows",
+                    "200000", "--fem-rows", "200000"], tmp_path)
+    _check(line, d, 1, 20, 3)
+    # the compact line: what the driver keeps
+    lc, lr = line["cpu_baseline"], line["roofline"]
+    assert set(lc) >= {"value", "unit", "cores", "kind", "sample", "spmv_omp_gbs",
+                       "k10"}
+    assert lc["kind"] == "port" and lc["cores"] >= 1 and lc["value"] > 0
+    assert "32^3" in lc["sample"] and len(lc["sample"]) < 160
+    assert lc["parity_checks_bit_exact"] is True
+    assert lr["csr_order"]["kernel"] == "csr_lxw_kernel<double>"
+    assert _rel(lr["csr_order"]["frac"], lr["algorithmic_bytes_per_launch"]
+                / lr["csr_order"]["ms_per_apply"] / 1e6 / 8000.0)
+    assert lr["general_cg_iters_per_s"] > 0
+    ns = lr["north_star"]
+    assert ns["rows"] == 216 ** 3 and 0 < ns["rowblock_frac"] < 1
+    assert 0 < ns["lx_frac"] < 1 and ns["default_frac"] > 0
+    assert set(lr["ragged"]) >= {"fem_spmv", "fem_tail_spmv", "fem81_spmv",
+                                 "fem_sym_spmv", "fem_tail_sym_spmv",
+                                 "unstructured_spmv"}
+    for k, v in lr["ragged"].items():
+        if k != "fem_sym_cg_iters_per_s":
+            assert len(v) == 2 and v[0] > 0 and v[1] > 0, k
+    assert lr["plan_extra_over_csr_bytes"] >= 0
+    assert line["symmetric"]["iters_per_s"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
     assert c["cores"] <= c["host"]["physical_cores"] and "32^3" in c["sample"]
@@ -101,7 +148,7 @@ def test_bench_single_gpu_line():
     assert d["csr_sjds_spmv"]["form"]["sjds"] == 1
     # the general-CSR line inside `roofline` (the block the driver keeps): the
     # AUTO plan without the lattice analysis, same CG loop, SURVEY 8d's bytes
-    co = r_ = d["roofline"]["csr_order"]
+    co = d["roofline"]["csr_order"]
     assert "csr_lxw_kernel" in co["kernel"] and 0 < co["frac"] <= 1.5
     assert abs(co["frac"] - co["algorithmic_bytes_per_launch"] / co["ms_per_apply"]
                / 1e6 / 8000.0) < 1e-9
@@ -155,89 +202,93 @@ def test_bench_single_gpu_line():
     assert mp["x_rel_diff"] < 1e-7
 
 
-def test_bench_without_the_symmetry_check():
+def test_bench_without_the_symmetry_check(tmp_path):
     """--no-bake: the line of a lattice matrix whose values stay in CSR order
     (the CSR-order lattice kernel; DESIGN.md section 7, 'reading the headline')."""
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"),
-                          "--grid", "128", "--steps", "10", "--warmup", "2",
-                          "--no-bake", "--no-extras", "--no-cpu-baseline"],
-                         capture_output=True, text=True, timeout=600)
-    assert res.returncode == 0, res.stderr[-3000:]
-    d = _line(res.stdout)
-    _check(d, 1, 10, 2)
+    line, d = _run(["--grid", "128", "--steps", "10", "--warmup", "2",
+                    "--no-bake", "--no-extras", "--no-cpu-baseline"], tmp_path)
+    _check(line, d, 1, 10, 2)
+    assert line["roofline"]["kernel"] == "csr_lattice_kernel<double>"
     assert d["plan"]["form"]["sdia"] == 0 and d["plan"]["form"]["lat"] == 1
     assert "csr_lattice_kernel" in d["roofline"]["kernel"]
     assert d["roofline"]["frac"] <= d["roofline"]["frac_csr_equivalent"]
 
 
-def test_bench_with_the_values_streamed():
+def test_bench_with_the_values_streamed(tmp_path):
     """--no-const: the headline of a lattice matrix whose coefficients vary (the
     half diagonal form streams the lower values)."""
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"),
-                          "--grid", "128", "--steps", "10", "--warmup", "2",
-                          "--no-const", "--no-extras", "--no-cpu-baseline"],
-                         capture_output=True, text=True, timeout=600)
-    assert res.returncode == 0, res.stderr[-3000:]
-    d = _line(res.stdout)
-    _check(d, 1, 10, 2)
+    line, d = _run(["--grid", "128", "--steps", "10", "--warmup", "2",
+                    "--no-const", "--no-extras", "--no-cpu-baseline"], tmp_path)
+    _check(line, d, 1, 10, 2)
     assert d["plan"]["form"]["sdia"] == 1 and d["plan"]["form"]["sdia_const"] == 0
     assert "csr_sym_dia_kernel<double, general order>" in d["roofline"]["kernel"]
 
 
-def test_bench_two_rank_rehearsal():
+def _torchrun(nproc):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    res = subprocess.run(
-        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-         "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus",
-         "2", "--steps", "10", "--warmup", "2", "--grid", "64", "--transport",
-         "gloo"], capture_output=True, text=True, timeout=600)
-    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
-    d = _line(res.stdout)
-    _check(d, 2, 10, 2)
-    assert "REHEARSAL" in d["data"] and "cpu_baseline" not in d
-    assert d["halo_selfcheck"] == "ok" and len(d["ranks"]) == 2
-    assert [r["neighbours"] for r in d["ranks"]] == [1, 1]
+    return ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node",
+            str(nproc), "--master-addr", "127.0.0.1", "--master-port", str(port)]
+
+
+def _k10_one_rank(grid, steps, tmp_path):
+    (tmp_path / "one").mkdir(exist_ok=True)
+    line, _ = _run(["--grid", str(grid), "--steps", str(steps), "--warmup", "2",
+                    "--no-cpu-baseline", "--no-extras"], tmp_path / "one")
+    return line["cg_rel_residual"]["k10"]
+
+
+def test_bench_two_rank_rehearsal_self_launched(tmp_path, monkeypatch):
+    """`python bench.py --gpus 2 ...` with NO launcher and no WORLD_SIZE in the
+    environment (the shape of the driver's N = 1 command): bench.py starts the
+    two ranks itself as child processes -- the parent never touches the GPU --
+    and forwards rank 0's line."""
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    line, d = _run(["--gpus", "2", "--steps", "10", "--warmup", "2", "--grid", "64",
+                    "--transport", "gloo"], tmp_path)
+    _check(line, d, 2, 10, 2)
+    assert "child processes" in line["launcher"]
+    assert "REHEARSAL" in line["data"] and "cpu_baseline" not in line
+    assert line["halo_selfcheck"] == "ok" and len(line["ranks"]) == 2
+    # per rank: [neighbours, ghosts, rows]
+    assert [r[0] for r in line["ranks"]] == [1, 1]
+    assert [r[1] for r in line["ranks"]] == [64 * 64, 64 * 64]
+    assert sum(r[2] for r in line["ranks"]) == 64 ** 3
     assert [r["ghosts"] for r in d["ranks"]] == [64 * 64, 64 * 64]
-    assert sum(r["rows"] for r in d["ranks"]) == 64 ** 3
     # the distributed run reproduces the one-rank residual after 10 iterations
-    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"),
-                          "--grid", "64", "--steps", "10", "--warmup", "2",
-                          "--no-cpu-baseline"],
-                         capture_output=True, text=True, timeout=600)
-    assert one.returncode == 0, one.stderr[-3000:]
-    k10 = _line(one.stdout)["cg_rel_residual"]["k10"]
-    assert abs(d["cg_rel_residual"]["k10"] - k10) <= 1e-10 * k10
+    k10 = _k10_one_rank(64, 10, tmp_path)
+    assert abs(line["cg_rel_residual"]["k10"] - k10) <= 1e-10 * k10
 
 
-def test_bench_two_rank_rehearsal_onesided_halo():
-    """The same rehearsal with --cm onesided_put_active: the two ranks are
-    processes sharing GPU 0, the halo moves by peer stores into IPC-mapped
-    windows (one put kernel per exchange), and the run lands on the same
-    residual."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    res = subprocess.run(
-        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-         "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus",
-         "2", "--steps", "10", "--warmup", "2", "--grid", "64", "--transport",
-         "gloo", "--cm", "onesided_put_active"],
-        capture_output=True, text=True, timeout=600)
-    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
-    d = _line(res.stdout)
-    _check(d, 2, 10, 2)
-    assert "peer stores" in d["config"]["halo"] and d["halo_selfcheck"] == "ok"
-    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"),
-                          "--grid", "64", "--steps", "10", "--warmup", "2",
-                          "--no-cpu-baseline", "--no-extras"],
+def test_bench_self_launch_reports_a_failing_rank(tmp_path, monkeypatch):
+    """a child that dies gives the parent a non-zero exit code and no line"""
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus",
+                          "2", "--steps", "4", "--warmup", "1", "--grid", "32",
+                          "--transport", "gloo", "--petsc-matrix",
+                          str(tmp_path / "no_such_file.dat")],
                          capture_output=True, text=True, timeout=600)
-    assert one.returncode == 0, one.stderr[-3000:]
-    k10 = _line(one.stdout)["cg_rel_residual"]["k10"]
-    assert abs(d["cg_rel_residual"]["k10"] - k10) <= 1e-10 * k10
+    assert res.returncode != 0
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_two_rank_rehearsal_onesided_halo(tmp_path):
+    """The rehearsal under torch.distributed.run (the driver's N > 1 command)
+    with --cm onesided_put_active: the two ranks are processes sharing GPU 0,
+    the halo moves by peer stores into IPC-mapped windows (one put kernel per
+    exchange), and the run lands on the same residual."""
+    line, d = _run(["--gpus", "2", "--steps", "10", "--warmup", "2", "--grid", "64",
+                    "--transport", "gloo", "--cm", "onesided_put_active"],
+                   tmp_path, launcher=_torchrun(2))
+    _check(line, d, 2, 10, 2)
+    assert "launcher" not in line
+    assert "peer stores" in line["config"]["halo"]
+    assert line["halo_selfcheck"] == "ok"
+    k10 = _k10_one_rank(64, 10, tmp_path)
+    assert abs(line["cg_rel_residual"]["k10"] - k10) <= 1e-10 * k10
 
 
 def _gpu_count():
@@ -247,30 +298,19 @@ def _gpu_count():
 
 @pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs (RCCL refuses two "
                     "ranks on one device); the 1-GPU boxes run the gloo rehearsal")
-def test_bench_two_gpus_over_rccl():
+def test_bench_two_gpus_over_rccl(tmp_path, monkeypatch):
     """The real transport: two ranks, one GPU each, RCCL send/recv for the halo
     on the side stream and RCCL all-reduce (its own communicator) for the
-    scalars.  The line must prove itself: RCCL reports 2 ranks, the halo
-    self-check passed, and the run lands on the one-rank residual."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    res = subprocess.run(
-        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-         "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus",
-         "2", "--steps", "12", "--warmup", "2", "--grid", "128"],
-        capture_output=True, text=True, timeout=900)
-    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
-    d = _line(res.stdout)
-    _check(d, 2, 12, 2)
-    assert d["rccl"]["nranks"] == 2 and d["rccl"]["separate_reduction_comm"]
-    assert d["halo_selfcheck"] == "ok"
-    assert [r["ghosts"] for r in d["ranks"]] == [128 * 128] * 2
-    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"),
-                          "--grid", "128", "--steps", "12", "--warmup", "2",
-                          "--no-cpu-baseline", "--no-extras"],
-                         capture_output=True, text=True, timeout=600)
-    assert one.returncode == 0, one.stderr[-3000:]
-    k10 = _line(one.stdout)["cg_rel_residual"]["k10"]
-    assert abs(d["cg_rel_residual"]["k10"] - k10) <= 1e-10 * k10
+    scalars -- started the way the driver may start it, `python bench.py --gpus
+    2` without a launcher.  The line must prove itself: RCCL reports 2 ranks,
+    the halo self-check passed, and the run lands on the one-rank residual."""
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    line, d = _run(["--gpus", "2", "--steps", "12", "--warmup", "2", "--grid",
+                    "128"], tmp_path, timeout=900)
+    _check(line, d, 2, 12, 2)
+    assert line["rccl"]["nranks"] == 2 and line["rccl"]["separate_reduction_comm"]
+    assert line["halo_selfcheck"] == "ok"
+    assert [r[1] for r in line["ranks"]] == [128 * 128] * 2
+    k10 = _k10_one_rank(128, 12, tmp_path)
+    assert abs(line["cg_rel_residual"]["k10"] - k10) <= 1e-10 * k10
