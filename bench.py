@@ -124,6 +124,9 @@ def parse():
     ap.add_argument("--petsc-rhs", default=None,
                     help="PETSc binary vector file for the right-hand side "
                          "(demos/cg.cpp:51); default: the Gaussian vector")
+    ap.add_argument("--put-timeout-ms", type=int, default=None,
+                    help="bound of the waits of the one-sided halo and of the peer "
+                         "reduction (ctx option put_timeout_ms; default 60 s)")
     ap.add_argument("--detail", default=None,
                     help="where the full record goes (every sub-record, plan "
                          "costs, cross-checks, notes); default "
@@ -841,9 +844,12 @@ def main():
                              f"{rccl['nranks']}, expected {rank} of {world}")
     else:
         comm = host.Comm.self_comm()
-    if args.peer_reduce and args.cm.startswith("onesided"):
-        raise SystemExit("--peer-reduce goes with the two-sided halo models (the "
-                         "pair with the one-sided halo is not validated)")
+    # (--peer-reduce with a one-sided --cm: the LIBRARY refuses the pair -- the
+    # L2GMap built below falls back to the two-sided exchange on every rank;
+    # the line's config.halo says what ran)
+    if args.put_timeout_ms is not None:
+        _lib.call("spmv_hip_ctx_set_option", exec_.context, b"put_timeout_ms",
+                  args.put_timeout_ms)
     peer_reduce = bool(world > 1 and args.peer_reduce
                        and comm.enable_peer_reduce(exec_))
 

@@ -989,6 +989,8 @@ int spmvh_cg_ex(spmvh_comm* comm, spmvh_exec* exec, spmvh_matrix* A,
     CgOptions opt;
     opt.time_spmv = (time_spmv & 1) != 0;
     opt.consumer_reductions = (time_spmv & 4) == 0; // bit 2 switches it off
+    if ((time_spmv >> 8) & 0xff) // bits 8-15: CgOptions::poll_every (0 = default)
+      opt.poll_every = (time_spmv >> 8) & 0xff;
     CgStats st;
     *num_its = cg(*comm->comm, *exec->hip, *A->A, b, x, kmax, rtol,
                   rnorm_history ? &hist : nullptr, &opt, &st,

@@ -2,8 +2,11 @@
 #include "comm.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
+
+#include <unistd.h>
 
 #include "executor.h"
 #include "spmv_hip.h"
@@ -62,6 +65,26 @@ struct ReduceCard { // what a rank tells the others about its window
 };
 } // namespace
 
+bool Comm::pair_allowed()
+{
+  const char* e = std::getenv("SPMV_ALLOW_PUT_WITH_PEER_REDUCE");
+  return e && e[0] == '1';
+}
+
+bool Comm::ranks_share_a_process() const
+{
+  if (_shared_process < 0) {
+    const std::vector<int64_t> pids
+        = allgather_value<int64_t>(static_cast<int64_t>(getpid()));
+    int shared = 0;
+    for (size_t a = 0; a < pids.size(); ++a)
+      for (size_t b = a + 1; b < pids.size(); ++b)
+        shared = shared || pids[a] == pids[b];
+    _shared_process = shared;
+  }
+  return _shared_process != 0;
+}
+
 bool Comm::enable_peer_reduce(const HipExecutor& exec) const
 {
   if (_reduce)
@@ -73,7 +96,12 @@ bool Comm::enable_peer_reduce(const HipExecutor& exec) const
   std::memset(&mine, 0, sizeof(mine));
   spmv_hip_reduce* r = nullptr;
   int fine = 0;
-  int rc = P <= SPMV_HIP_REDUCE_MAX_RANKS
+  // not beside a one-sided halo where ranks share a process (comm.h); every
+  // rank takes the same decision: the counts are collective by construction
+  // and the process ids are exchanged
+  const bool refused
+      = _onesided_maps > 0 && ranks_share_a_process() && !pair_allowed();
+  int rc = (P <= SPMV_HIP_REDUCE_MAX_RANKS && !refused)
                ? spmv_hip_reduce_create(exec.context(), P, me, &r, mine.handle,
                                         &mine.address, &mine.pid, &fine)
                : SPMV_HIP_ENOTSUP;
@@ -102,6 +130,9 @@ bool Comm::enable_peer_reduce(const HipExecutor& exec) const
   }
   _reduce = r;
   _reduce_ctx = exec.context();
+  _reduce_exec = &exec;
+  _reduce_stream_set = false;
+  exec.attach_reduce_owner(this); // ~HipExecutor closes it if we are still here
   return true;
 }
 
@@ -118,11 +149,22 @@ void Comm::close_peer_reduce() const
   spmv_hip_reduce_destroy(_reduce);
   _reduce = nullptr;
   _reduce_ctx = nullptr;
+  if (_reduce_exec)
+    _reduce_exec->detach_reduce_owner(this);
+  _reduce_exec = nullptr;
 }
 
 void Comm::reduce_sum(double* device_inout, size_t count, void* stream) const
 {
   if (_reduce && count <= SPMV_HIP_REDUCE_MAX_COUNT) {
+    // the double-buffered slots rely on stream order (epoch k+1's store into
+    // a slot follows epoch k-1's read of it): when the caller moves to another
+    // stream, the previous one is drained first (rare: cg() stays on one)
+    void* resolved = stream ? stream : _reduce_exec->get_stream();
+    if (_reduce_stream_set && _reduce_stream != resolved)
+      _reduce_exec->synchronize_stream(_reduce_stream);
+    _reduce_stream = resolved;
+    _reduce_stream_set = true;
     throw_on_error(spmv_hip_reduce_sum_f64(_reduce_ctx, _reduce, device_inout,
                                            static_cast<int>(count), stream),
                    "spmv_hip_reduce_sum_f64");
@@ -231,6 +273,14 @@ void RcclComm::allreduce_sum(double* device_inout, size_t count,
 }
 
 // ---- CallbackComm ------------------------------------------------------------
+CallbackComm::~CallbackComm()
+{
+  try { // (collective: every rank destroys its communicator)
+    close_peer_reduce();
+  } catch (...) {
+  }
+}
+
 void CallbackComm::allgather(const void* send, void* recv, size_t bytes) const
 {
   if (!_cb.allgather || _cb.allgather(_cb.user, send, recv, bytes) != 0)

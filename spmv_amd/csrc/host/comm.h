@@ -83,11 +83,30 @@ public:
   // are COLLECTIVE over the communicator; close_peer_reduce() before the
   // communicator (or the executor) goes away -- derived destructors do.
   // Returns false (and stays on allreduce_sum) when some rank cannot reach
-  // some other rank's window.
+  // some other rank's window -- or when an L2GMap with the ONE-SIDED halo
+  // lives on this communicator AND two ranks of it share a process (ranks as
+  // threads): that pair is refused by the library, on every rank alike
+  // (conversely an L2GMap built after enable_peer_reduce() then falls back to
+  // the two-sided exchange).  Why: DESIGN.md section 6 -- with both in use
+  // the exchanges of 2 to 8 thread ranks time out whatever the host's
+  // run-ahead, while one process per rank (the production topology) runs the
+  // pair.  The executor closes the reduction of a communicator that outlives
+  // it.  reduce_sum() relies on stream order between consecutive reductions
+  // (double-buffered slots): a call on another stream than the previous one
+  // drains that one first.
   bool enable_peer_reduce(const HipExecutor& exec) const;
   void close_peer_reduce() const;
   bool peer_reduce() const { return _reduce != nullptr; }
   void reduce_sum(double* device_inout, size_t count, void* stream) const;
+  // L2GMap's bookkeeping of one-sided maps on this communicator (collective
+  // by construction: every rank builds and destroys the same maps)
+  void note_onesided_map(int delta) const { _onesided_maps += delta; }
+  int onesided_maps() const { return _onesided_maps; }
+  // SPMV_ALLOW_PUT_WITH_PEER_REDUCE=1 lifts the refusal (probes only)
+  static bool pair_allowed();
+  // two ranks of this communicator live in one process (collective on its
+  // first call: the process ids are exchanged once)
+  bool ranks_share_a_process() const;
 
   // ---- helpers built on allgather (host, setup only) ----------------------
   template <typename T>
@@ -107,11 +126,17 @@ public:
 private:
   mutable spmv_hip_reduce* _reduce = nullptr;
   mutable spmv_hip_ctx* _reduce_ctx = nullptr;
+  mutable const HipExecutor* _reduce_exec = nullptr;
+  mutable void* _reduce_stream = nullptr;
+  mutable bool _reduce_stream_set = false;
+  mutable int _onesided_maps = 0;
+  mutable int _shared_process = -1; // unknown until asked
 };
 
 class SelfComm final : public Comm
 {
 public:
+  ~SelfComm() override { close_peer_reduce(); }
   int rank() const override { return 0; }
   int size() const override { return 1; }
   void allgather(const void* send, void* recv, size_t bytes) const override;
@@ -183,6 +208,7 @@ public:
       : _rank(rank), _size(size), _cb(cb)
   {
   }
+  ~CallbackComm() override;
   int rank() const override { return _rank; }
   int size() const override { return _size; }
   void allgather(const void* send, void* recv, size_t bytes) const override;

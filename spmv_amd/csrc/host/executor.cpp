@@ -1,10 +1,12 @@
 // HostExecutor / HipExecutor: see executor.h.
 #include "executor.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
+#include "comm.h"
 #include "csr.h"
 #include "spmv_hip.h"
 
@@ -113,7 +115,31 @@ HipExecutor::HipExecutor(int device_id, std::shared_ptr<DeviceExecutor> host)
   _dev_info.id = device_id;
 }
 
-HipExecutor::~HipExecutor() { spmv_hip_ctx_destroy(_ctx); }
+HipExecutor::~HipExecutor()
+{
+  // a communicator that outlives its executor: its reduction window lives in
+  // this context (collective, like the communicator's own destruction)
+  const std::vector<const Comm*> owners = _reduce_owners;
+  for (const Comm* c : owners) {
+    try {
+      c->close_peer_reduce();
+    } catch (...) {
+    }
+  }
+  spmv_hip_ctx_destroy(_ctx);
+}
+
+void HipExecutor::attach_reduce_owner(const Comm* comm) const
+{
+  _reduce_owners.push_back(comm);
+}
+
+void HipExecutor::detach_reduce_owner(const Comm* comm) const
+{
+  _reduce_owners.erase(
+      std::remove(_reduce_owners.begin(), _reduce_owners.end(), comm),
+      _reduce_owners.end());
+}
 
 void HipExecutor::synchronize() const
 {

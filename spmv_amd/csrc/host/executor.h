@@ -21,11 +21,14 @@
 #include <cstdint>
 #include <memory>
 #include <string>
+#include <vector>
 
 struct spmv_hip_ctx; // include/spmv_hip.h
 
 namespace spmv
 {
+
+class Comm;
 
 template <typename T>
 class CSRMatrix;
@@ -219,6 +222,10 @@ public:
                        float* out) const;
   void scatter_add_run(int num_indices, const int32_t* indices,
                        const double* in, double* out) const;
+  // communicators whose peer reduction lives in this executor's context
+  // (Comm::enable_peer_reduce): closed by ~HipExecutor if still open
+  void attach_reduce_owner(const Comm* comm) const;
+  void detach_reduce_owner(const Comm* comm) const;
 
 protected:
   void* _alloc(size_t num_bytes) const override;
@@ -236,6 +243,7 @@ private:
   HipExecutor(int device_id, std::shared_ptr<DeviceExecutor> host);
   std::shared_ptr<DeviceExecutor> _host;
   spmv_hip_ctx* _ctx = nullptr;
+  mutable std::vector<const Comm*> _reduce_owners;
 };
 
 } // namespace spmv

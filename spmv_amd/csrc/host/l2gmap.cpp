@@ -166,7 +166,12 @@ void L2GMap::setup_put(std::int64_t local_size)
   const std::size_t nn = _neighbours.size();
   spmv_hip_put* put = nullptr;
   mine.stage_bytes = 8 * static_cast<std::int64_t>(_ghosts.size() > 0 ? _ghosts.size() : 1);
-  if (nn <= SPMV_HIP_PUT_MAX_PEERS
+  // not beside the peer reduction of the CG scalars where ranks share a
+  // process (comm.h): such a communicator keeps the two-sided exchange -- on
+  // every rank, `ok` travels
+  const bool refused = _comm->peer_reduce() && _comm->ranks_share_a_process()
+                       && !Comm::pair_allowed();
+  if (!refused && nn <= SPMV_HIP_PUT_MAX_PEERS
       && spmv_hip_put_create(_hip->context(), (size_t)mine.stage_bytes, &put,
                              mine.handle, &mine.raw, &mine.pid)
              == SPMV_HIP_OK) {
@@ -219,6 +224,8 @@ void L2GMap::setup_put(std::int64_t local_size)
   // is keyed on it, not on this rank's own window (a rank without neighbours
   // has none, yet must take part)
   _put_agreed = all_ok;
+  if (all_ok)
+    _comm->note_onesided_map(+1);
   if (all_ok && nn > 0) {
     _put = put;
   } else {
@@ -245,6 +252,7 @@ L2GMap::~L2GMap()
     if (_put)
       spmv_hip_put_destroy(_put);
     _put = nullptr;
+    _comm->note_onesided_map(-1);
   }
   try {
     if (_hip) {

@@ -679,15 +679,18 @@ class CgWorkspace:
 
 
 def cg_ex(comm, exec_, A, b_ptr, x_ptr, kmax, rtol, workspace=None,
-          time_spmv=False, history=False, consumer_reductions=True):
+          time_spmv=False, history=False, consumer_reductions=True,
+          poll_every=0):
     """cg with the optional arguments: returns (k, history, spmv_ms_total,
-    spmv_launches)."""
+    spmv_launches).  poll_every: CgOptions::poll_every (how many iterations the
+    host may run ahead of the device's `done` flag; 0 = the default, 16)."""
     k, n = C.c_int(), C.c_int()
     ms = f64()
     hist = np.zeros(kmax + 1) if history else None
     call("spmvh_cg_ex", comm.h, exec_.h, A.h, b_ptr, x_ptr, kmax, float(rtol),
          C.byref(k), _np_ptr(hist), workspace.h if workspace else None,
-         int(time_spmv) | (0 if consumer_reductions else 4), C.byref(ms),
+         int(time_spmv) | (0 if consumer_reductions else 4)
+         | ((int(poll_every) & 0xff) << 8), C.byref(ms),
          C.byref(n))
     return (k.value, hist[:k.value + 1] if history else None, ms.value,
             n.value)

@@ -291,6 +291,23 @@ def test_bench_two_rank_rehearsal_onesided_halo(tmp_path):
     assert abs(line["cg_rel_residual"]["k10"] - k10) <= 1e-10 * k10
 
 
+def test_bench_rehearsal_onesided_halo_with_peer_reduction(tmp_path):
+    """The pair the library refuses for thread ranks -- one-sided halo + the
+    deterministic peer reduction of the CG scalars -- in the production
+    topology, one PROCESS per rank (4 ranks sharing GPU 0 over IPC handles):
+    neither exchange touches the host, 40 iterations, the one-rank residual."""
+    line, d = _run(["--gpus", "4", "--steps", "40", "--warmup", "3", "--grid", "64",
+                    "--transport", "gloo", "--cm", "onesided_put_active",
+                    "--peer-reduce", "--put-timeout-ms", "10000"],
+                   tmp_path, launcher=_torchrun(4))
+    _check(line, d, 4, 40, 3)
+    assert "peer stores" in line["config"]["halo"]
+    assert line["cg_scalar_reductions"].startswith("peer windows")
+    assert line["halo_selfcheck"] == "ok"
+    k10 = _k10_one_rank(64, 40, tmp_path)
+    assert abs(line["cg_rel_residual"]["k10"] - k10) <= 1e-10 * k10
+
+
 def _gpu_count():
     import torch
     return torch.cuda.device_count()  # does not initialise the GPU

@@ -49,11 +49,21 @@ def main():
                     help="the CG scalars by the deterministic peer reduction "
                          "(Comm::enable_peer_reduce) instead of the transport's "
                          "all-reduce")
+    ap.add_argument("--poll-every", type=int, default=0,
+                    help="CgOptions::poll_every: iterations the host may run "
+                         "ahead of the device (0 = default 16)")
+    ap.add_argument("--allow-pair", action="store_true",
+                    help="PROBE: --peer-reduce together with the one-sided halo "
+                         "(the library refuses the pair; SPMV_ALLOW_PUT_WITH_PEER_"
+                         "REDUCE=1 lifts that for this probe)")
+    ap.add_argument("--timeout-ms", type=int, default=20000,
+                    help="put / peer-reduce wait bound (ctx put_timeout_ms)")
     args = ap.parse_args()
     if args.peer_reduce and args.cm.startswith("onesided"):
-        # the pair does not complete with the ranks as threads (two sets of
-        # polling kernels on one process's hardware queues): not offered
-        raise SystemExit("--peer-reduce goes with the two-sided halo models")
+        if not args.allow_pair:
+            raise SystemExit("--peer-reduce goes with the two-sided halo models "
+                             "(--allow-pair: the probe of the pair)")
+        os.environ["SPMV_ALLOW_PUT_WITH_PEER_REDUCE"] = "1"
     P, n = args.ranks, args.grid
     N = n ** 3
     cm = getattr(host, args.cm.upper())
@@ -103,12 +113,13 @@ def main():
             # reduction kernel that in turn waits for this rank's (ranks in
             # processes of their own do not share that wait).  A stuck wait
             # fails in 20 s.
-            _lib.call("spmv_hip_ctx_set_option", ctx, b"put_timeout_ms", 20000)
+            _lib.call("spmv_hip_ctx_set_option", ctx, b"put_timeout_ms",
+                      args.timeout_ms)
             rec["peer_reduce"] = bool(comm.enable_peer_reduce(exec_))
         tw.bar.wait()
         t0 = time.perf_counter()
         k, hist, _, _ = host.cg_ex(comm, exec_, A, d_b, d_x, args.steps, 0.0, ws,
-                                   history=True)
+                                   history=True, poll_every=args.poll_every)
         exec_.synchronize()
         rec["cg_wall_s"] = time.perf_counter() - t0
         rec["k"] = k
