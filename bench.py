@@ -443,6 +443,12 @@ def kernel_of(A, symmetric):
         return ("csr_rowblock_lx_kernel<double> (LX form: x windows staged in "
                 "LDS, 16-bit column offsets; fused p.Ap)",
                 algo, nnz * 10 + (rows + 1) * 4 + nrb * 144 + y_x)
+    if A.plan_get("xw"):
+        return ("csr_lxw_kernel<double, XW> (the caller's CSR arrays as they "
+                "are: values and 32-bit column indices by LDS-DMA one row block "
+                "ahead, the row block's x windows staged in LDS, a column turned "
+                "into its staged position by the block's window list; fused p.Ap)",
+                algo, algo + nrb * 144)
     return ("csr_rowblock_kernel<double> (gather; fused p.Ap)", algo, algo)
 
 
@@ -453,7 +459,7 @@ def plan_record(A):
             # the caller's CSR arrays the plan's memory comes on top of
             "csr_bytes": nnz * 12 + (rows + 1) * 4,
             "form": {k: A.plan_get(k) for k in
-                     ("lat", "lx", "lxw", "sjds", "sym_sj", "wdia", "wdia_const",
+                     ("lat", "lx", "lxw", "xw", "sjds", "sym_sj", "wdia", "wdia_const",
                       "wdia_hbox", "slat", "sdia", "sdia_const", "sym_det", "zwalk")}}
 
 
@@ -563,6 +569,8 @@ def spmv_record(exec_, comm, host, _lib, n, symmetric, reps, lattice=True,
         opts[b"lx_min_nnz"] = (1 << 62, 1 << 20)
     if not sj:  # nor the sliced jagged form: the plain row-block gather kernel
         opts[b"sj_min_nnz"] = (1 << 62, 1 << 20)
+    if not xw:  # ... nor staged x windows: the gather kernel
+        opts[b"xw_min_nnz"] = (1 << 62, 1 << 20)
     if not bake:
         opts[b"bake_general"] = (0, 1)
     if not const:  # stream the values even where the diagonals are constant
@@ -718,8 +726,14 @@ def compact_line(out, detail_path):
             ns[key + "_frac"] = sig(out[rec]["frac_csr_equivalent"])
         roof["north_star"] = ns
     if "csr_rowblock_spmv" in out:
-        roof["csr_rowblock"] = [sig(out["csr_rowblock_spmv"]["ms_per_apply"]),
-                                sig(out["csr_rowblock_spmv"]["frac_csr_equivalent"])]
+        # the caller's CSR arrays streamed as they are: [ms, frac of B_csr,
+        # fabric bytes] with the x windows staged (XW), and the gather kernel
+        for key, rec in (("csr_rowblock", "csr_rowblock_spmv"),
+                         ("csr_gather", "csr_gather_spmv")):
+            if rec in out:
+                roof[key] = [sig(out[rec]["ms_per_apply"]),
+                             sig(out[rec]["frac_csr_equivalent"]),
+                             out[rec].get("traffic")]
     if "ragged" in r:
         # name: [ms per apply, frac of SURVEY 8d's bytes (B_sym for *_sym_*)]
         roof["ragged"] = {k: [sig(v["ms_per_apply"]), sig(v["frac"])]
@@ -1232,9 +1246,14 @@ def main():
                 if not (args.no_lattice or args.no_lx):
                     out["csr_lx_spmv"] = rec("csr_lx_spmv", n, False, 20,
                                              lattice=False)
+                    # ... the caller's arrays as they are: x windows staged
+                    # (XW), and the gather kernel
                     out["csr_rowblock_spmv"] = rec("csr_rowblock_spmv", n, False,
                                                    20, lattice=False, lx=False,
                                                    sj=False)
+                    out["csr_gather_spmv"] = rec("csr_gather_spmv", n, False,
+                                                 20, lattice=False, lx=False,
+                                                 sj=False, xw=False)
                     # ... and the sliced jagged form on this matrix (7 entries
                     # per row are too few for it: the LX form is the AUTO choice)
                     out["csr_sjds_spmv"] = rec("csr_sjds_spmv", n, False, 20,

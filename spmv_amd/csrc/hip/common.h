@@ -26,6 +26,17 @@ struct spmv_hip_ctx {
   // x windows by LDS-DMA one row block ahead; "lx_dma", 0 = the register-staged
   // kernel's layout)
   int lx_dma = 1;
+  // plans that keep the caller's CSR arrays as they are (no lattice, LX or
+  // sliced jagged form) stage the x windows of every row block in LDS from
+  // this many entries on ("xw_min_nnz": the XW kernel of spmv_lxw.hip; the
+  // plan adds 144 B per row block, the CSR arrays are streamed untouched)
+  int64_t xw_min_nnz = (int64_t)1 << 20;
+  // ... and only when x (num_cols * 8 bytes) is at least this large
+  // ("xw_min_x_bytes"): while x fits the Infinity Cache the gather kernel is the
+  // faster of the two (216^3: 0.200 against 0.211 ms), beyond it the staged
+  // windows are (512^3: 2.49 against 2.57 ms on one box, 13.8 instead of
+  // 15.7 GB across the fabric)
+  int64_t xw_min_x_bytes = (int64_t)128 << 20;
   // plans try the lattice form (constant column offsets per row block, no
   // index stream) for general matrices with at least this many entries
   // ("lat_min_nnz")

@@ -150,6 +150,18 @@ constexpr int kLxwMaxPieces = 16;  // 2048 staged elements (16 KiB fp64)
 constexpr int kLxwPieces0 = 4;
 constexpr int kLxwRec = 20;        // ints per record (4 + 16)
 constexpr int kLxwAlign = 4;       // window starts: multiples of 4 columns
+// XW: the same kernel on the CALLER's column indices (no 16-bit copy): the
+// record carries, after the LXW words, the windows themselves -- an entry's
+// staged position is its column + the delta of the last window that starts at
+// or below it.
+//   [kXwFirst0 + k]  first column of window k + 1 (k = 0..6; INT32_MAX: none)
+//   [kXwDelta0 + k]  staged offset - first column of window k (k = 0..7)
+// (the 7-point matrix of a 512^3 grid has five windows per row block: the two
+// planes, the two lines -- 256 columns away from the block's own -- and its own)
+constexpr int kXwMaxWin = 8;
+constexpr int kXwFirst0 = kLxwPieces0 + kLxwMaxPieces; // 20
+constexpr int kXwDelta0 = kXwFirst0 + kXwMaxWin;       // 28
+constexpr int kXwRec = 36;
 
 // Lattice form (spmv_lat.hip)
 constexpr int kLatMaxOff = 8; // offsets per row block = mask bits
@@ -352,7 +364,7 @@ struct spmv_hip_csr_plan {
   bool structure_baked() const
   {
     return row_list || lx_lidx || lat_tab || slat_mask || t_ptr || lxw_rec
-           || wdia_val || sj_lenperm;
+           || xw_rec || wdia_val || sj_lenperm;
   }
   // ROWBLOCK "LX" form: LDS-staged x windows + 16-bit local column indices
   // (csr_rowblock_lx_kernel); built by plan_create when most row blocks qualify
@@ -372,6 +384,13 @@ struct spmv_hip_csr_plan {
   int lxw_max_cnt = 0;        // most entries in a staged row block
   int lxw_max_pieces = 0;     // most staged pieces of a row block
   int lxw_blocks_per_cu = 0;  // 0 = what the LDS footprint allows
+  // XW: the LDS-DMA kernel on the caller's CSR arrays as they are (values,
+  // 32-bit column indices), x windows staged: what a plan without lattice / LX
+  // / sliced jagged form runs instead of the gather kernel (spmv_lxw.hip)
+  int32_t* xw_rec = nullptr; // kXwRec ints per row block
+  int xw = 0;                // use it (plan_set "xw")
+  int xw_staged = 0;         // row blocks whose windows are staged
+  int xw_max_cnt = 0, xw_max_pieces = 0;
   // Lattice form (spmv_lat.hip): every row block's columns are row + one of
   // <= 8 constant offsets => no index stream, values arrive by LDS-DMA
   int32_t* lat_tab = nullptr;  // kLatRec ints per row block: count, offsets
@@ -474,6 +493,15 @@ int spmv_lxw_run_f64(const spmv_hip_csr_plan* pl, hipStream_t st,
                      const int32_t* rowptr, const int32_t* colind,
                      const double* values, double alpha, const double* in,
                      double beta, double* out, DotOut dot);
+int spmv_xw_grid(const spmv_hip_csr_plan* pl, int elem_bytes);
+int spmv_xw_run_f64(const spmv_hip_csr_plan* pl, hipStream_t st,
+                    const int32_t* rowptr, const int32_t* colind,
+                    const double* values, double alpha, const double* in,
+                    double beta, double* out, DotOut dot);
+int spmv_xw_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st,
+                    const int32_t* rowptr, const int32_t* colind,
+                    const float* values, float alpha, const float* in,
+                    float beta, float* out);
 int spmv_lxw_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st,
                      const int32_t* rowptr, const int32_t* colind,
                      const float* values, float alpha, const float* in,

@@ -120,6 +120,16 @@ int spmv_hip_ctx_set_option(spmv_hip_ctx* ctx, const char* key, int64_t value)
     ctx->lx_min_nnz = value;
     return SPMV_HIP_OK;
   }
+  if (!strcmp(key, "xw_min_x_bytes")) {
+    SPMV_REQUIRE(value >= 0);
+    ctx->xw_min_x_bytes = value;
+    return SPMV_HIP_OK;
+  }
+  if (!strcmp(key, "xw_min_nnz")) {
+    SPMV_REQUIRE(value >= 0);
+    ctx->xw_min_nnz = value;
+    return SPMV_HIP_OK;
+  }
   if (!strcmp(key, "lat_min_nnz")) {
     SPMV_REQUIRE(value >= 0);
     ctx->lat_min_nnz = value;

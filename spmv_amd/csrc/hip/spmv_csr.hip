@@ -423,12 +423,17 @@ __global__ __launch_bounds__(kBlock) void csr_rowblock_lx_kernel(
 //   wrec    != nullptr: also the record of the DMA kernel (spmv_lxw.hip):
 //           span, piece list; stat[0] / stat[1] collect the largest entry count
 //           and piece count of a staged block
+//   xw      != 0: ONLY that record, in the XW layout (kXwRec ints: the windows
+//           themselves follow the piece list; at most kXwMaxWin of them) -- no
+//           16-bit indices, no register-kernel record (lidx, tab unused);
+//           stat[2] counts the staged blocks
 template <int ITEMS>
 __global__ __launch_bounds__(kBlock) void lx_build_kernel(
     int32_t num_rows, int32_t num_cols, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ colind, uint16_t* __restrict__ lidx,
     int32_t* __restrict__ tab, int num_row_blocks, int end_bit, int align,
-    int pad, int cap, int32_t* __restrict__ wrec, int32_t* __restrict__ stat)
+    int pad, int cap, int32_t* __restrict__ wrec, int32_t* __restrict__ stat,
+    int xw)
 {
   using Sort = hipcub::BlockRadixSort<int32_t, kBlock, ITEMS, int32_t>;
   using Scan = hipcub::BlockScan<int32_t, kBlock>;
@@ -448,7 +453,9 @@ __global__ __launch_bounds__(kBlock) void lx_build_kernel(
     const int nr = min(kRows, num_rows - r0);
     const int32_t a = rowptr[r0], b = rowptr[r0 + nr];
     const int cnt = b - a;
-    int32_t* wr = wrec ? wrec + (int64_t)rb * kLxwRec : nullptr;
+    int32_t* wr
+        = wrec ? wrec + (int64_t)rb * (xw ? kXwRec : kLxwRec) : nullptr;
+    const int max_win = xw ? kXwMaxWin : kLxMaxWin;
     __syncthreads(); // previous block done with the shared arrays
     if (wr && t == 0) {
       wr[0] = -1; // direct unless the analysis below succeeds
@@ -457,7 +464,7 @@ __global__ __launch_bounds__(kBlock) void lx_build_kernel(
       wr[3] = 0;
     }
     if (cnt > CAP) {
-      if (t == 0)
+      if (t == 0 && !xw)
         tab[(int64_t)rb * kLxRec] = -1;
       continue; // uniform
     }
@@ -485,9 +492,9 @@ __global__ __launch_bounds__(kBlock) void lx_build_kernel(
     }
     int32_t total_windows = 0;
     Scan(tmp.scan).InclusiveSum(flag, wid, total_windows);
-    if (total_windows > kLxMaxWin
+    if (total_windows > max_win
         || (cnt > 0 && s_key[cnt - 1] >= col_limit)) {
-      if (t == 0)
+      if (t == 0 && !xw)
         tab[(int64_t)rb * kLxRec] = -1;
       continue; // uniform (block-wide aggregate / shared value)
     }
@@ -516,24 +523,31 @@ __global__ __launch_bounds__(kBlock) void lx_build_kernel(
     }
     __syncthreads();
     if (s_direct) {
-      if (t == 0)
+      if (t == 0 && !xw)
         tab[(int64_t)rb * kLxRec] = -1;
       continue;
     }
+    if (!xw) {
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-      const int idx = t * ITEMS + i;
-      if (idx < cnt)
-        lidx[a + pos[i]]
-            = (uint16_t)(s_wo[wid[i] - 1] + (key[i] - s_ws[wid[i] - 1]));
+      for (int i = 0; i < ITEMS; ++i) {
+        const int idx = t * ITEMS + i;
+        if (idx < cnt)
+          lidx[a + pos[i]]
+              = (uint16_t)(s_wo[wid[i] - 1] + (key[i] - s_ws[wid[i] - 1]));
+      }
+      int32_t* rec = tab + (int64_t)rb * kLxRec;
+      if (t < total_windows)
+        rec[1 + t] = s_ws[t];
+      if (t <= total_windows)
+        rec[1 + kLxMaxWin + t] = s_wo[t];
+      if (t == 0)
+        rec[0] = total_windows;
+    } else if (t < kXwMaxWin) {
+      // the windows themselves: where window t + 1 starts, and what turns a
+      // column of window t into its staged position
+      wr[kXwFirst0 + t] = t + 1 < total_windows ? s_ws[t + 1] : INT32_MAX;
+      wr[kXwDelta0 + t] = t < total_windows ? s_wo[t] - s_ws[t] : 0;
     }
-    int32_t* rec = tab + (int64_t)rb * kLxRec;
-    if (t < total_windows)
-      rec[1 + t] = s_ws[t];
-    if (t <= total_windows)
-      rec[1 + kLxMaxWin + t] = s_wo[t];
-    if (t == 0)
-      rec[0] = total_windows;
     if (wr && t == 0) {
       // the staged buffer as DMA pieces of kLxwPiece elements: source column
       // of each (pad == kLxwPiece: windows start at piece boundaries)
@@ -548,6 +562,8 @@ __global__ __launch_bounds__(kBlock) void lx_build_kernel(
         atomicMax(&stat[0], cnt);
       if (np > *(volatile int*)&stat[1])
         atomicMax(&stat[1], np);
+      if (xw)
+        atomicAdd(&stat[2], 1); // (one per staged block, spread over the grid)
     }
   }
 }
@@ -667,6 +683,9 @@ int launch_rowblock_x(const spmv_hip_csr_plan* pl, hipStream_t st, int grid,
                       const TV* values, T alpha, const T* in, T beta, T* out,
                       DotOut dot)
 {
+  // (the plane-walk order does nothing for this kernel: one step of an XCD's
+  // workgroups streams more than its L2 holds -- 2.89 against 2.91 ms at
+  // 512^3, 0.217 against 0.198 at 216^3; profiles/r05_rowblock_walk.log)
   const RowBlockOrder ord = pl->row_block_order(nrb);
   if (ord.xcd_group > 0)
     hipLaunchKernelGGL((csr_rowblock_kernel<TV, T, CH, NT, ALIGNED, DOT, true>),
@@ -774,6 +793,14 @@ int launch_rowblock(const spmv_hip_csr_plan* pl, hipStream_t st,
 #undef SPMV_LX
     SPMV_CHECK_LAUNCH();
     return SPMV_HIP_OK;
+  }
+  // the caller's arrays as they are, x windows staged (spmv_lxw.hip, XW)
+  if (pl->xw && pl->xw_rec && al && aligned16(in)) {
+    if constexpr (sizeof(T) == 8)
+      return spmv_xw_run_f64(pl, st, rowptr, colind, values, alpha, in, beta,
+                             out, DOT ? dot : DotOut());
+    else
+      return spmv_xw_run_f32(pl, st, rowptr, colind, values, alpha, in, beta, out);
   }
 #define SPMV_RB(CH, NT, AL)                                                    \
   return launch_rowblock_x<T, T, CH, NT, AL, DOT>(pl, st, grid, nrb, rowptr,   \
@@ -884,6 +911,44 @@ int run_general(const spmv_hip_csr_plan* pl, hipStream_t st,
 }
 
 
+// Plane distance of a matrix on a 3-D grid that stays out of the lattice form
+// (its values, boundary rows or a permutation of the entries keep it there):
+// the farthest column above and below the diagonal in a row block in the middle
+// of the matrix, when the two agree (and are far enough to be planes); else 0.
+int64_t plane_distance(const spmv_hip_csr_plan* pl, const int32_t* rowptr,
+                       const int32_t* colind)
+{
+  const int nrb = (pl->num_rows + kRows - 1) / kRows;
+  const int mid = nrb / 2;
+  const int32_t r0 = mid * kRows;
+  const int nr = std::min(kRows, pl->num_rows - r0);
+  if (nr <= 0)
+    return 0;
+  std::vector<int32_t> rp(nr + 1), ci;
+  hipError_t em = hipMemcpy(rp.data(), rowptr + r0, sizeof(int32_t) * (nr + 1),
+                            hipMemcpyDeviceToHost);
+  const int64_t cnt = em == hipSuccess ? (int64_t)rp[nr] - rp[0] : 0;
+  if (cnt <= 0 || cnt > 65536) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  ci.resize((size_t)cnt);
+  em = hipMemcpy(ci.data(), colind + rp[0], sizeof(int32_t) * (size_t)cnt,
+                 hipMemcpyDeviceToHost);
+  if (em != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  int64_t up = 0, down = 0;
+  for (int i = 0; i < nr; ++i)
+    for (int32_t j = rp[i]; j < rp[i + 1]; ++j) {
+      const int64_t d = (int64_t)ci[(size_t)(j - rp[0])] - (r0 + i);
+      up = d > up ? d : up;
+      down = -d > down ? -d : down;
+    }
+  return (up == down && up >= 2 * kRows && up <= INT32_MAX) ? up : 0;
+}
+
 // Compact the indices of the non-empty rows on the device (plan time, once).
 int build_row_list(spmv_hip_csr_plan* pl, const int32_t* rowptr)
 {
@@ -933,6 +998,76 @@ void free_lx(spmv_hip_csr_plan* pl)
   pl->lxw_rec = nullptr;
   pl->lx = pl->lx_staged = pl->lx_blocks = 0;
   pl->lxw = pl->lxw_max_cnt = pl->lxw_max_pieces = 0;
+}
+
+void free_xw(spmv_hip_csr_plan* pl)
+{
+  (void)hipFree(pl->xw_rec);
+  pl->xw_rec = nullptr;
+  pl->xw = pl->xw_staged = pl->xw_max_cnt = pl->xw_max_pieces = 0;
+}
+
+// The XW records (spmv_lxw.hip): per row block its span, the DMA pieces of its
+// x windows and the windows themselves.  144 B per row block; the CSR arrays
+// stay the caller's.  Kept only if most blocks are staged.
+int build_xw(spmv_hip_csr_plan* pl, const int32_t* rowptr, const int32_t* colind)
+{
+  SPMV_CHECK_HIP(hipSetDevice(pl->ctx->device));
+  free_xw(pl);
+  const int nrb = (pl->num_rows + kRows - 1) / kRows;
+  if (nrb == 0 || pl->nnz == 0 || pl->num_cols < kLxwAlign)
+    return SPMV_HIP_OK;
+  hipStream_t st = pl->ctx->stream;
+  int32_t* d_stat = nullptr;
+  hipError_t e = hipMalloc(&pl->xw_rec, sizeof(int32_t) * (size_t)nrb * kXwRec);
+  if (e == hipSuccess)
+    e = hipMalloc(&d_stat, 3 * sizeof(int32_t));
+  if (e == hipSuccess)
+    e = hipMemsetAsync(d_stat, 0, 3 * sizeof(int32_t), st);
+  if (e == hipSuccess)
+    e = hipMemsetAsync(pl->xw_rec, 0, sizeof(int32_t) * (size_t)nrb * kXwRec, st);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(d_stat);
+    free_xw(pl);
+    return e == hipErrorOutOfMemory ? SPMV_HIP_OK : static_cast<int>(e);
+  }
+  int end_bit = 1;
+  while (end_bit < 31 && ((int64_t)1 << end_bit) < pl->num_cols)
+    ++end_bit;
+  int grid = pl->ctx->num_cus * 4;
+  grid = grid > nrb ? nrb : grid;
+  const double avg = (double)pl->nnz / pl->num_rows;
+  if (avg <= 6.0)
+    hipLaunchKernelGGL(lx_build_kernel<8>, dim3(grid), dim3(kBlock), 0, st,
+                       pl->num_rows, pl->num_cols, rowptr, colind, nullptr,
+                       nullptr, nrb, end_bit, kLxwAlign, kLxwPiece,
+                       kLxwMaxPieces * kLxwPiece, pl->xw_rec, d_stat, 1);
+  else
+    hipLaunchKernelGGL(lx_build_kernel<16>, dim3(grid), dim3(kBlock), 0, st,
+                       pl->num_rows, pl->num_cols, rowptr, colind, nullptr,
+                       nullptr, nrb, end_bit, kLxwAlign, kLxwPiece,
+                       kLxwMaxPieces * kLxwPiece, pl->xw_rec, d_stat, 1);
+  e = hipGetLastError();
+  int32_t h_stat[3] = {0, 0, 0};
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(h_stat, d_stat, sizeof(h_stat), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st);
+  (void)hipFree(d_stat);
+  if (e != hipSuccess) {
+    free_xw(pl);
+    return static_cast<int>(e);
+  }
+  pl->xw_max_cnt = h_stat[0];
+  pl->xw_max_pieces = h_stat[1];
+  pl->xw_staged = h_stat[2];
+  if ((int64_t)pl->xw_staged * 2 < nrb) { // mostly direct blocks: the gather kernel
+    free_xw(pl);
+    return SPMV_HIP_OK;
+  }
+  pl->xw = 1;
+  return SPMV_HIP_OK;
 }
 
 struct IsStagedRecord {
@@ -994,12 +1129,12 @@ int build_lx(spmv_hip_csr_plan* pl, const int32_t* rowptr,
     hipLaunchKernelGGL(lx_build_kernel<8>, dim3(grid), dim3(kBlock), 0, st,
                        pl->num_rows, pl->num_cols, rowptr, colind, pl->lx_lidx,
                        pl->lx_tab, nrb, end_bit, align, pad, cap, pl->lxw_rec,
-                       d_stat);
+                       d_stat, 0);
   else
     hipLaunchKernelGGL(lx_build_kernel<16>, dim3(grid), dim3(kBlock), 0, st,
                        pl->num_rows, pl->num_cols, rowptr, colind, pl->lx_lidx,
                        pl->lx_tab, nrb, end_bit, align, pad, cap, pl->lxw_rec,
-                       d_stat);
+                       d_stat, 0);
   e = hipGetLastError();
   int32_t h_stat[2] = {0, 0};
   if (dma && e == hipSuccess)
@@ -1056,33 +1191,14 @@ int build_lx(spmv_hip_csr_plan* pl, const int32_t* rowptr,
   // Plane distance = the farthest column above and below the diagonal in a
   // row block in the middle of the matrix, when the two agree.
   {
-    const int mid = nrb / 2;
-    const int32_t r0 = mid * kRows;
-    const int nr = std::min(kRows, pl->num_rows - r0);
-    std::vector<int32_t> rp(nr + 1), ci;
-    hipError_t em = hipMemcpy(rp.data(), rowptr + r0, sizeof(int32_t) * (nr + 1),
-                              hipMemcpyDeviceToHost);
-    const int64_t cnt = em == hipSuccess ? (int64_t)rp[nr] - rp[0] : 0;
-    if (cnt > 0 && cnt <= 65536) {
-      ci.resize((size_t)cnt);
-      em = hipMemcpy(ci.data(), colind + rp[0], sizeof(int32_t) * (size_t)cnt,
-                     hipMemcpyDeviceToHost);
-      int64_t up = 0, down = 0;
-      if (em == hipSuccess)
-        for (int i = 0; i < nr; ++i)
-          for (int32_t j = rp[i]; j < rp[i + 1]; ++j) {
-            const int64_t d = (int64_t)ci[(size_t)(j - rp[0])] - (r0 + i);
-            up = d > up ? d : up;
-            down = -d > down ? -d : down;
-          }
-      if (up == down && up >= 2 * kRows && up <= INT32_MAX) {
-        pl->lattice_d1 = 0;
-        pl->lattice_d2 = (int)up;
-        const int rc = spmv_zwalk_order_build(pl, pl->lattice_d2,
-                                              spmv_walk_grid(pl), 0, false);
-        if (rc != SPMV_HIP_OK)
-          return rc;
-      }
+    const int64_t d2 = plane_distance(pl, rowptr, colind);
+    if (d2 > 0) {
+      pl->lattice_d1 = 0;
+      pl->lattice_d2 = (int)d2;
+      const int rc = spmv_zwalk_order_build(pl, pl->lattice_d2,
+                                            spmv_walk_grid(pl), 0, false);
+      if (rc != SPMV_HIP_OK)
+        return rc;
     }
   }
   return SPMV_HIP_OK;
@@ -1161,7 +1277,9 @@ int spmv_walk_grid(const spmv_hip_csr_plan* pl)
     return spmv_slat_grid(pl);
   if (pl->lat_tab)
     return spmv_lat_grid(pl);
-  return (pl->lxw && pl->lxw_rec) ? spmv_lxw_grid(pl, 8) : rowblock_grid(pl);
+  if (pl->lxw && pl->lxw_rec)
+    return spmv_lxw_grid(pl, 8);
+  return (pl->xw && pl->xw_rec) ? spmv_xw_grid(pl, 8) : rowblock_grid(pl);
 }
 
 void spmv_zwalk_free(spmv_hip_csr_plan* pl)
@@ -1466,6 +1584,24 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
     // diagonal forms have refused the matrix (a 27-point stencil has 27
     // entries per row too, and its analysis would be 50 ms for nothing).
     pl->sj_wanted = !pl->lat && !pl->lx && num_non_zeros >= ctx->sj_min_nnz;
+    // Neither of them and no sliced jagged form to come: the caller's CSR
+    // arrays as they are.  From ctx->xw_min_nnz entries on the XW kernel
+    // (spmv_lxw.hip): values and the 32-bit column indices by LDS-DMA, the x
+    // windows of every row block staged -- the gather kernel fetched x across
+    // the fabric 3.5 times at 512^3 -- in the plane-walk order when the
+    // matrix sits on a 3-D grid.
+    if (rc == SPMV_HIP_OK && !pl->lat && !pl->lx && !pl->sj_wanted
+        && num_non_zeros >= ctx->xw_min_nnz && avg <= 16.0
+        && (int64_t)num_cols * 8 >= ctx->xw_min_x_bytes) {
+      rc = build_xw(pl, rowptr, colind);
+      if (rc == SPMV_HIP_OK && pl->xw) {
+        const int64_t d2 = plane_distance(pl, rowptr, colind);
+        if (d2 > 0) {
+          pl->lattice_d2 = (int)d2;
+          rc = spmv_zwalk_order_build(pl, d2, spmv_walk_grid(pl), 0, false);
+        }
+      }
+    }
     if (rc != SPMV_HIP_OK) {
       spmv_hip_csr_plan_destroy(pl);
       return rc;
@@ -1519,10 +1655,11 @@ int spmv_hip_csr_plan_destroy(spmv_hip_csr_plan* plan)
   if (plan
       && (plan->row_list || plan->lx_lidx || plan->lat_tab || plan->t_ptr
           || plan->slat_mask || plan->zw_table || plan->wdia_val
-          || plan->sdia_val || plan->sj_lenperm)) {
+          || plan->sdia_val || plan->sj_lenperm || plan->xw_rec)) {
     (void)hipSetDevice(plan->ctx->device);
     (void)hipFree(plan->row_list);
     free_lx(plan);
+    free_xw(plan);
     spmv_lat_free(plan);
     spmv_symt_free(plan);
     spmv_sdia_free(plan);
@@ -1765,7 +1902,8 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
   } else if (!strcmp(key, "blocks_per_cu")) {
     SPMV_REQUIRE(value >= 1 && value <= kBlocksPerCU);
     plan->blocks_per_cu = value;
-    if (plan->zw_table && plan->lx_lidx && !plan->lat_tab) // tied to the grid
+    if (plan->zw_table && !plan->lat_tab && !plan->symmetric
+        && !plan->sdia_val) // (LX or plain row blocks) tied to the grid
       return spmv_zwalk_order_build(plan, plan->zw_d2, spmv_walk_grid(plan), 0,
                                     true);
   } else if (!strcmp(key, "lx")) {
@@ -1779,10 +1917,18 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
     if (plan->zw_table && plan->lx_lidx && !plan->lat_tab) // another grid
       return spmv_zwalk_order_build(plan, plan->zw_d2, spmv_walk_grid(plan), 0,
                                     true);
+  } else if (!strcmp(key, "xw")) {
+    // the LDS-DMA kernel on the caller's CSR arrays (needs its records)
+    SPMV_REQUIRE(value == 0 || plan->xw_rec);
+    plan->xw = value != 0;
+    if (plan->zw_table && plan->xw_rec && !plan->lat_tab && !plan->lx_lidx)
+      return spmv_zwalk_order_build(plan, plan->zw_d2, spmv_walk_grid(plan), 0,
+                                    true);
   } else if (!strcmp(key, "lxw_blocks_per_cu")) {
     SPMV_REQUIRE(value >= 0 && value <= kBlocksPerCU);
     plan->lxw_blocks_per_cu = value;
-    if (plan->zw_table && plan->lxw_rec && plan->lxw && !plan->lat_tab)
+    if (plan->zw_table && !plan->lat_tab
+        && ((plan->lxw_rec && plan->lxw) || (plan->xw_rec && plan->xw)))
       return spmv_zwalk_order_build(plan, plan->zw_d2, spmv_walk_grid(plan), 0,
                                     true);
   } else if (!strcmp(key, "lx_chunks")) {
@@ -1899,9 +2045,7 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
   } else if (!strcmp(key, "zwalk_segments")) {
     // (re)build the plane-walk table of the plan's lattice kernel with `value`
     // runs along the plane axis (0 = choose), whatever the size
-    SPMV_REQUIRE(value >= 0
-                 && (plan->slat_mask || plan->lat_tab || plan->lx_lidx)
-                 && plan->zw_d2 > 0);
+    SPMV_REQUIRE(value >= 0 && plan->zw_d2 > 0);
     return spmv_zwalk_order_build(plan, plan->zw_d2, spmv_walk_grid(plan), value,
                                   true);
   } else if (!strcmp(key, "sym_det")) {
@@ -1998,6 +2142,10 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
     *value = plan->wdia && plan->wdia_val ? plan->wdia_hbox : 0;
   else if (!strcmp(key, "wdia_offsets"))
     *value = plan->wdia_val ? plan->wdia_K : 0;
+  else if (!strcmp(key, "xw"))
+    *value = plan->xw && plan->xw_rec ? 1 : 0;
+  else if (!strcmp(key, "xw_staged"))
+    *value = plan->xw_staged;
   else if (!strcmp(key, "plan_us"))
     *value = plan->plan_us;
   else if (!strcmp(key, "values_changed_us"))
@@ -2013,6 +2161,8 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
       b += 2 * (nnz + 8) + 4 * nrb * kLxRec;
     if (plan->lxw_rec)
       b += 4 * nrb * kLxwRec;
+    if (plan->xw_rec)
+      b += 4 * nrb * kXwRec;
     if (plan->lat_tab)
       b += 48 * nrb + n;
     if (plan->slat_mask)

@@ -62,10 +62,25 @@
 // instead of one (three value slots, 75 KiB per workgroup, still two per CU:
 // 2.51 against 2.54 ms at 512^3, 3 % slower at 128^3 and 384^3 -- the bytes a
 // workgroup has in flight are not what bounds the kernel either).
+//
+// XW variant (round 5): the same kernel on the CALLER's CSR arrays as they are.
+// The 16-bit offsets are a plan-owned copy of the index stream (2 B per entry
+// of plan memory, 10 B per entry streamed); the plain row-block kernel streams
+// the caller's arrays untouched but gathers x entry by entry -- at 512^3 x
+// crossed the fabric 3.5 times (15.6 GB read for 12.9 GB of matrix + x;
+// profiles/r04_pmc_csr_rowblock_spmv_*), and walking the row blocks plane by
+// plane does not help it: one step of an XCD's workgroups streams 6.8 MB
+// through its 4 MB L2 (2.89 against 2.91 ms, profiles/r05_rowblock_walk.log).
+// XW = true streams `colind` (32 bit) by LDS-DMA where the LX form streams its
+// offsets, stages the same x windows, and turns a column into its staged
+// position with the block's window list (at most eight windows: a select
+// chain on uniform registers; more windows: the block gathers).  Plan memory:
+// 144 B per row block.
 #include "csr_plan.h"
 #include "lat_dma.h"
 
 #include <new>
+#include <type_traits>
 
 namespace
 {
@@ -83,13 +98,14 @@ struct LxwBlock {
 // after the step's wait.  Not scalar loads: those share their counter with
 // the LDS reads, so the first LDS read of the row sums would wait for a
 // record coming from HBM -- 1-2 us per step.
+template <int REC>
 __device__ __forceinline__ int32_t lxw_fetch(int rb,
                                              const int32_t* __restrict__ rec)
 {
   int32_t w = 0;
   if (rb >= 0) {
     const int l = (int)(threadIdx.x & 63);
-    w = rec[(int64_t)rb * kLxwRec + (l < kLxwRec ? l : kLxwRec - 1)];
+    w = rec[(int64_t)rb * REC + (l < REC ? l : REC - 1)];
   }
   return w;
 }
@@ -146,7 +162,9 @@ __device__ __forceinline__ LxwRegs<T> lxw_loads(const LxwBlock& blk, int t,
 //          share a register: a table entry is a LOADED value, and the compiler
 //          waits for every load in flight -- the DMA pieces included -- before
 //          it lets the computed alternative overwrite that register.
-template <typename TV, typename T, bool DOT, bool NT, bool TAB>
+//   XW     the index stream is the caller's `colind` (lidx unused), the
+//          record is the XW one (kXwRec ints: windows behind the pieces)
+template <typename TV, typename T, bool DOT, bool NT, bool TAB, bool XW>
 __global__ __launch_bounds__(kBlock) void csr_lxw_kernel(
     int32_t num_rows, int32_t num_cols, int64_t nnz,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
@@ -155,16 +173,19 @@ __global__ __launch_bounds__(kBlock) void csr_lxw_kernel(
     T* __restrict__ out, DotOut dot, RowBlockOrder ord, int vcap, int lcap,
     int xcap)
 {
+  using IDX = typename std::conditional<XW, int32_t, uint16_t>::type;
+  constexpr int REC = XW ? kXwRec : kLxwRec;
+  constexpr int IA = 16 / (int)sizeof(IDX) - 1; // index chunk alignment mask
   constexpr int V = 16 / (int)sizeof(TV); // values per 16-byte chunk
   constexpr int E = 16 / (int)sizeof(T);  // x elements per 16-byte chunk
   // lanes of one DMA instruction that cover a piece of kLxwPiece elements
   constexpr int PL = kLxwPiece / E;       // 64 (fp64), 32 (fp32)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   TV* const s_val = reinterpret_cast<TV*>(smem);
-  uint16_t* const s_lidx
-      = reinterpret_cast<uint16_t*>(smem + 2 * (size_t)vcap * sizeof(TV));
+  IDX* const s_lidx
+      = reinterpret_cast<IDX*>(smem + 2 * (size_t)vcap * sizeof(TV));
   T* const s_x = reinterpret_cast<T*>(smem + 2 * (size_t)vcap * sizeof(TV)
-                                      + 2 * (size_t)lcap * sizeof(uint16_t));
+                                      + 2 * (size_t)lcap * sizeof(IDX));
   __shared__ double s_red[kBlock / 64];
 
   const int t = threadIdx.x;
@@ -178,7 +199,7 @@ __global__ __launch_bounds__(kBlock) void csr_lxw_kernel(
 
   // does the block's data sit in its LDS slots?
   auto fits = [&](const LxwBlock& b) {
-    return b.cnt + (b.a & (V - 1)) <= vcap && b.cnt + (b.a & 7) <= lcap;
+    return b.cnt + (b.a & (V - 1)) <= vcap && b.cnt + (b.a & IA) <= lcap;
   };
   // A wave's share of a block's piece list: pieces wave, wave + 4, ... as
   // UNIFORM values, extracted from the per-lane list right after a wait -- a
@@ -205,8 +226,12 @@ __global__ __launch_bounds__(kBlock) void csr_lxw_kernel(
                           s_val + (size_t)sl * vcap, t);
     if (b.nwin < 0)
       return;
-    lat_issue_dma<uint16_t, NT>(lidx, nnz + 8, a & ~(int64_t)7, e,
-                                s_lidx + (size_t)sl * lcap, t);
+    if constexpr (XW)
+      lat_issue_dma<int32_t, NT>(colind, nnz, a & ~(int64_t)IA, e,
+                                 s_lidx + (size_t)sl * lcap, t);
+    else
+      lat_issue_dma<uint16_t, NT>(lidx, nnz + 8, a & ~(int64_t)IA, e,
+                                  s_lidx + (size_t)sl * lcap, t);
     const unsigned lds0 = (unsigned)(uintptr_t)(
         (__attribute__((address_space(3))) void*)(s_x + (size_t)sl * xcap));
 #pragma unroll
@@ -229,12 +254,14 @@ __global__ __launch_bounds__(kBlock) void csr_lxw_kernel(
   LxwBlock cur;
   int nxt_rb;
   int32_t nxt_w; // the next block's record, in flight
+  int32_t cur_w0;
   {
     const int rb0 = order_slot_decode(ord, slot_raw(it));
     nxt_rb = order_slot_decode(ord, slot_raw(it + stride));
-    const int32_t w0 = lxw_fetch(rb0, rec);
-    nxt_w = lxw_fetch(nxt_rb, rec);
+    const int32_t w0 = lxw_fetch<REC>(rb0, rec);
+    nxt_w = lxw_fetch<REC>(nxt_rb, rec);
     cur = lxw_decode(rb0, w0);
+    cur_w0 = w0;
     issue(cur, pieces_of(w0), 0);
   }
   int nn_raw = slot_raw(it + 2 * stride);
@@ -249,6 +276,28 @@ __global__ __launch_bounds__(kBlock) void csr_lxw_kernel(
   T y_late = T(0);
   int32_t r_late = -1;
 
+  // XW: the current block's windows as uniform values (taken from its record
+  // right after a wait, like the piece list)
+  struct Windows {
+    int32_t f[kXwMaxWin]; // f[k]: first column of window k (f[0] unused)
+    int32_t d[kXwMaxWin];
+  };
+  auto windows_of = [&](int32_t w) {
+    Windows ws;
+#pragma unroll
+    for (int k = 0; k < kXwMaxWin; ++k) {
+      ws.f[k] = 0;
+      ws.d[k] = 0;
+      if constexpr (XW) {
+        if (k > 0)
+          ws.f[k] = __builtin_amdgcn_readlane(w, kXwFirst0 + k - 1);
+        ws.d[k] = __builtin_amdgcn_readlane(w, kXwDelta0 + k);
+      }
+    }
+    return ws;
+  };
+  Windows cur_ws = windows_of(cur_w0);
+
   auto step = [&](const LxwRegs<T>& g, LxwRegs<T>& gn) {
     // everything this wave has in flight has landed; after the barrier that
     // holds for all waves, and all of them have left the previous block (the
@@ -259,12 +308,13 @@ __global__ __launch_bounds__(kBlock) void csr_lxw_kernel(
       out[r_late] = y_late;
     r_late = -1;
     const LxwBlock nxt = lxw_decode(nxt_rb, nxt_w);
+    const Windows nxt_ws = windows_of(nxt_w);
     issue(nxt, pieces_of(nxt_w), slot ^ 1);
     gn = lxw_loads<T, DOT>(nxt, t, num_rows, rowptr, in, beta, out);
     // the block after the next one: its table entry has landed with the wait
     // above; its record is needed a step from now
     const int nn_rb = order_slot_decode(ord, nn_raw);
-    const int32_t nn_w = lxw_fetch(nn_rb, rec);
+    const int32_t nn_w = lxw_fetch<REC>(nn_rb, rec);
     const int nnn_raw = slot_raw(it + 3 * stride);
 
     const int32_t r = cur.rb * kRows + t;
@@ -276,7 +326,7 @@ __global__ __launch_bounds__(kBlock) void csr_lxw_kernel(
         // index by the entry's position in `values`
         const TV* sv = s_val + (size_t)slot * vcap + (cur.a & (V - 1)) - cur.a;
         if (cur.nwin >= 0) {
-          const uint16_t* sl = s_lidx + (size_t)slot * lcap + (cur.a & 7) - cur.a;
+          const IDX* sl = s_lidx + (size_t)slot * lcap + (cur.a & IA) - cur.a;
           const T* sx = s_x + (size_t)slot * xcap;
           // eight entries' LDS reads in flight (offsets, then values and x:
           // two round trips per eight entries), adds strictly left to right;
@@ -289,6 +339,19 @@ __global__ __launch_bounds__(kBlock) void csr_lxw_kernel(
               const int32_t jj = j + k < hi ? j + k : hi - 1;
               l[k] = sl[jj];
               v[k] = (T)sv[jj];
+            }
+            if constexpr (XW) {
+              // column -> staged position: + the delta of the last window
+              // that starts at or below it (windows ascend)
+#pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                const int32_t c = (int32_t)l[k];
+                int32_t d = cur_ws.d[0];
+#pragma unroll
+                for (int q = 1; q < kXwMaxWin; ++q)
+                  d = c >= cur_ws.f[q] ? cur_ws.d[q] : d;
+                l[k] = (unsigned)(c + d);
+              }
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k)
@@ -317,6 +380,7 @@ __global__ __launch_bounds__(kBlock) void csr_lxw_kernel(
     }
     slot ^= 1;
     cur = nxt;
+    cur_ws = nxt_ws;
     nxt_rb = nn_rb;
     nxt_w = nn_w;
     nn_raw = nnn_raw;
@@ -341,18 +405,22 @@ struct LxwGeom {
   int per_cu;
 };
 
-LxwGeom lxw_geom(const spmv_hip_csr_plan* pl, int elem_bytes)
+// idx_bytes: 2 (the LX form's offsets) or 4 (XW: the caller's column indices)
+LxwGeom lxw_geom(const spmv_hip_csr_plan* pl, int elem_bytes, int idx_bytes)
 {
   LxwGeom g;
+  const bool xw = idx_bytes == 4;
   const int V = 16 / elem_bytes;
+  const int max_cnt = xw ? pl->xw_max_cnt : pl->lxw_max_cnt;
   // slot for the largest staged block plus the slack of the 16-byte alignment
   // of its first chunk, in whole 1-KiB DMA pieces; at most 32 KiB
-  int64_t vb = ((int64_t)(pl->lxw_max_cnt + V) * elem_bytes + 1023) & ~1023ll;
+  int64_t vb = ((int64_t)(max_cnt + V) * elem_bytes + 1023) & ~1023ll;
   vb = vb < 1024 ? 1024 : (vb > 32768 ? 32768 : vb);
   g.vcap = (int)(vb / elem_bytes);
-  int64_t lb = ((int64_t)(g.vcap + 8) * 2 + 1023) & ~1023ll;
-  g.lcap = (int)(lb / 2);
-  int np = pl->lxw_max_pieces < 1 ? 1 : pl->lxw_max_pieces;
+  int64_t lb = ((int64_t)(g.vcap + 8) * idx_bytes + 1023) & ~1023ll;
+  g.lcap = (int)(lb / idx_bytes);
+  int np = xw ? pl->xw_max_pieces : pl->lxw_max_pieces;
+  np = np < 1 ? 1 : np;
   g.xcap = np * kLxwPiece;
   g.lds = 2 * (size_t)vb + 2 * (size_t)lb + 2 * (size_t)g.xcap * elem_bytes;
   int per = (int)((160 * 1024 - 1024) / (g.lds + 64));
@@ -363,42 +431,9 @@ LxwGeom lxw_geom(const spmv_hip_csr_plan* pl, int elem_bytes)
   return g;
 }
 
-template <typename TV, typename T, bool DOT>
-int lxw_launch(const spmv_hip_csr_plan* pl, hipStream_t st,
-               const int32_t* rowptr, const int32_t* colind, const TV* values,
-               T alpha, const T* in, T beta, T* out, DotOut dot)
+int lxw_grid(const spmv_hip_csr_plan* pl, int elem_bytes, int idx_bytes)
 {
-  const LxwGeom g = lxw_geom(pl, (int)sizeof(T));
-  const int nrb = (pl->num_rows + kRows - 1) / kRows;
-  const int grid = spmv_lxw_grid(pl, (int)sizeof(T));
-  RowBlockOrder ord = pl->row_block_order(nrb);
-  ord.xcd_group = pl->lat_xcd_group;
-  if (pl->zwalk && pl->zw_table && pl->zw_grid == grid) {
-    ord.table = pl->zw_table;
-    ord.num_slots = pl->zw_slots;
-  }
-  auto kern = ord.table
-                  ? (pl->nontemporal ? csr_lxw_kernel<TV, T, DOT, true, true>
-                                     : csr_lxw_kernel<TV, T, DOT, false, true>)
-                  : (pl->nontemporal ? csr_lxw_kernel<TV, T, DOT, true, false>
-                                     : csr_lxw_kernel<TV, T, DOT, false, false>);
-  if (g.lds > 48 * 1024) // beyond the default dynamic-LDS limit
-    SPMV_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(kern),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), g.lds, st, pl->num_rows,
-                     pl->num_cols, pl->nnz, rowptr, colind, values, pl->lx_lidx,
-                     pl->lxw_rec, alpha, in, beta, out, dot, ord, g.vcap, g.lcap,
-                     g.xcap);
-  SPMV_CHECK_LAUNCH();
-  return SPMV_HIP_OK;
-}
-
-} // namespace
-
-int spmv_lxw_grid(const spmv_hip_csr_plan* pl, int elem_bytes)
-{
-  const LxwGeom g = lxw_geom(pl, elem_bytes);
+  const LxwGeom g = lxw_geom(pl, elem_bytes, idx_bytes);
   const int nrb = (pl->num_rows + kRows - 1) / kRows;
   int grid = pl->ctx->num_cus * g.per_cu;
   if (grid > pl->ctx->dot_blocks)
@@ -412,16 +447,60 @@ int spmv_lxw_grid(const spmv_hip_csr_plan* pl, int elem_bytes)
   return grid;
 }
 
+template <typename TV, typename T, bool DOT, bool XW>
+int lxw_launch(const spmv_hip_csr_plan* pl, hipStream_t st,
+               const int32_t* rowptr, const int32_t* colind, const TV* values,
+               T alpha, const T* in, T beta, T* out, DotOut dot)
+{
+  const LxwGeom g = lxw_geom(pl, (int)sizeof(T), XW ? 4 : 2);
+  const int nrb = (pl->num_rows + kRows - 1) / kRows;
+  const int grid = lxw_grid(pl, (int)sizeof(T), XW ? 4 : 2);
+  RowBlockOrder ord = pl->row_block_order(nrb);
+  ord.xcd_group = pl->lat_xcd_group;
+  if (pl->zwalk && pl->zw_table && pl->zw_grid == grid) {
+    ord.table = pl->zw_table;
+    ord.num_slots = pl->zw_slots;
+  }
+  auto kern
+      = ord.table
+            ? (pl->nontemporal ? csr_lxw_kernel<TV, T, DOT, true, true, XW>
+                               : csr_lxw_kernel<TV, T, DOT, false, true, XW>)
+            : (pl->nontemporal ? csr_lxw_kernel<TV, T, DOT, true, false, XW>
+                               : csr_lxw_kernel<TV, T, DOT, false, false, XW>);
+  if (g.lds > 48 * 1024) // beyond the default dynamic-LDS limit
+    SPMV_CHECK_HIP(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(kern),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), g.lds, st, pl->num_rows,
+                     pl->num_cols, pl->nnz, rowptr, colind, values,
+                     XW ? nullptr : pl->lx_lidx, XW ? pl->xw_rec : pl->lxw_rec,
+                     alpha, in, beta, out, dot, ord, g.vcap, g.lcap, g.xcap);
+  SPMV_CHECK_LAUNCH();
+  return SPMV_HIP_OK;
+}
+
+} // namespace
+
+int spmv_lxw_grid(const spmv_hip_csr_plan* pl, int elem_bytes)
+{
+  return lxw_grid(pl, elem_bytes, 2);
+}
+
+int spmv_xw_grid(const spmv_hip_csr_plan* pl, int elem_bytes)
+{
+  return lxw_grid(pl, elem_bytes, 4);
+}
+
 int spmv_lxw_run_f64(const spmv_hip_csr_plan* pl, hipStream_t st,
                      const int32_t* rowptr, const int32_t* colind,
                      const double* values, double alpha, const double* in,
                      double beta, double* out, DotOut dot)
 {
   if (dot.partials)
-    return lxw_launch<double, double, true>(pl, st, rowptr, colind, values,
-                                            alpha, in, beta, out, dot);
-  return lxw_launch<double, double, false>(pl, st, rowptr, colind, values, alpha,
-                                           in, beta, out, dot);
+    return lxw_launch<double, double, true, false>(pl, st, rowptr, colind, values,
+                                                   alpha, in, beta, out, dot);
+  return lxw_launch<double, double, false, false>(pl, st, rowptr, colind, values,
+                                                  alpha, in, beta, out, dot);
 }
 
 int spmv_lxw_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st,
@@ -429,6 +508,27 @@ int spmv_lxw_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st,
                      const float* values, float alpha, const float* in,
                      float beta, float* out)
 {
-  return lxw_launch<float, float, false>(pl, st, rowptr, colind, values, alpha,
-                                         in, beta, out, DotOut());
+  return lxw_launch<float, float, false, false>(pl, st, rowptr, colind, values,
+                                                alpha, in, beta, out, DotOut());
+}
+
+int spmv_xw_run_f64(const spmv_hip_csr_plan* pl, hipStream_t st,
+                    const int32_t* rowptr, const int32_t* colind,
+                    const double* values, double alpha, const double* in,
+                    double beta, double* out, DotOut dot)
+{
+  if (dot.partials)
+    return lxw_launch<double, double, true, true>(pl, st, rowptr, colind, values,
+                                                  alpha, in, beta, out, dot);
+  return lxw_launch<double, double, false, true>(pl, st, rowptr, colind, values,
+                                                 alpha, in, beta, out, dot);
+}
+
+int spmv_xw_run_f32(const spmv_hip_csr_plan* pl, hipStream_t st,
+                    const int32_t* rowptr, const int32_t* colind,
+                    const float* values, float alpha, const float* in,
+                    float beta, float* out)
+{
+  return lxw_launch<float, float, false, true>(pl, st, rowptr, colind, values,
+                                               alpha, in, beta, out, DotOut());
 }

@@ -140,11 +140,18 @@ def test_bench_single_gpu_line(tmp_path):
     assert ns["form"]["sdia"] == 1 and "full" in ns["kernel"]
     assert d["north_star_spmv"]["form"]["lat"] == 1
     # the kernels of matrices WITHOUT lattice structure, measured and checked
-    assert d["csr_rowblock_spmv"]["form"] == dict(lat=0, lx=0, lxw=0, sjds=0,
-                                                  sym_sj=0, wdia=0, wdia_const=0,
-                                                  wdia_hbox=0, slat=0,
-                                                  sdia=0, sdia_const=0, sym_det=0,
-                                                  zwalk=0)
+    # the caller's CSR arrays as they are: the gather kernel, and (from 2^20
+    # entries on -- 64^3 has more) the XW kernel with the x windows staged
+    assert d["csr_gather_spmv"]["form"] == dict(lat=0, lx=0, lxw=0, xw=0, sjds=0,
+                                                sym_sj=0, wdia=0, wdia_const=0,
+                                                wdia_hbox=0, slat=0,
+                                                sdia=0, sdia_const=0, sym_det=0,
+                                                zwalk=0)
+    assert "csr_rowblock_kernel" in d["csr_gather_spmv"]["kernel"]
+    # (XW only where x outgrows the caches: not at this test's 64^3)
+    rbf = d["csr_rowblock_spmv"]["form"]
+    assert rbf["xw"] == 0 and rbf["lx"] == 0 and rbf["sjds"] == 0 and rbf["lat"] == 0
+    assert len(lr["csr_rowblock"]) == 3 and len(lr["csr_gather"]) == 3
     assert d["csr_sjds_spmv"]["form"]["sjds"] == 1
     # the general-CSR line inside `roofline` (the block the driver keeps): the
     # AUTO plan without the lattice analysis, same CG loop, SURVEY 8d's bytes

@@ -1782,6 +1782,179 @@ def test_lx_fuzz_banded(lx_ctx):
 
 
 # ---------------------------------------------------------------------------
+# XW: the LDS-DMA kernel on the CALLER's CSR arrays (32-bit column indices
+# streamed as they are, x windows staged; spmv_lxw.hip) -- what a plan without
+# lattice / LX / sliced jagged form runs instead of the gather kernel
+# ---------------------------------------------------------------------------
+@pytest.fixture()
+def xw_ctx():
+    c = hip.Context(0)
+    c.set_option("lx_min_nnz", 1 << 62)  # no LX form: the arrays stay the caller's
+    c.set_option("lat_min_nnz", 1 << 62)
+    c.set_option("sj_min_nnz", 1 << 62)
+    c.set_option("xw_min_nnz", 0)
+    c.set_option("xw_min_x_bytes", 0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_xw_kernel_on_the_callers_arrays_bit_exact(xw_ctx, dtype):
+    """Poisson grids (3 windows per row block), a banded matrix with far blocks
+    and two row blocks of scattered columns (those gather), a tridiagonal matrix
+    with an odd column count (the blocks at the end of x gather), a matrix whose
+    row blocks need MORE than four windows (they gather): every alpha / beta,
+    non-temporal loads on / off, the fused dot -- the oracle's bits, and the
+    plain gather kernel on the same plan (xw = 0) too."""
+    ctx = xw_ctx
+    rng = np.random.default_rng(177)
+    cases = []
+    for n in (16, 20, 33):
+        rp, ci, va = poisson.poisson3d_csr(n)
+        cases.append((f"poisson{n}", rp, ci.astype(np.int32), va, n ** 3, n ** 3))
+    rp, ci, va = _banded_mixed(rng, 5000)
+    cases.append(("banded_mixed", rp, ci, va, 5000, 5000))
+    rp, ci, va = oracle.tridiag_csr(70001)
+    cases.append(("tridiag", rp, ci, va, 70001, 70001))
+    # the diagonal and eight far bands, at most eight windows per row block
+    # (staged) -- but for eight row blocks with a ninth band (those gather)
+    N6 = 40000
+    offs6 = [0] + [s * d for d in (3000, 6000, 9000, 20000) for s in (-1, 1)]
+    rp, ci, va = _stencil_csr(rng, N6, offs6, drop=0.2)
+    extra = np.arange(10240, 12288)
+    rows = np.concatenate([np.repeat(np.arange(N6), np.diff(rp)), extra])
+    cols = np.concatenate([ci, extra + 15000]).astype(np.int32)
+    order = np.lexsort((cols, rows))
+    rp = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=N6))]
+                        ).astype(np.int32)
+    ci, va = cols[order], rng.uniform(-1, 1, len(cols))
+    cases.append(("many_windows", rp, ci, va, N6, N6))
+    # ... and bands every 1200 columns: more than eight windows everywhere
+    offs9 = [0] + [s * 1200 * k for k in range(1, 12) for s in (-1, 1)]
+    rp, ci, va = _stencil_csr(rng, N6, offs9, drop=0.2)
+    cases.append(("too_many_windows", rp, ci, va, N6, N6))
+    for name, rp, ci, va, nrows, ncols in cases:
+        va = va.astype(dtype)
+        x = rng.uniform(-1, 1, ncols).astype(dtype)
+        y0 = rng.uniform(-1, 1, nrows).astype(dtype)
+        blk = hip.CsrBlock(ctx, nrows, ncols, rp, ci, va, None, False,
+                           hip.ALGO_ROWBLOCK, dtype)
+        nrb = (nrows + 255) // 256
+        assert blk.get("lx") == 0 and blk.get("lat") == 0 and blk.get("sjds") == 0
+        if name == "too_many_windows":
+            # every row block would gather: the records are dropped
+            assert blk.get("xw") == 0, name
+            blk.free()
+            continue
+        assert blk.get("xw") == 1, name
+        if name in ("banded_mixed", "many_windows"):
+            assert 0 < blk.get("xw_staged") < nrb
+        else:
+            assert nrb - blk.get("xw_staged") <= (0 if ncols % 4 == 0 else 3)
+        assert blk.get("plan_kib") <= (nrb * 144 + 4 * 2048 * 512) // 1024 + 2
+        dx = ctx.upload(x, dtype)
+        part = ctx.empty(ctx.dot_partials_len, np.float64)
+        for alpha, beta in ((1.0, 0.0), (-0.5, 0.0), (2.0, 1.0), (1.0, -0.25)):
+            y_ref = oracle.csr_spmv(rp, ci, va, x, alpha, beta, y0)  # f32-aware
+            for nt in (0, 1):
+                blk.set("nontemporal", nt)
+                for xw in (1, 0):
+                    blk.set("xw", xw)
+                    dy = ctx.upload(np.full(nrows, np.nan, dtype) if beta == 0
+                                    else y0, dtype)
+                    dot = dtype == np.float64 and beta == 0 and nrows == ncols
+                    blk.mult(alpha, dx.ptr, beta, dy.ptr,
+                             dot_partials=part.ptr if dot else None)
+                    y = dy.numpy()
+                    dy.free()
+                    assert np.array_equal(y, y_ref), (name, alpha, beta, nt, xw)
+                    if dot:
+                        want = float(np.dot(x.astype(np.float64), y_ref))
+                        got = float(np.sum(part.numpy()))
+                        assert abs(got - want) <= 1e-12 * (np.abs(x) @ np.abs(y_ref))
+            blk.set("xw", 1)
+        for b in (dx, part):
+            b.free()
+        blk.free()
+
+
+@pytest.mark.parametrize("n", [32, 33, 48])
+def test_xw_plane_walk_bit_exact(xw_ctx, n):
+    """The XW kernel on 3-D grids in the plane-walk order (forced tables with
+    1-3 runs, table off, one workgroup per CU) -- random values, a third of the
+    entries dropped.  Same bits as the oracle."""
+    ctx = xw_ctx
+    rng = np.random.default_rng(900 + n)
+    N = n ** 3
+    offs = [-n * n, -n, -1, 0, 1, n, n * n]
+    for drop in (0.0, 0.3):
+        rp, ci, va = _stencil_csr(rng, N, offs, drop=drop)
+        x = rng.uniform(-1, 1, N)
+        y0 = rng.uniform(-1, 1, N)
+        blk = hip.CsrBlock(ctx, N, N, rp, ci, va, None, False, hip.ALGO_ROWBLOCK)
+        assert blk.get("xw") == 1 and blk.get("lx") == 0 and blk.get("lat") == 0
+        assert blk.get("lattice_d2") == n * n
+        dx = ctx.upload(x)
+        for alpha, beta in ((1.0, 0.0), (-0.5, 0.75)):
+            y_ref = oracle.csr_spmv(rp, ci, va, x, alpha, beta, y0)
+            for knobs in (dict(), dict(zwalk_segments=1), dict(zwalk_segments=2),
+                          dict(zwalk_segments=3), dict(zwalk=0),
+                          dict(zwalk=1, lxw_blocks_per_cu=1),
+                          dict(lxw_blocks_per_cu=0), dict(xw=0), dict(xw=1)):
+                for k, v in knobs.items():
+                    blk.set(k, v)
+                dy = ctx.upload(np.full(N, np.nan) if beta == 0 else y0)
+                blk.mult(alpha, dx.ptr, beta, dy.ptr)
+                assert np.array_equal(dy.numpy(), y_ref), (n, drop, alpha, knobs)
+                dy.free()
+        dx.free()
+        blk.free()
+
+
+def test_xw_fuzz_banded(xw_ctx):
+    """Random banded matrices through the XW kernel: empty rows, empty row
+    blocks, ragged last block, repeated and unsorted columns, a row too long
+    for the plan kernel, bands too wide to stage, rectangular blocks."""
+    ctx = xw_ctx
+    rng = np.random.default_rng(int(os.environ.get("SPMV_FUZZ_SEED", str(0x2F))))
+    seen_xw = 0
+    for case in range(int(os.environ.get("SPMV_FUZZ_TRIALS", "24"))):
+        nrows = int(rng.choice([1, 255, 256, 257, 700, 3001]))
+        ncols = nrows + int(rng.integers(0, 50))
+        half = int(rng.choice([3, 40, 200, 900, 4000]))
+        lens = rng.poisson(float(rng.choice([1.0, 4.0, 9.0])), nrows)
+        lens[rng.random(nrows) < float(rng.choice([0.0, 0.3]))] = 0
+        if case % 5 == 0 and nrows > 600:
+            lens[256:512] = 0
+        if case % 7 == 0 and nrows > 300:
+            lens[rng.integers(0, nrows)] = 5000
+        rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        rows = np.repeat(np.arange(nrows), lens)
+        ci = np.clip(rows + rng.integers(-half, half + 1, len(rows)), 0,
+                     ncols - 1).astype(np.int32)
+        va = rng.uniform(-1, 1, len(ci))
+        x = rng.uniform(-1, 1, ncols)
+        y0 = rng.uniform(-1, 1, nrows)
+        if len(ci) == 0:
+            continue
+        blk = hip.CsrBlock(ctx, nrows, ncols, rp, ci, va, None, False,
+                           hip.ALGO_ROWBLOCK)
+        seen_xw += blk.get("xw")
+        dx = ctx.upload(x)
+        for alpha, beta in ((1.0, 0.0), (0.5, -1.0)):
+            y_ref = oracle.csr_spmv(rp, ci, va, x, alpha, beta, y0)
+            dy = ctx.upload(np.full(nrows, np.nan) if beta == 0 else y0)
+            blk.mult(alpha, dx.ptr, beta, dy.ptr)
+            assert np.array_equal(dy.numpy(), y_ref), (case, nrows, half,
+                                                       blk.get("xw"),
+                                                       blk.get("xw_staged"))
+            dy.free()
+        dx.free()
+        blk.free()
+    assert seen_xw > 0
+
+
+# ---------------------------------------------------------------------------
 # Lattice form (spmv_lat.hip): constant column offsets per row block, values by
 # LDS-DMA one row block ahead, no index stream.  Same bits as the oracle.
 # ---------------------------------------------------------------------------

@@ -763,6 +763,15 @@ def test_full_size_kernels_agree_bit_for_bit(exec_, comm, n):
             _lib.call("spmv_hip_fill_const_f64", ctx, N, float("nan"), d_y, None)
             B.mult(d_x, d_y)
             assert np.array_equal(exec_.copy_to_host(d_y, N), y_dia), name
+            if name == "rowblock":
+                # that was the XW kernel (the caller's arrays, x windows
+                # staged, plane-walk order); the gather kernel on the same plan
+                assert B.plan_get("xw") == 1 and B.plan_get("zwalk") == 1
+                B.plan_set("xw", 0)
+                _lib.call("spmv_hip_fill_const_f64", ctx, N, float("nan"), d_y,
+                          None)
+                B.mult(d_x, d_y)
+                assert np.array_equal(exec_.copy_to_host(d_y, N), y_dia), "gather"
             B.close()
     exec_.free(d_x), exec_.free(d_y)
 
@@ -784,8 +793,9 @@ def test_spmv_512_cubed_against_the_oracle_itself(exec_, comm):
     is summed left to right whatever the thread count), symmetric storage
     against the sequential oracle.csr_spmv_sym (csr_kernels.cpp:26-40) -- the
     default plans (constant diagonals) and, for general storage, the plan a
-    matrix without lattice structure gets (LX) and the plain row-block kernel
-    that streams the caller's CSR arrays.  Bit for bit."""
+    matrix without lattice structure gets (LX) and the two kernels that stream
+    the caller's CSR arrays as they are (XW: x windows staged; the gather
+    kernel).  Bit for bit."""
     avail = _mem_available_gb()
     if avail < 40:
         pytest.skip(f"MemAvailable is {avail:.0f} GB: the host copy of the 512^3 "
@@ -824,6 +834,10 @@ def test_spmv_512_cubed_against_the_oracle_itself(exec_, comm):
         for key, want in form.items():
             assert B.plan_get(key) == want, (name, key)
         assert np.array_equal(product(B), y_ref), name
+        if name == "rowblock":  # that was the XW kernel; now the gather kernel
+            assert B.plan_get("xw") == 1
+            B.plan_set("xw", 0)
+            assert np.array_equal(product(B), y_ref), "gather"
         B.close()
     del y_ref
 
@@ -846,7 +860,9 @@ def _with_ctx_options(exec_, opts, fn):
     """run fn() with context options set, restore the defaults afterwards"""
     from spmv_amd import _lib
     defaults = {b"lat_min_nnz": 1 << 20, b"lx_min_nnz": 1 << 20,
-                b"sj_min_nnz": 1 << 20, b"poisson_stencil": 7, b"bake_general": 1}
+                b"sj_min_nnz": 1 << 20, b"xw_min_nnz": 1 << 20,
+                b"xw_min_x_bytes": 128 << 20,
+                b"poisson_stencil": 7, b"bake_general": 1}
     for k, v in opts.items():
         _lib.call("spmv_hip_ctx_set_option", exec_.context, k, v)
     try:
@@ -867,6 +883,7 @@ def test_spmv_production_size_csr_order_kernels(exec_, comm, form):
         opts[b"lx_min_nnz"] = 1 << 62
     if form == "rowblock":
         opts[b"sj_min_nnz"] = 1 << 62
+        opts[b"xw_min_x_bytes"] = 0  # (by default only where x outgrows the caches)
     for n in (128, 216):
         N = n ** 3
         rp, ci, va = oracle.poisson3d(n)
@@ -884,6 +901,14 @@ def test_spmv_production_size_csr_order_kernels(exec_, comm, form):
         A.col_map().update(d_x)
         A.mult(d_x, d_y)
         assert np.array_equal(exec_.copy_to_host(d_y, N), y_ref), (form, n)
+        # the caller's arrays as they are: the XW kernel (x windows staged) is
+        # the plan's choice, the gather kernel the same plan's fallback
+        assert A.plan_get("xw") == (1 if form == "rowblock" else 0)
+        if form == "rowblock":
+            A.plan_set("xw", 0)
+            exec_.memset(d_y, 0xFF, 8 * N)
+            A.mult(d_x, d_y)
+            assert np.array_equal(exec_.copy_to_host(d_y, N), y_ref), ("gather", n)
         A.close()
         exec_.free(d_x), exec_.free(d_y)
 

@@ -21,7 +21,9 @@ run symmetric_value_stream_spmv 512 tools/prof_spmv.py --n 512 --reps 6 --symmet
 run csr_nonsymmetric_spmv 512 tools/prof_spmv.py --n 512 --reps 6 --asym
 run csr_lattice_spmv 512 tools/prof_spmv.py --n 512 --reps 6 --no-bake
 run csr_lx_spmv 512 tools/prof_spmv.py --n 512 --reps 6 --no-lat
-run csr_rowblock_spmv 512 tools/prof_spmv.py --n 512 --reps 6 --no-lx
+OFF=4611686018427387904
+run csr_rowblock_spmv 512 tools/prof_spmv.py --n 512 --reps 6 --no-lx --ctx sj_min_nnz=$OFF
+run csr_gather_spmv 512 tools/prof_spmv.py --n 512 --reps 6 --no-lx --ctx sj_min_nnz=$OFF xw_min_nnz=$OFF
 run stencil27_spmv 256 tools/prof_matrix.py --kind stencil27 --n 256
 run stencil27_value_stream_spmv 256 tools/prof_matrix.py --kind stencil27 --n 256 --set const_diagonals=0
 run unstructured_spmv 10000000 tools/prof_matrix.py --kind unstructured --rows 10000000
@@ -29,6 +31,7 @@ run fem_spmv 10000000 tools/prof_matrix.py --kind fem --rows 10000000
 run fem_tail_spmv 10000000 tools/prof_matrix.py --kind fem_tail --rows 10000000
 run fem81_spmv 10000000 tools/prof_matrix.py --kind fem81 --rows 10000000
 run fem_sym_spmv 10000000 tools/prof_matrix.py --kind fem_sym --rows 10000000
+run fem_tail_sym_spmv 10000000 tools/prof_matrix.py --kind fem_tail_sym --rows 10000000
 run csr_order 512 tools/prof_spmv.py --n 512 --reps 6 --no-lat --dot
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/rp_$R

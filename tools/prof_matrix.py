@@ -15,7 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--kind", default="unstructured",
                     choices=["unstructured", "stencil27", "fem", "fem_tail",
-                             "fem81", "fem_sym"])
+                             "fem81", "fem_sym", "fem_tail_sym"])
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--n", type=int, default=256)
     ap.add_argument("--reps", type=int, default=6)
@@ -33,7 +33,8 @@ def main():
     elif args.kind.startswith("fem"):
         kw = {"fem": dict(), "fem_tail": dict(tail_permille=10),
               "fem81": dict(min_len=81, max_len=81),
-              "fem_sym": dict(symmetric=True)}[args.kind]
+              "fem_sym": dict(symmetric=True),
+              "fem_tail_sym": dict(symmetric=True, tail_permille=10)}[args.kind]
         A = host.Matrix.create_fem_like(comm, exec_, args.rows, **kw)
         N = args.rows
     else:
