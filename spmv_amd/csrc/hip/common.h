@@ -68,10 +68,14 @@ struct spmv_hip_ctx {
   // blocks of 16 slices sorted by length across the block, two slices per wave
   // ("sj_sigma"; 0: every slice sorted for itself, one slice per wave)
   int sj_sigma = 1;
-  // symmetric storage takes the sliced jagged form only while the long rows
-  // of its two blocks (which stay inside the slices there) hold at most this
-  // share of the entries ("sym_sj_long_permille")
+  // symmetric storage takes the sliced jagged form only while the long
+  // COLUMNS of the stored lower block (rows of the merged matrix: they stay
+  // inside the slices) hold at most this share of the entries
+  // ("sym_sj_long_permille")
   int sym_sj_long_permille = 50;
+  // ... its long ROWS go to the long-row kernels ("sym_sj_long_rows"; 0: they
+  // stay inside the slices too and count against the share above)
+  int sym_sj_long_rows = 1;
   // one-sided halo: how long a put kernel polls for its neighbour before the
   // exchange fails with SPMV_HIP_EPEER ("put_timeout_ms")
   int put_timeout_ms = 60000;

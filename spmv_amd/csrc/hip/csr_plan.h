@@ -539,8 +539,9 @@ int spmv_sjds_bake_f32(spmv_hip_csr_plan* pl, const float* values, const int32_t
 int spmv_sjds_bake_f32f64(spmv_hip_csr_plan* pl, const float* values32, hipStream_t st);
 int spmv_sjds_run_f32f64(const spmv_hip_csr_plan* pl, hipStream_t st, double alpha,
                          const double* in, double beta, double* out, DotOut dot);
-int spmv_sjds_sym_merge(const spmv_hip_csr_plan* pl, int32_t** vptr, int32_t** vcol,
-                        int32_t** vmap, hipStream_t st);
+int spmv_sjds_sym_merge(const spmv_hip_csr_plan* pl, int long_thr, int32_t** vptr,
+                        int32_t** vcol, int32_t** vmap, int64_t* total, hipStream_t st);
+int spmv_sjds_sym_build(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan, hipStream_t st);
 int spmv_sjds_run_sym_f64(const spmv_hip_csr_plan* pl, hipStream_t st,
                           const double* diagonal, double alpha, const double* in,
                           double beta, double* out, DotOut dot);

@@ -190,6 +190,11 @@ int spmv_hip_ctx_set_option(spmv_hip_ctx* ctx, const char* key, int64_t value)
     ctx->sj_sigma = (int)value;
     return SPMV_HIP_OK;
   }
+  if (!strcmp(key, "sym_sj_long_rows")) {
+    SPMV_REQUIRE(value == 0 || value == 1);
+    ctx->sym_sj_long_rows = (int)value;
+    return SPMV_HIP_OK;
+  }
   if (!strcmp(key, "sym_sj_long_permille")) {
     SPMV_REQUIRE(value >= 0 && value <= 1000);
     ctx->sym_sj_long_permille = (int)value;

@@ -1440,51 +1440,11 @@ static int sym_sj_bake(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan, const T* valu
     return SPMV_HIP_ENOTSUP;
   const auto t0 = std::chrono::steady_clock::now();
   if (!plan->sjt) {
-    // long rows stay inside the slices in this form (and a slice runs as long
-    // as its longest row): a matrix with more than a few of them -- rows of
-    // the lower block, or columns = rows of its transpose -- keeps the
-    // transposed-map kernel
-    int64_t la = 0, lb = 0;
-    int rl = spmv_sjds_long_entries(ctx, plan->num_rows, plan->nnz, plan->rowptr0, &la, st);
-    if (rl == SPMV_HIP_OK)
-      rl = spmv_sjds_long_entries(ctx, plan->num_rows, plan->nnz, plan->t_ptr, &lb, st);
-    if (rl != SPMV_HIP_OK)
-      return rl;
-    if ((la + lb) * 1000 > (int64_t)ctx->sym_sj_long_permille * 2 * plan->nnz)
-      return SPMV_HIP_ENOTSUP;
-    // the merged matrix: per row its lower entries, then its column's
-    const int rm = spmv_sjds_sym_merge(plan, &plan->sjv_ptr, &plan->sjv_col,
-                                       &plan->sjv_map, st);
-    if (rm != SPMV_HIP_OK)
-      return rm == SPMV_HIP_ENOMEM ? SPMV_HIP_ENOTSUP : rm;
-    spmv_hip_csr_plan* ch = new (std::nothrow) spmv_hip_csr_plan;
-    int rb = ch ? SPMV_HIP_OK : SPMV_HIP_ENOMEM;
-    if (ch) {
-      ch->ctx = ctx;
-      ch->num_rows = plan->num_rows;
-      ch->num_cols = plan->num_cols;
-      ch->nnz = 2 * plan->nnz;
-      ch->symmetric = false;
-      ch->rowptr0 = plan->sjv_ptr;
-      ch->colind0 = plan->sjv_col;
-      rb = spmv_sjds_build(ch, plan->sjv_ptr, plan->sjv_col, ctx->sj_wpb, 2, 1);
-    }
-    // (the columns were for the analysis only: the kernel reads its codes)
-    (void)hipFree(plan->sjv_col);
-    plan->sjv_col = nullptr;
-    if (ch)
-      ch->colind0 = nullptr;
-    if (rb != SPMV_HIP_OK || !ch->sj_lenperm) {
-      if (ch) {
-        spmv_sjds_free(ch);
-        delete ch;
-      }
-      (void)hipFree(plan->sjv_ptr);
-      (void)hipFree(plan->sjv_map);
-      plan->sjv_ptr = plan->sjv_map = nullptr;
-      return rb != SPMV_HIP_OK ? rb : SPMV_HIP_ENOTSUP;
-    }
-    plan->sjt = ch;
+    // the structure: the long rows' list (parent), the merged matrix sliced
+    // jagged (child) -- spmv_sjds_plan.hip
+    const int rs = spmv_sjds_sym_build(ctx, plan, st);
+    if (rs != SPMV_HIP_OK)
+      return rs;
   }
   plan->plan_us += (int)std::chrono::duration_cast<std::chrono::microseconds>(
                        std::chrono::steady_clock::now() - t0)
@@ -2121,17 +2081,26 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
     *value = plan->sj_lenperm && plan->nnz > 0
                  ? (int)((plan->sj_units * plan->sj_unit * 1000) / plan->nnz)
                  : 0;
+  // (symmetric storage: the long rows of the stored block are the PARENT's)
   else if (!strcmp(key, "sj_long_panels"))
-    *value = plan->sj_lenperm && plan->sj_long_sorted && plan->sj_long_panels ? 1 : 0;
+    *value = (plan->sj_lenperm || plan->sjt) && plan->sj_long_sorted
+                     && plan->sj_long_panels
+                 ? 1
+                 : 0;
+  else if (!strcmp(key, "sj_long_sorted"))
+    *value = (plan->sj_lenperm || plan->sjt) && plan->sj_nlong > 0
+                     && plan->sj_long_sorted
+                 ? 1
+                 : 0;
   else if (!strcmp(key, "sj_long_table"))
-    *value = plan->sj_lenperm && plan->sj_long_sorted && plan->sj_long_panels
-                     && plan->sj_lt_tab && plan->sj_long_table
+    *value = (plan->sj_lenperm || plan->sjt) && plan->sj_long_sorted
+                     && plan->sj_long_panels && plan->sj_lt_tab && plan->sj_long_table
                  ? 1
                  : 0;
   else if (!strcmp(key, "sj_long_table_kib"))
     *value = (int)((plan->sj_lt_entries * 4 + (int64_t)plan->sj_lt_nsg * 16) / 1024);
   else if (!strcmp(key, "sj_long_rows"))
-    *value = plan->sj_lenperm ? plan->sj_nlong : 0;
+    *value = (plan->sj_lenperm || plan->sjt) ? plan->sj_nlong : 0;
   else if (!strcmp(key, "sj_wide"))
     *value = plan->sj_lenperm ? plan->sj_wide_alloc : 0;
   else if (!strcmp(key, "sj_blocks_per_cu"))
@@ -2190,7 +2159,11 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
       b += 4 * plan->sj_units * plan->sj_unit;
     if (plan->sjt && plan->sjt->sj_lenperm) { // symmetric storage: the merged matrix
       const spmv_hip_csr_plan* c = plan->sjt;
-      b += 4 * (n + 1) + 8 * nnz; // its row pointer, the positions of its values
+      b += 4 * (n + 1) + 4 * c->nnz; // its row pointer, the positions of its values
+      if (plan->sj_long_rows) // the stored block's long rows: list, table, codes
+        b += 4 * (int64_t)plan->sj_nlong + 4 * plan->sj_lt_entries
+             + 16 * (int64_t)plan->sj_lt_nsg + 2 * plan->sj_lt_codes_n
+             + 8 * (int64_t)plan->sj_nlong;
       b += 4 * ((n + 63) / 64 * 64) + 8 * (int64_t)c->sj_nblk
            + 4 * (int64_t)c->sj_nblk * c->sj_stride
            + (c->sj_wide_alloc ? 4 : 2) * c->sj_units * c->sj_unit

@@ -865,6 +865,22 @@ def _sym_lower_cases():
     va = rng.uniform(-1, 1, len(cols))
     cases["ragged_long_column"] = (rp2.astype(np.int32), cols.astype(np.int32), va,
                                    rng.uniform(1, 2, nr))
+    # an "arrow": ragged short rows, 40 LONG rows of 200-900 entries with
+    # UNSORTED columns (the gathered long-row kernel), and a dense LAST row
+    # (within the arrays' last entries: it stays inside the slices)
+    nr = 6000
+    lens = np.minimum(rng.integers(0, 12, nr), np.arange(nr))
+    long_rows = rng.choice(np.arange(1500, nr - 1), 40, replace=False)
+    lens[long_rows] = rng.integers(200, 900, 40)
+    lens[nr - 1] = 700
+    rp = np.zeros(nr + 1, np.int64)
+    np.cumsum(lens, out=rp[1:])
+    ci = np.empty(rp[-1], np.int32)
+    for r in range(nr):
+        if lens[r]:
+            ci[rp[r]:rp[r + 1]] = rng.permutation(rng.choice(r, lens[r], replace=False))
+    cases["arrow_unsorted"] = (rp.astype(np.int32), ci, rng.uniform(-1, 1, len(ci)),
+                               rng.uniform(1, 2, nr))
     return cases
 
 
@@ -888,9 +904,10 @@ def test_symmetric_storage_sliced_jagged_bit_exact(sj_ctx, wpb):
         y0 = rng.uniform(-1, 1, nr)
         blk = hip.CsrBlock(ctx, nr, nr, rp, ci, va, dg, True)
         assert blk.get("sym_sj") == 0
-        if name != "fem":
-            # long rows / a long column hold more than 5 % of the entries: left
-            # to itself the plan keeps the transposed-map kernel ...
+        if name == "ragged_long_column":
+            # a long COLUMN holds more than 5 % of the entries (it would stay
+            # inside the slices): left to itself the plan keeps the
+            # transposed-map kernel ...
             with pytest.raises(Exception):  # SPMV_HIP_ENOTSUP: no form applies
                 blk.bake()
             assert blk.get("sym_sj") == 0 and blk.get("sjds") == 0, name
@@ -904,6 +921,16 @@ def test_symmetric_storage_sliced_jagged_bit_exact(sj_ctx, wpb):
         assert blk.get("sym_sj") == 1 and blk.get("sjds") == 1, name
         if wpb:
             assert blk.get("sj_wpb") == wpb
+        # LONG rows of the stored block: their lower part by the long-row
+        # kernels on the caller's arrays (table-driven where the columns
+        # ascend, gathered where not), launched before the slices' kernel
+        nlong = blk.get("sj_long_rows")
+        if name == "fem_tail":
+            assert nlong > 10 and blk.get("sj_long_sorted") == 1
+        elif name == "arrow_unsorted":
+            assert nlong == 40 and blk.get("sj_long_sorted") == 0
+        else:
+            assert nlong == 0, name
         dx = ctx.upload(x)
         for alpha, beta in ((1.0, 0.0), (-0.75, 0.0), (2.5, -0.5)):
             y_ref = oracle.csr_spmv_sym(rp, ci, va, dg, x, alpha, beta, y0)
@@ -941,6 +968,29 @@ def test_symmetric_storage_sliced_jagged_bit_exact(sj_ctx, wpb):
             b.free()
         blk.free()
     part.free()
+    # long rows kept INSIDE the slices (context option sym_sj_long_rows = 0: they
+    # then count against the 5 %, lifted here) -- the round-4 form of the same
+    ctx.set_option("sym_sj_long_rows", 0)
+    ctx.set_option("sym_sj_long_permille", 1000)
+    for name in ("fem_tail", "arrow_unsorted"):
+        rp, ci, va, dg = _sym_lower_cases()[name]
+        nr = len(rp) - 1
+        x = rng.uniform(-1, 1, nr)
+        y0 = rng.uniform(-1, 1, nr)
+        blk = hip.CsrBlock(ctx, nr, nr, rp, ci, va, dg, True)
+        blk.bake()
+        assert blk.get("sym_sj") == 1 and blk.get("sj_long_rows") == 0
+        dx = ctx.upload(x)
+        for alpha, beta in ((1.0, 0.0), (2.5, -0.5)):
+            dy = ctx.upload(np.full(nr, np.nan) if beta == 0 else y0)
+            blk.mult(alpha, dx.ptr, beta, dy.ptr)
+            assert np.array_equal(dy.numpy(), oracle.csr_spmv_sym(rp, ci, va, dg, x,
+                                                                  alpha, beta, y0)), name
+            dy.free()
+        dx.free()
+        blk.free()
+    ctx.set_option("sym_sj_long_rows", 1)
+    ctx.set_option("sym_sj_long_permille", 50)
     # fp32
     rp, ci, va, dg = _sym_lower_cases()["fem"]
     nr = len(rp) - 1
@@ -954,6 +1004,70 @@ def test_symmetric_storage_sliced_jagged_bit_exact(sj_ctx, wpb):
     assert np.array_equal(dy.numpy(), oracle.csr_spmv_sym(rp, ci, va32, dg32, x32, -1.5))
     for b in (dx, dy):
         b.free()
+    blk.free()
+    rp, ci, va, dg = _sym_lower_cases()["fem_tail"]  # ... with long rows
+    nr = len(rp) - 1
+    va32, dg32 = va.astype(np.float32), dg.astype(np.float32)
+    x32 = rng.uniform(-1, 1, nr).astype(np.float32)
+    blk = hip.CsrBlock(ctx, nr, nr, rp, ci, va32, dg32, True, dtype=np.float32)
+    blk.bake()
+    assert blk.get("sym_sj") == 1 and blk.get("sj_long_rows") > 10
+    dx, dy = ctx.upload(x32), ctx.upload(np.full(nr, np.nan, np.float32))
+    for alpha in (1.0, -1.5):
+        blk.mult(alpha, dx.ptr, 0.0, dy.ptr)
+        assert np.array_equal(dy.numpy(),
+                              oracle.csr_spmv_sym(rp, ci, va32, dg32, x32, alpha))
+    for b in (dx, dy):
+        b.free()
+    blk.free()
+
+
+def test_sliced_jagged_rows_too_long_for_the_sigma_word(sj_ctx):
+    """a row that stays in the slices shares a 32-bit word with its
+    position -- 21 bits of length beside the sigma layout's 10.  A bordered
+    matrix's dense LAST row (never taken out as long: it ends with the arrays)
+    with more than 2^21 entries makes the plan leave the sigma layout; the same
+    as a dense COLUMN of symmetric storage (a row of the merged matrix)."""
+    ctx = sj_ctx
+    rng = np.random.default_rng(0x2021)
+    n = (1 << 21) + 70_000
+    # general storage: tridiagonal + a dense last row
+    i = np.arange(n - 1)
+    rows = np.concatenate([i, i[1:], i[:-1], np.full(n, n - 1)])
+    cols = np.concatenate([i, i[1:] - 1, i[:-1] + 1, np.arange(n)])
+    order = np.lexsort((cols, rows))
+    rows, cols = rows[order], cols[order].astype(np.int32)
+    rp = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n))]).astype(np.int32)
+    va = rng.uniform(-1, 1, len(cols))
+    x = rng.uniform(-1, 1, n)
+    blk = hip.CsrBlock(ctx, n, n, rp, cols, va, None, False)
+    blk.bake()
+    assert blk.get("sjds") == 1 and blk.get("sj_sigma") == 0
+    assert blk.get("sj_long_rows") == 0  # the dense row is inside a slice
+    dx, dy = ctx.upload(x), ctx.upload(np.full(n, np.nan))
+    blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+    assert np.array_equal(dy.numpy(), oracle.csr_spmv(rp, cols, va, x))
+    dy.free()
+    blk.free()
+    # symmetric storage: a subdiagonal + a dense first column
+    rows = np.concatenate([np.arange(1, n), np.arange(2, n)])
+    cols = np.concatenate([np.zeros(n - 1, np.int64), np.arange(1, n - 1)])
+    order = np.lexsort((cols, rows))
+    rows, cols = rows[order], cols[order].astype(np.int32)
+    rp = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n))]).astype(np.int32)
+    va = rng.uniform(-1, 1, len(cols))
+    dg = rng.uniform(1, 2, n)
+    ctx.set_option("sym_sj_long_permille", 1000)  # (the column is half the entries)
+    blk = hip.CsrBlock(ctx, n, n, rp, cols, va, dg, True)
+    blk.bake()
+    ctx.set_option("sym_sj_long_permille", 50)
+    assert blk.get("sym_sj") == 1 and blk.get("sj_sigma") == 0
+    for alpha, beta in ((1.0, 0.0), (-0.5, 0.0)):
+        dy = ctx.upload(np.full(n, np.nan))
+        blk.mult(alpha, dx.ptr, beta, dy.ptr)
+        assert np.array_equal(dy.numpy(), oracle.csr_spmv_sym(rp, cols, va, dg, x, alpha))
+        dy.free()
+    dx.free()
     blk.free()
 
 

@@ -24,9 +24,12 @@ KINDS = {
     "fem15": dict(min_len=15, max_len=15),  # the mean of "fem", every row alike
     "fem_long": dict(min_len=40, max_len=120),  # ragged AND long
     "fem_mid": dict(min_len=20, max_len=80),
+    # symmetric storage (strictly lower part + diagonal; run with --no-check)
+    "fem_sym": dict(symmetric=True),
+    "fem_tail_sym": dict(symmetric=True, tail_permille=10),
 }
 ALGO = {"rowblock": 1, "vector": 2, "scalar": 3}
-FORM_KEYS = ("algo", "lat", "lx", "lxw", "wdia", "wdia_half", "wdia_hbox", "sdia", "sjds", "sj_wpb", "sj_unit", "sj_sigma",
+FORM_KEYS = ("algo", "sym_sj", "sj_long_rows", "sj_long_table", "lat", "lx", "lxw", "wdia", "wdia_half", "wdia_hbox", "sdia", "sjds", "sj_wpb", "sj_unit", "sj_sigma",
              "sj_max_chunks", "sj_far_permille", "sj_staged_bytes_per_entry_x100",
              "sj_wide", "sj_long_rows", "lx_staged", "lx_blocks", "blocks_per_cu", "nontemporal")
 
