@@ -326,14 +326,21 @@ def kernel_of(A, symmetric):
                     algo, nnz * 8 + rows * (4 + 1 + 8) + y_x)
         if A.plan_get("sym_sj"):
             wpb = A.plan_get("sj_wpb")
+            nlong = A.plan_get("sj_long_rows")
             return (f"csr_sjds_kernel<double, {wpb} slices per block, symmetric "
-                    "storage> (no lattice structure: the merged matrix -- per row "
+                    "storage>"
+                    + (f" + csr_sjds_longt_kernel ({nlong} long rows of the stored "
+                       "block: their lower part from the caller's arrays, before "
+                       "the slices)" if nlong else "")
+                    + " (no lattice structure: the merged matrix -- per row "
                     "its stored lower entries, then its column's entries in the "
                     "reference's order -- in the sliced jagged form: the plan's "
                     "copy of the values and 16-bit column codes, x staged in LDS; "
                     "one pass, the sum turning into y = alpha (d x + L x) + beta y "
                     "where the column's entries begin; atomic-free, bit-exact; "
                     "fused p.Ap)",
+                    # every stored entry twice (value + code); long rows: their
+                    # lower part once from the CSR arrays (12 B) + once merged
                     algo, nnz * 20 + rows * (4 + 8 + 8 + 8 + 8) + cols * 8)
         if A.plan_get("sym_det"):
             return ("csr_symt_kernel<double> (transposed map, atomic-free, "
@@ -557,7 +564,7 @@ def timed_spmv(exec_, A, N, _lib, reps, crosscheck=False):
 
 def spmv_record(exec_, comm, host, _lib, n, symmetric, reps, lattice=True,
                 bake=True, skew_ppm=0, lx=True, record=None, stencil=7,
-                const=True, sj=True):
+                const=True, sj=True, xw=True):
     """one plain-SpMV sub-record on the n^3 matrix in the given storage/form
     (skew_ppm: the generator's non-symmetric variant of the matrix; stencil 27:
     the 27-point operator)"""

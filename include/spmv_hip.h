@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SPMV_HIP_ABI_VERSION 3
+#define SPMV_HIP_ABI_VERSION 4
 
 enum {
   SPMV_HIP_OK = 0,
@@ -85,6 +85,9 @@ int spmv_hip_synchronize(spmv_hip_ctx* ctx); /* whole device */
  *   operator (all neighbours with |dx|,|dy|,|dz| <= 1; diagonal 26,
  *   off-diagonal -1); its row slabs must be whole planes. */
 int spmv_hip_ctx_set_option(spmv_hip_ctx* ctx, const char* key, int64_t value);
+/* ... and read back (release_csr, put_timeout_ms, the *_min_nnz thresholds,
+ * xw_min_x_bytes); SPMV_HIP_EINVAL for a key without a getter */
+int spmv_hip_ctx_get_option(const spmv_hip_ctx* ctx, const char* key, int64_t* value);
 /*   "lx_min_nnz": csr_plan_create builds the LX form of a general matrix
  *   (LDS-staged x windows + 16-bit column offsets, 2 B per entry of extra
  *   device memory) from this many entries on.  Default 2^20; a huge value
@@ -257,6 +260,32 @@ int spmv_hip_csr_plan_bake_values_f32(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan
  * call cost. */
 int spmv_hip_csr_plan_values_changed(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan,
                                      void* stream);
+/* PLAN MEMORY (ABI 4).  A plan that took one of the value-baking forms holds a
+ * complete copy of the matrix in its own format; the caller's `colind` and
+ * `values` are then read by nothing but a fallback.  (The reference's CSRMatrix
+ * owns exactly one copy of the matrix, spmv/csr_matrix.cpp:34-70; with a plan
+ * on top the device would hold two.)
+ *   plan_owns_matrix     *mask = the arrays the plan no longer needs to read:
+ *                        bit 0 (1) = colind, bit 1 (2) = values.  Non-zero for a
+ *                        general plan in a diagonal form (values by offset,
+ *                        or no values at all where every diagonal is constant)
+ *                        or in the sliced jagged form WITHOUT long rows (those
+ *                        are streamed from the caller's arrays); 0 otherwise
+ *                        (CSR-order kernels, LX, XW, lattice kernels, symmetric
+ *                        storage, an fp32 twin baked for the mixed SpMV).
+ *                        `rowptr` is never given up (4 B per row).
+ *   plan_release_matrix  the caller frees the arrays of `mask` (a subset of
+ *                        what plan_owns_matrix reports, else SPMV_HIP_EINVAL).
+ *                        From then on the plan COMPARES the `colind` / `values`
+ *                        pointers of a launch with the ones it was built from
+ *                        and never reads them, and refuses with SPMV_HIP_EINVAL
+ *                        whatever would: plan_values_changed, plan_bake_values_*
+ *                        (a drop included), plan_set of a key that selects
+ *                        another kernel, a launch the baked form does not take
+ *                        (other pointers, an x that is not 16-byte aligned).
+ *                        Irreversible for the plan's lifetime. */
+int spmv_hip_csr_plan_owns_matrix(const spmv_hip_csr_plan* plan, int* mask);
+int spmv_hip_csr_plan_release_matrix(spmv_hip_csr_plan* plan, int mask);
 /* ... and the fp32 copy for spmv_hip_csr_spmv_f32f64 (mixed precision) on a
  * general fp64 plan whose values are baked: `values32` is the caller's fp32
  * copy of the CSR values (the same device check runs on its bits).  Launches

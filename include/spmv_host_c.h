@@ -161,6 +161,10 @@ int spmvh_matrix_plan_get(spmvh_matrix* A, int remote, const char* key,
  * those while `on`. */
 int spmvh_matrix_enable_mixed(spmvh_matrix* A, int* ok);
 int spmvh_matrix_use_mixed(spmvh_matrix* A, int on);
+/* CSRMatrix::release_csr on both blocks: the device copies of colind / values
+ * of a block whose plan holds the matrix in its own format are freed
+ * (spmv_hip_csr_plan_owns_matrix); *bytes_freed = what came back (0: nothing) */
+int spmvh_matrix_release_csr(spmvh_matrix* A, int64_t* bytes_freed);
 int spmvh_matrix_plan_set(spmvh_matrix* A, int remote, const char* key,
                           int value);
 /* A.col_map()->update(x) ; A.mult(x, y) ; A.col_map()->update_finalise(x) */

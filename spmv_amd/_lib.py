@@ -52,6 +52,7 @@ _PROTOS = {
     "spmv_hip_num_cus": ([vp, P(C.c_int)], C.c_int),
     "spmv_hip_synchronize": ([vp], C.c_int),
     "spmv_hip_ctx_set_option": ([vp, C.c_char_p, i64], C.c_int),
+    "spmv_hip_ctx_get_option": ([vp, C.c_char_p, C.POINTER(i64)], C.c_int),
     "spmv_hip_stream_create": ([vp, P(vp)], C.c_int),
     "spmv_hip_stream_create_priority": ([vp, C.c_int, P(vp)], C.c_int),
     "spmv_hip_stream_destroy": ([vp, vp], C.c_int),
@@ -82,6 +83,8 @@ _PROTOS = {
     "spmv_hip_csr_plan_bake_values_f32": ([vp, vp, vp, vp, vp], C.c_int),
     "spmv_hip_csr_plan_bake_values_f32f64": ([vp, vp, vp, vp], C.c_int),
     "spmv_hip_csr_plan_values_changed": ([vp, vp, vp], C.c_int),
+    "spmv_hip_csr_plan_owns_matrix": ([vp, C.POINTER(C.c_int)], C.c_int),
+    "spmv_hip_csr_plan_release_matrix": ([vp, C.c_int], C.c_int),
     "spmv_hip_csr_plan_algo": ([vp, P(C.c_int)], C.c_int),
     "spmv_hip_csr_plan_set": ([vp, C.c_char_p, C.c_int], C.c_int),
     "spmv_hip_csr_plan_get": ([vp, C.c_char_p, P(C.c_int)], C.c_int),

@@ -26,6 +26,10 @@ struct spmv_hip_ctx {
   // x windows by LDS-DMA one row block ahead; "lx_dma", 0 = the register-staged
   // kernel's layout)
   int lx_dma = 1;
+  // the host mirror's CSRMatrix frees its device copies of colind / values
+  // once a plan holds the matrix in its own format ("release_csr";
+  // spmv_hip_csr_plan_owns_matrix); read by the mirror, nothing here acts on it
+  int release_csr = 0;
   // plans that keep the caller's CSR arrays as they are (no lattice, LX or
   // sliced jagged form) stage the x windows of every row block in LDS from
   // this many entries on ("xw_min_nnz": the XW kernel of spmv_lxw.hip; the

@@ -361,6 +361,9 @@ struct spmv_hip_csr_plan {
   // structure: it is refused (SPMV_HIP_EINVAL).
   const int32_t* rowptr0 = nullptr;
   const int32_t* colind0 = nullptr;
+  // arrays the caller has freed (spmv_hip_csr_plan_release_matrix): bit 0 =
+  // colind, bit 1 = values -- compared, never read, from then on
+  int released = 0;
   bool structure_baked() const
   {
     return row_list || lx_lidx || lat_tab || slat_mask || t_ptr || lxw_rec

@@ -102,6 +102,28 @@ int spmv_hip_num_cus(const spmv_hip_ctx* ctx, int* num_cus)
   return SPMV_HIP_OK;
 }
 
+int spmv_hip_ctx_get_option(const spmv_hip_ctx* ctx, const char* key, int64_t* value)
+{
+  SPMV_REQUIRE(ctx && key && value);
+  if (!strcmp(key, "release_csr"))
+    *value = ctx->release_csr;
+  else if (!strcmp(key, "put_timeout_ms"))
+    *value = ctx->put_timeout_ms;
+  else if (!strcmp(key, "xw_min_nnz"))
+    *value = ctx->xw_min_nnz;
+  else if (!strcmp(key, "xw_min_x_bytes"))
+    *value = ctx->xw_min_x_bytes;
+  else if (!strcmp(key, "lx_min_nnz"))
+    *value = ctx->lx_min_nnz;
+  else if (!strcmp(key, "lat_min_nnz"))
+    *value = ctx->lat_min_nnz;
+  else if (!strcmp(key, "sj_min_nnz"))
+    *value = ctx->sj_min_nnz;
+  else
+    return SPMV_HIP_EINVAL;
+  return SPMV_HIP_OK;
+}
+
 int spmv_hip_ctx_set_option(spmv_hip_ctx* ctx, const char* key, int64_t value)
 {
   SPMV_REQUIRE(ctx && key);
@@ -118,6 +140,11 @@ int spmv_hip_ctx_set_option(spmv_hip_ctx* ctx, const char* key, int64_t value)
   if (!strcmp(key, "lx_min_nnz")) {
     SPMV_REQUIRE(value >= 0);
     ctx->lx_min_nnz = value;
+    return SPMV_HIP_OK;
+  }
+  if (!strcmp(key, "release_csr")) {
+    SPMV_REQUIRE(value == 0 || value == 1);
+    ctx->release_csr = (int)value;
     return SPMV_HIP_OK;
   }
   if (!strcmp(key, "xw_min_x_bytes")) {

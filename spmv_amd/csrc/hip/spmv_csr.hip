@@ -1462,6 +1462,38 @@ static int sym_sj_bake(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan, const T* valu
   return SPMV_HIP_OK;
 }
 
+
+// the arrays a launch with the baked pointers does not read (plan_owns_matrix)
+static int plan_owned_mask(const spmv_hip_csr_plan* pl)
+{
+  if (pl->symmetric || pl->nnz == 0)
+    return 0;
+  // an fp32 twin for the mixed SpMV: its launches may fall back to CSR order
+  if (pl->sdia32_val || pl->wdia32_val || pl->sj_val32)
+    return 0;
+  if (pl->sdia && pl->sdia_val && pl->sdia_general && pl->sdia_values0)
+    return 3;
+  if (pl->wdia && pl->wdia_val && pl->wdia_values0)
+    return 3;
+  if (pl->sj && pl->sj_val && pl->sj_values0 && pl->sj_nlong == 0 && pl->num_cols >= 2)
+    return 3;
+  return 0;
+}
+
+// does a launch with these operands take the form that owns the matrix?
+template <typename T>
+static bool released_launch_ok(const spmv_hip_csr_plan* pl, const T* values,
+                               const T* in)
+{
+  if (pl->algo != SPMV_HIP_ALGO_ROWBLOCK || plan_owned_mask(pl) == 0)
+    return false;
+  if (pl->sdia && pl->sdia_val && pl->sdia_general)
+    return pl->sdia_elem == (int)sizeof(T) && values == pl->sdia_values0;
+  if (pl->wdia && pl->wdia_val)
+    return pl->wdia_elem == (int)sizeof(T) && values == pl->wdia_values0;
+  return pl->sj_elem == (int)sizeof(T) && values == pl->sj_values0 && aligned16(in);
+}
+
 extern "C" {
 
 int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
@@ -1638,6 +1670,7 @@ int spmv_hip_csr_plan_bake_values_f64(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan
 {
   SPMV_SET_DEVICE(ctx);
   SPMV_REQUIRE(plan && plan->ctx == ctx);
+  SPMV_REQUIRE(!plan->released); // (its source arrays were given up)
   hipStream_t st = spmv_stream(ctx, stream);
   if (values) // (as in plan_create: the caller's kernels are not plan time)
     SPMV_CHECK_HIP(hipStreamSynchronize(st));
@@ -1684,6 +1717,7 @@ int spmv_hip_csr_plan_bake_values_f32(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan
 {
   SPMV_SET_DEVICE(ctx);
   SPMV_REQUIRE(plan && plan->ctx == ctx);
+  SPMV_REQUIRE(!plan->released); // (its source arrays were given up)
   hipStream_t st = spmv_stream(ctx, stream);
   if (values)
     SPMV_CHECK_HIP(hipStreamSynchronize(st));
@@ -1725,6 +1759,7 @@ int spmv_hip_csr_plan_bake_values_f32f64(spmv_hip_ctx* ctx,
 {
   SPMV_SET_DEVICE(ctx);
   SPMV_REQUIRE(plan && plan->ctx == ctx);
+  SPMV_REQUIRE(!plan->released); // (its source arrays were given up)
   hipStream_t st = spmv_stream(ctx, stream);
   // whichever form holds the fp64 values (by offset, in jagged order) gets
   // its fp32 twin
@@ -1739,11 +1774,27 @@ int spmv_hip_csr_plan_bake_values_f32f64(spmv_hip_ctx* ctx,
   return spmv_sdia_bake_f32f64(plan, values32, st);
 }
 
+int spmv_hip_csr_plan_owns_matrix(const spmv_hip_csr_plan* plan, int* mask)
+{
+  SPMV_REQUIRE(plan && mask);
+  *mask = plan_owned_mask(plan);
+  return SPMV_HIP_OK;
+}
+
+int spmv_hip_csr_plan_release_matrix(spmv_hip_csr_plan* plan, int mask)
+{
+  SPMV_REQUIRE(plan && mask >= 0 && (mask & ~plan_owned_mask(plan)) == 0);
+  plan->released |= mask;
+  return SPMV_HIP_OK;
+}
+
 int spmv_hip_csr_plan_values_changed(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan,
                                      void* stream)
 {
   SPMV_SET_DEVICE(ctx);
   SPMV_REQUIRE(plan && plan->ctx == ctx);
+  // (the arrays the copies would be refreshed from are gone)
+  SPMV_REQUIRE(!plan->released);
   hipStream_t st = spmv_stream(ctx, stream);
   const auto t_begin = std::chrono::steady_clock::now();
   const int plan_us0 = plan->plan_us;
@@ -1835,6 +1886,11 @@ int spmv_hip_csr_plan_algo(const spmv_hip_csr_plan* plan, int* algo)
 int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
 {
   SPMV_REQUIRE(plan && key);
+  // arrays given up (plan_release_matrix): no key may select a kernel that
+  // would read them
+  if (plan->released)
+    for (const char* k : {"algo", "sdia", "wdia", "sjds", "lat", "lx", "lxw", "xw"})
+      SPMV_REQUIRE(strcmp(key, k) != 0);
   if (!strcmp(key, "algo")) {
     // ROWLIST needs the list built at plan creation
     SPMV_REQUIRE(value >= SPMV_HIP_ALGO_ROWBLOCK
@@ -2264,6 +2320,8 @@ int spmv_hip_csr_spmv_f64(spmv_hip_ctx* ctx, const spmv_hip_csr_plan* plan,
     return SPMV_HIP_OK;
   SPMV_REQUIRE(in && out);
   SPMV_REQUIRE(num_non_zeros == 0 || (rowptr && colind && values));
+  // arrays given up: only the form that owns the matrix may run
+  SPMV_REQUIRE(!plan->released || released_launch_ok(plan, values, in));
   hipStream_t st = spmv_stream(ctx, stream);
   if (plan->symmetric) {
     DotOut dot;
@@ -2303,6 +2361,7 @@ int spmv_hip_csr_spmv_f32f64(spmv_hip_ctx* ctx, const spmv_hip_csr_plan* plan,
 {
   SPMV_SET_DEVICE(ctx);
   SPMV_REQUIRE(plan && plan->ctx == ctx && !plan->symmetric);
+  SPMV_REQUIRE(!plan->released); // (mixed launches may read the CSR arrays)
   SPMV_REQUIRE(num_rows == plan->num_rows && num_cols == plan->num_cols
                && num_non_zeros == plan->nnz);
   SPMV_REQUIRE(!plan->structure_baked()
@@ -2349,6 +2408,7 @@ int spmv_hip_csr_spmv_f32(spmv_hip_ctx* ctx, const spmv_hip_csr_plan* plan,
     return SPMV_HIP_OK;
   SPMV_REQUIRE(in && out);
   SPMV_REQUIRE(num_non_zeros == 0 || (rowptr && colind && values));
+  SPMV_REQUIRE(!plan->released || released_launch_ok(plan, values, in));
   hipStream_t st = spmv_stream(ctx, stream);
   if (plan->symmetric)
     return spmv_run_symmetric_f32(plan, st, rowptr, colind, values, diagonal,

@@ -513,6 +513,17 @@ int spmvh_matrix_plan_set(spmvh_matrix* A, int remote, const char* key,
   });
 }
 
+int spmvh_matrix_release_csr(spmvh_matrix* A, int64_t* bytes_freed)
+{
+  return guarded([&] {
+    require(A && bytes_freed, "NULL argument");
+    *bytes_freed = 0;
+    for (const SubMatrix<double>* b : {A->A->local_block(), A->A->remote_block()})
+      if (const auto* csr = dynamic_cast<const CSRMatrix<double>*>(b))
+        *bytes_freed += static_cast<int64_t>(csr->release_csr());
+  });
+}
+
 int spmvh_matrix_enable_mixed(spmvh_matrix* A, int* ok)
 {
   return guarded([&] {

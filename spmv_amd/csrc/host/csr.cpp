@@ -216,8 +216,10 @@ CSRMatrix<T>::~CSRMatrix()
   try {
     this->_exec->spmv_finalize(_op);
     this->_exec->free(_rowptr);
-    this->_exec->free(_colind);
-    this->_exec->free(_values);
+    if (!_released) { // (else tokens: release_csr freed them)
+      this->_exec->free(_colind);
+      this->_exec->free(_values);
+    }
     this->_exec->free(_values32);
     this->_exec->free(this->_diagonal);
   } catch (...) {
@@ -225,8 +227,32 @@ CSRMatrix<T>::~CSRMatrix()
 }
 
 template <typename T>
+size_t CSRMatrix<T>::release_csr() const
+{
+  if (_released || this->_num_non_zeros == 0 || _values32 || !_op.plan())
+    return 0;
+  auto* hip = dynamic_cast<const HipExecutor*>(this->_exec.get());
+  if (!hip)
+    return 0;
+  int mask = 0;
+  throw_on_error(spmv_hip_csr_plan_owns_matrix(_op.plan(), &mask),
+                 "spmv_hip_csr_plan_owns_matrix");
+  if (mask != 3) // both or nothing: one flag, one rule
+    return 0;
+  throw_on_error(spmv_hip_csr_plan_release_matrix(_op.plan(), mask),
+                 "spmv_hip_csr_plan_release_matrix");
+  hip->synchronize(); // no launch of an earlier form still reads them
+  this->_exec->free(_colind);
+  this->_exec->free(_values);
+  _released = true; // the pointers stay as tokens
+  return (size_t)this->_num_non_zeros * (sizeof(int32_t) + sizeof(T));
+}
+
+template <typename T>
 void CSRMatrix<T>::enable_mixed() const
 {
+  if (_released)
+    return; // the fp64 values it would convert were given back
   if (_values32 || this->_symmetric || this->_num_non_zeros == 0
       || !std::is_same<T, double>::value)
     return;

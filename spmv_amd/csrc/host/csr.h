@@ -153,6 +153,19 @@ public:
   void use_mixed(bool on) const { _mixed_on = on && _values32 != nullptr; }
   bool mixed_in_use() const { return _mixed_on; }
 
+  // PLAN MEMORY.  The reference's CSRMatrix owns ONE copy of the matrix
+  // (csr_matrix.cpp:34-70); a plan in a value-baking form (diagonal forms, the
+  // sliced jagged form without long rows) holds a second one in its own
+  // format.  release_csr() frees the device copies of colind and values when
+  // the plan reports that it no longer reads them
+  // (spmv_hip_csr_plan_owns_matrix / _release_matrix) and returns the bytes
+  // given back (0: the plan still needs them).  Afterwards colind() / values()
+  // are TOKENS the launches compare, not readable memory; enable_mixed() is a
+  // no-op; mult() is unchanged, bit for bit.  The executor does it by itself
+  // after spmv_init when the context option "release_csr" is set.
+  size_t release_csr() const;
+  bool csr_released() const { return _released; }
+
   const int32_t* rowptr() const { return _rowptr; }
   const int32_t* colind() const { return _colind; }
   const T* values() const { return _values; }
@@ -166,6 +179,7 @@ private:
   T* _values = nullptr;
   mutable float* _values32 = nullptr; // enable_mixed()
   mutable bool _mixed_on = false;
+  mutable bool _released = false; // _colind / _values freed (release_csr)
   CSRSpMV<T> _op;
 };
 

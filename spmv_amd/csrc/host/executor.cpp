@@ -280,12 +280,23 @@ void HipExecutor::_copy_to(void* dst, const DeviceExecutor& dst_exec,
 }
 
 // double dispatch, cuda/cuda_executor.cpp:96-150
+// context option "release_csr": a matrix whose plan holds it in a format of its
+// own gives the device copies of colind / values back (CSRMatrix::release_csr)
+template <typename T>
+static void release_if_asked(spmv_hip_ctx* ctx, const CSRMatrix<T>& mat)
+{
+  int64_t on = 0;
+  if (spmv_hip_ctx_get_option(ctx, "release_csr", &on) == SPMV_HIP_OK && on)
+    (void)mat.release_csr();
+}
+
 void HipExecutor::spmv_init(CSRSpMV<float>& op, const CSRMatrix<float>& mat) const
 {
   op.init(mat.rows(), mat.cols(), mat.non_zeros(), mat.rowptr(), mat.colind(),
           mat.values(), mat.symmetric(), *this);
   op.bake_values(mat.values(), mat.symmetric() ? mat.diagonal() : nullptr,
                  *this);
+  release_if_asked(_ctx, mat);
 }
 void HipExecutor::spmv_init(CSRSpMV<double>& op,
                             const CSRMatrix<double>& mat) const
@@ -294,6 +305,7 @@ void HipExecutor::spmv_init(CSRSpMV<double>& op,
           mat.values(), mat.symmetric(), *this);
   op.bake_values(mat.values(), mat.symmetric() ? mat.diagonal() : nullptr,
                  *this);
+  release_if_asked(_ctx, mat);
 }
 void HipExecutor::spmv_run(const CSRSpMV<float>& op, const CSRMatrix<float>& mat,
                            float alpha, float* in, float beta, float* out) const

@@ -158,6 +158,11 @@ bool Matrix<T>::enable_mixed() const
 {
   if (_symmetric || !std::is_same<T, double>::value)
     return false;
+  // (a block that gave its CSR values back -- CSRMatrix::release_csr -- has
+  // nothing to convert: no mixed mode for this matrix)
+  if ((_mat_local && _mat_local->csr_released())
+      || (_mat_remote && _mat_remote->csr_released()))
+    return false;
   if (_mat_local)
     _mat_local->enable_mixed();
   if (_mat_remote)

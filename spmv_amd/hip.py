@@ -31,9 +31,11 @@ class Buffer:
         self.ptr = p.value  # None for a zero-byte allocation
 
     def free(self):
-        if self.ptr:
+        # (freed = True: given back already, the address kept as a token --
+        # CsrBlock.release_matrix)
+        if self.ptr and not getattr(self, "freed", False):
             call("spmv_hip_free", self.ctx.h, self.ptr)
-            self.ptr = None
+        self.ptr = None
 
     def numpy(self, count=None, offset=0):
         """Blocking device->host copy of `count` elements from `offset`."""
@@ -231,6 +233,27 @@ class CsrBlock:
         """spmv_hip_csr_plan_values_changed: the baked arrays were rewritten in
         place; refresh the plan's copies."""
         call("spmv_hip_csr_plan_values_changed", self.ctx.h, self.plan, None)
+
+    def owns_matrix(self):
+        """spmv_hip_csr_plan_owns_matrix: bit 0 = colind, bit 1 = values are no
+        longer read by the plan's kernel"""
+        m = C.c_int()
+        call("spmv_hip_csr_plan_owns_matrix", self.plan, C.byref(m))
+        return m.value
+
+    def release_matrix(self):
+        """spmv_hip_csr_plan_release_matrix + free this block's device copies of
+        the arrays the plan owns (the buffers' addresses stay as the tokens the
+        launches compare).  Returns the mask released."""
+        m = self.owns_matrix()
+        if m == 3:
+            call("spmv_hip_csr_plan_release_matrix", self.plan, m)
+            self.ctx.synchronize()
+            for buf in (self.colind, self.values):
+                call("spmv_hip_free", self.ctx.h, buf.ptr)
+                buf.freed = True
+            return m
+        return 0
 
     def set(self, key, value):
         call("spmv_hip_csr_plan_set", self.plan, key.encode(), int(value))

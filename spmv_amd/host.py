@@ -58,6 +58,7 @@ _PROTOS = {
     "spmvh_matrix_f32_mult": [vp, vp, vp],
     "spmvh_split_create_dist": [vp, vp, vp, vp, i64, i64, vp, i64, vp, i64,
                                 C.c_int, C.c_int, PTR(vp), PTR(i64)],
+    "spmvh_matrix_release_csr": [vp, PTR(i64)],
     "spmvh_matrix_create_poisson3d": [vp, vp, i32, C.c_int, C.c_int, PTR(vp)],
     "spmvh_matrix_create_unstructured": [vp, vp, i64, C.c_int, i64, C.c_int,
                                          C.c_uint64, PTR(vp)],
@@ -440,6 +441,14 @@ class Matrix:
         if self.h:
             call("spmvh_matrix_destroy", self.h)
             self.h = None
+
+    def release_csr(self):
+        """CSRMatrix::release_csr on both blocks: frees the device copies of
+        colind / values where the plan holds the matrix in its own format;
+        returns the bytes given back (0: the plan still reads them)."""
+        v = i64()
+        call("spmvh_matrix_release_csr", self.h, C.byref(v))
+        return v.value
 
     def rows(self):
         v = C.c_int()

@@ -1071,6 +1071,113 @@ def test_sliced_jagged_rows_too_long_for_the_sigma_word(sj_ctx):
     blk.free()
 
 
+def test_plan_owns_the_matrix_and_the_caller_releases_it(sj_ctx):
+    """PLAN MEMORY (ABI 4).  A general plan in the sliced jagged form without
+    long rows, or in a diagonal form, reports that it no longer reads colind /
+    values (spmv_hip_csr_plan_owns_matrix = 3); after
+    spmv_hip_csr_plan_release_matrix the caller frees them: launches with the
+    same (now dangling) pointers return the same bits, and whatever would read
+    the arrays is refused cleanly -- plan_values_changed, a re-bake, a knob that
+    selects a CSR-order kernel, a launch with other pointers.  Plans that still
+    stream the caller's arrays (long rows, no baked copy, symmetric storage)
+    own nothing."""
+    ctx = sj_ctx
+    rng = np.random.default_rng(0x0A4)
+    # (1) sliced jagged, ragged rows, no long ones
+    rp, ci, va = poisson.fem_like_csr(9000, jitter=64, layer=500)
+    nr = len(rp) - 1
+    x = rng.uniform(-1, 1, nr)
+    y0 = rng.uniform(-1, 1, nr)
+    blk = hip.CsrBlock(ctx, nr, nr, rp, ci, va, None, False)
+    assert blk.owns_matrix() == 0  # nothing baked yet
+    blk.bake()
+    assert blk.get("sjds") == 1 and blk.get("sj_long_rows") == 0
+    assert blk.owns_matrix() == 3
+    dx = ctx.upload(x)
+    refs = {}
+    for alpha, beta in ((1.0, 0.0), (-0.5, 0.75)):
+        refs[(alpha, beta)] = oracle.csr_spmv(rp, ci, va, x, alpha, beta, y0)
+    assert blk.release_matrix() == 3
+    part = ctx.empty(ctx.dot_partials_len, np.float64)
+    for (alpha, beta), y_ref in refs.items():
+        dy = ctx.upload(np.full(nr, np.nan) if beta == 0 else y0)
+        blk.mult(alpha, dx.ptr, beta, dy.ptr,
+                 dot_partials=part.ptr if beta == 0 else None)
+        assert np.array_equal(dy.numpy(), y_ref), (alpha, beta)
+        dy.free()
+    dy = ctx.upload(np.zeros(nr))
+    with pytest.raises(Exception):
+        blk.values_changed()  # the arrays it would re-read are gone
+    with pytest.raises(Exception):
+        blk.bake()
+    with pytest.raises(Exception):
+        blk.bake(drop=True)
+    with pytest.raises(Exception):
+        blk.set("sjds", 0)  # the CSR-order kernels would read freed memory
+    with pytest.raises(Exception):
+        blk.set("algo", hip.ALGO_SCALAR)
+    blk.set("sj_blocks_per_cu", 1)  # (a knob of the form itself: fine)
+    # another values pointer (a live allocation, so surely another address):
+    # there is no CSR-order fallback any more
+    # (the allocator may hand the freed address out again: the second half of a
+    # double-length buffer cannot be it)
+    other = ctx.upload(np.concatenate([va, va]))
+    with pytest.raises(Exception):
+        hip.call("spmv_hip_csr_spmv_f64", ctx.h, blk.plan, nr, nr, len(va),
+                 blk.rowptr.ptr, blk.colind.ptr, other.ptr + 8 * len(va), None, 1.0,
+                 dx.ptr, 0.0, dy.ptr, None, None)
+    blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+    assert np.array_equal(dy.numpy(), refs[(1.0, 0.0)])
+    for b in (other, dy, part):
+        b.free()
+    blk.free()
+    # (2) long rows are streamed from the caller's arrays: nothing to release
+    rp2, ci2, va2 = poisson.fem_like_csr(30_000, jitter=64, layer=900, tail_permille=20,
+                                         tail_min=100, tail_max=1500, tail_stride=16)
+    blk = hip.CsrBlock(ctx, 30_000, 30_000, rp2, ci2, va2, None, False)
+    blk.bake()
+    assert blk.get("sj_long_rows") > 0 and blk.owns_matrix() == 0
+    assert blk.release_matrix() == 0
+    with pytest.raises(Exception):  # not a subset of what the plan owns
+        hip.call("spmv_hip_csr_plan_release_matrix", blk.plan, 3)
+    blk.values_changed()  # still allowed
+    blk.free()
+    # (3) symmetric storage owns nothing either
+    lrp, lci, lva, dg = lower_split(rp, ci, va)
+    blk = hip.CsrBlock(ctx, nr, nr, lrp, lci, lva, dg, True)
+    blk.bake()
+    assert blk.get("sym_sj") == 1 and blk.owns_matrix() == 0
+    blk.free()
+    dx.free()
+    # (4) a diagonal form (27-point stencil, values by offset)
+    c2 = hip.Context(0)
+    c2.set_option("lat_min_nnz", 0)
+    c2.set_option("lx_min_nnz", 0)
+    c2.set_option("const_diagonals", 0)
+    n = 20
+    rp, ci, va = poisson.stencil27_csr(n)
+    ci = ci.astype(np.int32)
+    va = va * rng.uniform(0.5, 1.5, len(va))  # not symmetric: the full form
+    N = n ** 3
+    x = rng.uniform(-1, 1, N)
+    blk = hip.CsrBlock(c2, N, N, rp, ci, va, None, False)
+    blk.bake()
+    assert blk.get("wdia") == 1 and blk.owns_matrix() == 3
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    assert blk.release_matrix() == 3
+    dx, dy = c2.upload(x), c2.upload(np.full(N, np.nan))
+    blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+    assert np.array_equal(dy.numpy(), y_ref)
+    with pytest.raises(Exception):
+        blk.set("wdia", 0)
+    with pytest.raises(Exception):
+        blk.values_changed()
+    for b in (dx, dy):
+        b.free()
+    blk.free()
+    c2.close()
+
+
 def test_mixed_precision_sliced_jagged_bit_exact(sj_ctx):
     """plan_bake_values_f32f64 on a plan in the sliced jagged form: the fp32 twin
     of the jagged copy (and, for the long rows, the caller's fp32 CSR values).

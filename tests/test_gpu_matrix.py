@@ -598,13 +598,14 @@ def test_petsc_file_of_a_ragged_matrix_one_million_rows(exec_, comm, tmp_path, k
     A.close()
     # ... and read with symmetric = true (demos/cg.cpp:47: the reader keeps the
     # strictly lower part and the diagonal, Matrix.cpp:337-349): the merged
-    # matrix in the sliced jagged form where the long rows leave room for it,
-    # else the transposed map -- the reference's symmetric loop bit for bit
+    # matrix in the sliced jagged form, the long rows of the stored block (the
+    # tail) by the long-row kernels -- the reference's symmetric loop bit for bit
     from util import lower_split
     lrp, lci, lva, ldg = lower_split(rp, ci, va)
     A = host.read_petsc_binary_matrix(fa, comm, exec_, True, host.P2P_NONBLOCKING)
     assert A.symmetric() and A.rows() == N
-    assert A.plan_get("sym_sj") == (1 if kind == "fem" else 0)
+    assert A.plan_get("sym_sj") == 1
+    assert (A.plan_get("sj_long_rows") > 0) == (kind == "fem_tail")
     exec_.memset(d_y, 0xFF, 8 * N)
     A.mult(d_x, d_y)
     assert np.array_equal(exec_.copy_to_host(d_y, N),
@@ -774,6 +775,60 @@ def test_full_size_kernels_agree_bit_for_bit(exec_, comm, n):
                 assert np.array_equal(exec_.copy_to_host(d_y, N), y_dia), "gather"
             B.close()
     exec_.free(d_x), exec_.free(d_y)
+
+
+def test_release_csr_keeps_a_fem_matrix_near_one_copy(exec_, comm):
+    """PLAN MEMORY at the mirror: a 10 M-row x 15 FEM-like
+    matrix in the sliced jagged form holds the plan's copy (values + 16-bit
+    codes) beside the caller's CSR arrays -- 1.9 times the CSR bytes resident.
+    CSRMatrix::release_csr gives colind and values back: at most 1.2 times the
+    CSR bytes stay, mult() returns the same bits, the fused dot still works, and
+    the context option "release_csr" does it at creation."""
+    from spmv_amd import _lib
+    ctx = exec_.context
+    N = 10_000_000
+    A = host.Matrix.create_fem_like(comm, exec_, N)
+    rows, cols, nnz = A.blocks()["local"]
+    csr_bytes = nnz * 12 + (rows + 1) * 4
+    plan_bytes = A.plan_get("plan_kib") * 1024
+    assert A.plan_get("sjds") == 1 and A.plan_get("sj_long_rows") == 0
+    assert 0.8 < plan_bytes / csr_bytes < 1.1
+    d_x, d_y = exec_.alloc(N), exec_.alloc(N)
+    _lib.call("spmv_hip_fill_gaussian_f64", ctx, N, 0, N, d_x, None)
+    A.mult(d_x, d_y)
+    y_before = exec_.copy_to_host(d_y, N)
+    freed = A.release_csr()
+    assert freed == nnz * 12
+    assert A.release_csr() == 0  # once
+    resident = csr_bytes - freed + plan_bytes
+    assert resident <= 1.2 * csr_bytes, resident / csr_bytes
+    exec_.memset(d_y, 0xFF, 8 * N)
+    A.mult(d_x, d_y)
+    assert np.array_equal(exec_.copy_to_host(d_y, N), y_before)
+    with pytest.raises(Exception):  # the CSR-order kernels would read freed memory
+        A.plan_set("sjds", 0)
+    assert not A.enable_mixed()  # the fp64 values it would convert are gone
+    # cg() on the released matrix (fused dot, 3 launches per iteration)
+    d_b, d_s = exec_.alloc(N), exec_.alloc(N)
+    _lib.call("spmv_hip_fill_gaussian_f64", ctx, N, 0, N, d_b, None)
+    k, hist = host.cg(comm, exec_, A, d_b, d_s, 5, 0.0)
+    assert k == 5 and np.isfinite(hist).all()
+    A.close()
+    # ... and by itself under the context option
+    _lib.call("spmv_hip_ctx_set_option", ctx, b"release_csr", 1)
+    try:
+        B = host.Matrix.create_fem_like(comm, exec_, N)
+    finally:
+        _lib.call("spmv_hip_ctx_set_option", ctx, b"release_csr", 0)
+    assert B.release_csr() == 0  # already given back
+    exec_.memset(d_y, 0xFF, 8 * N)
+    B.mult(d_x, d_y)
+    assert np.array_equal(exec_.copy_to_host(d_y, N), y_before)
+    k2, hist2 = host.cg(comm, exec_, B, d_b, d_s, 5, 0.0)
+    assert np.array_equal(hist2, hist)
+    B.close()
+    for p in (d_x, d_y, d_b, d_s):
+        exec_.free(p)
 
 
 def _mem_available_gb():
