@@ -90,7 +90,7 @@ def parse():
     ap.add_argument("--cpu-n", type=int, default=0,
                     help="grid of the CPU baseline (0 = the benchmark's own, "
                          "or 256 when host memory is short)")
-    ap.add_argument("--cpu-iters", type=int, default=10)
+    ap.add_argument("--cpu-iters", type=int, default=100)
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="0 = physical cores this job may use")
     ap.add_argument("--reducer-kernels", action="store_true",
@@ -478,7 +478,7 @@ def pmc_traffic(record, kernel_name, n, world):
     if world != 1:
         return None, None
     try:
-        for rnd in ("r04", "r03"):
+        for rnd in ("r05", "r04", "r03"):
             path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary.json")
             if os.path.exists(path):
                 rec = json.load(open(path)).get("records", {}).get(record)
@@ -749,6 +749,12 @@ def compact_line(out, detail_path):
         cg = r["ragged"].get("fem_sym_cg")
         if cg:
             roof["ragged"]["fem_sym_cg_iters_per_s"] = sig(cg["iters/s"])
+        # plan memory on top of the caller's CSR arrays (x their bytes); with
+        # CSRMatrix::release_csr the general sliced jagged plans without long
+        # rows give colind and values back: resident = 1 + this - 12 nnz / csr
+        roof["ragged_plan_over_csr"] = {
+            k: sig(out[k]["plan_extra_bytes"] / out[k]["csr_bytes"], 3)
+            for k in r["ragged"] if k in out and "csr_bytes" in out[k]}
     if "plan" in out and r["algorithmic_bytes_per_launch"]:
         roof["plan_extra_over_csr_bytes"] = sig(
             out["plan"]["plan_extra_bytes"] / out["plan"]["csr_bytes"], 3)

@@ -225,6 +225,9 @@ int spmv_hip_csr_plan_destroy(spmv_hip_csr_plan* plan);
  *   constant diagonals  (either storage; ctx option "const_diagonals") when
  *                    every diagonal is constant, bit for bit, the plan keeps
  *                    no values at all: one number per diagonal + the mask.
+ * plan_create and plan_bake_values wait for `stream` before they start (the
+ * plan's clock counts the plan's work) and return after the plan's own kernels
+ * have completed.
  * Anything else: SPMV_HIP_ENOTSUP, nothing changes.  Costs (offsets + 1) * 8 B
  * per row of device memory (constant diagonals: 1 or 4 B per row).  A launch that passes these very `values` (and
  * `diagonal`) pointers takes the diagonal-form kernel; a launch with other
@@ -250,7 +253,9 @@ int spmv_hip_csr_plan_bake_values_f32(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan
  *   diagonal forms       the checks run again on the new values (constant
  *                        diagonals? still symmetric?) and the copy is rebuilt
  *                        in the form they allow; a matrix the forms no longer
- *                        hold falls back to the CSR-order kernels;
+ *                        hold falls back to the CSR-order kernels (no other
+ *                        form is built inside this call: bake again for the
+ *                        sliced jagged form);
  *   fp32 copies of the mixed SpMV likewise.
  * A plan without a baked copy: nothing to do.  SPMV_HIP_OK in all these cases
  * -- launches with the same pointers then return the NEW matrix's product.

@@ -1,6 +1,9 @@
 // Shared internals of libspmv_hip.so (gfx950 only).
 #pragma once
 
+#include <mutex>
+#include <vector>
+
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -83,7 +86,11 @@ struct spmv_hip_ctx {
   // one-sided halo: how long a put kernel polls for its neighbour before the
   // exchange fails with SPMV_HIP_EPEER ("put_timeout_ms")
   int put_timeout_ms = 60000;
-  const int32_t* watched[16] = {}; // error words of the put windows (see below)
+  // error words of the put / reduction windows (see below): a growable list
+  // under a mutex -- a context may carry any number of one-sided maps, and
+  // threads of an application may build them side by side
+  std::vector<const int32_t*> watched;
+  std::mutex watched_mutex;
   // the device Poisson generator's non-symmetric variant ("poisson_skew_ppm":
   // lower neighbours -1 - s, upper -1 + s, s = value * 1e-6; 0 = the Poisson
   // matrix).  For measurements of kernels on matrices that are not symmetric.
@@ -95,7 +102,8 @@ struct spmv_hip_ctx {
 
 // error words (pinned host memory, written by kernels) the context looks at
 // whenever the host synchronises: a non-zero one = SPMV_HIP_EPEER
-void spmv_ctx_watch(spmv_hip_ctx* ctx, const int32_t* word, bool add);
+// (false: no memory for the entry -- the window must not be used unwatched)
+bool spmv_ctx_watch(spmv_hip_ctx* ctx, const int32_t* word, bool add);
 int spmv_ctx_check_watched(const spmv_hip_ctx* ctx);
 
 #define SPMV_CHECK_HIP(expr)                                                   \

@@ -364,6 +364,9 @@ struct spmv_hip_csr_plan {
   // arrays the caller has freed (spmv_hip_csr_plan_release_matrix): bit 0 =
   // colind, bit 1 = values -- compared, never read, from then on
   int released = 0;
+  // set while plan_values_changed re-runs the value-dependent checks: no form
+  // that was not there before is built (no allocation inside that call)
+  int no_new_forms = 0;
   bool structure_baked() const
   {
     return row_list || lx_lidx || lat_tab || slat_mask || t_ptr || lxw_rec

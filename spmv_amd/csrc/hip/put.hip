@@ -219,15 +219,16 @@ int spmv_hip_put_create(spmv_hip_ctx* ctx, size_t stage_bytes,
   if (e == hipSuccess)
     e = hipHostMalloc(reinterpret_cast<void**>(&p->host_err), sizeof(int32_t),
                       hipHostMallocMapped);
+  bool watched = false;
   if (e == hipSuccess) {
     *p->host_err = 0;
-    spmv_ctx_watch(ctx, p->host_err, true);
+    watched = spmv_ctx_watch(ctx, p->host_err, true);
   }
-  if (e != hipSuccess) {
+  if (e != hipSuccess || !watched) { // (never a window whose failures go unseen)
     (void)hipFree(p->window);
     (void)hipHostFree(p->host_err);
     delete p;
-    return static_cast<int>(e);
+    return e != hipSuccess ? static_cast<int>(e) : SPMV_HIP_ENOMEM;
   }
   memset(ipc_handle, 0, SPMV_HIP_IPC_HANDLE_BYTES);
   memcpy(ipc_handle, &h, sizeof(h));
@@ -516,7 +517,13 @@ int spmv_hip_reduce_create(spmv_hip_ctx* ctx, int nranks, int rank,
     return static_cast<int>(e);
   }
   *r->host_err = 0;
-  spmv_ctx_watch(ctx, r->host_err, true);
+  if (!spmv_ctx_watch(ctx, r->host_err, true)) {
+    (void)hipFree(r->window);
+    (void)hipFree(r->dev_peers);
+    (void)hipHostFree(r->host_err);
+    delete r;
+    return SPMV_HIP_ENOMEM;
+  }
   (void)hipHostGetDevicePointer(reinterpret_cast<void**>(&r->dev_err), r->host_err, 0);
   r->host_peers[rank] = r->window;
   if (nranks == 1) { // (nobody to connect)

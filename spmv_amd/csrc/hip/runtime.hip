@@ -11,22 +11,32 @@
 // The put windows' error words (put.hip): a put kernel that gave up waiting for
 // its neighbour leaves NaN ghosts and sets its word; the host learns of it at
 // the next point where it waits for the device anyway.
-void spmv_ctx_watch(spmv_hip_ctx* ctx, const int32_t* word, bool add)
+bool spmv_ctx_watch(spmv_hip_ctx* ctx, const int32_t* word, bool add)
 {
-  for (auto& w : ctx->watched) {
-    if (add && w == nullptr) {
-      w = word;
-      return;
+  std::lock_guard<std::mutex> lock(ctx->watched_mutex);
+  auto& ws = ctx->watched;
+  if (add) {
+    try {
+      ws.push_back(word);
+    } catch (...) {
+      return false;
     }
-    if (!add && w == word)
-      w = nullptr;
+    return true;
   }
+  for (size_t i = 0; i < ws.size(); ++i)
+    if (ws[i] == word) {
+      ws[i] = ws.back();
+      ws.pop_back();
+      break;
+    }
+  return true;
 }
 
 int spmv_ctx_check_watched(const spmv_hip_ctx* ctx)
 {
+  std::lock_guard<std::mutex> lock(const_cast<spmv_hip_ctx*>(ctx)->watched_mutex);
   for (const int32_t* w : ctx->watched)
-    if (w && *reinterpret_cast<const volatile int32_t*>(w))
+    if (*reinterpret_cast<const volatile int32_t*>(w))
       return SPMV_HIP_EPEER;
   return SPMV_HIP_OK;
 }

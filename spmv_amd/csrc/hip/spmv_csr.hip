@@ -1685,8 +1685,11 @@ int spmv_hip_csr_plan_bake_values_f64(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan
   }
   // a plan in the sliced jagged form keeps its own copy of the values in that
   // order (the diagonal forms never coexist with it)
+  // (not from plan_values_changed: that call builds no new form and allocates
+  // nothing -- a matrix the diagonal forms no longer hold goes back to the
+  // CSR-order kernels, as its contract says)
   if (!plan->symmetric && values && rc == SPMV_HIP_ENOTSUP && plan->sj_wanted
-      && !plan->sj_lenperm) {
+      && !plan->sj_lenperm && !plan->no_new_forms) {
     // the structure of the sliced jagged form, now that it is known to be used
     const auto t0 = std::chrono::steady_clock::now();
     const int rb = spmv_sjds_build(plan, plan->rowptr0, plan->colind0,
@@ -1728,8 +1731,11 @@ int spmv_hip_csr_plan_bake_values_f32(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan
   } else if (!plan->symmetric && rc == SPMV_HIP_OK) {
     (void)spmv_wdia_bake_f32(plan, nullptr, st);
   }
+  // (not from plan_values_changed: that call builds no new form and allocates
+  // nothing -- a matrix the diagonal forms no longer hold goes back to the
+  // CSR-order kernels, as its contract says)
   if (!plan->symmetric && values && rc == SPMV_HIP_ENOTSUP && plan->sj_wanted
-      && !plan->sj_lenperm) {
+      && !plan->sj_lenperm && !plan->no_new_forms) {
     // the structure of the sliced jagged form, now that it is known to be used
     const auto t0 = std::chrono::steady_clock::now();
     const int rb = spmv_sjds_build(plan, plan->rowptr0, plan->colind0,
@@ -1824,6 +1830,11 @@ int spmv_hip_csr_plan_values_changed(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan,
   // they no longer hold: ENOTSUP = back to the CSR-order kernels, which is a
   // correct outcome of this call)
   if (rc == SPMV_HIP_OK && (plan->sdia_val || plan->wdia_val)) {
+    struct NoNewForms { // (reset on every path out of this block)
+      spmv_hip_csr_plan* p;
+      ~NoNewForms() { p->no_new_forms = 0; }
+    } guard{plan};
+    plan->no_new_forms = 1;
     const void* v32 = plan->sdia32_values0 ? plan->sdia32_values0
                                            : plan->wdia32_values0;
     if (plan->sdia_val ? plan->sdia_elem == 8 : plan->wdia_elem == 8) {
