@@ -275,9 +275,12 @@ int spmv_hip_csr_plan_values_changed(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan,
  *                        general plan in a diagonal form (values by offset,
  *                        or no values at all where every diagonal is constant)
  *                        or in the sliced jagged form WITHOUT long rows (those
- *                        are streamed from the caller's arrays); 0 otherwise
- *                        (CSR-order kernels, LX, XW, lattice kernels, symmetric
- *                        storage, an fp32 twin baked for the mixed SpMV).
+ *                        are streamed from the caller's arrays), and for
+ *                        symmetric storage in the merged sliced jagged form
+ *                        without long rows (its kernel reads the merged copy,
+ *                        `rowptr` and `diagonal`); 0 otherwise (CSR-order
+ *                        kernels, LX, XW, lattice kernels, the other symmetric
+ *                        forms, an fp32 twin baked for the mixed SpMV).
  *                        `rowptr` is never given up (4 B per row).
  *   plan_release_matrix  the caller frees the arrays of `mask` (a subset of
  *                        what plan_owns_matrix reports, else SPMV_HIP_EINVAL).
@@ -288,7 +291,9 @@ int spmv_hip_csr_plan_values_changed(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan,
  *                        (a drop included), plan_set of a key that selects
  *                        another kernel, a launch the baked form does not take
  *                        (other pointers, an x that is not 16-byte aligned).
- *                        Irreversible for the plan's lifetime. */
+ *                        A symmetric plan also drops what only those refused
+ *                        paths read (transposed map, value positions: 16 B per
+ *                        stored entry).  Irreversible for the plan's lifetime. */
 int spmv_hip_csr_plan_owns_matrix(const spmv_hip_csr_plan* plan, int* mask);
 int spmv_hip_csr_plan_release_matrix(spmv_hip_csr_plan* plan, int mask);
 /* ... and the fp32 copy for spmv_hip_csr_spmv_f32f64 (mixed precision) on a

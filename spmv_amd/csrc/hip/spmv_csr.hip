@@ -1466,8 +1466,16 @@ static int sym_sj_bake(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan, const T* valu
 // the arrays a launch with the baked pointers does not read (plan_owns_matrix)
 static int plan_owned_mask(const spmv_hip_csr_plan* pl)
 {
-  if (pl->symmetric || pl->nnz == 0)
+  if (pl->nnz == 0)
     return 0;
+  // symmetric storage in the merged sliced jagged form, no long rows (those
+  // are streamed from the caller's arrays): the kernel reads the merged copy,
+  // the caller's row pointer and diagonal
+  if (pl->symmetric)
+    return pl->sym_det && pl->sym_sj && pl->sj && pl->sjt && pl->sjt->sj_val
+                   && pl->sjt->sj_values0 && pl->sj_nlong == 0 && pl->num_cols >= 2
+               ? 3
+               : 0;
   // an fp32 twin for the mixed SpMV: its launches may fall back to CSR order
   if (pl->sdia32_val || pl->wdia32_val || pl->sj_val32)
     return 0;
@@ -1483,10 +1491,13 @@ static int plan_owned_mask(const spmv_hip_csr_plan* pl)
 // does a launch with these operands take the form that owns the matrix?
 template <typename T>
 static bool released_launch_ok(const spmv_hip_csr_plan* pl, const T* values,
-                               const T* in)
+                               const T* in, const T* diagonal)
 {
   if (pl->algo != SPMV_HIP_ALGO_ROWBLOCK || plan_owned_mask(pl) == 0)
     return false;
+  if (pl->symmetric)
+    return pl->sjt->sj_elem == (int)sizeof(T) && values == pl->sjt->sj_values0
+           && diagonal == pl->sj_diag0 && aligned16(in);
   if (pl->sdia && pl->sdia_val && pl->sdia_general)
     return pl->sdia_elem == (int)sizeof(T) && values == pl->sdia_values0;
   if (pl->wdia && pl->wdia_val)
@@ -1791,6 +1802,19 @@ int spmv_hip_csr_plan_release_matrix(spmv_hip_csr_plan* plan, int mask)
 {
   SPMV_REQUIRE(plan && mask >= 0 && (mask & ~plan_owned_mask(plan)) == 0);
   plan->released |= mask;
+  if (plan->symmetric && plan->released == 3 && plan->sjt) {
+    // what only the refused paths would read goes too: the transposed map (the
+    // fallback kernel) and the positions of the merged values (values_changed)
+    // -- 16 B per stored entry: symmetric storage then holds the merged copy,
+    // the row pointer and the diagonal, 1.75 times its own CSR bytes
+    SPMV_CHECK_HIP(hipSetDevice(plan->ctx->device));
+    SPMV_CHECK_HIP(hipDeviceSynchronize());
+    (void)hipFree(plan->t_pos);
+    (void)hipFree(plan->t_row);
+    plan->t_pos = plan->t_row = nullptr;
+    (void)hipFree(plan->sjv_map);
+    plan->sjv_map = nullptr;
+  }
   return SPMV_HIP_OK;
 }
 
@@ -1900,7 +1924,8 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
   // arrays given up (plan_release_matrix): no key may select a kernel that
   // would read them
   if (plan->released)
-    for (const char* k : {"algo", "sdia", "wdia", "sjds", "lat", "lx", "lxw", "xw"})
+    for (const char* k : {"algo", "sdia", "wdia", "sjds", "lat", "lx", "lxw", "xw",
+                          "sym_det", "slat"})
       SPMV_REQUIRE(strcmp(key, k) != 0);
   if (!strcmp(key, "algo")) {
     // ROWLIST needs the list built at plan creation
@@ -2226,7 +2251,8 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
       b += 4 * plan->sj_units * plan->sj_unit;
     if (plan->sjt && plan->sjt->sj_lenperm) { // symmetric storage: the merged matrix
       const spmv_hip_csr_plan* c = plan->sjt;
-      b += 4 * (n + 1) + 4 * c->nnz; // its row pointer, the positions of its values
+      // its row pointer, the positions of its values (until released)
+      b += 4 * (n + 1) + (plan->sjv_map ? 4 * c->nnz : 0);
       if (plan->sj_long_rows) // the stored block's long rows: list, table, codes
         b += 4 * (int64_t)plan->sj_nlong + 4 * plan->sj_lt_entries
              + 16 * (int64_t)plan->sj_lt_nsg + 2 * plan->sj_lt_codes_n
@@ -2239,7 +2265,7 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
         b += (int64_t)c->sj_elem * c->sj_units * c->sj_unit;
     }
     if (plan->t_ptr)
-      b += 4 * (n + 1) + 8 * nnz;
+      b += 4 * (n + 1) + (plan->t_row ? 8 * nnz : 0);
     if (plan->zw_table)
       b += 4 * (int64_t)plan->zw_slots;
     *value = (int)((b + 1023) / 1024);
@@ -2332,7 +2358,7 @@ int spmv_hip_csr_spmv_f64(spmv_hip_ctx* ctx, const spmv_hip_csr_plan* plan,
   SPMV_REQUIRE(in && out);
   SPMV_REQUIRE(num_non_zeros == 0 || (rowptr && colind && values));
   // arrays given up: only the form that owns the matrix may run
-  SPMV_REQUIRE(!plan->released || released_launch_ok(plan, values, in));
+  SPMV_REQUIRE(!plan->released || released_launch_ok(plan, values, in, diagonal));
   hipStream_t st = spmv_stream(ctx, stream);
   if (plan->symmetric) {
     DotOut dot;
@@ -2419,7 +2445,7 @@ int spmv_hip_csr_spmv_f32(spmv_hip_ctx* ctx, const spmv_hip_csr_plan* plan,
     return SPMV_HIP_OK;
   SPMV_REQUIRE(in && out);
   SPMV_REQUIRE(num_non_zeros == 0 || (rowptr && colind && values));
-  SPMV_REQUIRE(!plan->released || released_launch_ok(plan, values, in));
+  SPMV_REQUIRE(!plan->released || released_launch_ok(plan, values, in, diagonal));
   hipStream_t st = spmv_stream(ctx, stream);
   if (plan->symmetric)
     return spmv_run_symmetric_f32(plan, st, rowptr, colind, values, diagonal,

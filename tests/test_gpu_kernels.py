@@ -1078,9 +1078,9 @@ def test_plan_owns_the_matrix_and_the_caller_releases_it(sj_ctx):
     spmv_hip_csr_plan_release_matrix the caller frees them: launches with the
     same (now dangling) pointers return the same bits, and whatever would read
     the arrays is refused cleanly -- plan_values_changed, a re-bake, a knob that
-    selects a CSR-order kernel, a launch with other pointers.  Plans that still
-    stream the caller's arrays (long rows, no baked copy, symmetric storage)
-    own nothing."""
+    selects a CSR-order kernel, a launch with other pointers.  Symmetric storage
+    in the merged form likewise (its transposed map goes too).  Plans that still
+    stream the caller's arrays (long rows, no baked copy) own nothing."""
     ctx = sj_ctx
     rng = np.random.default_rng(0x0A4)
     # (1) sliced jagged, ragged rows, no long ones
@@ -1142,11 +1142,35 @@ def test_plan_owns_the_matrix_and_the_caller_releases_it(sj_ctx):
         hip.call("spmv_hip_csr_plan_release_matrix", blk.plan, 3)
     blk.values_changed()  # still allowed
     blk.free()
-    # (3) symmetric storage owns nothing either
+    # (3) symmetric storage in the merged form, no long rows: the kernel reads
+    # the merged copy, the row pointer and the diagonal -- colind and values go,
+    # and with them the plan's transposed map and value positions (16 B per
+    # stored entry, needed by the refused paths only)
     lrp, lci, lva, dg = lower_split(rp, ci, va)
     blk = hip.CsrBlock(ctx, nr, nr, lrp, lci, lva, dg, True)
     blk.bake()
-    assert blk.get("sym_sj") == 1 and blk.owns_matrix() == 0
+    assert blk.get("sym_sj") == 1 and blk.owns_matrix() == 3
+    kib0 = blk.get("plan_kib")
+    srefs = {ab: oracle.csr_spmv_sym(lrp, lci, lva, dg, x, ab[0], ab[1], y0)
+             for ab in ((1.0, 0.0), (-0.5, 0.75), (2.0, 0.0))}
+    assert blk.release_matrix() == 3
+    assert kib0 - blk.get("plan_kib") >= 16 * len(lva) // 1024 - 1
+    for (alpha, beta), y_ref in srefs.items():
+        dy = ctx.upload(np.full(nr, np.nan) if beta == 0 else y0)
+        blk.mult(alpha, dx.ptr, beta, dy.ptr)
+        assert np.array_equal(dy.numpy(), y_ref), ("symmetric", alpha, beta)
+        dy.free()
+    for bad in (lambda: blk.values_changed(), lambda: blk.set("sjds", 0),
+                lambda: blk.set("sym_det", 0), lambda: blk.bake()):
+        with pytest.raises(Exception):
+            bad()
+    blk.free()
+    # ... with long rows (streamed from the caller's arrays): nothing
+    trp, tci, tva, tdg = lower_split(rp2, ci2, va2)
+    blk = hip.CsrBlock(ctx, 30_000, 30_000, trp, tci, tva, tdg, True)
+    blk.bake()
+    assert blk.get("sym_sj") == 1 and blk.get("sj_long_rows") > 0
+    assert blk.owns_matrix() == 0
     blk.free()
     dx.free()
     # (4) a diagonal form (27-point stencil, values by offset)
