@@ -1313,6 +1313,73 @@ def test_unstructured_ranks_threaded(world, N, seed):
     tw.run(rank_body, gpu=True)
 
 
+def test_symmetric_fem_matrix_with_long_rows_on_three_ranks():
+    """create_matrix(..., symmetric = true) on a FEM-like matrix with a tail of
+    long rows, distributed over three ranks (threads): every rank's local block
+    takes the merged sliced jagged form with its long rows on the long-row
+    kernels, the remote block is general -- update + mult equal the oracle's
+    three-rank simulation of Matrix.cpp:337-349 + csr_kernels.cpp:26-40 bit for
+    bit, for the blocking and the overlapping model, and cg() runs on it."""
+    import scipy.sparse as sp
+    from thread_world import ThreadWorld
+    from util import lower_split
+    world, N = 3, 45_000
+    rp0, ci0, va0 = poisson.fem_like_csr(N, jitter=64, layer=900, tail_permille=20,
+                                         tail_min=150, tail_max=900, tail_stride=5)
+    lrp, lci, lva, dg = lower_split(rp0, ci0, va0)
+    L = sp.csr_matrix((lva, lci, lrp), shape=(N, N))
+    # strictly diagonally dominant: SPD
+    dg = np.abs(L).sum(1).A1 + np.abs(L).sum(0).A1 + 1.0
+    S = (L + L.T + sp.diags(dg)).tocsr()
+    S.sort_indices()
+    rp, ci, va = S.indptr.astype(np.int32), S.indices.astype(np.int64), S.data
+    x = np.random.default_rng(31).uniform(-1, 1, N)
+    ranges = oracle.owner_ranges(world, N)
+    locs = [oracle.localise_rows(rp, ci, va, int(ranges[r]), int(ranges[r + 1]))
+            for r in range(world)]
+    refs = {cm: oracle.dist_spmv(world, rp, ci, va, x, True, cm)
+            for cm in (host.P2P_BLOCKING, host.P2P_NONBLOCKING)}
+    b = oracle.csr_spmv(rp, ci.astype(np.int32), va, np.ones(N))
+    x_ref, k_ref, _ = oracle.dist_cg(world, rp, ci, va, b, 60, 1e-10, True,
+                                     host.P2P_NONBLOCKING)
+    tw = ThreadWorld(world, timeout=60.0)
+    seen = []
+
+    def rank_body(rank, comm, exec_):
+        from spmv_amd import _lib
+        _lib.call("spmv_hip_ctx_set_option", exec_.context, b"sj_min_nnz", 0)
+        r0, r1 = int(ranges[rank]), int(ranges[rank + 1])
+        lrp_, lci_, lva_, ghosts = locs[rank]
+        for cm in (host.P2P_BLOCKING, host.P2P_NONBLOCKING):
+            A = host.Matrix.create_matrix(comm, exec_, lrp_, lci_, lva_, r1 - r0,
+                                          r1 - r0, [], ghosts, True, cm)
+            assert A.plan_get("sym_sj") == 1 and A.plan_get("sj_long_rows") > 0
+            l2g = A.col_map()
+            d_x = exec_.alloc(l2g.local_size() + l2g.num_ghosts())
+            d_y = exec_.alloc(r1 - r0)
+            exec_.copy_from_host(d_x, x[r0:r1])
+            exec_.memset(d_y, 0xFF, 8 * (r1 - r0))
+            l2g.update(d_x)
+            A.mult(d_x, d_y)
+            exec_.synchronize()
+            y = tw.gather(rank, exec_.copy_to_host(d_y, r1 - r0))
+            assert np.array_equal(y, refs[cm]), (rank, cm)
+            if cm == host.P2P_NONBLOCKING:
+                d_b, d_s = exec_.alloc(r1 - r0), exec_.alloc(r1 - r0)
+                exec_.copy_from_host(d_b, b[r0:r1])
+                k, hist = host.cg(comm, exec_, A, d_b, d_s, 60, 1e-10)
+                sol = tw.gather(rank, exec_.copy_to_host(d_s, r1 - r0))
+                assert abs(k - k_ref) <= 1
+                assert np.linalg.norm(sol - x_ref) <= 1e-8 * np.linalg.norm(x_ref)
+                exec_.free(d_b), exec_.free(d_s)
+            A.close()
+            exec_.free(d_x), exec_.free(d_y)
+        seen.append(rank)
+
+    tw.run(rank_body, gpu=True)
+    assert sorted(seen) == list(range(world))
+
+
 @pytest.mark.parametrize("symmetric", [False, True])
 def test_cg_consumer_reductions_equal_reducer_kernels(exec_, comm, symmetric):
     """CgOptions::consumer_reductions (the one-rank default: the update kernels
