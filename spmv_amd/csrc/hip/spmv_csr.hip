@@ -2161,14 +2161,17 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
   else if (!strcmp(key, "sj_max_chunks"))
     *value = plan->sj_lenperm ? plan->sj_maxk
              : plan->sjt && plan->sjt->sj_lenperm ? plan->sjt->sj_maxk : 0;
-  else if (!strcmp(key, "sj_far_permille"))
-    *value = plan->sj_lenperm && plan->nnz > 0
-                 ? (int)((plan->sj_far * 1000 + plan->nnz - 1) / plan->nnz)
-                 : 0;
-  else if (!strcmp(key, "sj_staged_bytes_per_entry_x100"))
-    *value = plan->sj_lenperm && plan->nnz > 0
-                 ? (int)(plan->sj_sumk * 12800 / plan->nnz)
-                 : 0;
+  else if (!strcmp(key, "sj_far_permille")) {
+    // (symmetric storage: of the merged matrix)
+    const spmv_hip_csr_plan* c
+        = plan->sj_lenperm ? plan : (plan->sjt && plan->sjt->sj_lenperm ? plan->sjt : nullptr);
+    *value = c && c->nnz > 0 ? (int)((c->sj_far * 1000 + c->nnz - 1) / c->nnz) : 0;
+  }
+  else if (!strcmp(key, "sj_staged_bytes_per_entry_x100")) {
+    const spmv_hip_csr_plan* c
+        = plan->sj_lenperm ? plan : (plan->sjt && plan->sjt->sj_lenperm ? plan->sjt : nullptr);
+    *value = c && c->nnz > 0 ? (int)(c->sj_sumk * 12800 / c->nnz) : 0;
+  }
   else if (!strcmp(key, "sj_pad_permille")) // entries of padding per 1000 stored
     *value = plan->sj_lenperm && plan->nnz > 0
                  ? (int)((plan->sj_units * plan->sj_unit * 1000) / plan->nnz)
@@ -2194,7 +2197,8 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
   else if (!strcmp(key, "sj_long_rows"))
     *value = (plan->sj_lenperm || plan->sjt) ? plan->sj_nlong : 0;
   else if (!strcmp(key, "sj_wide"))
-    *value = plan->sj_lenperm ? plan->sj_wide_alloc : 0;
+    *value = plan->sj_lenperm ? plan->sj_wide_alloc
+             : plan->sjt && plan->sjt->sj_lenperm ? plan->sjt->sj_wide_alloc : 0;
   else if (!strcmp(key, "sj_blocks_per_cu"))
     *value = plan->sj_blocks_per_cu;
   else if (!strcmp(key, "wdia"))

@@ -283,7 +283,11 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
     // (symmetric storage with alpha = 1, beta = 0 -- Matrix::mult, cg(): 1 * s is
     // s and fl(1 * v) is v, so nothing turns: the merged row's products are
     // added to d_i x_i as they are, the plain slice with a starting value)
-    const bool sym_plain = MODE == 3 && alpha == T(1) && beta == T(0);
+    // MODE 4 = MODE 3 with alpha = 1, beta = 0 as its own instantiation: only the
+    // plain slice is compiled in (the two paths in one kernel spilled: 127
+    // registers + 28 B of scratch per lane)
+    constexpr bool SYM = MODE == 3 || MODE == 4;
+    constexpr bool sym_plain = MODE == 4;
     // symmetric storage, one row: where its sum starts and how many stored
     // lower entries precede its column's.  A row whose lower part is LONG gave
     // it to the long-row kernel (launched before this one): it starts from the
@@ -320,14 +324,14 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
       nlow[h] = 0;
       // (symmetric storage: the second slice's row data are loaded when its
       // turn comes -- both sets live across the first slice cost spills)
-      if (MODE == 3 && h > 0)
+      if (SYM && h > 0)
         continue;
       const int32_t myrow_c = myrow[h] < A.num_rows ? myrow[h] : A.num_rows - 1;
-      if constexpr (DOT || MODE == 3)
+      if constexpr (DOT || SYM)
         x_own[h] = in[myrow_c];
       if (beta != T(0))
         y0[h] = out[myrow_c];
-      if constexpr (MODE == 3)
+      if constexpr (SYM)
         sym_row(myrow_c, x_own[h], init[h], nlow[h]);
     }
     const int32_t* cl = A.chunks + (int64_t)b * A.stride;
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
     for (int h = 0; h < SPW; ++h) {
       if (!have[h])
         continue;
-      if (MODE == 3 && h > 0) {
+      if (SYM && h > 0) {
         const int32_t myrow_c = myrow[h] < A.num_rows ? myrow[h] : A.num_rows - 1;
         x_own[h] = in[myrow_c];
         if (beta != T(0))
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
         const SjUnit<uint32_t, E>* cs
             = reinterpret_cast<const SjUnit<uint32_t, E>*>(A.codes + 4 * a_b)
               + (ub_slice[h] - ub_block);
-        if (sym_plain)
+        if constexpr (sym_plain)
           sum = sj_slice<T, TV, uint32_t, true, E, 0>(vs, cs, mylen, lane, s_x, in,
                                                       init[h], alpha);
         else
@@ -411,7 +415,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
             = reinterpret_cast<const SjUnit<uint16_t, E>*>(
                   A.codes + (A.wide_alloc ? 4 : 2) * a_b)
               + (ub_slice[h] - ub_block);
-        if (sym_plain)
+        if constexpr (sym_plain)
           sum = sj_slice<T, TV, uint16_t, false, E, 0>(vs, cs, mylen, lane, s_x, in,
                                                        init[h], alpha);
         else
@@ -420,9 +424,9 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
                                                           beta * y0[h], beta != T(0));
       }
       if (myrow[h] < A.num_rows && in_slice[h]) {
-        const T c = MODE == 3 ? sum : alpha * sum;
+        const T c = SYM ? sum : alpha * sum;
         T y = c;
-        if (beta != T(0) && MODE != 3)
+        if (beta != T(0) && !SYM)
           y = c + beta * y0[h];
         out[myrow[h]] = y;
         if constexpr (DOT)
@@ -519,7 +523,7 @@ int sj_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
   ord.xcd_group = grid >= 8 ? pl->sj_xcd_group : 0;
   ord.num_row_blocks = pl->sj_nblk;
   ord.nt_store = 0;
-  if constexpr (MODE == 3) {
+  if constexpr (MODE == 3 || MODE == 4) {
     // symmetric storage: the long rows of the stored lower block FIRST, by the
     // long-row kernels on the caller's arrays (the parent plan lists them);
     // the slices' kernel below starts those rows from the y they leave
@@ -626,15 +630,21 @@ int sj_run_sym(const spmv_hip_csr_plan* pl, hipStream_t st, const T* diagonal, T
   const spmv_hip_csr_plan* m = pl->sjt;
   if (m->sj_unit != 2)
     return SPMV_HIP_EINVAL;
+  // (alpha = 1, beta = 0 -- Matrix::mult, cg(): 1 * s is s and fl(1 * v) is v,
+  // nothing turns: an instantiation of its own, MODE 4)
+  const bool plain = alpha == T(1) && beta == T(0);
+#define SJ_SYM(WPB, SIGV)                                                      \
+  (plain ? sj_launch<T, WPB, 2, DOT, 4, T, SIGV>(m, st, alpha, in, beta, out, dot, \
+                                                 diagonal, pl->rowptr0, pl)   \
+         : sj_launch<T, WPB, 2, DOT, 3, T, SIGV>(m, st, alpha, in, beta, out, dot, \
+                                                 diagonal, pl->rowptr0, pl))
   if (m->sj_wpb == 8)
-    return sj_launch<T, 8, 2, DOT, 3>(m, st, alpha, in, beta, out, dot, diagonal,
-                                      pl->rowptr0, pl);
+    return SJ_SYM(8, false);
   if (m->sj_wpb == 16 && m->sj_sigma)
-    return sj_launch<T, 8, 2, DOT, 3, T, true>(m, st, alpha, in, beta, out, dot, diagonal,
-                                               pl->rowptr0, pl);
+    return SJ_SYM(8, true);
   if (m->sj_wpb == 16)
-    return sj_launch<T, 16, 2, DOT, 3>(m, st, alpha, in, beta, out, dot, diagonal,
-                                       pl->rowptr0, pl);
+    return SJ_SYM(16, false);
+#undef SJ_SYM
   return SPMV_HIP_EINVAL;
 }
 } // namespace
