@@ -243,6 +243,52 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
   constexpr int CG = NT / 8;
   double dot_acc = 0.0;
   const int num_slots = order_slots(ord);
+  // ROWLDS (symmetric storage, alpha = 1, beta = 0): a row's own data travel
+  // through LDS.  In the sorted blocks a wave's 64 rows lie anywhere in the
+  // block's 1024: its loads of the diagonal, of x_i and of the two row-pointer
+  // words and its store of y_i are 64 different cache lines each -- five such
+  // instructions per slice are four times the L2 requests of the slice's whole
+  // entry stream.  Here the workgroup stages d_i x_i (or, for a row whose lower
+  // part the long-row kernel took, the y it left) for the block's rows with
+  // coalesced loads next to the chunks of x, the lanes pick theirs up in LDS,
+  // leave y_i there, and the block's y goes out coalesced while the next
+  // block's x is staged (the fused dot is taken there too).
+  // YLDS: the general kernel in the sigma layout hands its y over the same way
+  // (alpha sum in LDS; beta y0 and the fused dot are taken at the flush).
+  constexpr bool ROWLDS = MODE == 4;
+  constexpr bool YLDS = ROWLDS || (MODE == 0 && SIG);
+  __shared__ T s_init[ROWLDS ? R : 1];
+  __shared__ T s_y[YLDS ? R : 1];
+  // (general storage: the rows the long-row kernel writes are not the slices'
+  // to store; one bit per row of the block, two sets in turn -- the flush reads
+  // one while the next block's slices fill the other)
+  constexpr bool SKIPS = YLDS && MODE == 0;
+  __shared__ uint32_t s_skip[SKIPS ? 2 : 1][SKIPS ? R / 32 : 1];
+  int skip_set = 0;
+  int32_t flush_r0 = -1; // first row of the block whose y sits in s_y
+  auto flush_y = [&]() {
+    if constexpr (YLDS) {
+      if (flush_r0 >= 0) // uniform
+        for (int i = t; i < R; i += NT) {
+          const int32_t row = flush_r0 + i;
+          if (row < A.num_rows) {
+            const T c = s_y[i];
+            if constexpr (MODE == 0) {
+              if ((s_skip[skip_set ^ 1][i >> 5] >> (i & 31)) & 1u)
+                continue; // a LONG row: the long-row kernel writes its y
+              T y = c;
+              if (beta != T(0))
+                y = c + beta * out[row];
+              out[row] = y;
+            } else {
+              out[row] = c;
+            }
+            if constexpr (DOT)
+              dot_acc += (double)in[row] * (double)c;
+          }
+        }
+    }
+  };
   // the chunk numbers of a block are requested a whole block ahead (the lists
   // are padded to the stride, so the request does not need the block's count)
   int32_t ch[4];
@@ -326,6 +372,8 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
       // turn comes -- both sets live across the first slice cost spills)
       if (SYM && h > 0)
         continue;
+      if constexpr (YLDS)
+        continue; // (the row's data come / go through LDS)
       const int32_t myrow_c = myrow[h] < A.num_rows ? myrow[h] : A.num_rows - 1;
       if constexpr (DOT || SYM)
         x_own[h] = in[myrow_c];
@@ -344,6 +392,26 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
 #ifdef SJ_PROBE
     const long long pq1 = wall_clock64();
 #endif
+    if constexpr (YLDS && !ROWLDS) {
+      flush_y(); // (the previous block's y: its slices are done)
+      if (t < R / 32)
+        s_skip[skip_set][t] = 0u;
+      flush_r0 = r0;
+    }
+    if constexpr (ROWLDS) {
+      flush_y(); // (the previous block's y: its slices are done)
+      for (int i = t; i < R; i += NT) {
+        const int32_t row = r0 + i;
+        T v = T(0);
+        if (row < A.num_rows) {
+          const int32_t la = low_rowptr[row], lb = low_rowptr[row + 1];
+          v = sj_is_long(la, lb, A.sym_long_thr, A.sym_nnz) ? out[row]
+                                                             : diagonal[row] * in[row];
+        }
+        s_init[i] = v;
+      }
+      flush_r0 = r0;
+    }
     for (int c0 = cg; c0 < K; c0 += 4 * CG) {
       pair_t xv[4];
       const int64_t cmax = ((int64_t)A.num_cols - 2) & ~(int64_t)1;
@@ -387,7 +455,9 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
     for (int h = 0; h < SPW; ++h) {
       if (!have[h])
         continue;
-      if (SYM && h > 0) {
+      if constexpr (ROWLDS)
+        init[h] = s_init[myrow[h] - r0];
+      if (SYM && !ROWLDS && h > 0) {
         const int32_t myrow_c = myrow[h] < A.num_rows ? myrow[h] : A.num_rows - 1;
         x_own[h] = in[myrow_c];
         if (beta != T(0))
@@ -423,7 +493,15 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
                                                           init[h], alpha, nlow[h],
                                                           beta * y0[h], beta != T(0));
       }
-      if (myrow[h] < A.num_rows && in_slice[h]) {
+      if constexpr (ROWLDS) {
+        if (in_slice[h]) // (every row of a symmetric child plan is)
+          s_y[myrow[h] - r0] = sum;
+      } else if constexpr (YLDS) {
+        if (in_slice[h])
+          s_y[myrow[h] - r0] = alpha * sum;
+        else if (myrow[h] < A.num_rows)
+          atomicOr(&s_skip[skip_set][(myrow[h] - r0) >> 5], 1u << ((myrow[h] - r0) & 31));
+      } else if (myrow[h] < A.num_rows && in_slice[h]) {
         const T c = SYM ? sum : alpha * sum;
         T y = c;
         if (beta != T(0) && !SYM)
@@ -440,6 +518,8 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
           pr_slice += pq4 - pq3, ++pr_blocks;
     }
 #endif
+    if constexpr (SKIPS)
+      skip_set ^= 1; // (the next flush reads the set this block filled)
   }
 #ifdef SJ_PROBE
   // (100 MHz ticks) waves 0 and WPB - 1 of a few workgroups
@@ -449,6 +529,10 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
            (int)blockIdx.x, wave, pr_blocks, pr_wait, pr_stage, pr_bar, pr_slice,
            wall_clock64() - pr_begin);
 #endif
+  if constexpr (YLDS) {
+    __syncthreads(); // the last block's slices are done
+    flush_y();
+  }
   if constexpr (DOT) {
     // the workgroup's partial (fixed tree: deterministic), the array's unused
     // tail cleared -- spmv_dot_epilogue for WPB waves
@@ -506,8 +590,13 @@ int sj_launch(const spmv_hip_csr_plan* pl, hipStream_t st, T alpha, const T* in,
   A.lt_codes = pl->sj_lt_codes;
   A.lt_coff = pl->sj_lt_coff;
   const size_t lds = (size_t)pl->sj_maxk * kSjChunk * sizeof(T) + 16;
-  int wgs = pl->sj_blocks_per_cu > 0 ? pl->sj_blocks_per_cu
-                                     : sj_wgs_per_cu(WPB, (int64_t)lds + 64);
+  // (MODE 4 keeps the block's d x and y in static LDS beside the staged x)
+  const int64_t lds_static
+      = (MODE == 4 ? 2 : (MODE == 0 && SIG ? 1 : 0))
+        * (int64_t)(64 * WPB * (SIG ? 2 : 1)) * (int64_t)sizeof(T);
+  int wgs = pl->sj_blocks_per_cu > 0
+                ? pl->sj_blocks_per_cu
+                : sj_wgs_per_cu(WPB, (int64_t)lds + lds_static + 64);
   int grid = pl->ctx->num_cus * wgs;
   if (grid > pl->ctx->dot_blocks)
     grid = pl->ctx->dot_blocks;
