@@ -511,6 +511,10 @@ __global__ __launch_bounds__(kBlock) void csr_const_dia_kernel(
 // clamp-free 32-bit index path and test-free sums for the blocks and waves
 // inside the lattice -- no change: with every load and store removed the kernel
 // takes 0.37 ms (its instructions), under the 0.60 the memory side needs.
+// (Round 5, once more with the boundary values loaded from ONE address per wave
+// -- a single line each -- and every shuffle unconditional: 0.615 against 0.594
+// at 512^3, 0.283 against 0.272 at 384^3, bit-equal.  The x[i -+ 1] loads hit
+// the vector L1; the shuffles cost more than they save.)
 // Ablations (0.65 on that box): without the x[i -+ 1] loads 0.56, without the
 // outer neighbour lines 0.61, without both 0.50, without the stores 0.55.
 // ---------------------------------------------------------------------------
