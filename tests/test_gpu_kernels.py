@@ -1433,6 +1433,82 @@ def test_fem_like_generator_matches_numpy_twin(ctx, kind):
         hip.call("spmv_hip_fem_count", ctx.h, C.byref(bad), 1, C.byref(nnz), None)
 
 
+@pytest.mark.parametrize("kind", ["fem", "fem_tail"])
+def test_fem_ten_million_rows_against_the_oracle_itself(kind):
+    """The benchmark's ragged records at THEIR size, compared with the oracle
+    (not kernel against kernel): the 10 M-row FEM-like matrix from the device
+    generator (the numpy twin's arrays, test above; the twin itself takes three
+    minutes at this size) copied to the host -- general storage against
+    oracle.omp_spmv (csr_kernels.cpp:41-51: rows are summed left to right on any
+    thread count), its symmetric storage (device-side lower split,
+    Matrix.cpp:337-349) against the sequential oracle.csr_spmv_sym
+    (csr_kernels.cpp:26-40) -- the sliced jagged form, the long rows' kernels,
+    the merged symmetric form.  Every element identical."""
+    from spmv_amd.host import FemParams
+    avail = 0.0
+    try:
+        with open("/proc/meminfo") as f:
+            avail = next(int(ln.split()[1]) for ln in f
+                         if ln.startswith("MemAvailable")) / 2 ** 20
+    except (OSError, StopIteration):
+        pass
+    if avail < 24:
+        pytest.skip(f"MemAvailable is {avail:.0f} GB: the host copies of the 10 M-row "
+                    "matrix (3.6 GB) and the oracle's vectors need 24 GB")
+    ctx = hip.Context(0)
+    N = 10_000_000
+    kw = FEM_KINDS[kind]
+    prm = FemParams(**poisson.fem_params(N, **kw))
+    d_rp = ctx.empty(N + 1, np.int32)
+    nnz = C.c_int64()
+    hip.call("spmv_hip_fem_count", ctx.h, C.byref(prm), d_rp.ptr, C.byref(nnz), None)
+    d_ci, d_va = ctx.empty(nnz.value, np.int32), ctx.empty(nnz.value, np.float64)
+    hip.call("spmv_hip_fem_fill_f64", ctx.h, C.byref(prm), nnz.value, d_rp.ptr,
+             d_ci.ptr, d_va.ptr, None)
+    rp, ci, va = d_rp.numpy(), d_ci.numpy(), d_va.numpy()
+    x = oracle.gaussian_x_fast(N) + 0.25
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    y_ref = oracle.omp_spmv(rp, ci, va, x, num_threads=threads)
+    # general storage: the plan on the generator's own device arrays
+    blk = hip.CsrBlock(ctx, N, N, rp, ci, va, None, False)
+    blk.bake()
+    assert blk.get("sjds") == 1
+    assert (blk.get("sj_long_rows") > 0) == (kind == "fem_tail")
+    dx, dy = ctx.upload(x), ctx.upload(np.full(N, np.nan))
+    blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+    assert np.array_equal(dy.numpy(), y_ref), "general storage"
+    blk.free()
+    del y_ref
+    # symmetric storage: lower part + diagonal, split on the device
+    o_rp = ctx.empty(N + 1, np.int32)
+    lnnz = C.c_int64()
+    hip.call("spmv_hip_csr_lower_split_count", ctx.h, N, d_rp.ptr, d_ci.ptr, o_rp.ptr,
+             C.byref(lnnz), None)
+    o_ci, o_va = ctx.empty(lnnz.value, np.int32), ctx.empty(lnnz.value, np.float64)
+    o_dg = ctx.empty(N, np.float64)
+    hip.call("spmv_hip_csr_lower_split_fill_f64", ctx.h, N, d_rp.ptr, d_ci.ptr,
+             d_va.ptr, o_rp.ptr, o_ci.ptr, o_va.ptr, o_dg.ptr, None)
+    lrp, lci, lva, ldg = o_rp.numpy(), o_ci.numpy(), o_va.numpy(), o_dg.numpy()
+    for b in (d_rp, d_ci, d_va, o_rp, o_ci, o_va, o_dg):
+        b.free()
+    del rp, ci, va
+    ys_ref = oracle.csr_spmv_sym(lrp, lci, lva, ldg, x)
+    blk = hip.CsrBlock(ctx, N, N, lrp, lci, lva, ldg, True)
+    blk.bake()
+    assert blk.get("sym_sj") == 1
+    assert (blk.get("sj_long_rows") > 0) == (kind == "fem_tail")
+    for alpha, beta in ((1.0, 0.0), (-0.5, 0.0)):
+        dy.write(np.full(N, np.nan))
+        blk.mult(alpha, dx.ptr, beta, dy.ptr)
+        ref = ys_ref if alpha == 1.0 else oracle.csr_spmv_sym(lrp, lci, lva, ldg, x,
+                                                              alpha)
+        assert np.array_equal(dy.numpy(), ref), ("symmetric storage", alpha)
+    blk.free()
+    for b in (dx, dy):
+        b.free()
+    ctx.close()
+
+
 def test_lower_split_on_the_device_matches_the_host_rule(ctx):
     """spmv_hip_csr_lower_split_count / _fill_f64 (symmetric storage from a
     general block: entries below the diagonal kept in order, diagonal entries
