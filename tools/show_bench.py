@@ -1,10 +1,23 @@
-"""Prints the headline numbers of a bench.py JSON line (a log file)."""
+"""Prints the headline numbers of a bench.py run: give it the DETAIL file
+(gpurun_out/bench_detail.json, the full record) or the log with the compact
+line -- then the detail file named in the line is read."""
 import json
+import os
 import sys
 
-for ln in open(sys.argv[1]):
-    if ln.startswith("{"):
-        d = json.loads(ln)
+text = open(sys.argv[1]).read()
+if text.lstrip().startswith("{") and "\n" in text.strip():
+    d = json.loads(text)  # the detail file (indented JSON)
+else:
+    for ln in text.splitlines():
+        if ln.startswith("{"):
+            d = json.loads(ln)
+    if "detail" in d and "plan" not in d:  # the compact line: follow it
+        path = d["detail"]
+        if not os.path.isabs(path):
+            path = os.path.join(os.path.dirname(os.path.dirname(
+                os.path.abspath(__file__))), path)
+        d = json.load(open(path))
 print("value %.1f it/s  ms/step %.3f" % (d["value"], d["ms_per_step"]))
 r = d["roofline"]
 print("main: %.4f ms frac %.3f csr_eq %.3f traffic_frac %s" % (
