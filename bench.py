@@ -17,18 +17,23 @@ SpMV), timed live with HIP events on its own stream inside the timed region;
 `cpu_baseline` is the oracle's OpenMP SpMV + CG (= the reference's CPU path,
 restated) on the host cores this job may use, rank 0 at N = 1 only.
 
-Pricing.  Every `frac` in the line is PHYSICAL: the bytes the kernel's data
-format makes it load and store per launch (`requested_bytes_per_launch`) over
-the measured launch time over the 8 TB/s HBM peak, so it cannot exceed 1.  The
-plans re-encode the CSR arrays at set-up time (16-bit column offsets, no index
-stream at all for lattice matrices, half the values for symmetric ones, NO
-values where every diagonal is constant -- the Poisson matrix; sub-record
-`value_stream_spmv` and `--no-const` time the same matrix with its values
-streamed), so the same launch also has a CSR-EQUIVALENT rate -- SURVEY 8d's algorithmic CSR
-bytes (12 B per entry, row pointer, x, y) over the same time: what a kernel
-streaming the caller's CSR arrays would have to sustain to be as fast.  That
-figure is reported as `csr_equivalent_gbs` / `frac_csr_equivalent` and may
-exceed the peak; it is a speed-up statement, not a bandwidth.
+What the headline times (round 6).  `value`, `ms_per_step` and `roofline`
+belong to the CSR-ORDER plan: the matrix as a general CSR matrix, the
+plan-time lattice analysis (and with it every stencil form) switched off, so
+that the SpMV streams every stored value and an index per entry -- the kernel
+any banded CSR matrix of this shape gets (the LX form: values + 16-bit column
+offsets by LDS-DMA, x windows staged).  `roofline.frac` = SURVEY 8d's
+algorithmic bytes B_csr (12 B per entry, row pointer, x, y) / the kernel's
+average launch time measured live / 8 TB/s; `bytes_per_launch` = B_csr; and
+(B_csr + 9 N 8) / ms_per_step stays below the peak.  What the AUTO plan does
+with THIS matrix -- it finds the lattice and that every diagonal is constant,
+and streams no matrix at all -- is faster and is reported beside it as
+`roofline.specialised` (`--specialised` makes it the main line, as in rounds
+1-5): there `frac_physical` prices the bytes that kernel's own format moves and
+`frac_csr_equivalent` prices B_csr over its time -- a speed-up statement that
+exceeds 1, not a bandwidth.  Likewise `symmetric` (BASELINE configs[3]) is the
+symmetric storage with its values STREAMED, priced with B_sym, the
+constant-diagonal run beside it.
 """
 import argparse
 import json
@@ -96,9 +101,14 @@ def parse():
     ap.add_argument("--reducer-kernels", action="store_true",
                     help="finish dot products with the single-workgroup reducer "
                          "launches even on one rank (experiments)")
+    ap.add_argument("--specialised", action="store_true",
+                    help="the main line on the AUTO plan of the Poisson matrix "
+                         "(lattice + constant diagonals: no matrix stream), as in "
+                         "rounds 1-5; default: the CSR-order plan, the "
+                         "specialised run in roofline.specialised")
     ap.add_argument("--no-lattice", action="store_true",
-                    help="no lattice form: the LX form as any matrix without "
-                         "lattice structure gets it (experiments)")
+                    help="(the default since round 6) no lattice form: the LX "
+                         "form as any matrix without lattice structure gets it")
     ap.add_argument("--no-bake", action="store_true",
                     help="no plan-time symmetry check of the general matrix: the "
                          "lattice kernel on the caller's CSR values (experiments)")
@@ -478,7 +488,7 @@ def pmc_traffic(record, kernel_name, n, world):
     if world != 1:
         return None, None
     try:
-        for rnd in ("r05", "r04", "r03"):
+        for rnd in ("r06", "r05", "r04", "r03"):
             path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary.json")
             if os.path.exists(path):
                 rec = json.load(open(path)).get("records", {}).get(record)
@@ -626,6 +636,38 @@ def matrix_spmv_record(exec_, A, _lib, symmetric, reps, record, grid, workload,
     return rec
 
 
+def cg_record(exec_, comm, host, _lib, A, N, steps, symmetric, record, n, workload):
+    """`steps` timed CG iterations (3 warm-up) on matrix A with the Gaussian
+    right-hand side: iterations/s, the SpMV kernel's live-timed launches and
+    their pricing (SURVEY 8d's bytes and the format's own)."""
+    ctx = exec_.context
+    d_b, d_x = exec_.alloc(N), exec_.alloc(N)
+    _lib.call("spmv_hip_fill_gaussian_f64", ctx, N, 0, N, d_b, None)
+    ws = host.CgWorkspace(exec_)
+    host.cg_ex(comm, exec_, A, d_b, d_x, 3, 0.0, ws)
+    ws.reserve_timing(steps)
+    exec_.synchronize()
+    t0 = time.perf_counter()
+    _, h, ms, launches = host.cg_ex(comm, exec_, A, d_b, d_x, steps, 0.0, ws,
+                                    time_spmv=True, history=True)
+    exec_.synchronize()
+    el = time.perf_counter() - t0
+    kern, algo, req = kernel_of(A, symmetric)
+    ms /= max(launches, 1)
+    tr, src = pmc_traffic(record, kern, n, 1)
+    rec = {"workload": workload, "iters/s": steps / el, "steps": steps,
+           "ms_per_step": el / steps * 1e3, "kernel": kern, "avg_launch_ms": ms,
+           "launches_timed": launches,
+           "cg_rel_residual_k10": float(h[min(10, len(h) - 1)] / h[0])}
+    rec.update(price(ms, algo, req, tr))
+    rec["traffic_source"] = src
+    rec.update(plan_record(A))
+    ws.close()
+    exec_.free(d_b), exec_.free(d_x)
+    return rec
+
+
+
 def mixed_precision_record(exec_, comm, host, _lib, n, rtol=1e-10, kmax=6000):
     """the same solve (Gaussian right-hand side, to rtol) with
     the fp64 values and with CgOptions::mixed -- iterations, wall time, the
@@ -711,18 +753,21 @@ def compact_line(out, detail_path):
     line["config"] = out["config"]
     roof = {"bound": r["bound"], "achieved": sig(r["achieved"]), "peak": r["peak"],
             "unit": r["unit"], "frac": sig(r["frac"]),
-            "traffic": r["traffic"], "frac_traffic": sig(r["frac_traffic"]),
+            "traffic": r["traffic"], "traffic_source": r["traffic_source"],
+            "frac_traffic": sig(r["frac_traffic"]),
             "kernel": kname(r["kernel"]), "avg_launch_ms": sig(r["avg_launch_ms"]),
             "launches_timed": r["launches_timed"],
             "bytes_per_launch": r["bytes_per_launch"],
-            "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
-            "frac_csr_equivalent": sig(r["frac_csr_equivalent"])}
-    co = r.get("csr_order")
-    if co:
-        roof["csr_order"] = {"kernel": kname(co["kernel"]),
-                             "ms_per_apply": sig(co["ms_per_apply"]),
-                             "frac": sig(co["frac"]), "traffic": co["traffic"]}
-        roof["general_cg_iters_per_s"] = sig(r["general_cg_iters_per_s"])
+            "format_bytes_per_launch": r["format_bytes_per_launch"],
+            "frac_format": sig(r["frac_format"]),
+            "step_algorithmic_gbs": sig(r["step_algorithmic_gbs"]),
+            "plan": r["plan"]}
+    sp = r.get("specialised")
+    if sp:
+        roof["specialised"] = {k: (sig(v) if isinstance(v, float) else v)
+                               for k, v in sp.items()
+                               if k in ("kernel", "iters_per_s", "ms",
+                                        "frac_physical", "frac_csr_equivalent")}
     if "north_star_rowblock_spmv" in out:
         # 216^3 (the north star's 10 M rows), priced with SURVEY 8d's B_csr
         ns = {"rows": out["north_star_rowblock_spmv"]["rows"]}
@@ -755,6 +800,10 @@ def compact_line(out, detail_path):
         roof["ragged_plan_over_csr"] = {
             k: sig(out[k]["plan_extra_bytes"] / out[k]["csr_bytes"], 3)
             for k in r["ragged"] if k in out and "csr_bytes" in out[k]}
+    rs = out.get("rank_shape")
+    if rs:  # per-rank critical path at configs[4]'s shapes (a model, 1 GPU)
+        roof["rank_shape_ms"] = {str(k): sig(v["ms_per_iteration"])
+                                 for k, v in rs.items() if isinstance(v, dict)}
     if "plan" in out and r["algorithmic_bytes_per_launch"]:
         roof["plan_extra_over_csr_bytes"] = sig(
             out["plan"]["plan_extra_bytes"] / out["plan"]["csr_bytes"], 3)
@@ -763,11 +812,19 @@ def compact_line(out, detail_path):
                                if k in ("k10", "k10_ok")}
     if "symmetric" in out:  # BASELINE configs[3]
         s_ = out["symmetric"]
+        # frac = SURVEY 8d's B_sym / avg launch / peak (values streamed)
         line["symmetric"] = {"iters_per_s": sig(s_["iters/s"]),
                              "kernel": kname(s_["kernel"]),
                              "avg_launch_ms": sig(s_["avg_launch_ms"]),
-                             "frac": sig(s_["frac"]),
-                             "frac_of_B_sym": sig(s_["frac_csr_equivalent"])}
+                             "frac": sig(s_["frac_csr_equivalent"]),
+                             "frac_format": sig(s_["frac"]),
+                             "traffic": s_.get("traffic")}
+        sp = s_.get("specialised")
+        if sp:
+            line["symmetric"]["specialised"] = {
+                "iters_per_s": sig(sp["iters/s"]), "kernel": kname(sp["kernel"]),
+                "ms": sig(sp["avg_launch_ms"]), "frac_physical": sig(sp["frac"]),
+                "frac_of_B_sym": sig(sp["frac_csr_equivalent"])}
     for k in ("halo_selfcheck", "rccl", "cg_scalar_reductions", "launcher"):
         if k in out:
             line[k] = out[k]
@@ -887,24 +944,36 @@ def main():
     n = args.n
     N = n ** 3
     ctx = exec_.context
-    if args.no_lattice or args.no_lx:
-        _lib.call("spmv_hip_ctx_set_option", ctx, b"lat_min_nnz", 1 << 62)
+    # The headline's plan (module docstring): CSR order -- no lattice analysis
+    # for general storage, values streamed for symmetric storage -- unless
+    # --specialised; a PETSc file always gets the AUTO plan.
+    plain = not (args.specialised or args.petsc_matrix)
+    main_opts = {}
+    if args.no_lattice or args.no_lx or (plain and not args.symmetric):
+        main_opts[b"lat_min_nnz"] = (1 << 62, 1 << 20)
     if args.no_bake:
-        _lib.call("spmv_hip_ctx_set_option", ctx, b"bake_general", 0)
-    if args.no_const:
-        _lib.call("spmv_hip_ctx_set_option", ctx, b"const_diagonals", 0)
+        main_opts[b"bake_general"] = (0, 1)
+    if args.no_const or (plain and args.symmetric):
+        main_opts[b"const_diagonals"] = (0, 1)
     if args.no_lx:
-        _lib.call("spmv_hip_ctx_set_option", ctx, b"lx_min_nnz", 1 << 62)
+        main_opts[b"lx_min_nnz"] = (1 << 62, 1 << 20)
     cm = getattr(host, args.cm.upper())
     exec_.synchronize()
     t_create = time.perf_counter()
-    if args.petsc_matrix:
-        # the reference demos' input path (demos/cg.cpp:47-51, demos/spmv.cpp:43):
-        # every rank reads its row slab of the file (spmv/read_petsc.cpp:40-228)
-        A = host.read_petsc_binary_matrix(args.petsc_matrix, comm, exec_,
-                                          args.symmetric, cm)
-    else:
-        A = host.Matrix.create_poisson3d(comm, exec_, n, args.symmetric, cm)
+    for k_, (v_, _) in main_opts.items():
+        _lib.call("spmv_hip_ctx_set_option", ctx, k_, v_)
+    try:
+        if args.petsc_matrix:
+            # the reference demos' input path (demos/cg.cpp:47-51,
+            # demos/spmv.cpp:43): every rank reads its row slab of the file
+            # (spmv/read_petsc.cpp:40-228)
+            A = host.read_petsc_binary_matrix(args.petsc_matrix, comm, exec_,
+                                              args.symmetric, cm)
+        else:
+            A = host.Matrix.create_poisson3d(comm, exec_, n, args.symmetric, cm)
+    finally:  # the sub-records below set what they need themselves
+        for k_, (_, d_) in main_opts.items():
+            _lib.call("spmv_hip_ctx_set_option", ctx, k_, d_)
     exec_.synchronize()
     t_create = time.perf_counter() - t_create  # generator + upload-free plan
     l2g = A.col_map()
@@ -1017,7 +1086,10 @@ def main():
         per_rank = [mine]
 
     if rank == 0:
-        traffic, traffic_source = pmc_traffic("main", kernel, n, world)
+        traffic, traffic_source = pmc_traffic(
+            "csr_order" if plain and not args.symmetric else
+            "symmetric_value_stream_spmv" if plain else
+            "symmetric" if args.symmetric else "main", kernel, n, world)
         pr = price(spmv_ms_avg, kernel_bytes, requested_bytes, traffic)
         k10 = float(hist[min(10, len(hist) - 1)] / hist[0])
         resid = {"k10": k10, "kK": float(hist[-1] / hist[0])}
@@ -1052,35 +1124,53 @@ def main():
                                             if l2g.onesided() else
                                             " (RCCL send/recv on a side stream)"))
                        if world > 1 else "none (1 rank)"},
-            # PHYSICAL roofline of the dominant kernel: the bytes its data
-            # format makes it load and store per launch / the launch time
-            # measured live (HIP events on the kernel's stream) / 8 TB/s
-            "roofline": {"bound": "hbm", "achieved": pr["GB/s"],
+            # roofline of the dominant kernel (the local block's SpMV), timed
+            # live with HIP events on its stream.  CSR-order plan (default):
+            # achieved / frac / bytes_per_launch are SURVEY 8d's algorithmic
+            # bytes (B_csr, or B_sym for symmetric storage); --specialised or a
+            # PETSc file: the bytes the AUTO plan's own format moves (PHYSICAL),
+            # with the CSR-equivalent figure beside it.
+            "roofline": {"bound": "hbm",
+                         "achieved": (pr["csr_equivalent_gbs"] if plain
+                                      else pr["GB/s"]),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": pr["frac"],
-                         "bytes_per_launch": requested_bytes,
-                         "requested_bytes_per_launch": requested_bytes,
-                         "frac_requested": pr["frac"],
+                         "frac": (pr["frac_csr_equivalent"] if plain
+                                  else pr["frac"]),
+                         "frac_prices": ("SURVEY 8d algorithmic bytes ("
+                                         + ("B_sym" if args.symmetric else "B_csr")
+                                         + ") / avg_launch_ms / peak" if plain else
+                                         "the bytes the plan's own format moves "
+                                         "(physical) / avg_launch_ms / peak"),
+                         "bytes_per_launch": (kernel_bytes if plain
+                                              else requested_bytes),
+                         # what the plan's format of the matrix really loads
+                         # and stores (LX: 10 B per entry instead of CSR's 12)
+                         "format_bytes_per_launch": requested_bytes,
+                         "frac_format": pr["frac"],
                          "traffic": traffic, "traffic_source": traffic_source,
                          # ... and with the bytes the PMC passes saw cross the
                          # fabric: what the HBM side is really asked to do
                          "frac_traffic": pr.get("frac_traffic"),
-                         # the same launch priced as if it had streamed the
-                         # caller's CSR arrays (12 B per entry, row
-                         # pointer, x, y): a speed-up statement, may exceed peak
                          "algorithmic_bytes_per_launch": kernel_bytes,
                          "csr_equivalent_gbs": pr["csr_equivalent_gbs"],
                          "frac_csr_equivalent": pr["frac_csr_equivalent"],
-                         "note": ("achieved / frac price the bytes the plan's "
-                                  "format of the matrix makes compulsory "
-                                  "(bytes_per_launch); csr_equivalent_gbs prices "
-                                  "SURVEY 8d's CSR bytes over the same time and "
-                                  "is not a bandwidth; sub-records "
+                         # SURVEY 8d's bytes of a whole step (SpMV + 9 vector
+                         # passes) over ms_per_step: must stay below the peak
+                         "step_algorithmic_gbs":
+                             iter_bytes / (elapsed / args.steps) / 1e9,
+                         "note": ("default: the CSR-order plan, achieved / frac / "
+                                  "bytes_per_launch = SURVEY 8d's algorithmic "
+                                  "bytes; format_bytes_per_launch / frac_format "
+                                  "= what the plan's own format moves; "
+                                  "roofline.specialised = the AUTO plan of this "
+                                  "matrix in the same loop; sub-records "
                                   "value_stream_spmv (lattice matrix whose "
-                                  "coefficients vary: the values are streamed), "
-                                  "csr_lx_spmv / csr_rowblock_spmv / "
-                                  "unstructured_spmv (no lattice structure) are "
-                                  "the kernels other matrices get"),
+                                  "coefficients vary), csr_lx_spmv / "
+                                  "csr_rowblock_spmv / unstructured_spmv are the "
+                                  "kernels other matrices get"),
+                         "plan": ("csr-order (lattice analysis off; symmetric "
+                                  "storage: values streamed)" if plain else
+                                  "AUTO (specialised to the matrix)"),
                          "kernel": kernel,
                          "avg_launch_ms": spmv_ms_avg,
                          "launches_timed": spmv_launches},
@@ -1155,42 +1245,37 @@ def main():
                 At.close()
                 exec_.free(d_b), exec_.free(d_x)
             # BASELINE configs[3]: symmetric storage at the same size, the CG
-            # loop on it and its kernel
+            # loop on it.  First with the values STREAMED (constant-diagonal
+            # detection off: the half diagonal form any symmetric lattice
+            # matrix with varying coefficients gets), priced with SURVEY 8d's
+            # B_sym; the AUTO plan's constant-diagonal run beside it.
             if not args.symmetric:
-                As = host.Matrix.create_poisson3d(self_comm, exec_, n, True, cm)
-                d_b, d_x = exec_.alloc(N), exec_.alloc(N)
-                _lib.call("spmv_hip_fill_gaussian_f64", ctx, N, 0, N, d_b, None)
-                ws2 = host.CgWorkspace(exec_)
                 steps = min(args.steps, 20)
-                host.cg_ex(self_comm, exec_, As, d_b, d_x, 3, 0.0, ws2)
-                ws2.reserve_timing(steps)
-                exec_.synchronize()
-                t0 = time.perf_counter()
-                _, h2, ms2, l2 = host.cg_ex(self_comm, exec_, As, d_b, d_x, steps,
-                                            0.0, ws2, time_spmv=True, history=True)
-                exec_.synchronize()
-                el2 = time.perf_counter() - t0
-                kern2, algo2, req2 = kernel_of(As, True)
-                ms2 /= max(l2, 1)
-                tr2, src2 = pmc_traffic("symmetric", kern2, n, world)
-                out["symmetric"] = {
-                    "workload": f"poisson3d_{n}^3_symmetric-csr_fp64_cg",
-                    "iters/s": steps / el2, "steps": steps, "kernel": kern2,
-                    "avg_launch_ms": ms2,
-                    "parity": "bit-exact vs the oracle (atomic-free)"
-                    if "atomic-free" in kern2 else "tolerance (atomics)",
-                    "cg_rel_residual_k10": float(h2[min(10, len(h2) - 1)] / h2[0])}
-                # algorithmic bytes here = SURVEY 8d's B_sym (lower entries at
-                # 12 B, row pointer, diagonal, x, y)
-                out["symmetric"].update(price(ms2, algo2, req2, tr2))
-                out["symmetric"]["traffic_source"] = src2
-                out["symmetric"].update(plan_record(As))
-                ws2.close()
-                As.close()
-                exec_.free(d_b), exec_.free(d_x)
-                # The same CG with the matrix values STREAMED (constant-diagonal
-                # detection off): what the loop costs on a lattice matrix whose
-                # coefficients vary -- the half diagonal form of rounds 2-3
+
+                def sym_cg(const, record):
+                    _lib.call("spmv_hip_ctx_set_option", ctx, b"const_diagonals",
+                              1 if const else 0)
+                    try:
+                        As = host.Matrix.create_poisson3d(self_comm, exec_, n, True,
+                                                          cm)
+                    finally:
+                        _lib.call("spmv_hip_ctx_set_option", ctx,
+                                  b"const_diagonals", 1)
+                    r_ = cg_record(exec_, self_comm, host, _lib, As, N, steps, True,
+                                   record, n,
+                                   f"poisson3d_{n}^3_symmetric-csr_fp64_cg"
+                                   + ("" if const else "_values_streamed"))
+                    r_["parity"] = ("bit-exact vs the oracle (atomic-free)"
+                                    if "atomic-free" in r_["kernel"]
+                                    else "tolerance (atomics)")
+                    As.close()
+                    return r_
+                out["symmetric"] = sym_cg(False, "symmetric_value_stream_spmv")
+                out["symmetric"]["specialised"] = sym_cg(True, "symmetric")
+                # The same CG with the GENERAL matrix's values streamed (lattice
+                # analysis on, constant-diagonal detection off): what the loop
+                # costs on a lattice matrix whose coefficients vary -- the half
+                # diagonal form of rounds 2-3
                 if not (args.no_const or args.no_bake or args.no_lattice
                         or args.no_lx):
                     _lib.call("spmv_hip_ctx_set_option", ctx, b"const_diagonals", 0)
@@ -1200,35 +1285,11 @@ def main():
                     finally:
                         _lib.call("spmv_hip_ctx_set_option", ctx,
                                   b"const_diagonals", 1)
-                    d_b, d_x = exec_.alloc(N), exec_.alloc(N)
-                    _lib.call("spmv_hip_fill_gaussian_f64", ctx, N, 0, N, d_b, None)
-                    ws3 = host.CgWorkspace(exec_)
-                    steps = min(args.steps, 20)
-                    host.cg_ex(self_comm, exec_, Av, d_b, d_x, 3, 0.0, ws3)
-                    ws3.reserve_timing(steps)
-                    exec_.synchronize()
-                    t0 = time.perf_counter()
-                    _, h3, ms3, l3 = host.cg_ex(self_comm, exec_, Av, d_b, d_x,
-                                                steps, 0.0, ws3, time_spmv=True,
-                                                history=True)
-                    exec_.synchronize()
-                    el3 = time.perf_counter() - t0
-                    kern3, algo3, req3 = kernel_of(Av, False)
-                    ms3 /= max(l3, 1)
-                    tr3, src3 = pmc_traffic("value_stream_spmv", kern3, n, world)
-                    out["value_stream_cg"] = {
-                        "workload": f"poisson3d_{n}^3_csr_fp64_cg_values_streamed",
-                        "iters/s": steps / el3, "steps": steps,
-                        "ms_per_step": el3 / steps * 1e3, "kernel": kern3,
-                        "avg_launch_ms": ms3,
-                        "cg_rel_residual_k10":
-                            float(h3[min(10, len(h3) - 1)] / h3[0])}
-                    out["value_stream_cg"].update(price(ms3, algo3, req3, tr3))
-                    out["value_stream_cg"]["traffic_source"] = src3
-                    out["value_stream_cg"].update(plan_record(Av))
-                    ws3.close()
+                    out["value_stream_cg"] = cg_record(
+                        exec_, self_comm, host, _lib, Av, N, steps, False,
+                        "value_stream_spmv", n,
+                        f"poisson3d_{n}^3_csr_fp64_cg_values_streamed")
                     Av.close()
-                    exec_.free(d_b), exec_.free(d_x)
                 rec = lambda name, *a, **kw: spmv_record(  # noqa: E731
                     exec_, self_comm, host, _lib, *a, record=name, **kw)
                 # a lattice matrix that is NOT symmetric (the generator's skewed
@@ -1271,53 +1332,32 @@ def main():
                     # per row are too few for it: the LX form is the AUTO choice)
                     out["csr_sjds_spmv"] = rec("csr_sjds_spmv", n, False, 20,
                                                lattice=False, lx=False)
-            if not args.symmetric and not (args.no_lattice or args.no_lx):
-                # THE GENERAL-CSR LINE, kept inside `roofline` (the block the
-                # driver stores): the same matrix and the same CG loop with the
-                # plan-time lattice analysis switched off -- what a CSR matrix
-                # of this shape WITHOUT stencil structure gets from the AUTO
-                # plan (the LX form: values + 16-bit column offsets streamed, x
-                # windows staged in LDS).  frac = SURVEY 8d's CSR bytes / time.
-                _lib.call("spmv_hip_ctx_set_option", ctx, b"lat_min_nnz", 1 << 62)
-                try:
-                    Ag = host.Matrix.create_poisson3d(self_comm, exec_, n, False,
-                                                      cm)
-                finally:
-                    _lib.call("spmv_hip_ctx_set_option", ctx, b"lat_min_nnz",
-                              1 << 20)
-                d_b, d_x = exec_.alloc(N), exec_.alloc(N)
-                _lib.call("spmv_hip_fill_gaussian_f64", ctx, N, 0, N, d_b, None)
-                ws4 = host.CgWorkspace(exec_)
-                steps = min(args.steps, 30)
-                host.cg_ex(self_comm, exec_, Ag, d_b, d_x, 3, 0.0, ws4)
-                ws4.reserve_timing(steps)
-                exec_.synchronize()
-                t0 = time.perf_counter()
-                _, h4, ms4, l4 = host.cg_ex(self_comm, exec_, Ag, d_b, d_x, steps,
-                                            0.0, ws4, time_spmv=True, history=True)
-                exec_.synchronize()
-                el4 = time.perf_counter() - t0
-                kern4, algo4, req4 = kernel_of(Ag, False)
-                ms4 /= max(l4, 1)
-                tr4, src4 = pmc_traffic("csr_order", kern4, n, world)
-                out["roofline"]["csr_order"] = {
-                    "what": "the kernel the AUTO plan picks for this matrix with "
-                            "the lattice analysis (and with it every stencil "
-                            "form) switched off, inside the same CG loop",
-                    "kernel": kern4.split(" (")[0], "ms_per_apply": ms4,
-                    "launches_timed": l4,
-                    "algorithmic_bytes_per_launch": algo4,
-                    "achieved": algo4 / ms4 / 1e6, "unit": "GB/s",
-                    "frac": algo4 / ms4 / 1e6 / HBM_PEAK_GBS,
-                    "requested_bytes_per_launch": req4,
-                    "frac_requested": req4 / ms4 / 1e6 / HBM_PEAK_GBS,
-                    "traffic": tr4, "traffic_source": src4,
-                    "cg_rel_residual_k10": float(h4[min(10, len(h4) - 1)] / h4[0]),
-                    "plan_ms": Ag.plan_get("plan_us") / 1e3}
-                out["roofline"]["general_cg_iters_per_s"] = steps / el4
-                ws4.close()
+            if not args.symmetric and plain:
+                # WHAT THE AUTO PLAN DOES WITH THIS MATRIX, kept inside `roofline`
+                # (the block the driver stores): the same CG loop with the
+                # plan-time analysis on -- it finds the lattice and that every
+                # diagonal is constant and streams no matrix at all (rounds 1-5's
+                # main line).  frac_physical = the bytes that kernel's own format
+                # moves / time / peak; frac_csr_equivalent = SURVEY 8d's CSR
+                # bytes over the same time: a speed-up statement, exceeds 1.
+                Ag = host.Matrix.create_poisson3d(self_comm, exec_, n, False, cm)
+                r_ = cg_record(exec_, self_comm, host, _lib, Ag, N,
+                               min(args.steps, 30), False, "main", n,
+                               f"poisson3d_{n}^3_csr_fp64_cg_auto_plan")
                 Ag.close()
-                exec_.free(d_b), exec_.free(d_x)
+                out["specialised_cg"] = r_
+                out["roofline"]["specialised"] = {
+                    "what": "the AUTO plan of this matrix (lattice analysis + "
+                            "constant diagonals: no matrix stream) in the same "
+                            "CG loop",
+                    "kernel": r_["kernel"].split(" (")[0],
+                    "iters_per_s": r_["iters/s"], "ms": r_["avg_launch_ms"],
+                    "ms_per_step": r_["ms_per_step"],
+                    "frac_physical": r_["frac"],
+                    "frac_csr_equivalent": r_["frac_csr_equivalent"],
+                    "bytes_per_launch": r_["requested_bytes"],
+                    "traffic": r_.get("traffic"),
+                    "cg_rel_residual_k10": r_["cg_rel_residual_k10"]}
             if not args.symmetric:
                 # RAGGED ROWS (what the PETSc reader typically delivers): seeded
                 # FEM-like matrices, 10 M rows -- row lengths 5-40 in three

@@ -143,11 +143,15 @@ constexpr int kLxGap = 16;   // columns closer than this share a window
 // ... the DMA kernel's own record (one per row block):
 //   [0] number of windows, or -1 = direct (global gather)
 //   [1] first entry of the block's span in `values`   [2] its entry count
-//   [3] number of staged pieces
+//   [3] number of staged pieces (low byte) | (staged position of column
+//       rb * kRows + 1) << 8 when the block's own columns [rb * kRows, + rows)
+//       lie inside one staged window, 0 there otherwise: the fused dot's x_i
 //   [kLxwPieces0 + p]  first column of piece p (kLxwPiece elements each)
 constexpr int kLxwPiece = 128;     // staged elements per piece
 constexpr int kLxwMaxPieces = 16;  // 2048 staged elements (16 KiB fp64)
 constexpr int kLxwPieces0 = 4;
+constexpr int kLxwNpMask = 0xff;   // word [3]: pieces
+constexpr int kLxwOwnShift = 8;    // ... own position + 1
 constexpr int kLxwRec = 20;        // ints per record (4 + 16)
 constexpr int kLxwAlign = 4;       // window starts: multiples of 4 columns
 // XW: the same kernel on the CALLER's column indices (no 16-bit copy): the

@@ -556,7 +556,14 @@ __global__ __launch_bounds__(kBlock) void lx_build_kernel(
         for (int c = s_ws[k]; c < s_we[k]; c += kLxwPiece)
           wr[kLxwPieces0 + np++] = c;
       wr[0] = total_windows;
-      wr[3] = np; // = s_wo[total_windows] / kLxwPiece <= cap / kLxwPiece
+      // where the block's OWN columns are staged (x_i of the fused dot): the
+      // window that holds [r0, r0 + nr), if one does
+      int own = -1;
+      for (int k = 0; k < total_windows; ++k)
+        if (s_ws[k] <= r0 && r0 + nr <= s_we[k])
+          own = s_wo[k] + (r0 - s_ws[k]);
+      // np = s_wo[total_windows] / kLxwPiece <= cap / kLxwPiece
+      wr[3] = np | ((own + 1) << kLxwOwnShift);
       // (read first: an atomic per row block on one address is milliseconds)
       if (cnt > *(volatile int*)&stat[0])
         atomicMax(&stat[0], cnt);

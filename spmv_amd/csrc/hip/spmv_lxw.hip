@@ -91,6 +91,8 @@ struct LxwBlock {
   int32_t a;     // span start in `values`
   int32_t cnt;   // entries
   int np;        // staged pieces
+  int own;       // staged position of the block's first row's OWN column
+                 // (x[rb * kRows] -- the fused dot's x), -1 = not staged
 };
 
 // A block's record travels as ONE vector load (lane l holds word l) issued a
@@ -112,13 +114,15 @@ __device__ __forceinline__ int32_t lxw_fetch(int rb,
 
 __device__ __forceinline__ LxwBlock lxw_decode(int rb, int32_t w)
 {
-  LxwBlock b{-1, -1, 0, 0, 0};
+  LxwBlock b{-1, -1, 0, 0, 0, -1};
   if (rb >= 0) {
     b.rb = rb;
     b.nwin = __builtin_amdgcn_readlane(w, 0);
     b.a = __builtin_amdgcn_readlane(w, 1);
     b.cnt = __builtin_amdgcn_readlane(w, 2);
-    b.np = __builtin_amdgcn_readlane(w, 3);
+    const int32_t w3 = __builtin_amdgcn_readlane(w, 3);
+    b.np = w3 & kLxwNpMask;
+    b.own = (w3 >> kLxwOwnShift) - 1;
   }
   return b;
 }
@@ -126,10 +130,15 @@ __device__ __forceinline__ LxwBlock lxw_decode(int rb, int32_t w)
 template <typename T>
 struct LxwRegs {
   int32_t lo, hi; // the row's span
-  T y0, x_own;
+  T y0;
 };
 
-template <typename T, bool DOT>
+// (The fused dot's x_i is NOT among them: the block's own columns sit in one
+// of its staged windows wherever the rows have a diagonal neighbourhood -- the
+// plan records where, LxwBlock::own -- and are read from LDS in the block's own
+// step.  As a second global load a step ahead it cost the kernel 15 % at 512^3:
+// 2.53 against 2.19 ms, profiles/r05_rocprof_bench_n512_kernel_stats.csv.)
+template <typename T>
 __device__ __forceinline__ LxwRegs<T> lxw_loads(const LxwBlock& blk, int t,
                                                 int32_t num_rows,
                                                 const int32_t* __restrict__ rowptr,
@@ -138,7 +147,7 @@ __device__ __forceinline__ LxwRegs<T> lxw_loads(const LxwBlock& blk, int t,
 {
   LxwRegs<T> g;
   g.lo = g.hi = 0;
-  g.y0 = g.x_own = T(0);
+  g.y0 = T(0);
   if (blk.rb >= 0) {
     const int32_t r = blk.rb * kRows + t;
     if (r < num_rows) {
@@ -146,8 +155,6 @@ __device__ __forceinline__ LxwRegs<T> lxw_loads(const LxwBlock& blk, int t,
       g.hi = rowptr[r + 1];
       if (beta != T(0))
         g.y0 = out[r];
-      if constexpr (DOT)
-        g.x_own = in[r];
     }
   }
   return g;
@@ -265,7 +272,7 @@ __global__ __launch_bounds__(kBlock) void csr_lxw_kernel(
     issue(cur, pieces_of(w0), 0);
   }
   int nn_raw = slot_raw(it + 2 * stride);
-  LxwRegs<T> gA = lxw_loads<T, DOT>(cur, t, num_rows, rowptr, in, beta, out);
+  LxwRegs<T> gA = lxw_loads<T>(cur, t, num_rows, rowptr, in, beta, out);
   LxwRegs<T> gB;
   int slot = 0;
   // The y of a block is STORED A STEP LATER, right after the next step's wait:
@@ -310,7 +317,7 @@ __global__ __launch_bounds__(kBlock) void csr_lxw_kernel(
     const LxwBlock nxt = lxw_decode(nxt_rb, nxt_w);
     const Windows nxt_ws = windows_of(nxt_w);
     issue(nxt, pieces_of(nxt_w), slot ^ 1);
-    gn = lxw_loads<T, DOT>(nxt, t, num_rows, rowptr, in, beta, out);
+    gn = lxw_loads<T>(nxt, t, num_rows, rowptr, in, beta, out);
     // the block after the next one: its table entry has landed with the wait
     // above; its record is needed a step from now
     const int nn_rb = order_slot_decode(ord, nn_raw);
@@ -320,6 +327,8 @@ __global__ __launch_bounds__(kBlock) void csr_lxw_kernel(
     const int32_t r = cur.rb * kRows + t;
     if (cur.rb >= 0 && r < num_rows) {
       T sum = 0;
+      T x_own = T(0);
+      bool own_staged = false;
       int32_t j = g.lo;
       const int32_t hi = g.hi;
       if (cur.cnt > 0 && fits(cur)) {
@@ -328,6 +337,12 @@ __global__ __launch_bounds__(kBlock) void csr_lxw_kernel(
         if (cur.nwin >= 0) {
           const IDX* sl = s_lidx + (size_t)slot * lcap + (cur.a & IA) - cur.a;
           const T* sx = s_x + (size_t)slot * xcap;
+          if constexpr (DOT) {
+            if (cur.own >= 0) { // uniform
+              x_own = sx[cur.own + t];
+              own_staged = true;
+            }
+          }
           // eight entries' LDS reads in flight (offsets, then values and x:
           // two round trips per eight entries), adds strictly left to right;
           // entries past the row's end read a valid slot and are not added
@@ -375,8 +390,11 @@ __global__ __launch_bounds__(kBlock) void csr_lxw_kernel(
         y = c + beta * g.y0;
       y_late = y;
       r_late = r;
-      if constexpr (DOT)
-        dot_acc += (double)g.x_own * (double)c;
+      if constexpr (DOT) {
+        if (!own_staged) // a block without a staged window over its own rows
+          x_own = in[r];
+        dot_acc += (double)x_own * (double)c;
+      }
     }
     slot ^= 1;
     cur = nxt;

@@ -44,7 +44,7 @@ def _rel(a, b):
     return abs(a - b) <= 2e-5 * abs(b)
 
 
-def _check(line, d, n_gpus, steps, warmup):
+def _check(line, d, n_gpus, steps, warmup, plain=True):
     for k in REQUIRED:
         assert k in line and k in d, k
         if k != "roofline":
@@ -60,14 +60,28 @@ def _check(line, d, n_gpus, steps, warmup):
     assert " " not in c["kernel"].split("<")[0]  # a name, not a paragraph
     assert _rel(c["frac"], c["achieved"] / c["peak"])
     assert c["launches_timed"] == steps and c["avg_launch_ms"] > 0
-    # physical: the bytes the kernel's format moves over the measured time
     assert _rel(c["achieved"], c["bytes_per_launch"] / c["avg_launch_ms"] / 1e6)
-    assert c["algorithmic_bytes_per_launch"] >= c["bytes_per_launch"]
-    assert _rel(c["frac_csr_equivalent"], c["algorithmic_bytes_per_launch"]
-                / c["avg_launch_ms"] / 1e6 / 8000.0)
-    assert (c["traffic"] is None) == (c["frac_traffic"] is None)
-    # ... the detail file: the same numbers at full precision, with the notes
     r = d["roofline"]
+    if plain:
+        # the headline prices SURVEY 8d's algorithmic bytes of the CSR-order
+        # plan: every stored value and an index per entry are streamed
+        assert c["plan"].startswith("csr-order")
+        assert c["bytes_per_launch"] == r["algorithmic_bytes_per_launch"]
+        assert c["format_bytes_per_launch"] <= c["bytes_per_launch"]
+        rows = d["plan"]["csr_bytes"]  # nnz * 12 + (rows + 1) * 4
+        assert c["format_bytes_per_launch"] >= 0.8 * rows
+    else:
+        # physical: the bytes the kernel's format moves over the measured time
+        assert c["plan"].startswith("AUTO")
+        assert c["bytes_per_launch"] == c["format_bytes_per_launch"]
+        assert r["algorithmic_bytes_per_launch"] >= c["bytes_per_launch"]
+    assert _rel(c["frac_format"], c["format_bytes_per_launch"]
+                / c["avg_launch_ms"] / 1e6 / 8000.0)
+    assert _rel(r["frac_csr_equivalent"], r["algorithmic_bytes_per_launch"]
+                / r["avg_launch_ms"] / 1e6 / 8000.0)
+    assert (c["traffic"] is None) == (c["frac_traffic"] is None)
+    assert (c["traffic"] is None) == (c["traffic_source"] is None)
+    # ... the detail file: the same numbers at full precision, with the notes
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "note" in r
     assert _rel(c["frac"], r["frac"]) and _rel(c["avg_launch_ms"], r["avg_launch_ms"])
     assert (r["traffic"] is None) == (r["traffic_source"] is None)
@@ -90,10 +104,13 @@ def test_bench_single_gpu_line(tmp_path):
     assert lc["kind"] == "port" and lc["cores"] >= 1 and lc["value"] > 0
     assert "32^3" in lc["sample"] and len(lc["sample"]) < 160
     assert lc["parity_checks_bit_exact"] is True
-    assert lr["csr_order"]["kernel"] == "csr_lxw_kernel<double>"
-    assert _rel(lr["csr_order"]["frac"], lr["algorithmic_bytes_per_launch"]
-                / lr["csr_order"]["ms_per_apply"] / 1e6 / 8000.0)
-    assert lr["general_cg_iters_per_s"] > 0
+    # the headline is the CSR-order plan's kernel ...
+    assert lr["kernel"] == "csr_lxw_kernel<double>"
+    # ... and what the AUTO plan does with this matrix stands beside it
+    sp = lr["specialised"]
+    assert sp["kernel"].startswith("csr_const_dia_tile_kernel<double, general order")
+    assert sp["iters_per_s"] > 0 and sp["ms"] > 0
+    assert sp["frac_csr_equivalent"] > sp["frac_physical"] > 0
     ns = lr["north_star"]
     assert ns["rows"] == 216 ** 3 and 0 < ns["rowblock_frac"] < 1
     assert 0 < ns["lx_frac"] < 1 and ns["default_frac"] > 0
@@ -105,6 +122,7 @@ def test_bench_single_gpu_line(tmp_path):
             assert len(v) == 2 and v[0] > 0 and v[1] > 0, k
     assert lr["plan_extra_over_csr_bytes"] >= 0
     assert line["symmetric"]["iters_per_s"] > 0
+    assert line["symmetric"]["specialised"]["iters_per_s"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
     assert c["cores"] <= c["host"]["physical_cores"] and "32^3" in c["sample"]
@@ -113,12 +131,21 @@ def test_bench_single_gpu_line(tmp_path):
     # BASELINE configs[3] in the default line: symmetric storage, atomic-free
     sym = d["symmetric"]
     assert sym["frac"] > 0 and sym["iters/s"] > 0 and "atomic-free" in sym["kernel"]
+    assert sym["form"]["sdia_const"] == 0 and sym["specialised"]["iters/s"] > 0
+    assert abs(sym["specialised"]["cg_rel_residual_k10"]
+               / sym["cg_rel_residual_k10"] - 1) < 1e-9
     assert d["csr_lx_spmv"]["form"]["lx"] == 1 and d["csr_lx_spmv"]["form"]["lat"] == 0
-    # every diagonal of the Poisson matrix is constant: no values are streamed
-    assert d["plan"]["form"]["sdia"] == 1 and d["plan"]["form"]["sdia_const"] == 1
+    # the main plan: the LX form, the lattice analysis off
+    assert d["plan"]["form"]["lx"] == 1 and d["plan"]["form"]["lat"] == 0
+    assert d["plan"]["form"]["sdia"] == 0
+    # the AUTO plan: every diagonal of the Poisson matrix is constant, no values
+    # are streamed
+    spc = d["specialised_cg"]
+    assert spc["form"]["sdia"] == 1 and spc["form"]["sdia_const"] == 1
     assert "csr_const_dia_tile_kernel<double, general order, 4 lattice lines" \
-        in d["roofline"]["kernel"]
-    assert d["roofline"]["bytes_per_launch"] == 17 * 64 ** 3
+        in spc["kernel"]
+    assert spc["requested_bytes"] == 17 * 64 ** 3
+    assert abs(spc["cg_rel_residual_k10"] / d["cg_rel_residual"]["k10"] - 1) < 1e-9
     # (symmetric storage of 64^3 is below the lattice analysis' size: the
     # transposed map; tests/test_gpu_matrix.py covers the larger grids)
     # ... the same matrix with its values streamed (what a lattice matrix with
@@ -153,16 +180,6 @@ def test_bench_single_gpu_line(tmp_path):
     assert rbf["xw"] == 0 and rbf["lx"] == 0 and rbf["sjds"] == 0 and rbf["lat"] == 0
     assert len(lr["csr_rowblock"]) == 3 and len(lr["csr_gather"]) == 3
     assert d["csr_sjds_spmv"]["form"]["sjds"] == 1
-    # the general-CSR line inside `roofline` (the block the driver keeps): the
-    # AUTO plan without the lattice analysis, same CG loop, SURVEY 8d's bytes
-    co = d["roofline"]["csr_order"]
-    assert "csr_lxw_kernel" in co["kernel"] and 0 < co["frac"] <= 1.5
-    assert abs(co["frac"] - co["algorithmic_bytes_per_launch"] / co["ms_per_apply"]
-               / 1e6 / 8000.0) < 1e-9
-    assert co["algorithmic_bytes_per_launch"] == d["roofline"][
-        "algorithmic_bytes_per_launch"]
-    assert abs(co["cg_rel_residual_k10"] / d["cg_rel_residual"]["k10"] - 1) < 1e-9
-    assert d["roofline"]["general_cg_iters_per_s"] > 0
     # ragged rows: the sliced jagged form, bit-equal to the reference loop
     rg = d["roofline"]["ragged"]
     # ... and in symmetric storage both blocks of it, bit-equal to the
@@ -213,8 +230,9 @@ def test_bench_without_the_symmetry_check(tmp_path):
     """--no-bake: the line of a lattice matrix whose values stay in CSR order
     (the CSR-order lattice kernel; DESIGN.md section 7, 'reading the headline')."""
     line, d = _run(["--grid", "128", "--steps", "10", "--warmup", "2",
-                    "--no-bake", "--no-extras", "--no-cpu-baseline"], tmp_path)
-    _check(line, d, 1, 10, 2)
+                    "--specialised", "--no-bake", "--no-extras",
+                    "--no-cpu-baseline"], tmp_path)
+    _check(line, d, 1, 10, 2, plain=False)
     assert line["roofline"]["kernel"] == "csr_lattice_kernel<double>"
     assert d["plan"]["form"]["sdia"] == 0 and d["plan"]["form"]["lat"] == 1
     assert "csr_lattice_kernel" in d["roofline"]["kernel"]
@@ -225,8 +243,9 @@ def test_bench_with_the_values_streamed(tmp_path):
     """--no-const: the headline of a lattice matrix whose coefficients vary (the
     half diagonal form streams the lower values)."""
     line, d = _run(["--grid", "128", "--steps", "10", "--warmup", "2",
-                    "--no-const", "--no-extras", "--no-cpu-baseline"], tmp_path)
-    _check(line, d, 1, 10, 2)
+                    "--specialised", "--no-const", "--no-extras",
+                    "--no-cpu-baseline"], tmp_path)
+    _check(line, d, 1, 10, 2, plain=False)
     assert d["plan"]["form"]["sdia"] == 1 and d["plan"]["form"]["sdia_const"] == 0
     assert "csr_sym_dia_kernel<double, general order>" in d["roofline"]["kernel"]
 
