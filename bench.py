@@ -460,6 +460,12 @@ def kernel_of(A, symmetric):
         return ("csr_rowblock_lx_kernel<double> (LX form: x windows staged in "
                 "LDS, 16-bit column offsets; fused p.Ap)",
                 algo, nnz * 10 + (rows + 1) * 4 + nrb * 144 + y_x)
+    if A.plan_get("xw") and A.plan_get("xw_pick") == 0:
+        return ("csr_rowblock_kernel<double> (gather; the plan's first launches "
+                "timed it against the XW kernel -- x windows staged over the same "
+                "arrays -- and found it faster on this device: "
+                f"{A.plan_get('xw_probe_gather_us')} against "
+                f"{A.plan_get('xw_probe_xw_us')} us; fused p.Ap)", algo, algo)
     if A.plan_get("xw"):
         return ("csr_lxw_kernel<double, XW> (the caller's CSR arrays as they "
                 "are: values and 32-bit column indices by LDS-DMA one row block "
@@ -617,6 +623,8 @@ def matrix_spmv_record(exec_, A, _lib, symmetric, reps, record, grid, workload,
     plan = plan_record(A)
     r = timed_spmv(exec_, A, rows, _lib, reps, crosscheck)
     ms, same = r if crosscheck else (r, None)
+    if A.plan_get("xw"):  # XW or gather: the plan's first launches decided
+        kernel, algo, req = kernel_of(A, symmetric)
     traffic, source = pmc_traffic(record, kernel, grid, 1)
     rec = {"workload": workload, "rows": rows, "nnz_stored": nnz,
            "kernel": kernel, "ms_per_apply": ms, "applies_timed": reps}

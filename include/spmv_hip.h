@@ -83,7 +83,18 @@ int spmv_hip_synchronize(spmv_hip_ctx* ctx); /* whole device */
  *   variant (lower neighbours -1 - s, upper -1 + s, s = value * 1e-6).
  *   "poisson_stencil": 7 (default) or 27 -- the generator writes the 27-point
  *   operator (all neighbours with |dx|,|dy|,|dz| <= 1; diagonal 26,
- *   off-diagonal -1); its row slabs must be whole planes. */
+ *   off-diagonal -1); its row slabs must be whole planes.
+ *   "csr_in_place": 1 = plans make NO copy of the index or value stream of a
+ *   matrix without lattice structure -- neither the LX form's 16-bit offsets
+ *   (2 B per entry) nor the sliced jagged arrays (10 B per entry): the caller's
+ *   CSR arrays are streamed as they are, x windows staged in LDS where the
+ *   columns of a row block form <= 8 windows (the XW kernel, 144 B of plan
+ *   memory per 256 rows), gathered otherwise.  Default 0.
+ *   "xw_min_nnz", "xw_min_x_bytes": from how many entries / how large an x on
+ *   such a plan stages the windows; "xw_probe": 1 (default) = its first four
+ *   launches -- each a complete product with the same bits -- time the XW
+ *   kernel against the gather kernel and the plan keeps the faster one
+ *   (csr_plan_get "xw_pick"); 0 = XW wherever its records exist. */
 int spmv_hip_ctx_set_option(spmv_hip_ctx* ctx, const char* key, int64_t value);
 /* ... and read back (release_csr, put_timeout_ms, the *_min_nnz thresholds,
  * xw_min_x_bytes); SPMV_HIP_EINVAL for a key without a getter */
@@ -326,6 +337,10 @@ int spmv_hip_zwalk_table(int32_t num_rows, int64_t plane_rows, int grid,
  *                  diagonals on a 3-D lattice: lattice lines per lane (1, 2,
  *                  4), its own plane-walk table, workgroups per CU
  *   "lxw" "lxw_blocks_per_cu"            LX form: the LDS-DMA kernel on/off
+ *   "xw" "xw_probe"                      the same kernel on the caller's CSR
+ *                  arrays (plans with XW records): on/off -- 1 asks for it by
+ *                  name and ends the probe --; xw_probe 1 = let the next four
+ *                  launches choose between it and the gather kernel again
  *   "wdia" "wdia_xcd_group" "wdia_blocks_per_cu" "wdia_zwalk"
  *   "wdia_zwalk_segments"                wide diagonal form (baked plans)
  *   "wdia_box" "wdia_box_segments" "wdia_box_blocks_per_cu"   constant
@@ -347,6 +362,10 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value);
  * offsets of the baked copy), "sdia_general" (baked from a general matrix: 1 = symmetric, half stored; 2 =
  * full form), "sdia_mixed" (fp32 copy), "sdia_const" (constant diagonals: no
  * values kept), "sdia_tile" (lines per lane in use), "sdia_tile_walk"; "lxw";
+ * "xw", "xw_staged" (row blocks with staged windows), "xw_pick" (1 = the XW
+ * kernel runs, 0 = the plan's probe found the gather kernel faster, -1 = the
+ * probe's four launches are not all complete), "xw_probe_xw_us",
+ * "xw_probe_gather_us" (what it measured);
  * "wdia", "wdia_offsets", "wdia_half", "wdia_const", "wdia_box", "wdia_mixed", "wdia_d2",
  * "wdia_zwalk", "wdia_zwalk_segments";
  * "blocks_per_cu", "nontemporal"; "plan_us" (wall time of plan creation, its

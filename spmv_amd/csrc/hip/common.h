@@ -44,6 +44,13 @@ struct spmv_hip_ctx {
   // windows are (512^3: 2.49 against 2.57 ms on one box, 13.8 instead of
   // 15.7 GB across the fabric)
   int64_t xw_min_x_bytes = (int64_t)128 << 20;
+  // ... and lets its first four launches decide between that kernel and the
+  // gather kernel ("xw_probe"; 0: XW whenever its records exist)
+  int xw_probe = 1;
+  // plans keep the caller's CSR arrays of a matrix without lattice structure
+  // as they are -- no LX form (2 B per entry of plan memory), no sliced jagged
+  // copy (10 B per entry): the XW / gather kernels ("csr_in_place"; default 0)
+  int csr_in_place = 0;
   // plans try the lattice form (constant column offsets per row block, no
   // index stream) for general matrices with at least this many entries
   // ("lat_min_nnz")

@@ -401,6 +401,10 @@ struct spmv_hip_csr_plan {
   int xw = 0;                // use it (plan_set "xw")
   int xw_staged = 0;         // row blocks whose windows are staged
   int xw_max_cnt = 0, xw_max_pieces = 0;
+  // ... or the gather kernel, whichever the FIRST LAUNCHES show to be faster
+  // on this device: the two stream the same arrays at rates a few per cent
+  // apart and which one leads differs from box to box (XwProbe, spmv_csr.hip)
+  struct XwProbe* xw_probe = nullptr;
   // Lattice form (spmv_lat.hip): every row block's columns are row + one of
   // <= 8 constant offsets => no index stream, values arrive by LDS-DMA
   int32_t* lat_tab = nullptr;  // kLatRec ints per row block: count, offsets

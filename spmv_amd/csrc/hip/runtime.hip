@@ -123,6 +123,10 @@ int spmv_hip_ctx_get_option(const spmv_hip_ctx* ctx, const char* key, int64_t* v
     *value = ctx->xw_min_nnz;
   else if (!strcmp(key, "xw_min_x_bytes"))
     *value = ctx->xw_min_x_bytes;
+  else if (!strcmp(key, "xw_probe"))
+    *value = ctx->xw_probe;
+  else if (!strcmp(key, "csr_in_place"))
+    *value = ctx->csr_in_place;
   else if (!strcmp(key, "lx_min_nnz"))
     *value = ctx->lx_min_nnz;
   else if (!strcmp(key, "lat_min_nnz"))
@@ -165,6 +169,16 @@ int spmv_hip_ctx_set_option(spmv_hip_ctx* ctx, const char* key, int64_t value)
   if (!strcmp(key, "xw_min_nnz")) {
     SPMV_REQUIRE(value >= 0);
     ctx->xw_min_nnz = value;
+    return SPMV_HIP_OK;
+  }
+  if (!strcmp(key, "xw_probe")) {
+    SPMV_REQUIRE(value == 0 || value == 1);
+    ctx->xw_probe = (int)value;
+    return SPMV_HIP_OK;
+  }
+  if (!strcmp(key, "csr_in_place")) {
+    SPMV_REQUIRE(value == 0 || value == 1);
+    ctx->csr_in_place = (int)value;
     return SPMV_HIP_OK;
   }
   if (!strcmp(key, "lat_min_nnz")) {

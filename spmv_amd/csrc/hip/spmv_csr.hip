@@ -684,6 +684,98 @@ __global__ __launch_bounds__(kBlock) void csr_vector_kernel(
     spmv_dot_epilogue(dot, dot_acc, s_red);
 }
 
+} // namespace
+
+// XW or the gather kernel?  Both stream the caller's arrays untouched and give
+// the same bits; XW moves 2 GB less across the fabric at 512^3 but runs two
+// workgroups per CU against eight, and which of them is faster differed from
+// box to box by a few per cent either way (five pairs
+// 4 : 1 for XW, the round-5 driver's box the other way).  So the plan lets its
+// first four launches decide -- every one of them a full, correct product:
+//   launch 0 XW, 1 gather (cold: not looked at), 2 XW, 3 gather (timed by HIP
+//   events on the launch's own stream); the first later launch that finds the
+//   last event complete reads the two times and fixes the choice.
+// Nothing is allocated, nothing runs twice, no launch waits for the host.
+struct XwProbe {
+  int launches = 0;
+  int decided = 0;  // the choice is fixed
+  int use_xw = 1;   // ... to this
+  hipEvent_t ev[4][2] = {};
+  float us_xw = 0.f, us_gather = 0.f;
+};
+
+namespace
+{
+
+void xw_probe_free(spmv_hip_csr_plan* pl)
+{
+  if (!pl->xw_probe)
+    return;
+  for (auto& e : pl->xw_probe->ev)
+    for (hipEvent_t& h : e)
+      if (h) {
+        (void)hipEventDestroy(h);
+        h = nullptr;
+      }
+  delete pl->xw_probe;
+  pl->xw_probe = nullptr;
+}
+
+void xw_probe_drop_events(XwProbe* pb)
+{
+  for (auto& e : pb->ev)
+    for (hipEvent_t& h : e)
+      if (h) {
+        (void)hipEventDestroy(h);
+        h = nullptr;
+      }
+}
+
+// Which kernel does this launch run (1 = XW, 0 = gather)?  *probing = the
+// index of the event pair to record around it, or -1.
+int xw_probe_pick(XwProbe* pb, hipStream_t st, int* probing)
+{
+  *probing = -1;
+  if (!pb || pb->decided)
+    return pb ? pb->use_xw : 1;
+  if (pb->launches < 4) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    // (inside a graph capture nothing is timed: XW, as without the probe)
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess
+        || cs != hipStreamCaptureStatusNone) {
+      (void)hipGetLastError();
+      return 1;
+    }
+    const int i = pb->launches;
+    if (!pb->ev[i][0]
+        && (hipEventCreate(&pb->ev[i][0]) != hipSuccess
+            || hipEventCreate(&pb->ev[i][1]) != hipSuccess)) {
+      (void)hipGetLastError();
+      xw_probe_drop_events(pb);
+      pb->decided = 1; // no events: the size rule stands
+      return pb->use_xw;
+    }
+    *probing = i;
+    return (i & 1) ? 0 : 1;
+  }
+  // the four launches are out: read them as soon as the last one has finished
+  if (hipEventQuery(pb->ev[3][1]) == hipSuccess) {
+    float a = 0.f, b = 0.f;
+    if (hipEventElapsedTime(&a, pb->ev[2][0], pb->ev[2][1]) == hipSuccess
+        && hipEventElapsedTime(&b, pb->ev[3][0], pb->ev[3][1]) == hipSuccess) {
+      pb->us_xw = a * 1e3f;
+      pb->us_gather = b * 1e3f;
+      pb->use_xw = a <= b ? 1 : 0;
+    }
+    (void)hipGetLastError();
+    xw_probe_drop_events(pb);
+    pb->decided = 1;
+    return pb->use_xw;
+  }
+  (void)hipGetLastError(); // hipErrorNotReady
+  return 1;
+}
+
 template <typename TV, typename T, int CH, bool NT, bool ALIGNED, bool DOT>
 int launch_rowblock_x(const spmv_hip_csr_plan* pl, hipStream_t st, int grid,
                       int nrb, const int32_t* rowptr, const int32_t* colind,
@@ -801,14 +893,38 @@ int launch_rowblock(const spmv_hip_csr_plan* pl, hipStream_t st,
     SPMV_CHECK_LAUNCH();
     return SPMV_HIP_OK;
   }
-  // the caller's arrays as they are, x windows staged (spmv_lxw.hip, XW)
+  // the caller's arrays as they are, x windows staged (spmv_lxw.hip, XW) --
+  // or gathered, where the plan's first launches found that faster (XwProbe)
+  int probing = -1;
   if (pl->xw && pl->xw_rec && al && aligned16(in)) {
-    if constexpr (sizeof(T) == 8)
-      return spmv_xw_run_f64(pl, st, rowptr, colind, values, alpha, in, beta,
-                             out, DOT ? dot : DotOut());
-    else
-      return spmv_xw_run_f32(pl, st, rowptr, colind, values, alpha, in, beta, out);
+    const int use_xw = xw_probe_pick(pl->xw_probe, st, &probing);
+    if (probing >= 0)
+      SPMV_CHECK_HIP(hipEventRecord(pl->xw_probe->ev[probing][0], st));
+    if (use_xw) {
+      int rc;
+      if constexpr (sizeof(T) == 8)
+        rc = spmv_xw_run_f64(pl, st, rowptr, colind, values, alpha, in, beta, out,
+                             DOT ? dot : DotOut());
+      else
+        rc = spmv_xw_run_f32(pl, st, rowptr, colind, values, alpha, in, beta, out);
+      if (probing >= 0 && rc == SPMV_HIP_OK) {
+        SPMV_CHECK_HIP(hipEventRecord(pl->xw_probe->ev[probing][1], st));
+        pl->xw_probe->launches = probing + 1;
+      }
+      return rc;
+    }
   }
+  // (a probed gather launch: the closing event and the count)
+  struct ProbeEnd {
+    const spmv_hip_csr_plan* pl;
+    hipStream_t st;
+    int i;
+    ~ProbeEnd()
+    {
+      if (i >= 0 && hipEventRecord(pl->xw_probe->ev[i][1], st) == hipSuccess)
+        pl->xw_probe->launches = i + 1;
+    }
+  } probe_end{pl, st, probing};
 #define SPMV_RB(CH, NT, AL)                                                    \
   return launch_rowblock_x<T, T, CH, NT, AL, DOT>(pl, st, grid, nrb, rowptr,   \
                                                colind, values, alpha, in,     \
@@ -1012,6 +1128,7 @@ void free_xw(spmv_hip_csr_plan* pl)
   (void)hipFree(pl->xw_rec);
   pl->xw_rec = nullptr;
   pl->xw = pl->xw_staged = pl->xw_max_cnt = pl->xw_max_pieces = 0;
+  xw_probe_free(pl);
 }
 
 // The XW records (spmv_lxw.hip): per row block its span, the DMA pieces of its
@@ -1074,7 +1191,34 @@ int build_xw(spmv_hip_csr_plan* pl, const int32_t* rowptr, const int32_t* colind
     return SPMV_HIP_OK;
   }
   pl->xw = 1;
+  if (pl->ctx->xw_probe)
+    pl->xw_probe = new (std::nothrow) XwProbe;
   return SPMV_HIP_OK;
+}
+
+// ... with the plane-walk order when the matrix sits on a 3-D grid
+int build_xw_and_walk(spmv_hip_csr_plan* pl, const int32_t* rowptr,
+                      const int32_t* colind)
+{
+  int rc = build_xw(pl, rowptr, colind);
+  if (rc == SPMV_HIP_OK && pl->xw) {
+    const int64_t d2 = plane_distance(pl, rowptr, colind);
+    if (d2 > 0) {
+      pl->lattice_d2 = (int)d2;
+      rc = spmv_zwalk_order_build(pl, d2, spmv_walk_grid(pl), 0, false);
+    }
+  }
+  return rc;
+}
+
+// may this plan stage x windows over the caller's arrays?
+bool xw_applies(const spmv_hip_csr_plan* pl)
+{
+  const spmv_hip_ctx* ctx = pl->ctx;
+  return !pl->symmetric && pl->algo == SPMV_HIP_ALGO_ROWBLOCK && !pl->lat && !pl->lx
+         && pl->num_rows > 0 && pl->nnz >= ctx->xw_min_nnz
+         && (double)pl->nnz / pl->num_rows <= 16.0
+         && (int64_t)pl->num_cols * 8 >= ctx->xw_min_x_bytes;
 }
 
 struct IsStagedRecord {
@@ -1585,7 +1729,10 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
     int rc = SPMV_HIP_OK;
     if (num_non_zeros >= ctx->lat_min_nnz && avg <= 8.0)
       rc = spmv_lat_build(pl, rowptr, colind);
-    if (rc == SPMV_HIP_OK && !pl->lat && num_non_zeros >= ctx->lx_min_nnz
+    // (ctx option "csr_in_place": the plan makes no copy of the index or value
+    // stream -- neither the LX form's offsets nor the sliced jagged arrays)
+    const bool copies = !ctx->csr_in_place;
+    if (rc == SPMV_HIP_OK && !pl->lat && copies && num_non_zeros >= ctx->lx_min_nnz
         && avg <= 16.0 && (int64_t)num_cols * 8 <= ctx->lx_max_x_bytes)
       rc = build_lx(pl, rowptr, colind);
     // Neither: the sliced jagged form (spmv_sjds.hip) -- ragged rows, more
@@ -1593,25 +1740,21 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
     // built by plan_bake_values, structure and values together, once the
     // diagonal forms have refused the matrix (a 27-point stencil has 27
     // entries per row too, and its analysis would be 50 ms for nothing).
-    pl->sj_wanted = !pl->lat && !pl->lx && num_non_zeros >= ctx->sj_min_nnz;
+    pl->sj_wanted
+        = !pl->lat && !pl->lx && copies && num_non_zeros >= ctx->sj_min_nnz;
     // Neither of them and no sliced jagged form to come: the caller's CSR
     // arrays as they are.  From ctx->xw_min_nnz entries on the XW kernel
     // (spmv_lxw.hip): values and the 32-bit column indices by LDS-DMA, the x
     // windows of every row block staged -- the gather kernel fetched x across
     // the fabric 3.5 times at 512^3 -- in the plane-walk order when the
-    // matrix sits on a 3-D grid.
-    if (rc == SPMV_HIP_OK && !pl->lat && !pl->lx && !pl->sj_wanted
-        && num_non_zeros >= ctx->xw_min_nnz && avg <= 16.0
-        && (int64_t)num_cols * 8 >= ctx->xw_min_x_bytes) {
-      rc = build_xw(pl, rowptr, colind);
-      if (rc == SPMV_HIP_OK && pl->xw) {
-        const int64_t d2 = plane_distance(pl, rowptr, colind);
-        if (d2 > 0) {
-          pl->lattice_d2 = (int)d2;
-          rc = spmv_zwalk_order_build(pl, d2, spmv_walk_grid(pl), 0, false);
-        }
-      }
-    }
+    // matrix sits on a 3-D grid.  With default options a matrix XW can stage
+    // is one the LX form can stage too (the same window analysis, 16 windows
+    // against 8), so XW is what "csr_in_place" plans get, what is left when
+    // the LX form's 2 B per entry could not be allocated, and -- below, in
+    // plan_bake_values -- what a plan whose sliced jagged form was declined
+    // runs instead of the gather kernel.
+    if (rc == SPMV_HIP_OK && !pl->sj_wanted && xw_applies(pl))
+      rc = build_xw_and_walk(pl, rowptr, colind);
     if (rc != SPMV_HIP_OK) {
       spmv_hip_csr_plan_destroy(pl);
       return rc;
@@ -1723,6 +1866,22 @@ int spmv_hip_csr_plan_bake_values_f64(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan
     const int rj = spmv_sjds_bake_f64(plan, values, nullptr, st);
     rc = values == nullptr ? (rj != SPMV_HIP_OK ? rj : rc) : rj;
   }
+  // the sliced jagged form was wanted and could not be had (rows too long for
+  // its length field, no memory for the copy): stage the x windows over the
+  // caller's arrays rather than gather, where that applies
+  if (values && rc == SPMV_HIP_ENOTSUP && plan->sj_wanted && !plan->sj_lenperm
+      && !plan->no_new_forms) {
+    plan->sj_wanted = false; // (declined: later bakes do not analyse it again)
+    if (!plan->xw_rec && xw_applies(plan)) {
+      const auto t0 = std::chrono::steady_clock::now();
+      const int rx = build_xw_and_walk(plan, plan->rowptr0, plan->colind0);
+      if (rx != SPMV_HIP_OK)
+        return rx;
+      plan->plan_us += (int)std::chrono::duration_cast<std::chrono::microseconds>(
+                           std::chrono::steady_clock::now() - t0)
+                           .count();
+    }
+  }
   // symmetric storage without lattice structure: both blocks sliced jagged
   if (plan->symmetric && (values == nullptr ? plan->sjt != nullptr
                                             : rc == SPMV_HIP_ENOTSUP)) {
@@ -1768,6 +1927,22 @@ int spmv_hip_csr_plan_bake_values_f32(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan
       && (values == nullptr || rc == SPMV_HIP_ENOTSUP)) {
     const int rj = spmv_sjds_bake_f32(plan, values, nullptr, st);
     rc = values == nullptr ? (rj != SPMV_HIP_OK ? rj : rc) : rj;
+  }
+  // the sliced jagged form was wanted and could not be had (rows too long for
+  // its length field, no memory for the copy): stage the x windows over the
+  // caller's arrays rather than gather, where that applies
+  if (values && rc == SPMV_HIP_ENOTSUP && plan->sj_wanted && !plan->sj_lenperm
+      && !plan->no_new_forms) {
+    plan->sj_wanted = false; // (declined: later bakes do not analyse it again)
+    if (!plan->xw_rec && xw_applies(plan)) {
+      const auto t0 = std::chrono::steady_clock::now();
+      const int rx = build_xw_and_walk(plan, plan->rowptr0, plan->colind0);
+      if (rx != SPMV_HIP_OK)
+        return rx;
+      plan->plan_us += (int)std::chrono::duration_cast<std::chrono::microseconds>(
+                           std::chrono::steady_clock::now() - t0)
+                           .count();
+    }
   }
   if (plan->symmetric && (values == nullptr ? plan->sjt != nullptr
                                             : rc == SPMV_HIP_ENOTSUP)) {
@@ -1980,9 +2155,23 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
     // the LDS-DMA kernel on the caller's CSR arrays (needs its records)
     SPMV_REQUIRE(value == 0 || plan->xw_rec);
     plan->xw = value != 0;
+    if (plan->xw_probe && value) { // asked for by name: no probe decides
+      plan->xw_probe->decided = 1;
+      plan->xw_probe->use_xw = 1;
+    }
     if (plan->zw_table && plan->xw_rec && !plan->lat_tab && !plan->lx_lidx)
       return spmv_zwalk_order_build(plan, plan->zw_d2, spmv_walk_grid(plan), 0,
                                     true);
+  } else if (!strcmp(key, "xw_probe")) {
+    // 1: (re)start the choice between XW and the gather kernel by the next
+    // four launches; 0: XW from here on
+    SPMV_REQUIRE((value == 0 || value == 1) && plan->xw_rec);
+    if (!plan->xw_probe)
+      plan->xw_probe = new (std::nothrow) XwProbe;
+    SPMV_REQUIRE(plan->xw_probe);
+    xw_probe_drop_events(plan->xw_probe);
+    *plan->xw_probe = XwProbe();
+    plan->xw_probe->decided = value ? 0 : 1;
   } else if (!strcmp(key, "lxw_blocks_per_cu")) {
     SPMV_REQUIRE(value >= 0 && value <= kBlocksPerCU);
     plan->lxw_blocks_per_cu = value;
@@ -2218,6 +2407,15 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
     *value = plan->xw && plan->xw_rec ? 1 : 0;
   else if (!strcmp(key, "xw_staged"))
     *value = plan->xw_staged;
+  else if (!strcmp(key, "xw_pick")) // -1: the probe is still running
+    *value = !(plan->xw && plan->xw_rec) ? 0
+             : !plan->xw_probe           ? 1
+             : plan->xw_probe->decided   ? plan->xw_probe->use_xw
+                                         : -1;
+  else if (!strcmp(key, "xw_probe_xw_us"))
+    *value = plan->xw_probe ? (int)plan->xw_probe->us_xw : 0;
+  else if (!strcmp(key, "xw_probe_gather_us"))
+    *value = plan->xw_probe ? (int)plan->xw_probe->us_gather : 0;
   else if (!strcmp(key, "plan_us"))
     *value = plan->plan_us;
   else if (!strcmp(key, "values_changed_us"))

@@ -2329,6 +2329,141 @@ def test_xw_fuzz_banded(xw_ctx):
     assert seen_xw > 0
 
 
+def test_xw_probe_lets_the_first_launches_choose(xw_ctx):
+    """XW or the gather kernel: launches 0-3 of a plan with XW records alternate
+    between the two under HIP events, a later launch reads the times and fixes
+    the choice.  Every launch -- probing or not -- returns
+    the oracle's bits; plan_set "xw_probe" restarts or ends the probe, "xw" = 1
+    asks for the kernel by name; the context option switches the probe off."""
+    ctx = xw_ctx
+    n = 40
+    N = n ** 3
+    rp, ci, va = poisson.poisson3d_csr(n)
+    ci = ci.astype(np.int32)
+    rng = np.random.default_rng(61)
+    va = rng.uniform(-1, 1, len(va))
+    x = rng.uniform(-1, 1, N)
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    blk = hip.CsrBlock(ctx, N, N, rp, ci, va, None, False, hip.ALGO_ROWBLOCK)
+    assert blk.get("xw") == 1 and blk.get("xw_pick") == -1
+    dx = ctx.upload(x)
+    part = ctx.empty(ctx.dot_partials_len, np.float64)
+
+    def launch(dot=False):
+        dy = ctx.upload(np.full(N, np.nan))
+        blk.mult(1.0, dx.ptr, 0.0, dy.ptr, dot_partials=part.ptr if dot else None)
+        y = dy.numpy()  # (synchronises)
+        dy.free()
+        assert np.array_equal(y, y_ref)
+    for i in range(4):
+        assert blk.get("xw_pick") == -1, i
+        launch(dot=bool(i & 1))
+    launch()  # the four are complete: this one reads them
+    pick = blk.get("xw_pick")
+    assert pick in (0, 1)
+    assert blk.get("xw_probe_xw_us") > 0 and blk.get("xw_probe_gather_us") > 0
+    assert pick == (blk.get("xw_probe_xw_us") <= blk.get("xw_probe_gather_us")) \
+        or blk.get("xw_probe_xw_us") == blk.get("xw_probe_gather_us")
+    launch(dot=True)
+    assert blk.get("xw_pick") == pick
+    blk.set("xw_probe", 1)  # again
+    assert blk.get("xw_pick") == -1
+    for _ in range(6):
+        launch()
+    assert blk.get("xw_pick") in (0, 1)
+    blk.set("xw_probe", 0)
+    assert blk.get("xw_pick") == 1
+    blk.set("xw_probe", 1)
+    blk.set("xw", 1)  # by name
+    assert blk.get("xw_pick") == 1
+    launch()
+    blk.free()
+    ctx.set_option("xw_probe", 0)
+    blk = hip.CsrBlock(ctx, N, N, rp, ci, va, None, False, hip.ALGO_ROWBLOCK)
+    assert blk.get("xw") == 1 and blk.get("xw_pick") == 1
+    launch()
+    blk.free()
+    for b in (dx, part):
+        b.free()
+
+
+def test_sliced_jagged_form_declined_leaves_the_xw_kernel():
+    """a plan that wanted the sliced jagged form and could not have
+    it (here: 8 staged chunks per block leave nearly every entry far) stages the
+    x windows over the caller's arrays instead of gathering -- with the default
+    sj_min_nnz / xw_min_nnz thresholds (both 2^20)."""
+    ctx = hip.Context(0)
+    ctx.set_option("lx_min_nnz", 1 << 62)
+    ctx.set_option("lat_min_nnz", 1 << 62)
+    ctx.set_option("sj_max_chunks", 8)
+    ctx.set_option("xw_min_x_bytes", 0)
+    n = 64
+    N = n ** 3
+    rp, ci, va = poisson.poisson3d_csr(n)
+    ci = ci.astype(np.int32)
+    rng = np.random.default_rng(62)
+    va = rng.uniform(-1, 1, len(va))
+    x = rng.uniform(-1, 1, N)
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    blk = hip.CsrBlock(ctx, N, N, rp, ci, va, None, False, hip.ALGO_ROWBLOCK)
+    assert blk.get("xw") == 0  # the sliced jagged form is to come with the values
+    with pytest.raises(Exception):  # SPMV_HIP_ENOTSUP: no form holds the values
+        blk.bake()
+    assert blk.get("sjds") == 0 and blk.get("lx") == 0 and blk.get("lat") == 0
+    assert blk.get("xw") == 1 and blk.get("xw_staged") == (N + 255) // 256
+    with pytest.raises(Exception):  # ... and the analysis is not repeated
+        blk.bake()
+    dx = ctx.upload(x)
+    for _ in range(6):
+        dy = ctx.upload(np.full(N, np.nan))
+        blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+        assert np.array_equal(dy.numpy(), y_ref)
+        dy.free()
+    assert blk.get("xw_pick") in (0, 1)
+    dx.free()
+    blk.free()
+    ctx.close()
+
+
+def test_csr_in_place_plans_take_xw_at_the_default_thresholds():
+    """The context option csr_in_place: no copy of the index or value stream (no
+    LX form, no sliced jagged form) -- a banded matrix whose x outgrows the
+    caches (17 M columns = 134 MB >= xw_min_x_bytes) gets the XW kernel with
+    every threshold at its default; without the option the LX form."""
+    N = 17_000_000
+    rng = np.random.default_rng(63)
+    rows = np.arange(N, dtype=np.int64)
+    cols = np.stack([rows + 60 * k - 120 + rng.integers(0, 50, N) for k in range(4)],
+                    axis=1)
+    ci = np.clip(cols, 0, N - 1).astype(np.int32).ravel()
+    rp = (np.arange(N + 1, dtype=np.int64) * 4).astype(np.int32)
+    va = rng.uniform(-1, 1, len(ci))
+    x = rng.uniform(-1, 1, N)
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    for in_place in (1, 0):
+        ctx = hip.Context(0)
+        ctx.set_option("csr_in_place", in_place)
+        blk = hip.CsrBlock(ctx, N, N, rp, ci, va, None, False, hip.ALGO_AUTO)
+        assert blk.get("lat") == 0 and blk.get("sjds") == 0
+        if in_place:
+            assert blk.get("xw") == 1 and blk.get("lx") == 0
+            # 144 B per row block, nothing per entry
+            assert blk.get("plan_kib") <= ((N + 255) // 256 * 144) // 1024 + 8
+        else:
+            assert blk.get("xw") == 0 and blk.get("lx") == 1
+        dx = ctx.upload(x)
+        for _ in range(6):
+            dy = ctx.upload(np.full(N, np.nan))
+            blk.mult(1.0, dx.ptr, 0.0, dy.ptr)
+            assert np.array_equal(dy.numpy(), y_ref), in_place
+            dy.free()
+        if in_place:
+            assert blk.get("xw_pick") in (0, 1)
+        dx.free()
+        blk.free()
+        ctx.close()
+
+
 # ---------------------------------------------------------------------------
 # Lattice form (spmv_lat.hip): constant column offsets per row block, values by
 # LDS-DMA one row block ahead, no index stream.  Same bits as the oracle.
