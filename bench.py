@@ -134,6 +134,13 @@ def parse():
     ap.add_argument("--petsc-rhs", default=None,
                     help="PETSc binary vector file for the right-hand side "
                          "(demos/cg.cpp:51); default: the Gaussian vector")
+    ap.add_argument("--rank-shape", type=int, nargs="*", default=None, metavar="P",
+                    help="MODEL, instead of the benchmark: one interior rank of "
+                         "P (default 2 4 8) ranks at --grid, alone on this GPU, "
+                         "the P > 1 launch sequence of cg() with a no-op "
+                         "transport -- ms per iteration and launches per "
+                         "iteration of the per-rank critical path "
+                         "(tools/rank_shape.py; DESIGN.md section 6)")
     ap.add_argument("--put-timeout-ms", type=int, default=None,
                     help="bound of the waits of the one-sided halo and of the peer "
                          "reduction (ctx option put_timeout_ms; default 60 s)")
@@ -808,10 +815,6 @@ def compact_line(out, detail_path):
         roof["ragged_plan_over_csr"] = {
             k: sig(out[k]["plan_extra_bytes"] / out[k]["csr_bytes"], 3)
             for k in r["ragged"] if k in out and "csr_bytes" in out[k]}
-    rs = out.get("rank_shape")
-    if rs:  # per-rank critical path at configs[4]'s shapes (a model, 1 GPU)
-        roof["rank_shape_ms"] = {str(k): sig(v["ms_per_iteration"])
-                                 for k, v in rs.items() if isinstance(v, dict)}
     if "plan" in out and r["algorithmic_bytes_per_launch"]:
         roof["plan_extra_over_csr_bytes"] = sig(
             out["plan"]["plan_extra_bytes"] / out["plan"]["csr_bytes"], 3)
@@ -899,6 +902,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.rank_shape is not None:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import rank_shape
+        recs = {}
+        for plain in (True, False):
+            for P in (args.rank_shape or [2, 4, 8]):
+                recs[("csr_order" if plain else "specialised") + f"_P{P}"] = \
+                    rank_shape.model(P, args.n, args.steps, plain,
+                                     symmetric=args.symmetric)
+        print(json.dumps({"rank_shape": recs, "grid": args.n, "steps": args.steps,
+                          "data": "MODEL: one rank of P alone on one GPU, no-op "
+                                  "transport; not a scaling measurement"}),
+              flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
     if world != args.gpus:

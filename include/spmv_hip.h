@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SPMV_HIP_ABI_VERSION 4
+#define SPMV_HIP_ABI_VERSION 5
 
 enum {
   SPMV_HIP_OK = 0,
@@ -679,11 +679,21 @@ int spmv_hip_put_connect(spmv_hip_put* put, int k, const void* peer_ipc_handle,
                          int32_t send_count, int32_t recv_offset,
                          int32_t recv_count, int peer_fine_grained);
 int spmv_hip_put_fine_grained(const spmv_hip_put* put, int* fine_grained);
+/* labels for the diagnosis below: my rank, and the rank behind neighbour slot
+ * k (k = -1: my rank only) */
+int spmv_hip_put_label(spmv_hip_put* put, int my_rank, int k, int peer_rank);
 int spmv_hip_put_finish(spmv_hip_put* put);
 int spmv_hip_put_exchange(spmv_hip_ctx* ctx, spmv_hip_put* put, size_t elem_bytes,
                           const void* send_buf, void* ghost_tail, void* stream);
 int spmv_hip_put_status(const spmv_hip_put* put, int* failed);
 int spmv_hip_put_destroy(spmv_hip_put* put);
+
+/* After SPMV_HIP_EPEER: WHICH bounded wait gave up (ABI 5).  The first waiter
+ * that times out -- a put kernel at its FREE or DATA flag, a reduction kernel
+ * at a peer's slot -- records which wait it was, on which neighbour slot / rank,
+ * the epoch it saw there and the epoch it wanted; this formats that record of
+ * the context's first failed window into `buf` (empty string: none failed). */
+int spmv_hip_peer_error_detail(const spmv_hip_ctx* ctx, char* buf, size_t len);
 
 /* ---- deterministic peer reduction of the CG scalars -------------------------
  * The two MPI_Allreduce of cg() (cg.cpp:65,75; and :49) move ONE double each.

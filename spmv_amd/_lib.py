@@ -140,6 +140,8 @@ _PROTOS = {
     "spmv_hip_put_connect": ([vp, C.c_int, vp, C.c_uint64, i64, sz, i32, i32, i32,
                               i32, i32, i32, C.c_int], C.c_int),
     "spmv_hip_put_fine_grained": ([vp, P(C.c_int)], C.c_int),
+    "spmv_hip_put_label": ([vp, C.c_int, C.c_int, C.c_int], C.c_int),
+    "spmv_hip_peer_error_detail": ([vp, C.c_char_p, sz], C.c_int),
     "spmv_hip_put_finish": ([vp], C.c_int),
     "spmv_hip_put_exchange": ([vp, vp, sz, vp, vp, vp], C.c_int),
     "spmv_hip_put_status": ([vp, P(C.c_int)], C.c_int),

@@ -107,6 +107,29 @@ struct spmv_hip_ctx {
   int poisson_stencil = 7;
 };
 
+// What a bounded wait that times out leaves behind: a record of kPeerErrWords
+// int32 in pinned host memory whose FIRST word is the error flag the context
+// watches.  The first waiter to fail claims the record and describes itself --
+// which wait, on whom, the epoch it saw against the epoch it wanted -- so that
+// SPMV_HIP_EPEER names the kernel that never arrived instead of one bit:
+//   [0] error flag      [1] claim          [2] which wait (PeerWait)
+//   [3] peer: neighbour slot (put) / rank (reduce)
+//   [4] workgroup of the waiter            [5] my rank (label, -1 = unknown)
+//   [6..7] epoch seen   [8..9] epoch wanted
+//   [kPeerErrLabels + k] rank behind neighbour slot k (put; -1 = unknown)
+enum PeerWait : int32_t {
+  kWaitNone = 0,
+  kWaitPutFree = 1,   // put kernel, step (b): the neighbour's "your segment in
+                      // my window is free" -- its put kernel of this epoch has
+                      // not STARTED
+  kWaitPutData = 2,   // put kernel, step (d): the neighbour's data flag -- its
+                      // put kernel started but has not finished its stores
+  kWaitReduceSlot = 3 // reduction kernel: the peer's slot in my window -- its
+                      // reduction kernel of this epoch has not run
+};
+constexpr int kPeerErrLabels = 12;
+constexpr int kPeerErrWords = kPeerErrLabels + 16; // SPMV_HIP_PUT_MAX_PEERS
+
 // error words (pinned host memory, written by kernels) the context looks at
 // whenever the host synchronises: a non-zero one = SPMV_HIP_EPEER
 // (false: no memory for the entry -- the window must not be used unwatched)
@@ -169,6 +192,25 @@ struct DotOut {
 };
 
 #ifdef __HIPCC__
+// a timed-out wait describes itself (first failure wins the record), then
+// raises the flag
+__device__ __forceinline__ void spmv_peer_fail(int32_t* err, int32_t which,
+                                               int32_t peer, uint64_t seen,
+                                               uint64_t wanted)
+{
+  if (atomicCAS_system(reinterpret_cast<int*>(err + 1), 0, 1) == 0) {
+    err[2] = which;
+    err[3] = peer;
+    err[4] = (int32_t)blockIdx.x;
+    err[6] = (int32_t)(seen & 0xffffffffu);
+    err[7] = (int32_t)(seen >> 32);
+    err[8] = (int32_t)(wanted & 0xffffffffu);
+    err[9] = (int32_t)(wanted >> 32);
+    __threadfence_system();
+  }
+  __hip_atomic_store(err, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Block-wide sum of one double per thread (fixed tree => deterministic).
 __device__ __forceinline__ double spmv_block_sum(double v, double* s_red)
 {

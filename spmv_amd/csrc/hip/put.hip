@@ -74,18 +74,21 @@ __device__ __forceinline__ uint64_t* put_flags(char* window, size_t stage_bytes)
 // thread 0 polls, the workgroup follows; false = timed out
 __device__ __forceinline__ bool put_wait(const uint64_t* flag, uint64_t epoch,
                                          int32_t* err,
-                                         unsigned long long timeout_ticks)
+                                         unsigned long long timeout_ticks,
+                                         int32_t which, int32_t slot)
 {
   __shared__ int s_ok;
   if (threadIdx.x == 0) {
     const unsigned long long t0 = wall_clock64();
     int ok = 1;
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+    uint64_t seen;
+    while ((seen = __hip_atomic_load(flag, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_SYSTEM))
            < epoch) {
       __builtin_amdgcn_s_sleep(16);
       if (wall_clock64() - t0 > timeout_ticks) {
         ok = 0;
-        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        spmv_peer_fail(err, which, slot, seen, epoch);
         break;
       }
     }
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(kBlock) void put_exchange_kernel(
       dst[i] = ~WORD(0); // all ones: a NaN in either width
   };
   // (b) ... and so may I, once it says the same
-  if (!put_wait(my_free_flag, epoch, err, timeout_ticks)) {
+  if (!put_wait(my_free_flag, epoch, err, timeout_ticks, kWaitPutFree, k)) {
     poison();
     return;
   }
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(kBlock) void put_exchange_kernel(
   }
   // (d) the neighbour's data -> the ghost tail (loads that bypass the caches:
   // the lines were written by another agent)
-  if (!put_wait(my_data_flag, epoch, err, timeout_ticks)) {
+  if (!put_wait(my_data_flag, epoch, err, timeout_ticks, kWaitPutData, k)) {
     poison();
     return;
   }
@@ -217,11 +220,13 @@ int spmv_hip_put_create(spmv_hip_ctx* ctx, size_t stage_bytes,
   if (e == hipSuccess)
     e = hipMemset(p->window, 0, bytes);
   if (e == hipSuccess)
-    e = hipHostMalloc(reinterpret_cast<void**>(&p->host_err), sizeof(int32_t),
-                      hipHostMallocMapped);
+    e = hipHostMalloc(reinterpret_cast<void**>(&p->host_err),
+                      sizeof(int32_t) * kPeerErrWords, hipHostMallocMapped);
   bool watched = false;
   if (e == hipSuccess) {
-    *p->host_err = 0;
+    memset(p->host_err, 0, sizeof(int32_t) * kPeerErrWords);
+    for (int k = 5; k < kPeerErrWords; k = k == 5 ? kPeerErrLabels : k + 1)
+      p->host_err[k] = -1; // labels unknown until spmv_hip_put_label
     watched = spmv_ctx_watch(ctx, p->host_err, true);
   }
   if (e != hipSuccess || !watched) { // (never a window whose failures go unseen)
@@ -349,6 +354,15 @@ int spmv_hip_put_exchange(spmv_hip_ctx* ctx, spmv_hip_put* put, size_t elem_byte
   return SPMV_HIP_OK;
 }
 
+int spmv_hip_put_label(spmv_hip_put* put, int my_rank, int k, int peer_rank)
+{
+  SPMV_REQUIRE(put && k >= -1 && k < SPMV_HIP_PUT_MAX_PEERS);
+  put->host_err[5] = my_rank;
+  if (k >= 0)
+    put->host_err[kPeerErrLabels + k] = peer_rank;
+  return SPMV_HIP_OK;
+}
+
 int spmv_hip_put_fine_grained(const spmv_hip_put* put, int* fine_grained)
 {
   SPMV_REQUIRE(put && fine_grained);
@@ -435,7 +449,9 @@ __global__ __launch_bounds__(64) void peer_reduce_kernel(
     const ReduceSlot* src = peers[me] + par + t;
     const unsigned long long t0 = wall_clock64();
     bool ok = true;
-    while (__hip_atomic_load(&src->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+    uint64_t seen;
+    while ((seen = __hip_atomic_load(&src->epoch, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_SYSTEM))
            < epoch) {
       __builtin_amdgcn_s_sleep(4);
       if (wall_clock64() - t0 > timeout_ticks) {
@@ -450,7 +466,7 @@ __global__ __launch_bounds__(64) void peer_reduce_kernel(
                                       __HIP_MEMORY_SCOPE_SYSTEM);
     } else {
       s_fail = 1;
-      __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      spmv_peer_fail(err, kWaitReduceSlot, t, seen, epoch);
     }
   }
   __syncthreads();
@@ -508,15 +524,16 @@ int spmv_hip_reduce_create(spmv_hip_ctx* ctx, int nranks, int rank,
     e = hipMalloc(reinterpret_cast<void**>(&r->dev_peers),
                   sizeof(ReduceSlot*) * SPMV_HIP_REDUCE_MAX_RANKS);
   if (e == hipSuccess)
-    e = hipHostMalloc(reinterpret_cast<void**>(&r->host_err), sizeof(int32_t),
-                      hipHostMallocMapped);
+    e = hipHostMalloc(reinterpret_cast<void**>(&r->host_err),
+                      sizeof(int32_t) * kPeerErrWords, hipHostMallocMapped);
   if (e != hipSuccess) {
     (void)hipFree(r->window);
     (void)hipFree(r->dev_peers);
     delete r;
     return static_cast<int>(e);
   }
-  *r->host_err = 0;
+  memset(r->host_err, 0, sizeof(int32_t) * kPeerErrWords);
+  r->host_err[5] = rank;
   if (!spmv_ctx_watch(ctx, r->host_err, true)) {
     (void)hipFree(r->window);
     (void)hipFree(r->dev_peers);

@@ -43,6 +43,47 @@ int spmv_ctx_check_watched(const spmv_hip_ctx* ctx)
 
 extern "C" {
 
+int spmv_hip_peer_error_detail(const spmv_hip_ctx* ctx, char* buf, size_t len)
+{
+  SPMV_REQUIRE(ctx && buf && len > 0);
+  buf[0] = 0;
+  std::lock_guard<std::mutex> lock(const_cast<spmv_hip_ctx*>(ctx)->watched_mutex);
+  for (const int32_t* w : ctx->watched) {
+    const volatile int32_t* v = reinterpret_cast<const volatile int32_t*>(w);
+    if (!v[0])
+      continue;
+    if (!v[1]) { // (flag without a claimed record: cannot happen after a sync)
+      snprintf(buf, len, "a bounded wait timed out (no record)");
+      return SPMV_HIP_OK;
+    }
+    const int which = v[2], peer = v[3];
+    const unsigned long long seen
+        = (unsigned long long)(uint32_t)v[6] | ((unsigned long long)(uint32_t)v[7] << 32);
+    const unsigned long long wanted
+        = (unsigned long long)(uint32_t)v[8] | ((unsigned long long)(uint32_t)v[9] << 32);
+    if (which == kWaitReduceSlot)
+      snprintf(buf, len,
+               "rank %d: reduction kernel of epoch %llu timed out waiting for rank "
+               "%d's slot in its window (slot shows epoch %llu: that rank's "
+               "reduction kernel of this epoch never ran)",
+               (int)v[5], wanted, peer, seen);
+    else
+      snprintf(buf, len,
+               "rank %d: put kernel of epoch %llu (workgroup %d) timed out waiting "
+               "for the %s flag of neighbour slot %d (rank %d); the flag shows "
+               "epoch %llu: %s",
+               (int)v[5], wanted, (int)v[4],
+               which == kWaitPutFree ? "FREE" : "DATA", peer,
+               peer >= 0 && peer < 16 ? (int)v[kPeerErrLabels + peer] : -1, seen,
+               which == kWaitPutFree
+                   ? "that neighbour's put kernel of this epoch never started"
+                   : "that neighbour's put kernel started (or not) but its stores "
+                     "never completed");
+    return SPMV_HIP_OK;
+  }
+  return SPMV_HIP_OK;
+}
+
 int spmv_hip_abi_version(void) { return SPMV_HIP_ABI_VERSION; }
 
 const char* spmv_hip_error_string(int code)

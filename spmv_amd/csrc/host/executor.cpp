@@ -21,6 +21,19 @@ void throw_on_error(int code, const char* what)
                              + std::to_string(code) + ")");
 }
 
+// a synchronisation point that found a timed-out wait (SPMV_HIP_EPEER): say
+// which wait it was, on whom, and the epochs (spmv_hip_peer_error_detail)
+static void throw_on_sync_error(spmv_hip_ctx* ctx, int code, const char* what)
+{
+  if (code != SPMV_HIP_EPEER)
+    return throw_on_error(code, what);
+  char detail[512] = {0};
+  (void)spmv_hip_peer_error_detail(ctx, detail, sizeof(detail));
+  throw std::runtime_error(std::string(what) + ": " + spmv_hip_error_string(code)
+                           + " (code " + std::to_string(code) + ")"
+                           + (detail[0] ? std::string(" -- ") + detail : ""));
+}
+
 // ---------------------------------------------------------------------------
 // HostExecutor: memory only
 // ---------------------------------------------------------------------------
@@ -143,7 +156,7 @@ void HipExecutor::detach_reduce_owner(const Comm* comm) const
 
 void HipExecutor::synchronize() const
 {
-  throw_on_error(spmv_hip_synchronize(_ctx), "spmv_hip_synchronize");
+  throw_on_sync_error(_ctx, spmv_hip_synchronize(_ctx), "spmv_hip_synchronize");
 }
 
 int HipExecutor::get_num_devices() const
@@ -207,14 +220,14 @@ void HipExecutor::stream_wait_event(void* s, void* e) const
 }
 void HipExecutor::synchronize_stream(void* s) const
 {
-  throw_on_error(spmv_hip_stream_synchronize(_ctx, s),
-                 "spmv_hip_stream_synchronize");
+  throw_on_sync_error(_ctx, spmv_hip_stream_synchronize(_ctx, s),
+                      "spmv_hip_stream_synchronize");
 }
 
 void HipExecutor::synchronize_event(void* e) const
 {
-  throw_on_error(spmv_hip_event_synchronize(_ctx, e),
-                 "spmv_hip_event_synchronize");
+  throw_on_sync_error(_ctx, spmv_hip_event_synchronize(_ctx, e),
+                      "spmv_hip_event_synchronize");
 }
 
 void* HipExecutor::_alloc(size_t num_bytes) const

@@ -210,6 +210,8 @@ void L2GMap::setup_put(std::int64_t local_size)
                               _x_recv_offset[i]
                                   - static_cast<std::int32_t>(local_size),
                               _x_recv_count[i], peer.fine);
+    if (rc == SPMV_HIP_OK) // (names in a timed-out wait's diagnosis)
+      rc = spmv_hip_put_label(put, _rank, static_cast<int>(i), _neighbours[i]);
   }
   if (rc == SPMV_HIP_OK && nn > 0)
     rc = spmv_hip_put_finish(put);

@@ -528,6 +528,10 @@ def test_put_exchange_times_out_instead_of_hanging(ctx):
     hip.call("spmv_hip_put_connect", put, 0, handle, raw, pid, 8 * n, 0, 3, 0, n,
              0, n, 1)
     hip.call("spmv_hip_put_finish", put)
+    hip.call("spmv_hip_put_label", put, 7, 0, 9)  # I am rank 7, slot 0 is rank 9
+    buf = C.create_string_buffer(512)
+    hip.call("spmv_hip_peer_error_detail", ctx.h, buf, 512)
+    assert buf.value == b""  # nothing has failed
     # a segment outside the staging buffers is refused at connect time
     with pytest.raises(Exception):
         hip.call("spmv_hip_put_connect", put, 1, handle, raw, pid, 8 * n, 1, 3, 0,
@@ -544,6 +548,13 @@ def test_put_exchange_times_out_instead_of_hanging(ctx):
     failed = C.c_int()
     hip.call("spmv_hip_put_status", put, C.byref(failed))
     assert failed.value == 1
+    # ... and the failure says WHICH wait gave up: the first exchange (epoch 1)
+    # never saw slot 0's FREE flag move (it signalled slot 3 instead)
+    hip.call("spmv_hip_peer_error_detail", ctx.h, buf, 512)
+    msg = buf.value.decode()
+    assert "rank 7: put kernel of epoch 1" in msg and "FREE flag" in msg, msg
+    assert "neighbour slot 0 (rank 9)" in msg and "shows epoch 0" in msg, msg
+    assert "never started" in msg
     # nothing was delivered, and the ghosts cannot be taken for valid ones: NaN
     out = np.empty(n)
     hip.call("spmv_hip_copy_d2h_async", ctx.h, out.ctypes.data_as(C.c_void_p),

@@ -158,7 +158,7 @@ def test_every_declared_symbol_is_exported():
             assert hasattr(lib, n), f"{n} declared in {header} but not exported"
     # and the Python prototypes cover exactly the declared ABI
     assert sorted(_lib.HIP_SYMBOLS) == _declared("spmv_hip.h", "spmv_hip_")
-    assert _lib.hip.spmv_hip_abi_version() == 4
+    assert _lib.hip.spmv_hip_abi_version() == 5
 
 
 def test_error_strings_and_loud_failure_without_gpu():

@@ -118,9 +118,21 @@ def main():
             rec["peer_reduce"] = bool(comm.enable_peer_reduce(exec_))
         tw.bar.wait()
         t0 = time.perf_counter()
-        k, hist, _, _ = host.cg_ex(comm, exec_, A, d_b, d_x, args.steps, 0.0, ws,
-                                   history=True, poll_every=args.poll_every)
-        exec_.synchronize()
+        try:
+            k, hist, _, _ = host.cg_ex(comm, exec_, A, d_b, d_x, args.steps, 0.0,
+                                       ws, history=True,
+                                       poll_every=args.poll_every)
+            exec_.synchronize()
+        except Exception as e:
+            # every rank's own account of the wait that gave up (the first
+            # failure alone would hide what the OTHER rank was waiting for);
+            # give the peers' kernels time to run into their own bound first
+            time.sleep(args.timeout_ms / 1e3 + 1.0)
+            buf = C.create_string_buffer(512)
+            _lib.call("spmv_hip_peer_error_detail", ctx, buf, 512)
+            print(f"rank {rank} FAILED: {e}\n  rank {rank} record: "
+                  f"{buf.value.decode() or '(none)'}", flush=True)
+            raise
         rec["cg_wall_s"] = time.perf_counter() - t0
         rec["k"] = k
         rec["k10"] = float(hist[min(10, len(hist) - 1)] / hist[0])
