@@ -10,6 +10,9 @@
 
 #include "common.h"
 
+#include <chrono>
+#include <cstdio>
+
 constexpr int kRows = kBlock; // rows per workgroup in ROWBLOCK kernels
 
 // clang ext-vector types: 16-byte loads/stores, accepted by the
@@ -173,6 +176,30 @@ constexpr int kLatRec = 12;   // ints per row-block record: count, 3 pad, offset
                               // (the offsets 16-byte aligned: one scalar load)
 // Wide diagonal form (spmv_wdia.hip): up to this many distinct col - row
 constexpr int kWdiaMaxOff = 32;
+
+// SPMV_PLAN_TRACE=1: where a plan's set-up time goes (stderr, milliseconds since
+// the tracer was made; every mark synchronises the device first so that the
+// kernels of a phase are counted in it).  Measurement only.
+struct PlanTrace {
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  const char* who;
+  explicit PlanTrace(const char* w)
+      : on(getenv("SPMV_PLAN_TRACE") != nullptr), t0(std::chrono::steady_clock::now()),
+        who(w)
+  {
+  }
+  void mark(const char* what) const
+  {
+    if (!on)
+      return;
+    (void)hipDeviceSynchronize();
+    fprintf(stderr, "%s %-14s %9.3f ms\n", who, what,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now()
+                                                      - t0)
+                .count());
+  }
+};
 
 template <typename T>
 static inline bool aligned16(const T* p)
@@ -443,7 +470,32 @@ struct spmv_hip_csr_plan {
 };
 
 
+// XW or the gather kernel: the state of a plan's first-launches probe
+// (xw_probe_pick, spmv_csr.hip)
+struct XwProbe {
+  int launches = 0;
+  int decided = 0;  // the choice is fixed
+  int use_xw = 1;   // ... to this
+  hipEvent_t ev[4][2] = {};
+  float us_xw = 0.f, us_gather = 0.f;
+};
+
 // --- cross-file entry points (one definition each) -------------------------
+// spmv_csr.hip
+int spmv_rowblock_grid(const spmv_hip_csr_plan* pl); // grid of the row-block kernels
+// spmv_csr_forms.hip: plan-time builders of the general plans
+int spmv_build_row_list(spmv_hip_csr_plan* pl, const int32_t* rowptr);
+void spmv_free_lx(spmv_hip_csr_plan* pl);
+void spmv_free_xw(spmv_hip_csr_plan* pl);
+int spmv_build_lx(spmv_hip_csr_plan* pl, const int32_t* rowptr, const int32_t* colind);
+// the XW records, + the plane-walk order when the matrix sits on a 3-D grid
+int spmv_build_xw_and_walk(spmv_hip_csr_plan* pl, const int32_t* rowptr,
+                           const int32_t* colind);
+bool spmv_xw_applies(const spmv_hip_csr_plan* pl); // may this plan stage x windows?
+void xw_probe_free(spmv_hip_csr_plan* pl);
+void xw_probe_drop_events(XwProbe* pb);
+// spmv_csr_plan.hip: the arrays a launch with the baked pointers does not read
+int spmv_plan_owned_mask(const spmv_hip_csr_plan* pl);
 // spmv_sym.hip
 int spmv_run_symmetric_f64(const spmv_hip_csr_plan* pl, hipStream_t st,
                            const int32_t* rowptr, const int32_t* colind,

@@ -404,9 +404,14 @@ __global__ __launch_bounds__(64 * WPB, 4) void csr_sjds_kernel(
         const int32_t row = r0 + i;
         T v = T(0);
         if (row < A.num_rows) {
-          const int32_t la = low_rowptr[row], lb = low_rowptr[row + 1];
-          v = sj_is_long(la, lb, A.sym_long_thr, A.sym_nnz) ? out[row]
-                                                             : diagonal[row] * in[row];
+          // (no long rows in the stored block -- the threshold is at its
+          // default: nothing to look up in the row pointer, 4 B per row saved)
+          bool lng = false;
+          if (A.sym_long_thr != INT32_MAX) { // uniform
+            const int32_t la = low_rowptr[row], lb = low_rowptr[row + 1];
+            lng = sj_is_long(la, lb, A.sym_long_thr, A.sym_nnz);
+          }
+          v = lng ? out[row] : diagonal[row] * in[row];
         }
         s_init[i] = v;
       }

@@ -238,9 +238,11 @@ __global__ __launch_bounds__(64 * WPB) void csr_sjds_long_kernel(
                 const int64_t i = eh + l; // (eh advances with the steps)
                 const bool ok = open && i < rbh && c[u] < pend;
                 const T x = s_x[ok ? (int32_t)(c[u] - p0) : 0];
-                // a lane without an entry contributes +0.0: the sum starts at
-                // +0.0 and can never become -0.0, so adding it changes no bit
-                const T pr = ok ? v[u] * x : T(0);
+                // a lane without an entry contributes -0.0, the identity of the
+                // addition for EVERY sum (+0.0 would turn a sum of -0.0 -- a
+                // symmetric row starts at d_i x_i, which can be that -- into
+                // +0.0)
+                const T pr = ok ? v[u] * x : -T(0);
                 // valid lanes are a prefix of the group: ascending columns
                 const uint64_t bal = __ballot(ok);
                 const int nv = __popcll((bal >> (lane & ~7)) & 0xFFull);
@@ -526,10 +528,11 @@ __global__ __launch_bounds__(512, 4) void csr_sjds_longt_kernel(
 #pragma unroll
           for (int k = 0; k < EPL; ++k) {
             const bool ok = pos + EPL * l + k < end;
-            // a lane without an entry contributes +0.0: the sum starts at +0.0
-            // and can never become -0.0, so adding it changes no bit
+            // a lane without an entry contributes -0.0, the identity of the
+            // addition for every sum, a -0.0 included (symmetric storage starts
+            // a row at d_i x_i)
             const T prod = (T)v.e[k] * xs[k];
-            pr[k] = ok ? prod : T(0);
+            pr[k] = ok ? prod : -T(0);
           }
           T tsum = acc[0];
 #pragma unroll

@@ -1012,6 +1012,7 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
   const int n = pl->num_rows;
   if (n < 64 || pl->nnz < 1)
     return SPMV_HIP_OK;
+  const PlanTrace tr(" sjds_build");
   const int kcap = pl->ctx->sj_max_chunks;
   // long rows: more than four times the average length, and more than 96
   int thr = (int)(pl->nnz * 4 / n);
@@ -1117,6 +1118,7 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
     cleanup();
     return SPMV_HIP_OK;
   }
+  tr.mark("count");
   // The SIGMA layout (blocks of 16 slices sorted by length across the block,
   // two slices per wave: sj_sigma_kernel) for blocks of 1024 rows; `nsl` then
   // counts the slices of whole blocks.
@@ -1170,6 +1172,7 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
     cleanup();
     return SPMV_HIP_OK;
   }
+  tr.mark("max length");
   int sigma = 0;
   if (best == 16 && pl->ctx->sj_sigma && h_max < (1 << (31 - kSjSigBits))) {
     sigma = 1;
@@ -1212,6 +1215,7 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
       e = hipStreamSynchronize(st);
     (void)hipFree(tmp);
   }
+  tr.mark("sigma / units");
   const int R = 64 * best;
   const int nblk = (n + R - 1) / R;
   const int stride = best_st.maxk > 0 ? (int)((best_st.maxk + 7) / 8 * 8) : 8;
@@ -1226,6 +1230,7 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
     e = hipMalloc(&pl->sj_codes, code_bytes);
   if (e == hipSuccess) // (the slack's codes must be valid LDS indices: 0)
     e = hipMemsetAsync(pl->sj_codes, 0, code_bytes, st);
+  tr.mark("alloc codes");
   if (e == hipSuccess) {
     const int grid = spmv_grid_for(pl->ctx, nblk, 1);
 #define SJ_FILL(RR)                                                            \
@@ -1244,6 +1249,7 @@ int spmv_sjds_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
   }
   if (e == hipSuccess)
     e = hipStreamSynchronize(st);
+  tr.mark("fill");
   cleanup();
   if (e != hipSuccess) {
     spmv_sjds_free(pl);
@@ -1451,6 +1457,7 @@ int spmv_sjds_sym_merge(const spmv_hip_csr_plan* pl, int long_thr, int32_t** vpt
 // transposed-map kernel.  ENOTSUP: the form does not apply.
 int spmv_sjds_sym_build(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan, hipStream_t st)
 {
+  const PlanTrace tr("sym_build");
   int64_t la = 0, lb = 0;
   int rl = spmv_sjds_long_entries(ctx, plan->num_rows, plan->nnz, plan->t_ptr, &lb, st);
   if (rl == SPMV_HIP_OK && !ctx->sym_sj_long_rows)
@@ -1464,26 +1471,38 @@ int spmv_sjds_sym_build(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan, hipStream_t 
   thr = thr > kSjLongMin ? thr : kSjLongMin;
   if (!ctx->sym_sj_long_rows)
     thr = INT32_MAX;
-  spmv_sj_lt_free(plan);
-  (void)hipFree(plan->sj_long_rows);
-  plan->sj_long_rows = nullptr;
-  plan->sj_nlong = 0;
+  // (one clean-up for every way out without the form: the parent's long-row
+  // state must not outlive a form that was not built -- ADVICE r05)
+  auto drop_long = [&]() {
+    spmv_sj_lt_free(plan);
+    (void)hipFree(plan->sj_long_rows);
+    plan->sj_long_rows = nullptr;
+    plan->sj_nlong = 0;
+    plan->sj_long_thr = INT32_MAX;
+  };
+  drop_long();
   plan->sj_long_thr = thr;
   if (thr != INT32_MAX) {
     int rc = spmv_sj_build_long_list(plan, plan->rowptr0, plan->colind0, thr, st);
     if (rc == SPMV_HIP_OK && plan->sj_nlong > 0)
       rc = spmv_sj_build_long_table(plan, plan->rowptr0, plan->colind0, st);
-    if (rc != SPMV_HIP_OK)
+    if (rc != SPMV_HIP_OK) {
+      drop_long();
       return rc == SPMV_HIP_ENOMEM ? SPMV_HIP_ENOTSUP : rc;
+    }
   }
   if (plan->sj_nlong == 0)
     plan->sj_long_thr = thr = INT32_MAX;
+  tr.mark("long rows");
   // the merged matrix: per row its (short) lower part, then its column's entries
   int64_t total = 0;
   const int rm = spmv_sjds_sym_merge(plan, thr, &plan->sjv_ptr, &plan->sjv_col,
                                      &plan->sjv_map, &total, st);
-  if (rm != SPMV_HIP_OK)
+  if (rm != SPMV_HIP_OK) {
+    drop_long();
     return rm == SPMV_HIP_ENOMEM ? SPMV_HIP_ENOTSUP : rm;
+  }
+  tr.mark("merge");
   spmv_hip_csr_plan* ch = new (std::nothrow) spmv_hip_csr_plan;
   int rb = ch ? SPMV_HIP_OK : SPMV_HIP_ENOMEM;
   if (ch) {
@@ -1497,6 +1516,7 @@ int spmv_sjds_sym_build(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan, hipStream_t 
     rb = total > 0 ? spmv_sjds_build(ch, plan->sjv_ptr, plan->sjv_col, ctx->sj_wpb, 2, 1)
                    : SPMV_HIP_OK;
   }
+  tr.mark("sjds_build");
   // (the columns were for the analysis only: the kernel reads its codes)
   (void)hipFree(plan->sjv_col);
   plan->sjv_col = nullptr;
@@ -1510,10 +1530,7 @@ int spmv_sjds_sym_build(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan, hipStream_t 
     (void)hipFree(plan->sjv_ptr);
     (void)hipFree(plan->sjv_map);
     plan->sjv_ptr = plan->sjv_map = nullptr;
-    spmv_sj_lt_free(plan);
-    (void)hipFree(plan->sj_long_rows);
-    plan->sj_long_rows = nullptr;
-    plan->sj_nlong = 0;
+    drop_long();
     return rb != SPMV_HIP_OK ? rb : SPMV_HIP_ENOTSUP;
   }
   plan->sjt = ch;

@@ -314,16 +314,23 @@ __global__ __launch_bounds__(kBlock) void slat_offsets_kernel(
 {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < num_rows;
        i += (int64_t)gridDim.x * blockDim.x) {
+    // a matrix that is no lattice says so in its first rows: nobody goes on
+    // after that (read first -- on the 10 M-row FEM-like matrix every row of
+    // this kernel raised the flag with an atomic of its own, and every entry
+    // tried the eight slots: 33 of the symmetric plan's 53 ms,
+    // profiles/r06_plan_fem_sym_kernel_stats.csv)
+    if (*(volatile int32_t*)fail)
+      return;
     const int32_t lo = rowptr[i], hi = rowptr[i + 1];
     if (hi - lo > kSlatMaxOff) {
       atomicOr(fail, 1);
-      continue;
+      return;
     }
     for (int32_t j = lo; j < hi; ++j) {
       const int32_t d = colind[j] - (int32_t)i;
       if (d >= 0) { // not strictly lower
         atomicOr(fail, 1);
-        continue;
+        return;
       }
       bool placed = false;
       for (int s = 0; s < 8 && !placed; ++s) {
@@ -332,8 +339,10 @@ __global__ __launch_bounds__(kBlock) void slat_offsets_kernel(
           cur = atomicCAS(set + s, INT32_MAX, d);
         placed = (cur == d || cur == INT32_MAX);
       }
-      if (!placed)
+      if (!placed) {
         atomicOr(fail, 1);
+        return;
+      }
     }
   }
 }

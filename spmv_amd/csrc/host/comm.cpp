@@ -2,8 +2,11 @@
 #include "comm.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
+#include <random>
 #include <stdexcept>
 
 #include <unistd.h>
@@ -71,15 +74,39 @@ bool Comm::pair_allowed()
   return e && e[0] == '1';
 }
 
+namespace
+{
+// What identifies THIS process among the ranks of a communicator: not its pid
+// alone -- ranks in separate pid namespaces (one container per GPU: every rank
+// is pid 1 or 7) or on different hosts can share one -- but the pid together
+// with a 64-bit token drawn once per process.
+struct ProcessToken {
+  int64_t pid;
+  uint64_t nonce;
+};
+ProcessToken process_token()
+{
+  static const uint64_t nonce = [] {
+    std::random_device rd;
+    uint64_t v = (static_cast<uint64_t>(rd()) << 32) ^ rd();
+    v ^= static_cast<uint64_t>(
+        std::chrono::steady_clock::now().time_since_epoch().count());
+    return v ^ reinterpret_cast<uintptr_t>(&v);
+  }();
+  return ProcessToken{static_cast<int64_t>(getpid()), nonce};
+}
+} // namespace
+
 bool Comm::ranks_share_a_process() const
 {
   if (_shared_process < 0) {
-    const std::vector<int64_t> pids
-        = allgather_value<int64_t>(static_cast<int64_t>(getpid()));
+    const std::vector<ProcessToken> ids
+        = allgather_value<ProcessToken>(process_token());
     int shared = 0;
-    for (size_t a = 0; a < pids.size(); ++a)
-      for (size_t b = a + 1; b < pids.size(); ++b)
-        shared = shared || pids[a] == pids[b];
+    for (size_t a = 0; a < ids.size(); ++a)
+      for (size_t b = a + 1; b < ids.size(); ++b)
+        shared = shared
+                 || (ids[a].pid == ids[b].pid && ids[a].nonce == ids[b].nonce);
     _shared_process = shared;
   }
   return _shared_process != 0;
@@ -101,6 +128,11 @@ bool Comm::enable_peer_reduce(const HipExecutor& exec) const
   // and the process ids are exchanged
   const bool refused
       = _onesided_maps > 0 && ranks_share_a_process() && !pair_allowed();
+  if (refused && me == 0) // (said once per attempt: the fast path is off, the
+    // results are not affected -- ADVICE r05)
+    std::fprintf(stderr, "spmv: peer reduction not enabled: a one-sided halo lives on "
+                         "this communicator and two of its ranks share a process "
+                         "(comm.h); cg() keeps the transport's all-reduce\n");
   int rc = (P <= SPMV_HIP_REDUCE_MAX_RANKS && !refused)
                ? spmv_hip_reduce_create(exec.context(), P, me, &r, mine.handle,
                                         &mine.address, &mine.pid, &fine)
@@ -143,15 +175,25 @@ void Comm::close_peer_reduce() const
   // nobody still stores into a window that is about to go: every rank's last
   // reduction has completed when its kernel has (stream order), and a rank
   // arrives here after synchronising -- the allgather is the barrier
+  // (the local teardown happens whether or not the barrier throws -- a callback
+  // transport whose peer is already gone: a second close, from the
+  // communicator's destructor after the executor's, must find nothing left
+  // to synchronise or detach)
+  struct Teardown {
+    const Comm* c;
+    ~Teardown()
+    {
+      spmv_hip_reduce_destroy(c->_reduce);
+      c->_reduce = nullptr;
+      c->_reduce_ctx = nullptr;
+      if (c->_reduce_exec)
+        c->_reduce_exec->detach_reduce_owner(c);
+      c->_reduce_exec = nullptr;
+    }
+  } teardown{this};
   spmv_hip_synchronize(_reduce_ctx);
   int32_t token = 1;
   (void)allgather_value<int32_t>(token);
-  spmv_hip_reduce_destroy(_reduce);
-  _reduce = nullptr;
-  _reduce_ctx = nullptr;
-  if (_reduce_exec)
-    _reduce_exec->detach_reduce_owner(this);
-  _reduce_exec = nullptr;
 }
 
 void Comm::reduce_sum(double* device_inout, size_t count, void* stream) const
