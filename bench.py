@@ -485,6 +485,9 @@ def kernel_of(A, symmetric):
 def plan_record(A):
     rows, cols, nnz = A.blocks()["local"]
     return {"plan_ms": A.plan_get("plan_us") / 1e3,
+            # ... of it inside hipMalloc / hipFree (the plan's own arrays, the
+            # scratch of its analysis): where a stalled allocator would show
+            "plan_mem_ms": A.plan_get("plan_mem_us") / 1e3,
             "plan_extra_bytes": A.plan_get("plan_kib") * 1024,
             # the caller's CSR arrays the plan's memory comes on top of
             "csr_bytes": nnz * 12 + (rows + 1) * 4,

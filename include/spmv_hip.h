@@ -369,7 +369,9 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value);
  * "wdia", "wdia_offsets", "wdia_half", "wdia_const", "wdia_box", "wdia_mixed", "wdia_d2",
  * "wdia_zwalk", "wdia_zwalk_segments";
  * "blocks_per_cu", "nontemporal"; "plan_us" (wall time of plan creation, its
- * analysis kernels included) and "plan_kib" (device memory the plan owns). */
+ * analysis kernels included), "plan_mem_us" (the part of it -- and of later
+ * bakes -- spent inside hipMalloc / hipFree) and "plan_kib" (device memory the
+ * plan owns). */
 int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
                           int* value);
 

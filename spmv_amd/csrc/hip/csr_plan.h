@@ -385,6 +385,7 @@ struct spmv_hip_csr_plan {
   int32_t num_listed = 0;
   int nt_store = 0; // non-temporal y stores
   int plan_us = 0;  // wall time of plan creation (analysis kernels included)
+  int plan_mem_us = 0; // ... of it (and of later bakes): inside hipMalloc / hipFree
   int values_changed_us = 0; // ... of the last spmv_hip_csr_plan_values_changed
   // The arrays the plan analysed.  Every form beyond the plain gather kernels
   // bakes their CONTENT in (offsets, masks, row lists, transposed map), so a

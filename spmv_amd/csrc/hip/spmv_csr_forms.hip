@@ -15,6 +15,8 @@
 #include <utility>
 #include <vector>
 
+#include "plan_malloc.h" // (last: hipMalloc / hipFree below are timed)
+
 namespace
 {
 

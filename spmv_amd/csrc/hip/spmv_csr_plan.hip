@@ -15,6 +15,25 @@
 #include <utility>
 #include <vector>
 
+#include "plan_malloc.h" // (last: hipMalloc / hipFree below are timed)
+
+thread_local int64_t spmv_plan_mem_ns = 0; // (plan_malloc.h)
+
+namespace
+{
+// files what the memory calls of one plan-API call took under the plan
+struct MemClock {
+  spmv_hip_csr_plan* pl;
+  int64_t t0;
+  explicit MemClock(spmv_hip_csr_plan* p = nullptr) : pl(p), t0(spmv_plan_mem_ns) {}
+  ~MemClock()
+  {
+    if (pl)
+      pl->plan_mem_us += (int)((spmv_plan_mem_ns - t0) / 1000);
+  }
+};
+} // namespace
+
 // Symmetric storage of a matrix without lattice structure (FEM matrices, what
 // read_petsc_binary_matrix delivers with symmetric = true): the reference's
 // loop (csr_kernels.cpp:26-40) seen from the row, in the sliced jagged form of
@@ -115,6 +134,8 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
   if (!pl)
     return SPMV_HIP_ENOMEM;
   pl->ctx = ctx;
+  MemClock mem_clock(pl); // (a failed creation destroys pl before this is read:
+                          // every such path below hands the clock a null plan)
   pl->num_rows = num_rows;
   pl->num_cols = num_cols;
   pl->nnz = num_non_zeros;
@@ -135,6 +156,7 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
   }
   if (algo < SPMV_HIP_ALGO_ROWBLOCK || algo > SPMV_HIP_ALGO_ROWLIST
       || (algo == SPMV_HIP_ALGO_ROWLIST && (symmetric || num_non_zeros == 0))) {
+    mem_clock.pl = nullptr;
     delete pl;
     return SPMV_HIP_EINVAL;
   }
@@ -142,6 +164,7 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
   if (algo == SPMV_HIP_ALGO_ROWLIST) {
     int rc = spmv_build_row_list(pl, rowptr);
     if (rc != SPMV_HIP_OK) {
+      mem_clock.pl = nullptr;
       delete pl;
       return rc;
     }
@@ -191,6 +214,7 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
     if (rc == SPMV_HIP_OK && !pl->sj_wanted && spmv_xw_applies(pl))
       rc = spmv_build_xw_and_walk(pl, rowptr, colind);
     if (rc != SPMV_HIP_OK) {
+      mem_clock.pl = nullptr;
       spmv_hip_csr_plan_destroy(pl);
       return rc;
     }
@@ -216,6 +240,7 @@ int spmv_hip_csr_plan_create(spmv_hip_ctx* ctx, int32_t num_rows,
       rc = spmv_symt_build(pl, rowptr, colind);
     mark("symt");
     if (rc != SPMV_HIP_OK) {
+      mem_clock.pl = nullptr;
       spmv_hip_csr_plan_destroy(pl);
       return rc;
     }
@@ -266,6 +291,7 @@ int spmv_hip_csr_plan_bake_values_f64(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan
 {
   SPMV_SET_DEVICE(ctx);
   SPMV_REQUIRE(plan && plan->ctx == ctx);
+  MemClock mem_clock(plan);
   SPMV_REQUIRE(!plan->released); // (its source arrays were given up)
   hipStream_t st = spmv_stream(ctx, stream);
   if (values) // (as in plan_create: the caller's kernels are not plan time)
@@ -332,6 +358,7 @@ int spmv_hip_csr_plan_bake_values_f32(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan
 {
   SPMV_SET_DEVICE(ctx);
   SPMV_REQUIRE(plan && plan->ctx == ctx);
+  MemClock mem_clock(plan);
   SPMV_REQUIRE(!plan->released); // (its source arrays were given up)
   hipStream_t st = spmv_stream(ctx, stream);
   if (values)
@@ -393,6 +420,7 @@ int spmv_hip_csr_plan_bake_values_f32f64(spmv_hip_ctx* ctx,
 {
   SPMV_SET_DEVICE(ctx);
   SPMV_REQUIRE(plan && plan->ctx == ctx);
+  MemClock mem_clock(plan);
   SPMV_REQUIRE(!plan->released); // (its source arrays were given up)
   hipStream_t st = spmv_stream(ctx, stream);
   // whichever form holds the fp64 values (by offset, in jagged order) gets
@@ -440,6 +468,7 @@ int spmv_hip_csr_plan_values_changed(spmv_hip_ctx* ctx, spmv_hip_csr_plan* plan,
 {
   SPMV_SET_DEVICE(ctx);
   SPMV_REQUIRE(plan && plan->ctx == ctx);
+  MemClock mem_clock(plan);
   // (the arrays the copies would be refreshed from are gone)
   SPMV_REQUIRE(!plan->released);
   hipStream_t st = spmv_stream(ctx, stream);
@@ -834,6 +863,8 @@ int spmv_hip_csr_plan_get(const spmv_hip_csr_plan* plan, const char* key,
     *value = plan->xw_probe ? (int)plan->xw_probe->us_gather : 0;
   else if (!strcmp(key, "plan_us"))
     *value = plan->plan_us;
+  else if (!strcmp(key, "plan_mem_us")) // of plan_us: inside hipMalloc / hipFree
+    *value = plan->plan_mem_us;
   else if (!strcmp(key, "values_changed_us"))
     *value = plan->values_changed_us;
   else if (!strcmp(key, "plan_kib")) {

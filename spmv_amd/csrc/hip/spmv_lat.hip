@@ -59,6 +59,8 @@
 
 #include <new>
 
+#include "plan_malloc.h" // (last: hipMalloc / hipFree below are timed)
+
 namespace
 {
 

@@ -9,6 +9,8 @@
 #include <chrono>
 #include <new>
 
+#include "plan_malloc.h" // (last: hipMalloc / hipFree below are timed)
+
 namespace
 {
 

@@ -5,6 +5,8 @@
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 #include <hipcub/hipcub.hpp>
 
+#include "plan_malloc.h" // (last: hipMalloc / hipFree below are timed)
+
 namespace
 {
 

@@ -59,6 +59,8 @@
 #include "csr_plan.h"
 #include "lat_dma.h"
 
+#include "plan_malloc.h" // (last: hipMalloc / hipFree below are timed)
+
 static void sdia_free_arrays(spmv_hip_csr_plan* pl);
 
 namespace

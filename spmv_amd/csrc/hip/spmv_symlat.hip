@@ -36,6 +36,8 @@
 #include "csr_plan.h"
 #include "lat_dma.h"
 
+#include "plan_malloc.h" // (last: hipMalloc / hipFree below are timed)
+
 namespace
 {
 

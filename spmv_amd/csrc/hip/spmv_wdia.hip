@@ -50,6 +50,8 @@
 #include <new>
 #include <type_traits>
 
+#include "plan_malloc.h" // (last: hipMalloc / hipFree below are timed)
+
 namespace
 {
 
