@@ -655,6 +655,8 @@ int spmv_hip_csr_plan_set(spmv_hip_csr_plan* plan, const char* key, int value)
   } else if (!strcmp(key, "sj_blocks_per_cu")) {
     SPMV_REQUIRE(value >= 0 && value <= kBlocksPerCU);
     plan->sj_blocks_per_cu = value;
+    if (plan->sjt) // (symmetric storage: the merged matrix's plan is launched)
+      plan->sjt->sj_blocks_per_cu = value;
   } else if (!strcmp(key, "sj_xcd_group")) {
     SPMV_REQUIRE(value >= 0 && value <= 4096);
     plan->sj_xcd_group = value;
