@@ -120,6 +120,27 @@ def main():
     yr, ym = y_ref.numpy(), y.numpy()
     same = bool(np.array_equal(yr, ym))
     bad = int(np.sum(yr != ym))
+    # ---- the pipelined version --------------------------------------------------
+    lib2 = C.CDLL(os.path.join(HERE, "libmarch_probe2.so"))
+    p2 = march_build.pack_v2(p)
+    dev2 = {k: ctx.upload(v) for k, v in p2.items()}
+    ptr2 = lambda k: C.c_void_p(dev2[k].ptr)  # noqa: E731
+
+    def run2():
+        rc = lib2.march2_spmv(
+            C.c_int(grid), C.c_int(p["nunits"]), ptr("unit_step0"), ptr2("steps"),
+            ptr2("chunks_padded"), ptr("meta"), ptr2("dval"), ptr2("sbp"),
+            ptr("a_val"), ptr2("a_code32"), ptr("bc_code"), ptr("bs_val"),
+            ptr("bs_code"), ptr("cc_code"), ptr("cs_val"), ptr("cs_code"),
+            C.c_int64(N), C.c_void_p(x.ptr), C.c_void_p(y.ptr),
+            C.c_void_p(part.ptr), None)
+        assert rc == 0, rc
+    ctx.memset(y.ptr, 0xFF, 8 * N)
+    ms2 = timed(ctx, run2, args.reps)
+    ctx.synchronize()
+    ym2 = y.numpy()
+    same2 = bool(np.array_equal(yr, ym2))
+    bad2 = int(np.sum(yr != ym2))
     moved = march_build.bytes_moved(p)
     st = p["stats"]
     out = {"rows": N, "stored_entries": int(lnnz.value), "far_offset": S,
@@ -127,6 +148,9 @@ def main():
            "product_kernel_ms": ms_ref, "product_frac_of_B_sym": B_sym / ms_ref / 8e9,
            "marched_ms": ms, "marched_frac_of_B_sym": B_sym / ms / 8e9,
            "bit_equal": same, "rows_that_differ": bad,
+           "marched_pipelined_ms": ms2,
+           "marched_pipelined_frac_of_B_sym": B_sym / ms2 / 8e9,
+           "pipelined_bit_equal": same2, "pipelined_rows_that_differ": bad2,
            "marched_bytes_per_launch": moved,
            "marched_bytes_per_stored_entry":
                (st["stored"] * 10 + (st["captured_near"] + st["captured_far"]) * 2

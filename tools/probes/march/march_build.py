@@ -236,6 +236,43 @@ def build(rowptr, colind, values, diag, S, lseg, stash_cap, x_cap, sort_rows=Tru
     return out
 
 
+def pack_v2(p):
+    """the arrays of march_probe2.hip from build()'s: step descriptors, stream
+    bases packed per (tile, slice), the diagonal per lane, stream A's code with
+    the entry's stash position in its upper half"""
+    nsteps = len(p["step_tile"])
+    ntiles = len(p["tile_row0"])
+    steps = np.zeros((nsteps + 2, 8), dtype=np.int32)
+    steps[:, 0] = -1
+    steps[:nsteps, 0] = p["step_tile"]
+    steps[:nsteps, 1] = p["step_chunk0"][:-1]
+    steps[:nsteps, 2] = np.diff(p["step_chunk0"])
+    steps[:nsteps, 3] = p["step_own0"]
+    t = np.maximum(p["step_tile"], 0)
+    steps[:nsteps, 4] = p["tile_row0"][t]
+    steps[nsteps:, 1] = p["step_chunk0"][-1]
+    sbp = np.zeros((ntiles * SLICES, 8), dtype=np.uint32)
+    for c in range(5):
+        sbp[:, c] = p["sb%d" % c][:-1]
+    meta = p["meta"]
+    valid = (meta >> np.uint64(63)) != 0
+    loc = ((meta >> np.uint64(40)) & np.uint64(0xffff)).astype(np.int64)
+    tile = np.arange(len(meta)) // B
+    row = np.where(valid, p["tile_row0"][tile] + loc, 0)
+    dval = np.where(valid, p["diag"][row], 0.0)
+    nA = len(p["a_code"])
+    # (position of an entry in its tile's stream: its index minus the tile's base)
+    tile_of_pos = np.searchsorted(p["sb0"][::SLICES].astype(np.int64),
+                                  np.arange(nA), side="right") - 1
+    tile_of_pos = np.clip(tile_of_pos, 0, ntiles - 1)
+    idx = np.arange(nA) - p["sb0"][::SLICES].astype(np.int64)[tile_of_pos]
+    idx = np.clip(idx, 0, 65535)
+    a_code = p["a_code"].astype(np.uint32) | (idx.astype(np.uint32) << np.uint32(16))
+    chunks = np.concatenate([p["chunks"], np.zeros(1024, dtype=np.int32)])
+    return {"steps": steps, "sbp": sbp, "dval": dval, "a_code32": a_code,
+            "chunks_padded": chunks}
+
+
 def bytes_moved(p):
     s = p["stats"]
     cap = s["captured_near"] + s["captured_far"]
