@@ -50,9 +50,16 @@ def main():
     ap.add_argument("--no-sort", action="store_true",
                     help="lanes in row order (no sort by length inside a tile)")
     ap.add_argument("--grid", type=int, default=0)
+    ap.add_argument("--tile", type=int, default=1024, choices=[1024, 512],
+                    help="rows per tile (512: 8 waves, ~70 KB of LDS, two "
+                         "workgroups per CU)")
     ap.add_argument("--fem", nargs="*", default=[], help="generator key=value ...")
     args = ap.parse_args()
-    lib = C.CDLL(os.path.join(HERE, "libmarch_probe.so"))
+    suf = "" if args.tile == 1024 else "_512"
+    march_build.B = args.tile
+    march_build.SLICES = args.tile // 64
+    wgs_per_cu = 1 if args.tile == 1024 else 2
+    lib = C.CDLL(os.path.join(HERE, f"libmarch_probe{suf}.so"))
     stash, xcap = C.c_int(), C.c_int()
     lib.march_limits(C.byref(stash), C.byref(xcap))
     ctx = hip.Context(0)
@@ -95,13 +102,14 @@ def main():
     assert S > march_build.B, S
     nlev = (N + S - 1) // S
     nchain = (S + march_build.B - 1) // march_build.B
-    lseg = args.lseg or max(2, int(np.ceil(nlev * nchain / (2.0 * ctx.num_cus))))
+    lseg = args.lseg or max(2, int(np.ceil(nlev * nchain
+                                           / (2.0 * wgs_per_cu * ctx.num_cus))))
     p = march_build.build(rp, ci, va, dg, S, lseg, stash.value, xcap.value,
                           sort_rows=not args.no_sort)
     t_build = time.perf_counter() - t0
     dev = {k: ctx.upload(v) for k, v in p.items()
            if isinstance(v, np.ndarray) and k != "diag"}
-    grid = args.grid or min(p["nunits"], ctx.num_cus)
+    grid = args.grid or min(p["nunits"], wgs_per_cu * ctx.num_cus)
     ptr = lambda k: C.c_void_p(dev[k].ptr)  # noqa: E731
 
     def run():
@@ -121,7 +129,7 @@ def main():
     same = bool(np.array_equal(yr, ym))
     bad = int(np.sum(yr != ym))
     # ---- the pipelined version --------------------------------------------------
-    lib2 = C.CDLL(os.path.join(HERE, "libmarch_probe2.so"))
+    lib2 = C.CDLL(os.path.join(HERE, f"libmarch_probe2{suf}.so"))
     p2 = march_build.pack_v2(p)
     dev2 = {k: ctx.upload(v) for k, v in p2.items()}
     ptr2 = lambda k: C.c_void_p(dev2[k].ptr)  # noqa: E731
@@ -144,7 +152,7 @@ def main():
     moved = march_build.bytes_moved(p)
     st = p["stats"]
     out = {"rows": N, "stored_entries": int(lnnz.value), "far_offset": S,
-           "levels_per_unit": lseg, "grid": grid, "sorted_lanes": not args.no_sort,
+           "levels_per_unit": lseg, "grid": grid, "tile_rows": args.tile, "sorted_lanes": not args.no_sort,
            "product_kernel_ms": ms_ref, "product_frac_of_B_sym": B_sym / ms_ref / 8e9,
            "marched_ms": ms, "marched_frac_of_B_sym": B_sym / ms / 8e9,
            "bit_equal": same, "rows_that_differ": bad,

@@ -46,8 +46,8 @@ def run(p, x, N):
             def walk(stream, tile, mm, lenshift, acc, val, code, from_stash, to_stash,
                      x_own=None):
                 sb = p["sb%d" % stream]
-                for sl in range(16):
-                    base = int(sb[tile * 16 + sl])
+                for sl in range(march_build.SLICES):
+                    base = int(sb[tile * march_build.SLICES + sl])
                     lens = [(int(mm[sl * 64 + l]) >> lenshift) & 0xff for l in range(64)]
                     k = 0
                     while any(k < ln for ln in lens):
@@ -59,7 +59,7 @@ def run(p, x, N):
                                 pr = val[base] * xv if val is not None else xv
                                 acc[v] = acc[v] + pr
                                 if to_stash:
-                                    stash[base - int(sb[tile * 16])] = val[base] * x_own[v]
+                                    stash[base - int(sb[tile * march_build.SLICES])] = val[base] * x_own[v]
                                 base += 1
                         k += 1
             if T >= 0:
@@ -87,9 +87,11 @@ def main():
     from spmv_amd import poisson
     from util import lower_split
     rng = np.random.default_rng(5)
-    for N, layer, jit, lseg, sort in ((30000, 5000, 512, 3, True),
-                                      (30000, 5000, 512, 2, False),
-                                      (26000, 4500, 300, 100, True)):
+    for N, layer, jit, lseg, sort, tile in ((30000, 5000, 512, 3, True, 1024),
+                                            (30000, 5000, 512, 2, False, 1024),
+                                            (26000, 4500, 300, 100, True, 1024),
+                                            (30000, 5000, 512, 3, True, 512)):
+        march_build.B, march_build.SLICES = tile, tile // 64
         rp, ci, va = poisson.fem_like_csr(N, layer=layer, jitter=jit)
         lrp, lci, lva, ldg = lower_split(rp, ci, va)
         S = march_build.far_offset(lrp, lci)

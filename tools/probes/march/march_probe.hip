@@ -30,9 +30,15 @@
 
 namespace
 {
-constexpr int NT = 1024;
-constexpr int kStash = 9216;  // products (72 KiB)
-constexpr int kXcap = 6144;   // staged x elements (48 KiB)
+#ifndef MARCH_NT
+#define MARCH_NT 1024
+#define MARCH_STASH 9216
+#define MARCH_XCAP 6144
+#endif
+constexpr int NT = MARCH_NT;
+constexpr int NSL = NT / 64; // slices (waves) of a tile
+constexpr int kStash = MARCH_STASH; // products
+constexpr int kXcap = MARCH_XCAP;   // staged x elements
 constexpr int G = 8;          // entries of a lane in flight
 
 struct MarchArgs {
@@ -147,26 +153,26 @@ __global__ __launch_bounds__(NT) void march_kernel(MarchArgs a,
           x_own = sx[a.step_own0[st] + (int)((meta >> 40) & 0xffffu)];
           s = dd * x_own;
         }
-        const uint32_t tbase = a.sb[0][(int64_t)T * 16];
+        const uint32_t tbase = a.sb[0][(int64_t)T * NSL];
         s = march_pass<true, false, true>(s, (int)(meta & 0xffu),
-                                          a.sb[0][(int64_t)T * 16 + slice], a.a_val,
+                                          a.sb[0][(int64_t)T * NSL + slice], a.a_val,
                                           a.a_code, sx, stash, tbase, x_own);
       }
       __syncthreads(); // the tile's products are in the stash
       if (T >= 0) {
         s = march_pass<false, true, false>(s, (int)((meta >> 8) & 0xffu),
-                                           a.sb[1][(int64_t)T * 16 + slice], nullptr,
+                                           a.sb[1][(int64_t)T * NSL + slice], nullptr,
                                            a.bc_code, sx, stash, 0u, 0.0);
         s = march_pass<true, false, false>(s, (int)((meta >> 16) & 0xffu),
-                                           a.sb[2][(int64_t)T * 16 + slice], a.bs_val,
+                                           a.sb[2][(int64_t)T * NSL + slice], a.bs_val,
                                            a.bs_code, sx, stash, 0u, 0.0);
       }
       if (ptile >= 0) {
         pend = march_pass<false, true, false>(pend, (int)((pmeta >> 24) & 0xffu),
-                                              a.sb[3][(int64_t)ptile * 16 + slice],
+                                              a.sb[3][(int64_t)ptile * NSL + slice],
                                               nullptr, a.cc_code, sx, stash, 0u, 0.0);
         pend = march_pass<true, false, false>(pend, (int)((pmeta >> 32) & 0xffu),
-                                              a.sb[4][(int64_t)ptile * 16 + slice],
+                                              a.sb[4][(int64_t)ptile * NSL + slice],
                                               a.cs_val, a.cs_code, sx, stash, 0u, 0.0);
         if (prow >= 0) {
           y[prow] = pend;

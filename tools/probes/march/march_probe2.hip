@@ -12,9 +12,15 @@
 
 namespace
 {
-constexpr int NT = 1024;
-constexpr int kStash = 9216; // products (72 KiB)
-constexpr int kXcap = 6144;  // staged x elements (48 KiB)
+#ifndef MARCH_NT
+#define MARCH_NT 1024
+#define MARCH_STASH 9216
+#define MARCH_XCAP 6144
+#endif
+constexpr int NT = MARCH_NT;
+constexpr int NSL = NT / 64; // slices (waves) of a tile
+constexpr int kStash = MARCH_STASH; // products
+constexpr int kXcap = MARCH_XCAP;  // staged x elements
 constexpr int GA = 8;        // entries of a lane in flight per group, stream A
 constexpr int GS = 2;        // ... the streamed parts (Bs, Cs)
 constexpr int GC = 4;        // ... the captured parts (Bc, Cc): codes only
@@ -92,7 +98,7 @@ __global__ __launch_bounds__(NT) void march2_kernel(MarchArgs2 a,
       const int t = d.tile >= 0 ? d.tile : 0;
       meta = d.tile >= 0 ? a.meta[(int64_t)t * NT + v] : 0ull;
       dv = a.dval[(int64_t)t * NT + v];
-      const uint4* q = reinterpret_cast<const uint4*>(a.sbp + ((int64_t)t * 16 + slice) * 8);
+      const uint4* q = reinterpret_cast<const uint4*>(a.sbp + ((int64_t)t * NSL + slice) * 8);
       const uint4 q0 = q[0], q1 = q[1];
       sb[0] = q0.x, sb[1] = q0.y, sb[2] = q0.z, sb[3] = q0.w, sb[4] = q1.x;
 #pragma unroll
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(NT) void march2_kernel(MarchArgs2 a,
       const int lenBs = (int)((meta >> 16) & 0xffu);
       const int lenCc = (int)((pmeta >> 24) & 0xffu), lenCs = (int)((pmeta >> 32) & 0xffu);
       const uint32_t tbase = __builtin_amdgcn_readfirstlane(
-          a.sbp[(int64_t)(hasT ? d0.tile : 0) * 16 * 8]);
+          a.sbp[(int64_t)(hasT ? d0.tile : 0) * NSL * 8]);
       uint32_t bA = __builtin_amdgcn_readfirstlane(sb[0]);
       uint32_t bBc = __builtin_amdgcn_readfirstlane(sb[1]);
       uint32_t bBs = __builtin_amdgcn_readfirstlane(sb[2]);
