@@ -28,7 +28,7 @@ struct SjSel {
 // set, the words nearest to the diagonal are kept.  All 256 threads call it;
 // s_bits[kSjSpanWords], s_pre[kSjSpanWords + 1].
 __device__ SjSel sj_select(int32_t r0, int32_t r1, int32_t num_cols,
-                           const int32_t* __restrict__ rowptr,
+                           int32_t num_rows_all, const int32_t* __restrict__ rowptr,
                            const int32_t* __restrict__ colind, int kcap,
                            int long_thr, int64_t nnz, uint32_t* s_bits,
                            int32_t* s_pre, SjSel* s_sel)
@@ -48,15 +48,35 @@ __device__ SjSel sj_select(int32_t r0, int32_t r1, int32_t num_cols,
     s_bits[w] = 0u;
   __syncthreads();
   // one lane per row; LONG rows are not part of the slices (phase 0 of the
-  // kernel takes them), so they do not choose chunks
-  for (int32_t row = r0 + t; row < r1; row += kBlock) {
-    const int32_t a = rowptr[row], b = rowptr[row + 1];
-    if (sj_is_long(a, b, long_thr, nnz))
-      continue;
-    for (int32_t e = a; e < b; ++e) {
-      const int32_t rel = colind[e] / kSjChunk - lo;
-      if (rel >= 0 && rel < kSpan)
-        atomicOr(&s_bits[rel >> 5], 1u << (rel & 31));
+  // kernel takes them), so they do not choose chunks.  Where the rows average
+  // 32 entries and more a WAVE takes a row, its lanes consecutive entries:
+  // one lane per row reads such rows 324 B apart (81 per row) and every line
+  // comes in again and again -- 23 of the 56 ms of the 10 M x 81 plan were this
+  // loop and its twin in sj_count_kernel (profiles/r06_plan_fem81_kernel_stats.csv)
+  if (nnz >= (int64_t)32 * num_rows_all) { // uniform
+    for (int32_t row = r0 + (t >> 6); row < r1; row += kBlock / 64) {
+      const int32_t a = rowptr[row], b = rowptr[row + 1];
+      if (sj_is_long(a, b, long_thr, nnz))
+        continue;
+      for (int32_t e = a + (t & 63); e < b; e += 64) {
+        const int32_t rel = colind[e] / kSjChunk - lo;
+        if (rel >= 0 && rel < kSpan) {
+          const uint32_t bit = 1u << (rel & 31);
+          if (!(s_bits[rel >> 5] & bit)) // (neighbours set the same bits)
+            atomicOr(&s_bits[rel >> 5], bit);
+        }
+      }
+    }
+  } else {
+    for (int32_t row = r0 + t; row < r1; row += kBlock) {
+      const int32_t a = rowptr[row], b = rowptr[row + 1];
+      if (sj_is_long(a, b, long_thr, nnz))
+        continue;
+      for (int32_t e = a; e < b; ++e) {
+        const int32_t rel = colind[e] / kSjChunk - lo;
+        if (rel >= 0 && rel < kSpan)
+          atomicOr(&s_bits[rel >> 5], 1u << (rel & 31));
+      }
     }
   }
   __syncthreads();
@@ -141,15 +161,25 @@ __global__ __launch_bounds__(kBlock) void sj_count_kernel(
     const int32_t r1 = min(r0 + R, num_rows);
     if (threadIdx.x == 0)
       s_far = 0;
-    const SjSel sel = sj_select(r0, r1, num_cols, rowptr, colind, kcap, long_thr,
-                                nnz, s_bits, s_pre, &s_sel);
+    const SjSel sel = sj_select(r0, r1, num_cols, num_rows, rowptr, colind, kcap,
+                                long_thr, nnz, s_bits, s_pre, &s_sel);
     int32_t far = 0;
-    for (int32_t row = r0 + threadIdx.x; row < r1; row += kBlock) {
-      const int32_t a = rowptr[row], e1 = rowptr[row + 1];
-      if (sj_is_long(a, e1, long_thr, nnz))
-        continue;
-      for (int32_t e = a; e < e1; ++e)
-        far += sj_index(sel, s_bits, s_pre, colind[e]) < 0 ? 1 : 0;
+    if (nnz >= (int64_t)32 * num_rows) { // (a wave per row: see sj_select)
+      for (int32_t row = r0 + (threadIdx.x >> 6); row < r1; row += kBlock / 64) {
+        const int32_t a = rowptr[row], e1 = rowptr[row + 1];
+        if (sj_is_long(a, e1, long_thr, nnz))
+          continue;
+        for (int32_t e = a + (threadIdx.x & 63); e < e1; e += 64)
+          far += sj_index(sel, s_bits, s_pre, colind[e]) < 0 ? 1 : 0;
+      }
+    } else {
+      for (int32_t row = r0 + threadIdx.x; row < r1; row += kBlock) {
+        const int32_t a = rowptr[row], e1 = rowptr[row + 1];
+        if (sj_is_long(a, e1, long_thr, nnz))
+          continue;
+        for (int32_t e = a; e < e1; ++e)
+          far += sj_index(sel, s_bits, s_pre, colind[e]) < 0 ? 1 : 0;
+      }
     }
     if (far)
       atomicAdd(&s_far, far);
@@ -314,8 +344,8 @@ __global__ __launch_bounds__(kBlock) void sj_fill_kernel(
   for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
     const int32_t r0 = b * R;
     const int32_t r1 = min(r0 + R, num_rows);
-    const SjSel sel = sj_select(r0, r1, num_cols, rowptr, colind, kcap, long_thr,
-                                nnz, s_bits, s_pre, &s_sel);
+    const SjSel sel = sj_select(r0, r1, num_cols, num_rows, rowptr, colind, kcap,
+                                long_thr, nnz, s_bits, s_pre, &s_sel);
     for (int w = sel.wa + threadIdx.x; w <= sel.wb; w += kBlock) {
       uint32_t bits = s_bits[w];
       int32_t rank = s_pre[w] - s_pre[sel.wa];

@@ -878,6 +878,8 @@ __global__ __launch_bounds__(kBlock) void sdia_offsets_kernel(
 {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < num_rows;
        i += (int64_t)gridDim.x * blockDim.x) {
+    if (*(volatile int32_t*)fail) // (a ninth offset was found: nobody goes on)
+      return;
     for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
       const int64_t d64 = (int64_t)colind[j] - i;
       if (d64 == 0)

@@ -640,6 +640,12 @@ __global__ __launch_bounds__(kBlock) void wdia_offsets_kernel(
     __syncthreads();
     const int32_t j0 = s_rp[0], j1 = s_rp[nr];
     for (int32_t j = j0 + t; j < j1; j += kBlock) {
+      // (a matrix on more than 32 diagonals says so within its first row
+      // block: read the flag first -- on the 10 M x 81 FEM-like matrix every
+      // entry of every workgroup's first block raised it with an atomic of its
+      // own, 5.8 ms of the plan; profiles/r06_plan_fem81_kernel_stats.csv)
+      if (*(volatile int32_t*)fail)
+        continue;
       const int r = wdia_row_of(s_rp, nr, j);
       const int64_t d64 = (int64_t)colind[j] - (r0 + r);
       if (d64 <= INT32_MIN || d64 > INT32_MAX

@@ -110,6 +110,7 @@ def main():
         base = {"kind": kind, "rows": rows, "nnz": nnz,
                 "avg_row": nnz / rows, "B_csr": algo_bytes,
                 "plan_ms": A.plan_get("plan_us") / 1e3,
+                "plan_mem_ms": A.plan_get("plan_mem_us") / 1e3,
                 "plan_kib": A.plan_get("plan_kib")}
         for var in args.variants:
             A.plan_set("algo", auto_algo)
