@@ -95,6 +95,10 @@ int spmvh_comm_destroy(spmvh_comm* comm);
  * collective; *ok = 0: some rank cannot reach some window, the transport's
  * all-reduce stays) and one reduction through it (Comm::reduce_sum) */
 int spmvh_comm_enable_peer_reduce(spmvh_comm* comm, spmvh_exec* exec, int* ok);
+/* Comm::ranks_share_a_process (collective on its first call): do two ranks of
+ * the communicator live in ONE process (ranks as threads)?  Decided by a
+ * per-process token (pid + a 64-bit nonce), not the pid alone */
+int spmvh_comm_ranks_share_a_process(spmvh_comm* comm, int* shared);
 int spmvh_comm_reduce_sum(spmvh_comm* comm, double* device_inout, int count,
                           void* stream);
 

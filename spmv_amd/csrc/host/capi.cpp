@@ -301,6 +301,14 @@ int spmvh_comm_enable_peer_reduce(spmvh_comm* comm, spmvh_exec* exec, int* ok)
   });
 }
 
+int spmvh_comm_ranks_share_a_process(spmvh_comm* comm, int* shared)
+{
+  return guarded([&] {
+    require(comm && shared, "NULL argument");
+    *shared = comm->comm->ranks_share_a_process() ? 1 : 0;
+  });
+}
+
 int spmvh_comm_reduce_sum(spmvh_comm* comm, double* device_inout, int count,
                           void* stream)
 {

@@ -48,6 +48,7 @@ _PROTOS = {
     "spmvh_comm_destroy": [vp],
     "spmvh_comm_enable_peer_reduce": [vp, vp, PTR(C.c_int)],
     "spmvh_comm_reduce_sum": [vp, vp, C.c_int, vp],
+    "spmvh_comm_ranks_share_a_process": [vp, PTR(C.c_int)],
     "spmvh_matrix_create": [vp, vp, vp, vp, vp, i64, i64, vp, i64, vp, i64,
                             C.c_int, C.c_int, PTR(vp)],
     "spmvh_matrix_f32_create": [vp, vp, vp, vp, vp, i64, i64, vp, i64, vp, i64,
@@ -252,6 +253,12 @@ class Comm:
 
     def reduce_sum(self, device_ptr, count=1, stream=None):
         call("spmvh_comm_reduce_sum", self.h, device_ptr, int(count), stream)
+
+    def ranks_share_a_process(self):
+        """Comm::ranks_share_a_process (collective on its first call)"""
+        v = C.c_int()
+        call("spmvh_comm_ranks_share_a_process", self.h, C.byref(v))
+        return bool(v.value)
 
     def close(self):
         if self.h:

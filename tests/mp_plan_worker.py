@@ -22,6 +22,9 @@ from util import assembled_inputs, box_partition, permute_csr  # noqa: E402
 def main():
     rank, world = dist_util.init_gloo()
     comm = host.Comm.callback(rank, world, dist_util.make_allgather(world))
+    # one PROCESS per rank: no two ranks share one (per-process token = pid +
+    # nonce, exchanged over the communicator; comm.cpp)
+    assert comm.ranks_share_a_process() is False
     cases = []
     # KAT (tests/test_spmv.cpp:56-64) and small Poisson grids
     kat = (np.array([0, 3, 6, 9, 13, 15], np.int32),

@@ -271,6 +271,22 @@ def test_l2g_plan_gloo(world):
     assert res.stdout.count("plan + split OK") == world
 
 
+def test_ranks_as_threads_share_a_process():
+    """Comm::ranks_share_a_process: threads of this process do (the library then
+    refuses the peer reduction beside a one-sided halo), a single rank does not;
+    the gloo workers above assert the process case."""
+    from thread_world import ThreadWorld
+    seen = [None] * 3
+
+    def rank_body(rank, comm):
+        seen[rank] = comm.ranks_share_a_process()
+    ThreadWorld(3).run(rank_body)
+    assert seen == [True, True, True]
+    c = host.Comm.self_comm()
+    assert c.ranks_share_a_process() is False
+    c.close()
+
+
 # ---------------------------------------------------------------------------
 # PETSc binary ingest (spmv/read_petsc.cpp), host-only parse
 # ---------------------------------------------------------------------------
