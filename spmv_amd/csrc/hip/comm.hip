@@ -196,8 +196,12 @@ static int neighbor_exchange(spmv_hip_comm* comm, size_t elem, int num_neighbour
   SPMV_SET_DEVICE(comm->ctx);
   hipStream_t st = spmv_stream(comm->ctx, stream);
   for (int i = 0; i < num_neighbours; ++i) {
+    // (a neighbour is another rank -- except on a ONE-rank communicator, where
+    // rank 0 may exchange with itself: a loopback through RCCL's own send /
+    // recv pair, which lets a 1-GPU box execute this grouped call for real;
+    // L2GMap never asks for it)
     SPMV_REQUIRE(host_neighbours[i] >= 0 && host_neighbours[i] < comm->nranks
-                 && host_neighbours[i] != comm->rank);
+                 && (host_neighbours[i] != comm->rank || comm->nranks == 1));
     SPMV_REQUIRE(host_send_counts[i] >= 0 && host_recv_counts[i] >= 0);
     SPMV_REQUIRE(host_send_counts[i] == 0 || send_buf);
     SPMV_REQUIRE(host_recv_counts[i] == 0 || recv_base);
@@ -252,8 +256,11 @@ int spmv_hip_comm_allreduce_sum_f64(spmv_hip_comm* comm, double* inout,
                                     size_t count, void* stream)
 {
   SPMV_REQUIRE(comm && (count == 0 || inout));
-  if (count == 0 || comm->nranks == 1)
+  if (count == 0)
     return SPMV_HIP_OK;
+  // (a one-rank communicator goes through RCCL too: the call is then a copy
+  // onto itself, and a 1-GPU box has executed the very call the N-rank run
+  // makes; one-rank RUNS use SelfComm, which has no transport at all)
   SPMV_SET_DEVICE(comm->ctx);
   SPMV_CHECK_NCCL(ncclAllReduce(inout, inout, count, ncclDouble, ncclSum,
                                 comm->red, spmv_stream(comm->ctx, stream)));

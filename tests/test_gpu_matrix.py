@@ -545,6 +545,71 @@ def test_rccl_comm_single_rank(exec_):
     comm.close()
 
 
+def test_rccl_grouped_send_recv_loopback(exec_):
+    """The grouped ncclSend / ncclRecv of the halo exchange (hip/comm.hip,
+    L2GMap.cpp:564-642) EXECUTED on a 1-GPU box: a one-rank RCCL communicator
+    whose rank exchanges with itself -- two "neighbours" (both rank 0), distinct
+    segments, fp64 and fp32, on a side stream behind a kernel that produces the
+    send buffer (stream order, no host wait between them).  Not a transfer over
+    xGMI -- but the calls, their grouping and their stream semantics run through
+    the RCCL library the process loaded."""
+    import ctypes as C
+    from spmv_amd import _lib
+    ctx = exec_.context
+    ident = host.rccl_unique_id()
+    comm = C.c_void_p()
+    _lib.call("spmv_hip_comm_create", ctx, 1, 0, bytes(ident), C.byref(comm))
+    stream = C.c_void_p()
+    _lib.call("spmv_hip_stream_create", ctx, C.byref(stream))
+    n0, n1 = 70_001, 262_144
+    I32 = C.c_int32 * 2
+    nb = I32(0, 0)
+    scnt, soff = I32(n0, n1), I32(5, 5 + n0)
+    rcnt, roff = I32(n0, n1), I32(n1 + 3, 3)  # the two segments swap places
+    for elem, fn, dt in ((8, "spmv_hip_comm_neighbor_exchange_f64", np.float64),
+                         (4, "spmv_hip_comm_neighbor_exchange_f32", np.float32)):
+        total = 5 + n0 + n1
+        d_send = exec_.alloc(total * elem // 8 + 1)
+        d_recv = exec_.alloc((n0 + n1 + 3) * elem // 8 + 1)
+        exec_.memset(d_recv, 0xFF, (n0 + n1 + 3) * elem)
+        exec_.synchronize()
+        # the send buffer is produced ON the stream, right before the exchange
+        if elem == 8:
+            _lib.call("spmv_hip_fill_gaussian_f64", ctx, total, 0, total, d_send,
+                      stream)
+            want = np.exp(-10 * (5 * (np.arange(total) / float(total) - 0.5)) ** 2)
+        else:
+            want = np.linspace(-1, 1, total).astype(np.float32)
+            _lib.call("spmv_hip_copy_h2d_async", ctx, d_send,
+                      want.ctypes.data_as(C.c_void_p), total * 4, stream)
+        _lib.call(fn, comm, 2, nb, d_send, scnt, soff, d_recv, rcnt, roff, stream)
+        _lib.call("spmv_hip_stream_synchronize", ctx, stream)
+        got = np.empty(n0 + n1 + 3, dt)
+        _lib.call("spmv_hip_copy_d2h_async", ctx, got.ctypes.data_as(C.c_void_p),
+                  d_recv, (n0 + n1 + 3) * elem, None)
+        exec_.synchronize()
+        if elem == 8:
+            assert np.allclose(got[n1 + 3:], want[5:5 + n0], rtol=1e-15, atol=0)
+            assert np.allclose(got[3:3 + n1], want[5 + n0:], rtol=1e-15, atol=0)
+        else:
+            assert np.array_equal(got[n1 + 3:], want[5:5 + n0])
+            assert np.array_equal(got[3:3 + n1], want[5 + n0:])
+        assert np.all(np.isnan(got[:3]))  # untouched
+        exec_.free(d_send), exec_.free(d_recv)
+    # ... and the scalar all-reduce of cg() (cg.cpp:49,65,75) through ncclAllReduce
+    # on the same stream: one rank, so the sum is the value itself
+    vals = np.array([3.25, -1.5, 1e-300])
+    d_v = exec_.alloc(3)
+    _lib.call("spmv_hip_copy_h2d_async", ctx, d_v, vals.ctypes.data_as(C.c_void_p),
+              24, stream)
+    _lib.call("spmv_hip_comm_allreduce_sum_f64", comm, d_v, 3, stream)
+    _lib.call("spmv_hip_stream_synchronize", ctx, stream)
+    assert np.array_equal(exec_.copy_to_host(d_v, 3), vals)
+    exec_.free(d_v)
+    _lib.call("spmv_hip_stream_destroy", ctx, stream)
+    _lib.call("spmv_hip_comm_destroy", comm)
+
+
 @pytest.mark.parametrize("symmetric", [False, True])
 def test_read_petsc_binary(exec_, comm, tmp_path, symmetric):
     """demos/cg.cpp flow: read A and b from PETSc binary files, solve."""
