@@ -4,7 +4,9 @@ matrix without lattice structure (the merged matrix in the sliced jagged form,
 spmv_sjds.hip) -- same matrix (the benchmark's FEM-like matrix in symmetric
 storage), same x, ONE box, HIP events; the two results compared bit for bit.
 
+    make -C tools/probes/march          # the kernels (hipcc, gfx950)
     python tools/probes/march/march_ab.py [--rows 10000000] [--lseg 20] [--no-sort]
+                                        [--tile 512]
 """
 import argparse
 import ctypes as C
