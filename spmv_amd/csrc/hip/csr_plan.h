@@ -1,5 +1,8 @@
 // Shared internals of the CSR SpMV translation units (gfx950 only):
-//   spmv_csr.hip   general kernels (ROWBLOCK, LX form, VECTOR, SCALAR, ROWLIST),
+//   spmv_csr.hip        general kernels (ROWBLOCK, LX form, VECTOR, SCALAR, ROWLIST),
+//   spmv_csr_forms.hip  plan-time builders (LX / XW windows, row list, plane walk)
+//   spmv_csr_plan.hip   the plan API (create / bake / set / get)
+//   (below, "spmv_csr.hip" in older comments: the three of them)
 //                  plan creation, the C entry points
 //   spmv_sym.hip   symmetric-storage kernels (csr_kernels.cpp:26-40)
 //   spmv_lat.hip   lattice form: constant column offsets per row block
@@ -511,7 +514,7 @@ int spmv_run_symmetric_f32(const spmv_hip_csr_plan* pl, hipStream_t st,
 int spmv_symt_build(spmv_hip_csr_plan* pl, const int32_t* rowptr,
                     const int32_t* colind);
 void spmv_symt_free(spmv_hip_csr_plan* pl);
-// spmv_csr.hip: (re)build the plane-walk table for planes `d2` rows apart, a
+// spmv_csr_forms.hip: (re)build the plane-walk table for planes `d2` rows apart, a
 // grid of `grid` workgroups and `segments` runs along the plane axis (0 =
 // choose); leaves zw_table null when the lattice is too small for it to pay
 // (unless `force`)

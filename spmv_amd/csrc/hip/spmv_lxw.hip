@@ -5,7 +5,7 @@
 // of spmv/csr_kernels.cpp:41-51: a row is summed left to right, mul and add
 // rounded separately => bit-identical to the oracle.
 //
-// The LX form (spmv_csr.hip) rewrites every entry's column as a 16-bit offset
+// The LX form (spmv_csr_forms.hip) rewrites every entry's column as a 16-bit offset
 // into a per-row-block set of staged x WINDOWS.  The register-staged kernel
 // (csr_rowblock_lx_kernel) alternates phases -- fetch windows, wait, stream a
 // tile of values + offsets, wait, multiply, park products in LDS, barrier, add

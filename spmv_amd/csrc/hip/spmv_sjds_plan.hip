@@ -1479,7 +1479,7 @@ int spmv_sjds_sym_merge(const spmv_hip_csr_plan* pl, int long_thr, int32_t** vpt
 }
 
 // Symmetric storage of a matrix without lattice structure: everything of the
-// merged form but the values (sym_sj_bake in spmv_csr.hip bakes those).  The
+// merged form but the values (sym_sj_bake in spmv_csr_plan.hip bakes those).  The
 // rows of the stored lower block that are LONG (more than four times the merged
 // matrix's average length, and more than 96 entries) are listed in the PARENT
 // plan, with the table of the table-driven kernel, exactly as a general
