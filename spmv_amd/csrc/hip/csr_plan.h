@@ -1,9 +1,8 @@
 // Shared internals of the CSR SpMV translation units (gfx950 only):
 //   spmv_csr.hip        general kernels (ROWBLOCK, LX form, VECTOR, SCALAR, ROWLIST),
+//                       their launches, the C entry points of the product
 //   spmv_csr_forms.hip  plan-time builders (LX / XW windows, row list, plane walk)
 //   spmv_csr_plan.hip   the plan API (create / bake / set / get)
-//   (below, "spmv_csr.hip" in older comments: the three of them)
-//                  plan creation, the C entry points
 //   spmv_sym.hip   symmetric-storage kernels (csr_kernels.cpp:26-40)
 //   spmv_lat.hip   lattice form: constant column offsets per row block
 //   spmv_symlat.hip  the same idea for the symmetric storage
