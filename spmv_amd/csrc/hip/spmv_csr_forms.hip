@@ -312,6 +312,55 @@ void spmv_free_xw(spmv_hip_csr_plan* pl)
   xw_probe_free(pl);
 }
 
+// Most entries any 256-row block holds: the plan kernel sorts a block's
+// columns with 8 keys per thread (2048) where that suffices -- half the work of
+// the 16-key instantiation, which the 7-point matrix (1792 entries per block)
+// was given for its AVERAGE of 6.99 entries per row (lx_build_kernel<16> 33.6 ms
+// of the 512^3 plan, profiles/r06_rocprof_bench_n512_kernel_stats.csv).
+struct RowBlockEntries {
+  const int32_t* rowptr;
+  int32_t num_rows;
+  __host__ __device__ int32_t operator()(int32_t rb) const
+  {
+    const int64_t r0 = (int64_t)rb * kRows;
+    const int64_t r1 = r0 + kRows < num_rows ? r0 + kRows : num_rows;
+    return rowptr[r1] - rowptr[r0];
+  }
+};
+
+static int max_block_entries(const spmv_hip_csr_plan* pl, const int32_t* rowptr, int nrb,
+                             hipStream_t st, int32_t* out)
+{
+  *out = INT32_MAX; // (on any failure: the large instantiation)
+  int32_t* d_max = nullptr;
+  void* tmp = nullptr;
+  size_t tb = 0;
+  hipcub::CountingInputIterator<int32_t> ids(0);
+  hipcub::TransformInputIterator<int32_t, RowBlockEntries,
+                                 hipcub::CountingInputIterator<int32_t>>
+      cnt(ids, RowBlockEntries{rowptr, pl->num_rows});
+  hipError_t e = hipMalloc(&d_max, sizeof(int32_t));
+  if (e == hipSuccess)
+    e = hipcub::DeviceReduce::Max(nullptr, tb, cnt, d_max, nrb, st);
+  if (e == hipSuccess)
+    e = hipMalloc(&tmp, tb ? tb : 16);
+  if (e == hipSuccess)
+    e = hipcub::DeviceReduce::Max(tmp, tb, cnt, d_max, nrb, st);
+  int32_t h = INT32_MAX;
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(&h, d_max, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st);
+  (void)hipFree(tmp);
+  (void)hipFree(d_max);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return SPMV_HIP_OK; // (not fatal: *out stays at its default)
+  }
+  *out = h;
+  return SPMV_HIP_OK;
+}
+
 // The XW records (spmv_lxw.hip): per row block its span, the DMA pieces of its
 // x windows and the windows themselves.  144 B per row block; the CSR arrays
 // stay the caller's.  Kept only if most blocks are staged.
@@ -342,8 +391,9 @@ int spmv_build_xw(spmv_hip_csr_plan* pl, const int32_t* rowptr, const int32_t* c
     ++end_bit;
   int grid = pl->ctx->num_cus * 4;
   grid = grid > nrb ? nrb : grid;
-  const double avg = (double)pl->nnz / pl->num_rows;
-  if (avg <= 6.0)
+  int32_t max_cnt = 0;
+  (void)max_block_entries(pl, rowptr, nrb, st, &max_cnt);
+  if (max_cnt <= 8 * kBlock)
     hipLaunchKernelGGL(lx_build_kernel<8>, dim3(grid), dim3(kBlock), 0, st,
                        pl->num_rows, pl->num_cols, rowptr, colind, nullptr,
                        nullptr, nrb, end_bit, kLxwAlign, kLxwPiece,
@@ -456,8 +506,9 @@ int spmv_build_lx(spmv_hip_csr_plan* pl, const int32_t* rowptr,
     ++end_bit;
   int grid = pl->ctx->num_cus * 4;
   grid = grid > nrb ? nrb : grid;
-  const double avg = (double)pl->nnz / pl->num_rows;
-  if (avg <= 6.0)
+  int32_t max_cnt = 0;
+  (void)max_block_entries(pl, rowptr, nrb, st, &max_cnt);
+  if (max_cnt <= 8 * kBlock)
     hipLaunchKernelGGL(lx_build_kernel<8>, dim3(grid), dim3(kBlock), 0, st,
                        pl->num_rows, pl->num_cols, rowptr, colind, pl->lx_lidx,
                        pl->lx_tab, nrb, end_bit, align, pad, cap, pl->lxw_rec,
